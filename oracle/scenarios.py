@@ -1,0 +1,104 @@
+"""Scripted clips used to pin the oracle against the executed reference and to parity-test
+the HIP path against the oracle.  TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+A scenario is (cfg overrides, frame source, event script).  ``run_scenario`` drives any
+processor exposing the reference ``InferenceCore`` surface (``step``, ``delete_objects``,
+``output_prob_to_mask``) -- the reference itself, ``OracleProcessor`` or the HIP product.
+"""
+import hashlib
+import os
+import numpy as np
+import torch
+
+from cutie_amd.utils.synth import SyntheticClip
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')
+
+LT_SMALL = dict(count_usage=True, max_mem_frames=4, min_mem_frames=2, num_prototypes=8,
+                max_num_tokens=40, buffer_tokens=12)
+
+SCENARIOS = {
+    # configs[0] of BASELINE.json: examples/bike, 480p, (2) objects, scripting_demo.py settings
+    'bike': dict(cfg=dict(max_internal_size=480), kind='bike', frames=4, sub=8),
+    # small clip, 3 objects, FIFO working memory wraps (mem_every=2, max_mem_frames=3)
+    'small_fifo': dict(cfg=dict(mem_every=2, max_mem_frames=3, stagger_updates=1),
+                       kind='synth', h=96, w=136, k=3, frames=14, sub=2),
+    # long-term memory with scaled-down limits: consolidation and pruning both fire
+    'small_lt': dict(cfg=dict(mem_every=2, use_long_term=True, long_term=LT_SMALL),
+                     kind='synth', h=96, w=128, k=3, frames=44, sub=2),
+    # objects added at different frames (multi-bucket), mask merge, delete
+    # (scripting_demo_add_del_objects.py pattern)
+    'small_add_del': dict(cfg=dict(mem_every=3), kind='synth', h=112, w=128, k=4, frames=16, sub=2,
+                          add_at={0: [1], 4: [2], 7: [3, 4]}, delete_at={10: [1]}),
+}
+
+
+def _bike_frames():
+    from PIL import Image
+    d = os.path.join(GOLDEN_DIR, 'bike')
+    names = sorted(n for n in os.listdir(d) if n.endswith('.jpg'))
+    imgs = [torch.from_numpy(np.array(Image.open(os.path.join(d, n)).convert('RGB'))).permute(2, 0, 1).float() / 255
+            for n in names]
+    mask = torch.from_numpy(np.array(Image.open(os.path.join(d, '00000.png')))).long()
+    return imgs, mask
+
+
+def scenario_inputs(name):
+    """-> list of (image, mask_or_None, objects_or_None), dict frame->objects to delete (before the step)"""
+    sc = SCENARIOS[name]
+    if sc['kind'] == 'bike':
+        imgs, mask = _bike_frames()
+        objs = [int(o) for o in np.unique(mask.numpy()) if o != 0]
+        return [(imgs[0], mask, objs)] + [(im, None, None) for im in imgs[1:]], {}
+    clip = SyntheticClip(sc['h'], sc['w'], sc['k'], sc['frames'], seed=3)
+    full = clip.first_mask()
+    add_at = sc.get('add_at', {0: clip.objects})
+    steps = []
+    for t in range(sc['frames']):
+        if t in add_at:
+            ids = add_at[t]
+            m = torch.zeros_like(full)
+            for i in ids:
+                y0, y1, x0, x1 = clip.rects[i - 1]
+                dx = (2 * t) % 16          # rectangles drift with the texture
+                m[y0:y1, max(x0 - dx, 0):max(x1 - dx, 1)] = i
+            steps.append((clip.frame(t), m, list(ids)))
+        else:
+            steps.append((clip.frame(t), None, None))
+    return steps, sc.get('delete_at', {})
+
+
+def run_scenario(make_processor, name, device='cpu', record=None):
+    """make_processor(cfg_overrides) -> processor.  Returns list of per-frame prob tensors (cpu fp32)."""
+    sc = SCENARIOS[name]
+    proc = make_processor(sc['cfg'])
+    steps, deletes = scenario_inputs(name)
+    outs = []
+    with torch.inference_mode():
+        for t, (img, mask, objs) in enumerate(steps):
+            if t in deletes:
+                proc.delete_objects(deletes[t])
+            img = img.to(device)
+            if mask is not None:
+                p = proc.step(img, mask.to(device), objects=objs)
+            else:
+                p = proc.step(img)
+            outs.append(p.detach().float().cpu())
+            if record is not None:
+                record(t, proc)
+    return outs, proc
+
+
+def summarize(outs, sub):
+    """Compact golden record: sub-sampled probs (fp16), argmax md5 and class histograms."""
+    rec = {}
+    for t, p in enumerate(outs):
+        am = p.argmax(0).to(torch.uint8).numpy()
+        rec[f'prob_{t}'] = p[:, ::sub, ::sub].numpy().astype(np.float16)
+        rec[f'md5_{t}'] = np.frombuffer(hashlib.md5(am.tobytes()).digest(), dtype=np.uint8)
+        rec[f'hist_{t}'] = np.bincount(am.ravel(), minlength=p.shape[0]).astype(np.int64)
+        # top1-top2 margin map (fp16, sub-sampled) for margin-aware argmax checks
+        if p.shape[0] > 1:
+            top2 = p.topk(2, dim=0)[0]
+            rec[f'margin_{t}'] = (top2[0] - top2[1])[::sub, ::sub].numpy().astype(np.float16)
+    return rec
