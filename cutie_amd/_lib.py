@@ -1,0 +1,98 @@
+"""ctypes binding of libcutie_hip.so (C ABI: include/cutie_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing, stale, or no HIP device is
+present, ``get_executor()`` raises.  (tests/mock_exec.py can inject a torch interpreter of the op
+descriptors to check the host-side wiring on CPU; that interpreter lives under tests/ only.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcutie_hip.so')
+ABI_VERSION = 1
+OP_STRUCT_SIZE = 208
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'(or `make -C cutie_amd/csrc`).  cutie_amd has no CPU fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.cutie_exec.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.cutie_exec.restype = ctypes.c_int
+    lib.cutie_exec_one.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.cutie_exec_one.restype = ctypes.c_int
+    lib.cutie_graph_capture.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.cutie_graph_capture.restype = ctypes.c_void_p
+    lib.cutie_graph_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.cutie_graph_launch.restype = ctypes.c_int
+    lib.cutie_graph_destroy.argtypes = [ctypes.c_void_p]
+    lib.cutie_graph_destroy.restype = None
+    lib.cutie_time_ops.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.cutie_time_ops.restype = ctypes.c_float
+    lib.cutie_hip_last_error.argtypes = []
+    lib.cutie_hip_last_error.restype = ctypes.c_char_p
+    lib.cutie_hip_abi_version.restype = ctypes.c_int
+    lib.cutie_op_struct_size.restype = ctypes.c_int
+    if lib.cutie_hip_abi_version() != ABI_VERSION or lib.cutie_op_struct_size() != OP_STRUCT_SIZE:
+        raise HipLibraryError(f'{LIB_PATH} is stale (ABI {lib.cutie_hip_abi_version()}, '
+                              f'op size {lib.cutie_op_struct_size()}); rebuild it.')
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = ['cutie_exec', 'cutie_exec_one', 'cutie_graph_capture', 'cutie_graph_launch',
+                    'cutie_graph_destroy', 'cutie_time_ops', 'cutie_hip_last_error',
+                    'cutie_hip_abi_version', 'cutie_op_struct_size']
+
+
+class HipExecutor:
+    """Runs op-descriptor arrays on the current torch HIP stream."""
+    is_mock = False
+
+    def __init__(self):
+        import torch
+        self.lib = load()
+        if not torch.cuda.is_available():
+            raise HipLibraryError('no HIP device visible: cutie_amd runs on MI355X only (no CPU fallback).')
+        self._torch = torch
+
+    def stream(self):
+        return self._torch.cuda.current_stream().cuda_stream
+
+    def run(self, arr):
+        rc = self.lib.cutie_exec(arr.ctypes.data, len(arr), self.stream())
+        if rc != 0:
+            raise RuntimeError('cutie_exec failed: ' + self.lib.cutie_hip_last_error().decode())
+
+    def time_ops(self, arr, iters):
+        ms = self.lib.cutie_time_ops(arr.ctypes.data, len(arr), iters, self.stream())
+        if ms < 0:
+            raise RuntimeError('cutie_time_ops failed: ' + self.lib.cutie_hip_last_error().decode())
+        return ms
+
+
+_executor = None
+
+
+def get_executor():
+    global _executor
+    if _executor is None:
+        _executor = HipExecutor()
+    return _executor
+
+
+def set_executor_for_testing(ex):
+    """Test hook (tests/mock_exec.py): inject an interpreter of the descriptors.  Never used by the product."""
+    global _executor
+    _executor = ex

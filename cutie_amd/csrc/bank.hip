@@ -1,0 +1,134 @@
+// Long-term memory maintenance kernels (reference: MemoryManager.consolidation / compress_features,
+// memory_manager.py:309-358; KeyValueMemoryStore.remove_obsolete_features, kv_memory_store.py:209-242).
+// These run once every ~25 frames on <= 10^4 tokens, so they are plain fp32 kernels (exact arithmetic matters
+// more than speed here: they decide which prototypes survive).
+#include "common.h"
+#include <math.h>
+
+// order[rank(i)] = i for rank < k, rank by descending use/life, ties -> lower index
+__global__ __launch_bounds__(256) void rank_select_kernel(const float* __restrict__ use, const float* __restrict__ life,
+                                                          int* __restrict__ order, int n, int k) {
+    __shared__ float tile[256];
+    int i = blockIdx.x * 256 + threadIdx.x;
+    float ui = (i < n) ? use[i] / life[i] : 0.f;
+    int rank = 0;
+    for (int base = 0; base < n; base += 256) {
+        int l = base + threadIdx.x;
+        tile[threadIdx.x] = (l < n) ? use[l] / life[l] : -INFINITY;
+        __syncthreads();
+        int lim = min(256, n - base);
+        for (int t = 0; t < lim; ++t) {
+            float u = tile[t];
+            rank += (u > ui) || (u == ui && (base + t) < i);
+        }
+        __syncthreads();
+    }
+    if (i < n && rank < k) order[rank] = i;
+}
+
+__global__ void gather_rows_kernel(const uint32_t* __restrict__ src, const int* __restrict__ order, uint32_t* __restrict__ dst,
+                                   int k, int roww, long ss, long ds) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)k * roww) return;
+    int r = idx / roww, c = idx - (long)r * roww;
+    dst[(long)r * ds + c] = src[(long)order[r] * ss + c];
+}
+
+// one block per prototype: aff[p,:] = softmax_i(sim(cand_i, proto_p))
+__global__ __launch_bounds__(256) void consol_aff_kernel(const float* __restrict__ ckey, const float* __restrict__ cshr,
+                                                         const float* __restrict__ pkey, const float* __restrict__ psel,
+                                                         float* __restrict__ aff, int n) {
+    __shared__ float pk[64], pe[64], red[256];
+    __shared__ float bsq_s;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    if (tid < 64) { pk[tid] = pkey[(long)p * 64 + tid]; pe[tid] = psel[(long)p * 64 + tid]; }
+    __syncthreads();
+    if (tid == 0) {
+        float b = 0.f;
+        for (int c = 0; c < 64; ++c) b += pe[c] * pk[c] * pk[c];
+        bsq_s = b;
+    }
+    __syncthreads();
+    const float bsq = bsq_s;
+    float* row = aff + (long)p * n;
+    float mx = -INFINITY;
+    for (int i = tid; i < n; i += 256) {
+        const float* k = ckey + (long)i * 64;
+        float asq = 0.f, ab = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) { float kv = k[c]; asq += kv * kv * pe[c]; ab += kv * pk[c] * pe[c]; }
+        float s = (-asq + 2.f * ab - bsq) * cshr[i] * 0.125f;
+        row[i] = s;
+        mx = fmaxf(mx, s);
+    }
+    red[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+    mx = red[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = tid; i < n; i += 256) { float e = expf(row[i] - mx); row[i] = e; sum += e; }
+    red[tid] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    float inv = 1.f / red[0];
+    for (int i = tid; i < n; i += 256) row[i] *= inv;
+}
+
+// grid (ceil(C/64), ceil(P/4)); block 256 = 4 prototypes x 64 channels
+template <bool F32>
+__global__ __launch_bounds__(256) void consol_read_kernel(const float* __restrict__ aff, const void* __restrict__ V, void* __restrict__ out,
+                                                          int n, int P, int C, int ldv, int ldo) {
+    __shared__ float a[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), pp = threadIdx.x >> 6, p = blockIdx.y * 4 + pp;
+    float acc = 0.f;
+    for (int base = 0; base < n; base += 64) {
+        int l = base + (threadIdx.x & 63);
+        a[pp][threadIdx.x & 63] = (p < P && l < n) ? aff[(long)p * n + l] : 0.f;
+        __syncthreads();
+        int lim = min(64, n - base);
+        if (c < C)
+            for (int t = 0; t < lim; ++t) {
+                float v = F32 ? ((const float*)V)[(long)(base + t) * ldv + c] : bf2f(((const bf16_t*)V)[(long)(base + t) * ldv + c]);
+                acc += a[pp][t] * v;
+            }
+        __syncthreads();
+    }
+    if (p < P && c < C) {
+        if (F32) ((float*)out)[(long)p * ldo + c] = acc;
+        else ((bf16_t*)out)[(long)p * ldo + c] = f2bf(acc);
+    }
+}
+
+int launch_bank(const cutie_op* op, hipStream_t s) {
+    const int32_t* i = op->i;
+    const uint64_t* p = op->p;
+    switch (op->kind) {
+        case CUTIE_OP_RANK_SELECT:
+            hipLaunchKernelGGL(rank_select_kernel, dim3((i[0] + 255) / 256), dim3(256), 0, s, (const float*)p[0], (const float*)p[1], (int*)p[2], i[0], i[1]);
+            break;
+        case CUTIE_OP_GATHER_ROWS: {
+            int roww = i[1] / 4;
+            long n = (long)i[0] * roww;
+            hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)p[0], (const int*)p[1],
+                               (uint32_t*)p[2], i[0], roww, (long)i[2] / 4, (long)i[3] / 4);
+            break;
+        }
+        case CUTIE_OP_CONSOL_AFF:
+            hipLaunchKernelGGL(consol_aff_kernel, dim3(i[1]), dim3(256), 0, s, (const float*)p[0], (const float*)p[1], (const float*)p[2],
+                               (const float*)p[3], (float*)p[4], i[0]);
+            break;
+        case CUTIE_OP_CONSOL_READ: {
+            dim3 grid((i[2] + 63) / 64, (i[1] + 3) / 4);
+            if (op->flags & 1)
+                hipLaunchKernelGGL(consol_read_kernel<true>, grid, dim3(256), 0, s, (const float*)p[0], (const void*)p[1], (void*)p[2], i[0], i[1], i[2], i[3], i[4]);
+            else
+                hipLaunchKernelGGL(consol_read_kernel<false>, grid, dim3(256), 0, s, (const float*)p[0], (const void*)p[1], (void*)p[2], i[0], i[1], i[2], i[3], i[4]);
+            break;
+        }
+        default:
+            cutie_set_error("bank: unknown op kind %d", op->kind);
+            return -3;
+    }
+    return (int)hipGetLastError();
+}

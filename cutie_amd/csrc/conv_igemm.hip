@@ -1,0 +1,220 @@
+// Implicit-GEMM convolution on MFMA (gfx950), NHWC bf16 activations, fp32 accumulate.
+//
+// One kernel family covers every nn.Conv2d / GConv2d / pixel-token nn.Linear of the hot path
+// (CUTIE_OP_CONV in include/cutie_hip.h).  GEMM view:  D[cout][pixel] = sum_k W[cout][k] * X[pixel][k],
+// k = (kh*KW + kw)*Cin + c.  The weights are the MFMA "A" operand and the im2col pixels the "B"
+// operand, so each lane of v_mfma_f32_16x16x32_bf16 ends up holding 4 *consecutive output channels*
+// of one pixel -> 8-byte bf16 (16-byte f32) NHWC stores and residual loads.
+//
+// Tiling: 256 threads = 4 waves, block tile BM pixels x BN channels, BK = 32 per step, global ->
+// register -> LDS staging (the gather needs per-chunk zero fill for the halo and the optional fused
+// input ReLU), double-buffered LDS, one barrier per K step.  LDS rows are 64 B (32 bf16); the 16-B
+// chunk index is XOR-swizzled with ((row>>3)&1)*3 so that the four 16-lane groups of a ds_read_b128
+// fragment read hit 16 distinct 16-B slots of the 256-B bank row (conflict-free).
+#include "common.h"
+
+struct ConvParams {
+    const bf16_t* x1; const bf16_t* x2; const bf16_t* w; const float* bias; const bf16_t* res; void* y;
+    int B, H, W, C1, C2, ldx1, ldx2, OH, OW, Cout, ldy, KH, KW, stride, pad, ldr, Kpad;
+    int flags, M, Cin, OHW;
+};
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+__device__ __forceinline__ int swz(int row) { return ((row >> 3) & 1) * 3; }
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+    constexpr int NX = (BM * 4) / 256;                  // X chunks (16 B) per thread per K step
+    constexpr int NWC = (BN * 4 + 255) / 256;           // W chunks per thread per K step
+    constexpr int TM = BM / WM / 16;                    // 16-pixel tiles per wave
+    constexpr int TN = BN / WN / 16;                    // 16-channel tiles per wave
+    static_assert(WM * WN == 4 && NX >= 1 && TM >= 1 && TN >= 1, "bad tile");
+    __shared__ u32x4 smem[2][(BM + BN) * 4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kc = tid & 3;                              // this thread's 8-element chunk inside BK
+    const bool relu_in = p.flags & CUTIE_F_RELU_IN;
+
+    // ---- per-thread im2col row state (fixed over the K loop) ----
+    int rb[NX], rih[NX], riw[NX];
+    bool rvalid[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        int row = (tid + i * 256) >> 2;
+        int m = m0 + row;
+        rvalid[i] = m < p.M;
+        int mm = rvalid[i] ? m : 0;
+        int b = mm / p.OHW;
+        int rem = mm - b * p.OHW;
+        int oh = rem / p.OW;
+        int ow = rem - oh * p.OW;
+        rb[i] = b * p.H;
+        rih[i] = oh * p.stride - p.pad;
+        riw[i] = ow * p.stride - p.pad;
+    }
+    int kcur = kc * 8, kh = 0, kw = 0;                   // channel / tap of this thread's chunk
+    while (kcur >= p.Cin) { kcur -= p.Cin; if (++kw == p.KW) { kw = 0; ++kh; } }
+
+    const int wrow = (tid >> 2);                         // W rows handled: wrow + i*64
+    u32x4 xr[NX], wr[NWC];
+
+#define LOAD_TILE(KS)                                                                                      \
+    {                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                   \
+            u32x4 v = {0u, 0u, 0u, 0u};                                                                     \
+            int ih = rih[i] + kh, iw = riw[i] + kw;                                                        \
+            if (rvalid[i] && kh < p.KH && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {  \
+                long pix = ((long)(rb[i] + ih)) * p.W + iw;                                                \
+                const bf16_t* src = (kcur < p.C1) ? p.x1 + pix * p.ldx1 + kcur                             \
+                                                  : p.x2 + pix * p.ldx2 + (kcur - p.C1);                   \
+                v = *reinterpret_cast<const u32x4*>(src);                                                  \
+                if (relu_in) { v.x = relu_bf2(v.x); v.y = relu_bf2(v.y); v.z = relu_bf2(v.z); v.w = relu_bf2(v.w); } \
+            }                                                                                              \
+            xr[i] = v;                                                                                     \
+        }                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < NWC; ++i) {                                                  \
+            int n = wrow + i * 64;                                                                         \
+            if (BN < 64) n = n < BN ? n : BN - 1;                                                          \
+            wr[i] = *reinterpret_cast<const u32x4*>(p.w + (long)(n0 + n) * p.Kpad + (KS) * 32 + kc * 8);   \
+        }                                                                                                  \
+        kcur += 32;                                                                                        \
+        while (kcur >= p.Cin) { kcur -= p.Cin; if (++kw == p.KW) { kw = 0; ++kh; } }                       \
+    }
+#define STORE_TILE(BUF)                                                                                    \
+    {                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                   \
+            int row = (tid + i * 256) >> 2;                                                                \
+            smem[BUF][row * 4 + (kc ^ swz(row))] = xr[i];                                                  \
+        }                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < NWC; ++i) {                                                  \
+            int n = wrow + i * 64;                                                                         \
+            if (BN * 4 >= 256 || n < BN) smem[BUF][(BM + n) * 4 + (kc ^ swz(n))] = wr[i];                  \
+        }                                                                                                  \
+    }
+
+    const int wm = wave / WN, wn = wave % WN;
+    const int pm0 = wm * (BM / WM), cn0 = wn * (BN / WN);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.Kpad / 32;
+    LOAD_TILE(0);
+    STORE_TILE(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) LOAD_TILE(ks + 1);
+        bf16x8 bfr[TM], afr[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            int row = pm0 + t * 16 + l15;
+            bfr[t] = __builtin_bit_cast(bf16x8, smem[buf][row * 4 + (l4 ^ swz(row))]);
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            int row = cn0 + t * 16 + l15;
+            afr[t] = __builtin_bit_cast(bf16x8, smem[buf][(BM + row) * 4 + (l4 ^ swz(row))]);
+        }
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
+        if (ks + 1 < nk) STORE_TILE(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + residual + activation, NHWC store (4 consecutive channels per lane) ----
+    const int act = (p.flags >> CUTIE_ACT_SHIFT) & 7;
+    const bool out_f32 = p.flags & CUTIE_F_OUT_F32;
+    const bool res_bcast = p.flags & CUTIE_F_RES_BCAST;
+    const bool vec_ok = (p.ldy & 3) == 0;
+    const bool resvec_ok = (p.ldr & 3) == 0;
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        int m = m0 + pm0 + b * 16 + l15;
+        if (m >= p.M) continue;
+        int mres = res_bcast ? (m % p.OHW) : m;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            int ch0 = n0 + cn0 + a * 16 + l4 * 4;
+            if (ch0 >= p.Cout) continue;
+            float v[4];
+            bool full = ch0 + 3 < p.Cout;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[a][b][r];
+                if (p.bias && ch0 + r < p.Cout) v[r] += p.bias[ch0 + r];
+            }
+            if (p.res) {
+                const bf16_t* rp = p.res + (long)mres * p.ldr + ch0;
+                if (full && resvec_ok) {
+                    uint2 rr = *reinterpret_cast<const uint2*>(rp);
+                    v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                    v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (ch0 + r < p.Cout) v[r] += bf2f(rp[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (act == CUTIE_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+                else if (act == CUTIE_ACT_SIGMOID) v[r] = sigmoidf_(v[r]);
+                else if (act == CUTIE_ACT_SQ1) v[r] = v[r] * v[r] + 1.f;
+            }
+            if (out_f32) {
+                float* yp = reinterpret_cast<float*>(p.y) + (long)m * p.ldy + ch0;
+                if (full && vec_ok) *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (ch0 + r < p.Cout) yp[r] = v[r];
+                }
+            } else {
+                bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + (long)m * p.ldy + ch0;
+                if (full && vec_ok) *reinterpret_cast<uint2*>(yp) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (ch0 + r < p.Cout) yp[r] = f2bf(v[r]);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const ConvParams& p, hipStream_t s) {
+    dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+}
+
+int launch_conv(const cutie_op* op, hipStream_t s) {
+    ConvParams p;
+    p.x1 = (const bf16_t*)op->p[0]; p.x2 = (const bf16_t*)op->p[1]; p.w = (const bf16_t*)op->p[2];
+    p.bias = (const float*)op->p[3]; p.res = (const bf16_t*)op->p[4]; p.y = (void*)op->p[5];
+    const int32_t* i = op->i;
+    p.B = i[0]; p.H = i[1]; p.W = i[2]; p.C1 = i[3]; p.C2 = i[4]; p.ldx1 = i[5]; p.ldx2 = i[6];
+    p.OH = i[7]; p.OW = i[8]; p.Cout = i[9]; p.ldy = i[10]; p.KH = i[11]; p.KW = i[12];
+    p.stride = i[13]; p.pad = i[14]; p.ldr = i[15]; p.Kpad = i[16];
+    p.flags = op->flags; p.OHW = p.OH * p.OW; p.M = p.B * p.OHW; p.Cin = p.C1 + p.C2;
+    if ((p.C1 & 7) || (p.C2 & 7) || (p.ldx1 & 7) || (p.C2 && (p.ldx2 & 7)) || (p.Kpad & 31) ||
+        p.Kpad < p.KH * p.KW * p.Cin || p.M <= 0 || p.Cout <= 0) {
+        cutie_set_error("conv: bad geometry C1=%d C2=%d ldx1=%d ldx2=%d Kpad=%d M=%d Cout=%d",
+                        p.C1, p.C2, p.ldx1, p.ldx2, p.Kpad, p.M, p.Cout);
+        return -2;
+    }
+    switch (i[17]) {
+        case 0: return launch_cfg<128, 128, 2, 2>(p, s);
+        case 1: return launch_cfg<128, 64, 2, 2>(p, s);
+        case 2: return launch_cfg<64, 64, 2, 2>(p, s);
+        case 3: return launch_cfg<256, 16, 4, 1>(p, s);
+        case 4: return launch_cfg<64, 128, 2, 2>(p, s);
+        default: cutie_set_error("conv: bad tile id %d", i[17]); return -2;
+    }
+}

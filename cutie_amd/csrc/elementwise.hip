@@ -1,0 +1,590 @@
+// HBM-bound kernels of the hot path: layout/normalisation, pooling, resampling, gates, epilogues.
+// All are coalesced along the channel (NHWC) or pixel (planar masks) axis with 16-byte accesses
+// where the layout allows; see include/cutie_hip.h for the op contracts and reference citations.
+#include "common.h"
+#include <math.h>
+
+#define GRID1D(n, bs) dim3((unsigned)(((long)(n) + (bs) - 1) / (bs)))
+
+// ---------------------------------------------------------------------------------------------
+__global__ void maxpool_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int B, int H, int W, int C8,
+                               int OH, int OW, int relu) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)B * OH * OW * C8;
+    if (idx >= total) return;
+    int c = idx % C8; long t = idx / C8;
+    int ow = t % OW; t /= OW; int oh = t % OH; int b = t / OH;
+    float m[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = relu ? 0.f : -INFINITY;
+    for (int dy = 0; dy < 3; ++dy) {
+        int ih = oh * 2 - 1 + dy;
+        if ((unsigned)ih >= (unsigned)H) continue;
+        for (int dx = 0; dx < 3; ++dx) {
+            int iw = ow * 2 - 1 + dx;
+            if ((unsigned)iw >= (unsigned)W) continue;
+            uint4 v = x[(((long)b * H + ih) * W + iw) * C8 + c];
+            uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                m[2 * i] = fmaxf(m[2 * i], __uint_as_float(u[i] << 16));
+                m[2 * i + 1] = fmaxf(m[2 * i + 1], __uint_as_float(u[i] & 0xffff0000u));
+            }
+        }
+    }
+    y[idx] = make_uint4(pack_bf2(m[0], m[1]), pack_bf2(m[2], m[3]), pack_bf2(m[4], m[5]), pack_bf2(m[6], m[7]));
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void img_prep_kernel(const float* __restrict__ img, const float* __restrict__ masks, uint4* __restrict__ y,
+                                int h0, int w0, int H, int W, int pl, int pt, int K,
+                                float m0, float m1, float m2, float s0, float s1, float s2) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long HW = (long)H * W;
+    if (idx >= HW * K) return;
+    int k = idx / HW; long pix = idx - (long)k * HW;
+    int yy = pix / W, xx = pix - (long)yy * W;
+    int sy = yy - pt, sx = xx - pl;
+    float r = 0.f, g = 0.f, b = 0.f;
+    if ((unsigned)sy < (unsigned)h0 && (unsigned)sx < (unsigned)w0) {
+        long o = (long)sy * w0 + sx, plane = (long)h0 * w0;
+        r = img[o]; g = img[plane + o]; b = img[2 * plane + o];
+    }
+    r = (r - m0) / s0; g = (g - m1) / s1; b = (b - m2) / s2;
+    float mk = 0.f, others = 0.f;
+    if (masks) {
+        float sum = 0.f;
+        for (int j = 0; j < K; ++j) sum += masks[(long)j * HW + pix];
+        mk = masks[(long)k * HW + pix];
+        others = fminf(fmaxf(sum - mk, 0.f), 1.f);
+    }
+    y[idx] = make_uint4(pack_bf2(r, g), pack_bf2(b, mk), pack_bf2(others, 0.f), 0u);
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void up_coord(int o, int n_in, float scale, int& i0, int& i1, float& lam) {
+    float src = ((float)o + 0.5f) * scale - 0.5f;          // torch: area_pixel_compute_source_index
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    if (i0 > n_in - 1) i0 = n_in - 1;
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    lam = src - (float)i0;
+}
+
+__global__ void upsample2x_add_kernel(const uint4* __restrict__ g, const uint4* __restrict__ skip, uint4* __restrict__ y,
+                                      int B, int h, int w, int C8) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int OH = 2 * h, OW = 2 * w;
+    long total = (long)B * OH * OW * C8;
+    if (idx >= total) return;
+    int c = idx % C8; long t = idx / C8;
+    int ox = t % OW; t /= OW; int oy = t % OH; int b = t / OH;
+    int y0, y1, x0, x1; float ly, lx;
+    up_coord(oy, h, 0.5f, y0, y1, ly);
+    up_coord(ox, w, 0.5f, x0, x1, lx);
+    const uint4* gb = g + (long)b * h * w * C8;
+    uint4 v00 = gb[((long)y0 * w + x0) * C8 + c], v01 = gb[((long)y0 * w + x1) * C8 + c];
+    uint4 v10 = gb[((long)y1 * w + x0) * C8 + c], v11 = gb[((long)y1 * w + x1) * C8 + c];
+    uint4 sk = skip[((long)oy * OW + ox) * C8 + c];
+    const uint32_t* a = &v00.x; const uint32_t* bq = &v01.x; const uint32_t* cq = &v10.x; const uint32_t* d = &v11.x;
+    const uint32_t* s = &sk.x;
+    float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+    uint32_t out[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float lo = w00 * __uint_as_float(a[i] << 16) + w01 * __uint_as_float(bq[i] << 16) +
+                   w10 * __uint_as_float(cq[i] << 16) + w11 * __uint_as_float(d[i] << 16) + __uint_as_float(s[i] << 16);
+        float hi = w00 * __uint_as_float(a[i] & 0xffff0000u) + w01 * __uint_as_float(bq[i] & 0xffff0000u) +
+                   w10 * __uint_as_float(cq[i] & 0xffff0000u) + w11 * __uint_as_float(d[i] & 0xffff0000u) +
+                   __uint_as_float(s[i] & 0xffff0000u);
+        out[i] = pack_bf2(lo, hi);
+    }
+    y[idx] = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void area_down_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int C,
+                                      int ldx, int ldy, int r) {
+    int C8 = C >> 3, OH = H / r, OW = W / r;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)B * OH * OW * C8;
+    if (idx >= total) return;
+    int c = idx % C8; long t = idx / C8;
+    int ox = t % OW; t /= OW; int oy = t % OH; int b = t / OH;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int dy = 0; dy < r; ++dy)
+        for (int dx = 0; dx < r; ++dx) {
+            const uint4 v = *reinterpret_cast<const uint4*>(x + (((long)b * H + oy * r + dy) * W + ox * r + dx) * ldx + c * 8);
+            const uint32_t* u = &v.x;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[2 * i] += __uint_as_float(u[i] << 16);
+                acc[2 * i + 1] += __uint_as_float(u[i] & 0xffff0000u);
+            }
+        }
+    float inv = 1.f / (float)(r * r);
+    uint4 o = make_uint4(pack_bf2(acc[0] * inv, acc[1] * inv), pack_bf2(acc[2] * inv, acc[3] * inv),
+                         pack_bf2(acc[4] * inv, acc[5] * inv), pack_bf2(acc[6] * inv, acc[7] * inv));
+    *reinterpret_cast<uint4*>(y + (((long)b * OH + oy) * OW + ox) * ldy + c * 8) = o;
+}
+
+__global__ void area_down_f32_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int C,
+                                     int ldx, int ldy, int r, int Cz) {
+    int OH = H / r, OW = W / r;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)B * OH * OW;
+    if (idx >= total) return;
+    int ox = idx % OW; long t = idx / OW; int oy = t % OH; int b = t / OH;
+    float inv = 1.f / (float)(r * r);
+    bf16_t* yp = y + idx * ldy;
+    for (int c = 0; c < C; ++c) {
+        float acc = 0.f;
+        for (int dy = 0; dy < r; ++dy)
+            for (int dx = 0; dx < r; ++dx) acc += x[(((long)b * H + oy * r + dy) * W + ox * r + dx) * ldx + c];
+        yp[c] = f2bf(acc * inv);
+    }
+    for (int c = C; c < Cz; ++c) yp[c] = 0;
+}
+
+// masks f32 [K,H,W] -> m16 f32 [K,h,w]
+__global__ void mask_down_mean_kernel(const float* __restrict__ m, float* __restrict__ m16, int K, int H, int W, int r) {
+    int h = H / r, w = W / r;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)K * h * w) return;
+    int ox = idx % w; long t = idx / w; int oy = t % h; int k = t / h;
+    float acc = 0.f;
+    for (int dy = 0; dy < r; ++dy) {
+        const float* row = m + ((long)k * H + oy * r + dy) * W + ox * r;
+        for (int dx = 0; dx < r; ++dx) acc += row[dx];
+    }
+    m16[idx] = acc / (float)(r * r);
+}
+// m16 f32 [K,hw] -> pair bf16 [K,hw,8] = (mask, others, 0...)
+__global__ void mask_pair_kernel(const float* __restrict__ m16, uint4* __restrict__ y, int K, int hw) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)K * hw) return;
+    int k = idx / hw; int p = idx - (long)k * hw;
+    float sum = 0.f;
+    for (int j = 0; j < K; ++j) sum += m16[(long)j * hw + p];
+    float mk = m16[idx];
+    float others = fminf(fmaxf(sum - mk, 0.f), 1.f);
+    y[idx] = make_uint4(pack_bf2(mk, others), 0u, 0u, 0u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GAP: grid (C/64, B), block 256 = 4 row slices x 64 channels
+__global__ void gap_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int HW, int C) {
+    __shared__ float red[4][64];
+    int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), s = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < C)
+        for (int p = s; p < HW; p += 4) acc += bf2f(x[((long)b * HW + p) * C + c]);
+    red[s][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (s == 0 && c < C) y[(long)b * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)HW;
+}
+
+__global__ void eca_apply_kernel(const uint4* __restrict__ x, const float* __restrict__ gap, const float* __restrict__ wk,
+                                 const uint4* __restrict__ r, uint4* __restrict__ y, int B, int HW, int C) {
+    int C8 = C >> 3;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)B * HW * C8;
+    if (idx >= total) return;
+    int c8 = idx % C8; int b = idx / ((long)HW * C8);
+    const float* g = gap + (long)b * C;
+    float k0 = wk[0], k1 = wk[1], k2 = wk[2], k3 = wk[3], k4 = wk[4];
+    float sc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int c = c8 * 8 + i;
+        float a = k2 * g[c];
+        if (c >= 2) a += k0 * g[c - 2];
+        if (c >= 1) a += k1 * g[c - 1];
+        if (c + 1 < C) a += k3 * g[c + 1];
+        if (c + 2 < C) a += k4 * g[c + 2];
+        sc[i] = sigmoidf_(a);
+    }
+    uint4 xv = x[idx], rv = r[idx];
+    const uint32_t* xu = &xv.x; const uint32_t* ru = &rv.x;
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float lo = __uint_as_float(xu[i] << 16) * sc[2 * i] + __uint_as_float(ru[i] << 16);
+        float hi = __uint_as_float(xu[i] & 0xffff0000u) * sc[2 * i + 1] + __uint_as_float(ru[i] & 0xffff0000u);
+        o[i] = pack_bf2(lo, hi);
+    }
+    y[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void gru_kernel(const float* __restrict__ v, float* __restrict__ h, bf16_t* __restrict__ hb, long n, int C) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * C) return;
+    long row = idx / C; int c = idx - row * C;
+    const float* vr = v + row * 3 * C;
+    float f = sigmoidf_(vr[c]), u = sigmoidf_(vr[C + c]), nv = tanhf(vr[2 * C + c]);
+    float nh = f * h[idx] * (1.f - u) + u * nv;
+    h[idx] = nh;
+    hb[idx] = f2bf(nh);
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float clamp_logit(float p) {
+    p = fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f);
+    return logf(p / (1.f - p));
+}
+
+__global__ void seg_agg_kernel(const float* __restrict__ lg, float* __restrict__ agg, int K, int hw) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hw) return;
+    float bg = 1.f;
+    for (int k = 0; k < K; ++k) {
+        float pr = 1.f / (1.f + expf(-lg[(long)k * hw + p]));
+        bg *= (1.f - pr);
+        agg[(long)(k + 1) * hw + p] = clamp_logit(pr);
+    }
+    agg[p] = clamp_logit(bg);
+}
+
+__global__ void up4_softmax_kernel(const float* __restrict__ agg, float* __restrict__ prob, float* __restrict__ lup,
+                                   int P, int h, int w) {
+    int OH = 4 * h, OW = 4 * w;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)OH * OW) return;
+    int ox = idx % OW, oy = idx / OW;
+    int y0, y1, x0, x1; float ly, lx;
+    up_coord(oy, h, 0.25f, y0, y1, ly);
+    up_coord(ox, w, 0.25f, x0, x1, lx);
+    float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+    long o00 = (long)y0 * w + x0, o01 = (long)y0 * w + x1, o10 = (long)y1 * w + x0, o11 = (long)y1 * w + x1;
+    long hw = (long)h * w, OHW = (long)OH * OW;
+    float mx = -INFINITY;
+    for (int c = 0; c < P; ++c) {
+        const float* a = agg + c * hw;
+        float v = w00 * a[o00] + w01 * a[o01] + w10 * a[o10] + w11 * a[o11];
+        if (lup) lup[c * OHW + idx] = v;
+        mx = fmaxf(mx, v);
+    }
+    float sum = 0.f;
+    for (int c = 0; c < P; ++c) {
+        const float* a = agg + c * hw;
+        float v = w00 * a[o00] + w01 * a[o01] + w10 * a[o10] + w11 * a[o11];
+        sum += expf(v - mx);
+    }
+    float inv = 1.f / sum;
+    for (int c = 0; c < P; ++c) {
+        const float* a = agg + c * hw;
+        float v = w00 * a[o00] + w01 * a[o01] + w10 * a[o10] + w11 * a[o11];
+        prob[c * OHW + idx] = expf(v - mx) * inv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void mask_merge_kernel(const void* __restrict__ inmask, const float* __restrict__ pred, const int* __restrict__ src,
+                                  float* __restrict__ planes, int h0, int w0, int H, int W, int pl, int pt, int Knew,
+                                  int Kold, int nfloat, int fmode) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long HW = (long)H * W;
+    if (idx >= HW) return;
+    int yy = idx / W, xx = idx - (long)yy * W;
+    int sy = yy - pt, sx = xx - pl;
+    bool inside = (unsigned)sy < (unsigned)h0 && (unsigned)sx < (unsigned)w0;
+    long so = (long)sy * w0 + sx, plane = (long)h0 * w0;
+    int iv = 0; bool covered = false;
+    if (!fmode) {
+        iv = inside ? ((const int*)inmask)[so] : 0;
+        covered = iv > 0;
+    } else {
+        float mx = 0.f;   // F.pad pads with 0
+        if (inside) { mx = -INFINITY; for (int c = 0; c < nfloat; ++c) mx = fmaxf(mx, ((const float*)inmask)[c * plane + so]); }
+        covered = mx > 0.5f;
+    }
+    for (int t = 0; t < Knew; ++t) {
+        int s = src[t];
+        float v;
+        if (s >= 0) {
+            if (!fmode) v = (iv == s) ? 1.f : 0.f;
+            else v = inside ? ((const float*)inmask)[s * plane + so] : 0.f;
+        } else {
+            v = (pred && t < Kold && !covered) ? pred[(long)(t + 1) * HW + idx] : 0.f;
+        }
+        planes[(long)t * HW + idx] = v;
+    }
+}
+
+__global__ void agg_softmax_kernel(const float* __restrict__ planes, float* __restrict__ prob, int K, long HW) {
+    long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    float bg = 1.f, mx;
+    for (int k = 0; k < K; ++k) bg *= (1.f - planes[k * HW + p]);
+    float l0 = clamp_logit(bg);
+    mx = l0;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, clamp_logit(planes[k * HW + p]));
+    float sum = expf(l0 - mx);
+    for (int k = 0; k < K; ++k) sum += expf(clamp_logit(planes[k * HW + p]) - mx);
+    float inv = 1.f / sum;
+    prob[p] = expf(l0 - mx) * inv;
+    for (int k = 0; k < K; ++k) prob[(k + 1) * HW + p] = expf(clamp_logit(planes[k * HW + p]) - mx) * inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LINEAR (small M): block = 16 output columns x 16 k-lanes; rows processed 8 at a time
+__global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, const float* __restrict__ xadd,
+                                                           const bf16_t* __restrict__ W, const float* __restrict__ bias,
+                                                           const float* __restrict__ res, float* __restrict__ y, int M, int N,
+                                                           int Kd, int ldx, int ldy, int add_rows, int relu) {
+    int col = blockIdx.x * 16 + (threadIdx.x >> 4);
+    int kl = threadIdx.x & 15;
+    bool cvalid = col < N;
+    const bf16_t* wrow = W + (long)(cvalid ? col : 0) * Kd;
+    for (int m0 = 0; m0 < M; m0 += 8) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = kl * 8; k < Kd; k += 128) {
+            uint4 wv = *reinterpret_cast<const uint4*>(wrow + k);
+            const uint32_t* wu = &wv.x;
+            float wf[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { wf[2 * i] = __uint_as_float(wu[i] << 16); wf[2 * i + 1] = __uint_as_float(wu[i] & 0xffff0000u); }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                int m = m0 + r;
+                if (m < M) {
+                    const float* xr = x + (long)m * ldx + k;
+                    float4 a = *reinterpret_cast<const float4*>(xr), b = *reinterpret_cast<const float4*>(xr + 4);
+                    if (xadd) {
+                        const float* ar = xadd + (long)(m % add_rows) * Kd + k;
+                        float4 c = *reinterpret_cast<const float4*>(ar), d = *reinterpret_cast<const float4*>(ar + 4);
+                        a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w; b.x += d.x; b.y += d.y; b.z += d.z; b.w += d.w;
+                    }
+                    acc[r] += a.x * wf[0] + a.y * wf[1] + a.z * wf[2] + a.w * wf[3] + b.x * wf[4] + b.y * wf[5] + b.z * wf[6] + b.w * wf[7];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float v = acc[r];
+            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+            int m = m0 + r;
+            if (kl == 0 && cvalid && m < M) {
+                if (bias) v += bias[col];
+                if (relu) v = fmaxf(v, 0.f);
+                if (res) v += res[(long)m * N + col];
+                y[(long)m * ldy + col] = v;
+            }
+        }
+    }
+}
+
+// LAYERNORM: one wave per row
+__global__ void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                 float* __restrict__ y, int M, int C) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (long)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    float mean = wave_sum(s) / (float)C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) { float d = xr[c] - mean; v += d * d; }
+    float rstd = rsqrtf(wave_sum(v) / (float)C + 1e-5f);
+    for (int c = lane; c < C; c += 64) y[(long)row * C + c] = (xr[c] - mean) * rstd * g[c] + b[c];
+}
+
+__global__ void query_init_kernel(const float* __restrict__ om, float* __restrict__ y, int rows, int C) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)rows * C) return;
+    int r = idx / C, c = idx - (long)r * C;
+    y[idx] = om[(long)r * (C + 1) + c] / (om[(long)r * (C + 1) + C] + 1e-4f);
+}
+
+// SUMMARIZE: grid (C/64, K), block 256 = 4 pixel slices x 64 channels
+__global__ __launch_bounds__(256) void summarize_kernel(const bf16_t* __restrict__ feat, const float* __restrict__ wl,
+                                                        const float* __restrict__ m16, float* __restrict__ y, int HW, int C, int Q) {
+    __shared__ float red[4][64][17];
+    int k = blockIdx.y, cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, s = threadIdx.x >> 6;
+    float acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    float area = 0.f;                      // threads with cl < Q accumulate the area of summary cl
+    for (int p = s; p < HW; p += 4) {
+        long row = (long)k * HW + p;
+        float f = bf2f(feat[row * C + c]);
+        float m = m16[row];
+        const float* wr = wl + row * Q;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float wgt = (1.f / (1.f + expf(-wr[q]))) * (q < 8 ? m : 1.f - m);
+            acc[q] += wgt * f;
+            if (q == cl) area += wgt;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[s][cl][q] = acc[q];
+    red[s][cl][16] = area;
+    __syncthreads();
+    if (s == 0) {
+        for (int q = 0; q < 16; ++q)
+            y[((long)k * Q + q) * (C + 1) + c] = red[0][cl][q] + red[1][cl][q] + red[2][cl][q] + red[3][cl][q];
+        if (blockIdx.x == 0 && cl < Q)
+            y[((long)k * Q + cl) * (C + 1) + C] = red[0][cl][16] + red[1][cl][16] + red[2][cl][16] + red[3][cl][16];
+    }
+}
+
+__global__ void add_pe_kernel(const uint4* __restrict__ x, const uint4* __restrict__ pe, uint4* __restrict__ y, int B, long n8) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * n8) return;
+    uint4 a = x[idx], b = pe[idx % n8];
+    const uint32_t* au = &a.x; const uint32_t* bu = &b.x;
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        o[i] = pack_bf2(__uint_as_float(au[i] << 16) + __uint_as_float(bu[i] << 16),
+                        __uint_as_float(au[i] & 0xffff0000u) + __uint_as_float(bu[i] & 0xffff0000u));
+    y[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void memset32_kernel(uint32_t* d, long n, uint32_t v) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = v;
+}
+__global__ void copy2d_kernel(const uint32_t* __restrict__ s, uint32_t* __restrict__ d, long rows, int roww, long ss, long ds) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * roww) return;
+    long r = i / roww; int c = i - r * roww;
+    d[r * ds + c] = s[r * ss + c];
+}
+__global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float a) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += a * x[i];
+}
+__global__ void tick_kernel(float* life, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) life[i] += 1.f;
+}
+__global__ void cast_kernel(const void* s, void* d, long n, int to_f32) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (to_f32) ((float*)d)[i] = bf2f(((const bf16_t*)s)[i]);
+    else ((bf16_t*)d)[i] = f2bf(((const float*)s)[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+int launch_elementwise(const cutie_op* op, hipStream_t s) {
+    const int32_t* i = op->i;
+    const uint64_t* p = op->p;
+    const int BS = 256;
+    switch (op->kind) {
+        case CUTIE_OP_MAXPOOL: {
+            int C8 = i[3] / 8;
+            long n = (long)i[0] * i[4] * i[5] * C8;
+            hipLaunchKernelGGL(maxpool_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const uint4*)p[0], (uint4*)p[1], i[0], i[1], i[2], C8, i[4], i[5], op->flags & 1);
+            break;
+        }
+        case CUTIE_OP_IMG_PREP: {
+            int K = p[1] ? i[6] : 1;
+            long n = (long)i[2] * i[3] * K;
+            hipLaunchKernelGGL(img_prep_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], (const float*)p[1], (uint4*)p[2],
+                               i[0], i[1], i[2], i[3], i[4], i[5], K, op->f[0], op->f[1], op->f[2], op->f[3], op->f[4], op->f[5]);
+            break;
+        }
+        case CUTIE_OP_UPSAMPLE2X_ADD: {
+            int C8 = i[3] / 8;
+            long n = (long)i[0] * 4 * i[1] * i[2] * C8;
+            hipLaunchKernelGGL(upsample2x_add_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const uint4*)p[0], (const uint4*)p[1], (uint4*)p[2], i[0], i[1], i[2], C8);
+            break;
+        }
+        case CUTIE_OP_AREA_DOWN: {
+            int r = i[6];
+            long np = (long)i[0] * (i[1] / r) * (i[2] / r);
+            if (op->flags & 1)
+                hipLaunchKernelGGL(area_down_f32_kernel, GRID1D(np, BS), dim3(BS), 0, s, (const float*)p[0], (bf16_t*)p[1], i[0], i[1], i[2], i[3], i[4], i[5], r, i[7]);
+            else
+                hipLaunchKernelGGL(area_down_bf16_kernel, GRID1D(np * (i[3] / 8), BS), dim3(BS), 0, s, (const bf16_t*)p[0], (bf16_t*)p[1], i[0], i[1], i[2], i[3], i[4], i[5], r);
+            break;
+        }
+        case CUTIE_OP_MASK_DOWN: {
+            int K = i[0], r = i[3], h = i[1] / r, w = i[2] / r;
+            long n = (long)K * h * w;
+            float* m16 = (float*)p[2];
+            if (!m16) { cutie_set_error("mask_down: m16 buffer required"); return -2; }
+            hipLaunchKernelGGL(mask_down_mean_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], m16, K, i[1], i[2], r);
+            hipLaunchKernelGGL(mask_pair_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const float*)m16, (uint4*)p[1], K, h * w);
+            break;
+        }
+        case CUTIE_OP_GAP:
+            hipLaunchKernelGGL(gap_kernel, dim3((i[2] + 63) / 64, i[0]), dim3(256), 0, s, (const bf16_t*)p[0], (float*)p[1], i[1], i[2]);
+            break;
+        case CUTIE_OP_ECA_APPLY: {
+            long n = (long)i[0] * i[1] * (i[2] / 8);
+            hipLaunchKernelGGL(eca_apply_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const uint4*)p[0], (const float*)p[1], (const float*)p[2], (const uint4*)p[3], (uint4*)p[4], i[0], i[1], i[2]);
+            break;
+        }
+        case CUTIE_OP_GRU: {
+            long n = (long)i[0] * i[1];
+            hipLaunchKernelGGL(gru_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (bf16_t*)p[2], (long)i[0], i[1]);
+            break;
+        }
+        case CUTIE_OP_SEG_AGG:
+            hipLaunchKernelGGL(seg_agg_kernel, GRID1D(i[1], BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], i[0], i[1]);
+            break;
+        case CUTIE_OP_UP4_SOFTMAX: {
+            long n = (long)16 * i[1] * i[2];
+            hipLaunchKernelGGL(up4_softmax_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0], i[1], i[2]);
+            break;
+        }
+        case CUTIE_OP_MASK_MERGE: {
+            long n = (long)i[2] * i[3];
+            hipLaunchKernelGGL(mask_merge_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const void*)p[0], (const float*)p[1], (const int*)p[2], (float*)p[3],
+                               i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], op->flags & 1);
+            break;
+        }
+        case CUTIE_OP_AGG_SOFTMAX:
+            hipLaunchKernelGGL(agg_softmax_kernel, GRID1D(i[1], BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], i[0], (long)i[1]);
+            break;
+        case CUTIE_OP_LINEAR:
+            if ((i[2] & 7) || (i[3] & 3)) { cutie_set_error("linear: Kd %% 8 / ldx %% 4"); return -2; }
+            hipLaunchKernelGGL(linear_small_kernel, dim3((i[1] + 15) / 16), dim3(256), 0, s, (const float*)p[0], (const float*)p[1], (const bf16_t*)p[2],
+                               (const float*)p[3], (const float*)p[4], (float*)p[5], i[0], i[1], i[2], i[3], i[4], i[5] > 0 ? i[5] : 1, op->flags & 1);
+            break;
+        case CUTIE_OP_LAYERNORM:
+            hipLaunchKernelGGL(layernorm_kernel, dim3((i[0] + 3) / 4), dim3(256), 0, s, (const float*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[3], i[0], i[1]);
+            break;
+        case CUTIE_OP_QUERY_INIT: {
+            long n = (long)i[0] * i[1];
+            hipLaunchKernelGGL(query_init_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], i[0], i[1]);
+            break;
+        }
+        case CUTIE_OP_SUMMARIZE:
+            if (i[3] != 16 || (i[2] & 63)) { cutie_set_error("summarize: Q must be 16, C %% 64"); return -2; }
+            hipLaunchKernelGGL(summarize_kernel, dim3(i[2] / 64, i[0]), dim3(256), 0, s, (const bf16_t*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[3], i[1], i[2], i[3]);
+            break;
+        case CUTIE_OP_ADD_PE: {
+            long n8 = i[1] / 8;
+            hipLaunchKernelGGL(add_pe_kernel, GRID1D((long)i[0] * n8, BS), dim3(BS), 0, s, (const uint4*)p[0], (const uint4*)p[1], (uint4*)p[2], i[0], n8);
+            break;
+        }
+        case CUTIE_OP_MEMSET32:
+            hipLaunchKernelGGL(memset32_kernel, GRID1D(i[0], BS), dim3(BS), 0, s, (uint32_t*)p[0], (long)i[0], (uint32_t)i[1]);
+            break;
+        case CUTIE_OP_COPY2D: {
+            int roww = i[1] / 4;
+            long n = (long)i[0] * roww;
+            hipLaunchKernelGGL(copy2d_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const uint32_t*)p[0], (uint32_t*)p[1], (long)i[0], roww, (long)i[2] / 4, (long)i[3] / 4);
+            break;
+        }
+        case CUTIE_OP_AXPY:
+            hipLaunchKernelGGL(axpy_kernel, GRID1D(i[0], BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (long)i[0], op->f[0]);
+            break;
+        case CUTIE_OP_USAGE_TICK:
+            hipLaunchKernelGGL(tick_kernel, GRID1D(i[0], BS), dim3(BS), 0, s, (float*)p[0], (long)i[0]);
+            break;
+        case CUTIE_OP_CAST:
+            hipLaunchKernelGGL(cast_kernel, GRID1D(i[0], BS), dim3(BS), 0, s, (const void*)p[0], (void*)p[1], (long)i[0], op->flags & 1);
+            break;
+        default:
+            cutie_set_error("elementwise: unknown op kind %d", op->kind);
+            return -3;
+    }
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,237 @@
+"""``InferenceCore`` -- per-frame scheduler; same surface and frame logic as the reference
+cutie/inference/inference_core.py:18-345, with every tensor op of the frame issued as HIP launch plans.
+
+Kept from the reference (file:line): memory-frame / segmentation / sensory-update schedule (:238-243),
+stagger_ti (:37-41), mask merge semantics (:259-300), last_mask = prob[1:] (:302), memorise (:308-315),
+unpad (:320), optional internal resize (:206-228, :321-326), delete_objects (:330-335),
+output_prob_to_mask (:337-345).
+Not supported yet (raises): flip_aug (bs=2), chunk_size > 0 -- SURVEY.md section 8f rank 4.
+"""
+import logging
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ..model import plans
+from .image_feature_store import ImageFeatureStore
+from .memory_manager import MemoryManager
+from .object_manager import ObjectManager
+
+log = logging.getLogger()
+F32 = torch.float32
+
+
+def pad_geometry(h, w, d=16):
+    """tensor_utils.pad_divide_by (cutie/utils/tensor_utils.py:7-22): symmetric zero pad to a multiple of d."""
+    new_h = h + d - h % d if h % d > 0 else h
+    new_w = w + d - w % d if w % d > 0 else w
+    lh, uh = int((new_h - h) / 2), int(new_h - h) - int((new_h - h) / 2)
+    lw, uw = int((new_w - w) / 2), int(new_w - w) - int((new_w - w) / 2)
+    return new_h, new_w, (lw, uw, lh, uh)
+
+
+def unpad(img: torch.Tensor, pad) -> torch.Tensor:
+    """cutie/utils/tensor_utils.py:25-44 (3-D case): a view, no copy."""
+    if pad[2] + pad[3] > 0:
+        img = img[:, pad[2]:img.shape[1] - pad[3], :]
+    if pad[0] + pad[1] > 0:
+        img = img[:, :, pad[0]:img.shape[2] - pad[1]]
+    return img
+
+
+class InferenceCore:
+    def __init__(self, network, cfg, *, image_feature_store: ImageFeatureStore = None):
+        self.network = network
+        self.cfg = cfg
+        self.mem_every = cfg.mem_every
+        stagger_updates = cfg.stagger_updates
+        self.chunk_size = cfg.chunk_size
+        self.save_aux = cfg.save_aux
+        self.max_internal_size = cfg.max_internal_size
+        self.flip_aug = cfg.flip_aug
+        if self.flip_aug:
+            raise NotImplementedError('flip_aug (batch of 2) is not supported by the HIP path yet')
+        if self.chunk_size is not None and self.chunk_size > 0:
+            raise NotImplementedError('chunk_size > 0 is not supported by the HIP path yet (all objects run batched)')
+        self.curr_ti = -1
+        self.last_mem_ti = 0
+        if stagger_updates >= self.mem_every:
+            self.stagger_ti = set(range(1, self.mem_every + 1))
+        else:
+            self.stagger_ti = set(np.round(np.linspace(1, self.mem_every, stagger_updates)).astype(int))
+        self.object_manager = ObjectManager()
+        self.memory = MemoryManager(cfg=cfg, object_manager=self.object_manager)
+        self.image_feature_store = ImageFeatureStore(self.network) if image_feature_store is None else image_feature_store
+        self.last_mask = None
+        self.pad = (0, 0, 0, 0)
+
+    def clear_memory(self):
+        self.curr_ti = -1
+        self.last_mem_ti = 0
+        self.memory = MemoryManager(cfg=self.cfg, object_manager=self.object_manager)
+
+    def clear_non_permanent_memory(self):
+        self.curr_ti = -1
+        self.last_mem_ti = 0
+        self.memory.clear_non_permanent_memory()
+
+    def clear_sensory_memory(self):
+        self.curr_ti = -1
+        self.last_mem_ti = 0
+        self.memory.clear_sensory_memory()
+
+    def update_config(self, cfg):
+        self.mem_every = cfg['mem_every']
+        self.memory.update_config(cfg)
+
+    # ---- memorise (inference_core.py:71-121) ------------------------------------------------------------------
+    def _add_memory(self, image, pix_feat, prob, key, shrinkage, selection, *, is_deep_update=True, force_permanent=False):
+        if prob.shape[1] == 0:
+            log.warning('Trying to add an empty object mask to memory!')
+            return
+        as_permanent = 'all' if force_permanent else 'first'
+        ids = self.object_manager.all_obj_ids
+        self.memory.initialize_sensory_if_needed(key, ids)
+        g = getattr(image, '_cutie_raw', None)                 # (h0, w0, H, W, pad_left, pad_top) of the un-padded frame
+        raw = (image, g[0], g[1], g[4], g[5]) if g is not None else None
+        msk_value, sensory, obj_value, _ = self.network.encode_mask(
+            image, pix_feat, self.memory.get_sensory(ids), prob, deep_update=is_deep_update, chunk_size=self.chunk_size,
+            need_weights=self.save_aux, _raw=raw)
+        self.memory.add_memory(key, shrinkage, msk_value, obj_value, ids, selection=selection, as_permanent=as_permanent)
+        self.last_mem_ti = self.curr_ti
+        if is_deep_update:
+            self.memory.update_sensory(sensory, ids)
+
+    # ---- segment (inference_core.py:123-170) ---------------------------------------------------------------------
+    def _segment(self, key, selection, pix_feat, ms_features, update_sensory=True) -> torch.Tensor:
+        if not self.memory.engaged:
+            log.warning('Trying to segment without any memory!')
+            return torch.zeros((1, key.shape[-2] * 16, key.shape[-1] * 16), device=key.device, dtype=key.dtype)
+        ids = self.object_manager.all_obj_ids
+        memory_readout = self.memory.read(pix_feat, key, selection, self.last_mask, self.network)
+        stacked = self.memory.readout_stacked(ids)
+        memory_readout = stacked if stacked is not None else self.object_manager.realize_dict(memory_readout)
+        sensory, _, pred_prob_with_bg = self.network.segment(ms_features, memory_readout, self.memory.get_sensory(ids),
+                                                             chunk_size=self.chunk_size, update_sensory=update_sensory,
+                                                             _need_logits=False)
+        pred_prob_with_bg = pred_prob_with_bg[0]
+        if update_sensory:
+            self.memory.update_sensory(sensory, ids)
+        return pred_prob_with_bg
+
+    # ---- step (inference_core.py:172-328) ------------------------------------------------------------------------------
+    def step(self, image: torch.Tensor, mask: Optional[torch.Tensor] = None, objects: Optional[List[int]] = None, *,
+             idx_mask: bool = True, end: bool = False, delete_buffer: bool = True, force_permanent: bool = False) -> torch.Tensor:
+        if objects is None and mask is not None:
+            assert not idx_mask
+            objects = list(range(1, mask.shape[0] + 1))
+
+        resize_needed = False
+        if self.max_internal_size > 0:
+            h, w = image.shape[-2:]
+            min_side = min(h, w)
+            if min_side > self.max_internal_size:
+                # GUI-only path of the reference (:206-228); torch resampling, not a HIP kernel yet
+                resize_needed = True
+                new_h = int(h / min_side * self.max_internal_size)
+                new_w = int(w / min_side * self.max_internal_size)
+                image = F.interpolate(image.unsqueeze(0), size=(new_h, new_w), mode='bilinear', align_corners=False)[0]
+                if mask is not None:
+                    if idx_mask:
+                        mask = F.interpolate(mask.unsqueeze(0).unsqueeze(0).float(), size=(new_h, new_w),
+                                             mode='nearest-exact')[0, 0].round().long()
+                    else:
+                        mask = F.interpolate(mask.unsqueeze(0), size=(new_h, new_w), mode='bilinear', align_corners=False)[0]
+
+        self.curr_ti += 1
+        h0, w0 = image.shape[-2:]
+        H, W, self.pad = pad_geometry(h0, w0, 16)
+        pl, pt = self.pad[0], self.pad[2]
+        # zero-padding to /16 is fused into the first kernel of each plan: hand over the raw frame + geometry
+        image = image.to(F32).contiguous()
+        image._cutie_raw = (h0, w0, H, W, pl, pt)
+
+        is_mem_frame = ((self.curr_ti - self.last_mem_ti >= self.mem_every) or (mask is not None)) and (not end)
+        need_segment = (mask is None) or (self.object_manager.num_obj > 0 and not self.object_manager.has_all(objects))
+        update_sensory = ((self.curr_ti - self.last_mem_ti) in self.stagger_ti) and (not end)
+
+        ms_feat, pix_feat = self.image_feature_store.get_features(self.curr_ti, image)
+        key, shrinkage, selection = self.image_feature_store.get_key(self.curr_ti, image)
+
+        if need_segment:
+            pred_prob_with_bg = self._segment(key, selection, pix_feat, ms_feat, update_sensory=update_sensory)
+
+        if mask is not None:
+            k_old = self.object_manager.num_obj
+            corresponding_tmp_ids, _ = self.object_manager.add_new_objects(objects)
+            k_new = self.object_manager.num_obj
+            if not need_segment and idx_mask and len(objects) == 0:
+                if delete_buffer:
+                    self.image_feature_store.delete(self.curr_ti)
+                log.warning('Trying to insert an empty mask as memory!')
+                return torch.zeros((1, key.shape[-2] * 16, key.shape[-1] * 16), device=key.device, dtype=key.dtype)
+            pred_prob_with_bg = self._mask_to_prob(mask, objects, corresponding_tmp_ids, idx_mask, need_segment,
+                                                   pred_prob_with_bg if need_segment else None, k_old, k_new,
+                                                   h0, w0, H, W, pl, pt)
+
+        self.last_mask = pred_prob_with_bg[1:].unsqueeze(0)
+
+        if is_mem_frame or force_permanent:
+            self._add_memory(image, pix_feat, self.last_mask, key, shrinkage, selection, force_permanent=force_permanent)
+
+        if delete_buffer:
+            self.image_feature_store.delete(self.curr_ti)
+
+        output_prob = unpad(pred_prob_with_bg, self.pad)
+        if resize_needed:
+            output_prob = F.interpolate(output_prob.unsqueeze(0), size=(h, w), mode='bilinear', align_corners=False)[0]
+        return output_prob
+
+    def _mask_to_prob(self, mask, objects, tmp_ids, idx_mask, need_segment, pred, k_old, k_new, h0, w0, H, W, pl, pt):
+        """inference_core.py:259-300 as two kernels (MASK_MERGE, AGG_SOFTMAX)."""
+        net = self.network
+        dev = net.device
+        src = [-1] * k_new
+        if need_segment:
+            # planes of known objects keep the prediction unless the input mask provides them
+            n_planes = max(k_new, pred.shape[0] - 1)
+            for mask_id, tmp_id in enumerate(tmp_ids):
+                # sic: float masks are indexed by tmp id in the reference (:276)
+                src[tmp_id - 1] = int(objects[mask_id]) if idx_mask else int(tmp_id)
+            k_pred = pred.shape[0] - 1
+        else:
+            if idx_mask:
+                n_planes = len(tmp_ids)
+                src = [int(objects[mask_id]) for mask_id, _ in enumerate(tmp_ids)]
+            else:
+                n_planes = mask.shape[0]
+                src = list(range(n_planes))
+            k_pred = 0
+        src = src[:n_planes] + [-1] * (n_planes - len(src))
+        if idx_mask:
+            inmask = mask.to(device=dev, dtype=torch.int32).contiguous()
+            nfloat = 0
+        else:
+            inmask = mask.to(device=dev, dtype=F32).contiguous()
+            nfloat = inmask.shape[0]
+        src_t = torch.tensor(src, dtype=torch.int32).to(dev)
+        eng = net.engine()
+        P = eng.plan(('m2p', n_planes, k_pred, h0, w0, H, W, pl, pt, not idx_mask, nfloat), plans.build_mask_to_prob,
+                     n_planes, k_pred, h0, w0, H, W, pl, pt, not idx_mask, nfloat)
+        prob = torch.empty((n_planes + 1, H, W), dtype=F32, device=dev)
+        P.run(inmask=inmask, pred=pred.contiguous() if pred is not None else None, src=src_t, prob=prob)
+        return prob
+
+    def delete_objects(self, objects: List[int]) -> None:
+        self.object_manager.delete_objects(objects)
+        self.memory.purge_except(self.object_manager.all_obj_ids)
+
+    def output_prob_to_mask(self, output_prob: torch.Tensor) -> torch.Tensor:
+        mask = torch.argmax(output_prob, dim=0)
+        lut = torch.zeros(output_prob.shape[0], dtype=mask.dtype, device=mask.device)
+        for tmp_id, obj in self.object_manager.tmp_id_to_obj.items():
+            if tmp_id < lut.shape[0]:
+                lut[tmp_id] = obj.id
+        return lut[mask]

@@ -1,0 +1,382 @@
+"""``MemoryManager`` -- sensory / object / working / long-term memory on MI355X; mirrors the surface of
+cutie/inference/memory_manager.py:14-383 on top of the contiguous bank of kv_memory_store.py.
+
+Reference behaviour kept (with file:line):
+  * buckets = objects first seen in the same frame (kv_memory_store.py:96-117); first insertion of a bucket is
+    permanent ('first'), ``force_permanent`` makes every insertion permanent ('all')   (:119-130)
+  * FIFO working memory of ``max_mem_frames-1`` frames (memory_manager.py:38,296)
+  * long-term memory: usage counting (:151-162), consolidation of the oldest frames into ``num_prototypes``
+    prototypes by top-usage + dense-softmax potentiation (:309-358), pruning of obsolete prototypes (:287-291)
+  * object memory = streaming sum of the summaries (:252-271); sensory memory per object (:360-375)
+Per-object state lives in stacked tensors in tmp-id order (objects of one bucket are always contiguous there).
+"""
+import logging
+from typing import Dict, List
+
+import torch
+
+from .. import ops as O
+from .kv_memory_store import Bucket, StoreView, LIFE_EPS_BITS
+from .object_manager import ObjectManager
+
+log = logging.getLogger()
+BF16, F32 = torch.bfloat16, torch.float32
+CAND_CAP = 1024          # candidate slots per query column (typical fill ~35; see csrc/affinity.hip)
+
+
+class MemoryManager:
+    def __init__(self, cfg, object_manager: ObjectManager):
+        self.object_manager = object_manager
+        self.sensory_dim = cfg.model.sensory_dim
+        self.top_k = cfg.top_k
+        self.chunk_size = cfg.chunk_size
+        self.save_aux = cfg.save_aux
+        self.use_long_term = cfg.use_long_term
+        self.count_long_term_usage = cfg.long_term.count_usage
+        self._read_cfg(cfg)
+        self.CK = self.CV = None
+        self.H = self.W = None
+        self.buckets: Dict[int, Bucket] = {}
+        self._next_bucket = 0
+        self.work_mem = StoreView(self, False)
+        self.long_mem = StoreView(self, True) if self.use_long_term else None
+        # stacked per-object state, rows in the order of self._ids
+        self._ids: List[int] = []
+        self._sens_f32 = None        # [K,h,w,CS]
+        self._sens_bf16 = None
+        self._objv = None            # [K,Q,C+1] f32
+        self._objv_ids: List[int] = []
+        self._orphan_objv = {}       # summaries of deleted objects (the reference never purges obj_v, :298-307)
+        self._scratch = {}
+        self.config_stale = True
+        self.engaged = False
+        self.aux = None
+
+    def _read_cfg(self, cfg):
+        if self.use_long_term:
+            self.max_mem_frames = cfg.long_term.max_mem_frames - 1
+            self.min_mem_frames = cfg.long_term.min_mem_frames - 1
+            self.num_prototypes = cfg.long_term.num_prototypes
+            self.max_long_tokens = cfg.long_term.max_num_tokens
+            self.buffer_tokens = cfg.long_term.buffer_tokens
+        else:
+            self.max_mem_frames = cfg.max_mem_frames - 1
+
+    def update_config(self, cfg) -> None:
+        self.config_stale = True
+        self.top_k = cfg['top_k']
+        assert self.use_long_term == cfg.use_long_term, 'cannot update this'
+        assert self.count_long_term_usage == cfg.long_term.count_usage, 'cannot update this'
+        self._read_cfg(cfg)
+
+    # ---- sensory memory (memory_manager.py:360-375) --------------------------------------------------
+    def initialize_sensory_if_needed(self, sample_key: torch.Tensor, ids: List[int]):
+        new = [o for o in ids if o not in self._ids]
+        if not new:
+            return
+        _, _, h, w = sample_key.shape
+        dev = sample_key.device
+        zf = torch.zeros((len(new), h, w, self.sensory_dim), dtype=F32, device=dev)
+        zb = torch.zeros((len(new), h, w, self.sensory_dim), dtype=BF16, device=dev)
+        if self._sens_f32 is None or not self._ids:
+            self._sens_f32, self._sens_bf16 = zf, zb
+        else:
+            self._sens_f32 = torch.cat([self._sens_f32, zf], 0)
+            self._sens_bf16 = torch.cat([self._sens_bf16, zb], 0)
+        self._ids = self._ids + new
+
+    def _rows(self, ids: List[int], order: List[int]):
+        """(start, stop) of `ids` inside the stacked state ordered by `order`; ids must be a contiguous run."""
+        pos = [order.index(o) for o in ids]
+        assert pos == list(range(pos[0], pos[0] + len(pos))), 'objects of a bucket must be contiguous in tmp-id order'
+        return pos[0], pos[0] + len(pos)
+
+    def get_sensory(self, ids: List[int]):
+        """logical [1,K,CS,h,w] fp32 view of the stacked state (+ its bf16 shadow as attribute)."""
+        a, b = self._rows(ids, self._ids)
+        t = self._sens_f32[a:b].permute(0, 3, 1, 2).unsqueeze(0)
+        t._cutie_bf16 = self._sens_bf16[a:b]
+        return t
+
+    def update_sensory(self, sensory: torch.Tensor, ids: List[int]):
+        a, b = self._rows(ids, self._ids)
+        phys = sensory[0].permute(0, 2, 3, 1)
+        if phys.data_ptr() != self._sens_f32[a:b].data_ptr():          # foreign tensor: copy in
+            self._sens_f32[a:b].copy_(phys)
+            self._sens_bf16[a:b].copy_(phys)
+        # else: the kernels already updated the state in place
+
+    def clear_sensory_memory(self):
+        self._ids, self._sens_f32, self._sens_bf16 = [], None, None
+
+    # ---- helpers ------------------------------------------------------------------------------------------
+    def _buf(self, name, shape, dtype, dev):
+        t = self._scratch.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.device != dev:
+            t = torch.zeros(shape, dtype=dtype, device=dev)
+            self._scratch[name] = t
+        return t
+
+    def _get_mask_by_ids(self, mask: torch.Tensor, obj_ids: List[int]) -> torch.Tensor:
+        tmp = [self.object_manager.find_tmp_by_id(o) - 1 for o in obj_ids]
+        if tmp == list(range(tmp[0], tmp[0] + len(tmp))):
+            return mask[:, tmp[0]:tmp[0] + len(tmp)]
+        return mask[:, tmp]
+
+    # ---- read (memory_manager.py:112-208) ---------------------------------------------------------------------
+    def read(self, pix_feat: torch.Tensor, query_key: torch.Tensor, selection: torch.Tensor, last_mask: torch.Tensor,
+             network) -> Dict[int, torch.Tensor]:
+        q = getattr(query_key, '_cutie_query', None)
+        if q is None:
+            raise RuntimeError('query_key must come from CUTIE.transform_key (it carries the similarity operands)')
+        h, w = pix_feat.shape[-2:]
+        HW = h * w
+        HWp = q['Bhi'].shape[0]
+        dev = pix_feat.device
+        all_readout = {}
+        for bucket in self.buckets.values():
+            K = len(bucket.objects)
+            ranges = [r for r in bucket.ranges() if r[1] > 0]
+            G = sum(-(-n // 16) for _, n in ranges)
+            gmax = self._buf('gmax', (max(G, 1), HWp), F32, dev)
+            tau = self._buf('tau', (HW,), F32, dev)
+            cval = self._buf('cand_val', (HW, CAND_CAP), F32, dev)
+            cidx = self._buf('cand_idx', (HW, CAND_CAP), torch.int32, dev)
+            count = self._buf('count', (HW,), torch.int32, dev)
+            ovf = self._buf('overflow', (1,), torch.int32, dev)
+            readout = torch.empty((K, h, w, self.CV), dtype=BF16, device=dev)
+            ol = O.OpList()
+            ol.memset32(count, HW, 0)
+            common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=CAND_CAP)
+            ol.aff_score(bucket.Ahi, bucket.Alo, bucket.scale, q['Bhi'], q['Blo'], q['cq'], gmax, None, None, None, mode=0, **common)
+            ol.aff_select(gmax, tau, HW=HW, HWp=HWp, G=G, top_k=self.top_k)
+            ol.aff_score(bucket.Ahi, bucket.Alo, bucket.scale, q['Bhi'], q['Blo'], q['cq'], tau, cval, cidx, count, mode=1, **common)
+            usage = None
+            if self.use_long_term:
+                # usage bookkeeping (kv_memory_store.py:151-162): life += 1 for every counted token
+                usage = bucket.use
+                if bucket.n_work > 0:
+                    ol.usage_tick(bucket.life[bucket.work_start:], bucket.n_work)
+                if bucket.n_long > 0 and self.count_long_term_usage:
+                    ol.usage_tick(bucket.life, bucket.n_long)
+            ol.aff_readout(cval, cidx, count, bucket.vptrs(), usage, readout, ovf, HW=HW, cap=CAND_CAP, top_k=self.top_k,
+                           K=K, CV=self.CV)
+            ol.run()
+            objects = bucket.objects
+            this_sensory = self.get_sensory(objects)
+            this_last_mask = self._get_mask_by_ids(last_mask, objects)
+            visual_readout = readout.permute(0, 3, 1, 2).unsqueeze(0)
+            pixel_readout = network.pixel_fusion(pix_feat, visual_readout, this_sensory, this_last_mask)
+            a, b = self._rows(objects, self._objv_ids)
+            this_obj_mem = self._objv[a:b].unsqueeze(0).unsqueeze(2)                # [1,K,1,Q,C+1]
+            readout_memory, aux_features = network.readout_query(pixel_readout, this_obj_mem)
+            for i, obj in enumerate(objects):
+                all_readout[obj] = readout_memory[:, i]
+            self._last_readout = (objects, readout_memory)
+            if self.save_aux:
+                self.aux = {'sensory': this_sensory, 'pixel_readout': pixel_readout,
+                            'q_logits': aux_features['logits'] if aux_features else None}
+        return all_readout
+
+    def readout_stacked(self, all_obj_ids):
+        """The per-object dict of read() re-stacked in tmp-id order (ObjectManager.realize_dict) without a copy when
+        a single bucket holds every object."""
+        objs, t = getattr(self, '_last_readout', (None, None))
+        if objs is not None and list(objs) == list(all_obj_ids):
+            return t
+        return None
+
+    # ---- write (memory_manager.py:210-296) ------------------------------------------------------------------------
+    def add_memory(self, key, shrinkage, msk_value, obj_value, objects: List[int], selection=None, *, as_permanent='no') -> None:
+        bs = key.shape[0]
+        assert bs == 1 and shrinkage.shape[0] == 1 and msk_value.shape[0] == 1
+        self.engaged = True
+        if self.H is None or self.config_stale:
+            self.config_stale = False
+            self.H, self.W = msk_value.shape[-2:]
+            self.HW = self.H * self.W
+            self.max_work_tokens = self.max_mem_frames * self.HW
+            if self.use_long_term:
+                self.min_work_tokens = self.min_mem_frames * self.HW
+        HW = self.HW
+        dev = key.device
+        self.CK = key.shape[1]
+        self.CV = msk_value.shape[2]
+        # physical views: key [HW,CK] f32, shrinkage [HW] f32, selection [HW,CK] f32, values [K,HW,CV] bf16
+        kphys = key[0].permute(1, 2, 0).reshape(HW, self.CK)
+        sphys = shrinkage.reshape(HW)
+        ephys = selection[0].permute(1, 2, 0).reshape(HW, self.CK) if selection is not None else None
+        kphys, sphys = kphys.to(F32).contiguous(), sphys.to(F32).contiguous()
+        if ephys is not None:
+            ephys = ephys.to(F32).contiguous()
+        vphys = msk_value[0].permute(0, 2, 3, 1)
+        if vphys.dtype != BF16 or not vphys.is_contiguous():
+            vphys = vphys.to(BF16).contiguous()
+        vphys = vphys.reshape(len(objects), HW, self.CV)
+
+        ol = O.OpList()
+        # ---- object memory: streaming sum (:252-271)
+        if obj_value is not None:
+            ov = obj_value[0].to(F32).contiguous()                     # [K,Q,C+1]
+            known = [o for o in objects if o in self._objv_ids]
+            new = [o for o in objects if o not in self._objv_ids]
+            if known:
+                ka, kb = self._rows(known, self._objv_ids)
+                ia = objects.index(known[0])
+                ol.axpy(ov[ia:ia + len(known)], self._objv[ka:kb], n=len(known) * ov.shape[1] * ov.shape[2], a=1.0)
+            if new:
+                ia = objects.index(new[0])
+                rows = ov[ia:ia + len(new)].clone()
+                for j, o in enumerate(new):
+                    if o in self._orphan_objv:                        # object re-added after deletion
+                        rows[j] += self._orphan_objv.pop(o)
+                self._objv = rows if (self._objv is None or not self._objv_ids) else torch.cat([self._objv, rows], 0)
+                self._objv_ids = self._objv_ids + new
+
+        # ---- bucket assignment (kv_memory_store.py:96-117)
+        enabled = []
+        new_objs = [o for o in objects if not any(o in b.objects for b in self.buckets.values())]
+        if new_objs:
+            work_cap = self.max_work_tokens
+            b = Bucket(self._next_bucket, new_objs, HW, self.CK, self.CV, dev, use_long_term=self.use_long_term,
+                       work_cap=work_cap, long_cap=self.max_long_tokens if self.use_long_term else 0)
+            self.buckets[b.id] = b
+            self._next_bucket += 1
+        for b in self.buckets.values():
+            if any(o in objects for o in b.objects):
+                enabled.append(b)
+
+        for b in enabled:
+            to_perm = (as_permanent == 'all') or (as_permanent == 'first' and b.n_perm == 0)
+            if to_perm:
+                if b.n_perm + HW > b.P:
+                    b.grow_perm(b.n_perm + HW)
+                slot = b.perm_start + b.n_perm
+                b.n_perm += HW
+            else:
+                if b.Wc < HW:
+                    continue                                            # max_mem_frames == 1: no working memory at all
+                if self.use_long_term:
+                    slot = b.work_start + b.n_work                      # linear; consolidation compacts
+                    b.n_work += HW
+                else:
+                    frames = b.Wc // HW                                 # FIFO ring (:296, kv_memory_store.py:206-207)
+                    slot = b.work_start + (b.ring % frames) * HW
+                    b.ring += 1
+                    b.n_work = min(b.n_work + HW, frames * HW)
+            ol.key_prep(kphys, sphys, b.Ahi[slot:], b.Alo[slot:], b.scale[slot:], n=HW, query=False)
+            if self.use_long_term:
+                ol.copy2d(kphys, b.rawkey[slot:], rows=HW, rowbytes=4 * self.CK, src_stride=4 * self.CK, dst_stride=4 * self.CK)
+                ol.copy2d(sphys, b.rawshr[slot:], rows=1, rowbytes=4 * HW, src_stride=4 * HW, dst_stride=4 * HW)
+                if ephys is not None:
+                    ol.copy2d(ephys, b.rawsel[slot:], rows=HW, rowbytes=4 * self.CK, src_stride=4 * self.CK, dst_stride=4 * self.CK)
+                ol.memset32(b.use[slot:], HW, 0)
+                ol.memset32(b.life[slot:], HW, LIFE_EPS_BITS)
+            for o in b.objects:
+                if o in objects:
+                    i = objects.index(o)
+                    ol.copy2d(vphys[i], b.values[o][slot:], rows=1, rowbytes=2 * HW * self.CV, src_stride=2 * HW * self.CV,
+                              dst_stride=2 * HW * self.CV)
+        if len(ol):
+            ol.run()
+
+        # ---- long-term maintenance (:281-293)
+        if self.use_long_term:
+            for b in list(self.buckets.values()):
+                if b.n_work >= self.max_work_tokens:
+                    if b.n_long >= self.max_long_tokens - self.num_prototypes:
+                        self._remove_obsolete(b, self.max_long_tokens - self.num_prototypes - self.buffer_tokens)
+                    self._compress(b)
+
+    # ---- long-term consolidation (memory_manager.py:309-358) ----------------------------------------------------------
+    def _compress(self, b: Bucket):
+        HW, dev = self.HW, b.device
+        P = self.num_prototypes
+        n = b.n_work - self.min_work_tokens            # candidates: the oldest working tokens
+        if n <= 0:
+            return
+        ws = b.work_start
+        ol = O.OpList()
+        order = self._buf('proto_order', (P,), torch.int32, dev)
+        ol.rank_select(b.use[ws:], b.life[ws:], order, n=n, k=P)                          # topk(usage, P) (:339)
+        dst = b.n_long                                                                    # prototypes appended to the LT region
+        ol.gather_rows(b.rawkey[ws:], order, b.rawkey[dst:], k=P, rowbytes=4 * b.CK, src_stride=4 * b.CK, dst_stride=4 * b.CK)
+        psel = self._buf('proto_sel', (P, b.CK), F32, dev)
+        ol.gather_rows(b.rawsel[ws:], order, psel, k=P, rowbytes=4 * b.CK, src_stride=4 * b.CK, dst_stride=4 * b.CK)
+        aff = self._buf('consol_aff', (P, n), F32, dev)
+        ol.consol_aff(b.rawkey[ws:], b.rawshr[ws:], b.rawkey[dst:], psel, aff, n=n, P=P)     # potentiation (:347-350)
+        for o in b.objects:
+            ol.consol_read(aff, b.values[o][ws:], b.values[o][dst:], n=n, P=P, C=b.CV, ldv=b.CV, ldo=b.CV)
+        ol.consol_read(aff, b.rawshr[ws:], b.rawshr[dst:], n=n, P=P, C=1, ldv=1, ldo=1, f32=True)
+        ol.key_prep(b.rawkey[dst:], b.rawshr[dst:], b.Ahi[dst:], b.Alo[dst:], b.scale[dst:], n=P, query=False)
+        ol.memset32(b.use[dst:], P, 0)
+        ol.memset32(b.life[dst:], P, LIFE_EPS_BITS)
+        # drop the consolidated tokens: keep the newest min_work_tokens, moved to the region start
+        keep = self.min_work_tokens
+        for t, rowbytes in b.arrays():
+            nb = rowbytes * keep
+            ol.copy2d(t[ws + n:], t[ws:], rows=1, rowbytes=nb, src_stride=nb, dst_stride=nb)
+        ol.run()
+        b.n_long += P
+        b.n_work = keep
+
+    def _remove_obsolete(self, b: Bucket, max_size: int):
+        """kv_memory_store.py:209-242: keep the `max_size` most-used long-term tokens (in top-k order)."""
+        dev = b.device
+        n = b.n_long
+        order = self._buf('lt_order', (max_size,), torch.int32, dev)
+        ol = O.OpList()
+        ol.rank_select(b.use, b.life, order, n=n, k=max_size)
+        tmps = []
+        for t, rowbytes in b.arrays():
+            tmp = torch.empty((max_size,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+            ol.gather_rows(t, order, tmp, k=max_size, rowbytes=rowbytes, src_stride=rowbytes, dst_stride=rowbytes)
+            tmps.append((t, tmp, rowbytes))
+        for t, tmp, rowbytes in tmps:
+            nb = rowbytes * max_size
+            ol.copy2d(tmp, t, rows=1, rowbytes=nb, src_stride=nb, dst_stride=nb)
+        ol.run()
+        b.n_long = max_size
+
+    # ---- object deletion / clearing ----------------------------------------------------------------------------------------
+    def purge_except(self, obj_keep_idx: List[int]) -> None:
+        keep = set(obj_keep_idx)
+        for bid in list(self.buckets.keys()):
+            b = self.buckets[bid]
+            b.remove_objects(keep)
+            if not b.objects:
+                del self.buckets[bid]
+        if self._ids:
+            rows = [i for i, o in enumerate(self._ids) if o in keep]
+            if len(rows) != len(self._ids):
+                idx = torch.tensor(rows, dtype=torch.long, device=self._sens_f32.device)
+                self._sens_f32 = self._sens_f32.index_select(0, idx)
+                self._sens_bf16 = self._sens_bf16.index_select(0, idx)
+                self._ids = [self._ids[i] for i in rows]
+        if self._objv_ids:
+            rows = [i for i, o in enumerate(self._objv_ids) if o in keep]
+            if len(rows) != len(self._objv_ids):
+                for i, o in enumerate(self._objv_ids):
+                    if o not in keep:
+                        self._orphan_objv[o] = self._objv[i].clone()
+                idx = torch.tensor(rows, dtype=torch.long, device=self._objv.device)
+                self._objv = self._objv.index_select(0, idx)
+                self._objv_ids = [self._objv_ids[i] for i in rows]
+        self._last_readout = (None, None)
+        if not self.buckets:
+            self.engaged = False
+
+    def clear_non_permanent_memory(self):
+        for b in self.buckets.values():
+            b.n_work = 0
+            b.ring = 0
+            b.n_long = 0
+
+    # reference attribute names used by callers / tests
+    @property
+    def sensory(self):
+        return {o: self._sens_f32[i].permute(2, 0, 1).unsqueeze(0) for i, o in enumerate(self._ids)}
+
+    @property
+    def obj_v(self):
+        return {o: self._objv[i].unsqueeze(0) for i, o in enumerate(self._objv_ids)}

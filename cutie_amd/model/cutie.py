@@ -1,0 +1,430 @@
+"""``CUTIE`` -- drop-in mirror of the reference ``cutie.model.cutie.CUTIE`` (cutie/model/cutie.py:18-260)
+whose compute runs as HIP launch plans on MI355X.
+
+Same constructor, same six public methods, same ``state_dict`` keys (527 tensors) so reference checkpoints
+load unchanged through ``load_weights``.  Differences a caller can observe:
+  * tensors returned by the facade methods keep the reference's *logical* shapes (``[1,C,H,W]``,
+    ``[1,K,C,h,w]``) but are bf16 views of NHWC device buffers (like autocast would return half tensors);
+    keys/shrinkage/selection, logits, probabilities, summaries and the sensory state stay fp32.
+  * the sensory state passed to ``segment`` / ``encode_mask`` is updated in place (and returned).
+  * inference only: ``read_memory`` / ``compute_aux`` / ``forward`` (training paths) raise.
+There is no CPU fallback: every method needs libcutie_hip.so and a HIP device.
+"""
+import logging
+from typing import Dict, Iterable, List
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..ops import OpList
+from . import plans
+from .param_spec import build_spec
+from .weights import fold_bn, pack_conv, pack_linear, linear_as_conv
+
+log = logging.getLogger()
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+# ---- logical <-> physical layout helpers -----------------------------------------------------------
+def nhwc_of(t, C=None):
+    """logical [B,C,H,W] -> physical contiguous bf16 [B,H,W,C] (no copy when it already is our layout)."""
+    p = t.permute(0, 2, 3, 1)
+    if p.dtype != BF16 or not p.is_contiguous():
+        p = p.to(BF16).contiguous()
+    return p
+
+
+def group_nhwc_of(t, dtype=BF16):
+    """logical [1,K,C,h,w] -> physical [K,h,w,C]."""
+    assert t.shape[0] == 1, 'batch size 1 only (flip_aug is not supported yet)'
+    p = t[0].permute(0, 2, 3, 1)
+    if p.dtype != dtype or not p.is_contiguous():
+        p = p.to(dtype).contiguous()
+    return p
+
+
+def logical(p):
+    """physical [B,H,W,C] -> logical [B,C,H,W] view."""
+    return p.permute(0, 3, 1, 2)
+
+
+def group_logical(p):
+    """physical [K,h,w,C] -> logical [1,K,C,h,w] view."""
+    return p.permute(0, 3, 1, 2).unsqueeze(0)
+
+
+class Engine:
+    """Device-resident packed weights + plan cache for one CUTIE module state."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], m, device):
+        self.m, self.device = m, device
+        self.w = {}
+        self._plans = {}
+        self._pe = {}
+        self._rep = {}
+        sd = {k: v.detach().float().cpu() for k, v in sd.items() if v.is_floating_point()}
+        self.sd = sd
+        W, dev = self.w, device
+        CS, CV = m['sensory_dim'], m['value_dim']
+        up = m['mask_decoder']['up_dims']
+
+        def conv(name, segs=None, bn=None):
+            w = sd[name + '.weight']
+            b = sd.get(name + '.bias')
+            if bn is not None:
+                w, b = fold_bn(w, sd, bn)
+            W[name] = pack_conv(w, b, dev, segs)
+
+        # ResNet trunks with eval-mode BN folded (resnet.py)
+        for prefix, in_ch in (('pixel_encoder', 3), ('mask_encoder', 5)):
+            conv(prefix + '.conv1', segs=[(in_ch, 8)], bn=prefix + '.bn1')
+            for k in sd:
+                if k.startswith(prefix + '.') and k.endswith('.weight') and sd[k].dim() == 4 and k != prefix + '.conv1.weight':
+                    name = k[:-len('.weight')]
+                    if '.fuser.' in name or '.sensory_update.' in name:
+                        continue
+                    if name.endswith('.downsample.0'):
+                        conv(name, bn=name[:-1] + '1')
+                    else:
+                        conv(name, bn=name.replace('.conv', '.bn'))
+        for name in ['pix_feat_proj', 'key_proj.pix_feat_proj', 'key_proj.key_proj', 'key_proj.d_proj', 'key_proj.e_proj',
+                     'mask_decoder.sensory_update.g16_conv', 'mask_decoder.sensory_update.g8_conv',
+                     'mask_decoder.decoder_feat_proc.transforms.0', 'mask_decoder.decoder_feat_proc.transforms.1',
+                     'mask_decoder.up_16_8.out_conv.downsample', 'mask_decoder.up_16_8.out_conv.conv1',
+                     'mask_decoder.up_16_8.out_conv.conv2', 'mask_decoder.up_8_4.out_conv.conv1',
+                     'mask_decoder.up_8_4.out_conv.conv2', 'mask_decoder.pred',
+                     'object_transformer.pixel_init_proj', 'object_transformer.pixel_emb_proj']:
+            conv(name)
+        conv('mask_decoder.sensory_update.g4_conv', segs=[(up[2], up[2]), (1, 8)])
+        conv('mask_decoder.sensory_update.transform', segs=[(CS, CS), (CS, CS)])
+        conv('mask_encoder.sensory_update.transform', segs=[(CV, CV), (CS, CS)])
+        conv('pixel_fuser.sensory_compress', segs=[(CS, CS), (2, 8)])
+        ca_blocks = []
+        for fz in ('mask_encoder.fuser', 'pixel_fuser.fuser'):
+            conv(fz + '.distributor.x_transform')
+            conv(fz + '.distributor.g_transform')
+            ca_blocks += [fz + '.block1', fz + '.block2']
+        t = 'object_transformer'
+        ot = m['object_transformer']
+        C = m['embed_dim']
+        for b in range(ot['num_blocks']):
+            q = f'{t}.blocks.{b}'
+            ca_blocks.append(q + '.pixel_ffn.conv')
+            rp, sa, rq = q + '.read_from_pixel.cross_attn', q + '.self_attn.self_attn', q + '.read_from_query.cross_attn'
+            Wp, bp = sd[rp + '.in_proj_weight'], sd[rp + '.in_proj_bias']
+            Ws, bs = sd[sa + '.in_proj_weight'], sd[sa + '.in_proj_bias']
+            Wq, bq = sd[rq + '.in_proj_weight'], sd[rq + '.in_proj_bias']
+            # pixel-side merged projection [k (read_from_pixel) | v (read_from_pixel) | q (read_from_query)]
+            wm = torch.cat([Wp[C:2 * C], Wp[2 * C:], Wq[:C]], 0)
+            bm = torch.cat([bp[C:2 * C], bp[2 * C:], bq[:C]], 0)
+            W[q + '.pixel_proj'] = linear_as_conv(wm, bm, dev)
+            # the same projections applied to the (block-invariant) pixel positional term; v gets none
+            wpe = torch.cat([Wp[C:2 * C], torch.zeros(C, C), Wq[:C]], 0)
+            W[q + '.pe_proj'] = linear_as_conv(wpe, None, dev)
+            W[q + '.read_from_pixel.q'] = pack_linear(Wp[:C], bp[:C], dev)
+            W[q + '.read_from_pixel.out'] = pack_linear(sd[rp + '.out_proj.weight'], sd[rp + '.out_proj.bias'], dev)
+            W[q + '.self_attn.qk'] = pack_linear(Ws[:2 * C], bs[:2 * C], dev)
+            W[q + '.self_attn.v'] = pack_linear(Ws[2 * C:], bs[2 * C:], dev)
+            W[q + '.self_attn.out'] = pack_linear(sd[sa + '.out_proj.weight'], sd[sa + '.out_proj.bias'], dev)
+            W[q + '.read_from_query.k'] = pack_linear(Wq[C:2 * C], bq[C:2 * C], dev)
+            W[q + '.read_from_query.v'] = pack_linear(Wq[2 * C:], bq[2 * C:], dev)
+            W[q + '.read_from_query.out'] = linear_as_conv(sd[rq + '.out_proj.weight'], sd[rq + '.out_proj.bias'], dev)
+            for ln in ('.read_from_pixel.norm', '.self_attn.norm', '.ffn.norm'):
+                W[q + ln + '.weight'] = sd[q + ln + '.weight'].to(dev)
+                W[q + ln + '.bias'] = sd[q + ln + '.bias'].to(dev)
+            W[q + '.ffn.linear1'] = pack_linear(sd[q + '.ffn.linear1.weight'], sd[q + '.ffn.linear1.bias'], dev)
+            W[q + '.ffn.linear2'] = pack_linear(sd[q + '.ffn.linear2.weight'], sd[q + '.ffn.linear2.bias'], dev)
+        for b in range(ot['num_blocks'] + 1):
+            conv(f'{t}.mask_pred.{b}.1')
+        for name in ca_blocks:
+            conv(name + '.conv1')
+            conv(name + '.conv2')
+            W[name + '.conv.weight'] = sd[name + '.conv.weight'].reshape(-1).to(dev).contiguous()
+        W[t + '.summary_to_query_init'] = pack_linear(sd[t + '.summary_to_query_init.weight'], sd[t + '.summary_to_query_init.bias'], dev)
+        W[t + '.summary_to_query_emb'] = pack_linear(sd[t + '.summary_to_query_emb.weight'], sd[t + '.summary_to_query_emb.bias'], dev)
+        u = 'object_summarizer'
+        for name in ('.input_proj', '.feature_pred.0', '.feature_pred.2', '.weights_pred.0', '.weights_pred.2'):
+            W[u + name] = linear_as_conv(sd[u + name + '.weight'], sd[u + name + '.bias'], dev)
+
+    def pe(self, h, w):
+        """bf16 [h*w, C] positional encoding (both PositionalEncoding instances use the same formula)."""
+        if (h, w) not in self._pe:
+            e = plans.positional_encoding(h, w, self.m['embed_dim'], self.m['pixel_pe_scale'], self.m['pixel_pe_temperature'])
+            self._pe[(h, w)] = e.reshape(h * w, -1).to(BF16).to(self.device).contiguous()
+        return self._pe[(h, w)]
+
+    def rep_embedding(self, which, K):
+        key = (which, K)
+        if key not in self._rep:
+            e = self.sd[f'object_transformer.{which}.weight']
+            self._rep[key] = e.repeat(K, 1).to(self.device).contiguous()
+        return self._rep[key]
+
+    def plan(self, key, builder, *args):
+        p = self._plans.get(key)
+        if p is None:
+            p = builder(self, *args)
+            p.ol.finalize()
+            self._plans[key] = p
+        return p
+
+
+class _Container(nn.Module):
+    pass
+
+
+class CUTIE(nn.Module):
+    def __init__(self, cfg, *, single_object=False):
+        super().__init__()
+        if single_object:
+            raise NotImplementedError('single_object=True is a training-time variant; not on the inference path')
+        self.cfg = cfg
+        m = cfg.model if hasattr(cfg, 'model') else cfg['model']
+        self.model_cfg = m
+        self.ms_dims = m['pixel_encoder']['ms_dims']
+        self.key_dim, self.value_dim = m['key_dim'], m['value_dim']
+        self.sensory_dim, self.pixel_dim, self.embed_dim = m['sensory_dim'], m['pixel_dim'], m['embed_dim']
+        self.single_object = single_object
+        self.object_transformer_enabled = m['object_transformer']['num_blocks'] > 0
+        if not self.object_transformer_enabled:
+            raise NotImplementedError('num_blocks == 0 is not supported')
+        self._spec = build_spec(m)
+        g = torch.Generator().manual_seed(0)
+        for name, (shape, role) in self._spec.items():
+            self._register(name, shape, role, g)
+        self.register_buffer('pixel_mean', torch.tensor(m['pixel_mean'], dtype=F32).view(-1, 1, 1), False)
+        self.register_buffer('pixel_std', torch.tensor(m['pixel_std'], dtype=F32).view(-1, 1, 1), False)
+        self._eng = None
+        self._key_cache = None
+        self.eval()
+
+    # ---- parameter tree with the reference's names --------------------------------------------------
+    def _register(self, name, shape, role, g):
+        parts = name.split('.')
+        mod = self
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, _Container())
+            mod = getattr(mod, p)
+        leaf = parts[-1]
+        if role in ('w', 'emb', 'eca'):
+            fan_in = max(1, int(torch.tensor(shape[1:]).prod())) if len(shape) > 1 else 1
+            t = torch.randn(shape, generator=g) * (1.0 / fan_in ** 0.5)
+            mod.register_parameter(leaf, nn.Parameter(t))
+        elif role in ('b', 'bn_b', 'ln_b'):
+            mod.register_parameter(leaf, nn.Parameter(torch.zeros(shape)))
+        elif role in ('bn_w', 'ln_w'):
+            mod.register_parameter(leaf, nn.Parameter(torch.ones(shape)))
+        elif role == 'bn_mean':
+            mod.register_buffer(leaf, torch.zeros(shape))
+        elif role == 'bn_var':
+            mod.register_buffer(leaf, torch.ones(shape))
+        elif role == 'bn_nbt':
+            mod.register_buffer(leaf, torch.tensor(0, dtype=torch.long))
+        elif role == 'buf':
+            dim = shape[0] * 2
+            inv = 1.0 / (self.model_cfg['pixel_pe_temperature'] ** (torch.arange(0, dim, 2).float() / dim))
+            mod.register_buffer(leaf, inv)
+        else:
+            raise KeyError(role)
+
+    def train(self, mode=True):
+        # inference-only module; BN statistics are always frozen in the reference too (big_modules.py:56-61)
+        return super().train(False)
+
+    def _apply(self, fn, *a, **k):
+        self._eng = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._eng = None
+        return super().load_state_dict(*a, **k)
+
+    def load_weights(self, src_dict, init_as_zero_if_needed=False) -> None:
+        """cutie.py:212-256: accepts single-object checkpoints (4-channel mask_encoder.conv1 etc.)."""
+        src_dict = dict(src_dict)
+        k = 'mask_encoder.conv1.weight'
+        if k in src_dict and src_dict[k].shape[1] == 4:
+            log.info(f'Converting {k} from single object to multiple objects.')
+            pads = torch.zeros((64, 1, 7, 7), device=src_dict[k].device)
+            if not init_as_zero_if_needed:
+                nn.init.orthogonal_(pads)
+            src_dict[k] = torch.cat([src_dict[k], pads], 1)
+        k = 'pixel_fuser.sensory_compress.weight'
+        if k in src_dict and src_dict[k].shape[1] == self.sensory_dim + 1:
+            log.info(f'Converting {k} from single object to multiple objects.')
+            pads = torch.zeros((self.value_dim, 1, 1, 1), device=src_dict[k].device)
+            if not init_as_zero_if_needed:
+                nn.init.orthogonal_(pads)
+            src_dict[k] = torch.cat([src_dict[k], pads], 1)
+        own = self.state_dict()
+        for k in src_dict:
+            if k not in own:
+                log.info(f'Key {k} found in src_dict but not in self.state_dict()!!!')
+        for k in own:
+            if k not in src_dict:
+                log.info(f'Key {k} found in self.state_dict() but not in src_dict!!!')
+        self.load_state_dict(src_dict, strict=False)
+
+    @property
+    def device(self) -> torch.device:
+        return self.pixel_mean.device
+
+    def engine(self) -> Engine:
+        if self._eng is None:
+            _lib.get_executor()           # fails loudly when the HIP library / device is missing
+            self._eng = Engine(self.state_dict(), self.model_cfg, self.device)
+        return self._eng
+
+    # ---- facade methods ---------------------------------------------------------------------------------
+    def _encode(self, image, h0, w0, H, W, pad_left, pad_top):
+        """image f32 [3,h0,w0] (un-padded) -> dict of physical outputs (fused encode_image + transform_key)."""
+        eng = self.engine()
+        dev = self.device
+        m = self.model_cfg
+        P = eng.plan(('enc', h0, w0, H, W, pad_left, pad_top), plans.build_encode, h0, w0, H, W, pad_left, pad_top)
+        h, w = H // 16, W // 16
+        hw = h * w
+        HWp = -(-hw // 64) * 64
+        ms = self.ms_dims
+        e = lambda shape, dt=BF16: torch.empty(shape, dtype=dt, device=dev)
+        out = dict(f16=e((1, h, w, ms[0])), f8=e((1, 2 * h, 2 * w, ms[1])), f4=e((1, 4 * h, 4 * w, ms[2])),
+                   pix_feat=e((1, h, w, m['pixel_dim'])), key=e((hw, m['key_dim']), F32), shr=e((hw,), F32),
+                   sel=e((hw, m['key_dim']), F32), Bhi=torch.zeros((HWp, 128), dtype=BF16, device=dev),
+                   Blo=torch.zeros((HWp, 128), dtype=BF16, device=dev), cq=torch.zeros((HWp,), dtype=F32, device=dev))
+        image = image.to(F32).contiguous()
+        P.run(image=image, **out)
+        out['h'], out['w'] = h, w
+        return out
+
+    def encode_image(self, image: torch.Tensor) -> (Iterable[torch.Tensor], torch.Tensor):
+        """image [1,3,H,W] in [0,1] (already padded to /16) -> ((f16, f8, f4), pix_feat); cutie.py:61-64"""
+        assert image.dim() == 4 and image.shape[0] == 1, 'batch size 1 only'
+        H, W = image.shape[-2:]
+        return self._encode_image_raw(image[0], H, W, H, W, 0, 0)
+
+    def _encode_image_raw(self, image, h0, w0, H, W, pad_left, pad_top):
+        """Same as encode_image for an un-padded frame [3,h0,w0]: the zero pad of
+        InferenceCore.step (tensor_utils.pad_divide_by) is fused into the first kernel."""
+        o = self._encode(image, h0, w0, H, W, pad_left, pad_top)
+        ms = (logical(o['f16']), logical(o['f8']), logical(o['f4']))
+        self._key_cache = (o['f16'], o)
+        return ms, logical(o['pix_feat'])
+
+    def _key_views(self, o):
+        h, w = o['h'], o['w']
+        key = o['key'].view(1, h, w, -1).permute(0, 3, 1, 2)
+        shr = o['shr'].view(1, 1, h, w)
+        sel = o['sel'].view(1, h, w, -1).permute(0, 3, 1, 2)
+        return key, shr, sel
+
+    def transform_key(self, final_pix_feat: torch.Tensor, *, need_sk: bool = True, need_ek: bool = True):
+        """cutie.py:92-98.  Returns fp32 (key, shrinkage, selection) in logical [1,C,h,w] shapes."""
+        f16 = nhwc_of(final_pix_feat)
+        if self._key_cache is not None and self._key_cache[0].data_ptr() == f16.data_ptr():
+            o = self._key_cache[1]            # computed by the fused encode plan
+        else:
+            eng = self.engine()
+            h, w = f16.shape[1:3]
+            hw, HWp = h * w, -(-h * w // 64) * 64
+            dev = self.device
+            o = dict(key=torch.empty((hw, self.key_dim), dtype=F32, device=dev), shr=torch.empty((hw,), dtype=F32, device=dev),
+                     sel=torch.empty((hw, self.key_dim), dtype=F32, device=dev),
+                     Bhi=torch.zeros((HWp, 128), dtype=BF16, device=dev), Blo=torch.zeros((HWp, 128), dtype=BF16, device=dev),
+                     cq=torch.zeros((HWp,), dtype=F32, device=dev), h=h, w=w)
+            P = eng.plan(('key', h, w), plans.build_transform_key, h, w)
+            P.run(f16=f16, **{k: v for k, v in o.items() if k not in ('h', 'w')})
+        key, shr, sel = self._key_views(o)
+        key._cutie_query = o                  # similarity operands ride along for MemoryManager.read
+        return key, (shr if need_sk else None), (sel if need_ek else None)
+
+    @staticmethod
+    def _sensory_pair(sensory):
+        """sensory logical [1,K,CS,h,w] fp32 -> (phys f32 [K,h,w,CS], bf16 shadow)."""
+        phys = group_nhwc_of(sensory, F32)
+        shadow = getattr(sensory, '_cutie_bf16', None)
+        if shadow is None or shadow.shape != phys.shape:
+            shadow = phys.to(BF16)
+        return phys, shadow
+
+    def encode_mask(self, image, ms_features, sensory, masks, *, deep_update=True, chunk_size=-1, need_weights=False,
+                    _raw=None):
+        """cutie.py:66-90.  image [1,3,H,W]; ms_features = stride-16 pix_feat; sensory [1,K,CS,h,w] fp32 (updated in
+        place when deep_update); masks [1,K,H,W] -> (value, sensory, summaries [1,K,Q,C+1], None)."""
+        eng = self.engine()
+        dev = self.device
+        K = masks.shape[1]
+        H, W = masks.shape[-2:]
+        h, w = H // 16, W // 16
+        if _raw is not None:
+            img, h0, w0, pl, pt = _raw
+        else:
+            img, h0, w0, pl, pt = image[0], H, W, 0, 0
+        pix = nhwc_of(ms_features)
+        sf, sb = self._sensory_pair(sensory)
+        mk = masks[0].to(F32).contiguous()
+        P = eng.plan(('emask', K, h0, w0, H, W, pl, pt, bool(deep_update)), plans.build_encode_mask, K, h0, w0, H, W, pl, pt,
+                     bool(deep_update))
+        value = torch.empty((K, h, w, self.value_dim), dtype=BF16, device=dev)
+        summ = torch.empty((K, self.model_cfg['object_summarizer']['num_summaries'], self.embed_dim + 1), dtype=F32, device=dev)
+        P.run(image=img.to(F32).contiguous(), masks=mk, pix_feat=pix, sensory_f32=sf, sensory_bf16=sb, value=value, summ=summ)
+        new_sens = group_logical(sf)
+        new_sens._cutie_bf16 = sb
+        return group_logical(value), new_sens, summ.unsqueeze(0), None
+
+    def pixel_fusion(self, pix_feat, pixel, sensory, last_mask, *, chunk_size=-1):
+        """cutie.py:142-157.  pixel = memory readout [1,K,CV,h,w]; last_mask [1,K,H,W] -> fused [1,K,CE,h,w]"""
+        eng = self.engine()
+        pf = nhwc_of(pix_feat)
+        px = group_nhwc_of(pixel)
+        K, h, w = px.shape[:3]
+        _, sb = self._sensory_pair(sensory)
+        lm = last_mask[0].to(F32).contiguous()
+        P = eng.plan(('fuse', K, h, w), plans.build_pixel_fusion, K, h, w)
+        fused = torch.empty((K, h, w, self.embed_dim), dtype=BF16, device=self.device)
+        P.run(pix_feat=pf, pixel=px, sensory_bf16=sb, last_mask=lm, fused=fused)
+        return group_logical(fused)
+
+    def readout_query(self, pixel_readout, obj_memory, *, selector=None, need_weights=False):
+        """cutie.py:159-170 -> QueryTransformer.  obj_memory [1,K,T,Q,C+1] (T summed) -> (pixel [1,K,C,h,w], aux)"""
+        assert selector is None, 'selector is a training-time argument'
+        eng = self.engine()
+        px = group_nhwc_of(pixel_readout)
+        K, h, w = px.shape[:3]
+        om = obj_memory[0].to(F32)
+        om = om.sum(dim=1) if om.shape[1] != 1 else om[:, 0]
+        om = om.contiguous()
+        P = eng.plan(('rq', K, h, w), plans.build_readout_query, K, h, w)
+        out = torch.empty((K, h, w, self.embed_dim), dtype=BF16, device=self.device)
+        P.run(pixel=px, obj_mem=om, out=out)
+        aux = {'logits': [P.bufs['aux_logits'][i].view(1, K, h, w) for i in range(P.bufs['aux_logits'].shape[0])],
+               'q_weights': None, 'p_weights': None}
+        return group_logical(out), aux
+
+    def segment(self, ms_image_feat: List[torch.Tensor], memory_readout, sensory, *, selector=None, chunk_size=-1,
+                update_sensory=True, _need_logits=True):
+        """cutie.py:172-203.  -> (sensory [1,K,CS,h,w], logits [1,K+1,H,W], prob [1,K+1,H,W]) fp32"""
+        assert selector is None, 'selector is a training-time argument'
+        eng = self.engine()
+        dev = self.device
+        p16 = group_nhwc_of(memory_readout)
+        K, h, w = p16.shape[:3]
+        f8, f4 = nhwc_of(ms_image_feat[1]), nhwc_of(ms_image_feat[2])
+        sf, sb = self._sensory_pair(sensory)
+        P = eng.plan(('seg', K, h, w, bool(update_sensory)), plans.build_segment, K, h, w, bool(update_sensory))
+        prob = torch.empty((K + 1, 16 * h, 16 * w), dtype=F32, device=dev)
+        lup = torch.empty((K + 1, 16 * h, 16 * w), dtype=F32, device=dev) if _need_logits else None
+        P.run(f8=f8, f4=f4, p16=p16, sensory_f32=sf, sensory_bf16=sb, prob=prob, logits_up=lup)
+        new_sens = group_logical(sf)
+        new_sens._cutie_bf16 = sb
+        return new_sens, (lup.unsqueeze(0) if lup is not None else None), prob.unsqueeze(0)
+
+    def read_memory(self, *a, **k):
+        raise NotImplementedError('read_memory is the training-time path (cutie.py:102-140); inference reads through MemoryManager')
+
+    def compute_aux(self, *a, **k):
+        raise NotImplementedError('aux heads are training-only (cutie.py:205-207)')
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError

@@ -1,0 +1,349 @@
+"""Launch-plan builders for the CUTIE stages (one plan = one ``cutie_exec`` call).
+
+Each builder lays out the kernels of one facade method of the reference ``CUTIE`` (cutie/model/cutie.py)
+over static scratch buffers; per-call inputs/outputs are named dynamic pointer slots (``ops.Dyn``).
+Activations are NHWC bf16 ([B,H,W,C], B = objects), fp32 where the reference forces fp32
+(logits, GRU state, summaries, keys).
+"""
+import math
+import torch
+
+from .. import ops as O
+from ..ops import Dyn
+from .param_spec import RESNET_LAYERS
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class Act:
+    """NHWC activation handle: tensor (or Dyn slot), batch, height, width, channels, channel stride."""
+    __slots__ = ('t', 'B', 'H', 'W', 'C', 'ld')
+
+    def __init__(self, t, B, H, W, C, ld=None):
+        self.t, self.B, self.H, self.W, self.C, self.ld = t, B, H, W, C, (C if ld is None else ld)
+
+
+def positional_encoding(h, w, dim_total, scale, temperature):
+    """[h,w,dim_total] sinusoidal PE (x half, then y half): positional_encoding.py:20-97 of the reference
+    (normalize=True, eps=1e-6).  Constant per resolution -> computed once on the host at plan build."""
+    dim = int(math.ceil(dim_total / 4) * 2)
+    inv_freq = 1.0 / (temperature ** (torch.arange(0, dim, 2).float() / dim))
+    py = torch.arange(h, dtype=torch.float32)
+    px = torch.arange(w, dtype=torch.float32)
+    py = py / (py[-1] + 1e-6) * scale
+    px = px / (px[-1] + 1e-6) * scale
+    sy, sx = py[:, None] * inv_freq[None], px[:, None] * inv_freq[None]
+    ey = torch.stack((sy.sin(), sy.cos()), -1).flatten(-2)
+    ex = torch.stack((sx.sin(), sx.cos()), -1).flatten(-2)
+    emb = torch.zeros(h, w, dim * 2)
+    emb[:, :, :dim] = ex[None]
+    emb[:, :, dim:] = ey[:, None]
+    return emb
+
+
+class Plan:
+    def __init__(self, eng):
+        self.eng = eng
+        self.dev = eng.device
+        self.ol = O.OpList()
+        self.bufs = {}
+        self.meta = {}
+
+    def buf(self, name, shape, dtype=BF16):
+        assert name not in self.bufs, name
+        t = torch.zeros(tuple(int(s) for s in shape), dtype=dtype, device=self.dev)
+        self.bufs[name] = t
+        return t
+
+    def run(self, **dyn):
+        self.ol.run(**dyn)
+
+    # ---- conv helper ------------------------------------------------------------------
+    def conv(self, wname, x, *, name=None, out=None, stride=1, pad=None, x2=None, res=None, res_bcast=False,
+             relu_in=False, act=O.ACT_NONE, out_f32=False, ldy=None):
+        w = self.eng.w[wname]
+        if pad is None:
+            pad = (w.kh - 1) // 2
+        OH = (x.H + 2 * pad - w.kh) // stride + 1
+        OW = (x.W + 2 * pad - w.kw) // stride + 1
+        if out is None:
+            t = self.buf(name or wname, (x.B, OH, OW, w.cout), F32 if out_f32 else BF16)
+            out = Act(t, x.B, OH, OW, w.cout, w.cout if ldy is None else ldy)
+        else:
+            assert out.B == x.B and out.H == OH and out.W == OW and out.C == w.cout, (wname, out.B, out.H, out.W, out.C, OH, OW, w.cout)
+        if res is not None:
+            assert res.C == w.cout and res.H == OH and res.W == OW
+        self.ol.conv(x.t, w, out.t, B=x.B, H=x.H, W=x.W, C1=x.C, ldx1=x.ld, OH=OH, OW=OW, ldy=out.ld, stride=stride,
+                     pad=pad, x2=None if x2 is None else x2.t, C2=0 if x2 is None else x2.C,
+                     ldx2=0 if x2 is None else x2.ld, res=None if res is None else res.t,
+                     ldr=0 if res is None else res.ld, res_bcast=res_bcast, relu_in=relu_in, act=act, out_f32=out_f32)
+        return out
+
+    # ---- shared blocks ------------------------------------------------------------------
+    def ca_block(self, prefix, x, name, out=None):
+        """CAResBlock (channel_attn.py:7-39): conv3x3(relu) x2, ECA channel attention, residual."""
+        t1 = self.conv(prefix + '.conv1', x, name=name + '.t1', relu_in=True, act=O.ACT_RELU)
+        t2 = self.conv(prefix + '.conv2', t1, name=name + '.t2')
+        gap = self.buf(name + '.gap', (x.B, x.C), F32)
+        HW = x.H * x.W
+        self.ol.gap(t2.t, gap, B=x.B, HW=HW, C=x.C)
+        if out is None:
+            out = Act(self.buf(name + '.out', (x.B, x.H, x.W, x.C)), x.B, x.H, x.W, x.C)
+        self.ol.eca_apply(t2.t, gap, self.eng.w[prefix + '.conv.weight'], x.t, out.t, B=x.B, HW=HW, C=x.C)
+        return out
+
+    def fusion_block(self, prefix, x, g, name, out=None):
+        """GroupFeatureFusionBlock (group_modules.py:102-127)."""
+        xt = self.conv(prefix + '.distributor.x_transform', x, name=name + '.xt')
+        g0 = self.conv(prefix + '.distributor.g_transform', g, name=name + '.g0', res=xt, res_bcast=True)
+        g1 = self.ca_block(prefix + '.block1', g0, name + '.b1')
+        return self.ca_block(prefix + '.block2', g1, name + '.b2', out=out)
+
+    def resnet(self, prefix, x, taps=None):
+        """ResNet trunk after the stem/pool (resnet.py:51-124); taps: layer attr -> output Act override."""
+        bottleneck, layers = RESNET_LAYERS[prefix]
+        feats = {}
+        for (lname, planes, nb, lstride) in layers:
+            for bi in range(nb):
+                p = f'{prefix}.{lname}.{bi}'
+                s = lstride if bi == 0 else 1
+                last = bi == nb - 1
+                out = taps.get(lname) if (taps and last) else None
+                if bottleneck:
+                    t1 = self.conv(p + '.conv1', x, act=O.ACT_RELU)
+                    t2 = self.conv(p + '.conv2', t1, stride=s, act=O.ACT_RELU)
+                    r = self.conv(p + '.downsample.0', x, stride=s) if (p + '.downsample.0') in self.eng.w else x
+                    x = self.conv(p + '.conv3', t2, res=r, act=O.ACT_RELU, out=out)
+                else:
+                    t1 = self.conv(p + '.conv1', x, stride=s, act=O.ACT_RELU)
+                    r = self.conv(p + '.downsample.0', x, stride=s) if (p + '.downsample.0') in self.eng.w else x
+                    x = self.conv(p + '.conv2', t1, res=r, act=O.ACT_RELU, out=out)
+            feats[lname] = x
+        return x, feats
+
+
+# ---------------------------------------------------------------------------------------------------
+def build_encode(eng, h0, w0, H, W, pad_left, pad_top):
+    """CUTIE.encode_image + transform_key (cutie.py:61-64,92-98; big_modules.py:45-54,81-87) + query-side
+    similarity operands.  dyn in: image f32 [3,h0,w0].  dyn out: f16,f8,f4,pix_feat (bf16 NHWC), key,shr,sel
+    (f32 [hw,*]), Bhi,Blo (bf16 [HWp,128]), cq (f32 [HWp])."""
+    P = Plan(eng)
+    m = eng.m
+    img8 = P.buf('img8', (1, H, W, 8))
+    P.ol.img_prep(Dyn('image'), None, img8, h0=h0, w0=w0, H=H, W=W, pad_left=pad_left, pad_top=pad_top, K=1,
+                  mean=m['pixel_mean'], std=m['pixel_std'])
+    x = P.conv('pixel_encoder.conv1', Act(img8, 1, H, W, 8), stride=2, pad=3, act=O.ACT_RELU)
+    pool = P.buf('pool', (1, x.H // 2, x.W // 2, 64))
+    P.ol.maxpool(x.t, pool, B=1, H=x.H, W=x.W, C=64)
+    x = Act(pool, 1, x.H // 2, x.W // 2, 64)
+    h4, w4, h8, w8, h, w = H // 4, W // 4, H // 8, W // 8, H // 16, W // 16
+    ms = m['pixel_encoder']['ms_dims']
+    taps = {'res2': Act(Dyn('f4'), 1, h4, w4, ms[2]), 'layer2': Act(Dyn('f8'), 1, h8, w8, ms[1]),
+            'layer3': Act(Dyn('f16'), 1, h, w, ms[0])}
+    f16, _ = P.resnet('pixel_encoder', x, taps)
+    P.conv('pix_feat_proj', f16, out=Act(Dyn('pix_feat'), 1, h, w, m['pixel_dim']))
+    build_key_ops(P, f16, h, w)
+    P.meta.update(h=h, w=w)
+    return P
+
+
+def build_key_ops(P, f16, h, w):
+    m = P.eng.m
+    CK = m['key_dim']
+    kx = P.conv('key_proj.pix_feat_proj', f16, name='keyx')
+    P.conv('key_proj.key_proj', kx, out=Act(Dyn('key'), 1, h, w, CK), out_f32=True)
+    P.conv('key_proj.d_proj', kx, out=Act(Dyn('shr'), 1, h, w, 1), out_f32=True, act=O.ACT_SQ1)
+    P.conv('key_proj.e_proj', kx, out=Act(Dyn('sel'), 1, h, w, CK), out_f32=True, act=O.ACT_SIGMOID)
+    P.ol.key_prep(Dyn('key'), Dyn('sel'), Dyn('Bhi'), Dyn('Blo'), Dyn('cq'), n=h * w, query=True)
+
+
+def build_transform_key(eng, h, w):
+    """Stand-alone CUTIE.transform_key for callers that bring their own f16 (dyn in: f16)."""
+    P = Plan(eng)
+    build_key_ops(P, Act(Dyn('f16'), 1, h, w, eng.m['pixel_encoder']['ms_dims'][0]), h, w)
+    return P
+
+
+def build_pixel_fusion(eng, K, h, w):
+    """CUTIE.pixel_fusion (cutie.py:142-157; big_modules.py:207-235).
+    dyn in: pix_feat, pixel (readout) bf16 [K,h,w,CV], sensory_bf16 [K,h,w,CS], last_mask f32 [K,16h,16w].
+    dyn out: fused bf16 [K,h,w,CE]."""
+    P = Plan(eng)
+    m = eng.m
+    pair = P.buf('pair', (K, h, w, 8))
+    m16 = P.buf('m16', (K, h, w), F32)
+    P.ol.mask_down(Dyn('last_mask'), pair, m16, K=K, H=16 * h, W=16 * w)
+    pixel = Act(Dyn('pixel'), K, h, w, m['value_dim'])
+    p16 = P.conv('pixel_fuser.sensory_compress', Act(Dyn('sensory_bf16'), K, h, w, m['sensory_dim']),
+                 x2=Act(pair, K, h, w, 8), res=pixel, name='p16')
+    P.fusion_block('pixel_fuser.fuser', Act(Dyn('pix_feat'), 1, h, w, m['pixel_dim']), p16, 'fuse',
+                   out=Act(Dyn('fused'), K, h, w, m['embed_dim']))
+    return P
+
+
+def build_readout_query(eng, K, h, w):
+    """CUTIE.readout_query -> QueryTransformer.forward (object_transformer.py:114-177).
+    dyn in: pixel bf16 [K,h,w,C], obj_mem f32 [K,Q,C+1].  dyn out: out bf16 [K,h,w,C].
+    Aux logits of every block are kept in bufs['aux_logits'] (f32 [blocks+1,K,hw]) for tests."""
+    P = Plan(eng)
+    m, ol, W = eng.m, P.ol, eng.w
+    ot = m['object_transformer']
+    C, Q, heads, nb = m['embed_dim'], ot['num_queries'], ot['num_heads'], ot['num_blocks']
+    HW, M = h * w, K * Q
+    t = 'object_transformer'
+    f = lambda name, shape: P.buf(name, shape, F32)
+    vals = f('vals', (M, C))
+    ol.query_init(Dyn('obj_mem'), vals, rows=M, C=C)
+    query, query_emb = f('query', (M, C)), f('query_emb', (M, C))
+    ol.linear(vals, W[t + '.summary_to_query_init'], query, M=M, res=eng.rep_embedding('query_init', K))
+    ol.linear(vals, W[t + '.summary_to_query_emb'], query_emb, M=M, res=eng.rep_embedding('query_emb', K))
+    pix_in = Act(Dyn('pixel'), K, h, w, C)
+    pixel = P.conv(t + '.pixel_init_proj', pix_in, name='pixel_init')
+    pe = Act(eng.pe(h, w), 1, h, w, C)
+    pixel_pe = P.conv(t + '.pixel_emb_proj', pix_in, name='pixel_pe', res=pe, res_bcast=True)
+    aux = f('aux_logits', (nb + 1, K, HW))
+    fg = P.buf('fg', (K, HW), torch.uint8)
+    nfg = P.buf('nfg', (K,), torch.int32)
+    P.conv(t + '.mask_pred.0.1', pixel, relu_in=True, out_f32=True, out=Act(aux[0], K, h, w, 1))
+    ol.aux_mask(aux[0], fg, nfg, K=K, HW=HW)
+    x = query
+    for b in range(nb):
+        q = f'{t}.blocks.{b}'
+        n = f'b{b}.'
+        R = P.conv(q + '.pe_proj', pixel_pe, name=n + 'R')                       # [Wk.pe | 0 | Wq2.pe]
+        kvq = P.conv(q + '.pixel_proj', pixel, name=n + 'kvq', res=R)            # k | v | q2 of the pixels
+        # read_from_pixel (CrossAttention, transformer_layers.py:75-98): residual is the normed x
+        xn = f(n + 'xn', (M, C))
+        ol.layernorm(x, W[q + '.read_from_pixel.norm.weight'], W[q + '.read_from_pixel.norm.bias'], xn, M=M, C=C)
+        qp = f(n + 'qp', (M, C))
+        ol.linear(xn, W[q + '.read_from_pixel.q'], qp, M=M, x_add=query_emb, add_rows=M)
+        att = f(n + 'att', (M, C))
+        ol.attn_q2p(qp, kvq.t, fg, nfg, att, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C)
+        x1 = f(n + 'x1', (M, C))
+        ol.linear(att, W[q + '.read_from_pixel.out'], x1, M=M, res=xn)
+        # self attention (transformer_layers.py:28-41)
+        y = f(n + 'y', (M, C))
+        ol.layernorm(x1, W[q + '.self_attn.norm.weight'], W[q + '.self_attn.norm.bias'], y, M=M, C=C)
+        qk = f(n + 'qk', (M, 2 * C))
+        ol.linear(y, W[q + '.self_attn.qk'], qk, M=M, x_add=query_emb, add_rows=M)
+        v = f(n + 'v', (M, C))
+        ol.linear(y, W[q + '.self_attn.v'], v, M=M)
+        sa = f(n + 'sa', (M, C))
+        ol.attn_self(qk, v, sa, K=K, Q=Q, C=C, heads=heads)
+        x2 = f(n + 'x2', (M, C))
+        ol.linear(sa, W[q + '.self_attn.out'], x2, M=M, res=y)
+        # FFN (transformer_layers.py:113-118)
+        z = f(n + 'z', (M, C))
+        ol.layernorm(x2, W[q + '.ffn.norm.weight'], W[q + '.ffn.norm.bias'], z, M=M, C=C)
+        hid = f(n + 'hid', (M, ot['ff_dim']))
+        ol.linear(z, W[q + '.ffn.linear1'], hid, M=M, relu=True)
+        x3 = f(n + 'x3', (M, C))
+        ol.linear(hid, W[q + '.ffn.linear2'], x3, M=M, res=x2)
+        x = x3
+        # read_from_query (no norm, residual on the pixels)
+        kq, vq = f(n + 'kq', (M, C)), f(n + 'vq', (M, C))
+        ol.linear(x, W[q + '.read_from_query.k'], kq, M=M, x_add=query_emb, add_rows=M)
+        ol.linear(x, W[q + '.read_from_query.v'], vq, M=M)
+        pa = P.buf(n + 'pa', (K, h, w, C))
+        ol.attn_p2q(kvq.t.view(-1)[2 * C:], kq, vq, pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C)
+        pf = P.conv(q + '.read_from_query.out', Act(pa, K, h, w, C), name=n + 'pf', res=pixel)
+        # PixelFFN (transformer_layers.py:121-136)
+        last = b == nb - 1
+        pixel = P.ca_block(q + '.pixel_ffn.conv', pf, n + 'ffn', out=Act(Dyn('out'), K, h, w, C) if last else None)
+        P.conv(f'{t}.mask_pred.{b + 1}.1', pixel, relu_in=True, out_f32=True, out=Act(aux[b + 1], K, h, w, 1))
+        if not last:
+            ol.aux_mask(aux[b + 1], fg, nfg, K=K, HW=HW)
+    return P
+
+
+def build_segment(eng, K, h, w, update_sensory):
+    """CUTIE.segment -> MaskDecoder.forward + sigmoid/aggregate/x4/softmax (cutie.py:172-203;
+    big_modules.py:257-306; modules.py:8-68).
+    dyn in: f8, f4 (bf16), p16 (memory readout) bf16 [K,h,w,C], sensory_f32 / sensory_bf16 [K,h,w,CS] (in-place).
+    dyn out: prob f32 [K+1,16h,16w] (+ logits_up if bound)."""
+    P = Plan(eng)
+    m, ol = eng.m, P.ol
+    up = m['mask_decoder']['up_dims']
+    ms = m['pixel_encoder']['ms_dims']
+    CS = m['sensory_dim']
+    h8, w8, h4, w4 = 2 * h, 2 * w, 4 * h, 4 * w
+    f8p = P.conv('mask_decoder.decoder_feat_proc.transforms.0', Act(Dyn('f8'), 1, h8, w8, ms[1]), name='f8p')
+    f4p = P.conv('mask_decoder.decoder_feat_proc.transforms.1', Act(Dyn('f4'), 1, h4, w4, ms[2]), name='f4p')
+    p16 = Act(Dyn('p16'), K, h, w, up[0])
+    u8 = P.buf('u8', (K, h8, w8, up[0]))
+    ol.upsample2x_add(p16.t, f8p.t, u8, B=K, h=h, w=w, C=up[0])
+    u8 = Act(u8, K, h8, w8, up[0])
+    t1 = P.conv('mask_decoder.up_16_8.out_conv.conv1', u8, relu_in=True, act=O.ACT_RELU)
+    ds = P.conv('mask_decoder.up_16_8.out_conv.downsample', u8)
+    p8 = P.conv('mask_decoder.up_16_8.out_conv.conv2', t1, res=ds, name='p8')
+    u4 = P.buf('u4', (K, h4, w4, up[1]))
+    ol.upsample2x_add(p8.t, f4p.t, u4, B=K, h=h8, w=w8, C=up[1])
+    u4 = Act(u4, K, h4, w4, up[1])
+    t2 = P.conv('mask_decoder.up_8_4.out_conv.conv1', u4, relu_in=True, act=O.ACT_RELU)
+    p4 = P.conv('mask_decoder.up_8_4.out_conv.conv2', t2, res=u4, name='p4')
+    logits = P.buf('logits', (K, h4, w4), F32)
+    P.conv('mask_decoder.pred', p4, relu_in=True, out_f32=True, out=Act(logits, K, h4, w4, 1))
+    if update_sensory:
+        p8d = P.buf('p8d', (K, h, w, up[1]))
+        ol.area_down(p8.t, p8d, B=K, H=h8, W=w8, C=up[1], ldx=up[1], ldy=up[1], r=2)
+        p4d = P.buf('p4d', (K, h, w, up[2]))
+        ol.area_down(p4.t, p4d, B=K, H=h4, W=w4, C=up[2], ldx=up[2], ldy=up[2], r=4)
+        lgd = P.buf('lgd', (K, h, w, 8))
+        ol.area_down(logits, lgd, B=K, H=h4, W=w4, C=1, ldx=1, ldy=8, r=4, f32_in=True, Cz=8)
+        g1 = P.conv('mask_decoder.sensory_update.g16_conv', p16, name='g1')
+        g2 = P.conv('mask_decoder.sensory_update.g8_conv', Act(p8d, K, h, w, up[1]), res=g1, name='g2')
+        g3 = P.conv('mask_decoder.sensory_update.g4_conv', Act(p4d, K, h, w, up[2]), x2=Act(lgd, K, h, w, 8), res=g2, name='g3')
+        vals = P.conv('mask_decoder.sensory_update.transform', g3, x2=Act(Dyn('sensory_bf16'), K, h, w, CS),
+                      out_f32=True, name='gru_vals')
+        ol.gru(vals.t, Dyn('sensory_f32'), Dyn('sensory_bf16'), n=K * h * w, C=CS)
+    agg = P.buf('agg', (K + 1, h4, w4), F32)
+    ol.seg_agg(logits, agg, K=K, hw=h4 * w4)
+    ol.up4_softmax(agg, Dyn('prob'), Dyn('logits_up'), P=K + 1, h=h4, w=w4)
+    return P
+
+
+def build_encode_mask(eng, K, h0, w0, H, W, pad_left, pad_top, deep_update=True):
+    """CUTIE.encode_mask -> MaskEncoder.forward + ObjectSummarizer.forward (cutie.py:66-90;
+    big_modules.py:122-182; object_summarizer.py:55-89).
+    dyn in: image f32 [3,h0,w0], masks f32 [K,H,W], pix_feat, sensory_f32/sensory_bf16 (in-place deep update).
+    dyn out: value bf16 [K,h,w,CV], summ f32 [K,Q,C+1]."""
+    P = Plan(eng)
+    m, ol = eng.m, P.ol
+    h, w = H // 16, W // 16
+    CV, CS, CE, Q = m['value_dim'], m['sensory_dim'], m['embed_dim'], m['object_summarizer']['num_summaries']
+    x8 = P.buf('x8', (K, H, W, 8))
+    ol.img_prep(Dyn('image'), Dyn('masks'), x8, h0=h0, w0=w0, H=H, W=W, pad_left=pad_left, pad_top=pad_top, K=K,
+                mean=m['pixel_mean'], std=m['pixel_std'])
+    x = P.conv('mask_encoder.conv1', Act(x8, K, H, W, 8), stride=2, pad=3)          # conv+bn, then maxpool, then relu
+    pool = P.buf('pool', (K, x.H // 2, x.W // 2, 64))
+    ol.maxpool(x.t, pool, B=K, H=x.H, W=x.W, C=64, relu=True)
+    g16, _ = P.resnet('mask_encoder', Act(pool, K, x.H // 2, x.W // 2, 64))
+    value = P.fusion_block('mask_encoder.fuser', Act(Dyn('pix_feat'), 1, h, w, m['pixel_dim']), g16, 'fuse',
+                           out=Act(Dyn('value'), K, h, w, CV))
+    if deep_update:
+        vals = P.conv('mask_encoder.sensory_update.transform', value, x2=Act(Dyn('sensory_bf16'), K, h, w, CS),
+                      out_f32=True, name='gru_vals')
+        ol.gru(vals.t, Dyn('sensory_f32'), Dyn('sensory_bf16'), n=K * h * w, C=CS)
+    # object summarizer
+    pair = P.buf('pair', (K, h, w, 8))
+    m16 = P.buf('m16', (K, h, w), F32)
+    ol.mask_down(Dyn('masks'), pair, m16, K=K, H=H, W=W)
+    pe = Act(eng.pe(h, w), 1, h, w, CE)
+    v1 = P.conv('object_summarizer.input_proj', value, res=pe, res_bcast=True, name='sum.v1')
+    f1 = P.conv('object_summarizer.feature_pred.0', v1, act=O.ACT_RELU, name='sum.f1')
+    feat = P.conv('object_summarizer.feature_pred.2', f1, name='sum.feat')
+    w1 = P.conv('object_summarizer.weights_pred.0', v1, act=O.ACT_RELU, name='sum.w1')
+    wl = P.conv('object_summarizer.weights_pred.2', w1, out_f32=True, name='sum.wl')
+    ol.summarize(feat.t, wl.t, m16, Dyn('summ'), K=K, HW=h * w, C=CE, Q=Q)
+    return P
+
+
+def build_mask_to_prob(eng, Knew, Kold, h0, w0, H, W, pad_left, pad_top, float_mode, nfloat):
+    """Input-mask handling of InferenceCore.step (inference_core.py:259-300): merge -> aggregate -> softmax.
+    dyn in: inmask (i32 [h0,w0] | f32 [n,h0,w0]), pred f32 [Kold+1,H,W] (or 0), src i32 [Knew].  dyn out: prob."""
+    P = Plan(eng)
+    planes = P.buf('planes', (Knew, H, W), F32)
+    P.ol.mask_merge(Dyn('inmask'), Dyn('pred'), Dyn('src'), planes, h0=h0, w0=w0, H=H, W=W, pad_left=pad_left,
+                    pad_top=pad_top, Knew=Knew, Kold=Kold, nfloat=nfloat, float_mode=float_mode)
+    P.ol.agg_softmax(planes, Dyn('prob'), K=Knew, HW=H * W)
+    return P

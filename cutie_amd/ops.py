@@ -1,0 +1,243 @@
+"""Launch-plan builder: Python mirror of the ``cutie_op`` descriptor of include/cutie_hip.h.
+
+An ``OpList`` records kernel descriptors over torch-allocated device buffers (torch = memory + stream
+plumbing only); ``run()`` hands the whole array to ``cutie_exec`` in ONE C call.  Pointer slots can be
+declared *dynamic* (named) and patched per call, so a cached plan is reused across frames.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+NI, NF, NP = 24, 6, 10
+OP_DTYPE = np.dtype([('kind', '<i4'), ('flags', '<i4'), ('i', '<i4', (NI,)), ('f', '<f4', (NF,)), ('p', '<u8', (NP,))])
+assert OP_DTYPE.itemsize == _lib.OP_STRUCT_SIZE
+
+# op kinds (include/cutie_hip.h)
+(CONV, MAXPOOL, IMG_PREP, UPSAMPLE2X_ADD, AREA_DOWN, MASK_DOWN, GAP, ECA_APPLY, GRU, SEG_AGG, UP4_SOFTMAX,
+ MASK_MERGE, AGG_SOFTMAX, LINEAR, LAYERNORM, QUERY_INIT, AUX_MASK, ATTN_Q2P, ATTN_SELF, ATTN_P2Q, SUMMARIZE,
+ ADD_PE, KEY_PREP, AFF_SCORE, AFF_SELECT, AFF_READOUT, MEMSET32, COPY2D, AXPY, USAGE_TICK, RANK_SELECT,
+ GATHER_ROWS, CONSOL_AFF, CONSOL_READ, CAST) = range(1, 36)
+
+F_RELU_IN, F_OUT_F32, F_RES_BCAST = 1, 2, 4
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQ1 = 0, 1, 2, 3
+ACT_SHIFT = 4
+
+TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (256, 16), 4: (64, 128)}
+NUM_CU = 256
+
+
+def pick_tile(M, cout):
+    """Largest MFMA block tile that still yields >= NUM_CU workgroups (256 CUs to fill)."""
+    if cout <= 16:
+        return 3
+    cands = [0, 4, 1, 2] if cout > 64 else [1, 2]
+    best, best_blocks = None, -1
+    for t in cands:
+        bm, bn = TILES[t]
+        blocks = -(-M // bm) * -(-cout // bn)
+        if blocks >= NUM_CU:
+            return t
+        if blocks > best_blocks:
+            best, best_blocks = t, blocks
+    return best
+
+
+class Dyn:
+    """A named, per-call patched pointer (optionally with a byte offset)."""
+    __slots__ = ('name', 'offset')
+
+    def __init__(self, name, offset=0):
+        self.name, self.offset = name, offset
+
+
+def _ptr(t):
+    if t is None:
+        return 0
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+class OpList:
+    def __init__(self):
+        self.recs = []          # (kind, flags, ints, floats, ptrs)
+        self.keep = []          # tensors kept alive
+        self.dyn = {}           # name -> [(op index, slot, offset)]
+        self.arr = None
+
+    # ---- generic ------------------------------------------------------------------
+    def add(self, kind, flags=0, ints=(), floats=(), ptrs=()):
+        idx = len(self.recs)
+        pl = []
+        for slot, t in enumerate(ptrs):
+            if isinstance(t, Dyn):
+                self.dyn.setdefault(t.name, []).append((idx, slot, t.offset))
+                pl.append(0)
+            else:
+                if isinstance(t, torch.Tensor):
+                    self.keep.append(t)
+                pl.append(_ptr(t))
+        self.recs.append((kind, flags, [int(v) for v in ints], [float(v) for v in floats], pl))
+        self.arr = None
+        return idx
+
+    def finalize(self):
+        arr = np.zeros(len(self.recs), dtype=OP_DTYPE)
+        for n, (kind, flags, ints, floats, ptrs) in enumerate(self.recs):
+            arr['kind'][n] = kind
+            arr['flags'][n] = flags
+            arr['i'][n, :len(ints)] = ints
+            arr['f'][n, :len(floats)] = floats
+            arr['p'][n, :len(ptrs)] = ptrs
+        self.arr = arr
+        return arr
+
+    def bind(self, **tensors):
+        """Patch dynamic pointer slots.  Values: torch tensors or raw ints."""
+        if self.arr is None:
+            self.finalize()
+        p = self.arr['p']
+        for name, t in tensors.items():
+            base = _ptr(t)
+            for (idx, slot, off) in self.dyn.get(name, ()):
+                p[idx, slot] = base + off if base else 0
+
+    def run(self, **tensors):
+        if self.arr is None:
+            self.finalize()
+        if tensors:
+            self.bind(**tensors)
+        _lib.get_executor().run(self.arr)
+
+    def __len__(self):
+        return len(self.recs)
+
+    # ---- builders (argument order mirrors include/cutie_hip.h) -----------------------
+    def conv(self, x1, w, y, *, B, H, W, C1, ldx1, OH, OW, ldy, stride=1, pad=0, x2=None, C2=0, ldx2=0,
+             res=None, ldr=0, res_bcast=False, relu_in=False, act=ACT_NONE, out_f32=False, tile=None):
+        """w: PackedConv (weights.py)."""
+        flags = (F_RELU_IN if relu_in else 0) | (F_OUT_F32 if out_f32 else 0) | (F_RES_BCAST if res_bcast else 0) | (act << ACT_SHIFT)
+        assert C1 + C2 == w.cin_padded, (C1, C2, w.cin_padded)
+        M = B * OH * OW
+        if tile is None:
+            tile = pick_tile(M, w.cout)
+        return self.add(CONV, flags,
+                        [B, H, W, C1, C2, ldx1, ldx2, OH, OW, w.cout, ldy, w.kh, w.kw, stride, pad, ldr, w.kpad, tile],
+                        [], [x1, x2, w.weight, w.bias, res, y])
+
+    def maxpool(self, x, y, *, B, H, W, C, relu=False):
+        OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        return self.add(MAXPOOL, 1 if relu else 0, [B, H, W, C, OH, OW], [], [x, y])
+
+    def img_prep(self, image, masks, y, *, h0, w0, H, W, pad_left, pad_top, K, mean, std):
+        return self.add(IMG_PREP, 0, [h0, w0, H, W, pad_left, pad_top, K], list(mean) + list(std), [image, masks, y])
+
+    def upsample2x_add(self, g, skip, y, *, B, h, w, C):
+        return self.add(UPSAMPLE2X_ADD, 0, [B, h, w, C], [], [g, skip, y])
+
+    def area_down(self, x, y, *, B, H, W, C, ldx, ldy, r, f32_in=False, Cz=None):
+        return self.add(AREA_DOWN, 1 if f32_in else 0, [B, H, W, C, ldx, ldy, r, C if Cz is None else Cz], [], [x, y])
+
+    def mask_down(self, masks, pair, m16, *, K, H, W, r=16):
+        return self.add(MASK_DOWN, 0, [K, H, W, r], [], [masks, pair, m16])
+
+    def gap(self, x, y, *, B, HW, C):
+        return self.add(GAP, 0, [B, HW, C], [], [x, y])
+
+    def eca_apply(self, x, gap, wk, r, y, *, B, HW, C):
+        return self.add(ECA_APPLY, 0, [B, HW, C], [], [x, gap, wk, r, y])
+
+    def gru(self, values, h, hb, *, n, C):
+        return self.add(GRU, 0, [n, C], [], [values, h, hb])
+
+    def seg_agg(self, logits, agg, *, K, hw):
+        return self.add(SEG_AGG, 0, [K, hw], [], [logits, agg])
+
+    def up4_softmax(self, agg, prob, logits_up, *, P, h, w):
+        return self.add(UP4_SOFTMAX, 0, [P, h, w], [], [agg, prob, logits_up])
+
+    def mask_merge(self, inmask, pred, src, planes, *, h0, w0, H, W, pad_left, pad_top, Knew, Kold, nfloat, float_mode):
+        return self.add(MASK_MERGE, 1 if float_mode else 0, [h0, w0, H, W, pad_left, pad_top, Knew, Kold, nfloat], [],
+                        [inmask, pred, src, planes])
+
+    def agg_softmax(self, planes, prob, *, K, HW):
+        return self.add(AGG_SOFTMAX, 0, [K, HW], [], [planes, prob])
+
+    def linear(self, x, w, y, *, M, ldx=None, ldy=None, x_add=None, add_rows=0, res=None, relu=False):
+        """w: PackedLinear."""
+        return self.add(LINEAR, 1 if relu else 0,
+                        [M, w.n, w.kd, w.kd if ldx is None else ldx, w.n if ldy is None else ldy, add_rows], [],
+                        [x, x_add, w.weight, w.bias, res, y])
+
+    def layernorm(self, x, g, b, y, *, M, C):
+        return self.add(LAYERNORM, 0, [M, C], [], [x, g, b, y])
+
+    def query_init(self, obj_mem, y, *, rows, C):
+        return self.add(QUERY_INIT, 0, [rows, C], [], [obj_mem, y])
+
+    def aux_mask(self, logits, fg, nfg, *, K, HW):
+        self.memset32(nfg, K, 0)
+        return self.add(AUX_MASK, 0, [K, HW], [], [logits, fg, nfg])
+
+    def attn_q2p(self, q, kv, fg, nfg, y, *, K, Q, HW, C, heads, ldkv, voff):
+        return self.add(ATTN_Q2P, 0, [K, Q, HW, C, heads, ldkv, voff], [], [q, kv, fg, nfg, y])
+
+    def attn_self(self, qk, v, y, *, K, Q, C, heads):
+        return self.add(ATTN_SELF, 0, [K, Q, C, heads], [], [qk, v, y])
+
+    def attn_p2q(self, q, kq, vq, y, *, K, Q, HW, C, heads, ldq):
+        return self.add(ATTN_P2Q, 0, [K, Q, HW, C, heads, ldq], [], [q, kq, vq, y])
+
+    def summarize(self, feat, wl, m16, y, *, K, HW, C, Q):
+        return self.add(SUMMARIZE, 0, [K, HW, C, Q], [], [feat, wl, m16, y])
+
+    def add_pe(self, x, pe, y, *, B, n):
+        return self.add(ADD_PE, 0, [B, n], [], [x, pe, y])
+
+    def key_prep(self, key, aux, hi, lo, sc, *, n, query):
+        return self.add(KEY_PREP, 1 if query else 0, [n], [], [key, aux, hi, lo, sc])
+
+    def aff_score(self, Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count, *, HW, HWp, ranges, cap, mode):
+        ranges = [(s, n) for (s, n) in ranges if n > 0]
+        assert 1 <= len(ranges) <= 3
+        G = sum(-(-n // 16) for _, n in ranges)
+        ints = [HW, HWp, len(ranges)]
+        for r in range(3):
+            ints += list(ranges[r]) if r < len(ranges) else [0, 0]
+        ints += [G, cap, mode]
+        return self.add(AFF_SCORE, 0, ints, [], [Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count])
+
+    def aff_select(self, gmax, tau, *, HW, HWp, G, top_k):
+        return self.add(AFF_SELECT, 0, [HW, HWp, G, top_k], [], [gmax, tau])
+
+    def aff_readout(self, cand_val, cand_idx, count, vptrs, usage, y, overflow, *, HW, cap, top_k, K, CV):
+        return self.add(AFF_READOUT, 0, [HW, cap, top_k, K, CV], [], [cand_val, cand_idx, count, vptrs, usage, y, overflow])
+
+    def memset32(self, dst, n, value=0):
+        return self.add(MEMSET32, 0, [n, value], [], [dst])
+
+    def copy2d(self, src, dst, *, rows, rowbytes, src_stride, dst_stride):
+        assert rowbytes % 4 == 0 and src_stride % 4 == 0 and dst_stride % 4 == 0
+        return self.add(COPY2D, 0, [rows, rowbytes, src_stride, dst_stride], [], [src, dst])
+
+    def axpy(self, x, y, *, n, a=1.0):
+        return self.add(AXPY, 0, [n], [a], [x, y])
+
+    def usage_tick(self, life, n):
+        return self.add(USAGE_TICK, 0, [n], [], [life])
+
+    def rank_select(self, use, life, order, *, n, k):
+        return self.add(RANK_SELECT, 0, [n, k], [], [use, life, order])
+
+    def gather_rows(self, src, order, dst, *, k, rowbytes, src_stride, dst_stride):
+        return self.add(GATHER_ROWS, 0, [k, rowbytes, src_stride, dst_stride], [], [src, order, dst])
+
+    def consol_aff(self, ckey, cshr, pkey, psel, aff, *, n, P):
+        return self.add(CONSOL_AFF, 0, [n, P], [], [ckey, cshr, pkey, psel, aff])
+
+    def consol_read(self, aff, V, out, *, n, P, C, ldv, ldo, f32=False):
+        return self.add(CONSOL_READ, 1 if f32 else 0, [n, P, C, ldv, ldo], [], [aff, V, out])
+
+    def cast(self, src, dst, *, n, to_f32=False):
+        return self.add(CAST, 1 if to_f32 else 0, [n], [], [src, dst])

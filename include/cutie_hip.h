@@ -1,0 +1,213 @@
+/*
+ * cutie_hip.h -- C ABI of libcutie_hip.so, the MI355X (gfx950) kernel library behind the
+ * Cutie per-frame inference hot path (InferenceCore.step).
+ *
+ * The reference (hkchengrex/Cutie) has no FFI for this path: all arithmetic is delegated to
+ * torch ops.  This header is therefore the boundary WE define under the
+ * reference's Python surface (cutie.model.cutie.CUTIE / cutie.inference.inference_core.InferenceCore,
+ * mirrored in cutie_amd/).  Each op below cites the reference torch-op sequence it replaces.
+ *
+ * Conventions
+ *   - plain C, no torch types: raw device pointers + explicit sizes; the caller owns all memory
+ *     (nothing is allocated inside); every entry point takes the hipStream_t to launch on (as void*).
+ *   - return 0 on success, negative on error; cutie_hip_last_error() gives the message.
+ *   - activations are NHWC ("pixel-major, channel-contiguous") bf16 unless stated; batch = objects.
+ *   - a frame is executed as a *launch plan*: an array of cutie_op descriptors over a pre-allocated
+ *     arena, replayed by cutie_exec() (one C call per stage; graph-capturable: no allocation, no sync).
+ */
+#ifndef CUTIE_HIP_H
+#define CUTIE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUTIE_OP_NI 24
+#define CUTIE_OP_NF 6
+#define CUTIE_OP_NP 10
+
+typedef struct cutie_op {
+    int32_t kind;               /* CUTIE_OP_* */
+    int32_t flags;              /* op-specific bit flags */
+    int32_t i[CUTIE_OP_NI];     /* integer parameters (per-op meaning below) */
+    float f[CUTIE_OP_NF];       /* float parameters */
+    uint64_t p[CUTIE_OP_NP];    /* device pointers */
+} cutie_op;                     /* 208 bytes, mirrored by cutie_amd/ops.py:OP_DTYPE */
+
+/* ---- conv flags ---- */
+#define CUTIE_F_RELU_IN   1   /* relu applied to the input while loading (conv(F.relu(x))) */
+#define CUTIE_F_OUT_F32   2   /* output stored as f32 (default bf16) */
+#define CUTIE_F_RES_BCAST 4   /* residual has batch 1 and is broadcast over the B objects */
+#define CUTIE_ACT_SHIFT   4   /* activation code in bits 4..6 */
+#define CUTIE_ACT_NONE    0
+#define CUTIE_ACT_RELU    1
+#define CUTIE_ACT_SIGMOID 2
+#define CUTIE_ACT_SQ1     3   /* x*x + 1   (shrinkage, big_modules.py:84) */
+
+enum {
+    /* CONV: y = act(conv2d(relu_in?(cat(x1,x2)), w) + bias + res)   -- implicit-GEMM on MFMA.
+     * replaces nn.Conv2d / GConv2d (+ folded BatchNorm2d + ReLU + residual add) everywhere:
+     * resnet.py:51-124, big_modules.py:36,81-87,207-235,257-306, group_modules.py:33-58,102-127,
+     * channel_attn.py:25-29, modules.py:22-31,46-85, nn.Linear on pixel tokens (object_transformer.py,
+     * transformer_layers.py, object_summarizer.py).
+     * p0=x1 bf16 [B,H,W,ldx1]  p1=x2 bf16 [B,H,W,ldx2] (virtual channel concat, may be 0)
+     * p2=w bf16 [CoutPad][Kpad] (k = (kh*KW+kw)*Cin + c, zero padded)  p3=bias f32[Cout] (may be 0)
+     * p4=res bf16 [B|1,OH,OW,ldr] (may be 0)  p5=y bf16|f32 [B,OH,OW,ldy]
+     * i: 0 B 1 H 2 W 3 C1 4 C2 5 ldx1 6 ldx2 7 OH 8 OW 9 Cout 10 ldy 11 KH 12 KW 13 stride 14 pad
+     *    15 ldr 16 Kpad 17 tile (0=128x128 1=128x64 2=64x64 3=256x16 4=64x128) */
+    CUTIE_OP_CONV = 1,
+    /* MAXPOOL 3x3 s2 p1 (+relu if flags&1): resnet.py:131-134, big_modules.py:47-48,158-160
+     * p0=x bf16 [B,H,W,C] p1=y bf16 [B,OH,OW,C]   i: 0 B 1 H 2 W 3 C 4 OH 5 OW */
+    CUTIE_OP_MAXPOOL = 2,
+    /* IMG_PREP: (image-mean)/std, zero-pad to /16, CHW f32 -> NHWC8 bf16; with masks also the
+     * per-object [image, mask_k, others_k] stack of the mask encoder.
+     * cutie.py:62,76,49-59; tensor_utils.py:7-22; big_modules.py:134-139
+     * p0=image f32 [3,h0,w0] p1=masks f32 [K,H,W] (0 => K=1, image only) p2=y bf16 [K,H,W,8]
+     * i: 0 h0 1 w0 2 H 3 W 4 pad_left 5 pad_top 6 K     f: 0..2 mean 3..5 std */
+    CUTIE_OP_IMG_PREP = 3,
+    /* UPSAMPLE2X_ADD: y = bilinear_x2(g, align_corners=False) + skip (broadcast over objects)
+     * group_modules.py:19-23 + MainToGroupDistributor('add') modules.py:15-18
+     * p0=g bf16 [B,h,w,C] p1=skip bf16 [1,2h,2w,C] p2=y bf16 [B,2h,2w,C]   i: 0 B 1 h 2 w 3 C */
+    CUTIE_OP_UPSAMPLE2X_ADD = 4,
+    /* AREA_DOWN: r x r mean (F.interpolate mode='area', integer ratio) on NHWC bf16|f32 input
+     * group_modules.py:26-30 (modules.py:59-60)
+     * p0=x [B,H,W,ldx] (bf16, or f32 if flags&1) p1=y bf16 [B,H/r,W/r,ldy] (channels [0,C); channels
+     * [C,Cz) are zero-filled)   i: 0 B 1 H 2 W 3 C 4 ldx 5 ldy 6 r 7 Cz */
+    CUTIE_OP_AREA_DOWN = 5,
+    /* MASK_DOWN: planar f32 masks [K,H,W] -> 16x area mean -> bf16 [K,h,w,8] = (mask, others, 0..)
+     * plus plain f32 copy [K,h,w] of the down-sampled mask (object summarizer).
+     * cutie.py:149-150,49-59; object_summarizer.py:62
+     * p0=masks f32 [K,H,W] p1=y bf16 [K,h,w,8] p2=m16 f32 [K,h,w] (may be 0)  i: 0 K 1 H 2 W 3 r */
+    CUTIE_OP_MASK_DOWN = 6,
+    /* GAP: per-(b,c) mean over pixels (nn.AdaptiveAvgPool2d(1)), channel_attn.py:31-32
+     * p0=x bf16 [B,HW,C] p1=y f32 [B,C]   i: 0 B 1 HW 2 C */
+    CUTIE_OP_GAP = 7,
+    /* ECA_APPLY: y = x * sigmoid(conv1d_k5(gap))[c] + r    channel_attn.py:33-37
+     * p0=x bf16 [B,HW,C] p1=gap f32 [B,C] p2=w f32[5] p3=r bf16 [B,HW,C] p4=y bf16   i: 0 B 1 HW 2 C */
+    CUTIE_OP_ECA_APPLY = 8,
+    /* GRU: h' = sig(f)*h*(1-sig(u)) + sig(u)*tanh(n), values=[f|u|n] f32   modules.py:35-43
+     * p0=values f32 [B,HW,3C] p1=h f32 [B,HW,C] (in/out) p2=h_bf16 bf16 [B,HW,C] (out)  i: 0 n=B*HW 1 C */
+    CUTIE_OP_GRU = 9,
+    /* SEG_AGG: prob=sigmoid(logit); aggregate -> (K+1) logits at 1/4 res   cutie.py:193-198,
+     * tensor_utils.py:47-55      p0=logits f32 [K,h,w] p1=agg f32 [K+1,h,w]   i: 0 K 1 h*w */
+    CUTIE_OP_SEG_AGG = 10,
+    /* UP4_SOFTMAX: bilinear x4 (align_corners=False) of the K+1 logit planes, softmax over planes
+     * cutie.py:199-200   p0=agg f32 [K+1,h,w] p1=prob f32 [K+1,4h,4w] p2=logits_up f32 (may be 0)
+     * i: 0 K+1 1 h 2 w */
+    CUTIE_OP_UP4_SOFTMAX = 11,
+    /* MASK_MERGE: build the per-object mask planes of a frame with an input mask
+     * inference_core.py:259-300.  plane t: src[t] >= 0 -> (idx==src[t]) [idx mode] / fmask[src[t]] [float
+     * mode]; else (pred==0 ? 0 : (covered ? 0 : pred[t+1])).  Input mask is un-padded; planes are padded.
+     * p0=idx i32 [h0,w0] | fmask f32 [n,h0,w0] p1=pred f32 [Kold+1,H,W] (may be 0) p2=src i32 [Knew]
+     * p3=planes f32 [Knew,H,W]   i: 0 h0 1 w0 2 H 3 W 4 pad_left 5 pad_top 6 Knew 7 Kold 8 nfloat
+     * flags&1: float mode */
+    CUTIE_OP_MASK_MERGE = 12,
+    /* AGG_SOFTMAX: prob = softmax(aggregate(planes))   inference_core.py:299-300
+     * p0=planes f32 [K,HW] p1=prob f32 [K+1,HW]   i: 0 K 1 HW */
+    CUTIE_OP_AGG_SOFTMAX = 13,
+    /* LINEAR: small-M f32 linear for the object-query side (M = K*16 rows)
+     * y = act(x @ W^T + b) + res     nn.Linear / MHA in/out projections, transformer_layers.py
+     * p0=x f32 [M,ldx] p1=x_add f32 [M|16, Kd] (added to x before the product, may be 0)
+     * p2=W bf16 [N,Kd] p3=bias f32 [N] p4=res f32 [M,N] (may be 0) p5=y f32 [M,ldy]
+     * i: 0 M 1 N 2 Kd 3 ldx 4 ldy 5 add_rows (x_add row = m % add_rows)   flags&1 relu */
+    CUTIE_OP_LINEAR = 14,
+    /* LAYERNORM over the last dim (eps 1e-5)   p0=x f32 [M,C] p1=g p2=b f32[C] p3=y f32 [M,C]  i: 0 M 1 C */
+    CUTIE_OP_LAYERNORM = 15,
+    /* QUERY_INIT: obj_values = sums/(area+1e-4)   object_transformer.py:125-132
+     * p0=obj_mem f32 [K,Q,C+1] p1=y f32 [K*Q,C]   i: 0 K*Q 1 C */
+    CUTIE_OP_QUERY_INIT = 16,
+    /* AUX_MASK: foreground mask from mask_pred logits   object_transformer.py:179-205
+     * p0=logits f32 [K,HW] p1=fg u8 [K,HW] p2=nfg i32 [K] (must be zeroed: MEMSET op before)
+     * i: 0 K 1 HW */
+    CUTIE_OP_AUX_MASK = 17,
+    /* ATTN_Q2P: masked cross attention, 16 object queries <- HW pixels, 8 heads x 32
+     * transformer_layers.py:45-98 (nn.MultiheadAttention core), object_transformer.py:56-61
+     * p0=q f32 [K,Q,C] (projected) p1=kv bf16 [K,HW,ldkv] (k at +0, v at +voff) p2=fg u8 [K,HW]
+     * p3=nfg i32 [K] p4=y f32 [K,Q,C]   i: 0 K 1 Q 2 HW 3 C 4 heads 5 ldkv 6 voff */
+    CUTIE_OP_ATTN_Q2P = 18,
+    /* ATTN_SELF: 16x16 self attention per object  transformer_layers.py:12-41
+     * p0=qk f32 [K,Q,2C] (q at +0, k at +C) p1=v f32 [K,Q,C] p2=y f32 [K,Q,C]  i: 0 K 1 Q 2 C 3 heads */
+    CUTIE_OP_ATTN_SELF = 19,
+    /* ATTN_P2Q: pixels <- 16 queries cross attention  object_transformer.py:66-70
+     * p0=q bf16 [K,HW,ldq] p1=kq f32 [K,Q,C] p2=vq f32 [K,Q,C] p3=y bf16 [K,HW,C]
+     * i: 0 K 1 Q 2 HW 3 C 4 heads 5 ldq */
+    CUTIE_OP_ATTN_P2Q = 20,
+    /* SUMMARIZE: weights=sigmoid(logits)*[m x8 | (1-m) x8]; sums=einsum; area   object_summarizer.py:11-23
+     * p0=feature bf16 [K,HW,C] p1=wlogits f32 [K,HW,Q] p2=m16 f32 [K,HW] p3=y f32 [K,Q,C+1]
+     * i: 0 K 1 HW 2 C 3 Q */
+    CUTIE_OP_SUMMARIZE = 21,
+    /* ADD_PE: y = x + pe (broadcast over objects), bf16     object_summarizer.py:74-76
+     * p0=x bf16 [B,HW,C] p1=pe bf16 [HW,C] p2=y   i: 0 B 1 HW*C */
+    CUTIE_OP_ADD_PE = 22,
+    /* KEY_PREP: split-bf16 MFMA operands of the anisotropic-L2 similarity  memory_utils.py:30-42
+     * memory side (flags=0): A=[k^2|k] -> A_hi,A_lo bf16 [n,128], scale=shrinkage/sqrt(CK) f32 [n]
+     * query side  (flags=1): B=[-e|2*k*e] -> B_hi,B_lo, c=sum(e*k^2)
+     * p0=key f32 [n,64] p1=shr f32 [n] (mem) | sel f32 [n,64] (query) p2=hi p3=lo p4=scale|c   i: 0 n */
+    CUTIE_OP_KEY_PREP = 23,
+    /* AFF_SCORE: S = scale_i*(A_i.B_j - c_j) tiles on MFMA (3-term split bf16, fp32-class accuracy)
+     * mode 0: per-(16-token tile, query) maxima -> gmax f32 [G,HWp]
+     * mode 1: append (S,token) with S >= tau_j to cand lists (f32,i32) [HW,cap], count i32 [HW]
+     * memory_utils.py:7-46 get_similarity + the candidate pre-filter of top-k (:58)
+     * p0=A_hi p1=A_lo p2=scale (bank base pointers, rows = physical token slots) p3=B_hi p4=B_lo p5=c
+     * p6=gmax | tau f32 [HW]  p7=cand_val p8=cand_idx p9=count
+     * i: 0 HW 1 HWp 2 nranges 3.. (start,n) x3  9 G 10 cap 11 mode */
+    CUTIE_OP_AFF_SCORE = 24,
+    /* AFF_SELECT: tau_j = top_k-th largest of gmax[:,j] (or -inf if G < top_k)
+     * p0=gmax f32 [G,HWp] p1=tau f32 [HW]   i: 0 HW 1 HWp 2 G 3 top_k */
+    CUTIE_OP_AFF_SELECT = 25,
+    /* AFF_READOUT: exact top-k of the candidates (ties -> lower slot), softmax, usage += w,
+     * readout[o,j,:] = sum_i w_i V_o[i,:]    memory_utils.py:58-63,75; memory_manager.py:77-88
+     * p0=cand_val p1=cand_idx p2=count p3=vptrs u64[K] (device array of per-object value-bank bases,
+     * bf16 [slots,CV]) p4=usage f32 [slots] (may be 0) p5=y bf16 [K,HW,CV] p6=overflow i32[1]
+     * i: 0 HW 1 cap 2 top_k 3 K 4 CV */
+    CUTIE_OP_AFF_READOUT = 26,
+    /* MEMSET32: fill n 32-bit words with value i[1]   p0=dst   i: 0 n 1 value */
+    CUTIE_OP_MEMSET32 = 27,
+    /* COPY2D: rows x rowbytes strided device copy (bank append / compaction; replaces torch.cat,
+     * kv_memory_store.py:7-16)   p0=src p1=dst   i: 0 rows 1 rowbytes(mult of 4) 2 src_stride 3 dst_stride */
+    CUTIE_OP_COPY2D = 28,
+    /* AXPY: y[i] += a * x[i] (f32)  streaming object-memory sum, memory_manager.py:264-269
+     * p0=x p1=y  i: 0 n  f: 0 a */
+    CUTIE_OP_AXPY = 29,
+    /* USAGE_TICK: life[i] += 1 for i in [0,n)   kv_memory_store.py:161  p0=life  i: 0 n */
+    CUTIE_OP_USAGE_TICK = 30,
+    /* RANK_SELECT: order[r] = index of the r-th largest of use/life (ties -> lower index), r < k
+     * torch.topk(usage, k) of memory_manager.py:339 and kv_memory_store.py:222
+     * p0=use f32[n] p1=life f32[n] p2=order i32[k]   i: 0 n 1 k */
+    CUTIE_OP_RANK_SELECT = 31,
+    /* GATHER_ROWS: dst[r,:] = src[order[r],:]   p0=src p1=order i32 p2=dst  i: 0 k 1 rowbytes 2 src_stride 3 dst_stride */
+    CUTIE_OP_GATHER_ROWS = 32,
+    /* CONSOL_AFF: dense-softmax potentiation of long-term consolidation  memory_manager.py:347-350
+     * aff[p,i] = softmax_i( sim(cand_i, proto_p) )   (with max shift, memory_utils.py:68-71)
+     * p0=ckey f32 [n,64] p1=cshr f32 [n] p2=pkey f32 [P,64] p3=psel f32 [P,64] p4=aff f32 [P,n]  i: 0 n 1 P */
+    CUTIE_OP_CONSOL_AFF = 33,
+    /* CONSOL_READ: out[p,:] = sum_i aff[p,i] * V[i,:]    memory_manager.py:352-356
+     * p0=aff f32 [P,n] p1=V (bf16 [n,C], or f32 if flags&1) p2=out (bf16|f32 like V) [P,C]
+     * i: 0 n 1 P 2 C 3 ldv 4 ldo */
+    CUTIE_OP_CONSOL_READ = 34,
+    /* CAST: f32 [n] -> bf16 [n] (flags=0) or bf16 -> f32 (flags=1)   p0=src p1=dst  i: 0 n */
+    CUTIE_OP_CAST = 35,
+    CUTIE_OP__COUNT
+};
+
+/* Execute n descriptors in order on `stream`.  Returns 0 or a negative error code. */
+int cutie_exec(const cutie_op* ops, int n, void* stream);
+/* Single-op entry (used by the kernel unit tests). */
+int cutie_exec_one(const cutie_op* op, void* stream);
+/* HIP-graph capture of a plan: returns an opaque handle (0 on failure); replay with cutie_graph_launch. */
+void* cutie_graph_capture(const cutie_op* ops, int n, void* stream);
+int cutie_graph_launch(void* graph, void* stream);
+void cutie_graph_destroy(void* graph);
+/* Timing helper: runs the plan `iters` times between two hipEvents on `stream`, returns mean ms (<0 on error).
+ * bench.py uses it to time the dominant kernel on the launch stream (roofline.achieved). */
+float cutie_time_ops(const cutie_op* ops, int n, int iters, void* stream);
+const char* cutie_hip_last_error(void);
+int cutie_hip_abi_version(void);
+int cutie_op_struct_size(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

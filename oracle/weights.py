@@ -170,10 +170,10 @@ def param_spec(m=MODEL_CFG):
 # recurrence is contractive: parity over a whole trajectory is then a meaningful test.
 CONV_GAINS = [
     ('key_proj.key_proj', 2.8), ('key_proj.d_proj', 3.0), ('key_proj.e_proj', 3.0),
-    ('mask_decoder.pred', 1.5), ('.mask_pred.', 1.0),
+    ('mask_decoder.pred', 3.0), ('.mask_pred.', 1.0),
     ('', 1.0),
 ]
-LINEAR_GAINS = [('', 1.0)]
+LINEAR_GAINS = [('read_from_query.cross_attn.out_proj', 0.25), ('in_proj_weight', 0.7), ('', 1.0)]
 
 
 def _conv_gain(name):
@@ -205,7 +205,7 @@ def make_state_dict(seed=0, m=MODEL_CFG):
         elif kind == 'bias':
             v = r.standard_normal(shape) * 0.05
             if name == 'mask_decoder.pred.bias':
-                v = v - 1.5            # keeps fg/bg balanced with random features
+                v = v - 0.6            # keeps fg/bg balanced with random features
         elif kind == 'bn_w':
             last = name.endswith('bn3.weight') or (name.endswith('bn2.weight') and 'mask_encoder' in name)
             v = r.uniform(0.7, 1.1, shape) * (0.45 if last else 1.0)

@@ -1,0 +1,497 @@
+"""Torch-CPU interpreter of the ``cutie_op`` descriptors (include/cutie_hip.h).  TEST INFRASTRUCTURE ONLY.
+
+Two uses:
+  * ``-m "not gpu"`` tests inject it with ``cutie_amd._lib.set_executor_for_testing`` so the whole host side
+    (plan builders, memory bank, InferenceCore mirror) is checked against the oracle without a GPU;
+  * ``-m gpu`` kernel unit tests run the same descriptor through the HIP kernel (device buffers) and through
+    this interpreter (host copies) and compare.
+It reads/writes host memory by raw address, exactly like the kernels do with device pointers.  Values stored
+as bf16 are rounded to bf16 here too (fp32 accumulation inside an op), so HIP-vs-mock differences are
+accumulation-order noise only.
+"""
+import ctypes
+import math
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from cutie_amd import ops as O
+
+BF16, F32, I32, U8, U64 = 'bf16', 'f32', 'i32', 'u8', 'u64'
+_NP = {BF16: (np.uint16, 2), F32: (np.float32, 4), I32: (np.int32, 4), U8: (np.uint8, 1), U64: (np.uint64, 8)}
+
+
+def view(ptr, dtype, shape, strides=None):
+    """Tensor aliasing host memory at `ptr` (strides in elements, default contiguous)."""
+    npdt, isz = _NP[dtype]
+    shape = tuple(int(s) for s in shape)
+    if strides is None:
+        strides, acc = [], 1
+        for s in reversed(shape):
+            strides.append(acc)
+            acc *= s
+        strides = tuple(reversed(strides))
+    extent = 1 + sum((s - 1) * st for s, st in zip(shape, strides)) if all(s > 0 for s in shape) else 0
+    if extent == 0:
+        return torch.zeros(shape)
+    buf = (ctypes.c_char * (extent * isz)).from_address(int(ptr))
+    a = np.frombuffer(buf, dtype=npdt)
+    t = torch.from_numpy(a)
+    if dtype == BF16:
+        t = t.view(torch.bfloat16)
+    elif dtype == U64:
+        t = t.view(torch.int64)
+    return t.as_strided(shape, strides)
+
+
+def _act(v, code):
+    if code == O.ACT_RELU:
+        return F.relu(v)
+    if code == O.ACT_SIGMOID:
+        return torch.sigmoid(v)
+    if code == O.ACT_SQ1:
+        return v * v + 1
+    return v
+
+
+def _clamp_logit(p):
+    p = p.clamp(1e-7, 1 - 1e-7)
+    return torch.log(p / (1 - p))
+
+
+def _up_coords(n_out, n_in, scale):
+    src = ((torch.arange(n_out, dtype=torch.float32) + 0.5) * scale - 0.5).clamp(min=0)
+    i0 = src.floor().long().clamp(max=n_in - 1)
+    i1 = (i0 + 1).clamp(max=n_in - 1)
+    return i0, i1, src - i0.float()
+
+
+def _bilinear(x, scale_inv):
+    """x [..., h, w] fp32 -> upsampled by 1/scale_inv, align_corners=False (same formula as the kernels)."""
+    h, w = x.shape[-2:]
+    oh, ow = int(round(h / scale_inv)), int(round(w / scale_inv))
+    y0, y1, ly = _up_coords(oh, h, scale_inv)
+    x0, x1, lx = _up_coords(ow, w, scale_inv)
+    ly = ly.view(-1, 1)
+    lx = lx.view(1, -1)
+    g = lambda yy, xx: x[..., yy, :][..., :, xx]
+    return ((1 - ly) * (1 - lx)) * g(y0, x0) + ((1 - ly) * lx) * g(y0, x1) + (ly * (1 - lx)) * g(y1, x0) + (ly * lx) * g(y1, x1)
+
+
+def unpack_conv_weight(wp, cout, kh, kw, cin):
+    """packed bf16 [CoutPad, Kpad] -> fp32 [cout, cin, kh, kw]"""
+    return wp[:cout, :kh * kw * cin].float().view(cout, kh, kw, cin).permute(0, 3, 1, 2).contiguous()
+
+
+class MockExecutor:
+    is_mock = True
+
+    def run(self, arr):
+        for rec in arr:
+            self.run_one(rec)
+
+    def stream(self):
+        return 0
+
+    def run_one(self, rec):
+        kind = int(rec['kind'])
+        fn = getattr(self, '_op_%d' % kind, None)
+        if fn is None:
+            raise NotImplementedError(f'mock op kind {kind}')
+        fn(int(rec['flags']), [int(v) for v in rec['i']], [float(v) for v in rec['f']], [int(v) for v in rec['p']])
+
+    # ---- CONV ---------------------------------------------------------------------
+    def _op_1(self, flags, i, f, p):
+        B, H, W, C1, C2, ldx1, ldx2, OH, OW, Cout, ldy, KH, KW, stride, pad, ldr, Kpad, tile = i[:18]
+        Cin = C1 + C2
+        x = view(p[0], BF16, (B, H, W, C1), (H * W * ldx1, W * ldx1, ldx1, 1)).float()
+        if C2:
+            x2 = view(p[1], BF16, (B, H, W, C2), (H * W * ldx2, W * ldx2, ldx2, 1)).float()
+            x = torch.cat([x, x2], -1)
+        if flags & O.F_RELU_IN:
+            x = F.relu(x)
+        coutpad = -(-Cout // 128) * 128
+        w = unpack_conv_weight(view(p[2], BF16, (coutpad, Kpad)), Cout, KH, KW, Cin)
+        bias = view(p[3], F32, (Cout,)).clone() if p[3] else None
+        y = F.conv2d(x.permute(0, 3, 1, 2), w, bias, stride, pad).permute(0, 2, 3, 1)
+        assert y.shape[1] == OH and y.shape[2] == OW, (y.shape, OH, OW)
+        if p[4]:
+            rb = 1 if flags & O.F_RES_BCAST else B
+            y = y + view(p[4], BF16, (rb, OH, OW, Cout), (OH * OW * ldr, OW * ldr, ldr, 1)).float()
+        y = _act(y, (flags >> O.ACT_SHIFT) & 7)
+        out = view(p[5], F32 if flags & O.F_OUT_F32 else BF16, (B, OH, OW, Cout), (OH * OW * ldy, OW * ldy, ldy, 1))
+        out.copy_(y)
+
+    # ---- MAXPOOL --------------------------------------------------------------------
+    def _op_2(self, flags, i, f, p):
+        B, H, W, C, OH, OW = i[:6]
+        x = view(p[0], BF16, (B, H, W, C)).float().permute(0, 3, 1, 2)
+        y = F.max_pool2d(x, 3, 2, 1)
+        if flags & 1:
+            y = F.relu(y)
+        view(p[1], BF16, (B, OH, OW, C)).copy_(y.permute(0, 2, 3, 1))
+
+    # ---- IMG_PREP -------------------------------------------------------------------
+    def _op_3(self, flags, i, f, p):
+        h0, w0, H, W, pl, pt, K = i[:7]
+        K = K if p[1] else 1
+        img = view(p[0], F32, (3, h0, w0))
+        full = torch.zeros(3, H, W)
+        full[:, pt:pt + h0, pl:pl + w0] = img
+        mean = torch.tensor(f[0:3]).view(3, 1, 1)
+        std = torch.tensor(f[3:6]).view(3, 1, 1)
+        full = (full - mean) / std
+        out = torch.zeros(K, H, W, 8)
+        out[..., 0:3] = full.permute(1, 2, 0)
+        if p[1]:
+            m = view(p[1], F32, (K, H, W))
+            out[..., 3] = m
+            out[..., 4] = (m.sum(0, keepdim=True) - m).clamp(0, 1)
+        view(p[2], BF16, (K, H, W, 8)).copy_(out)
+
+    # ---- UPSAMPLE2X_ADD ---------------------------------------------------------------
+    def _op_4(self, flags, i, f, p):
+        B, h, w, C = i[:4]
+        g = view(p[0], BF16, (B, h, w, C)).float().permute(0, 3, 1, 2)
+        skip = view(p[1], BF16, (1, 2 * h, 2 * w, C)).float()
+        y = _bilinear(g, 0.5).permute(0, 2, 3, 1) + skip
+        view(p[2], BF16, (B, 2 * h, 2 * w, C)).copy_(y)
+
+    # ---- AREA_DOWN -------------------------------------------------------------------
+    def _op_5(self, flags, i, f, p):
+        B, H, W, C, ldx, ldy, r, Cz = i[:8]
+        x = view(p[0], F32 if flags & 1 else BF16, (B, H, W, C), (H * W * ldx, W * ldx, ldx, 1)).float()
+        y = F.avg_pool2d(x.permute(0, 3, 1, 2), r).permute(0, 2, 3, 1)
+        oh, ow = H // r, W // r
+        out = view(p[1], BF16, (B, oh, ow, max(C, Cz)), (oh * ow * ldy, ow * ldy, ldy, 1))
+        out[..., :C] = y.to(torch.bfloat16)
+        if (flags & 1) and Cz > C:
+            out[..., C:Cz] = 0
+
+    # ---- MASK_DOWN --------------------------------------------------------------------
+    def _op_6(self, flags, i, f, p):
+        K, H, W, r = i[:4]
+        m = view(p[0], F32, (K, H, W))
+        m16 = F.avg_pool2d(m.unsqueeze(0), r)[0]
+        h, w = H // r, W // r
+        view(p[2], F32, (K, h, w)).copy_(m16)
+        out = torch.zeros(K, h, w, 8)
+        out[..., 0] = m16
+        out[..., 1] = (m16.sum(0, keepdim=True) - m16).clamp(0, 1)
+        view(p[1], BF16, (K, h, w, 8)).copy_(out)
+
+    # ---- GAP / ECA ----------------------------------------------------------------------
+    def _op_7(self, flags, i, f, p):
+        B, HW, C = i[:3]
+        view(p[1], F32, (B, C)).copy_(view(p[0], BF16, (B, HW, C)).float().mean(1))
+
+    def _op_8(self, flags, i, f, p):
+        B, HW, C = i[:3]
+        x = view(p[0], BF16, (B, HW, C)).float()
+        gap = view(p[1], F32, (B, C))
+        wk = view(p[2], F32, (5,))
+        sc = torch.sigmoid(F.conv1d(gap.view(B, 1, C), wk.view(1, 1, 5), None, 1, 2)).view(B, 1, C)
+        r = view(p[3], BF16, (B, HW, C)).float()
+        view(p[4], BF16, (B, HW, C)).copy_(x * sc + r)
+
+    # ---- GRU ------------------------------------------------------------------------------
+    def _op_9(self, flags, i, f, p):
+        n, C = i[:2]
+        v = view(p[0], F32, (n, 3 * C))
+        h = view(p[1], F32, (n, C))
+        fg, u, nv = torch.sigmoid(v[:, :C]), torch.sigmoid(v[:, C:2 * C]), torch.tanh(v[:, 2 * C:])
+        nh = fg * h * (1 - u) + u * nv
+        h.copy_(nh)
+        view(p[2], BF16, (n, C)).copy_(nh)
+
+    # ---- SEG_AGG / UP4_SOFTMAX ---------------------------------------------------------------
+    def _op_10(self, flags, i, f, p):
+        K, hw = i[:2]
+        pr = torch.sigmoid(view(p[0], F32, (K, hw)))
+        agg = view(p[1], F32, (K + 1, hw))
+        agg[0] = _clamp_logit(torch.prod(1 - pr, dim=0))
+        agg[1:] = _clamp_logit(pr)
+
+    def _op_11(self, flags, i, f, p):
+        P, h, w = i[:3]
+        up = _bilinear(view(p[0], F32, (P, h, w)), 0.25)
+        if p[2]:
+            view(p[2], F32, (P, 4 * h, 4 * w)).copy_(up)
+        view(p[1], F32, (P, 4 * h, 4 * w)).copy_(torch.softmax(up, dim=0))
+
+    # ---- MASK_MERGE / AGG_SOFTMAX ----------------------------------------------------------------
+    def _op_12(self, flags, i, f, p):
+        h0, w0, H, W, pl, pt, Knew, Kold, nfloat = i[:9]
+        src = view(p[2], I32, (Knew,))
+        planes = view(p[3], F32, (Knew, H, W))
+        pred = view(p[1], F32, (Kold + 1, H, W)) if p[1] else None
+        if flags & 1:
+            fm = torch.zeros(nfloat, H, W)
+            fm[:, pt:pt + h0, pl:pl + w0] = view(p[0], F32, (nfloat, h0, w0))
+            covered = fm.max(0)[0] > 0.5
+        else:
+            idx = torch.zeros(H, W, dtype=torch.int32)
+            idx[pt:pt + h0, pl:pl + w0] = view(p[0], I32, (h0, w0))
+            covered = idx > 0
+        for t in range(Knew):
+            s = int(src[t])
+            if s >= 0:
+                planes[t] = fm[s] if flags & 1 else (idx == s).float()
+            elif pred is not None and t < Kold:
+                planes[t] = torch.where(covered, torch.zeros(()), pred[t + 1])
+            else:
+                planes[t] = 0
+
+    def _op_13(self, flags, i, f, p):
+        K, HW = i[:2]
+        pl = view(p[0], F32, (K, HW))
+        lg = torch.cat([_clamp_logit(torch.prod(1 - pl, dim=0, keepdim=True)), _clamp_logit(pl)], 0)
+        view(p[1], F32, (K + 1, HW)).copy_(torch.softmax(lg, dim=0))
+
+    # ---- LINEAR / LAYERNORM / QUERY_INIT ------------------------------------------------------------
+    def _op_14(self, flags, i, f, p):
+        M, N, Kd, ldx, ldy, add_rows = i[:6]
+        x = view(p[0], F32, (M, Kd), (ldx, 1)).clone()
+        if p[1]:
+            R = max(add_rows, 1)
+            xa = view(p[1], F32, (R, Kd))
+            x = x + xa[torch.arange(M) % R]
+        w = view(p[2], BF16, (N, Kd)).float()
+        y = x @ w.t()
+        if p[3]:
+            y = y + view(p[3], F32, (N,))
+        if flags & 1:
+            y = F.relu(y)
+        if p[4]:
+            y = y + view(p[4], F32, (M, N))
+        view(p[5], F32, (M, N), (ldy, 1)).copy_(y)
+
+    def _op_15(self, flags, i, f, p):
+        M, C = i[:2]
+        x = view(p[0], F32, (M, C)).clone()
+        view(p[3], F32, (M, C)).copy_(F.layer_norm(x, (C,), view(p[1], F32, (C,)), view(p[2], F32, (C,)), 1e-5))
+
+    def _op_16(self, flags, i, f, p):
+        rows, C = i[:2]
+        om = view(p[0], F32, (rows, C + 1))
+        view(p[1], F32, (rows, C)).copy_(om[:, :C] / (om[:, C:] + 1e-4))
+
+    # ---- AUX_MASK / attention ----------------------------------------------------------------------------
+    def _op_17(self, flags, i, f, p):
+        K, HW = i[:2]
+        pr = torch.sigmoid(view(p[0], F32, (K, HW)))
+        lg = torch.cat([_clamp_logit(torch.prod(1 - pr, dim=0, keepdim=True)), _clamp_logit(pr)], 0)
+        fg = lg[1:] >= lg.max(0, keepdim=True)[0]
+        view(p[1], U8, (K, HW)).copy_(fg.to(torch.uint8))
+        nfg = view(p[2], I32, (K,))
+        nfg += fg.sum(1).to(torch.int32)
+
+    def _op_18(self, flags, i, f, p):
+        K, Q, HW, C, heads, ldkv, voff = i[:7]
+        hd = C // heads
+        q = view(p[0], F32, (K, Q, C)).view(K, Q, heads, hd).transpose(1, 2)
+        k = view(p[1], BF16, (K, HW, C), (HW * ldkv, ldkv, 1)).float().view(K, HW, heads, hd).transpose(1, 2)
+        v = view(p[1] + 2 * voff, BF16, (K, HW, C), (HW * ldkv, ldkv, 1)).float().view(K, HW, heads, hd).transpose(1, 2)
+        fg = view(p[2], U8, (K, HW)).bool()
+        nfg = view(p[3], I32, (K,))
+        att = (q @ k.transpose(-1, -2)) / math.sqrt(hd)                 # [K,heads,Q,HW]
+        for kk in range(K):
+            n = int(nfg[kk])
+            if n != 0:
+                att[kk, :, :Q // 2, :] = att[kk, :, :Q // 2, :].masked_fill(~fg[kk], float('-inf'))
+            if n != HW:
+                att[kk, :, Q // 2:, :] = att[kk, :, Q // 2:, :].masked_fill(fg[kk], float('-inf'))
+        out = (att.softmax(-1) @ v).transpose(1, 2).reshape(K, Q, C)
+        view(p[4], F32, (K, Q, C)).copy_(out)
+
+    def _op_19(self, flags, i, f, p):
+        K, Q, C, heads = i[:4]
+        hd = C // heads
+        qk = view(p[0], F32, (K, Q, 2 * C))
+        q = qk[..., :C].reshape(K, Q, heads, hd).transpose(1, 2)
+        k = qk[..., C:].reshape(K, Q, heads, hd).transpose(1, 2)
+        v = view(p[1], F32, (K, Q, C)).view(K, Q, heads, hd).transpose(1, 2)
+        att = ((q @ k.transpose(-1, -2)) / math.sqrt(hd)).softmax(-1)
+        view(p[2], F32, (K, Q, C)).copy_((att @ v).transpose(1, 2).reshape(K, Q, C))
+
+    def _op_20(self, flags, i, f, p):
+        K, Q, HW, C, heads, ldq = i[:6]
+        hd = C // heads
+        q = view(p[0], BF16, (K, HW, C), (HW * ldq, ldq, 1)).float().view(K, HW, heads, hd).transpose(1, 2)
+        k = view(p[1], F32, (K, Q, C)).view(K, Q, heads, hd).transpose(1, 2)
+        v = view(p[2], F32, (K, Q, C)).view(K, Q, heads, hd).transpose(1, 2)
+        att = ((q @ k.transpose(-1, -2)) / math.sqrt(hd)).softmax(-1)
+        view(p[3], BF16, (K, HW, C)).copy_((att @ v).transpose(1, 2).reshape(K, HW, C))
+
+    # ---- SUMMARIZE / ADD_PE ---------------------------------------------------------------------------------
+    def _op_21(self, flags, i, f, p):
+        K, HW, C, Q = i[:4]
+        feat = view(p[0], BF16, (K, HW, C)).float()
+        wl = view(p[1], F32, (K, HW, Q))
+        m = view(p[2], F32, (K, HW)).unsqueeze(-1)
+        rep = torch.cat([m.expand(-1, -1, Q // 2), (1 - m).expand(-1, -1, Q // 2)], -1)
+        wgt = torch.sigmoid(wl) * rep
+        out = view(p[3], F32, (K, Q, C + 1))
+        out[..., :C] = torch.einsum('kpq,kpc->kqc', wgt, feat)
+        out[..., C] = wgt.sum(1)
+
+    def _op_22(self, flags, i, f, p):
+        B, n = i[:2]
+        x = view(p[0], BF16, (B, n)).float()
+        view(p[2], BF16, (B, n)).copy_(x + view(p[1], BF16, (n,)).float())
+
+    # ---- affinity -----------------------------------------------------------------------------------------------
+    def _op_23(self, flags, i, f, p):
+        n = i[0]
+        key = view(p[0], F32, (n, 64))
+        if flags & 1:
+            e = view(p[1], F32, (n, 64))
+            v = torch.cat([-e, 2 * key * e], 1)
+            view(p[4], F32, (n,)).copy_((e * key * key).sum(1))
+        else:
+            v = torch.cat([key * key, key], 1)
+            view(p[4], F32, (n,)).copy_(view(p[1], F32, (n,)) * 0.125)
+        hi = v.to(torch.bfloat16)
+        lo = (v - hi.float()).to(torch.bfloat16)
+        view(p[2], BF16, (n, 128)).copy_(hi)
+        view(p[3], BF16, (n, 128)).copy_(lo)
+
+    @staticmethod
+    def _ranges(i):
+        nr = i[2]
+        return [(i[3 + 2 * r], i[4 + 2 * r]) for r in range(nr)]
+
+    def _scores(self, i, p):
+        """[(slot indices, S[n_r, HW])] per range, computed like the kernel (3-term split bf16)."""
+        HW = i[0]
+        Bh = view(p[3], BF16, (HW, 128)).float()
+        Bl = view(p[4], BF16, (HW, 128)).float()
+        c = view(p[5], F32, (HW,))
+        out = []
+        for (s, n) in self._ranges(i):
+            Ah = view(p[0] + 2 * 128 * s, BF16, (n, 128)).float()
+            Al = view(p[1] + 2 * 128 * s, BF16, (n, 128)).float()
+            sc = view(p[2] + 4 * s, F32, (n,))
+            acc = (Ah @ Bl.t() + Al @ Bh.t()) + Ah @ Bh.t()
+            out.append((torch.arange(s, s + n), sc[:, None] * (acc - c[None, :])))
+        return out
+
+    def _op_24(self, flags, i, f, p):
+        HW, HWp = i[0], i[1]
+        G, cap, mode = i[9], i[10], i[11]
+        sc = self._scores(i, p)
+        if mode == 0:
+            gmax = view(p[6], F32, (G, HWp))
+            g = 0
+            for (_, S) in sc:
+                n = S.shape[0]
+                T = -(-n // 16)
+                Sp = torch.full((T * 16, HW), float('-inf'))
+                Sp[:n] = S
+                gmax[g:g + T, :HW] = Sp.view(T, 16, HW).max(1)[0]
+                g += T
+        else:
+            tau = view(p[6], F32, (HW,))
+            thr = tau - tau.abs() * 1e-6 - 1e-30
+            thr = torch.where(torch.isinf(tau), torch.full_like(tau, float('-inf')), thr)
+            cv = view(p[7], F32, (HW, cap))
+            ci = view(p[8], I32, (HW, cap))
+            cnt = view(p[9], I32, (HW,))
+            for (slots, S) in sc:
+                for j in range(HW):
+                    sel = torch.nonzero(S[:, j] >= thr[j]).flatten()
+                    c0 = int(cnt[j])
+                    m = min(len(sel), max(cap - c0, 0))
+                    cv[j, c0:c0 + m] = S[sel[:m], j]
+                    ci[j, c0:c0 + m] = slots[sel[:m]].to(torch.int32)
+                    cnt[j] = c0 + len(sel)
+
+    def _op_25(self, flags, i, f, p):
+        HW, HWp, G, k = i[:4]
+        gmax = view(p[0], F32, (G, HWp))[:, :HW]
+        tau = view(p[1], F32, (HW,))
+        if G < k:
+            tau.fill_(float('-inf'))
+        else:
+            tau.copy_(gmax.topk(k, dim=0)[0][-1])
+
+    def _op_26(self, flags, i, f, p):
+        HW, cap, topk, K, CV = i[:5]
+        cv = view(p[0], F32, (HW, cap))
+        ci = view(p[1], I32, (HW, cap))
+        cnt = view(p[2], I32, (HW,))
+        vptrs = view(p[3], U64, (K,))
+        usage = p[4]
+        out = view(p[5], BF16, (K, HW, CV))
+        for j in range(HW):
+            n = min(int(cnt[j]), cap)
+            if int(cnt[j]) > cap:
+                view(p[6], I32, (1,))[0] += 1
+            v, idx = cv[j, :n], ci[j, :n].long()
+            # descending by value, ties -> lower slot
+            order = sorted(range(n), key=lambda t: (-float(v[t]), int(idx[t])))[:topk]
+            order = torch.tensor(order, dtype=torch.long)
+            sv, si = v[order], idx[order]
+            w = torch.exp(sv - sv[0])
+            w = w / w.sum()
+            if usage:
+                u = view(usage, F32, (int(si.max()) + 1,))
+                u.index_add_(0, si, w)
+            for o in range(K):
+                V = view(int(vptrs[o]), BF16, (int(si.max()) + 1, CV)).float()
+                out[o, j] = (w[:, None] * V[si]).sum(0).to(torch.bfloat16)
+
+    # ---- misc --------------------------------------------------------------------------------------------------------
+    def _op_27(self, flags, i, f, p):
+        view(p[0], I32, (i[0],)).fill_(i[1])
+
+    def _op_28(self, flags, i, f, p):
+        rows, rb, ss, ds = i[:4]
+        src = view(p[0], U8, (rows, rb), (ss, 1)).clone()
+        view(p[1], U8, (rows, rb), (ds, 1)).copy_(src)
+
+    def _op_29(self, flags, i, f, p):
+        n = i[0]
+        y = view(p[1], F32, (n,))
+        y += f[0] * view(p[0], F32, (n,))
+
+    def _op_30(self, flags, i, f, p):
+        life = view(p[0], F32, (i[0],))
+        life += 1
+
+    def _op_31(self, flags, i, f, p):
+        n, k = i[:2]
+        u = view(p[0], F32, (n,)) / view(p[1], F32, (n,))
+        order = sorted(range(n), key=lambda t: (-float(u[t]), t))[:k]
+        view(p[2], I32, (k,)).copy_(torch.tensor(order, dtype=torch.int32))
+
+    def _op_32(self, flags, i, f, p):
+        k, rb, ss, ds = i[:4]
+        order = view(p[1], I32, (k,)).long()
+        nsrc = int(order.max()) + 1
+        src = view(p[0], U8, (nsrc, rb), (ss, 1))
+        view(p[2], U8, (k, rb), (ds, 1)).copy_(src[order])
+
+    def _op_33(self, flags, i, f, p):
+        n, P = i[:2]
+        ck, cs = view(p[0], F32, (n, 64)), view(p[1], F32, (n,))
+        pk, pe = view(p[2], F32, (P, 64)), view(p[3], F32, (P, 64))
+        a_sq = (ck * ck) @ pe.t()
+        two_ab = 2 * (ck @ (pk * pe).t())
+        b_sq = (pe * pk * pk).sum(1)[None, :]
+        sim = (-a_sq + two_ab - b_sq) * cs[:, None] * 0.125           # [n,P]
+        view(p[4], F32, (P, n)).copy_(torch.softmax(sim, dim=0).t())
+
+    def _op_34(self, flags, i, f, p):
+        n, P, C, ldv, ldo = i[:5]
+        aff = view(p[0], F32, (P, n))
+        dt = F32 if flags & 1 else BF16
+        V = view(p[1], dt, (n, C), (ldv, 1)).float()
+        view(p[2], dt, (P, C), (ldo, 1)).copy_(aff @ V)
+
+    def _op_35(self, flags, i, f, p):
+        n = i[0]
+        if flags & 1:
+            view(p[1], F32, (n,)).copy_(view(p[0], BF16, (n,)).float())
+        else:
+            view(p[1], BF16, (n,)).copy_(view(p[0], F32, (n,)))
