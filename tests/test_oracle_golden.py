@@ -65,11 +65,11 @@ def test_oracle_matches_reference_trajectory(name, oracle_net):
         # semantic difference: frames 0..38 incl. 9 consolidations and 2 prunings agree to fp16 storage precision)
         tol = 5e-2 if (name == 'small_lt' and t >= 39) else 2e-3
         assert err < tol, (name, t, err)
-        # argmax identical wherever the reference's top-1/top-2 margin is meaningful
-        am = p.argmax(0).to(torch.uint8).numpy()
-        if bytes(hashlib.md5(am.tobytes()).digest()) != bytes(gold[f'md5_{t}'].tobytes()):
-            hist = np.bincount(am.ravel(), minlength=p.shape[0])
-            assert np.abs(hist - gold[f'hist_{t}']).sum() <= (0.05 if tol > 1e-2 else 0.002) * am.size, (name, t)
+        # argmax identical wherever the reference's top-1/top-2 margin is meaningful (objects are nearly tied
+        # under random weights, so raw argmax maps are not comparable)
+        margin = torch.from_numpy(gold[f'margin_{t}'].astype(np.float32))
+        conf = margin > 4 * tol
+        assert bool((got.argmax(0) == ref.argmax(0))[conf].all()), (name, t)
 
 
 def test_oracle_matches_reference_stages(oracle_net):
