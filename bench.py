@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py -- frames/sec of the Cutie per-frame hot path (InferenceCore.step) on MI355X.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric "frames/sec (480p, 3 objects)"): synthetic 854x480
+clip, 3 objects, long-term memory enabled, eval_config defaults (mem_every=5, top_k=30), bf16 storage / fp32
+accumulate, seeded random-init weights (no checkpoint offline).  One step = one propagated frame through
+InferenceCore.step with the frame already resident in HBM; the FPS definition mirrors the reference's
+cutie/eval_vos.py:126-145,165-167 (time around processor.step only).  With N GPUs each rank runs its own clip
+(clip sharding: weak scaling, no collective on the data path; the final gather of per-rank times is RCCL).
+
+One JSON line is printed by rank 0.  Extra objects:
+  roofline           dominant kernel family (implicit-GEMM conv on MFMA): algorithmic flops of the conv launches
+                     of the timed frames / their device time, measured live with hipEvents on the launch stream
+  roofline_affinity  the fused affinity read-out (similarity + top-k + softmax + V read-out) credited with the
+                     reference's dense algorithmic flops (256+512K)*N*HW  
+  cpu_baseline       the oracle (torch-fp32 restatement of the reference, "port") timed on this box's host cores
+                     on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0        # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--objects', type=int, default=3)
+    ap.add_argument('--height', type=int, default=480)
+    ap.add_argument('--width', type=int, default=854)
+    ap.add_argument('--no-long-term', action='store_true')
+    ap.add_argument('--preroll', type=int, default=300,
+                    help='untimed frames run before the warm-up so the memory bank is in its steady-state size')
+    ap.add_argument('--cpu-frames', type=int, default=12, help='frames of the CPU baseline sample (0 = skip)')
+    ap.add_argument('--no-roofline', action='store_true')
+    return ap.parse_args()
+
+
+class Recorder:
+    """Wraps the executor to capture the descriptor arrays of one frame (for the per-kernel timing)."""
+
+    def __init__(self, ex):
+        self.ex, self.rec, self.on = ex, [], False
+        self.is_mock = ex.is_mock
+
+    def run(self, arr):
+        if self.on:
+            self.rec.append(arr.copy())
+        self.ex.run(arr)
+
+    def stream(self):
+        return self.ex.stream()
+
+
+def conv_flops(arr):
+    from cutie_amd import ops as O
+    f = 0.0
+    for r in arr:
+        if r['kind'] == O.CONV:
+            i = r['i']
+            M = int(i[0]) * int(i[7]) * int(i[8])
+            f += 2.0 * M * int(i[9]) * int(i[11]) * int(i[12]) * int(i[18])
+    return f
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    from cutie_amd import _lib, ops as O
+    from cutie_amd.config import default_config
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.model.cutie import CUTIE
+    from cutie_amd.utils.synth import SyntheticClip
+
+    K = args.objects
+    use_lt = not args.no_long_term
+    cfg = default_config(use_long_term=use_lt)
+    torch.manual_seed(0)
+    net = CUTIE(cfg).to(dev).eval()
+    try:                                                   # same deterministic weights as the parity tests
+        from oracle.weights import make_state_dict
+        sd = make_state_dict(seed=0)
+        net.load_weights(sd)
+    except ImportError:
+        sd = None
+    rec = Recorder(_lib.get_executor())
+    _lib.set_executor_for_testing(rec)                     # only a recording shim around the HIP executor
+
+    clip = SyntheticClip(args.height, args.width, K, 128, seed=1 + rank)       # one clip per rank
+    frames = torch.stack([clip.frame(t) for t in range(128)]).to(dev)           # resident in HBM (630 MB)
+    mask = clip.first_mask().to(dev)
+    proc = InferenceCore(net, cfg=cfg)
+    with torch.inference_mode():
+        proc.step(frames[0], mask, objects=clip.objects)
+        t_idx = 1
+        for _ in range(args.preroll + args.warmup):
+            proc.step(frames[t_idx % 128])
+            t_idx += 1
+        torch.cuda.synchronize()
+        n_tok_start = sum(b.size() for b in proc.memory.buckets.values())
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            proc.step(frames[t_idx % 128])
+            t_idx += 1
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        n_tok_end = sum(b.size() for b in proc.memory.buckets.values())
+
+        # ---- per-kernel-family timing on the launch stream (hipEvents inside cutie_time_ops) ----
+        roof = roof_aff = None
+        if not args.no_roofline and rank == 0:
+            conv_t = conv_f = aff_t = aff_f = 0.0
+            nrec = 5                                        # one mem_every cycle: 4 plain + 1 memory frame
+            for _ in range(nrec):
+                rec.rec, rec.on = [], True
+                proc.step(frames[t_idx % 128])
+                t_idx += 1
+                rec.on = False
+                torch.cuda.synchronize()
+                allops = np.concatenate(rec.rec)
+                convs = allops[allops['kind'] == O.CONV]
+                # the affinity plan = [memset(count), score/0, select, score/1, (usage ticks), readout]; keep the memset so the
+                # candidate lists are rebuilt from empty on every timed replay
+                affs = np.concatenate([a[a['kind'] != O.USAGE_TICK] for a in rec.rec if (a['kind'] == O.AFF_SCORE).any()])
+                conv_t += rec.ex.time_ops(convs, 3) * 1e-3
+                conv_f += conv_flops(convs)
+                aff_t += rec.ex.time_ops(affs, 3) * 1e-3
+                HW = (proc.memory.H * proc.memory.W)
+                for b in proc.memory.buckets.values():
+                    aff_f += (256 + 512 * len(b.objects)) * float(b.size()) * HW
+            n_conv = int((allops['kind'] == O.CONV).sum())
+            roof = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<*> (all conv launches of a frame)',
+                    'achieved': round(conv_f / conv_t / 1e12, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(conv_f / conv_t / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                    'gflop_per_frame': round(conv_f / nrec / 1e9, 1), 'ms_per_frame': round(conv_t / nrec * 1e3, 3),
+                    'launches_per_frame': n_conv}
+            roof_aff = {'bound': 'mfma', 'kernel': 'aff_score x2 + aff_select + aff_readout',
+                        'achieved': round(aff_f / aff_t / 1e12, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(aff_f / aff_t / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                        'algorithmic_gflop_per_frame': round(aff_f / nrec / 1e9, 1), 'ms_per_frame': round(aff_t / nrec * 1e3, 4),
+                        'memory_tokens': n_tok_end,
+                        'note': 'algorithmic = dense (256+512K)*N*HW of the reference; the kernels do the top-k readout sparsely'}
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    tmax = float(t.item())
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_frames > 0 and sd is not None:
+        from oracle.inference import OracleProcessor, DEFAULT_CFG
+        from oracle.net import OracleNet
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        onet = OracleNet(sd)
+        ocfg = dict(DEFAULT_CFG)
+        ocfg['use_long_term'] = use_lt
+        oproc = OracleProcessor(onet, ocfg)
+        with torch.inference_mode():
+            oproc.step(clip.frame(0), clip.first_mask(), objects=clip.objects)
+            oproc.step(clip.frame(1))                      # warm-up (lazy inits)
+            c0 = time.perf_counter()
+            for tt in range(2, 2 + args.cpu_frames):
+                oproc.step(clip.frame(tt))
+            cpu_t = time.perf_counter() - c0
+        cpu = {'value': round(args.cpu_frames / cpu_t, 3), 'unit': 'frames/s', 'cores': torch.get_num_threads(),
+               'kind': 'port',
+               'sample': f'{args.cpu_frames} propagated frames (frames 2..{1 + args.cpu_frames}) of the same {args.width}x{args.height} '
+                         f'{K}-object clip, oracle (torch fp32 restatement of the reference) on host cores, frame 0/1 excluded'}
+
+    if rank == 0:
+        fps = world * args.steps / tmax
+        out = {
+            'metric': 'frames/sec (480p, 3 objects)', 'value': round(fps, 2), 'unit': 'frames/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(tmax / args.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'synthetic {args.width}x{args.height} {K}-object clip, long_term={use_lt}, one clip per GPU '
+                                   f'(SURVEY 8d C2/C3), eval_config defaults (mem_every=5, top_k=30), random-init weights',
+                       'preroll_frames': args.preroll, 'memory_tokens_start': n_tok_start, 'memory_tokens_end': n_tok_end,
+                       'parallelism': f'clip-shard x{world}', 'accumulate': 'fp32'},
+        }
+        if roof is not None:
+            out['roofline'] = roof
+            out['roofline_affinity'] = roof_aff
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
+            out['speedup_vs_cpu'] = round(fps / cpu['value'], 1)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -150,7 +150,7 @@ class InferenceCore:
         H, W, self.pad = pad_geometry(h0, w0, 16)
         pl, pt = self.pad[0], self.pad[2]
         # zero-padding to /16 is fused into the first kernel of each plan: hand over the raw frame + geometry
-        image = image.to(F32).contiguous()
+        image = image.to(device=self.network.device, dtype=F32).contiguous()
         image._cutie_raw = (h0, w0, H, W, pl, pt)
 
         is_mem_frame = ((self.curr_ti - self.last_mem_ti >= self.mem_every) or (mask is not None)) and (not end)

@@ -273,7 +273,10 @@ class CUTIE(nn.Module):
 
     def engine(self) -> Engine:
         if self._eng is None:
-            _lib.get_executor()           # fails loudly when the HIP library / device is missing
+            ex = _lib.get_executor()      # fails loudly when the HIP library / device is missing
+            if not ex.is_mock and self.device.type != 'cuda':
+                raise RuntimeError('CUTIE parameters live on %s: move the module to the MI355X first (.cuda()); '
+                                   'cutie_amd has no CPU path' % self.device)
             self._eng = Engine(self.state_dict(), self.model_cfg, self.device)
         return self._eng
 

@@ -11,11 +11,12 @@ BN_EPS = 1e-5
 
 class PackedConv:
     """bf16 weight [CoutPad, Kpad] with k = (kh*KW + kw)*CinPadded + c; f32 bias [Cout] or None."""
-    __slots__ = ('weight', 'bias', 'cout', 'cin_padded', 'kh', 'kw', 'kpad')
+    __slots__ = ('weight', 'bias', 'cout', 'cin_padded', 'kh', 'kw', 'kpad', 'cin_real')
 
-    def __init__(self, weight, bias, cout, cin_padded, kh, kw, kpad):
+    def __init__(self, weight, bias, cout, cin_padded, kh, kw, kpad, cin_real=None):
         self.weight, self.bias, self.cout, self.cin_padded = weight, bias, cout, cin_padded
         self.kh, self.kw, self.kpad = kh, kw, kpad
+        self.cin_real = cin_padded if cin_real is None else cin_real      # un-padded channels (flop accounting)
 
 
 class PackedLinear:
@@ -58,7 +59,7 @@ def pack_conv(w, bias, device, segs=None):
     packed = torch.zeros(coutpad, kpad)
     packed[:cout, :k] = flat
     return PackedConv(packed.to(torch.bfloat16).to(device).contiguous(),
-                      None if bias is None else bias.float().to(device).contiguous(), cout, cin_p, kh, kw, kpad)
+                      None if bias is None else bias.float().to(device).contiguous(), cout, cin_p, kh, kw, kpad, cin_real=cin)
 
 
 def pack_linear(w, bias, device):

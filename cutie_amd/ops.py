@@ -123,7 +123,7 @@ class OpList:
         if tile is None:
             tile = pick_tile(M, w.cout)
         return self.add(CONV, flags,
-                        [B, H, W, C1, C2, ldx1, ldx2, OH, OW, w.cout, ldy, w.kh, w.kw, stride, pad, ldr, w.kpad, tile],
+                        [B, H, W, C1, C2, ldx1, ldx2, OH, OW, w.cout, ldy, w.kh, w.kw, stride, pad, ldr, w.kpad, tile, w.cin_real],
                         [], [x1, x2, w.weight, w.bias, res, y])
 
     def maxpool(self, x, y, *, B, H, W, C, relu=False):

@@ -1,0 +1,494 @@
+"""Per-kernel parity on the MI355X: every op kind of include/cutie_hip.h is run through the HIP kernel (via the
+C ABI, cutie_exec) and through the torch interpreter of the same descriptor (tests/mock_exec.py) on identical
+seeded inputs.  Tolerances: bf16 outputs within 2 bf16 ulps of the tensor scale (accumulation order differs),
+fp32 outputs rtol 2e-3 (bf16 operands, fp32 accumulate), integer / index outputs bit-exact.
+"""
+import math
+import numpy as np
+import pytest
+import torch
+
+from cutie_amd import _lib, ops as O
+from cutie_amd.model.weights import pack_conv, pack_linear
+from mock_exec import MockExecutor
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def run_both(build, seed=0):
+    """build(dev, g) -> (OpList, {name: output tensor}).  Returns (hip outputs, mock outputs) on CPU."""
+    res = []
+    for dev, ex in (('cuda', _lib.HipExecutor()), ('cpu', MockExecutor())):
+        ol, outs = build(dev, _gen(seed))
+        arr = ol.finalize()
+        ex.run(arr)
+        if dev == 'cuda':
+            torch.cuda.synchronize()
+        res.append({k: v.detach().cpu().clone() for k, v in outs.items()})
+    return res
+
+
+def check(hip, ref, name='', rtol=None):
+    for k in ref:
+        a, b = hip[k], ref[k]
+        assert a.shape == b.shape, (name, k, a.shape, b.shape)
+        if not b.is_floating_point():
+            assert torch.equal(a, b), (name, k, 'integer mismatch', int((a != b).sum()))
+            continue
+        tol = rtol if rtol is not None else (1.6e-2 if b.dtype == BF16 else 2e-3)
+        a, b = a.float(), b.float()
+        assert torch.isfinite(a).all(), (name, k, 'non-finite output')
+        scale = float(b.abs().max().clamp(min=1e-6))
+        err = float((a - b).abs().max())
+        if err > tol * scale:
+            idx = np.unravel_index(int((a - b).abs().argmax()), a.shape)
+            raise AssertionError(f'{name}:{k} max|d|={err:.4g} scale={scale:.4g} tol={tol} at {idx} hip={float(a[idx])} ref={float(b[idx])}')
+
+
+def rnd(g, shape, dtype=BF16, dev='cpu', scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(dev)
+
+
+# ---- CONV ------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # B,H,W,C1,Cout,k,stride, extras
+    dict(B=1, H=30, W=54, C1=512, Cout=256, k=1),
+    dict(B=1, H=30, W=54, C1=256, Cout=1024, k=1, res=True, act=O.ACT_RELU),
+    dict(B=1, H=60, W=108, C1=128, Cout=128, k=3, stride=2, act=O.ACT_RELU),
+    dict(B=1, H=64, W=96, C1=8, Cout=64, k=7, stride=2, pad=3, act=O.ACT_RELU),
+    dict(B=3, H=30, W=54, C1=256, Cout=256, k=3, relu_in=True, act=O.ACT_RELU),
+    dict(B=3, H=30, W=54, C1=256, Cout=256, k=1, res=True, res_bcast=True),
+    dict(B=3, H=30, W=54, C1=256, C2=8, Cout=256, k=1, res=True),
+    dict(B=2, H=30, W=54, C1=256, C2=256, Cout=768, k=3, out_f32=True),
+    dict(B=3, H=24, W=40, C1=128, Cout=1, k=3, relu_in=True, out_f32=True),
+    dict(B=1, H=30, W=54, C1=256, Cout=1, k=3, out_f32=True, act=O.ACT_SQ1),
+    dict(B=1, H=30, W=54, C1=256, Cout=64, k=3, out_f32=True, act=O.ACT_SIGMOID),
+    dict(B=3, H=30, W=54, C1=256, Cout=16, k=1, out_f32=True),
+    dict(B=2, H=17, W=23, C1=64, Cout=96, k=3),                       # ragged M and Cout
+    dict(B=1, H=120, W=216, C1=64, Cout=64, k=1, act=O.ACT_RELU),
+    dict(B=1, H=9, W=7, C1=32, Cout=40, k=3, stride=2),
+]
+
+
+def _conv_build(c, tile):
+    def build(dev, g):
+        B, H, W, C1, Cout, k = c['B'], c['H'], c['W'], c['C1'], c['Cout'], c['k']
+        C2 = c.get('C2', 0)
+        stride, pad = c.get('stride', 1), c.get('pad', (k - 1) // 2)
+        OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        w = torch.randn(Cout, C1 + C2, k, k, generator=g) / math.sqrt((C1 + C2) * k * k)
+        b = torch.randn(Cout, generator=g) * 0.1
+        pc = pack_conv(w, b, dev, segs=[(C1, C1)] + ([(C2, C2)] if C2 else []))
+        x1 = rnd(g, (B, H, W, C1), dev=dev)
+        x2 = rnd(g, (B, H, W, C2), dev=dev) if C2 else None
+        res = rnd(g, (1 if c.get('res_bcast') else B, OH, OW, Cout), dev=dev) if c.get('res') else None
+        y = torch.zeros((B, OH, OW, Cout), dtype=F32 if c.get('out_f32') else BF16, device=dev)
+        ol = O.OpList()
+        ol.conv(x1, pc, y, B=B, H=H, W=W, C1=C1, ldx1=C1, OH=OH, OW=OW, ldy=Cout, stride=stride, pad=pad, x2=x2, C2=C2,
+                ldx2=C2, res=res, ldr=Cout, res_bcast=c.get('res_bcast', False), relu_in=c.get('relu_in', False),
+                act=c.get('act', O.ACT_NONE), out_f32=c.get('out_f32', False), tile=tile)
+        return ol, {'y': y}
+    return build
+
+
+@pytest.mark.parametrize('ci', range(len(CONV_CASES)))
+def test_conv_auto_tile(ci):
+    hip, ref = run_both(_conv_build(CONV_CASES[ci], None), seed=ci)
+    check(hip, ref, f'conv[{ci}]')
+
+
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('ci', [0, 2, 4, 6, 12, 14])
+def test_conv_every_tile(ci, tile):
+    c = CONV_CASES[ci]
+    hip, ref = run_both(_conv_build(c, tile), seed=100 + ci)
+    check(hip, ref, f'conv[{ci}] tile{tile}')
+
+
+def test_conv_strided_channel_slices():
+    """ldx / ldy larger than C (reading / writing channel slices of wider NHWC buffers)."""
+    def build(dev, g):
+        B, H, W = 2, 12, 20
+        big = rnd(g, (B, H, W, 96), dev=dev)
+        w = torch.randn(48, 64, 1, 1, generator=g) / 8
+        pc = pack_conv(w, None, dev)
+        out = torch.zeros((B, H, W, 80), dtype=BF16, device=dev)
+        ol = O.OpList()
+        ol.conv(big.view(-1)[16:], pc, out.view(-1)[8:], B=B, H=H, W=W, C1=64, ldx1=96, OH=H, OW=W, ldy=80)
+        return ol, {'out': out}
+    hip, ref = run_both(build)
+    check(hip, ref, 'conv slices')
+
+
+# ---- elementwise family ------------------------------------------------------------------------------
+def test_maxpool():
+    for relu in (False, True):
+        def build(dev, g):
+            x = rnd(g, (2, 24, 36, 64), dev=dev)
+            y = torch.zeros((2, 12, 18, 64), dtype=BF16, device=dev)
+            ol = O.OpList()
+            ol.maxpool(x, y, B=2, H=24, W=36, C=64, relu=relu)
+            return ol, {'y': y}
+        check(*run_both(build), name=f'maxpool relu={relu}', rtol=1e-6)
+
+
+def test_img_prep():
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    for K in (0, 3):
+        def build(dev, g):
+            img = torch.rand((3, 30, 43), generator=g).to(dev)
+            H, W = 32, 48
+            masks = torch.rand((K, H, W), generator=g).to(dev) if K else None
+            y = torch.zeros((max(K, 1), H, W, 8), dtype=BF16, device=dev)
+            ol = O.OpList()
+            ol.img_prep(img, masks, y, h0=30, w0=43, H=H, W=W, pad_left=2, pad_top=1, K=max(K, 1), mean=mean, std=std)
+            return ol, {'y': y}
+        check(*run_both(build), name=f'img_prep K={K}')
+
+
+def test_upsample2x_add():
+    def build(dev, g):
+        x = rnd(g, (3, 7, 9, 128), dev=dev)
+        skip = rnd(g, (1, 14, 18, 128), dev=dev)
+        y = torch.zeros((3, 14, 18, 128), dtype=BF16, device=dev)
+        ol = O.OpList()
+        ol.upsample2x_add(x, skip, y, B=3, h=7, w=9, C=128)
+        return ol, {'y': y}
+    check(*run_both(build), name='upsample2x_add')
+
+
+def test_area_down():
+    def build(dev, g):
+        x = rnd(g, (2, 16, 24, 128), dev=dev)
+        y = torch.zeros((2, 4, 6, 128), dtype=BF16, device=dev)
+        lg = torch.randn((2, 16, 24), generator=g).to(dev)
+        y2 = torch.ones((2, 4, 6, 8), dtype=BF16, device=dev)
+        ol = O.OpList()
+        ol.area_down(x, y, B=2, H=16, W=24, C=128, ldx=128, ldy=128, r=4)
+        ol.area_down(lg, y2, B=2, H=16, W=24, C=1, ldx=1, ldy=8, r=4, f32_in=True, Cz=8)
+        return ol, {'y': y, 'y2': y2}
+    check(*run_both(build), name='area_down')
+
+
+def test_mask_down():
+    def build(dev, g):
+        m = torch.rand((3, 64, 96), generator=g).to(dev)
+        pair = torch.ones((3, 4, 6, 8), dtype=BF16, device=dev)
+        m16 = torch.zeros((3, 4, 6), dtype=F32, device=dev)
+        ol = O.OpList()
+        ol.mask_down(m, pair, m16, K=3, H=64, W=96)
+        return ol, {'pair': pair, 'm16': m16}
+    check(*run_both(build), name='mask_down', rtol=1e-2)
+
+
+def test_gap_eca():
+    def build(dev, g):
+        B, HW, C = 3, 1620, 256
+        x = rnd(g, (B, HW, C), dev=dev)
+        r = rnd(g, (B, HW, C), dev=dev)
+        gap = torch.zeros((B, C), dtype=F32, device=dev)
+        wk = (torch.randn(5, generator=g) * 0.6).to(dev)
+        y = torch.zeros((B, HW, C), dtype=BF16, device=dev)
+        ol = O.OpList()
+        ol.gap(x, gap, B=B, HW=HW, C=C)
+        ol.eca_apply(x, gap, wk, r, y, B=B, HW=HW, C=C)
+        return ol, {'gap': gap, 'y': y}
+    hip, ref = run_both(build)
+    check(hip, ref, 'gap/eca')
+
+
+def test_gru():
+    def build(dev, g):
+        n, C = 500, 256
+        v = (torch.randn((n, 3 * C), generator=g) * 2).to(dev)
+        h = torch.randn((n, C), generator=g).to(dev)
+        hb = torch.zeros((n, C), dtype=BF16, device=dev)
+        ol = O.OpList()
+        ol.gru(v, h, hb, n=n, C=C)
+        return ol, {'h': h, 'hb': hb}
+    check(*run_both(build), name='gru', rtol=1e-3)
+
+
+def test_seg_epilogue():
+    def build(dev, g):
+        K, h, w = 3, 12, 20
+        lg = (torch.randn((K, h, w), generator=g) * 3).to(dev)
+        agg = torch.zeros((K + 1, h, w), dtype=F32, device=dev)
+        prob = torch.zeros((K + 1, 4 * h, 4 * w), dtype=F32, device=dev)
+        lup = torch.zeros((K + 1, 4 * h, 4 * w), dtype=F32, device=dev)
+        ol = O.OpList()
+        ol.seg_agg(lg, agg, K=K, hw=h * w)
+        ol.up4_softmax(agg, prob, lup, P=K + 1, h=h, w=w)
+        return ol, {'agg': agg, 'prob': prob, 'lup': lup}
+    check(*run_both(build), name='seg epilogue', rtol=2e-4)
+
+
+def test_mask_merge_and_agg():
+    for fmode in (False, True):
+        def build(dev, g):
+            h0, w0, H, W = 30, 43, 32, 48
+            Kold, Knew = 2, 4
+            if fmode:
+                inmask = torch.rand((5, h0, w0), generator=g).to(dev)
+                src = torch.tensor([-1, 3, 1, 4], dtype=torch.int32).to(dev)
+            else:
+                inmask = torch.randint(0, 6, (h0, w0), generator=g).to(torch.int32).to(dev)
+                src = torch.tensor([-1, 5, 2, 4], dtype=torch.int32).to(dev)
+            pred = torch.softmax(torch.randn((Kold + 1, H, W), generator=g), 0).to(dev)
+            planes = torch.zeros((Knew, H, W), dtype=F32, device=dev)
+            prob = torch.zeros((Knew + 1, H, W), dtype=F32, device=dev)
+            ol = O.OpList()
+            ol.mask_merge(inmask, pred, src, planes, h0=h0, w0=w0, H=H, W=W, pad_left=2, pad_top=1, Knew=Knew, Kold=Kold,
+                          nfloat=5 if fmode else 0, float_mode=fmode)
+            ol.agg_softmax(planes, prob, K=Knew, HW=H * W)
+            return ol, {'planes': planes, 'prob': prob}
+        check(*run_both(build), name=f'mask_merge float={fmode}', rtol=2e-4)
+
+
+def test_linear_layernorm_queryinit():
+    def build(dev, g):
+        M, Kd, N = 48, 256, 2048
+        x = torch.randn((M, Kd), generator=g).to(dev)
+        xa = torch.randn((M, Kd), generator=g).to(dev)
+        pl = pack_linear(torch.randn((N, Kd), generator=g) / 16, torch.randn(N, generator=g) * 0.1, dev)
+        y = torch.zeros((M, N), dtype=F32, device=dev)
+        pl2 = pack_linear(torch.randn((Kd, N), generator=g) / 45, torch.randn(Kd, generator=g) * 0.1, dev)
+        res = torch.randn((M, Kd), generator=g).to(dev)
+        y2 = torch.zeros((M, Kd), dtype=F32, device=dev)
+        ln = torch.zeros((M, Kd), dtype=F32, device=dev)
+        gw, gb = torch.rand(Kd, generator=g).to(dev) + 0.5, torch.randn(Kd, generator=g).to(dev) * 0.1
+        om = torch.rand((M, Kd + 1), generator=g).to(dev) + 0.1
+        qi = torch.zeros((M, Kd), dtype=F32, device=dev)
+        ol = O.OpList()
+        ol.linear(x, pl, y, M=M, x_add=xa, add_rows=M, relu=True)
+        ol.linear(y, pl2, y2, M=M, res=res)
+        ol.layernorm(y2, gw, gb, ln, M=M, C=Kd)
+        ol.query_init(om, qi, rows=M, C=Kd)
+        return ol, {'y': y, 'y2': y2, 'ln': ln, 'qi': qi}
+    check(*run_both(build), name='linear/ln', rtol=2e-3)
+
+
+def test_linear_broadcast_add_rows():
+    def build(dev, g):
+        M, Kd, N = 32, 256, 512
+        x = torch.randn((M, Kd), generator=g).to(dev)
+        xa = torch.randn((16, Kd), generator=g).to(dev)
+        pl = pack_linear(torch.randn((N, Kd), generator=g) / 16, None, dev)
+        y = torch.zeros((M, N), dtype=F32, device=dev)
+        ol = O.OpList()
+        ol.linear(x, pl, y, M=M, x_add=xa, add_rows=16)
+        return ol, {'y': y}
+    check(*run_both(build), name='linear add_rows', rtol=2e-3)
+
+
+# ---- attention -----------------------------------------------------------------------------------------
+def _aux_inputs(g, K, HW, mode):
+    lg = torch.randn((K, HW), generator=g) * 2
+    if mode == 'nofg':
+        lg[0] = -20.0          # object 0 never foreground  -> fg queries of object 0 get un-blocked
+    if mode == 'allfg':
+        lg[:] = -20.0
+        lg[1] = 20.0           # object 1 foreground everywhere -> its bg queries get un-blocked
+    return lg
+
+
+@pytest.mark.parametrize('mode', ['mixed', 'nofg', 'allfg'])
+def test_aux_mask_and_q2p(mode):
+    def build(dev, g):
+        K, Q, HW, C, heads = 3, 16, 1620, 256, 8
+        lg = _aux_inputs(g, K, HW, mode).to(dev)
+        fg = torch.zeros((K, HW), dtype=torch.uint8, device=dev)
+        nfg = torch.zeros((K,), dtype=torch.int32, device=dev)
+        q = torch.randn((K, Q, C), generator=g).to(dev)
+        kv = rnd(g, (K, HW, 3 * C), dev=dev)
+        y = torch.zeros((K, Q, C), dtype=F32, device=dev)
+        ol = O.OpList()
+        ol.aux_mask(lg, fg, nfg, K=K, HW=HW)
+        ol.attn_q2p(q, kv, fg, nfg, y, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C)
+        return ol, {'fg': fg, 'nfg': nfg, 'y': y}
+    check(*run_both(build), name=f'aux_mask/q2p {mode}', rtol=3e-3)
+
+
+def test_attn_self_and_p2q():
+    def build(dev, g):
+        K, Q, HW, C, heads = 3, 16, 700, 256, 8
+        qk = torch.randn((K, Q, 2 * C), generator=g).to(dev)
+        v = torch.randn((K, Q, C), generator=g).to(dev)
+        y = torch.zeros((K, Q, C), dtype=F32, device=dev)
+        qp = rnd(g, (K, HW, 3 * C), dev=dev)
+        kq = torch.randn((K, Q, C), generator=g).to(dev)
+        y2 = torch.zeros((K, HW, C), dtype=BF16, device=dev)
+        ol = O.OpList()
+        ol.attn_self(qk, v, y, K=K, Q=Q, C=C, heads=heads)
+        ol.attn_p2q(qp.view(-1)[2 * C:], kq, v, y2, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C)
+        return ol, {'y': y, 'y2': y2}
+    check(*run_both(build), name='attn self/p2q', rtol=None)
+
+
+def test_summarize_add_pe():
+    def build(dev, g):
+        K, HW, C, Q = 3, 1620, 256, 16
+        feat = rnd(g, (K, HW, C), dev=dev)
+        wl = torch.randn((K, HW, Q), generator=g).to(dev)
+        m16 = torch.rand((K, HW), generator=g).to(dev)
+        y = torch.zeros((K, Q, C + 1), dtype=F32, device=dev)
+        pe = rnd(g, (HW * C,), dev=dev)
+        z = torch.zeros((K, HW * C), dtype=BF16, device=dev)
+        ol = O.OpList()
+        ol.summarize(feat, wl, m16, y, K=K, HW=HW, C=C, Q=Q)
+        ol.add_pe(feat, pe, z, B=K, n=HW * C)
+        return ol, {'y': y, 'z': z}
+    check(*run_both(build), name='summarize/add_pe', rtol=2e-3)
+
+
+# ---- affinity pipeline ---------------------------------------------------------------------------------------
+def _affinity_build(HW, ranges, slots, K, top_k, with_usage, dup=False):
+    def build(dev, g):
+        CV, cap = 256, 1024
+        HWp = -(-HW // 64) * 64
+        mkey = torch.randn((slots, 64), generator=g) * 0.8
+        if dup:                                    # duplicated memory frames -> exact score ties
+            half = slots // 2
+            mkey[half:2 * half] = mkey[:half]
+        mshr = torch.rand((slots,), generator=g) * 2 + 1
+        qkey = torch.randn((HW, 64), generator=g) * 0.8
+        qsel = torch.rand((HW, 64), generator=g)
+        mkey, mshr, qkey, qsel = mkey.to(dev), mshr.to(dev), qkey.to(dev), qsel.to(dev)
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        Ahi, Alo, scale = z((slots + 16, 128), BF16), z((slots + 16, 128), BF16), z((slots + 16,), F32)
+        Bhi, Blo, cq = z((HWp, 128), BF16), z((HWp, 128), BF16), z((HWp,), F32)
+        G = sum(-(-n // 16) for _, n in ranges if n > 0)
+        gmax, tau = z((G, HWp), F32), z((HW,), F32)
+        cval, cidx, count, ovf = z((HW, cap), F32), z((HW, cap), torch.int32), z((HW,), torch.int32), z((1,), torch.int32)
+        vals = [rnd(g, (slots + 16, CV), dev=dev) for _ in range(K)]
+        vptrs = torch.tensor([v.data_ptr() for v in vals], dtype=torch.int64).to(dev)
+        usage = z((slots + 16,), F32) if with_usage else None
+        y = z((K, HW, CV), BF16)
+        ol = O.OpList()
+        ol.keep += vals
+        ol.key_prep(mkey, mshr, Ahi, Alo, scale, n=slots, query=False)
+        ol.key_prep(qkey, qsel, Bhi, Blo, cq, n=HW, query=True)
+        ol.memset32(count, HW, 0)
+        common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=cap)
+        ol.aff_score(Ahi, Alo, scale, Bhi, Blo, cq, gmax, None, None, None, mode=0, **common)
+        ol.aff_select(gmax, tau, HW=HW, HWp=HWp, G=G, top_k=top_k)
+        ol.aff_score(Ahi, Alo, scale, Bhi, Blo, cq, tau, cval, cidx, count, mode=1, **common)
+        ol.aff_readout(cval, cidx, count, vptrs, usage, y, ovf, HW=HW, cap=cap, top_k=top_k, K=K, CV=CV)
+        outs = {'Ahi': Ahi, 'Alo': Alo, 'scale': scale, 'Bhi': Bhi, 'Blo': Blo, 'cq': cq, 'tau': tau, 'y': y, 'ovf': ovf,
+                'gmax': gmax[:, :HW], 'count': count}
+        if with_usage:
+            outs['usage'] = usage
+        # dense fp32 reference of the reference algorithm (memory_utils.py) for the oracle-level check
+        outs['_mkey'], outs['_mshr'], outs['_qkey'], outs['_qsel'] = mkey, mshr, qkey, qsel
+        for i, v in enumerate(vals):
+            outs[f'_v{i}'] = v
+        return ol, outs
+    return build
+
+
+@pytest.mark.parametrize('case', [
+    dict(HW=1620, ranges=[(0, 1620)], slots=1620, K=3, top_k=30, usage=False),
+    dict(HW=1620, ranges=[(0, 300), (1000, 1620), (3000, 4000)], slots=7100, K=2, top_k=30, usage=True),
+    dict(HW=48, ranges=[(0, 48)], slots=48, K=3, top_k=30, usage=True),               # G < top_k
+    dict(HW=100, ranges=[(0, 1003)], slots=1003, K=1, top_k=5, usage=False),           # ragged tail tile
+])
+def test_affinity_pipeline(case):
+    build = _affinity_build(case['HW'], case['ranges'], case['slots'], case['K'], case['top_k'], case['usage'])
+    hip, ref = run_both(build, seed=7)
+    exact = ['Ahi', 'Alo', 'Bhi', 'Blo']
+    for k in exact:
+        assert torch.equal(hip[k].view(torch.int16), ref[k].view(torch.int16)), k
+    check({k: hip[k] for k in ('scale', 'cq', 'tau', 'gmax')}, {k: ref[k] for k in ('scale', 'cq', 'tau', 'gmax')}, 'aff', rtol=1e-5)
+    assert int(hip['ovf']) == 0
+    check({'y': hip['y']}, {'y': ref['y']}, 'aff readout')
+    if case['usage']:
+        check({'usage': hip['usage']}, {'usage': ref['usage']}, 'aff usage', rtol=1e-4)
+    # and against the reference algorithm in dense fp32 (what the oracle computes)
+    from oracle.net import get_similarity, topk_softmax
+    HW, K = case['HW'], case['K']
+    slots = torch.cat([torch.arange(s, s + n) for s, n in case['ranges']])
+    sim = get_similarity(hip['_mkey'][slots].t().float(), hip['_mshr'][slots].float(), hip['_qkey'].t().float(), hip['_qsel'].t().float())
+    aff, usage = topk_softmax(sim, case['top_k'])
+    for o in range(K):
+        dense = (hip[f'_v{o}'][slots].float().t() @ aff).t()             # [HW,CV]
+        err = float((hip['y'][o].float() - dense).abs().max())
+        assert err < 2e-2 * float(dense.abs().max()), ('dense oracle', o, err)
+    if case['usage']:
+        u = torch.zeros_like(hip['usage'])
+        u[slots] = usage
+        assert float((hip['usage'] - u).abs().max()) < 1e-3
+
+
+def test_affinity_exact_ties_are_deterministic():
+    """Duplicated memory tokens give exactly tied scores; ties resolve to the lower slot, like the interpreter."""
+    build = _affinity_build(200, [(0, 800)], 800, 1, 30, False, dup=True)
+    hip, ref = run_both(build, seed=3)
+    check({'y': hip['y']}, {'y': ref['y']}, 'aff ties')
+
+
+# ---- bank / long-term kernels ---------------------------------------------------------------------------------
+def test_bank_misc():
+    def build(dev, g):
+        n = 3000
+        src = torch.randn((n, 64), generator=g).to(dev)
+        dst = torch.zeros((n, 80), dtype=F32, device=dev)
+        a = torch.randn((n,), generator=g).to(dev)
+        b = torch.randn((n,), generator=g).to(dev)
+        life = torch.rand((n,), generator=g).to(dev)
+        ms = torch.zeros((n,), dtype=torch.int32, device=dev)
+        c1 = torch.randn((n,), generator=g).to(dev)
+        c2 = torch.zeros((n,), dtype=BF16, device=dev)
+        c3 = torch.zeros((n,), dtype=F32, device=dev)
+        ol = O.OpList()
+        ol.copy2d(src, dst, rows=n, rowbytes=256, src_stride=256, dst_stride=320)
+        ol.axpy(a, b, n=n, a=0.5)
+        ol.usage_tick(life, n)
+        ol.memset32(ms, n, 869711765)
+        ol.cast(c1, c2, n=n)
+        ol.cast(c2, c3, n=n, to_f32=True)
+        return ol, {'dst': dst, 'b': b, 'life': life, 'ms': ms, 'c2': c2, 'c3': c3}
+    check(*run_both(build), name='bank misc', rtol=1e-6)
+
+
+def test_rank_select_gather():
+    def build(dev, g):
+        n, k = 5000, 700
+        use = torch.rand((n,), generator=g)
+        use[::7] = 0.0                                       # ties
+        life = torch.rand((n,), generator=g) + 0.5
+        life[::7] = 1.0
+        use, life = use.to(dev), life.to(dev)
+        order = torch.zeros((k,), dtype=torch.int32, device=dev)
+        src = torch.randn((n, 64), generator=g).to(dev)
+        dst = torch.zeros((k, 64), dtype=F32, device=dev)
+        ol = O.OpList()
+        ol.rank_select(use, life, order, n=n, k=k)
+        ol.gather_rows(src, order, dst, k=k, rowbytes=256, src_stride=256, dst_stride=256)
+        return ol, {'order': order, 'dst': dst}
+    hip, ref = run_both(build)
+    assert torch.equal(hip['order'], ref['order'])
+    assert torch.equal(hip['dst'], ref['dst'])
+
+
+def test_consolidation_kernels():
+    def build(dev, g):
+        n, P, C = 2000, 128, 256
+        ck = (torch.randn((n, 64), generator=g) * 0.8).to(dev)
+        cs = (torch.rand((n,), generator=g) * 2 + 1).to(dev)
+        pk = (torch.randn((P, 64), generator=g) * 0.8).to(dev)
+        pe = torch.rand((P, 64), generator=g).to(dev)
+        aff = torch.zeros((P, n), dtype=F32, device=dev)
+        V = rnd(g, (n, C), dev=dev)
+        out = torch.zeros((P, C), dtype=BF16, device=dev)
+        outs = torch.zeros((P,), dtype=F32, device=dev)
+        ol = O.OpList()
+        ol.consol_aff(ck, cs, pk, pe, aff, n=n, P=P)
+        ol.consol_read(aff, V, out, n=n, P=P, C=C, ldv=C, ldo=C)
+        ol.consol_read(aff, cs, outs, n=n, P=P, C=1, ldv=1, ldo=1, f32=True)
+        return ol, {'aff': aff, 'out': out, 'outs': outs}
+    check(*run_both(build), name='consolidation', rtol=None)
