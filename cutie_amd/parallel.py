@@ -1,0 +1,58 @@
+"""Clip sharding over the GPUs of one node.
+
+The per-frame state of a clip is a strict recurrence in time, so a clip never spans GPUs; independent clips are
+distributed round-robin, one process per GPU (``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm,
+"gloo" in the CPU tests).  There is no collective on the per-frame path: the only communication is the final
+gather of per-clip results to rank 0 -- a direct (non-ring) gather, since the payload is small and latency-bound.
+"""
+from typing import Callable, Dict, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def shard_clips(num_clips: int, rank: int, world_size: int) -> List[int]:
+    """Clip c runs on rank c mod world_size (the reference creates one InferenceCore per video, eval_vos.py:97)."""
+    return [c for c in range(num_clips) if c % world_size == rank]
+
+
+def run_sharded(clip_ids: Sequence[int], run_clip: Callable[[int], Dict], *, gather_masks: bool = False):
+    """Run ``run_clip(clip_id) -> {'frames': int, 'seconds': float, 'masks': uint8 tensor [T,H,W] (optional)}`` for
+    this rank's share of ``clip_ids`` and gather the results on rank 0.  Returns {clip_id: result} on rank 0, None elsewhere."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    mine = [c for i, c in enumerate(clip_ids) if i % world == rank]
+    local = {}
+    for c in mine:
+        r = run_clip(c)
+        if not gather_masks:
+            r = {k: v for k, v in r.items() if k != 'masks'}
+        local[c] = r
+    if world == 1:
+        return local
+    # scalars via all_gather_object (tiny); masks via tensor gather so they travel device-to-device over xGMI
+    stats = {c: {k: v for k, v in r.items() if k != 'masks'} for c, r in local.items()}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, stats)
+    result = {}
+    for g in gathered:
+        result.update(g)
+    if gather_masks:
+        for i, c in enumerate(clip_ids):
+            owner = i % world
+            if rank == owner and owner != 0:
+                m = local[c]['masks'].contiguous()
+                meta = torch.tensor(list(m.shape), dtype=torch.int64, device=m.device)
+                dist.send(meta, dst=0)
+                dist.send(m, dst=0)
+            elif rank == 0:
+                if owner == 0:
+                    result[c]['masks'] = local[c]['masks']
+                else:
+                    dev = local[next(iter(local))]['masks'].device if local else torch.device('cpu')
+                    meta = torch.zeros(3, dtype=torch.int64, device=dev)
+                    dist.recv(meta, src=owner)
+                    m = torch.empty(tuple(int(v) for v in meta.tolist()), dtype=torch.uint8, device=dev)
+                    dist.recv(m, src=owner)
+                    result[c]['masks'] = m
+    return result if rank == 0 else None
