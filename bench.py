@@ -69,6 +69,21 @@ class Recorder:
         return self.ex.stream()
 
 
+def usable_cores():
+    """Host cores this process may really use (affinity mask and cgroup quota), capped at 32 for the CPU baseline."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    env = os.environ.get('OMP_NUM_THREADS')
+    if env and env.isdigit():
+        n = min(n, int(env))
+    return max(1, min(n, 32))
+
+
 def conv_flops(arr):
     from cutie_amd import ops as O
     f = 0.0
@@ -182,7 +197,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_frames > 0 and sd is not None:
         from oracle.inference import OracleProcessor, DEFAULT_CFG
         from oracle.net import OracleNet
-        ncores = os.cpu_count() or 1
+        ncores = usable_cores()
         torch.set_num_threads(ncores)
         onet = OracleNet(sd)
         ocfg = dict(DEFAULT_CFG)
@@ -192,9 +207,14 @@ def main():
             oproc.step(clip.frame(0), clip.first_mask(), objects=clip.objects)
             oproc.step(clip.frame(1))                      # warm-up (lazy inits)
             c0 = time.perf_counter()
+            n_cpu = 0
             for tt in range(2, 2 + args.cpu_frames):
                 oproc.step(clip.frame(tt))
+                n_cpu += 1
+                if time.perf_counter() - c0 > 30.0:            # bounded sample
+                    break
             cpu_t = time.perf_counter() - c0
+            args.cpu_frames = n_cpu
         cpu = {'value': round(args.cpu_frames / cpu_t, 3), 'unit': 'frames/s', 'cores': torch.get_num_threads(),
                'kind': 'port',
                'sample': f'{args.cpu_frames} propagated frames (frames 2..{1 + args.cpu_frames}) of the same {args.width}x{args.height} '

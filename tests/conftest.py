@@ -7,7 +7,22 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:                                   # cgroup v2 quota
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
 def pytest_configure(config):
+    # the GPU boxes expose 256 logical CPUs; torch's default (one thread per CPU) makes the CPU-side oracle /
+    # interpreter crawl when several processes share them
+    import torch
+    torch.set_num_threads(max(1, min(8, usable_cores())))
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 

@@ -211,7 +211,9 @@ def test_gru():
         ol = O.OpList()
         ol.gru(v, h, hb, n=n, C=C)
         return ol, {'h': h, 'hb': hb}
-    check(*run_both(build), name='gru', rtol=1e-3)
+    hip, ref = run_both(build)
+    check({'h': hip['h']}, {'h': ref['h']}, 'gru', rtol=1e-4)
+    check({'hb': hip['hb']}, {'hb': ref['hb']}, 'gru shadow')          # bf16: within one ulp of the rounding point
 
 
 def test_seg_epilogue():
@@ -403,7 +405,11 @@ def test_affinity_pipeline(case):
     exact = ['Ahi', 'Alo', 'Bhi', 'Blo']
     for k in exact:
         assert torch.equal(hip[k].view(torch.int16), ref[k].view(torch.int16)), k
-    check({k: hip[k] for k in ('scale', 'cq', 'tau', 'gmax')}, {k: ref[k] for k in ('scale', 'cq', 'tau', 'gmax')}, 'aff', rtol=1e-5)
+    G = sum(-(-n // 16) for _, n in case['ranges'])
+    keys = ('scale', 'cq', 'gmax') + (('tau',) if G >= case['top_k'] else ())
+    check({k: hip[k] for k in keys}, {k: ref[k] for k in keys}, 'aff', rtol=1e-5)
+    if G < case['top_k']:
+        assert bool(torch.isinf(hip['tau']).all()) and bool((hip['tau'] < 0).all())      # "take everything"
     assert int(hip['ovf']) == 0
     check({'y': hip['y']}, {'y': ref['y']}, 'aff readout')
     if case['usage']:
