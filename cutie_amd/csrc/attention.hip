@@ -35,20 +35,22 @@ __global__ void aux_mask_kernel(const float* __restrict__ lg, uint8_t* __restric
     }
 }
 
-// ATTN_Q2P: grid (heads, K); 4 waves, wave w owns queries 4w..4w+3; lanes stream over pixels.
+// ATTN_Q2P: grid (heads, K, Q/4); the block owns 4 queries; its 4 waves split the pixels (wave w takes pixels
+// w*64 + lane + 256 i) with a per-lane online softmax; lanes are merged by shuffles, waves through LDS.
 __global__ __launch_bounds__(256) void attn_q2p_kernel(const float* __restrict__ q, const bf16_t* __restrict__ kv,
                                                        const uint8_t* __restrict__ fg, const int* __restrict__ nfg,
                                                        float* __restrict__ y, int Q, int HW, int C, int ldkv, int voff) {
-    __shared__ float red[4][64][4];          // [wave][lane][query] scratch for the final merge
-    const int hh = blockIdx.x, k = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ float sM[4][4], sL[4][4], sA[4][4][32];     // [wave][query]([dim])
+    const int hh = blockIdx.x, k = blockIdx.y, q0 = blockIdx.z * 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float scale = rsqrtf(32.f);
     float qv[4][32];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int d = 0; d < 32; ++d) qv[i][d] = q[((long)k * Q + wave * 4 + i) * C + hh * 32 + d] * scale;
+        for (int d = 0; d < 32; ++d) qv[i][d] = q[((long)k * Q + q0 + i) * C + hh * 32 + d] * scale;
     const int n_fg = nfg[k];
-    const bool is_fg_query = wave < 2;                     // queries 0..7 attend foreground only
+    const bool is_fg_query = q0 < Q / 2;                   // queries 0..7 attend foreground only
     // row fully blocked -> unblocked (object_transformer.py:203)
     const bool masked = is_fg_query ? (n_fg != 0) : (n_fg != HW);
     float m[4], l[4], acc[4][32];
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void attn_q2p_kernel(const float* __restrict__
 #pragma unroll
         for (int d = 0; d < 32; ++d) acc[i][d] = 0.f;
     }
-    for (int p = lane; p < HW; p += 64) {
+    for (int p = wave * 64 + lane; p < HW; p += 256) {
         if (masked) {
             bool f = fg[(long)k * HW + p] != 0;
             if (f != is_fg_query) continue;                // blocked
@@ -89,23 +91,31 @@ __global__ __launch_bounds__(256) void attn_q2p_kernel(const float* __restrict__
             m[i] = mn;
         }
     }
-    // merge the 64 lanes' partial softmax states
+    // merge the 64 lanes of each wave (un-normalised, relative to the wave maximum)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float M = wave_max(m[i]);
         float f = (m[i] == -INFINITY) ? 0.f : __expf(m[i] - M);
         float L = wave_sum(l[i] * f);
-        float inv = 1.f / L;
+        if (lane == 0) { sM[wave][i] = M; sL[wave][i] = L; }
 #pragma unroll
         for (int d = 0; d < 32; ++d) {
             float v = wave_sum(acc[i][d] * f);
-            if (lane == d) red[wave][d][i] = v * inv;
+            if (lane == d) sA[wave][i][d] = v;
         }
     }
     __syncthreads();
-    if (lane < 32) {
+    if (threadIdx.x < 128) {                               // (query i, dim d) merge over the 4 waves
+        int i = threadIdx.x >> 5, d = threadIdx.x & 31;
+        float Mg = fmaxf(fmaxf(sM[0][i], sM[1][i]), fmaxf(sM[2][i], sM[3][i]));
+        float num = 0.f, den = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[((long)k * Q + wave * 4 + i) * C + hh * 32 + lane] = red[wave][lane][i];
+        for (int w = 0; w < 4; ++w) {
+            float f = (sM[w][i] == -INFINITY) ? 0.f : __expf(sM[w][i] - Mg);
+            num += sA[w][i][d] * f;
+            den += sL[w][i] * f;
+        }
+        y[((long)k * Q + q0 + i) * C + hh * 32 + d] = num / den;
     }
 }
 
@@ -204,7 +214,7 @@ int launch_attention(const cutie_op* op, hipStream_t s) {
             break;
         case CUTIE_OP_ATTN_Q2P:
             if (i[1] != 16 || i[3] != i[4] * 32) { cutie_set_error("attn_q2p: Q=16, head dim 32 only"); return -2; }
-            hipLaunchKernelGGL(attn_q2p_kernel, dim3(i[4], i[0]), dim3(256), 0, s, (const float*)p[0], (const bf16_t*)p[1], (const uint8_t*)p[2],
+            hipLaunchKernelGGL(attn_q2p_kernel, dim3(i[4], i[0], i[1] / 4), dim3(256), 0, s, (const float*)p[0], (const bf16_t*)p[1], (const uint8_t*)p[2],
                                (const int*)p[3], (float*)p[4], i[1], i[2], i[3], i[5], i[6]);
             break;
         case CUTIE_OP_ATTN_SELF:

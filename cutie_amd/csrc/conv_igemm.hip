@@ -53,43 +53,60 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         rih[i] = oh * p.stride - p.pad;
         riw[i] = ow * p.stride - p.pad;
     }
-    int kcur = kc * 8, kh = 0, kw = 0;                   // channel / tap of this thread's chunk
-    while (kcur >= p.Cin) { kcur -= p.Cin; if (++kw == p.KW) { kw = 0; ++kh; } }
+    int kcur = kc * 8 - 32, kh = 0, kw = 0;              // channel / tap of this thread's chunk (normalised below)
 
     const int wrow = (tid >> 2);                         // W rows handled: wrow + i*64
-    u32x4 xr[NX], wr[NWC];
+    constexpr int S = 4;                                 // register prefetch ring: tiles ks+1 .. ks+S-1 are in flight
+    u32x4 xr[S][NX], wr[S][NWC];
 
-#define LOAD_TILE(KS)                                                                                      \
+    unsigned okmask[S];                                  // bit i of okmask[slot]: chunk i of that tile is real data (else zero)
+    // Branch-free on purpose: loads behind exec-masked branches (or data-dependent loops between them) make hipcc's
+    // waitcnt insertion fall back to vmcnt(0), which would drain the whole prefetch ring at every LDS write.
+#define ADVANCE_TAP()                                                                                      \
     {                                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                   \
-            u32x4 v = {0u, 0u, 0u, 0u};                                                                     \
-            int ih = rih[i] + kh, iw = riw[i] + kw;                                                        \
-            if (rvalid[i] && kh < p.KH && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {  \
-                long pix = ((long)(rb[i] + ih)) * p.W + iw;                                                \
-                const bf16_t* src = (kcur < p.C1) ? p.x1 + pix * p.ldx1 + kcur                             \
-                                                  : p.x2 + pix * p.ldx2 + (kcur - p.C1);                   \
-                v = *reinterpret_cast<const u32x4*>(src);                                                  \
-                if (relu_in) { v.x = relu_bf2(v.x); v.y = relu_bf2(v.y); v.z = relu_bf2(v.z); v.w = relu_bf2(v.w); } \
-            }                                                                                              \
-            xr[i] = v;                                                                                     \
+        kcur += 32;                                                                                        \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {     /* Cin >= 8: at most 4 wraps per 32 */      \
+            const bool w_ = kcur >= p.Cin;                                                                 \
+            kcur -= w_ ? p.Cin : 0;                                                                        \
+            kw += w_ ? 1 : 0;                                                                              \
+            const bool w2_ = kw == p.KW;                                                                   \
+            kw = w2_ ? 0 : kw;                                                                             \
+            kh += w2_ ? 1 : 0;                                                                             \
         }                                                                                                  \
+    }
+#define LOAD_TILE(KS, SLOT)                                                                                \
+    {                                                                                                      \
+        unsigned ok_ = 0;                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                   \
+            const int ih = rih[i] + kh, iw = riw[i] + kw;                                                  \
+            const bool v_ = rvalid[i] && kh < p.KH && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W; \
+            const long pix = ((long)(rb[i] + ih)) * p.W + iw;                                              \
+            const bf16_t* src = (kcur < p.C1) ? p.x1 + pix * p.ldx1 + kcur : p.x2 + pix * p.ldx2 + (kcur - p.C1); \
+            src = v_ ? src : p.x1;                           /* any mapped address; the value is discarded */ \
+            xr[SLOT][i] = *reinterpret_cast<const u32x4*>(src);                                            \
+            ok_ |= v_ ? (1u << i) : 0u;                                                                    \
+        }                                                                                                  \
+        okmask[SLOT] = ok_;                                                                                \
         _Pragma("unroll") for (int i = 0; i < NWC; ++i) {                                                  \
             int n = wrow + i * 64;                                                                         \
             if (BN < 64) n = n < BN ? n : BN - 1;                                                          \
-            wr[i] = *reinterpret_cast<const u32x4*>(p.w + (long)(n0 + n) * p.Kpad + (KS) * 32 + kc * 8);   \
+            wr[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w + (long)(n0 + n) * p.Kpad + (KS) * 32 + kc * 8); \
         }                                                                                                  \
-        kcur += 32;                                                                                        \
-        while (kcur >= p.Cin) { kcur -= p.Cin; if (++kw == p.KW) { kw = 0; ++kh; } }                       \
+        ADVANCE_TAP();                                                                                     \
     }
-#define STORE_TILE(BUF)                                                                                    \
+#define STORE_TILE(BUF, SLOT)                                                                              \
     {                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                   \
-            int row = (tid + i * 256) >> 2;                                                                \
-            smem[BUF][row * 4 + (kc ^ swz(row))] = xr[i];                                                  \
+            const int row = (tid + i * 256) >> 2;                                                          \
+            u32x4 v = xr[SLOT][i];                                                                         \
+            const unsigned keep = (okmask[SLOT] >> i) & 1u ? 0xffffffffu : 0u;                             \
+            v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;                                            \
+            if (relu_in) { v.x = relu_bf2(v.x); v.y = relu_bf2(v.y); v.z = relu_bf2(v.z); v.w = relu_bf2(v.w); } \
+            smem[BUF][row * 4 + (kc ^ swz(row))] = v;                                                      \
         }                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < NWC; ++i) {                                                  \
-            int n = wrow + i * 64;                                                                         \
-            if (BN * 4 >= 256 || n < BN) smem[BUF][(BM + n) * 4 + (kc ^ swz(n))] = wr[i];                  \
+            const int n = wrow + i * 64;                                                                   \
+            if (BN * 4 >= 256 || n < BN) smem[BUF][(BM + n) * 4 + (kc ^ swz(n))] = wr[SLOT][i];            \
         }                                                                                                  \
     }
 
@@ -102,31 +119,50 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // K loop.  Tile t lives in ring slot t % S; the loads of tile ks+S-1 are issued before the MFMAs of tile ks, so a
+    // global/L2 round trip has S-2 whole iterations to land (the kernel is latency-, not bandwidth-bound at the
+    // small M of the stride-16 layers).  LDS is double-buffered; one barrier per K step.
     const int nk = p.Kpad / 32;
-    LOAD_TILE(0);
-    STORE_TILE(0);
+    ADVANCE_TAP();                                       // kcur = kc*8, wrapped into (kh, kw, c)
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t)
+        if (t < nk) LOAD_TILE(t, t);
+    STORE_TILE(0, 0);
     __syncthreads();
-    for (int ks = 0; ks < nk; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < nk) LOAD_TILE(ks + 1);
-        bf16x8 bfr[TM], afr[TN];
+#define K_ITER(KS, U, DO_LOAD, DO_STORE)                                                                   \
+    {                                                                                                      \
+        const int buf = (U) & 1;                             /* == KS & 1 (S is even) */                   \
+        if (DO_LOAD) LOAD_TILE((KS) + S - 1, ((U) + S - 1) % S);                                           \
+        bf16x8 bfr[TM], afr[TN];                                                                           \
+        _Pragma("unroll") for (int t = 0; t < TM; ++t) {                                                   \
+            const int row = pm0 + t * 16 + l15;                                                            \
+            bfr[t] = __builtin_bit_cast(bf16x8, smem[buf][row * 4 + (l4 ^ swz(row))]);                     \
+        }                                                                                                  \
+        _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                                   \
+            const int row = cn0 + t * 16 + l15;                                                            \
+            afr[t] = __builtin_bit_cast(bf16x8, smem[buf][(BM + row) * 4 + (l4 ^ swz(row))]);              \
+        }                                                                                                  \
+        _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                     \
+            _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                 \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);   \
+        if (DO_STORE) STORE_TILE(buf ^ 1, ((U) + 1) % S);                                                  \
+        __syncthreads();                                                                                   \
+    }
+    int ks0 = 0;
+    // steady state: straight-line body (no guards), so the compiler can keep counted vmcnt waits
+    for (; ks0 + 2 * S - 1 <= nk; ks0 += S) {
+        K_ITER(ks0 + 0, 0, true, true)
+        K_ITER(ks0 + 1, 1, true, true)
+        K_ITER(ks0 + 2, 2, true, true)
+        K_ITER(ks0 + 3, 3, true, true)
+    }
+    // tail: the last < 2S steps, guarded
+    for (; ks0 < nk; ks0 += S) {
 #pragma unroll
-        for (int t = 0; t < TM; ++t) {
-            int row = pm0 + t * 16 + l15;
-            bfr[t] = __builtin_bit_cast(bf16x8, smem[buf][row * 4 + (l4 ^ swz(row))]);
+        for (int u = 0; u < S; ++u) {
+            const int ks = ks0 + u;
+            if (ks < nk) K_ITER(ks, u, ks + S - 1 < nk, ks + 1 < nk)
         }
-#pragma unroll
-        for (int t = 0; t < TN; ++t) {
-            int row = cn0 + t * 16 + l15;
-            afr[t] = __builtin_bit_cast(bf16x8, smem[buf][(BM + row) * 4 + (l4 ^ swz(row))]);
-        }
-#pragma unroll
-        for (int a = 0; a < TN; ++a)
-#pragma unroll
-            for (int b = 0; b < TM; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);
-        if (ks + 1 < nk) STORE_TILE(buf ^ 1);
-        __syncthreads();
     }
 
     // ---- epilogue: bias + residual + activation, NHWC store (4 consecutive channels per lane) ----

@@ -5,6 +5,7 @@
 #include <math.h>
 
 #define GRID1D(n, bs) dim3((unsigned)(((long)(n) + (bs) - 1) / (bs)))
+__global__ void memset32_kernel(uint32_t* d, long n, uint32_t v);
 
 // ---------------------------------------------------------------------------------------------
 __global__ void maxpool_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int B, int H, int W, int C8,
@@ -146,18 +147,20 @@ __global__ void area_down_f32_kernel(const float* __restrict__ x, bf16_t* __rest
     for (int c = C; c < Cz; ++c) yp[c] = 0;
 }
 
-// masks f32 [K,H,W] -> m16 f32 [K,h,w]
+// masks f32 [K,H,W] -> m16 f32 [K,h,w]: one wave per output pixel (r*r = 256 inputs, 4 per lane, row-coalesced)
 __global__ void mask_down_mean_kernel(const float* __restrict__ m, float* __restrict__ m16, int K, int H, int W, int r) {
     int h = H / r, w = W / r;
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long idx = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
     if (idx >= (long)K * h * w) return;
     int ox = idx % w; long t = idx / w; int oy = t % h; int k = t / h;
     float acc = 0.f;
-    for (int dy = 0; dy < r; ++dy) {
-        const float* row = m + ((long)k * H + oy * r + dy) * W + ox * r;
-        for (int dx = 0; dx < r; ++dx) acc += row[dx];
+    for (int e = lane; e < r * r; e += 64) {
+        int dy = e / r, dx = e - dy * r;
+        acc += m[((long)k * H + oy * r + dy) * W + ox * r + dx];
     }
-    m16[idx] = acc / (float)(r * r);
+    acc = wave_sum(acc);
+    if (lane == 0) m16[idx] = acc / (float)(r * r);
 }
 // m16 f32 [K,hw] -> pair bf16 [K,hw,8] = (mask, others, 0...)
 __global__ void mask_pair_kernel(const float* __restrict__ m16, uint4* __restrict__ y, int K, int hw) {
@@ -172,16 +175,32 @@ __global__ void mask_pair_kernel(const float* __restrict__ m16, uint4* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// GAP: grid (C/64, B), block 256 = 4 row slices x 64 channels
-__global__ void gap_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int HW, int C) {
-    __shared__ float red[4][64];
-    int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), s = threadIdx.x >> 6;
-    float acc = 0.f;
-    if (c < C)
-        for (int p = s; p < HW; p += 4) acc += bf2f(x[((long)b * HW + p) * C + c]);
-    red[s][threadIdx.x & 63] = acc;
+// GAP: grid (ceil(HW/64), B); block 256 = 8 pixel rows x 32 channel-octets (C = 256) per step; per-block partial sums
+// are reduced in LDS and added to y with one float atomic per (block, channel).  y is zeroed by a memset launch first.
+__global__ __launch_bounds__(256) void gap_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int HW, int C, float inv) {
+    __shared__ float red[2048 + 32];                      // [row group][C + 1]
+    const int b = blockIdx.y, p0 = blockIdx.x * 64;
+    const int C8 = C >> 3;
+    const int c8 = threadIdx.x % C8, rg = threadIdx.x / C8, nrg = 256 / C8;       // C=256: 32 octets x 8 row groups
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = rg; r < 64; r += nrg) {
+        int p = p0 + r;
+        if (p < HW) {
+            uint4 v = *reinterpret_cast<const uint4*>(x + ((long)b * HW + p) * C + c8 * 8);
+            acc[0] += __uint_as_float(v.x << 16); acc[1] += __uint_as_float(v.x & 0xffff0000u);
+            acc[2] += __uint_as_float(v.y << 16); acc[3] += __uint_as_float(v.y & 0xffff0000u);
+            acc[4] += __uint_as_float(v.z << 16); acc[5] += __uint_as_float(v.z & 0xffff0000u);
+            acc[6] += __uint_as_float(v.w << 16); acc[7] += __uint_as_float(v.w & 0xffff0000u);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[rg * (C + 1) + c8 * 8 + i] = acc[i];
     __syncthreads();
-    if (s == 0 && c < C) y[(long)b * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)HW;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float sum = 0.f;
+        for (int g = 0; g < nrg; ++g) sum += red[g * (C + 1) + c];
+        atomicAdd(&y[(long)b * C + c], sum * inv);
+    }
 }
 
 __global__ void eca_apply_kernel(const uint4* __restrict__ x, const float* __restrict__ gap, const float* __restrict__ wk,
@@ -328,50 +347,54 @@ __global__ void agg_softmax_kernel(const float* __restrict__ planes, float* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-// LINEAR (small M): block = 16 output columns x 16 k-lanes; rows processed 8 at a time
+// LINEAR (small M): grid (ceil(N/4), ceil(M/16)); block = 4 waves, wave w owns output column 4*bx + w for 16 rows;
+// the K dimension is split over the 64 lanes (coalesced 16-B weight / 32-B activation loads), then wave-reduced.
 __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, const float* __restrict__ xadd,
                                                            const bf16_t* __restrict__ W, const float* __restrict__ bias,
                                                            const float* __restrict__ res, float* __restrict__ y, int M, int N,
                                                            int Kd, int ldx, int ldy, int add_rows, int relu) {
-    int col = blockIdx.x * 16 + (threadIdx.x >> 4);
-    int kl = threadIdx.x & 15;
-    bool cvalid = col < N;
-    const bf16_t* wrow = W + (long)(cvalid ? col : 0) * Kd;
-    for (int m0 = 0; m0 < M; m0 += 8) {
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int k = kl * 8; k < Kd; k += 128) {
-            uint4 wv = *reinterpret_cast<const uint4*>(wrow + k);
-            const uint32_t* wu = &wv.x;
-            float wf[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 4 + wave, m0 = blockIdx.y * 16;
+    if (col >= N) return;                                    // whole wave
+    const bf16_t* wrow = W + (long)col * Kd;
+    float acc[16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { wf[2 * i] = __uint_as_float(wu[i] << 16); wf[2 * i + 1] = __uint_as_float(wu[i] & 0xffff0000u); }
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k = lane * 8; k < Kd; k += 512) {
+        uint4 wv = *reinterpret_cast<const uint4*>(wrow + k);
+        float wf[8];
+        wf[0] = __uint_as_float(wv.x << 16); wf[1] = __uint_as_float(wv.x & 0xffff0000u);
+        wf[2] = __uint_as_float(wv.y << 16); wf[3] = __uint_as_float(wv.y & 0xffff0000u);
+        wf[4] = __uint_as_float(wv.z << 16); wf[5] = __uint_as_float(wv.z & 0xffff0000u);
+        wf[6] = __uint_as_float(wv.w << 16); wf[7] = __uint_as_float(wv.w & 0xffff0000u);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                int m = m0 + r;
-                if (m < M) {
-                    const float* xr = x + (long)m * ldx + k;
-                    float4 a = *reinterpret_cast<const float4*>(xr), b = *reinterpret_cast<const float4*>(xr + 4);
-                    if (xadd) {
-                        const float* ar = xadd + (long)(m % add_rows) * Kd + k;
-                        float4 c = *reinterpret_cast<const float4*>(ar), d = *reinterpret_cast<const float4*>(ar + 4);
-                        a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w; b.x += d.x; b.y += d.y; b.z += d.z; b.w += d.w;
-                    }
-                    acc[r] += a.x * wf[0] + a.y * wf[1] + a.z * wf[2] + a.w * wf[3] + b.x * wf[4] + b.y * wf[5] + b.z * wf[6] + b.w * wf[7];
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            float v = acc[r];
-            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+        for (int r = 0; r < 16; ++r) {
             int m = m0 + r;
-            if (kl == 0 && cvalid && m < M) {
-                if (bias) v += bias[col];
-                if (relu) v = fmaxf(v, 0.f);
-                if (res) v += res[(long)m * N + col];
-                y[(long)m * ldy + col] = v;
+            if (m < M) {                                     // wave-uniform
+                const float* xr = x + (long)m * ldx + k;
+                float4 a = *reinterpret_cast<const float4*>(xr), b = *reinterpret_cast<const float4*>(xr + 4);
+                if (xadd) {
+                    const float* ar = xadd + (long)(m % add_rows) * Kd + k;
+                    float4 c = *reinterpret_cast<const float4*>(ar), d = *reinterpret_cast<const float4*>(ar + 4);
+                    a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w; b.x += d.x; b.y += d.y; b.z += d.z; b.w += d.w;
+                }
+                acc[r] += a.x * wf[0] + a.y * wf[1] + a.z * wf[2] + a.w * wf[3] + b.x * wf[4] + b.y * wf[5] + b.z * wf[6] + b.w * wf[7];
             }
         }
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = wave_sum(acc[r]);
+        if (lane == r) mine = v;
+    }
+    int m = m0 + lane;
+    if (lane < 16 && m < M) {
+        float v = mine;
+        if (bias) v += bias[col];
+        if (relu) v = fmaxf(v, 0.f);
+        if (res) v += res[(long)m * N + col];
+        y[(long)m * ldy + col] = v;
     }
 }
 
@@ -397,26 +420,37 @@ __global__ void query_init_kernel(const float* __restrict__ om, float* __restric
     y[idx] = om[(long)r * (C + 1) + c] / (om[(long)r * (C + 1) + C] + 1e-4f);
 }
 
-// SUMMARIZE: grid (C/64, K), block 256 = 4 pixel slices x 64 channels
+// SUMMARIZE: grid (C/64, K, ceil(HW/128)); block 256 = 4 pixel slices x 64 channels over a 128-pixel chunk; the
+// per-pixel weights sigmoid(logit)*mask are computed once per block into LDS; partial sums go to y with float atomics
+// (y zeroed by a memset launch first).
 __global__ __launch_bounds__(256) void summarize_kernel(const bf16_t* __restrict__ feat, const float* __restrict__ wl,
                                                         const float* __restrict__ m16, float* __restrict__ y, int HW, int C, int Q) {
+    __shared__ float wsm[128][17];
     __shared__ float red[4][64][17];
-    int k = blockIdx.y, cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, s = threadIdx.x >> 6;
+    const int k = blockIdx.y, cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, s = threadIdx.x >> 6;
+    const int p0 = blockIdx.z * 128;
+    for (int t = threadIdx.x; t < 128 * 16; t += 256) {
+        int pp = t >> 4, q = t & 15, p = p0 + pp;
+        float wgt = 0.f;
+        if (p < HW) {
+            long row = (long)k * HW + p;
+            float m = m16[row];
+            wgt = (1.f / (1.f + expf(-wl[row * Q + q]))) * (q < 8 ? m : 1.f - m);
+        }
+        wsm[pp][q] = wgt;
+    }
+    __syncthreads();
     float acc[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    float area = 0.f;                      // threads with cl < Q accumulate the area of summary cl
-    for (int p = s; p < HW; p += 4) {
-        long row = (long)k * HW + p;
-        float f = bf2f(feat[row * C + c]);
-        float m = m16[row];
-        const float* wr = wl + row * Q;
+    float area = 0.f;
+    for (int pp = s; pp < 128; pp += 4) {
+        int p = p0 + pp;
+        if (p >= HW) break;
+        float f = bf2f(feat[((long)k * HW + p) * C + c]);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            float wgt = (1.f / (1.f + expf(-wr[q]))) * (q < 8 ? m : 1.f - m);
-            acc[q] += wgt * f;
-            if (q == cl) area += wgt;
-        }
+        for (int q = 0; q < 16; ++q) acc[q] += wsm[pp][q] * f;
+        if (cl < 16) area += wsm[pp][cl];
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) red[s][cl][q] = acc[q];
@@ -424,9 +458,9 @@ __global__ __launch_bounds__(256) void summarize_kernel(const bf16_t* __restrict
     __syncthreads();
     if (s == 0) {
         for (int q = 0; q < 16; ++q)
-            y[((long)k * Q + q) * (C + 1) + c] = red[0][cl][q] + red[1][cl][q] + red[2][cl][q] + red[3][cl][q];
+            atomicAdd(&y[((long)k * Q + q) * (C + 1) + c], red[0][cl][q] + red[1][cl][q] + red[2][cl][q] + red[3][cl][q]);
         if (blockIdx.x == 0 && cl < Q)
-            y[((long)k * Q + cl) * (C + 1) + C] = red[0][cl][16] + red[1][cl][16] + red[2][cl][16] + red[3][cl][16];
+            atomicAdd(&y[((long)k * Q + cl) * (C + 1) + C], red[0][cl][16] + red[1][cl][16] + red[2][cl][16] + red[3][cl][16]);
     }
 }
 
@@ -508,13 +542,17 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             long n = (long)K * h * w;
             float* m16 = (float*)p[2];
             if (!m16) { cutie_set_error("mask_down: m16 buffer required"); return -2; }
-            hipLaunchKernelGGL(mask_down_mean_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], m16, K, i[1], i[2], r);
+            hipLaunchKernelGGL(mask_down_mean_kernel, GRID1D(n * 64, BS), dim3(BS), 0, s, (const float*)p[0], m16, K, i[1], i[2], r);
             hipLaunchKernelGGL(mask_pair_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const float*)m16, (uint4*)p[1], K, h * w);
             break;
         }
-        case CUTIE_OP_GAP:
-            hipLaunchKernelGGL(gap_kernel, dim3((i[2] + 63) / 64, i[0]), dim3(256), 0, s, (const bf16_t*)p[0], (float*)p[1], i[1], i[2]);
+        case CUTIE_OP_GAP: {
+            if (i[2] > 256 || (i[2] & 7) || 256 % (i[2] / 8)) { cutie_set_error("gap: C must divide 256 octet-wise (C=%d)", i[2]); return -2; }
+            long n = (long)i[0] * i[2];
+            hipLaunchKernelGGL(memset32_kernel, GRID1D(n, BS), dim3(BS), 0, s, (uint32_t*)p[1], n, 0u);
+            hipLaunchKernelGGL(gap_kernel, dim3((i[1] + 63) / 64, i[0]), dim3(256), 0, s, (const bf16_t*)p[0], (float*)p[1], i[1], i[2], 1.f / (float)i[1]);
             break;
+        }
         case CUTIE_OP_ECA_APPLY: {
             long n = (long)i[0] * i[1] * (i[2] / 8);
             hipLaunchKernelGGL(eca_apply_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const uint4*)p[0], (const float*)p[1], (const float*)p[2], (const uint4*)p[3], (uint4*)p[4], i[0], i[1], i[2]);
@@ -544,7 +582,7 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             break;
         case CUTIE_OP_LINEAR:
             if ((i[2] & 7) || (i[3] & 3)) { cutie_set_error("linear: Kd %% 8 / ldx %% 4"); return -2; }
-            hipLaunchKernelGGL(linear_small_kernel, dim3((i[1] + 15) / 16), dim3(256), 0, s, (const float*)p[0], (const float*)p[1], (const bf16_t*)p[2],
+            hipLaunchKernelGGL(linear_small_kernel, dim3((i[1] + 3) / 4, (i[0] + 15) / 16), dim3(256), 0, s, (const float*)p[0], (const float*)p[1], (const bf16_t*)p[2],
                                (const float*)p[3], (const float*)p[4], (float*)p[5], i[0], i[1], i[2], i[3], i[4], i[5] > 0 ? i[5] : 1, op->flags & 1);
             break;
         case CUTIE_OP_LAYERNORM:
@@ -557,7 +595,11 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
         }
         case CUTIE_OP_SUMMARIZE:
             if (i[3] != 16 || (i[2] & 63)) { cutie_set_error("summarize: Q must be 16, C %% 64"); return -2; }
-            hipLaunchKernelGGL(summarize_kernel, dim3(i[2] / 64, i[0]), dim3(256), 0, s, (const bf16_t*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[3], i[1], i[2], i[3]);
+            {
+                long n = (long)i[0] * i[3] * (i[2] + 1);
+                hipLaunchKernelGGL(memset32_kernel, GRID1D(n, BS), dim3(BS), 0, s, (uint32_t*)p[3], n, 0u);
+            }
+            hipLaunchKernelGGL(summarize_kernel, dim3(i[2] / 64, i[0], (i[1] + 127) / 128), dim3(256), 0, s, (const bf16_t*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[3], i[1], i[2], i[3]);
             break;
         case CUTIE_OP_ADD_PE: {
             long n8 = i[1] / 8;
