@@ -6,11 +6,15 @@
 // operand, so each lane of v_mfma_f32_16x16x32_bf16 ends up holding 4 *consecutive output channels*
 // of one pixel -> 8-byte bf16 (16-byte f32) NHWC stores and residual loads.
 //
-// Tiling: 256 threads = 4 waves, block tile BM pixels x BN channels, BK = 32 per step, global ->
-// register -> LDS staging (the gather needs per-chunk zero fill for the halo and the optional fused
-// input ReLU), double-buffered LDS, one barrier per K step.  LDS rows are 64 B (32 bf16); the 16-B
-// chunk index is XOR-swizzled with ((row>>3)&1)*3 so that the four 16-lane groups of a ds_read_b128
-// fragment read hit 16 distinct 16-B slots of the 256-B bank row (conflict-free).
+// Tiling: 256 threads = 4 waves, block tile BM pixels x BN channels x BK (32/64/128) per step.
+//   * global -> registers -> LDS staging (the im2col gather needs per-chunk zero fill for the halo, the optional
+//     fused input ReLU and the 2-source channel concat), with a register *prefetch ring* of S tiles: the loads of
+//     tile ks+S-1 are issued before the MFMAs of tile ks.  At the small M of the stride-16 layers (1620 pixels per
+//     object) the kernel is latency-, not bandwidth-bound, so the ring (counted vmcnt waits, kept branch-free so
+//     hipcc does not fall back to vmcnt(0)) and a larger BK (fewer barriers per MFMA) are what matter.
+//   * LDS double-buffered, one barrier per K step; rows are BK*2 bytes and the 16-B chunk index is XOR-swizzled
+//     (row&(CPR-1), or ((row>>3)&1)*3 for 64-B rows) so ds_read_b128 fragment reads spread over the bank rows.
+//   * the tile shape is chosen per layer by the host (autotuned at plan build, cutie_amd/model/plans.py).
 #include "common.h"
 
 struct ConvParams {
@@ -20,20 +24,29 @@ struct ConvParams {
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-__device__ __forceinline__ int swz(int row) { return ((row >> 3) & 1) * 3; }
 
-template <int BM, int BN, int WM, int WN>
+template <int CPR>
+__device__ __forceinline__ int swz(int row) {
+    return CPR == 4 ? ((row >> 3) & 1) * 3 : (row & (CPR - 1));
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int S>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
-    constexpr int NX = (BM * 4) / 256;                  // X chunks (16 B) per thread per K step
-    constexpr int NWC = (BN * 4 + 255) / 256;           // W chunks per thread per K step
-    constexpr int TM = BM / WM / 16;                    // 16-pixel tiles per wave
-    constexpr int TN = BN / WN / 16;                    // 16-channel tiles per wave
-    static_assert(WM * WN == 4 && NX >= 1 && TM >= 1 && TN >= 1, "bad tile");
-    __shared__ u32x4 smem[2][(BM + BN) * 4];
+    constexpr int CPR = BK / 8;                         // 16-B chunks per LDS row
+    constexpr int RPT = 256 / CPR;                      // rows covered by one pass of the 256 threads
+    constexpr int NX = (BM * CPR) / 256;                // X chunks per thread per tile
+    constexpr int NWC = (BN * CPR + 255) / 256;         // W chunks per thread per tile
+    constexpr int TM = BM / WM / 16;                    // 16-pixel MFMA tiles per wave
+    constexpr int TN = BN / WN / 16;                    // 16-channel MFMA tiles per wave
+    constexpr int KSUB = BK / 32;                       // MFMA k-steps per tile
+    constexpr int NWRAP = BK == 32 ? 4 : BK / 32;       // tap wraps per tile advance (BK > 32 requires Cin >= 32)
+    static_assert(WM * WN == 4 && NX >= 1 && TM >= 1 && TN >= 1 && S >= 2, "bad tile");
+    __shared__ u32x4 smem[2][(BM + BN) * CPR];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int kc = tid & 3;                              // this thread's 8-element chunk inside BK
+    const int kc = tid % CPR;                            // this thread's 8-element chunk inside BK
+    const int trow = tid / CPR;                          // first row handled (then + RPT per extra chunk)
     const bool relu_in = p.flags & CUTIE_F_RELU_IN;
 
     // ---- per-thread im2col row state (fixed over the K loop) ----
@@ -41,8 +54,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     bool rvalid[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        int row = (tid + i * 256) >> 2;
-        int m = m0 + row;
+        int m = m0 + trow + i * RPT;
         rvalid[i] = m < p.M;
         int mm = rvalid[i] ? m : 0;
         int b = mm / p.OHW;
@@ -53,19 +65,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         rih[i] = oh * p.stride - p.pad;
         riw[i] = ow * p.stride - p.pad;
     }
-    int kcur = kc * 8 - 32, kh = 0, kw = 0;              // channel / tap of this thread's chunk (normalised below)
+    int kcur = kc * 8 - BK, kh = 0, kw = 0;              // channel / tap of this thread's chunk (normalised below)
 
-    const int wrow = (tid >> 2);                         // W rows handled: wrow + i*64
-    constexpr int S = 4;                                 // register prefetch ring: tiles ks+1 .. ks+S-1 are in flight
     u32x4 xr[S][NX], wr[S][NWC];
-
     unsigned okmask[S];                                  // bit i of okmask[slot]: chunk i of that tile is real data (else zero)
     // Branch-free on purpose: loads behind exec-masked branches (or data-dependent loops between them) make hipcc's
     // waitcnt insertion fall back to vmcnt(0), which would drain the whole prefetch ring at every LDS write.
 #define ADVANCE_TAP()                                                                                      \
     {                                                                                                      \
-        kcur += 32;                                                                                        \
-        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {     /* Cin >= 8: at most 4 wraps per 32 */      \
+        kcur += BK;                                                                                        \
+        _Pragma("unroll") for (int r_ = 0; r_ < NWRAP; ++r_) {                                             \
             const bool w_ = kcur >= p.Cin;                                                                 \
             kcur -= w_ ? p.Cin : 0;                                                                        \
             kw += w_ ? 1 : 0;                                                                              \
@@ -88,25 +97,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         }                                                                                                  \
         okmask[SLOT] = ok_;                                                                                \
         _Pragma("unroll") for (int i = 0; i < NWC; ++i) {                                                  \
-            int n = wrow + i * 64;                                                                         \
-            if (BN < 64) n = n < BN ? n : BN - 1;                                                          \
-            wr[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w + (long)(n0 + n) * p.Kpad + (KS) * 32 + kc * 8); \
+            int n = trow + i * RPT;                                                                        \
+            if (BN < RPT) n = n < BN ? n : BN - 1;                                                         \
+            wr[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w + (long)(n0 + n) * p.Kpad + (KS) * BK + kc * 8); \
         }                                                                                                  \
         ADVANCE_TAP();                                                                                     \
     }
 #define STORE_TILE(BUF, SLOT)                                                                              \
     {                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                   \
-            const int row = (tid + i * 256) >> 2;                                                          \
+            const int row = trow + i * RPT;                                                                \
             u32x4 v = xr[SLOT][i];                                                                         \
             const unsigned keep = (okmask[SLOT] >> i) & 1u ? 0xffffffffu : 0u;                             \
             v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;                                            \
             if (relu_in) { v.x = relu_bf2(v.x); v.y = relu_bf2(v.y); v.z = relu_bf2(v.z); v.w = relu_bf2(v.w); } \
-            smem[BUF][row * 4 + (kc ^ swz(row))] = v;                                                      \
+            smem[BUF][row * CPR + (kc ^ swz<CPR>(row))] = v;                                               \
         }                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < NWC; ++i) {                                                  \
-            const int n = wrow + i * 64;                                                                   \
-            if (BN * 4 >= 256 || n < BN) smem[BUF][(BM + n) * 4 + (kc ^ swz(n))] = wr[SLOT][i];            \
+            const int n = trow + i * RPT;                                                                  \
+            if (BN >= RPT || n < BN) smem[BUF][(BM + n) * CPR + (kc ^ swz<CPR>(n))] = wr[SLOT][i];         \
         }                                                                                                  \
     }
 
@@ -120,9 +129,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // K loop.  Tile t lives in ring slot t % S; the loads of tile ks+S-1 are issued before the MFMAs of tile ks, so a
-    // global/L2 round trip has S-2 whole iterations to land (the kernel is latency-, not bandwidth-bound at the
-    // small M of the stride-16 layers).  LDS is double-buffered; one barrier per K step.
-    const int nk = p.Kpad / 32;
+    // global/L2 round trip has S-2 whole iterations to land.  LDS is double-buffered; one barrier per tile.
+    const int nk = p.Kpad / BK;
     ADVANCE_TAP();                                       // kcur = kc*8, wrapped into (kh, kw, c)
 #pragma unroll
     for (int t = 0; t < S - 1; ++t)
@@ -131,32 +139,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     __syncthreads();
 #define K_ITER(KS, U, DO_LOAD, DO_STORE)                                                                   \
     {                                                                                                      \
-        const int buf = (U) & 1;                             /* == KS & 1 (S is even) */                   \
+        const int buf = (KS) & 1;                                                                          \
         if (DO_LOAD) LOAD_TILE((KS) + S - 1, ((U) + S - 1) % S);                                           \
-        bf16x8 bfr[TM], afr[TN];                                                                           \
-        _Pragma("unroll") for (int t = 0; t < TM; ++t) {                                                   \
-            const int row = pm0 + t * 16 + l15;                                                            \
-            bfr[t] = __builtin_bit_cast(bf16x8, smem[buf][row * 4 + (l4 ^ swz(row))]);                     \
+        _Pragma("unroll") for (int j = 0; j < KSUB; ++j) {                                                 \
+            bf16x8 bfr[TM], afr[TN];                                                                       \
+            _Pragma("unroll") for (int t = 0; t < TM; ++t) {                                               \
+                const int row = pm0 + t * 16 + l15;                                                        \
+                bfr[t] = __builtin_bit_cast(bf16x8, smem[buf][row * CPR + ((j * 4 + l4) ^ swz<CPR>(row))]); \
+            }                                                                                              \
+            _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                               \
+                const int row = cn0 + t * 16 + l15;                                                        \
+                afr[t] = __builtin_bit_cast(bf16x8, smem[buf][(BM + row) * CPR + ((j * 4 + l4) ^ swz<CPR>(row))]); \
+            }                                                                                              \
+            _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                 \
+                _Pragma("unroll") for (int b = 0; b < TM; ++b)                                             \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0); \
         }                                                                                                  \
-        _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                                   \
-            const int row = cn0 + t * 16 + l15;                                                            \
-            afr[t] = __builtin_bit_cast(bf16x8, smem[buf][(BM + row) * 4 + (l4 ^ swz(row))]);              \
-        }                                                                                                  \
-        _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                     \
-            _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                 \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0);   \
         if (DO_STORE) STORE_TILE(buf ^ 1, ((U) + 1) % S);                                                  \
         __syncthreads();                                                                                   \
     }
     int ks0 = 0;
     // steady state: straight-line body (no guards), so the compiler can keep counted vmcnt waits
     for (; ks0 + 2 * S - 1 <= nk; ks0 += S) {
-        K_ITER(ks0 + 0, 0, true, true)
-        K_ITER(ks0 + 1, 1, true, true)
-        K_ITER(ks0 + 2, 2, true, true)
-        K_ITER(ks0 + 3, 3, true, true)
+#pragma unroll
+        for (int u = 0; u < S; ++u) K_ITER(ks0 + u, u, true, true)
     }
-    // tail: the last < 2S steps, guarded
+    // tail: the last < 2S tiles, guarded
     for (; ks0 < nk; ks0 += S) {
 #pragma unroll
         for (int u = 0; u < S; ++u) {
@@ -223,13 +231,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK, int S>
 static int launch_cfg(const ConvParams& p, hipStream_t s) {
+    if (p.Kpad % BK) { cutie_set_error("conv: Kpad %d not a multiple of BK %d", p.Kpad, BK); return -2; }
+    if (BK > 32 && p.Cin < 32) { cutie_set_error("conv: BK %d needs Cin >= 32 (Cin=%d)", BK, p.Cin); return -2; }
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, S>), grid, dim3(256), 0, s, p);
     return (int)hipGetLastError();
 }
 
+// tile table (mirrored by cutie_amd/ops.py:TILES): id -> BM, BN, BK
 int launch_conv(const cutie_op* op, hipStream_t s) {
     ConvParams p;
     p.x1 = (const bf16_t*)op->p[0]; p.x2 = (const bf16_t*)op->p[1]; p.w = (const bf16_t*)op->p[2];
@@ -246,11 +257,19 @@ int launch_conv(const cutie_op* op, hipStream_t s) {
         return -2;
     }
     switch (i[17]) {
-        case 0: return launch_cfg<128, 128, 2, 2>(p, s);
-        case 1: return launch_cfg<128, 64, 2, 2>(p, s);
-        case 2: return launch_cfg<64, 64, 2, 2>(p, s);
-        case 3: return launch_cfg<256, 16, 4, 1>(p, s);
-        case 4: return launch_cfg<64, 128, 2, 2>(p, s);
+        case 0: return launch_cfg<128, 128, 2, 2, 32, 4>(p, s);
+        case 1: return launch_cfg<128, 64, 2, 2, 32, 4>(p, s);
+        case 2: return launch_cfg<64, 64, 2, 2, 32, 4>(p, s);
+        case 3: return launch_cfg<256, 16, 4, 1, 32, 4>(p, s);
+        case 4: return launch_cfg<64, 128, 2, 2, 32, 4>(p, s);
+        case 5: return launch_cfg<64, 64, 2, 2, 64, 4>(p, s);
+        case 6: return launch_cfg<64, 128, 2, 2, 64, 3>(p, s);
+        case 7: return launch_cfg<128, 128, 2, 2, 64, 2>(p, s);
+        case 8: return launch_cfg<64, 64, 2, 2, 128, 3>(p, s);
+        case 9: return launch_cfg<32, 64, 2, 2, 64, 4>(p, s);
+        case 10: return launch_cfg<128, 64, 2, 2, 64, 3>(p, s);
+        case 11: return launch_cfg<32, 64, 2, 2, 128, 3>(p, s);
+        case 12: return launch_cfg<32, 128, 2, 2, 64, 3>(p, s);
         default: cutie_set_error("conv: bad tile id %d", i[17]); return -2;
     }
 }

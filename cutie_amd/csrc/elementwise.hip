@@ -175,9 +175,10 @@ __global__ void mask_pair_kernel(const float* __restrict__ m16, uint4* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// GAP: grid (ceil(HW/64), B); block 256 = 8 pixel rows x 32 channel-octets (C = 256) per step; per-block partial sums
-// are reduced in LDS and added to y with one float atomic per (block, channel).  y is zeroed by a memset launch first.
-__global__ __launch_bounds__(256) void gap_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int HW, int C, float inv) {
+// GAP, two deterministic stages (no float atomics: results are bit-reproducible run to run):
+//  1. grid (ceil(HW/64), B): block 256 = row groups x channel octets over a 64-pixel chunk -> part[b][chunk][c]
+//  2. grid (B): sums the chunks in order and scales by 1/HW
+__global__ __launch_bounds__(256) void gap_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, int HW, int C) {
     __shared__ float red[2048 + 32];                      // [row group][C + 1]
     const int b = blockIdx.y, p0 = blockIdx.x * 64;
     const int C8 = C >> 3;
@@ -199,7 +200,15 @@ __global__ __launch_bounds__(256) void gap_kernel(const bf16_t* __restrict__ x, 
     for (int c = threadIdx.x; c < C; c += 256) {
         float sum = 0.f;
         for (int g = 0; g < nrg; ++g) sum += red[g * (C + 1) + c];
-        atomicAdd(&y[(long)b * C + c], sum * inv);
+        part[((long)b * gridDim.x + blockIdx.x) * C + c] = sum;
+    }
+}
+__global__ void gap_final_kernel(const float* __restrict__ part, float* __restrict__ y, int nchunk, int C, float inv) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float sum = 0.f;
+        for (int k = 0; k < nchunk; ++k) sum += part[((long)b * nchunk + k) * C + c];
+        y[(long)b * C + c] = sum * inv;
     }
 }
 
@@ -421,8 +430,8 @@ __global__ void query_init_kernel(const float* __restrict__ om, float* __restric
 }
 
 // SUMMARIZE: grid (C/64, K, ceil(HW/128)); block 256 = 4 pixel slices x 64 channels over a 128-pixel chunk; the
-// per-pixel weights sigmoid(logit)*mask are computed once per block into LDS; partial sums go to y with float atomics
-// (y zeroed by a memset launch first).
+// per-pixel weights sigmoid(logit)*mask are computed once per block into LDS; per-chunk partial sums go to
+// part[k][chunk][q][C+1] and are summed in chunk order by summarize_final_kernel (deterministic, no float atomics).
 __global__ __launch_bounds__(256) void summarize_kernel(const bf16_t* __restrict__ feat, const float* __restrict__ wl,
                                                         const float* __restrict__ m16, float* __restrict__ y, int HW, int C, int Q) {
     __shared__ float wsm[128][17];
@@ -457,11 +466,21 @@ __global__ __launch_bounds__(256) void summarize_kernel(const bf16_t* __restrict
     red[s][cl][16] = area;
     __syncthreads();
     if (s == 0) {
+        float* yp = y + ((long)k * gridDim.z + blockIdx.z) * Q * (C + 1);
         for (int q = 0; q < 16; ++q)
-            atomicAdd(&y[((long)k * Q + q) * (C + 1) + c], red[0][cl][q] + red[1][cl][q] + red[2][cl][q] + red[3][cl][q]);
+            yp[(long)q * (C + 1) + c] = red[0][cl][q] + red[1][cl][q] + red[2][cl][q] + red[3][cl][q];
         if (blockIdx.x == 0 && cl < Q)
-            atomicAdd(&y[((long)k * Q + cl) * (C + 1) + C], red[0][cl][16] + red[1][cl][16] + red[2][cl][16] + red[3][cl][16]);
+            yp[(long)cl * (C + 1) + C] = red[0][cl][16] + red[1][cl][16] + red[2][cl][16] + red[3][cl][16];
     }
+}
+
+__global__ void summarize_final_kernel(const float* __restrict__ part, float* __restrict__ y, int nchunk, int n) {
+    const int k = blockIdx.y;
+    int e = blockIdx.x * blockDim.x + threadIdx.x;          // element of [Q, C+1]
+    if (e >= n) return;
+    float sum = 0.f;
+    for (int c = 0; c < nchunk; ++c) sum += part[((long)k * nchunk + c) * n + e];
+    y[(long)k * n + e] = sum;
 }
 
 __global__ void add_pe_kernel(const uint4* __restrict__ x, const uint4* __restrict__ pe, uint4* __restrict__ y, int B, long n8) {
@@ -548,9 +567,10 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
         }
         case CUTIE_OP_GAP: {
             if (i[2] > 256 || (i[2] & 7) || 256 % (i[2] / 8)) { cutie_set_error("gap: C must divide 256 octet-wise (C=%d)", i[2]); return -2; }
-            long n = (long)i[0] * i[2];
-            hipLaunchKernelGGL(memset32_kernel, GRID1D(n, BS), dim3(BS), 0, s, (uint32_t*)p[1], n, 0u);
-            hipLaunchKernelGGL(gap_kernel, dim3((i[1] + 63) / 64, i[0]), dim3(256), 0, s, (const bf16_t*)p[0], (float*)p[1], i[1], i[2], 1.f / (float)i[1]);
+            if (!p[2]) { cutie_set_error("gap: scratch buffer required"); return -2; }
+            int nchunk = (i[1] + 63) / 64;
+            hipLaunchKernelGGL(gap_partial_kernel, dim3(nchunk, i[0]), dim3(256), 0, s, (const bf16_t*)p[0], (float*)p[2], i[1], i[2]);
+            hipLaunchKernelGGL(gap_final_kernel, dim3(i[0]), dim3(256), 0, s, (const float*)p[2], (float*)p[1], nchunk, i[2], 1.f / (float)i[1]);
             break;
         }
         case CUTIE_OP_ECA_APPLY: {
@@ -596,10 +616,11 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
         case CUTIE_OP_SUMMARIZE:
             if (i[3] != 16 || (i[2] & 63)) { cutie_set_error("summarize: Q must be 16, C %% 64"); return -2; }
             {
-                long n = (long)i[0] * i[3] * (i[2] + 1);
-                hipLaunchKernelGGL(memset32_kernel, GRID1D(n, BS), dim3(BS), 0, s, (uint32_t*)p[3], n, 0u);
+                if (!p[4]) { cutie_set_error("summarize: scratch buffer required"); return -2; }
+                int nchunk = (i[1] + 127) / 128, n = i[3] * (i[2] + 1);
+                hipLaunchKernelGGL(summarize_kernel, dim3(i[2] / 64, i[0], nchunk), dim3(256), 0, s, (const bf16_t*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[4], i[1], i[2], i[3]);
+                hipLaunchKernelGGL(summarize_final_kernel, dim3((n + 255) / 256, i[0]), dim3(256), 0, s, (const float*)p[4], (float*)p[3], nchunk, n);
             }
-            hipLaunchKernelGGL(summarize_kernel, dim3(i[2] / 64, i[0], (i[1] + 127) / 128), dim3(256), 0, s, (const bf16_t*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[3], i[1], i[2], i[3]);
             break;
         case CUTIE_OP_ADD_PE: {
             long n8 = i[1] / 8;

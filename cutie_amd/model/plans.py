@@ -48,6 +48,7 @@ class Plan:
         self.ol = O.OpList()
         self.bufs = {}
         self.meta = {}
+        self.tuned = False
 
     def buf(self, name, shape, dtype=BF16):
         assert name not in self.bufs, name
@@ -56,7 +57,44 @@ class Plan:
         return t
 
     def run(self, **dyn):
+        if not self.tuned:
+            self.tuned = True
+            self.autotune_convs(**dyn)
         self.ol.run(**dyn)
+
+    def autotune_convs(self, **dyn):
+        """Pick the fastest tile shape for every conv of this plan by timing the candidates on the device
+        (hipEvents on the launch stream, cutie_time_ops).  Called once per plan, at its first run, with the real
+        dynamic buffers bound; results are cached per conv geometry on the engine.  No-op under the test interpreter."""
+        from .. import _lib
+        ex = _lib.get_executor()
+        ex = getattr(ex, 'ex', ex)                       # bench.py's recording shim wraps the real executor
+        if ex.is_mock or not hasattr(ex, 'time_ops'):
+            return
+        ol = self.ol
+        if ol.arr is None:
+            ol.finalize()
+        ol.bind(**dyn)
+        arr = ol.arr
+        cache = self.eng.tile_cache
+        for n in range(len(arr)):
+            if arr['kind'][n] != O.CONV:
+                continue
+            i = arr['i'][n]
+            M, cout, cin = int(i[0]) * int(i[7]) * int(i[8]), int(i[9]), int(i[3]) + int(i[4])
+            key = (M, cout, cin, int(i[11]), int(i[13]), int(arr['flags'][n]) & 3, int(i[1]), int(i[2]))
+            best = cache.get(key)
+            if best is None:
+                one = arr[n:n + 1].copy()
+                best, best_t = int(i[17]), None
+                for t in O.tile_candidates(M, cout, cin):
+                    one['i'][0, 17] = t
+                    ms = ex.time_ops(one, 3)
+                    if best_t is None or ms < best_t:
+                        best, best_t = t, ms
+                cache[key] = best
+            arr['i'][n, 17] = best
+        self.tuned = True
 
     # ---- conv helper ------------------------------------------------------------------
     def conv(self, wname, x, *, name=None, out=None, stride=1, pad=None, x2=None, res=None, res_bcast=False,

@@ -53,7 +53,7 @@ def pack_conv(w, bias, device, segs=None):
     w = torch.cat(parts, 1)
     cin_p = w.shape[1]
     k = kh * kw * cin_p
-    kpad = -(-k // 32) * 32
+    kpad = -(-k // 128) * 128                  # multiple of every BK the kernel family uses (32/64/128)
     coutpad = -(-cout // 128) * 128
     flat = w.permute(0, 2, 3, 1).reshape(cout, k)
     packed = torch.zeros(coutpad, kpad)

@@ -23,18 +23,40 @@ F_RELU_IN, F_OUT_F32, F_RES_BCAST = 1, 2, 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQ1 = 0, 1, 2, 3
 ACT_SHIFT = 4
 
-TILES = {0: (128, 128), 1: (128, 64), 2: (64, 64), 3: (256, 16), 4: (64, 128)}
+# conv tile table (mirrors the switch in csrc/conv_igemm.hip): id -> (BM, BN, BK)
+TILES = {0: (128, 128, 32), 1: (128, 64, 32), 2: (64, 64, 32), 3: (256, 16, 32), 4: (64, 128, 32),
+         5: (64, 64, 64), 6: (64, 128, 64), 7: (128, 128, 64), 8: (64, 64, 128), 9: (32, 64, 64),
+         10: (128, 64, 64), 11: (32, 64, 128), 12: (32, 128, 64)}
 NUM_CU = 256
 
 
-def pick_tile(M, cout):
-    """Largest MFMA block tile that still yields >= NUM_CU workgroups (256 CUs to fill)."""
+def tile_candidates(M, cout, cin):
+    """Tile ids that are legal for a conv (BK > 32 needs Cin >= 32; tiny Cout uses the 256x16 tile)."""
+    if cout <= 16:
+        return [3]
+    out = []
+    for t, (bm, bn, bk) in TILES.items():
+        if t == 3 or (bk > 32 and cin < 32):
+            continue
+        if bn == 128 and cout <= 64:
+            continue
+        if bm * 2 > max(M, 64) * 2 and bm > 64:          # do not pad a tiny M to a huge tile
+            continue
+        out.append(t)
+    return out
+
+
+def pick_tile(M, cout, cin=64):
+    """Static heuristic (used when no GPU is present to autotune): the largest tile that still yields
+    >= NUM_CU workgroups, with BK=64 when the input has enough channels."""
     if cout <= 16:
         return 3
-    cands = [0, 4, 1, 2] if cout > 64 else [1, 2]
+    cands = [6, 5, 9] if cin >= 32 else [4, 2]
+    if cout <= 64:
+        cands = [c for c in cands if TILES[c][1] <= 64] or [2]
     best, best_blocks = None, -1
     for t in cands:
-        bm, bn = TILES[t]
+        bm, bn, _ = TILES[t]
         blocks = -(-M // bm) * -(-cout // bn)
         if blocks >= NUM_CU:
             return t
@@ -121,7 +143,7 @@ class OpList:
         assert C1 + C2 == w.cin_padded, (C1, C2, w.cin_padded)
         M = B * OH * OW
         if tile is None:
-            tile = pick_tile(M, w.cout)
+            tile = pick_tile(M, w.cout, C1 + C2)
         return self.add(CONV, flags,
                         [B, H, W, C1, C2, ldx1, ldx2, OH, OW, w.cout, ldy, w.kh, w.kw, stride, pad, ldr, w.kpad, tile, w.cin_real],
                         [], [x1, x2, w.weight, w.bias, res, y])
@@ -142,8 +164,10 @@ class OpList:
     def mask_down(self, masks, pair, m16, *, K, H, W, r=16):
         return self.add(MASK_DOWN, 0, [K, H, W, r], [], [masks, pair, m16])
 
-    def gap(self, x, y, *, B, HW, C):
-        return self.add(GAP, 0, [B, HW, C], [], [x, y])
+    def gap(self, x, y, *, B, HW, C, scratch=None):
+        if scratch is None:
+            scratch = torch.zeros((B, -(-HW // 64), C), dtype=torch.float32, device=y.device)
+        return self.add(GAP, 0, [B, HW, C], [], [x, y, scratch])
 
     def eca_apply(self, x, gap, wk, r, y, *, B, HW, C):
         return self.add(ECA_APPLY, 0, [B, HW, C], [], [x, gap, wk, r, y])
@@ -189,8 +213,10 @@ class OpList:
     def attn_p2q(self, q, kq, vq, y, *, K, Q, HW, C, heads, ldq):
         return self.add(ATTN_P2Q, 0, [K, Q, HW, C, heads, ldq], [], [q, kq, vq, y])
 
-    def summarize(self, feat, wl, m16, y, *, K, HW, C, Q):
-        return self.add(SUMMARIZE, 0, [K, HW, C, Q], [], [feat, wl, m16, y])
+    def summarize(self, feat, wl, m16, y, *, K, HW, C, Q, scratch=None):
+        if scratch is None:
+            scratch = torch.zeros((K, -(-HW // 128), Q, C + 1), dtype=torch.float32, device=m16.device)
+        return self.add(SUMMARIZE, 0, [K, HW, C, Q], [], [feat, wl, m16, y, scratch])
 
     def add_pe(self, x, pe, y, *, B, n):
         return self.add(ADD_PE, 0, [B, n], [], [x, pe, y])

@@ -83,7 +83,7 @@ enum {
      * p0=masks f32 [K,H,W] p1=y bf16 [K,h,w,8] p2=m16 f32 [K,h,w] (may be 0)  i: 0 K 1 H 2 W 3 r */
     CUTIE_OP_MASK_DOWN = 6,
     /* GAP: per-(b,c) mean over pixels (nn.AdaptiveAvgPool2d(1)), channel_attn.py:31-32
-     * p0=x bf16 [B,HW,C] p1=y f32 [B,C]   i: 0 B 1 HW 2 C */
+     * p0=x bf16 [B,HW,C] p1=y f32 [B,C] p2=scratch f32 [B,ceil(HW/64),C] (deterministic 2-stage sum)   i: 0 B 1 HW 2 C */
     CUTIE_OP_GAP = 7,
     /* ECA_APPLY: y = x * sigmoid(conv1d_k5(gap))[c] + r    channel_attn.py:33-37
      * p0=x bf16 [B,HW,C] p1=gap f32 [B,C] p2=w f32[5] p3=r bf16 [B,HW,C] p4=y bf16   i: 0 B 1 HW 2 C */
@@ -137,6 +137,7 @@ enum {
     CUTIE_OP_ATTN_P2Q = 20,
     /* SUMMARIZE: weights=sigmoid(logits)*[m x8 | (1-m) x8]; sums=einsum; area   object_summarizer.py:11-23
      * p0=feature bf16 [K,HW,C] p1=wlogits f32 [K,HW,Q] p2=m16 f32 [K,HW] p3=y f32 [K,Q,C+1]
+     * p4=scratch f32 [K,ceil(HW/128),Q,C+1] (deterministic 2-stage sum)
      * i: 0 K 1 HW 2 C 3 Q */
     CUTIE_OP_SUMMARIZE = 21,
     /* ADD_PE: y = x + pe (broadcast over objects), bf16     object_summarizer.py:74-76
