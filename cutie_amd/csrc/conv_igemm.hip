@@ -31,17 +31,22 @@ __device__ __forceinline__ int swz(int row) {
 }
 
 template <int BM, int BN, int WM, int WN, int BK, int S>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) {
+    constexpr int NT = WM * WN * 64;                    // 4 or 8 waves
     constexpr int CPR = BK / 8;                         // 16-B chunks per LDS row
-    constexpr int RPT = 256 / CPR;                      // rows covered by one pass of the 256 threads
-    constexpr int NX = (BM * CPR) / 256;                // X chunks per thread per tile
-    constexpr int NWC = (BN * CPR + 255) / 256;         // W chunks per thread per tile
+    constexpr int RPT = NT / CPR;                       // rows covered by one pass of the NT threads
+    constexpr int NX = (BM * CPR) / NT;                 // X chunks per thread per tile
+    constexpr int NWC = (BN * CPR + NT - 1) / NT;       // W chunks per thread per tile
     constexpr int TM = BM / WM / 16;                    // 16-pixel MFMA tiles per wave
     constexpr int TN = BN / WN / 16;                    // 16-channel MFMA tiles per wave
     constexpr int KSUB = BK / 32;                       // MFMA k-steps per tile
     constexpr int NWRAP = BK == 32 ? 4 : BK / 32;       // tap wraps per tile advance (BK > 32 requires Cin >= 32)
-    static_assert(WM * WN == 4 && NX >= 1 && TM >= 1 && TN >= 1 && S >= 2, "bad tile");
-    __shared__ u32x4 smem[2][(BM + BN) * CPR];
+    static_assert((NT == 256 || NT == 512) && NX >= 1 && TM >= 1 && TN >= 1 && S >= 2 && (BM * CPR) % NT == 0, "bad tile");
+    constexpr int LDC = BN + 4;                         // fp32 row stride of the epilogue tile (pad: bank spread)
+    constexpr int PIPE_CHUNKS = 2 * (BM + BN) * CPR;    // 16-B chunks of the double-buffered operand tiles
+    constexpr int EPI_CHUNKS = (BM * LDC * 4 + 15) / 16;
+    __shared__ u32x4 smem_raw[PIPE_CHUNKS > EPI_CHUNKS ? PIPE_CHUNKS : EPI_CHUNKS];
+    u32x4 (*smem)[(BM + BN) * CPR] = reinterpret_cast<u32x4 (*)[(BM + BN) * CPR]>(smem_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -173,59 +178,75 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         }
     }
 
-    // ---- epilogue: bias + residual + activation, NHWC store (4 consecutive channels per lane) ----
+    // ---- epilogue.  The MFMA layout gives each lane 4 consecutive channels of one pixel (8-B pieces); the tile is
+    // transposed through LDS (fp32) so that global traffic is whole 16-B chunks along the channel axis: threads
+    // walk [pixel][8-channel chunk], i.e. full 128/256-B lines per pixel for the residual loads and the stores. ----
+    float* ctile = reinterpret_cast<float*>(smem_raw);   // the K loop ended with a barrier: operand tiles are dead
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int px = pm0 + b * 16 + l15, ch = cn0 + a * 16 + l4 * 4;
+            *reinterpret_cast<f32x4*>(ctile + px * LDC + ch) = acc[a][b];
+        }
+    __syncthreads();
     const int act = (p.flags >> CUTIE_ACT_SHIFT) & 7;
     const bool out_f32 = p.flags & CUTIE_F_OUT_F32;
     const bool res_bcast = p.flags & CUTIE_F_RES_BCAST;
-    const bool vec_ok = (p.ldy & 3) == 0;
-    const bool resvec_ok = (p.ldr & 3) == 0;
+    const bool vec_y = out_f32 ? ((p.ldy & 3) == 0) : ((p.ldy & 7) == 0);
+    const bool vec_r = (p.ldr & 7) == 0;
+    constexpr int CH8 = BN / 8;                          // 8-channel chunks per tile row
+    for (int q = tid; q < BM * CH8; q += NT) {
+        const int px = q / CH8, c8 = q - px * CH8;
+        const int m = m0 + px, ch0 = n0 + c8 * 8;
+        if (m >= p.M || ch0 >= p.Cout) continue;
+        float v[8];
+        {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(ctile + px * LDC + c8 * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(ctile + px * LDC + c8 * 8 + 4);
+            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        }
+        const bool full = ch0 + 7 < p.Cout;
+        if (p.bias) {
 #pragma unroll
-    for (int b = 0; b < TM; ++b) {
-        int m = m0 + pm0 + b * 16 + l15;
-        if (m >= p.M) continue;
-        int mres = res_bcast ? (m % p.OHW) : m;
-#pragma unroll
-        for (int a = 0; a < TN; ++a) {
-            int ch0 = n0 + cn0 + a * 16 + l4 * 4;
-            if (ch0 >= p.Cout) continue;
-            float v[4];
-            bool full = ch0 + 3 < p.Cout;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[a][b][r];
-                if (p.bias && ch0 + r < p.Cout) v[r] += p.bias[ch0 + r];
-            }
-            if (p.res) {
-                const bf16_t* rp = p.res + (long)mres * p.ldr + ch0;
-                if (full && resvec_ok) {
-                    uint2 rr = *reinterpret_cast<const uint2*>(rp);
-                    v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-                    v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (ch0 + r < p.Cout) v[r] += bf2f(rp[r]);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (act == CUTIE_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
-                else if (act == CUTIE_ACT_SIGMOID) v[r] = sigmoidf_(v[r]);
-                else if (act == CUTIE_ACT_SQ1) v[r] = v[r] * v[r] + 1.f;
-            }
-            if (out_f32) {
-                float* yp = reinterpret_cast<float*>(p.y) + (long)m * p.ldy + ch0;
-                if (full && vec_ok) *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
-                else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (ch0 + r < p.Cout) yp[r] = v[r];
-                }
+            for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) v[r] += p.bias[ch0 + r];
+        }
+        if (p.res) {
+            const int mres = res_bcast ? (m % p.OHW) : m;
+            const bf16_t* rp = p.res + (long)mres * p.ldr + ch0;
+            if (full && vec_r) {
+                const uint4 rr = *reinterpret_cast<const uint4*>(rp);
+                v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+                v[4] += __uint_as_float(rr.z << 16); v[5] += __uint_as_float(rr.z & 0xffff0000u);
+                v[6] += __uint_as_float(rr.w << 16); v[7] += __uint_as_float(rr.w & 0xffff0000u);
             } else {
-                bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + (long)m * p.ldy + ch0;
-                if (full && vec_ok) *reinterpret_cast<uint2*>(yp) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) if (ch0 + r < p.Cout) yp[r] = f2bf(v[r]);
-                }
+                for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) v[r] += bf2f(rp[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (act == CUTIE_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+            else if (act == CUTIE_ACT_SIGMOID) v[r] = sigmoidf_(v[r]);
+            else if (act == CUTIE_ACT_SQ1) v[r] = v[r] * v[r] + 1.f;
+        }
+        if (out_f32) {
+            float* yp = reinterpret_cast<float*>(p.y) + (long)m * p.ldy + ch0;
+            if (full && vec_y) {
+                *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) yp[r] = v[r];
+            }
+        } else {
+            bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + (long)m * p.ldy + ch0;
+            if (full && vec_y) {
+                *reinterpret_cast<uint4*>(yp) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) yp[r] = f2bf(v[r]);
             }
         }
     }
@@ -236,7 +257,7 @@ static int launch_cfg(const ConvParams& p, hipStream_t s) {
     if (p.Kpad % BK) { cutie_set_error("conv: Kpad %d not a multiple of BK %d", p.Kpad, BK); return -2; }
     if (BK > 32 && p.Cin < 32) { cutie_set_error("conv: BK %d needs Cin >= 32 (Cin=%d)", BK, p.Cin); return -2; }
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, S>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, S>), grid, dim3(WM * WN * 64), 0, s, p);
     return (int)hipGetLastError();
 }
 
@@ -270,6 +291,12 @@ int launch_conv(const cutie_op* op, hipStream_t s) {
         case 10: return launch_cfg<128, 64, 2, 2, 64, 3>(p, s);
         case 11: return launch_cfg<32, 64, 2, 2, 128, 3>(p, s);
         case 12: return launch_cfg<32, 128, 2, 2, 64, 3>(p, s);
+        case 13: return launch_cfg<64, 64, 2, 4, 64, 4>(p, s);        // 8 waves
+        case 14: return launch_cfg<128, 64, 4, 2, 64, 4>(p, s);
+        case 15: return launch_cfg<64, 128, 2, 4, 64, 4>(p, s);
+        case 16: return launch_cfg<128, 128, 2, 4, 64, 3>(p, s);
+        case 17: return launch_cfg<64, 64, 2, 4, 128, 3>(p, s);
+        case 18: return launch_cfg<128, 128, 2, 4, 32, 4>(p, s);
         default: cutie_set_error("conv: bad tile id %d", i[17]); return -2;
     }
 }

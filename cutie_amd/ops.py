@@ -26,7 +26,8 @@ ACT_SHIFT = 4
 # conv tile table (mirrors the switch in csrc/conv_igemm.hip): id -> (BM, BN, BK)
 TILES = {0: (128, 128, 32), 1: (128, 64, 32), 2: (64, 64, 32), 3: (256, 16, 32), 4: (64, 128, 32),
          5: (64, 64, 64), 6: (64, 128, 64), 7: (128, 128, 64), 8: (64, 64, 128), 9: (32, 64, 64),
-         10: (128, 64, 64), 11: (32, 64, 128), 12: (32, 128, 64)}
+         10: (128, 64, 64), 11: (32, 64, 128), 12: (32, 128, 64),
+         13: (64, 64, 64), 14: (128, 64, 64), 15: (64, 128, 64), 16: (128, 128, 64), 17: (64, 64, 128), 18: (128, 128, 32)}   # 13+: 8 waves
 NUM_CU = 256
 
 

@@ -102,7 +102,7 @@ def test_conv_auto_tile(ci):
     check(hip, ref, f'conv[{ci}]')
 
 
-@pytest.mark.parametrize('tile', list(range(13)))
+@pytest.mark.parametrize('tile', list(range(19)))
 @pytest.mark.parametrize('ci', [0, 2, 4, 6, 7, 12, 14])
 def test_conv_every_tile(ci, tile):
     c = CONV_CASES[ci]
