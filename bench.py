@@ -131,7 +131,8 @@ def main():
     frames = torch.stack([clip.frame(t) for t in range(128)]).to(dev)           # resident in HBM (630 MB)
     mask = clip.first_mask().to(dev)
     proc = InferenceCore(net, cfg=cfg)
-    with torch.inference_mode():
+    side = torch.cuda.Stream(device=dev)                   # a real (capturable) stream, not the legacy null stream
+    with torch.inference_mode(), torch.cuda.stream(side):
         proc.step(frames[0], mask, objects=clip.objects)
         t_idx = 1
         for _ in range(args.preroll + args.warmup):
@@ -176,6 +177,24 @@ def main():
                 for b in proc.memory.buckets.values():
                     aff_f += (256 + 512 * len(b.objects)) * float(b.size()) * HW
             n_conv = int((allops['kind'] == O.CONV).sum())
+            # device-time breakdown of the last recorded frame by op kind (back-to-back replays, hipEvents), and the
+            # whole frame replayed as ONE HIP graph (no host involvement): shows how much of the step is launch gaps
+            names = {v: k for k, v in vars(O).items() if k.isupper() and isinstance(v, int) and 1 <= v <= 35 and k not in ('NI', 'NF', 'NP', 'NUM_CU')}
+            breakdown = {}
+            for kind in sorted(set(int(k) for k in allops['kind'])):
+                sel = allops[allops['kind'] == kind]
+                breakdown[names.get(kind, str(kind))] = [int(len(sel)), round(rec.ex.time_ops(sel, 3) * 1e3, 1)]
+            lib = rec.ex.lib
+            g = lib.cutie_graph_capture(allops.ctypes.data, len(allops), rec.ex.stream())
+            graph_ms = None
+            if g:
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    lib.cutie_graph_launch(g, rec.ex.stream())
+                torch.cuda.synchronize()
+                graph_ms = (time.perf_counter() - t1) / 20 * 1e3
+                lib.cutie_graph_destroy(g)
             roof = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<*> (all conv launches of a frame)',
                     'achieved': round(conv_f / conv_t / 1e12, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(conv_f / conv_t / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': None,
@@ -234,6 +253,8 @@ def main():
         if roof is not None:
             out['roofline'] = roof
             out['roofline_affinity'] = roof_aff
+            out['device_us_by_kind'] = breakdown
+            out['frame_as_one_hip_graph_ms'] = None if graph_ms is None else round(graph_ms, 3)
         if cpu is not None:
             out['cpu_baseline'] = cpu
             out['speedup_vs_cpu'] = round(fps / cpu['value'], 1)

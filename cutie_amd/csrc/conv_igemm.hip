@@ -252,6 +252,52 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) 
     }
 }
 
+// ---- Cout == 1 convolutions (mask_pred 1x1, d_proj / pred 3x3): a per-pixel dot product, HBM/L2-bound.  An MFMA tile
+// would waste 15/16 of its columns and (at M = 1620) leave 249 CUs idle, so: LP = Cin/8 lanes per output pixel, each lane
+// owns 8 channels (one 16-B load per tap), weights staged once per block in LDS, shuffle reduction over the LP lanes.
+__global__ __launch_bounds__(256) void conv_cout1_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wlds_raw[];
+    u32x4* wlds = reinterpret_cast<u32x4*>(wlds_raw);                   // [KH*KW][Cin/8] chunks of the single filter
+    const int LP = p.Cin >> 3;                                           // lanes per pixel (power of two, <= 64)
+    const int ntap = p.KH * p.KW;
+    for (int t = threadIdx.x; t < ntap * LP; t += 256) wlds[t] = *reinterpret_cast<const u32x4*>(p.w + (long)t * 8);
+    __syncthreads();
+    const int ppb = 256 / LP;                                            // pixels per block
+    const int sub = threadIdx.x / LP, cl = threadIdx.x % LP;
+    const int m = blockIdx.x * ppb + sub;
+    float acc = 0.f;
+    if (m < p.M) {
+        const int b = m / p.OHW, rem = m - b * p.OHW, oh = rem / p.OW, ow = rem - oh * p.OW;
+        const bool relu_in = p.flags & CUTIE_F_RELU_IN;
+        for (int kh = 0; kh < p.KH; ++kh) {
+            const int ih = oh * p.stride - p.pad + kh;
+            if ((unsigned)ih >= (unsigned)p.H) continue;
+            for (int kw = 0; kw < p.KW; ++kw) {
+                const int iw = ow * p.stride - p.pad + kw;
+                if ((unsigned)iw >= (unsigned)p.W) continue;
+                u32x4 xv = *reinterpret_cast<const u32x4*>(p.x1 + (((long)b * p.H + ih) * p.W + iw) * p.ldx1 + cl * 8);
+                if (relu_in) { xv.x = relu_bf2(xv.x); xv.y = relu_bf2(xv.y); xv.z = relu_bf2(xv.z); xv.w = relu_bf2(xv.w); }
+                const u32x4 wv = wlds[(kh * p.KW + kw) * LP + cl];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc += __uint_as_float(xv[i] << 16) * __uint_as_float(wv[i] << 16);
+                    acc += __uint_as_float(xv[i] & 0xffff0000u) * __uint_as_float(wv[i] & 0xffff0000u);
+                }
+            }
+        }
+    }
+    for (int o = LP >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (cl == 0 && m < p.M) {
+        float v = acc + (p.bias ? p.bias[0] : 0.f);
+        const int act = (p.flags >> CUTIE_ACT_SHIFT) & 7;
+        if (act == CUTIE_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == CUTIE_ACT_SIGMOID) v = sigmoidf_(v);
+        else if (act == CUTIE_ACT_SQ1) v = v * v + 1.f;
+        if (p.flags & CUTIE_F_OUT_F32) reinterpret_cast<float*>(p.y)[(long)m * p.ldy] = v;
+        else reinterpret_cast<bf16_t*>(p.y)[(long)m * p.ldy] = f2bf(v);
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int BK, int S>
 static int launch_cfg(const ConvParams& p, hipStream_t s) {
     if (p.Kpad % BK) { cutie_set_error("conv: Kpad %d not a multiple of BK %d", p.Kpad, BK); return -2; }
@@ -276,6 +322,16 @@ int launch_conv(const cutie_op* op, hipStream_t s) {
         cutie_set_error("conv: bad geometry C1=%d C2=%d ldx1=%d ldx2=%d Kpad=%d M=%d Cout=%d",
                         p.C1, p.C2, p.ldx1, p.ldx2, p.Kpad, p.M, p.Cout);
         return -2;
+    }
+    if (i[17] == 19) {                                   // dedicated Cout == 1 kernel
+        const int LP = p.Cin >> 3;
+        if (p.Cout != 1 || p.C2 != 0 || p.res || LP > 64 || (LP & (LP - 1)) || LP < 1) {
+            cutie_set_error("conv cout1: needs Cout=1, single source, no residual, Cin/8 a power of two <= 64 (Cin=%d)", p.Cin);
+            return -2;
+        }
+        const int ppb = 256 / LP;
+        hipLaunchKernelGGL(conv_cout1_kernel, dim3((p.M + ppb - 1) / ppb), dim3(256), (size_t)p.KH * p.KW * LP * 16, s, p);
+        return (int)hipGetLastError();
     }
     switch (i[17]) {
         case 0: return launch_cfg<128, 128, 2, 2, 32, 4>(p, s);

@@ -87,7 +87,10 @@ class Plan:
             if best is None:
                 one = arr[n:n + 1].copy()
                 best, best_t = int(i[17]), None
-                for t in O.tile_candidates(M, cout, cin):
+                cands = O.tile_candidates(M, cout, cin)
+                if int(i[4]) or arr['p'][n, 4]:              # 2-source or residual conv: no cout1 kernel
+                    cands = [t for t in cands if t != O.COUT1_TILE]
+                for t in cands:
                     one['i'][0, 17] = t
                     ms = ex.time_ops(one, 3)
                     if best_t is None or ms < best_t:

@@ -31,10 +31,18 @@ TILES = {0: (128, 128, 32), 1: (128, 64, 32), 2: (64, 64, 32), 3: (256, 16, 32),
 NUM_CU = 256
 
 
+COUT1_TILE = 19          # dedicated per-pixel dot-product kernel (conv_cout1_kernel)
+
+
+def cout1_ok(cout, cin, c2=0, res=False):
+    lp = cin // 8
+    return cout == 1 and c2 == 0 and not res and cin % 8 == 0 and 1 <= lp <= 64 and (lp & (lp - 1)) == 0
+
+
 def tile_candidates(M, cout, cin):
     """Tile ids that are legal for a conv (BK > 32 needs Cin >= 32; tiny Cout uses the 256x16 tile)."""
     if cout <= 16:
-        return [3]
+        return [3] + ([COUT1_TILE] if cout1_ok(cout, cin) else [])
     out = []
     for t, (bm, bn, bk) in TILES.items():
         if t == 3 or (bk > 32 and cin < 32):
@@ -144,7 +152,7 @@ class OpList:
         assert C1 + C2 == w.cin_padded, (C1, C2, w.cin_padded)
         M = B * OH * OW
         if tile is None:
-            tile = pick_tile(M, w.cout, C1 + C2)
+            tile = COUT1_TILE if cout1_ok(w.cout, C1 + C2, C2, res is not None) else pick_tile(M, w.cout, C1 + C2)
         return self.add(CONV, flags,
                         [B, H, W, C1, C2, ldx1, ldx2, OH, OW, w.cout, ldy, w.kh, w.kw, stride, pad, ldr, w.kpad, tile, w.cin_real],
                         [], [x1, x2, w.weight, w.bias, res, y])

@@ -106,10 +106,22 @@ def test_conv_auto_tile(ci):
 @pytest.mark.parametrize('ci', [0, 2, 4, 6, 7, 12, 14])
 def test_conv_every_tile(ci, tile):
     c = CONV_CASES[ci]
-    if O.TILES[tile][2] > 32 and c['C1'] + c.get('C2', 0) < 32:
+    if tile in O.TILES and O.TILES[tile][2] > 32 and c['C1'] + c.get('C2', 0) < 32:
         pytest.skip('BK > 32 needs Cin >= 32')
     hip, ref = run_both(_conv_build(c, tile), seed=100 + ci)
     check(hip, ref, f'conv[{ci}] tile{tile}')
+
+
+@pytest.mark.parametrize('ci', [8, 9])
+def test_conv_cout1_kernel(ci):
+    hip, ref = run_both(_conv_build(CONV_CASES[ci], O.COUT1_TILE), seed=300 + ci)
+    check(hip, ref, f'conv cout1 [{ci}]')
+
+
+def test_conv_cout1_1x1_relu_in():
+    c = dict(B=3, H=30, W=54, C1=256, Cout=1, k=1, relu_in=True, out_f32=True)
+    hip, ref = run_both(_conv_build(c, O.COUT1_TILE), seed=9)
+    check(hip, ref, 'conv cout1 1x1')
 
 
 def test_conv_strided_channel_slices():
