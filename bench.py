@@ -50,6 +50,8 @@ def parse():
                     help='untimed frames run before the warm-up so the memory bank is in its steady-state size')
     ap.add_argument('--cpu-frames', type=int, default=12, help='frames of the CPU baseline sample (0 = skip)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-breakdown', action='store_true')
+    ap.add_argument('--no-graph', action='store_true')
     return ap.parse_args()
 
 
@@ -181,11 +183,16 @@ def main():
             # whole frame replayed as ONE HIP graph (no host involvement): shows how much of the step is launch gaps
             names = {v: k for k, v in vars(O).items() if k.isupper() and isinstance(v, int) and 1 <= v <= 35 and k not in ('NI', 'NF', 'NP', 'NUM_CU')}
             breakdown = {}
-            for kind in sorted(set(int(k) for k in allops['kind'])):
+            aff_kinds = (O.AFF_SCORE, O.AFF_SELECT, O.AFF_READOUT)
+            if not args.no_breakdown:
+                breakdown['AFFINITY(score x2+select+readout)'] = [int(len(affs)), round(rec.ex.time_ops(affs, 3) * 1e3, 1)]
+            for kind in ([] if args.no_breakdown else sorted(set(int(k) for k in allops['kind']) - set(aff_kinds))):
                 sel = allops[allops['kind'] == kind]
+                if os.environ.get('BENCH_DEBUG'):
+                    print('replay kind', kind, names.get(kind), len(sel), file=sys.stderr, flush=True)
                 breakdown[names.get(kind, str(kind))] = [int(len(sel)), round(rec.ex.time_ops(sel, 3) * 1e3, 1)]
             lib = rec.ex.lib
-            g = lib.cutie_graph_capture(allops.ctypes.data, len(allops), rec.ex.stream())
+            g = None if args.no_graph else lib.cutie_graph_capture(allops.ctypes.data, len(allops), rec.ex.stream())
             graph_ms = None
             if g:
                 torch.cuda.synchronize()

@@ -60,9 +60,16 @@ struct ScoreParams {
     int HW, HWp, nranges, rs[3], rn[3], G, cap, mode, tiles_per_block;
 };
 
-// grid (HWp/64, ceil(G/tiles_per_block)); wave w of the block owns queries j0 + 16w .. +15
+typedef __attribute__((ext_vector_type(4))) unsigned int au32x4;
+
+// grid (HWp/64, ceil(G/tiles_per_block)); wave w of the block owns queries j0 + 16w .. +15.
+// The memory operands of 4 consecutive 16-token tiles (64 rows x [hi|lo] x 256 B = 32 KB) are staged ONCE per block in
+// LDS (double-buffered, register prefetch of the next group) and shared by the 4 waves; rows are XOR-swizzled by
+// (row & 15) so the ds_read_b128 fragment reads are conflict-free.  B fragments of the 16 queries stay in registers.
+#define AFF_TG 4                                      // tiles per LDS group
 __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+    __shared__ au32x4 lds[2][2 * 64 * 16];            // [buffer][hi/lo][row][16 chunks]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int j = blockIdx.x * 64 + wave * 16 + l15;                   // query column of this lane
     bf16x8 bh[4], bl[4];
 #pragma unroll
@@ -80,52 +87,93 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
     const int g0 = blockIdx.y * p.tiles_per_block;
     const int g1 = min(g0 + p.tiles_per_block, p.G);
     const int T0 = (p.rn[0] + 15) >> 4, T1 = (p.nranges > 1) ? ((p.rn[1] + 15) >> 4) : 0;
-    for (int g = g0; g < g1; ++g) {
-        int r, lt;
+    // this thread stages chunk (row = tid >> 2 .. , 4 chunks) : 64 rows x 16 chunks x 2 arrays = 2048 chunks / 256 threads = 8
+    const int srow = tid >> 2, sc0 = (tid & 3) * 4;                    // row 0..63, chunks sc0..sc0+3 of hi and of lo
+    au32x4 st[8];
+    auto tile_slot = [&](int g, int& start, int& n, int& lt) {
+        int r;
         if (g < T0) { r = 0; lt = g; } else if (g < T0 + T1) { r = 1; lt = g - T0; } else { r = 2; lt = g - T0 - T1; }
-        const int start = p.rs[r], n = p.rn[r];
-        const long arow = (long)(start + lt * 16 + l15) * 128 + l4 * 8;
-        bf16x8 ah[4], al[4];
+        start = p.rs[r]; n = p.rn[r];
+    };
+#define AFF_LOAD(GRP)                                                                                      \
+    {                                                                                                      \
+        int gt = (GRP) + (srow >> 4);                      /* tile of this staging row */                  \
+        gt = gt < g1 ? gt : g1 - 1;                        /* clamp: rows of missing tiles are never used */ \
+        int start_, n_, lt_;                                                                               \
+        tile_slot(gt, start_, n_, lt_);                                                                    \
+        const long off_ = (long)(start_ + lt_ * 16 + (srow & 15)) * 128 + sc0 * 8;                         \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                    \
+            st[c] = *reinterpret_cast<const au32x4*>(p.Ahi + off_ + c * 8);                                \
+            st[4 + c] = *reinterpret_cast<const au32x4*>(p.Alo + off_ + c * 8);                            \
+        }                                                                                                  \
+    }
+#define AFF_STORE(BUF)                                                                                     \
+    {                                                                                                      \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                    \
+            lds[BUF][srow * 16 + ((sc0 + c) ^ (srow & 15))] = st[c];                                       \
+            lds[BUF][1024 + srow * 16 + ((sc0 + c) ^ (srow & 15))] = st[4 + c];                            \
+        }                                                                                                  \
+    }
+    AFF_LOAD(g0);
+    AFF_STORE(0);
+    __syncthreads();
+    int buf = 0;
+    for (int gg = g0; gg < g1; gg += AFF_TG) {
+        const bool more = gg + AFF_TG < g1;
+        if (more) AFF_LOAD(gg + AFF_TG);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            ah[ks] = *reinterpret_cast<const bf16x8*>(p.Ahi + arow + ks * 32);
-            al[ks] = *reinterpret_cast<const bf16x8*>(p.Alo + arow + ks * 32);
-        }
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < AFF_TG; ++t) {
+            const int g = gg + t;
+            if (g < g1) {                                               // block-uniform
+                int start, n, lt;
+                tile_slot(g, start, n, lt);
+                const int row = t * 16 + l15;
+                bf16x8 ah[4], al[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {                                // small cross terms first
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bl[ks], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], bh[ks], acc, 0, 0, 0);
-        }
+                for (int ks = 0; ks < 4; ++ks) {
+                    ah[ks] = __builtin_bit_cast(bf16x8, lds[buf][row * 16 + ((ks * 4 + l4) ^ l15)]);
+                    al[ks] = __builtin_bit_cast(bf16x8, lds[buf][1024 + row * 16 + ((ks * 4 + l4) ^ l15)]);
+                }
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bh[ks], acc, 0, 0, 0);
-        // lane holds tokens lt*16 + l4*4 + r (r = 0..3) of query j
-        float s[4];
-        float mx = -INFINITY;
+                for (int ks = 0; ks < 4; ++ks) {                        // small cross terms first
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bl[ks], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], bh[ks], acc, 0, 0, 0);
+                }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int local = lt * 16 + l4 * 4 + q;
-            bool valid = local < n;
-            float sc = valid ? p.scale[start + local] : 0.f;
-            s[q] = valid ? sc * (acc[q] - cj) : -INFINITY;
-            mx = fmaxf(mx, s[q]);
-        }
-        if (p.mode == 0) {
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            if (l4 == 0) p.gmax_or_tau[(long)g * p.HWp + j] = mx;
-        } else if (jvalid) {
+                for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bh[ks], acc, 0, 0, 0);
+                // lane holds tokens lt*16 + l4*4 + q (q = 0..3) of query j
+                float s[4];
+                float mx = -INFINITY;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (s[q] >= thr && s[q] > -INFINITY) {
-                    int pos = atomicAdd(&p.count[j], 1);
-                    if (pos < p.cap) {
-                        p.cand_val[(long)j * p.cap + pos] = s[q];
-                        p.cand_idx[(long)j * p.cap + pos] = start + lt * 16 + l4 * 4 + q;
+                for (int q = 0; q < 4; ++q) {
+                    int local = lt * 16 + l4 * 4 + q;
+                    bool valid = local < n;
+                    float sc = valid ? p.scale[start + local] : 0.f;
+                    s[q] = valid ? sc * (acc[q] - cj) : -INFINITY;
+                    mx = fmaxf(mx, s[q]);
+                }
+                if (p.mode == 0) {
+                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    if (l4 == 0) p.gmax_or_tau[(long)g * p.HWp + j] = mx;
+                } else if (jvalid) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (s[q] >= thr && s[q] > -INFINITY) {
+                            int pos = atomicAdd(&p.count[j], 1);
+                            if (pos < p.cap) {
+                                p.cand_val[(long)j * p.cap + pos] = s[q];
+                                p.cand_idx[(long)j * p.cap + pos] = start + lt * 16 + l4 * 4 + q;
+                            }
+                        }
                     }
                 }
             }
         }
+        if (more) AFF_STORE(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
     }
 }
 
@@ -205,8 +253,9 @@ __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __
     int cnt = count[j];
     if (cnt > cap) { if (tid == 0) atomicAdd(overflow, 1); cnt = cap; }
     for (int t = tid; t < cnt; t += RO_THREADS) { cv[t] = cand_val[(long)j * cap + t]; ci[t] = cand_idx[(long)j * cap + t]; }
-    __syncthreads();
     const int nsel = min(cnt, topk);
+    if (tid < RO_MAXK) { sel_v[tid] = -INFINITY; sel_i[tid] = cnt > 0 ? cand_idx[(long)j * cap] : 0; sel_w[tid] = 0.f; }
+    __syncthreads();
     for (int t = tid; t < cnt; t += RO_THREADS) {
         float v = cv[t]; int id = ci[t];
         int rank = 0;
@@ -218,7 +267,7 @@ __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __
     }
     __syncthreads();
     if (tid < 64) {                                            // softmax over the selected scores (wave 0)
-        float e = (tid < nsel) ? expf(sel_v[tid] - sel_v[0]) : 0.f;
+        float e = (tid < nsel && sel_v[tid] > -INFINITY) ? expf(sel_v[tid] - sel_v[0]) : 0.f;   // unassigned rank (duplicate entries): weight 0
         float sum = wave_sum(e);
         if (tid < nsel) {
             float w = e / sum;
@@ -272,6 +321,7 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             // enough blocks to fill 256 CUs a few times over, at least 8 tiles per block
             int tpb = (int)(((long)G * qb + 1023) / 1024);
             if (tpb < 8) tpb = 8;
+            tpb = (tpb + AFF_TG - 1) / AFF_TG * AFF_TG;
             sp.tiles_per_block = tpb;
             hipLaunchKernelGGL(aff_score_kernel, dim3(qb, (G + tpb - 1) / tpb), dim3(256), 0, s, sp);
             break;
