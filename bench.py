@@ -181,7 +181,7 @@ def main():
             n_conv = int((allops['kind'] == O.CONV).sum())
             # device-time breakdown of the last recorded frame by op kind (back-to-back replays, hipEvents), and the
             # whole frame replayed as ONE HIP graph (no host involvement): shows how much of the step is launch gaps
-            names = {v: k for k, v in vars(O).items() if k.isupper() and isinstance(v, int) and 1 <= v <= 35 and k not in ('NI', 'NF', 'NP', 'NUM_CU')}
+            names = O.KIND_NAMES
             breakdown = {}
             aff_kinds = (O.AFF_SCORE, O.AFF_SELECT, O.AFF_READOUT)
             if not args.no_breakdown:

@@ -19,6 +19,13 @@ assert OP_DTYPE.itemsize == _lib.OP_STRUCT_SIZE
  ADD_PE, KEY_PREP, AFF_SCORE, AFF_SELECT, AFF_READOUT, MEMSET32, COPY2D, AXPY, USAGE_TICK, RANK_SELECT,
  GATHER_ROWS, CONSOL_AFF, CONSOL_READ, CAST) = range(1, 36)
 
+KIND_NAMES = {}
+for _n in ('CONV MAXPOOL IMG_PREP UPSAMPLE2X_ADD AREA_DOWN MASK_DOWN GAP ECA_APPLY GRU SEG_AGG UP4_SOFTMAX MASK_MERGE '
+           'AGG_SOFTMAX LINEAR LAYERNORM QUERY_INIT AUX_MASK ATTN_Q2P ATTN_SELF ATTN_P2Q SUMMARIZE ADD_PE KEY_PREP '
+           'AFF_SCORE AFF_SELECT AFF_READOUT MEMSET32 COPY2D AXPY USAGE_TICK RANK_SELECT GATHER_ROWS CONSOL_AFF '
+           'CONSOL_READ CAST').split():
+    KIND_NAMES[globals()[_n]] = _n
+
 F_RELU_IN, F_OUT_F32, F_RES_BCAST = 1, 2, 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQ1 = 0, 1, 2, 3
 ACT_SHIFT = 4
