@@ -70,7 +70,16 @@ typedef __attribute__((ext_vector_type(4))) unsigned int au32x4;
 __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
     __shared__ au32x4 lds[2][2 * 64 * 16];            // [buffer][hi/lo][row][16 chunks]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-    const int j = blockIdx.x * 64 + wave * 16 + l15;                   // query column of this lane
+    // XCD-aware mapping (see conv_igemm.hip): consecutive logical blocks share the token chunk (query block fastest)
+    int bx, by;
+    {
+        const int nb = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = id & 7, kq = id >> 3, q = nb >> 3, r = nb & 7;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kq;
+        by = logical / (int)gridDim.x;
+        bx = logical - by * (int)gridDim.x;
+    }
+    const int j = bx * 64 + wave * 16 + l15;                           // query column of this lane
     bf16x8 bh[4], bl[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
         float tau = p.gmax_or_tau[j];
         thr = tau - fabsf(tau) * 1e-6f - 1e-30f;                        // never lose the k-th element to 1 ulp
     }
-    const int g0 = blockIdx.y * p.tiles_per_block;
+    const int g0 = by * p.tiles_per_block;
     const int g1 = min(g0 + p.tiles_per_block, p.G);
     const int T0 = (p.rn[0] + 15) >> 4, T1 = (p.nranges > 1) ? ((p.rn[1] + 15) >> 4) : 0;
     // this thread stages chunk (row = tid >> 2 .. , 4 chunks) : 64 rows x 16 chunks x 2 arrays = 2048 chunks / 256 threads = 8

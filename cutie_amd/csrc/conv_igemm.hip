@@ -49,7 +49,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) 
     u32x4 (*smem)[(BM + BN) * CPR] = reinterpret_cast<u32x4 (*)[(BM + BN) * CPR]>(smem_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // XCD-aware tile mapping: hardware block b runs on XCD b % 8 (8 private L2s).  Give every XCD a contiguous run of
+    // logical tiles (channel tile fastest) so the blocks sharing an activation row-band hit the same L2 instead of each
+    // XCD pulling its own copy through the fabric (rocprof FETCH_SIZE was ~8x the unique bytes without it).  Bijective
+    // for any grid size; affects speed only.
+    int m0, n0;
+    {
+        const int nb = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = id & 7, kq = id >> 3, q = nb >> 3, r = nb & 7;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kq;
+        const int mt = logical / (int)gridDim.y;
+        m0 = mt * BM;
+        n0 = (logical - mt * (int)gridDim.y) * BN;
+    }
     const int kc = tid % CPR;                            // this thread's 8-element chunk inside BK
     const int trow = tid / CPR;                          // first row handled (then + RPT per extra chunk)
     const bool relu_in = p.flags & CUTIE_F_RELU_IN;
