@@ -57,7 +57,7 @@ struct ScoreParams {
     const bf16_t* Ahi; const bf16_t* Alo; const float* scale;
     const bf16_t* Bhi; const bf16_t* Blo; const float* c;
     float* gmax_or_tau; float* cand_val; int* cand_idx; int* count;
-    int HW, HWp, nranges, rs[3], rn[3], G, cap, mode, tiles_per_block;
+    int HW, HWp, nranges, rs[3], rn[3], G, cap, mode, tiles_per_block, Gld;
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int au32x4;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
                 if (p.mode == 0) {
                     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                    if (l4 == 0) p.gmax_or_tau[(long)g * p.HWp + j] = mx;
+                    if (l4 == 0) p.gmax_or_tau[(long)j * p.Gld + g] = mx;
                 } else if (jvalid) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -197,7 +197,7 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 
 // one wave per query column; 4 waves per block.  Exact k-th largest by 4x8-bit radix select.
 __global__ __launch_bounds__(256) void aff_select_kernel(const float* __restrict__ gmax, float* __restrict__ tau,
-                                                         int HW, int HWp, int G, int k) {
+                                                         int HW, int Gld, int G, int k) {
     __shared__ int hist[4][256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + wave;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void aff_select_kernel(const float* __restrict
         for (int b = lane; b < 256; b += 64) hist[wave][b] = 0;
         __builtin_amdgcn_wave_barrier();
         for (int g = lane; g < G; g += 64) {
-            uint32_t key = f2key(gmax[(long)g * HWp + j]);
+            uint32_t key = f2key(gmax[(long)j * Gld + g]);
             if ((key & mask) == prefix) atomicAdd(&hist[wave][(key >> shift) & 255], 1);
         }
         __builtin_amdgcn_wave_barrier();
@@ -290,6 +290,7 @@ __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __
         int o = u / C8, c8 = u - o * C8;
         const bf16_t* V = reinterpret_cast<const bf16_t*>(vptrs[o]);
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 6
         for (int t = 0; t < nsel; ++t) {
             uint4 v = *reinterpret_cast<const uint4*>(V + (long)sel_i[t] * CV + c8 * 8);
             const uint32_t* vu = &v.x;
@@ -322,7 +323,7 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             sp.gmax_or_tau = (float*)p[6]; sp.cand_val = (float*)p[7]; sp.cand_idx = (int*)p[8]; sp.count = (int*)p[9];
             sp.HW = i[0]; sp.HWp = i[1]; sp.nranges = i[2];
             for (int r = 0; r < 3; ++r) { sp.rs[r] = i[3 + 2 * r]; sp.rn[r] = (r < sp.nranges) ? i[4 + 2 * r] : 0; }
-            sp.G = i[9]; sp.cap = i[10]; sp.mode = i[11];
+            sp.G = i[9]; sp.cap = i[10]; sp.mode = i[11]; sp.Gld = (sp.G + 63) / 64 * 64;
             int G = 0;
             for (int r = 0; r < 3; ++r) G += (sp.rn[r] + 15) / 16;
             if (G != sp.G || (sp.HWp & 63) || sp.nranges < 1 || sp.nranges > 3) { cutie_set_error("aff_score: bad ranges (G=%d vs %d, HWp=%d)", G, sp.G, sp.HWp); return -2; }
@@ -336,7 +337,7 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             break;
         }
         case CUTIE_OP_AFF_SELECT:
-            hipLaunchKernelGGL(aff_select_kernel, dim3((i[0] + 3) / 4), dim3(256), 0, s, (const float*)p[0], (float*)p[1], i[0], i[1], i[2], i[3]);
+            hipLaunchKernelGGL(aff_select_kernel, dim3((i[0] + 3) / 4), dim3(256), 0, s, (const float*)p[0], (float*)p[1], i[0], (i[2] + 63) / 64 * 64, i[2], i[3]);
             break;
         case CUTIE_OP_AFF_READOUT: {
             if (i[2] > RO_MAXK || (i[4] & 7)) { cutie_set_error("aff_readout: top_k <= %d, CV %% 8", RO_MAXK); return -2; }

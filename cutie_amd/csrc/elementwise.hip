@@ -356,20 +356,26 @@ __global__ void agg_softmax_kernel(const float* __restrict__ planes, float* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-// LINEAR (small M): grid (ceil(N/4), ceil(M/16)); block = 4 waves, wave w owns output column 4*bx + w for 16 rows;
-// the K dimension is split over the 64 lanes (coalesced 16-B weight / 32-B activation loads), then wave-reduced.
+// LINEAR (small M = K_objects*16 rows): grid (ceil(N / (4*CPW)), ceil(M/16)); block = 4 waves.  LPC = min(64, Kd/8)
+// lanes cooperate on one output column (each lane owns 8 consecutive k per 512-wide sweep: 16-B weight loads,
+// 32-B activation loads), so a wave computes CPW = 64/LPC columns x 16 rows.  The 16 per-row partial sums are
+// combined with a reduce-scatter butterfly (8+4+2+1 exchanges, then log2(LPC/16) plain steps) instead of 16 full
+// wave reductions: 17 shuffles instead of 96.
+template <int LPC>
 __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, const float* __restrict__ xadd,
                                                            const bf16_t* __restrict__ W, const float* __restrict__ bias,
                                                            const float* __restrict__ res, float* __restrict__ y, int M, int N,
                                                            int Kd, int ldx, int ldy, int add_rows, int relu) {
+    constexpr int CPW = 64 / LPC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = blockIdx.x * 4 + wave, m0 = blockIdx.y * 16;
-    if (col >= N) return;                                    // whole wave
-    const bf16_t* wrow = W + (long)col * Kd;
+    const int sub = lane / LPC, cl = lane % LPC;             // column slot inside the wave, lane inside the column group
+    const int col = (blockIdx.x * 4 + wave) * CPW + sub, m0 = blockIdx.y * 16;
+    const bool cvalid = col < N;
+    const bf16_t* wrow = W + (long)(cvalid ? col : 0) * Kd;
     float acc[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int k = lane * 8; k < Kd; k += 512) {
+    for (int k = cl * 8; k < Kd; k += LPC * 8) {
         uint4 wv = *reinterpret_cast<const uint4*>(wrow + k);
         float wf[8];
         wf[0] = __uint_as_float(wv.x << 16); wf[1] = __uint_as_float(wv.x & 0xffff0000u);
@@ -379,27 +385,48 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int m = m0 + r;
-            if (m < M) {                                     // wave-uniform
-                const float* xr = x + (long)m * ldx + k;
-                float4 a = *reinterpret_cast<const float4*>(xr), b = *reinterpret_cast<const float4*>(xr + 4);
-                if (xadd) {
-                    const float* ar = xadd + (long)(m % add_rows) * Kd + k;
-                    float4 c = *reinterpret_cast<const float4*>(ar), d = *reinterpret_cast<const float4*>(ar + 4);
-                    a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w; b.x += d.x; b.y += d.y; b.z += d.z; b.w += d.w;
-                }
-                acc[r] += a.x * wf[0] + a.y * wf[1] + a.z * wf[2] + a.w * wf[3] + b.x * wf[4] + b.y * wf[5] + b.z * wf[6] + b.w * wf[7];
+            m = m < M ? m : M - 1;                           // clamp (rows >= M are never stored)
+            const float* xr = x + (long)m * ldx + k;
+            float4 a = *reinterpret_cast<const float4*>(xr), b = *reinterpret_cast<const float4*>(xr + 4);
+            if (xadd) {
+                const float* ar = xadd + (long)(m % add_rows) * Kd + k;
+                float4 c = *reinterpret_cast<const float4*>(ar), d = *reinterpret_cast<const float4*>(ar + 4);
+                a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w; b.x += d.x; b.y += d.y; b.z += d.z; b.w += d.w;
             }
+            acc[r] += a.x * wf[0] + a.y * wf[1] + a.z * wf[2] + a.w * wf[3] + b.x * wf[4] + b.y * wf[5] + b.z * wf[6] + b.w * wf[7];
         }
     }
-    float mine = 0.f;
+    // reduce-scatter over the top 4 bits of cl: after step s the lane keeps 16 >> (s+1) rows
+    constexpr int TOP = LPC / 2;                              // 32 (LPC 64) or 16 (LPC 32)
+    float v8[8], v4[4], v2[2], v1;
+    {
+        const bool up = cl & TOP;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float v = wave_sum(acc[r]);
-        if (lane == r) mine = v;
+        for (int r = 0; r < 8; ++r) { float send = up ? acc[r] : acc[r + 8]; float recv = __shfl_xor(send, TOP, 64); v8[r] = (up ? acc[r + 8] : acc[r]) + recv; }
     }
-    int m = m0 + lane;
-    if (lane < 16 && m < M) {
-        float v = mine;
+    {
+        const bool up = cl & (TOP / 2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float send = up ? v8[r] : v8[r + 4]; float recv = __shfl_xor(send, TOP / 2, 64); v4[r] = (up ? v8[r + 4] : v8[r]) + recv; }
+    }
+    {
+        const bool up = cl & (TOP / 4);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { float send = up ? v4[r] : v4[r + 2]; float recv = __shfl_xor(send, TOP / 4, 64); v2[r] = (up ? v4[r + 2] : v4[r]) + recv; }
+    }
+    {
+        const bool up = cl & (TOP / 8);
+        float send = up ? v2[0] : v2[1];
+        float recv = __shfl_xor(send, TOP / 8, 64);
+        v1 = (up ? v2[1] : v2[0]) + recv;
+    }
+#pragma unroll
+    for (int o = TOP / 16; o > 0; o >>= 1) v1 += __shfl_xor(v1, o, 64);
+    // row owned by this lane: the four butterfly bits, most significant first
+    const int row = ((cl & TOP) ? 8 : 0) + ((cl & (TOP / 2)) ? 4 : 0) + ((cl & (TOP / 4)) ? 2 : 0) + ((cl & (TOP / 8)) ? 1 : 0);
+    const int m = m0 + row;
+    if ((cl & (TOP / 8 - 1)) == 0 && cvalid && m < M) {
+        float v = v1;
         if (bias) v += bias[col];
         if (relu) v = fmaxf(v, 0.f);
         if (res) v += res[(long)m * N + col];
@@ -600,11 +627,17 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
         case CUTIE_OP_AGG_SOFTMAX:
             hipLaunchKernelGGL(agg_softmax_kernel, GRID1D(i[1], BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], i[0], (long)i[1]);
             break;
-        case CUTIE_OP_LINEAR:
-            if ((i[2] & 7) || (i[3] & 3)) { cutie_set_error("linear: Kd %% 8 / ldx %% 4"); return -2; }
-            hipLaunchKernelGGL(linear_small_kernel, dim3((i[1] + 3) / 4, (i[0] + 15) / 16), dim3(256), 0, s, (const float*)p[0], (const float*)p[1], (const bf16_t*)p[2],
-                               (const float*)p[3], (const float*)p[4], (float*)p[5], i[0], i[1], i[2], i[3], i[4], i[5] > 0 ? i[5] : 1, op->flags & 1);
+        case CUTIE_OP_LINEAR: {
+            if ((i[2] & 7) || (i[3] & 3) || i[2] < 256) { cutie_set_error("linear: Kd %% 8, ldx %% 4, Kd >= 256 required (Kd=%d)", i[2]); return -2; }
+            const int add_rows = i[5] > 0 ? i[5] : 1;
+            if (i[2] >= 512)
+                hipLaunchKernelGGL(linear_small_kernel<64>, dim3((i[1] + 3) / 4, (i[0] + 15) / 16), dim3(256), 0, s, (const float*)p[0], (const float*)p[1], (const bf16_t*)p[2],
+                                   (const float*)p[3], (const float*)p[4], (float*)p[5], i[0], i[1], i[2], i[3], i[4], add_rows, op->flags & 1);
+            else
+                hipLaunchKernelGGL(linear_small_kernel<32>, dim3((i[1] + 7) / 8, (i[0] + 15) / 16), dim3(256), 0, s, (const float*)p[0], (const float*)p[1], (const bf16_t*)p[2],
+                                   (const float*)p[3], (const float*)p[4], (float*)p[5], i[0], i[1], i[2], i[3], i[4], add_rows, op->flags & 1);
             break;
+        }
         case CUTIE_OP_LAYERNORM:
             hipLaunchKernelGGL(layernorm_kernel, dim3((i[0] + 3) / 4), dim3(256), 0, s, (const float*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[3], i[0], i[1]);
             break;

@@ -138,7 +138,7 @@ class MemoryManager:
             K = len(bucket.objects)
             ranges = [r for r in bucket.ranges() if r[1] > 0]
             G = sum(-(-n // 16) for _, n in ranges)
-            gmax = self._buf('gmax', (max(G, 1), HWp), F32, dev)
+            gmax = self._buf('gmax', (HWp, -(-max(G, 1) // 64) * 64), F32, dev)
             tau = self._buf('tau', (HW,), F32, dev)
             cval = self._buf('cand_val', (HW, CAND_CAP), F32, dev)
             cidx = self._buf('cand_idx', (HW, CAND_CAP), torch.int32, dev)

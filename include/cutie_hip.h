@@ -149,7 +149,7 @@ enum {
      * p0=key f32 [n,64] p1=shr f32 [n] (mem) | sel f32 [n,64] (query) p2=hi p3=lo p4=scale|c   i: 0 n */
     CUTIE_OP_KEY_PREP = 23,
     /* AFF_SCORE: S = scale_i*(A_i.B_j - c_j) tiles on MFMA (3-term split bf16, fp32-class accuracy)
-     * mode 0: per-(16-token tile, query) maxima -> gmax f32 [G,HWp]
+     * mode 0: per-(16-token tile, query) maxima -> gmax f32 [HWp, Gld] (query-major, Gld = G rounded up to 64)
      * mode 1: append (S,token) with S >= tau_j to cand lists (f32,i32) [HW,cap], count i32 [HW]
      * memory_utils.py:7-46 get_similarity + the candidate pre-filter of top-k (:58)
      * p0=A_hi p1=A_lo p2=scale (bank base pointers, rows = physical token slots) p3=B_hi p4=B_lo p5=c
@@ -157,7 +157,7 @@ enum {
      * i: 0 HW 1 HWp 2 nranges 3.. (start,n) x3  9 G 10 cap 11 mode */
     CUTIE_OP_AFF_SCORE = 24,
     /* AFF_SELECT: tau_j = top_k-th largest of gmax[:,j] (or -inf if G < top_k)
-     * p0=gmax f32 [G,HWp] p1=tau f32 [HW]   i: 0 HW 1 HWp 2 G 3 top_k */
+     * p0=gmax f32 [HWp,Gld] p1=tau f32 [HW]   i: 0 HW 1 HWp 2 G 3 top_k */
     CUTIE_OP_AFF_SELECT = 25,
     /* AFF_READOUT: exact top-k of the candidates (ties -> lower slot), softmax, usage += w,
      * readout[o,j,:] = sum_i w_i V_o[i,:]    memory_utils.py:58-63,75; memory_manager.py:77-88

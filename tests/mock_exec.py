@@ -381,14 +381,15 @@ class MockExecutor:
         G, cap, mode = i[9], i[10], i[11]
         sc = self._scores(i, p)
         if mode == 0:
-            gmax = view(p[6], F32, (G, HWp))
+            Gld = -(-G // 64) * 64
+            gmax = view(p[6], F32, (HWp, Gld))
             g = 0
             for (_, S) in sc:
                 n = S.shape[0]
                 T = -(-n // 16)
                 Sp = torch.full((T * 16, HW), float('-inf'))
                 Sp[:n] = S
-                gmax[g:g + T, :HW] = Sp.view(T, 16, HW).max(1)[0]
+                gmax[:HW, g:g + T] = Sp.view(T, 16, HW).max(1)[0].t()
                 g += T
         else:
             tau = view(p[6], F32, (HW,))
@@ -408,12 +409,13 @@ class MockExecutor:
 
     def _op_25(self, flags, i, f, p):
         HW, HWp, G, k = i[:4]
-        gmax = view(p[0], F32, (G, HWp))[:, :HW]
+        Gld = -(-G // 64) * 64
+        gmax = view(p[0], F32, (HWp, Gld))[:HW, :G]
         tau = view(p[1], F32, (HW,))
         if G < k:
             tau.fill_(float('-inf'))
         else:
-            tau.copy_(gmax.topk(k, dim=0)[0][-1])
+            tau.copy_(gmax.topk(k, dim=1)[0][:, -1])
 
     def _op_26(self, flags, i, f, p):
         HW, cap, topk, K, CV = i[:5]

@@ -379,7 +379,8 @@ def _affinity_build(HW, ranges, slots, K, top_k, with_usage, dup=False):
         Ahi, Alo, scale = z((slots + 16, 128), BF16), z((slots + 16, 128), BF16), z((slots + 16,), F32)
         Bhi, Blo, cq = z((HWp, 128), BF16), z((HWp, 128), BF16), z((HWp,), F32)
         G = sum(-(-n // 16) for _, n in ranges if n > 0)
-        gmax, tau = z((G, HWp), F32), z((HW,), F32)
+        Gld = -(-G // 64) * 64
+        gmax, tau = z((HWp, Gld), F32), z((HW,), F32)
         cval, cidx, count, ovf = z((HW, cap), F32), z((HW, cap), torch.int32), z((HW,), torch.int32), z((1,), torch.int32)
         vals = [rnd(g, (slots + 16, CV), dev=dev) for _ in range(K)]
         vptrs = torch.tensor([v.data_ptr() for v in vals], dtype=torch.int64).to(dev)
@@ -396,7 +397,7 @@ def _affinity_build(HW, ranges, slots, K, top_k, with_usage, dup=False):
         ol.aff_score(Ahi, Alo, scale, Bhi, Blo, cq, tau, cval, cidx, count, mode=1, **common)
         ol.aff_readout(cval, cidx, count, vptrs, usage, y, ovf, HW=HW, cap=cap, top_k=top_k, K=K, CV=CV)
         outs = {'Ahi': Ahi, 'Alo': Alo, 'scale': scale, 'Bhi': Bhi, 'Blo': Blo, 'cq': cq, 'tau': tau, 'y': y, 'ovf': ovf,
-                'gmax': gmax[:, :HW], 'count': count}
+                'gmax': gmax[:HW, :G], 'count': count}
         if with_usage:
             outs['usage'] = usage
         # dense fp32 reference of the reference algorithm (memory_utils.py) for the oracle-level check
