@@ -1,7 +1,7 @@
 // Object-transformer attention kernels (QueryTransformerBlock, reference object_transformer.py:12-73).
-// 16 object queries per object, 8 heads x 32: these are HBM-/latency-bound (arithmetic intensity < 50 flop/B),
-// so they are written as streaming kernels with online softmax, not MFMA tiles.  The pixel-side linear
-// projections that feed them are MFMA convs (conv_igemm.hip).
+// 16 object queries per object, 8 heads x 32: latency-bound (a few MFLOP per launch).  The query->pixel product runs
+// on 16x16x32 MFMA tiles with split-bf16 operands (flash-style online softmax); the pixel->query side streams.
+// The pixel-side linear projections that feed them are MFMA convs (conv_igemm.hip).
 #include "common.h"
 #include <math.h>
 
@@ -35,87 +35,122 @@ __global__ void aux_mask_kernel(const float* __restrict__ lg, uint8_t* __restric
     }
 }
 
-// ATTN_Q2P: grid (heads, K, Q/4); the block owns 4 queries; its 4 waves split the pixels (wave w takes pixels
-// w*64 + lane + 256 i) with a per-lane online softmax; lanes are merged by shuffles, waves through LDS.
-__global__ __launch_bounds__(256) void attn_q2p_kernel(const float* __restrict__ q, const bf16_t* __restrict__ kv,
-                                                       const uint8_t* __restrict__ fg, const int* __restrict__ nfg,
-                                                       float* __restrict__ y, int Q, int HW, int C, int ldkv, int voff) {
-    __shared__ float sM[4][4], sL[4][4], sA[4][4][32];     // [wave][query]([dim])
-    const int hh = blockIdx.x, k = blockIdx.y, q0 = blockIdx.z * 4;
+// ATTN_Q2P: masked cross-attention of the 16 object queries over the HW pixels (object_transformer.py:176-206).
+// grid (heads, K), block 1024 = 16 waves; wave w owns the 32-pixel chunks w, w+16, ...  Both products run on MFMA in
+// the transposed form, so that a lane's accumulator column is always "its" query (lane & 15):
+//     S^T[pixel][query] = K[pixel][dim] . Q^T[dim][query]        (Q split hi+lo bf16: ~fp32 scores)
+//     O^T[dim][query]   = V^T[dim][pixel] . P^T[pixel][query]    (P split hi+lo bf16)
+// The D layout of S^T (4 consecutive pixels of one query per lane) is used directly as the B operand of the second
+// product: the k-slot <-> pixel assignment of that MFMA is free, and V^T is gathered to match it.  Online softmax
+// state (m, l) is per query, shared by the 4 lanes of a query through two xor-shuffles.  Waves merge through LDS.
+typedef __attribute__((ext_vector_type(4))) uint32_t q2p_u32x4;
+union q2p_frag { q2p_u32x4 u; bf16x8 b; };
+
+__device__ __forceinline__ void split_bf2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    bf16_t ha = f2bf(a), hb = f2bf(b);
+    hi = (uint32_t)ha | ((uint32_t)hb << 16);
+    lo = (uint32_t)f2bf(a - bf2f(ha)) | ((uint32_t)f2bf(b - bf2f(hb)) << 16);
+}
+
+__global__ __launch_bounds__(1024) void attn_q2p_kernel(const float* __restrict__ q, const bf16_t* __restrict__ kv,
+                                                        const uint8_t* __restrict__ fg, const int* __restrict__ nfg,
+                                                        float* __restrict__ y, int Q, int HW, int C, int ldkv, int voff) {
+    __shared__ float sO[16][16][33];                       // [wave][query][dim]
+    __shared__ float sM[16][16], sL[16][16];
+    const int hh = blockIdx.x, k = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c16 = lane & 15, g = lane >> 4;              // c16: query (B/D column) or pixel/dim (A row)
     const float scale = rsqrtf(32.f);
-    float qv[4][32];
+    q2p_frag qh, ql;
+    {
+        const float* qr = q + ((long)k * Q + c16) * C + hh * 32 + 8 * g;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int d = 0; d < 32; ++d) qv[i][d] = q[((long)k * Q + q0 + i) * C + hh * 32 + d] * scale;
+        for (int j = 0; j < 4; ++j) { uint32_t h_, l_; split_bf2(qr[2 * j] * scale, qr[2 * j + 1] * scale, h_, l_); qh.u[j] = h_; ql.u[j] = l_; }
+    }
     const int n_fg = nfg[k];
-    const bool is_fg_query = q0 < Q / 2;                   // queries 0..7 attend foreground only
+    const bool is_fg_query = c16 < Q / 2;                  // queries 0..7 attend foreground only
     // row fully blocked -> unblocked (object_transformer.py:203)
     const bool masked = is_fg_query ? (n_fg != 0) : (n_fg != HW);
-    float m[4], l[4], acc[4][32];
+    float m = -INFINITY, l = 0.f;
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    const bf16_t* kvb = kv + (long)k * HW * ldkv + hh * 32;
+    const uint8_t* fgb = fg + (long)k * HW;
+    const int nchunk = (HW + 31) >> 5;
+    for (int ch = wave; ch < nchunk; ch += 16) {
+        const int p0 = ch * 32;
+        q2p_frag ka[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        m[i] = -INFINITY; l[i] = 0.f;
+        for (int t = 0; t < 2; ++t) {
+            int p = min(p0 + t * 16 + c16, HW - 1);
+            ka[t].u = *reinterpret_cast<const q2p_u32x4*>(kvb + (long)p * ldkv + 8 * g);
+        }
+        q2p_frag va0, va1;                                 // V^T rows c16 / c16+16, k-slots = this lane group's 8 pixels
+        uint8_t fgv[8];
 #pragma unroll
-        for (int d = 0; d < 32; ++d) acc[i][d] = 0.f;
+        for (int jj = 0; jj < 4; ++jj) {
+            const int ja = 2 * jj, jb = 2 * jj + 1;
+            int pa = min(p0 + (ja >> 2) * 16 + 4 * g + (ja & 3), HW - 1);
+            int pb = min(p0 + (jb >> 2) * 16 + 4 * g + (jb & 3), HW - 1);
+            const bf16_t* ra = kvb + (long)pa * ldkv + voff + c16;
+            const bf16_t* rb = kvb + (long)pb * ldkv + voff + c16;
+            va0.u[jj] = (uint32_t)ra[0] | ((uint32_t)rb[0] << 16);
+            va1.u[jj] = (uint32_t)ra[16] | ((uint32_t)rb[16] << 16);
+            fgv[ja] = fgb[pa]; fgv[jb] = fgb[pb];
+        }
+        f32x4 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[t].b, qh.b, z, 0, 0, 0);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[t].b, ql.b, z, 0, 0, 0);
+        }
+        float sv[8], tm = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = p0 + (j >> 2) * 16 + 4 * g + (j & 3);
+            const bool ok = p < HW && (!masked || ((fgv[j] != 0) == is_fg_query));
+            sv[j] = ok ? s[j >> 2][j & 3] : -INFINITY;
+            tm = fmaxf(tm, sv[j]);
+        }
+        tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
+        tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+        const float mn = fmaxf(m, tm);
+        const float mref = (mn == -INFINITY) ? 0.f : mn;
+        const float alpha = __expf(m - mref);
+        float pe[8], ps = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pe[j] = (sv[j] == -INFINITY) ? 0.f : __expf(sv[j] - mref); ps += pe[j]; }
+        l = l * alpha + ps;
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        q2p_frag ph, pl;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { uint32_t h_, l_; split_bf2(pe[2 * jj], pe[2 * jj + 1], h_, l_); ph.u[jj] = h_; pl.u[jj] = l_; }
+        o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va0.b, ph.b, o0, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va0.b, pl.b, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va1.b, ph.b, o1, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va1.b, pl.b, o1, 0, 0, 0);
     }
-    for (int p = wave * 64 + lane; p < HW; p += 256) {
-        if (masked) {
-            bool f = fg[(long)k * HW + p] != 0;
-            if (f != is_fg_query) continue;                // blocked
-        }
-        const bf16_t* kr = kv + ((long)k * HW + p) * ldkv + hh * 32;
-        float kf[32], vf[32];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (g == 0) { sM[wave][c16] = m; sL[wave][c16] = l; }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            uint4 a = *reinterpret_cast<const uint4*>(kr + c * 8);
-            uint4 b = *reinterpret_cast<const uint4*>(kr + voff + c * 8);
-            const uint32_t* au = &a.x; const uint32_t* bu = &b.x;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                kf[c * 8 + 2 * j] = __uint_as_float(au[j] << 16); kf[c * 8 + 2 * j + 1] = __uint_as_float(au[j] & 0xffff0000u);
-                vf[c * 8 + 2 * j] = __uint_as_float(bu[j] << 16); vf[c * 8 + 2 * j + 1] = __uint_as_float(bu[j] & 0xffff0000u);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < 32; ++d) s += qv[i][d] * kf[d];
-            float mn = fmaxf(m[i], s);
-            float alpha = __expf(m[i] - mn), pe = __expf(s - mn);
-            l[i] = l[i] * alpha + pe;
-#pragma unroll
-            for (int d = 0; d < 32; ++d) acc[i][d] = acc[i][d] * alpha + pe * vf[d];
-            m[i] = mn;
-        }
-    }
-    // merge the 64 lanes of each wave (un-normalised, relative to the wave maximum)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float M = wave_max(m[i]);
-        float f = (m[i] == -INFINITY) ? 0.f : __expf(m[i] - M);
-        float L = wave_sum(l[i] * f);
-        if (lane == 0) { sM[wave][i] = M; sL[wave][i] = L; }
-#pragma unroll
-        for (int d = 0; d < 32; ++d) {
-            float v = wave_sum(acc[i][d] * f);
-            if (lane == d) sA[wave][i][d] = v;
-        }
-    }
+    for (int r = 0; r < 4; ++r) { sO[wave][c16][4 * g + r] = o0[r]; sO[wave][c16][16 + 4 * g + r] = o1[r]; }
     __syncthreads();
-    if (threadIdx.x < 128) {                               // (query i, dim d) merge over the 4 waves
-        int i = threadIdx.x >> 5, d = threadIdx.x & 31;
-        float Mg = fmaxf(fmaxf(sM[0][i], sM[1][i]), fmaxf(sM[2][i], sM[3][i]));
+    if (threadIdx.x < 512) {                               // (query i, dim d): merge the 16 waves
+        const int i = threadIdx.x >> 5, d = threadIdx.x & 31;
+        float Mg = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) Mg = fmaxf(Mg, sM[w][i]);
         float num = 0.f, den = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < 16; ++w) {
             float f = (sM[w][i] == -INFINITY) ? 0.f : __expf(sM[w][i] - Mg);
-            num += sA[w][i][d] * f;
+            num += sO[w][i][d] * f;
             den += sL[w][i] * f;
         }
-        y[((long)k * Q + q0 + i) * C + hh * 32 + d] = num / den;
+        y[((long)k * Q + i) * C + hh * 32 + d] = num / den;
     }
 }
 
@@ -214,7 +249,7 @@ int launch_attention(const cutie_op* op, hipStream_t s) {
             break;
         case CUTIE_OP_ATTN_Q2P:
             if (i[1] != 16 || i[3] != i[4] * 32) { cutie_set_error("attn_q2p: Q=16, head dim 32 only"); return -2; }
-            hipLaunchKernelGGL(attn_q2p_kernel, dim3(i[4], i[0], i[1] / 4), dim3(256), 0, s, (const float*)p[0], (const bf16_t*)p[1], (const uint8_t*)p[2],
+            hipLaunchKernelGGL(attn_q2p_kernel, dim3(i[4], i[0]), dim3(1024), 0, s, (const float*)p[0], (const bf16_t*)p[1], (const uint8_t*)p[2],
                                (const int*)p[3], (float*)p[4], i[1], i[2], i[3], i[5], i[6]);
             break;
         case CUTIE_OP_ATTN_SELF:

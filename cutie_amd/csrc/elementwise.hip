@@ -212,36 +212,45 @@ __global__ void gap_final_kernel(const float* __restrict__ part, float* __restri
     }
 }
 
-__global__ void eca_apply_kernel(const uint4* __restrict__ x, const float* __restrict__ gap, const float* __restrict__ wk,
-                                 const uint4* __restrict__ r, uint4* __restrict__ y, int B, int HW, int C) {
-    int C8 = C >> 3;
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long total = (long)B * HW * C8;
-    if (idx >= total) return;
-    int c8 = idx % C8; int b = idx / ((long)HW * C8);
-    const float* g = gap + (long)b * C;
-    float k0 = wk[0], k1 = wk[1], k2 = wk[2], k3 = wk[3], k4 = wk[4];
-    float sc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int c = c8 * 8 + i;
-        float a = k2 * g[c];
-        if (c >= 2) a += k0 * g[c - 2];
-        if (c >= 1) a += k1 * g[c - 1];
-        if (c + 1 < C) a += k3 * g[c + 1];
-        if (c + 2 < C) a += k4 * g[c + 2];
-        sc[i] = sigmoidf_(a);
+// ECA_APPLY: y = x * sigmoid(conv1d_k5(mean_hw(x)))[c] + r.  grid (ceil(HW/32), B), block 256.  The prologue finishes the
+// deterministic GAP reduction (sum of the per-chunk partials in chunk order) for all C channels, applies the 5-tap
+// channel conv + sigmoid once per block into LDS, then the block streams 32 pixels x C channels (16-B accesses).
+__global__ __launch_bounds__(256) void eca_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ part,
+                                                        const float* __restrict__ wk, const bf16_t* __restrict__ r,
+                                                        bf16_t* __restrict__ y, float* __restrict__ gap_out, int HW, int C, int nchunk) {
+    __shared__ float gap[256 + 4], sc[256];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const float inv = 1.f / (float)HW;
+    for (int c = tid; c < C; c += 256) {
+        float sum = 0.f;
+        for (int k = 0; k < nchunk; ++k) sum += part[((long)b * nchunk + k) * C + c];
+        gap[c + 2] = sum * inv;
+        if (gap_out && blockIdx.x == 0) gap_out[(long)b * C + c] = sum * inv;
     }
-    uint4 xv = x[idx], rv = r[idx];
-    const uint32_t* xu = &xv.x; const uint32_t* ru = &rv.x;
-    uint32_t o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float lo = __uint_as_float(xu[i] << 16) * sc[2 * i] + __uint_as_float(ru[i] << 16);
-        float hi = __uint_as_float(xu[i] & 0xffff0000u) * sc[2 * i + 1] + __uint_as_float(ru[i] & 0xffff0000u);
-        o[i] = pack_bf2(lo, hi);
+    if (tid < 2) { gap[tid] = 0.f; gap[C + 2 + tid] = 0.f; }            // zero padding of the conv1d
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float a = wk[0] * gap[c] + wk[1] * gap[c + 1] + wk[2] * gap[c + 2] + wk[3] * gap[c + 3] + wk[4] * gap[c + 4];
+        sc[c] = sigmoidf_(a);
     }
-    y[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+    __syncthreads();
+    const int C8 = C >> 3;
+    const int p0 = blockIdx.x * 32;
+    for (int q = tid; q < 32 * C8; q += 256) {
+        const int pp = q / C8, c8 = q - pp * C8, p = p0 + pp;
+        if (p >= HW) break;
+        const long off = ((long)b * HW + p) * C + c8 * 8;
+        const uint4 xv = *reinterpret_cast<const uint4*>(x + off), rv = *reinterpret_cast<const uint4*>(r + off);
+        const uint32_t* xu = &xv.x; const uint32_t* ru = &rv.x;
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float lo = __uint_as_float(xu[i] << 16) * sc[c8 * 8 + 2 * i] + __uint_as_float(ru[i] << 16);
+            float hi = __uint_as_float(xu[i] & 0xffff0000u) * sc[c8 * 8 + 2 * i + 1] + __uint_as_float(ru[i] & 0xffff0000u);
+            o[i] = pack_bf2(lo, hi);
+        }
+        *reinterpret_cast<uint4*>(y + off) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -597,12 +606,15 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             if (!p[2]) { cutie_set_error("gap: scratch buffer required"); return -2; }
             int nchunk = (i[1] + 63) / 64;
             hipLaunchKernelGGL(gap_partial_kernel, dim3(nchunk, i[0]), dim3(256), 0, s, (const bf16_t*)p[0], (float*)p[2], i[1], i[2]);
-            hipLaunchKernelGGL(gap_final_kernel, dim3(i[0]), dim3(256), 0, s, (const float*)p[2], (float*)p[1], nchunk, i[2], 1.f / (float)i[1]);
+            if (!(op->flags & 1))          // flags&1: the consumer (ECA_APPLY) finishes the reduction itself
+                hipLaunchKernelGGL(gap_final_kernel, dim3(i[0]), dim3(256), 0, s, (const float*)p[2], (float*)p[1], nchunk, i[2], 1.f / (float)i[1]);
             break;
         }
         case CUTIE_OP_ECA_APPLY: {
-            long n = (long)i[0] * i[1] * (i[2] / 8);
-            hipLaunchKernelGGL(eca_apply_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const uint4*)p[0], (const float*)p[1], (const float*)p[2], (const uint4*)p[3], (uint4*)p[4], i[0], i[1], i[2]);
+            if (i[2] > 256 || (i[2] & 7)) { cutie_set_error("eca: C <= 256, C %% 8"); return -2; }
+            int nchunk = (i[1] + 63) / 64;
+            hipLaunchKernelGGL(eca_apply_kernel, dim3((i[1] + 31) / 32, i[0]), dim3(256), 0, s, (const bf16_t*)p[0], (const float*)p[5], (const float*)p[2],
+                               (const bf16_t*)p[3], (bf16_t*)p[4], (float*)p[1], i[1], i[2], nchunk);
             break;
         }
         case CUTIE_OP_GRU: {

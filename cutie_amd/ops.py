@@ -180,13 +180,17 @@ class OpList:
     def mask_down(self, masks, pair, m16, *, K, H, W, r=16):
         return self.add(MASK_DOWN, 0, [K, H, W, r], [], [masks, pair, m16])
 
-    def gap(self, x, y, *, B, HW, C, scratch=None):
+    def gap(self, x, y, *, B, HW, C, scratch=None, partial_only=False):
         if scratch is None:
             scratch = torch.zeros((B, -(-HW // 64), C), dtype=torch.float32, device=y.device)
-        return self.add(GAP, 0, [B, HW, C], [], [x, y, scratch])
+        self._last_gap_scratch = scratch
+        return self.add(GAP, 1 if partial_only else 0, [B, HW, C], [], [x, y, scratch])
 
-    def eca_apply(self, x, gap, wk, r, y, *, B, HW, C):
-        return self.add(ECA_APPLY, 0, [B, HW, C], [], [x, gap, wk, r, y])
+    def eca_apply(self, x, gap, wk, r, y, *, B, HW, C, part=None):
+        """part: the GAP partials of the preceding gap(..., partial_only=True) (defaults to the last gap scratch)."""
+        if part is None:
+            part = self._last_gap_scratch
+        return self.add(ECA_APPLY, 0, [B, HW, C], [], [x, gap, wk, r, y, part])
 
     def gru(self, values, h, hb, *, n, C):
         return self.add(GRU, 0, [n, C], [], [values, h, hb])

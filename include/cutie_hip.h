@@ -83,10 +83,12 @@ enum {
      * p0=masks f32 [K,H,W] p1=y bf16 [K,h,w,8] p2=m16 f32 [K,h,w] (may be 0)  i: 0 K 1 H 2 W 3 r */
     CUTIE_OP_MASK_DOWN = 6,
     /* GAP: per-(b,c) mean over pixels (nn.AdaptiveAvgPool2d(1)), channel_attn.py:31-32
-     * p0=x bf16 [B,HW,C] p1=y f32 [B,C] p2=scratch f32 [B,ceil(HW/64),C] (deterministic 2-stage sum)   i: 0 B 1 HW 2 C */
+     * p0=x bf16 [B,HW,C] p1=y f32 [B,C] p2=part f32 [B,ceil(HW/64),C] (deterministic 2-stage sum)   i: 0 B 1 HW 2 C
+     * flags&1: only the per-chunk partials are produced (ECA_APPLY finishes the reduction in its prologue) */
     CUTIE_OP_GAP = 7,
     /* ECA_APPLY: y = x * sigmoid(conv1d_k5(gap))[c] + r    channel_attn.py:33-37
-     * p0=x bf16 [B,HW,C] p1=gap f32 [B,C] p2=w f32[5] p3=r bf16 [B,HW,C] p4=y bf16   i: 0 B 1 HW 2 C */
+     * p0=x bf16 [B,HW,C] p1=gap f32 [B,C] (written: the finished means) p2=w f32[5] p3=r bf16 [B,HW,C] p4=y bf16
+     * p5=part f32 [B,ceil(HW/64),C] (GAP partials)   i: 0 B 1 HW 2 C */
     CUTIE_OP_ECA_APPLY = 8,
     /* GRU: h' = sig(f)*h*(1-sig(u)) + sig(u)*tanh(n), values=[f|u|n] f32   modules.py:35-43
      * p0=values f32 [B,HW,3C] p1=h f32 [B,HW,C] (in/out) p2=h_bf16 bf16 [B,HW,C] (out)  i: 0 n=B*HW 1 C */

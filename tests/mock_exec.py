@@ -183,12 +183,20 @@ class MockExecutor:
     # ---- GAP / ECA ----------------------------------------------------------------------
     def _op_7(self, flags, i, f, p):
         B, HW, C = i[:3]
-        view(p[1], F32, (B, C)).copy_(view(p[0], BF16, (B, HW, C)).float().mean(1))
+        x = view(p[0], BF16, (B, HW, C)).float()
+        nchunk = -(-HW // 64)
+        part = view(p[2], F32, (B, nchunk, C))
+        for k in range(nchunk):
+            part[:, k] = x[:, k * 64:(k + 1) * 64].sum(1)
+        if not (flags & 1):
+            view(p[1], F32, (B, C)).copy_(part.sum(1) / HW)
 
     def _op_8(self, flags, i, f, p):
         B, HW, C = i[:3]
         x = view(p[0], BF16, (B, HW, C)).float()
+        nchunk = -(-HW // 64)
         gap = view(p[1], F32, (B, C))
+        gap.copy_(view(p[5], F32, (B, nchunk, C)).sum(1) / HW)
         wk = view(p[2], F32, (5,))
         sc = torch.sigmoid(F.conv1d(gap.view(B, 1, C), wk.view(1, 1, 5), None, 1, 2)).view(B, 1, C)
         r = view(p[3], BF16, (B, HW, C)).float()

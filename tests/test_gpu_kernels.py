@@ -209,7 +209,7 @@ def test_gap_eca():
         wk = (torch.randn(5, generator=g) * 0.6).to(dev)
         y = torch.zeros((B, HW, C), dtype=BF16, device=dev)
         ol = O.OpList()
-        ol.gap(x, gap, B=B, HW=HW, C=C)
+        ol.gap(x, gap, B=B, HW=HW, C=C, partial_only=True)
         ol.eca_apply(x, gap, wk, r, y, B=B, HW=HW, C=C)
         return ol, {'gap': gap, 'y': y}
     hip, ref = run_both(build)
