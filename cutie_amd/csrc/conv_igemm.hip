@@ -21,6 +21,7 @@ struct ConvParams {
     const bf16_t* x1; const bf16_t* x2; const bf16_t* w; const float* bias; const bf16_t* res; void* y;
     int B, H, W, C1, C2, ldx1, ldx2, OH, OW, Cout, ldy, KH, KW, stride, pad, ldr, Kpad;
     int flags, M, Cin, OHW;
+    float* part; int splitk, ldp, Kslice;                // split-K: fp32 partial tiles [splitk][M][ldp]
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -30,7 +31,61 @@ __device__ __forceinline__ int swz(int row) {
     return CPR == 4 ? ((row >> 3) & 1) * 3 : (row & (CPR - 1));
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int S>
+// Epilogue tail for 8 consecutive output channels of one pixel: bias, residual, activation, 16-B stores.
+__device__ __forceinline__ void conv_finish(const ConvParams& p, float* v, int m, int ch0) {
+    const int act = (p.flags >> CUTIE_ACT_SHIFT) & 7;
+    const bool out_f32 = p.flags & CUTIE_F_OUT_F32;
+    const bool res_bcast = p.flags & CUTIE_F_RES_BCAST;
+    const bool vec_y = out_f32 ? ((p.ldy & 3) == 0) : ((p.ldy & 7) == 0);
+    const bool vec_r = (p.ldr & 7) == 0;
+    const bool full = ch0 + 7 < p.Cout;
+    if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) v[r] += p.bias[ch0 + r];
+    }
+    if (p.res) {
+        const int mres = res_bcast ? (m % p.OHW) : m;
+        const bf16_t* rp = p.res + (long)mres * p.ldr + ch0;
+        if (full && vec_r) {
+            const uint4 rr = *reinterpret_cast<const uint4*>(rp);
+            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+            v[4] += __uint_as_float(rr.z << 16); v[5] += __uint_as_float(rr.z & 0xffff0000u);
+            v[6] += __uint_as_float(rr.w << 16); v[7] += __uint_as_float(rr.w & 0xffff0000u);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) v[r] += bf2f(rp[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (act == CUTIE_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+        else if (act == CUTIE_ACT_SIGMOID) v[r] = sigmoidf_(v[r]);
+        else if (act == CUTIE_ACT_SQ1) v[r] = v[r] * v[r] + 1.f;
+    }
+    if (out_f32) {
+        float* yp = reinterpret_cast<float*>(p.y) + (long)m * p.ldy + ch0;
+        if (full && vec_y) {
+            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) yp[r] = v[r];
+        }
+    } else {
+        bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + (long)m * p.ldy + ch0;
+        if (full && vec_y) {
+            *reinterpret_cast<uint4*>(yp) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) yp[r] = f2bf(v[r]);
+        }
+    }
+}
+
+// OCC: waves per SIMD the register allocator must leave room for (pinned per tile: hipcc's occupancy heuristic is
+// otherwise chaotic w.r.t. small source changes, e.g. 156 -> 208 VGPRs on the 32x64x128 tile = 3 -> 2 resident blocks).
+template <int BM, int BN, int WM, int WN, int BK, int S, int OCC>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) {
     constexpr int NT = WM * WN * 64;                    // 4 or 8 waves
     constexpr int CPR = BK / 8;                         // 16-B chunks per LDS row
@@ -82,7 +137,26 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) 
         rih[i] = oh * p.stride - p.pad;
         riw[i] = ow * p.stride - p.pad;
     }
-    int kcur = kc * 8 - BK, kh = 0, kw = 0;              // channel / tap of this thread's chunk (normalised below)
+    // split-K: grid.z slices the K tiles; this block owns tiles [kbeg, kbeg + nk)
+    // (nk is deliberately written as <kernel argument> / BK, like the unsplit kernel's Kpad / BK: hipcc's register
+    // allocation for this kernel is chaotic in the form of this expression -- any other spelling costs 40-50 VGPRs)
+    const int nk = p.Kslice / BK;
+    const int kbeg = (int)blockIdx.z * nk;
+    const bf16_t* wp[NWC];                               // this thread's weight chunks of the next tile to load
+#pragma unroll
+    for (int i = 0; i < NWC; ++i) {
+        int n = trow + i * RPT;
+        if (BN < RPT) n = n < BN ? n : BN - 1;
+        wp[i] = p.w + (long)(n0 + n) * p.Kpad + (long)kbeg * BK + kc * 8;
+    }
+    int kcur, kh, kw;                                    // channel / tap of this thread's chunk of the next tile to load
+    {
+        const int kabs = kbeg * BK + kc * 8;
+        const int tap = kabs / p.Cin;
+        kcur = kabs - tap * p.Cin;
+        kh = tap / p.KW;
+        kw = tap - kh * p.KW;
+    }
 
     u32x4 xr[S][NX], wr[S][NWC];
     unsigned okmask[S];                                  // bit i of okmask[slot]: chunk i of that tile is real data (else zero)
@@ -114,9 +188,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) 
         }                                                                                                  \
         okmask[SLOT] = ok_;                                                                                \
         _Pragma("unroll") for (int i = 0; i < NWC; ++i) {                                                  \
-            int n = trow + i * RPT;                                                                        \
-            if (BN < RPT) n = n < BN ? n : BN - 1;                                                         \
-            wr[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w + (long)(n0 + n) * p.Kpad + (KS) * BK + kc * 8); \
+            wr[SLOT][i] = *reinterpret_cast<const u32x4*>(wp[i]);                                          \
+            wp[i] += BK;                                                                                   \
         }                                                                                                  \
         ADVANCE_TAP();                                                                                     \
     }
@@ -147,8 +220,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) 
 
     // K loop.  Tile t lives in ring slot t % S; the loads of tile ks+S-1 are issued before the MFMAs of tile ks, so a
     // global/L2 round trip has S-2 whole iterations to land.  LDS is double-buffered; one barrier per tile.
-    const int nk = p.Kpad / BK;
-    ADVANCE_TAP();                                       // kcur = kc*8, wrapped into (kh, kw, c)
 #pragma unroll
     for (int t = 0; t < S - 1; ++t)
         if (t < nk) LOAD_TILE(t, t);
@@ -202,66 +273,48 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) 
             *reinterpret_cast<f32x4*>(ctile + px * LDC + ch) = acc[a][b];
         }
     __syncthreads();
-    const int act = (p.flags >> CUTIE_ACT_SHIFT) & 7;
-    const bool out_f32 = p.flags & CUTIE_F_OUT_F32;
-    const bool res_bcast = p.flags & CUTIE_F_RES_BCAST;
-    const bool vec_y = out_f32 ? ((p.ldy & 3) == 0) : ((p.ldy & 7) == 0);
-    const bool vec_r = (p.ldr & 7) == 0;
     constexpr int CH8 = BN / 8;                          // 8-channel chunks per tile row
+    if (p.splitk == 1) {
+        for (int q = tid; q < BM * CH8; q += NT) {
+            const int px = q / CH8, c8 = q - px * CH8;
+            const int m = m0 + px, ch0 = n0 + c8 * 8;
+            if (m >= p.M || ch0 >= p.Cout) continue;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(ctile + px * LDC + c8 * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(ctile + px * LDC + c8 * 8 + 4);
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            conv_finish(p, v, m, ch0);
+        }
+        return;
+    }
+    // split-K: park the raw fp32 partial tile; conv_splitk_reduce_kernel (next launch on the stream) sums the slices in
+    // slice order and runs the epilogue.  (A single-kernel "last arriver reduces" variant was measured first: the
+    // device-scope release/acquire fences it needs write back / invalidate the XCD's L2 and cost 25-60 us per launch.)
+    float* part = p.part + (long)blockIdx.z * p.M * p.ldp;
     for (int q = tid; q < BM * CH8; q += NT) {
         const int px = q / CH8, c8 = q - px * CH8;
         const int m = m0 + px, ch0 = n0 + c8 * 8;
         if (m >= p.M || ch0 >= p.Cout) continue;
-        float v[8];
-        {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(ctile + px * LDC + c8 * 8);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(ctile + px * LDC + c8 * 8 + 4);
-            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-        }
-        const bool full = ch0 + 7 < p.Cout;
-        if (p.bias) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) v[r] += p.bias[ch0 + r];
-        }
-        if (p.res) {
-            const int mres = res_bcast ? (m % p.OHW) : m;
-            const bf16_t* rp = p.res + (long)mres * p.ldr + ch0;
-            if (full && vec_r) {
-                const uint4 rr = *reinterpret_cast<const uint4*>(rp);
-                v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-                v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-                v[4] += __uint_as_float(rr.z << 16); v[5] += __uint_as_float(rr.z & 0xffff0000u);
-                v[6] += __uint_as_float(rr.w << 16); v[7] += __uint_as_float(rr.w & 0xffff0000u);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) v[r] += bf2f(rp[r]);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            if (act == CUTIE_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
-            else if (act == CUTIE_ACT_SIGMOID) v[r] = sigmoidf_(v[r]);
-            else if (act == CUTIE_ACT_SQ1) v[r] = v[r] * v[r] + 1.f;
-        }
-        if (out_f32) {
-            float* yp = reinterpret_cast<float*>(p.y) + (long)m * p.ldy + ch0;
-            if (full && vec_y) {
-                *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) yp[r] = v[r];
-            }
-        } else {
-            bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + (long)m * p.ldy + ch0;
-            if (full && vec_y) {
-                *reinterpret_cast<uint4*>(yp) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-            } else {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) yp[r] = f2bf(v[r]);
-            }
-        }
+        float* dst = part + (long)m * p.ldp + ch0;
+        *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(ctile + px * LDC + c8 * 8);
+        *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(ctile + px * LDC + c8 * 8 + 4);
     }
+}
+
+// Second half of a split-K conv: y = epilogue(sum_z part[z]) ; one thread per (pixel, 8-channel chunk).
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvParams p) {
+    const int c8n = p.ldp >> 3;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (long)p.M * c8n) return;
+    const int m = (int)(q / c8n), ch0 = (int)(q - (long)m * c8n) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < p.splitk; ++z) {
+        const float* src = p.part + ((long)z * p.M + m) * p.ldp + ch0;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 4);
+        v[0] += lo[0]; v[1] += lo[1]; v[2] += lo[2]; v[3] += lo[3];
+        v[4] += hi[0]; v[5] += hi[1]; v[6] += hi[2]; v[7] += hi[3];
+    }
+    conv_finish(p, v, m, ch0);
 }
 
 // ---- Cout == 1 convolutions (mask_pred 1x1, d_proj / pred 3x3): a per-pixel dot product, HBM/L2-bound.  An MFMA tile
@@ -310,12 +363,20 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int S>
-static int launch_cfg(const ConvParams& p, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int BK, int S, int OCC>
+static int launch_cfg(ConvParams p, hipStream_t s) {
     if (p.Kpad % BK) { cutie_set_error("conv: Kpad %d not a multiple of BK %d", p.Kpad, BK); return -2; }
     if (BK > 32 && p.Cin < 32) { cutie_set_error("conv: BK %d needs Cin >= 32 (Cin=%d)", BK, p.Cin); return -2; }
-    dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, S>), grid, dim3(WM * WN * 64), 0, s, p);
+    const int nk_all = p.Kpad / BK;
+    if (p.splitk > nk_all) { cutie_set_error("conv: splitk %d > K tiles %d", p.splitk, nk_all); return -2; }
+    if (nk_all % p.splitk) { cutie_set_error("conv: splitk %d must divide the %d K tiles", p.splitk, nk_all); return -2; }
+    p.Kslice = p.Kpad / p.splitk;
+    dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.splitk);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, S, OCC>), grid, dim3(WM * WN * 64), 0, s, p);
+    if (p.splitk > 1) {
+        const long nq = (long)p.M * (p.ldp >> 3);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, p);
+    }
     return (int)hipGetLastError();
 }
 
@@ -329,6 +390,12 @@ int launch_conv(const cutie_op* op, hipStream_t s) {
     p.OH = i[7]; p.OW = i[8]; p.Cout = i[9]; p.ldy = i[10]; p.KH = i[11]; p.KW = i[12];
     p.stride = i[13]; p.pad = i[14]; p.ldr = i[15]; p.Kpad = i[16];
     p.flags = op->flags; p.OHW = p.OH * p.OW; p.M = p.B * p.OHW; p.Cin = p.C1 + p.C2;
+    p.splitk = i[19] > 1 ? i[19] : 1; p.part = (float*)op->p[6];
+    p.ldp = (p.Cout + 7) & ~7;
+    if (p.splitk > 1 && (!p.part || (long)p.splitk * p.M * p.ldp > (long)i[20] * 1024)) {
+        cutie_set_error("conv: split-K %d needs the fp32 partial scratch (p6, capacity i20 KiB-floats)", p.splitk);
+        return -2;
+    }
     if ((p.C1 & 7) || (p.C2 & 7) || (p.ldx1 & 7) || (p.C2 && (p.ldx2 & 7)) || (p.Kpad & 31) ||
         p.Kpad < p.KH * p.KW * p.Cin || p.M <= 0 || p.Cout <= 0) {
         cutie_set_error("conv: bad geometry C1=%d C2=%d ldx1=%d ldx2=%d Kpad=%d M=%d Cout=%d",
@@ -346,25 +413,25 @@ int launch_conv(const cutie_op* op, hipStream_t s) {
         return (int)hipGetLastError();
     }
     switch (i[17]) {
-        case 0: return launch_cfg<128, 128, 2, 2, 32, 4>(p, s);
-        case 1: return launch_cfg<128, 64, 2, 2, 32, 4>(p, s);
-        case 2: return launch_cfg<64, 64, 2, 2, 32, 4>(p, s);
-        case 3: return launch_cfg<256, 16, 4, 1, 32, 4>(p, s);
-        case 4: return launch_cfg<64, 128, 2, 2, 32, 4>(p, s);
-        case 5: return launch_cfg<64, 64, 2, 2, 64, 4>(p, s);
-        case 6: return launch_cfg<64, 128, 2, 2, 64, 3>(p, s);
-        case 7: return launch_cfg<128, 128, 2, 2, 64, 2>(p, s);
-        case 8: return launch_cfg<64, 64, 2, 2, 128, 3>(p, s);
-        case 9: return launch_cfg<32, 64, 2, 2, 64, 4>(p, s);
-        case 10: return launch_cfg<128, 64, 2, 2, 64, 3>(p, s);
-        case 11: return launch_cfg<32, 64, 2, 2, 128, 3>(p, s);
-        case 12: return launch_cfg<32, 128, 2, 2, 64, 3>(p, s);
-        case 13: return launch_cfg<64, 64, 2, 4, 64, 4>(p, s);        // 8 waves
-        case 14: return launch_cfg<128, 64, 4, 2, 64, 4>(p, s);
-        case 15: return launch_cfg<64, 128, 2, 4, 64, 4>(p, s);
-        case 16: return launch_cfg<128, 128, 2, 4, 64, 3>(p, s);
-        case 17: return launch_cfg<64, 64, 2, 4, 128, 3>(p, s);
-        case 18: return launch_cfg<128, 128, 2, 4, 32, 4>(p, s);
+        case 0: return launch_cfg<128, 128, 2, 2, 32, 4, 2>(p, s);
+        case 1: return launch_cfg<128, 64, 2, 2, 32, 4, 3>(p, s);
+        case 2: return launch_cfg<64, 64, 2, 2, 32, 4, 4>(p, s);
+        case 3: return launch_cfg<256, 16, 4, 1, 32, 4, 3>(p, s);
+        case 4: return launch_cfg<64, 128, 2, 2, 32, 4, 3>(p, s);
+        case 5: return launch_cfg<64, 64, 2, 2, 64, 4, 3>(p, s);
+        case 6: return launch_cfg<64, 128, 2, 2, 64, 3, 2>(p, s);
+        case 7: return launch_cfg<128, 128, 2, 2, 64, 2, 2>(p, s);
+        case 8: return launch_cfg<64, 64, 2, 2, 128, 3, 2>(p, s);
+        case 9: return launch_cfg<32, 64, 2, 2, 64, 4, 4>(p, s);
+        case 10: return launch_cfg<128, 64, 2, 2, 64, 3, 2>(p, s);
+        case 11: return launch_cfg<32, 64, 2, 2, 128, 3, 3>(p, s);
+        case 12: return launch_cfg<32, 128, 2, 2, 64, 3, 2>(p, s);
+        case 13: return launch_cfg<64, 64, 2, 4, 64, 4, 5>(p, s);        // 8 waves
+        case 14: return launch_cfg<128, 64, 4, 2, 64, 4, 4>(p, s);
+        case 15: return launch_cfg<64, 128, 2, 4, 64, 4, 4>(p, s);
+        case 16: return launch_cfg<128, 128, 2, 4, 64, 3, 3>(p, s);
+        case 17: return launch_cfg<64, 64, 2, 4, 128, 3, 4>(p, s);
+        case 18: return launch_cfg<128, 128, 2, 4, 32, 4, 4>(p, s);
         default: cutie_set_error("conv: bad tile id %d", i[17]); return -2;
     }
 }

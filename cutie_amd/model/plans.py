@@ -86,17 +86,18 @@ class Plan:
             best = cache.get(key)
             if best is None:
                 one = arr[n:n + 1].copy()
-                best, best_t = int(i[17]), None
+                best, best_t = (int(i[17]), 1), None
                 cands = O.tile_candidates(M, cout, cin)
                 if int(i[4]) or arr['p'][n, 4]:              # 2-source or residual conv: no cout1 kernel
                     cands = [t for t in cands if t != O.COUT1_TILE]
                 for t in cands:
-                    one['i'][0, 17] = t
-                    ms = min(ex.time_ops(one, 8) for _ in range(3))
-                    if best_t is None or ms < best_t:
-                        best, best_t = t, ms
+                    for sk in O.splitk_candidates(M, cout, int(i[16]), t):
+                        one['i'][0, 17], one['i'][0, 19] = t, sk
+                        ms = min(ex.time_ops(one, 8) for _ in range(3))
+                        if best_t is None or ms < best_t:
+                            best, best_t = (t, sk), ms
                 cache[key] = best
-            arr['i'][n, 17] = best
+            arr['i'][n, 17], arr['i'][n, 19] = best
         self.tuned = True
 
     # ---- conv helper ------------------------------------------------------------------

@@ -62,6 +62,38 @@ def tile_candidates(M, cout, cin):
     return out
 
 
+SPLITK_PART_FLOATS = 16 << 20           # 64 MiB of fp32 partial tiles
+_splitk_scratch = {}
+
+
+def splitk_scratch(device):
+    """fp32 partial-tile scratch shared by every split-K conv of a device (launches are stream-ordered)."""
+    key = str(device)
+    if key not in _splitk_scratch:
+        n = SPLITK_PART_FLOATS if torch.device(device).type == 'cuda' else 1024
+        _splitk_scratch[key] = torch.zeros(n, dtype=torch.float32, device=device)
+    return _splitk_scratch[key]
+
+
+def splitk_candidates(M, cout, kpad, tile):
+    """Split-K factors worth timing for a conv on a given tile: only when the plain grid leaves CUs idle."""
+    if tile == COUT1_TILE or tile == 3:
+        return [1]
+    bm, bn, bk = TILES[tile]
+    blocks = -(-M // bm) * -(-cout // bn)
+    nk = kpad // bk
+    ldp = (cout + 7) & ~7
+    out = [1]
+    for sk in (2, 3, 4, 6, 8, 9, 12, 16, 18):
+        if blocks >= NUM_CU or blocks * sk > 6 * NUM_CU or nk // sk < 2:
+            break
+        if sk * M * ldp > SPLITK_PART_FLOATS:
+            break
+        if nk % sk == 0:                                 # equal slices only (conv_igemm.hip)
+            out.append(sk)
+    return out
+
+
 def pick_tile(M, cout, cin=64):
     """Static heuristic (used when no GPU is present to autotune): the largest tile that still yields
     >= NUM_CU workgroups, with BK=64 when the input has enough channels."""
@@ -153,16 +185,18 @@ class OpList:
 
     # ---- builders (argument order mirrors include/cutie_hip.h) -----------------------
     def conv(self, x1, w, y, *, B, H, W, C1, ldx1, OH, OW, ldy, stride=1, pad=0, x2=None, C2=0, ldx2=0,
-             res=None, ldr=0, res_bcast=False, relu_in=False, act=ACT_NONE, out_f32=False, tile=None):
+             res=None, ldr=0, res_bcast=False, relu_in=False, act=ACT_NONE, out_f32=False, tile=None, splitk=1):
         """w: PackedConv (weights.py)."""
         flags = (F_RELU_IN if relu_in else 0) | (F_OUT_F32 if out_f32 else 0) | (F_RES_BCAST if res_bcast else 0) | (act << ACT_SHIFT)
         assert C1 + C2 == w.cin_padded, (C1, C2, w.cin_padded)
         M = B * OH * OW
         if tile is None:
             tile = COUT1_TILE if cout1_ok(w.cout, C1 + C2, C2, res is not None) else pick_tile(M, w.cout, C1 + C2)
+        part = splitk_scratch(w.weight.device)
         return self.add(CONV, flags,
-                        [B, H, W, C1, C2, ldx1, ldx2, OH, OW, w.cout, ldy, w.kh, w.kw, stride, pad, ldr, w.kpad, tile, w.cin_real],
-                        [], [x1, x2, w.weight, w.bias, res, y])
+                        [B, H, W, C1, C2, ldx1, ldx2, OH, OW, w.cout, ldy, w.kh, w.kw, stride, pad, ldr, w.kpad, tile, w.cin_real,
+                         splitk, part.numel() // 1024],
+                        [], [x1, x2, w.weight, w.bias, res, y, part])
 
     def maxpool(self, x, y, *, B, H, W, C, relu=False):
         OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1

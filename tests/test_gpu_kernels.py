@@ -75,7 +75,7 @@ CONV_CASES = [
 ]
 
 
-def _conv_build(c, tile):
+def _conv_build(c, tile, splitk=1):
     def build(dev, g):
         B, H, W, C1, Cout, k = c['B'], c['H'], c['W'], c['C1'], c['Cout'], c['k']
         C2 = c.get('C2', 0)
@@ -91,7 +91,7 @@ def _conv_build(c, tile):
         ol = O.OpList()
         ol.conv(x1, pc, y, B=B, H=H, W=W, C1=C1, ldx1=C1, OH=OH, OW=OW, ldy=Cout, stride=stride, pad=pad, x2=x2, C2=C2,
                 ldx2=C2, res=res, ldr=Cout, res_bcast=c.get('res_bcast', False), relu_in=c.get('relu_in', False),
-                act=c.get('act', O.ACT_NONE), out_f32=c.get('out_f32', False), tile=tile)
+                act=c.get('act', O.ACT_NONE), out_f32=c.get('out_f32', False), tile=tile, splitk=splitk)
         return ol, {'y': y}
     return build
 
@@ -110,6 +110,48 @@ def test_conv_every_tile(ci, tile):
         pytest.skip('BK > 32 needs Cin >= 32')
     hip, ref = run_both(_conv_build(c, tile), seed=100 + ci)
     check(hip, ref, f'conv[{ci}] tile{tile}')
+
+
+@pytest.mark.parametrize('splitk', [2, 3, 4, 9])
+@pytest.mark.parametrize('tile', [0, 5, 7, 8, 11, 13, 16])
+@pytest.mark.parametrize('ci', [0, 2, 4, 5, 6, 7, 12, 14])
+def test_conv_split_k(ci, tile, splitk):
+    """grid.z K slices + reduce launch: same result as the single-pass kernel for every epilogue variant
+    (residual / broadcast residual / 2-source / f32 out / ragged M and Cout / stride 2)."""
+    c = CONV_CASES[ci]
+    cin = c['C1'] + c.get('C2', 0)
+    nk = -(-(cin * c['k'] * c['k']) // 128) * 128 // O.TILES[tile][2]
+    if splitk > nk or nk % splitk:
+        pytest.skip('the slice count must divide the K tiles')
+    if splitk * c['B'] * c['H'] * c['W'] * ((c['Cout'] + 7) & ~7) > O.SPLITK_PART_FLOATS:
+        pytest.skip('partials exceed the scratch')
+    hip, ref = run_both(_conv_build(c, tile, splitk), seed=500 + ci)
+    check(hip, ref, f'conv[{ci}] tile{tile} splitk{splitk}')
+
+
+def test_conv_split_k_repeatable():
+    """Two launches of the same split-K conv give bit-identical outputs (slices are summed in slice order)."""
+    dev = 'cuda'
+    c = CONV_CASES[4]
+    g = torch.Generator().manual_seed(7)
+    ol, outs = _conv_build(c, 8, 3)(dev, g)
+    arr = ol.finalize()
+    ex = _lib.HipExecutor()
+    ex.run(arr)
+    torch.cuda.synchronize()
+    a = outs['y'].clone()
+    ex.run(arr)
+    torch.cuda.synchronize()
+    assert torch.equal(a, outs['y'])
+
+
+def test_conv_split_k_rejects_bad_factor():
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(7)
+    ol, _ = _conv_build(CONV_CASES[0], 8, 3)(dev, g)        # 512/128 = 4 K tiles: 3 slices do not divide them
+    arr = ol.finalize()
+    with pytest.raises(Exception):
+        _lib.HipExecutor().run(arr)
 
 
 @pytest.mark.parametrize('ci', [8, 9])

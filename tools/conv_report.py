@@ -55,14 +55,14 @@ def main():
             i = one['i'][0]
             M, cout, k, cin = int(i[0]) * int(i[7]) * int(i[8]), int(i[9]), int(i[11]), int(i[18])
             fl = 2.0 * M * cout * k * k * cin
-            rows.append((us, M, cin, cout, k, int(i[13]), int(i[17]), fl / us / 1e6))
+            rows.append((us, M, cin, cout, k, int(i[13]), int(i[17]), fl / us / 1e6, int(i[19])))
         tot = sum(r[0] for r in rows)
         print(f'{len(rows)} convs, {tot:.1f} us back-to-back (isolated timing), {sum(r[7] * r[0] for r in rows) / tot:.1f} TFLOP/s average')
-        print('    us      M   Cin  Cout k s tile   TFLOP/s   cum%')
+        print('    us      M   Cin  Cout k s tile splitk  TFLOP/s   cum%')
         cum = 0.0
         for r in sorted(rows, key=lambda r: -r[0]):
             cum += r[0]
-            print(f'{r[0]:7.1f} {r[1]:6d} {r[2]:5d} {r[3]:5d} {r[4]} {r[5]} {str(O.TILES.get(r[6], "c1")):>15s} {r[7]:8.1f} {cum / tot * 100:6.1f}')
+            print(f'{r[0]:7.1f} {r[1]:6d} {r[2]:5d} {r[3]:5d} {r[4]} {r[5]} {str(O.TILES.get(r[6], "c1")):>15s} {r[8]:2d} {r[7]:8.1f} {cum / tot * 100:6.1f}')
 
 
 if __name__ == '__main__':
