@@ -179,6 +179,24 @@ def main():
                 for b in proc.memory.buckets.values():
                     aff_f += (256 + 512 * len(b.objects)) * float(b.size()) * HW
             n_conv = int((allops['kind'] == O.CONV).sum())
+            # the affinity matmul on its own (score pass 0 = the S = A.B^T tiles + tile maxima; valid in isolation), and the
+            # other stages by prefix differences of the 5-op plan [memset, score/0, select, score/1, readout]
+            aff_parts = None
+            if len(affs) == 5 and int(affs['kind'][1]) == O.AFF_SCORE:
+                sc = affs[1:2]
+                t_mm = min(rec.ex.time_ops(sc, 10) for _ in range(3)) * 1e-3
+                ii = sc['i'][0]
+                n_tok, hw = sum(int(ii[4 + 2 * r]) for r in range(int(ii[2]))), int(ii[0])
+                issued = 3 * 2.0 * 128 * (int(ii[9]) * 16) * int(ii[1])      # 3 split-bf16 terms, padded tiles
+                pre = [min(rec.ex.time_ops(affs[:k], 10) for _ in range(3)) * 1e3 for k in (1, 2, 3, 4, 5)]
+                aff_parts = {'kernel': 'aff_score_kernel mode 0 (S = A.B^T on v_mfma_f32_16x16x32_bf16, 3 split terms)',
+                             'us': round(t_mm * 1e6, 2), 'tokens': n_tok, 'queries': hw,
+                             'mfma_issued_tflops': round(issued / t_mm / 1e12, 1),
+                             'mfma_util': round(issued / t_mm / 1e12 / PEAK_BF16_TFLOPS, 4),
+                             'fp32_equivalent_tflops': round(2.0 * 128 * n_tok * hw / t_mm / 1e12, 1),
+                             'stage_us': {'memset': round(pre[0], 1), 'score0': round(pre[1] - pre[0], 1),
+                                          'select': round(pre[2] - pre[1], 1), 'score1': round(pre[3] - pre[2], 1),
+                                          'readout': round(pre[4] - pre[3], 1)}}
             # device-time breakdown of the last recorded frame by op kind (back-to-back replays, hipEvents), and the
             # whole frame replayed as ONE HIP graph (no host involvement): shows how much of the step is launch gaps
             names = O.KIND_NAMES
@@ -211,7 +229,7 @@ def main():
                         'achieved': round(aff_f / aff_t / 1e12, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': round(aff_f / aff_t / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': None,
                         'algorithmic_gflop_per_frame': round(aff_f / nrec / 1e9, 1), 'ms_per_frame': round(aff_t / nrec * 1e3, 4),
-                        'memory_tokens': n_tok_end,
+                        'memory_tokens': n_tok_end, 'matmul': aff_parts,
                         'note': 'algorithmic = dense (256+512K)*N*HW of the reference; the kernels do the top-k readout sparsely'}
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

@@ -62,13 +62,29 @@ struct ScoreParams {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int au32x4;
 
-// grid (HWp/64, ceil(G/tiles_per_block)); wave w of the block owns queries j0 + 16w .. +15.
+// grid (ceil(HWp/128), ceil(G/tiles_per_block)); wave w of the block owns queries j0 + 32w .. +31 (two MFMA column sets).
 // The memory operands of 4 consecutive 16-token tiles (64 rows x [hi|lo] x 256 B = 32 KB) are staged ONCE per block in
 // LDS (double-buffered, register prefetch of the next group) and shared by the 4 waves; rows are XOR-swizzled by
-// (row & 15) so the ds_read_b128 fragment reads are conflict-free.  B fragments of the 16 queries stay in registers.
+// (row & 15) so the ds_read_b128 fragment reads are conflict-free.  The B fragments of the wave's 32 queries stay in
+// registers, so one set of 8 A-fragment reads feeds 24 MFMAs (with 16 queries per wave the loop was LDS-bound).
+// mode 1 appends through wave-private LDS lists (ballot + mbcnt positions, no atomics in the loop; one dense burst of
+// global atomics per wave at the end).
+// candidate counters: one per query, each in its own 128-B line (the ~50 returning atomics per query of the 77k per
+// frame otherwise all land on 51 cache lines and serialise in a couple of L2 channels: +23 us)
+#define AFF_CSTRIDE 32
 #define AFF_TG 4                                      // tiles per LDS group
+#define AFF_LCAP 1024                                 // LDS candidate list entries per block ...
+#define AFF_WCAP (AFF_LCAP / 4)                       // ... = 4 wave-private lists (overflow -> direct global append)
+#define AFF_LDS_BYTES (2 * 2 * 64 * 16 * 16 + AFF_LCAP * 12 + 16 + 2 * 64 * 4)
+template <int AFF_NQ>                                 // 16-query column sets per wave (1 or 2)
 __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
-    __shared__ au32x4 lds[2][2 * 64 * 16];            // [buffer][hi/lo][row][16 chunks]
+    extern __shared__ __attribute__((aligned(16))) unsigned char aff_smem[];
+    au32x4 (*lds)[2 * 64 * 16] = reinterpret_cast<au32x4 (*)[2 * 64 * 16]>(aff_smem);   // [buffer][hi/lo][row][16 chunks]
+    int* l_j = reinterpret_cast<int*>(aff_smem + 2 * 2 * 64 * 16 * 16);
+    int* l_idx = l_j + AFF_LCAP;
+    float* l_val = reinterpret_cast<float*>(l_idx + AFF_LCAP);
+    int* l_n = reinterpret_cast<int*>(l_val + AFF_LCAP);
+    float (*lsc)[64] = reinterpret_cast<float (*)[64]>(l_n + 4);        // [buffer][row of the group]: scale_i (0 for padding rows)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     // XCD-aware mapping (see conv_igemm.hip): consecutive logical blocks share the token chunk (query block fastest)
     int bx, by;
@@ -79,49 +95,98 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
         by = logical / (int)gridDim.x;
         bx = logical - by * (int)gridDim.x;
     }
-    const int j = bx * 64 + wave * 16 + l15;                           // query column of this lane
-    bf16x8 bh[4], bl[4];
+    int* wl_j = l_j + wave * AFF_WCAP; int* wl_idx = l_idx + wave * AFF_WCAP; float* wl_val = l_val + wave * AFF_WCAP;
+    int wcount = 0;                                                     // wave-uniform fill of the wave's list
+    int jq[AFF_NQ];                                                     // query column of this lane, per set
+    bool jvalid[AFF_NQ];
+    float cj[AFF_NQ], thr[AFF_NQ];
+    bf16x8 bh[AFF_NQ][4], bl[AFF_NQ][4];
+    // The block's query operand (64*AFF_NQ rows x [hi|lo] x 256 B) is one contiguous run per array: copy it through LDS
+    // with whole-line loads (fragment-shaped global loads touch 16 half-used lines per instruction and were most of this
+    // kernel's fixed cost), then pull each wave's B fragments into registers.  Uses the A buffers before the K loop.
+    {
+        constexpr int QROWS = 64 * AFF_NQ, NCH = QROWS * 16 / 256;      // 16-B chunks per thread per array
+        const int q0 = bx * QROWS;
+        au32x4 tb[2][NCH];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        bh[ks] = *reinterpret_cast<const bf16x8*>(p.Bhi + (long)j * 128 + ks * 32 + l4 * 8);
-        bl[ks] = *reinterpret_cast<const bf16x8*>(p.Blo + (long)j * 128 + ks * 32 + l4 * 8);
+        for (int i = 0; i < NCH; ++i) {
+            const int q = tid + 256 * i, row = q >> 4;
+            const int jr = min(q0 + row, p.HWp - 1);                    // B rows exist up to HWp
+            tb[0][i] = *reinterpret_cast<const au32x4*>(p.Bhi + (long)jr * 128 + (q & 15) * 8);
+            tb[1][i] = *reinterpret_cast<const au32x4*>(p.Blo + (long)jr * 128 + (q & 15) * 8);
+        }
+        au32x4* lb = reinterpret_cast<au32x4*>(aff_smem);               // [hi|lo][QROWS][16 chunks], chunk ^ (row & 15)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int q = tid + 256 * i, row = q >> 4;
+            lb[row * 16 + ((q & 15) ^ (row & 15))] = tb[0][i];
+            lb[QROWS * 16 + row * 16 + ((q & 15) ^ (row & 15))] = tb[1][i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < AFF_NQ; ++u) {
+            const int row = wave * (16 * AFF_NQ) + u * 16 + l15;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bh[u][ks] = __builtin_bit_cast(bf16x8, lb[row * 16 + ((ks * 4 + l4) ^ l15)]);
+                bl[u][ks] = __builtin_bit_cast(bf16x8, lb[QROWS * 16 + row * 16 + ((ks * 4 + l4) ^ l15)]);
+            }
+        }
+        __syncthreads();                                                // the A staging below overwrites this area
     }
-    const bool jvalid = j < p.HW;
-    const float cj = jvalid ? p.c[j] : 0.f;
-    float thr = INFINITY;
-    if (p.mode == 1 && jvalid) {
-        float tau = p.gmax_or_tau[j];
-        thr = tau - fabsf(tau) * 1e-6f - 1e-30f;                        // never lose the k-th element to 1 ulp
+#pragma unroll
+    for (int u = 0; u < AFF_NQ; ++u) {
+        jq[u] = bx * (64 * AFF_NQ) + wave * (16 * AFF_NQ) + u * 16 + l15;
+        jvalid[u] = jq[u] < p.HW;
+        cj[u] = jvalid[u] ? p.c[jq[u]] : 0.f;
+        thr[u] = INFINITY;
+        if (p.mode == 1 && jvalid[u]) {
+            float tau = p.gmax_or_tau[jq[u]];
+            thr[u] = tau - fabsf(tau) * 1e-6f - 1e-30f;                 // never lose the k-th element to 1 ulp
+        }
     }
     const int g0 = by * p.tiles_per_block;
     const int g1 = min(g0 + p.tiles_per_block, p.G);
     const int T0 = (p.rn[0] + 15) >> 4, T1 = (p.nranges > 1) ? ((p.rn[1] + 15) >> 4) : 0;
     // this thread stages chunk (row = tid >> 2 .. , 4 chunks) : 64 rows x 16 chunks x 2 arrays = 2048 chunks / 256 threads = 8
-    const int srow = tid >> 2, sc0 = (tid & 3) * 4;                    // row 0..63, chunks sc0..sc0+3 of hi and of lo
+    const int srow = tid >> 4, sch = tid & 15;                         // rows srow + 16c (c = 0..3 = the group's 4 tiles), chunk sch: whole 256-B rows per wave
     au32x4 st[8];
+    float st_sc = 0.f;
     auto tile_slot = [&](int g, int& start, int& n, int& lt) {
-        int r;
-        if (g < T0) { r = 0; lt = g; } else if (g < T0 + T1) { r = 1; lt = g - T0; } else { r = 2; lt = g - T0 - T1; }
-        start = p.rs[r]; n = p.rn[r];
+        // (selects, not p.rs[r]: dynamic indexing of the kernel-argument arrays costs scalar memory loads per tile)
+        if (g < T0) { lt = g; start = p.rs[0]; n = p.rn[0]; }
+        else if (g < T0 + T1) { lt = g - T0; start = p.rs[1]; n = p.rn[1]; }
+        else { lt = g - T0 - T1; start = p.rs[2]; n = p.rn[2]; }
     };
 #define AFF_LOAD(GRP)                                                                                      \
     {                                                                                                      \
-        int gt = (GRP) + (srow >> 4);                      /* tile of this staging row */                  \
-        gt = gt < g1 ? gt : g1 - 1;                        /* clamp: rows of missing tiles are never used */ \
-        int start_, n_, lt_;                                                                               \
-        tile_slot(gt, start_, n_, lt_);                                                                    \
-        const long off_ = (long)(start_ + lt_ * 16 + (srow & 15)) * 128 + sc0 * 8;                         \
         _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                    \
-            st[c] = *reinterpret_cast<const au32x4*>(p.Ahi + off_ + c * 8);                                \
-            st[4 + c] = *reinterpret_cast<const au32x4*>(p.Alo + off_ + c * 8);                            \
+            int gt = (GRP) + c;                                /* tile of staging row srow + 16c */        \
+            gt = gt < g1 ? gt : g1 - 1;                        /* clamp: rows of missing tiles are never used */ \
+            int start_, n_, lt_;                                                                           \
+            tile_slot(gt, start_, n_, lt_);                                                                \
+            const long off_ = (long)(start_ + lt_ * 16 + srow) * 128 + sch * 8;                            \
+            st[c] = *reinterpret_cast<const au32x4*>(p.Ahi + off_);                                        \
+            st[4 + c] = *reinterpret_cast<const au32x4*>(p.Alo + off_);                                    \
         }                                                                                                  \
+        /* the per-token scale rides along (threads 0..63 = the group's 64 rows): a global load inside the MFMA loop */ \
+        /* would make every tile wait for this whole prefetch (vmcnt is in-order) */                      \
+        int gs_ = (GRP) + ((tid & 63) >> 4);                                                               \
+        gs_ = gs_ < g1 ? gs_ : g1 - 1;                                                                     \
+        int s2_, n2_, lt2_;                                                                                \
+        tile_slot(gs_, s2_, n2_, lt2_);                                                                    \
+        const int loc_ = lt2_ * 16 + (tid & 15);                                                           \
+        const float sv_ = p.scale[s2_ + (loc_ < n2_ ? loc_ : n2_ - 1)];                                    \
+        st_sc = loc_ < n2_ ? sv_ : 0.f;                                                                    \
     }
 #define AFF_STORE(BUF)                                                                                     \
     {                                                                                                      \
         _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                    \
-            lds[BUF][srow * 16 + ((sc0 + c) ^ (srow & 15))] = st[c];                                       \
-            lds[BUF][1024 + srow * 16 + ((sc0 + c) ^ (srow & 15))] = st[4 + c];                            \
+            const int row_ = srow + 16 * c;                                                                \
+            lds[BUF][row_ * 16 + (sch ^ srow)] = st[c];                                                    \
+            lds[BUF][1024 + row_ * 16 + (sch ^ srow)] = st[4 + c];                                         \
         }                                                                                                  \
+        if (tid < 64) lsc[BUF][tid] = st_sc;                                                               \
     }
     AFF_LOAD(g0);
     AFF_STORE(0);
@@ -130,8 +195,11 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
     for (int gg = g0; gg < g1; gg += AFF_TG) {
         const bool more = gg + AFF_TG < g1;
         if (more) AFF_LOAD(gg + AFF_TG);
+        float gm[AFF_NQ][AFF_TG];
 #pragma unroll
         for (int t = 0; t < AFF_TG; ++t) {
+#pragma unroll
+            for (int u = 0; u < AFF_NQ; ++u) gm[u][t] = -INFINITY;
             const int g = gg + t;
             if (g < g1) {                                               // block-uniform
                 int start, n, lt;
@@ -143,46 +211,68 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
                     ah[ks] = __builtin_bit_cast(bf16x8, lds[buf][row * 16 + ((ks * 4 + l4) ^ l15)]);
                     al[ks] = __builtin_bit_cast(bf16x8, lds[buf][1024 + row * 16 + ((ks * 4 + l4) ^ l15)]);
                 }
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                // lane holds tokens lt*16 + l4*4 + q (q = 0..3) of its query
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(&lsc[buf][t * 16 + l4 * 4]);
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {                        // small cross terms first
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bl[ks], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], bh[ks], acc, 0, 0, 0);
-                }
+                for (int u = 0; u < AFF_NQ; ++u) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bh[ks], acc, 0, 0, 0);
-                // lane holds tokens lt*16 + l4*4 + q (q = 0..3) of query j
-                float s[4];
-                float mx = -INFINITY;
+                    for (int ks = 0; ks < 4; ++ks) {                    // small cross terms first
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bl[u][ks], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], bh[u][ks], acc, 0, 0, 0);
+                    }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int local = lt * 16 + l4 * 4 + q;
-                    bool valid = local < n;
-                    float sc = valid ? p.scale[start + local] : 0.f;
-                    s[q] = valid ? sc * (acc[q] - cj) : -INFINITY;
-                    mx = fmaxf(mx, s[q]);
-                }
-                if (p.mode == 0) {
-                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                    if (l4 == 0) p.gmax_or_tau[(long)j * p.Gld + g] = mx;
-                } else if (jvalid) {
+                    for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bh[u][ks], acc, 0, 0, 0);
+                    float s[4], mx = -INFINITY;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        if (s[q] >= thr && s[q] > -INFINITY) {
-                            int pos = atomicAdd(&p.count[j], 1);
-                            if (pos < p.cap) {
-                                p.cand_val[(long)j * p.cap + pos] = s[q];
-                                p.cand_idx[(long)j * p.cap + pos] = start + lt * 16 + l4 * 4 + q;
+                        const bool valid = lt * 16 + l4 * 4 + q < n;
+                        s[q] = valid ? sc[q] * (acc[q] - cj[u]) : -INFINITY;
+                        mx = fmaxf(mx, s[q]);
+                    }
+                    if (p.mode == 0) {
+                        gm[u][t] = rows_max(mx);
+                    } else if (__ballot(jvalid[u] && mx >= thr[u])) {   // wave-uniform: some lane has a candidate in this tile
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const bool hit = jvalid[u] && s[q] >= thr[u] && s[q] > -INFINITY;
+                            const unsigned long long m = __ballot(hit);
+                            if (m) {
+                                // the wave owns its queries: positions come from a wave-private counter + lane prefix
+                                // (mbcnt), no atomics and no waits inside the MFMA loop
+                                const int pos = wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                if (hit) {
+                                    const int tok = start + lt * 16 + l4 * 4 + q;
+                                    if (pos < AFF_WCAP) { wl_j[pos] = jq[u]; wl_idx[pos] = tok; wl_val[pos] = s[q]; }
+                                    else {                              // wave list full: straight to the global list
+                                        const int gp = atomicAdd(&p.count[jq[u] * AFF_CSTRIDE], 1);
+                                        if (gp < p.cap) { p.cand_val[(long)jq[u] * p.cap + gp] = s[q]; p.cand_idx[(long)jq[u] * p.cap + gp] = tok; }
+                                    }
+                                }
+                                wcount += __popcll(m);
                             }
                         }
                     }
                 }
             }
         }
+        if (p.mode == 0 && l4 == 0) {                                   // 4 tile maxima per query: one 16-B store
+#pragma unroll
+            for (int u = 0; u < AFF_NQ; ++u)
+                if (jq[u] < p.HWp)
+                    *reinterpret_cast<f32x4*>(p.gmax_or_tau + (long)jq[u] * p.Gld + gg) = (f32x4){gm[u][0], gm[u][1], gm[u][2], gm[u][3]};
+        }
         if (more) AFF_STORE(buf ^ 1);
         __syncthreads();
         buf ^= 1;
+    }
+    if (p.mode == 1) {                                                  // flush this wave's candidates: one dense burst of global atomics
+        const int n = min(wcount, AFF_WCAP);
+        for (int e = lane; e < n; e += 64) {
+            const int j = wl_j[e];
+            const int pos = atomicAdd(&p.count[j * AFF_CSTRIDE], 1);
+            if (pos < p.cap) { p.cand_val[(long)j * p.cap + pos] = wl_val[e]; p.cand_idx[(long)j * p.cap + pos] = wl_idx[e]; }
+        }
     }
 }
 
@@ -246,6 +336,8 @@ __global__ __launch_bounds__(256) void aff_select_kernel(const float* __restrict
 }
 
 #define RO_THREADS 128
+typedef __attribute__((ext_vector_type(4))) unsigned int ro_u32x4;
+typedef __attribute__((ext_vector_type(4))) int ro_i32x4;
 #define RO_MAXK 64
 // one block per query column
 __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
@@ -255,22 +347,44 @@ __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float* cv = reinterpret_cast<float*>(lds_raw);             // [cap]
     int* ci = reinterpret_cast<int*>(lds_raw + (size_t)cap * 4);  // [cap]
-    __shared__ float sel_v[RO_MAXK];
-    __shared__ int sel_i[RO_MAXK];
-    __shared__ float sel_w[RO_MAXK];
-    const int j = blockIdx.x, tid = threadIdx.x;
-    int cnt = count[j];
+    __shared__ __attribute__((aligned(16))) float sel_v[RO_MAXK];
+    __shared__ __attribute__((aligned(16))) int sel_i[RO_MAXK];
+    __shared__ __attribute__((aligned(16))) float sel_w[RO_MAXK];
+    // XCD-aware: hardware block b runs on XCD b % 8; give each XCD one contiguous stripe of queries (neighbouring pixels
+    // select overlapping memory tokens, so a stripe's value rows stay in that XCD's L2 instead of all 8 L2s fetching all)
+    const int per = (HW + 7) >> 3;
+    const int j = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    const int tid = threadIdx.x;
+    if (j >= HW || (int)(blockIdx.x >> 3) >= per) return;
+    // every global round trip that does not depend on another is issued up front: the count, the first RO_THREADS
+    // candidates (typical fill is 30-50 of the 1024 slots), the bank base pointer of this thread's object
+    const int C8 = CV >> 3;
+    const int o_mine = min(tid / C8, K - 1);
+    const bf16_t* Vbase = reinterpret_cast<const bf16_t*>(vptrs[o_mine]);
+    const int t0 = tid < cap ? tid : cap - 1;
+    const float v0 = cand_val[(long)j * cap + t0];
+    const int i0 = cand_idx[(long)j * cap + t0];
+    const int first = cand_idx[(long)j * cap];
+    int cnt = count[j * AFF_CSTRIDE];
     if (cnt > cap) { if (tid == 0) atomicAdd(overflow, 1); cnt = cap; }
-    for (int t = tid; t < cnt; t += RO_THREADS) { cv[t] = cand_val[(long)j * cap + t]; ci[t] = cand_idx[(long)j * cap + t]; }
+    const int cnt4 = (cnt + 3) & ~3;                           // LDS lists padded to a multiple of 4 with (-inf, INT_MAX)
+    if (tid < cnt) { cv[tid] = v0; ci[tid] = i0; }
+    for (int t = tid + RO_THREADS; t < cnt; t += RO_THREADS) { cv[t] = cand_val[(long)j * cap + t]; ci[t] = cand_idx[(long)j * cap + t]; }
+    if (tid < cnt4 - cnt) { cv[cnt + tid] = -INFINITY; ci[cnt + tid] = 0x7fffffff; }
     const int nsel = min(cnt, topk);
-    if (tid < RO_MAXK) { sel_v[tid] = -INFINITY; sel_i[tid] = cnt > 0 ? cand_idx[(long)j * cap] : 0; sel_w[tid] = 0.f; }
+    // padding / unassigned ranks: any valid slot (gathered with weight 0)
+    if (tid < RO_MAXK) { sel_v[tid] = -INFINITY; sel_i[tid] = cnt > 0 ? first : 0; sel_w[tid] = 0.f; }
     __syncthreads();
+    // exact rank of every candidate (descending value, ties -> lower slot); the lists are read 4 entries per ds_read_b128
     for (int t = tid; t < cnt; t += RO_THREADS) {
-        float v = cv[t]; int id = ci[t];
+        const float v = cv[t]; const int id = ci[t];
         int rank = 0;
-        for (int u = 0; u < cnt; ++u) {
-            float w = cv[u];
-            rank += (w > v) || (w == v && ci[u] < id);
+#pragma unroll 2
+        for (int u = 0; u < cnt4; u += 4) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(cv + u);
+            const ro_i32x4 d = *reinterpret_cast<const ro_i32x4*>(ci + u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rank += (w[e] > v) || (w[e] == v && d[e] < id);
         }
         if (rank < nsel) { sel_v[rank] = v; sel_i[rank] = id; }
     }
@@ -285,20 +399,35 @@ __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __
         }
     }
     __syncthreads();
-    const int C8 = CV >> 3;
+    // sparse V gather: 16 independent 16-B row loads in flight per thread (the gather is latency-bound: ~46 KB of 512-B
+    // rows per query from banks that do not fit one XCD's L2); padding entries carry weight 0 and a valid slot
+    const int nround = (nsel + 15) >> 4;
     for (int u = tid; u < K * C8; u += RO_THREADS) {
         int o = u / C8, c8 = u - o * C8;
-        const bf16_t* V = reinterpret_cast<const bf16_t*>(vptrs[o]);
+        const bf16_t* V = (u == tid ? Vbase : reinterpret_cast<const bf16_t*>(vptrs[o])) + c8 * 8;
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 6
-        for (int t = 0; t < nsel; ++t) {
-            uint4 v = *reinterpret_cast<const uint4*>(V + (long)sel_i[t] * CV + c8 * 8);
-            const uint32_t* vu = &v.x;
-            float w = sel_w[t];
+        for (int r = 0; r < nround; ++r) {
+            ro_u32x4 v[16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[2 * i] += w * __uint_as_float(vu[i] << 16);
-                acc[2 * i + 1] += w * __uint_as_float(vu[i] & 0xffff0000u);
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const ro_i32x4 si = *reinterpret_cast<const ro_i32x4*>(sel_i + r * 16 + t4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[t4 * 4 + e] = *reinterpret_cast<const ro_u32x4*>(V + (long)si[e] * CV);
+            }
+            float wv[16];
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(sel_w + r * 16 + t4 * 4);
+                wv[t4 * 4] = w4[0]; wv[t4 * 4 + 1] = w4[1]; wv[t4 * 4 + 2] = w4[2]; wv[t4 * 4 + 3] = w4[3];
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float w = wv[t];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[2 * i] += w * __uint_as_float(v[t][i] << 16);
+                    acc[2 * i + 1] += w * __uint_as_float(v[t][i] & 0xffff0000u);
+                }
             }
         }
         *reinterpret_cast<uint4*>(y + ((long)o * HW + j) * CV + c8 * 8) =
@@ -326,23 +455,35 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             sp.G = i[9]; sp.cap = i[10]; sp.mode = i[11]; sp.Gld = (sp.G + 63) / 64 * 64;
             int G = 0;
             for (int r = 0; r < 3; ++r) G += (sp.rn[r] + 15) / 16;
-            if (G != sp.G || (sp.HWp & 63) || sp.nranges < 1 || sp.nranges > 3) { cutie_set_error("aff_score: bad ranges (G=%d vs %d, HWp=%d)", G, sp.G, sp.HWp); return -2; }
-            int qb = sp.HWp / 64;
-            // enough blocks to fill 256 CUs a few times over, at least 8 tiles per block
-            int tpb = (int)(((long)G * qb + 1023) / 1024);
+            if (G != sp.G || (sp.HWp & 63) || sp.nranges < 1 || sp.nranges > 3 || (sp.Gld & 3)) { cutie_set_error("aff_score: bad ranges (G=%d vs %d, HWp=%d)", G, sp.G, sp.HWp); return -2; }
+            const int nq = i[12] == 1 ? 1 : 2;
+            int qb = (sp.HWp + 64 * nq - 1) / (64 * nq);
+            static bool lds_attr_set = false;
+            if (!lds_attr_set) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(aff_score_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, AFF_LDS_BYTES) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(aff_score_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, AFF_LDS_BYTES) != hipSuccess) {
+                    cutie_set_error("aff_score: cannot raise the dynamic LDS limit to %d bytes", AFF_LDS_BYTES);
+                    return -2;
+                }
+                lds_attr_set = true;
+            }
+            // ~2 resident blocks per CU (512 blocks), at least 8 tiles per block: the block prologue (its query operand,
+            // 64 KB through LDS) is amortised over the tiles, measured best around 16 tiles at 11k tokens x 1620 queries
+            int tpb = (int)(((long)G * qb + 511) / 512);
             if (tpb < 8) tpb = 8;
             tpb = (tpb + AFF_TG - 1) / AFF_TG * AFF_TG;
             sp.tiles_per_block = tpb;
-            hipLaunchKernelGGL(aff_score_kernel, dim3(qb, (G + tpb - 1) / tpb), dim3(256), 0, s, sp);
+            if (nq == 1) hipLaunchKernelGGL(aff_score_kernel<1>, dim3(qb, (G + tpb - 1) / tpb), dim3(256), AFF_LDS_BYTES, s, sp);
+            else hipLaunchKernelGGL(aff_score_kernel<2>, dim3(qb, (G + tpb - 1) / tpb), dim3(256), AFF_LDS_BYTES, s, sp);
             break;
         }
         case CUTIE_OP_AFF_SELECT:
             hipLaunchKernelGGL(aff_select_kernel, dim3((i[0] + 3) / 4), dim3(256), 0, s, (const float*)p[0], (float*)p[1], i[0], (i[2] + 63) / 64 * 64, i[2], i[3]);
             break;
         case CUTIE_OP_AFF_READOUT: {
-            if (i[2] > RO_MAXK || (i[4] & 7)) { cutie_set_error("aff_readout: top_k <= %d, CV %% 8", RO_MAXK); return -2; }
+            if (i[2] > RO_MAXK || (i[4] & 7) || (i[1] & 3)) { cutie_set_error("aff_readout: top_k <= %d, CV %% 8, cap %% 4", RO_MAXK); return -2; }
             size_t lds = (size_t)i[1] * 8;
-            hipLaunchKernelGGL(aff_readout_kernel, dim3(i[0]), dim3(RO_THREADS), lds, s, (const float*)p[0], (const int*)p[1], (const int*)p[2],
+            hipLaunchKernelGGL(aff_readout_kernel, dim3(((i[0] + 7) / 8) * 8), dim3(RO_THREADS), lds, s, (const float*)p[0], (const int*)p[1], (const int*)p[2],
                                (const uint64_t*)p[3], (float*)p[4], (bf16_t*)p[5], (int*)p[6], i[0], i[1], i[2], i[3], i[4]);
             break;
         }

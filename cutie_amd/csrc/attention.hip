@@ -112,8 +112,7 @@ __global__ __launch_bounds__(1024) void attn_q2p_kernel(const float* __restrict_
             sv[j] = ok ? s[j >> 2][j & 3] : -INFINITY;
             tm = fmaxf(tm, sv[j]);
         }
-        tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
-        tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+        tm = rows_max(tm);
         const float mn = fmaxf(m, tm);
         const float mref = (mn == -INFINITY) ? 0.f : mn;
         const float alpha = __expf(m - mref);
@@ -132,8 +131,7 @@ __global__ __launch_bounds__(1024) void attn_q2p_kernel(const float* __restrict_
         o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va1.b, ph.b, o1, 0, 0, 0);
         o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va1.b, pl.b, o1, 0, 0, 0);
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = rows_sum(l);
     if (g == 0) { sM[wave][c16] = m; sL[wave][c16] = l; }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { sO[wave][c16][4 * g + r] = o0[r]; sO[wave][c16][16 + 4 * g + r] = o1[r]; }

@@ -30,6 +30,23 @@ __device__ __forceinline__ uint32_t relu_bf2(uint32_t w) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// max / sum over the 4 lanes {l, l^16, l^32, l^48} (the 4 row groups of an MFMA accumulator column) without touching
+// LDS: v_permlane16_swap / v_permlane32_swap (gfx950) instead of ds_bpermute shuffles.
+__device__ __forceinline__ float rows_max(float v) {
+    unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    unsigned a = __float_as_uint(fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])));
+    auto r2 = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    return fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+}
+__device__ __forceinline__ float rows_sum(float v) {
+    unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    unsigned a = __float_as_uint(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+    auto r2 = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -142,11 +142,11 @@ class MemoryManager:
             tau = self._buf('tau', (HW,), F32, dev)
             cval = self._buf('cand_val', (HW, CAND_CAP), F32, dev)
             cidx = self._buf('cand_idx', (HW, CAND_CAP), torch.int32, dev)
-            count = self._buf('count', (HW,), torch.int32, dev)
+            count = self._buf('count', (HW * O.OpList.AFF_CSTRIDE,), torch.int32, dev)
             ovf = self._buf('overflow', (1,), torch.int32, dev)
             readout = torch.empty((K, h, w, self.CV), dtype=BF16, device=dev)
             ol = O.OpList()
-            ol.memset32(count, HW, 0)
+            ol.memset32(count, HW * O.OpList.AFF_CSTRIDE, 0)
             common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=CAND_CAP)
             ol.aff_score(bucket.Ahi, bucket.Alo, bucket.scale, q['Bhi'], q['Blo'], q['cq'], gmax, None, None, None, mode=0, **common)
             ol.aff_select(gmax, tau, HW=HW, HWp=HWp, G=G, top_k=self.top_k)

@@ -278,6 +278,8 @@ class OpList:
     def key_prep(self, key, aux, hi, lo, sc, *, n, query):
         return self.add(KEY_PREP, 1 if query else 0, [n], [], [key, aux, hi, lo, sc])
 
+    AFF_CSTRIDE = 32          # ints between the candidate counters of consecutive queries (one cache line each)
+
     def aff_score(self, Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count, *, HW, HWp, ranges, cap, mode):
         ranges = [(s, n) for (s, n) in ranges if n > 0]
         assert 1 <= len(ranges) <= 3

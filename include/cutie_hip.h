@@ -155,7 +155,7 @@ enum {
     CUTIE_OP_KEY_PREP = 23,
     /* AFF_SCORE: S = scale_i*(A_i.B_j - c_j) tiles on MFMA (3-term split bf16, fp32-class accuracy)
      * mode 0: per-(16-token tile, query) maxima -> gmax f32 [HWp, Gld] (query-major, Gld = G rounded up to 64)
-     * mode 1: append (S,token) with S >= tau_j to cand lists (f32,i32) [HW,cap], count i32 [HW]
+     * mode 1: append (S,token) with S >= tau_j to cand lists (f32,i32) [HW,cap], count i32 [HW*32] (counter of query j at [32*j]: one 128-B line each)
      * memory_utils.py:7-46 get_similarity + the candidate pre-filter of top-k (:58)
      * p0=A_hi p1=A_lo p2=scale (bank base pointers, rows = physical token slots) p3=B_hi p4=B_lo p5=c
      * p6=gmax | tau f32 [HW]  p7=cand_val p8=cand_idx p9=count

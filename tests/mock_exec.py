@@ -405,7 +405,7 @@ class MockExecutor:
             thr = torch.where(torch.isinf(tau), torch.full_like(tau, float('-inf')), thr)
             cv = view(p[7], F32, (HW, cap))
             ci = view(p[8], I32, (HW, cap))
-            cnt = view(p[9], I32, (HW,))
+            cnt = view(p[9], I32, (HW, 32))[:, 0]
             for (slots, S) in sc:
                 for j in range(HW):
                     sel = torch.nonzero(S[:, j] >= thr[j]).flatten()
@@ -429,7 +429,7 @@ class MockExecutor:
         HW, cap, topk, K, CV = i[:5]
         cv = view(p[0], F32, (HW, cap))
         ci = view(p[1], I32, (HW, cap))
-        cnt = view(p[2], I32, (HW,))
+        cnt = view(p[2], I32, (HW, 32))[:, 0]
         vptrs = view(p[3], U64, (K,))
         usage = p[4]
         out = view(p[5], BF16, (K, HW, CV))

@@ -423,7 +423,7 @@ def _affinity_build(HW, ranges, slots, K, top_k, with_usage, dup=False):
         G = sum(-(-n // 16) for _, n in ranges if n > 0)
         Gld = -(-G // 64) * 64
         gmax, tau = z((HWp, Gld), F32), z((HW,), F32)
-        cval, cidx, count, ovf = z((HW, cap), F32), z((HW, cap), torch.int32), z((HW,), torch.int32), z((1,), torch.int32)
+        cval, cidx, count, ovf = z((HW, cap), F32), z((HW, cap), torch.int32), z((HW * 32,), torch.int32), z((1,), torch.int32)
         vals = [rnd(g, (slots + 16, CV), dev=dev) for _ in range(K)]
         vptrs = torch.tensor([v.data_ptr() for v in vals], dtype=torch.int64).to(dev)
         usage = z((slots + 16,), F32) if with_usage else None
@@ -432,7 +432,7 @@ def _affinity_build(HW, ranges, slots, K, top_k, with_usage, dup=False):
         ol.keep += vals
         ol.key_prep(mkey, mshr, Ahi, Alo, scale, n=slots, query=False)
         ol.key_prep(qkey, qsel, Bhi, Blo, cq, n=HW, query=True)
-        ol.memset32(count, HW, 0)
+        ol.memset32(count, HW * 32, 0)
         common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=cap)
         ol.aff_score(Ahi, Alo, scale, Bhi, Blo, cq, gmax, None, None, None, mode=0, **common)
         ol.aff_select(gmax, tau, HW=HW, HWp=HWp, G=G, top_k=top_k)

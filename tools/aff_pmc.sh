@@ -1,0 +1,26 @@
+# PMC passes over tools/aff_pmc.py (rocprofv3 counter collection + kernel trace only); prints the LAST aff_score dispatch
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export OMP_NUM_THREADS=16
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES" "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_INSTS_BRANCH SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT" "SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE"; do
+  i=$((i+1))
+  timeout 280 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/affpmc$i -- python tools/aff_pmc.py "$@" > gpurun_out/affpmc$i.log 2>&1
+done
+python - <<'PY'
+import csv, glob, collections, os
+for d in sorted(glob.glob('gpurun_out/affpmc*/')):
+    cc = glob.glob(d + '**/*counter_collection.csv', recursive=True)
+    kt = glob.glob(d + '**/*kernel_trace.csv', recursive=True)
+    if not cc: continue
+    rows = [r for r in csv.DictReader(open(cc[0])) if os.environ.get('AFF_PMC_KERNEL', 'aff_score') in r['Kernel_Name']]
+    last = max(int(r['Dispatch_Id']) for r in rows)
+    vals = {r['Counter_Name']: float(r['Counter_Value']) for r in rows if int(r['Dispatch_Id']) == last}
+    dur = None
+    if kt:
+        k = [r for r in csv.DictReader(open(kt[0])) if os.environ.get('AFF_PMC_KERNEL', 'aff_score') in r['Kernel_Name']]
+        k.sort(key=lambda r: int(r['Dispatch_Id']))
+        dur = (int(k[-1]['End_Timestamp']) - int(k[-1]['Start_Timestamp'])) / 1e3
+        g = (k[-1]['Grid_Size_X'], k[-1]['Grid_Size_Y'], k[-1]['LDS_Block_Size'], k[-1]['VGPR_Count'], k[-1].get('Accum_VGPR_Count'))
+    print('last dispatch', last, 'dur_us', dur, g, vals)
+PY
+rm -rf gpurun_out/affpmc*
