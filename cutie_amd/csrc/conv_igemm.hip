@@ -85,25 +85,32 @@ __device__ __forceinline__ void conv_finish(const ConvParams& p, float* v, int m
 
 // OCC: waves per SIMD the register allocator must leave room for (pinned per tile: hipcc's occupancy heuristic is
 // otherwise chaotic w.r.t. small source changes, e.g. 156 -> 208 VGPRs on the 32x64x128 tile = 3 -> 2 resident blocks).
-template <int BM, int BN, int WM, int WN, int BK, int S, int OCC>
-__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) {
-    constexpr int NT = WM * WN * 64;                    // 4 or 8 waves
+// WK: K groups per block.  WK > 1 = intra-block split-K: the block holds WK independent copies of the whole 4-wave (or
+// 8-wave) pipeline, each with its own LDS buffers and accumulators, each streaming 1/WK of the K tiles of the SAME output
+// tile; the accumulators are summed through LDS before the epilogue.  The L2->CU fill rate of this chip scales with the
+// number of waves that have loads in flight (~11 GB/s per wave, tools/membench.hip), and the small-M layers of this model
+// cannot put more than ~1 block on a CU; splitting the OUTPUT tile over more waves (the 8-wave tiles) leaves the bytes in
+// flight per block unchanged, splitting K doubles them.
+template <int BM, int BN, int WM, int WN, int BK, int S, int OCC, int WK>
+__global__ __launch_bounds__(WM * WN * WK * 64) void conv_igemm_kernel(ConvParams p) {
+    constexpr int NTB = WM * WN * WK * 64;              // threads per block
+    constexpr int NT = WM * WN * 64;                    // threads per K group: 4 or 8 waves
     constexpr int CPR = BK / 8;                         // 16-B chunks per LDS row
-    constexpr int RPT = NT / CPR;                       // rows covered by one pass of the NT threads
+    constexpr int RPT = NT / CPR;                       // rows covered by one pass of the group's threads
     constexpr int NX = (BM * CPR) / NT;                 // X chunks per thread per tile
     constexpr int NWC = (BN * CPR + NT - 1) / NT;       // W chunks per thread per tile
     constexpr int TM = BM / WM / 16;                    // 16-pixel MFMA tiles per wave
     constexpr int TN = BN / WN / 16;                    // 16-channel MFMA tiles per wave
     constexpr int KSUB = BK / 32;                       // MFMA k-steps per tile
     constexpr int NWRAP = BK == 32 ? 4 : BK / 32;       // tap wraps per tile advance (BK > 32 requires Cin >= 32)
-    static_assert((NT == 256 || NT == 512) && NX >= 1 && TM >= 1 && TN >= 1 && S >= 2 && (BM * CPR) % NT == 0, "bad tile");
+    static_assert((NT == 256 || NT == 512) && NTB <= 1024 && NX >= 1 && TM >= 1 && TN >= 1 && S >= 2 && (BM * CPR) % NT == 0, "bad tile");
     constexpr int LDC = BN + 4;                         // fp32 row stride of the epilogue tile (pad: bank spread)
-    constexpr int PIPE_CHUNKS = 2 * (BM + BN) * CPR;    // 16-B chunks of the double-buffered operand tiles
-    constexpr int EPI_CHUNKS = (BM * LDC * 4 + 15) / 16;
-    __shared__ u32x4 smem_raw[PIPE_CHUNKS > EPI_CHUNKS ? PIPE_CHUNKS : EPI_CHUNKS];
-    u32x4 (*smem)[(BM + BN) * CPR] = reinterpret_cast<u32x4 (*)[(BM + BN) * CPR]>(smem_raw);
+    constexpr int GRP_CHUNKS = 2 * (BM + BN) * CPR;     // 16-B chunks of one group's double-buffered operand tiles
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem_raw[];    // max(WK * GRP_CHUNKS, epilogue tile): conv_lds_bytes()
+    const int grp = threadIdx.x / NT;                   // K group of this wave (wave-uniform)
+    u32x4 (*smem)[(BM + BN) * CPR] = reinterpret_cast<u32x4 (*)[(BM + BN) * CPR]>(smem_raw + grp * GRP_CHUNKS);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x % NT, lane = tid & 63, wave = tid >> 6;   // position inside the K group
     // XCD-aware tile mapping: hardware block b runs on XCD b % 8 (8 private L2s).  Give every XCD a contiguous run of
     // logical tiles (channel tile fastest) so the blocks sharing an activation row-band hit the same L2 instead of each
     // XCD pulling its own copy through the fabric (rocprof FETCH_SIZE was ~8x the unique bytes without it).  Bijective
@@ -140,8 +147,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) 
     // split-K: grid.z slices the K tiles; this block owns tiles [kbeg, kbeg + nk)
     // (nk is deliberately written as <kernel argument> / BK, like the unsplit kernel's Kpad / BK: hipcc's register
     // allocation for this kernel is chaotic in the form of this expression -- any other spelling costs 40-50 VGPRs)
-    const int nk = p.Kslice / BK;
-    const int kbeg = (int)blockIdx.z * nk;
+    const int nk = p.Kslice / (BK * WK);
+    const int kbeg = ((int)blockIdx.z * WK + grp) * nk;
     const bf16_t* wp[NWC];                               // this thread's weight chunks of the next tile to load
 #pragma unroll
     for (int i = 0; i < NWC; ++i) {
@@ -266,16 +273,23 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) 
     // walk [pixel][8-channel chunk], i.e. full 128/256-B lines per pixel for the residual loads and the stores. ----
     float* ctile = reinterpret_cast<float*>(smem_raw);   // the K loop ended with a barrier: operand tiles are dead
 #pragma unroll
-    for (int b = 0; b < TM; ++b)
+    for (int g = WK - 1; g >= 0; --g) {                  // K groups add their accumulators in a fixed order
+        if (grp == g) {
 #pragma unroll
-        for (int a = 0; a < TN; ++a) {
-            const int px = pm0 + b * 16 + l15, ch = cn0 + a * 16 + l4 * 4;
-            *reinterpret_cast<f32x4*>(ctile + px * LDC + ch) = acc[a][b];
+            for (int b = 0; b < TM; ++b)
+#pragma unroll
+                for (int a = 0; a < TN; ++a) {
+                    const int px = pm0 + b * 16 + l15, ch = cn0 + a * 16 + l4 * 4;
+                    f32x4* dst = reinterpret_cast<f32x4*>(ctile + px * LDC + ch);
+                    if (g == WK - 1) *dst = acc[a][b];
+                    else { f32x4 t = *dst; t[0] += acc[a][b][0]; t[1] += acc[a][b][1]; t[2] += acc[a][b][2]; t[3] += acc[a][b][3]; *dst = t; }
+                }
         }
-    __syncthreads();
+        __syncthreads();
+    }
     constexpr int CH8 = BN / 8;                          // 8-channel chunks per tile row
     if (p.splitk == 1) {
-        for (int q = tid; q < BM * CH8; q += NT) {
+        for (int q = threadIdx.x; q < BM * CH8; q += NTB) {
             const int px = q / CH8, c8 = q - px * CH8;
             const int m = m0 + px, ch0 = n0 + c8 * 8;
             if (m >= p.M || ch0 >= p.Cout) continue;
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) 
     // slice order and runs the epilogue.  (A single-kernel "last arriver reduces" variant was measured first: the
     // device-scope release/acquire fences it needs write back / invalidate the XCD's L2 and cost 25-60 us per launch.)
     float* part = p.part + (long)blockIdx.z * p.M * p.ldp;
-    for (int q = tid; q < BM * CH8; q += NT) {
+    for (int q = threadIdx.x; q < BM * CH8; q += NTB) {
         const int px = q / CH8, c8 = q - px * CH8;
         const int m = m0 + px, ch0 = n0 + c8 * 8;
         if (m >= p.M || ch0 >= p.Cout) continue;
@@ -363,16 +377,32 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int S, int OCC>
+template <int BM, int BN, int BK, int WK>
+constexpr int conv_lds_bytes() {
+    constexpr int pipe = WK * 2 * (BM + BN) * (BK / 8) * 16, epi = BM * (BN + 4) * 4;
+    return pipe > epi ? pipe : epi;
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int S, int OCC, int WK = 1>
 static int launch_cfg(ConvParams p, hipStream_t s) {
     if (p.Kpad % BK) { cutie_set_error("conv: Kpad %d not a multiple of BK %d", p.Kpad, BK); return -2; }
     if (BK > 32 && p.Cin < 32) { cutie_set_error("conv: BK %d needs Cin >= 32 (Cin=%d)", BK, p.Cin); return -2; }
     const int nk_all = p.Kpad / BK;
     if (p.splitk > nk_all) { cutie_set_error("conv: splitk %d > K tiles %d", p.splitk, nk_all); return -2; }
-    if (nk_all % p.splitk) { cutie_set_error("conv: splitk %d must divide the %d K tiles", p.splitk, nk_all); return -2; }
+    if (nk_all % (p.splitk * WK)) { cutie_set_error("conv: splitk %d x %d K groups must divide the %d K tiles", p.splitk, WK, nk_all); return -2; }
     p.Kslice = p.Kpad / p.splitk;
+    constexpr int lds = conv_lds_bytes<BM, BN, BK, WK>();
+    static bool attr_set = false;                        // one flag per instantiation
+    if (!attr_set) {
+        if (lds > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, BK, S, OCC, WK>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            cutie_set_error("conv: cannot raise the dynamic LDS limit to %d bytes", lds);
+            return -2;
+        }
+        attr_set = true;
+    }
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.splitk);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, S, OCC>), grid, dim3(WM * WN * 64), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, S, OCC, WK>), grid, dim3(WM * WN * WK * 64), lds, s, p);
     if (p.splitk > 1) {
         const long nq = (long)p.M * (p.ldp >> 3);
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, p);
@@ -432,6 +462,18 @@ int launch_conv(const cutie_op* op, hipStream_t s) {
         case 16: return launch_cfg<128, 128, 2, 4, 64, 3, 3>(p, s);
         case 17: return launch_cfg<64, 64, 2, 4, 128, 3, 4>(p, s);
         case 18: return launch_cfg<128, 128, 2, 4, 32, 4, 4>(p, s);
+        // 20..: two (or four) K groups per block (intra-block split-K), 8 (16) waves
+        case 20: return launch_cfg<64, 64, 2, 2, 64, 4, 3, 2>(p, s);
+        case 21: return launch_cfg<64, 64, 2, 2, 128, 3, 2, 2>(p, s);
+        case 22: return launch_cfg<32, 64, 2, 2, 128, 3, 3, 2>(p, s);
+        case 23: return launch_cfg<128, 64, 2, 2, 64, 3, 2, 2>(p, s);
+        case 24: return launch_cfg<64, 128, 2, 2, 64, 3, 2, 2>(p, s);
+        case 25: return launch_cfg<128, 128, 2, 2, 64, 2, 2, 2>(p, s);
+        case 26: return launch_cfg<32, 64, 2, 2, 64, 4, 4, 2>(p, s);
+        case 27: return launch_cfg<64, 64, 2, 2, 64, 3, 3, 4>(p, s);
+        case 28: return launch_cfg<32, 64, 2, 2, 64, 4, 4, 4>(p, s);
+        case 29: return launch_cfg<64, 128, 2, 2, 32, 4, 3, 2>(p, s);
+        case 30: return launch_cfg<64, 64, 2, 2, 32, 4, 4, 2>(p, s);
         default: cutie_set_error("conv: bad tile id %d", i[17]); return -2;
     }
 }

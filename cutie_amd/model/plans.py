@@ -87,7 +87,7 @@ class Plan:
             if best is None:
                 one = arr[n:n + 1].copy()
                 best, best_t = (int(i[17]), 1), None
-                cands = O.tile_candidates(M, cout, cin)
+                cands = O.tile_candidates(M, cout, cin, int(i[16]))
                 if int(i[4]) or arr['p'][n, 4]:              # 2-source or residual conv: no cout1 kernel
                     cands = [t for t in cands if t != O.COUT1_TILE]
                 for t in cands:

@@ -34,7 +34,11 @@ ACT_SHIFT = 4
 TILES = {0: (128, 128, 32), 1: (128, 64, 32), 2: (64, 64, 32), 3: (256, 16, 32), 4: (64, 128, 32),
          5: (64, 64, 64), 6: (64, 128, 64), 7: (128, 128, 64), 8: (64, 64, 128), 9: (32, 64, 64),
          10: (128, 64, 64), 11: (32, 64, 128), 12: (32, 128, 64),
-         13: (64, 64, 64), 14: (128, 64, 64), 15: (64, 128, 64), 16: (128, 128, 64), 17: (64, 64, 128), 18: (128, 128, 32)}   # 13+: 8 waves
+         13: (64, 64, 64), 14: (128, 64, 64), 15: (64, 128, 64), 16: (128, 128, 64), 17: (64, 64, 128), 18: (128, 128, 32),   # 13+: 8 waves
+         # 20+: WK K groups per block (intra-block split-K: WK copies of the 4-wave pipeline on one output tile)
+         20: (64, 64, 64), 21: (64, 64, 128), 22: (32, 64, 128), 23: (128, 64, 64), 24: (64, 128, 64), 25: (128, 128, 64),
+         26: (32, 64, 64), 27: (64, 64, 64), 28: (32, 64, 64), 29: (64, 128, 32), 30: (64, 64, 32)}
+TILE_WK = {20: 2, 21: 2, 22: 2, 23: 2, 24: 2, 25: 2, 26: 2, 27: 4, 28: 4, 29: 2, 30: 2}     # K groups per block (default 1)
 NUM_CU = 256
 
 
@@ -46,13 +50,17 @@ def cout1_ok(cout, cin, c2=0, res=False):
     return cout == 1 and c2 == 0 and not res and cin % 8 == 0 and 1 <= lp <= 64 and (lp & (lp - 1)) == 0
 
 
-def tile_candidates(M, cout, cin):
-    """Tile ids that are legal for a conv (BK > 32 needs Cin >= 32; tiny Cout uses the 256x16 tile)."""
+def tile_candidates(M, cout, cin, kpad=None):
+    """Tile ids that are legal for a conv (BK > 32 needs Cin >= 32; tiny Cout uses the 256x16 tile; the K groups of a
+    WK tile must divide the K tiles)."""
     if cout <= 16:
         return [3] + ([COUT1_TILE] if cout1_ok(cout, cin) else [])
     out = []
     for t, (bm, bn, bk) in TILES.items():
         if t == 3 or (bk > 32 and cin < 32):
+            continue
+        wk = TILE_WK.get(t, 1)
+        if wk > 1 and (kpad is None or (kpad // bk) % wk or kpad // bk < 2 * wk):
             continue
         if bn == 128 and cout <= 64:
             continue
@@ -81,7 +89,7 @@ def splitk_candidates(M, cout, kpad, tile):
         return [1]
     bm, bn, bk = TILES[tile]
     blocks = -(-M // bm) * -(-cout // bn)
-    nk = kpad // bk
+    nk = kpad // bk // TILE_WK.get(tile, 1)
     ldp = (cout + 7) & ~7
     out = [1]
     for sk in (2, 3, 4, 6, 8, 9, 12, 16, 18):

@@ -102,26 +102,33 @@ def test_conv_auto_tile(ci):
     check(hip, ref, f'conv[{ci}]')
 
 
-@pytest.mark.parametrize('tile', list(range(19)))
+def _k_tiles(c, tile):
+    cin = c['C1'] + c.get('C2', 0)
+    return -(-(cin * c['k'] * c['k']) // 128) * 128 // O.TILES[tile][2]
+
+
+@pytest.mark.parametrize('tile', sorted(O.TILES))
 @pytest.mark.parametrize('ci', [0, 2, 4, 6, 7, 12, 14])
 def test_conv_every_tile(ci, tile):
     c = CONV_CASES[ci]
     if tile in O.TILES and O.TILES[tile][2] > 32 and c['C1'] + c.get('C2', 0) < 32:
         pytest.skip('BK > 32 needs Cin >= 32')
+    if _k_tiles(c, tile) % O.TILE_WK.get(tile, 1):
+        pytest.skip('the K groups of this tile do not divide the K tiles')
     hip, ref = run_both(_conv_build(c, tile), seed=100 + ci)
     check(hip, ref, f'conv[{ci}] tile{tile}')
 
 
 @pytest.mark.parametrize('splitk', [2, 3, 4, 9])
-@pytest.mark.parametrize('tile', [0, 5, 7, 8, 11, 13, 16])
+@pytest.mark.parametrize('tile', [0, 5, 7, 8, 11, 13, 16, 20, 22])
 @pytest.mark.parametrize('ci', [0, 2, 4, 5, 6, 7, 12, 14])
 def test_conv_split_k(ci, tile, splitk):
     """grid.z K slices + reduce launch: same result as the single-pass kernel for every epilogue variant
     (residual / broadcast residual / 2-source / f32 out / ragged M and Cout / stride 2)."""
     c = CONV_CASES[ci]
     cin = c['C1'] + c.get('C2', 0)
-    nk = -(-(cin * c['k'] * c['k']) // 128) * 128 // O.TILES[tile][2]
-    if splitk > nk or nk % splitk:
+    nk = _k_tiles(c, tile) // O.TILE_WK.get(tile, 1)
+    if _k_tiles(c, tile) % O.TILE_WK.get(tile, 1) or splitk > nk or nk % splitk:
         pytest.skip('the slice count must divide the K tiles')
     if splitk * c['B'] * c['H'] * c['W'] * ((c['Cout'] + 7) & ~7) > O.SPLITK_PART_FLOATS:
         pytest.skip('partials exceed the scratch')

@@ -62,7 +62,7 @@ def main():
         cum = 0.0
         for r in sorted(rows, key=lambda r: -r[0]):
             cum += r[0]
-            print(f'{r[0]:7.1f} {r[1]:6d} {r[2]:5d} {r[3]:5d} {r[4]} {r[5]} {str(O.TILES.get(r[6], "c1")):>15s} {r[8]:2d} {r[7]:8.1f} {cum / tot * 100:6.1f}')
+            print(f'{r[0]:7.1f} {r[1]:6d} {r[2]:5d} {r[3]:5d} {r[4]} {r[5]} {str(O.TILES.get(r[6], "c1")) + ("x%d" % O.TILE_WK[r[6]] if r[6] in O.TILE_WK else ""):>17s} {r[8]:2d} {r[7]:8.1f} {cum / tot * 100:6.1f}')
 
 
 if __name__ == '__main__':

@@ -19,10 +19,10 @@ def main():
     x = torch.randn(B, H, W, Cin).to(torch.bfloat16).to(dev)
     y = torch.zeros(B, H, W, Cout, dtype=torch.bfloat16, device=dev)
     fl = 2.0 * B * H * W * Cout * Cin * k * k
-    for t in O.tile_candidates(B * H * W, Cout, Cin):
+    for t in O.tile_candidates(B * H * W, Cout, Cin, pc.kpad):
         row = []
-        for sk in (1, 2, 3, 4, 6, 9, 12, 18):
-            nk = pc.kpad // O.TILES[t][2] if t in O.TILES else 0
+        for sk in (1, 2, 3):
+            nk = pc.kpad // O.TILES[t][2] // O.TILE_WK.get(t, 1) if t in O.TILES else 0
             if t not in O.TILES or nk % sk or nk // sk < 1 or sk * B * H * W * Cout > O.SPLITK_PART_FLOATS:
                 continue
             ol = O.OpList()
@@ -30,7 +30,7 @@ def main():
             arr = ol.finalize()
             us = min(ex.time_ops(arr, 10) for _ in range(3)) * 1e3
             row.append(f'sk{sk}:{us:6.1f}us({fl / us / 1e6:5.0f}TF)')
-        print(t, O.TILES.get(t), ' '.join(row))
+        print(t, O.TILES.get(t), 'wk%d' % O.TILE_WK.get(t, 1), ' '.join(row))
 
 
 if __name__ == '__main__':
