@@ -52,7 +52,67 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--clips-in-flight', type=int, default=4,
+                    help='also measure the aggregate frames/s with this many independent clips in flight per GPU '
+                         '(one host thread + HIP stream + CUTIE.fork() each; reported as "multi_clip"; 0 = skip)')
     return ap.parse_args()
+
+
+def multi_clip_throughput(net, cfg, args, K, rank, dist, dev):
+    """Same workload, C independent clips in flight on this GPU (cutie_amd/parallel.py:run_concurrent's scheme with a
+    common start line): returns the seconds the slowest clip needed for args.steps frames after the pre-roll."""
+    import threading
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.utils.synth import SyntheticClip
+    C, NF = args.clips_in_flight, 48
+    data = []
+    for c in range(C):
+        clip = SyntheticClip(args.height, args.width, K, NF, seed=101 + 16 * rank + c)
+        data.append((torch.stack([clip.frame(t) for t in range(NF)]).to(dev), clip.first_mask().to(dev), clip.objects))
+    views = [net] + [net.fork() for _ in range(C - 1)]
+    start, done = threading.Barrier(C + 1), threading.Barrier(C + 1)
+    finish, errors = [0.0] * C, []
+
+    def work(i):
+        frames, mask, objs = data[i]
+        stream = torch.cuda.Stream(device=dev)
+        try:
+            with torch.inference_mode(), torch.cuda.stream(stream):
+                proc = InferenceCore(views[i], cfg=cfg)
+                proc.step(frames[0], mask, objects=objs)
+                for t in range(1, 1 + args.preroll + args.warmup):
+                    proc.step(frames[t % NF])
+                stream.synchronize()
+                start.wait()
+                for t in range(args.steps):
+                    proc.step(frames[(7 + t) % NF])
+                stream.synchronize()
+                finish[i] = time.perf_counter()
+        except BaseException as e:
+            errors.append(e)
+            start.abort()
+        finally:
+            try:
+                done.wait()
+            except threading.BrokenBarrierError:
+                pass
+
+    threads = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(C)]
+    for t in threads:
+        t.start()
+    try:
+        start.wait()
+    except threading.BrokenBarrierError:
+        raise errors[0]
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    done.wait()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return max(finish) - t0
 
 
 class Recorder:
@@ -237,6 +297,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     tmax = float(t.item())
 
+    multi = None
+    if args.clips_in_flight > 1:
+        mt = torch.tensor([multi_clip_throughput(net, cfg, args, K, rank, dist, dev)], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(mt, op=dist.ReduceOp.MAX)
+        mt = float(mt.item())
+        multi = {'clips_in_flight_per_gpu': args.clips_in_flight, 'value': round(world * args.clips_in_flight * args.steps / mt, 2),
+                 'unit': 'frames/s', 'ms_per_step': round(mt / args.steps * 1e3, 4),
+                 'note': 'same workload, independent clips interleaved on one GPU (one host thread + HIP stream + CUTIE.fork() per '
+                         'clip, cutie_amd/parallel.py); "value" above stays one clip per GPU'}
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0 and sd is not None:
         from oracle.inference import OracleProcessor, DEFAULT_CFG
@@ -280,6 +351,8 @@ def main():
             out['roofline_affinity'] = roof_aff
             out['device_us_by_kind'] = breakdown
             out['frame_as_one_hip_graph_ms'] = None if graph_ms is None else round(graph_ms, 3)
+        if multi is not None:
+            out['multi_clip'] = multi
         if cpu is not None:
             out['cpu_baseline'] = cpu
             out['speedup_vs_cpu'] = round(fps / cpu['value'], 1)

@@ -162,6 +162,15 @@ class Engine:
             self._rep[key] = e.repeat(K, 1).to(self.device).contiguous()
         return self._rep[key]
 
+    def fork(self):
+        """A second engine over the SAME packed weights and autotune cache with its own plans (= its own activation
+        buffers): what a second clip processed concurrently on another stream needs."""
+        e = object.__new__(Engine)
+        e.__dict__.update(self.__dict__)
+        e._plans = {}
+        e.__dict__.pop('_splitk_part', None)
+        return e
+
     def plan(self, key, builder, *args):
         p = self._plans.get(key)
         if p is None:
@@ -271,6 +280,16 @@ class CUTIE(nn.Module):
     @property
     def device(self) -> torch.device:
         return self.pixel_mean.device
+
+    def fork(self) -> 'CUTIE':
+        """A view of this network for a second concurrent clip (own HIP stream / host thread): shares the parameters, the
+        packed device weights and the autotuned tile choices, owns its launch plans and activation buffers.
+        (No counterpart in the reference, where torch allocates activations per call.)"""
+        import copy
+        f = copy.copy(self)                      # nn.Module shallow copy: the parameter / buffer dicts are shared
+        f._eng = self.engine().fork()
+        f._key_cache = None
+        return f
 
     def engine(self) -> Engine:
         if self._eng is None:

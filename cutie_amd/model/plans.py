@@ -45,7 +45,7 @@ class Plan:
     def __init__(self, eng):
         self.eng = eng
         self.dev = eng.device
-        self.ol = O.OpList()
+        self.ol = O.OpList(scratch_owner=eng)
         self.bufs = {}
         self.meta = {}
         self.tuned = False

@@ -74,13 +74,17 @@ SPLITK_PART_FLOATS = 16 << 20           # 64 MiB of fp32 partial tiles
 _splitk_scratch = {}
 
 
-def splitk_scratch(device):
-    """fp32 partial-tile scratch shared by every split-K conv of a device (launches are stream-ordered)."""
-    key = str(device)
-    if key not in _splitk_scratch:
-        n = SPLITK_PART_FLOATS if torch.device(device).type == 'cuda' else 1024
-        _splitk_scratch[key] = torch.zeros(n, dtype=torch.float32, device=device)
-    return _splitk_scratch[key]
+def splitk_scratch(device, owner=None):
+    """fp32 partial-tile scratch of split-K convs.  One buffer per owner (an Engine: the launches of one engine are
+    stream-ordered, engines forked for concurrent clips must not share partials; it lives and dies with the owner);
+    owner None = one per device."""
+    dev = torch.device(device)
+    store = _splitk_scratch if owner is None else owner.__dict__.setdefault('_splitk_part', {})
+    key = str(dev)
+    if key not in store:
+        n = SPLITK_PART_FLOATS if dev.type == 'cuda' else 1024
+        store[key] = torch.zeros(n, dtype=torch.float32, device=device)
+    return store[key]
 
 
 def splitk_candidates(M, cout, kpad, tile):
@@ -138,7 +142,8 @@ def _ptr(t):
 
 
 class OpList:
-    def __init__(self):
+    def __init__(self, scratch_owner=None):
+        self.scratch_owner = scratch_owner   # see splitk_scratch
         self.recs = []          # (kind, flags, ints, floats, ptrs)
         self.keep = []          # tensors kept alive
         self.dyn = {}           # name -> [(op index, slot, offset)]
@@ -200,7 +205,7 @@ class OpList:
         M = B * OH * OW
         if tile is None:
             tile = COUT1_TILE if cout1_ok(w.cout, C1 + C2, C2, res is not None) else pick_tile(M, w.cout, C1 + C2)
-        part = splitk_scratch(w.weight.device)
+        part = splitk_scratch(w.weight.device, self.scratch_owner)
         return self.add(CONV, flags,
                         [B, H, W, C1, C2, ldx1, ldx2, OH, OW, w.cout, ldy, w.kh, w.kw, stride, pad, ldr, w.kpad, tile, w.cin_real,
                          splitk, part.numel() // 1024],

@@ -4,7 +4,14 @@ The per-frame state of a clip is a strict recurrence in time, so a clip never sp
 distributed round-robin, one process per GPU (``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm,
 "gloo" in the CPU tests).  There is no collective on the per-frame path: the only communication is the final
 gather of per-clip results to rank 0 -- a direct (non-ring) gather, since the payload is small and latency-bound.
+
+Inside one GPU, several clips can be *in flight* at once (``run_concurrent``): one host thread + HIP stream +
+``CUTIE.fork()`` per clip.  A single clip is a chain of ~200 dependent small launches per frame and leaves most of the 256
+CUs idle most of the time (kernel-boundary bubbles, layers with < 256 workgroups); four independent chains interleave on
+the hardware queues and nearly double the frames/s of the GPU.
 """
+import queue
+import threading
 from typing import Callable, Dict, List, Sequence
 
 import torch
@@ -14,6 +21,61 @@ import torch.distributed as dist
 def shard_clips(num_clips: int, rank: int, world_size: int) -> List[int]:
     """Clip c runs on rank c mod world_size (the reference creates one InferenceCore per video, eval_vos.py:97)."""
     return [c for c in range(num_clips) if c % world_size == rank]
+
+
+def run_concurrent(net, clip_ids: Sequence[int], run_clip: Callable, *, streams: int = 4) -> Dict[int, Dict]:
+    """Run ``run_clip(net_view, clip_id) -> result`` for every clip with up to ``streams`` clips in flight on the GPU of
+    ``net``.  Every worker owns a host thread, a HIP stream and a ``net.fork()`` (shared weights, private launch plans and
+    activation buffers); clips are pulled from a common queue.  The first clip runs alone when the conv tiles are not
+    tuned yet, so the autotuner times kernels on a quiet device.  Results are bit-identical to running the clips one
+    after another (every kernel is deterministic and no state is shared between views)."""
+    clip_ids = list(clip_ids)
+    results: Dict[int, Dict] = {}
+    if not clip_ids:
+        return results
+    on_gpu = net.device.type == 'cuda'
+    n = max(1, min(streams, len(clip_ids)))
+    errors: List[BaseException] = []
+    jobs: 'queue.Queue' = queue.Queue()
+    for c in clip_ids:
+        jobs.put(c)
+    tuned = threading.Event()
+    if net.engine().tile_cache or not on_gpu:
+        tuned.set()
+
+    def work(view, first):
+        stream = torch.cuda.Stream(device=net.device) if on_gpu else None
+        try:
+            with torch.inference_mode():
+                while True:
+                    if not first:
+                        tuned.wait()
+                    try:
+                        c = jobs.get_nowait()
+                    except queue.Empty:
+                        return
+                    if stream is not None:
+                        with torch.cuda.stream(stream):
+                            r = run_clip(view, c)
+                        stream.synchronize()
+                    else:
+                        r = run_clip(view, c)
+                    results[c] = r
+                    tuned.set()
+                    first = False
+        except BaseException as e:          # surfaced in the caller's thread
+            errors.append(e)
+            tuned.set()
+
+    views = [net] + [net.fork() for _ in range(n - 1)]
+    threads = [threading.Thread(target=work, args=(views[i], i == 0), daemon=True) for i in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return results
 
 
 def run_sharded(clip_ids: Sequence[int], run_clip: Callable[[int], Dict], *, gather_masks: bool = False):

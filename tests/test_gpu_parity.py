@@ -160,6 +160,29 @@ def test_480p_properties(gpu_net):
         assert torch.equal(outs[0], outs[1])
 
 
+def test_concurrent_clips_match_sequential(gpu_net):
+    """parallel.run_concurrent: 4 clips in flight on one GPU (host thread + HIP stream + CUTIE.fork() each) produce
+    bit-identical probabilities to the same clips run one after another."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.parallel import run_concurrent
+    from cutie_amd.utils.synth import SyntheticClip
+
+    def run_clip(net, c):
+        clip = SyntheticClip(240, 432, 3, 12, seed=40 + c)
+        proc = InferenceCore(net, cfg=default_config(mem_every=3))
+        outs = [proc.step(clip.frame(0).cuda(), clip.first_mask().cuda(), objects=clip.objects)]
+        for t in range(1, 12):
+            outs.append(proc.step(clip.frame(t).cuda()))
+        return torch.stack(outs).cpu()
+
+    with torch.inference_mode():
+        seq = {c: run_clip(gpu_net, c) for c in range(5)}
+    conc = run_concurrent(gpu_net, list(range(5)), run_clip, streams=4)
+    for c in range(5):
+        assert torch.isfinite(conc[c]).all()
+        assert torch.equal(conc[c], seq[c]), (c, float((conc[c] - seq[c]).abs().max()))
+
+
 def test_product_requires_hip_library():
     """No CPU fallback: a CPU-resident module must refuse to run."""
     from cutie_amd.model.cutie import CUTIE

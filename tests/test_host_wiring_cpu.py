@@ -128,3 +128,29 @@ def test_trajectory_matches_oracle(name, product_net, oracle_net):
         confident = (top2[0] - top2[1]) > 0.12
         assert bool((p.argmax(0) == o.argmax(0))[confident].all()), (name, t)
     print(name, 'worst prob err', worst)
+
+
+def _run_clip_small(net, seed, frames=4):
+    """A short 3-object clip through InferenceCore; returns the stacked probabilities."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.utils.synth import SyntheticClip
+    clip = SyntheticClip(64, 96, 2, frames, seed=seed)
+    proc = InferenceCore(net, cfg=default_config(mem_every=2))
+    out = [proc.step(clip.frame(0), clip.first_mask(), objects=clip.objects)]
+    for t in range(1, frames):
+        out.append(proc.step(clip.frame(t)))
+    return torch.stack([o.float().cpu() for o in out])
+
+
+def test_fork_and_concurrent_clips_match_sequential(product_net):
+    """CUTIE.fork() views (shared weights, private plans) and parallel.run_concurrent (one host thread per clip) give
+    exactly the sequential results."""
+    from cutie_amd.parallel import run_concurrent
+    with torch.inference_mode():
+        seq = {c: _run_clip_small(product_net, 20 + c) for c in range(3)}
+        fork = product_net.fork()
+        assert fork.engine() is not product_net.engine() and fork.engine().w is product_net.engine().w
+        assert torch.equal(_run_clip_small(fork, 21), seq[1])
+    conc = run_concurrent(product_net, [0, 1, 2], lambda view, c: _run_clip_small(view, 20 + c), streams=3)
+    for c in range(3):
+        assert torch.equal(conc[c], seq[c]), c
