@@ -52,6 +52,8 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-lookahead', action='store_true',
+                    help='do not pass next_image to step (no overlap of the next frame\'s image encoder on a side stream)')
     ap.add_argument('--clips-in-flight', type=int, default=4,
                     help='also measure the aggregate frames/s with this many independent clips in flight per GPU '
                          '(one host thread + HIP stream + CUTIE.fork() each; reported as "multi_clip"; 0 = skip)')
@@ -79,14 +81,16 @@ def multi_clip_throughput(net, cfg, args, K, rank, dist, dev):
         try:
             with torch.inference_mode(), torch.cuda.stream(stream):
                 proc = InferenceCore(views[i], cfg=cfg)
-                proc.step(frames[0], mask, objects=objs)
+                nxt = (lambda t: None) if args.no_lookahead else (lambda t: frames[(t + 1) % NF])
+                proc.step(frames[0], mask, objects=objs, next_image=nxt(0))
                 for t in range(1, 1 + args.preroll + args.warmup):
-                    proc.step(frames[t % NF])
-                stream.synchronize()
+                    proc.step(frames[t % NF], next_image=nxt(t))
+                torch.cuda.synchronize()
                 start.wait()
                 for t in range(args.steps):
-                    proc.step(frames[(7 + t) % NF])
-                stream.synchronize()
+                    tt = 1 + args.preroll + args.warmup + t
+                    proc.step(frames[tt % NF], next_image=nxt(tt))
+                torch.cuda.synchronize()
                 finish[i] = time.perf_counter()
         except BaseException as e:
             errors.append(e)
@@ -195,10 +199,11 @@ def main():
     proc = InferenceCore(net, cfg=cfg)
     side = torch.cuda.Stream(device=dev)                   # a real (capturable) stream, not the legacy null stream
     with torch.inference_mode(), torch.cuda.stream(side):
-        proc.step(frames[0], mask, objects=clip.objects)
+        la = (lambda t: None) if args.no_lookahead else (lambda t: frames[(t + 1) % 128])   # the next frame, as a video reader knows it
+        proc.step(frames[0], mask, objects=clip.objects, next_image=la(0))
         t_idx = 1
         for _ in range(args.preroll + args.warmup):
-            proc.step(frames[t_idx % 128])
+            proc.step(frames[t_idx % 128], next_image=la(t_idx))
             t_idx += 1
         torch.cuda.synchronize()
         n_tok_start = sum(b.size() for b in proc.memory.buckets.values())
@@ -207,7 +212,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            proc.step(frames[t_idx % 128])
+            proc.step(frames[t_idx % 128], next_image=la(t_idx))
             t_idx += 1
         torch.cuda.synchronize()
         if dist is not None:
@@ -344,7 +349,9 @@ def main():
             'config': {'workload': f'synthetic {args.width}x{args.height} {K}-object clip, long_term={use_lt}, one clip per GPU '
                                    f'(SURVEY 8d C2/C3), eval_config defaults (mem_every=5, top_k=30), random-init weights',
                        'preroll_frames': args.preroll, 'memory_tokens_start': n_tok_start, 'memory_tokens_end': n_tok_end,
-                       'parallelism': f'clip-shard x{world}', 'accumulate': 'fp32'},
+                       'parallelism': f'clip-shard x{world}', 'accumulate': 'fp32',
+                       'lookahead': 'off' if args.no_lookahead else 'step(next_image=...): the next frame\'s image encoder runs on a '
+                                    'side stream (same kernels, bit-identical results)'},
         }
         if roof is not None:
             out['roofline'] = roof

@@ -66,6 +66,51 @@ class InferenceCore:
         self.image_feature_store = ImageFeatureStore(self.network) if image_feature_store is None else image_feature_store
         self.last_mask = None
         self.pad = (0, 0, 0, 0)
+        self._enc_stream = None        # side stream of the look-ahead image encoder (prefetch)
+        self._prefetched = None        # (key of the source frame, prepared image, features, event)
+
+    # ---- look-ahead image encoder (no counterpart in the reference) ---------------------------------------------
+    @staticmethod
+    def _frame_key(image):
+        return (image.data_ptr(), tuple(image.shape), image.dtype, image._version)
+
+    def _prepare_image(self, image):
+        """Frame -> (f32 contiguous device tensor carrying the pad geometry, geometry).  Zero-padding to /16 is fused into
+        the first kernel of each plan: the raw frame + geometry are handed over instead of a padded copy."""
+        h0, w0 = image.shape[-2:]
+        H, W, pad = pad_geometry(h0, w0, 16)
+        image = image.to(device=self.network.device, dtype=F32).contiguous()
+        image._cutie_raw = (h0, w0, H, W, pad[0], pad[2])
+        return image, (h0, w0, H, W, pad)
+
+    def prefetch(self, image: torch.Tensor) -> None:
+        """Optional look-ahead: start the image encoder (ResNet-50 + key projection, ~30 % of a frame and independent of
+        the memory state) of the frame that will be passed to the NEXT ``step`` on a side stream, so that it overlaps with
+        the read-out / transformer / decoder of the current frame.  ``step(next_image=...)`` calls this.  If the next
+        ``step`` receives a different tensor the result is simply dropped.  Results are bit-identical to the unpipelined
+        order (same kernels, same inputs)."""
+        if self.max_internal_size > 0 and min(image.shape[-2:]) > self.max_internal_size:
+            return                                             # the GUI resize path stays unpipelined
+        dev = self.network.device
+        if dev.type != 'cuda':
+            return
+        src_key = self._frame_key(image)
+        main = torch.cuda.current_stream(dev)
+        prepared, _ = self._prepare_image(image)               # (conversion, if any, runs on the caller's stream)
+        if self._enc_stream is None:
+            self._enc_stream = torch.cuda.Stream(device=dev)
+        enc = self._enc_stream
+        enc.wait_stream(main)                                  # frame conversion + any earlier encoder run on the main stream
+        with torch.cuda.stream(enc):
+            ms_features, pix_feat = self.network._encode_image_raw(prepared, *prepared._cutie_raw)
+            key, shrinkage, selection = self.network.transform_key(ms_features[0])
+            ev = torch.cuda.Event()
+            ev.record(enc)
+        feats = (ms_features, pix_feat, key, shrinkage, selection)
+        for t in list(ms_features) + [pix_feat, key, shrinkage, selection] + list(self.network._key_cache[1].values()):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(main)                          # allocated on the side stream, consumed on the main one
+        self._prefetched = (src_key, prepared, feats, ev)
 
     def clear_memory(self):
         self.curr_ti = -1
@@ -123,7 +168,10 @@ class InferenceCore:
 
     # ---- step (inference_core.py:172-328) ------------------------------------------------------------------------------
     def step(self, image: torch.Tensor, mask: Optional[torch.Tensor] = None, objects: Optional[List[int]] = None, *,
-             idx_mask: bool = True, end: bool = False, delete_buffer: bool = True, force_permanent: bool = False) -> torch.Tensor:
+             idx_mask: bool = True, end: bool = False, delete_buffer: bool = True, force_permanent: bool = False,
+             next_image: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Same contract as the reference (inference_core.py:172-328).  ``next_image`` (optional, not in the reference): the
+        frame of the following ``step``; its image encoder is started on a side stream (see ``prefetch``)."""
         if objects is None and mask is not None:
             assert not idx_mask
             objects = list(range(1, mask.shape[0] + 1))
@@ -146,12 +194,19 @@ class InferenceCore:
                         mask = F.interpolate(mask.unsqueeze(0), size=(new_h, new_w), mode='bilinear', align_corners=False)[0]
 
         self.curr_ti += 1
-        h0, w0 = image.shape[-2:]
-        H, W, self.pad = pad_geometry(h0, w0, 16)
-        pl, pt = self.pad[0], self.pad[2]
-        # zero-padding to /16 is fused into the first kernel of each plan: hand over the raw frame + geometry
-        image = image.to(device=self.network.device, dtype=F32).contiguous()
-        image._cutie_raw = (h0, w0, H, W, pl, pt)
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None and not resize_needed and pre[0] == self._frame_key(image):
+            # this frame's encoder already ran (or is running) on the side stream
+            image = pre[1]
+            torch.cuda.current_stream(image.device).wait_event(pre[3])
+            self.image_feature_store._store[self.curr_ti] = pre[2]
+            h0, w0, H, W, pl, pt = image._cutie_raw
+            self.pad = pad_geometry(h0, w0, 16)[2]
+        else:
+            if pre is not None:                                # stale look-ahead: order the encoder plan's buffers, drop it
+                torch.cuda.current_stream(pre[1].device).wait_event(pre[3])
+            image, (h0, w0, H, W, self.pad) = self._prepare_image(image)
+            pl, pt = self.pad[0], self.pad[2]
 
         is_mem_frame = ((self.curr_ti - self.last_mem_ti >= self.mem_every) or (mask is not None)) and (not end)
         need_segment = (mask is None) or (self.object_manager.num_obj > 0 and not self.object_manager.has_all(objects))
@@ -159,6 +214,8 @@ class InferenceCore:
 
         ms_feat, pix_feat = self.image_feature_store.get_features(self.curr_ti, image)
         key, shrinkage, selection = self.image_feature_store.get_key(self.curr_ti, image)
+        if next_image is not None and not end:
+            self.prefetch(next_image)
 
         if need_segment:
             pred_prob_with_bg = self._segment(key, selection, pix_feat, ms_feat, update_sensory=update_sensory)

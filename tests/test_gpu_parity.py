@@ -160,6 +160,32 @@ def test_480p_properties(gpu_net):
         assert torch.equal(outs[0], outs[1])
 
 
+def test_lookahead_encoder_matches_plain_order(gpu_net):
+    """step(next_image=...) overlaps the next frame's image encoder on a side stream: bit-identical probabilities, also when
+    the hint is wrong (a different frame arrives) or missing for some frames."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.utils.synth import SyntheticClip
+    clip = SyntheticClip(240, 432, 3, 16, seed=77)
+    frames = torch.stack([clip.frame(t) for t in range(16)]).cuda()
+    mask = clip.first_mask().cuda()
+
+    def run(hint):
+        proc = InferenceCore(gpu_net, cfg=default_config(mem_every=3))
+        outs = [proc.step(frames[0], mask, objects=clip.objects, next_image=hint(0))]
+        for t in range(1, 16):
+            outs.append(proc.step(frames[t], next_image=hint(t)))
+        torch.cuda.synchronize()
+        return torch.stack(outs).cpu()
+
+    with torch.inference_mode():
+        plain = run(lambda t: None)
+        piped = run(lambda t: frames[t + 1] if t + 1 < 16 else None)
+        mixed = run(lambda t: None if t % 3 == 0 else (frames[(t + 5) % 16] if t % 3 == 1 else frames[min(t + 1, 15)]))
+    assert torch.isfinite(plain).all()
+    assert torch.equal(piped, plain)
+    assert torch.equal(mixed, plain)
+
+
 def test_concurrent_clips_match_sequential(gpu_net):
     """parallel.run_concurrent: 4 clips in flight on one GPU (host thread + HIP stream + CUTIE.fork() each) produce
     bit-identical probabilities to the same clips run one after another."""

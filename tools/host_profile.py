@@ -22,6 +22,12 @@ with torch.inference_mode(), torch.cuda.stream(torch.cuda.Stream()):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f'host issue time {1e3 * (t1 - t0) / 100:.3f} ms/frame ; with device drain {1e3 * (t2 - t0) / 100:.3f} ms/frame')
+    iso = []
+    for t in range(40):
+        torch.cuda.synchronize()
+        a = time.perf_counter(); proc.step(frames[t % 64]); iso.append(time.perf_counter() - a)
+    iso.sort()
+    print(f'host issue time with an EMPTY queue: median {1e3 * iso[len(iso) // 2]:.3f} ms/frame, min {1e3 * iso[0]:.3f}')
     pr = cProfile.Profile(); pr.enable()
     for t in range(100): proc.step(frames[t % 64])
     pr.disable(); torch.cuda.synchronize()
