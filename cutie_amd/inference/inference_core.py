@@ -72,7 +72,7 @@ class InferenceCore:
     # ---- look-ahead image encoder (no counterpart in the reference) ---------------------------------------------
     @staticmethod
     def _frame_key(image):
-        return (image.data_ptr(), tuple(image.shape), image.dtype, image._version)
+        return (image.data_ptr(), tuple(image.shape), tuple(image.stride()), image.dtype)
 
     def _prepare_image(self, image):
         """Frame -> (f32 contiguous device tensor carrying the pad geometry, geometry).  Zero-padding to /16 is fused into
@@ -86,8 +86,9 @@ class InferenceCore:
     def prefetch(self, image: torch.Tensor) -> None:
         """Optional look-ahead: start the image encoder (ResNet-50 + key projection, ~30 % of a frame and independent of
         the memory state) of the frame that will be passed to the NEXT ``step`` on a side stream, so that it overlaps with
-        the read-out / transformer / decoder of the current frame.  ``step(next_image=...)`` calls this.  If the next
-        ``step`` receives a different tensor the result is simply dropped.  Results are bit-identical to the unpipelined
+        the read-out / transformer / decoder of the current frame.  ``step(next_image=...)`` calls this.  The hint is matched
+        by storage (address / shape / strides), so pass the same tensor (or view) to the next ``step`` and do not modify it
+        in between; if the next ``step`` receives a different tensor the result is simply dropped.  Results are bit-identical to the unpipelined
         order (same kernels, same inputs)."""
         if self.max_internal_size > 0 and min(image.shape[-2:]) > self.max_internal_size:
             return                                             # the GUI resize path stays unpipelined
@@ -110,7 +111,8 @@ class InferenceCore:
         for t in list(ms_features) + [pix_feat, key, shrinkage, selection] + list(self.network._key_cache[1].values()):
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(main)                          # allocated on the side stream, consumed on the main one
-        self._prefetched = (src_key, prepared, feats, ev)
+        # (the source tensor is kept referenced until the next step: its address cannot be recycled for another frame)
+        self._prefetched = (src_key, prepared, feats, ev, image)
 
     def clear_memory(self):
         self.curr_ti = -1

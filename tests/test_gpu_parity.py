@@ -160,6 +160,30 @@ def test_480p_properties(gpu_net):
         assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize('h,w,K,frames', [(480, 854, 1, 12), (1080, 1920, 5, 8)])
+def test_other_baseline_configs_properties(gpu_net, h, w, K, frames):
+    """BASELINE.json configs[1] (480p, 1 object) and configs[4] (1080p, 5 objects: HW = 8160 queries) through the same
+    size-independent properties: shapes, finiteness, simplex, bank bookkeeping, first frame returns the input mask."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.utils.synth import SyntheticClip
+    clip = SyntheticClip(h, w, K, frames, seed=3)
+    proc = InferenceCore(gpu_net, cfg=default_config(use_long_term=True, mem_every=2))
+    H, W = -(-h // 16) * 16, -(-w // 16) * 16
+    hw = (H // 16) * (W // 16)
+    with torch.inference_mode():
+        mask = clip.first_mask().cuda()
+        p0 = proc.step(clip.frame(0).cuda(), mask, objects=clip.objects)
+        assert p0.shape == (K + 1, h, w)
+        assert torch.equal(proc.output_prob_to_mask(p0), mask)
+        for t in range(1, frames):
+            p = proc.step(clip.frame(t).cuda(), next_image=clip.frame(t + 1).cuda() if t + 1 < frames else None)
+            assert p.shape == (K + 1, h, w) and torch.isfinite(p).all()
+            assert float((p.sum(0) - 1).abs().max()) < 1e-4
+            b = list(proc.memory.buckets.values())[0]
+            assert b.n_perm == hw and b.n_work == (t // 2) * hw
+        assert int(proc.memory._scratch['overflow'].item()) == 0
+
+
 def test_lookahead_encoder_matches_plain_order(gpu_net):
     """step(next_image=...) overlaps the next frame's image encoder on a side stream: bit-identical probabilities, also when
     the hint is wrong (a different frame arrives) or missing for some frames."""
