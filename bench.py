@@ -285,9 +285,21 @@ def main():
                 torch.cuda.synchronize()
                 graph_ms = (time.perf_counter() - t1) / 20 * 1e3
                 lib.cutie_graph_destroy(g)
+            # HBM traffic of the same kernel family from the committed rocprofv3 PMC passes (tools/profile_round.sh: FETCH_SIZE x2
+            # per the gfx950 correction + WRITE_SIZE, bytes per launch); null when no profile summary is present
+            traffic = None
+            try:
+                import glob
+                summ = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_summary.json')))
+                if summ:
+                    pm = json.load(open(summ[-1]))['pmc']['conv_igemm_kernel<*>']
+                    traffic = round((pm['fetch_MB_per_dispatch_x2_gfx950_corrected'] + pm['write_MB_per_dispatch']) * 1e6)
+            except Exception:
+                traffic = None
             roof = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<*> (all conv launches of a frame)',
                     'achieved': round(conv_f / conv_t / 1e12, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(conv_f / conv_t / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                    'frac': round(conv_f / conv_t / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+                    'traffic_unit': 'HBM bytes per conv launch (rocprofv3 PMC, profiles/)',
                     'gflop_per_frame': round(conv_f / nrec / 1e9, 1), 'ms_per_frame': round(conv_t / nrec * 1e3, 3),
                     'launches_per_frame': n_conv}
             roof_aff = {'bound': 'mfma', 'kernel': 'aff_score x2 + aff_select + aff_readout',

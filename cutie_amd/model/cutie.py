@@ -61,7 +61,7 @@ class Engine:
         self.m, self.device = m, device
         self.w = {}
         self._plans = {}
-        self.tile_cache = {}         # conv geometry -> autotuned tile id
+        self.tile_cache = plans.load_tile_cache()   # conv geometry -> autotuned (tile id, split-K); optionally persisted
         self._pe = {}
         self._rep = {}
         sd = {k: v.detach().float().cpu() for k, v in sd.items() if v.is_floating_point()}

@@ -41,6 +41,33 @@ def positional_encoding(h, w, dim_total, scale, temperature):
     return emb
 
 
+TILE_CACHE_ENV = 'CUTIE_AMD_TILE_CACHE'
+
+
+def load_tile_cache():
+    """Autotuned conv tiles persisted across processes: if $CUTIE_AMD_TILE_CACHE names a JSON file, it seeds the cache and
+    is rewritten whenever a plan is tuned (keys are conv geometries, so one file serves every resolution / object count)."""
+    import json, os
+    path = os.environ.get(TILE_CACHE_ENV)
+    if not path or not os.path.exists(path):
+        return {}
+    try:
+        return {tuple(k): tuple(v) for k, v in json.load(open(path))['tiles']}
+    except Exception:
+        return {}
+
+
+def save_tile_cache(cache):
+    import json, os
+    path = os.environ.get(TILE_CACHE_ENV)
+    if not path:
+        return
+    tmp = path + '.tmp%d' % os.getpid()
+    with open(tmp, 'w') as f:
+        json.dump({'tiles': [[list(k), list(v)] for k, v in cache.items()]}, f)
+    os.replace(tmp, path)
+
+
 class Plan:
     def __init__(self, eng):
         self.eng = eng
@@ -77,6 +104,7 @@ class Plan:
         ol.bind(**dyn)
         arr = ol.arr
         cache = self.eng.tile_cache
+        tuned_any = False
         for n in range(len(arr)):
             if arr['kind'][n] != O.CONV:
                 continue
@@ -97,8 +125,11 @@ class Plan:
                         if best_t is None or ms < best_t:
                             best, best_t = (t, sk), ms
                 cache[key] = best
+                tuned_any = True
             arr['i'][n, 17], arr['i'][n, 19] = best
         self.tuned = True
+        if tuned_any:
+            save_tile_cache(cache)
 
     # ---- conv helper ------------------------------------------------------------------
     def conv(self, wname, x, *, name=None, out=None, stride=1, pad=None, x2=None, res=None, res_bcast=False,

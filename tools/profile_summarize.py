@@ -1,0 +1,61 @@
+"""Condense the rocprofv3 output of tools/profile_round.sh into profiles/<round>_*.{csv,json}."""
+import collections, csv, glob, json, os, re, sys
+
+src, rnd = sys.argv[1], sys.argv[2]
+os.makedirs('profiles', exist_ok=True)
+
+
+def short(name):
+    name = re.sub(r'^void ', '', name)
+    m = re.match(r'(conv_igemm_kernel)<', name)
+    if m:
+        return 'conv_igemm_kernel<*>'
+    m = re.match(r'(\w+)<[^>]*>', name)
+    return (m.group(1) + '<*>') if m and name.startswith(('aff_score', 'linear_small')) else name.split('(')[0][:90]
+
+
+st = glob.glob(os.path.join(src, 'stats', '**', '*kernel_stats.csv'), recursive=True)
+if st:
+    rows = list(csv.DictReader(open(st[0])))
+    with open(f'profiles/{rnd}_bench_kernel_stats.csv', 'w') as f:
+        w = csv.writer(f)
+        w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+        for r in rows:
+            w.writerow([r['Name'][:160], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in rows:
+        a = agg[short(r['Name'])]
+        a[0] += int(r['Calls']); a[1] += float(r['TotalDurationNs'])
+    tot = sum(v[1] for v in agg.values())
+    fam = [{'kernel': k, 'calls': v[0], 'total_ms': round(v[1] / 1e6, 3), 'avg_us': round(v[1] / v[0] / 1e3, 2), 'pct': round(100 * v[1] / tot, 2)}
+           for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])]
+else:
+    fam = []
+pm = collections.defaultdict(lambda: collections.defaultdict(float))
+disp = collections.defaultdict(set)
+for f in glob.glob(os.path.join(src, 'pmc*', '**', '*counter_collection.csv'), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = short(r['Kernel_Name'])
+        pm[k][r['Counter_Name']] += float(r['Counter_Value'])
+        disp[(k, r['Counter_Name'])].add(r['Dispatch_Id'])
+kern = {}
+for k, c in pm.items():
+    d = dict(c)
+    n = {cn: len(disp[(k, cn)]) for cn in c}
+    out = {cn: v for cn, v in d.items()}
+    out['dispatches'] = max(n.values())
+    if 'FETCH_SIZE' in d:
+        # FETCH_SIZE / WRITE_SIZE are in KiB-like 1 KB units; gfx950 reports 1/2 for wide coalesced reads (MI355X_MICROARCH.md)
+        out['fetch_MB_per_dispatch_x2_gfx950_corrected'] = round(2 * d['FETCH_SIZE'] / n['FETCH_SIZE'] / 1024, 3)
+    if 'WRITE_SIZE' in d:
+        out['write_MB_per_dispatch'] = round(d['WRITE_SIZE'] / n['WRITE_SIZE'] / 1024, 3)
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in d and d.get('GRBM_GUI_ACTIVE'):
+        out['mfma_busy_over_gui_active'] = round(d['SQ_VALU_MFMA_BUSY_CYCLES'] / d['GRBM_GUI_ACTIVE'], 3)
+    if d.get('SQ_LDS_IDX_ACTIVE'):
+        out['lds_bank_conflict_frac'] = round(d.get('SQ_LDS_BANK_CONFLICT', 0.0) / d['SQ_LDS_IDX_ACTIVE'], 4)
+    kern[k] = out
+json.dump({'command': 'rocprofv3 --kernel-trace --stats / --pmc <set> --kernel-trace -- python bench.py --steps 60 --warmup 10 --preroll 60 '
+                      '--cpu-frames 0 --no-roofline --clips-in-flight 0 (tools/profile_round.sh; separate passes for the SQ set, FETCH_SIZE, WRITE_SIZE)',
+           'notes': 'sums over every dispatch of the run (incl. the conv autotune trials at the first frames); GRBM_GUI_ACTIVE is summed over the 8 XCCs',
+           'families_by_time': fam, 'pmc': kern}, open(f'profiles/{rnd}_summary.json', 'w'), indent=1)
+print(json.dumps(fam[:12], indent=0))
