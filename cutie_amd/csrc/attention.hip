@@ -153,16 +153,17 @@ __global__ __launch_bounds__(1024) void attn_q2p_kernel(const float* __restrict_
 }
 
 // ATTN_SELF: grid (heads, K), block 64: lane = query*4 + part (8 dims each)
-__global__ void attn_self_kernel(const float* __restrict__ qk, const float* __restrict__ v, float* __restrict__ y, int Q, int C) {
+__global__ void attn_self_kernel(const float* __restrict__ qk, const float* __restrict__ v, float* __restrict__ y, int Q, int C,
+                                 int ldqk, int ldv) {
     const int hh = blockIdx.x, k = blockIdx.y, lane = threadIdx.x, qi = lane >> 2, part = lane & 3;
     const float scale = rsqrtf(32.f);
     float qf[8];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) qf[d] = qk[((long)k * Q + qi) * 2 * C + hh * 32 + part * 8 + d] * scale;
+    for (int d = 0; d < 8; ++d) qf[d] = qk[((long)k * Q + qi) * ldqk + hh * 32 + part * 8 + d] * scale;
     float s[16], mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const float* kr = qk + ((long)k * Q + j) * 2 * C + C + hh * 32 + part * 8;
+        const float* kr = qk + ((long)k * Q + j) * ldqk + C + hh * 32 + part * 8;
         float a = 0.f;
 #pragma unroll
         for (int d = 0; d < 8; ++d) a += qf[d] * kr[d];
@@ -178,7 +179,7 @@ __global__ void attn_self_kernel(const float* __restrict__ qk, const float* __re
     float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const float* vr = v + ((long)k * Q + j) * C + hh * 32 + part * 8;
+        const float* vr = v + ((long)k * Q + j) * ldv + hh * 32 + part * 8;
 #pragma unroll
         for (int d = 0; d < 8; ++d) o[d] += s[j] * vr[d];
     }
@@ -189,13 +190,13 @@ __global__ void attn_self_kernel(const float* __restrict__ qk, const float* __re
 // ATTN_P2Q: grid (ceil(HW/256), heads, K): one thread per (pixel, head)
 __global__ __launch_bounds__(256) void attn_p2q_kernel(const bf16_t* __restrict__ q, const float* __restrict__ kq,
                                                        const float* __restrict__ vq, bf16_t* __restrict__ y, int Q, int HW,
-                                                       int C, int ldq) {
+                                                       int C, int ldq, int ldkv) {
     __shared__ float ks[16][32], vs[16][32];
     const int hh = blockIdx.y, k = blockIdx.z;
     for (int t = threadIdx.x; t < 512; t += 256) {
         int j = t >> 5, d = t & 31;
-        ks[j][d] = kq[((long)k * Q + j) * C + hh * 32 + d];
-        vs[j][d] = vq[((long)k * Q + j) * C + hh * 32 + d];
+        ks[j][d] = kq[((long)k * Q + j) * ldkv + hh * 32 + d];
+        vs[j][d] = vq[((long)k * Q + j) * ldkv + hh * 32 + d];
     }
     __syncthreads();
     int p = blockIdx.x * 256 + threadIdx.x;
@@ -252,12 +253,13 @@ int launch_attention(const cutie_op* op, hipStream_t s) {
             break;
         case CUTIE_OP_ATTN_SELF:
             if (i[1] != 16 || i[2] != i[3] * 32) { cutie_set_error("attn_self: Q=16, head dim 32 only"); return -2; }
-            hipLaunchKernelGGL(attn_self_kernel, dim3(i[3], i[0]), dim3(64), 0, s, (const float*)p[0], (const float*)p[1], (float*)p[2], i[1], i[2]);
+            hipLaunchKernelGGL(attn_self_kernel, dim3(i[3], i[0]), dim3(64), 0, s, (const float*)p[0], (const float*)p[1], (float*)p[2], i[1], i[2],
+                               i[4] > 0 ? i[4] : 2 * i[2], i[5] > 0 ? i[5] : i[2]);
             break;
         case CUTIE_OP_ATTN_P2Q:
             if (i[1] != 16 || i[3] != i[4] * 32) { cutie_set_error("attn_p2q: Q=16, head dim 32 only"); return -2; }
             hipLaunchKernelGGL(attn_p2q_kernel, dim3((i[2] + 255) / 256, i[4], i[0]), dim3(256), 0, s, (const bf16_t*)p[0], (const float*)p[1],
-                               (const float*)p[2], (bf16_t*)p[3], i[1], i[2], i[3], i[5]);
+                               (const float*)p[2], (bf16_t*)p[3], i[1], i[2], i[3], i[5], i[6] > 0 ? i[6] : i[3]);
             break;
         default:
             cutie_set_error("attention: unknown op kind %d", op->kind);

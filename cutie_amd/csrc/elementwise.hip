@@ -443,6 +443,99 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
     }
 }
 
+// LINEAR on MFMA: one block per 16 rows x 16 columns, its 4 waves split K and are summed through LDS.  x is fp32 (the
+// query side of the transformer is an fp32 island) and is split into bf16 hi + lo on the fly, W is bf16: two
+// v_mfma_f32_16x16x32_bf16 per 32 k (fp32-class accuracy), no cross-lane reduction, one memory round trip per wave.
+// A = x rows (lane: row l&15, k 8*(l>>4)..+7), B = W^T (lane: column l&15, same k: a contiguous 16-B piece of W's row).
+__global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xadd,
+                                                          const bf16_t* __restrict__ W, const float* __restrict__ bias,
+                                                          const float* __restrict__ res, float* __restrict__ y, int M, int N,
+                                                          int Kd, int ldx, int ldy, int add_rows, int relu, int add_cols,
+                                                          const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                          float* __restrict__ ln_out, float eps) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+    __shared__ f32x4 red[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const int m = min(m0 + c, M - 1), n = min(n0 + c, N - 1);
+    const int per = (Kd >> 5) >> 2;                          // 32-wide k steps per wave (Kd % 128 == 0)
+    const float* xrow = x + (long)m * ldx;
+    // fused LayerNorm over the Kd inputs of row m (flag: ln_g != 0; Kd == 256): lane (c, g) reads the 64 values
+    // k = 64 g .. of its row, the 4 lanes of a row combine through permlane swaps; every wave does this for itself
+    float mean = 0.f, rstd = 1.f;
+    if (ln_g) {
+        float v[64], sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(xrow + g * 64 + i * 4);
+            v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+            sum += (t.x + t.y) + (t.z + t.w);
+        }
+        mean = rows_sum(sum) * (1.f / 256.f);
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) { const float d = v[i] - mean; sq += d * d; }
+        rstd = rsqrtf(rows_sum(sq) * (1.f / 256.f) + eps);
+    }
+    const bool use_add = xadd && (add_cols <= 0 || n0 < add_cols);       // block-uniform: x_add feeds only the first add_cols outputs
+    const int kw = (wave * per) * 32 + 8 * g;
+    const float* xr = xrow + kw;
+    const float* ar = use_add ? xadd + (long)(m % add_rows) * Kd + kw : nullptr;
+    const bf16_t* wr = W + (long)n * Kd + kw;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int ks = 0; ks < per; ++ks) {
+        float4 a = *reinterpret_cast<const float4*>(xr + ks * 32), b = *reinterpret_cast<const float4*>(xr + ks * 32 + 4);
+        if (ln_g) {
+            const float4 g0 = *reinterpret_cast<const float4*>(ln_g + kw + ks * 32), g1 = *reinterpret_cast<const float4*>(ln_g + kw + ks * 32 + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(ln_b + kw + ks * 32), b1 = *reinterpret_cast<const float4*>(ln_b + kw + ks * 32 + 4);
+            a.x = (a.x - mean) * rstd * g0.x + b0.x; a.y = (a.y - mean) * rstd * g0.y + b0.y;
+            a.z = (a.z - mean) * rstd * g0.z + b0.z; a.w = (a.w - mean) * rstd * g0.w + b0.w;
+            b.x = (b.x - mean) * rstd * g1.x + b1.x; b.y = (b.y - mean) * rstd * g1.y + b1.y;
+            b.z = (b.z - mean) * rstd * g1.z + b1.z; b.w = (b.w - mean) * rstd * g1.w + b1.w;
+            if (ln_out && blockIdx.x == 0 && m0 + c < M) {                // the normalised rows are a side output (residuals)
+                *reinterpret_cast<float4*>(ln_out + (long)m * Kd + kw + ks * 32) = a;
+                *reinterpret_cast<float4*>(ln_out + (long)m * Kd + kw + ks * 32 + 4) = b;
+            }
+        }
+        if (ar) {
+            const float4 p = *reinterpret_cast<const float4*>(ar + ks * 32), q = *reinterpret_cast<const float4*>(ar + ks * 32 + 4);
+            a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w; b.x += q.x; b.y += q.y; b.z += q.z; b.w += q.w;
+        }
+        const u4 wv = *reinterpret_cast<const u4*>(wr + ks * 32);
+        const float xs[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        u4 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16_t h0 = f2bf(xs[2 * i]), h1 = f2bf(xs[2 * i + 1]);
+            hi[i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+            lo[i] = (uint32_t)f2bf(xs[2 * i] - bf2f(h0)) | ((uint32_t)f2bf(xs[2 * i + 1] - bf2f(h1)) << 16);
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, lo), __builtin_bit_cast(bf16x8, wv), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, hi), __builtin_bit_cast(bf16x8, wv), acc, 0, 0, 0);
+    }
+    if (wave) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) { const f32x4 t = red[w][lane]; acc[0] += t[0]; acc[1] += t[1]; acc[2] += t[2]; acc[3] += t[3]; }
+        const int nn = n0 + c;
+        if (nn < N) {
+            const float bv = bias ? bias[nn] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mm = m0 + 4 * g + r;
+                if (mm < M) {
+                    float v = acc[r] + bv;
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (res) v += res[(long)mm * N + nn];
+                    y[(long)mm * ldy + nn] = v;
+                }
+            }
+        }
+    }
+}
+
 // LAYERNORM: one wave per row
 __global__ void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
                                  float* __restrict__ y, int M, int C) {
@@ -642,7 +735,15 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
         case CUTIE_OP_LINEAR: {
             if ((i[2] & 7) || (i[3] & 3) || i[2] < 256) { cutie_set_error("linear: Kd %% 8, ldx %% 4, Kd >= 256 required (Kd=%d)", i[2]); return -2; }
             const int add_rows = i[5] > 0 ? i[5] : 1;
-            if (i[2] >= 512)
+            const bool ln = op->flags & 2;
+            if (ln && (i[2] != 256 || !p[6] || !p[7] || (i[3] & 3))) { cutie_set_error("linear: fused LayerNorm needs Kd == 256, gamma and beta"); return -2; }
+            if ((ln || i[6] > 0) && (i[2] & 127)) { cutie_set_error("linear: LayerNorm / add_cols need Kd %% 128 == 0"); return -2; }
+            if (i[6] > 0 && (i[6] & 15)) { cutie_set_error("linear: add_cols must be a multiple of 16"); return -2; }
+            if ((i[2] & 127) == 0)
+                hipLaunchKernelGGL(linear_mfma_kernel, dim3((i[1] + 15) / 16, (i[0] + 15) / 16), dim3(256), 0, s, (const float*)p[0], (const float*)p[1], (const bf16_t*)p[2],
+                                   (const float*)p[3], (const float*)p[4], (float*)p[5], i[0], i[1], i[2], i[3], i[4], add_rows, op->flags & 1, i[6],
+                                   ln ? (const float*)p[6] : nullptr, (const float*)p[7], (float*)p[8], op->f[0] > 0.f ? op->f[0] : 1e-5f);
+            else if (i[2] >= 512)
                 hipLaunchKernelGGL(linear_small_kernel<64>, dim3((i[1] + 3) / 4, (i[0] + 15) / 16), dim3(256), 0, s, (const float*)p[0], (const float*)p[1], (const bf16_t*)p[2],
                                    (const float*)p[3], (const float*)p[4], (float*)p[5], i[0], i[1], i[2], i[3], i[4], add_rows, op->flags & 1);
             else

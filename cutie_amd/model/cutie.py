@@ -125,15 +125,13 @@ class Engine:
             W[q + '.pe_proj'] = linear_as_conv(wpe, None, dev)
             W[q + '.read_from_pixel.q'] = pack_linear(Wp[:C], bp[:C], dev)
             W[q + '.read_from_pixel.out'] = pack_linear(sd[rp + '.out_proj.weight'], sd[rp + '.out_proj.bias'], dev)
-            W[q + '.self_attn.qk'] = pack_linear(Ws[:2 * C], bs[:2 * C], dev)
-            W[q + '.self_attn.v'] = pack_linear(Ws[2 * C:], bs[2 * C:], dev)
+            W[q + '.self_attn.qkv'] = pack_linear(Ws, bs, dev)                    # one launch; the query PE feeds q and k only
             W[q + '.self_attn.out'] = pack_linear(sd[sa + '.out_proj.weight'], sd[sa + '.out_proj.bias'], dev)
-            W[q + '.read_from_query.k'] = pack_linear(Wq[C:2 * C], bq[C:2 * C], dev)
-            W[q + '.read_from_query.v'] = pack_linear(Wq[2 * C:], bq[2 * C:], dev)
+            W[q + '.read_from_query.kv'] = pack_linear(Wq[C:], bq[C:], dev)        # [k | v]; the query PE feeds k only
             W[q + '.read_from_query.out'] = linear_as_conv(sd[rq + '.out_proj.weight'], sd[rq + '.out_proj.bias'], dev)
             for ln in ('.read_from_pixel.norm', '.self_attn.norm', '.ffn.norm'):
-                W[q + ln + '.weight'] = sd[q + ln + '.weight'].to(dev)
-                W[q + ln + '.bias'] = sd[q + ln + '.bias'].to(dev)
+                W[q + ln + '.weight'] = sd[q + ln + '.weight'].to(dev).contiguous()
+                W[q + ln + '.bias'] = sd[q + ln + '.bias'].to(dev).contiguous()
             W[q + '.ffn.linear1'] = pack_linear(sd[q + '.ffn.linear1.weight'], sd[q + '.ffn.linear1.bias'], dev)
             W[q + '.ffn.linear2'] = pack_linear(sd[q + '.ffn.linear2.weight'], sd[q + '.ffn.linear2.bias'], dev)
         for b in range(ot['num_blocks'] + 1):

@@ -285,40 +285,35 @@ def build_readout_query(eng, K, h, w):
         n = f'b{b}.'
         R = P.conv(q + '.pe_proj', pixel_pe, name=n + 'R')                       # [Wk.pe | 0 | Wq2.pe]
         kvq = P.conv(q + '.pixel_proj', pixel, name=n + 'kvq', res=R)            # k | v | q2 of the pixels
-        # read_from_pixel (CrossAttention, transformer_layers.py:75-98): residual is the normed x
+        # read_from_pixel (CrossAttention, transformer_layers.py:75-98): residual is the normed x.  Every LayerNorm of the
+        # block is fused into the linear that consumes it (the normalised rows are kept where the reference reuses them).
+        ln = lambda name: (W[q + name + '.weight'], W[q + name + '.bias'])
         xn = f(n + 'xn', (M, C))
-        ol.layernorm(x, W[q + '.read_from_pixel.norm.weight'], W[q + '.read_from_pixel.norm.bias'], xn, M=M, C=C)
         qp = f(n + 'qp', (M, C))
-        ol.linear(xn, W[q + '.read_from_pixel.q'], qp, M=M, x_add=query_emb, add_rows=M)
+        ol.linear(x, W[q + '.read_from_pixel.q'], qp, M=M, x_add=query_emb, add_rows=M, ln=ln('.read_from_pixel.norm'), ln_out=xn)
         att = f(n + 'att', (M, C))
         ol.attn_q2p(qp, kvq.t, fg, nfg, att, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C)
         x1 = f(n + 'x1', (M, C))
         ol.linear(att, W[q + '.read_from_pixel.out'], x1, M=M, res=xn)
-        # self attention (transformer_layers.py:28-41)
+        # self attention (transformer_layers.py:28-41): q | k | v in one launch, the query PE feeds q and k only
         y = f(n + 'y', (M, C))
-        ol.layernorm(x1, W[q + '.self_attn.norm.weight'], W[q + '.self_attn.norm.bias'], y, M=M, C=C)
-        qk = f(n + 'qk', (M, 2 * C))
-        ol.linear(y, W[q + '.self_attn.qk'], qk, M=M, x_add=query_emb, add_rows=M)
-        v = f(n + 'v', (M, C))
-        ol.linear(y, W[q + '.self_attn.v'], v, M=M)
+        qkv = f(n + 'qkv', (M, 3 * C))
+        ol.linear(x1, W[q + '.self_attn.qkv'], qkv, M=M, x_add=query_emb, add_rows=M, add_cols=2 * C, ln=ln('.self_attn.norm'), ln_out=y)
         sa = f(n + 'sa', (M, C))
-        ol.attn_self(qk, v, sa, K=K, Q=Q, C=C, heads=heads)
+        ol.attn_self(qkv, qkv.view(-1)[2 * C:], sa, K=K, Q=Q, C=C, heads=heads, ldqk=3 * C, ldv=3 * C)
         x2 = f(n + 'x2', (M, C))
         ol.linear(sa, W[q + '.self_attn.out'], x2, M=M, res=y)
         # FFN (transformer_layers.py:113-118)
-        z = f(n + 'z', (M, C))
-        ol.layernorm(x2, W[q + '.ffn.norm.weight'], W[q + '.ffn.norm.bias'], z, M=M, C=C)
         hid = f(n + 'hid', (M, ot['ff_dim']))
-        ol.linear(z, W[q + '.ffn.linear1'], hid, M=M, relu=True)
+        ol.linear(x2, W[q + '.ffn.linear1'], hid, M=M, relu=True, ln=ln('.ffn.norm'))
         x3 = f(n + 'x3', (M, C))
         ol.linear(hid, W[q + '.ffn.linear2'], x3, M=M, res=x2)
         x = x3
-        # read_from_query (no norm, residual on the pixels)
-        kq, vq = f(n + 'kq', (M, C)), f(n + 'vq', (M, C))
-        ol.linear(x, W[q + '.read_from_query.k'], kq, M=M, x_add=query_emb, add_rows=M)
-        ol.linear(x, W[q + '.read_from_query.v'], vq, M=M)
+        # read_from_query (no norm, residual on the pixels): k | v of the queries in one launch
+        kv2 = f(n + 'kv2', (M, 2 * C))
+        ol.linear(x, W[q + '.read_from_query.kv'], kv2, M=M, x_add=query_emb, add_rows=M, add_cols=C)
         pa = P.buf(n + 'pa', (K, h, w, C))
-        ol.attn_p2q(kvq.t.view(-1)[2 * C:], kq, vq, pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C)
+        ol.attn_p2q(kvq.t.view(-1)[2 * C:], kv2, kv2.view(-1)[C:], pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C, ldkv=2 * C)
         pf = P.conv(q + '.read_from_query.out', Act(pa, K, h, w, C), name=n + 'pf', res=pixel)
         # PixelFFN (transformer_layers.py:121-136)
         last = b == nb - 1

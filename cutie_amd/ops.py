@@ -255,11 +255,14 @@ class OpList:
     def agg_softmax(self, planes, prob, *, K, HW):
         return self.add(AGG_SOFTMAX, 0, [K, HW], [], [planes, prob])
 
-    def linear(self, x, w, y, *, M, ldx=None, ldy=None, x_add=None, add_rows=0, res=None, relu=False):
-        """w: PackedLinear."""
-        return self.add(LINEAR, 1 if relu else 0,
-                        [M, w.n, w.kd, w.kd if ldx is None else ldx, w.n if ldy is None else ldy, add_rows], [],
-                        [x, x_add, w.weight, w.bias, res, y])
+    def linear(self, x, w, y, *, M, ldx=None, ldy=None, x_add=None, add_rows=0, res=None, relu=False, add_cols=0,
+               ln=None, ln_out=None, eps=1e-5):
+        """w: PackedLinear.  ln = (gamma, beta): nn.LayerNorm fused in front (ln_out: where to keep the normalised rows);
+        add_cols: x_add feeds only the first add_cols output columns."""
+        flags = (1 if relu else 0) | (2 if ln is not None else 0)
+        return self.add(LINEAR, flags,
+                        [M, w.n, w.kd, w.kd if ldx is None else ldx, w.n if ldy is None else ldy, add_rows, add_cols], [eps],
+                        [x, x_add, w.weight, w.bias, res, y, ln[0] if ln else None, ln[1] if ln else None, ln_out])
 
     def layernorm(self, x, g, b, y, *, M, C):
         return self.add(LAYERNORM, 0, [M, C], [], [x, g, b, y])
@@ -274,11 +277,11 @@ class OpList:
     def attn_q2p(self, q, kv, fg, nfg, y, *, K, Q, HW, C, heads, ldkv, voff):
         return self.add(ATTN_Q2P, 0, [K, Q, HW, C, heads, ldkv, voff], [], [q, kv, fg, nfg, y])
 
-    def attn_self(self, qk, v, y, *, K, Q, C, heads):
-        return self.add(ATTN_SELF, 0, [K, Q, C, heads], [], [qk, v, y])
+    def attn_self(self, qk, v, y, *, K, Q, C, heads, ldqk=0, ldv=0):
+        return self.add(ATTN_SELF, 0, [K, Q, C, heads, ldqk, ldv], [], [qk, v, y])
 
-    def attn_p2q(self, q, kq, vq, y, *, K, Q, HW, C, heads, ldq):
-        return self.add(ATTN_P2Q, 0, [K, Q, HW, C, heads, ldq], [], [q, kq, vq, y])
+    def attn_p2q(self, q, kq, vq, y, *, K, Q, HW, C, heads, ldq, ldkv=0):
+        return self.add(ATTN_P2Q, 0, [K, Q, HW, C, heads, ldq, ldkv], [], [q, kq, vq, y])
 
     def summarize(self, feat, wl, m16, y, *, K, HW, C, Q, scratch=None):
         if scratch is None:

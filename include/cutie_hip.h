@@ -117,7 +117,11 @@ enum {
      * y = act(x @ W^T + b) + res     nn.Linear / MHA in/out projections, transformer_layers.py
      * p0=x f32 [M,ldx] p1=x_add f32 [M|16, Kd] (added to x before the product, may be 0)
      * p2=W bf16 [N,Kd] p3=bias f32 [N] p4=res f32 [M,N] (may be 0) p5=y f32 [M,ldy]
-     * i: 0 M 1 N 2 Kd 3 ldx 4 ldy 5 add_rows (x_add row = m % add_rows)   flags&1 relu */
+     * i: 0 M 1 N 2 Kd 3 ldx 4 ldy 5 add_rows (x_add row = m % add_rows)
+     *    6 add_cols (> 0: x_add feeds only the output columns < add_cols, e.g. merged [q|k|v] projections where
+     *      only q and k see the positional term; multiple of 16)
+     * flags&1 relu   flags&2 fused nn.LayerNorm on x first (Kd == 256): p6=gamma f32[Kd] p7=beta f32[Kd]
+     *      p8=ln_out f32 [M,Kd] (may be 0: the normalised rows, which the reference reuses as residual) f0=eps */
     CUTIE_OP_LINEAR = 14,
     /* LAYERNORM over the last dim (eps 1e-5)   p0=x f32 [M,C] p1=g p2=b f32[C] p3=y f32 [M,C]  i: 0 M 1 C */
     CUTIE_OP_LAYERNORM = 15,
@@ -134,11 +138,12 @@ enum {
      * p3=nfg i32 [K] p4=y f32 [K,Q,C]   i: 0 K 1 Q 2 HW 3 C 4 heads 5 ldkv 6 voff */
     CUTIE_OP_ATTN_Q2P = 18,
     /* ATTN_SELF: 16x16 self attention per object  transformer_layers.py:12-41
-     * p0=qk f32 [K,Q,2C] (q at +0, k at +C) p1=v f32 [K,Q,C] p2=y f32 [K,Q,C]  i: 0 K 1 Q 2 C 3 heads */
+     * p0=qk f32 [K,Q,ldqk] (q at +0, k at +C) p1=v f32 [K,Q,ldv] p2=y f32 [K,Q,C]
+     * i: 0 K 1 Q 2 C 3 heads 4 ldqk (0: 2C) 5 ldv (0: C) */
     CUTIE_OP_ATTN_SELF = 19,
     /* ATTN_P2Q: pixels <- 16 queries cross attention  object_transformer.py:66-70
-     * p0=q bf16 [K,HW,ldq] p1=kq f32 [K,Q,C] p2=vq f32 [K,Q,C] p3=y bf16 [K,HW,C]
-     * i: 0 K 1 Q 2 HW 3 C 4 heads 5 ldq */
+     * p0=q bf16 [K,HW,ldq] p1=kq f32 [K,Q,ldkv] p2=vq f32 [K,Q,ldkv] p3=y bf16 [K,HW,C]
+     * i: 0 K 1 Q 2 HW 3 C 4 heads 5 ldq 6 ldkv (0: C) */
     CUTIE_OP_ATTN_P2Q = 20,
     /* SUMMARIZE: weights=sigmoid(logits)*[m x8 | (1-m) x8]; sums=einsum; area   object_summarizer.py:11-23
      * p0=feature bf16 [K,HW,C] p1=wlogits f32 [K,HW,Q] p2=m16 f32 [K,HW] p3=y f32 [K,Q,C+1]

@@ -258,14 +258,22 @@ class MockExecutor:
 
     # ---- LINEAR / LAYERNORM / QUERY_INIT ------------------------------------------------------------
     def _op_14(self, flags, i, f, p):
-        M, N, Kd, ldx, ldy, add_rows = i[:6]
+        M, N, Kd, ldx, ldy, add_rows, add_cols = i[:7]
         x = view(p[0], F32, (M, Kd), (ldx, 1)).clone()
+        if flags & 2:
+            x = F.layer_norm(x, (Kd,), view(p[6], F32, (Kd,)), view(p[7], F32, (Kd,)), f[0] if f[0] > 0 else 1e-5)
+            if p[8]:
+                view(p[8], F32, (M, Kd)).copy_(x)
+        w = view(p[2], BF16, (N, Kd)).float()
+        y = x @ w.t()
         if p[1]:
             R = max(add_rows, 1)
             xa = view(p[1], F32, (R, Kd))
-            x = x + xa[torch.arange(M) % R]
-        w = view(p[2], BF16, (N, Kd)).float()
-        y = x @ w.t()
+            ya = (x + xa[torch.arange(M) % R]) @ w.t()
+            if add_cols > 0:
+                y[:, :add_cols] = ya[:, :add_cols]
+            else:
+                y = ya
         if p[3]:
             y = y + view(p[3], F32, (N,))
         if flags & 1:
@@ -313,21 +321,23 @@ class MockExecutor:
         view(p[4], F32, (K, Q, C)).copy_(out)
 
     def _op_19(self, flags, i, f, p):
-        K, Q, C, heads = i[:4]
+        K, Q, C, heads, ldqk, ldv = i[:6]
         hd = C // heads
-        qk = view(p[0], F32, (K, Q, 2 * C))
+        ldqk, ldv = ldqk or 2 * C, ldv or C
+        qk = view(p[0], F32, (K, Q, 2 * C), (Q * ldqk, ldqk, 1))
         q = qk[..., :C].reshape(K, Q, heads, hd).transpose(1, 2)
         k = qk[..., C:].reshape(K, Q, heads, hd).transpose(1, 2)
-        v = view(p[1], F32, (K, Q, C)).view(K, Q, heads, hd).transpose(1, 2)
+        v = view(p[1], F32, (K, Q, C), (Q * ldv, ldv, 1)).reshape(K, Q, heads, hd).transpose(1, 2)
         att = ((q @ k.transpose(-1, -2)) / math.sqrt(hd)).softmax(-1)
         view(p[2], F32, (K, Q, C)).copy_((att @ v).transpose(1, 2).reshape(K, Q, C))
 
     def _op_20(self, flags, i, f, p):
-        K, Q, HW, C, heads, ldq = i[:6]
+        K, Q, HW, C, heads, ldq, ldkv = i[:7]
         hd = C // heads
+        ldkv = ldkv or C
         q = view(p[0], BF16, (K, HW, C), (HW * ldq, ldq, 1)).float().view(K, HW, heads, hd).transpose(1, 2)
-        k = view(p[1], F32, (K, Q, C)).view(K, Q, heads, hd).transpose(1, 2)
-        v = view(p[2], F32, (K, Q, C)).view(K, Q, heads, hd).transpose(1, 2)
+        k = view(p[1], F32, (K, Q, C), (Q * ldkv, ldkv, 1)).reshape(K, Q, heads, hd).transpose(1, 2)
+        v = view(p[2], F32, (K, Q, C), (Q * ldkv, ldkv, 1)).reshape(K, Q, heads, hd).transpose(1, 2)
         att = ((q @ k.transpose(-1, -2)) / math.sqrt(hd)).softmax(-1)
         view(p[3], BF16, (K, HW, C)).copy_((att @ v).transpose(1, 2).reshape(K, HW, C))
 

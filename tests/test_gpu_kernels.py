@@ -351,6 +351,39 @@ def test_linear_broadcast_add_rows():
     check(*run_both(build), name='linear add_rows', rtol=2e-3)
 
 
+@pytest.mark.parametrize('M,Kd,N,ld', [(48, 256, 256, 256), (16, 256, 768, 800), (80, 2048, 256, 256), (5, 384, 40, 48), (48, 264, 256, 256)])
+def test_linear_shapes(M, Kd, N, ld):
+    """Ragged M / N, strided output, K split over the 4 waves (MFMA kernel for Kd % 128 == 0, butterfly kernel otherwise)."""
+    def build(dev, g):
+        x = torch.randn((M, Kd), generator=g).to(dev)
+        pl = pack_linear(torch.randn((N, Kd), generator=g) / math.sqrt(Kd), torch.randn(N, generator=g) * 0.1, dev)
+        res = torch.randn((M, N), generator=g).to(dev)
+        y = torch.zeros((M, ld), dtype=F32, device=dev)
+        ol = O.OpList()
+        ol.linear(x, pl, y, M=M, res=res, ldy=ld)
+        return ol, {'y': y}
+    check(*run_both(build, seed=M + N), name=f'linear {M}x{Kd}x{N}', rtol=2e-3)
+
+
+def test_linear_fused_layernorm_and_add_cols():
+    """LayerNorm fused in front of the projection (normalised rows kept as a side output), positional term feeding only
+    the first add_cols outputs (merged q|k|v)."""
+    def build(dev, g):
+        M, Kd, N = 48, 256, 768
+        x = (torch.randn((M, Kd), generator=g) * 3 + 1).to(dev)
+        xa = torch.randn((M, Kd), generator=g).to(dev)
+        pl = pack_linear(torch.randn((N, Kd), generator=g) / 16, torch.randn(N, generator=g) * 0.1, dev)
+        gw, gb = (torch.rand(Kd, generator=g) + 0.5).to(dev), (torch.randn(Kd, generator=g) * 0.1).to(dev)
+        y = torch.zeros((M, N), dtype=F32, device=dev)
+        xn = torch.zeros((M, Kd), dtype=F32, device=dev)
+        y2 = torch.zeros((M, N), dtype=F32, device=dev)
+        ol = O.OpList()
+        ol.linear(x, pl, y, M=M, x_add=xa, add_rows=M, add_cols=512, ln=(gw, gb), ln_out=xn)
+        ol.linear(x, pl, y2, M=M, relu=True, ln=(gw, gb))
+        return ol, {'y': y, 'xn': xn, 'y2': y2}
+    check(*run_both(build), name='linear ln', rtol=2e-3)
+
+
 # ---- attention -----------------------------------------------------------------------------------------
 def _aux_inputs(g, K, HW, mode):
     lg = torch.randn((K, HW), generator=g) * 2
@@ -388,11 +421,20 @@ def test_attn_self_and_p2q():
         qp = rnd(g, (K, HW, 3 * C), dev=dev)
         kq = torch.randn((K, Q, C), generator=g).to(dev)
         y2 = torch.zeros((K, HW, C), dtype=BF16, device=dev)
+        # the same operands packed the way the merged projections produce them: [q | k | v] rows and [k | v] rows
+        qkv = torch.cat([qk.cpu(), v.cpu()], -1).contiguous().to(dev)
+        kv = torch.cat([kq.cpu(), v.cpu()], -1).contiguous().to(dev)
+        y3 = torch.zeros((K, Q, C), dtype=F32, device=dev)
+        y4 = torch.zeros((K, HW, C), dtype=BF16, device=dev)
         ol = O.OpList()
         ol.attn_self(qk, v, y, K=K, Q=Q, C=C, heads=heads)
         ol.attn_p2q(qp.view(-1)[2 * C:], kq, v, y2, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C)
-        return ol, {'y': y, 'y2': y2}
-    check(*run_both(build), name='attn self/p2q', rtol=None)
+        ol.attn_self(qkv, qkv.view(-1)[2 * C:], y3, K=K, Q=Q, C=C, heads=heads, ldqk=3 * C, ldv=3 * C)
+        ol.attn_p2q(qp.view(-1)[2 * C:], kv, kv.view(-1)[C:], y4, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C, ldkv=2 * C)
+        return ol, {'y': y, 'y2': y2, 'y3': y3, 'y4': y4}
+    hip, ref = run_both(build)
+    check(hip, ref, name='attn self/p2q', rtol=None)
+    assert torch.equal(hip['y'], hip['y3']) and torch.equal(hip['y2'], hip['y4'])
 
 
 def test_summarize_add_pe():
