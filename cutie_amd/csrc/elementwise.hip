@@ -651,6 +651,23 @@ __global__ void cast_kernel(const void* s, void* d, long n, int to_f32) {
     else ((bf16_t*)d)[i] = f2bf(((const float*)s)[i]);
 }
 
+// PROB_TO_ID: id[y,x] = lut[argmax_p prob[p,y,x]] (first maximum wins, like torch.argmax); 4 pixels per thread when aligned.
+template <typename OUT>
+__global__ void prob_to_id_kernel(const float* __restrict__ prob, const int* __restrict__ lut, OUT* __restrict__ out,
+                                  int P, int H, int W, long plane, int ldrow) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)H * W) return;
+    const int yy = (int)(idx / W), xx = (int)(idx - (long)yy * W);
+    const float* src = prob + (long)yy * ldrow + xx;
+    float best = src[0];
+    int arg = 0;
+    for (int q = 1; q < P; ++q) {
+        const float v = src[(long)q * plane];
+        if (v > best) { best = v; arg = q; }
+    }
+    out[idx] = (OUT)lut[arg];
+}
+
 // ---------------------------------------------------------------------------------------------
 int launch_elementwise(const cutie_op* op, hipStream_t s) {
     const int32_t* i = op->i;
@@ -791,6 +808,18 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
         case CUTIE_OP_CAST:
             hipLaunchKernelGGL(cast_kernel, GRID1D(i[0], BS), dim3(BS), 0, s, (const void*)p[0], (void*)p[1], (long)i[0], op->flags & 1);
             break;
+        case CUTIE_OP_PROB_TO_ID: {
+            const long n = (long)i[1] * i[2];
+            const long plane = (long)i[3];
+            if (i[0] < 1) { cutie_set_error("prob_to_id: P >= 1"); return -2; }
+            if ((op->flags & 3) == 0)
+                hipLaunchKernelGGL(prob_to_id_kernel<uint8_t>, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], (const int*)p[1], (uint8_t*)p[2], i[0], i[1], i[2], plane, i[4]);
+            else if ((op->flags & 3) == 1)
+                hipLaunchKernelGGL(prob_to_id_kernel<int32_t>, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], (const int*)p[1], (int32_t*)p[2], i[0], i[1], i[2], plane, i[4]);
+            else
+                hipLaunchKernelGGL(prob_to_id_kernel<long long>, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], (const int*)p[1], (long long*)p[2], i[0], i[1], i[2], plane, i[4]);
+            break;
+        }
         default:
             cutie_set_error("elementwise: unknown op kind %d", op->kind);
             return -3;

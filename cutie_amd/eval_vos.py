@@ -1,0 +1,119 @@
+"""Dataset-level driver: the loop of the reference cutie/eval_vos.py:85-171 without hydra (one InferenceCore per video,
+first-mask alignment, ``end`` on the last frame, FPS = frames / sum of device-event time around ``step``), on top of
+``VOSTestDataset`` / ``VideoReader`` / ``ResultSaver``.
+
+    python -m cutie_amd.eval_vos --images DIR/JPEGImages --masks DIR/Annotations --output OUT [--weights ckpt.pth]
+        [--size 480] [--use-all-masks] [--long-term] [--dataset d17-val] [--visualize] [--clips-in-flight 4]
+
+With several GPUs launch it under torch.distributed.run: videos are sharded over the ranks (cutie_amd/parallel.py)."""
+import argparse
+import logging
+import os
+import time
+from os import path
+from typing import Dict
+
+import torch
+
+from .config import default_config
+from .inference.data.vos_test_dataset import VOSTestDataset
+from .inference.inference_core import InferenceCore
+from .inference.utils.results_utils import ResultSaver, make_zip
+
+log = logging.getLogger()
+
+
+def process_video(network, cfg, vid_reader, mask_output_root, *, dataset='generic', save_all=True, visualize=False,
+                  visualize_output_root=None, lookahead=True) -> Dict:
+    """One video through a fresh InferenceCore (eval_vos.py:97-151).  Returns {'frames', 'seconds'} (time around step)."""
+    processor = InferenceCore(network, cfg=cfg)
+    saver = ResultSaver(mask_output_root, vid_reader.vid_name, dataset=dataset, object_manager=processor.object_manager,
+                        use_long_id=vid_reader.use_long_id, palette=vid_reader.get_palette(), visualize=visualize,
+                        visualize_output_root=visualize_output_root, processor=processor)
+    dev = network.device
+    on_gpu = dev.type == 'cuda'
+    n = len(vid_reader)
+    total, frames, first_mask_loaded = 0.0, 0, False
+    try:
+        nxt = vid_reader[0] if n else None
+        for ti in range(n):
+            data, nxt = nxt, (vid_reader[ti + 1] if ti + 1 < n else None)
+            image = data['rgb'].to(dev)
+            next_image = nxt['rgb'].to(dev) if (nxt is not None and lookahead) else None
+            if nxt is not None and next_image is not None:
+                nxt['rgb'] = next_image                       # the same tensor is handed to the next step (look-ahead match)
+            mask = data.get('mask')
+            mask = mask.to(dev) if mask is not None else None
+            valid = data.get('valid_labels')
+            valid = valid.tolist() if valid is not None else None
+            info = data['info']
+            if not first_mask_loaded:
+                if mask is None:
+                    continue                                  # nothing to do before the first mask
+                first_mask_loaded = True
+            if on_gpu:
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            else:
+                t0 = time.perf_counter()
+            prob = processor.step(image, mask, valid, end=(ti == n - 1), next_image=next_image)
+            if on_gpu:
+                e1.record()
+                torch.cuda.synchronize()
+                total += e0.elapsed_time(e1) / 1000
+            else:
+                total += time.perf_counter() - t0
+            frames += 1
+            if save_all or info['save']:
+                saver.process(prob, info['frame'], resize_needed=info['resize_needed'], shape=info['shape'],
+                              last_frame=(ti == n - 1), path_to_image=info['path_to_image'])
+    finally:
+        saver.end()
+    return {'frames': frames, 'seconds': total}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--images', required=True)
+    ap.add_argument('--masks', required=True)
+    ap.add_argument('--output', required=True)
+    ap.add_argument('--weights')
+    ap.add_argument('--dataset', default='generic')
+    ap.add_argument('--size', type=int, default=-1)
+    ap.add_argument('--subset')
+    ap.add_argument('--use-all-masks', action='store_true')
+    ap.add_argument('--long-term', action='store_true')
+    ap.add_argument('--visualize', action='store_true')
+    ap.add_argument('--clips-in-flight', type=int, default=1)
+    args = ap.parse_args()
+    from .model.cutie import CUTIE
+    from .parallel import run_concurrent, shard_clips
+    import torch.distributed as dist
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    if world > 1:
+        dist.init_process_group(backend='nccl')
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    cfg = default_config(use_long_term=args.long_term)
+    net = CUTIE(cfg).cuda().eval()
+    if args.weights:
+        net.load_weights(torch.load(args.weights, map_location='cpu'))
+    meta = VOSTestDataset(args.images, args.masks, use_all_masks=args.use_all_masks, size=args.size, subset=args.subset)
+    readers = list(meta.get_datasets())
+    mine = shard_clips(len(readers), rank, world)
+    mask_root = path.join(args.output, 'Annotations')
+    run = lambda view, c: process_video(view, cfg, readers[c], mask_root, dataset=args.dataset, visualize=args.visualize,
+                                        visualize_output_root=path.join(args.output, 'Visualizations'))
+    with torch.inference_mode():
+        res = run_concurrent(net, mine, run, streams=max(1, args.clips_in_flight))
+    frames, secs = sum(r['frames'] for r in res.values()), sum(r['seconds'] for r in res.values())
+    print(f'rank {rank}: {frames} frames, {secs:.2f} s in step, FPS {frames / max(secs, 1e-9):.1f}')
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        make_zip(args.dataset, args.output, 'cutie_amd', mask_root)
+
+
+if __name__ == '__main__':
+    main()

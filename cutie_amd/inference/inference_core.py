@@ -14,6 +14,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .. import ops as O
 from ..model import plans
 from .image_feature_store import ImageFeatureStore
 from .memory_manager import MemoryManager
@@ -287,10 +288,24 @@ class InferenceCore:
         self.object_manager.delete_objects(objects)
         self.memory.purge_except(self.object_manager.all_obj_ids)
 
-    def output_prob_to_mask(self, output_prob: torch.Tensor) -> torch.Tensor:
-        mask = torch.argmax(output_prob, dim=0)
-        lut = torch.zeros(output_prob.shape[0], dtype=mask.dtype, device=mask.device)
+    def output_prob_to_mask(self, output_prob: torch.Tensor, *, dtype: torch.dtype = torch.int64) -> torch.Tensor:
+        """inference_core.py:337-345: argmax over the probability planes + tmp-id -> object-id remap, as one kernel
+        (PROB_TO_ID) that reads the un-padded view `step` returned in place.  ``dtype`` (not in the reference): uint8 /
+        int32 / int64 output; the reference returns int64."""
+        P, H, W = output_prob.shape
+        dev = self.network.device
+        lut = [0] * P
         for tmp_id, obj in self.object_manager.tmp_id_to_obj.items():
-            if tmp_id < lut.shape[0]:
-                lut[tmp_id] = obj.id
-        return lut[mask]
+            if tmp_id < P:
+                lut[tmp_id] = int(obj.id)
+        if dtype == torch.uint8 and max(lut) > 255:
+            raise ValueError('object ids above 255 need dtype=torch.int32 / int64')
+        prob = output_prob
+        if prob.dtype != F32 or prob.device != dev or prob.stride(2) != 1:
+            prob = prob.to(device=dev, dtype=F32).contiguous()
+        out = torch.empty((H, W), dtype=dtype, device=dev)
+        ol = O.OpList()
+        ol.prob_to_id(prob, torch.tensor(lut, dtype=torch.int32).to(dev), out, P=P, H=H, W=W, plane=prob.stride(0), ldrow=prob.stride(1))
+        ol.finalize()
+        ol.run()
+        return out

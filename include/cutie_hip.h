@@ -201,6 +201,12 @@ enum {
     CUTIE_OP_CONSOL_READ = 34,
     /* CAST: f32 [n] -> bf16 [n] (flags=0) or bf16 -> f32 (flags=1)   p0=src p1=dst  i: 0 n */
     CUTIE_OP_CAST = 35,
+    /* PROB_TO_ID: id = lut[argmax over the P planes] -- InferenceCore.output_prob_to_mask (inference_core.py:337-345) and
+     * ResultSaver.process (results_utils.py:93-106: argmax + tmp-id -> object-id remap), fused; first maximum wins.
+     * p0=prob f32 (P planes of H x W, plane stride i3 elements, row stride i4: the un-padded view that `step` returns
+     * is addressed in place) p1=lut i32[P] p2=out [H,W] u8 (flags&3 == 0) | i32 (1) | i64 (2)
+     * i: 0 P 1 H 2 W 3 plane stride 4 row stride */
+    CUTIE_OP_PROB_TO_ID = 36,
     CUTIE_OP__COUNT
 };
 

@@ -17,8 +17,8 @@ import torch.nn.functional as F
 
 from cutie_amd import ops as O
 
-BF16, F32, I32, U8, U64 = 'bf16', 'f32', 'i32', 'u8', 'u64'
-_NP = {BF16: (np.uint16, 2), F32: (np.float32, 4), I32: (np.int32, 4), U8: (np.uint8, 1), U64: (np.uint64, 8)}
+BF16, F32, I32, U8, U64, I64 = 'bf16', 'f32', 'i32', 'u8', 'u64', 'i64'
+_NP = {BF16: (np.uint16, 2), F32: (np.float32, 4), I32: (np.int32, 4), U8: (np.uint8, 1), U64: (np.uint64, 8), I64: (np.int64, 8)}
 
 
 def view(ptr, dtype, shape, strides=None):
@@ -508,6 +508,14 @@ class MockExecutor:
         dt = F32 if flags & 1 else BF16
         V = view(p[1], dt, (n, C), (ldv, 1)).float()
         view(p[2], dt, (P, C), (ldo, 1)).copy_(aff @ V)
+
+    def _op_36(self, flags, i, f, p):
+        P, H, W, plane, ldrow = i[:5]
+        prob = view(p[0], F32, (P, H, W), (plane, ldrow, 1))
+        lut = view(p[1], I32, (P,)).long()
+        ids = lut[prob.argmax(0)]
+        dt = {0: U8, 1: I32, 2: I64}[flags & 3]
+        view(p[2], dt, (H, W)).copy_(ids)
 
     def _op_35(self, flags, i, f, p):
         n = i[0]

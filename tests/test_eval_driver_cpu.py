@@ -1,0 +1,98 @@
+"""Section 8(f) rank 1 on CPU: VideoReader / VOSTestDataset / ResultSaver / eval driver on a generated video folder, the HIP ops
+executed by the torch interpreter of the descriptors (tests/mock_exec.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from cutie_amd import _lib
+from cutie_amd.config import default_config
+from cutie_amd.inference.utils.results_utils import davis_palette, davis_palette_np, voc_palette
+from oracle.weights import make_state_dict
+
+from mock_exec import MockExecutor
+
+
+@pytest.fixture(scope='module')
+def product_net():
+    from cutie_amd.model.cutie import CUTIE
+    _lib.set_executor_for_testing(MockExecutor())
+    net = CUTIE(default_config())
+    net.load_weights(make_state_dict(seed=0))
+    yield net
+    _lib.set_executor_for_testing(None)
+
+
+def _make_video(root, name, n=4, h=64, w=96, ids=(1, 3)):
+    from cutie_amd.utils.synth import SyntheticClip
+    clip = SyntheticClip(h, w, len(ids), n, seed=9)
+    os.makedirs(os.path.join(root, 'JPEGImages', name)); os.makedirs(os.path.join(root, 'Annotations', name))
+    for t in range(n):
+        arr = (clip.frame(t).permute(1, 2, 0).numpy() * 255).round().astype(np.uint8)
+        Image.fromarray(arr).save(os.path.join(root, 'JPEGImages', name, f'{t:05d}.jpg'), quality=95)
+    m = clip.first_mask().numpy()
+    lut = np.zeros(256, dtype=np.uint8)
+    for k, oid in enumerate(ids):
+        lut[k + 1] = oid
+    png = Image.fromarray(lut[m].astype(np.uint8))
+    png.putpalette(davis_palette)
+    png.save(os.path.join(root, 'Annotations', name, '00000.png'))
+    return lut[m]
+
+
+def test_palette_is_the_voc_colour_map():
+    assert davis_palette_np.shape == (256, 3)
+    assert davis_palette_np[:4].tolist() == [[0, 0, 0], [128, 0, 0], [0, 128, 0], [128, 128, 0]]
+    assert voc_palette(256)[255].tolist() == [224, 224, 192]
+
+
+def test_video_reader_semantics(tmp_path):
+    from cutie_amd.inference.data.vos_test_dataset import VOSTestDataset
+    first = _make_video(str(tmp_path), 'vidA', n=3, h=64, w=96, ids=(1, 3))
+    ds = VOSTestDataset(os.path.join(tmp_path, 'JPEGImages'), os.path.join(tmp_path, 'Annotations'), use_all_masks=False, size=48)
+    assert len(ds) == 1
+    rd = next(iter(ds.get_datasets()))
+    assert rd.vid_name == 'vidA' and len(rd) == 3 and not rd.use_long_id and rd.get_palette() is not None
+    d0, d1 = rd[0], rd[1]
+    assert d0['rgb'].shape == (3, 48, 72) and d0['rgb'].dtype == torch.float32 and 0 <= float(d0['rgb'].min()) and float(d0['rgb'].max()) <= 1
+    assert d0['info']['resize_needed'] and d0['info']['shape'] == (64, 96) and d0['info']['frame'] == '00000.jpg'
+    assert d0['mask'].shape == (48, 72) and sorted(d0['valid_labels'].tolist()) == [1, 3]
+    assert 'mask' not in d1 and d1['info']['time_index'] == 1
+    full = VOSTestDataset(os.path.join(tmp_path, 'JPEGImages'), os.path.join(tmp_path, 'Annotations'), use_all_masks=False)
+    r0 = next(iter(full.get_datasets()))[0]
+    assert not r0['info']['resize_needed'] and torch.equal(r0['mask'], torch.from_numpy(first).long())
+
+
+def test_eval_driver_writes_palette_pngs(tmp_path, product_net):
+    """Whole loop (reader -> InferenceCore.step -> fused argmax/remap -> writer thread): the first PNG is the input mask with
+    the original object ids and palette; later frames agree with output_prob_to_mask on the same probabilities."""
+    from cutie_amd.eval_vos import process_video
+    from cutie_amd.inference.data.vos_test_dataset import VOSTestDataset
+    from cutie_amd.inference.inference_core import InferenceCore
+    first = _make_video(str(tmp_path), 'vidB', n=3, h=64, w=96, ids=(2, 5))
+    ds = VOSTestDataset(os.path.join(tmp_path, 'JPEGImages'), os.path.join(tmp_path, 'Annotations'), use_all_masks=False)
+    rd = next(iter(ds.get_datasets()))
+    out = os.path.join(tmp_path, 'out')
+    with torch.inference_mode():
+        r = process_video(product_net, default_config(mem_every=2), rd, out, dataset='d17-val', visualize=True,
+                          visualize_output_root=os.path.join(tmp_path, 'vis'))
+        assert r['frames'] == 3 and r['seconds'] > 0
+        files = sorted(os.listdir(os.path.join(out, 'vidB')))
+        assert files == ['00000.png', '00001.png', '00002.png']
+        p0 = Image.open(os.path.join(out, 'vidB', '00000.png'))
+        assert p0.mode == 'P' and p0.getpalette()[:6] == [0, 0, 0, 128, 0, 0]
+        assert np.array_equal(np.array(p0), first)
+        assert sorted(os.listdir(os.path.join(tmp_path, 'vis', 'vidB'))) == ['00000.jpg', '00001.jpg', '00002.jpg']
+        # reference semantics of the id remap on a second pass
+        proc = InferenceCore(product_net, cfg=default_config(mem_every=2))
+        d = [rd[t] for t in range(3)]
+        proc.step(d[0]['rgb'], d[0]['mask'], d[0]['valid_labels'].tolist())
+        prob = proc.step(d[1]['rgb'])
+        ids = proc.output_prob_to_mask(prob)
+        assert ids.dtype == torch.int64 and set(torch.unique(ids).tolist()) <= {0, 2, 5}
+        lut = torch.tensor([0, 2, 5])
+        assert torch.equal(ids, lut[prob.argmax(0)])
+        assert np.array_equal(np.array(Image.open(os.path.join(out, 'vidB', '00001.png'))), ids.numpy().astype(np.uint8))
+        assert torch.equal(proc.output_prob_to_mask(prob, dtype=torch.uint8).long(), ids)

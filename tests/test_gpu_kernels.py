@@ -604,3 +604,21 @@ def test_consolidation_kernels():
         ol.consol_read(aff, cs, outs, n=n, P=P, C=1, ldv=1, ldo=1, f32=True)
         return ol, {'aff': aff, 'out': out, 'outs': outs}
     check(*run_both(build), name='consolidation', rtol=None)
+
+
+@pytest.mark.parametrize('dt', [torch.uint8, torch.int32, torch.int64])
+def test_prob_to_id(dt):
+    """argmax + id remap on the un-padded, strided view that InferenceCore.step returns; ties -> first plane."""
+    def build(dev, g):
+        P, Hp, Wp, H, W = 4, 48, 64, 45, 59
+        full = torch.rand((P, Hp, Wp), generator=g)
+        full[1, 5:9] = full[2, 5:9]                               # exact ties between planes 1 and 2
+        full = full.to(dev)
+        prob = full[:, 2:2 + H, 3:3 + W]
+        lut = torch.tensor([0, 7, 3, 200], dtype=torch.int32).to(dev)
+        out = torch.zeros((H, W), dtype=dt, device=dev)
+        ol = O.OpList()
+        ol.prob_to_id(prob, lut, out, P=P, H=H, W=W, plane=prob.stride(0), ldrow=prob.stride(1))
+        return ol, {'out': out}
+    hip, ref = run_both(build)
+    assert torch.equal(hip['out'], ref['out'])

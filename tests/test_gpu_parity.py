@@ -233,6 +233,40 @@ def test_concurrent_clips_match_sequential(gpu_net):
         assert torch.equal(conc[c], seq[c]), (c, float((conc[c] - seq[c]).abs().max()))
 
 
+def test_eval_driver_on_bike_example(gpu_net, tmp_path):
+    """Section 8(f) rank 1: the bike frames through VideoReader -> InferenceCore -> fused argmax/remap -> PNG writer; the first
+    PNG reproduces the annotation, every PNG equals output_prob_to_mask of a second pass."""
+    import os
+    import shutil
+    import numpy as np
+    from PIL import Image
+    from cutie_amd.eval_vos import process_video
+    from cutie_amd.inference.data.video_reader import VideoReader
+    from cutie_amd.inference.inference_core import InferenceCore
+    src = os.path.join(os.path.dirname(__file__), 'golden', 'bike')
+    img_dir, msk_dir = os.path.join(tmp_path, 'JPEGImages', 'bike'), os.path.join(tmp_path, 'Annotations', 'bike')
+    os.makedirs(img_dir); os.makedirs(msk_dir)
+    for f in sorted(os.listdir(src)):
+        shutil.copy(os.path.join(src, f), img_dir if f.endswith('.jpg') else msk_dir)
+    rd = VideoReader('bike', img_dir, msk_dir)
+    out = os.path.join(tmp_path, 'out')
+    cfg = default_config()
+    with torch.inference_mode():
+        r = process_video(gpu_net, cfg, rd, out, dataset='d17-val')
+        assert r['frames'] == len(rd)
+        ann = np.array(Image.open(os.path.join(msk_dir, sorted(os.listdir(msk_dir))[0])))
+        assert np.array_equal(np.array(Image.open(os.path.join(out, 'bike', rd.frames[0][:-4] + '.png'))), ann)
+        proc = InferenceCore(gpu_net, cfg=cfg)
+        for t in range(len(rd)):
+            d = rd[t]
+            prob = proc.step(d['rgb'].cuda(), d['mask'].cuda() if 'mask' in d else None,
+                             d['valid_labels'].tolist() if 'valid_labels' in d else None, end=(t == len(rd) - 1))
+            ids = proc.output_prob_to_mask(prob)
+            assert ids.dtype == torch.int64 and ids.shape == ann.shape
+            png = np.array(Image.open(os.path.join(out, 'bike', rd.frames[t][:-4] + '.png')))
+            assert np.array_equal(png, ids.cpu().numpy().astype(np.uint8)), t
+
+
 def test_product_requires_hip_library():
     """No CPU fallback: a CPU-resident module must refuse to run."""
     from cutie_amd.model.cutie import CUTIE
