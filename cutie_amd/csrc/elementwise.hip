@@ -651,6 +651,27 @@ __global__ void cast_kernel(const void* s, void* d, long n, int to_f32) {
     else ((bf16_t*)d)[i] = f2bf(((const float*)s)[i]);
 }
 
+// RESIZE: F.interpolate(size=(OH,OW)) of C planes, mode bilinear (align_corners=False, no antialias) or nearest-exact.
+__global__ void resize_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W, int OH, int OW,
+                              long splane, int sld, int nearest) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)C * OH * OW) return;
+    const int ox = (int)(idx % OW), oy = (int)((idx / OW) % OH), c = (int)(idx / ((long)OW * OH));
+    const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
+    const float* p = src + (long)c * splane;
+    if (nearest) {
+        const int iy = min((int)floorf((oy + 0.5f) * sy), H - 1), ix = min((int)floorf((ox + 0.5f) * sx), W - 1);
+        dst[idx] = p[(long)iy * sld + ix];
+        return;
+    }
+    const float fy = fmaxf((oy + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf((ox + 0.5f) * sx - 0.5f, 0.f);
+    const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float a = p[(long)y0 * sld + x0], b = p[(long)y0 * sld + x1], cc = p[(long)y1 * sld + x0], d = p[(long)y1 * sld + x1];
+    dst[idx] = (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * cc + lx * d);
+}
+
 // PROB_TO_ID: id[y,x] = lut[argmax_p prob[p,y,x]] (first maximum wins, like torch.argmax); 4 pixels per thread when aligned.
 template <typename OUT>
 __global__ void prob_to_id_kernel(const float* __restrict__ prob, const int* __restrict__ lut, OUT* __restrict__ out,
@@ -808,6 +829,13 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
         case CUTIE_OP_CAST:
             hipLaunchKernelGGL(cast_kernel, GRID1D(i[0], BS), dim3(BS), 0, s, (const void*)p[0], (void*)p[1], (long)i[0], op->flags & 1);
             break;
+        case CUTIE_OP_RESIZE: {
+            const long n = (long)i[0] * i[3] * i[4];
+            if (i[1] < 1 || i[2] < 1 || i[3] < 1 || i[4] < 1) { cutie_set_error("resize: empty shape"); return -2; }
+            hipLaunchKernelGGL(resize_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], i[0], i[1], i[2], i[3], i[4],
+                               (long)i[5], i[6], op->flags & 1);
+            break;
+        }
         case CUTIE_OP_PROB_TO_ID: {
             const long n = (long)i[1] * i[2];
             const long plane = (long)i[3];

@@ -12,7 +12,6 @@ from typing import List, Optional
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from .. import ops as O
 from ..model import plans
@@ -115,6 +114,20 @@ class InferenceCore:
         # (the source tensor is kept referenced until the next step: its address cannot be recycled for another frame)
         self._prefetched = (src_key, prepared, feats, ev, image)
 
+    def _resize(self, x: torch.Tensor, size, *, nearest: bool = False) -> torch.Tensor:
+        """F.interpolate(x[None], size, bilinear align_corners=False | nearest-exact)[0] for f32 [C,H,W] as the RESIZE kernel."""
+        dev = self.network.device
+        x = x.to(device=dev, dtype=F32)
+        if x.stride(2) != 1:
+            x = x.contiguous()
+        C, H, W = x.shape
+        out = torch.empty((C, int(size[0]), int(size[1])), dtype=F32, device=dev)
+        ol = O.OpList()
+        ol.resize(x, out, C=C, H=H, W=W, OH=out.shape[1], OW=out.shape[2], plane=x.stride(0), ldrow=x.stride(1), nearest=nearest)
+        ol.finalize()
+        ol.run()
+        return out
+
     def clear_memory(self):
         self.curr_ti = -1
         self.last_mem_ti = 0
@@ -184,17 +197,16 @@ class InferenceCore:
             h, w = image.shape[-2:]
             min_side = min(h, w)
             if min_side > self.max_internal_size:
-                # GUI-only path of the reference (:206-228); torch resampling, not a HIP kernel yet
+                # internal-resolution path of the reference (:206-228), RESIZE kernel
                 resize_needed = True
                 new_h = int(h / min_side * self.max_internal_size)
                 new_w = int(w / min_side * self.max_internal_size)
-                image = F.interpolate(image.unsqueeze(0), size=(new_h, new_w), mode='bilinear', align_corners=False)[0]
+                image = self._resize(image, (new_h, new_w))
                 if mask is not None:
                     if idx_mask:
-                        mask = F.interpolate(mask.unsqueeze(0).unsqueeze(0).float(), size=(new_h, new_w),
-                                             mode='nearest-exact')[0, 0].round().long()
+                        mask = self._resize(mask.unsqueeze(0).float(), (new_h, new_w), nearest=True)[0].round().long()
                     else:
-                        mask = F.interpolate(mask.unsqueeze(0), size=(new_h, new_w), mode='bilinear', align_corners=False)[0]
+                        mask = self._resize(mask, (new_h, new_w))
 
         self.curr_ti += 1
         pre, self._prefetched = self._prefetched, None
@@ -246,7 +258,7 @@ class InferenceCore:
 
         output_prob = unpad(pred_prob_with_bg, self.pad)
         if resize_needed:
-            output_prob = F.interpolate(output_prob.unsqueeze(0), size=(h, w), mode='bilinear', align_corners=False)[0]
+            output_prob = self._resize(output_prob, (h, w))
         return output_prob
 
     def _mask_to_prob(self, mask, objects, tmp_ids, idx_mask, need_segment, pred, k_old, k_new, h0, w0, H, W, pl, pt):

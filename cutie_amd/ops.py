@@ -17,13 +17,13 @@ assert OP_DTYPE.itemsize == _lib.OP_STRUCT_SIZE
 (CONV, MAXPOOL, IMG_PREP, UPSAMPLE2X_ADD, AREA_DOWN, MASK_DOWN, GAP, ECA_APPLY, GRU, SEG_AGG, UP4_SOFTMAX,
  MASK_MERGE, AGG_SOFTMAX, LINEAR, LAYERNORM, QUERY_INIT, AUX_MASK, ATTN_Q2P, ATTN_SELF, ATTN_P2Q, SUMMARIZE,
  ADD_PE, KEY_PREP, AFF_SCORE, AFF_SELECT, AFF_READOUT, MEMSET32, COPY2D, AXPY, USAGE_TICK, RANK_SELECT,
- GATHER_ROWS, CONSOL_AFF, CONSOL_READ, CAST, PROB_TO_ID) = range(1, 37)
+ GATHER_ROWS, CONSOL_AFF, CONSOL_READ, CAST, PROB_TO_ID, RESIZE) = range(1, 38)
 
 KIND_NAMES = {}
 for _n in ('CONV MAXPOOL IMG_PREP UPSAMPLE2X_ADD AREA_DOWN MASK_DOWN GAP ECA_APPLY GRU SEG_AGG UP4_SOFTMAX MASK_MERGE '
            'AGG_SOFTMAX LINEAR LAYERNORM QUERY_INIT AUX_MASK ATTN_Q2P ATTN_SELF ATTN_P2Q SUMMARIZE ADD_PE KEY_PREP '
            'AFF_SCORE AFF_SELECT AFF_READOUT MEMSET32 COPY2D AXPY USAGE_TICK RANK_SELECT GATHER_ROWS CONSOL_AFF '
-           'CONSOL_READ CAST PROB_TO_ID').split():
+           'CONSOL_READ CAST PROB_TO_ID RESIZE').split():
     KIND_NAMES[globals()[_n]] = _n
 
 F_RELU_IN, F_OUT_F32, F_RES_BCAST = 1, 2, 4
@@ -341,6 +341,9 @@ class OpList:
         """out dtype picks the kernel: uint8 / int32 / int64."""
         code = {torch.uint8: 0, torch.int32: 1, torch.int64: 2}[out.dtype]
         return self.add(PROB_TO_ID, code, [P, H, W, plane, ldrow], [], [prob, lut, out])
+
+    def resize(self, src, dst, *, C, H, W, OH, OW, plane, ldrow, nearest=False):
+        return self.add(RESIZE, 1 if nearest else 0, [C, H, W, OH, OW, plane, ldrow], [], [src, dst])
 
     def cast(self, src, dst, *, n, to_f32=False):
         return self.add(CAST, 1 if to_f32 else 0, [n], [], [src, dst])

@@ -207,6 +207,10 @@ enum {
      * is addressed in place) p1=lut i32[P] p2=out [H,W] u8 (flags&3 == 0) | i32 (1) | i64 (2)
      * i: 0 P 1 H 2 W 3 plane stride 4 row stride */
     CUTIE_OP_PROB_TO_ID = 36,
+    /* RESIZE: F.interpolate(x, size=(OH,OW)) -- the max_internal_size path of InferenceCore.step (inference_core.py:206-228,
+     * 321-326): bilinear align_corners=False without antialias (flags&1 == 0) or nearest-exact (flags&1, index masks).
+     * p0=src f32 (C planes of H x W, plane stride i5, row stride i6) p1=dst f32 [C,OH,OW]   i: 0 C 1 H 2 W 3 OH 4 OW 5 6 */
+    CUTIE_OP_RESIZE = 37,
     CUTIE_OP__COUNT
 };
 

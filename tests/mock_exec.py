@@ -509,6 +509,15 @@ class MockExecutor:
         V = view(p[1], dt, (n, C), (ldv, 1)).float()
         view(p[2], dt, (P, C), (ldo, 1)).copy_(aff @ V)
 
+    def _op_37(self, flags, i, f, p):
+        C, H, W, OH, OW, plane, ldrow = i[:7]
+        src = view(p[0], F32, (C, H, W), (plane, ldrow, 1)).clone().unsqueeze(0)
+        if flags & 1:
+            out = F.interpolate(src, size=(OH, OW), mode='nearest-exact')
+        else:
+            out = F.interpolate(src, size=(OH, OW), mode='bilinear', align_corners=False)
+        view(p[1], F32, (C, OH, OW)).copy_(out[0])
+
     def _op_36(self, flags, i, f, p):
         P, H, W, plane, ldrow = i[:5]
         prob = view(p[0], F32, (P, H, W), (plane, ldrow, 1))

@@ -622,3 +622,22 @@ def test_prob_to_id(dt):
         return ol, {'out': out}
     hip, ref = run_both(build)
     assert torch.equal(hip['out'], ref['out'])
+
+
+@pytest.mark.parametrize('nearest', [False, True])
+@pytest.mark.parametrize('shape', [((3, 37, 53), (24, 35)), ((4, 30, 54), (480, 854)), ((1, 97, 61), (48, 31))])
+def test_resize(shape, nearest):
+    """F.interpolate(size=...) bilinear align_corners=False / nearest-exact, up- and down-sampling, strided source view."""
+    (C, H, W), (OH, OW) = shape
+    def build(dev, g):
+        full = torch.rand((C, H + 3, W + 5), generator=g).to(dev)
+        src = full[:, 1:1 + H, 2:2 + W]
+        out = torch.zeros((C, OH, OW), dtype=F32, device=dev)
+        ol = O.OpList()
+        ol.resize(src, out, C=C, H=H, W=W, OH=OH, OW=OW, plane=src.stride(0), ldrow=src.stride(1), nearest=nearest)
+        return ol, {'out': out}
+    hip, ref = run_both(build)
+    if nearest:
+        assert torch.equal(hip['out'], ref['out'])
+    else:
+        check(hip, ref, name='resize', rtol=1e-5)
