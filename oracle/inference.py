@@ -216,6 +216,30 @@ class OracleProcessor:
         self.engaged = False
         self.HW = None
 
+    # ---- interactive surface (inference_core.py:52-69, memory_manager.py:59-75,377-380) ------------
+    def clear_non_permanent_memory(self):
+        self.curr_ti, self.last_mem_ti = -1, 0
+        for b in list(self.work.buckets):
+            self.work.sieve(b, 0, 0, 0)                               # kv_memory_store.py:305-308
+        if self.use_long_term:
+            for b in list(self.long.buckets):
+                self.long.sieve(b, 0, 0, 0)
+
+    def update_config(self, cfg):
+        cfg = dict(DEFAULT_CFG, **cfg) if isinstance(cfg, dict) else cfg
+        self.mem_every = cfg['mem_every']
+        self.top_k = cfg['top_k']
+        lt = cfg['long_term']
+        assert self.use_long_term == cfg['use_long_term'] and self.count_lt_usage == lt['count_usage'], 'cannot update this'
+        if self.use_long_term:
+            self.max_mem_frames = lt['max_mem_frames'] - 1
+            self.min_mem_frames = lt['min_mem_frames'] - 1
+            self.num_prototypes = lt['num_prototypes']
+            self.max_long_tokens = lt['max_num_tokens']
+            self.buffer_tokens = lt['buffer_tokens']
+        else:
+            self.max_mem_frames = cfg['max_mem_frames'] - 1
+
     # ---- object manager ----------------------------------------------------------
     def _add_objects(self, objects):
         tmp = []

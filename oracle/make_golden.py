@@ -50,10 +50,14 @@ def import_reference():
     om.DictConfig = DictConfig
     om.open_dict = None
     sys.modules['omegaconf'] = om
-    # the repo root carries a drop-in `cutie` alias package; make sure the reference wins here
-    sys.path = [p for p in sys.path if os.path.abspath(p or '.') != os.path.abspath(os.path.join(HERE, '..'))]
-    sys.path.insert(0, REF)
-    sys.path.append(os.path.abspath(os.path.join(HERE, '..')))
+    # The repo root carries a drop-in `cutie` alias package, and the reference's `cutie` is a namespace package (no
+    # __init__.py): a regular package anywhere on sys.path would win.  So: import what this script needs from the repo
+    # first, then take the repo root off the path and let `cutie` resolve to the reference.
+    root = os.path.abspath(os.path.join(HERE, '..'))
+    if root not in [os.path.abspath(p or '.') for p in sys.path]:
+        sys.path.append(root)
+    import oracle.weights, oracle.scenarios, cutie_amd.utils.synth        # noqa: F401,E401
+    sys.path = [REF] + [p for p in sys.path if os.path.abspath(p or '.') != root]
     for k in [k for k in sys.modules if k == 'cutie' or k.startswith('cutie.')]:
         del sys.modules[k]
     from cutie.model.utils import resnet
@@ -124,7 +128,10 @@ def main():
     print('reference state_dict:', len(ref_sd), 'tensors,', sum(v.numel() for v in ref_sd.values()) / 1e6, 'M')
 
     # ---- scenario trajectories ------------------------------------------------------
+    only = [a for a in sys.argv[1:] if a in S.SCENARIOS]          # e.g. `python oracle/make_golden.py small_interactive`
     for name, sc in S.SCENARIOS.items():
+        if only and name not in only:
+            continue
         sizes = []
 
         def make(over):
@@ -134,13 +141,16 @@ def main():
                 proc.max_internal_size = over['max_internal_size']
             return proc
 
-        outs, proc = S.run_scenario(make, name, record=lambda t, p: sizes.append(memory_sizes(p)))
+        wrap = lambda over: reference_cfg(**{k: (_wrap(v) if isinstance(v, dict) else v) for k, v in over.items()})
+        outs, proc = S.run_scenario(make, name, record=lambda t, p: sizes.append(memory_sizes(p)), make_cfg=wrap)
         rec = S.summarize(outs, sc['sub'])
         rec['mem_sizes'] = np.array(sizes, dtype=np.int64)
         np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), **rec)
         print(name, 'frames', len(outs), 'shape', tuple(outs[-1].shape), 'mem', sizes[-1],
               'hist', rec[f'hist_{len(outs) - 1}'])
 
+    if only:
+        return
     # ---- per-stage probes of the facade methods -----------------------------------------
     from cutie_amd.utils.synth import SyntheticClip
     clip = SyntheticClip(128, 192, 3, 4, seed=5)

@@ -30,6 +30,11 @@ SCENARIOS = {
     # (scripting_demo_add_del_objects.py pattern)
     'small_add_del': dict(cfg=dict(mem_every=3), kind='synth', h=112, w=128, k=4, frames=16, sub=2,
                           add_at={0: [1], 4: [2], 7: [3, 4]}, delete_at={10: [1]}),
+    # interactive surface (gui/main_controller.py:303-368, scripts/process_video.py): a corrected mask committed as permanent
+    # memory (force_permanent -> prepend to the permanent part), update_config (mem_every 2 -> 3), clear_non_permanent_memory
+    'small_interactive': dict(cfg=dict(mem_every=2, max_mem_frames=3), kind='synth', h=96, w=128, k=3, frames=15, sub=2,
+                              add_at={0: [1, 2, 3], 5: [1, 2, 3]}, permanent_at=[5], update_config_at={8: dict(mem_every=3)},
+                              clear_non_permanent_at=[11]),
 }
 
 
@@ -68,8 +73,10 @@ def scenario_inputs(name):
     return steps, sc.get('delete_at', {})
 
 
-def run_scenario(make_processor, name, device='cpu', record=None):
-    """make_processor(cfg_overrides) -> processor.  Returns list of per-frame prob tensors (cpu fp32)."""
+def run_scenario(make_processor, name, device='cpu', record=None, make_cfg=None):
+    """make_processor(cfg_overrides) -> processor.  Returns list of per-frame prob tensors (cpu fp32).
+    make_cfg(cfg_overrides) -> the config object handed to update_config (defaults to the override dict merged by the
+    processor factory's own rules: pass the factory's config builder)."""
     sc = SCENARIOS[name]
     proc = make_processor(sc['cfg'])
     steps, deletes = scenario_inputs(name)
@@ -78,9 +85,15 @@ def run_scenario(make_processor, name, device='cpu', record=None):
         for t, (img, mask, objs) in enumerate(steps):
             if t in deletes:
                 proc.delete_objects(deletes[t])
+            if t in sc.get('update_config_at', {}):
+                over = dict(sc['cfg'])
+                over.update(sc['update_config_at'][t])
+                proc.update_config(make_cfg(over) if make_cfg is not None else over)
+            if t in sc.get('clear_non_permanent_at', ()):
+                proc.clear_non_permanent_memory()
             img = img.to(device)
             if mask is not None:
-                p = proc.step(img, mask.to(device), objects=objs)
+                p = proc.step(img, mask.to(device), objects=objs, force_permanent=(t in sc.get('permanent_at', ())))
             else:
                 p = proc.step(img)
             outs.append(p.detach().float().cpu())

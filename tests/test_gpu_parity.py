@@ -88,7 +88,7 @@ def _mem_sizes(p):
             sum(b.n_long for b in m.buckets.values()), len(m.buckets)]
 
 
-@pytest.mark.parametrize('name', ['small_fifo', 'small_add_del', 'small_lt', 'bike'])
+@pytest.mark.parametrize('name', ['small_fifo', 'small_add_del', 'small_lt', 'small_interactive', 'bike'])
 def test_trajectory_matches_oracle_gpu(name, gpu_net, oracle_net):
     from cutie_amd.inference.inference_core import InferenceCore
     gold = np.load(S.GOLDEN_DIR + f'/{name}.npz')
@@ -104,7 +104,8 @@ def test_trajectory_matches_oracle_gpu(name, gpu_net, oracle_net):
         return proc
 
     oouts, oproc = S.run_scenario(make_o, name)
-    outs, proc = S.run_scenario(make_p, name, device='cuda', record=lambda t, p: sizes.append(_mem_sizes(p)))
+    outs, proc = S.run_scenario(make_p, name, device='cuda', record=lambda t, p: sizes.append(_mem_sizes(p)),
+                                make_cfg=lambda over: default_config(**over))
     assert np.array_equal(np.array(sizes), gold['mem_sizes'])
     report = []
     for t, (p, o) in enumerate(zip(outs, oouts)):

@@ -100,11 +100,11 @@ def _run_product(net, name):
         sizes.append([sum(b.n_perm + b.n_work for b in m.buckets.values()), sum(b.n_perm for b in m.buckets.values()),
                       sum(b.n_long for b in m.buckets.values()), len(m.buckets)])
 
-    outs, proc = S.run_scenario(make, name, record=rec)
+    outs, proc = S.run_scenario(make, name, record=rec, make_cfg=lambda over: default_config(**over))
     return outs, sizes
 
 
-@pytest.mark.parametrize('name', ['small_fifo', 'small_add_del', 'small_lt'])
+@pytest.mark.parametrize('name', ['small_fifo', 'small_add_del', 'small_lt', 'small_interactive'])
 def test_trajectory_matches_oracle(name, product_net, oracle_net):
     gold = np.load(S.GOLDEN_DIR + f'/{name}.npz')
 
