@@ -672,6 +672,18 @@ __global__ void resize_kernel(const float* __restrict__ src, float* __restrict__
     dst[idx] = (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * cc + lx * d);
 }
 
+// FLIP_W: dst[c,y,x] = alpha * src[c,y,W-1-x] + beta * dst[c,y,x]  (beta == 0: dst is not read)
+__global__ void flip_w_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows, int W, int slds, int dlds,
+                              float alpha, float beta) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * W) return;
+    const long r = idx / W;
+    const int x = (int)(idx - r * W);
+    const float v = alpha * src[r * slds + (W - 1 - x)];
+    float* d = dst + r * dlds + x;
+    *d = beta != 0.f ? v + beta * *d : v;
+}
+
 // PROB_TO_ID: id[y,x] = lut[argmax_p prob[p,y,x]] (first maximum wins, like torch.argmax); 4 pixels per thread when aligned.
 template <typename OUT>
 __global__ void prob_to_id_kernel(const float* __restrict__ prob, const int* __restrict__ lut, OUT* __restrict__ out,
@@ -828,6 +840,11 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             break;
         case CUTIE_OP_CAST:
             hipLaunchKernelGGL(cast_kernel, GRID1D(i[0], BS), dim3(BS), 0, s, (const void*)p[0], (void*)p[1], (long)i[0], op->flags & 1);
+            break;
+        case CUTIE_OP_FLIP_W:
+            if (i[0] < 1 || i[1] < 1) { cutie_set_error("flip_w: empty shape"); return -2; }
+            hipLaunchKernelGGL(flip_w_kernel, GRID1D((long)i[0] * i[1], BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (long)i[0], i[1], i[2], i[3],
+                               op->f[0], op->f[1]);
             break;
         case CUTIE_OP_RESIZE: {
             const long n = (long)i[0] * i[3] * i[4];

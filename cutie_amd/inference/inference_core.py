@@ -5,7 +5,8 @@ Kept from the reference (file:line): memory-frame / segmentation / sensory-updat
 stagger_ti (:37-41), mask merge semantics (:259-300), last_mask = prob[1:] (:302), memorise (:308-315),
 unpad (:320), optional internal resize (:206-228, :321-326), delete_objects (:330-335),
 output_prob_to_mask (:337-345).
-Not supported yet (raises): flip_aug (bs=2), chunk_size > 0 -- SURVEY.md section 8f rank 4.
+flip_aug (the reference's batch of [frame, flipped frame], :142-143,162-165,234-235,303-305) runs as a second lane with its
+own memory bank; chunk_size is accepted (no effect: objects are always batched).
 """
 import logging
 from typing import List, Optional
@@ -42,7 +43,7 @@ def unpad(img: torch.Tensor, pad) -> torch.Tensor:
 
 
 class InferenceCore:
-    def __init__(self, network, cfg, *, image_feature_store: ImageFeatureStore = None):
+    def __init__(self, network, cfg, *, image_feature_store: ImageFeatureStore = None, _lane_of: 'InferenceCore' = None):
         self.network = network
         self.cfg = cfg
         self.mem_every = cfg.mem_every
@@ -50,19 +51,24 @@ class InferenceCore:
         self.chunk_size = cfg.chunk_size
         self.save_aux = cfg.save_aux
         self.max_internal_size = cfg.max_internal_size
-        self.flip_aug = cfg.flip_aug
-        if self.flip_aug:
-            raise NotImplementedError('flip_aug (batch of 2) is not supported by the HIP path yet')
+        # flip_aug: the reference pushes [frame, flipped frame] through everything as a batch of two; the two batch elements
+        # interact only through the averaged prediction, so the flipped one is a second lane (= a nested core sharing the
+        # object manager, with its own memory bank / sensory state / feature store) instead of a batch dimension in every plan
+        self.flip_aug = bool(cfg.flip_aug) and _lane_of is None
+        # chunk_size (big_modules.py:141-180,267-302) only bounds the reference's activation memory by looping over groups of
+        # objects; objects are independent in those stages, so the result does not depend on it.  The HIP plans always run
+        # every object in one batch (288 GB of HBM), i.e. the setting is accepted and has no effect.
         if self.chunk_size is not None and self.chunk_size > 0:
-            raise NotImplementedError('chunk_size > 0 is not supported by the HIP path yet (all objects run batched)')
+            log.info('chunk_size=%d accepted: the HIP path batches all objects, results are identical', self.chunk_size)
         self.curr_ti = -1
         self.last_mem_ti = 0
         if stagger_updates >= self.mem_every:
             self.stagger_ti = set(range(1, self.mem_every + 1))
         else:
             self.stagger_ti = set(np.round(np.linspace(1, self.mem_every, stagger_updates)).astype(int))
-        self.object_manager = ObjectManager()
+        self.object_manager = ObjectManager() if _lane_of is None else _lane_of.object_manager
         self.memory = MemoryManager(cfg=cfg, object_manager=self.object_manager)
+        self._flip = InferenceCore(network, cfg, _lane_of=self) if self.flip_aug else None
         self.image_feature_store = ImageFeatureStore(self.network) if image_feature_store is None else image_feature_store
         self.last_mask = None
         self.pad = (0, 0, 0, 0)
@@ -128,24 +134,46 @@ class InferenceCore:
         ol.run()
         return out
 
+    def _flip_w(self, x: torch.Tensor, out: torch.Tensor = None, alpha: float = 1.0, beta: float = 0.0) -> torch.Tensor:
+        """out = alpha * torch.flip(x, dims=[-1]) + beta * out (FLIP_W kernel); x f32 with a contiguous last dimension."""
+        x = x.to(device=self.network.device, dtype=F32)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        if out is None:
+            out = torch.empty_like(x)
+        W = x.shape[-1]
+        ol = O.OpList()
+        ol.flip_w(x, out, rows=x.numel() // W, W=W, alpha=alpha, beta=beta)
+        ol.finalize()
+        ol.run()
+        return out
+
     def clear_memory(self):
         self.curr_ti = -1
         self.last_mem_ti = 0
         self.memory = MemoryManager(cfg=self.cfg, object_manager=self.object_manager)
+        if self._flip is not None:
+            self._flip.clear_memory()
 
     def clear_non_permanent_memory(self):
         self.curr_ti = -1
         self.last_mem_ti = 0
         self.memory.clear_non_permanent_memory()
+        if self._flip is not None:
+            self._flip.clear_non_permanent_memory()
 
     def clear_sensory_memory(self):
         self.curr_ti = -1
         self.last_mem_ti = 0
         self.memory.clear_sensory_memory()
+        if self._flip is not None:
+            self._flip.clear_sensory_memory()
 
     def update_config(self, cfg):
         self.mem_every = cfg['mem_every']
         self.memory.update_config(cfg)
+        if self._flip is not None:
+            self._flip.update_config(cfg)
 
     # ---- memorise (inference_core.py:71-121) ------------------------------------------------------------------
     def _add_memory(self, image, pix_feat, prob, key, shrinkage, selection, *, is_deep_update=True, force_permanent=False):
@@ -229,11 +257,23 @@ class InferenceCore:
 
         ms_feat, pix_feat = self.image_feature_store.get_features(self.curr_ti, image)
         key, shrinkage, selection = self.image_feature_store.get_key(self.curr_ti, image)
-        if next_image is not None and not end:
+        fl = self._flip
+        if fl is not None:
+            # the reference flips the PADDED frame (:231-235): flipping the raw frame swaps the left / right pads
+            fl.curr_ti, fl.pad = self.curr_ti, self.pad
+            image_f = self._flip_w(image)
+            image_f._cutie_raw = (h0, w0, H, W, self.pad[1], pt)
+            ms_f, pix_f = fl.image_feature_store.get_features(self.curr_ti, image_f)
+            key_f, shr_f, sel_f = fl.image_feature_store.get_key(self.curr_ti, image_f)
+        elif next_image is not None and not end:
             self.prefetch(next_image)
 
         if need_segment:
             pred_prob_with_bg = self._segment(key, selection, pix_feat, ms_feat, update_sensory=update_sensory)
+            if fl is not None:
+                pred_f = fl._segment(key_f, sel_f, pix_f, ms_f, update_sensory=update_sensory)
+                if self.memory.engaged:                        # average of the pass and the un-flipped flipped pass (:162-165)
+                    pred_prob_with_bg = self._flip_w(pred_f, out=pred_prob_with_bg.contiguous(), alpha=0.5, beta=0.5)
 
         if mask is not None:
             k_old = self.object_manager.num_obj
@@ -249,12 +289,18 @@ class InferenceCore:
                                                    h0, w0, H, W, pl, pt)
 
         self.last_mask = pred_prob_with_bg[1:].unsqueeze(0)
+        if fl is not None:
+            fl.last_mask = self._flip_w(self.last_mask)        # (:303-305)
 
         if is_mem_frame or force_permanent:
             self._add_memory(image, pix_feat, self.last_mask, key, shrinkage, selection, force_permanent=force_permanent)
+            if fl is not None:
+                fl._add_memory(image_f, pix_f, fl.last_mask, key_f, shr_f, sel_f, force_permanent=force_permanent)
 
         if delete_buffer:
             self.image_feature_store.delete(self.curr_ti)
+            if fl is not None:
+                fl.image_feature_store.delete(self.curr_ti)
 
         output_prob = unpad(pred_prob_with_bg, self.pad)
         if resize_needed:
@@ -299,6 +345,8 @@ class InferenceCore:
     def delete_objects(self, objects: List[int]) -> None:
         self.object_manager.delete_objects(objects)
         self.memory.purge_except(self.object_manager.all_obj_ids)
+        if self._flip is not None:
+            self._flip.memory.purge_except(self.object_manager.all_obj_ids)
 
     def output_prob_to_mask(self, output_prob: torch.Tensor, *, dtype: torch.dtype = torch.int64) -> torch.Tensor:
         """inference_core.py:337-345: argmax over the probability planes + tmp-id -> object-id remap, as one kernel

@@ -17,13 +17,13 @@ assert OP_DTYPE.itemsize == _lib.OP_STRUCT_SIZE
 (CONV, MAXPOOL, IMG_PREP, UPSAMPLE2X_ADD, AREA_DOWN, MASK_DOWN, GAP, ECA_APPLY, GRU, SEG_AGG, UP4_SOFTMAX,
  MASK_MERGE, AGG_SOFTMAX, LINEAR, LAYERNORM, QUERY_INIT, AUX_MASK, ATTN_Q2P, ATTN_SELF, ATTN_P2Q, SUMMARIZE,
  ADD_PE, KEY_PREP, AFF_SCORE, AFF_SELECT, AFF_READOUT, MEMSET32, COPY2D, AXPY, USAGE_TICK, RANK_SELECT,
- GATHER_ROWS, CONSOL_AFF, CONSOL_READ, CAST, PROB_TO_ID, RESIZE) = range(1, 38)
+ GATHER_ROWS, CONSOL_AFF, CONSOL_READ, CAST, PROB_TO_ID, RESIZE, FLIP_W) = range(1, 39)
 
 KIND_NAMES = {}
 for _n in ('CONV MAXPOOL IMG_PREP UPSAMPLE2X_ADD AREA_DOWN MASK_DOWN GAP ECA_APPLY GRU SEG_AGG UP4_SOFTMAX MASK_MERGE '
            'AGG_SOFTMAX LINEAR LAYERNORM QUERY_INIT AUX_MASK ATTN_Q2P ATTN_SELF ATTN_P2Q SUMMARIZE ADD_PE KEY_PREP '
            'AFF_SCORE AFF_SELECT AFF_READOUT MEMSET32 COPY2D AXPY USAGE_TICK RANK_SELECT GATHER_ROWS CONSOL_AFF '
-           'CONSOL_READ CAST PROB_TO_ID RESIZE').split():
+           'CONSOL_READ CAST PROB_TO_ID RESIZE FLIP_W').split():
     KIND_NAMES[globals()[_n]] = _n
 
 F_RELU_IN, F_OUT_F32, F_RES_BCAST = 1, 2, 4
@@ -344,6 +344,9 @@ class OpList:
 
     def resize(self, src, dst, *, C, H, W, OH, OW, plane, ldrow, nearest=False):
         return self.add(RESIZE, 1 if nearest else 0, [C, H, W, OH, OW, plane, ldrow], [], [src, dst])
+
+    def flip_w(self, src, dst, *, rows, W, slds=None, dlds=None, alpha=1.0, beta=0.0):
+        return self.add(FLIP_W, 0, [rows, W, W if slds is None else slds, W if dlds is None else dlds], [alpha, beta], [src, dst])
 
     def cast(self, src, dst, *, n, to_f32=False):
         return self.add(CAST, 1 if to_f32 else 0, [n], [], [src, dst])

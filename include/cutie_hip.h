@@ -211,6 +211,10 @@ enum {
      * 321-326): bilinear align_corners=False without antialias (flags&1 == 0) or nearest-exact (flags&1, index masks).
      * p0=src f32 (C planes of H x W, plane stride i5, row stride i6) p1=dst f32 [C,OH,OW]   i: 0 C 1 H 2 W 3 OH 4 OW 5 6 */
     CUTIE_OP_RESIZE = 37,
+    /* FLIP_W: dst = f0 * flip_last_dim(src) + f1 * dst   -- torch.flip(x, dims=[-1]) of the flip_aug path and the averaging
+     * of the two passes (inference_core.py:162-165,234-235,303-305).  src and dst must not overlap.
+     * p0=src f32 [rows, W] (row stride i2) p1=dst f32 [rows, W] (row stride i3)   i: 0 rows 1 W 2 3   f: 0 alpha 1 beta */
+    CUTIE_OP_FLIP_W = 38,
     CUTIE_OP__COUNT
 };
 

@@ -2,7 +2,7 @@
 (``InferenceCore`` + ``MemoryManager`` + ``KeyValueMemoryStore`` + ``ObjectManager``)
 in plain torch-fp32 on CPU.
 
-TEST INFRASTRUCTURE (see oracle/__init__.py).  bs = 1 only (no flip_aug), all
+TEST INFRASTRUCTURE (see oracle/__init__.py).  bs = 1; flip_aug = a second lane (see __init__), all
 objects in one chunk (chunk_size = -1), which is how every BASELINE config runs.
 """
 import math
@@ -204,6 +204,11 @@ class OracleProcessor:
         else:
             self.max_mem_frames = cfg['max_mem_frames'] - 1
         self.count_lt_usage = lt['count_usage']
+        # flip_aug (inference_core.py:142-143,162-165,234-235,303-305): the reference runs [image, flipped image] as a batch of
+        # two through everything; the two batch elements never interact except for the averaged prediction, so the second
+        # one is restated as a lane with its own memory that shares the object list
+        self.flip_aug = bool(cfg.get('flip_aug', False))
+        self._flip = OracleProcessor(net, dict(cfg, flip_aug=False)) if self.flip_aug else None
         self.curr_ti, self.last_mem_ti = -1, 0
         self.obj_ids = []            # tmp id = position + 1   (object_manager.py)
         self.last_mask = None
@@ -218,6 +223,8 @@ class OracleProcessor:
 
     # ---- interactive surface (inference_core.py:52-69, memory_manager.py:59-75,377-380) ------------
     def clear_non_permanent_memory(self):
+        if self._flip is not None:
+            self._flip.clear_non_permanent_memory()
         self.curr_ti, self.last_mem_ti = -1, 0
         for b in list(self.work.buckets):
             self.work.sieve(b, 0, 0, 0)                               # kv_memory_store.py:305-308
@@ -226,6 +233,8 @@ class OracleProcessor:
                 self.long.sieve(b, 0, 0, 0)
 
     def update_config(self, cfg):
+        if self._flip is not None:
+            self._flip.update_config(cfg)
         cfg = dict(DEFAULT_CFG, **cfg) if isinstance(cfg, dict) else cfg
         self.mem_every = cfg['mem_every']
         self.top_k = cfg['top_k']
@@ -252,6 +261,9 @@ class OracleProcessor:
 
     def delete_objects(self, objects):
         # inference_core.py:330-335, memory_manager.py:298-307
+        if self._flip is not None:
+            self._flip.obj_ids = list(self.obj_ids)
+            self._flip.delete_objects(objects)
         self.obj_ids = [o for o in self.obj_ids if o not in objects]
         self.work.purge_except(self.obj_ids)
         if self.use_long_term and self.long.engaged():
@@ -400,8 +412,16 @@ class OracleProcessor:
 
         ms, pix_feat = self.net.encode_image(image)
         key, shrinkage, selection = self.net.transform_key(ms[0])
+        fl = self._flip
+        if fl is not None:
+            fl.obj_ids, fl.curr_ti = self.obj_ids, self.curr_ti
+            image_f = torch.flip(image, dims=[-1])                      # of the PADDED frame (:231-235)
+            ms_f, pix_f = self.net.encode_image(image_f)
+            key_f, shr_f, sel_f = self.net.transform_key(ms_f[0])
         if need_segment:
             prob = self._segment(key, selection, pix_feat, ms, update_sensory)
+            if fl is not None:
+                prob = (prob + torch.flip(fl._segment(key_f, sel_f, pix_f, ms_f, update_sensory), dims=[-1])) / 2
         if mask is not None:
             tmp_ids = self._add_objects(objects)
             mask, _ = pad_divide_by(mask, 16)
@@ -425,9 +445,14 @@ class OracleProcessor:
                 mask = torch.stack([mask == objects[mi] for mi, _ in enumerate(tmp_ids)], dim=0)
             prob = torch.softmax(aggregate(mask, dim=0), dim=0)
         self.last_mask = prob[1:].unsqueeze(0)
+        if fl is not None:
+            fl.obj_ids = self.obj_ids
+            fl.last_mask = torch.flip(self.last_mask, dims=[-1])
         if is_mem_frame or force_permanent:
             self._add_memory(image, pix_feat, self.last_mask, key, shrinkage, selection,
                              force_permanent=force_permanent)
+            if fl is not None:
+                fl._add_memory(image_f, pix_f, fl.last_mask, key_f, shr_f, sel_f, force_permanent=force_permanent)
         out = unpad(prob, self.pad)
         if resize_needed:
             out = F.interpolate(out.unsqueeze(0), size=(h, w), mode='bilinear', align_corners=False)[0]

@@ -509,6 +509,13 @@ class MockExecutor:
         V = view(p[1], dt, (n, C), (ldv, 1)).float()
         view(p[2], dt, (P, C), (ldo, 1)).copy_(aff @ V)
 
+    def _op_38(self, flags, i, f, p):
+        rows, W, slds, dlds = i[:4]
+        src = view(p[0], F32, (rows, W), (slds, 1)).clone()
+        dst = view(p[1], F32, (rows, W), (dlds, 1))
+        out = f[0] * torch.flip(src, dims=[-1])
+        dst.copy_(out + f[1] * dst if f[1] != 0 else out)
+
     def _op_37(self, flags, i, f, p):
         C, H, W, OH, OW, plane, ldrow = i[:7]
         src = view(p[0], F32, (C, H, W), (plane, ldrow, 1)).clone().unsqueeze(0)

@@ -641,3 +641,18 @@ def test_resize(shape, nearest):
         assert torch.equal(hip['out'], ref['out'])
     else:
         check(hip, ref, name='resize', rtol=1e-5)
+
+
+def test_flip_w():
+    def build(dev, g):
+        src = torch.rand((3, 17, 45), generator=g).to(dev)
+        dst = torch.zeros((3, 17, 45), dtype=F32, device=dev)
+        acc = torch.rand((4, 20, 64), generator=g).to(dev)
+        other = torch.rand((4, 20, 64), generator=g).to(dev)
+        ol = O.OpList()
+        ol.flip_w(src, dst, rows=3 * 17, W=45)
+        ol.flip_w(other, acc, rows=4 * 20, W=64, alpha=0.5, beta=0.5)          # average of a pass and a flipped pass
+        return ol, {'dst': dst, 'acc': acc}
+    hip, ref = run_both(build)
+    assert torch.equal(hip['dst'], ref['dst'])
+    check(hip, ref, name='flip_w', rtol=1e-6)
