@@ -6,6 +6,8 @@ Activations are NHWC bf16 ([B,H,W,C], B = objects), fp32 where the reference for
 (logits, GRU state, summaries, keys).
 """
 import math
+import os
+
 import torch
 
 from .. import ops as O
@@ -42,25 +44,37 @@ def positional_encoding(h, w, dim_total, scale, temperature):
 
 
 TILE_CACHE_ENV = 'CUTIE_AMD_TILE_CACHE'
+# timing effort of the conv autotuner: min over TUNE_REPS runs of TUNE_ITERS launches ($CUTIE_AMD_TUNE="reps x iters")
+TUNE_REPS, TUNE_ITERS = (int(v) for v in os.environ.get('CUTIE_AMD_TUNE', '3x8').lower().split('x'))
+
+
+PACKAGED_TILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tiles_gfx950.json')
 
 
 def load_tile_cache():
-    """Autotuned conv tiles persisted across processes: if $CUTIE_AMD_TILE_CACHE names a JSON file, it seeds the cache and
-    is rewritten whenever a plan is tuned (keys are conv geometries, so one file serves every resolution / object count)."""
-    import json, os
+    """Autotuned conv tiles persisted across processes.  Seeds, in this order: the packaged table of thoroughly timed
+    choices for the common 480p shapes (cutie_amd/tiles_gfx950.json, written by tools/tune_tiles.py: removes the run-to-run
+    variance of quick tuning and the tuning time at start-up), then $CUTIE_AMD_TILE_CACHE if it names a JSON file (that file
+    is rewritten whenever a plan is tuned).  Keys are conv geometries, so one table serves every resolution / object count;
+    geometries not in the table are tuned at their first use.  CUTIE_AMD_TILE_CACHE=none disables both."""
+    import json
     path = os.environ.get(TILE_CACHE_ENV)
-    if not path or not os.path.exists(path):
+    if path == 'none':
         return {}
-    try:
-        return {tuple(k): tuple(v) for k, v in json.load(open(path))['tiles']}
-    except Exception:
-        return {}
+    cache = {}
+    for f in (PACKAGED_TILES, path):
+        if f and os.path.exists(f):
+            try:
+                cache.update({tuple(k): tuple(v) for k, v in json.load(open(f))['tiles']})
+            except Exception:
+                pass
+    return cache
 
 
 def save_tile_cache(cache):
-    import json, os
+    import json
     path = os.environ.get(TILE_CACHE_ENV)
-    if not path:
+    if not path or path == 'none':
         return
     tmp = path + '.tmp%d' % os.getpid()
     with open(tmp, 'w') as f:
@@ -115,13 +129,14 @@ class Plan:
             if best is None:
                 one = arr[n:n + 1].copy()
                 best, best_t = (int(i[17]), 1), None
-                cands = O.tile_candidates(M, cout, cin, int(i[16]))
+                cands = O.tile_candidates(M, cout, cin, int(i[16]),
+                                          geom=dict(kh=int(i[11]), stride=int(i[13]), pad=int(i[14]), W=int(i[2]), c2=int(i[4])))
                 if int(i[4]) or arr['p'][n, 4]:              # 2-source or residual conv: no cout1 kernel
                     cands = [t for t in cands if t != O.COUT1_TILE]
                 for t in cands:
                     for sk in O.splitk_candidates(M, cout, int(i[16]), t):
                         one['i'][0, 17], one['i'][0, 19] = t, sk
-                        ms = min(ex.time_ops(one, 8) for _ in range(3))
+                        ms = min(ex.time_ops(one, TUNE_ITERS) for _ in range(TUNE_REPS))
                         if best_t is None or ms < best_t:
                             best, best_t = (t, sk), ms
                 cache[key] = best

@@ -37,8 +37,24 @@ TILES = {0: (128, 128, 32), 1: (128, 64, 32), 2: (64, 64, 32), 3: (256, 16, 32),
          13: (64, 64, 64), 14: (128, 64, 64), 15: (64, 128, 64), 16: (128, 128, 64), 17: (64, 64, 128), 18: (128, 128, 32),   # 13+: 8 waves
          # 20+: WK K groups per block (intra-block split-K: WK copies of the 4-wave pipeline on one output tile)
          20: (64, 64, 64), 21: (64, 64, 128), 22: (32, 64, 128), 23: (128, 64, 64), 24: (64, 128, 64), 25: (128, 128, 64),
-         26: (32, 64, 64), 27: (64, 64, 64), 28: (32, 64, 64), 29: (64, 128, 32), 30: (64, 64, 32)}
-TILE_WK = {20: 2, 21: 2, 22: 2, 23: 2, 24: 2, 25: 2, 26: 2, 27: 4, 28: 4, 29: 2, 30: 2}     # K groups per block (default 1)
+         26: (32, 64, 64), 27: (64, 64, 64), 28: (32, 64, 64), 29: (64, 128, 32), 30: (64, 64, 32),
+         # 40+: 3x3 / stride 1 / pad 1 with the input patch resident in LDS (conv3x3_patch_kernel; small feature maps only)
+         40: (128, 64, 64), 41: (64, 64, 64), 42: (64, 128, 64), 43: (128, 64, 64), 44: (64, 64, 64)}
+TILE_WK = {20: 2, 21: 2, 22: 2, 23: 2, 24: 2, 25: 2, 26: 2, 27: 4, 28: 4, 29: 2, 30: 2, 40: 2, 41: 2, 42: 2, 43: 1, 44: 1}
+PATCH_TILES = (40, 41, 42, 43, 44)
+
+
+def patch_tile_ok(tile, *, cin, kh, stride, pad, W, c2=0):
+    """conv3x3_patch_kernel eligibility (mirrors launch_patch in conv_igemm.hip)."""
+    bm, bn, _ = TILES[tile]
+    wk = TILE_WK[tile]
+    if kh != 3 or stride != 1 or pad != 1 or c2 or cin < 64 or cin & (cin - 1):
+        return False
+    nk = 9 * cin // 64
+    if nk % wk or nk // wk < 2:
+        return False
+    lds = max((bm + 2 * (W + 2) + 2) * cin * 2 + wk * 2 * bn * 128, bm * (bn + 4) * 4)
+    return lds <= 160 * 1024     # K groups per block (default 1)
 NUM_CU = 256
 
 
@@ -50,14 +66,18 @@ def cout1_ok(cout, cin, c2=0, res=False):
     return cout == 1 and c2 == 0 and not res and cin % 8 == 0 and 1 <= lp <= 64 and (lp & (lp - 1)) == 0
 
 
-def tile_candidates(M, cout, cin, kpad=None):
+def tile_candidates(M, cout, cin, kpad=None, geom=None):
     """Tile ids that are legal for a conv (BK > 32 needs Cin >= 32; tiny Cout uses the 256x16 tile; the K groups of a
-    WK tile must divide the K tiles)."""
+    WK tile must divide the K tiles; geom = dict(kh, stride, pad, W, c2) enables the patch-resident 3x3 tiles)."""
     if cout <= 16:
         return [3] + ([COUT1_TILE] if cout1_ok(cout, cin) else [])
     out = []
     for t, (bm, bn, bk) in TILES.items():
         if t == 3 or (bk > 32 and cin < 32):
+            continue
+        if t in PATCH_TILES:
+            if geom is not None and patch_tile_ok(t, cin=cin, **geom) and not (bn == 128 and cout <= 64):
+                out.append(t)
             continue
         wk = TILE_WK.get(t, 1)
         if wk > 1 and (kpad is None or (kpad // bk) % wk or kpad // bk < 2 * wk):
@@ -89,7 +109,7 @@ def splitk_scratch(device, owner=None):
 
 def splitk_candidates(M, cout, kpad, tile):
     """Split-K factors worth timing for a conv on a given tile: only when the plain grid leaves CUs idle."""
-    if tile == COUT1_TILE or tile == 3:
+    if tile == COUT1_TILE or tile == 3 or tile in PATCH_TILES:
         return [1]
     bm, bn, bk = TILES[tile]
     blocks = -(-M // bm) * -(-cout // bn)

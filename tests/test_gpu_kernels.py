@@ -113,10 +113,42 @@ def test_conv_every_tile(ci, tile):
     c = CONV_CASES[ci]
     if tile in O.TILES and O.TILES[tile][2] > 32 and c['C1'] + c.get('C2', 0) < 32:
         pytest.skip('BK > 32 needs Cin >= 32')
+    if tile in O.PATCH_TILES:
+        pytest.skip('patch-resident tiles have their own cases (test_conv_patch_tiles)')
     if _k_tiles(c, tile) % O.TILE_WK.get(tile, 1):
         pytest.skip('the K groups of this tile do not divide the K tiles')
     hip, ref = run_both(_conv_build(c, tile), seed=100 + ci)
     check(hip, ref, f'conv[{ci}] tile{tile}')
+
+
+PATCH_CASES = [
+    dict(B=3, H=30, W=54, C1=256, Cout=256, k=3, relu_in=True, act=O.ACT_RELU),          # CAResBlock conv (480p, 3 objects)
+    dict(B=1, H=30, W=54, C1=256, Cout=64, k=3, out_f32=True, act=O.ACT_SIGMOID),        # key projection e_proj
+    dict(B=2, H=17, W=23, C1=64, Cout=96, k=3, res=True),                                 # ragged M and Cout, residual
+    dict(B=3, H=9, W=7, C1=128, Cout=40, k=3, res=True, res_bcast=True, out_f32=True),   # tiny map: whole images inside a patch
+    dict(B=1, H=40, W=60, C1=256, Cout=256, k=3),
+]
+
+
+@pytest.mark.parametrize('tile', O.PATCH_TILES)
+@pytest.mark.parametrize('ci', range(len(PATCH_CASES)))
+def test_conv_patch_tiles(ci, tile):
+    """3x3 / stride 1 / pad 1 with the input neighbourhood resident in LDS: image borders, object (batch) boundaries inside a
+    block, ragged tails, every epilogue variant."""
+    c = PATCH_CASES[ci]
+    if not O.patch_tile_ok(tile, cin=c['C1'], kh=3, stride=1, pad=1, W=c['W']):
+        pytest.skip('not eligible (K groups / LDS)')
+    hip, ref = run_both(_conv_build(c, tile), seed=700 + ci)
+    check(hip, ref, f'patch conv[{ci}] tile{tile}')
+
+
+def test_conv_patch_tile_rejects_other_geometries():
+    g = torch.Generator().manual_seed(1)
+    for c in (dict(B=1, H=30, W=54, C1=256, Cout=64, k=1), dict(B=1, H=60, W=108, C1=128, Cout=128, k=3, stride=2),
+              dict(B=1, H=68, W=120, C1=256, Cout=256, k=3)):                               # 1x1, strided, patch too large for LDS
+        ol, _ = _conv_build(c, 40)('cuda', g)
+        with pytest.raises(Exception):
+            _lib.HipExecutor().run(ol.finalize())
 
 
 @pytest.mark.parametrize('splitk', [2, 3, 4, 9])

@@ -19,11 +19,11 @@ def main():
     x = torch.randn(B, H, W, Cin).to(torch.bfloat16).to(dev)
     y = torch.zeros(B, H, W, Cout, dtype=torch.bfloat16, device=dev)
     fl = 2.0 * B * H * W * Cout * Cin * k * k
-    for t in O.tile_candidates(B * H * W, Cout, Cin, pc.kpad):
+    for t in O.tile_candidates(B * H * W, Cout, Cin, pc.kpad, geom=dict(kh=k, stride=1, pad=(k - 1) // 2, W=W)):
         row = []
         for sk in (1, 2, 3):
             nk = pc.kpad // O.TILES[t][2] // O.TILE_WK.get(t, 1) if t in O.TILES else 0
-            if t not in O.TILES or nk % sk or nk // sk < 1 or sk * B * H * W * Cout > O.SPLITK_PART_FLOATS:
+            if (t in O.PATCH_TILES and sk > 1) or t not in O.TILES or nk % sk or nk // sk < 1 or sk * B * H * W * Cout > O.SPLITK_PART_FLOATS:
                 continue
             ol = O.OpList()
             ol.conv(x, pc, y, B=B, H=H, W=W, C1=Cin, ldx1=Cin, OH=H, OW=W, ldy=Cout, pad=(k - 1) // 2, tile=t, splitk=sk)
