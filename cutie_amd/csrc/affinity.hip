@@ -338,6 +338,9 @@ __global__ __launch_bounds__(256) void aff_select_kernel(const float* __restrict
 #define RO_THREADS 128
 typedef __attribute__((ext_vector_type(4))) unsigned int ro_u32x4;
 typedef __attribute__((ext_vector_type(4))) int ro_i32x4;
+// (a pointer loaded from memory has no known address space: hipcc would emit flat_load, whose lgkmcnt accounting couples the
+// gather with every LDS read of the selection lists)
+typedef const __attribute__((address_space(1))) ro_u32x4* ro_gptr;
 #define RO_MAXK 64
 // one block per query column
 __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __
             for (int t4 = 0; t4 < 4; ++t4) {
                 const ro_i32x4 si = *reinterpret_cast<const ro_i32x4*>(sel_i + r * 16 + t4 * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[t4 * 4 + e] = *reinterpret_cast<const ro_u32x4*>(V + (long)si[e] * CV);
+                for (int e = 0; e < 4; ++e) v[t4 * 4 + e] = *(ro_gptr)(V + (long)si[e] * CV);   // bank pointers come from memory: force global_load
             }
             float wv[16];
 #pragma unroll
