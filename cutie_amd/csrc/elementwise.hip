@@ -221,6 +221,22 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const bf16_t* __restrict
     __shared__ float gap[256 + 4], sc[256];
     const int b = blockIdx.y, tid = threadIdx.x;
     const float inv = 1.f / (float)HW;
+    // the activation / residual chunks of this thread are requested first: they do not depend on the channel scale, so their
+    // latency overlaps the reduction of the partial sums (C <= 256: at most 4 chunks of 8 channels per thread and block)
+    const int C8 = C >> 3;
+    const int p0 = blockIdx.x * 32;
+    uint4 xv[4], rv[4];
+    long offs[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int q = tid + it * 256;
+        const int pp = q / C8, c8 = q - pp * C8, p = p0 + pp;
+        const bool ok = q < 32 * C8 && p < HW;
+        offs[it] = ok ? ((long)b * HW + p) * C + c8 * 8 : -1;
+        const long o = ok ? offs[it] : 0;
+        xv[it] = *reinterpret_cast<const uint4*>(x + o);
+        rv[it] = *reinterpret_cast<const uint4*>(r + o);
+    }
     for (int c = tid; c < C; c += 256) {
         float sum = 0.f;
         for (int k = 0; k < nchunk; ++k) sum += part[((long)b * nchunk + k) * C + c];
@@ -234,14 +250,12 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const bf16_t* __restrict
         sc[c] = sigmoidf_(a);
     }
     __syncthreads();
-    const int C8 = C >> 3;
-    const int p0 = blockIdx.x * 32;
-    for (int q = tid; q < 32 * C8; q += 256) {
-        const int pp = q / C8, c8 = q - pp * C8, p = p0 + pp;
-        if (p >= HW) break;
-        const long off = ((long)b * HW + p) * C + c8 * 8;
-        const uint4 xv = *reinterpret_cast<const uint4*>(x + off), rv = *reinterpret_cast<const uint4*>(r + off);
-        const uint32_t* xu = &xv.x; const uint32_t* ru = &rv.x;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        if (offs[it] < 0) continue;
+        const int q = tid + it * 256;
+        const int c8 = q % C8;
+        const uint32_t* xu = &xv[it].x; const uint32_t* ru = &rv[it].x;
         uint32_t o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -249,7 +263,7 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const bf16_t* __restrict
             float hi = __uint_as_float(xu[i] & 0xffff0000u) * sc[c8 * 8 + 2 * i + 1] + __uint_as_float(ru[i] & 0xffff0000u);
             o[i] = pack_bf2(lo, hi);
         }
-        *reinterpret_cast<uint4*>(y + off) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4*>(y + offs[it]) = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 

@@ -167,6 +167,7 @@ class Engine:
         e.__dict__.update(self.__dict__)
         e._plans = {}
         e.__dict__.pop('_splitk_part', None)
+        e.__dict__.pop('_qpool', None)
         return e
 
     def plan(self, key, builder, *args):
@@ -310,10 +311,20 @@ class CUTIE(nn.Module):
         HWp = -(-hw // 64) * 64
         ms = self.ms_dims
         e = lambda shape, dt=BF16: torch.empty(shape, dtype=dt, device=dev)
+        # query-side affinity operands: rows [hw, HWp) are padding that must stay zero and is never written, so a small
+        # rotating pool of buffers zeroed once replaces three fill launches per frame (at most two frames' features are
+        # alive at a time: the current one and the look-ahead)
+        pool = eng.__dict__.setdefault('_qpool', {}).setdefault((HWp, str(dev)), {'n': 0, 'bufs': []})
+        if len(pool['bufs']) < 4:
+            pool['bufs'].append((torch.zeros((HWp, 128), dtype=BF16, device=dev), torch.zeros((HWp, 128), dtype=BF16, device=dev),
+                                 torch.zeros((HWp,), dtype=F32, device=dev)))
+            qb = pool['bufs'][-1]
+        else:
+            qb = pool['bufs'][pool['n'] % 4]
+        pool['n'] += 1
         out = dict(f16=e((1, h, w, ms[0])), f8=e((1, 2 * h, 2 * w, ms[1])), f4=e((1, 4 * h, 4 * w, ms[2])),
                    pix_feat=e((1, h, w, m['pixel_dim'])), key=e((hw, m['key_dim']), F32), shr=e((hw,), F32),
-                   sel=e((hw, m['key_dim']), F32), Bhi=torch.zeros((HWp, 128), dtype=BF16, device=dev),
-                   Blo=torch.zeros((HWp, 128), dtype=BF16, device=dev), cq=torch.zeros((HWp,), dtype=F32, device=dev))
+                   sel=e((hw, m['key_dim']), F32), Bhi=qb[0], Blo=qb[1], cq=qb[2])
         image = image.to(F32).contiguous()
         P.run(image=image, **out)
         out['h'], out['w'] = h, w
