@@ -66,6 +66,7 @@ class Engine:
         self._rep = {}
         sd = {k: v.detach().float().cpu() for k, v in sd.items() if v.is_floating_point()}
         self.sd = sd
+        self._pe_w = {}
         W, dev = self.w, device
         CS, CV = m['sensory_dim'], m['value_dim']
         up = m['mask_decoder']['up_dims']
@@ -94,8 +95,7 @@ class Engine:
                      'mask_decoder.decoder_feat_proc.transforms.0', 'mask_decoder.decoder_feat_proc.transforms.1',
                      'mask_decoder.up_16_8.out_conv.downsample', 'mask_decoder.up_16_8.out_conv.conv1',
                      'mask_decoder.up_16_8.out_conv.conv2', 'mask_decoder.up_8_4.out_conv.conv1',
-                     'mask_decoder.up_8_4.out_conv.conv2', 'mask_decoder.pred',
-                     'object_transformer.pixel_init_proj', 'object_transformer.pixel_emb_proj']:
+                     'mask_decoder.up_8_4.out_conv.conv2', 'mask_decoder.pred']:
             conv(name)
         conv('mask_decoder.sensory_update.g4_conv', segs=[(up[2], up[2]), (1, 8)])
         conv('mask_decoder.sensory_update.transform', segs=[(CS, CS), (CS, CS)])
@@ -122,7 +122,7 @@ class Engine:
             W[q + '.pixel_proj'] = linear_as_conv(wm, bm, dev)
             # the same projections applied to the (block-invariant) pixel positional term; v gets none
             wpe = torch.cat([Wp[C:2 * C], torch.zeros(C, C), Wq[:C]], 0)
-            W[q + '.pe_proj'] = linear_as_conv(wpe, None, dev)
+            self._pe_w[b] = wpe
             W[q + '.read_from_pixel.q'] = pack_linear(Wp[:C], bp[:C], dev)
             W[q + '.read_from_pixel.out'] = pack_linear(sd[rp + '.out_proj.weight'], sd[rp + '.out_proj.bias'], dev)
             W[q + '.self_attn.qkv'] = pack_linear(Ws, bs, dev)                    # one launch; the query PE feeds q and k only
@@ -134,6 +134,11 @@ class Engine:
                 W[q + ln + '.bias'] = sd[q + ln + '.bias'].to(dev).contiguous()
             W[q + '.ffn.linear1'] = pack_linear(sd[q + '.ffn.linear1.weight'], sd[q + '.ffn.linear1.bias'], dev)
             W[q + '.ffn.linear2'] = pack_linear(sd[q + '.ffn.linear2.weight'], sd[q + '.ffn.linear2.bias'], dev)
+        # the positional term R_b = [Wk_b pe | 0 | Wq2_b pe] of every block depends only on pixel_pe: one conv for all blocks
+        W[t + '.pe_proj_all'] = linear_as_conv(torch.cat([self._pe_w.pop(b) for b in range(ot['num_blocks'])], 0), None, dev)
+        # pixel_init_proj | pixel_emb_proj read the same input: one conv with 2C output channels
+        W[t + '.pixel_init_emb'] = pack_conv(torch.cat([sd[t + '.pixel_init_proj.weight'], sd[t + '.pixel_emb_proj.weight']], 0),
+                                             torch.cat([sd[t + '.pixel_init_proj.bias'], sd[t + '.pixel_emb_proj.bias']], 0), dev)
         for b in range(ot['num_blocks'] + 1):
             conv(f'{t}.mask_pred.{b}.1')
         for name in ca_blocks:
@@ -152,6 +157,14 @@ class Engine:
             e = plans.positional_encoding(h, w, self.m['embed_dim'], self.m['pixel_pe_scale'], self.m['pixel_pe_temperature'])
             self._pe[(h, w)] = e.reshape(h * w, -1).to(BF16).to(self.device).contiguous()
         return self._pe[(h, w)]
+
+    def pe0(self, h, w):
+        """bf16 [h*w, 2C]: [0 | positional encoding] -- the broadcast residual of the merged pixel_init | pixel_emb conv."""
+        key = ('pe0', h, w)
+        if key not in self._pe:
+            e = self.pe(h, w)
+            self._pe[key] = torch.cat([torch.zeros_like(e), e], 1).contiguous()
+        return self._pe[key]
 
     def rep_embedding(self, which, K):
         key = (which, K)

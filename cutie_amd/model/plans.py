@@ -286,9 +286,11 @@ def build_readout_query(eng, K, h, w):
     ol.linear(vals, W[t + '.summary_to_query_init'], query, M=M, res=eng.rep_embedding('query_init', K))
     ol.linear(vals, W[t + '.summary_to_query_emb'], query_emb, M=M, res=eng.rep_embedding('query_emb', K))
     pix_in = Act(Dyn('pixel'), K, h, w, C)
-    pixel = P.conv(t + '.pixel_init_proj', pix_in, name='pixel_init')
-    pe = Act(eng.pe(h, w), 1, h, w, C)
-    pixel_pe = P.conv(t + '.pixel_emb_proj', pix_in, name='pixel_pe', res=pe, res_bcast=True)
+    # pixel = pixel_init_proj(x), pixel_pe = pixel_emb_proj(x) + PE: one conv, two channel slices of its output
+    both = P.conv(t + '.pixel_init_emb', pix_in, name='pixel_init_emb', res=Act(eng.pe0(h, w), 1, h, w, 2 * C), res_bcast=True)
+    pixel = Act(both.t, K, h, w, C, 2 * C)
+    pixel_pe = Act(both.t.view(-1)[C:], K, h, w, C, 2 * C)
+    R_all = P.conv(t + '.pe_proj_all', pixel_pe, name='R_all')                   # [Wk.pe | 0 | Wq2.pe] of every block
     aux = f('aux_logits', (nb + 1, K, HW))
     fg = P.buf('fg', (K, HW), torch.uint8)
     nfg = P.buf('nfg', (K,), torch.int32)
@@ -298,7 +300,7 @@ def build_readout_query(eng, K, h, w):
     for b in range(nb):
         q = f'{t}.blocks.{b}'
         n = f'b{b}.'
-        R = P.conv(q + '.pe_proj', pixel_pe, name=n + 'R')                       # [Wk.pe | 0 | Wq2.pe]
+        R = Act(R_all.t.view(-1)[b * 3 * C:], K, h, w, 3 * C, nb * 3 * C)
         kvq = P.conv(q + '.pixel_proj', pixel, name=n + 'kvq', res=R)            # k | v | q2 of the pixels
         # read_from_pixel (CrossAttention, transformer_layers.py:75-98): residual is the normed x.  Every LayerNorm of the
         # block is fused into the linear that consumes it (the normalised rows are kept where the reference reuses them).
