@@ -3,7 +3,7 @@
 Stated tolerance (bf16 activation/weight storage, fp32 accumulation, fp32 keys/logits/GRU state/summaries):
   * per-stage tensors: max |d| <= 3e-2 * max|oracle| (5e-2 after the object transformer)
   * per-frame probabilities over whole trajectories: max |dprob| <= 0.15, mean |dprob| <= 0.05, no growth in time
-  * argmax object ids identical wherever the oracle's top-1/top-2 margin exceeds 0.12 (with the synthetic
+  * argmax object ids identical wherever the oracle's top-1/top-2 margin exceeds 0.30 = twice the per-class bound (with the synthetic
     weights several objects are nearly tied per pixel; with a real checkpoint the margin mask is ~everything)
   * memory-bank bookkeeping (token counts, permanent size, long-term size, buckets) bit-exact vs the golden
     values recorded from the executed reference.
@@ -115,7 +115,7 @@ def test_trajectory_matches_oracle_gpu(name, gpu_net, oracle_net):
         report.append((t, float(d.max()), float(d.mean())))
         assert float(d.max()) < 0.15 and float(d.mean()) < 0.05, (name, report)
         top2 = o.topk(2, dim=0)[0]
-        confident = (top2[0] - top2[1]) > 0.12
+        confident = (top2[0] - top2[1]) > 0.30          # = 2 x the per-class bound 0.15: below it an argmax flip is within tolerance
         agree = (p.argmax(0) == o.argmax(0))
         assert bool(agree[confident].all()), (name, t, float(agree[confident].float().mean()))
         # object-id masks through the public API as well
@@ -183,6 +183,91 @@ def test_other_baseline_configs_properties(gpu_net, h, w, K, frames):
             b = list(proc.memory.buckets.values())[0]
             assert b.n_perm == hw and b.n_work == (t // 2) * hw
         assert int(proc.memory._scratch['overflow'].item()) == 0
+
+
+class _Rec:
+    """Executor shim that records every descriptor array of a run."""
+    def __init__(self, ex):
+        self.ex, self.rec, self.is_mock = ex, [], ex.is_mock
+
+    def run(self, arr):
+        self.rec.append(arr.copy())
+        self.ex.run(arr)
+
+    def stream(self):
+        return self.ex.stream()
+
+    def time_ops(self, arr, iters):
+        return self.ex.time_ops(arr, iters)
+
+
+@pytest.mark.parametrize('name', ['small_fifo', 'small_add_del'])
+def test_every_conv_candidate_agrees_on_the_real_layers(name, gpu_net):
+    """The autotuner may pick any legal (tile, split-K) for a layer, so every candidate must give the same result on every conv
+    geometry the model really launches (small maps: partial tiles, tiny W, K = 1..4 objects), not only on the hand-written
+    cases of test_gpu_kernels.py.  Replays the recorded conv descriptors of a whole scenario with each candidate into a scratch
+    output and compares with the plain 64x64 tile."""
+    from cutie_amd import ops as O
+    from cutie_amd.inference.inference_core import InferenceCore
+    real = _lib.get_executor()
+    rec = _Rec(real)
+    _lib.set_executor_for_testing(rec)
+    try:
+        with torch.inference_mode():
+            S.run_scenario(lambda over: InferenceCore(gpu_net, cfg=default_config(**over)), name, device='cuda',
+                           make_cfg=lambda over: default_config(**over))
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_executor_for_testing(None)
+    seen, bad = set(), []
+    for arr in rec.rec:
+        for n in range(len(arr)):
+            if arr['kind'][n] != O.CONV:
+                continue
+            i = arr['i'][n]
+            M, cout, cin, ldy = int(i[0]) * int(i[7]) * int(i[8]), int(i[9]), int(i[3]) + int(i[4]), int(i[10])
+            key = tuple(int(v) for v in i[:17]) + (int(arr['flags'][n]),)
+            if key in seen:
+                continue
+            seen.add(key)
+            f32 = bool(int(arr['flags'][n]) & O.F_OUT_F32)
+            geom = dict(kh=int(i[11]), stride=int(i[13]), pad=int(i[14]), W=int(i[2]), c2=int(i[4]))
+            cands = O.tile_candidates(M, cout, cin, int(i[16]), geom=geom)
+            if int(i[4]) or arr['p'][n, 4]:
+                cands = [t for t in cands if t != O.COUT1_TILE]
+            # fresh inputs of the recorded geometry (the recorded activations may have been freed and recycled since)
+            g = torch.Generator().manual_seed(len(seen))
+            npx, nout = int(i[0]) * int(i[1]) * int(i[2]), int(i[7]) * int(i[8])
+            x1 = (torch.randn(npx * int(i[5]) + 64, generator=g) * 0.5).to(torch.bfloat16).cuda()
+            base = arr[n:n + 1].copy()
+            base['p'][0, 0] = x1.data_ptr()
+            if int(i[4]):
+                x2 = (torch.randn(npx * int(i[6]) + 64, generator=g) * 0.5).to(torch.bfloat16).cuda()
+                base['p'][0, 1] = x2.data_ptr()
+            if arr['p'][n, 4]:
+                nb = 1 if int(arr['flags'][n]) & O.F_RES_BCAST else int(i[0])
+                res = (torch.randn(nb * nout * int(i[15]) + 64, generator=g) * 0.5).to(torch.bfloat16).cuda()
+                base['p'][0, 4] = res.data_ptr()
+            ref = None
+            for t in ([2] if cout > 16 else [3]) + cands:
+                for sk in O.splitk_candidates(M, cout, int(i[16]), t):
+                    one = base.copy()
+                    out = torch.full((M * ldy + 64,), float('nan'), dtype=torch.float32 if f32 else torch.bfloat16, device='cuda')
+                    one['p'][0, 5] = out.data_ptr()
+                    one['i'][0, 17], one['i'][0, 19] = t, sk
+                    real.run(one)
+                    torch.cuda.synchronize()
+                    got = out[:M * ldy].view(M, ldy)[:, :cout].float()
+                    if ref is None:
+                        ref = got
+                        assert torch.isfinite(ref).all(), key
+                        continue
+                    err = float((got - ref).abs().max())
+                    tol = 2e-2 * float(ref.abs().max().clamp(min=1e-3))          # bf16 output rounding of a different summation order
+                    if not (err <= tol) or not torch.isfinite(got).all():
+                        bad.append((key, t, sk, err, tol))
+    assert not bad, bad[:10]
+    print(name, len(seen), 'conv geometries checked')
 
 
 def test_lookahead_encoder_matches_plain_order(gpu_net):

@@ -125,7 +125,7 @@ def test_trajectory_matches_oracle(name, product_net, oracle_net):
         assert err < 0.15 and float((p - o).abs().mean()) < 0.05, (name, t, err, float((p - o).abs().mean()))
         # argmax agreement wherever the oracle's top-1/top-2 margin exceeds the tolerance
         top2 = o.topk(2, dim=0)[0]
-        confident = (top2[0] - top2[1]) > 0.12
+        confident = (top2[0] - top2[1]) > 0.30          # = 2 x the per-class bound 0.15: below it an argmax flip is within tolerance
         assert bool((p.argmax(0) == o.argmax(0))[confident].all()), (name, t)
     print(name, 'worst prob err', worst)
 
