@@ -96,3 +96,53 @@ def test_eval_driver_writes_palette_pngs(tmp_path, product_net):
         assert torch.equal(ids, lut[prob.argmax(0)])
         assert np.array_equal(np.array(Image.open(os.path.join(out, 'vidB', '00001.png'))), ids.numpy().astype(np.uint8))
         assert torch.equal(proc.output_prob_to_mask(prob, dtype=torch.uint8).long(), ids)
+
+
+def test_video_reader_options_and_long_ids(tmp_path):
+    """start / end / reverse / enabled_frame_list / to_save / use_all_masks, RGB long-id masks (id = R + 256 G + 65536 B) and the
+    long-id writer (inverse mapping); make_zip layouts."""
+    import shutil
+    from cutie_amd.inference.data.video_reader import VideoReader
+    from cutie_amd.inference.object_manager import ObjectManager
+    from cutie_amd.inference.utils.results_utils import ResultSaver, make_zip
+    root = str(tmp_path)
+    _make_video(root, 'v', n=5, h=32, w=48, ids=(1, 2))
+    img_dir, msk_dir = os.path.join(root, 'JPEGImages', 'v'), os.path.join(root, 'Annotations', 'v')
+    rd = VideoReader('v', img_dir, msk_dir, start=1, end=4)
+    assert [rd[i]['info']['frame'] for i in range(len(rd))] == ['00001.jpg', '00002.jpg', '00003.jpg'] and rd[0]['info']['time_index'] == 1
+    rd = VideoReader('v', img_dir, msk_dir, reverse=True, to_save=['00003'])
+    assert rd[0]['info']['frame'] == '00004.jpg' and [rd[i]['info']['save'] for i in range(5)] == [False, True, False, False, False]
+    rd = VideoReader('v', img_dir, msk_dir, enabled_frame_list=['00000', '00002'])
+    assert len(rd) == 2 and 'mask' in rd[0]
+    # a second annotated frame is only read with use_all_masks
+    shutil.copy(os.path.join(msk_dir, '00000.png'), os.path.join(msk_dir, '00003.png'))
+    assert 'mask' not in VideoReader('v', img_dir, msk_dir)[3] and 'mask' in VideoReader('v', img_dir, msk_dir, use_all_masks=True)[3]
+    # long ids: RGB annotation -> integer ids -> RGB output
+    lmsk = os.path.join(root, 'long', 'v')
+    os.makedirs(lmsk)
+    ids = np.zeros((32, 48), dtype=np.int64); ids[4:12, 5:20] = 70000; ids[15:30, 10:40] = 300
+    rgb = np.stack([ids & 255, (ids >> 8) & 255, (ids >> 16) & 255], -1).astype(np.uint8)
+    Image.fromarray(rgb).save(os.path.join(lmsk, '00000.png'))
+    rd = VideoReader('v', img_dir, lmsk)
+    assert rd.use_long_id and rd.get_palette() is None
+    d0 = rd[0]
+    assert torch.equal(d0['mask'], torch.from_numpy(ids)) and sorted(d0['valid_labels'].tolist()) == [300, 70000]
+    om = ObjectManager()
+    om.add_new_objects([300, 70000])
+    out = os.path.join(root, 'out')
+    saver = ResultSaver(out, 'v', dataset='generic', object_manager=om, use_long_id=True)
+    prob = torch.zeros(3, 32, 48); prob[0] = 0.4; prob[1, 15:30, 10:40] = 0.9; prob[2, 4:12, 5:20] = 0.9
+    saver.process(prob, '00000.jpg')
+    saver.end()
+    back = np.array(Image.open(os.path.join(out, 'v', '00000.png'))).astype(np.int64)
+    assert np.array_equal(back[..., 0] + 256 * back[..., 1] + 65536 * back[..., 2], ids)
+    with pytest.raises(NotImplementedError):
+        ResultSaver(out, 'v', dataset='generic', object_manager=om, use_long_id=False, save_scores=True)
+    # archive layouts
+    run = os.path.join(root, 'run'); os.makedirs(os.path.join(run, 'Annotations', 'v'))
+    shutil.copy(os.path.join(out, 'v', '00000.png'), os.path.join(run, 'Annotations', 'v'))
+    make_zip('y19-val', run, 'exp', os.path.join(run, 'Annotations'))
+    make_zip('d17-test-dev', run, 'exp', os.path.join(run, 'Annotations'))
+    make_zip('d17-val', run, 'exp', os.path.join(run, 'Annotations'))
+    assert os.path.exists(os.path.join(run, 'exp_y19-val.zip')) and os.path.exists(os.path.join(run, 'exp_d17-test-dev.zip'))
+    assert not os.path.exists(os.path.join(run, 'exp_d17-val.zip'))
