@@ -72,7 +72,7 @@ def multi_clip_throughput(net, cfg, args, K, rank, dist, dev):
         clip = SyntheticClip(args.height, args.width, K, NF, seed=101 + 16 * rank + c)
         data.append((torch.stack([clip.frame(t) for t in range(NF)]).to(dev), clip.first_mask().to(dev), clip.objects))
     views = [net] + [net.fork() for _ in range(C - 1)]
-    start, done = threading.Barrier(C + 1), threading.Barrier(C + 1)
+    ready, start, done = threading.Barrier(C + 1), threading.Barrier(C + 1), threading.Barrier(C + 1)
     finish, errors = [0.0] * C, []
 
     def work(i):
@@ -86,7 +86,8 @@ def multi_clip_throughput(net, cfg, args, K, rank, dist, dev):
                 for t in range(1, 1 + args.preroll + args.warmup):
                     proc.step(frames[t % NF], next_image=nxt(t))
                 torch.cuda.synchronize()
-                start.wait()
+                ready.wait()                                # pre-roll done on this clip
+                start.wait()                                # released once every rank is ready
                 for t in range(args.steps):
                     tt = 1 + args.preroll + args.warmup + t
                     proc.step(frames[tt % NF], next_image=nxt(tt))
@@ -94,6 +95,7 @@ def multi_clip_throughput(net, cfg, args, K, rank, dist, dev):
                 finish[i] = time.perf_counter()
         except BaseException as e:
             errors.append(e)
+            ready.abort()
             start.abort()
         finally:
             try:
@@ -105,12 +107,13 @@ def multi_clip_throughput(net, cfg, args, K, rank, dist, dev):
     for t in threads:
         t.start()
     try:
+        ready.wait()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
         start.wait()
     except threading.BrokenBarrierError:
         raise errors[0]
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
     done.wait()
     for t in threads:
         t.join()

@@ -1,4 +1,5 @@
-"""Replay the affinity score pass (mode 0) of a warmed-up 480p clip N times: the target of rocprofv3 --pmc runs."""
+"""Replay the affinity score pass (mode 0; AFF_PMC_ALL=1: the whole 5-op affinity plan) of a warmed-up 480p clip N times:
+a target for tools/pmc_kernel.sh, e.g.  PMC_KERNEL=aff_score bash tools/pmc_kernel.sh python tools/aff_pmc.py"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from bench import Recorder
