@@ -100,6 +100,50 @@ __global__ __launch_bounds__(256) void consol_read_kernel(const float* __restric
     }
 }
 
+// Fast path of CONSOL_READ for bf16 value banks (C % 8 == 0, C <= 256): the n candidates are split over CR_NS blocks per group
+// of 8 prototypes (256 blocks instead of 128 threads-bound ones looping over all 8100 candidates: 840 us -> ~10 us per
+// object), 16-B value loads shared by the 8 prototypes of a block, fp32 partial sums, then a fixed-order sum (deterministic).
+#define CR_NS 16
+__global__ __launch_bounds__(256) void consol_read_part_kernel(const float* __restrict__ aff, const bf16_t* __restrict__ V,
+                                                               float* __restrict__ part, int n, int P, int C, int ldv) {
+    const int c8 = threadIdx.x & 31, pq = threadIdx.x >> 5, p = blockIdx.x * 8 + pq, ns = blockIdx.y;
+    const int chunk = (n + CR_NS - 1) / CR_NS, t0 = ns * chunk, t1 = min(n, t0 + chunk);
+    const bool live = p < P && c8 * 8 < C;
+    const float* ar = aff + (long)(live ? p : 0) * n;
+    const bf16_t* vr = V + (live ? c8 * 8 : 0);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int t = t0; t < t1; ++t) {
+        const float a = ar[t];
+        const uint4 v = *reinterpret_cast<const uint4*>(vr + (long)t * ldv);
+        const uint32_t* vu = &v.x;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[2 * i] += a * __uint_as_float(vu[i] << 16);
+            acc[2 * i + 1] += a * __uint_as_float(vu[i] & 0xffff0000u);
+        }
+    }
+    if (live) {
+        float* dst = part + ((long)ns * P + p) * C + c8 * 8;
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
+__global__ void consol_read_sum_kernel(const float* __restrict__ part, bf16_t* __restrict__ out, int P, int C, int ldo) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, C8 = C >> 3;
+    if (idx >= P * C8) return;
+    const int p = idx / C8, c8 = idx - p * C8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int ns = 0; ns < CR_NS; ++ns) {
+        const float* src = part + ((long)ns * P + p) * C + c8 * 8;
+        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+    }
+    *reinterpret_cast<uint4*>(out + (long)p * ldo + c8 * 8) =
+        make_uint4(pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3]), pack_bf2(acc[4], acc[5]), pack_bf2(acc[6], acc[7]));
+}
+
 int launch_bank(const cutie_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     const uint64_t* p = op->p;
@@ -119,6 +163,13 @@ int launch_bank(const cutie_op* op, hipStream_t s) {
                                (const float*)p[3], (float*)p[4], i[0]);
             break;
         case CUTIE_OP_CONSOL_READ: {
+            if (!(op->flags & 1) && p[3] && (i[2] & 7) == 0 && i[2] <= 256 && (i[3] & 7) == 0 && (i[4] & 7) == 0) {
+                hipLaunchKernelGGL(consol_read_part_kernel, dim3((i[1] + 7) / 8, CR_NS), dim3(256), 0, s, (const float*)p[0], (const bf16_t*)p[1],
+                                   (float*)p[3], i[0], i[1], i[2], i[3]);
+                const int nq = i[1] * (i[2] >> 3);
+                hipLaunchKernelGGL(consol_read_sum_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, (const float*)p[3], (bf16_t*)p[2], i[1], i[2], i[4]);
+                break;
+            }
             dim3 grid((i[2] + 63) / 64, (i[1] + 3) / 4);
             if (op->flags & 1)
                 hipLaunchKernelGGL(consol_read_kernel<true>, grid, dim3(256), 0, s, (const float*)p[0], (const void*)p[1], (void*)p[2], i[0], i[1], i[2], i[3], i[4]);

@@ -306,7 +306,8 @@ class MemoryManager:
         aff = self._buf('consol_aff', (P, n), F32, dev)
         ol.consol_aff(b.rawkey[ws:], b.rawshr[ws:], b.rawkey[dst:], psel, aff, n=n, P=P)     # potentiation (:347-350)
         for o in b.objects:
-            ol.consol_read(aff, b.values[o][ws:], b.values[o][dst:], n=n, P=P, C=b.CV, ldv=b.CV, ldo=b.CV)
+            ol.consol_read(aff, b.values[o][ws:], b.values[o][dst:], n=n, P=P, C=b.CV, ldv=b.CV, ldo=b.CV,
+                           scratch=self._buf('consol_part', (16 * P * b.CV,), F32, dev))
         ol.consol_read(aff, b.rawshr[ws:], b.rawshr[dst:], n=n, P=P, C=1, ldv=1, ldo=1, f32=True)
         ol.key_prep(b.rawkey[dst:], b.rawshr[dst:], b.Ahi[dst:], b.Alo[dst:], b.scale[dst:], n=P, query=False)
         ol.memset32(b.use[dst:], P, 0)

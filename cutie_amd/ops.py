@@ -354,8 +354,9 @@ class OpList:
     def consol_aff(self, ckey, cshr, pkey, psel, aff, *, n, P):
         return self.add(CONSOL_AFF, 0, [n, P], [], [ckey, cshr, pkey, psel, aff])
 
-    def consol_read(self, aff, V, out, *, n, P, C, ldv, ldo, f32=False):
-        return self.add(CONSOL_READ, 1 if f32 else 0, [n, P, C, ldv, ldo], [], [aff, V, out])
+    def consol_read(self, aff, V, out, *, n, P, C, ldv, ldo, f32=False, scratch=None):
+        """scratch: f32 [16 * P * C] -> split-n fast path for bf16 value banks."""
+        return self.add(CONSOL_READ, 1 if f32 else 0, [n, P, C, ldv, ldo], [], [aff, V, out, scratch])
 
     def prob_to_id(self, prob, lut, out, *, P, H, W, plane, ldrow):
         """out dtype picks the kernel: uint8 / int32 / int64."""

@@ -197,6 +197,7 @@ enum {
     CUTIE_OP_CONSOL_AFF = 33,
     /* CONSOL_READ: out[p,:] = sum_i aff[p,i] * V[i,:]    memory_manager.py:352-356
      * p0=aff f32 [P,n] p1=V (bf16 [n,C], or f32 if flags&1) p2=out (bf16|f32 like V) [P,C]
+     * p3=scratch f32 [16*P*C] (optional: enables the split-n fast path for bf16 V with C % 8 == 0, C <= 256)
      * i: 0 n 1 P 2 C 3 ldv 4 ldo */
     CUTIE_OP_CONSOL_READ = 34,
     /* CAST: f32 [n] -> bf16 [n] (flags=0) or bf16 -> f32 (flags=1)   p0=src p1=dst  i: 0 n */

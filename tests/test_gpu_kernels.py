@@ -634,7 +634,9 @@ def test_consolidation_kernels():
         ol.consol_aff(ck, cs, pk, pe, aff, n=n, P=P)
         ol.consol_read(aff, V, out, n=n, P=P, C=C, ldv=C, ldo=C)
         ol.consol_read(aff, cs, outs, n=n, P=P, C=1, ldv=1, ldo=1, f32=True)
-        return ol, {'aff': aff, 'out': out, 'outs': outs}
+        out2 = torch.zeros((P, C), dtype=BF16, device=dev)                  # split-n fast path (scratch given)
+        ol.consol_read(aff, V, out2, n=n, P=P, C=C, ldv=C, ldo=C, scratch=torch.zeros(16 * P * C, dtype=F32, device=dev))
+        return ol, {'aff': aff, 'out': out, 'outs': outs, 'out2': out2}
     check(*run_both(build), name='consolidation', rtol=None)
 
 
