@@ -144,6 +144,22 @@ __global__ void consol_read_sum_kernel(const float* __restrict__ part, bf16_t* _
         make_uint4(pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3]), pack_bf2(acc[4], acc[5]), pack_bf2(acc[6], acc[7]));
 }
 
+// CONSOL_READ with C == 1 (prototype shrinkage): one block per prototype, strided partial sums + fixed-order tree (deterministic)
+__global__ __launch_bounds__(256) void consol_dot_kernel(const float* __restrict__ aff, const float* __restrict__ v, float* __restrict__ out,
+                                                         int n, int ldv, int ldo) {
+    __shared__ float red[256];
+    const int p = blockIdx.x;
+    float acc = 0.f;
+    for (int t = threadIdx.x; t < n; t += 256) acc += aff[(long)p * n + t] * v[(long)t * ldv];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(long)p * ldo] = red[0];
+}
+
 int launch_bank(const cutie_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     const uint64_t* p = op->p;
@@ -168,6 +184,10 @@ int launch_bank(const cutie_op* op, hipStream_t s) {
                                    (float*)p[3], i[0], i[1], i[2], i[3]);
                 const int nq = i[1] * (i[2] >> 3);
                 hipLaunchKernelGGL(consol_read_sum_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, (const float*)p[3], (bf16_t*)p[2], i[1], i[2], i[4]);
+                break;
+            }
+            if ((op->flags & 1) && i[2] == 1) {
+                hipLaunchKernelGGL(consol_dot_kernel, dim3(i[1]), dim3(256), 0, s, (const float*)p[0], (const float*)p[1], (float*)p[2], i[0], i[3], i[4]);
                 break;
             }
             dim3 grid((i[2] + 63) / 64, (i[1] + 3) / 4);
