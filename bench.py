@@ -187,12 +187,9 @@ def main():
     cfg = default_config(use_long_term=use_lt)
     torch.manual_seed(0)
     net = CUTIE(cfg).to(dev).eval()
-    try:                                                   # same deterministic weights as the parity tests
-        from oracle.weights import make_state_dict
-        sd = make_state_dict(seed=0)
-        net.load_weights(sd)
-    except ImportError:
-        sd = None
+    from cutie_amd.utils.synth_weights import make_state_dict   # same deterministic synthetic weights as the parity tests
+    sd = make_state_dict(seed=0)
+    net.load_weights(sd)
     rec = Recorder(_lib.get_executor())
     _lib.set_executor_for_testing(rec)                     # only a recording shim around the HIP executor
 
@@ -329,7 +326,7 @@ def main():
                          'clip, cutie_amd/parallel.py); "value" above stays one clip per GPU'}
 
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_frames > 0 and sd is not None:
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
         from oracle.inference import OracleProcessor, DEFAULT_CFG
         from oracle.net import OracleNet
         ncores = usable_cores()

@@ -13,7 +13,7 @@ file:line it follows.
 Parity pin: the reference ships no tests or golden vectors,
 so the oracle is pinned against the *executed reference*: ``oracle/make_golden.py``
 imports the unmodified reference from ``/root/reference`` (CPU, fp32), runs it on
-seeded inputs with the deterministic weights of ``oracle/weights.py`` and commits
+seeded inputs with the deterministic synthetic weights (``cutie_amd/utils/synth_weights.py``) and commits
 sub-sampled outputs under ``tests/golden/``; ``tests/test_oracle_golden.py``
 checks this restatement against those vectors.
 """

@@ -7,7 +7,7 @@ from cutie_amd.config import default_config
 from cutie_amd.inference.inference_core import InferenceCore
 from cutie_amd.model.cutie import CUTIE
 from cutie_amd.utils.synth import SyntheticClip
-from oracle.weights import make_state_dict
+from cutie_amd.utils.synth_weights import make_state_dict
 
 cfg = default_config(use_long_term=True)
 net = CUTIE(cfg).cuda().eval(); net.load_weights(make_state_dict(0))

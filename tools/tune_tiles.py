@@ -12,7 +12,7 @@ from cutie_amd.config import default_config            # noqa: E402
 from cutie_amd.inference.inference_core import InferenceCore   # noqa: E402
 from cutie_amd.model.cutie import CUTIE               # noqa: E402
 from cutie_amd.utils.synth import SyntheticClip       # noqa: E402
-from oracle.weights import make_state_dict            # noqa: E402
+from cutie_amd.utils.synth_weights import make_state_dict            # noqa: E402
 
 assert os.environ.get('CUTIE_AMD_TILE_CACHE', 'none') != 'none', 'set CUTIE_AMD_TILE_CACHE to the output file'
 cfg = default_config(use_long_term=True)
