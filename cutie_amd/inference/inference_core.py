@@ -6,7 +6,7 @@ stagger_ti (:37-41), mask merge semantics (:259-300), last_mask = prob[1:] (:302
 unpad (:320), optional internal resize (:206-228, :321-326), delete_objects (:330-335),
 output_prob_to_mask (:337-345).
 flip_aug (the reference's batch of [frame, flipped frame], :142-143,162-165,234-235,303-305) runs as a second lane with its
-own memory bank; chunk_size is accepted (no effect: objects are always batched).
+own memory bank; chunk_size > 0 groups the objects in the memory read-out like the reference.
 """
 import logging
 from typing import List, Optional
@@ -55,11 +55,10 @@ class InferenceCore:
         # interact only through the averaged prediction, so the flipped one is a second lane (= a nested core sharing the
         # object manager, with its own memory bank / sensory state / feature store) instead of a batch dimension in every plan
         self.flip_aug = bool(cfg.flip_aug) and _lane_of is None
-        # chunk_size (big_modules.py:141-180,267-302) only bounds the reference's activation memory by looping over groups of
-        # objects; objects are independent in those stages, so the result does not depend on it.  The HIP plans always run
-        # every object in one batch (288 GB of HBM), i.e. the setting is accepted and has no effect.
-        if self.chunk_size is not None and self.chunk_size > 0:
-            log.info('chunk_size=%d accepted: the HIP path batches all objects, results are identical', self.chunk_size)
+        # chunk_size: in the mask encoder and the decoder (big_modules.py:141-180,267-302) the reference's object chunks are
+        # equivalent to the batched form (the HIP plans always batch; 288 GB of HBM).  In MemoryManager.read
+        # (memory_manager.py:169-186) they are not: fusion and object transformer see only the objects of a chunk, which is
+        # replicated there (pinned by the `small_chunk` golden scenario).
         self.curr_ti = -1
         self.last_mem_ti = 0
         if stagger_updates >= self.mem_every:

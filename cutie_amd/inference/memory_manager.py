@@ -162,20 +162,28 @@ class MemoryManager:
             ol.aff_readout(cval, cidx, count, bucket.vptrs(), usage, readout, ovf, HW=HW, cap=CAND_CAP, top_k=self.top_k,
                            K=K, CV=self.CV)
             ol.run()
-            objects = bucket.objects
-            this_sensory = self.get_sensory(objects)
-            this_last_mask = self._get_mask_by_ids(last_mask, objects)
-            visual_readout = readout.permute(0, 3, 1, 2).unsqueeze(0)
-            pixel_readout = network.pixel_fusion(pix_feat, visual_readout, this_sensory, this_last_mask)
-            a, b = self._rows(objects, self._objv_ids)
-            this_obj_mem = self._objv[a:b].unsqueeze(0).unsqueeze(2)                # [1,K,1,Q,C+1]
-            readout_memory, aux_features = network.readout_query(pixel_readout, this_obj_mem)
-            for i, obj in enumerate(objects):
-                all_readout[obj] = readout_memory[:, i]
-            self._last_readout = (objects, readout_memory)
-            if self.save_aux:
-                self.aux = {'sensory': this_sensory, 'pixel_readout': pixel_readout,
-                            'q_logits': aux_features['logits'] if aux_features else None}
+            # chunk_size > 0 (memory_manager.py:169-186): pixel fusion and the object transformer run per group of chunk_size
+            # objects -- this is NOT only a memory knob: the "others" mask of the fusion and the foreground / background
+            # attention masks of the transformer are computed inside a group.  (encode_mask / segment chunks are equivalent
+            # to the batched form and stay batched.)
+            cs = self.chunk_size if (self.chunk_size is not None and self.chunk_size >= 1) else K
+            chunks = []
+            for c0 in range(0, K, cs):
+                objects = bucket.objects[c0:c0 + cs]
+                this_sensory = self.get_sensory(objects)
+                this_last_mask = self._get_mask_by_ids(last_mask, objects)
+                visual_readout = readout[c0:c0 + cs].permute(0, 3, 1, 2).unsqueeze(0)
+                pixel_readout = network.pixel_fusion(pix_feat, visual_readout, this_sensory, this_last_mask)
+                a, b = self._rows(objects, self._objv_ids)
+                this_obj_mem = self._objv[a:b].unsqueeze(0).unsqueeze(2)                # [1,K,1,Q,C+1]
+                readout_memory, aux_features = network.readout_query(pixel_readout, this_obj_mem)
+                for i, obj in enumerate(objects):
+                    all_readout[obj] = readout_memory[:, i]
+                chunks.append((objects, readout_memory))
+                if self.save_aux:
+                    self.aux = {'sensory': this_sensory, 'pixel_readout': pixel_readout,
+                                'q_logits': aux_features['logits'] if aux_features else None}
+            self._last_readout = chunks[0] if len(chunks) == 1 else (None, None)
         return all_readout
 
     def readout_stacked(self, all_obj_ids):

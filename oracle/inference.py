@@ -192,6 +192,7 @@ class OracleProcessor:
         else:
             self.stagger_ti = set(np.round(np.linspace(1, self.mem_every, su)).astype(int).tolist())
         self.max_internal_size = cfg['max_internal_size']
+        self.chunk_size = cfg.get('chunk_size', -1)
         self.top_k = cfg['top_k']
         self.use_long_term = cfg['use_long_term']
         lt = cfg['long_term']
@@ -306,14 +307,20 @@ class OracleProcessor:
                     v = torch.cat([self.long.v[o], v], -1)
                 vals.append(v)
             V = torch.stack(vals, 0)                                  # [K,CV,N]
-            ro = (V.flatten(0, 1) @ aff).view(1, len(objs), V.shape[1], h, w)
-            sens = torch.stack([self.sensory[o] for o in objs], 1)
-            lm = self.last_mask[:, [self.obj_ids.index(o) for o in objs]]
-            fused = self.net.pixel_fusion(pix_feat, ro, sens, lm)
-            om = torch.stack([self.obj_v[o] for o in objs], 1).unsqueeze(2)
-            rq = self.net.readout_query(fused, om)
-            for i, o in enumerate(objs):
-                out[o] = rq[:, i]
+            ro_all = (V.flatten(0, 1) @ aff).view(1, len(objs), V.shape[1], h, w)
+            # chunk_size > 0 (memory_manager.py:169-186): fusion and object transformer run per group of objects, so the
+            # "others" mask and the transformer's foreground/background attention masks only see the objects of the group
+            cs = self.chunk_size if self.chunk_size >= 1 else len(objs)
+            for c0 in range(0, len(objs), cs):
+                sub = objs[c0:c0 + cs]
+                ro = ro_all[:, c0:c0 + cs]
+                sens = torch.stack([self.sensory[o] for o in sub], 1)
+                lm = self.last_mask[:, [self.obj_ids.index(o) for o in sub]]
+                fused = self.net.pixel_fusion(pix_feat, ro, sens, lm)
+                om = torch.stack([self.obj_v[o] for o in sub], 1).unsqueeze(2)
+                rq = self.net.readout_query(fused, om)
+                for i, o in enumerate(sub):
+                    out[o] = rq[:, i]
         return out
 
     # ---- memory write (memory_manager.py:210-296, 309-358) -------------------------

@@ -35,6 +35,9 @@ SCENARIOS = {
     'small_interactive': dict(cfg=dict(mem_every=2, max_mem_frames=3), kind='synth', h=96, w=128, k=3, frames=15, sub=2,
                               add_at={0: [1, 2, 3], 5: [1, 2, 3]}, permanent_at=[5], update_config_at={8: dict(mem_every=3)},
                               clear_non_permanent_at=[11]),
+    # chunk_size > 0: the reference loops over groups of 2 objects in encode_mask / pixel_fusion / segment; the oracle and the
+    # product always batch every object -- this pins that the setting does not change the result
+    'small_chunk': dict(cfg=dict(mem_every=2, max_mem_frames=3, chunk_size=2), kind='synth', h=96, w=136, k=3, frames=10, sub=2),
     # flip augmentation (bs = 2 in the reference) with long-term memory; width 121 -> asymmetric pad (3 | 4)
     'small_flip': dict(cfg=dict(mem_every=2, flip_aug=True, use_long_term=True, long_term=LT_SMALL),
                        kind='synth', h=96, w=121, k=2, frames=26, sub=2),
