@@ -4,6 +4,8 @@ first-mask alignment, ``end`` on the last frame, FPS = frames / sum of device-ev
 
     python -m cutie_amd.eval_vos --images DIR/JPEGImages --masks DIR/Annotations --output OUT [--weights ckpt.pth]
         [--size 480] [--use-all-masks] [--long-term] [--dataset d17-val] [--visualize] [--clips-in-flight 4]
+        [--flip-aug] [--save-scores]      (multi-scale testing: one run per --size with --save-scores, then
+                                           python -m cutie_amd.merge_multi_scale --list OUT_a OUT_b --output MERGED)
 
 With several GPUs launch it under torch.distributed.run: videos are sharded over the ranks (cutie_amd/parallel.py)."""
 import argparse
@@ -24,12 +26,13 @@ log = logging.getLogger()
 
 
 def process_video(network, cfg, vid_reader, mask_output_root, *, dataset='generic', save_all=True, visualize=False,
-                  visualize_output_root=None, lookahead=True) -> Dict:
+                  visualize_output_root=None, lookahead=True, save_scores=False, score_output_root=None) -> Dict:
     """One video through a fresh InferenceCore (eval_vos.py:97-151).  Returns {'frames', 'seconds'} (time around step)."""
     processor = InferenceCore(network, cfg=cfg)
     saver = ResultSaver(mask_output_root, vid_reader.vid_name, dataset=dataset, object_manager=processor.object_manager,
                         use_long_id=vid_reader.use_long_id, palette=vid_reader.get_palette(), visualize=visualize,
-                        visualize_output_root=visualize_output_root, processor=processor)
+                        visualize_output_root=visualize_output_root, processor=processor, save_scores=save_scores,
+                        score_output_root=score_output_root)
     dev = network.device
     on_gpu = dev.type == 'cuda'
     n = len(vid_reader)
@@ -86,6 +89,8 @@ def main():
     ap.add_argument('--long-term', action='store_true')
     ap.add_argument('--visualize', action='store_true')
     ap.add_argument('--clips-in-flight', type=int, default=1)
+    ap.add_argument('--flip-aug', action='store_true')
+    ap.add_argument('--save-scores', action='store_true')
     args = ap.parse_args()
     from .model.cutie import CUTIE
     from .parallel import run_concurrent, shard_clips
@@ -94,7 +99,7 @@ def main():
     if world > 1:
         dist.init_process_group(backend='nccl')
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-    cfg = default_config(use_long_term=args.long_term)
+    cfg = default_config(use_long_term=args.long_term, flip_aug=args.flip_aug, save_scores=args.save_scores)
     net = CUTIE(cfg).cuda().eval()
     if args.weights:
         net.load_weights(torch.load(args.weights, map_location='cpu'))
@@ -103,7 +108,8 @@ def main():
     mine = shard_clips(len(readers), rank, world)
     mask_root = path.join(args.output, 'Annotations')
     run = lambda view, c: process_video(view, cfg, readers[c], mask_root, dataset=args.dataset, visualize=args.visualize,
-                                        visualize_output_root=path.join(args.output, 'Visualizations'))
+                                        visualize_output_root=path.join(args.output, 'Visualizations'),
+                                        save_scores=args.save_scores, score_output_root=path.join(args.output, 'Scores'))
     with torch.inference_mode():
         res = run_concurrent(net, mine, run, streams=max(1, args.clips_in_flight))
     frames, secs = sum(r['frames'] for r in res.values()), sum(r['seconds'] for r in res.values())

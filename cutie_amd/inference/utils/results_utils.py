@@ -3,8 +3,11 @@ cutie/inference/utils/results_utils.py:30-256 (``process`` / ``end`` / ``make_zi
 
 MI355X-side difference: argmax + tmp-id -> object-id remap run as ONE kernel (PROB_TO_ID) that writes uint8 (int32 for
 long ids), so the device-to-host copy is H*W bytes instead of the (K+1)*H*W*4 bytes of probabilities, and the host thread
-only encodes the PNG.  Not supported here (raise): score dumps for multi-scale testing (``save_scores``: needs hickle) and
-the BURST json writer (``init_json``) -- SURVEY.md section 8(f) rank 4 / out of scope.
+only encodes the PNG.  ``save_scores`` (multi-scale testing, :94,195-209): probabilities are quantised to uint8 (x255,
+truncation) ON THE DEVICE, so the copy is 4x smaller too; the reference stores them with hickle (HDF5, lzf), which is not in
+this image, so the container here is ``<frame>.npz`` (key ``prob``) and ``backward.npz`` (keys ``obj_ids`` / ``tmp_ids``) --
+``cutie_amd.merge_multi_scale`` reads these (and ``.hkl`` when hickle is importable).  Not supported (raise): the BURST
+json writer (``init_json``).
 Long ids (RGB masks) are written as id = R + 256 G + 65536 B, the inverse of VideoReader's decoding."""
 import logging
 import os
@@ -48,6 +51,9 @@ class _Job:
     frame_name: str
     path_to_image: Optional[str]
     all_obj_ids: list
+    prob: Optional[torch.Tensor] = None      # CPU uint8 [K+1,H,W] (save_scores)
+    last_frame: bool = False
+    tmp_to_obj: Optional[dict] = None        # {tmp_id: object id} at the time of the frame
 
 
 class ResultSaver:
@@ -56,8 +62,9 @@ class ResultSaver:
                  processor=None):
         """``processor`` (optional, not in the reference): the InferenceCore whose fused PROB_TO_ID kernel does argmax+remap;
         without it a plain torch argmax + lookup is used (e.g. for probabilities that did not come from an InferenceCore)."""
-        if save_scores:
-            raise NotImplementedError('save_scores (multi-scale score dumps) is not supported')
+        if save_scores and score_output_root is None:
+            raise ValueError('save_scores needs score_output_root')
+        self.save_scores, self.score_output_root = save_scores, score_output_root
         if init_json is not None or 'burst' in dataset.lower():
             raise NotImplementedError('the BURST json writer is not supported')
         self.output_root, self.video_name, self.dataset = output_root, video_name, dataset.lower()
@@ -85,7 +92,10 @@ class ResultSaver:
                 if tmp_id < lut.shape[0]:
                     lut[tmp_id] = obj.id
             mask = lut[idx].to(out_dtype)
-        self.queue.put(_Job(self, mask.cpu(), frame_name, path_to_image, [o.id for o in self.object_manager.obj_to_tmp_id]))
+        q = (prob * 255).to(torch.uint8).cpu() if self.save_scores else None       # == numpy astype(uint8) of prob*255
+        self.queue.put(_Job(self, mask.cpu(), frame_name, path_to_image, [o.id for o in self.object_manager.obj_to_tmp_id],
+                            prob=q, last_frame=last_frame,
+                            tmp_to_obj={t: o.id for t, o in self.object_manager.tmp_id_to_obj.items()} if last_frame else None))
 
     def end(self):
         self.queue.put(None)
@@ -115,6 +125,14 @@ def _writer(queue: Queue):
                 out_dir = path.join(s.output_root, s.video_name)
                 os.makedirs(out_dir, exist_ok=True)
                 out_img.save(path.join(out_dir, job.frame_name[:-4] + '.png'))
+            if s.save_scores:
+                sc_dir = path.join(s.score_output_root, s.video_name)
+                os.makedirs(sc_dir, exist_ok=True)
+                if job.last_frame:                                 # the reference's backward.hkl: {object id: tmp id}
+                    ids = sorted(job.tmp_to_obj.items())
+                    np.savez(path.join(sc_dir, 'backward.npz'), obj_ids=np.array([o for _, o in ids], dtype=np.int64),
+                             tmp_ids=np.array([t for t, _ in ids], dtype=np.int64))
+                np.savez_compressed(path.join(sc_dir, job.frame_name[:-4] + '.npz'), prob=job.prob.numpy())
             if s.visualize:
                 if job.path_to_image is None:
                     raise ValueError('Cannot visualize without path_to_image')

@@ -137,7 +137,7 @@ def test_video_reader_options_and_long_ids(tmp_path):
     back = np.array(Image.open(os.path.join(out, 'v', '00000.png'))).astype(np.int64)
     assert np.array_equal(back[..., 0] + 256 * back[..., 1] + 65536 * back[..., 2], ids)
     with pytest.raises(NotImplementedError):
-        ResultSaver(out, 'v', dataset='generic', object_manager=om, use_long_id=False, save_scores=True)
+        ResultSaver(out, 'v', dataset='burst-val', object_manager=om, use_long_id=False)
     # archive layouts
     run = os.path.join(root, 'run'); os.makedirs(os.path.join(run, 'Annotations', 'v'))
     shutil.copy(os.path.join(out, 'v', '00000.png'), os.path.join(run, 'Annotations', 'v'))
@@ -146,3 +146,41 @@ def test_video_reader_options_and_long_ids(tmp_path):
     make_zip('d17-val', run, 'exp', os.path.join(run, 'Annotations'))
     assert os.path.exists(os.path.join(run, 'exp_y19-val.zip')) and os.path.exists(os.path.join(run, 'exp_d17-test-dev.zip'))
     assert not os.path.exists(os.path.join(run, 'exp_d17-val.zip'))
+
+
+def test_score_dumps_and_multi_scale_merge(tmp_path, product_net):
+    """Section 8(f) rank 4: save_scores dumps (uint8 prob x255, backward map on the last frame) of a plain and a flip_aug run,
+    merged like scripts/merge_multi_scale.py: float sum -> argmax -> tmp id -> object id -> palette PNG (+ DAVIS zip)."""
+    from cutie_amd.eval_vos import process_video
+    from cutie_amd.inference.data.vos_test_dataset import VOSTestDataset
+    from cutie_amd.merge_multi_scale import load_backward, load_scores, merge
+    _make_video(str(tmp_path), 'vidC', n=3, h=64, w=96, ids=(2, 5))
+    ds = VOSTestDataset(os.path.join(tmp_path, 'JPEGImages'), os.path.join(tmp_path, 'Annotations'), use_all_masks=False)
+    rd = next(iter(ds.get_datasets()))
+    runs = []
+    with torch.inference_mode():
+        for name, flip in (('runA', False), ('runB', True)):
+            root = os.path.join(tmp_path, name)
+            process_video(product_net, default_config(mem_every=2, flip_aug=flip), rd, os.path.join(root, 'Annotations'),
+                          dataset='d17-val', save_scores=True, score_output_root=os.path.join(root, 'Scores'))
+            runs.append(root)
+    sc = os.path.join(runs[0], 'Scores', 'vidC')
+    assert sorted(os.listdir(sc)) == ['00000.npz', '00001.npz', '00002.npz', 'backward.npz']
+    assert load_backward(sc) == {2: 1, 5: 2}
+    a, b = load_scores(os.path.join(sc, '00001.npz')), load_scores(os.path.join(runs[1], 'Scores', 'vidC', '00001.npz'))
+    assert a.dtype == np.uint8 and a.shape == (3, 64, 96) and b.shape == a.shape
+    assert np.abs(a.astype(np.int32).sum(0) - 255).max() <= 3            # truncated probabilities of a softmax
+    # the dump of a single run reproduces that run's PNG wherever the quantised argmax is unambiguous
+    png = np.array(Image.open(os.path.join(runs[0], 'Annotations', 'vidC', '00001.png')))
+    srt = np.sort(a.astype(np.int32), 0)
+    clear = srt[-1] > srt[-2]
+    assert np.array_equal(np.array([0, 2, 5])[a.argmax(0)][clear], png[clear])
+    out = os.path.join(tmp_path, 'merged')
+    assert merge(runs, out, dataset='D', num_proc=1) == 3
+    assert os.path.exists(out + '.zip')
+    want = np.array([0, 2, 5], dtype=np.uint8)[(a.astype(np.float32) + b).argmax(0)]
+    got = Image.open(os.path.join(out, 'vidC', '00001.png'))
+    assert got.mode == 'P' and np.array_equal(np.array(got), want)
+    with pytest.raises(ValueError):
+        from cutie_amd.inference.utils.results_utils import ResultSaver
+        ResultSaver(out, 'x', dataset='d17-val', object_manager=None, use_long_id=False, save_scores=True)
