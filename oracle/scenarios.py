@@ -35,9 +35,13 @@ SCENARIOS = {
     'small_interactive': dict(cfg=dict(mem_every=2, max_mem_frames=3), kind='synth', h=96, w=128, k=3, frames=15, sub=2,
                               add_at={0: [1, 2, 3], 5: [1, 2, 3]}, permanent_at=[5], update_config_at={8: dict(mem_every=3)},
                               clear_non_permanent_at=[11]),
-    # chunk_size > 0: the reference loops over groups of 2 objects in encode_mask / pixel_fusion / segment; the oracle and the
-    # product always batch every object -- this pins that the setting does not change the result
+    # chunk_size > 0: the reference's MemoryManager.read runs fusion + object transformer per group of 2 objects (the "others"
+    # mask and the attention masks only see the group), so the result differs from chunk_size = -1
     'small_chunk': dict(cfg=dict(mem_every=2, max_mem_frames=3, chunk_size=2), kind='synth', h=96, w=136, k=3, frames=10, sub=2),
+    # remaining step() arguments: soft float masks (idx_mask=False) on the first and on a later frame, an index mask that
+    # re-specifies every known object (need_segment False), end=True on the last frame (no memory / sensory update)
+    'small_misc': dict(cfg=dict(mem_every=3, max_mem_frames=3), kind='synth', h=96, w=120, k=3, frames=12, sub=2,
+                       add_at={0: [1, 2, 3], 5: [1, 2, 3], 8: [1, 2, 3]}, float_mask_at=[0, 8], end_at=[11]),
     # flip augmentation (bs = 2 in the reference) with long-term memory; width 121 -> asymmetric pad (3 | 4)
     'small_flip': dict(cfg=dict(mem_every=2, flip_aug=True, use_long_term=True, long_term=LT_SMALL),
                        kind='synth', h=96, w=121, k=2, frames=26, sub=2),
@@ -98,10 +102,15 @@ def run_scenario(make_processor, name, device='cpu', record=None, make_cfg=None)
             if t in sc.get('clear_non_permanent_at', ()):
                 proc.clear_non_permanent_memory()
             img = img.to(device)
-            if mask is not None:
-                p = proc.step(img, mask.to(device), objects=objs, force_permanent=(t in sc.get('permanent_at', ())))
+            end = t in sc.get('end_at', ())
+            if mask is not None and t in sc.get('float_mask_at', ()):
+                # soft planes in tmp-id order (0.9 inside, 0.05 outside): the reference's idx_mask=False input
+                planes = torch.stack([(mask == o).float() * 0.85 + 0.05 for o in objs]).to(device)
+                p = proc.step(img, planes, objects=objs, idx_mask=False, end=end)
+            elif mask is not None:
+                p = proc.step(img, mask.to(device), objects=objs, force_permanent=(t in sc.get('permanent_at', ())), end=end)
             else:
-                p = proc.step(img)
+                p = proc.step(img, end=end)
             outs.append(p.detach().float().cpu())
             if record is not None:
                 record(t, proc)
