@@ -222,7 +222,25 @@ class OracleProcessor:
         self.engaged = False
         self.HW = None
 
-    # ---- interactive surface (inference_core.py:52-69, memory_manager.py:59-75,377-380) ------------
+    # ---- interactive surface (inference_core.py:52-69, memory_manager.py:59-75,377-383) ------------
+    def clear_memory(self):
+        # inference_core.py:52-55: a NEW MemoryManager built from the construction-time cfg (working / long-term / sensory /
+        # object memory all gone); the object manager -- and with it the tmp ids -- survives
+        if self._flip is not None:
+            self._flip.clear_memory()
+        self.curr_ti, self.last_mem_ti = -1, 0
+        mem_every = self.mem_every
+        OracleProcessor.update_config(self, self.cfg)               # memory limits back to the original cfg ...
+        self.mem_every = mem_every                                  # ... but InferenceCore.mem_every is not touched
+        self._reset_memory()
+
+    def clear_sensory_memory(self):
+        # inference_core.py:62-65, memory_manager.py:382-383: re-created as zeros by the next _add_memory (:360-366)
+        if self._flip is not None:
+            self._flip.clear_sensory_memory()
+        self.curr_ti, self.last_mem_ti = -1, 0
+        self.sensory = {}
+
     def clear_non_permanent_memory(self):
         if self._flip is not None:
             self._flip.clear_non_permanent_memory()

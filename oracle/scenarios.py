@@ -42,6 +42,10 @@ SCENARIOS = {
     # re-specifies every known object (need_segment False), end=True on the last frame (no memory / sensory update)
     'small_misc': dict(cfg=dict(mem_every=3, max_mem_frames=3), kind='synth', h=96, w=120, k=3, frames=12, sub=2,
                        add_at={0: [1, 2, 3], 5: [1, 2, 3], 8: [1, 2, 3]}, float_mask_at=[0, 8], end_at=[11]),
+    # GUI patterns (gui/main_controller.py:297-306,542-543): "propagate" = clear_sensory_memory() then step(image, previous
+    # prob[1:], idx_mask=False) with objects=None; "reset all memory" = clear_memory() followed by a fresh index mask
+    'small_clear': dict(cfg=dict(mem_every=3, max_mem_frames=3), kind='synth', h=96, w=120, k=2, frames=13, sub=2,
+                        add_at={0: [1, 2], 8: [1, 2]}, repropagate_at=[4], clear_memory_at=[8]),
     # flip augmentation (bs = 2 in the reference) with long-term memory; width 121 -> asymmetric pad (3 | 4)
     'small_flip': dict(cfg=dict(mem_every=2, flip_aug=True, use_long_term=True, long_term=LT_SMALL),
                        kind='synth', h=96, w=121, k=2, frames=26, sub=2),
@@ -103,6 +107,15 @@ def run_scenario(make_processor, name, device='cpu', record=None, make_cfg=None)
                 proc.clear_non_permanent_memory()
             img = img.to(device)
             end = t in sc.get('end_at', ())
+            if t in sc.get('clear_memory_at', ()):
+                proc.clear_memory()
+            if t in sc.get('repropagate_at', ()):
+                proc.clear_sensory_memory()
+                p = proc.step(img.to(device), outs[-1][1:].to(device), idx_mask=False)
+                outs.append(p.detach().float().cpu())
+                if record is not None:
+                    record(t, proc)
+                continue
             if mask is not None and t in sc.get('float_mask_at', ()):
                 # soft planes in tmp-id order (0.9 inside, 0.05 outside): the reference's idx_mask=False input
                 planes = torch.stack([(mask == o).float() * 0.85 + 0.05 for o in objs]).to(device)
