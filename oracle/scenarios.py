@@ -46,6 +46,11 @@ SCENARIOS = {
     # prob[1:], idx_mask=False) with objects=None; "reset all memory" = clear_memory() followed by a fresh index mask
     'small_clear': dict(cfg=dict(mem_every=3, max_mem_frames=3), kind='synth', h=96, w=120, k=2, frames=13, sub=2,
                         add_at={0: [1, 2], 8: [1, 2]}, repropagate_at=[4], clear_memory_at=[8]),
+    # scripts/process_video.py:94-120,139-176: every given mask is first committed to PERMANENT memory (one-hot float planes,
+    # objects=None, force_permanent=True), then the video runs from frame 0 and meets the same masks again; long-term memory on
+    'small_video': dict(cfg=dict(mem_every=3, use_long_term=True, long_term=LT_SMALL), kind='synth', h=96, w=120, k=2,
+                        frames=14, sub=2, add_at={0: [1, 2], 6: [1, 2]}, float_mask_at=[0, 6], float_kind='onehot',
+                        precommit=[0, 6]),
     # flip augmentation (bs = 2 in the reference) with long-term memory; width 121 -> asymmetric pad (3 | 4)
     'small_flip': dict(cfg=dict(mem_every=2, flip_aug=True, use_long_term=True, long_term=LT_SMALL),
                        kind='synth', h=96, w=121, k=2, frames=26, sub=2),
@@ -95,7 +100,17 @@ def run_scenario(make_processor, name, device='cpu', record=None, make_cfg=None)
     proc = make_processor(sc['cfg'])
     steps, deletes = scenario_inputs(name)
     outs = []
+
+    def planes_of(mask, objs):
+        if sc.get('float_kind') == 'onehot':                         # index_numpy_to_one_hot_torch(...)[1:]
+            return torch.stack([(mask == o).float() for o in objs]).to(device)
+        # soft planes in tmp-id order (0.9 inside, 0.05 outside)
+        return torch.stack([(mask == o).float() * 0.85 + 0.05 for o in objs]).to(device)
+
     with torch.inference_mode():
+        for t in sc.get('precommit', ()):
+            img, mask, objs = steps[t]
+            proc.step(img.to(device), planes_of(mask, objs), idx_mask=False, force_permanent=True)
         for t, (img, mask, objs) in enumerate(steps):
             if t in deletes:
                 proc.delete_objects(deletes[t])
@@ -117,9 +132,7 @@ def run_scenario(make_processor, name, device='cpu', record=None, make_cfg=None)
                     record(t, proc)
                 continue
             if mask is not None and t in sc.get('float_mask_at', ()):
-                # soft planes in tmp-id order (0.9 inside, 0.05 outside): the reference's idx_mask=False input
-                planes = torch.stack([(mask == o).float() * 0.85 + 0.05 for o in objs]).to(device)
-                p = proc.step(img, planes, objects=objs, idx_mask=False, end=end)
+                p = proc.step(img, planes_of(mask, objs), objects=objs, idx_mask=False, end=end)   # idx_mask=False input
             elif mask is not None:
                 p = proc.step(img, mask.to(device), objects=objs, force_permanent=(t in sc.get('permanent_at', ())), end=end)
             else:

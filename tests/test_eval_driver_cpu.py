@@ -184,3 +184,40 @@ def test_score_dumps_and_multi_scale_merge(tmp_path, product_net):
     with pytest.raises(ValueError):
         from cutie_amd.inference.utils.results_utils import ResultSaver
         ResultSaver(out, 'x', dataset='d17-val', object_manager=None, use_long_id=False, save_scores=True)
+
+
+def test_process_video_workflow(tmp_path, product_net):
+    """Section 8(f) rank 3: scripts/process_video.py -- masks committed to permanent memory first, then the whole video,
+    memory clean-up by device-memory ratio.  (The step sequence itself is pinned to the reference by scenario small_video.)"""
+    from cutie_amd.process_video import check_to_clear_non_permanent_memory, one_hot_planes, process_video, video_config
+    from cutie_amd.utils.synth import SyntheticClip
+    clip = SyntheticClip(64, 96, 2, 7, seed=4)
+    frames, masks, out = os.path.join(tmp_path, 'frames'), os.path.join(tmp_path, 'masks'), os.path.join(tmp_path, 'out')
+    os.makedirs(frames); os.makedirs(masks)
+    for t in range(7):
+        Image.fromarray((clip.frame(t).permute(1, 2, 0).numpy() * 255).round().astype(np.uint8)).save(
+            os.path.join(frames, f'{t:07d}.png'))
+    m0 = clip.first_mask().numpy().astype(np.uint8)
+    for t in (0, 4):
+        png = Image.fromarray(m0); png.putpalette(davis_palette); png.save(os.path.join(masks, f'{t:07d}.png'))
+    assert torch.equal(one_hot_planes(m0, 2, 'cpu'), torch.nn.functional.one_hot(torch.from_numpy(m0).long(), 3).permute(2, 0, 1).float()[1:])
+    with pytest.raises(RuntimeError):
+        one_hot_planes(m0, 1, 'cpu')
+    cfg = video_config(mem_every=2, max_internal_size=-1)
+    assert cfg.use_long_term and video_config().mem_every == 10 and video_config().max_internal_size == 480
+    calls = []
+
+    def fake_info():                                    # 95 % used on the 4th query only
+        calls.append(1)
+        return (5, 100) if len(calls) == 4 else (60, 100)
+
+    r = process_video(product_net, cfg, frames, masks, out, mem_cleanup_ratio=0.9, mem_get_info=fake_info)
+    assert r['frames'] == 7 and r['num_objects'] == 2 and r['cleanups'] == 1 and len(calls) == 7
+    proc = r['processor']
+    HW = (64 // 16) * (96 // 16)
+    # two committed masks + the same two met again in the video (each first-in-bucket / forced insert is permanent)
+    assert proc.memory.work_mem.perm_size(0) >= 2 * HW
+    assert sorted(os.listdir(out)) == [f'{t:07d}.png' for t in range(7)]
+    p0 = Image.open(os.path.join(out, '0000000.png'))
+    assert p0.mode == 'P' and np.array_equal(np.array(p0), m0)          # a one-hot mask comes back as itself
+    assert not check_to_clear_non_permanent_memory(proc, -1, fake_info) and len(calls) == 7

@@ -104,7 +104,7 @@ def _run_product(net, name):
     return outs, sizes
 
 
-@pytest.mark.parametrize('name', ['small_fifo', 'small_add_del', 'small_lt', 'small_interactive', 'small_flip', 'small_chunk', 'small_misc', 'small_clear'])
+@pytest.mark.parametrize('name', ['small_fifo', 'small_add_del', 'small_lt', 'small_interactive', 'small_flip', 'small_chunk', 'small_misc', 'small_clear', 'small_video'])
 def test_trajectory_matches_oracle(name, product_net, oracle_net):
     gold = np.load(S.GOLDEN_DIR + f'/{name}.npz')
 
