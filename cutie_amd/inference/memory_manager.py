@@ -195,7 +195,10 @@ class MemoryManager:
         return None
 
     # ---- write (memory_manager.py:210-296) ------------------------------------------------------------------------
-    def add_memory(self, key, shrinkage, msk_value, obj_value, objects: List[int], selection=None, *, as_permanent='no') -> None:
+    def add_memory(self, key, shrinkage, msk_value, obj_value, objects: List[int], selection=None, *, as_permanent=False) -> None:
+        # the default is the reference's (memory_manager.py:218) and just as unusable: its store asserts the same
+        # (kv_memory_store.py:79); InferenceCore always passes 'no' / 'first' / 'all'
+        assert as_permanent in ['no', 'first', 'all']
         bs = key.shape[0]
         assert bs == 1 and shrinkage.shape[0] == 1 and msk_value.shape[0] == 1
         self.engaged = True

@@ -177,3 +177,36 @@ def test_max_internal_size_path(product_net):
         r0 = ref.step(small, msmall, objects=clip.objects)
         up = torch.nn.functional.interpolate(r0[None], size=(96, 144), mode='bilinear', align_corners=False)[0]
         assert torch.allclose(p0, up, atol=1e-5)
+
+
+def test_caller_visible_attributes(product_net):
+    """the instance attributes reference callers read or write (scripting_demo.py:21, eval_vos.py:101,
+    gui/main_controller.py:107-110,494-516) exist with the reference's meaning."""
+    from cutie_amd.inference.image_feature_store import ImageFeatureStore
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.utils.synth import SyntheticClip
+    cfg = default_config(mem_every=2, use_long_term=True, long_term=dict(count_usage=True, max_mem_frames=4, min_mem_frames=2,
+                                                                         num_prototypes=8, max_num_tokens=40, buffer_tokens=12))
+    store = ImageFeatureStore(product_net, no_warning=True)
+    proc = InferenceCore(product_net, cfg=cfg, image_feature_store=store)
+    assert proc.image_feature_store is store and proc.curr_ti == -1 and proc.last_mask is None
+    proc.max_internal_size = -1                                   # written by scripting_demo.py:21
+    clip = SyntheticClip(64, 90, 2, 4, seed=2)
+    with torch.inference_mode():
+        proc.step(clip.frame(0), clip.first_mask(), objects=[3, 7])
+        proc.step(clip.frame(1))
+        proc.step(clip.frame(2), delete_buffer=False)
+    HW = 4 * 6
+    m = proc.memory
+    assert proc.curr_ti == 2 and proc.mem_every == 2 and tuple(proc.pad) == (3, 3, 0, 0)
+    assert (m.max_mem_frames, m.min_mem_frames, m.max_long_tokens, m.num_prototypes) == (3, 1, 40, 8)
+    assert m.max_work_tokens == 3 * HW and m.min_work_tokens == 1 * HW
+    assert m.work_mem.perm_size(0) == HW and m.work_mem.non_perm_size(0) == HW and m.long_mem.non_perm_size(0) == 0
+    assert m.work_mem.size(0) == 2 * HW and m.work_mem.engaged() and not m.long_mem.engaged() and m.work_mem.num_objects == 2
+    om = proc.object_manager
+    assert om.all_obj_ids == [3, 7] and om.num_obj == 2 and [o.id for o in om.obj_to_tmp_id] == [3, 7]
+    assert {t: o.id for t, o in om.tmp_id_to_obj.items()} == {1: 3, 2: 7} and om.find_tmp_by_id(7) == 2
+    assert proc.last_mask.shape == (1, 2, 64, 96)
+    assert len(store) == 1                                        # delete_buffer=False kept frame 2's features
+    store.delete(2)
+    assert len(store) == 0
