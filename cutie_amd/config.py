@@ -44,6 +44,10 @@ MODEL_BASE = dict(
     mask_decoder=dict(up_dims=[256, 128, 128]),
 )
 
+# cutie/config/model/small.yaml: base with a ResNet-18 pixel encoder
+MODEL_SMALL = dict(MODEL_BASE, pixel_encoder=dict(type='resnet18', ms_dims=[256, 128, 64]))
+MODELS = {'base': MODEL_BASE, 'small': MODEL_SMALL}
+
 # cutie/config/eval_config.yaml:11-51 + datasets.d17-val (use_long_term False, mem_every 5) hoisted
 EVAL_DEFAULTS = dict(
     exp_id='default', dataset='d17-val', amp=False, weights='output/cutie-base-mega.pth', flip_aug=False,
@@ -55,8 +59,9 @@ EVAL_DEFAULTS = dict(
 
 
 def default_config(**overrides):
+    """eval_config defaults; ``model='small'`` selects model/small.yaml like hydra's ``model=small`` override."""
     cfg = copy.deepcopy(EVAL_DEFAULTS)
     cfg['model'] = copy.deepcopy(MODEL_BASE)
     for k, v in overrides.items():
-        cfg[k] = copy.deepcopy(v)
+        cfg[k] = copy.deepcopy(MODELS[v]) if (k == 'model' and isinstance(v, str)) else copy.deepcopy(v)
     return wrap(cfg)

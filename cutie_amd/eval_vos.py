@@ -4,7 +4,7 @@ first-mask alignment, ``end`` on the last frame, FPS = frames / sum of device-ev
 
     python -m cutie_amd.eval_vos --images DIR/JPEGImages --masks DIR/Annotations --output OUT [--weights ckpt.pth]
         [--size 480] [--use-all-masks] [--long-term] [--dataset d17-val] [--visualize] [--clips-in-flight 4]
-        [--flip-aug] [--save-scores]      (multi-scale testing: one run per --size with --save-scores, then
+        [--model small] [--flip-aug] [--save-scores]      (multi-scale testing: one run per --size with --save-scores, then
                                            python -m cutie_amd.merge_multi_scale --list OUT_a OUT_b --output MERGED)
 
 With several GPUs launch it under torch.distributed.run: videos are sharded over the ranks (cutie_amd/parallel.py)."""
@@ -90,6 +90,7 @@ def main():
     ap.add_argument('--visualize', action='store_true')
     ap.add_argument('--clips-in-flight', type=int, default=1)
     ap.add_argument('--flip-aug', action='store_true')
+    ap.add_argument('--model', default='base', choices=['base', 'small'], help='cutie/config/model/{base,small}.yaml')
     ap.add_argument('--save-scores', action='store_true')
     args = ap.parse_args()
     from .model.cutie import CUTIE
@@ -99,7 +100,7 @@ def main():
     if world > 1:
         dist.init_process_group(backend='nccl')
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-    cfg = default_config(use_long_term=args.long_term, flip_aug=args.flip_aug, save_scores=args.save_scores)
+    cfg = default_config(model=args.model, use_long_term=args.long_term, flip_aug=args.flip_aug, save_scores=args.save_scores)
     net = CUTIE(cfg).cuda().eval()
     if args.weights:
         net.load_weights(torch.load(args.weights, map_location='cpu'))

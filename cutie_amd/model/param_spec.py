@@ -70,10 +70,15 @@ class _Spec(OrderedDict):
                 cin = planes * exp
 
 
-RESNET_LAYERS = {  # name -> (bottleneck?, [(layer attr, planes, blocks, stride)])
-    'pixel_encoder': (True, [('res2', 64, 3, 1), ('layer2', 128, 4, 2), ('layer3', 256, 6, 2)]),
-    'mask_encoder': (False, [('layer1', 64, 2, 1), ('layer2', 128, 2, 2), ('layer3', 256, 2, 2)]),
-}
+def resnet_layers(m, prefix):
+    """-> (bottleneck?, [(layer attr, planes, blocks, stride)]) of a trunk (resnet.py:127-179; the pixel encoder calls its
+    first stage ``res2``, big_modules.py:39).  model/base.yaml: ResNet-50 pixel encoder; model/small.yaml: ResNet-18."""
+    first = 'res2' if prefix == 'pixel_encoder' else 'layer1'
+    kind = m[prefix]['type']
+    assert kind in ('resnet18', 'resnet50'), kind
+    depth = (3, 4, 6) if kind == 'resnet50' else (2, 2, 2)
+    return kind == 'resnet50', [(first, 64, depth[0], 1), ('layer2', 128, depth[1], 2), ('layer3', 256, depth[2], 2)]
+
 
 
 def build_spec(m):
@@ -82,9 +87,9 @@ def build_spec(m):
     ms = m['pixel_encoder']['ms_dims']
     up = m['mask_decoder']['up_dims']
     ot = m['object_transformer']
-    assert m['pixel_encoder']['type'] == 'resnet50' and m['mask_encoder']['type'] == 'resnet18', \
-        'only the base model (resnet50 / resnet18) is supported'
-    s.resnet_trunk('pixel_encoder', True, 3, 'res2')
+    assert m['mask_encoder']['type'] == 'resnet18', 'the mask encoder of every released model is a ResNet-18'
+    s.resnet_trunk('pixel_encoder', resnet_layers(m, 'pixel_encoder')[0], 3, 'res2')
+    assert ms[0] == (1024 if m['pixel_encoder']['type'] == 'resnet50' else 256), 'ms_dims do not match the pixel encoder'
     s.conv('pix_feat_proj', C, ms[0], 1)
     s.conv('key_proj.pix_feat_proj', C, ms[0], 1)
     s.conv('key_proj.key_proj', CK, C, 3)

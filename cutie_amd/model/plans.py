@@ -12,7 +12,7 @@ import torch
 
 from .. import ops as O
 from ..ops import Dyn
-from .param_spec import RESNET_LAYERS
+from .param_spec import resnet_layers
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -189,7 +189,7 @@ class Plan:
 
     def resnet(self, prefix, x, taps=None):
         """ResNet trunk after the stem/pool (resnet.py:51-124); taps: layer attr -> output Act override."""
-        bottleneck, layers = RESNET_LAYERS[prefix]
+        bottleneck, layers = resnet_layers(self.eng.m, prefix)
         feats = {}
         for (lname, planes, nb, lstride) in layers:
             for bi in range(nb):

@@ -13,7 +13,7 @@ reference, on purpose: frames from a directory are RGB (the reference hands Open
 (long-term memory on, mem_every 10, max_internal_size 480).
 
     python -m cutie_amd.process_video -v FRAMES_DIR -m MASK_DIR -o OUT [--weights ckpt.pth] [--mem_every 10]
-        [--max_internal_size 480] [--mem_cleanup_ratio 0.9] [--num_objects N]"""
+        [--max_internal_size 480] [--mem_cleanup_ratio 0.9] [--num_objects N] [--model small]"""
 import os
 from argparse import ArgumentParser
 from os import path
@@ -190,9 +190,10 @@ def main():
     ap.add_argument('--mem_every', type=int, default=10)
     ap.add_argument('--max_internal_size', type=int, default=480)
     ap.add_argument('--mem_cleanup_ratio', type=float, default=-1)
+    ap.add_argument('--model', default='base', choices=['base', 'small'], help='cutie/config/model/{base,small}.yaml')
     args = ap.parse_args()
     from .model.cutie import CUTIE
-    cfg = video_config(mem_every=args.mem_every, max_internal_size=args.max_internal_size)
+    cfg = video_config(model=args.model, mem_every=args.mem_every, max_internal_size=args.max_internal_size)
     net = CUTIE(cfg).cuda().eval()
     if args.weights:
         net.load_weights(torch.load(args.weights, map_location='cpu'))

@@ -21,7 +21,10 @@ MODEL_CFG = dict(
     ms_dims=[1024, 512, 256], up_dims=[256, 128, 128],
     num_heads=8, num_blocks=3, num_queries=16, ff_dim=2048,
     pixel_pe_scale=32, pixel_pe_temperature=128,
+    pixel_encoder_type='resnet50',
 )
+# cutie/config/model/small.yaml: ResNet-18 pixel encoder (the "cutie-small" checkpoints)
+MODEL_CFG_SMALL = dict(MODEL_CFG, pixel_encoder_type='resnet18', ms_dims=[256, 128, 64])
 
 
 def _bn(spec, name, c):
@@ -105,7 +108,7 @@ def param_spec(m=MODEL_CFG):
     s = OrderedDict()
     C, CK, CV, CS, CE = m['pixel_dim'], m['key_dim'], m['value_dim'], m['sensory_dim'], m['embed_dim']
     ms, up = m['ms_dims'], m['up_dims']
-    _resnet(s, 'pixel_encoder', 'resnet50', 3, 'res2')          # big_modules.py:21-54
+    _resnet(s, 'pixel_encoder', m.get('pixel_encoder_type', 'resnet50'), 3, 'res2')   # big_modules.py:21-54
     _conv(s, 'pix_feat_proj', C, ms[0], 1)                      # cutie.py:36
     _conv(s, 'key_proj.pix_feat_proj', C, ms[0], 1)             # big_modules.py:64-87
     _conv(s, 'key_proj.key_proj', CK, C, 3)
@@ -205,7 +208,8 @@ def make_state_dict(seed=0, m=MODEL_CFG):
             if name == 'mask_decoder.pred.bias':
                 v = v - 0.6            # keeps fg/bg balanced with random features
         elif kind == 'bn_w':
-            last = name.endswith('bn3.weight') or (name.endswith('bn2.weight') and 'mask_encoder' in name)
+            basic = 'mask_encoder' in name or m.get('pixel_encoder_type', 'resnet50') == 'resnet18'
+            last = name.endswith('bn3.weight') or (name.endswith('bn2.weight') and basic)
             v = r.uniform(0.7, 1.1, shape) * (0.45 if last else 1.0)
         elif kind == 'bn_b':
             v = r.standard_normal(shape) * 0.05

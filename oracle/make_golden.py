@@ -12,6 +12,7 @@ of oracle/weights.py, and driven through the scenarios of oracle/scenarios.py.  
   tests/golden/<scenario>.npz          sub-sampled per-frame probabilities, argmax md5, memory sizes
   tests/golden/stages.npz              sampled per-stage tensors of the CUTIE facade methods
   tests/golden/state_dict_spec.json    reference state_dict key -> shape (pins oracle/weights.py)
+  tests/golden/model_small.npz, state_dict_spec_small.json   the same for cutie-small (model/small.yaml, ResNet-18 pixel encoder)
 
 TEST INFRASTRUCTURE (see oracle/__init__.py).
 """
@@ -69,9 +70,14 @@ def import_reference():
     return CUTIE, InferenceCore
 
 
-def reference_cfg(**over):
+def reference_cfg(model_name='base', **over):
     R = REF + '/cutie/config/'
     m = yaml.safe_load(open(R + 'model/base.yaml'))
+    if model_name != 'base':                                       # hydra `defaults: [base]` + overrides (model/small.yaml)
+        extra = yaml.safe_load(open(R + f'model/{model_name}.yaml'))
+        extra.pop('defaults')
+        for k, v in extra.items():
+            m[k] = {**m[k], **v} if isinstance(v, dict) else v
     m['object_transformer']['embed_dim'] = m['embed_dim']
     m['object_summarizer']['embed_dim'] = m['embed_dim']
     m['object_summarizer']['num_summaries'] = m['object_transformer']['num_queries']
@@ -102,6 +108,38 @@ def memory_sizes(proc):
     return [w, p, l, len(mem.work_mem.buckets)]
 
 
+def golden_model_small(CUTIE, InferenceCore):
+    """cutie-small (model/small.yaml: ResNet-18 pixel encoder): key set, encoder stage probes and one trajectory
+    (the small_fifo script) -> tests/golden/model_small.npz, state_dict_spec_small.json."""
+    from oracle.weights import MODEL_CFG_SMALL, make_state_dict, param_spec
+    from oracle import scenarios as S
+    from cutie_amd.utils.synth import SyntheticClip
+    net = CUTIE(reference_cfg('small')).eval()
+    ref_sd = net.state_dict()
+    spec = param_spec(MODEL_CFG_SMALL)
+    assert set(ref_sd.keys()) == set(spec.keys()), (set(ref_sd) ^ set(spec))
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(spec[k][0]), (k, v.shape, spec[k])
+    json.dump({k: list(v.shape) for k, v in ref_sd.items()},
+              open(os.path.join(GOLDEN, 'state_dict_spec_small.json'), 'w'), indent=0)
+    net.load_weights({k: v.clone() for k, v in make_state_dict(seed=0, m=MODEL_CFG_SMALL).items()})
+    print('reference cutie-small state_dict:', len(ref_sd), 'tensors,', sum(v.numel() for v in ref_sd.values()) / 1e6, 'M')
+    sizes = []
+    wrap = lambda over: reference_cfg('small', **{k: (_wrap(v) if isinstance(v, dict) else v) for k, v in over.items()})
+    outs, proc = S.run_scenario(lambda over: InferenceCore(net, cfg=wrap(over)), 'small_fifo',
+                                record=lambda t, p: sizes.append(memory_sizes(p)), make_cfg=wrap)
+    rec = S.summarize(outs, S.SCENARIOS['small_fifo']['sub'])
+    rec['mem_sizes'] = np.array(sizes, dtype=np.int64)
+    with torch.inference_mode():
+        img = SyntheticClip(128, 192, 3, 4, seed=5).frame(0).unsqueeze(0)
+        ms, pix = net.encode_image(img)
+        key, shr, sel = net.transform_key(ms[0])
+        for n, t in zip(['f16', 'f8', 'f4', 'pix_feat', 'key', 'shrinkage', 'selection'], [*ms, pix, key, shr, sel]):
+            rec['stage_' + n] = sample_tensor(t)
+    np.savez_compressed(os.path.join(GOLDEN, 'model_small.npz'), **rec)
+    print('model_small frames', len(outs), 'mem', sizes[-1], 'hist', rec[f'hist_{len(outs) - 1}'])
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
     os.makedirs(os.path.join(GOLDEN, 'bike'), exist_ok=True)
@@ -130,7 +168,7 @@ def main():
     # ---- scenario trajectories ------------------------------------------------------
     only = [a for a in sys.argv[1:] if a in S.SCENARIOS]          # e.g. `python oracle/make_golden.py small_interactive`
     for name, sc in S.SCENARIOS.items():
-        if only and name not in only:
+        if (only or 'model_small' in sys.argv[1:]) and name not in only:
             continue
         sizes = []
 
@@ -149,7 +187,9 @@ def main():
         print(name, 'frames', len(outs), 'shape', tuple(outs[-1].shape), 'mem', sizes[-1],
               'hist', rec[f'hist_{len(outs) - 1}'])
 
-    if only:
+    if not only or 'model_small' in sys.argv[1:]:
+        golden_model_small(CUTIE, InferenceCore)
+    if only or 'model_small' in sys.argv[1:]:
         return
     # ---- per-stage probes of the facade methods -----------------------------------------
     from cutie_amd.utils.synth import SyntheticClip

@@ -132,9 +132,13 @@ class OracleNet:
         x = (image - self.mean) / self.std
         x = F.relu(self.bn('pixel_encoder.bn1', self.conv('pixel_encoder.conv1', x, 2, 3)))
         x = F.max_pool2d(x, 3, 2, 1)
-        f4 = self._layer('pixel_encoder.res2', x, 3, 1, self._bottleneck)
-        f8 = self._layer('pixel_encoder.layer2', f4, 4, 2, self._bottleneck)
-        f16 = self._layer('pixel_encoder.layer3', f8, 6, 2, self._bottleneck)
+        if self.m.get('pixel_encoder_type', 'resnet50') == 'resnet18':      # model/small.yaml, big_modules.py:28-29
+            block, depth = self._basic, (2, 2, 2)
+        else:
+            block, depth = self._bottleneck, (3, 4, 6)
+        f4 = self._layer('pixel_encoder.res2', x, depth[0], 1, block)
+        f8 = self._layer('pixel_encoder.layer2', f4, depth[1], 2, block)
+        f16 = self._layer('pixel_encoder.layer3', f8, depth[2], 2, block)
         return (f16, f8, f4), self.conv('pix_feat_proj', f16)
 
     # ---- CUTIE.transform_key (cutie.py:92-98, big_modules.py:81-87) ---------------

@@ -1,0 +1,51 @@
+"""cutie-small (cutie/config/model/small.yaml: ResNet-18 pixel encoder, multi-scale dims [256,128,64]) on the MI355X against the
+oracle, which is pinned to the executed reference for this variant too (tests/golden/model_small.npz).  Same tolerances as
+tests/test_gpu_parity.py.  (The file sorts after the base-model suites on purpose: it is the newest widening.)"""
+import pytest
+import torch
+
+from cutie_amd import _lib
+from cutie_amd.config import default_config
+from oracle import scenarios as S
+from oracle.inference import OracleProcessor, DEFAULT_CFG
+from oracle.weights import MODEL_CFG_SMALL, make_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    assert torch.isfinite(a).all()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-6))
+
+
+def test_small_model_on_gpu():
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.model.cutie import CUTIE
+    from cutie_amd.utils.synth import SyntheticClip
+    from oracle.net import OracleNet
+    _lib.set_executor_for_testing(None)
+    sd = make_state_dict(seed=0, m=MODEL_CFG_SMALL)
+    onet = OracleNet(sd, MODEL_CFG_SMALL)
+    net = CUTIE(default_config(model='small')).cuda().eval()
+    net.load_weights(sd)
+    assert not _lib.get_executor().is_mock
+    with torch.inference_mode():
+        img = SyntheticClip(128, 192, 3, 4, seed=5).frame(0).unsqueeze(0)
+        ms, pix = net.encode_image(img.cuda())
+        key, shr, sel = net.transform_key(ms[0])
+        oms, opix = onet.encode_image(img)
+        okey, oshr, osel = onet.transform_key(oms[0])
+        assert [t.shape[1] for t in ms] == [256, 128, 64]
+        for n, a, b in zip(['f16', 'f8', 'f4', 'pix', 'key', 'shr', 'sel'], [*ms, pix, key, shr, sel], [*oms, opix, okey, oshr, osel]):
+            assert a.shape == b.shape and rel_err(a, b) < 3e-2, (n, rel_err(a, b))
+    cfgs = lambda over: default_config(model='small', **over)
+    outs, _ = S.run_scenario(lambda over: InferenceCore(net, cfg=cfgs(over)), 'small_fifo', device='cuda', make_cfg=cfgs)
+    oouts, _ = S.run_scenario(lambda over: OracleProcessor(onet, dict(DEFAULT_CFG, **over)), 'small_fifo')
+    for t, (p, o) in enumerate(zip(outs, oouts)):
+        assert torch.isfinite(p).all()
+        d = (p - o).abs()
+        assert float(d.max()) < 0.15 and float(d.mean()) < 0.05, (t, float(d.max()), float(d.mean()))
+        top2 = o.topk(2, dim=0)[0]
+        confident = (top2[0] - top2[1]) > 0.30
+        assert bool((p.argmax(0) == o.argmax(0))[confident].all()), t

@@ -210,3 +210,43 @@ def test_caller_visible_attributes(product_net):
     assert len(store) == 1                                        # delete_buffer=False kept frame 2's features
     store.delete(2)
     assert len(store) == 0
+
+
+def test_small_model_variant():
+    """cutie-small (model/small.yaml: ResNet-18 pixel encoder, ms_dims [256,128,64]): the reference's 359-key state_dict, encoder
+    stages and a whole trajectory against the oracle (itself pinned to the executed reference, tests/golden/model_small.npz)."""
+    import json, os
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.model.cutie import CUTIE
+    from cutie_amd.utils.synth import SyntheticClip
+    from oracle.net import OracleNet
+    from oracle.weights import MODEL_CFG_SMALL
+    sd = make_state_dict(seed=0, m=MODEL_CFG_SMALL)
+    onet = OracleNet(sd, MODEL_CFG_SMALL)
+    prev = _lib._executor
+    _lib.set_executor_for_testing(MockExecutor())
+    try:
+        net = CUTIE(default_config(model='small'))
+        ref = json.load(open(os.path.join(S.GOLDEN_DIR, 'state_dict_spec_small.json')))
+        assert list(net.state_dict().keys()) == list(ref.keys())
+        net.load_weights(sd)
+        with torch.inference_mode():
+            img = SyntheticClip(128, 192, 3, 4, seed=5).frame(0).unsqueeze(0)
+            ms, pix = net.encode_image(img)
+            key, shr, sel = net.transform_key(ms[0])
+            oms, opix = onet.encode_image(img)
+            okey, oshr, osel = onet.transform_key(oms[0])
+            assert [t.shape[1] for t in ms] == [256, 128, 64]
+            for n, a, b in zip(['f16', 'f8', 'f4', 'pix', 'key', 'shr', 'sel'], [*ms, pix, key, shr, sel], [*oms, opix, okey, oshr, osel]):
+                assert a.shape == b.shape and rel_err(a, b) < 3e-2, (n, rel_err(a, b))
+        cfgs = lambda over: default_config(model='small', **over)
+        outs, _ = S.run_scenario(lambda over: InferenceCore(net, cfg=cfgs(over)), 'small_fifo', make_cfg=cfgs)
+        oouts, _ = S.run_scenario(lambda over: OracleProcessor(onet, dict(DEFAULT_CFG, **over)), 'small_fifo')
+        worst = 0.0
+        for t, (p, o) in enumerate(zip(outs, oouts)):
+            err = float((p - o).abs().max())
+            assert err < 0.15 and float((p - o).abs().mean()) < 0.05, (t, err)
+            worst = max(worst, err)
+        print('cutie-small worst prob err', worst)
+    finally:
+        _lib.set_executor_for_testing(prev)

@@ -112,3 +112,39 @@ def test_oracle_matches_reference_stages(oracle_net):
         a, b = _sample(got[n]), gold[n]
         scale = max(float(np.abs(b[2:]).max()), 1e-3)
         assert np.abs(a - b).max() <= 1e-3 * scale + 1e-5, (n, np.abs(a - b).max(), scale)
+
+
+# ---- cutie-small (cutie/config/model/small.yaml: ResNet-18 pixel encoder) -----------------------------------------------------
+@pytest.fixture(scope='module')
+def oracle_net_small():
+    from oracle.net import OracleNet
+    from oracle.weights import MODEL_CFG_SMALL, make_state_dict
+    return OracleNet(make_state_dict(seed=0, m=MODEL_CFG_SMALL), MODEL_CFG_SMALL)
+
+
+def test_small_model_spec_and_oracle_match_reference(oracle_net_small):
+    import json
+    from cutie_amd.utils.synth import SyntheticClip
+    from oracle.weights import MODEL_CFG_SMALL, param_spec
+    ref = json.load(open(os.path.join(GOLDEN, 'state_dict_spec_small.json')))
+    spec = param_spec(MODEL_CFG_SMALL)
+    assert len(ref) == 359 and set(ref) == set(spec)
+    for k, shp in ref.items():
+        assert tuple(shp) == tuple(spec[k][0]), k
+    gold = np.load(os.path.join(GOLDEN, 'model_small.npz'))
+    net = oracle_net_small
+    with torch.inference_mode():
+        img = SyntheticClip(128, 192, 3, 4, seed=5).frame(0).unsqueeze(0)
+        ms, pix = net.encode_image(img)
+        key, shr, sel = net.transform_key(ms[0])
+        assert [t.shape[1] for t in ms] == [256, 128, 64]
+        for n, t in zip(['f16', 'f8', 'f4', 'pix_feat', 'key', 'shrinkage', 'selection'], [*ms, pix, key, shr, sel]):
+            np.testing.assert_allclose(_sample(t), gold['stage_' + n], rtol=1e-3, atol=2e-4, err_msg=n)
+    sizes = []
+    outs, _ = S.run_scenario(lambda over: OracleProcessor(net, dict(DEFAULT_CFG, **over)), 'small_fifo',
+                             record=lambda t, p: sizes.append(_mem_sizes(p)))
+    assert np.array_equal(np.array(sizes), gold['mem_sizes'])
+    sub = S.SCENARIOS['small_fifo']['sub']
+    for t, p in enumerate(outs):
+        ref_p = torch.from_numpy(gold[f'prob_{t}'].astype(np.float32))
+        assert (p[:, ::sub, ::sub] - ref_p).abs().max().item() < 2e-3, t
