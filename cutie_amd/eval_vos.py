@@ -18,6 +18,7 @@ from typing import Dict
 import torch
 
 from .config import default_config
+from .inference.data.prefetch import ReadAhead
 from .inference.data.vos_test_dataset import VOSTestDataset
 from .inference.inference_core import InferenceCore
 from .inference.utils.results_utils import ResultSaver, make_zip
@@ -26,7 +27,8 @@ log = logging.getLogger()
 
 
 def process_video(network, cfg, vid_reader, mask_output_root, *, dataset='generic', save_all=True, visualize=False,
-                  visualize_output_root=None, lookahead=True, save_scores=False, score_output_root=None) -> Dict:
+                  visualize_output_root=None, lookahead=True, save_scores=False, score_output_root=None,
+                  read_workers=4) -> Dict:
     """One video through a fresh InferenceCore (eval_vos.py:97-151).  Returns {'frames', 'seconds'} (time around step)."""
     processor = InferenceCore(network, cfg=cfg)
     saver = ResultSaver(mask_output_root, vid_reader.vid_name, dataset=dataset, object_manager=processor.object_manager,
@@ -38,9 +40,10 @@ def process_video(network, cfg, vid_reader, mask_output_root, *, dataset='generi
     n = len(vid_reader)
     total, frames, first_mask_loaded = 0.0, 0, False
     try:
-        nxt = vid_reader[0] if n else None
+        loader = iter(ReadAhead(vid_reader, workers=read_workers))      # decode runs ahead on threads (eval_vos.py:92)
+        nxt = next(loader, None)
         for ti in range(n):
-            data, nxt = nxt, (vid_reader[ti + 1] if ti + 1 < n else None)
+            data, nxt = nxt, next(loader, None)
             image = data['rgb'].to(dev)
             next_image = nxt['rgb'].to(dev) if (nxt is not None and lookahead) else None
             if nxt is not None and next_image is not None:
@@ -89,6 +92,7 @@ def main():
     ap.add_argument('--long-term', action='store_true')
     ap.add_argument('--visualize', action='store_true')
     ap.add_argument('--clips-in-flight', type=int, default=1)
+    ap.add_argument('--read-workers', type=int, default=4, help='decode threads per clip (0 = inline)')
     ap.add_argument('--flip-aug', action='store_true')
     ap.add_argument('--model', default='base', choices=['base', 'small'], help='cutie/config/model/{base,small}.yaml')
     ap.add_argument('--save-scores', action='store_true')
@@ -110,7 +114,8 @@ def main():
     mask_root = path.join(args.output, 'Annotations')
     run = lambda view, c: process_video(view, cfg, readers[c], mask_root, dataset=args.dataset, visualize=args.visualize,
                                         visualize_output_root=path.join(args.output, 'Visualizations'),
-                                        save_scores=args.save_scores, score_output_root=path.join(args.output, 'Scores'))
+                                        save_scores=args.save_scores, score_output_root=path.join(args.output, 'Scores'),
+                                        read_workers=args.read_workers)
     with torch.inference_mode():
         res = run_concurrent(net, mine, run, streams=max(1, args.clips_in_flight))
     frames, secs = sum(r['frames'] for r in res.values()), sum(r['seconds'] for r in res.values())

@@ -24,6 +24,7 @@ import torch
 from PIL import Image
 
 from .config import default_config
+from .inference.data.prefetch import ReadAhead
 from .inference.inference_core import InferenceCore
 from .inference.utils.results_utils import ResultSaver
 
@@ -74,8 +75,8 @@ class FrameSource:
         return torch.from_numpy(arr).permute(2, 0, 1).float() / 255
 
     def __iter__(self) -> Iterator[torch.Tensor]:
-        for i in range(self.count):
-            f = self.read(i)
+        # a directory decodes ahead on threads; a cv2.VideoCapture is a sequential, stateful decoder -> inline
+        for f in ReadAhead(self, workers=4 if self.cap is None else 0, length=self.count, getitem=self.read):
             if f is None:
                 return
             yield f

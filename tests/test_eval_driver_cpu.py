@@ -221,3 +221,34 @@ def test_process_video_workflow(tmp_path, product_net):
     p0 = Image.open(os.path.join(out, '0000000.png'))
     assert p0.mode == 'P' and np.array_equal(np.array(p0), m0)          # a one-hot mask comes back as itself
     assert not check_to_clear_non_permanent_memory(proc, -1, fake_info) and len(calls) == 7
+
+
+def test_read_ahead_is_ordered_and_bounded():
+    """The threaded loader yields source[i] in order, keeps at most ``depth`` items in flight, surfaces a reader error at the
+    frame it belongs to, and degrades to inline reads with workers=0."""
+    import threading, time
+    from cutie_amd.inference.data.prefetch import ReadAhead
+    started, lock = [], threading.Lock()
+
+    class Src:
+        def __len__(self):
+            return 23
+
+        def __getitem__(self, i):
+            with lock:
+                started.append(i)
+            time.sleep(0.002 * ((i * 7) % 5))                 # out-of-order completion
+            if i == 17:
+                raise ValueError('bad frame 17')
+            return i * i
+
+    got = []
+    with pytest.raises(ValueError, match='bad frame 17'):
+        for k, v in enumerate(ReadAhead(Src(), workers=4, depth=5)):
+            got.append(v)
+            with lock:
+                assert max(started) <= k + 5                  # never more than `depth` frames ahead of the consumer
+    assert got == [i * i for i in range(17)]
+    assert list(ReadAhead(list(range(9)), workers=0)) == list(range(9))
+    assert list(ReadAhead(None, workers=2, length=4, getitem=lambda i: -i)) == [0, -1, -2, -3]
+    assert list(ReadAhead([], workers=3)) == []
