@@ -250,3 +250,61 @@ def test_small_model_variant():
         print('cutie-small worst prob err', worst)
     finally:
         _lib.set_executor_for_testing(prev)
+
+
+@pytest.mark.parametrize('name', ['small_lt', 'small_interactive'])
+def test_bank_contents_match_oracle(name, product_net, oracle_net):
+    """SURVEY 8c(iii), beyond token counts: at the end of a trajectory the product's bank holds the same SET of tokens as the
+    oracle's stores -- per region (long-term / permanent / working) and per object the value rows, and in long-term mode the raw
+    keys with their usage / life counters.  The physical order differs by design (FIFO ring, in-place compaction), so rows are
+    matched through a fixed random projection."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    procs = {}
+    S.run_scenario(lambda over: procs.setdefault('o', OracleProcessor(oracle_net, dict(DEFAULT_CFG, **over))), name)
+    S.run_scenario(lambda over: procs.setdefault('p', InferenceCore(product_net, cfg=default_config(**over))), name,
+                   make_cfg=lambda over: default_config(**over))
+    o, p = procs['o'], procs['p']
+    g = torch.Generator().manual_seed(5)
+    rv, rk = torch.randn(256, generator=g), torch.randn(64, generator=g)
+
+    def match(a, b, tol, what):
+        assert a.shape == b.shape, (what, a.shape, b.shape)
+        sa, sb = torch.sort(a)[0], torch.sort(b)[0]
+        assert float((sa - sb).abs().max()) <= tol * max(1.0, float(sb.abs().max())), (what, float((sa - sb).abs().max()))
+
+    assert sorted(o.work.buckets) == sorted(p.memory.buckets)
+    for bid, bucket in p.memory.buckets.items():
+        assert bucket.objects == o.work.buckets[bid]
+        perm = o.work.perm_end[bid]
+        n_long = o.long.size(bid) if (o.use_long_term and bid in o.long.buckets) else 0
+        assert (bucket.n_long, bucket.n_perm, bucket.n_work) == (n_long, perm, o.work.size(bid) - perm)
+        regions = {'perm': (bucket.perm_start, bucket.n_perm), 'work': (bucket.work_start, bucket.n_work), 'long': (0, bucket.n_long)}
+        for obj in bucket.objects:
+            ov = {'perm': o.work.v[obj][:, :perm], 'work': o.work.v[obj][:, perm:]}
+            if n_long:
+                ov['long'] = o.long.v[obj]
+            for reg, t in ov.items():
+                a0, n = regions[reg]
+                match(bucket.values[obj][a0:a0 + n].float() @ rv, rv @ t, 3e-2, (bid, obj, reg, 'value'))
+        if o.use_long_term:
+            a0, n = regions['work']
+            ok = o.work.k[bid][:, perm:]
+            pk = bucket.rawkey[a0:a0 + n]
+            match(pk @ rk, rk @ ok, 3e-2, (bid, 'work key'))
+            # counters travel with their token: pair every product token with its nearest oracle key (must be a bijection)
+            nn = torch.cdist(pk, ok.t().contiguous()).argmin(1)
+            assert sorted(nn.tolist()) == list(range(n)), (bid, 'keys do not pair one-to-one')
+            life_o, life_p = o.work.life[bid][nn], bucket.life[a0:a0 + n]
+            use_o, use_p = o.work.use[bid][nn], bucket.use[a0:a0 + n]
+            assert float((life_o - life_p).abs().max()) < 1e-3, (bid, 'life')
+            assert float((use_o - use_p).abs().max()) < 0.25 and float((use_o - use_p).abs().mean()) < 0.02, \
+                (bid, 'use', float((use_o - use_p).abs().max()))
+            if n_long:
+                # prototypes are the top-usage candidates (memory_manager.py:338-341): near-ties in usage may pick different
+                # tokens under bf16, so the long-term sets agree for most, not all, prototypes; a shared prototype is the
+                # same key (it is a copy of a working-memory key)
+                lk, olk = bucket.rawkey[:n_long], o.long.k[bid].t().contiguous()
+                d = torch.cdist(lk, olk).min(1)[0] / olk.norm(dim=1).mean()
+                shared = float((d < 3e-2).float().mean())
+                print(name, 'bucket', bid, 'shared long-term prototypes', shared)
+                assert shared > 0.6, (bid, 'long-term prototypes', shared)
