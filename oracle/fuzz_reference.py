@@ -1,0 +1,122 @@
+"""Differential fuzz of the oracle against the EXECUTED reference: random event scripts (objects added over time, deletions,
+re-specified masks, soft float masks, permanent commits, update_config, clear_* calls, end flag; random memory settings incl.
+long-term memory and object chunks) are run through the unmodified reference InferenceCore and through OracleProcessor with
+the same weights; per-frame probabilities and memory-bank sizes must agree.  Complements the fixed golden scenarios
+(tests/golden): those travel to the GPU box, this runs only where /root/reference exists (the build container).
+
+    python oracle/fuzz_reference.py --seeds 0 1 2 [--frames 14]
+
+TEST INFRASTRUCTURE (see oracle/__init__.py)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, '..'))
+from oracle.make_golden import _wrap, import_reference, memory_sizes, reference_cfg      # noqa: E402
+
+
+def random_scenario(seed, frames):
+    from oracle.scenarios import LT_SMALL
+    r = np.random.Generator(np.random.PCG64(seed))
+    k = int(r.integers(2, 5))
+    cfg = dict(mem_every=int(r.integers(2, 4)), max_mem_frames=int(r.integers(2, 4)), stagger_updates=int(r.choice([1, 2, 5])))
+    if r.random() < 0.4:
+        cfg.update(use_long_term=True, long_term=dict(LT_SMALL))
+    if r.random() < 0.3:
+        cfg['chunk_size'] = int(r.integers(1, 3))
+    sc = dict(cfg=cfg, kind='synth', h=int(r.choice([80, 96, 100])), w=int(r.choice([112, 120, 136])), k=k, frames=frames, sub=2,
+              add_at={}, delete_at={}, float_mask_at=[], end_at=[], permanent_at=[], update_config_at={},
+              clear_non_permanent_at=[], repropagate_at=[], clear_memory_at=[])
+    first = int(r.integers(1, k + 1))
+    alive, unseen, deleted = list(range(1, first + 1)), list(range(first + 1, k + 1)), False
+    sc['add_at'][0] = list(alive)
+    if r.random() < 0.3:
+        sc['float_mask_at'].append(0)
+    for t in range(1, frames):
+        u = r.random()
+        if u < 0.12 and unseen:                                   # new objects, optionally together with known ones
+            n_new = int(r.integers(1, len(unseen) + 1))
+            new, unseen = unseen[:n_new], unseen[n_new:]
+            known = [o for o in alive if r.random() < 0.4]
+            sc['add_at'][t] = known + new                          # tmp-id order: known objects first (object_manager.py:53)
+            alive += new
+        elif u < 0.20 and len(alive) > 1:
+            victim = int(r.choice(alive))
+            alive.remove(victim)
+            deleted = True
+            sc['delete_at'][t] = [victim]
+        elif u < 0.28:                                             # every known object re-specified (need_segment False)
+            sc['add_at'][t] = list(alive)
+            if r.random() < 0.4 and not deleted and alive == list(range(1, len(alive) + 1)):
+                sc['float_mask_at'].append(t)
+            if r.random() < 0.5:
+                sc['permanent_at'].append(t)
+        elif u < 0.33:
+            sc['update_config_at'][t] = dict(mem_every=int(r.integers(2, 5)))
+        elif u < 0.38:
+            sc['clear_non_permanent_at'].append(t)
+        elif u < 0.43 and not deleted and alive == list(range(1, len(alive) + 1)):
+            sc['repropagate_at'].append(t)                         # clear_sensory_memory + previous soft output as the mask
+        elif u < 0.46:
+            sc['clear_memory_at'].append(t)
+            sc['add_at'][t] = list(alive)
+    if r.random() < 0.5:
+        sc['end_at'].append(frames - 1)
+    return sc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--seeds', type=int, nargs='+', default=[0, 1, 2])
+    ap.add_argument('--frames', type=int, default=14)
+    ap.add_argument('--tol', type=float, default=5e-3)
+    args = ap.parse_args()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    CUTIE, InferenceCore = import_reference()
+    from oracle import scenarios as S
+    from oracle.inference import DEFAULT_CFG, OracleProcessor
+    from oracle.net import OracleNet
+    from oracle.weights import make_state_dict
+    sd = make_state_dict(seed=0)
+    net = CUTIE(reference_cfg()).eval()
+    net.load_weights({k: v.clone() for k, v in sd.items()})
+    onet = OracleNet(sd)
+    wrap = lambda over: reference_cfg(**{k: (_wrap(v) if isinstance(v, dict) else v) for k, v in over.items()})
+    bad = 0
+    for seed in args.seeds:
+        sc = random_scenario(seed, args.frames)
+        S.SCENARIOS['_fuzz'] = sc
+        rs, os_ = [], []
+        try:
+            routs, _ = S.run_scenario(lambda over: InferenceCore(net, cfg=wrap(over)), '_fuzz',
+                                      record=lambda t, p: rs.append(memory_sizes(p)), make_cfg=wrap)
+        except Exception as e:                                     # the script trips a bug of the reference itself: not comparable
+            print(f'seed {seed}: skipped, the reference raised {type(e).__name__}: {e}')
+            continue
+
+        def osizes(p):
+            w = sum(p.work.size(b) for b in p.work.buckets)
+            pe = sum(p.work.perm_end[b] for b in p.work.buckets)
+            lt = sum(p.long.size(b) for b in p.long.buckets) if p.use_long_term else 0
+            return [w, pe, lt, len(p.work.buckets)]
+
+        oouts, _ = S.run_scenario(lambda over: OracleProcessor(onet, dict(DEFAULT_CFG, **over)), '_fuzz',
+                                  record=lambda t, p: os_.append(osizes(p)))
+        errs = [float((a - b).abs().max()) if a.shape == b.shape else float('inf') for a, b in zip(routs, oouts)]
+        ok = rs == os_ and max(errs) < args.tol
+        bad += not ok
+        events = {k: v for k, v in sc.items() if k.endswith('_at') and v}
+        print(f'seed {seed}: {"ok " if ok else "FAIL"} max|dprob| {max(errs):.2e} sizes_equal {rs == os_} cfg {sc["cfg"]} k={sc["k"]} {events}')
+        if not ok:
+            print('   per-frame errors', [f'{e:.1e}' for e in errs])
+            print('   ref sizes   ', rs)
+            print('   oracle sizes', os_)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == '__main__':
+    main()

@@ -49,3 +49,38 @@ def test_small_model_on_gpu():
         top2 = o.topk(2, dim=0)[0]
         confident = (top2[0] - top2[1]) > 0.30
         assert bool((p.argmax(0) == o.argmax(0))[confident].all()), t
+
+
+@pytest.mark.parametrize('seed', [0, 2, 4])
+def test_random_scripts_on_gpu(seed, oracle_net):
+    """Random event scripts (oracle/fuzz_reference.py; the oracle agrees with the executed reference on them to 2e-6) through
+    the HIP path: bank bookkeeping exact, probabilities within the trajectory tolerance."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.model.cutie import CUTIE
+    from oracle.fuzz_reference import random_scenario
+    _lib.set_executor_for_testing(None)
+    net = CUTIE(default_config()).cuda().eval()
+    net.load_weights(make_state_dict(seed=0))
+    S.SCENARIOS['_fuzz'] = random_scenario(seed, 14)
+    try:
+        ps, os_ = [], []
+
+        def psz(p):
+            m = p.memory
+            ps.append([sum(b.n_perm + b.n_work for b in m.buckets.values()), sum(b.n_perm for b in m.buckets.values()),
+                       sum(b.n_long for b in m.buckets.values()), len(m.buckets)])
+
+        def osz(p):
+            os_.append([sum(p.work.size(b) for b in p.work.buckets), sum(p.work.perm_end[b] for b in p.work.buckets),
+                        sum(p.long.size(b) for b in p.long.buckets) if p.use_long_term else 0, len(p.work.buckets)])
+
+        oouts, _ = S.run_scenario(lambda over: OracleProcessor(oracle_net, dict(DEFAULT_CFG, **over)), '_fuzz', record=lambda t, p: osz(p))
+        outs, _ = S.run_scenario(lambda over: InferenceCore(net, cfg=default_config(**over)), '_fuzz', device='cuda',
+                                 record=lambda t, p: psz(p), make_cfg=lambda over: default_config(**over))
+    finally:
+        del S.SCENARIOS['_fuzz']
+    assert ps == os_
+    for t, (p, o) in enumerate(zip(outs, oouts)):
+        assert torch.isfinite(p).all()
+        d = (p - o).abs()
+        assert float(d.max()) < 0.15 and float(d.mean()) < 0.05, (seed, t, float(d.max()), float(d.mean()))
