@@ -15,5 +15,7 @@ so the oracle is pinned against the *executed reference*: ``oracle/make_golden.p
 imports the unmodified reference from ``/root/reference`` (CPU, fp32), runs it on
 seeded inputs with the deterministic synthetic weights (``cutie_amd/utils/synth_weights.py``) and commits
 sub-sampled outputs under ``tests/golden/``; ``tests/test_oracle_golden.py``
-checks this restatement against those vectors.
+checks this restatement against those vectors.  ``oracle/fuzz_reference.py`` additionally compares the
+oracle with the live reference on random event scripts (agreement to ~2e-6), and
+``oracle/make_api_surface.py`` records the reference's public signatures for the drop-in test.
 """
