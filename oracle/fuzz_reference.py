@@ -66,6 +66,12 @@ def random_scenario(seed, frames):
             sc['add_at'][t] = list(alive)
     if r.random() < 0.5:
         sc['end_at'].append(frames - 1)
+    # drawn last so that the event scripts of earlier seeds stay what they were
+    if r.random() < 0.2:
+        cfg['flip_aug'] = True
+    if r.random() < 0.25 and sc['h'] > 80:
+        cfg['max_internal_size'] = 80                              # shorter side 96 / 100 -> internal resize path, still >= 30 tokens
+                                                                   # (with fewer than top_k tokens the reference's topk raises)
     return sc
 
 
@@ -110,7 +116,8 @@ def main():
         ok = rs == os_ and max(errs) < args.tol
         bad += not ok
         events = {k: v for k, v in sc.items() if k.endswith('_at') and v}
-        print(f'seed {seed}: {"ok " if ok else "FAIL"} max|dprob| {max(errs):.2e} sizes_equal {rs == os_} cfg {sc["cfg"]} k={sc["k"]} {events}')
+        brief = {k: v for k, v in sc['cfg'].items() if k != 'long_term'}
+        print(f'seed {seed}: {"ok " if ok else "FAIL"} max|dprob| {max(errs):.2e} sizes_equal {rs == os_} {sc["h"]}x{sc["w"]} k={sc["k"]} cfg {brief} {events}')
         if not ok:
             print('   per-frame errors', [f'{e:.1e}' for e in errs])
             print('   ref sizes   ', rs)

@@ -24,7 +24,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 
 @pytest.mark.skipif(not os.path.isdir('/root/reference/cutie'), reason='the reference checkout only exists in the build container')
 def test_oracle_matches_live_reference_on_random_scripts():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'fuzz_reference.py'), '--seeds', '3', '5', '8', '--tol', '2e-3'],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'fuzz_reference.py'), '--seeds', '5', '8', '20', '--tol', '2e-3'],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     lines = [ln for ln in r.stdout.split('\n') if ln.startswith('seed')]
     assert r.returncode == 0 and len(lines) == 3 and all(': ok' in ln for ln in lines), r.stdout[-3000:] + r.stderr[-2000:]
@@ -52,7 +52,7 @@ def oracle_sizes(p):
             sum(p.long.size(b) for b in p.long.buckets) if p.use_long_term else 0, len(p.work.buckets)]
 
 
-@pytest.mark.parametrize('seed', [0, 2, 6, 9])
+@pytest.mark.parametrize('seed', [0, 6, 20, 32])      # long-term + chunks; reference-crashing script; flip_aug; internal resize
 def test_product_matches_oracle_on_random_scripts(seed, product_net, oracle_net):
     """(seed 6 is a script the reference itself cannot run: deleting the only object of a bucket that holds nothing but
     permanent memory in long-term mode raises KeyError at kv_memory_store.py:300; oracle and product purge it cleanly.)"""
