@@ -279,7 +279,9 @@ class OracleProcessor:
         return tmp
 
     def delete_objects(self, objects):
-        # inference_core.py:330-335, memory_manager.py:298-307
+        # inference_core.py:330-335, memory_manager.py:298-307; a single id is accepted too (object_manager.py:59-60)
+        if isinstance(objects, int):
+            objects = [objects]
         if self._flip is not None:
             self._flip.obj_ids = list(self.obj_ids)
             self._flip.delete_objects(objects)

@@ -1,0 +1,46 @@
+"""Edge / error behaviour of the InferenceCore surface (segment without memory, empty masks, missing `objects`, unsorted object
+lists, deleting unknown / all objects, `end` on the first frame, arbitrary object ids, float masks without ids, odd frame
+sizes): the outcomes recorded from the EXECUTED reference (oracle/make_edge_cases.py -> tests/golden/edge_cases.json) must be
+reproduced by the product (descriptor interpreter on CPU) and by the oracle -- same exception types, same result summaries."""
+import json
+import os
+
+import pytest
+
+from cutie_amd import _lib
+from cutie_amd.config import default_config
+from oracle.edge_cases import CASES, run_case
+from oracle.inference import OracleProcessor, DEFAULT_CFG
+from oracle.weights import make_state_dict
+
+from mock_exec import MockExecutor
+
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'edge_cases.json')))
+
+
+@pytest.fixture(scope='module')
+def product_net():
+    from cutie_amd.model.cutie import CUTIE
+    prev = _lib._executor
+    _lib.set_executor_for_testing(MockExecutor())
+    net = CUTIE(default_config())
+    net.load_weights(make_state_dict(seed=0))
+    yield net
+    _lib.set_executor_for_testing(prev)
+
+
+def test_every_case_is_recorded():
+    assert sorted(GOLD) == sorted(CASES)
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_product_reproduces_reference_outcome(name, product_net):
+    from cutie_amd.inference.inference_core import InferenceCore
+    got = run_case(name, lambda over: InferenceCore(product_net, cfg=default_config(**over)))
+    assert got == GOLD[name], (name, got, GOLD[name])
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_oracle_reproduces_reference_outcome(name, oracle_net):
+    got = run_case(name, lambda over: OracleProcessor(oracle_net, dict(DEFAULT_CFG, **over)))
+    assert got == GOLD[name], (name, got, GOLD[name])
