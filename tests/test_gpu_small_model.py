@@ -84,3 +84,34 @@ def test_random_scripts_on_gpu(seed, oracle_net):
         assert torch.isfinite(p).all()
         d = (p - o).abs()
         assert float(d.max()) < 0.15 and float(d.mean()) < 0.05, (seed, t, float(d.max()), float(d.mean()))
+
+
+class _CudaInputs:
+    """Hands the (CPU) tensors of the edge-case scripts to the processor as device tensors; everything else passes through."""
+
+    def __init__(self, proc):
+        object.__setattr__(self, '_p', proc)
+
+    def __getattr__(self, k):
+        return getattr(self._p, k)
+
+    def step(self, image, mask=None, *a, **k):
+        return self._p.step(image.cuda(), None if mask is None else mask.cuda(), *a, **k)
+
+
+def test_edge_cases_on_gpu():
+    """tests/golden/edge_cases.json (outcomes recorded from the executed reference) through the HIP path."""
+    import json, os
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.model.cutie import CUTIE
+    from oracle.edge_cases import CASES, run_case
+    gold = json.load(open(os.path.join(S.GOLDEN_DIR, 'edge_cases.json')))
+    _lib.set_executor_for_testing(None)
+    net = CUTIE(default_config()).cuda().eval()
+    net.load_weights(make_state_dict(seed=0))
+    bad = {}
+    for name in sorted(CASES):
+        got = run_case(name, lambda over: _CudaInputs(InferenceCore(net, cfg=default_config(**over))))
+        if got != gold[name]:
+            bad[name] = (got, gold[name])
+    assert not bad, bad
