@@ -18,7 +18,6 @@ from typing import Dict, List
 import numpy as np
 import torch
 
-from .. import ops as O
 
 BF16, F32 = torch.bfloat16, torch.float32
 LIFE_EPS_BITS = int(np.float32(1e-7).view(np.int32))      # new tokens start with life = 1e-7 (kv_memory_store.py:134)

@@ -17,7 +17,6 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
-from ..ops import OpList
 from . import plans
 from .param_spec import build_spec
 from .weights import fold_bn, pack_conv, pack_linear, linear_as_conv

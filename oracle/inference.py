@@ -2,10 +2,9 @@
 (``InferenceCore`` + ``MemoryManager`` + ``KeyValueMemoryStore`` + ``ObjectManager``)
 in plain torch-fp32 on CPU.
 
-TEST INFRASTRUCTURE (see oracle/__init__.py).  bs = 1; flip_aug = a second lane (see __init__), all
-objects in one chunk (chunk_size = -1), which is how every BASELINE config runs.
+TEST INFRASTRUCTURE (see oracle/__init__.py).  bs = 1; flip_aug = a second lane (see __init__); chunk_size > 0 groups
+the objects in the memory read-out like memory_manager.py:169-186 (every BASELINE config runs with chunk_size = -1).
 """
-import math
 import numpy as np
 import torch
 import torch.nn.functional as F

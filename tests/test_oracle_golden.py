@@ -5,7 +5,6 @@ Tolerances: the oracle is the same fp32 math as the reference through the same t
 but associativity differs in a few places (e.g. folded reshapes), so fp32 round-off is allowed:
 prob atol 2e-3 (fp16 storage of the golden probs alone is 5e-4), stage probes rtol 1e-3.
 """
-import hashlib
 import os
 import numpy as np
 import pytest

@@ -36,7 +36,7 @@ def main():
             proc.step(clip.frame(t).cuda())
         torch.cuda.synchronize()
         rec.rec, rec.on = [], True
-        proc.step(clip.frame(15 if args.mem_frame else 12).cuda()) if False else proc.step(clip.frame(12).cuda())
+        proc.step(clip.frame(12).cuda())
         rec.on = False
         if args.mem_frame:
             rec.rec, rec.on = [], True

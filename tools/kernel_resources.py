@@ -4,7 +4,6 @@ one table.    python tools/kernel_resources.py > profiles/r01_kernel_resources.t
 import os
 import re
 import subprocess
-import sys
 import tempfile
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
