@@ -13,6 +13,15 @@ from oracle.weights import MODEL_CFG_SMALL, make_state_dict
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope='module')
+def gpu_net():
+    from cutie_amd.model.cutie import CUTIE
+    _lib.set_executor_for_testing(None)
+    net = CUTIE(default_config()).cuda().eval()
+    net.load_weights(make_state_dict(seed=0))
+    return net
+
+
 def rel_err(a, b):
     a, b = a.float().cpu(), b.float().cpu()
     assert torch.isfinite(a).all()
@@ -52,15 +61,12 @@ def test_small_model_on_gpu():
 
 
 @pytest.mark.parametrize('seed', [0, 2, 4])
-def test_random_scripts_on_gpu(seed, oracle_net):
+def test_random_scripts_on_gpu(seed, gpu_net, oracle_net):
     """Random event scripts (oracle/fuzz_reference.py; the oracle agrees with the executed reference on them to 2e-6) through
     the HIP path: bank bookkeeping exact, probabilities within the trajectory tolerance."""
     from cutie_amd.inference.inference_core import InferenceCore
-    from cutie_amd.model.cutie import CUTIE
     from oracle.fuzz_reference import random_scenario
-    _lib.set_executor_for_testing(None)
-    net = CUTIE(default_config()).cuda().eval()
-    net.load_weights(make_state_dict(seed=0))
+    net = gpu_net
     S.SCENARIOS['_fuzz'] = random_scenario(seed, 14)
     try:
         ps, os_ = [], []
@@ -99,16 +105,13 @@ class _CudaInputs:
         return self._p.step(image.cuda(), None if mask is None else mask.cuda(), *a, **k)
 
 
-def test_edge_cases_on_gpu():
+def test_edge_cases_on_gpu(gpu_net):
     """tests/golden/edge_cases.json (outcomes recorded from the executed reference) through the HIP path."""
     import json, os
     from cutie_amd.inference.inference_core import InferenceCore
-    from cutie_amd.model.cutie import CUTIE
     from oracle.edge_cases import CASES, run_case
     gold = json.load(open(os.path.join(S.GOLDEN_DIR, 'edge_cases.json')))
-    _lib.set_executor_for_testing(None)
-    net = CUTIE(default_config()).cuda().eval()
-    net.load_weights(make_state_dict(seed=0))
+    net = gpu_net
     bad = {}
     for name in sorted(CASES):
         got = run_case(name, lambda over: _CudaInputs(InferenceCore(net, cfg=default_config(**over))))
