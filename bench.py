@@ -106,15 +106,30 @@ def multi_clip_throughput(net, cfg, args, K, rank, dist, dev):
     threads = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(C)]
     for t in threads:
         t.start()
+    failed = False
     try:
         ready.wait()
-        if dist is not None:
-            dist.barrier()
-        t0 = time.perf_counter()
+    except threading.BrokenBarrierError:
+        failed = True
+    if dist is not None:
+        dist.barrier()                                      # reached by every rank, also by one whose pre-roll failed
+    def give_up():                                           # release the workers parked at `done`, then surface the error
+        done.abort()
+        for t in threads:
+            t.join(timeout=60)
+        raise errors[0]
+
+    if failed:
+        give_up()
+    t0 = time.perf_counter()
+    try:
         start.wait()
     except threading.BrokenBarrierError:
-        raise errors[0]
-    done.wait()
+        give_up()
+    try:
+        done.wait()
+    except threading.BrokenBarrierError:
+        give_up()
     for t in threads:
         t.join()
     if errors:
@@ -316,14 +331,24 @@ def main():
 
     multi = None
     if args.clips_in_flight > 1:
-        mt = torch.tensor([multi_clip_throughput(net, cfg, args, K, rank, dist, dev)], dtype=torch.float64, device=dev)
+        # an extra leg: a failure here is reported in the line, it must not take the headline measurement with it
+        try:
+            leg, leg_err = multi_clip_throughput(net, cfg, args, K, rank, dist, dev), None
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            leg, leg_err = 0.0, f'{type(e).__name__}: {e}'
+        mt = torch.tensor([leg, 0.0 if leg_err is None else 1.0], dtype=torch.float64, device=dev)
         if dist is not None:
             dist.all_reduce(mt, op=dist.ReduceOp.MAX)
-        mt = float(mt.item())
-        multi = {'clips_in_flight_per_gpu': args.clips_in_flight, 'value': round(world * args.clips_in_flight * args.steps / mt, 2),
-                 'unit': 'frames/s', 'ms_per_step': round(mt / args.steps * 1e3, 4),
-                 'note': 'same workload, independent clips interleaved on one GPU (one host thread + HIP stream + CUTIE.fork() per '
-                         'clip, cutie_amd/parallel.py); "value" above stays one clip per GPU'}
+        if float(mt[1].item()) > 0:
+            multi = {'clips_in_flight_per_gpu': args.clips_in_flight, 'error': leg_err or 'failed on another rank'}
+        else:
+            mt = float(mt[0].item())
+            multi = {'clips_in_flight_per_gpu': args.clips_in_flight, 'value': round(world * args.clips_in_flight * args.steps / mt, 2),
+                     'unit': 'frames/s', 'ms_per_step': round(mt / args.steps * 1e3, 4),
+                     'note': 'same workload, independent clips interleaved on one GPU (one host thread + HIP stream + CUTIE.fork() per '
+                             'clip, cutie_amd/parallel.py); "value" above stays one clip per GPU'}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
