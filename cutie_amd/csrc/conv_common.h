@@ -1,0 +1,84 @@
+// Pieces shared by the convolution kernels (conv_igemm.hip, conv_bufload.hip): launch parameters, 16-B global load,
+// LDS chunk swizzle and the epilogue tail.
+#pragma once
+#include "common.h"
+
+struct ConvParams {
+    const bf16_t* x1; const bf16_t* x2; const bf16_t* w; const float* bias; const bf16_t* res; void* y;
+    int B, H, W, C1, C2, ldx1, ldx2, OH, OW, Cout, ldy, KH, KW, stride, pad, ldr, Kpad;
+    int flags, M, Cin, OHW;
+    float* part; int splitk, ldp, Kslice;                // split-K: fp32 partial tiles [splitk][M][ldp]
+};
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+// 16-B load that is a global_load for sure.  Pointers that went through a select, an array of pointers or pointer
+// increments lose their address space and hipcc falls back to flat_load; a flat load counts in lgkmcnt as well as vmcnt, so
+// every wait for an LDS read would also wait for the whole weight / activation prefetch (no overlap of L2 latency with MFMA).
+typedef const __attribute__((address_space(1))) u32x4* gptr16;
+#define GLOAD16(ptr) (*(gptr16)(ptr))
+
+template <int CPR>
+__device__ __forceinline__ int swz(int row) {
+    return CPR == 4 ? ((row >> 3) & 1) * 3 : (row & (CPR - 1));
+}
+
+// Epilogue tail for 8 consecutive output channels of one pixel: bias, residual, activation, 16-B stores.
+__device__ __forceinline__ void conv_finish(const ConvParams& p, float* v, int m, int ch0) {
+    const int act = (p.flags >> CUTIE_ACT_SHIFT) & 7;
+    const bool out_f32 = p.flags & CUTIE_F_OUT_F32;
+    const bool res_bcast = p.flags & CUTIE_F_RES_BCAST;
+    const bool vec_y = out_f32 ? ((p.ldy & 3) == 0) : ((p.ldy & 7) == 0);
+    const bool vec_r = (p.ldr & 7) == 0;
+    const bool full = ch0 + 7 < p.Cout;
+    if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) v[r] += p.bias[ch0 + r];
+    }
+    if (p.res) {
+        const int mres = res_bcast ? (m % p.OHW) : m;
+        const bf16_t* rp = p.res + (long)mres * p.ldr + ch0;
+        if (full && vec_r) {
+            const uint4 rr = *reinterpret_cast<const uint4*>(rp);
+            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+            v[4] += __uint_as_float(rr.z << 16); v[5] += __uint_as_float(rr.z & 0xffff0000u);
+            v[6] += __uint_as_float(rr.w << 16); v[7] += __uint_as_float(rr.w & 0xffff0000u);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) v[r] += bf2f(rp[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (act == CUTIE_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+        else if (act == CUTIE_ACT_SIGMOID) v[r] = sigmoidf_(v[r]);
+        else if (act == CUTIE_ACT_SQ1) v[r] = v[r] * v[r] + 1.f;
+    }
+    if (out_f32) {
+        float* yp = reinterpret_cast<float*>(p.y) + (long)m * p.ldy + ch0;
+        if (full && vec_y) {
+            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) yp[r] = v[r];
+        }
+    } else {
+        bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + (long)m * p.ldy + ch0;
+        if (full && vec_y) {
+            *reinterpret_cast<uint4*>(yp) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) yp[r] = f2bf(v[r]);
+        }
+    }
+}
+
+// dynamic LDS of a conv tile: WK double-buffered operand pipelines, or the fp32 epilogue tile if that is larger
+template <int BM, int BN, int BK, int WK>
+constexpr int conv_lds_bytes() {
+    constexpr int pipe = WK * 2 * (BM + BN) * (BK / 8) * 16, epi = BM * (BN + 4) * 4;
+    return pipe > epi ? pipe : epi;
+}
+
+int launch_conv_bufload(const ConvParams& p, int tile, hipStream_t s);   // conv_bufload.hip (experimental tiles 50..)

@@ -15,78 +15,7 @@
 //   * LDS double-buffered, one barrier per K step; rows are BK*2 bytes and the 16-B chunk index is XOR-swizzled
 //     (row&(CPR-1), or ((row>>3)&1)*3 for 64-B rows) so ds_read_b128 fragment reads spread over the bank rows.
 //   * the tile shape is chosen per layer by the host (autotuned at plan build, cutie_amd/model/plans.py).
-#include "common.h"
-
-struct ConvParams {
-    const bf16_t* x1; const bf16_t* x2; const bf16_t* w; const float* bias; const bf16_t* res; void* y;
-    int B, H, W, C1, C2, ldx1, ldx2, OH, OW, Cout, ldy, KH, KW, stride, pad, ldr, Kpad;
-    int flags, M, Cin, OHW;
-    float* part; int splitk, ldp, Kslice;                // split-K: fp32 partial tiles [splitk][M][ldp]
-};
-
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-// 16-B load that is a global_load for sure.  Pointers that went through a select, an array of pointers or pointer
-// increments lose their address space and hipcc falls back to flat_load; a flat load counts in lgkmcnt as well as vmcnt, so
-// every wait for an LDS read would also wait for the whole weight / activation prefetch (no overlap of L2 latency with MFMA).
-typedef const __attribute__((address_space(1))) u32x4* gptr16;
-#define GLOAD16(ptr) (*(gptr16)(ptr))
-
-template <int CPR>
-__device__ __forceinline__ int swz(int row) {
-    return CPR == 4 ? ((row >> 3) & 1) * 3 : (row & (CPR - 1));
-}
-
-// Epilogue tail for 8 consecutive output channels of one pixel: bias, residual, activation, 16-B stores.
-__device__ __forceinline__ void conv_finish(const ConvParams& p, float* v, int m, int ch0) {
-    const int act = (p.flags >> CUTIE_ACT_SHIFT) & 7;
-    const bool out_f32 = p.flags & CUTIE_F_OUT_F32;
-    const bool res_bcast = p.flags & CUTIE_F_RES_BCAST;
-    const bool vec_y = out_f32 ? ((p.ldy & 3) == 0) : ((p.ldy & 7) == 0);
-    const bool vec_r = (p.ldr & 7) == 0;
-    const bool full = ch0 + 7 < p.Cout;
-    if (p.bias) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) v[r] += p.bias[ch0 + r];
-    }
-    if (p.res) {
-        const int mres = res_bcast ? (m % p.OHW) : m;
-        const bf16_t* rp = p.res + (long)mres * p.ldr + ch0;
-        if (full && vec_r) {
-            const uint4 rr = *reinterpret_cast<const uint4*>(rp);
-            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-            v[4] += __uint_as_float(rr.z << 16); v[5] += __uint_as_float(rr.z & 0xffff0000u);
-            v[6] += __uint_as_float(rr.w << 16); v[7] += __uint_as_float(rr.w & 0xffff0000u);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) v[r] += bf2f(rp[r]);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        if (act == CUTIE_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
-        else if (act == CUTIE_ACT_SIGMOID) v[r] = sigmoidf_(v[r]);
-        else if (act == CUTIE_ACT_SQ1) v[r] = v[r] * v[r] + 1.f;
-    }
-    if (out_f32) {
-        float* yp = reinterpret_cast<float*>(p.y) + (long)m * p.ldy + ch0;
-        if (full && vec_y) {
-            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) yp[r] = v[r];
-        }
-    } else {
-        bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + (long)m * p.ldy + ch0;
-        if (full && vec_y) {
-            *reinterpret_cast<uint4*>(yp) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-        } else {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) yp[r] = f2bf(v[r]);
-        }
-    }
-}
+#include "conv_common.h"
 
 // OCC: waves per SIMD the register allocator must leave room for (pinned per tile: hipcc's occupancy heuristic is
 // otherwise chaotic w.r.t. small source changes, e.g. 156 -> 208 VGPRs on the 32x64x128 tile = 3 -> 2 resident blocks).
@@ -616,12 +545,6 @@ static int launch_patch(ConvParams p, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-template <int BM, int BN, int BK, int WK>
-constexpr int conv_lds_bytes() {
-    constexpr int pipe = WK * 2 * (BM + BN) * (BK / 8) * 16, epi = BM * (BN + 4) * 4;
-    return pipe > epi ? pipe : epi;
-}
-
 template <int BM, int BN, int WM, int WN, int BK, int S, int OCC, int WK = 1>
 static int launch_cfg(ConvParams p, hipStream_t s) {
     if (p.Kpad % BK) { cutie_set_error("conv: Kpad %d not a multiple of BK %d", p.Kpad, BK); return -2; }
@@ -681,6 +604,7 @@ int launch_conv(const cutie_op* op, hipStream_t s) {
         hipLaunchKernelGGL(conv_cout1_kernel, dim3((p.M + ppb - 1) / ppb), dim3(256), (size_t)p.KH * p.KW * LP * 16, s, p);
         return (int)hipGetLastError();
     }
+    if (i[17] >= 50 && i[17] < 60) return launch_conv_bufload(p, i[17], s);     // experimental tiles (conv_bufload.hip)
     switch (i[17]) {
         case 0: return launch_cfg<128, 128, 2, 2, 32, 4, 2>(p, s);
         case 1: return launch_cfg<128, 64, 2, 2, 32, 4, 3>(p, s);

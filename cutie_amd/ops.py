@@ -4,6 +4,8 @@ An ``OpList`` records kernel descriptors over torch-allocated device buffers (to
 plumbing only); ``run()`` hands the whole array to ``cutie_exec`` in ONE C call.  Pointer slots can be
 declared *dynamic* (named) and patched per call, so a cached plan is reused across frames.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -42,6 +44,22 @@ TILES = {0: (128, 128, 32), 1: (128, 64, 32), 2: (64, 64, 32), 3: (256, 16, 32),
          40: (128, 64, 64), 41: (64, 64, 64), 42: (64, 128, 64), 43: (128, 64, 64), 44: (64, 64, 64)}
 TILE_WK = {20: 2, 21: 2, 22: 2, 23: 2, 24: 2, 25: 2, 26: 2, 27: 4, 28: 4, 29: 2, 30: 2, 40: 2, 41: 2, 42: 2, 43: 1, 44: 1}
 PATCH_TILES = (40, 41, 42, 43, 44)
+# 50+: EXPERIMENTAL buffer-load kernel (conv_bufload.hip): written after the last GPU minute of round 1 from the static
+# instruction mix of the default kernel (5-8 instead of 10-27 non-MFMA instructions per MFMA in the steady-state loop); its
+# integer logic is emulated on the CPU (tools/emulate_bufload_addressing.py) but it has not run on a GPU yet, so it takes part
+# in the autotuning ONLY with CUTIE_AMD_EXPERIMENTAL_TILES=1 (tests: test_gpu_kernels.py::test_conv_bufload_tiles, same switch).
+EXPERIMENTAL_TILES = {50: (128, 64, 64), 51: (64, 64, 64), 52: (64, 128, 64), 53: (32, 64, 128), 54: (64, 64, 128),
+                      55: (128, 128, 64), 56: (32, 64, 64)}
+
+
+def experimental_tiles_enabled():
+    return os.environ.get('CUTIE_AMD_EXPERIMENTAL_TILES', '0') not in ('', '0')
+
+
+def bufload_tile_ok(tile, *, cin, kh, c2=0, kpad=None):
+    """conv_bufload_kernel eligibility (mirrors launch_buf in conv_bufload.hip): a K tile must not straddle a tap or a source."""
+    bk = EXPERIMENTAL_TILES[tile][2]
+    return cin % bk == 0 and (c2 == 0 or (cin - c2) % bk == 0) and kh * kh <= 16 and (kpad is None or kpad % bk == 0)
 
 
 def patch_tile_ok(tile, *, cin, kh, stride, pad, W, c2=0):
@@ -54,7 +72,7 @@ def patch_tile_ok(tile, *, cin, kh, stride, pad, W, c2=0):
     if nk % wk or nk // wk < 2:
         return False
     lds = max((bm + 2 * (W + 2) + 2) * cin * 2 + wk * 2 * bn * 128, bm * (bn + 4) * 4)
-    return lds <= 160 * 1024     # K groups per block (default 1)
+    return lds <= 160 * 1024
 NUM_CU = 256
 
 
@@ -87,6 +105,11 @@ def tile_candidates(M, cout, cin, kpad=None, geom=None):
         if bm * 2 > max(M, 64) * 2 and bm > 64:          # do not pad a tiny M to a huge tile
             continue
         out.append(t)
+    if experimental_tiles_enabled() and geom is not None:
+        for t, (bm, bn, bk) in EXPERIMENTAL_TILES.items():
+            if bufload_tile_ok(t, cin=cin, kh=geom['kh'], c2=geom.get('c2', 0), kpad=kpad) and not (bn == 128 and cout <= 64) \
+                    and not (bm > 64 and bm > max(M, 64)):
+                out.append(t)
     return out
 
 
@@ -109,7 +132,7 @@ def splitk_scratch(device, owner=None):
 
 def splitk_candidates(M, cout, kpad, tile):
     """Split-K factors worth timing for a conv on a given tile: only when the plain grid leaves CUs idle."""
-    if tile == COUT1_TILE or tile == 3 or tile in PATCH_TILES:
+    if tile == COUT1_TILE or tile == 3 or tile in PATCH_TILES or tile in EXPERIMENTAL_TILES:
         return [1]
     bm, bn, bk = TILES[tile]
     blocks = -(-M // bm) * -(-cout // bn)

@@ -121,6 +121,31 @@ def test_conv_every_tile(ci, tile):
     check(hip, ref, f'conv[{ci}] tile{tile}')
 
 
+BUFLOAD_CASES = [
+    dict(B=3, H=30, W=54, C1=256, Cout=256, k=3, relu_in=True, act=O.ACT_RELU),          # CAResBlock conv (480p, 3 objects)
+    dict(B=1, H=30, W=54, C1=1024, Cout=256, k=1),                                        # pix_feat_proj
+    dict(B=1, H=120, W=216, C1=64, Cout=64, k=3, act=O.ACT_RELU),                        # ResNet layer1 3x3
+    dict(B=1, H=60, W=108, C1=256, Cout=512, k=1, stride=2),                              # 1x1 stride-2 downsample
+    dict(B=2, H=17, W=23, C1=64, Cout=96, k=3, res=True),                                 # ragged M and Cout, residual
+    dict(B=2, H=18, W=22, C1=128, Cout=72, k=3, stride=2, relu_in=True),                  # 3x3 stride 2
+    dict(B=3, H=30, W=54, C1=256, C2=256, Cout=768, k=3),                                 # GRU transform: two sources
+    dict(B=3, H=9, W=7, C1=128, C2=128, Cout=40, k=1, res=True, res_bcast=True, out_f32=True, relu_in=True),
+    dict(B=1, H=5, W=6, C1=128, Cout=64, k=3),                                            # M smaller than any tile
+]
+
+
+@pytest.mark.skipif(not O.experimental_tiles_enabled(), reason='experimental conv tiles are opt-in: CUTIE_AMD_EXPERIMENTAL_TILES=1')
+@pytest.mark.parametrize('tile', sorted(O.EXPERIMENTAL_TILES))
+@pytest.mark.parametrize('ci', range(len(BUFLOAD_CASES)))
+def test_conv_bufload_tiles(ci, tile):
+    """conv_bufload_kernel (tiles 50..) against the interpreter; first thing to run in round 2."""
+    c = BUFLOAD_CASES[ci]
+    if not O.bufload_tile_ok(tile, cin=c['C1'] + c.get('C2', 0), kh=c['k'], c2=c.get('C2', 0)):
+        pytest.skip('a K tile would straddle a tap / source on this tile')
+    hip, ref = run_both(_conv_build(c, tile), seed=300 + ci)
+    check(hip, ref, f'bufload[{ci}] tile{tile}')
+
+
 PATCH_CASES = [
     dict(B=3, H=30, W=54, C1=256, Cout=256, k=3, relu_in=True, act=O.ACT_RELU),          # CAResBlock conv (480p, 3 objects)
     dict(B=1, H=30, W=54, C1=256, Cout=64, k=3, out_f32=True, act=O.ACT_SIGMOID),        # key projection e_proj
