@@ -2,8 +2,9 @@
 // cutie_amd/ops.py; never chosen otherwise).  Written at the end of round 1 from the static instruction mix of the default
 // kernel (tools/isa_mix.py, profiles/r01_isa_mix.txt): conv_igemm_kernel issues 10-27 non-MFMA instructions per MFMA in its
 // steady-state loop, ~300-500 of them VALU (per-chunk im2col address arithmetic in 64 bit, halo predicates, the two-source
-// select, zero masking), and a wave64 VALU instruction occupies its SIMD for 4 cycles -- the vector ALU, not the matrix
-// pipe, bounds the loop.  This variant moves that work off the VALU:
+// select, zero masking, re-derived LDS indices).  At 2 cycles per wave64 VALU instruction that is more vector-pipe time than
+// the 48 MFMAs of the same loop need matrix-pipe time (~16 cycles each), and far more issue slots than one wave can spare
+// between MFMAs.  This variant moves that work off the VALU:
 //   * operands are fetched with `buffer_load_dwordx4 v, voffset, srsrc, soffset offen`: the per-thread byte offset of a
 //     chunk (pixel base + 16-B chunk) is a loop-invariant VGPR, everything that changes per K tile -- filter tap, channel
 //     offset, source tensor of a virtual concat, weight column -- is wave-uniform and goes into the SGPR soffset / srsrc;

@@ -2,9 +2,11 @@
 
 For each kernel the loop body (label ... backward branch to that label) that holds the most MFMAs -- or, for kernels without
 MFMA, the most instructions -- is classified into MFMA / VALU / SALU / LDS (ds_*) / VMEM (global/buffer/flat/scratch) / waitcnt /
-barrier / branch.  `issue ratio` = non-MFMA instructions per MFMA in that loop: one wave issues one instruction per cycle
-at best, a 16x16x32 bf16 MFMA occupies the matrix pipe for 8 cycles (4 passes x 2), so ratios well above ~7 mean the loop
-cannot keep the matrix pipe busy from a single wave and relies on other resident waves to fill it.
+barrier / branch.  `non-MFMA/MFMA` = the other instructions per MFMA in that loop.  Reading aid (constants of MI355X_MICROARCH.md): a wave issues
+its instructions in order; a wave64 VALU instruction takes 2 cycles on a SIMD-32, a v_mfma_f32_16x16x32_bf16 keeps the matrix
+pipe of its SIMD busy for ~16-17 cycles.  A loop with R non-MFMA instructions per MFMA therefore needs >= ~R (+VALU) issue cycles
+of its wave per 16-17 cycles of matrix work: above R ~ 8 a single wave cannot keep the matrix pipe fed and the kernel relies on
+several resident waves interleaving; when VALU x 2 alone exceeds MFMA x 16 the vector pipe is the bound.
 
     python tools/isa_mix.py [file.hip ...] > profiles/rNN_isa_mix.txt"""
 import os
