@@ -58,7 +58,8 @@ class InferenceCore:
         # chunk_size: in the mask encoder and the decoder (big_modules.py:141-180,267-302) the reference's object chunks are
         # equivalent to the batched form (the HIP plans always batch; 288 GB of HBM).  In MemoryManager.read
         # (memory_manager.py:169-186) they are not: fusion and object transformer see only the objects of a chunk, which is
-        # replicated there (pinned by the `small_chunk` golden scenario).
+        # replicated there (pinned by the `small_chunk` golden scenario).  Not replicated: with flip_aug the reference's chunked
+        # decoder views the dim-0 concatenation of per-chunk logits as [2, K, H, W] (big_modules.py:300-302), mixing the two lanes.
         self.curr_ti = -1
         self.last_mem_ti = 0
         if stagger_updates >= self.mem_every:
