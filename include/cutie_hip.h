@@ -56,7 +56,8 @@ enum {
      * p2=w bf16 [CoutPad][Kpad] (k = (kh*KW+kw)*Cin + c, zero padded)  p3=bias f32[Cout] (may be 0)
      * p4=res bf16 [B|1,OH,OW,ldr] (may be 0)  p5=y bf16|f32 [B,OH,OW,ldy]
      * i: 0 B 1 H 2 W 3 C1 4 C2 5 ldx1 6 ldx2 7 OH 8 OW 9 Cout 10 ldy 11 KH 12 KW 13 stride 14 pad
-     *    15 ldr 16 Kpad 17 tile id (table in conv_igemm.hip launch_conv / cutie_amd/ops.py TILES; 19 = Cout==1 kernel)
+     *    15 ldr 16 Kpad 17 tile id (table in conv_igemm.hip launch_conv / cutie_amd/ops.py TILES; 19 = Cout==1 kernel;
+     *       50..56 = experimental buffer-load kernel, conv_bufload.hip: Cin % BK == 0, no split-K, opt-in on the host side)
      *    18 real (un-padded) input channels: ignored by the kernel, used for flop accounting
      *    19 split-K factor (<=1: none; must divide Kpad/BK of the chosen tile).  grid.z slices the K tiles, every slice
      *       parks its fp32 partial tile in p6 and a second launch sums the slices in slice order (deterministic) and
