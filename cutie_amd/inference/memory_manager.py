@@ -145,23 +145,36 @@ class MemoryManager:
             count = self._buf('count', (HW * O.OpList.AFF_CSTRIDE,), torch.int32, dev)
             ovf = self._buf('overflow', (1,), torch.int32, dev)
             readout = torch.empty((K, h, w, self.CV), dtype=BF16, device=dev)
-            ol = O.OpList()
-            ol.memset32(count, HW * O.OpList.AFF_CSTRIDE, 0)
-            common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=CAND_CAP)
-            ol.aff_score(bucket.Ahi, bucket.Alo, bucket.scale, q['Bhi'], q['Blo'], q['cq'], gmax, None, None, None, mode=0, **common)
-            ol.aff_select(gmax, tau, HW=HW, HWp=HWp, G=G, top_k=self.top_k)
-            ol.aff_score(bucket.Ahi, bucket.Alo, bucket.scale, q['Bhi'], q['Blo'], q['cq'], tau, cval, cidx, count, mode=1, **common)
-            usage = None
-            if self.use_long_term:
+            # The affinity plan of a bucket only changes when its token ranges do (memory frames, consolidation, purge) or a
+            # setting is updated: the descriptors are built once per such state with named pointer slots and re-bound per frame
+            # (host time matters once several clips share one interpreter).
+            tick_work = self.use_long_term and bucket.n_work > 0
+            tick_long = self.use_long_term and bucket.n_long > 0 and self.count_long_term_usage
+            key = (tuple(ranges), K, HW, HWp, G, self.top_k, self.use_long_term, tick_work, tick_long, bucket.work_start,
+                   bucket.n_work, bucket.n_long)
+            cached = getattr(bucket, '_aff_plan', None)
+            if cached is None or cached[0] != key:
+                D = O.Dyn
+                ol = O.OpList()
+                ol.memset32(D('count'), HW * O.OpList.AFF_CSTRIDE, 0)
+                common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=CAND_CAP)
+                ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('gmax'), None, None, None, mode=0, **common)
+                ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k)
+                ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('tau'), D('cval'), D('cidx'), D('count'),
+                             mode=1, **common)
                 # usage bookkeeping (kv_memory_store.py:151-162): life += 1 for every counted token
-                usage = bucket.use
-                if bucket.n_work > 0:
-                    ol.usage_tick(bucket.life[bucket.work_start:], bucket.n_work)
-                if bucket.n_long > 0 and self.count_long_term_usage:
-                    ol.usage_tick(bucket.life, bucket.n_long)
-            ol.aff_readout(cval, cidx, count, bucket.vptrs(), usage, readout, ovf, HW=HW, cap=CAND_CAP, top_k=self.top_k,
-                           K=K, CV=self.CV)
-            ol.run()
+                if tick_work:
+                    ol.usage_tick(D('life', 4 * bucket.work_start), bucket.n_work)
+                if tick_long:
+                    ol.usage_tick(D('life'), bucket.n_long)
+                ol.aff_readout(D('cval'), D('cidx'), D('count'), D('vptrs'), D('usage') if self.use_long_term else None, D('readout'),
+                               D('ovf'), HW=HW, cap=CAND_CAP, top_k=self.top_k, K=K, CV=self.CV)
+                bucket._aff_plan = cached = (key, ol)
+            dyn = dict(count=count, Ahi=bucket.Ahi, Alo=bucket.Alo, scale=bucket.scale, Bhi=q['Bhi'], Blo=q['Blo'], cq=q['cq'],
+                       gmax=gmax, tau=tau, cval=cval, cidx=cidx, vptrs=bucket.vptrs(), readout=readout, ovf=ovf)
+            if self.use_long_term:
+                dyn.update(life=bucket.life, usage=bucket.use)
+            cached[1].run(**dyn)
             # chunk_size > 0 (memory_manager.py:169-186): pixel fusion and the object transformer run per group of chunk_size
             # objects -- this is NOT only a memory knob: the "others" mask of the fusion and the foreground / background
             # attention masks of the transformer are computed inside a group.  (encode_mask / segment chunks are equivalent
