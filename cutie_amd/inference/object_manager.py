@@ -61,8 +61,10 @@ class ObjectManager:
             lut[t] = o.id
         return lut[mask.long()]
 
-    def get_tmp_to_obj_mapping(self) -> Dict[int, ObjectInfo]:
-        return {obj.id: tmp_id for obj, tmp_id in self.tmp_id_to_obj.items()}
+    def get_tmp_to_obj_mapping(self) -> Dict[int, int]:
+        """{object id: tmp id} (what object_manager.py:106-108 is meant to return; the reference unpacks the (tmp id, object)
+        items the other way round and raises AttributeError, so nothing there can depend on it)."""
+        return {obj.id: tmp_id for tmp_id, obj in self.tmp_id_to_obj.items()}
 
     def realize_dict(self, obj_dict, dim=1) -> torch.Tensor:
         out = []

@@ -163,6 +163,70 @@ def case_memory_schedule(make):
     return sizes                                                    # FIFO: permanent 35 + at most (3-1) x 35 working tokens
 
 
+# ---- ObjectManager on its own (object_manager.py:7-149); `make` is only used to reach the processor's object manager ----------
+def _om(make):
+    p = make({})
+    return getattr(p, 'object_manager', None)
+
+
+def case_object_manager_bookkeeping(make):
+    om = _om(make)
+    if om is None:
+        return 'no object manager'                                 # the oracle restates it as a plain list
+    tmp, ids = om.add_new_objects([3, 7, 9])
+    out = {'add': [tmp, ids], 'again': list(om.add_new_objects([7, 11])), 'all': om.all_obj_ids, 'num': om.num_obj,
+           'has': [om.has_all([3, 11]), om.has_all([3, 4])], 'tmp_of_9': om.find_tmp_by_id(9), 'obj': repr(om.find_object_by_id(7))}
+    om.delete_objects(7)
+    out['after_delete'] = [om.all_obj_ids, om.find_tmp_by_id(9), sorted(om.tmp_id_to_obj)]
+    cls = torch.tensor([[0, 1, 2], [3, 3, 0]])
+    out['tmp_to_obj_cls'] = om.tmp_to_obj_cls(cls).tolist()
+    oh = om.make_one_hot(torch.tensor([[3, 9, 0], [11, 7, 3]]))
+    out['one_hot'] = [list(oh.shape), str(oh.dtype), oh.long().sum((1, 2)).tolist()]
+    rd = om.realize_dict({3: torch.zeros(1, 2), 9: torch.ones(1, 2), 11: torch.full((1, 2), 2.0)})
+    out['realize'] = [list(rd.shape), rd[0, :, 0].tolist()]
+    return out
+
+
+def case_object_manager_tmp_to_obj_mapping(make):
+    om = _om(make)
+    if om is None:
+        return 'no object manager'
+    om.add_new_objects([3, 7])
+    return {str(k): v for k, v in om.get_tmp_to_obj_mapping().items()}    # object_manager.py:106-108
+
+
+def case_object_manager_realize_dict_needs_every_object(make):
+    om = _om(make)
+    if om is None:
+        raise NotImplementedError                                   # same outcome for the list-based oracle
+    om.add_new_objects([1, 2])
+    return list(om.realize_dict({1: torch.zeros(1)}).shape)
+
+
+def case_object_manager_purge_inactive(make):
+    om = _om(make)
+    if om is None:
+        return 'no object manager'
+    om.add_new_objects([4, 5, 6])
+    for _ in range(3):
+        om.find_object_by_id(5).poke()
+    om.find_object_by_id(6).poke()
+    first = om.purge_inactive_objects(2)
+    om.find_object_by_id(6).unpoke()
+    second = om.purge_inactive_objects(0)
+    empty = om.make_one_hot(torch.zeros(2, 2, dtype=torch.long)) if True else None
+    return {'first': [first[0], list(first[1]), list(first[2])], 'second': [second[0], list(second[1]), list(second[2])],
+            'left': om.all_obj_ids, 'one_hot_shape': list(empty.shape)}
+
+
+def case_object_manager_empty_one_hot(make):
+    om = _om(make)
+    if om is None:
+        return 'no object manager'
+    oh = om.make_one_hot(torch.zeros(2, 3, dtype=torch.long))
+    return [list(oh.shape), str(oh.dtype)]
+
+
 CASES = {n[5:]: f for n, f in sorted(globals().items()) if n.startswith('case_')}
 
 
