@@ -17,6 +17,7 @@
 // Memory tokens are addressed by *physical bank slot*; the bank is contiguous per bucket (keys) and per
 // object (values), so the valid tokens are at most 3 slot ranges [long-term | permanent | working ring].
 #include "common.h"
+#include <stdlib.h>
 #include <math.h>
 
 __global__ void key_prep_kernel(const float* __restrict__ key, const float* __restrict__ aux, bf16_t* __restrict__ hi,
@@ -76,8 +77,13 @@ typedef __attribute__((ext_vector_type(4))) unsigned int au32x4;
 #define AFF_LCAP 1024                                 // LDS candidate list entries per block ...
 #define AFF_WCAP (AFF_LCAP / 4)                       // ... = 4 wave-private lists (overflow -> direct global append)
 #define AFF_LDS_BYTES (2 * 2 * 64 * 16 * 16 + AFF_LCAP * 12 + 16 + 2 * 64 * 4)
-template <int AFF_NQ>                                 // 16-query column sets per wave (1 or 2)
+// AFF_MODE: -1 = the pass is read from p.mode at run time (the default kernels: one binary serves both passes);
+// 0 / 1 = EXPERIMENTAL compile-time pass (opt-in: CUTIE_AMD_EXPERIMENTAL_AFF=1 in the environment of the process): the
+// max-only pass then carries neither the candidate-list code nor its registers.  Not yet run on a GPU (added after the last
+// GPU minute of round 1, like conv_bufload.hip); the default instantiations compile to the same ISA as before.
+template <int AFF_NQ, int AFF_MODE = -1>              // 16-query column sets per wave (1 or 2)
 __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
+    const int mode = AFF_MODE < 0 ? p.mode : AFF_MODE;
     extern __shared__ __attribute__((aligned(16))) unsigned char aff_smem[];
     au32x4 (*lds)[2 * 64 * 16] = reinterpret_cast<au32x4 (*)[2 * 64 * 16]>(aff_smem);   // [buffer][hi/lo][row][16 chunks]
     int* l_j = reinterpret_cast<int*>(aff_smem + 2 * 2 * 64 * 16 * 16);
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
         jvalid[u] = jq[u] < p.HW;
         cj[u] = jvalid[u] ? p.c[jq[u]] : 0.f;
         thr[u] = INFINITY;
-        if (p.mode == 1 && jvalid[u]) {
+        if (mode == 1 && jvalid[u]) {
             float tau = p.gmax_or_tau[jq[u]];
             thr[u] = tau - fabsf(tau) * 1e-6f - 1e-30f;                 // never lose the k-th element to 1 ulp
         }
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
                         s[q] = valid ? sc[q] * (acc[q] - cj[u]) : -INFINITY;
                         mx = fmaxf(mx, s[q]);
                     }
-                    if (p.mode == 0) {
+                    if (mode == 0) {
                         gm[u][t] = rows_max(mx);
                     } else if (__ballot(jvalid[u] && mx >= thr[u])) {   // wave-uniform: some lane has a candidate in this tile
 #pragma unroll
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
                 }
             }
         }
-        if (p.mode == 0 && l4 == 0) {                                   // 4 tile maxima per query: one 16-B store
+        if (mode == 0 && l4 == 0) {                                   // 4 tile maxima per query: one 16-B store
 #pragma unroll
             for (int u = 0; u < AFF_NQ; ++u)
                 if (jq[u] < p.HWp)
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
         __syncthreads();
         buf ^= 1;
     }
-    if (p.mode == 1) {                                                  // flush this wave's candidates: one dense burst of global atomics
+    if (mode == 1) {                                                    // flush this wave's candidates: one dense burst of global atomics
         const int n = min(wcount, AFF_WCAP);
         for (int e = lane; e < n; e += 64) {
             const int j = wl_j[e];
@@ -476,8 +482,28 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             if (tpb < 8) tpb = 8;
             tpb = (tpb + AFF_TG - 1) / AFF_TG * AFF_TG;
             sp.tiles_per_block = tpb;
-            if (nq == 1) hipLaunchKernelGGL(aff_score_kernel<1>, dim3(qb, (G + tpb - 1) / tpb), dim3(256), AFF_LDS_BYTES, s, sp);
-            else hipLaunchKernelGGL(aff_score_kernel<2>, dim3(qb, (G + tpb - 1) / tpb), dim3(256), AFF_LDS_BYTES, s, sp);
+            const dim3 grid(qb, (G + tpb - 1) / tpb);
+            static const bool experimental = [] { const char* e = getenv("CUTIE_AMD_EXPERIMENTAL_AFF"); return e && e[0] && e[0] != '0'; }();
+            if (experimental && (sp.mode == 0 || sp.mode == 1)) {          // compile-time pass (see the template comment): opt-in
+                static bool exp_attr_set = false;
+                if (!exp_attr_set) {
+                    const void* ks[4] = {reinterpret_cast<const void*>(aff_score_kernel<1, 0>), reinterpret_cast<const void*>(aff_score_kernel<1, 1>),
+                                         reinterpret_cast<const void*>(aff_score_kernel<2, 0>), reinterpret_cast<const void*>(aff_score_kernel<2, 1>)};
+                    for (const void* k : ks)
+                        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, AFF_LDS_BYTES) != hipSuccess) {
+                            cutie_set_error("aff_score: cannot raise the dynamic LDS limit to %d bytes", AFF_LDS_BYTES);
+                            return -2;
+                        }
+                    exp_attr_set = true;
+                }
+                if (nq == 1 && sp.mode == 0) hipLaunchKernelGGL((aff_score_kernel<1, 0>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
+                else if (nq == 1) hipLaunchKernelGGL((aff_score_kernel<1, 1>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
+                else if (sp.mode == 0) hipLaunchKernelGGL((aff_score_kernel<2, 0>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
+                else hipLaunchKernelGGL((aff_score_kernel<2, 1>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
+                break;
+            }
+            if (nq == 1) hipLaunchKernelGGL(aff_score_kernel<1>, grid, dim3(256), AFF_LDS_BYTES, s, sp);
+            else hipLaunchKernelGGL(aff_score_kernel<2>, grid, dim3(256), AFF_LDS_BYTES, s, sp);
             break;
         }
         case CUTIE_OP_AFF_SELECT:

@@ -21,12 +21,16 @@ PY
 CUTIE_AMD_TILE_CACHE=$OUT/tiles_experimental.json timeout 300 python bench.py --steps 200 --warmup 20 --cpu-frames 0 --clips-in-flight 0 > $OUT/4_bench_experimental.json 2> $OUT/4_bench_experimental.err
 unset CUTIE_AMD_EXPERIMENTAL_TILES
 timeout 300 python bench.py --steps 200 --warmup 20 --cpu-frames 0 --clips-in-flight 0 > $OUT/4_bench_packaged.json 2> $OUT/4_bench_packaged.err
+# 5. the compile-time-pass affinity score kernels (affinity.hip, AFF_MODE 0 / 1): parity, then the matmul's MFMA utilisation
+CUTIE_AMD_EXPERIMENTAL_AFF=1 timeout 300 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_parity.py -q -x -k "aff or trajectory" > $OUT/5_aff_tests.log 2>&1; tail -2 $OUT/5_aff_tests.log
+CUTIE_AMD_EXPERIMENTAL_AFF=1 timeout 300 python bench.py --steps 200 --warmup 20 --cpu-frames 0 --clips-in-flight 0 > $OUT/5_bench_aff.json 2> $OUT/5_bench_aff.err
 python - <<'PY'
 import json
-for n in ('experimental', 'packaged'):
+for n, f in (('experimental conv tiles', '4_bench_experimental'), ('packaged', '4_bench_packaged'), ('experimental affinity', '5_bench_aff')):
     try:
-        d = json.loads(open(f'gpurun_out/round2_open/4_bench_{n}.json').read().strip().split('\n')[-1])
-        print(n, d['value'], 'frames/s; conv', d.get('roofline', {}).get('achieved'), 'TFLOP/s, frac', d.get('roofline', {}).get('frac'))
+        d = json.loads(open(f'gpurun_out/round2_open/{f}.json').read().strip().split('\n')[-1])
+        print(n, d['value'], 'frames/s; conv', d.get('roofline', {}).get('achieved'), 'TFLOP/s, frac', d.get('roofline', {}).get('frac'),
+              '; affinity matmul mfma_util', (d.get('roofline_affinity', {}).get('matmul') or {}).get('mfma_util'))
     except Exception as e:
         print(n, 'no bench line:', e)
 PY
