@@ -4,7 +4,7 @@ long-term memory and object chunks) are run through the unmodified reference Inf
 the same weights; per-frame probabilities and memory-bank sizes must agree.  Complements the fixed golden scenarios
 (tests/golden): those travel to the GPU box, this runs only where /root/reference exists (the build container).
 
-    python oracle/fuzz_reference.py --seeds 0 1 2 [--frames 14]
+    python oracle/fuzz_reference.py --seeds 0 1 2 [--frames 14] [--model small]
 
 TEST INFRASTRUCTURE (see oracle/__init__.py)."""
 import argparse
@@ -85,18 +85,20 @@ def main():
     ap.add_argument('--seeds', type=int, nargs='+', default=[0, 1, 2])
     ap.add_argument('--frames', type=int, default=14)
     ap.add_argument('--tol', type=float, default=5e-3)
+    ap.add_argument('--model', default='base', choices=['base', 'small'], help='cutie/config/model/{base,small}.yaml')
     args = ap.parse_args()
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     CUTIE, InferenceCore = import_reference()
     from oracle import scenarios as S
     from oracle.inference import DEFAULT_CFG, OracleProcessor
     from oracle.net import OracleNet
-    from oracle.weights import make_state_dict
-    sd = make_state_dict(seed=0)
-    net = CUTIE(reference_cfg()).eval()
+    from oracle.weights import MODEL_CFG, MODEL_CFG_SMALL, make_state_dict
+    mcfg = MODEL_CFG_SMALL if args.model == 'small' else MODEL_CFG
+    sd = make_state_dict(seed=0, m=mcfg)
+    net = CUTIE(reference_cfg(args.model)).eval()
     net.load_weights({k: v.clone() for k, v in sd.items()})
-    onet = OracleNet(sd)
-    wrap = lambda over: reference_cfg(**{k: (_wrap(v) if isinstance(v, dict) else v) for k, v in over.items()})
+    onet = OracleNet(sd, mcfg)
+    wrap = lambda over: reference_cfg(args.model, **{k: (_wrap(v) if isinstance(v, dict) else v) for k, v in over.items()})
     bad = 0
     for seed in args.seeds:
         sc = random_scenario(seed, args.frames)
