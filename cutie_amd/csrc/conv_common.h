@@ -82,3 +82,4 @@ constexpr int conv_lds_bytes() {
 }
 
 int launch_conv_bufload(const ConvParams& p, int tile, hipStream_t s);   // conv_bufload.hip (experimental tiles 50..)
+int launch_conv_dma(const ConvParams& p, int tile, hipStream_t s);       // conv_dma.hip (LDS-DMA tiles 60..)

@@ -151,6 +151,7 @@ class InferenceCore:
     def clear_memory(self):
         self.curr_ti = -1
         self.last_mem_ti = 0
+        self.memory.check_overflow()
         self.memory = MemoryManager(cfg=self.cfg, object_manager=self.object_manager)
         if self._flip is not None:
             self._flip.clear_memory()
@@ -302,6 +303,8 @@ class InferenceCore:
             if fl is not None:
                 fl.image_feature_store.delete(self.curr_ti)
 
+        if end:
+            self.memory.check_overflow()
         output_prob = unpad(pred_prob_with_bg, self.pad)
         if resize_needed:
             output_prob = self._resize(output_prob, (h, w))
@@ -316,7 +319,9 @@ class InferenceCore:
             # planes of known objects keep the prediction unless the input mask provides them
             n_planes = max(k_new, pred.shape[0] - 1)
             for mask_id, tmp_id in enumerate(tmp_ids):
-                # sic: float masks are indexed by tmp id in the reference (:276)
+                # sic: float masks are indexed by tmp id in the reference (:276) -- and out of range raises there as well
+                if not idx_mask and tmp_id >= mask.shape[0]:
+                    raise IndexError(f'index {tmp_id} is out of bounds for dimension 0 with size {mask.shape[0]}')
                 src[tmp_id - 1] = int(objects[mask_id]) if idx_mask else int(tmp_id)
             k_pred = pred.shape[0] - 1
         else:

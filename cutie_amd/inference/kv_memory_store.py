@@ -84,29 +84,65 @@ class Bucket:
     def size(self):
         return self.n_long + self.n_perm + self.n_work
 
-    def grow_perm(self, need):
-        """Re-allocate with a larger permanent region (rare: GUI 'commit' / force_permanent)."""
-        old_tensors = [t for t, _ in self.arrays()]
-        oldP = self.P
-        while self.P < need:
-            self.P *= 2
-        self._alloc_like(old_tensors, oldP)
+    def work_order(self):
+        """Slot offsets (in frames of HW tokens) of the working tokens in time order, oldest first."""
+        nf = self.n_work // self.HW
+        if self.lt or nf == 0:
+            return list(range(nf))
+        frames = self.Wc // self.HW
+        if nf < frames:                                  # ring not full yet: written 0, 1, ... in order
+            return list(range(nf))
+        first = self.ring % frames                       # full ring: the next overwrite hits the oldest frame
+        return [(first + i) % frames for i in range(frames)]
 
-    def _alloc_like(self, old_tensors, oldP):
+    def reserve(self, L=None, P=None, Wc=None):
+        """Re-allocate the slabs with new region capacities (rare: permanent memory growing through ``force_permanent`` commits,
+        or the memory settings changed by ``update_config``, e.g. the GUI's working / long-term memory sliders).  Long-term and
+        permanent tokens are copied as they are; the working tokens are re-written in time order, and when the new working region
+        is smaller than what is stored only the newest tokens survive (what the reference's FIFO trim does on the next insertion,
+        kv_memory_store.py:206-207)."""
+        L = self.L if L is None else L
+        P = self.P if P is None else P
+        Wc = self.Wc if Wc is None else Wc
+        assert L >= self.n_long and P >= self.n_perm, (L, self.n_long, P, self.n_perm)
+        if (L, P, Wc) == (self.L, self.P, self.Wc):
+            return
+        HW = self.HW
+        order = self.work_order()
+        keep_frames = min(len(order), Wc // HW) if not self.lt else len(order)
+        if self.lt:
+            assert Wc >= self.n_work, 'long-term mode never drops working tokens outside consolidation'
+        order = order[len(order) - keep_frames:]
+        old = [(t, rb) for t, rb in self.arrays()]
+        oldL, oldP = self.L, self.P
         names = ['Ahi', 'Alo', 'scale'] + (['rawkey', 'rawsel', 'rawshr', 'use', 'life'] if self.lt else [])
         objs = list(self.values.keys())
+        self.L, self.P, self.Wc = L, P, Wc
         n = self.slots
         new = []
-        for t in old_tensors:
+        for t, _ in old:
             nt = torch.zeros((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
-            nt[:self.L + oldP] = t[:self.L + oldP]                          # long-term + permanent
-            nt[self.L + self.P:self.L + self.P + self.Wc] = t[self.L + oldP:self.L + oldP + self.Wc]
+            nt[:self.n_long] = t[:self.n_long]
+            nt[L:L + self.n_perm] = t[oldL:oldL + self.n_perm]
+            ws_old, ws_new = oldL + oldP, L + P
+            for j, f in enumerate(order):
+                nt[ws_new + j * HW:ws_new + (j + 1) * HW] = t[ws_old + f * HW:ws_old + (f + 1) * HW]
             new.append(nt)
         for name, nt in zip(names, new[:len(names)]):
             setattr(self, name, nt)
         for o, nt in zip(objs, new[len(names):]):
             self.values[o] = nt
+        self.n_work = keep_frames * HW
+        self.ring = keep_frames                          # time order again: the next ring write lands behind the newest frame
         self._vptrs = None
+        self._aff_plan = None
+
+    def grow_perm(self, need):
+        """A larger permanent region (GUI 'commit' / force_permanent)."""
+        P = self.P
+        while P < need:
+            P *= 2
+        self.reserve(P=P)
 
     def remove_objects(self, keep):
         self.objects = [o for o in self.objects if o in keep]

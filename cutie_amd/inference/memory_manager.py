@@ -11,6 +11,7 @@ Reference behaviour kept (with file:line):
 Per-object state lives in stacked tensors in tmp-id order (objects of one bucket are always contiguous there).
 """
 import logging
+import os
 from typing import Dict, List
 
 import torch
@@ -22,6 +23,7 @@ from .object_manager import ObjectManager
 log = logging.getLogger()
 BF16, F32 = torch.bfloat16, torch.float32
 CAND_CAP = 1024          # candidate slots per query column (typical fill ~35; see csrc/affinity.hip)
+_VALIDATE = os.environ.get('CUTIE_AMD_VALIDATE', '0') not in ('', '0')
 
 
 class MemoryManager:
@@ -169,6 +171,10 @@ class MemoryManager:
                     ol.usage_tick(D('life'), bucket.n_long)
                 ol.aff_readout(D('cval'), D('cidx'), D('count'), D('vptrs'), D('usage') if self.use_long_term else None, D('readout'),
                                D('ovf'), HW=HW, cap=CAND_CAP, top_k=self.top_k, K=K, CV=self.CV)
+                if self.use_long_term and bucket.n_long > 0 and not self.count_long_term_usage:
+                    # long_term.count_usage=False: the reference keeps no usage for long-term tokens (memory_manager.py:145-147);
+                    # the read-out kernel accumulates usage for every slot, so the long-term part is cleared again
+                    ol.memset32(D('usage'), bucket.n_long, 0)
                 bucket._aff_plan = cached = (key, ol)
             dyn = dict(count=count, Ahi=bucket.Ahi, Alo=bucket.Alo, scale=bucket.scale, Bhi=q['Bhi'], Blo=q['Blo'], cq=q['cq'],
                        gmax=gmax, tau=tau, cval=cval, cidx=cidx, vptrs=bucket.vptrs(), readout=readout, ovf=ovf)
@@ -197,7 +203,24 @@ class MemoryManager:
                     self.aux = {'sensory': this_sensory, 'pixel_readout': pixel_readout,
                                 'q_logits': aux_features['logits'] if aux_features else None}
             self._last_readout = chunks[0] if len(chunks) == 1 else (None, None)
+        if _VALIDATE:
+            self.check_overflow()
         return all_readout
+
+    def check_overflow(self) -> int:
+        """Number of queries whose candidate list overflowed CAND_CAP since the last check (their top-k was taken from a
+        truncated list, e.g. > 1024 exactly tied scores from duplicated permanent frames); warns and resets the counter.  Reads
+        one int from the device (a synchronisation): called at the end of a clip (``step(end=True)``), by ``clear_memory`` and
+        on every read when $CUTIE_AMD_VALIDATE is set."""
+        ovf = self._scratch.get('overflow')
+        if ovf is None:
+            return 0
+        n = int(ovf.item())
+        if n:
+            log.warning(f'affinity read-out: {n} queries had more than {CAND_CAP} candidates above the top-k threshold; '
+                        f'their read-out used a truncated candidate list')
+            ovf.zero_()
+        return n
 
     def readout_stacked(self, all_obj_ids):
         """The per-object dict of read() re-stacked in tmp-id order (ObjectManager.realize_dict) without a copy when
@@ -222,6 +245,8 @@ class MemoryManager:
             self.max_work_tokens = self.max_mem_frames * self.HW
             if self.use_long_term:
                 self.min_work_tokens = self.min_mem_frames * self.HW
+            for b in self.buckets.values():                              # update_config changed the limits: resize the slabs
+                self._fit_bucket(b)
         HW = self.HW
         dev = key.device
         self.CK = key.shape[1]
@@ -281,6 +306,8 @@ class MemoryManager:
                 if b.Wc < HW:
                     continue                                            # max_mem_frames == 1: no working memory at all
                 if self.use_long_term:
+                    if b.n_work + HW > b.Wc:
+                        self._fit_bucket(b, extra_work=HW)
                     slot = b.work_start + b.n_work                      # linear; consolidation compacts
                     b.n_work += HW
                 else:
@@ -288,6 +315,8 @@ class MemoryManager:
                     slot = b.work_start + (b.ring % frames) * HW
                     b.ring += 1
                     b.n_work = min(b.n_work + HW, frames * HW)
+            region_end = (b.perm_start + b.P) if to_perm else (b.work_start + b.Wc)
+            assert slot + HW <= region_end, ('memory bank overrun', slot, HW, region_end)
             ol.key_prep(kphys, sphys, b.Ahi[slot:], b.Alo[slot:], b.scale[slot:], n=HW, query=False)
             if self.use_long_term:
                 ol.copy2d(kphys, b.rawkey[slot:], rows=HW, rowbytes=4 * self.CK, src_stride=4 * self.CK, dst_stride=4 * self.CK)
@@ -312,6 +341,20 @@ class MemoryManager:
                         self._remove_obsolete(b, self.max_long_tokens - self.num_prototypes - self.buffer_tokens)
                     self._compress(b)
 
+    def _fit_bucket(self, b: Bucket, extra_work: int = 0):
+        """Make the slab capacities of a bucket match the current memory settings (they are sized when the bucket is created;
+        ``update_config`` -- the GUI's memory sliders -- may change max_mem_frames / max_num_tokens afterwards).  FIFO mode: the
+        working region is exactly the ring of max_mem_frames-1 frames (a smaller setting drops the oldest frames, like the
+        reference's trim at the next insertion).  Long-term mode: room for the tokens present plus one more frame, and for one
+        more batch of prototypes behind the long-term tokens."""
+        if self.use_long_term:
+            Wc = max(self.max_work_tokens, b.n_work + extra_work)
+            L = max(self.max_long_tokens, b.n_long + self.num_prototypes)
+            if Wc != b.Wc or L > b.L:
+                b.reserve(L=max(L, b.L), Wc=Wc)
+        elif b.Wc != self.max_work_tokens:
+            b.reserve(Wc=self.max_work_tokens)
+
     # ---- long-term consolidation (memory_manager.py:309-358) ----------------------------------------------------------
     def _compress(self, b: Bucket):
         HW, dev = self.HW, b.device
@@ -319,6 +362,9 @@ class MemoryManager:
         n = b.n_work - self.min_work_tokens            # candidates: the oldest working tokens
         if n <= 0:
             return
+        if b.n_long + P > b.L:
+            self._fit_bucket(b)
+        assert b.n_long + P <= b.L, ('long-term region overrun', b.n_long, P, b.L)
         ws = b.work_start
         ol = O.OpList()
         order = self._buf('proto_order', (P,), torch.int32, dev)
@@ -337,10 +383,14 @@ class MemoryManager:
         ol.memset32(b.use[dst:], P, 0)
         ol.memset32(b.life[dst:], P, LIFE_EPS_BITS)
         # drop the consolidated tokens: keep the newest min_work_tokens, moved to the region start
+        # (COPY2D is a parallel copy: source and destination must not overlap.  When fewer tokens are dropped than kept --
+        # min_mem_frames > max_mem_frames / 2 -- the move is issued as stream-ordered chunks of at most n rows, ascending, so
+        # that every chunk's destination ends where its source begins.)
         keep = self.min_work_tokens
         for t, rowbytes in b.arrays():
-            nb = rowbytes * keep
-            ol.copy2d(t[ws + n:], t[ws:], rows=1, rowbytes=nb, src_stride=nb, dst_stride=nb)
+            for c0 in range(0, keep, n):
+                nb = rowbytes * min(n, keep - c0)
+                ol.copy2d(t[ws + n + c0:], t[ws + c0:], rows=1, rowbytes=nb, src_stride=nb, dst_stride=nb)
         ol.run()
         b.n_long += P
         b.n_work = keep

@@ -48,6 +48,10 @@ TILE_CACHE_ENV = 'CUTIE_AMD_TILE_CACHE'
 TUNE_REPS, TUNE_ITERS = (int(v) for v in os.environ.get('CUTIE_AMD_TUNE', '3x8').lower().split('x'))
 
 
+# Timing-based tile selection for conv geometries that are NOT in the tuned table is opt-in ($CUTIE_AMD_AUTOTUNE=1, or
+# Engine.autotune = True): timing is noisy, and a different (tile, split-K) changes the fp32 summation order, so by default such
+# geometries take the deterministic static choice of ops.pick_tile and results are bit-reproducible across processes.
+AUTOTUNE = os.environ.get('CUTIE_AMD_AUTOTUNE', '0') not in ('', '0')
 PACKAGED_TILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tiles_gfx950.json')
 
 
@@ -126,6 +130,8 @@ class Plan:
             M, cout, cin = int(i[0]) * int(i[7]) * int(i[8]), int(i[9]), int(i[3]) + int(i[4])
             key = (M, cout, cin, int(i[11]), int(i[13]), int(arr['flags'][n]) & 3, int(i[1]), int(i[2]))
             best = cache.get(key)
+            if best is None and not getattr(self.eng, 'autotune', AUTOTUNE):
+                continue                                     # keep the deterministic static choice made when the plan was built
             if best is None:
                 one = arr[n:n + 1].copy()
                 best, best_t = (int(i[17]), 1), None
@@ -141,6 +147,8 @@ class Plan:
                             best, best_t = (t, sk), ms
                 cache[key] = best
                 tuned_any = True
+            if best[0] in O.DMA_TILES and not O.dma_tiles_enabled():
+                continue
             arr['i'][n, 17], arr['i'][n, 19] = best
         self.tuned = True
         if tuned_any:

@@ -52,6 +52,24 @@ EXPERIMENTAL_TILES = {50: (128, 64, 64), 51: (64, 64, 64), 52: (64, 128, 64), 53
                       55: (128, 128, 64), 56: (32, 64, 64)}
 
 
+# 60+: LDS-DMA kernel (conv_dma.hip): operands global -> LDS by buffer_load ... lds, rolled K loop with ~2-4 non-MFMA
+# instructions per MFMA.  id -> (BM, BN, BK); needs Cin % 64 == 0 (both sources of a virtual concat), no split-K.
+DMA_TILES = {60: (128, 128, 64), 61: (128, 128, 64), 62: (128, 128, 64), 63: (128, 64, 64), 64: (64, 128, 64), 65: (64, 64, 64),
+             66: (64, 64, 64), 67: (32, 64, 64), 68: (256, 128, 64), 69: (32, 128, 64)}
+
+
+ALL_TILES = {**TILES, **DMA_TILES}
+
+
+def dma_tiles_enabled():
+    return os.environ.get('CUTIE_AMD_DMA_TILES', '1') not in ('', '0')
+
+
+def dma_tile_ok(tile, *, cin, kh, c2=0):
+    """conv_dma_kernel eligibility (mirrors launch_dma in conv_dma.hip): a 64-channel K tile never straddles a tap or a source."""
+    return cin % 64 == 0 and (c2 == 0 or (c2 % 64 == 0 and (cin - c2) % 64 == 0)) and kh * kh <= 32
+
+
 def experimental_tiles_enabled():
     return os.environ.get('CUTIE_AMD_EXPERIMENTAL_TILES', '0') not in ('', '0')
 
@@ -105,6 +123,10 @@ def tile_candidates(M, cout, cin, kpad=None, geom=None):
         if bm * 2 > max(M, 64) * 2 and bm > 64:          # do not pad a tiny M to a huge tile
             continue
         out.append(t)
+    if dma_tiles_enabled() and geom is not None and dma_tile_ok(60, cin=cin, kh=geom['kh'], c2=geom.get('c2', 0)):
+        for t, (bm, bn, bk) in DMA_TILES.items():
+            if not (bn == 128 and cout <= 64) and not (bm > 64 and bm > max(M, 64)) and not (bm == 256 and M < 16384):
+                out.append(t)
     if experimental_tiles_enabled() and geom is not None:
         for t, (bm, bn, bk) in EXPERIMENTAL_TILES.items():
             if bufload_tile_ok(t, cin=cin, kh=geom['kh'], c2=geom.get('c2', 0), kpad=kpad) and not (bn == 128 and cout <= 64) \
@@ -132,7 +154,7 @@ def splitk_scratch(device, owner=None):
 
 def splitk_candidates(M, cout, kpad, tile):
     """Split-K factors worth timing for a conv on a given tile: only when the plain grid leaves CUs idle."""
-    if tile == COUT1_TILE or tile == 3 or tile in PATCH_TILES or tile in EXPERIMENTAL_TILES:
+    if tile == COUT1_TILE or tile == 3 or tile in PATCH_TILES or tile in EXPERIMENTAL_TILES or tile in DMA_TILES:
         return [1]
     bm, bn, bk = TILES[tile]
     blocks = -(-M // bm) * -(-cout // bn)
@@ -149,17 +171,21 @@ def splitk_candidates(M, cout, kpad, tile):
     return out
 
 
-def pick_tile(M, cout, cin=64):
-    """Static heuristic (used when no GPU is present to autotune): the largest tile that still yields
-    >= NUM_CU workgroups, with BK=64 when the input has enough channels."""
+def pick_tile(M, cout, cin=64, geom=None):
+    """Static, deterministic tile choice for conv geometries that are not in the tuned table (cutie_amd/tiles_gfx950.json):
+    the largest tile that still yields >= NUM_CU workgroups, else the one with the most workgroups -- among the LDS-DMA tiles
+    when the conv is eligible for them (geom = dict(kh, c2) given and Cin % 64 == 0), else among the register-staged ones."""
     if cout <= 16:
         return 3
-    cands = [6, 5, 9] if cin >= 32 else [4, 2]
+    if geom is not None and dma_tiles_enabled() and dma_tile_ok(60, cin=cin, kh=geom['kh'], c2=geom.get('c2', 0)):
+        cands = [60, 63, 64, 66, 67]
+    else:
+        cands = [6, 5, 9] if cin >= 32 else [4, 2]
     if cout <= 64:
-        cands = [c for c in cands if TILES[c][1] <= 64] or [2]
+        cands = [c for c in cands if ALL_TILES[c][1] <= 64] or [2]
     best, best_blocks = None, -1
     for t in cands:
-        bm, bn, _ = TILES[t]
+        bm, bn, _ = ALL_TILES[t]
         blocks = -(-M // bm) * -(-cout // bn)
         if blocks >= NUM_CU:
             return t
@@ -247,7 +273,7 @@ class OpList:
         assert C1 + C2 == w.cin_padded, (C1, C2, w.cin_padded)
         M = B * OH * OW
         if tile is None:
-            tile = COUT1_TILE if cout1_ok(w.cout, C1 + C2, C2, res is not None) else pick_tile(M, w.cout, C1 + C2)
+            tile = COUT1_TILE if cout1_ok(w.cout, C1 + C2, C2, res is not None) else pick_tile(M, w.cout, C1 + C2, dict(kh=w.kh, c2=C2))
         part = splitk_scratch(w.weight.device, self.scratch_owner)
         return self.add(CONV, flags,
                         [B, H, W, C1, C2, ldx1, ldx2, OH, OW, w.cout, ldy, w.kh, w.kw, stride, pad, ldr, w.kpad, tile, w.cin_real,

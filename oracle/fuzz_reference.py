@@ -77,6 +77,18 @@ def random_scenario(seed, frames):
     if r.random() < 0.25 and sc['h'] > 80:
         cfg['max_internal_size'] = 80                              # shorter side 96 / 100 -> internal resize path, still >= 30 tokens
                                                                    # (with fewer than top_k tokens the reference's topk raises)
+    if r.random() < 0.5 and frames > 4:
+        # memory limits changed mid-clip (the GUI's working / long-term memory sliders go through update_config,
+        # gui/main_controller.py:518-560): the token limits are re-derived at the next memory frame (memory_manager.py:228-235)
+        t = int(r.integers(2, frames - 1))
+        over = sc['update_config_at'].setdefault(t, {})
+        if cfg.get('use_long_term'):
+            mx = int(r.integers(3, 7))
+            lt = dict(cfg['long_term'], max_mem_frames=mx, min_mem_frames=int(r.integers(2, mx)),
+                      max_num_tokens=int(r.choice([24, 40, 64])), buffer_tokens=int(r.choice([4, 12])))
+            over['long_term'] = lt
+        else:
+            over['max_mem_frames'] = int(r.integers(2, 6))
     return sc
 
 

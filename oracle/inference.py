@@ -220,6 +220,7 @@ class OracleProcessor:
         self.sensory, self.obj_v = {}, {}
         self.engaged = False
         self.HW = None
+        self.config_stale = True
 
     # ---- interactive surface (inference_core.py:52-69, memory_manager.py:59-75,377-383) ------------
     def clear_memory(self):
@@ -254,6 +255,7 @@ class OracleProcessor:
         if self._flip is not None:
             self._flip.update_config(cfg)
         cfg = dict(DEFAULT_CFG, **cfg) if isinstance(cfg, dict) else cfg
+        self.config_stale = True                                    # memory_manager.py:59: token limits are re-derived at the next add
         self.mem_every = cfg['mem_every']
         self.top_k = cfg['top_k']
         lt = cfg['long_term']
@@ -371,7 +373,8 @@ class OracleProcessor:
         sens = torch.stack([self.sensory[o] for o in self.obj_ids], 1)
         value, new_sens, summ = self.net.encode_mask(image, pix_feat, sens, prob, deep_update=True)
         self.engaged = True
-        if self.HW is None:
+        if self.HW is None or self.config_stale:                    # memory_manager.py:228-235
+            self.config_stale = False
             self.HW = key.shape[-2] * key.shape[-1]
             self.max_work_tokens = self.max_mem_frames * self.HW
             if self.use_long_term:

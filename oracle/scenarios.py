@@ -51,10 +51,32 @@ SCENARIOS = {
     'small_video': dict(cfg=dict(mem_every=3, use_long_term=True, long_term=LT_SMALL), kind='synth', h=96, w=120, k=2,
                         frames=14, sub=2, add_at={0: [1, 2], 6: [1, 2]}, float_mask_at=[0, 6], float_kind='onehot',
                         precommit=[0, 6]),
+    # long-term memory where fewer tokens are consolidated than kept (min_mem_frames > max_mem_frames / 2): the compaction of
+    # the working region moves the kept tokens over a distance smaller than their extent (overlapping ranges)
+    'small_lt_overlap': dict(cfg=dict(mem_every=2, use_long_term=True, long_term=dict(LT_SMALL, max_mem_frames=6, min_mem_frames=5)),
+                             kind='synth', h=96, w=128, k=2, frames=30, sub=2),
+    # memory limits changed mid-clip through update_config (the GUI's memory sliders, gui/main_controller.py:518-560): the token
+    # limits are re-derived at the next memory frame (memory_manager.py:228-235) -- FIFO ring grown 2 -> 4 frames, then cut to 1
+    'small_cfg_fifo': dict(cfg=dict(mem_every=2, max_mem_frames=3), kind='synth', h=96, w=120, k=2, frames=18, sub=2,
+                           update_config_at={5: dict(max_mem_frames=5), 13: dict(max_mem_frames=2)}),
+    # ... and with long-term memory: larger working set + more long-term tokens, then both cut below what is stored
+    'small_cfg_lt': dict(cfg=dict(mem_every=2, use_long_term=True, long_term=LT_SMALL), kind='synth', h=96, w=120, k=2, frames=34, sub=2,
+                         update_config_at={9: dict(long_term=dict(LT_SMALL, max_mem_frames=6, min_mem_frames=5, max_num_tokens=64)),
+                                           23: dict(long_term=dict(LT_SMALL, max_mem_frames=3, min_mem_frames=2, max_num_tokens=24,
+                                                                   buffer_tokens=4))}),
     # flip augmentation (bs = 2 in the reference) with long-term memory; width 121 -> asymmetric pad (3 | 4)
     'small_flip': dict(cfg=dict(mem_every=2, flip_aug=True, use_long_term=True, long_term=LT_SMALL),
                        kind='synth', h=96, w=121, k=2, frames=26, sub=2),
 }
+
+
+def trajectory_bounds(model='base'):
+    """(max |dprob|, mean |dprob|, argmax margin) a free-running trajectory of the product is held to: 1.25 x the deviation of the
+    reference's OWN bf16 / fp16 autocast runs from its fp32 run on these scenarios, measured by oracle/make_envelope.py and
+    committed in tests/golden/amp_envelope.json (per model variant; argmax margin = twice the max bound)."""
+    import json
+    b = json.load(open(os.path.join(GOLDEN_DIR, 'amp_envelope.json')))['bounds'][model]
+    return b['trajectory_max'], b['trajectory_mean'], b['argmax_margin']
 
 
 def _bike_frames():

@@ -146,6 +146,28 @@ def test_conv_bufload_tiles(ci, tile):
     check(hip, ref, f'bufload[{ci}] tile{tile}')
 
 
+DMA_CASES = BUFLOAD_CASES + [
+    dict(B=1, H=30, W=54, C1=256, Cout=1024, k=1, res=True, act=O.ACT_RELU),             # ResNet conv3 + residual
+    dict(B=1, H=36, W=40, C1=128, Cout=128, k=3, stride=2, act=O.ACT_RELU),              # 3x3 stride 2: halo on two sides only
+    dict(B=3, H=30, W=54, C1=256, Cout=768, k=1, res=True),                               # transformer pixel projections
+    dict(B=2, H=21, W=19, C1=64, C2=192, Cout=130, k=3, relu_in=True, out_f32=True),     # unequal sources, ragged everything
+    dict(B=1, H=120, W=216, C1=128, Cout=128, k=3, relu_in=True, act=O.ACT_RELU),        # decoder 3x3 at stride 4 (large M)
+    dict(B=1, H=16, W=16, C1=2048, Cout=64, k=1),                                         # long K loop (32 tiles)
+    dict(B=1, H=12, W=20, C1=64, Cout=64, k=1),                                           # one K tile: shorter than the ring
+    dict(B=1, H=12, W=20, C1=128, Cout=64, k=1, act=O.ACT_SIGMOID, out_f32=True),        # two K tiles
+]
+
+
+@pytest.mark.parametrize('tile', sorted(O.DMA_TILES))
+@pytest.mark.parametrize('ci', range(len(DMA_CASES)))
+def test_conv_dma_tiles(ci, tile):
+    """conv_dma_kernel (tiles 60..: LDS-DMA staging, halo by out-of-range buffer offsets) against the interpreter."""
+    c = DMA_CASES[ci]
+    assert O.dma_tile_ok(tile, cin=c['C1'] + c.get('C2', 0), kh=c['k'], c2=c.get('C2', 0))
+    hip, ref = run_both(_conv_build(c, tile), seed=400 + ci)
+    check(hip, ref, f'dma[{ci}] tile{tile}')
+
+
 PATCH_CASES = [
     dict(B=3, H=30, W=54, C1=256, Cout=256, k=3, relu_in=True, act=O.ACT_RELU),          # CAResBlock conv (480p, 3 objects)
     dict(B=1, H=30, W=54, C1=256, Cout=64, k=3, out_f32=True, act=O.ACT_SIGMOID),        # key projection e_proj

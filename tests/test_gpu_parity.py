@@ -2,8 +2,10 @@
 
 Stated tolerance (bf16 activation/weight storage, fp32 accumulation, fp32 keys/logits/GRU state/summaries):
   * per-stage tensors: max |d| <= 3e-2 * max|oracle| (5e-2 after the object transformer)
-  * per-frame probabilities over whole trajectories: max |dprob| <= 0.15, mean |dprob| <= 0.05, no growth in time
-  * argmax object ids identical wherever the oracle's top-1/top-2 margin exceeds 0.30 = twice the per-class bound (with the synthetic
+  * per-frame probabilities over whole (free-running) trajectories: within 1.25 x the deviation of the REFERENCE'S OWN bf16 / fp16
+    autocast runs from its fp32 run on the same scenarios (oracle/make_envelope.py -> tests/golden/amp_envelope.json; base model:
+    max 0.13, mean 0.037); the tight per-frame bound is carried by the teacher-forced tests (tests/test_gpu_teacher.py)
+  * argmax object ids identical wherever the oracle's top-1/top-2 margin exceeds twice that max bound (with the synthetic
     weights several objects are nearly tied per pixel; with a real checkpoint the margin mask is ~everything)
   * memory-bank bookkeeping (token counts, permanent size, long-term size, buckets) bit-exact vs the golden
     values recorded from the executed reference.
@@ -20,6 +22,7 @@ from oracle.inference import OracleProcessor, DEFAULT_CFG
 from oracle.weights import make_state_dict
 
 pytestmark = pytest.mark.gpu
+BMAX, BMEAN, BMARGIN = S.trajectory_bounds('base')
 
 
 @pytest.fixture(scope='module')
@@ -88,7 +91,7 @@ def _mem_sizes(p):
             sum(b.n_long for b in m.buckets.values()), len(m.buckets)]
 
 
-@pytest.mark.parametrize('name', ['small_fifo', 'small_add_del', 'small_lt', 'small_interactive', 'small_flip', 'small_chunk', 'small_misc', 'small_clear', 'small_video', 'bike'])
+@pytest.mark.parametrize('name', ['small_fifo', 'small_add_del', 'small_lt', 'small_interactive', 'small_flip', 'small_chunk', 'small_misc', 'small_clear', 'small_video', 'small_lt_overlap', 'small_cfg_fifo', 'small_cfg_lt', 'bike'])
 def test_trajectory_matches_oracle_gpu(name, gpu_net, oracle_net):
     from cutie_amd.inference.inference_core import InferenceCore
     gold = np.load(S.GOLDEN_DIR + f'/{name}.npz')
@@ -113,9 +116,9 @@ def test_trajectory_matches_oracle_gpu(name, gpu_net, oracle_net):
         assert torch.isfinite(p).all()
         d = (p - o).abs()
         report.append((t, float(d.max()), float(d.mean())))
-        assert float(d.max()) < 0.15 and float(d.mean()) < 0.05, (name, report)
+        assert float(d.max()) < BMAX and float(d.mean()) < BMEAN, (name, report)
         top2 = o.topk(2, dim=0)[0]
-        confident = (top2[0] - top2[1]) > 0.30          # = 2 x the per-class bound 0.15: below it an argmax flip is within tolerance
+        confident = (top2[0] - top2[1]) > BMARGIN       # = 2 x the per-class bound: below it an argmax flip is within tolerance
         agree = (p.argmax(0) == o.argmax(0))
         assert bool(agree[confident].all()), (name, t, float(agree[confident].float().mean()))
         # object-id masks through the public API as well

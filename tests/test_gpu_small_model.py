@@ -1,6 +1,6 @@
 """cutie-small (cutie/config/model/small.yaml: ResNet-18 pixel encoder, multi-scale dims [256,128,64]) on the MI355X against the
-oracle, which is pinned to the executed reference for this variant too (tests/golden/model_small.npz).  Same tolerances as
-tests/test_gpu_parity.py.  (The file sorts after the base-model suites on purpose: it is the newest widening.)"""
+oracle, which is pinned to the executed reference for this variant too (tests/golden/model_small.npz).  Tolerances: the reference's own reduced-precision envelope for
+this variant (tests/golden/amp_envelope.json, see tests/test_gpu_parity.py).  (The file sorts after the base-model suites on purpose: it is the newest widening.)"""
 import pytest
 import torch
 
@@ -54,9 +54,10 @@ def test_small_model_on_gpu():
     for t, (p, o) in enumerate(zip(outs, oouts)):
         assert torch.isfinite(p).all()
         d = (p - o).abs()
-        assert float(d.max()) < 0.15 and float(d.mean()) < 0.05, (t, float(d.max()), float(d.mean()))
+        bmax, bmean, bmargin = S.trajectory_bounds('small')
+        assert float(d.max()) < bmax and float(d.mean()) < bmean, (t, float(d.max()), float(d.mean()))
         top2 = o.topk(2, dim=0)[0]
-        confident = (top2[0] - top2[1]) > 0.30
+        confident = (top2[0] - top2[1]) > bmargin
         assert bool((p.argmax(0) == o.argmax(0))[confident].all()), t
 
 
@@ -89,7 +90,8 @@ def test_random_scripts_on_gpu(seed, gpu_net, oracle_net):
     for t, (p, o) in enumerate(zip(outs, oouts)):
         assert torch.isfinite(p).all()
         d = (p - o).abs()
-        assert float(d.max()) < 0.15 and float(d.mean()) < 0.05, (seed, t, float(d.max()), float(d.mean()))
+        bmax, bmean, _ = S.trajectory_bounds('base')
+        assert float(d.max()) < bmax and float(d.mean()) < bmean, (seed, t, float(d.max()), float(d.mean()))
 
 
 class _CudaInputs:

@@ -1,0 +1,102 @@
+"""Teacher-forced per-frame parity on the MI355X (tests/teacher.py): before every frame the oracle's complete recurrent state is
+copied into the product, the product runs ONE ``step`` through the HIP path and is compared with the oracle's result for that
+frame -- at the small scenario sizes for both model variants, and at the BASELINE sizes (480p / 3 objects / long-term memory
+through the first consolidation; 1080p / 5 objects).
+
+Bound: the reference's OWN single-step reduced-precision deviation, measured by oracle/make_envelope.py (``one_step`` arm: a deep
+copy of the fp32 reference runs one step under bf16 / fp16 autocast from the fp32 state, at every frame of every scenario) and
+committed in tests/golden/amp_envelope.json, times the safety factor stored there (1.25).  Argmax object ids must be identical
+wherever the oracle's top-1 / top-2 margin exceeds twice the max bound.  Bank bookkeeping must be exact at every frame.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from cutie_amd import _lib
+from cutie_amd.config import default_config
+from oracle import scenarios as S
+from oracle.inference import OracleProcessor, DEFAULT_CFG
+from oracle.weights import MODEL_CFG_SMALL, make_state_dict
+import teacher
+
+pytestmark = pytest.mark.gpu
+BOUNDS = json.load(open(os.path.join(S.GOLDEN_DIR, 'amp_envelope.json')))['bounds']['one_step']
+
+
+def _nets(model):
+    from cutie_amd.model.cutie import CUTIE
+    from oracle.net import OracleNet
+    _lib.set_executor_for_testing(None)
+    if model == 'small':
+        sd = make_state_dict(seed=0, m=MODEL_CFG_SMALL)
+        return CUTIE(default_config(model='small')).cuda().eval(), OracleNet(sd, MODEL_CFG_SMALL), sd, (lambda over: default_config(model='small', **over))
+    sd = make_state_dict(seed=0)
+    return CUTIE(default_config()).cuda().eval(), OracleNet(sd), sd, (lambda over: default_config(**over))
+
+
+_cache = {}
+
+
+def nets(model):
+    if model not in _cache:
+        net, onet, sd, cfgs = _nets(model)
+        net.load_weights(sd)
+        _cache[model] = (net, onet, cfgs)
+    return _cache[model]
+
+
+def check_rows(rows, tag):
+    worst = max(rows, key=lambda r: r['max'])
+    print(tag, 'worst frame', worst['t'], 'max %.4f' % worst['max'], 'worst mean %.5f' % max(r['mean'] for r in rows),
+          'bound', BOUNDS['max'], BOUNDS['mean'], '| per frame:', [(r['t'], round(r['max'], 4), round(r['mean'], 5)) for r in rows])
+    for r in rows:
+        assert r['sizes_equal'], (tag, r['t'], 'memory-bank sizes differ')
+        assert r['max'] <= BOUNDS['max'] and r['mean'] <= BOUNDS['mean'], (tag, r)
+        if 'flips_above_margin' in r:
+            assert r['flips_above_margin'][BOUNDS['argmax_margin']] == 0, (tag, r)
+        if 'sensory_rel' in r:
+            assert r['sensory_rel'] < 8e-2, (tag, r)
+
+
+@pytest.mark.parametrize('model', ['base', 'small'])
+@pytest.mark.parametrize('name', ['small_fifo', 'small_lt', 'small_add_del', 'small_lt_overlap'])
+def test_teacher_forced_scenarios(name, model):
+    from cutie_amd.inference.inference_core import InferenceCore
+    net, onet, cfgs = nets(model)
+    over = S.SCENARIOS[name]['cfg']
+    steps, deletes = S.scenario_inputs(name)
+    rows = teacher.run_teacher_forced(steps, lambda: OracleProcessor(onet, dict(DEFAULT_CFG, **over)),
+                                      lambda: InferenceCore(net, cfg=cfgs(over)), 'cuda', deletes=deletes, margins=(BOUNDS['argmax_margin'],))
+    check_rows(rows, f'{model}:{name}')
+
+
+def _clip_steps(h, w, k, frames, seed=1):
+    from cutie_amd.utils.synth import SyntheticClip
+    clip = SyntheticClip(h, w, k, frames, seed=seed)
+    return [(clip.frame(0), clip.first_mask(), clip.objects)] + [(clip.frame(t), None, None) for t in range(1, frames)]
+
+
+def test_teacher_forced_480p_long_term():
+    """BASELINE C2 size: 854x480, 3 objects, long-term memory with the eval_config defaults, through frame 50: 1620-token memory
+    frames, the first consolidation (frame 45: 8100 candidates -> 128 prototypes) and reads from the long-term region, every
+    frame value-checked against the oracle from the oracle's state."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    net, onet, cfgs = nets('base')
+    over = dict(use_long_term=True)
+    rows = teacher.run_teacher_forced(_clip_steps(480, 854, 3, 51), lambda: OracleProcessor(onet, dict(DEFAULT_CFG, **over)),
+                                      lambda: InferenceCore(net, cfg=cfgs(over)), 'cuda', margins=(BOUNDS['argmax_margin'],))
+    assert len(rows) == 51
+    check_rows(rows, '480p K=3 LT')
+
+
+def test_teacher_forced_1080p():
+    """BASELINE C4 size: 1920x1080, 5 objects (8160 queries per frame), 7 frames incl. the second memory frame."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    net, onet, cfgs = nets('base')
+    rows = teacher.run_teacher_forced(_clip_steps(1080, 1920, 5, 7, seed=2), lambda: OracleProcessor(onet, dict(DEFAULT_CFG)),
+                                      lambda: InferenceCore(net, cfg=cfgs({})), 'cuda', margins=(BOUNDS['argmax_margin'],))
+    check_rows(rows, '1080p K=5')

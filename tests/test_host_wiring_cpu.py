@@ -104,7 +104,7 @@ def _run_product(net, name):
     return outs, sizes
 
 
-@pytest.mark.parametrize('name', ['small_fifo', 'small_add_del', 'small_lt', 'small_interactive', 'small_flip', 'small_chunk', 'small_misc', 'small_clear', 'small_video'])
+@pytest.mark.parametrize('name', ['small_fifo', 'small_add_del', 'small_lt', 'small_interactive', 'small_flip', 'small_chunk', 'small_misc', 'small_clear', 'small_video', 'small_lt_overlap', 'small_cfg_fifo', 'small_cfg_lt'])
 def test_trajectory_matches_oracle(name, product_net, oracle_net):
     gold = np.load(S.GOLDEN_DIR + f'/{name}.npz')
 
@@ -121,11 +121,12 @@ def test_trajectory_matches_oracle(name, product_net, oracle_net):
         assert p.shape == o.shape, (t, p.shape, o.shape)
         err = float((p - o).abs().max())
         worst = max(worst, err)
-        # bf16 activation storage, fp32 accumulation: max |dprob| < 0.15, mean |dprob| < 0.05, no growth over time
-        assert err < 0.15 and float((p - o).abs().mean()) < 0.05, (name, t, err, float((p - o).abs().mean()))
+        # bf16 activation storage, fp32 accumulation: within the reference's own reduced-precision envelope (S.trajectory_bounds)
+        bmax, bmean, bmargin = S.trajectory_bounds('base')
+        assert err < bmax and float((p - o).abs().mean()) < bmean, (name, t, err, float((p - o).abs().mean()))
         # argmax agreement wherever the oracle's top-1/top-2 margin exceeds the tolerance
         top2 = o.topk(2, dim=0)[0]
-        confident = (top2[0] - top2[1]) > 0.30          # = 2 x the per-class bound 0.15: below it an argmax flip is within tolerance
+        confident = (top2[0] - top2[1]) > bmargin       # = 2 x the per-class bound: below it an argmax flip is within tolerance
         assert bool((p.argmax(0) == o.argmax(0))[confident].all()), (name, t)
     print(name, 'worst prob err', worst)
 
@@ -245,7 +246,8 @@ def test_small_model_variant():
         worst = 0.0
         for t, (p, o) in enumerate(zip(outs, oouts)):
             err = float((p - o).abs().max())
-            assert err < 0.15 and float((p - o).abs().mean()) < 0.05, (t, err)
+            bmax, bmean, _ = S.trajectory_bounds('small')
+            assert err < bmax and float((p - o).abs().mean()) < bmean, (t, err)
             worst = max(worst, err)
         print('cutie-small worst prob err', worst)
     finally:

@@ -1,0 +1,124 @@
+"""Every conv of a 480p frame x every legal tile of every conv kernel (register-staged 0-44, buffer-load 50-56, LDS-DMA 60-69):
+isolated device time (hipEvents on the launch stream, min of REPS x ITERS launches).  Prints, per conv geometry, the best tile of
+each kernel family and writes the full table + the per-geometry winners (a tile table in the format of
+cutie_amd/tiles_gfx950.json) under gpurun_out/.  Run on the MI355X box:
+
+    python tools/conv_sweep.py [--objects 3] [--reps 3] [--iters 12] [--out gpurun_out/conv_sweep]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+
+
+def family(t, O):
+    if t in O.DMA_TILES:
+        return 'dma'
+    if t in O.EXPERIMENTAL_TILES:
+        return 'bufload'
+    if t in O.PATCH_TILES:
+        return 'patch'
+    return 'igemm'
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--objects', type=int, nargs='+', default=[3])
+    ap.add_argument('--reps', type=int, default=3)
+    ap.add_argument('--iters', type=int, default=12)
+    ap.add_argument('--height', type=int, default=480)
+    ap.add_argument('--width', type=int, default=854)
+    ap.add_argument('--out', default='gpurun_out/conv_sweep')
+    args = ap.parse_args()
+    os.environ.setdefault('CUTIE_AMD_EXPERIMENTAL_TILES', '1')
+    from bench import Recorder
+    from cutie_amd import _lib, ops as O
+    from cutie_amd.config import default_config
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.model.cutie import CUTIE
+    from cutie_amd.utils.synth import SyntheticClip
+    from cutie_amd.utils.synth_weights import make_state_dict
+    cfg = default_config(use_long_term=True)
+    net = CUTIE(cfg).cuda().eval()
+    net.load_weights(make_state_dict(0))
+    rec = Recorder(_lib.get_executor())
+    _lib.set_executor_for_testing(rec)
+    geoms = {}
+    with torch.inference_mode():
+        for K in args.objects:
+            clip = SyntheticClip(args.height, args.width, K, 16, seed=1)
+            proc = InferenceCore(net, cfg=cfg)
+            proc.step(clip.frame(0).cuda(), clip.first_mask().cuda(), objects=clip.objects)
+            for t in range(1, 4):
+                proc.step(clip.frame(t).cuda())
+            torch.cuda.synchronize()
+            rec.rec, rec.on = [], True
+            for t in range(4, 10):                       # covers a memory frame (mem_every = 5)
+                proc.step(clip.frame(t).cuda())
+            rec.on = False
+            torch.cuda.synchronize()
+            ops = np.concatenate(rec.rec)
+            for n in range(len(ops)):
+                if ops['kind'][n] != O.CONV:
+                    continue
+                i = ops['i'][n]
+                M, cout, cin = int(i[0]) * int(i[7]) * int(i[8]), int(i[9]), int(i[3]) + int(i[4])
+                key = (M, cout, cin, int(i[11]), int(i[13]), int(ops['flags'][n]) & 3, int(i[1]), int(i[2]))
+                if key not in geoms:
+                    geoms[key] = [ops[n:n + 1].copy(), 0]
+                geoms[key][1] += 1
+    rows, table = [], []
+    for key, (one, count) in geoms.items():
+        i = one['i'][0]
+        M, cout, cin, k = key[0], key[1], key[2], key[3]
+        cands = O.tile_candidates(M, cout, cin, int(i[16]), geom=dict(kh=k, stride=int(i[13]), pad=int(i[14]), W=int(i[2]), c2=int(i[4])))
+        if int(i[4]) or one['p'][0, 4]:
+            cands = [t for t in cands if t != O.COUT1_TILE]
+        res = {}
+        for t in cands:
+            for sk in O.splitk_candidates(M, cout, int(i[16]), t):
+                one['i'][0, 17], one['i'][0, 19] = t, sk
+                try:
+                    us = min(rec.ex.time_ops(one, args.iters) for _ in range(args.reps)) * 1e3
+                except RuntimeError as e:
+                    print('  tile', t, 'failed on', key, str(e)[:120])
+                    continue
+                res[(t, sk)] = us
+        fl = 2.0 * M * cout * k * k * int(i[18])
+        best = {}
+        for (t, sk), us in res.items():
+            f = family(t, O)
+            if f not in best or us < best[f][1]:
+                best[f] = ((t, sk), us)
+        (bt, bsk), bus = min(res.items(), key=lambda kv: kv[1])
+        table.append([list(key), [bt, bsk]])
+        rows.append(dict(key=list(key), count=count, gflop=fl / 1e9, best=[bt, bsk, bus],
+                         families={f: [v[0][0], v[0][1], v[1]] for f, v in best.items()},
+                         all={f'{t}x{sk}': us for (t, sk), us in res.items()}))
+    os.makedirs(os.path.dirname(args.out) or '.', exist_ok=True)
+    json.dump(rows, open(args.out + '.json', 'w'))
+    json.dump({'tiles': table}, open(args.out + '_tiles.json', 'w'))
+    fam = ['igemm', 'patch', 'bufload', 'dma']
+    tot = {f: 0.0 for f in fam + ['best', 'old']}
+    print(f'{"M":>6s} {"Cout":>5s} {"Cin":>5s} k s fl     HxW  n  GFLOP |' + ''.join(f' {f:>14s}' for f in fam) + ' |  best TFLOP/s')
+    for r in sorted(rows, key=lambda r: -r['best'][2] * r['count']):
+        key = r['key']
+        cells = ''
+        for f in fam:
+            v = r['families'].get(f)
+            cells += f' {v[0]:3d}x{v[1]:<2d} {v[2]:7.1f}' if v else ' ' * 15
+        old = min(v[2] for f, v in r['families'].items() if f in ('igemm', 'patch'))
+        tot['best'] += r['best'][2] * r['count']
+        tot['old'] += old * r['count']
+        print(f'{key[0]:6d} {key[1]:5d} {key[2]:5d} {key[3]} {key[4]} {key[5]} {key[6]:4d}x{key[7]:<4d} {r["count"]:2d} {r["gflop"]:6.2f} |{cells} | '
+              f'{r["best"][0]:3d} {r["gflop"] / r["best"][2] * 1e3:7.1f}')
+    print(f'sum over the recorded frames: best-of-all {tot["best"]:.1f} us, best of igemm/patch {tot["old"]:.1f} us '
+          f'({len(rows)} geometries, {sum(r["count"] for r in rows)} launches)')
+
+
+if __name__ == '__main__':
+    main()

@@ -19,6 +19,7 @@ cfg = default_config(use_long_term=True)
 net = CUTIE(cfg).cuda().eval()
 net.load_weights(make_state_dict(0))
 net.engine().tile_cache.clear()                          # re-time everything, ignore the packaged table
+net.engine().autotune = True
 with torch.inference_mode():
     for K in (3, 1, 2):
         clip = SyntheticClip(480, 854, K, 14, seed=K)
