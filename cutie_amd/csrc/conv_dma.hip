@@ -14,7 +14,7 @@
 //   * the halo needs no predicated pointer and no masking: a per-row bit mask over the filter taps is computed once and an
 //     invalid chunk is fetched at voffset 0x80000000 >= num_records, for which the buffer unit delivers zeros;
 //   * NS-deep LDS ring, loads of tile t+NS-1 in flight while tile t is multiplied, ONE barrier per K tile, counted vmcnt
-//     (raw s_barrier: __syncthreads() would drain the DMA queue);
+//     (raw s_barrier behind `s_waitcnt vmcnt(N) lgkmcnt(0)`: __syncthreads() would drain the DMA queue);
 //   * the fused input ReLU is applied to the pixel fragments after the LDS read (one v_pk_max_i16 per dword).
 // Steady-state loop of the 128x128 tile: 32 MFMA, 16 ds_read_b128, 8 LDS-DMA + 8 s_mov m0, ~12 VALU (3x3 halo select), ~10 SALU
 // per wave and K tile: ~1.5 non-MFMA per MFMA.
@@ -22,6 +22,7 @@
 // every operand < 2 GiB (32-bit buffer offsets).  GEMM view, fragment layout and epilogue are those of conv_igemm.hip:
 // D[cout][pixel], weights = MFMA A operand, a lane owns 4 consecutive output channels of one pixel.
 #include "conv_common.h"
+#include <stdlib.h>
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #define DMA_WORD3 0x00020000          // raw buffer descriptor, dword 3: DATA_FORMAT = 32 bit, no swizzle, no tid
@@ -29,10 +30,12 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #define DMA_OOB 0x80000000u           // any voffset >= DMA_RECORDS reads as zero
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 // s_waitcnt with only vmcnt counted (gfx9 encoding: vmcnt = simm16[3:0] | simm16[15:14] << 4, expcnt [6:4], lgkmcnt [11:8])
-#define WAIT_VMCNT(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (((N) >> 4) << 14) | (7 << 4) | (15 << 8))
-// Raw s_barrier (no vmcnt drain) fenced for the COMPILER only: no LDS read may sink below it (the next iteration's DMA of another
-// wave overwrites the stage just read) and no LDS-DMA / read may rise above it.
-#define TILE_BARRIER() { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+// ... and with lgkmcnt(0): this wave's LDS reads have RETURNED (what __syncthreads() waits for before its s_barrier, minus the
+// vmcnt(0) that would drain the DMA queue).  Needed before every barrier behind which another wave may overwrite what this wave
+// read: the next DMA into the stage just multiplied and, with no latency cushion at all, the epilogue's ds_write into the ring.
+#define WAIT_VMCNT_LDS(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (((N) >> 4) << 14) | (7 << 4) | (0 << 8))
+// Raw s_barrier (no vmcnt drain), fenced for the compiler: no LDS access or DMA may move across it.
+#define TILE_SYNC(N) { WAIT_VMCNT_LDS(N); asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 
 __device__ __forceinline__ rsrc_t dma_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, DMA_RECORDS, DMA_WORD3);
@@ -121,11 +124,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
     const int wdst = BM * 128 + wave * NWI * 1024;
 
     // ---- wave-uniform K-tile state (SGPRs): byte offsets of the current tap / channel tile, all advanced incrementally ----
-    int tap = 0, kw = 0;
-    int cc = 0;                                          // channel offset inside Cin (bytes)
-    int pixA = 0, pixB = 0;                              // byte offset of the current tap's pixel in source 1 / 2
-    unsigned wsoff = 0;
+    // Blocks start their K loop at different tiles (and wrap around): all blocks of a launch stream the SAME weight tiles, and
+    // started in lockstep they would ask the L2 for the same few lines at the same time.
     const int nk = p.Kslice / 64;
+    int kidx = p.kstag ? (int)(((unsigned)(blockIdx.y * gridDim.x + blockIdx.x) * (unsigned)p.kstag) % (unsigned)nk) : 0;
+    int tap = (kidx * 64) / p.Cin, kw = tap % p.KW;
+    int cc = (kidx * 64 - tap * p.Cin) * 2;              // channel offset inside Cin (bytes)
+    int pixA = ((tap / p.KW) * p.W + kw) * p.ldx1 * 2;   // byte offset of the current tap's pixel in source 1 / 2
+    int pixB = TWO ? ((tap / p.KW) * p.W + kw) * p.ldx2 * 2 : 0;
+    unsigned wsoff = (unsigned)kidx * 128u;
     const int cin2 = p.Cin * 2, c12 = p.C1 * 2;
     const int stepA1 = p.ldx1 * 2, stepA2 = (p.W - p.KW + 1) * p.ldx1 * 2;      // next tap in the row / first tap of the next row
     const int stepB1 = p.ldx2 * 2, stepB2 = (p.W - p.KW + 1) * p.ldx2 * 2;
@@ -158,6 +165,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
         kw = wrap2_ ? 0 : kw;                                                                              \
         pixA += wrap_ ? (wrap2_ ? stepA2 : stepA1) : 0;                                                    \
         if (TWO) pixB += wrap_ ? (wrap2_ ? stepB2 : stepB1) : 0;                                           \
+        const bool last_ = ++kidx == nk;                         /* staggered start: wrap around to tile 0 */ \
+        kidx = last_ ? 0 : kidx; wsoff = last_ ? 0u : wsoff; cc = last_ ? 0 : cc; tap = last_ ? 0 : tap;   \
+        kw = last_ ? 0 : kw; pixA = last_ ? 0 : pixA; pixB = last_ ? 0 : pixB;                             \
     }
 
     const int wm = wave / WN, wn = wave % WN;
@@ -200,22 +210,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) { LOAD_TILE(ld) ld += STAGE_B; }
-    if (nk >= NS - 1) { WAIT_VMCNT((NS - 2) * LPT); } else { WAIT_VMCNT(0); }
-    TILE_BARRIER()
+    if (nk >= NS - 1) { TILE_SYNC((NS - 2) * LPT) } else { TILE_SYNC(0) }
     int rd = 0;                                          // stage being multiplied
     int kt = 0;
     for (; kt < nk - (NS - 1); ++kt) {
         LOAD_TILE(ld)
         COMPUTE_TILE(rd)
-        WAIT_VMCNT((NS - 2) * LPT);
-        TILE_BARRIER()
+        TILE_SYNC((NS - 2) * LPT)
         ld = ld == (NS - 1) * STAGE_B ? 0 : ld + STAGE_B;
         rd = rd == (NS - 1) * STAGE_B ? 0 : rd + STAGE_B;
     }
     for (; kt < nk; ++kt) {                              // the last NS-1 tiles: nothing left to load
         COMPUTE_TILE(rd)
-        WAIT_VMCNT(0);
-        TILE_BARRIER()
+        TILE_SYNC(0)
         rd = rd == (NS - 1) * STAGE_B ? 0 : rd + STAGE_B;
     }
 #undef LOAD_TILE
@@ -274,6 +281,9 @@ static int launch_dma(ConvParams p, hipStream_t s) {
         return -2;
     }
     p.Kslice = p.KH * p.KW * p.Cin;                      // a multiple of 64: the zero-padded tail of Kpad is not visited
+    static int kstag_env = -1;                           // (experiment switch: CUTIE_DMA_KSTAG=0 disables the staggered K start)
+    if (kstag_env < 0) { const char* e = getenv("CUTIE_DMA_KSTAG"); kstag_env = e ? atoi(e) : 5; }
+    p.kstag = kstag_env;
     const bool relu = p.flags & CUTIE_F_RELU_IN, two = p.C2 != 0, halo = p.pad > 0;
     const int g = (int)gy;
 #define DMA_GO(H_, R_, T_) return launch_dma3<BM, BN, WM, WN, NS, H_, R_, T_>(p, s, g)
