@@ -10,16 +10,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even, NaN preserved (same rounding as torch's float->bfloat16)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// float -> bfloat16, round-to-nearest-even (the rounding of torch's .to(bfloat16)): the cast lowers to gfx950's
+// v_cvt_pk_bf16_f32 -- one instruction per PAIR, where the bit-twiddled form cost ~6 VALU per element in every epilogue
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
 __device__ __forceinline__ uint32_t pack_bf2(float a, float b) {
-    return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+    const bf16x2_t v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 // relu on two packed bf16: zero each half whose sign bit is set

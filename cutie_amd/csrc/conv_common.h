@@ -8,7 +8,6 @@ struct ConvParams {
     int B, H, W, C1, C2, ldx1, ldx2, OH, OW, Cout, ldy, KH, KW, stride, pad, ldr, Kpad;
     int flags, M, Cin, OHW;
     float* part; int splitk, ldp, Kslice;                // split-K: fp32 partial tiles [splitk][M][ldp]
-    int kstag;                                           // conv_dma: K-loop start stagger between blocks (0 = every block starts at tile 0)
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;

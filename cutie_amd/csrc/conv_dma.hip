@@ -15,27 +15,33 @@
 //     invalid chunk is fetched at voffset 0x80000000 >= num_records, for which the buffer unit delivers zeros;
 //   * NS-deep LDS ring, loads of tile t+NS-1 in flight while tile t is multiplied, ONE barrier per K tile, counted vmcnt
 //     (raw s_barrier behind `s_waitcnt vmcnt(N) lgkmcnt(0)`: __syncthreads() would drain the DMA queue);
-//   * the fused input ReLU is applied to the pixel fragments after the LDS read (one v_pk_max_i16 per dword).
-// Steady-state loop of the 128x128 tile: 32 MFMA, 16 ds_read_b128, 8 LDS-DMA + 8 s_mov m0, ~12 VALU (3x3 halo select), ~10 SALU
-// per wave and K tile: ~1.5 non-MFMA per MFMA.
-// Requirements (checked at launch): Cin % 64 == 0 (C1 % 64 == 0 as well for a two-source input), KH*KW <= 32, no split-K,
+//   * the DMA pieces of the next tile are issued BETWEEN the MFMAs of the current one (sched_group_barrier): a 64-lane 16-B
+//     DMA costs the issuing wave 60-180 cycles of address-pipeline time, which in front of the MFMAs was the longest single
+//     item of an iteration (measured round 2: 1600 cycles per K tile against 512 cycles of MFMA on the 128x128 tile);
+//   * the fused input ReLU is applied to the pixel fragments after the LDS read (one v_pk_max_i16 per dword);
+//   * prologue without per-tap loops or per-piece divisions, epilogue with the bias in registers and hardware bf16 packing:
+//     the fixed cost per block was 13-15 us on the 128x128 tile (40 of the 82 us of the 77760-pixel 3x3 layers).
+// Requirements (checked at launch): Cin % 64 == 0 (C1 % 64 == 0 as well for a two-source input), KH, KW <= 5, no split-K,
 // every operand < 2 GiB (32-bit buffer offsets).  GEMM view, fragment layout and epilogue are those of conv_igemm.hip:
 // D[cout][pixel], weights = MFMA A operand, a lane owns 4 consecutive output channels of one pixel.
 #include "conv_common.h"
-#include <stdlib.h>
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #define DMA_WORD3 0x00020000          // raw buffer descriptor, dword 3: DATA_FORMAT = 32 bit, no swizzle, no tid
 #define DMA_RECORDS 0x7fffffff        // bytes addressable through one descriptor
 #define DMA_OOB 0x80000000u           // any voffset >= DMA_RECORDS reads as zero
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-// s_waitcnt with only vmcnt counted (gfx9 encoding: vmcnt = simm16[3:0] | simm16[15:14] << 4, expcnt [6:4], lgkmcnt [11:8])
-// ... and with lgkmcnt(0): this wave's LDS reads have RETURNED (what __syncthreads() waits for before its s_barrier, minus the
-// vmcnt(0) that would drain the DMA queue).  Needed before every barrier behind which another wave may overwrite what this wave
-// read: the next DMA into the stage just multiplied and, with no latency cushion at all, the epilogue's ds_write into the ring.
+// s_waitcnt vmcnt(N) lgkmcnt(0) (gfx9 encoding: vmcnt = simm16[3:0] | simm16[15:14] << 4, expcnt [6:4], lgkmcnt [11:8]).
+// lgkmcnt(0): this wave's LDS reads have RETURNED (what __syncthreads() waits for before its s_barrier, minus the vmcnt(0) that
+// would drain the DMA queue).  Needed before every barrier behind which another wave may overwrite what this wave read: the next
+// DMA into the stage just multiplied and, with no latency cushion at all, the epilogue's ds_write into the ring.
 #define WAIT_VMCNT_LDS(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (((N) >> 4) << 14) | (7 << 4) | (0 << 8))
 // Raw s_barrier (no vmcnt drain), fenced for the compiler: no LDS access or DMA may move across it.
 #define TILE_SYNC(N) { WAIT_VMCNT_LDS(N); asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+// instruction classes of __builtin_amdgcn_sched_group_barrier
+#define SG_MFMA 0x8
+#define SG_VMEM 0x20
+#define SG_DSR 0x100
 
 __device__ __forceinline__ rsrc_t dma_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, DMA_RECORDS, DMA_WORD3);
@@ -52,7 +58,8 @@ constexpr int dma_lds_bytes() {
     return pipe > epi ? pipe : epi;
 }
 
-// HALO: some filter taps can fall outside the image (pad > 0); RELU: fused input ReLU; TWO: two-source (virtual concat) input.
+// HALO: the conv has more than one tap and / or padding (tap state + validity masks); RELU: fused input ReLU; TWO: two-source
+// (virtual concat) input.
 template <int BM, int BN, int WM, int WN, int NS, bool HALO, bool RELU, bool TWO>
 __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
 #if __HIP_DEVICE_COMPILE__     // (the host pass only needs the launch stub; the LDS-DMA builtin and the LDS address space exist on the device side)
@@ -61,11 +68,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
     constexpr int NWI = BN / 8 / NW;                    // W pieces per wave per K tile
     constexpr int LPT = NXI + NWI;                      // DMA instructions per wave per K tile
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int STAGE = (BM + BN) * CPR;              // 16-B units per ring stage
+    constexpr int STAGE_B = (BM + BN) * 128;            // bytes per ring stage
     constexpr int LDC = BN + 4;
-    static_assert(NXI >= 1 && NWI >= 1 && NXI * 8 * NW == BM && NWI * 8 * NW == BN && TM >= 1 && TN >= 1 && NS >= 2 && NS <= 4 && NXI <= 4 && NWI <= 4 &&
-                  (NS - 2) * LPT < 64, "bad tile");
+    static_assert(NXI >= 1 && NWI >= 1 && NXI * 8 * NW == BM && NWI * 8 * NW == BN && TM >= 1 && TN >= 1 && NS >= 2 && NS <= 4 &&
+                  NXI <= 4 && NWI <= 4 && (NS - 2) * LPT < 64 && NT % (BN / 8) == 0, "bad tile");
     extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // provably wave-uniform (LDS base of the DMA goes to M0)
@@ -78,6 +86,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
         m0 = mt * BM;
         n0 = (logical - mt * (int)gridDim.y) * BN;
     }
+    // ---- epilogue operands fetched up front (their latency hides behind the whole K loop): this thread's 8-channel column ----
+    constexpr int CH8 = BN / 8, PSTEP = NT / CH8;        // a thread keeps its channel chunk and walks down the pixels
+    const int ec8 = tid % CH8, epx0 = tid / CH8, ech0 = n0 + ec8 * 8;
+    float bias[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bias[r] = (p.bias && ech0 + r < p.Cout) ? p.bias[ech0 + r] : 0.f;
+
     // ---- loop-invariant per-lane state: byte offset of this lane's chunk in every piece, tap validity mask ----
     // The pieces of one operand share ONE M0 value per stage: piece i is issued with the instruction offset i * 1024, which the
     // hardware adds to the LDS address AND to the global address; the per-lane offset of piece i is lowered by the same amount
@@ -86,29 +101,37 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
     const int lr = lane >> 3;                            // row inside the piece
     const unsigned kcb = (unsigned)(((lane & 7) ^ lr) * 16);         // swizzled k-chunk (bytes): LDS slot lane & 7 holds chunk (lane & 7) ^ row
     unsigned xoff1[NXI], xoff2[NXI], vmask[NXI];
-#pragma unroll
-    for (int i = 0; i < NXI; ++i) {
-        const int m = m0 + (wave * NXI + i) * 8 + lr;
-        const bool valid = m < p.M;
-        const int mm = valid ? m : p.M - 1;              // rows past the end recompute the last pixel (never stored)
-        const int b = mm / p.OHW;
+    {
+        // (b, oh, ow) of the first piece's row by division, of the following pieces (+8 rows each) by carry
+        int m = m0 + wave * NXI * 8 + lr;
+        const int mm = m < p.M ? m : p.M - 1;            // rows past the end recompute the last pixel (never stored)
+        int b = mm / p.OHW;
         const int rem = mm - b * p.OHW;
-        const int oh = rem / p.OW;
-        const int ow = rem - oh * p.OW;
-        const int ih0 = oh * p.stride, iw0 = ow * p.stride;           // (the descriptors start at (-pad, -pad))
-        const unsigned pix = (unsigned)((b * p.H + ih0) * p.W + iw0);
-        xoff1[i] = pix * (unsigned)(p.ldx1 * 2) + kcb + PRE - (unsigned)i * 1024u;
-        xoff2[i] = TWO ? pix * (unsigned)(p.ldx2 * 2) + kcb + PRE - (unsigned)i * 1024u : 0u;
-        unsigned mk = 0;
-        if (HALO) {
-            int t = 0;
-            for (int kh = 0; kh < p.KH; ++kh)
-                for (int kw = 0; kw < p.KW; ++kw, ++t) {
-                    const int ih = ih0 - p.pad + kh, iw = iw0 - p.pad + kw;
-                    mk |= ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? (1u << t) : 0u;
+        int oh = rem / p.OW;
+        int ow = rem - oh * p.OW;
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+            const int ih0 = oh * p.stride, iw0 = ow * p.stride;       // (the descriptors start at (-pad, -pad))
+            const unsigned pix = (unsigned)((b * p.H + ih0) * p.W + iw0);
+            xoff1[i] = pix * (unsigned)(p.ldx1 * 2) + kcb + PRE - (unsigned)i * 1024u;
+            xoff2[i] = TWO ? pix * (unsigned)(p.ldx2 * 2) + kcb + PRE - (unsigned)i * 1024u : 0u;
+            unsigned mk = 0;
+            if (HALO) {
+                // valid taps = (valid rows) x (valid columns): KH + KW comparisons instead of KH * KW
+                unsigned cols = 0;
+                for (int k = 0; k < p.KW; ++k) cols |= ((unsigned)(iw0 - p.pad + k) < (unsigned)p.W) ? (1u << k) : 0u;
+                for (int k = 0; k < p.KH; ++k) mk |= ((unsigned)(ih0 - p.pad + k) < (unsigned)p.H) ? (cols << (k * p.KW)) : 0u;
+            }
+            vmask[i] = mk;
+            if (i + 1 < NXI) {                           // next piece: 8 rows further
+                m += 8;
+                if (m < p.M) {
+                    ow += 8;
+                    while (ow >= p.OW) { ow -= p.OW; ++oh; }
+                    while (oh >= p.OH) { oh -= p.OH; ++b; }
                 }
+            }
         }
-        vmask[i] = mk;
     }
     unsigned woff[NWI];
 #pragma unroll
@@ -118,26 +141,26 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
     const char* xb1 = reinterpret_cast<const char*>(p.x1 - shift * p.ldx1) - PRE;
     const char* xb2 = TWO ? reinterpret_cast<const char*>(p.x2 - shift * p.ldx2) - PRE : xb1;
     const rsrc_t rw = dma_rsrc(reinterpret_cast<const char*>(p.w) - PRE), rx1 = dma_rsrc(xb1), rx2 = dma_rsrc(xb2);
-    constexpr int STAGE_B = STAGE * 16;                              // bytes per ring stage
-    char* const lds = reinterpret_cast<char*>(smem);
     const int xdst = wave * NXI * 1024;                              // this wave's first X piece inside a stage (bytes)
     const int wdst = BM * 128 + wave * NWI * 1024;
 
     // ---- wave-uniform K-tile state (SGPRs): byte offsets of the current tap / channel tile, all advanced incrementally ----
-    // Blocks start their K loop at different tiles (and wrap around): all blocks of a launch stream the SAME weight tiles, and
-    // started in lockstep they would ask the L2 for the same few lines at the same time.
     const int nk = p.Kslice / 64;
-    int kidx = p.kstag ? (int)(((unsigned)(blockIdx.y * gridDim.x + blockIdx.x) * (unsigned)p.kstag) % (unsigned)nk) : 0;
-    int tap = (kidx * 64) / p.Cin, kw = tap % p.KW;
-    int cc = (kidx * 64 - tap * p.Cin) * 2;              // channel offset inside Cin (bytes)
-    int pixA = ((tap / p.KW) * p.W + kw) * p.ldx1 * 2;   // byte offset of the current tap's pixel in source 1 / 2
-    int pixB = TWO ? ((tap / p.KW) * p.W + kw) * p.ldx2 * 2 : 0;
-    unsigned wsoff = (unsigned)kidx * 128u;
+    int tap = 0, kw = 0;
+    int cc = 0;                                          // channel offset inside Cin (bytes)
+    int pixA = 0, pixB = 0;                              // byte offset of the current tap's pixel in source 1 / 2
+    unsigned wsoff = 0;
     const int cin2 = p.Cin * 2, c12 = p.C1 * 2;
     const int stepA1 = p.ldx1 * 2, stepA2 = (p.W - p.KW + 1) * p.ldx1 * 2;      // next tap in the row / first tap of the next row
     const int stepB1 = p.ldx2 * 2, stepB2 = (p.W - p.KW + 1) * p.ldx2 * 2;
 
-// (the instruction offset must be a literal: one macro expansion per piece)
+    // per-tile scalars of the tile about to be loaded; TILE_BEGIN computes them, XPIECE / WPIECE issue one DMA each (the
+    // instruction offset must be a literal: one macro expansion per piece), TILE_END advances the state
+#define TILE_BEGIN()                                                                                       \
+    const unsigned tapbit_ = 1u << tap;                                                                    \
+    const bool in1_ = !TWO || cc < c12;                          /* uniform: scalar selects, no branch */  \
+    const unsigned soff_ = (unsigned)(in1_ ? pixA + cc : pixB + cc - c12);                                 \
+    const rsrc_t rx_ = in1_ ? rx1 : rx2;
 #define XPIECE(I, LD)                                                                                      \
     if constexpr ((I) < NXI) {                                                                             \
         const unsigned v_ = in1_ ? xoff1[(I) < NXI ? (I) : 0] : xoff2[(I) < NXI ? (I) : 0];               \
@@ -147,37 +170,39 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
 #define WPIECE(I, LD)                                                                                      \
     if constexpr ((I) < NWI)                                                                               \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(lds + (LD) + wdst), 16, woff[(I) < NWI ? (I) : 0], wsoff, (I) * 1024, 0);
+#define TILE_END()                                                                                         \
+    {                                                                                                      \
+        wsoff += 128;                                                                                      \
+        cc += 128;                                               /* single tap, single source: soff = cc */ \
+        if (HALO || TWO) {                                                                                 \
+            const bool wrap_ = cc >= cin2;                                                                 \
+            cc = wrap_ ? 0 : cc;                                                                           \
+            if (HALO) {                                                                                    \
+                tap += wrap_ ? 1 : 0;                                                                      \
+                kw += wrap_ ? 1 : 0;                                                                       \
+                const bool wrap2_ = kw == p.KW;                                                            \
+                kw = wrap2_ ? 0 : kw;                                                                      \
+                pixA += wrap_ ? (wrap2_ ? stepA2 : stepA1) : 0;                                            \
+                if (TWO) pixB += wrap_ ? (wrap2_ ? stepB2 : stepB1) : 0;                                   \
+            }                                                                                              \
+        }                                                                                                  \
+    }
 #define LOAD_TILE(LD)                                                                                      \
     {                                                                                                      \
-        const unsigned tapbit_ = 1u << tap;                                                                \
-        const bool in1_ = !TWO || cc < c12;                      /* uniform: scalar selects, no branch */  \
-        const unsigned soff_ = (unsigned)(in1_ ? pixA + cc : pixB + cc - c12);                             \
-        const rsrc_t rx_ = in1_ ? rx1 : rx2;                                                               \
+        TILE_BEGIN()                                                                                       \
         XPIECE(0, LD) XPIECE(1, LD) XPIECE(2, LD) XPIECE(3, LD)                                            \
         WPIECE(0, LD) WPIECE(1, LD) WPIECE(2, LD) WPIECE(3, LD)                                            \
-        wsoff += 128;                                                                                      \
-        cc += 128;                                                                                         \
-        const bool wrap_ = cc >= cin2;                                                                     \
-        cc = wrap_ ? 0 : cc;                                                                               \
-        tap += wrap_ ? 1 : 0;                                                                              \
-        kw += wrap_ ? 1 : 0;                                                                               \
-        const bool wrap2_ = kw == p.KW;                                                                    \
-        kw = wrap2_ ? 0 : kw;                                                                              \
-        pixA += wrap_ ? (wrap2_ ? stepA2 : stepA1) : 0;                                                    \
-        if (TWO) pixB += wrap_ ? (wrap2_ ? stepB2 : stepB1) : 0;                                           \
-        const bool last_ = ++kidx == nk;                         /* staggered start: wrap around to tile 0 */ \
-        kidx = last_ ? 0 : kidx; wsoff = last_ ? 0u : wsoff; cc = last_ ? 0 : cc; tap = last_ ? 0 : tap;   \
-        kw = last_ ? 0 : kw; pixA = last_ ? 0 : pixA; pixB = last_ ? 0 : pixB;                             \
+        TILE_END()                                                                                         \
     }
 
     const int wm = wave / WN, wn = wave % WN;
     const int pm0 = wm * (BM / WM), cn0 = wn * (BN / WN);
     const int l15 = lane & 15, l4 = lane >> 4;
-    int rdx[2], rdw[2];                                              // fragment reads of the two k-steps (16-B units); tile row t adds t*16*CPR
+    int rdx[2], rdw[2];                                              // fragment reads of the two k-steps (bytes); tile row t adds t*16*128
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        rdx[j] = (pm0 + l15) * CPR + ((j * 4 + l4) ^ (l15 & 7));
-        rdw[j] = (BM + cn0 + l15) * CPR + ((j * 4 + l4) ^ (l15 & 7));
+        rdx[j] = ((pm0 + l15) * CPR + ((j * 4 + l4) ^ (l15 & 7))) * 16;
+        rdw[j] = ((BM + cn0 + l15) * CPR + ((j * 4 + l4) ^ (l15 & 7))) * 16;
     }
     f32x4 acc[TN][TM];
 #pragma unroll
@@ -185,27 +210,47 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#define COMPUTE_TILE(RD)                                                                                   \
+#define READ_FRAGS(J, RD, BFR, AFR)                                                                        \
+    _Pragma("unroll") for (int t = 0; t < TM; ++t) {                                                       \
+        u32x4 v = *reinterpret_cast<const u32x4*>(lds + (RD) + rdx[J] + t * 16 * 128);                     \
+        if (RELU) { v.x = relu2(v.x); v.y = relu2(v.y); v.z = relu2(v.z); v.w = relu2(v.w); }              \
+        BFR[t] = __builtin_bit_cast(bf16x8, v);                                                            \
+    }                                                                                                      \
+    _Pragma("unroll") for (int t = 0; t < TN; ++t) AFR[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + (RD) + rdw[J] + t * 16 * 128));
+#define MFMA_STEP(BFR, AFR)                                                                                \
+    _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                         \
+        _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                     \
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AFR[a], BFR[b], acc[a][b], 0, 0, 0);
+    // Scheduling of one iteration with a load: fragments of k-step 0, then LPT groups of { MF0 MFMAs of k-step 0, one DMA piece,
+    // RPP fragment reads of k-step 1 }, then the MFMAs of k-step 1.  (Program order of the memory operations is already this;
+    // the MFMAs, which the compiler may place anywhere, are pinned between them.)
+    constexpr int NMF = TM * TN, NRD = TM + TN;
+    constexpr int MF0 = NMF / LPT > 0 ? NMF / LPT : 1;  // MFMAs between two DMA pieces
+    constexpr int RPP = (NRD + LPT - 1) / LPT;          // fragment reads of k-step 1 per piece
+#define SCHED_GROUP(G)                                                                                     \
+    if constexpr ((G) < LPT) {                                                                             \
+        __builtin_amdgcn_sched_group_barrier(SG_MFMA, MF0, 0);                                             \
+        __builtin_amdgcn_sched_group_barrier(SG_VMEM, 1, 0);                                               \
+        __builtin_amdgcn_sched_group_barrier(SG_DSR, RPP, 0);                                              \
+    }
+#define COMPUTE_TILE(RD, LD, DO_LOAD)                                                                      \
     {                                                                                                      \
-        const u32x4* src_ = reinterpret_cast<const u32x4*>(lds + (RD));                                    \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
-            bf16x8 bfr[TM], afr[TN];                                                                       \
-            _Pragma("unroll") for (int t = 0; t < TM; ++t) {                                               \
-                u32x4 v = src_[rdx[j] + t * 16 * CPR];                                                     \
-                if (RELU) { v.x = relu2(v.x); v.y = relu2(v.y); v.z = relu2(v.z); v.w = relu2(v.w); }      \
-                bfr[t] = __builtin_bit_cast(bf16x8, v);                                                    \
-            }                                                                                              \
-            _Pragma("unroll") for (int t = 0; t < TN; ++t) afr[t] = __builtin_bit_cast(bf16x8, src_[rdw[j] + t * 16 * CPR]); \
-            _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                 \
-                _Pragma("unroll") for (int b = 0; b < TM; ++b)                                             \
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0); \
+        bf16x8 b0[TM], a0[TN], b1[TM], a1[TN];                                                             \
+        READ_FRAGS(0, RD, b0, a0)                                                                          \
+        if (DO_LOAD) LOAD_TILE(LD)                                                                         \
+        READ_FRAGS(1, RD, b1, a1)                                                                          \
+        MFMA_STEP(b0, a0)                                                                                  \
+        MFMA_STEP(b1, a1)                                                                                  \
+        if (DO_LOAD) {                                                                                     \
+            __builtin_amdgcn_sched_group_barrier(SG_DSR, NRD, 0);                                          \
+            SCHED_GROUP(0) SCHED_GROUP(1) SCHED_GROUP(2) SCHED_GROUP(3) SCHED_GROUP(4) SCHED_GROUP(5) SCHED_GROUP(6) SCHED_GROUP(7) \
         }                                                                                                  \
     }
 
     // ---- K loop (rolled; the ring stage offsets are wave-uniform run-time values).  Tile t lives in stage t % NS.
-    // Iteration t: issue the DMA of tile t+NS-1 (its stage was read in iteration t-1, which every wave has left through the
-    // barrier), multiply tile t, then wait until this wave's pieces of tile t+1 have landed (only the pieces of the NS-2 younger
-    // tiles may still be in flight) and meet the other waves. ----
+    // Iteration t: multiply tile t while issuing the DMA of tile t+NS-1 (its stage was read in iteration t-1, which every wave
+    // has left through the barrier), then wait until this wave's pieces of tile t+1 have landed (only the pieces of the NS-2
+    // younger tiles may still be in flight) and meet the other waves. ----
     int ld = 0;                                          // stage (byte offset) the next DMA goes to
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
@@ -214,23 +259,27 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
     int rd = 0;                                          // stage being multiplied
     int kt = 0;
     for (; kt < nk - (NS - 1); ++kt) {
-        LOAD_TILE(ld)
-        COMPUTE_TILE(rd)
+        COMPUTE_TILE(rd, ld, true)
         TILE_SYNC((NS - 2) * LPT)
         ld = ld == (NS - 1) * STAGE_B ? 0 : ld + STAGE_B;
         rd = rd == (NS - 1) * STAGE_B ? 0 : rd + STAGE_B;
     }
     for (; kt < nk; ++kt) {                              // the last NS-1 tiles: nothing left to load
-        COMPUTE_TILE(rd)
+        COMPUTE_TILE(rd, ld, false)
         TILE_SYNC(0)
         rd = rd == (NS - 1) * STAGE_B ? 0 : rd + STAGE_B;
     }
-#undef LOAD_TILE
-#undef XPIECE
-#undef WPIECE
 #undef COMPUTE_TILE
+#undef SCHED_GROUP
+#undef MFMA_STEP
+#undef READ_FRAGS
+#undef LOAD_TILE
+#undef TILE_END
+#undef WPIECE
+#undef XPIECE
+#undef TILE_BEGIN
 
-    // ---- epilogue: fp32 tile transposed through LDS, 16-B accesses along the channel axis (as conv_igemm_kernel) ----
+    // ---- epilogue: fp32 tile transposed through LDS, 16-B accesses along the channel axis; bias already in registers ----
     float* ctile = reinterpret_cast<float*>(smem);       // the loop ended with a barrier: the operand ring is dead
 #pragma unroll
     for (int b = 0; b < TM; ++b)
@@ -240,15 +289,49 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
             *reinterpret_cast<f32x4*>(ctile + px * LDC + ch) = acc[a][b];
         }
     __syncthreads();
-    constexpr int CH8 = BN / 8;
-    for (int q = tid; q < BM * CH8; q += NT) {
-        const int px = q / CH8, c8 = q - px * CH8;
-        const int m = m0 + px, ch0 = n0 + c8 * 8;
-        if (m >= p.M || ch0 >= p.Cout) continue;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(ctile + px * LDC + c8 * 8);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(ctile + px * LDC + c8 * 8 + 4);
-        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        conv_finish(p, v, m, ch0);
+    if (ech0 >= p.Cout) return;
+    const int act = (p.flags >> CUTIE_ACT_SHIFT) & 7;
+    const bool out_f32 = p.flags & CUTIE_F_OUT_F32, res_bcast = p.flags & CUTIE_F_RES_BCAST;
+    const bool fast = ech0 + 7 < p.Cout && (out_f32 ? (p.ldy & 3) == 0 : (p.ldy & 7) == 0) && (!p.res || (p.ldr & 7) == 0);
+    for (int px = epx0; px < BM; px += PSTEP) {
+        const int m = m0 + px;
+        if (m >= p.M) break;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(ctile + px * LDC + ec8 * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(ctile + px * LDC + ec8 * 8 + 4);
+        float v[8] = {lo[0] + bias[0], lo[1] + bias[1], lo[2] + bias[2], lo[3] + bias[3],
+                      hi[0] + bias[4], hi[1] + bias[5], hi[2] + bias[6], hi[3] + bias[7]};
+        if (!fast) {                                     // ragged channel tail / unaligned strides: the general tail (bias already added)
+            ConvParams q = p;
+            q.bias = nullptr;
+            conv_finish(q, v, m, ech0);
+            continue;
+        }
+        if (p.res) {
+            const int mres = res_bcast ? (m % p.OHW) : m;
+            const uint4 rr = *reinterpret_cast<const uint4*>(p.res + (long)mres * p.ldr + ech0);
+            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+            v[4] += __uint_as_float(rr.z << 16); v[5] += __uint_as_float(rr.z & 0xffff0000u);
+            v[6] += __uint_as_float(rr.w << 16); v[7] += __uint_as_float(rr.w & 0xffff0000u);
+        }
+        if (act == CUTIE_ACT_RELU) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+        } else if (act == CUTIE_ACT_SIGMOID) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = sigmoidf_(v[r]);
+        } else if (act == CUTIE_ACT_SQ1) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = v[r] * v[r] + 1.f;
+        }
+        if (out_f32) {
+            float* yp = reinterpret_cast<float*>(p.y) + (long)m * p.ldy + ech0;
+            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + (long)m * p.ldy + ech0;
+            *reinterpret_cast<uint4*>(yp) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+        }
     }
 #endif
 }
@@ -274,17 +357,14 @@ template <int BM, int BN, int WM, int WN, int NS>
 static int launch_dma(ConvParams p, hipStream_t s) {
     const long x1_bytes = (long)p.B * p.H * p.W * p.ldx1 * 2, x2_bytes = p.C2 ? (long)p.B * p.H * p.W * p.ldx2 * 2 : 0;
     const long gy = (p.Cout + BN - 1) / BN, w_bytes = gy * BN * (long)p.Kpad * 2;
-    if (p.Kpad % 64 || p.Cin % 64 || (p.C2 && p.C1 % 64) || p.KH * p.KW > 32 || p.splitk != 1 || p.Kpad < p.KH * p.KW * p.Cin ||
+    if (p.Kpad % 64 || p.Cin % 64 || (p.C2 && p.C1 % 64) || p.KH > 5 || p.KW > 5 || p.splitk != 1 || p.Kpad < p.KH * p.KW * p.Cin ||
         x1_bytes >= DMA_RECORDS - 8192 || x2_bytes >= DMA_RECORDS - 8192 || w_bytes >= DMA_RECORDS - 8192) {
-        cutie_set_error("conv DMA tile: needs Cin %% 64 == 0 (C1 too for two sources), KH*KW <= 32, no split-K, operands < 2 GiB "
+        cutie_set_error("conv DMA tile: needs Cin %% 64 == 0 (C1 too for two sources), KH, KW <= 5, no split-K, operands < 2 GiB "
                         "(Cin=%d C1=%d Kpad=%d k=%dx%d splitk=%d)", p.Cin, p.C1, p.Kpad, p.KH, p.KW, p.splitk);
         return -2;
     }
     p.Kslice = p.KH * p.KW * p.Cin;                      // a multiple of 64: the zero-padded tail of Kpad is not visited
-    static int kstag_env = -1;                           // (experiment switch: CUTIE_DMA_KSTAG=0 disables the staggered K start)
-    if (kstag_env < 0) { const char* e = getenv("CUTIE_DMA_KSTAG"); kstag_env = e ? atoi(e) : 5; }
-    p.kstag = kstag_env;
-    const bool relu = p.flags & CUTIE_F_RELU_IN, two = p.C2 != 0, halo = p.pad > 0;
+    const bool relu = p.flags & CUTIE_F_RELU_IN, two = p.C2 != 0, halo = p.pad > 0 || p.KH * p.KW > 1;
     const int g = (int)gy;
 #define DMA_GO(H_, R_, T_) return launch_dma3<BM, BN, WM, WN, NS, H_, R_, T_>(p, s, g)
     if (halo) {
@@ -311,6 +391,9 @@ int launch_conv_dma(const ConvParams& p, int tile, hipStream_t s) {
         case 67: return launch_dma<32, 64, 1, 4, 4>(p, s);           // 48 KB
         case 68: return launch_dma<256, 128, 4, 2, 3>(p, s);         // 8 waves, 64x64 per wave, 144 KB
         case 69: return launch_dma<32, 128, 1, 4, 4>(p, s);
+        case 70: return launch_dma<128, 128, 2, 4, 2>(p, s);         // 8 waves, 2-deep ring: 2 blocks = 16 waves per CU
+        case 71: return launch_dma<128, 64, 2, 2, 2>(p, s);          // 48 KB: 3 blocks per CU
+        case 72: return launch_dma<64, 64, 2, 2, 2>(p, s);           // 32 KB: 5 blocks per CU
         default: cutie_set_error("conv: bad DMA tile id %d", tile); return -2;
     }
 }

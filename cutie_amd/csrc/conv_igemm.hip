@@ -584,7 +584,6 @@ int launch_conv(const cutie_op* op, hipStream_t s) {
     p.flags = op->flags; p.OHW = p.OH * p.OW; p.M = p.B * p.OHW; p.Cin = p.C1 + p.C2;
     p.splitk = i[19] > 1 ? i[19] : 1; p.part = (float*)op->p[6];
     p.ldp = (p.Cout + 7) & ~7;
-    p.kstag = 0;
     if (p.splitk > 1 && (!p.part || (long)p.splitk * p.M * p.ldp > (long)i[20] * 1024)) {
         cutie_set_error("conv: split-K %d needs the fp32 partial scratch (p6, capacity i20 KiB-floats)", p.splitk);
         return -2;

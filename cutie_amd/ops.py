@@ -55,7 +55,8 @@ EXPERIMENTAL_TILES = {50: (128, 64, 64), 51: (64, 64, 64), 52: (64, 128, 64), 53
 # 60+: LDS-DMA kernel (conv_dma.hip): operands global -> LDS by buffer_load ... lds, rolled K loop with ~2-4 non-MFMA
 # instructions per MFMA.  id -> (BM, BN, BK); needs Cin % 64 == 0 (both sources of a virtual concat), no split-K.
 DMA_TILES = {60: (128, 128, 64), 61: (128, 128, 64), 62: (128, 128, 64), 63: (128, 64, 64), 64: (64, 128, 64), 65: (64, 64, 64),
-             66: (64, 64, 64), 67: (32, 64, 64), 68: (256, 128, 64), 69: (32, 128, 64)}
+             66: (64, 64, 64), 67: (32, 64, 64), 68: (256, 128, 64), 69: (32, 128, 64), 70: (128, 128, 64), 71: (128, 64, 64),
+             72: (64, 64, 64)}
 
 
 ALL_TILES = {**TILES, **DMA_TILES}
