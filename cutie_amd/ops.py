@@ -179,7 +179,7 @@ def pick_tile(M, cout, cin=64, geom=None):
     if cout <= 16:
         return 3
     if geom is not None and dma_tiles_enabled() and dma_tile_ok(60, cin=cin, kh=geom['kh'], c2=geom.get('c2', 0)):
-        cands = [60, 63, 64, 66, 67]
+        cands = [61, 71, 66, 67]
     else:
         cands = [6, 5, 9] if cin >= 32 else [4, 2]
     if cout <= 64:
