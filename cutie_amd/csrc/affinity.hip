@@ -77,13 +77,20 @@ typedef __attribute__((ext_vector_type(4))) unsigned int au32x4;
 #define AFF_LCAP 1024                                 // LDS candidate list entries per block ...
 #define AFF_WCAP (AFF_LCAP / 4)                       // ... = 4 wave-private lists (overflow -> direct global append)
 #define AFF_LDS_BYTES (2 * 2 * 64 * 16 * 16 + AFF_LCAP * 12 + 16 + 2 * 64 * 4)
-// AFF_MODE: -1 = the pass is read from p.mode at run time (the default kernels: one binary serves both passes);
-// 0 / 1 = EXPERIMENTAL compile-time pass (opt-in: CUTIE_AMD_EXPERIMENTAL_AFF=1 in the environment of the process): the
-// max-only pass then carries neither the candidate-list code nor its registers.  Not yet run on a GPU (added after the last
-// GPU minute of round 1, like conv_bufload.hip); the default instantiations compile to the same ISA as before.
-template <int AFF_NQ, int AFF_MODE = -1>              // 16-query column sets per wave (1 or 2)
+#undef AFF_LDS_BYTES
+#define AFF_LDS_BYTES (2 * 2 * 64 * 16 * 16 + AFF_LCAP * 12 + 16 + 2 * 2 * 64 * 4)
+// AFF_MODE (compile-time pass): 0 = per-(tile, query) maxima, 1 = candidate lists.  The max-only pass carries neither the
+// candidate-list code nor its registers (6 instead of 22 non-MFMA instructions per MFMA).
+// Round-2 changes, all from the instruction mix (the loop was SALU / VALU-bound, not MFMA-bound):
+//   * a wave stages ONE tile of the 4-tile group (16 rows x [hi|lo] x 256 B), so the token-range arithmetic (which of the <= 3
+//     slot ranges a tile lies in) is wave-uniform: once per wave and group in SGPRs instead of 5 times per thread in VGPRs;
+//   * -c_j is the accumulator's initial value and the padding rows carry an additive -inf next to a zero scale, so a score costs
+//     one v_fma (was: compare, subtract, multiply, select);
+//   * pass 1 skips every (16-token tile, 16-query set) whose pass-0 maximum is below the set's thresholds (flags & 1: the gmax
+//     matrix of pass 0 precedes tau in memory): ~85 % of the MFMA work of the second pass.
+template <int AFF_NQ, int AFF_MODE>                   // 16-query column sets per wave (1 or 2)
 __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
-    const int mode = AFF_MODE < 0 ? p.mode : AFF_MODE;
+    constexpr int mode = AFF_MODE;
     extern __shared__ __attribute__((aligned(16))) unsigned char aff_smem[];
     au32x4 (*lds)[2 * 64 * 16] = reinterpret_cast<au32x4 (*)[2 * 64 * 16]>(aff_smem);   // [buffer][hi/lo][row][16 chunks]
     int* l_j = reinterpret_cast<int*>(aff_smem + 2 * 2 * 64 * 16 * 16);
@@ -91,7 +98,9 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
     float* l_val = reinterpret_cast<float*>(l_idx + AFF_LCAP);
     int* l_n = reinterpret_cast<int*>(l_val + AFF_LCAP);
     float (*lsc)[64] = reinterpret_cast<float (*)[64]>(l_n + 4);        // [buffer][row of the group]: scale_i (0 for padding rows)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    float (*lpad)[64] = lsc + 2;                                        // [buffer][row]: 0, or -inf for padding rows
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware mapping (see conv_igemm.hip): consecutive logical blocks share the token chunk (query block fastest)
     int bx, by;
     {
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
     int wcount = 0;                                                     // wave-uniform fill of the wave's list
     int jq[AFF_NQ];                                                     // query column of this lane, per set
     bool jvalid[AFF_NQ];
-    float cj[AFF_NQ], thr[AFF_NQ];
+    float ncj[AFF_NQ], thr[AFF_NQ];
     bf16x8 bh[AFF_NQ][4], bl[AFF_NQ][4];
     // The block's query operand (64*AFF_NQ rows x [hi|lo] x 256 B) is one contiguous run per array: copy it through LDS
     // with whole-line loads (fragment-shaped global loads touch 16 half-used lines per instruction and were most of this
@@ -140,61 +149,73 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
         }
         __syncthreads();                                                // the A staging below overwrites this area
     }
+    const bool skip = mode == 1 && (p.mode & 2);                        // pass-0 maxima available: skip tiles without candidates
+    const float* tau_p = p.gmax_or_tau;
+    const float* gmax_p = p.gmax_or_tau - (long)p.HWp * p.Gld;
 #pragma unroll
     for (int u = 0; u < AFF_NQ; ++u) {
         jq[u] = bx * (64 * AFF_NQ) + wave * (16 * AFF_NQ) + u * 16 + l15;
         jvalid[u] = jq[u] < p.HW;
-        cj[u] = jvalid[u] ? p.c[jq[u]] : 0.f;
+        ncj[u] = jvalid[u] ? -p.c[jq[u]] : 0.f;
         thr[u] = INFINITY;
         if (mode == 1 && jvalid[u]) {
-            float tau = p.gmax_or_tau[jq[u]];
+            float tau = tau_p[jq[u]];
             thr[u] = tau - fabsf(tau) * 1e-6f - 1e-30f;                 // never lose the k-th element to 1 ulp
         }
     }
     const int g0 = by * p.tiles_per_block;
     const int g1 = min(g0 + p.tiles_per_block, p.G);
     const int T0 = (p.rn[0] + 15) >> 4, T1 = (p.nranges > 1) ? ((p.rn[1] + 15) >> 4) : 0;
-    // this thread stages chunk (row = tid >> 2 .. , 4 chunks) : 64 rows x 16 chunks x 2 arrays = 2048 chunks / 256 threads = 8
-    const int srow = tid >> 4, sch = tid & 15;                         // rows srow + 16c (c = 0..3 = the group's 4 tiles), chunk sch: whole 256-B rows per wave
+    // staging: wave w stages tile w of the group; thread = (row r, quarter qd of the 256-B row): 4 + 4 chunks of 16 B
+    const int sr = (lane >> 2), qd = lane & 3;
     au32x4 st[8];
-    float st_sc = 0.f;
-    auto tile_slot = [&](int g, int& start, int& n, int& lt) {
-        // (selects, not p.rs[r]: dynamic indexing of the kernel-argument arrays costs scalar memory loads per tile)
+    float st_sc = 0.f, st_pad = 0.f;
+    f32x4 gq[AFF_NQ];                                                   // pass-0 maxima of the NEXT group's 4 tiles (mode 1 + skip)
+#pragma unroll
+    for (int u = 0; u < AFF_NQ; ++u) gq[u] = (f32x4){INFINITY, INFINITY, INFINITY, INFINITY};
+    // token slot of the first row / number of valid rows of tile g (wave-uniform)
+    auto tile_slot = [&](int g, int& slot0, int& nvalid) {
+        int start, n, lt;
         if (g < T0) { lt = g; start = p.rs[0]; n = p.rn[0]; }
         else if (g < T0 + T1) { lt = g - T0; start = p.rs[1]; n = p.rn[1]; }
         else { lt = g - T0 - T1; start = p.rs[2]; n = p.rn[2]; }
+        slot0 = start + lt * 16;
+        nvalid = min(16, n - lt * 16);
     };
 #define AFF_LOAD(GRP)                                                                                      \
     {                                                                                                      \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                    \
-            int gt = (GRP) + c;                                /* tile of staging row srow + 16c */        \
-            gt = gt < g1 ? gt : g1 - 1;                        /* clamp: rows of missing tiles are never used */ \
-            int start_, n_, lt_;                                                                           \
-            tile_slot(gt, start_, n_, lt_);                                                                \
-            const long off_ = (long)(start_ + lt_ * 16 + srow) * 128 + sch * 8;                            \
-            st[c] = *reinterpret_cast<const au32x4*>(p.Ahi + off_);                                        \
-            st[4 + c] = *reinterpret_cast<const au32x4*>(p.Alo + off_);                                    \
+        int gt_ = (GRP) + wave;                                /* this wave's tile of the group */         \
+        gt_ = gt_ < g1 ? gt_ : g1 - 1;                         /* clamp: rows of missing tiles are never used */ \
+        int slot0_, nv_;                                                                                   \
+        tile_slot(gt_, slot0_, nv_);                                                                       \
+        const bool rv_ = sr < nv_;                                                                         \
+        const long off_ = (long)(slot0_ + (rv_ ? sr : nv_ - 1)) * 128 + qd * 32;                           \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
+            st[e] = *reinterpret_cast<const au32x4*>(p.Ahi + off_ + e * 8);                                \
+            st[4 + e] = *reinterpret_cast<const au32x4*>(p.Alo + off_ + e * 8);                            \
         }                                                                                                  \
-        /* the per-token scale rides along (threads 0..63 = the group's 64 rows): a global load inside the MFMA loop */ \
-        /* would make every tile wait for this whole prefetch (vmcnt is in-order) */                      \
-        int gs_ = (GRP) + ((tid & 63) >> 4);                                                               \
-        gs_ = gs_ < g1 ? gs_ : g1 - 1;                                                                     \
-        int s2_, n2_, lt2_;                                                                                \
-        tile_slot(gs_, s2_, n2_, lt2_);                                                                    \
-        const int loc_ = lt2_ * 16 + (tid & 15);                                                           \
-        const float sv_ = p.scale[s2_ + (loc_ < n2_ ? loc_ : n2_ - 1)];                                    \
-        st_sc = loc_ < n2_ ? sv_ : 0.f;                                                                    \
+        /* the per-token scale rides along: a global load inside the MFMA loop would make every tile wait for this whole */ \
+        /* prefetch (vmcnt is in-order) */                                                                 \
+        st_sc = rv_ ? p.scale[slot0_ + (rv_ ? sr : 0)] : 0.f;                                              \
+        st_pad = rv_ ? 0.f : -INFINITY;                                                                    \
+        if (skip) {                                                                                        \
+            _Pragma("unroll") for (int u = 0; u < AFF_NQ; ++u)                                             \
+                gq[u] = *reinterpret_cast<const f32x4*>(gmax_p + (long)min(jq[u], p.HWp - 1) * p.Gld + (GRP)); \
+        }                                                                                                  \
     }
 #define AFF_STORE(BUF)                                                                                     \
     {                                                                                                      \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                    \
-            const int row_ = srow + 16 * c;                                                                \
-            lds[BUF][row_ * 16 + (sch ^ srow)] = st[c];                                                    \
-            lds[BUF][1024 + row_ * 16 + (sch ^ srow)] = st[4 + c];                                         \
+        const int row_ = wave * 16 + sr;                                                                   \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
+            lds[BUF][row_ * 16 + ((qd * 4 + e) ^ sr)] = st[e];                                             \
+            lds[BUF][1024 + row_ * 16 + ((qd * 4 + e) ^ sr)] = st[4 + e];                                  \
         }                                                                                                  \
-        if (tid < 64) lsc[BUF][tid] = st_sc;                                                               \
+        if (qd == 0) { lsc[BUF][row_] = st_sc; lpad[BUF][row_] = st_pad; }                                 \
     }
+    f32x4 gcur[AFF_NQ];
     AFF_LOAD(g0);
+#pragma unroll
+    for (int u = 0; u < AFF_NQ; ++u) gcur[u] = gq[u];
     AFF_STORE(0);
     __syncthreads();
     int buf = 0;
@@ -208,54 +229,62 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
             for (int u = 0; u < AFF_NQ; ++u) gm[u][t] = -INFINITY;
             const int g = gg + t;
             if (g < g1) {                                               // block-uniform
-                int start, n, lt;
-                tile_slot(g, start, n, lt);
-                const int row = t * 16 + l15;
-                bf16x8 ah[4], al[4];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    ah[ks] = __builtin_bit_cast(bf16x8, lds[buf][row * 16 + ((ks * 4 + l4) ^ l15)]);
-                    al[ks] = __builtin_bit_cast(bf16x8, lds[buf][1024 + row * 16 + ((ks * 4 + l4) ^ l15)]);
-                }
-                // lane holds tokens lt*16 + l4*4 + q (q = 0..3) of its query
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(&lsc[buf][t * 16 + l4 * 4]);
+                bool need[AFF_NQ];
+                bool any = false;
 #pragma unroll
                 for (int u = 0; u < AFF_NQ; ++u) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    need[u] = !skip || __ballot(jvalid[u] && gcur[u][t] >= thr[u]) != 0;      // wave-uniform
+                    any |= need[u];
+                }
+                if (any) {
+                    int slot0, nvalid;
+                    if (mode == 1) tile_slot(g, slot0, nvalid);
+                    const int row = t * 16 + l15;
+                    bf16x8 ah[4], al[4];
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {                    // small cross terms first
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bl[u][ks], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], bh[u][ks], acc, 0, 0, 0);
+                    for (int ks = 0; ks < 4; ++ks) {
+                        ah[ks] = __builtin_bit_cast(bf16x8, lds[buf][row * 16 + ((ks * 4 + l4) ^ l15)]);
+                        al[ks] = __builtin_bit_cast(bf16x8, lds[buf][1024 + row * 16 + ((ks * 4 + l4) ^ l15)]);
                     }
+                    // lane holds tokens l4*4 + q (q = 0..3) of the tile for its query
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(&lsc[buf][t * 16 + l4 * 4]);
+                    const f32x4 pd = *reinterpret_cast<const f32x4*>(&lpad[buf][t * 16 + l4 * 4]);
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bh[u][ks], acc, 0, 0, 0);
-                    float s[4], mx = -INFINITY;
+                    for (int u = 0; u < AFF_NQ; ++u) {
+                        if (!need[u]) continue;
+                        f32x4 acc = {ncj[u], ncj[u], ncj[u], ncj[u]};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const bool valid = lt * 16 + l4 * 4 + q < n;
-                        s[q] = valid ? sc[q] * (acc[q] - cj[u]) : -INFINITY;
-                        mx = fmaxf(mx, s[q]);
-                    }
-                    if (mode == 0) {
-                        gm[u][t] = rows_max(mx);
-                    } else if (__ballot(jvalid[u] && mx >= thr[u])) {   // wave-uniform: some lane has a candidate in this tile
+                        for (int ks = 0; ks < 4; ++ks) {                // small cross terms first
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bl[u][ks], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], bh[u][ks], acc, 0, 0, 0);
+                        }
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const bool hit = jvalid[u] && s[q] >= thr[u] && s[q] > -INFINITY;
-                            const unsigned long long m = __ballot(hit);
-                            if (m) {
-                                // the wave owns its queries: positions come from a wave-private counter + lane prefix
-                                // (mbcnt), no atomics and no waits inside the MFMA loop
-                                const int pos = wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                                if (hit) {
-                                    const int tok = start + lt * 16 + l4 * 4 + q;
-                                    if (pos < AFF_WCAP) { wl_j[pos] = jq[u]; wl_idx[pos] = tok; wl_val[pos] = s[q]; }
-                                    else {                              // wave list full: straight to the global list
-                                        const int gp = atomicAdd(&p.count[jq[u] * AFF_CSTRIDE], 1);
-                                        if (gp < p.cap) { p.cand_val[(long)jq[u] * p.cap + gp] = s[q]; p.cand_idx[(long)jq[u] * p.cap + gp] = tok; }
+                        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bh[u][ks], acc, 0, 0, 0);
+                        float s[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) s[q] = fmaf(sc[q], acc[q], pd[q]);          // scale_i (A.B - c_j), -inf on padding rows
+                        const float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+                        if (mode == 0) {
+                            gm[u][t] = rows_max(mx);
+                        } else if (__ballot(jvalid[u] && mx >= thr[u])) {   // wave-uniform: some lane has a candidate in this tile
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const bool hit = jvalid[u] && s[q] >= thr[u] && s[q] > -INFINITY;
+                                const unsigned long long m = __ballot(hit);
+                                if (m) {
+                                    // the wave owns its queries: positions come from a wave-private counter + lane prefix
+                                    // (mbcnt), no atomics and no waits inside the MFMA loop
+                                    const int pos = wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                    if (hit) {
+                                        const int tok = slot0 + l4 * 4 + q;
+                                        if (pos < AFF_WCAP) { wl_j[pos] = jq[u]; wl_idx[pos] = tok; wl_val[pos] = s[q]; }
+                                        else {                              // wave list full: straight to the global list
+                                            const int gp = atomicAdd(&p.count[jq[u] * AFF_CSTRIDE], 1);
+                                            if (gp < p.cap) { p.cand_val[(long)jq[u] * p.cap + gp] = s[q]; p.cand_idx[(long)jq[u] * p.cap + gp] = tok; }
+                                        }
                                     }
+                                    wcount += __popcll(m);
                                 }
-                                wcount += __popcll(m);
                             }
                         }
                     }
@@ -268,10 +297,16 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
                 if (jq[u] < p.HWp)
                     *reinterpret_cast<f32x4*>(p.gmax_or_tau + (long)jq[u] * p.Gld + gg) = (f32x4){gm[u][0], gm[u][1], gm[u][2], gm[u][3]};
         }
-        if (more) AFF_STORE(buf ^ 1);
+        if (more) {
+            AFF_STORE(buf ^ 1);
+#pragma unroll
+            for (int u = 0; u < AFF_NQ; ++u) gcur[u] = gq[u];
+        }
         __syncthreads();
         buf ^= 1;
     }
+#undef AFF_LOAD
+#undef AFF_STORE
     if (mode == 1) {                                                    // flush this wave's candidates: one dense burst of global atomics
         const int n = min(wcount, AFF_WCAP);
         for (int e = lane; e < n; e += 64) {
@@ -289,6 +324,34 @@ __device__ __forceinline__ uint32_t f2key(float f) {
 __device__ __forceinline__ float key2f(uint32_t k) {
     uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
     return __uint_as_float(u);
+}
+
+// One wave per query column, 4 waves per block: exact k-th largest tile maximum, all in registers.  The G maxima of the column sit
+// MAXV per lane as order-preserving 32-bit keys; the answer is built bit by bit from the top (x |= bit while count(key >= x) >= k):
+// per step one v_cmp + s_bcnt1 + s_add per register -- no LDS, no atomics (the 4 x 8-bit histogram version below, kept for
+// G > 4096, needed 11 us for 1620 columns of 667 values; this one ~3 us).
+template <int MAXV>
+__global__ __launch_bounds__(256) void aff_select_reg_kernel(const float* __restrict__ gmax, float* __restrict__ tau,
+                                                             int HW, int Gld, int G, int k) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + wave;
+    if (j >= HW) return;                                    // whole wave exits together
+    if (G < k) { if (lane == 0) tau[j] = -INFINITY; return; }
+    uint32_t key[MAXV];
+#pragma unroll
+    for (int r = 0; r < MAXV; ++r) {
+        const int g = r * 64 + lane;
+        key[r] = g < G ? f2key(gmax[(long)j * Gld + g]) : 0u;            // padding sorts below every real value (-inf -> 0x007fffff)
+    }
+    uint32_t x = 0;
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t t = x | (1u << b);
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < MAXV; ++r) cnt += __popcll(__ballot(key[r] >= t));
+        x = cnt >= k ? t : x;                                // wave-uniform
+    }
+    if (lane == 0) tau[j] = key2f(x);
 }
 
 // one wave per query column; 4 waves per block.  Exact k-th largest by 4x8-bit radix select.
@@ -401,36 +464,33 @@ __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __
     if (tid < 64) {                                            // softmax over the selected scores (wave 0)
         float e = (tid < nsel && sel_v[tid] > -INFINITY) ? expf(sel_v[tid] - sel_v[0]) : 0.f;   // unassigned rank (duplicate entries): weight 0
         float sum = wave_sum(e);
-        if (tid < nsel) {
-            float w = e / sum;
-            sel_w[tid] = w;
-            if (usage) atomicAdd(&usage[sel_i[tid]], w);
-        }
+        if (tid < nsel) sel_w[tid] = e / sum;
     }
     __syncthreads();
     // sparse V gather: 16 independent 16-B row loads in flight per thread (the gather is latency-bound: ~46 KB of 512-B
     // rows per query from banks that do not fit one XCD's L2); padding entries carry weight 0 and a valid slot
-    const int nround = (nsel + 15) >> 4;
+    constexpr int RPR = 32;                                    // rows in flight per thread: top_k = 30 is ONE round trip
+    const int nround = (nsel + RPR - 1) / RPR;
     for (int u = tid; u < K * C8; u += RO_THREADS) {
         int o = u / C8, c8 = u - o * C8;
         const bf16_t* V = (u == tid ? Vbase : reinterpret_cast<const bf16_t*>(vptrs[o])) + c8 * 8;
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int r = 0; r < nround; ++r) {
-            ro_u32x4 v[16];
+            ro_u32x4 v[RPR];
 #pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                const ro_i32x4 si = *reinterpret_cast<const ro_i32x4*>(sel_i + r * 16 + t4 * 4);
+            for (int t4 = 0; t4 < RPR / 4; ++t4) {
+                const ro_i32x4 si = *reinterpret_cast<const ro_i32x4*>(sel_i + r * RPR + t4 * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[t4 * 4 + e] = *(ro_gptr)(V + (long)si[e] * CV);   // bank pointers come from memory: force global_load
             }
-            float wv[16];
+            float wv[RPR];
 #pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(sel_w + r * 16 + t4 * 4);
+            for (int t4 = 0; t4 < RPR / 4; ++t4) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(sel_w + r * RPR + t4 * 4);
                 wv[t4 * 4] = w4[0]; wv[t4 * 4 + 1] = w4[1]; wv[t4 * 4 + 2] = w4[2]; wv[t4 * 4 + 3] = w4[3];
             }
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
+            for (int t = 0; t < RPR; ++t) {
                 const float w = wv[t];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -442,6 +502,10 @@ __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __
         *reinterpret_cast<uint4*>(y + ((long)o * HW + j) * CV + c8 * 8) =
             make_uint4(pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3]), pack_bf2(acc[4], acc[5]), pack_bf2(acc[6], acc[7]));
     }
+    // usage += softmax weight of every selected token (kv_memory_store.py:151-162).  Last on purpose: on gfx950 an atomic counts in
+    // vmcnt like a load, so issued before the gather every wait for a value row also waited for the atomics, which serialise in
+    // the L2 on the popular tokens.
+    if (usage && tid < nsel) atomicAdd(&usage[sel_i[tid]], sel_w[tid]);
 }
 
 int launch_affinity(const cutie_op* op, hipStream_t s) {
@@ -467,13 +531,18 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             if (G != sp.G || (sp.HWp & 63) || sp.nranges < 1 || sp.nranges > 3 || (sp.Gld & 3)) { cutie_set_error("aff_score: bad ranges (G=%d vs %d, HWp=%d)", G, sp.G, sp.HWp); return -2; }
             const int nq = i[12] == 1 ? 1 : 2;
             int qb = (sp.HWp + 64 * nq - 1) / (64 * nq);
+            if (sp.mode != 0 && sp.mode != 1) { cutie_set_error("aff_score: mode %d", sp.mode); return -2; }
+            const int pass = sp.mode;
+            if (pass == 1 && (op->flags & 1)) sp.mode |= 2;     // pass-0 maxima precede tau in memory: tiles without candidates are skipped
             static bool lds_attr_set = false;
             if (!lds_attr_set) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(aff_score_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, AFF_LDS_BYTES) != hipSuccess ||
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(aff_score_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, AFF_LDS_BYTES) != hipSuccess) {
-                    cutie_set_error("aff_score: cannot raise the dynamic LDS limit to %d bytes", AFF_LDS_BYTES);
-                    return -2;
-                }
+                const void* ks[4] = {reinterpret_cast<const void*>(aff_score_kernel<1, 0>), reinterpret_cast<const void*>(aff_score_kernel<1, 1>),
+                                     reinterpret_cast<const void*>(aff_score_kernel<2, 0>), reinterpret_cast<const void*>(aff_score_kernel<2, 1>)};
+                for (const void* k : ks)
+                    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, AFF_LDS_BYTES) != hipSuccess) {
+                        cutie_set_error("aff_score: cannot raise the dynamic LDS limit to %d bytes", AFF_LDS_BYTES);
+                        return -2;
+                    }
                 lds_attr_set = true;
             }
             // ~2 resident blocks per CU (512 blocks), at least 8 tiles per block: the block prologue (its query operand,
@@ -483,30 +552,16 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             tpb = (tpb + AFF_TG - 1) / AFF_TG * AFF_TG;
             sp.tiles_per_block = tpb;
             const dim3 grid(qb, (G + tpb - 1) / tpb);
-            static const bool experimental = [] { const char* e = getenv("CUTIE_AMD_EXPERIMENTAL_AFF"); return e && e[0] && e[0] != '0'; }();
-            if (experimental && (sp.mode == 0 || sp.mode == 1)) {          // compile-time pass (see the template comment): opt-in
-                static bool exp_attr_set = false;
-                if (!exp_attr_set) {
-                    const void* ks[4] = {reinterpret_cast<const void*>(aff_score_kernel<1, 0>), reinterpret_cast<const void*>(aff_score_kernel<1, 1>),
-                                         reinterpret_cast<const void*>(aff_score_kernel<2, 0>), reinterpret_cast<const void*>(aff_score_kernel<2, 1>)};
-                    for (const void* k : ks)
-                        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, AFF_LDS_BYTES) != hipSuccess) {
-                            cutie_set_error("aff_score: cannot raise the dynamic LDS limit to %d bytes", AFF_LDS_BYTES);
-                            return -2;
-                        }
-                    exp_attr_set = true;
-                }
-                if (nq == 1 && sp.mode == 0) hipLaunchKernelGGL((aff_score_kernel<1, 0>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
-                else if (nq == 1) hipLaunchKernelGGL((aff_score_kernel<1, 1>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
-                else if (sp.mode == 0) hipLaunchKernelGGL((aff_score_kernel<2, 0>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
-                else hipLaunchKernelGGL((aff_score_kernel<2, 1>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
-                break;
-            }
-            if (nq == 1) hipLaunchKernelGGL(aff_score_kernel<1>, grid, dim3(256), AFF_LDS_BYTES, s, sp);
-            else hipLaunchKernelGGL(aff_score_kernel<2>, grid, dim3(256), AFF_LDS_BYTES, s, sp);
+            if (nq == 1 && pass == 0) hipLaunchKernelGGL((aff_score_kernel<1, 0>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
+            else if (nq == 1) hipLaunchKernelGGL((aff_score_kernel<1, 1>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
+            else if (pass == 0) hipLaunchKernelGGL((aff_score_kernel<2, 0>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
+            else hipLaunchKernelGGL((aff_score_kernel<2, 1>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
             break;
         }
         case CUTIE_OP_AFF_SELECT:
+            if (i[2] <= 1024) { hipLaunchKernelGGL(aff_select_reg_kernel<16>, dim3((i[0] + 3) / 4), dim3(256), 0, s, (const float*)p[0], (float*)p[1], i[0], (i[2] + 63) / 64 * 64, i[2], i[3]); break; }
+            if (i[2] <= 2048) { hipLaunchKernelGGL(aff_select_reg_kernel<32>, dim3((i[0] + 3) / 4), dim3(256), 0, s, (const float*)p[0], (float*)p[1], i[0], (i[2] + 63) / 64 * 64, i[2], i[3]); break; }
+            if (i[2] <= 4096) { hipLaunchKernelGGL(aff_select_reg_kernel<64>, dim3((i[0] + 3) / 4), dim3(256), 0, s, (const float*)p[0], (float*)p[1], i[0], (i[2] + 63) / 64 * 64, i[2], i[3]); break; }
             hipLaunchKernelGGL(aff_select_kernel, dim3((i[0] + 3) / 4), dim3(256), 0, s, (const float*)p[0], (float*)p[1], i[0], (i[2] + 63) / 64 * 64, i[2], i[3]);
             break;
         case CUTIE_OP_AFF_READOUT: {

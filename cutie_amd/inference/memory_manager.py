@@ -140,8 +140,11 @@ class MemoryManager:
             K = len(bucket.objects)
             ranges = [r for r in bucket.ranges() if r[1] > 0]
             G = sum(-(-n // 16) for _, n in ranges)
-            gmax = self._buf('gmax', (HWp, -(-max(G, 1) // 64) * 64), F32, dev)
-            tau = self._buf('tau', (HW,), F32, dev)
+            # pass-0 tile maxima [HWp, Gld] with the per-query thresholds right behind them (pass 1 reads both: it skips the tiles
+            # that cannot hold a candidate)
+            Gld = -(-max(G, 1) // 64) * 64
+            gbuf = self._buf('gmax_tau', (HWp * Gld + HWp,), F32, dev)
+            gmax, tau = gbuf[:HWp * Gld], gbuf[HWp * Gld:]
             cval = self._buf('cand_val', (HW, CAND_CAP), F32, dev)
             cidx = self._buf('cand_idx', (HW, CAND_CAP), torch.int32, dev)
             count = self._buf('count', (HW * O.OpList.AFF_CSTRIDE,), torch.int32, dev)
@@ -163,7 +166,7 @@ class MemoryManager:
                 ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('gmax'), None, None, None, mode=0, **common)
                 ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k)
                 ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('tau'), D('cval'), D('cidx'), D('count'),
-                             mode=1, **common)
+                             mode=1, gmax_precedes_tau=True, **common)
                 # usage bookkeeping (kv_memory_store.py:151-162): life += 1 for every counted token
                 if tick_work:
                     ol.usage_tick(D('life', 4 * bucket.work_start), bucket.n_work)

@@ -366,7 +366,9 @@ class OpList:
 
     AFF_CSTRIDE = 32          # ints between the candidate counters of consecutive queries (one cache line each)
 
-    def aff_score(self, Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count, *, HW, HWp, ranges, cap, mode):
+    def aff_score(self, Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count, *, HW, HWp, ranges, cap, mode, gmax_precedes_tau=False):
+        """gmax_precedes_tau (mode 1): `out` (= tau) sits right behind the [HWp, Gld] maxima of pass 0 in memory; the kernel then
+        skips every (tile, 16-query set) that cannot hold a candidate."""
         ranges = [(s, n) for (s, n) in ranges if n > 0]
         assert 1 <= len(ranges) <= 3
         G = sum(-(-n // 16) for _, n in ranges)
@@ -374,7 +376,7 @@ class OpList:
         for r in range(3):
             ints += list(ranges[r]) if r < len(ranges) else [0, 0]
         ints += [G, cap, mode]
-        return self.add(AFF_SCORE, 0, ints, [], [Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count])
+        return self.add(AFF_SCORE, 1 if (gmax_precedes_tau and mode == 1) else 0, ints, [], [Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count])
 
     def aff_select(self, gmax, tau, *, HW, HWp, G, top_k):
         return self.add(AFF_SELECT, 0, [HW, HWp, G, top_k], [], [gmax, tau])

@@ -165,7 +165,9 @@ enum {
      * memory_utils.py:7-46 get_similarity + the candidate pre-filter of top-k (:58)
      * p0=A_hi p1=A_lo p2=scale (bank base pointers, rows = physical token slots) p3=B_hi p4=B_lo p5=c
      * p6=gmax | tau f32 [HW]  p7=cand_val p8=cand_idx p9=count
-     * i: 0 HW 1 HWp 2 nranges 3.. (start,n) x3  9 G 10 cap 11 mode */
+     * i: 0 HW 1 HWp 2 nranges 3.. (start,n) x3  9 G 10 cap 11 mode
+     * flags&1 (mode 1): the gmax matrix of the mode-0 pass lies directly in front of tau in memory (p6 - HWp*Gld floats): every
+     *      (16-token tile, 16-query set) whose maximum is below the set's thresholds is skipped (same result, ~1/6 of the MFMA work) */
     CUTIE_OP_AFF_SCORE = 24,
     /* AFF_SELECT: tau_j = top_k-th largest of gmax[:,j] (or -inf if G < top_k)
      * p0=gmax f32 [HWp,Gld] p1=tau f32 [HW]   i: 0 HW 1 HWp 2 G 3 top_k */

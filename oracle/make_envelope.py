@@ -113,7 +113,8 @@ def main():
     only = [a for a in sys.argv[1:]]
     one_step_mode = 'one_step' in only
     only = [a for a in only if a != 'one_step']
-    jobs = [('base', n) for n in S.SCENARIOS] + [('small', 'small_fifo')]
+    jobs = [('base', n) for n in S.SCENARIOS] + [('small', n) for n in ('small_fifo', 'small_lt', 'small_add_del', 'small_lt_overlap',
+                                                                         'small_cfg_fifo', 'small_clear')]
     out_path = os.path.join(GOLDEN, 'amp_envelope.json')
     if only == ['bounds']:
         return finish(json.load(open(out_path)), out_path)

@@ -533,7 +533,7 @@ def test_summarize_add_pe():
 
 
 # ---- affinity pipeline ---------------------------------------------------------------------------------------
-def _affinity_build(HW, ranges, slots, K, top_k, with_usage, dup=False):
+def _affinity_build(HW, ranges, slots, K, top_k, with_usage, dup=False, skip=True):
     def build(dev, g):
         CV, cap = 256, 1024
         HWp = -(-HW // 64) * 64
@@ -550,7 +550,8 @@ def _affinity_build(HW, ranges, slots, K, top_k, with_usage, dup=False):
         Bhi, Blo, cq = z((HWp, 128), BF16), z((HWp, 128), BF16), z((HWp,), F32)
         G = sum(-(-n // 16) for _, n in ranges if n > 0)
         Gld = -(-G // 64) * 64
-        gmax, tau = z((HWp, Gld), F32), z((HW,), F32)
+        gbuf = z((HWp * Gld + HWp,), F32)                  # pass-0 maxima with the thresholds right behind them (pass 1 skips tiles)
+        gmax, tau = gbuf[:HWp * Gld].view(HWp, Gld), gbuf[HWp * Gld:HWp * Gld + HW]
         cval, cidx, count, ovf = z((HW, cap), F32), z((HW, cap), torch.int32), z((HW * 32,), torch.int32), z((1,), torch.int32)
         vals = [rnd(g, (slots + 16, CV), dev=dev) for _ in range(K)]
         vptrs = torch.tensor([v.data_ptr() for v in vals], dtype=torch.int64).to(dev)
@@ -564,7 +565,7 @@ def _affinity_build(HW, ranges, slots, K, top_k, with_usage, dup=False):
         common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=cap)
         ol.aff_score(Ahi, Alo, scale, Bhi, Blo, cq, gmax, None, None, None, mode=0, **common)
         ol.aff_select(gmax, tau, HW=HW, HWp=HWp, G=G, top_k=top_k)
-        ol.aff_score(Ahi, Alo, scale, Bhi, Blo, cq, tau, cval, cidx, count, mode=1, **common)
+        ol.aff_score(Ahi, Alo, scale, Bhi, Blo, cq, tau, cval, cidx, count, mode=1, gmax_precedes_tau=skip, **common)
         ol.aff_readout(cval, cidx, count, vptrs, usage, y, ovf, HW=HW, cap=cap, top_k=top_k, K=K, CV=CV)
         outs = {'Ahi': Ahi, 'Alo': Alo, 'scale': scale, 'Bhi': Bhi, 'Blo': Blo, 'cq': cq, 'tau': tau, 'y': y, 'ovf': ovf,
                 'gmax': gmax[:HW, :G], 'count': count}
@@ -584,8 +585,9 @@ def _affinity_build(HW, ranges, slots, K, top_k, with_usage, dup=False):
     dict(HW=48, ranges=[(0, 48)], slots=48, K=3, top_k=30, usage=True),               # G < top_k
     dict(HW=100, ranges=[(0, 1003)], slots=1003, K=1, top_k=5, usage=False),           # ragged tail tile
 ])
-def test_affinity_pipeline(case):
-    build = _affinity_build(case['HW'], case['ranges'], case['slots'], case['K'], case['top_k'], case['usage'])
+@pytest.mark.parametrize('skip', [True, False])
+def test_affinity_pipeline(case, skip):
+    build = _affinity_build(case['HW'], case['ranges'], case['slots'], case['K'], case['top_k'], case['usage'], skip=skip)
     hip, ref = run_both(build, seed=7)
     exact = ['Ahi', 'Alo', 'Bhi', 'Blo']
     for k in exact:
