@@ -338,11 +338,12 @@ __global__ __launch_bounds__(256) void aff_select_reg_kernel(const float* __rest
     if (j >= HW) return;                                    // whole wave exits together
     if (G < k) { if (lane == 0) tau[j] = -INFINITY; return; }
     uint32_t key[MAXV];
+    float raw[MAXV];
+    const float* row = gmax + (long)j * Gld;
 #pragma unroll
-    for (int r = 0; r < MAXV; ++r) {
-        const int g = r * 64 + lane;
-        key[r] = g < G ? f2key(gmax[(long)j * Gld + g]) : 0u;            // padding sorts below every real value (-inf -> 0x007fffff)
-    }
+    for (int r = 0; r < MAXV; ++r) raw[r] = row[min(r * 64 + lane, G - 1)];      // unconditional (clamped): all loads in flight at once
+#pragma unroll
+    for (int r = 0; r < MAXV; ++r) key[r] = r * 64 + lane < G ? f2key(raw[r]) : 0u;  // padding sorts below every real value (-inf -> 0x007fffff)
     uint32_t x = 0;
     for (int b = 31; b >= 0; --b) {
         const uint32_t t = x | (1u << b);

@@ -11,7 +11,7 @@ rm -rf $OUT; mkdir -p $OUT gpurun_out
 python bench.py --steps 20 --warmup 5 --preroll 30 --cpu-frames 0 --no-roofline --clips-in-flight 0 > $OUT/tune.log 2>&1
 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
 i=0
-for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16" "FETCH_SIZE" "WRITE_SIZE"; do
+for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16" "FETCH_SIZE" "WRITE_SIZE" ${EXTRA_PMC:+"$EXTRA_PMC"}; do
   i=$((i+1))
   timeout 500 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc$i -- $BENCH --no-lookahead > $OUT/pmc$i.log 2>&1 || tail -3 $OUT/pmc$i.log
 done

@@ -7,9 +7,9 @@ os.makedirs('profiles', exist_ok=True)
 
 def short(name):
     name = re.sub(r'^void ', '', name)
-    m = re.match(r'(conv_igemm_kernel)<', name)
+    m = re.match(r'(conv_igemm_kernel|conv_dma_kernel|conv_bufload_kernel|conv3x3_patch_kernel)<', name)
     if m:
-        return 'conv_igemm_kernel<*>'
+        return m.group(1) + '<*>'
     m = re.match(r'(\w+)<[^>]*>', name)
     return (m.group(1) + '<*>') if m and name.startswith(('aff_score', 'linear_small')) else name.split('(')[0][:90]
 
