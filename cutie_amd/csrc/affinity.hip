@@ -328,7 +328,7 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 
 // One wave per query column, 4 waves per block: exact k-th largest tile maximum, all in registers.  The G maxima of the column sit
 // MAXV per lane as order-preserving 32-bit keys; the answer is built bit by bit from the top (x |= bit while count(key >= x) >= k):
-// per step one v_cmp + s_bcnt1 + s_add per register -- no LDS, no atomics (the 4 x 8-bit histogram version below, kept for
+// per step one compare-and-add per register and one wave reduction -- no LDS atomics (the 4 x 8-bit histogram version below, kept for
 // G > 4096, needed 11 us for 1620 columns of 667 values; this one ~3 us).
 template <int MAXV>
 __global__ __launch_bounds__(256) void aff_select_reg_kernel(const float* __restrict__ gmax, float* __restrict__ tau,
@@ -344,13 +344,17 @@ __global__ __launch_bounds__(256) void aff_select_reg_kernel(const float* __rest
     for (int r = 0; r < MAXV; ++r) raw[r] = row[min(r * 64 + lane, G - 1)];      // unconditional (clamped): all loads in flight at once
 #pragma unroll
     for (int r = 0; r < MAXV; ++r) key[r] = r * 64 + lane < G ? f2key(raw[r]) : 0u;  // padding sorts below every real value (-inf -> 0x007fffff)
+    // (counted on the VALU, one wave reduction per bit: the ballot + s_bcnt1 + s_add form made the kernel scalar-unit-bound --
+    // 1700 SALU instructions per wave on the ONE scalar unit the 16 waves of a CU share: 17 us instead of 3)
     uint32_t x = 0;
     for (int b = 31; b >= 0; --b) {
         const uint32_t t = x | (1u << b);
-        int cnt = 0;
+        int c = 0;
 #pragma unroll
-        for (int r = 0; r < MAXV; ++r) cnt += __popcll(__ballot(key[r] >= t));
-        x = cnt >= k ? t : x;                                // wave-uniform
+        for (int r = 0; r < MAXV; ++r) c += key[r] >= t ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        x = c >= k ? t : x;                                  // wave-uniform
     }
     if (lane == 0) tau[j] = key2f(x);
 }
@@ -550,6 +554,7 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             // 64 KB through LDS) is amortised over the tiles, measured best around 16 tiles at 11k tokens x 1620 queries
             int tpb = (int)(((long)G * qb + 511) / 512);
             if (tpb < 8) tpb = 8;
+            if (i[13] > 0) tpb = i[13];                          // (tuning override: tiles per block)
             tpb = (tpb + AFF_TG - 1) / AFF_TG * AFF_TG;
             sp.tiles_per_block = tpb;
             const dim3 grid(qb, (G + tpb - 1) / tpb);
