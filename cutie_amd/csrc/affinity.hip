@@ -352,8 +352,7 @@ __global__ __launch_bounds__(256) void aff_select_reg_kernel(const float* __rest
         int c = 0;
 #pragma unroll
         for (int r = 0; r < MAXV; ++r) c += key[r] >= t ? 1 : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        c = wave_sum_i32(c);                                 // DPP + permlane swaps: ~60 cycles (six dependent ds_bpermute shuffles: ~600)
         x = c >= k ? t : x;                                  // wave-uniform
     }
     if (lane == 0) tau[j] = key2f(x);
@@ -474,7 +473,7 @@ __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __
     __syncthreads();
     // sparse V gather: 16 independent 16-B row loads in flight per thread (the gather is latency-bound: ~46 KB of 512-B
     // rows per query from banks that do not fit one XCD's L2); padding entries carry weight 0 and a valid slot
-    constexpr int RPR = 32;                                    // rows in flight per thread: top_k = 30 is ONE round trip
+    constexpr int RPR = 16;                                    // rows in flight per thread (32 would need 194 VGPRs: 4 instead of 10 resident blocks per CU)
     const int nround = (nsel + RPR - 1) / RPR;
     for (int u = tid; u < K * C8; u += RO_THREADS) {
         int o = u / C8, c8 = u - o * C8;

@@ -45,6 +45,19 @@ __device__ __forceinline__ float rows_sum(float v) {
     return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
 }
 
+// integer sum over the 64 lanes, result in every lane: butterfly inside each 16-lane row on the DPP path (quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror), then the 4 rows through v_permlane16_swap / v_permlane32_swap -- no LDS round trips
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);     // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);     // row_mirror
+    auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    const unsigned a = r[0] + r[1];
+    auto r2 = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    return (int)(r2[0] + r2[1]);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
