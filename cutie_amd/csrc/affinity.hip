@@ -168,11 +168,13 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
     const int T0 = (p.rn[0] + 15) >> 4, T1 = (p.nranges > 1) ? ((p.rn[1] + 15) >> 4) : 0;
     // staging: wave w stages tile w of the group; thread = (row r, quarter qd of the 256-B row): 4 + 4 chunks of 16 B
     const int sr = (lane >> 2), qd = lane & 3;
-    au32x4 st[8];
-    float st_sc = 0.f, st_pad = 0.f;
-    f32x4 gq[AFF_NQ];                                                   // pass-0 maxima of the NEXT group's 4 tiles (mode 1 + skip)
+    // TWO register sets: the loads of group g+2 are issued while group g is multiplied (with one set, a group's L2 round trip
+    // -- longer than the MFMAs of 4 tiles -- was exposed in every iteration: 5 x ~1.7 us of the 13 us of pass 0)
+    au32x4 st[2][8];
+    float st_sc[2] = {0.f, 0.f}, st_pad[2] = {0.f, 0.f};
+    f32x4 gq[2][AFF_NQ];                                                // pass-0 maxima of the staged groups' 4 tiles (mode 1 + skip)
 #pragma unroll
-    for (int u = 0; u < AFF_NQ; ++u) gq[u] = (f32x4){INFINITY, INFINITY, INFINITY, INFINITY};
+    for (int u = 0; u < AFF_NQ; ++u) gq[0][u] = gq[1][u] = (f32x4){INFINITY, INFINITY, INFINITY, INFINITY};
     // token slot of the first row / number of valid rows of tile g (wave-uniform)
     auto tile_slot = [&](int g, int& slot0, int& nvalid) {
         int start, n, lt;
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
         slot0 = start + lt * 16;
         nvalid = min(16, n - lt * 16);
     };
-#define AFF_LOAD(GRP)                                                                                      \
+#define AFF_LOAD(GRP, S)                                                                                      \
     {                                                                                                      \
         int gt_ = (GRP) + wave;                                /* this wave's tile of the group */         \
         gt_ = gt_ < g1 ? gt_ : g1 - 1;                         /* clamp: rows of missing tiles are never used */ \
@@ -191,37 +193,41 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
         const bool rv_ = sr < nv_;                                                                         \
         const long off_ = (long)(slot0_ + (rv_ ? sr : nv_ - 1)) * 128 + qd * 32;                           \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
-            st[e] = *reinterpret_cast<const au32x4*>(p.Ahi + off_ + e * 8);                                \
-            st[4 + e] = *reinterpret_cast<const au32x4*>(p.Alo + off_ + e * 8);                            \
+            st[S][e] = *reinterpret_cast<const au32x4*>(p.Ahi + off_ + e * 8);                                \
+            st[S][4 + e] = *reinterpret_cast<const au32x4*>(p.Alo + off_ + e * 8);                            \
         }                                                                                                  \
         /* the per-token scale rides along: a global load inside the MFMA loop would make every tile wait for this whole */ \
         /* prefetch (vmcnt is in-order) */                                                                 \
-        st_sc = rv_ ? p.scale[slot0_ + (rv_ ? sr : 0)] : 0.f;                                              \
-        st_pad = rv_ ? 0.f : -INFINITY;                                                                    \
+        st_sc[S] = rv_ ? p.scale[slot0_ + (rv_ ? sr : 0)] : 0.f;                                              \
+        st_pad[S] = rv_ ? 0.f : -INFINITY;                                                                    \
         if (skip) {                                                                                        \
             _Pragma("unroll") for (int u = 0; u < AFF_NQ; ++u)                                             \
-                gq[u] = *reinterpret_cast<const f32x4*>(gmax_p + (long)min(jq[u], p.HWp - 1) * p.Gld + (GRP)); \
+                gq[S][u] = *reinterpret_cast<const f32x4*>(gmax_p + (long)min(jq[u], p.HWp - 1) * p.Gld + (GRP)); \
         }                                                                                                  \
     }
-#define AFF_STORE(BUF)                                                                                     \
+#define AFF_STORE(BUF, S)                                                                                     \
     {                                                                                                      \
         const int row_ = wave * 16 + sr;                                                                   \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
-            lds[BUF][row_ * 16 + ((qd * 4 + e) ^ sr)] = st[e];                                             \
-            lds[BUF][1024 + row_ * 16 + ((qd * 4 + e) ^ sr)] = st[4 + e];                                  \
+            lds[BUF][row_ * 16 + ((qd * 4 + e) ^ sr)] = st[S][e];                                             \
+            lds[BUF][1024 + row_ * 16 + ((qd * 4 + e) ^ sr)] = st[S][4 + e];                                  \
         }                                                                                                  \
-        if (qd == 0) { lsc[BUF][row_] = st_sc; lpad[BUF][row_] = st_pad; }                                 \
+        if (qd == 0) { lsc[BUF][row_] = st_sc[S]; lpad[BUF][row_] = st_pad[S]; }                               \
     }
     f32x4 gcur[AFF_NQ];
-    AFF_LOAD(g0);
+    AFF_LOAD(g0, 0);
+    if (g0 + AFF_TG < g1) AFF_LOAD(g0 + AFF_TG, 1);
 #pragma unroll
-    for (int u = 0; u < AFF_NQ; ++u) gcur[u] = gq[u];
-    AFF_STORE(0);
+    for (int u = 0; u < AFF_NQ; ++u) gcur[u] = gq[0][u];
+    AFF_STORE(0, 0);
     __syncthreads();
-    int buf = 0;
-    for (int gg = g0; gg < g1; gg += AFF_TG) {
+    // group gg is multiplied from LDS buffer (gg - g0) / 4 & 1 = `half`; register set `half` is free again (its group is in LDS)
+    // and takes the loads of group gg + 2; register set half ^ 1 holds group gg + 1, stored to the other buffer after the MFMAs
+#pragma unroll 2
+    for (int gg = g0, half = 0; gg < g1; gg += AFF_TG, half ^= 1) {
+        const int buf = half;
         const bool more = gg + AFF_TG < g1;
-        if (more) AFF_LOAD(gg + AFF_TG);
+        if (gg + 2 * AFF_TG < g1) { if (half == 0) AFF_LOAD(gg + 2 * AFF_TG, 0) else AFF_LOAD(gg + 2 * AFF_TG, 1) }
         float gm[AFF_NQ][AFF_TG];
 #pragma unroll
         for (int t = 0; t < AFF_TG; ++t) {
@@ -298,12 +304,17 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
                     *reinterpret_cast<f32x4*>(p.gmax_or_tau + (long)jq[u] * p.Gld + gg) = (f32x4){gm[u][0], gm[u][1], gm[u][2], gm[u][3]};
         }
         if (more) {
-            AFF_STORE(buf ^ 1);
+            if (half == 0) {
+                AFF_STORE(1, 1);
 #pragma unroll
-            for (int u = 0; u < AFF_NQ; ++u) gcur[u] = gq[u];
+                for (int u = 0; u < AFF_NQ; ++u) gcur[u] = gq[1][u];
+            } else {
+                AFF_STORE(0, 0);
+#pragma unroll
+                for (int u = 0; u < AFF_NQ; ++u) gcur[u] = gq[0][u];
+            }
         }
         __syncthreads();
-        buf ^= 1;
     }
 #undef AFF_LOAD
 #undef AFF_STORE
