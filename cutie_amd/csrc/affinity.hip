@@ -255,17 +255,29 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
                     // lane holds tokens l4*4 + q (q = 0..3) of the tile for its query
                     const f32x4 sc = *reinterpret_cast<const f32x4*>(&lsc[buf][t * 16 + l4 * 4]);
                     const f32x4 pd = *reinterpret_cast<const f32x4*>(&lpad[buf][t * 16 + l4 * 4]);
+                    // 3 independent accumulators per query set (one per split term), interleaved over the sets: back-to-back MFMAs
+                    // on ONE accumulator wait out the matrix pipe's latency (~40 cycles each instead of 16 -- that chain, not the
+                    // loads, was the pass's time: 1040 cycles per tile for 384 cycles of MFMA)
+                    f32x4 a1[AFF_NQ], a2[AFF_NQ], a3[AFF_NQ];
+#pragma unroll
+                    for (int u = 0; u < AFF_NQ; ++u) {
+                        a1[u] = a2[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        a3[u] = (f32x4){ncj[u], ncj[u], ncj[u], ncj[u]};
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int u = 0; u < AFF_NQ; ++u) {
+                            a1[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bl[u][ks], a1[u], 0, 0, 0);
+                            a2[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], bh[u][ks], a2[u], 0, 0, 0);
+                            a3[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bh[u][ks], a3[u], 0, 0, 0);
+                        }
 #pragma unroll
                     for (int u = 0; u < AFF_NQ; ++u) {
                         if (!need[u]) continue;
-                        f32x4 acc = {ncj[u], ncj[u], ncj[u], ncj[u]};
+                        f32x4 acc;
 #pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) {                // small cross terms first
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bl[u][ks], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], bh[u][ks], acc, 0, 0, 0);
-                        }
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bh[u][ks], acc, 0, 0, 0);
+                        for (int q = 0; q < 4; ++q) acc[q] = a3[u][q] + (a1[u][q] + a2[u][q]);      // small cross terms first
                         float s[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) s[q] = fmaf(sc[q], acc[q], pd[q]);          // scale_i (A.B - c_j), -inf on padding rows
