@@ -168,13 +168,11 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
     const int T0 = (p.rn[0] + 15) >> 4, T1 = (p.nranges > 1) ? ((p.rn[1] + 15) >> 4) : 0;
     // staging: wave w stages tile w of the group; thread = (row r, quarter qd of the 256-B row): 4 + 4 chunks of 16 B
     const int sr = (lane >> 2), qd = lane & 3;
-    // TWO register sets: the loads of group g+2 are issued while group g is multiplied (with one set, a group's L2 round trip
-    // -- longer than the MFMAs of 4 tiles -- was exposed in every iteration: 5 x ~1.7 us of the 13 us of pass 0)
-    au32x4 st[2][8];
-    float st_sc[2] = {0.f, 0.f}, st_pad[2] = {0.f, 0.f};
-    f32x4 gq[2][AFF_NQ];                                                // pass-0 maxima of the staged groups' 4 tiles (mode 1 + skip)
+    au32x4 st[8];
+    float st_sc = 0.f, st_pad = 0.f;
+    f32x4 gq[AFF_NQ];                                                   // pass-0 maxima of the NEXT group's 4 tiles (mode 1 + skip)
 #pragma unroll
-    for (int u = 0; u < AFF_NQ; ++u) gq[0][u] = gq[1][u] = (f32x4){INFINITY, INFINITY, INFINITY, INFINITY};
+    for (int u = 0; u < AFF_NQ; ++u) gq[u] = (f32x4){INFINITY, INFINITY, INFINITY, INFINITY};
     // token slot of the first row / number of valid rows of tile g (wave-uniform)
     auto tile_slot = [&](int g, int& slot0, int& nvalid) {
         int start, n, lt;
@@ -184,7 +182,7 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
         slot0 = start + lt * 16;
         nvalid = min(16, n - lt * 16);
     };
-#define AFF_LOAD(GRP, S)                                                                                      \
+#define AFF_LOAD(GRP)                                                                                      \
     {                                                                                                      \
         int gt_ = (GRP) + wave;                                /* this wave's tile of the group */         \
         gt_ = gt_ < g1 ? gt_ : g1 - 1;                         /* clamp: rows of missing tiles are never used */ \
@@ -193,41 +191,37 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
         const bool rv_ = sr < nv_;                                                                         \
         const long off_ = (long)(slot0_ + (rv_ ? sr : nv_ - 1)) * 128 + qd * 32;                           \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
-            st[S][e] = *reinterpret_cast<const au32x4*>(p.Ahi + off_ + e * 8);                                \
-            st[S][4 + e] = *reinterpret_cast<const au32x4*>(p.Alo + off_ + e * 8);                            \
+            st[e] = *reinterpret_cast<const au32x4*>(p.Ahi + off_ + e * 8);                                \
+            st[4 + e] = *reinterpret_cast<const au32x4*>(p.Alo + off_ + e * 8);                            \
         }                                                                                                  \
         /* the per-token scale rides along: a global load inside the MFMA loop would make every tile wait for this whole */ \
         /* prefetch (vmcnt is in-order) */                                                                 \
-        st_sc[S] = rv_ ? p.scale[slot0_ + (rv_ ? sr : 0)] : 0.f;                                              \
-        st_pad[S] = rv_ ? 0.f : -INFINITY;                                                                    \
+        st_sc = rv_ ? p.scale[slot0_ + (rv_ ? sr : 0)] : 0.f;                                              \
+        st_pad = rv_ ? 0.f : -INFINITY;                                                                    \
         if (skip) {                                                                                        \
             _Pragma("unroll") for (int u = 0; u < AFF_NQ; ++u)                                             \
-                gq[S][u] = *reinterpret_cast<const f32x4*>(gmax_p + (long)min(jq[u], p.HWp - 1) * p.Gld + (GRP)); \
+                gq[u] = *reinterpret_cast<const f32x4*>(gmax_p + (long)min(jq[u], p.HWp - 1) * p.Gld + (GRP)); \
         }                                                                                                  \
     }
-#define AFF_STORE(BUF, S)                                                                                     \
+#define AFF_STORE(BUF)                                                                                     \
     {                                                                                                      \
         const int row_ = wave * 16 + sr;                                                                   \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
-            lds[BUF][row_ * 16 + ((qd * 4 + e) ^ sr)] = st[S][e];                                             \
-            lds[BUF][1024 + row_ * 16 + ((qd * 4 + e) ^ sr)] = st[S][4 + e];                                  \
+            lds[BUF][row_ * 16 + ((qd * 4 + e) ^ sr)] = st[e];                                             \
+            lds[BUF][1024 + row_ * 16 + ((qd * 4 + e) ^ sr)] = st[4 + e];                                  \
         }                                                                                                  \
-        if (qd == 0) { lsc[BUF][row_] = st_sc[S]; lpad[BUF][row_] = st_pad[S]; }                               \
+        if (qd == 0) { lsc[BUF][row_] = st_sc; lpad[BUF][row_] = st_pad; }                                 \
     }
     f32x4 gcur[AFF_NQ];
-    AFF_LOAD(g0, 0);
-    if (g0 + AFF_TG < g1) AFF_LOAD(g0 + AFF_TG, 1);
+    AFF_LOAD(g0);
 #pragma unroll
-    for (int u = 0; u < AFF_NQ; ++u) gcur[u] = gq[0][u];
-    AFF_STORE(0, 0);
+    for (int u = 0; u < AFF_NQ; ++u) gcur[u] = gq[u];
+    AFF_STORE(0);
     __syncthreads();
-    // group gg is multiplied from LDS buffer (gg - g0) / 4 & 1 = `half`; register set `half` is free again (its group is in LDS)
-    // and takes the loads of group gg + 2; register set half ^ 1 holds group gg + 1, stored to the other buffer after the MFMAs
-#pragma unroll 2
-    for (int gg = g0, half = 0; gg < g1; gg += AFF_TG, half ^= 1) {
-        const int buf = half;
+    int buf = 0;
+    for (int gg = g0; gg < g1; gg += AFF_TG) {
         const bool more = gg + AFF_TG < g1;
-        if (gg + 2 * AFF_TG < g1) { if (half == 0) AFF_LOAD(gg + 2 * AFF_TG, 0) else AFF_LOAD(gg + 2 * AFF_TG, 1) }
+        if (more) AFF_LOAD(gg + AFF_TG);
         float gm[AFF_NQ][AFF_TG];
 #pragma unroll
         for (int t = 0; t < AFF_TG; ++t) {
@@ -255,29 +249,17 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
                     // lane holds tokens l4*4 + q (q = 0..3) of the tile for its query
                     const f32x4 sc = *reinterpret_cast<const f32x4*>(&lsc[buf][t * 16 + l4 * 4]);
                     const f32x4 pd = *reinterpret_cast<const f32x4*>(&lpad[buf][t * 16 + l4 * 4]);
-                    // 3 independent accumulators per query set (one per split term), interleaved over the sets: back-to-back MFMAs
-                    // on ONE accumulator wait out the matrix pipe's latency (~40 cycles each instead of 16 -- that chain, not the
-                    // loads, was the pass's time: 1040 cycles per tile for 384 cycles of MFMA)
-                    f32x4 a1[AFF_NQ], a2[AFF_NQ], a3[AFF_NQ];
-#pragma unroll
-                    for (int u = 0; u < AFF_NQ; ++u) {
-                        a1[u] = a2[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        a3[u] = (f32x4){ncj[u], ncj[u], ncj[u], ncj[u]};
-                    }
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                        for (int u = 0; u < AFF_NQ; ++u) {
-                            a1[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bl[u][ks], a1[u], 0, 0, 0);
-                            a2[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], bh[u][ks], a2[u], 0, 0, 0);
-                            a3[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bh[u][ks], a3[u], 0, 0, 0);
-                        }
 #pragma unroll
                     for (int u = 0; u < AFF_NQ; ++u) {
                         if (!need[u]) continue;
-                        f32x4 acc;
+                        f32x4 acc = {ncj[u], ncj[u], ncj[u], ncj[u]};
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[q] = a3[u][q] + (a1[u][q] + a2[u][q]);      // small cross terms first
+                        for (int ks = 0; ks < 4; ++ks) {                // small cross terms first
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bl[u][ks], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], bh[u][ks], acc, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bh[u][ks], acc, 0, 0, 0);
                         float s[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) s[q] = fmaf(sc[q], acc[q], pd[q]);          // scale_i (A.B - c_j), -inf on padding rows
@@ -316,17 +298,12 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
                     *reinterpret_cast<f32x4*>(p.gmax_or_tau + (long)jq[u] * p.Gld + gg) = (f32x4){gm[u][0], gm[u][1], gm[u][2], gm[u][3]};
         }
         if (more) {
-            if (half == 0) {
-                AFF_STORE(1, 1);
+            AFF_STORE(buf ^ 1);
 #pragma unroll
-                for (int u = 0; u < AFF_NQ; ++u) gcur[u] = gq[1][u];
-            } else {
-                AFF_STORE(0, 0);
-#pragma unroll
-                for (int u = 0; u < AFF_NQ; ++u) gcur[u] = gq[0][u];
-            }
+            for (int u = 0; u < AFF_NQ; ++u) gcur[u] = gq[u];
         }
         __syncthreads();
+        buf ^= 1;
     }
 #undef AFF_LOAD
 #undef AFF_STORE
