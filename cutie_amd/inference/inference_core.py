@@ -89,13 +89,14 @@ class InferenceCore:
         image._cutie_raw = (h0, w0, H, W, pad[0], pad[2])
         return image, (h0, w0, H, W, pad)
 
-    def prefetch(self, image: torch.Tensor) -> None:
+    def prefetch(self, image: torch.Tensor, *, affinity: bool = False) -> None:
         """Optional look-ahead: start the image encoder (ResNet-50 + key projection, ~30 % of a frame and independent of
         the memory state) of the frame that will be passed to the NEXT ``step`` on a side stream, so that it overlaps with
         the read-out / transformer / decoder of the current frame.  ``step(next_image=...)`` calls this.  The hint is matched
         by storage (address / shape / strides), so pass the same tensor (or view) to the next ``step`` and do not modify it
         in between; if the next ``step`` receives a different tensor the result is simply dropped.  Results are bit-identical to the unpipelined
-        order (same kernels, same inputs)."""
+        order (same kernels, same inputs).  ``affinity=True`` (set by ``step`` when the current frame does not write the memory bank)
+        also runs the next frame's affinity read-out ahead: it depends on that frame's key and on the bank only."""
         if self.max_internal_size > 0 and min(image.shape[-2:]) > self.max_internal_size:
             return                                             # the GUI resize path stays unpipelined
         dev = self.network.device
@@ -111,10 +112,13 @@ class InferenceCore:
         with torch.cuda.stream(enc):
             ms_features, pix_feat = self.network._encode_image_raw(prepared, *prepared._cutie_raw)
             key, shrinkage, selection = self.network.transform_key(ms_features[0])
+            if affinity:
+                self.memory.prefetch_affinity(key)
             ev = torch.cuda.Event()
             ev.record(enc)
         feats = (ms_features, pix_feat, key, shrinkage, selection)
-        for t in list(ms_features) + [pix_feat, key, shrinkage, selection] + list(self.network._key_cache[1].values()):
+        ahead = [r for r, _ in self.network._key_cache[1].get('_readouts', {}).values()]
+        for t in list(ms_features) + [pix_feat, key, shrinkage, selection] + ahead + list(self.network._key_cache[1].values()):
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(main)                          # allocated on the side stream, consumed on the main one
         # (the source tensor is kept referenced until the next step: its address cannot be recycled for another frame)
@@ -267,7 +271,8 @@ class InferenceCore:
             ms_f, pix_f = fl.image_feature_store.get_features(self.curr_ti, image_f)
             key_f, shr_f, sel_f = fl.image_feature_store.get_key(self.curr_ti, image_f)
         elif next_image is not None and not end:
-            self.prefetch(next_image)
+            # (the next frame's read-out may run ahead only if this frame leaves the bank alone)
+            self.prefetch(next_image, affinity=not (is_mem_frame or force_permanent) and self.memory.engaged)
 
         if need_segment:
             pred_prob_with_bg = self._segment(key, selection, pix_feat, ms_feat, update_sensory=update_sensory)

