@@ -9,6 +9,7 @@ flip_aug (the reference's batch of [frame, flipped frame], :142-143,162-165,234-
 own memory bank; chunk_size > 0 groups the objects in the memory read-out like the reference.
 """
 import logging
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -22,6 +23,7 @@ from .object_manager import ObjectManager
 
 log = logging.getLogger()
 F32 = torch.float32
+AHEAD_AFFINITY = os.environ.get('CUTIE_AMD_AHEAD_AFFINITY', '1') not in ('', '0')     # look-ahead of the affinity read-out (see prefetch)
 
 
 def pad_geometry(h, w, d=16):
@@ -272,7 +274,7 @@ class InferenceCore:
             key_f, shr_f, sel_f = fl.image_feature_store.get_key(self.curr_ti, image_f)
         elif next_image is not None and not end:
             # (the next frame's read-out may run ahead only if this frame leaves the bank alone)
-            self.prefetch(next_image, affinity=not (is_mem_frame or force_permanent) and self.memory.engaged)
+            self.prefetch(next_image, affinity=AHEAD_AFFINITY and not (is_mem_frame or force_permanent) and self.memory.engaged)
 
         if need_segment:
             pred_prob_with_bg = self._segment(key, selection, pix_feat, ms_feat, update_sensory=update_sensory)
