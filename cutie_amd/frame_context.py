@@ -1,0 +1,38 @@
+"""Per-process registry of what the HIP path knows about a tensor it handed to the caller.
+
+The facade methods of ``CUTIE`` keep the reference's tensor-in / tensor-out signatures, but some results have companions the next
+method needs: the similarity operands of a key (split-bf16 ``B`` matrices), the bf16 shadow of the fp32 sensory state.  They used
+to ride on the tensors as Python attributes, which breaks as soon as a caller re-wraps a tensor (``key = key.clone()``,
+``key = key * 1``).  Here they are looked up by storage address instead -- any view of the buffer finds them -- and every consumer
+has a slow path that recomputes the companion when nothing is registered (a third-party caller of the six ``CUTIE`` methods).
+
+An entry holds references to its payload tensors, so the address it is keyed by cannot be recycled for another tensor while the
+entry lives; the table is a small LRU (frames in flight x a handful of entries)."""
+import threading
+from collections import OrderedDict
+
+_MAX = 96
+_lock = threading.Lock()
+_table = OrderedDict()          # (kind, data_ptr) -> (payload, pinned tensors)
+
+
+def remember(kind, tensor, payload, pin=()):
+    """Attach `payload` to the storage address of `tensor` (a later entry for the same address replaces it)."""
+    key = (kind, tensor.data_ptr())
+    with _lock:
+        _table.pop(key, None)
+        _table[key] = (payload, (tensor,) + tuple(pin))
+        while len(_table) > _MAX:
+            _table.popitem(last=False)
+
+
+def recall(kind, tensor):
+    """Payload registered for this tensor's storage address (None if unknown: the caller takes its slow path)."""
+    with _lock:
+        hit = _table.get((kind, tensor.data_ptr()))
+    return None if hit is None else hit[0]
+
+
+def forget(kind, tensor):
+    with _lock:
+        _table.pop((kind, tensor.data_ptr()), None)

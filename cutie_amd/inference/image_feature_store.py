@@ -5,6 +5,8 @@ Here ONE fused launch plan produces (ms_features, pix_feat) and (key, shrinkage,
 leaves the key outputs with the features and CUTIE.transform_key picks them up, so the two getters share one record.
 The look-ahead encoder of InferenceCore (side stream) deposits its record through ``_store`` directly."""
 import warnings
+
+from .. import frame_context
 from typing import Dict, Iterable, NamedTuple, Tuple
 
 import torch
@@ -27,7 +29,7 @@ class ImageFeatureStore:
         rec = self._store.get(index)
         if rec is None:
             net = self.network
-            geometry = getattr(image, '_cutie_raw', None)       # InferenceCore: un-padded frame + pad geometry (padding is
+            geometry = frame_context.recall('geometry', image)  # InferenceCore: un-padded frame + pad geometry (padding is
             if geometry is None:                                 # fused into the first kernel)
                 ms, pix = net.encode_image(image)
             else:

@@ -15,7 +15,7 @@ from typing import List, Optional
 import numpy as np
 import torch
 
-from .. import ops as O
+from .. import frame_context, ops as O
 from ..model import plans
 from .image_feature_store import ImageFeatureStore
 from .memory_manager import MemoryManager
@@ -88,7 +88,7 @@ class InferenceCore:
         h0, w0 = image.shape[-2:]
         H, W, pad = pad_geometry(h0, w0, 16)
         image = image.to(device=self.network.device, dtype=F32).contiguous()
-        image._cutie_raw = (h0, w0, H, W, pad[0], pad[2])
+        frame_context.remember('geometry', image, (h0, w0, H, W, pad[0], pad[2]))     # un-padded frame + pad geometry (see ImageFeatureStore)
         return image, (h0, w0, H, W, pad)
 
     def prefetch(self, image: torch.Tensor, *, affinity: bool = False) -> None:
@@ -112,10 +112,10 @@ class InferenceCore:
         enc = self._enc_stream
         enc.wait_stream(main)                                  # frame conversion + any earlier encoder run on the main stream
         with torch.cuda.stream(enc):
-            ms_features, pix_feat = self.network._encode_image_raw(prepared, *prepared._cutie_raw)
+            ms_features, pix_feat = self.network._encode_image_raw(prepared, *frame_context.recall('geometry', prepared))
             key, shrinkage, selection = self.network.transform_key(ms_features[0])
             if affinity:
-                self.memory.prefetch_affinity(key)
+                self.memory.prefetch_affinity(key, selection, self.network)
             ev = torch.cuda.Event()
             ev.record(enc)
         feats = (ms_features, pix_feat, key, shrinkage, selection)
@@ -190,7 +190,7 @@ class InferenceCore:
         as_permanent = 'all' if force_permanent else 'first'
         ids = self.object_manager.all_obj_ids
         self.memory.initialize_sensory_if_needed(key, ids)
-        g = getattr(image, '_cutie_raw', None)                 # (h0, w0, H, W, pad_left, pad_top) of the un-padded frame
+        g = frame_context.recall('geometry', image)            # (h0, w0, H, W, pad_left, pad_top) of the un-padded frame
         raw = (image, g[0], g[1], g[4], g[5]) if g is not None else None
         msk_value, sensory, obj_value, _ = self.network.encode_mask(
             image, pix_feat, self.memory.get_sensory(ids), prob, deep_update=is_deep_update, chunk_size=self.chunk_size,
@@ -250,7 +250,7 @@ class InferenceCore:
             image = pre[1]
             torch.cuda.current_stream(image.device).wait_event(pre[3])
             self.image_feature_store._store[self.curr_ti] = pre[2]
-            h0, w0, H, W, pl, pt = image._cutie_raw
+            h0, w0, H, W, pl, pt = frame_context.recall('geometry', image)
             self.pad = pad_geometry(h0, w0, 16)[2]
         else:
             if pre is not None:                                # stale look-ahead: order the encoder plan's buffers, drop it
@@ -269,7 +269,7 @@ class InferenceCore:
             # the reference flips the PADDED frame (:231-235): flipping the raw frame swaps the left / right pads
             fl.curr_ti, fl.pad = self.curr_ti, self.pad
             image_f = self._flip_w(image)
-            image_f._cutie_raw = (h0, w0, H, W, self.pad[1], pt)
+            frame_context.remember('geometry', image_f, (h0, w0, H, W, self.pad[1], pt))
             ms_f, pix_f = fl.image_feature_store.get_features(self.curr_ti, image_f)
             key_f, shr_f, sel_f = fl.image_feature_store.get_key(self.curr_ti, image_f)
         elif next_image is not None and not end:

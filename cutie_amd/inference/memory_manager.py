@@ -16,7 +16,7 @@ from typing import Dict, List
 
 import torch
 
-from .. import ops as O
+from .. import frame_context, ops as O
 from .kv_memory_store import Bucket, StoreView, LIFE_EPS_BITS
 from .object_manager import ObjectManager
 
@@ -98,9 +98,8 @@ class MemoryManager:
     def get_sensory(self, ids: List[int]):
         """logical [1,K,CS,h,w] fp32 view of the stacked state (+ its bf16 shadow as attribute)."""
         a, b = self._rows(ids, self._ids)
-        t = self._sens_f32[a:b].permute(0, 3, 1, 2).unsqueeze(0)
-        t._cutie_bf16 = self._sens_bf16[a:b]
-        return t
+        frame_context.remember('sensory_bf16', self._sens_f32[a:b], self._sens_bf16[a:b])     # found again by CUTIE.segment / encode_mask
+        return self._sens_f32[a:b].permute(0, 3, 1, 2).unsqueeze(0)
 
     def update_sensory(self, sensory: torch.Tensor, ids: List[int]):
         a, b = self._rows(ids, self._ids)
@@ -128,11 +127,6 @@ class MemoryManager:
         return mask[:, tmp]
 
     # ---- read (memory_manager.py:112-208) ---------------------------------------------------------------------
-    def _query_operands(self, query_key: torch.Tensor):
-        q = getattr(query_key, '_cutie_query', None)
-        if q is None:
-            raise RuntimeError('query_key must come from CUTIE.transform_key (it carries the similarity operands)')
-        return q
 
     def _affinity(self, bucket: Bucket, q, h: int, w: int, dev, tag: str = '') -> torch.Tensor:
         """Affinity read-out of one bucket for the query operands q: similarity -> exact top-k -> softmax -> sparse value gather
@@ -189,7 +183,7 @@ class MemoryManager:
         cached[1].run(**dyn)
         return readout
 
-    def prefetch_affinity(self, query_key: torch.Tensor) -> None:
+    def prefetch_affinity(self, query_key: torch.Tensor, selection: torch.Tensor, network) -> None:
         """Look-ahead lane (no counterpart in the reference): the affinity read-out of the NEXT frame depends only on that frame's
         key and on the bank, so when the current frame does not write the bank (not a memory frame) it can run ahead on the encoder's
         side stream.  The result rides on the query operands and is used by `read` if the bank is still the one it was read from
@@ -197,14 +191,14 @@ class MemoryManager:
         would count the frame's read twice; the reference's GUI path never deletes mid-propagation)."""
         if not self.engaged or self.CV is None:
             return
-        q = self._query_operands(query_key)
+        q = network.query_operands(query_key, selection)
         h, w = q['h'], q['w']
         dev = q['Bhi'].device
         q['_readouts'] = {bid: (self._affinity(b, q, h, w, dev, tag='#ahead'), self._version) for bid, b in self.buckets.items()}
 
     def read(self, pix_feat: torch.Tensor, query_key: torch.Tensor, selection: torch.Tensor, last_mask: torch.Tensor,
              network) -> Dict[int, torch.Tensor]:
-        q = self._query_operands(query_key)
+        q = network.query_operands(query_key, selection)
         h, w = pix_feat.shape[-2:]
         dev = pix_feat.device
         ahead = q.pop('_readouts', None) or {}

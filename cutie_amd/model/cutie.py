@@ -16,7 +16,7 @@ from typing import Dict, Iterable, List
 import torch
 import torch.nn as nn
 
-from .. import _lib
+from .. import _lib, frame_context
 from . import plans
 from .param_spec import build_spec
 from .weights import fold_bn, pack_conv, pack_linear, linear_as_conv
@@ -380,16 +380,38 @@ class CUTIE(nn.Module):
             P = eng.plan(('key', h, w), plans.build_transform_key, h, w)
             P.run(f16=f16, **{k: v for k, v in o.items() if k not in ('h', 'w')})
         key, shr, sel = self._key_views(o)
-        key._cutie_query = o                  # similarity operands ride along for MemoryManager.read
+        frame_context.remember('query', o['key'], o)     # the similarity operands of this key, found again by MemoryManager.read
         return key, (shr if need_sk else None), (sel if need_ek else None)
+
+    def query_operands(self, query_key: torch.Tensor, selection: torch.Tensor) -> dict:
+        """Split-bf16 similarity operands (Bhi, Blo, cq) of a query key.  Fast path: the key came out of ``transform_key`` (or is a
+        view of it) and its operands were computed by the same launch plan.  Slow path (a caller that cloned / rebuilt the key, or
+        brings its own): one KEY_PREP launch on fp32 copies of key and selection."""
+        o = frame_context.recall('query', query_key)
+        if o is not None:
+            return o
+        assert query_key.dim() == 4 and query_key.shape[0] == 1 and selection is not None, 'query key [1,CK,h,w] with its selection'
+        h, w = query_key.shape[-2:]
+        hw, HWp = h * w, -(-h * w // 64) * 64
+        dev = self.device
+        kphys = query_key[0].permute(1, 2, 0).reshape(hw, -1).to(device=dev, dtype=F32).contiguous()
+        ephys = selection[0].permute(1, 2, 0).reshape(hw, -1).to(device=dev, dtype=F32).contiguous()
+        o = dict(key=kphys, sel=ephys, Bhi=torch.zeros((HWp, 128), dtype=BF16, device=dev), Blo=torch.zeros((HWp, 128), dtype=BF16, device=dev),
+                 cq=torch.zeros((HWp,), dtype=F32, device=dev), h=h, w=w)
+        from .. import ops as O
+        ol = O.OpList()
+        ol.key_prep(kphys, ephys, o['Bhi'], o['Blo'], o['cq'], n=hw, query=True)
+        ol.run()
+        frame_context.remember('query', query_key, o)
+        return o
 
     @staticmethod
     def _sensory_pair(sensory):
         """sensory logical [1,K,CS,h,w] fp32 -> (phys f32 [K,h,w,CS], bf16 shadow)."""
         phys = group_nhwc_of(sensory, F32)
-        shadow = getattr(sensory, '_cutie_bf16', None)
+        shadow = frame_context.recall('sensory_bf16', phys)
         if shadow is None or shadow.shape != phys.shape:
-            shadow = phys.to(BF16)
+            shadow = phys.to(BF16)                # a state the HIP path has not produced itself: one cast
         return phys, shadow
 
     def encode_mask(self, image, ms_features, sensory, masks, *, deep_update=True, chunk_size=-1, need_weights=False,
@@ -414,7 +436,7 @@ class CUTIE(nn.Module):
         summ = torch.empty((K, self.model_cfg['object_summarizer']['num_summaries'], self.embed_dim + 1), dtype=F32, device=dev)
         P.run(image=img.to(F32).contiguous(), masks=mk, pix_feat=pix, sensory_f32=sf, sensory_bf16=sb, value=value, summ=summ)
         new_sens = group_logical(sf)
-        new_sens._cutie_bf16 = sb
+        frame_context.remember('sensory_bf16', sf, sb)
         return group_logical(value), new_sens, summ.unsqueeze(0), None
 
     def pixel_fusion(self, pix_feat, pixel, sensory, last_mask, *, chunk_size=-1):
@@ -461,7 +483,7 @@ class CUTIE(nn.Module):
         lup = torch.empty((K + 1, 16 * h, 16 * w), dtype=F32, device=dev) if _need_logits else None
         P.run(f8=f8, f4=f4, p16=p16, sensory_f32=sf, sensory_bf16=sb, prob=prob, logits_up=lup)
         new_sens = group_logical(sf)
-        new_sens._cutie_bf16 = sb
+        frame_context.remember('sensory_bf16', sf, sb)
         return new_sens, (lup.unsqueeze(0) if lup is not None else None), prob.unsqueeze(0)
 
     def read_memory(self, *a, **k):

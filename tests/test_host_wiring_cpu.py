@@ -310,3 +310,32 @@ def test_bank_contents_match_oracle(name, product_net, oracle_net):
                 shared = float((d < 3e-2).float().mean())
                 print(name, 'bucket', bid, 'shared long-term prototypes', shared)
                 assert shared > 0.6, (bid, 'long-term prototypes', shared)
+
+
+def test_rewrapped_tensors_take_the_slow_path(product_net):
+    """The companions of a facade result (similarity operands of a key, bf16 shadow of the sensory state) are found by storage
+    address (cutie_amd/frame_context.py); a caller that clones / rebuilds the tensors in between gets them recomputed instead of
+    an error -- same values."""
+    from cutie_amd import frame_context
+    from cutie_amd.utils.synth import SyntheticClip
+    net = product_net
+    with torch.inference_mode():
+        img = SyntheticClip(64, 96, 2, 2, seed=9).frame(0).unsqueeze(0)
+        ms, pix = net.encode_image(img)
+        key, shr, sel = net.transform_key(ms[0])
+        fast = net.query_operands(key, sel)
+        assert fast is frame_context.recall('query', key) and fast is net.query_operands(key[:, :, :, :], sel)      # any view finds it
+        slow = net.query_operands(key.clone(), sel.clone())
+        assert slow is not fast
+        for k in ('Bhi', 'Blo'):
+            assert torch.equal(slow[k].view(torch.int16), fast[k].view(torch.int16)), k
+        assert torch.allclose(slow['cq'], fast['cq'], rtol=1e-6, atol=1e-6)
+        # sensory state brought by the caller (no bf16 shadow registered): segment casts once and returns the same result as with
+        # the state it produced itself
+        K, h, w = 2, 4, 6
+        g = torch.Generator().manual_seed(3)
+        ro = torch.randn(1, K, 256, h, w, generator=g) * 0.3
+        sens = torch.randn(1, K, 256, h, w, generator=g) * 0.3
+        s1, _, p1 = net.segment(ms, ro, sens.clone(), update_sensory=True)
+        s2, _, p2 = net.segment(ms, ro, sens.clone().contiguous(), update_sensory=True)
+        assert torch.equal(p1, p2) and torch.equal(s1, s2)
