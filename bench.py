@@ -52,6 +52,9 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--full-bank-preroll', type=int, default=2000,
+                    help='also report frames/s with the memory bank at its steady-state size: an extra clip run this many frames '
+                         'before its timed steps (SURVEY C2: 18-26k tokens, pruning fires near frame 1995); 0 = skip')
     ap.add_argument('--no-lookahead', action='store_true',
                     help='do not pass next_image to step (no overlap of the next frame\'s image encoder on a side stream)')
     ap.add_argument('--clips-in-flight', type=int, default=4,
@@ -217,24 +220,42 @@ def main():
         la = (lambda t: None) if args.no_lookahead else (lambda t: frames[(t + 1) % 128])   # the next frame, as a video reader knows it
         proc.step(frames[0], mask, objects=clip.objects, next_image=la(0))
         t_idx = 1
-        for _ in range(args.preroll + args.warmup):
+        for _ in range(args.preroll):
             proc.step(frames[t_idx % 128], next_image=la(t_idx))
             t_idx += 1
         torch.cuda.synchronize()
         n_tok_start = sum(b.size() for b in proc.memory.buckets.values())
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            proc.step(frames[t_idx % 128], next_image=la(t_idx))
-            t_idx += 1
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        from cutie_amd.parallel import timed_steps
+        base = t_idx
+
+        def one_step(i):
+            proc.step(frames[(base + i) % 128], next_image=la(base + i))
+
+        # W warm-up steps, then exactly K timed steps between barrier + synchronize, MAX over the ranks (cutie_amd/parallel.py)
+        elapsed = timed_steps(one_step, args.steps, args.warmup, dev)
+        t_idx = base + args.warmup + args.steps
         n_tok_end = sum(b.size() for b in proc.memory.buckets.values())
+        # ---- the same clip WITHOUT the next_image hint: what an unchanged scripting_demo.py / eval loop of the reference gets ----
+        no_la = None
+        if not args.no_lookahead:
+            base2 = t_idx
+            t_nola = timed_steps(lambda i: proc.step(frames[(base2 + i) % 128]), args.steps, 2, dev)
+            t_idx = base2 + 2 + args.steps
+            no_la = {'value': round(world * args.steps / t_nola, 2), 'ms_per_step': round(t_nola / args.steps * 1e3, 4)}
+        # ---- full-bank point: long-term memory at its steady-state size ----
+        full_bank = None
+        if args.full_bank_preroll > 0 and use_lt:
+            proc_fb = InferenceCore(net, cfg=cfg)
+            proc_fb.step(frames[0], mask, objects=clip.objects, next_image=la(0))
+            for t in range(1, args.full_bank_preroll):
+                proc_fb.step(frames[t % 128], next_image=la(t))
+            torch.cuda.synchronize()
+            fb0 = args.full_bank_preroll
+            nfb = min(args.steps, 200)
+            t_fb = timed_steps(lambda i: proc_fb.step(frames[(fb0 + i) % 128], next_image=la(fb0 + i)), nfb, 5, dev)
+            full_bank = {'preroll_frames': args.full_bank_preroll, 'memory_tokens': sum(b.size() for b in proc_fb.memory.buckets.values()),
+                         'value': round(world * nfb / t_fb, 2), 'ms_per_step': round(t_fb / nfb * 1e3, 4), 'steps': nfb}
+            del proc_fb
 
         # ---- per-kernel-family timing on the launch stream (hipEvents inside cutie_time_ops) ----
         roof = roof_aff = None
@@ -307,11 +328,15 @@ def main():
                 import glob
                 summ = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_summary.json')))
                 if summ:
-                    pm = json.load(open(summ[-1]))['pmc']['conv_igemm_kernel<*>']
-                    traffic = round((pm['fetch_MB_per_dispatch_x2_gfx950_corrected'] + pm['write_MB_per_dispatch']) * 1e6)
+                    pmc = json.load(open(summ[-1]))['pmc']
+                    fam = [v for k, v in pmc.items() if k.startswith(('conv_igemm_kernel', 'conv_dma_kernel', 'conv3x3_patch_kernel'))
+                           and 'fetch_MB_per_dispatch_x2_gfx950_corrected' in v and 'write_MB_per_dispatch' in v]
+                    nd = sum(v['dispatches'] for v in fam)
+                    traffic = round(sum((v['fetch_MB_per_dispatch_x2_gfx950_corrected'] + v['write_MB_per_dispatch']) * v['dispatches']
+                                        for v in fam) / nd * 1e6) if nd else None
             except Exception:
                 traffic = None
-            roof = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<*> (all conv launches of a frame)',
+            roof = {'bound': 'mfma', 'kernel': 'conv_dma_kernel<*> + conv_igemm_kernel<*> + conv_cout1 (all conv launches of a frame)',
                     'achieved': round(conv_f / conv_t / 1e12, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(conv_f / conv_t / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
                     'traffic_unit': 'HBM bytes per conv launch (rocprofv3 PMC, profiles/)',
@@ -324,10 +349,7 @@ def main():
                         'memory_tokens': n_tok_end, 'matmul': aff_parts,
                         'note': 'algorithmic = dense (256+512K)*N*HW of the reference; the kernels do the top-k readout sparsely'}
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    tmax = float(t.item())
+    tmax = elapsed                                           # already the MAX over the ranks
 
     multi = None
     if args.clips_in_flight > 1:
@@ -372,8 +394,17 @@ def main():
                     break
             cpu_t = time.perf_counter() - c0
             args.cpu_frames = n_cpu
+        ratio = None
+        try:
+            ratio = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'cpu_reference_ratio.json')))
+        except Exception:
+            pass
         cpu = {'value': round(args.cpu_frames / cpu_t, 3), 'unit': 'frames/s', 'cores': torch.get_num_threads(),
                'kind': 'port',
+               'port_over_reference': None if ratio is None else ratio['oracle_over_reference'],
+               'port_over_reference_note': None if ratio is None else
+               f"the live reference (/root/reference) and this port timed on the same {ratio['cores']} cores of the build container, same workload "
+               f"(oracle/time_reference.py): reference {ratio['reference_fps']} frames/s, port {ratio['oracle_fps']} frames/s",
                'sample': f'{args.cpu_frames} propagated frames (frames 2..{1 + args.cpu_frames}) of the same {args.width}x{args.height} '
                          f'{K}-object clip, oracle (torch fp32 restatement of the reference) on host cores, frame 0/1 excluded'}
 
@@ -390,6 +421,11 @@ def main():
                        'lookahead': 'off' if args.no_lookahead else 'step(next_image=...): the next frame\'s image encoder runs on a '
                                     'side stream (same kernels, bit-identical results)'},
         }
+        if no_la is not None:
+            out['value_no_lookahead'] = no_la['value']
+            out['no_lookahead'] = dict(no_la, note='same clip, step(image) without the next_image hint (an unchanged scripting_demo.py)')
+        if full_bank is not None:
+            out['full_bank'] = full_bank
         if roof is not None:
             out['roofline'] = roof
             out['roofline_affinity'] = roof_aff

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int STAGE_B = (BM + BN) * 128;            // bytes per ring stage
     constexpr int LDC = BN + 4;
-    static_assert(NXI >= 1 && NWI >= 1 && NXI * 8 * NW == BM && NWI * 8 * NW == BN && TM >= 1 && TN >= 1 && NS >= 2 && NS <= 4 &&
+    static_assert(NXI >= 1 && NWI >= 1 && NXI * 8 * NW == BM && NWI * 8 * NW == BN && TM >= 1 && TN >= 1 && NS >= 2 && NS <= 8 &&
                   NXI <= 4 && NWI <= 4 && (NS - 2) * LPT < 64 && NT % (BN / 8) == 0, "bad tile");
     extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
     char* const lds = reinterpret_cast<char*>(smem);
@@ -394,6 +394,14 @@ int launch_conv_dma(const ConvParams& p, int tile, hipStream_t s) {
         case 70: return launch_dma<128, 128, 2, 4, 2>(p, s);         // 8 waves, 2-deep ring: 2 blocks = 16 waves per CU
         case 71: return launch_dma<128, 64, 2, 2, 2>(p, s);          // 48 KB: 3 blocks per CU
         case 72: return launch_dma<64, 64, 2, 2, 2>(p, s);           // 32 KB: 5 blocks per CU
+        // deep rings for the small-M layers (<= ~1.5 blocks per CU anyway): an iteration there is bound by the DMA latency divided
+        // by the tiles in flight (measured: 840 cycles per K tile for 128 cycles of MFMA with 2 tiles in flight)
+        case 73: return launch_dma<64, 64, 2, 2, 6>(p, s);           // 96 KB
+        case 74: return launch_dma<64, 64, 2, 2, 8>(p, s);           // 128 KB
+        case 75: return launch_dma<32, 64, 1, 4, 8>(p, s);           // 96 KB
+        case 76: return launch_dma<128, 64, 2, 2, 5>(p, s);          // 120 KB
+        case 77: return launch_dma<64, 128, 2, 2, 5>(p, s);          // 120 KB
+        case 78: return launch_dma<32, 128, 1, 4, 6>(p, s);          // 120 KB
         default: cutie_set_error("conv: bad DMA tile id %d", tile); return -2;
     }
 }

@@ -12,6 +12,7 @@ the hardware queues and nearly double the frames/s of the GPU (DESIGN.md section
 """
 import queue
 import threading
+import time
 from typing import Callable, Dict, List, Sequence
 
 import torch
@@ -21,6 +22,36 @@ import torch.distributed as dist
 def shard_clips(num_clips: int, rank: int, world_size: int) -> List[int]:
     """Clip c runs on rank c mod world_size (the reference creates one InferenceCore per video, eval_vos.py:97)."""
     return [c for c in range(num_clips) if c % world_size == rank]
+
+
+def timed_steps(step: Callable[[int], None], steps: int, warmup: int, device) -> float:
+    """The timing protocol of bench.py (one clip per rank, weak scaling): `warmup` untimed calls of step(i), then EXACTLY `steps`
+    timed calls bracketed by a barrier + device synchronisation on both sides; returns the MAX over the ranks of the elapsed
+    seconds (all-reduce: RCCL on the GPUs, gloo in the CPU tests) -- the whole job is as slow as its slowest rank."""
+    dev = torch.device(device)
+    on_gpu = dev.type == 'cuda'
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def fence():
+        if on_gpu:
+            torch.cuda.synchronize(dev)
+        if multi:
+            dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize(dev)
+
+    for i in range(warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if on_gpu else 'cpu')
+    if multi:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def run_concurrent(net, clip_ids: Sequence[int], run_clip: Callable, *, streams: int = 4) -> Dict[int, Dict]:

@@ -46,3 +46,80 @@ def test_clip_sharding_two_ranks_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) == 'ok'
+
+
+def _model_worker(rank, world, port, out):
+    """The bench protocol (cutie_amd.parallel.timed_steps, what bench.py runs under torch.distributed.run) and the clip-sharded
+    result gather with the REAL per-frame path on every rank: InferenceCore over the launch plans, executed by the descriptor
+    interpreter (no GPU here)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    torch.set_num_threads(2)
+    from cutie_amd import _lib
+    from cutie_amd.config import default_config
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.model.cutie import CUTIE
+    from cutie_amd.parallel import run_sharded, timed_steps
+    from cutie_amd.utils.synth import SyntheticClip
+    from cutie_amd.utils.synth_weights import make_state_dict
+    from mock_exec import MockExecutor
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    _lib.set_executor_for_testing(MockExecutor())
+    cfg = default_config(mem_every=2)
+    net = CUTIE(cfg)
+    net.load_weights(make_state_dict(seed=0))
+
+    def run_clip(c, frames=4):
+        clip = SyntheticClip(48, 64, 2, frames, seed=30 + c)
+        proc = InferenceCore(net, cfg=cfg)
+        ids = []
+        with torch.inference_mode():
+            p = proc.step(clip.frame(0), clip.first_mask(), objects=clip.objects)
+            ids.append(proc.output_prob_to_mask(p, dtype=torch.uint8))
+            for t in range(1, frames):
+                ids.append(proc.output_prob_to_mask(proc.step(clip.frame(t)), dtype=torch.uint8))
+        return {'frames': frames, 'seconds': 0.1, 'masks': torch.stack(ids)}
+
+    # 1. bench.py's timed region: one clip per rank, the slower rank (rank 1 sleeps) sets the time on every rank
+    import time
+    clip = SyntheticClip(48, 64, 2, 8, seed=rank)
+    proc = InferenceCore(net, cfg=cfg)
+    with torch.inference_mode():
+        proc.step(clip.frame(0), clip.first_mask(), objects=clip.objects)
+
+        def step(i):
+            proc.step(clip.frame(1 + i % 7))
+            if rank == 1:
+                time.sleep(0.05)
+
+        t0 = time.perf_counter()
+        tmax = timed_steps(step, steps=3, warmup=1, device='cpu')
+        mine = time.perf_counter() - t0
+    both = [None, None]
+    dist.all_gather_object(both, tmax)
+    assert both[0] == both[1] and tmax >= 3 * 0.05 and tmax <= mine + 1e-3, (both, mine)
+    # 2. clips sharded over the ranks, id masks gathered on rank 0 (direct sends): identical to the same clips run locally
+    res = run_sharded(list(range(3)), run_clip, gather_masks=True)
+    if rank == 0:
+        assert sorted(res) == [0, 1, 2]
+        for c in range(3):
+            assert torch.equal(res[c]['masks'], run_clip(c)['masks']), c
+        out.put('ok')
+    else:
+        assert res is None
+    dist.destroy_process_group()
+
+
+def test_bench_protocol_and_model_two_ranks_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 30500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_model_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) == 'ok'
