@@ -330,11 +330,22 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 // MAXV per lane as order-preserving 32-bit keys; the answer is built bit by bit from the top (x |= bit while count(key >= x) >= k):
 // per step one compare-and-add per register and one wave reduction -- no LDS atomics (the 4 x 8-bit histogram version below, kept for
 // G > 4096, needed 11 us for 1620 columns of 667 values; this one ~3 us).
+// Side jobs riding on AFF_SELECT (two fill launches and two tick launches less per read-out): the candidate counters of pass 1 are
+// cleared (one int per query, stride AFF_CSTRIDE) and the life counters of up to two token ranges advance by one (USAGE_TICK).
+struct SelectSide { int* count; float* lifeA; float* lifeB; int nA, nB; };
+__device__ __forceinline__ void select_side_jobs(const SelectSide& sd, int HW) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    if (sd.count) for (int q = gid; q < HW; q += nth) sd.count[q * AFF_CSTRIDE] = 0;
+    if (sd.lifeA) for (int t = gid; t < sd.nA; t += nth) sd.lifeA[t] += 1.f;
+    if (sd.lifeB) for (int t = gid; t < sd.nB; t += nth) sd.lifeB[t] += 1.f;
+}
+
 template <int MAXV>
 __global__ __launch_bounds__(256) void aff_select_reg_kernel(const float* __restrict__ gmax, float* __restrict__ tau,
-                                                             int HW, int Gld, int G, int k) {
+                                                             int HW, int Gld, int G, int k, SelectSide sd) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + wave;
+    select_side_jobs(sd, HW);
     if (j >= HW) return;                                    // whole wave exits together
     if (G < k) { if (lane == 0) tau[j] = -INFINITY; return; }
     uint32_t key[MAXV];
@@ -360,10 +371,11 @@ __global__ __launch_bounds__(256) void aff_select_reg_kernel(const float* __rest
 
 // one wave per query column; 4 waves per block.  Exact k-th largest by 4x8-bit radix select.
 __global__ __launch_bounds__(256) void aff_select_kernel(const float* __restrict__ gmax, float* __restrict__ tau,
-                                                         int HW, int Gld, int G, int k) {
+                                                         int HW, int Gld, int G, int k, SelectSide sd) {
     __shared__ int hist[4][256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + wave;
+    select_side_jobs(sd, HW);
     if (j >= HW) return;                                    // whole wave exits together
     if (G < k) { if (lane == 0) tau[j] = -INFINITY; return; }
     uint32_t prefix = 0, mask = 0;
@@ -563,12 +575,16 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             else hipLaunchKernelGGL((aff_score_kernel<2, 1>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
             break;
         }
-        case CUTIE_OP_AFF_SELECT:
-            if (i[2] <= 1024) { hipLaunchKernelGGL(aff_select_reg_kernel<16>, dim3((i[0] + 3) / 4), dim3(256), 0, s, (const float*)p[0], (float*)p[1], i[0], (i[2] + 63) / 64 * 64, i[2], i[3]); break; }
-            if (i[2] <= 2048) { hipLaunchKernelGGL(aff_select_reg_kernel<32>, dim3((i[0] + 3) / 4), dim3(256), 0, s, (const float*)p[0], (float*)p[1], i[0], (i[2] + 63) / 64 * 64, i[2], i[3]); break; }
-            if (i[2] <= 4096) { hipLaunchKernelGGL(aff_select_reg_kernel<64>, dim3((i[0] + 3) / 4), dim3(256), 0, s, (const float*)p[0], (float*)p[1], i[0], (i[2] + 63) / 64 * 64, i[2], i[3]); break; }
-            hipLaunchKernelGGL(aff_select_kernel, dim3((i[0] + 3) / 4), dim3(256), 0, s, (const float*)p[0], (float*)p[1], i[0], (i[2] + 63) / 64 * 64, i[2], i[3]);
+        case CUTIE_OP_AFF_SELECT: {
+            SelectSide sd = {(int*)p[2], (float*)p[3], (float*)p[4], i[4], i[5]};
+            const dim3 grid((i[0] + 3) / 4), block(256);
+            const int Gld = (i[2] + 63) / 64 * 64;
+            if (i[2] <= 1024) hipLaunchKernelGGL(aff_select_reg_kernel<16>, grid, block, 0, s, (const float*)p[0], (float*)p[1], i[0], Gld, i[2], i[3], sd);
+            else if (i[2] <= 2048) hipLaunchKernelGGL(aff_select_reg_kernel<32>, grid, block, 0, s, (const float*)p[0], (float*)p[1], i[0], Gld, i[2], i[3], sd);
+            else if (i[2] <= 4096) hipLaunchKernelGGL(aff_select_reg_kernel<64>, grid, block, 0, s, (const float*)p[0], (float*)p[1], i[0], Gld, i[2], i[3], sd);
+            else hipLaunchKernelGGL(aff_select_kernel, grid, block, 0, s, (const float*)p[0], (float*)p[1], i[0], Gld, i[2], i[3], sd);
             break;
+        }
         case CUTIE_OP_AFF_READOUT: {
             if (i[2] > RO_MAXK || (i[4] & 7) || (i[1] & 3)) { cutie_set_error("aff_readout: top_k <= %d, CV %% 8, cap %% 4", RO_MAXK); return -2; }
             size_t lds = (size_t)i[1] * 8;

@@ -10,24 +10,28 @@ __device__ __forceinline__ float clamp_logit_(float p) {
     return logf(p / (1.f - p));
 }
 
-// AUX_MASK: fg[k,p] = (L_k >= max(L_bg, max_j L_j));  nfg[k] += count
+// fg[k,p] = (L_k >= max(L_bg, max_j L_j)) with L = logit of the clamped probabilities (object_transformer.py:179-205)
+__device__ __forceinline__ bool aux_fg_(const float* __restrict__ lg, int K, int HW, int k, int p) {
+    float bg = 1.f, mx = -INFINITY, mine = 0.f;
+    for (int j = 0; j < K; ++j) {
+        const float pr = 1.f / (1.f + expf(-lg[(long)j * HW + p]));
+        const float l = clamp_logit_(pr);
+        bg *= (1.f - pr);
+        mx = fmaxf(mx, l);
+        mine = j == k ? l : mine;
+    }
+    return mine >= fmaxf(mx, clamp_logit_(bg));
+}
+
+// AUX_MASK: fg bytes + nfg[k] += count.  (The frame's plans use the fused form inside ATTN_Q2P; this op stays for callers
+// that want the mask itself.)
 __global__ void aux_mask_kernel(const float* __restrict__ lg, uint8_t* __restrict__ fg, int* __restrict__ nfg, int K, int HW) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     bool valid = p < HW;
-    float bg = 1.f, mx = -INFINITY;
-    if (valid) {
-        for (int k = 0; k < K; ++k) {
-            float pr = 1.f / (1.f + expf(-lg[(long)k * HW + p]));
-            bg *= (1.f - pr);
-            mx = fmaxf(mx, clamp_logit_(pr));
-        }
-        mx = fmaxf(mx, clamp_logit_(bg));
-    }
     for (int k = 0; k < K; ++k) {
         bool f = false;
         if (valid) {
-            float pr = 1.f / (1.f + expf(-lg[(long)k * HW + p]));
-            f = clamp_logit_(pr) >= mx;
+            f = aux_fg_(lg, K, HW, k, p);
             fg[(long)k * HW + p] = f ? 1 : 0;
         }
         unsigned long long b = __ballot(f);
@@ -43,6 +47,8 @@ __global__ void aux_mask_kernel(const float* __restrict__ lg, uint8_t* __restric
 // The D layout of S^T (4 consecutive pixels of one query per lane) is used directly as the B operand of the second
 // product: the k-slot <-> pixel assignment of that MFMA is free, and V^T is gathered to match it.  Online softmax
 // state (m, l) is per query, shared by the 4 lanes of a query through two xor-shuffles.  Waves merge through LDS.
+// lg != null: the foreground mask of object k is derived here from the mask_pred logits of all K objects (AUX_MASK fused: every
+// block recomputes its object's HW flags into LDS and counts them -- two launches and a global counter less per transformer block).
 typedef __attribute__((ext_vector_type(4))) uint32_t q2p_u32x4;
 union q2p_frag { q2p_u32x4 u; bf16x8 b; };
 
@@ -54,9 +60,12 @@ __device__ __forceinline__ void split_bf2(float a, float b, uint32_t& hi, uint32
 
 __global__ __launch_bounds__(1024) void attn_q2p_kernel(const float* __restrict__ q, const bf16_t* __restrict__ kv,
                                                         const uint8_t* __restrict__ fg, const int* __restrict__ nfg,
-                                                        float* __restrict__ y, int Q, int HW, int C, int ldkv, int voff) {
+                                                        float* __restrict__ y, int Q, int HW, int C, int ldkv, int voff,
+                                                        const float* __restrict__ lg) {
     __shared__ float sO[16][16][33];                       // [wave][query][dim]
     __shared__ float sM[16][16], sL[16][16];
+    __shared__ int sCnt;
+    extern __shared__ uint8_t sFg[];                       // HW flags (fused form only)
     const int hh = blockIdx.x, k = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c16 = lane & 15, g = lane >> 4;              // c16: query (B/D column) or pixel/dim (A row)
@@ -67,14 +76,30 @@ __global__ __launch_bounds__(1024) void attn_q2p_kernel(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) { uint32_t h_, l_; split_bf2(qr[2 * j] * scale, qr[2 * j + 1] * scale, h_, l_); qh.u[j] = h_; ql.u[j] = l_; }
     }
-    const int n_fg = nfg[k];
+    int n_fg;
+    if (lg) {
+        if (threadIdx.x == 0) sCnt = 0;
+        __syncthreads();
+        int cnt = 0;
+        for (int p = threadIdx.x; p < HW; p += 1024) {
+            const bool f = aux_fg_(lg, gridDim.y, HW, k, p);
+            sFg[p] = f ? 1 : 0;
+            cnt += f ? 1 : 0;
+        }
+        cnt = wave_sum_i32(cnt);
+        if (lane == 0 && cnt) atomicAdd(&sCnt, cnt);
+        __syncthreads();
+        n_fg = sCnt;
+    } else {
+        n_fg = nfg[k];
+    }
     const bool is_fg_query = c16 < Q / 2;                  // queries 0..7 attend foreground only
     // row fully blocked -> unblocked (object_transformer.py:203)
     const bool masked = is_fg_query ? (n_fg != 0) : (n_fg != HW);
     float m = -INFINITY, l = 0.f;
     f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
     const bf16_t* kvb = kv + (long)k * HW * ldkv + hh * 32;
-    const uint8_t* fgb = fg + (long)k * HW;
+    const uint8_t* fgb = lg ? sFg : fg + (long)k * HW;
     const int nchunk = (HW + 31) >> 5;
     for (int ch = wave; ch < nchunk; ch += 16) {
         const int p0 = ch * 32;
@@ -248,8 +273,13 @@ int launch_attention(const cutie_op* op, hipStream_t s) {
             break;
         case CUTIE_OP_ATTN_Q2P:
             if (i[1] != 16 || i[3] != i[4] * 32) { cutie_set_error("attn_q2p: Q=16, head dim 32 only"); return -2; }
-            hipLaunchKernelGGL(attn_q2p_kernel, dim3(i[4], i[0]), dim3(1024), 0, s, (const float*)p[0], (const bf16_t*)p[1], (const uint8_t*)p[2],
-                               (const int*)p[3], (float*)p[4], i[1], i[2], i[3], i[5], i[6]);
+            if ((op->flags & 1) && i[2] > 24576) { cutie_set_error("attn_q2p: fused aux mask holds HW <= 24576 flags in LDS (HW=%d)", i[2]); return -2; }
+            if (op->flags & 1)                               // p2 = mask_pred logits f32 [K,HW]; fg / nfg are not read
+                hipLaunchKernelGGL(attn_q2p_kernel, dim3(i[4], i[0]), dim3(1024), (size_t)((i[2] + 15) & ~15), s, (const float*)p[0], (const bf16_t*)p[1],
+                                   (const uint8_t*)nullptr, (const int*)nullptr, (float*)p[4], i[1], i[2], i[3], i[5], i[6], (const float*)p[2]);
+            else
+                hipLaunchKernelGGL(attn_q2p_kernel, dim3(i[4], i[0]), dim3(1024), 0, s, (const float*)p[0], (const bf16_t*)p[1], (const uint8_t*)p[2],
+                                   (const int*)p[3], (float*)p[4], i[1], i[2], i[3], i[5], i[6], (const float*)nullptr);
             break;
         case CUTIE_OP_ATTN_SELF:
             if (i[1] != 16 || i[2] != i[3] * 32) { cutie_set_error("attn_self: Q=16, head dim 32 only"); return -2; }

@@ -52,25 +52,28 @@ __device__ __forceinline__ unsigned relu2(unsigned w) {         // ReLU on two p
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), (s16x2){0, 0}));
 }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, int BK>
 constexpr int dma_lds_bytes() {
-    constexpr int pipe = NS * (BM + BN) * 128, epi = BM * (BN + 4) * 4;
+    constexpr int pipe = NS * (BM + BN) * BK * 2, epi = BM * (BN + 4) * 4;
     return pipe > epi ? pipe : epi;
 }
 
 // HALO: the conv has more than one tap and / or padding (tap state + validity masks); RELU: fused input ReLU; TWO: two-source
 // (virtual concat) input.
-template <int BM, int BN, int WM, int WN, int NS, bool HALO, bool RELU, bool TWO>
+// BK: K tile (64 or 128 channels of one tap): LDS rows of BK * 2 bytes, a DMA piece = 1 KiB = RPP rows.
+template <int BM, int BN, int WM, int WN, int NS, int BK, bool HALO, bool RELU, bool TWO>
 __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
 #if __HIP_DEVICE_COMPILE__     // (the host pass only needs the launch stub; the LDS-DMA builtin and the LDS address space exist on the device side)
-    constexpr int NW = WM * WN, NT = NW * 64, CPR = 8;  // BK = 64: 8 chunks of 16 B per LDS row
-    constexpr int NXI = BM / 8 / NW;                    // X pieces (8 rows x 128 B) per wave per K tile
-    constexpr int NWI = BN / 8 / NW;                    // W pieces per wave per K tile
+    constexpr int NW = WM * WN, NT = NW * 64, CPR = BK / 8;     // 16-B chunks per LDS row
+    constexpr int RPP = 64 / CPR;                       // rows per DMA piece (8 at BK = 64, 4 at BK = 128)
+    constexpr int ROWB = BK * 2, KSTEPS = BK / 32;      // bytes per LDS row, MFMA k-steps per tile
+    constexpr int NXI = BM / RPP / NW;                  // X pieces per wave per K tile
+    constexpr int NWI = BN / RPP / NW;                  // W pieces per wave per K tile
     constexpr int LPT = NXI + NWI;                      // DMA instructions per wave per K tile
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int STAGE_B = (BM + BN) * 128;            // bytes per ring stage
+    constexpr int STAGE_B = (BM + BN) * ROWB;           // bytes per ring stage
     constexpr int LDC = BN + 4;
-    static_assert(NXI >= 1 && NWI >= 1 && NXI * 8 * NW == BM && NWI * 8 * NW == BN && TM >= 1 && TN >= 1 && NS >= 2 && NS <= 8 &&
+    static_assert((BK == 64 || BK == 128) && NXI >= 1 && NWI >= 1 && NXI * RPP * NW == BM && NWI * RPP * NW == BN && TM >= 1 && TN >= 1 && NS >= 2 && NS <= 8 &&
                   NXI <= 4 && NWI <= 4 && (NS - 2) * LPT < 64 && NT % (BN / 8) == 0, "bad tile");
     extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
     char* const lds = reinterpret_cast<char*>(smem);
@@ -98,12 +101,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
     // hardware adds to the LDS address AND to the global address; the per-lane offset of piece i is lowered by the same amount
     // (the descriptors start PRE = 4096 bytes early, so the lowered offsets stay non-negative).
     constexpr unsigned PRE = 4096;
-    const int lr = lane >> 3;                            // row inside the piece
-    const unsigned kcb = (unsigned)(((lane & 7) ^ lr) * 16);         // swizzled k-chunk (bytes): LDS slot lane & 7 holds chunk (lane & 7) ^ row
+    const int lr = lane / CPR;                           // row inside the piece
+    // swizzled k-chunk (bytes): LDS slot (lane % CPR) of row r holds chunk (lane % CPR) ^ (r % CPR') -- r % 8 = lr at BK = 64 (pieces
+    // start at multiples of 8 rows); at BK = 128 the XOR uses r % 16, which depends on the piece: added per piece below
+    const unsigned kcb = BK == 64 ? (unsigned)(((lane & 7) ^ lr) * 16) : 0u;
     unsigned xoff1[NXI], xoff2[NXI], vmask[NXI];
     {
         // (b, oh, ow) of the first piece's row by division, of the following pieces (+8 rows each) by carry
-        int m = m0 + wave * NXI * 8 + lr;
+        int m = m0 + wave * NXI * RPP + lr;
         const int mm = m < p.M ? m : p.M - 1;            // rows past the end recompute the last pixel (never stored)
         int b = mm / p.OHW;
         const int rem = mm - b * p.OHW;
@@ -113,8 +118,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
         for (int i = 0; i < NXI; ++i) {
             const int ih0 = oh * p.stride, iw0 = ow * p.stride;       // (the descriptors start at (-pad, -pad))
             const unsigned pix = (unsigned)((b * p.H + ih0) * p.W + iw0);
-            xoff1[i] = pix * (unsigned)(p.ldx1 * 2) + kcb + PRE - (unsigned)i * 1024u;
-            xoff2[i] = TWO ? pix * (unsigned)(p.ldx2 * 2) + kcb + PRE - (unsigned)i * 1024u : 0u;
+            const unsigned kx = BK == 64 ? kcb : (unsigned)(((lane & 15) ^ (((wave * NXI + i) * RPP + lr) & 15)) * 16);
+            xoff1[i] = pix * (unsigned)(p.ldx1 * 2) + kx + PRE - (unsigned)i * 1024u;
+            xoff2[i] = TWO ? pix * (unsigned)(p.ldx2 * 2) + kx + PRE - (unsigned)i * 1024u : 0u;
             unsigned mk = 0;
             if (HALO) {
                 // valid taps = (valid rows) x (valid columns): KH + KW comparisons instead of KH * KW
@@ -123,10 +129,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
                 for (int k = 0; k < p.KH; ++k) mk |= ((unsigned)(ih0 - p.pad + k) < (unsigned)p.H) ? (cols << (k * p.KW)) : 0u;
             }
             vmask[i] = mk;
-            if (i + 1 < NXI) {                           // next piece: 8 rows further
-                m += 8;
+            if (i + 1 < NXI) {                           // next piece: RPP rows further
+                m += RPP;
                 if (m < p.M) {
-                    ow += 8;
+                    ow += RPP;
                     while (ow >= p.OW) { ow -= p.OW; ++oh; }
                     while (oh >= p.OH) { oh -= p.OH; ++b; }
                 }
@@ -136,16 +142,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
     unsigned woff[NWI];
 #pragma unroll
     for (int i = 0; i < NWI; ++i)
-        woff[i] = (unsigned)((n0 + (wave * NWI + i) * 8 + lr) * p.Kpad * 2) + kcb + PRE - (unsigned)i * 1024u;
+        woff[i] = (unsigned)((n0 + (wave * NWI + i) * RPP + lr) * p.Kpad * 2) + PRE - (unsigned)i * 1024u +
+                  (BK == 64 ? kcb : (unsigned)(((lane & 15) ^ (((wave * NWI + i) * RPP + lr) & 15)) * 16));
     const long shift = (long)p.pad * p.W + p.pad;                    // pixels
     const char* xb1 = reinterpret_cast<const char*>(p.x1 - shift * p.ldx1) - PRE;
     const char* xb2 = TWO ? reinterpret_cast<const char*>(p.x2 - shift * p.ldx2) - PRE : xb1;
     const rsrc_t rw = dma_rsrc(reinterpret_cast<const char*>(p.w) - PRE), rx1 = dma_rsrc(xb1), rx2 = dma_rsrc(xb2);
     const int xdst = wave * NXI * 1024;                              // this wave's first X piece inside a stage (bytes)
-    const int wdst = BM * 128 + wave * NWI * 1024;
+    const int wdst = BM * ROWB + wave * NWI * 1024;
 
     // ---- wave-uniform K-tile state (SGPRs): byte offsets of the current tap / channel tile, all advanced incrementally ----
-    const int nk = p.Kslice / 64;
+    const int nk = p.Kslice / BK;
     int tap = 0, kw = 0;
     int cc = 0;                                          // channel offset inside Cin (bytes)
     int pixA = 0, pixB = 0;                              // byte offset of the current tap's pixel in source 1 / 2
@@ -172,8 +179,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(lds + (LD) + wdst), 16, woff[(I) < NWI ? (I) : 0], wsoff, (I) * 1024, 0);
 #define TILE_END()                                                                                         \
     {                                                                                                      \
-        wsoff += 128;                                                                                      \
-        cc += 128;                                               /* single tap, single source: soff = cc */ \
+        wsoff += ROWB;                                                                                     \
+        cc += ROWB;                                              /* single tap, single source: soff = cc */ \
         if (HALO || TWO) {                                                                                 \
             const bool wrap_ = cc >= cin2;                                                                 \
             cc = wrap_ ? 0 : cc;                                                                           \
@@ -198,11 +205,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
     const int wm = wave / WN, wn = wave % WN;
     const int pm0 = wm * (BM / WM), cn0 = wn * (BN / WN);
     const int l15 = lane & 15, l4 = lane >> 4;
-    int rdx[2], rdw[2];                                              // fragment reads of the two k-steps (bytes); tile row t adds t*16*128
+    int rdx[KSTEPS], rdw[KSTEPS];                                    // fragment reads of the k-steps (bytes); tile row t adds t*16*ROWB
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        rdx[j] = ((pm0 + l15) * CPR + ((j * 4 + l4) ^ (l15 & 7))) * 16;
-        rdw[j] = ((BM + cn0 + l15) * CPR + ((j * 4 + l4) ^ (l15 & 7))) * 16;
+    for (int j = 0; j < KSTEPS; ++j) {
+        rdx[j] = ((pm0 + l15) * CPR + ((j * 4 + l4) ^ (l15 & (CPR - 1)))) * 16;
+        rdw[j] = ((BM + cn0 + l15) * CPR + ((j * 4 + l4) ^ (l15 & (CPR - 1)))) * 16;
     }
     f32x4 acc[TN][TM];
 #pragma unroll
@@ -212,26 +219,26 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
 
 #define READ_FRAGS(J, RD, BFR, AFR)                                                                        \
     _Pragma("unroll") for (int t = 0; t < TM; ++t) {                                                       \
-        u32x4 v = *reinterpret_cast<const u32x4*>(lds + (RD) + rdx[J] + t * 16 * 128);                     \
+        u32x4 v = *reinterpret_cast<const u32x4*>(lds + (RD) + rdx[J] + t * 16 * ROWB);                     \
         if (RELU) { v.x = relu2(v.x); v.y = relu2(v.y); v.z = relu2(v.z); v.w = relu2(v.w); }              \
         BFR[t] = __builtin_bit_cast(bf16x8, v);                                                            \
     }                                                                                                      \
-    _Pragma("unroll") for (int t = 0; t < TN; ++t) AFR[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + (RD) + rdw[J] + t * 16 * 128));
+    _Pragma("unroll") for (int t = 0; t < TN; ++t) AFR[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + (RD) + rdw[J] + t * 16 * ROWB));
 #define MFMA_STEP(BFR, AFR)                                                                                \
     _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                         \
         _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                     \
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AFR[a], BFR[b], acc[a][b], 0, 0, 0);
     // Scheduling of one iteration with a load: fragments of k-step 0, then LPT groups of { MF0 MFMAs of k-step 0, one DMA piece,
-    // RPP fragment reads of k-step 1 }, then the MFMAs of k-step 1.  (Program order of the memory operations is already this;
+    // RDP fragment reads of k-step 1 }, then the MFMAs of k-step 1.  (Program order of the memory operations is already this;
     // the MFMAs, which the compiler may place anywhere, are pinned between them.)
     constexpr int NMF = TM * TN, NRD = TM + TN;
     constexpr int MF0 = NMF / LPT > 0 ? NMF / LPT : 1;  // MFMAs between two DMA pieces
-    constexpr int RPP = (NRD + LPT - 1) / LPT;          // fragment reads of k-step 1 per piece
+    constexpr int RDP = (NRD + LPT - 1) / LPT;          // fragment reads of k-step 1 per piece
 #define SCHED_GROUP(G)                                                                                     \
     if constexpr ((G) < LPT) {                                                                             \
         __builtin_amdgcn_sched_group_barrier(SG_MFMA, MF0, 0);                                             \
         __builtin_amdgcn_sched_group_barrier(SG_VMEM, 1, 0);                                               \
-        __builtin_amdgcn_sched_group_barrier(SG_DSR, RPP, 0);                                              \
+        __builtin_amdgcn_sched_group_barrier(SG_DSR, RDP, 0);                                              \
     }
 #define COMPUTE_TILE(RD, LD, DO_LOAD)                                                                      \
     {                                                                                                      \
@@ -244,6 +251,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
         if (DO_LOAD) {                                                                                     \
             __builtin_amdgcn_sched_group_barrier(SG_DSR, NRD, 0);                                          \
             SCHED_GROUP(0) SCHED_GROUP(1) SCHED_GROUP(2) SCHED_GROUP(3) SCHED_GROUP(4) SCHED_GROUP(5) SCHED_GROUP(6) SCHED_GROUP(7) \
+        }                                                                                                  \
+        if constexpr (KSTEPS == 4) {                             /* BK = 128: two more k-steps */           \
+            bf16x8 b2[TM], a2[TN], b3[TM], a3[TN];                                                         \
+            READ_FRAGS(2, RD, b2, a2)                                                                      \
+            READ_FRAGS(3, RD, b3, a3)                                                                      \
+            MFMA_STEP(b2, a2)                                                                              \
+            MFMA_STEP(b3, a3)                                                                              \
         }                                                                                                  \
     }
 
@@ -336,12 +350,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool HALO, bool RELU, bool TWO>
+template <int BM, int BN, int WM, int WN, int NS, int BK, bool HALO, bool RELU, bool TWO>
 static int launch_dma3(const ConvParams& p, hipStream_t s, int gy) {
-    constexpr int lds = dma_lds_bytes<BM, BN, NS>();
+    constexpr int lds = dma_lds_bytes<BM, BN, NS, BK>();
     static bool attr_set = false;                        // one flag per instantiation
     if (!attr_set) {
-        if (lds > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<BM, BN, WM, WN, NS, HALO, RELU, TWO>),
+        if (lds > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<BM, BN, WM, WN, NS, BK, HALO, RELU, TWO>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             cutie_set_error("conv DMA tile: cannot raise the dynamic LDS limit to %d bytes", lds);
             return -2;
@@ -349,24 +363,24 @@ static int launch_dma3(const ConvParams& p, hipStream_t s, int gy) {
         attr_set = true;
     }
     dim3 grid((p.M + BM - 1) / BM, (unsigned)gy);
-    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NS, HALO, RELU, TWO>), grid, dim3(WM * WN * 64), lds, s, p);
+    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NS, BK, HALO, RELU, TWO>), grid, dim3(WM * WN * 64), lds, s, p);
     return (int)hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, int BK = 64>
 static int launch_dma(ConvParams p, hipStream_t s) {
     const long x1_bytes = (long)p.B * p.H * p.W * p.ldx1 * 2, x2_bytes = p.C2 ? (long)p.B * p.H * p.W * p.ldx2 * 2 : 0;
     const long gy = (p.Cout + BN - 1) / BN, w_bytes = gy * BN * (long)p.Kpad * 2;
-    if (p.Kpad % 64 || p.Cin % 64 || (p.C2 && p.C1 % 64) || p.KH > 5 || p.KW > 5 || p.splitk != 1 || p.Kpad < p.KH * p.KW * p.Cin ||
+    if (p.Kpad % BK || p.Cin % BK || (p.C2 && p.C1 % BK) || p.KH > 5 || p.KW > 5 || p.splitk != 1 || p.Kpad < p.KH * p.KW * p.Cin ||
         x1_bytes >= DMA_RECORDS - 8192 || x2_bytes >= DMA_RECORDS - 8192 || w_bytes >= DMA_RECORDS - 8192) {
-        cutie_set_error("conv DMA tile: needs Cin %% 64 == 0 (C1 too for two sources), KH, KW <= 5, no split-K, operands < 2 GiB "
-                        "(Cin=%d C1=%d Kpad=%d k=%dx%d splitk=%d)", p.Cin, p.C1, p.Kpad, p.KH, p.KW, p.splitk);
+        cutie_set_error("conv DMA tile: needs Cin %% %d == 0 (C1 too for two sources), KH, KW <= 5, no split-K, operands < 2 GiB "
+                        "(Cin=%d C1=%d Kpad=%d k=%dx%d splitk=%d)", BK, p.Cin, p.C1, p.Kpad, p.KH, p.KW, p.splitk);
         return -2;
     }
     p.Kslice = p.KH * p.KW * p.Cin;                      // a multiple of 64: the zero-padded tail of Kpad is not visited
     const bool relu = p.flags & CUTIE_F_RELU_IN, two = p.C2 != 0, halo = p.pad > 0 || p.KH * p.KW > 1;
     const int g = (int)gy;
-#define DMA_GO(H_, R_, T_) return launch_dma3<BM, BN, WM, WN, NS, H_, R_, T_>(p, s, g)
+#define DMA_GO(H_, R_, T_) return launch_dma3<BM, BN, WM, WN, NS, BK, H_, R_, T_>(p, s, g)
     if (halo) {
         if (relu) { if (two) DMA_GO(true, true, true); DMA_GO(true, true, false); }
         if (two) DMA_GO(true, false, true);
@@ -402,6 +416,13 @@ int launch_conv_dma(const ConvParams& p, int tile, hipStream_t s) {
         case 76: return launch_dma<128, 64, 2, 2, 5>(p, s);          // 120 KB
         case 77: return launch_dma<64, 128, 2, 2, 5>(p, s);          // 120 KB
         case 78: return launch_dma<32, 128, 1, 4, 6>(p, s);          // 120 KB
+        // BK = 128: half the K iterations (barrier + wait + scalar bookkeeping per iteration amortised over twice the MFMAs)
+        case 80: return launch_dma<64, 64, 2, 2, 3, 128>(p, s);      // 96 KB
+        case 81: return launch_dma<64, 64, 2, 2, 2, 128>(p, s);      // 64 KB: 2 blocks per CU
+        case 82: return launch_dma<32, 64, 1, 4, 3, 128>(p, s);      // 72 KB: 2 blocks per CU
+        case 83: return launch_dma<32, 64, 1, 4, 4, 128>(p, s);      // 96 KB
+        case 84: return launch_dma<64, 128, 2, 4, 2, 128>(p, s);     // 8 waves, 96 KB
+        case 85: return launch_dma<128, 64, 4, 2, 2, 128>(p, s);     // 8 waves, 96 KB
         default: cutie_set_error("conv: bad DMA tile id %d", tile); return -2;
     }
 }

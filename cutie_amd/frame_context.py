@@ -7,32 +7,38 @@ to ride on the tensors as Python attributes, which breaks as soon as a caller re
 has a slow path that recomputes the companion when nothing is registered (a third-party caller of the six ``CUTIE`` methods).
 
 An entry holds references to its payload tensors, so the address it is keyed by cannot be recycled for another tensor while the
-entry lives; the table is a small LRU (frames in flight x a handful of entries)."""
+entry lives; the table is a small LRU (frames in flight x a handful of entries) PER HOST THREAD: a clip is driven by one thread
+(cutie_amd/parallel.py), and a table shared by several clips in flight let a fast clip evict the entries a slow one was about to
+look up.  (An entry made on one thread and looked up on another is simply not found: slow path.)"""
 import threading
 from collections import OrderedDict
 
 _MAX = 96
-_lock = threading.Lock()
-_table = OrderedDict()          # (kind, data_ptr) -> (payload, pinned tensors)
+_local = threading.local()
+
+
+def _table():
+    t = getattr(_local, 'table', None)
+    if t is None:
+        t = _local.table = OrderedDict()          # (kind, data_ptr) -> (payload, pinned tensors)
+    return t
 
 
 def remember(kind, tensor, payload, pin=()):
     """Attach `payload` to the storage address of `tensor` (a later entry for the same address replaces it)."""
     key = (kind, tensor.data_ptr())
-    with _lock:
-        _table.pop(key, None)
-        _table[key] = (payload, (tensor,) + tuple(pin))
-        while len(_table) > _MAX:
-            _table.popitem(last=False)
+    t = _table()
+    t.pop(key, None)
+    t[key] = (payload, (tensor,) + tuple(pin))
+    while len(t) > _MAX:
+        t.popitem(last=False)
 
 
 def recall(kind, tensor):
     """Payload registered for this tensor's storage address (None if unknown: the caller takes its slow path)."""
-    with _lock:
-        hit = _table.get((kind, tensor.data_ptr()))
+    hit = _table().get((kind, tensor.data_ptr()))
     return None if hit is None else hit[0]
 
 
 def forget(kind, tensor):
-    with _lock:
-        _table.pop((kind, tensor.data_ptr()), None)
+    _table().pop((kind, tensor.data_ptr()), None)

@@ -106,13 +106,14 @@ class InferenceCore:
             return
         src_key = self._frame_key(image)
         main = torch.cuda.current_stream(dev)
-        prepared, _ = self._prepare_image(image)               # (conversion, if any, runs on the caller's stream)
+        prepared, (h0, w0, H, W, pad) = self._prepare_image(image)      # (conversion, if any, runs on the caller's stream)
+        geometry = (h0, w0, H, W, pad[0], pad[2])
         if self._enc_stream is None:
             self._enc_stream = torch.cuda.Stream(device=dev)
         enc = self._enc_stream
         enc.wait_stream(main)                                  # frame conversion + any earlier encoder run on the main stream
         with torch.cuda.stream(enc):
-            ms_features, pix_feat = self.network._encode_image_raw(prepared, *frame_context.recall('geometry', prepared))
+            ms_features, pix_feat = self.network._encode_image_raw(prepared, *geometry)
             key, shrinkage, selection = self.network.transform_key(ms_features[0])
             if affinity:
                 self.memory.prefetch_affinity(key, selection, self.network)
@@ -124,7 +125,7 @@ class InferenceCore:
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(main)                          # allocated on the side stream, consumed on the main one
         # (the source tensor is kept referenced until the next step: its address cannot be recycled for another frame)
-        self._prefetched = (src_key, prepared, feats, ev, image)
+        self._prefetched = (src_key, prepared, feats, ev, image, geometry)
 
     def _resize(self, x: torch.Tensor, size, *, nearest: bool = False) -> torch.Tensor:
         """F.interpolate(x[None], size, bilinear align_corners=False | nearest-exact)[0] for f32 [C,H,W] as the RESIZE kernel."""
@@ -250,7 +251,8 @@ class InferenceCore:
             image = pre[1]
             torch.cuda.current_stream(image.device).wait_event(pre[3])
             self.image_feature_store._store[self.curr_ti] = pre[2]
-            h0, w0, H, W, pl, pt = frame_context.recall('geometry', image)
+            h0, w0, H, W, pl, pt = pre[5]
+            frame_context.remember('geometry', image, pre[5])    # (for _add_memory / a third-party consumer of this frame)
             self.pad = pad_geometry(h0, w0, 16)[2]
         else:
             if pre is not None:                                # stale look-ahead: order the encoder plan's buffers, drop it

@@ -130,7 +130,7 @@ class MemoryManager:
 
     def _affinity(self, bucket: Bucket, q, h: int, w: int, dev, tag: str = '') -> torch.Tensor:
         """Affinity read-out of one bucket for the query operands q: similarity -> exact top-k -> softmax -> sparse value gather
-        (+ usage bookkeeping), 5-6 launches on the current stream.  Returns readout bf16 [K, h, w, CV].  `tag` selects a second set
+        (+ usage bookkeeping), 4 launches on the current stream.  Returns readout bf16 [K, h, w, CV].  `tag` selects a second set
         of scratch buffers (the look-ahead lane of `prefetch_affinity` runs on another stream)."""
         HW = h * w
         HWp = q['Bhi'].shape[0]
@@ -158,17 +158,18 @@ class MemoryManager:
         if cached is None or cached[0] != key:
             D = O.Dyn
             ol = O.OpList()
-            ol.memset32(D('count'), HW * O.OpList.AFF_CSTRIDE, 0)
             common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=CAND_CAP)
             ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('gmax'), None, None, None, mode=0, **common)
-            ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k)
+            # usage bookkeeping (kv_memory_store.py:151-162): life += 1 for every counted token -- rides on the selection launch,
+            # as does the clearing of pass 1's candidate counters
+            ticks = []
+            if tick_work:
+                ticks.append((D('life', 4 * bucket.work_start), bucket.n_work))
+            if tick_long:
+                ticks.append((D('life'), bucket.n_long))
+            ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), ticks=ticks)
             ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('tau'), D('cval'), D('cidx'), D('count'),
                          mode=1, gmax_precedes_tau=True, **common)
-            # usage bookkeeping (kv_memory_store.py:151-162): life += 1 for every counted token
-            if tick_work:
-                ol.usage_tick(D('life', 4 * bucket.work_start), bucket.n_work)
-            if tick_long:
-                ol.usage_tick(D('life'), bucket.n_long)
             ol.aff_readout(D('cval'), D('cidx'), D('count'), D('vptrs'), D('usage') if self.use_long_term else None, D('readout'),
                            D('ovf'), HW=HW, cap=CAND_CAP, top_k=self.top_k, K=K, CV=self.CV)
             if self.use_long_term and bucket.n_long > 0 and not self.count_long_term_usage:

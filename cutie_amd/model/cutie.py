@@ -326,7 +326,8 @@ class CUTIE(nn.Module):
         # query-side affinity operands: rows [hw, HWp) are padding that must stay zero and is never written, so a small
         # rotating pool of buffers zeroed once replaces three fill launches per frame (at most two frames' features are
         # alive at a time: the current one and the look-ahead)
-        pool = eng.__dict__.setdefault('_qpool', {}).setdefault((HWp, str(dev)), {'n': 0, 'bufs': []})
+        pool = eng.__dict__.setdefault('_qpool', {}).setdefault((hw, HWp, str(dev)), {'n': 0, 'bufs': []})   # keyed by hw too: another
+        # resolution with the same padded size would leave its rows in the padding
         if len(pool['bufs']) < 4:
             pool['bufs'].append((torch.zeros((HWp, 128), dtype=BF16, device=dev), torch.zeros((HWp, 128), dtype=BF16, device=dev),
                                  torch.zeros((HWp,), dtype=F32, device=dev)))

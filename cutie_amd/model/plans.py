@@ -300,10 +300,12 @@ def build_readout_query(eng, K, h, w):
     pixel_pe = Act(both.t.view(-1)[C:], K, h, w, C, 2 * C)
     R_all = P.conv(t + '.pe_proj_all', pixel_pe, name='R_all')                   # [Wk.pe | 0 | Wq2.pe] of every block
     aux = f('aux_logits', (nb + 1, K, HW))
-    fg = P.buf('fg', (K, HW), torch.uint8)
-    nfg = P.buf('nfg', (K,), torch.int32)
+    fused_mask = HW <= 24576                      # ATTN_Q2P derives the foreground mask from the logits itself (flags in LDS)
+    fg = None if fused_mask else P.buf('fg', (K, HW), torch.uint8)
+    nfg = None if fused_mask else P.buf('nfg', (K,), torch.int32)
     P.conv(t + '.mask_pred.0.1', pixel, relu_in=True, out_f32=True, out=Act(aux[0], K, h, w, 1))
-    ol.aux_mask(aux[0], fg, nfg, K=K, HW=HW)
+    if not fused_mask:
+        ol.aux_mask(aux[0], fg, nfg, K=K, HW=HW)
     x = query
     for b in range(nb):
         q = f'{t}.blocks.{b}'
@@ -317,7 +319,7 @@ def build_readout_query(eng, K, h, w):
         qp = f(n + 'qp', (M, C))
         ol.linear(x, W[q + '.read_from_pixel.q'], qp, M=M, x_add=query_emb, add_rows=M, ln=ln('.read_from_pixel.norm'), ln_out=xn)
         att = f(n + 'att', (M, C))
-        ol.attn_q2p(qp, kvq.t, fg, nfg, att, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C)
+        ol.attn_q2p(qp, kvq.t, fg, nfg, att, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=aux[b] if fused_mask else None)
         x1 = f(n + 'x1', (M, C))
         ol.linear(att, W[q + '.read_from_pixel.out'], x1, M=M, res=xn)
         # self attention (transformer_layers.py:28-41): q | k | v in one launch, the query PE feeds q and k only
@@ -344,7 +346,7 @@ def build_readout_query(eng, K, h, w):
         last = b == nb - 1
         pixel = P.ca_block(q + '.pixel_ffn.conv', pf, n + 'ffn', out=Act(Dyn('out'), K, h, w, C) if last else None)
         P.conv(f'{t}.mask_pred.{b + 1}.1', pixel, relu_in=True, out_f32=True, out=Act(aux[b + 1], K, h, w, 1))
-        if not last:
+        if not last and not fused_mask:
             ol.aux_mask(aux[b + 1], fg, nfg, K=K, HW=HW)
     return P
 

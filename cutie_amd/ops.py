@@ -56,7 +56,8 @@ EXPERIMENTAL_TILES = {50: (128, 64, 64), 51: (64, 64, 64), 52: (64, 128, 64), 53
 # instructions per MFMA.  id -> (BM, BN, BK); needs Cin % 64 == 0 (both sources of a virtual concat), no split-K.
 DMA_TILES = {60: (128, 128, 64), 61: (128, 128, 64), 62: (128, 128, 64), 63: (128, 64, 64), 64: (64, 128, 64), 65: (64, 64, 64),
              66: (64, 64, 64), 67: (32, 64, 64), 68: (256, 128, 64), 69: (32, 128, 64), 70: (128, 128, 64), 71: (128, 64, 64),
-             72: (64, 64, 64), 73: (64, 64, 64), 74: (64, 64, 64), 75: (32, 64, 64), 76: (128, 64, 64), 77: (64, 128, 64), 78: (32, 128, 64)}
+             72: (64, 64, 64), 73: (64, 64, 64), 74: (64, 64, 64), 75: (32, 64, 64), 76: (128, 64, 64), 77: (64, 128, 64), 78: (32, 128, 64),
+             80: (64, 64, 128), 81: (64, 64, 128), 82: (32, 64, 128), 83: (32, 64, 128), 84: (64, 128, 128), 85: (128, 64, 128)}
 
 
 ALL_TILES = {**TILES, **DMA_TILES}
@@ -67,8 +68,10 @@ def dma_tiles_enabled():
 
 
 def dma_tile_ok(tile, *, cin, kh, c2=0):
-    """conv_dma_kernel eligibility (mirrors launch_dma in conv_dma.hip): a 64-channel K tile never straddles a tap or a source."""
-    return cin % 64 == 0 and (c2 == 0 or (c2 % 64 == 0 and (cin - c2) % 64 == 0)) and kh * kh <= 32
+    """conv_dma_kernel eligibility (mirrors launch_dma in conv_dma.hip): a K tile (64 or 128 channels) never straddles a tap or a
+    source."""
+    bk = DMA_TILES[tile][2]
+    return cin % bk == 0 and (c2 == 0 or (c2 % bk == 0 and (cin - c2) % bk == 0)) and kh * kh <= 32
 
 
 def experimental_tiles_enabled():
@@ -126,7 +129,8 @@ def tile_candidates(M, cout, cin, kpad=None, geom=None):
         out.append(t)
     if dma_tiles_enabled() and geom is not None and dma_tile_ok(60, cin=cin, kh=geom['kh'], c2=geom.get('c2', 0)):
         for t, (bm, bn, bk) in DMA_TILES.items():
-            if not (bn == 128 and cout <= 64) and not (bm > 64 and bm > max(M, 64)) and not (bm == 256 and M < 16384):
+            if not (bn == 128 and cout <= 64) and not (bm > 64 and bm > max(M, 64)) and not (bm == 256 and M < 16384) \
+                    and dma_tile_ok(t, cin=cin, kh=geom['kh'], c2=geom.get('c2', 0)):
                 out.append(t)
     if experimental_tiles_enabled() and geom is not None:
         for t, (bm, bn, bk) in EXPERIMENTAL_TILES.items():
@@ -344,7 +348,10 @@ class OpList:
         self.memset32(nfg, K, 0)
         return self.add(AUX_MASK, 0, [K, HW], [], [logits, fg, nfg])
 
-    def attn_q2p(self, q, kv, fg, nfg, y, *, K, Q, HW, C, heads, ldkv, voff):
+    def attn_q2p(self, q, kv, fg, nfg, y, *, K, Q, HW, C, heads, ldkv, voff, logits=None):
+        """logits given: the foreground mask is derived inside the kernel from the mask_pred logits (AUX_MASK fused; fg / nfg unused)."""
+        if logits is not None:
+            return self.add(ATTN_Q2P, 1, [K, Q, HW, C, heads, ldkv, voff], [], [q, kv, logits, None, y])
         return self.add(ATTN_Q2P, 0, [K, Q, HW, C, heads, ldkv, voff], [], [q, kv, fg, nfg, y])
 
     def attn_self(self, qk, v, y, *, K, Q, C, heads, ldqk=0, ldv=0):
@@ -378,8 +385,11 @@ class OpList:
         ints += [G, cap, mode]
         return self.add(AFF_SCORE, 1 if (gmax_precedes_tau and mode == 1) else 0, ints, [], [Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count])
 
-    def aff_select(self, gmax, tau, *, HW, HWp, G, top_k):
-        return self.add(AFF_SELECT, 0, [HW, HWp, G, top_k], [], [gmax, tau])
+    def aff_select(self, gmax, tau, *, HW, HWp, G, top_k, clear_count=None, ticks=()):
+        """clear_count: pass 1's candidate counters, zeroed here; ticks: up to two (life, n) ranges advanced by one (USAGE_TICK)."""
+        ticks = list(ticks) + [(None, 0)] * (2 - len(ticks))
+        assert len(ticks) == 2
+        return self.add(AFF_SELECT, 0, [HW, HWp, G, top_k, ticks[0][1], ticks[1][1]], [], [gmax, tau, clear_count, ticks[0][0], ticks[1][0]])
 
     def aff_readout(self, cand_val, cand_idx, count, vptrs, usage, y, overflow, *, HW, cap, top_k, K, CV):
         return self.add(AFF_READOUT, 0, [HW, cap, top_k, K, CV], [], [cand_val, cand_idx, count, vptrs, usage, y, overflow])

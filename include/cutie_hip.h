@@ -136,7 +136,8 @@ enum {
     /* ATTN_Q2P: masked cross attention, 16 object queries <- HW pixels, 8 heads x 32
      * transformer_layers.py:45-98 (nn.MultiheadAttention core), object_transformer.py:56-61
      * p0=q f32 [K,Q,C] (projected) p1=kv bf16 [K,HW,ldkv] (k at +0, v at +voff) p2=fg u8 [K,HW]
-     * p3=nfg i32 [K] p4=y f32 [K,Q,C]   i: 0 K 1 Q 2 HW 3 C 4 heads 5 ldkv 6 voff */
+     * p3=nfg i32 [K] p4=y f32 [K,Q,C]   i: 0 K 1 Q 2 HW 3 C 4 heads 5 ldkv 6 voff
+     * flags&1: AUX_MASK fused -- p2=mask_pred logits f32 [K,HW] instead of fg, p3 unused (HW <= 24576) */
     CUTIE_OP_ATTN_Q2P = 18,
     /* ATTN_SELF: 16x16 self attention per object  transformer_layers.py:12-41
      * p0=qk f32 [K,Q,ldqk] (q at +0, k at +C) p1=v f32 [K,Q,ldv] p2=y f32 [K,Q,C]
@@ -170,7 +171,9 @@ enum {
      *      (16-token tile, 16-query set) whose maximum is below the set's thresholds is skipped (same result, ~1/6 of the MFMA work) */
     CUTIE_OP_AFF_SCORE = 24,
     /* AFF_SELECT: tau_j = top_k-th largest of gmax[:,j] (or -inf if G < top_k)
-     * p0=gmax f32 [HWp,Gld] p1=tau f32 [HW]   i: 0 HW 1 HWp 2 G 3 top_k */
+     * p0=gmax f32 [HWp,Gld] p1=tau f32 [HW]   i: 0 HW 1 HWp 2 G 3 top_k
+     * optional side jobs (0 = none): p2=count i32 [HW*32]: count[32 q] = 0 for every query (pass 1's candidate counters);
+     *      p3=life f32 [i4], p4=life f32 [i5]: += 1 (USAGE_TICK of two token ranges) */
     CUTIE_OP_AFF_SELECT = 25,
     /* AFF_READOUT: exact top-k of the candidates (ties -> lower slot), softmax, usage += w,
      * readout[o,j,:] = sum_i w_i V_o[i,:]    memory_utils.py:58-63,75; memory_manager.py:77-88

@@ -308,8 +308,14 @@ class MockExecutor:
         q = view(p[0], F32, (K, Q, C)).view(K, Q, heads, hd).transpose(1, 2)
         k = view(p[1], BF16, (K, HW, C), (HW * ldkv, ldkv, 1)).float().view(K, HW, heads, hd).transpose(1, 2)
         v = view(p[1] + 2 * voff, BF16, (K, HW, C), (HW * ldkv, ldkv, 1)).float().view(K, HW, heads, hd).transpose(1, 2)
-        fg = view(p[2], U8, (K, HW)).bool()
-        nfg = view(p[3], I32, (K,))
+        if flags & 1:                                                   # AUX_MASK fused: p2 = logits
+            pr = torch.sigmoid(view(p[2], F32, (K, HW)))
+            lg = torch.cat([_clamp_logit(torch.prod(1 - pr, dim=0, keepdim=True)), _clamp_logit(pr)], 0)
+            fg = lg[1:] >= lg.max(0, keepdim=True)[0]
+            nfg = fg.sum(1).to(torch.int32)
+        else:
+            fg = view(p[2], U8, (K, HW)).bool()
+            nfg = view(p[3], I32, (K,))
         att = (q @ k.transpose(-1, -2)) / math.sqrt(hd)                 # [K,heads,Q,HW]
         for kk in range(K):
             n = int(nfg[kk])
@@ -430,6 +436,11 @@ class MockExecutor:
         Gld = -(-G // 64) * 64
         gmax = view(p[0], F32, (HWp, Gld))[:HW, :G]
         tau = view(p[1], F32, (HW,))
+        if p[2]:                                                        # side jobs: clear pass 1's counters, advance life counters
+            view(p[2], I32, (HW, 32))[:, 0] = 0
+        for slot, n in ((3, i[4]), (4, i[5])):
+            if p[slot] and n > 0:
+                view(p[slot], F32, (n,)).add_(1.0)
         if G < k:
             tau.fill_(float('-inf'))
         else:

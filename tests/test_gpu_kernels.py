@@ -155,6 +155,8 @@ DMA_CASES = BUFLOAD_CASES + [
     dict(B=1, H=16, W=16, C1=2048, Cout=64, k=1),                                         # long K loop (32 tiles)
     dict(B=1, H=12, W=20, C1=64, Cout=64, k=1),                                           # one K tile: shorter than the ring
     dict(B=1, H=12, W=20, C1=128, Cout=64, k=1, act=O.ACT_SIGMOID, out_f32=True),        # two K tiles
+    dict(B=2, H=21, W=19, C1=128, C2=256, Cout=130, k=3, relu_in=True, out_f32=True),    # two sources, both multiples of 128
+    dict(B=1, H=23, W=31, C1=384, Cout=72, k=3, stride=2, act=O.ACT_RELU),               # 3 K tiles of 128 per tap, stride 2
 ]
 
 
@@ -163,7 +165,9 @@ DMA_CASES = BUFLOAD_CASES + [
 def test_conv_dma_tiles(ci, tile):
     """conv_dma_kernel (tiles 60..: LDS-DMA staging, halo by out-of-range buffer offsets) against the interpreter."""
     c = DMA_CASES[ci]
-    assert O.dma_tile_ok(tile, cin=c['C1'] + c.get('C2', 0), kh=c['k'], c2=c.get('C2', 0))
+    if not O.dma_tile_ok(tile, cin=c['C1'] + c.get('C2', 0), kh=c['k'], c2=c.get('C2', 0)):
+        assert O.DMA_TILES[tile][2] == 128
+        pytest.skip('128-channel K tile: sources are not multiples of 128')
     hip, ref = run_both(_conv_build(c, tile), seed=400 + ci)
     check(hip, ref, f'dma[{ci}] tile{tile}')
 
@@ -490,6 +494,23 @@ def test_aux_mask_and_q2p(mode):
         return ol, {'fg': fg, 'nfg': nfg, 'y': y}
     check(*run_both(build), name=f'aux_mask/q2p {mode}', rtol=3e-3)
 
+    def build_fused(dev, g):                       # the form the frame uses: mask derived inside ATTN_Q2P, bit-identical to the two-op form
+        K, Q, HW, C, heads = 3, 16, 1620, 256, 8
+        lg = _aux_inputs(g, K, HW, mode).to(dev)
+        fg = torch.zeros((K, HW), dtype=torch.uint8, device=dev)
+        nfg = torch.zeros((K,), dtype=torch.int32, device=dev)
+        q = torch.randn((K, Q, C), generator=g).to(dev)
+        kv = rnd(g, (K, HW, 3 * C), dev=dev)
+        y, y2 = (torch.zeros((K, Q, C), dtype=F32, device=dev) for _ in range(2))
+        ol = O.OpList()
+        ol.aux_mask(lg, fg, nfg, K=K, HW=HW)
+        ol.attn_q2p(q, kv, fg, nfg, y, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C)
+        ol.attn_q2p(q, kv, None, None, y2, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg)
+        return ol, {'y': y, 'y2': y2}
+    hip, ref = run_both(build_fused)
+    check(hip, ref, name=f'q2p fused aux mask {mode}', rtol=3e-3)
+    assert torch.equal(hip['y'], hip['y2'])
+
 
 def test_attn_self_and_p2q():
     def build(dev, g):
@@ -561,14 +582,22 @@ def _affinity_build(HW, ranges, slots, K, top_k, with_usage, dup=False, skip=Tru
         ol.keep += vals
         ol.key_prep(mkey, mshr, Ahi, Alo, scale, n=slots, query=False)
         ol.key_prep(qkey, qsel, Bhi, Blo, cq, n=HW, query=True)
-        ol.memset32(count, HW * 32, 0)
+        life = torch.arange(slots + 16, dtype=F32).to(dev)
         common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=cap)
+        if skip:                                   # the frame's form: stale counters, cleared by the selection launch, which also ticks
+            count += 5
+        else:
+            ol.memset32(count, HW * 32, 0)
         ol.aff_score(Ahi, Alo, scale, Bhi, Blo, cq, gmax, None, None, None, mode=0, **common)
-        ol.aff_select(gmax, tau, HW=HW, HWp=HWp, G=G, top_k=top_k)
+        if skip:
+            ol.aff_select(gmax, tau, HW=HW, HWp=HWp, G=G, top_k=top_k, clear_count=count,
+                          ticks=[(life[8:], slots // 2), (life, 5)])
+        else:
+            ol.aff_select(gmax, tau, HW=HW, HWp=HWp, G=G, top_k=top_k)
         ol.aff_score(Ahi, Alo, scale, Bhi, Blo, cq, tau, cval, cidx, count, mode=1, gmax_precedes_tau=skip, **common)
         ol.aff_readout(cval, cidx, count, vptrs, usage, y, ovf, HW=HW, cap=cap, top_k=top_k, K=K, CV=CV)
         outs = {'Ahi': Ahi, 'Alo': Alo, 'scale': scale, 'Bhi': Bhi, 'Blo': Blo, 'cq': cq, 'tau': tau, 'y': y, 'ovf': ovf,
-                'gmax': gmax[:HW, :G], 'count': count}
+                'gmax': gmax[:HW, :G], 'count': count.view(HW, 32)[:, 0], 'life': life}
         if with_usage:
             outs['usage'] = usage
         # dense fp32 reference of the reference algorithm (memory_utils.py) for the oracle-level check
@@ -598,6 +627,7 @@ def test_affinity_pipeline(case, skip):
     if G < case['top_k']:
         assert bool(torch.isinf(hip['tau']).all()) and bool((hip['tau'] < 0).all())      # "take everything"
     assert int(hip['ovf']) == 0
+    assert torch.equal(hip['life'], ref['life'])
     check({'y': hip['y']}, {'y': ref['y']}, 'aff readout')
     if case['usage']:
         check({'usage': hip['usage']}, {'usage': ref['usage']}, 'aff usage', rtol=1e-4)

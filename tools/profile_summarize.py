@@ -31,6 +31,23 @@ if st:
            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])]
 else:
     fam = []
+# per-stream occupancy of the steady state (last 40 % of the dispatches): which HIP stream is the critical path of a frame
+streams = {}
+kt = glob.glob(os.path.join(src, 'stats', '**', '*kernel_trace.csv'), recursive=True)
+if kt:
+    tr = list(csv.DictReader(open(kt[0])))
+    tr.sort(key=lambda r: int(r['Start_Timestamp']))
+    tr = tr[int(len(tr) * 0.6):]
+    key = 'Stream_Id' if tr and 'Stream_Id' in tr[0] else 'Queue_Id'
+    span = (int(tr[-1]['End_Timestamp']) - int(tr[0]['Start_Timestamp'])) / 1e6 if tr else 0.0
+    per = collections.defaultdict(lambda: [0, 0.0, collections.Counter()])
+    for r in tr:
+        a = per[r[key]]
+        d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
+        a[0] += 1; a[1] += d; a[2][short(r['Kernel_Name'])] += d
+    streams = {'keyed_by': key, 'span_ms': round(span, 3),
+               'streams': {k: {'dispatches': v[0], 'busy_ms': round(v[1], 3), 'busy_over_span': round(v[1] / span, 3) if span else None,
+                               'top': [[n, round(t, 3)] for n, t in v[2].most_common(6)]} for k, v in per.items()}}
 pm = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 for f in glob.glob(os.path.join(src, 'pmc*', '**', '*counter_collection.csv'), recursive=True):
@@ -57,5 +74,6 @@ for k, c in pm.items():
 json.dump({'command': 'rocprofv3 --kernel-trace --stats / --pmc <set> --kernel-trace -- python bench.py --steps 60 --warmup 10 --preroll 60 '
                       '--cpu-frames 0 --no-roofline --clips-in-flight 0 (tools/profile_round.sh; separate passes for the SQ set, FETCH_SIZE, WRITE_SIZE)',
            'notes': 'sums over every dispatch of the run (incl. the conv autotune trials at the first frames); GRBM_GUI_ACTIVE is summed over the 8 XCCs',
-           'families_by_time': fam, 'pmc': kern}, open(f'profiles/{rnd}_summary.json', 'w'), indent=1)
+           'families_by_time': fam, 'streams_steady_state': streams, 'pmc': kern}, open(f'profiles/{rnd}_summary.json', 'w'), indent=1)
 print(json.dumps(fam[:12], indent=0))
+print(json.dumps(streams, indent=0)[:3000])

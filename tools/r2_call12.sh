@@ -1,0 +1,9 @@
+OUT=gpurun_out/c12; mkdir -p $OUT
+timeout 600 python -m pytest tests/test_gpu_kernels.py -q -k "dma or eca or gap or ca_block" > $OUT/1_kernel_tests.log 2>&1; tail -3 $OUT/1_kernel_tests.log
+timeout 1200 python tools/conv_sweep.py --objects 3 1 2 --out $OUT/conv_sweep > $OUT/2_sweep.log 2>&1; tail -2 $OUT/2_sweep.log
+for v in old new; do
+if [ $v = new ]; then cp $OUT/conv_sweep_tiles.json cutie_amd/tiles_gfx950.json; fi
+timeout 300 python bench.py --steps 300 --warmup 20 --cpu-frames 0 --clips-in-flight 0 --full-bank-preroll 0 > $OUT/3_bench_$v.json 2> $OUT/3_bench_$v.err
+python -c "
+import json; d=json.loads(open('$OUT/3_bench_$v.json').read().strip().split('\n')[-1]); print('$v table:', d['value'], 'fps', d['ms_per_step'], 'no-lookahead', d.get('value_no_lookahead'), 'conv ms', d['roofline']['ms_per_frame'], 'frac', d['roofline']['frac'])"
+done
