@@ -24,11 +24,16 @@ def _table():
     return t
 
 
-def remember(kind, tensor, payload, pin=()):
-    """Attach `payload` to the storage address of `tensor` (a later entry for the same address replaces it)."""
+def remember(kind, tensor, payload, pin=(), cap=None):
+    """Attach `payload` to the storage address of `tensor` (a later entry for the same address replaces it).  cap: keep at most this
+    many entries of `kind` (large payloads -- whole feature maps -- of which only the last frames can still be asked for)."""
     key = (kind, tensor.data_ptr())
     t = _table()
     t.pop(key, None)
+    if cap is not None:
+        same = [k for k in t if k[0] == kind]
+        for k in same[:max(0, len(same) - cap + 1)]:
+            del t[k]
     t[key] = (payload, (tensor,) + tuple(pin))
     while len(t) > _MAX:
         t.popitem(last=False)

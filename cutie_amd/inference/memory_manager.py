@@ -23,6 +23,7 @@ from .object_manager import ObjectManager
 log = logging.getLogger()
 BF16, F32 = torch.bfloat16, torch.float32
 CAND_CAP = 1024          # candidate slots per query column (typical fill ~35; see csrc/affinity.hip)
+_UNFUSED = os.environ.get('CUTIE_AMD_UNFUSED', '0') not in ('', '0')      # diagnostic A/B switch, see model/plans.py
 _VALIDATE = os.environ.get('CUTIE_AMD_VALIDATE', '0') not in ('', '0')
 
 
@@ -167,7 +168,13 @@ class MemoryManager:
                 ticks.append((D('life', 4 * bucket.work_start), bucket.n_work))
             if tick_long:
                 ticks.append((D('life'), bucket.n_long))
-            ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), ticks=ticks)
+            if _UNFUSED:
+                ol.memset32(D('count'), HW * O.OpList.AFF_CSTRIDE, 0)
+                ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k)
+                for life, n in ticks:
+                    ol.usage_tick(life, n)
+            else:
+                ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), ticks=ticks)
             ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('tau'), D('cval'), D('cidx'), D('count'),
                          mode=1, gmax_precedes_tau=True, **common)
             ol.aff_readout(D('cval'), D('cidx'), D('count'), D('vptrs'), D('usage') if self.use_long_term else None, D('readout'),
@@ -230,12 +237,36 @@ class MemoryManager:
                     all_readout[obj] = readout_memory[:, i]
                 chunks.append((objects, readout_memory))
                 if self.save_aux:
-                    self.aux = {'sensory': this_sensory, 'pixel_readout': pixel_readout,
-                                'q_logits': aux_features['logits'] if aux_features else None}
+                    self.aux = self._aux_output(this_sensory, pixel_readout, aux_features)
             self._last_readout = chunks[0] if len(chunks) == 1 else (None, None)
         if _VALIDATE:
             self.check_overflow()
         return all_readout
+
+    @staticmethod
+    def _aux_output(sensory, pixel_readout, aux_features) -> dict:
+        """cfg.save_aux (memory_manager.py:197-206): the intermediate tensors of the last object chunk, under the reference's keys.
+        The reference itself cannot produce this dict in eval mode (it indexes aux_features['attn_mask'], which QueryTransformer
+        only fills while training: KeyError on the first read -- tests/golden/edge_cases.json, save_aux_on_read), so this is the
+        intended content rather than an observed one: logits are copies (the plan's buffers are rewritten by the next frame),
+        attn_mask is object_transformer.py:179-205 applied to the last block's logits, head 0, as float [1,K,Q,h,w] (1 = blocked);
+        the attention weights are not kept by the fused attention kernels (None, as with need_weights=False)."""
+        logits = [t.float().clone() for t in aux_features['logits']] if aux_features else None
+        attn_mask = None
+        if logits:
+            lg = logits[-1]                                               # [1,K,h,w]
+            prob = torch.sigmoid(lg)
+            bg = torch.prod(1 - prob, dim=1, keepdim=True).clamp(1e-7, 1 - 1e-7)
+            pr = prob.clamp(1e-7, 1 - 1e-7)
+            agg = torch.cat([torch.log(bg / (1 - bg)), torch.log(pr / (1 - pr))], 1)
+            fg = agg[:, 1:] >= agg.max(dim=1, keepdim=True)[0]            # [1,K,h,w]
+            Q = 16
+            m = torch.cat([(~fg).unsqueeze(2).expand(-1, -1, Q // 2, -1, -1), fg.unsqueeze(2).expand(-1, -1, Q // 2, -1, -1)], 2).clone()
+            full = m.flatten(3).all(-1)                                   # a fully blocked row is un-blocked (:203)
+            m[full] = False
+            attn_mask = m.float()
+        return {'sensory': sensory, 'pixel_readout': pixel_readout, 'q_logits': logits, 'q_weights': None, 'p_weights': None,
+                'attn_mask': attn_mask}
 
     def check_overflow(self) -> int:
         """Number of queries whose candidate list overflowed CAND_CAP since the last check (their top-k was taken from a

@@ -7,8 +7,9 @@ only encodes the PNG.  ``save_scores`` (multi-scale testing, :94,195-209): proba
 truncation) ON THE DEVICE, so the copy is 4x smaller too; the reference stores them with hickle (HDF5, lzf), which is not in
 this image, so the container here is ``<frame>.npz`` (key ``prob``) and ``backward.npz`` (keys ``obj_ids`` / ``tmp_ids``) --
 ``cutie_amd.merge_multi_scale`` reads these (and ``.hkl`` when hickle is importable).  Not supported (raise): the BURST
-json writer (``init_json``).
-Long ids (RGB masks) are written as id = R + 256 G + 65536 B, the inverse of VideoReader's decoding."""
+json writer (``init_json``: its RLE masks need pycocotools, which is not in this image).
+Long ids (RGB masks): as in the reference (:171-178) every object gets a random colour (utils/pano_utils.ID2RGBConverter), NOT the
+inverse of VideoReader's R + 256 G + 65536 B decoding.  Behaviour recorded from the executed reference: tests/golden/io/."""
 import logging
 import os
 import shutil
@@ -22,6 +23,8 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 from PIL import Image
+
+from ...utils.pano_utils import ID2RGBConverter
 
 log = logging.getLogger()
 
@@ -74,6 +77,7 @@ class ResultSaver:
         if self.visualize:
             self.colors = np.array(self.palette, dtype=np.uint8).reshape(-1, 3) if self.palette is not None else davis_palette_np
         self.need_remapping = True
+        self.id2rgb_converter = ID2RGBConverter()
         self.queue: Queue = Queue(maxsize=10)
         self.thread = Thread(target=_writer, args=(self.queue,), daemon=True)
         self.thread.start()
@@ -116,7 +120,9 @@ def _writer(queue: Queue):
             if s.save_mask:
                 if s.use_long_id:
                     m = out_mask.astype(np.uint32)
-                    rgb_mask = np.stack([m & 255, (m >> 8) & 255, (m >> 16) & 255], -1).astype(np.uint8)
+                    rgb_mask = np.zeros((*m.shape[-2:], 3), dtype=np.uint8)
+                    for oid in job.all_obj_ids:
+                        rgb_mask[m == oid] = s.id2rgb_converter.convert(oid)[1]
                     out_img = Image.fromarray(rgb_mask)
                 else:
                     out_img = Image.fromarray(out_mask.astype(np.uint8))

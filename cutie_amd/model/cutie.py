@@ -338,9 +338,16 @@ class CUTIE(nn.Module):
         out = dict(f16=e((1, h, w, ms[0])), f8=e((1, 2 * h, 2 * w, ms[1])), f4=e((1, 4 * h, 4 * w, ms[2])),
                    pix_feat=e((1, h, w, m['pixel_dim'])), key=e((hw, m['key_dim']), F32), shr=e((hw,), F32),
                    sel=e((hw, m['key_dim']), F32), Bhi=qb[0], Blo=qb[1], cq=qb[2])
+        W_ = eng.w
+        out.update(f8p=e((1, 2 * h, 2 * w, W_['mask_decoder.decoder_feat_proc.transforms.0'].cout)),
+                   f4p=e((1, 4 * h, 4 * w, W_['mask_decoder.decoder_feat_proc.transforms.1'].cout)),
+                   fuse_xt=e((1, h, w, W_['pixel_fuser.fuser.distributor.x_transform'].cout)))
         image = image.to(F32).contiguous()
         P.run(image=image, **out)
         out['h'], out['w'] = h, w
+        # image-only results that the decoder / pixel fuser consume (found by the address of the feature they derive from)
+        frame_context.remember('decoder_feats', out['f8'], (out['f8p'], out['f4p'], out['f4']), cap=4)
+        frame_context.remember('fuse_xt', out['pix_feat'], out['fuse_xt'], cap=4)
         return out
 
     def encode_image(self, image: torch.Tensor) -> (Iterable[torch.Tensor], torch.Tensor):
@@ -448,9 +455,10 @@ class CUTIE(nn.Module):
         K, h, w = px.shape[:3]
         _, sb = self._sensory_pair(sensory)
         lm = last_mask[0].to(F32).contiguous()
-        P = eng.plan(('fuse', K, h, w), plans.build_pixel_fusion, K, h, w)
+        xt = None if plans.UNFUSED else frame_context.recall('fuse_xt', pf)             # x_transform(pix_feat), computed with the encoder (None: a caller's own features)
+        P = eng.plan(('fuse', K, h, w, xt is not None), plans.build_pixel_fusion, K, h, w, xt is not None)
         fused = torch.empty((K, h, w, self.embed_dim), dtype=BF16, device=self.device)
-        P.run(pix_feat=pf, pixel=px, sensory_bf16=sb, last_mask=lm, fused=fused)
+        P.run(pix_feat=pf, pixel=px, sensory_bf16=sb, last_mask=lm, fused=fused, **({} if xt is None else {'fuse_xt': xt}))
         return group_logical(fused)
 
     def readout_query(self, pixel_readout, obj_memory, *, selector=None, need_weights=False):
@@ -479,10 +487,14 @@ class CUTIE(nn.Module):
         K, h, w = p16.shape[:3]
         f8, f4 = nhwc_of(ms_image_feat[1]), nhwc_of(ms_image_feat[2])
         sf, sb = self._sensory_pair(sensory)
-        P = eng.plan(('seg', K, h, w, bool(update_sensory)), plans.build_segment, K, h, w, bool(update_sensory))
+        pre = None if plans.UNFUSED else frame_context.recall('decoder_feats', f8)     # decoder_feat_proc(f8, f4), computed with the encoder
+        if pre is not None and pre[2].data_ptr() != f4.data_ptr():
+            pre = None                                         # (f8 of one frame with f4 of another: a caller's own mix)
+        P = eng.plan(('seg', K, h, w, bool(update_sensory), pre is not None), plans.build_segment, K, h, w, bool(update_sensory), pre is not None)
         prob = torch.empty((K + 1, 16 * h, 16 * w), dtype=F32, device=dev)
         lup = torch.empty((K + 1, 16 * h, 16 * w), dtype=F32, device=dev) if _need_logits else None
-        P.run(f8=f8, f4=f4, p16=p16, sensory_f32=sf, sensory_bf16=sb, prob=prob, logits_up=lup)
+        feats = dict(f8=f8, f4=f4) if pre is None else dict(f8p=pre[0], f4p=pre[1])
+        P.run(p16=p16, sensory_f32=sf, sensory_bf16=sb, prob=prob, logits_up=lup, **feats)
         new_sens = group_logical(sf)
         frame_context.remember('sensory_bf16', sf, sb)
         return new_sens, (lup.unsqueeze(0) if lup is not None else None), prob.unsqueeze(0)

@@ -51,6 +51,8 @@ TUNE_REPS, TUNE_ITERS = (int(v) for v in os.environ.get('CUTIE_AMD_TUNE', '3x8')
 # Timing-based tile selection for conv geometries that are NOT in the tuned table is opt-in ($CUTIE_AMD_AUTOTUNE=1, or
 # Engine.autotune = True): timing is noisy, and a different (tile, split-K) changes the fp32 summation order, so by default such
 # geometries take the deterministic static choice of ops.pick_tile and results are bit-reproducible across processes.
+# diagnostic: $CUTIE_AMD_UNFUSED=1 restores the unfused launch sequences of round 1 for in-box A/B timing (tools/r2_call*.sh)
+UNFUSED = os.environ.get('CUTIE_AMD_UNFUSED', '0') not in ('', '0')
 AUTOTUNE = os.environ.get('CUTIE_AMD_AUTOTUNE', '0') not in ('', '0')
 PACKAGED_TILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tiles_gfx950.json')
 
@@ -188,9 +190,10 @@ class Plan:
         self.ol.eca_apply(t2.t, gap, self.eng.w[prefix + '.conv.weight'], x.t, out.t, B=x.B, HW=HW, C=x.C)
         return out
 
-    def fusion_block(self, prefix, x, g, name, out=None):
-        """GroupFeatureFusionBlock (group_modules.py:102-127)."""
-        xt = self.conv(prefix + '.distributor.x_transform', x, name=name + '.xt')
+    def fusion_block(self, prefix, x, g, name, out=None, xt=None):
+        """GroupFeatureFusionBlock (group_modules.py:102-127).  xt: x_transform(x) computed elsewhere (the encoder plan)."""
+        if xt is None:
+            xt = self.conv(prefix + '.distributor.x_transform', x, name=name + '.xt')
         g0 = self.conv(prefix + '.distributor.g_transform', g, name=name + '.g0', res=xt, res_bcast=True)
         g1 = self.ca_block(prefix + '.block1', g0, name + '.b1')
         return self.ca_block(prefix + '.block2', g1, name + '.b2', out=out)
@@ -237,8 +240,16 @@ def build_encode(eng, h0, w0, H, W, pad_left, pad_top):
     taps = {'res2': Act(Dyn('f4'), 1, h4, w4, ms[2]), 'layer2': Act(Dyn('f8'), 1, h8, w8, ms[1]),
             'layer3': Act(Dyn('f16'), 1, h, w, ms[0])}
     f16, _ = P.resnet('pixel_encoder', x, taps)
-    P.conv('pix_feat_proj', f16, out=Act(Dyn('pix_feat'), 1, h, w, m['pixel_dim']))
+    pix = P.conv('pix_feat_proj', f16, out=Act(Dyn('pix_feat'), 1, h, w, m['pixel_dim']))
     build_key_ops(P, f16, h, w)
+    # Image-only convolutions of the mask decoder and the pixel fuser (DecoderFeatureProcessor, big_modules.py:244-255; the
+    # x_transform of MainToGroupDistributor, group_modules.py:112-115): they do not depend on the memory, so they run here -- with the
+    # look-ahead encoder on the side stream, off the frame's critical path -- and reach their consumers through frame_context.
+    W_ = eng.w
+    for wname, src, dname in (('mask_decoder.decoder_feat_proc.transforms.0', taps['layer2'], 'f8p'),
+                              ('mask_decoder.decoder_feat_proc.transforms.1', taps['res2'], 'f4p'),
+                              ('pixel_fuser.fuser.distributor.x_transform', pix, 'fuse_xt')):
+        P.conv(wname, src, out=Act(Dyn(dname), 1, src.H, src.W, W_[wname].cout))
     P.meta.update(h=h, w=w)
     return P
 
@@ -260,9 +271,10 @@ def build_transform_key(eng, h, w):
     return P
 
 
-def build_pixel_fusion(eng, K, h, w):
+def build_pixel_fusion(eng, K, h, w, pre=False):
     """CUTIE.pixel_fusion (cutie.py:142-157; big_modules.py:207-235).
-    dyn in: pix_feat, pixel (readout) bf16 [K,h,w,CV], sensory_bf16 [K,h,w,CS], last_mask f32 [K,16h,16w].
+    dyn in: pix_feat, pixel (readout) bf16 [K,h,w,CV], sensory_bf16 [K,h,w,CS], last_mask f32 [K,16h,16w];
+    pre: fuse_xt bf16 [1,h,w,CE] = x_transform(pix_feat) from the encoder plan instead of pix_feat.
     dyn out: fused bf16 [K,h,w,CE]."""
     P = Plan(eng)
     m = eng.m
@@ -272,8 +284,9 @@ def build_pixel_fusion(eng, K, h, w):
     pixel = Act(Dyn('pixel'), K, h, w, m['value_dim'])
     p16 = P.conv('pixel_fuser.sensory_compress', Act(Dyn('sensory_bf16'), K, h, w, m['sensory_dim']),
                  x2=Act(pair, K, h, w, 8), res=pixel, name='p16')
+    xt = Act(Dyn('fuse_xt'), 1, h, w, eng.w['pixel_fuser.fuser.distributor.x_transform'].cout) if pre else None
     P.fusion_block('pixel_fuser.fuser', Act(Dyn('pix_feat'), 1, h, w, m['pixel_dim']), p16, 'fuse',
-                   out=Act(Dyn('fused'), K, h, w, m['embed_dim']))
+                   out=Act(Dyn('fused'), K, h, w, m['embed_dim']), xt=xt)
     return P
 
 
@@ -300,7 +313,7 @@ def build_readout_query(eng, K, h, w):
     pixel_pe = Act(both.t.view(-1)[C:], K, h, w, C, 2 * C)
     R_all = P.conv(t + '.pe_proj_all', pixel_pe, name='R_all')                   # [Wk.pe | 0 | Wq2.pe] of every block
     aux = f('aux_logits', (nb + 1, K, HW))
-    fused_mask = HW <= 24576                      # ATTN_Q2P derives the foreground mask from the logits itself (flags in LDS)
+    fused_mask = HW <= 24576 and not UNFUSED                      # ATTN_Q2P derives the foreground mask from the logits itself (flags in LDS)
     fg = None if fused_mask else P.buf('fg', (K, HW), torch.uint8)
     nfg = None if fused_mask else P.buf('nfg', (K,), torch.int32)
     P.conv(t + '.mask_pred.0.1', pixel, relu_in=True, out_f32=True, out=Act(aux[0], K, h, w, 1))
@@ -351,10 +364,11 @@ def build_readout_query(eng, K, h, w):
     return P
 
 
-def build_segment(eng, K, h, w, update_sensory):
+def build_segment(eng, K, h, w, update_sensory, pre=False):
     """CUTIE.segment -> MaskDecoder.forward + sigmoid/aggregate/x4/softmax (cutie.py:172-203;
     big_modules.py:257-306; modules.py:8-68).
     dyn in: f8, f4 (bf16), p16 (memory readout) bf16 [K,h,w,C], sensory_f32 / sensory_bf16 [K,h,w,CS] (in-place).
+    pre: f8p, f4p (decoder_feat_proc of f8 / f4, from the encoder plan) instead of f8, f4.
     dyn out: prob f32 [K+1,16h,16w] (+ logits_up if bound)."""
     P = Plan(eng)
     m, ol = eng.m, P.ol
@@ -362,8 +376,11 @@ def build_segment(eng, K, h, w, update_sensory):
     ms = m['pixel_encoder']['ms_dims']
     CS = m['sensory_dim']
     h8, w8, h4, w4 = 2 * h, 2 * w, 4 * h, 4 * w
-    f8p = P.conv('mask_decoder.decoder_feat_proc.transforms.0', Act(Dyn('f8'), 1, h8, w8, ms[1]), name='f8p')
-    f4p = P.conv('mask_decoder.decoder_feat_proc.transforms.1', Act(Dyn('f4'), 1, h4, w4, ms[2]), name='f4p')
+    if pre:
+        f8p, f4p = Act(Dyn('f8p'), 1, h8, w8, up[0]), Act(Dyn('f4p'), 1, h4, w4, up[1])
+    else:
+        f8p = P.conv('mask_decoder.decoder_feat_proc.transforms.0', Act(Dyn('f8'), 1, h8, w8, ms[1]), name='f8p')
+        f4p = P.conv('mask_decoder.decoder_feat_proc.transforms.1', Act(Dyn('f4'), 1, h4, w4, ms[2]), name='f4p')
     p16 = Act(Dyn('p16'), K, h, w, up[0])
     u8 = P.buf('u8', (K, h8, w8, up[0]))
     ol.upsample2x_add(p16.t, f8p.t, u8, B=K, h=h, w=w, C=up[0])

@@ -227,6 +227,26 @@ def case_object_manager_empty_one_hot(make):
     return [list(oh.shape), str(oh.dtype)]
 
 
+def case_save_aux_on_read(make):
+    p, c = make({'save_aux': True}), _clip()                       # memory_manager.py:197-206 (KeyError in eval mode, see INTENDED)
+    p.step(c.frame(0), c.first_mask(), objects=c.objects)
+    p.step(c.frame(1))
+    aux = p.memory.aux
+    return {k: (None if aux[k] is None else ([list(t.shape) for t in aux[k]] if isinstance(aux[k], (list, tuple)) else list(aux[k].shape)))
+            for k in sorted(aux)}
+
+
+# where the product deliberately does not reproduce the reference: case -> (product outcome, why)
+INTENDED = {
+    'object_manager_tmp_to_obj_mapping': (['ok', {'3': 1, '7': 2}],
+                                          'the reference method unpacks (tmp id, object) the wrong way round and always raises'),
+    'save_aux_on_read': (['ok', {'attn_mask': [1, 3, 16, 5, 7], 'p_weights': None, 'pixel_readout': [1, 3, 256, 5, 7],
+                                 'q_logits': [[1, 3, 5, 7]] * 4, 'q_weights': None, 'sensory': [1, 3, 256, 5, 7]}],
+                         "memory_manager.py:197-206 reads aux_features['attn_mask'], which only exists in training mode: the reference "
+                         'raises KeyError on the first read with save_aux; the product returns the dict the code intends'),
+}
+
+
 CASES = {n[5:]: f for n, f in sorted(globals().items()) if n.startswith('case_')}
 
 

@@ -342,6 +342,11 @@ class OracleProcessor:
                 rq = self.net.readout_query(fused, om)
                 for i, o in enumerate(sub):
                     out[o] = rq[:, i]
+                if self.cfg.get('save_aux', False):
+                    # memory_manager.py:197-206 builds the aux dict from aux_features['attn_mask'], which QueryTransformer only
+                    # sets in training mode (object_transformer.py:171-175): with save_aux the EXECUTED reference raises here on
+                    # the first read (recorded in tests/golden/edge_cases.json)
+                    raise KeyError('attn_mask')
         return out
 
     # ---- memory write (memory_manager.py:210-296, 309-358) -------------------------

@@ -29,11 +29,7 @@ def product_net():
     _lib.set_executor_for_testing(prev)
 
 
-# where the product deliberately does not reproduce the reference: case -> (product outcome, why)
-INTENDED = {
-    'object_manager_tmp_to_obj_mapping': (['ok', {'3': 1, '7': 2}],
-                                          'the reference method unpacks (tmp id, object) the wrong way round and always raises'),
-}
+from oracle.edge_cases import INTENDED      # where the product deliberately does not reproduce the reference
 
 
 def test_every_case_is_recorded():

@@ -100,7 +100,7 @@ def test_eval_driver_writes_palette_pngs(tmp_path, product_net):
 
 def test_video_reader_options_and_long_ids(tmp_path):
     """start / end / reverse / enabled_frame_list / to_save / use_all_masks, RGB long-id masks (id = R + 256 G + 65536 B) and the
-    long-id writer (inverse mapping); make_zip layouts."""
+    long-id writer (random colour per object, as the reference); make_zip layouts."""
     import shutil
     from cutie_amd.inference.data.video_reader import VideoReader
     from cutie_amd.inference.object_manager import ObjectManager
@@ -134,8 +134,13 @@ def test_video_reader_options_and_long_ids(tmp_path):
     prob = torch.zeros(3, 32, 48); prob[0] = 0.4; prob[1, 15:30, 10:40] = 0.9; prob[2, 4:12, 5:20] = 0.9
     saver.process(prob, '00000.jpg')
     saver.end()
+    # the long-id writer gives every object a random colour (reference results_utils.py:171-178 + pano_utils.py; recorded
+    # behaviour: tests/test_io_fixtures_cpu.py): one colour per object, background black, the object's pixels exactly
     back = np.array(Image.open(os.path.join(out, 'v', '00000.png'))).astype(np.int64)
-    assert np.array_equal(back[..., 0] + 256 * back[..., 1] + 65536 * back[..., 2], ids)
+    code = back[..., 0] + 256 * back[..., 1] + 65536 * back[..., 2]
+    colours = {int(i): set(code[ids == i].tolist()) for i in (0, 300, 70000)}
+    assert colours[0] == {0} and all(len(colours[i]) == 1 for i in (300, 70000)) and colours[300] != colours[70000]
+    assert all(next(iter(colours[i])) >= 255 for i in (300, 70000))
     with pytest.raises(NotImplementedError):
         ResultSaver(out, 'v', dataset='burst-val', object_manager=om, use_long_id=False)
     # archive layouts

@@ -111,13 +111,13 @@ def test_edge_cases_on_gpu(gpu_net):
     """tests/golden/edge_cases.json (outcomes recorded from the executed reference) through the HIP path."""
     import json, os
     from cutie_amd.inference.inference_core import InferenceCore
-    from oracle.edge_cases import CASES, run_case
+    from oracle.edge_cases import CASES, INTENDED, run_case
     gold = json.load(open(os.path.join(S.GOLDEN_DIR, 'edge_cases.json')))
     net = gpu_net
     bad = {}
     for name in sorted(CASES):
         got = run_case(name, lambda over: _CudaInputs(InferenceCore(net, cfg=default_config(**over))))
-        want = {'object_manager_tmp_to_obj_mapping': ['ok', {'3': 1, '7': 2}]}.get(name, gold[name])   # see test_edge_cases_cpu.INTENDED
+        want = INTENDED[name][0] if name in INTENDED else gold[name]
         if got != want:
             bad[name] = (got, want)
     assert not bad, bad
