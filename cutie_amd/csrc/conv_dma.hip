@@ -37,7 +37,11 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 // DMA into the stage just multiplied and, with no latency cushion at all, the epilogue's ds_write into the ring.
 #define WAIT_VMCNT_LDS(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (((N) >> 4) << 14) | (7 << 4) | (0 << 8))
 // Raw s_barrier (no vmcnt drain), fenced for the compiler: no LDS access or DMA may move across it.
+#ifdef DMA_ABL_NO_BARRIER                                 // (ablation, see DMA_ISSUE below)
+#define TILE_SYNC(N) { WAIT_VMCNT_LDS(N); asm volatile("" ::: "memory"); }
+#else
 #define TILE_SYNC(N) { WAIT_VMCNT_LDS(N); asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+#endif
 // instruction classes of __builtin_amdgcn_sched_group_barrier
 #define SG_MFMA 0x8
 #define SG_VMEM 0x20
@@ -152,7 +156,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
     const int wdst = BM * ROWB + wave * NWI * 1024;
 
     // ---- wave-uniform K-tile state (SGPRs): byte offsets of the current tap / channel tile, all advanced incrementally ----
+#ifdef DMA_ABL_NO_LOOP
+    const int nk = 0;
+#else
     const int nk = p.Kslice / BK;
+#endif
     int tap = 0, kw = 0;
     int cc = 0;                                          // channel offset inside Cin (bytes)
     int pixA = 0, pixB = 0;                              // byte offset of the current tap's pixel in source 1 / 2
@@ -168,15 +176,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
     const bool in1_ = !TWO || cc < c12;                          /* uniform: scalar selects, no branch */  \
     const unsigned soff_ = (unsigned)(in1_ ? pixA + cc : pixB + cc - c12);                                 \
     const rsrc_t rx_ = in1_ ? rx1 : rx2;
+// Ablation switches for tools/ablate_conv.sh (extra diagnostic libraries; never defined in the product build): which of the three
+// streams of the K loop -- LDS-DMA fill, fragment reads, MFMA -- bounds a layer.  Results are garbage with any of them.
+#ifdef DMA_ABL_NO_DMA
+#define DMA_ISSUE(...) ((void)0)
+#else
+#define DMA_ISSUE(...) __builtin_amdgcn_raw_ptr_buffer_load_lds(__VA_ARGS__)
+#endif
 #define XPIECE(I, LD)                                                                                      \
     if constexpr ((I) < NXI) {                                                                             \
         const unsigned v_ = in1_ ? xoff1[(I) < NXI ? (I) : 0] : xoff2[(I) < NXI ? (I) : 0];               \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_, LDS_PTR(lds + (LD) + xdst), 16,                      \
+        DMA_ISSUE(rx_, LDS_PTR(lds + (LD) + xdst), 16,                                                     \
             (!HALO || (vmask[(I) < NXI ? (I) : 0] & tapbit_)) ? v_ : DMA_OOB, soff_, (I) * 1024, 0);       \
     }
 #define WPIECE(I, LD)                                                                                      \
     if constexpr ((I) < NWI)                                                                               \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(lds + (LD) + wdst), 16, woff[(I) < NWI ? (I) : 0], wsoff, (I) * 1024, 0);
+        DMA_ISSUE(rw, LDS_PTR(lds + (LD) + wdst), 16, woff[(I) < NWI ? (I) : 0], wsoff, (I) * 1024, 0);
 #define TILE_END()                                                                                         \
     {                                                                                                      \
         wsoff += ROWB;                                                                                     \
@@ -217,6 +232,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+#ifdef DMA_ABL_NO_DSREAD
+#define READ_FRAGS(J, RD, BFR, AFR)                                                                        \
+    _Pragma("unroll") for (int t = 0; t < TM; ++t) { u32x4 v = {(unsigned)(RD) + t, (unsigned)lane, 3u, (unsigned)(J)}; BFR[t] = __builtin_bit_cast(bf16x8, v); } \
+    _Pragma("unroll") for (int t = 0; t < TN; ++t) { u32x4 v = {(unsigned)(RD) + t, (unsigned)lane, 5u, (unsigned)(J)}; AFR[t] = __builtin_bit_cast(bf16x8, v); }
+#else
 #define READ_FRAGS(J, RD, BFR, AFR)                                                                        \
     _Pragma("unroll") for (int t = 0; t < TM; ++t) {                                                       \
         u32x4 v = *reinterpret_cast<const u32x4*>(lds + (RD) + rdx[J] + t * 16 * ROWB);                     \
@@ -224,10 +244,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
         BFR[t] = __builtin_bit_cast(bf16x8, v);                                                            \
     }                                                                                                      \
     _Pragma("unroll") for (int t = 0; t < TN; ++t) AFR[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + (RD) + rdw[J] + t * 16 * ROWB));
+#endif
+#ifdef DMA_ABL_NO_MFMA
+#define MFMA_STEP(BFR, AFR)                                                                                \
+    _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                         \
+        _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                     \
+            acc[a][b][0] += __uint_as_float(__builtin_bit_cast(u32x4, AFR[a]).x ^ __builtin_bit_cast(u32x4, BFR[b]).y);
+#else
 #define MFMA_STEP(BFR, AFR)                                                                                \
     _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                         \
         _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                     \
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AFR[a], BFR[b], acc[a][b], 0, 0, 0);
+#endif
     // Scheduling of one iteration with a load: fragments of k-step 0, then LPT groups of { MF0 MFMAs of k-step 0, one DMA piece,
     // RDP fragment reads of k-step 1 }, then the MFMAs of k-step 1.  (Program order of the memory operations is already this;
     // the MFMAs, which the compiler may place anywhere, are pinned between them.)
@@ -293,6 +321,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
 #undef XPIECE
 #undef TILE_BEGIN
 
+#ifdef DMA_ABL_NO_EPILOGUE
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
     // ---- epilogue: fp32 tile transposed through LDS, 16-B accesses along the channel axis; bias already in registers ----
     float* ctile = reinterpret_cast<float*>(smem);       // the loop ended with a barrier: the operand ring is dead
 #pragma unroll

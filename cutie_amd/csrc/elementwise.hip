@@ -162,6 +162,32 @@ __global__ void mask_down_mean_kernel(const float* __restrict__ m, float* __rest
     acc = wave_sum(acc);
     if (lane == 0) m16[idx] = acc / (float)(r * r);
 }
+// Both steps in one launch: one wave per output pixel walks the K objects (means in object order, then the pairs from the means it
+// has just written).  Same sums in the same order as the two kernels below.
+__global__ void mask_down_pair_kernel(const float* __restrict__ m, float* __restrict__ m16, uint4* __restrict__ y, int K, int H, int W, int r) {
+    const int h = H / r, w = W / r, hw = h * w;
+    const long px = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (px >= hw) return;                                   // whole wave
+    const int ox = px % w, oy = px / w;
+    float sum = 0.f;
+    for (int k = 0; k < K; ++k) {
+        float acc = 0.f;
+        for (int e = lane; e < r * r; e += 64) {
+            const int dy = e / r, dx = e - dy * r;
+            acc += m[((long)k * H + oy * r + dy) * W + ox * r + dx];
+        }
+        acc = wave_sum(acc) / (float)(r * r);
+        sum += acc;
+        if (lane == 0) m16[(long)k * hw + px] = acc;
+    }
+    if (lane == 0)
+        for (int k = 0; k < K; ++k) {
+            const float mk = m16[(long)k * hw + px];             // written by this lane above
+            const float others = fminf(fmaxf(sum - mk, 0.f), 1.f);
+            y[(long)k * hw + px] = make_uint4(pack_bf2(mk, others), 0u, 0u, 0u);
+        }
+}
 // m16 f32 [K,hw] -> pair bf16 [K,hw,8] = (mask, others, 0...)
 __global__ void mask_pair_kernel(const float* __restrict__ m16, uint4* __restrict__ y, int K, int hw) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -336,6 +362,57 @@ __global__ void up4_softmax_kernel(const float* __restrict__ agg, float* __restr
         float v = w00 * a[o00] + w01 * a[o01] + w10 * a[o10] + w11 * a[o11];
         prob[c * OHW + idx] = expf(v - mx) * inv;
     }
+}
+
+// SEG_AGG + UP4_SOFTMAX in one launch (flags&1 of UP4_SOFTMAX, P <= 16): the aggregated logits of the 4 bilinear taps are
+// recomputed per output pixel from the K raw logits (K sigmoids + K+1 logs per tap) instead of being staged in a [P,h,w] buffer by
+// a launch of their own; the P interpolated values stay in registers for max / sum / normalise.  Same operations in the same
+// order as the two-launch form: bit-identical.
+template <int PMAX>
+__global__ void up4_softmax_fused_kernel(const float* __restrict__ lg, float* __restrict__ prob, float* __restrict__ lup,
+                                         int K, int h, int w) {
+    const int OH = 4 * h, OW = 4 * w;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)OH * OW) return;
+    const int ox = idx % OW, oy = idx / OW;
+    int y0, y1, x0, x1; float ly, lx;
+    up_coord(oy, h, 0.25f, y0, y1, ly);
+    up_coord(ox, w, 0.25f, x0, x1, lx);
+    const float wt[4] = {(1.f - ly) * (1.f - lx), (1.f - ly) * lx, ly * (1.f - lx), ly * lx};
+    const long off[4] = {(long)y0 * w + x0, (long)y0 * w + x1, (long)y1 * w + x0, (long)y1 * w + x1};
+    const long hw = (long)h * w, OHW = (long)OH * OW;
+    float v[PMAX];
+#pragma unroll
+    for (int c = 0; c < PMAX; ++c) v[c] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float bg = 1.f;
+#pragma unroll
+        for (int k = 0; k < PMAX - 1; ++k)
+            if (k < K) {
+                const float pr = 1.f / (1.f + expf(-lg[(long)k * hw + off[t]]));
+                bg *= (1.f - pr);
+                const float a = wt[t] * clamp_logit(pr);
+                v[k + 1] = t == 0 ? a : v[k + 1] + a;
+            }
+        const float a = wt[t] * clamp_logit(bg);
+        v[0] = t == 0 ? a : v[0] + a;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < PMAX; ++c)
+        if (c <= K) {
+            if (lup) lup[c * OHW + idx] = v[c];
+            mx = fmaxf(mx, v[c]);
+        }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < PMAX; ++c)
+        if (c <= K) { v[c] = expf(v[c] - mx); sum += v[c]; }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int c = 0; c < PMAX; ++c)
+        if (c <= K) prob[c * OHW + idx] = v[c] * inv;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -762,8 +839,7 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             long n = (long)K * h * w;
             float* m16 = (float*)p[2];
             if (!m16) { cutie_set_error("mask_down: m16 buffer required"); return -2; }
-            hipLaunchKernelGGL(mask_down_mean_kernel, GRID1D(n * 64, BS), dim3(BS), 0, s, (const float*)p[0], m16, K, i[1], i[2], r);
-            hipLaunchKernelGGL(mask_pair_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const float*)m16, (uint4*)p[1], K, h * w);
+            hipLaunchKernelGGL(mask_down_pair_kernel, GRID1D((long)h * w * 64, BS), dim3(BS), 0, s, (const float*)p[0], m16, (uint4*)p[1], K, i[1], i[2], r);
             break;
         }
         case CUTIE_OP_GAP: {
@@ -792,6 +868,12 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             break;
         case CUTIE_OP_UP4_SOFTMAX: {
             long n = (long)16 * i[1] * i[2];
+            if (op->flags & 1) {                              // p0 = raw logits [K,h,w] (K = P - 1): SEG_AGG fused
+                if (i[0] > 16) { cutie_set_error("up4_softmax: the fused form holds P <= 16 planes in registers (P=%d)", i[0]); return -2; }
+                if (i[0] <= 8) hipLaunchKernelGGL(up4_softmax_fused_kernel<8>, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, i[1], i[2]);
+                else hipLaunchKernelGGL(up4_softmax_fused_kernel<16>, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, i[1], i[2]);
+                break;
+            }
             hipLaunchKernelGGL(up4_softmax_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0], i[1], i[2]);
             break;
         }

@@ -408,9 +408,12 @@ def build_segment(eng, K, h, w, update_sensory, pre=False):
         vals = P.conv('mask_decoder.sensory_update.transform', g3, x2=Act(Dyn('sensory_bf16'), K, h, w, CS),
                       out_f32=True, name='gru_vals')
         ol.gru(vals.t, Dyn('sensory_f32'), Dyn('sensory_bf16'), n=K * h * w, C=CS)
-    agg = P.buf('agg', (K + 1, h4, w4), F32)
-    ol.seg_agg(logits, agg, K=K, hw=h4 * w4)
-    ol.up4_softmax(agg, Dyn('prob'), Dyn('logits_up'), P=K + 1, h=h4, w=w4)
+    if K + 1 <= 16 and not UNFUSED:               # aggregation recomputed per bilinear tap inside the up-sampling launch
+        ol.up4_softmax(logits, Dyn('prob'), Dyn('logits_up'), P=K + 1, h=h4, w=w4, from_logits=True)
+    else:
+        agg = P.buf('agg', (K + 1, h4, w4), F32)
+        ol.seg_agg(logits, agg, K=K, hw=h4 * w4)
+        ol.up4_softmax(agg, Dyn('prob'), Dyn('logits_up'), P=K + 1, h=h4, w=w4)
     return P
 
 

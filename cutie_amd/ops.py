@@ -319,8 +319,9 @@ class OpList:
     def seg_agg(self, logits, agg, *, K, hw):
         return self.add(SEG_AGG, 0, [K, hw], [], [logits, agg])
 
-    def up4_softmax(self, agg, prob, logits_up, *, P, h, w):
-        return self.add(UP4_SOFTMAX, 0, [P, h, w], [], [agg, prob, logits_up])
+    def up4_softmax(self, agg, prob, logits_up, *, P, h, w, from_logits=False):
+        """from_logits: `agg` holds the K = P - 1 raw logit planes and the aggregation (SEG_AGG) runs inside the launch (P <= 16)."""
+        return self.add(UP4_SOFTMAX, 1 if from_logits else 0, [P, h, w], [], [agg, prob, logits_up])
 
     def mask_merge(self, inmask, pred, src, planes, *, h0, w0, H, W, pad_left, pad_top, Knew, Kold, nfloat, float_mode):
         return self.add(MASK_MERGE, 1 if float_mode else 0, [h0, w0, H, W, pad_left, pad_top, Knew, Kold, nfloat], [],

@@ -222,7 +222,12 @@ class MockExecutor:
 
     def _op_11(self, flags, i, f, p):
         P, h, w = i[:3]
-        up = _bilinear(view(p[0], F32, (P, h, w)), 0.25)
+        if flags & 1:                                                   # SEG_AGG fused: p0 = raw logits [P-1,h,w]
+            pr = torch.sigmoid(view(p[0], F32, (P - 1, h * w)))
+            agg = torch.cat([_clamp_logit(torch.prod(1 - pr, dim=0, keepdim=True)), _clamp_logit(pr)], 0).view(P, h, w)
+        else:
+            agg = view(p[0], F32, (P, h, w))
+        up = _bilinear(agg, 0.25)
         if p[2]:
             view(p[2], F32, (P, 4 * h, 4 * w)).copy_(up)
         view(p[1], F32, (P, 4 * h, 4 * w)).copy_(torch.softmax(up, dim=0))

@@ -375,6 +375,21 @@ def test_seg_epilogue():
         return ol, {'agg': agg, 'prob': prob, 'lup': lup}
     check(*run_both(build), name='seg epilogue', rtol=2e-4)
 
+    for K in (3, 9):                                   # the fused form (<= 8 and <= 16 planes): bit-identical to the two launches
+        def build2(dev, g):
+            h, w = 12, 20
+            lg = (torch.randn((K, h, w), generator=g) * 3).to(dev)
+            agg = torch.zeros((K + 1, h, w), dtype=F32, device=dev)
+            o = [torch.zeros((K + 1, 4 * h, 4 * w), dtype=F32, device=dev) for _ in range(4)]
+            ol = O.OpList()
+            ol.seg_agg(lg, agg, K=K, hw=h * w)
+            ol.up4_softmax(agg, o[0], o[1], P=K + 1, h=h, w=w)
+            ol.up4_softmax(lg, o[2], o[3], P=K + 1, h=h, w=w, from_logits=True)
+            return ol, {'prob': o[0], 'lup': o[1], 'prob_f': o[2], 'lup_f': o[3]}
+        hip, ref = run_both(build2)
+        check(hip, ref, name=f'seg epilogue fused K={K}', rtol=2e-4)
+        assert torch.equal(hip['prob'], hip['prob_f']) and torch.equal(hip['lup'], hip['lup_f'])
+
 
 def test_mask_merge_and_agg():
     for fmode in (False, True):
