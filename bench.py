@@ -281,15 +281,17 @@ def main():
                     aff_f += (256 + 512 * len(b.objects)) * float(b.size()) * HW
             n_conv = int((allops['kind'] == O.CONV).sum())
             # the affinity matmul on its own (score pass 0 = the S = A.B^T tiles + tile maxima; valid in isolation), and the
-            # other stages by prefix differences of the 5-op plan [memset, score/0, select, score/1, readout]
+            # other stages by prefix differences of the plan [score/0, select (+ counter clear, usage ticks), score/1, readout]
+            # (round-1 form, $CUTIE_AMD_UNFUSED: a memset in front)
             aff_parts = None
-            if len(affs) == 5 and int(affs['kind'][1]) == O.AFF_SCORE:
-                sc = affs[1:2]
+            s0 = next((k for k in range(len(affs)) if int(affs['kind'][k]) == O.AFF_SCORE), None)
+            if s0 is not None and len(affs) - s0 >= 4:
+                sc = affs[s0:s0 + 1]
                 t_mm = min(rec.ex.time_ops(sc, 10) for _ in range(3)) * 1e-3
                 ii = sc['i'][0]
                 n_tok, hw = sum(int(ii[4 + 2 * r]) for r in range(int(ii[2]))), int(ii[0])
                 issued = 3 * 2.0 * 128 * (int(ii[9]) * 16) * int(ii[1])      # 3 split-bf16 terms, padded tiles
-                pre = [min(rec.ex.time_ops(affs[:k], 10) for _ in range(3)) * 1e3 for k in (1, 2, 3, 4, 5)]
+                pre = [0.0] * (1 - s0) + [min(rec.ex.time_ops(affs[:k], 10) for _ in range(3)) * 1e3 for k in range(1, s0 + 5)]
                 aff_parts = {'kernel': 'aff_score_kernel mode 0 (S = A.B^T on v_mfma_f32_16x16x32_bf16, 3 split terms)',
                              'us': round(t_mm * 1e6, 2), 'tokens': n_tok, 'queries': hw,
                              'mfma_issued_tflops': round(issued / t_mm / 1e12, 1),

@@ -8,7 +8,12 @@ struct ConvParams {
     int B, H, W, C1, C2, ldx1, ldx2, OH, OW, Cout, ldy, KH, KW, stride, pad, ldr, Kpad;
     int flags, M, Cin, OHW;
     float* part; int splitk, ldp, Kslice;                // split-K: fp32 partial tiles [splitk][M][ldp]
+    // conv_dma only: per-(object, channel) sums of the stored output as fixed point (x 2^24, int64: integer atomics are order-
+    // independent, so the GAP that ECA consumes stays bit-reproducible) accumulated into gap[B][Cout]; zero[0..nzero) is cleared by
+    // block 0 (the buffer the NEXT conv of the block accumulates into)
+    long long* gap; unsigned long long* zero; int nzero;
 };
+#define GAP_FIXED_SCALE 16777216.f
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // 16-B load that is a global_load for sure.  Pointers that went through a select, an array of pointers or pointer

@@ -93,6 +93,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
         m0 = mt * BM;
         n0 = (logical - mt * (int)gridDim.y) * BN;
     }
+    if (p.zero && blockIdx.x == 0 && blockIdx.y == 0)      // side job: clear the GAP accumulator of the next conv
+        for (int z = tid; z < p.nzero; z += NT) p.zero[z] = 0ull;
     // ---- epilogue operands fetched up front (their latency hides behind the whole K loop): this thread's 8-channel column ----
     constexpr int CH8 = BN / 8, PSTEP = NT / CH8;        // a thread keeps its channel chunk and walks down the pixels
     const int ec8 = tid % CH8, epx0 = tid / CH8, ech0 = n0 + ec8 * 8;
@@ -334,10 +336,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
             *reinterpret_cast<f32x4*>(ctile + px * LDC + ch) = acc[a][b];
         }
     __syncthreads();
-    if (ech0 >= p.Cout) return;
+    const bool active = ech0 < p.Cout;
+    if (!active && !p.gap) return;                       // (GAP mode: every thread reaches the barrier below)
     const int act = (p.flags >> CUTIE_ACT_SHIFT) & 7;
     const bool out_f32 = p.flags & CUTIE_F_OUT_F32, res_bcast = p.flags & CUTIE_F_RES_BCAST;
     const bool fast = ech0 + 7 < p.Cout && (out_f32 ? (p.ldy & 3) == 0 : (p.ldy & 7) == 0) && (!p.res || (p.ldr & 7) == 0);
+    if (active)
     for (int px = epx0; px < BM; px += PSTEP) {
         const int m = m0 + px;
         if (m >= p.M) break;
@@ -375,7 +379,36 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
             *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
             bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + (long)m * p.ldy + ech0;
-            *reinterpret_cast<uint4*>(yp) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+            const uint4 o = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+            *reinterpret_cast<uint4*>(yp) = o;
+            if (p.gap) {                                 // the STORED (bf16-rounded) values go back into the tile for the column sums
+                const f32x4 a = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16), __uint_as_float(o.y & 0xffff0000u)};
+                const f32x4 b = {__uint_as_float(o.z << 16), __uint_as_float(o.z & 0xffff0000u), __uint_as_float(o.w << 16), __uint_as_float(o.w & 0xffff0000u)};
+                *reinterpret_cast<f32x4*>(ctile + px * LDC + ec8 * 8) = a;
+                *reinterpret_cast<f32x4*>(ctile + px * LDC + ec8 * 8 + 4) = b;
+            }
+        }
+    }
+    if (p.gap) {
+        // GAP partials of this tile: thread = (channel, row part); rows of one object summed in row order in fp32, each partial
+        // converted to fixed point and added with an integer atomic (a tile may straddle objects: flush at every boundary)
+        __syncthreads();
+        constexpr int PARTS = NT / BN, RPART = BM / PARTS;
+        static_assert(NT % BN == 0 && BM % PARTS == 0, "GAP row parts");
+        const int c = tid % BN, part = tid / BN;
+        const int rows = min(BM, p.M - m0);
+        if (n0 + c < p.Cout) {
+            const int r0 = part * RPART, r1 = min(r0 + RPART, rows);
+            int m = m0 + r0, obj = m / p.OHW, next_b = (obj + 1) * p.OHW;
+            float sum = 0.f;
+            for (int r = r0; r < r1; ++r, ++m) {
+                if (m == next_b) {
+                    atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)obj * p.Cout + n0 + c), (unsigned long long)__float2ll_rn(sum * GAP_FIXED_SCALE));
+                    sum = 0.f; ++obj; next_b += p.OHW;
+                }
+                sum += ctile[r * LDC + c];
+            }
+            if (r1 > r0) atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)obj * p.Cout + n0 + c), (unsigned long long)__float2ll_rn(sum * GAP_FIXED_SCALE));
         }
     }
 #endif

@@ -584,6 +584,11 @@ int launch_conv(const cutie_op* op, hipStream_t s) {
     p.flags = op->flags; p.OHW = p.OH * p.OW; p.M = p.B * p.OHW; p.Cin = p.C1 + p.C2;
     p.splitk = i[19] > 1 ? i[19] : 1; p.part = (float*)op->p[6];
     p.ldp = (p.Cout + 7) & ~7;
+    p.gap = (long long*)op->p[7]; p.zero = (unsigned long long*)op->p[8]; p.nzero = i[21];
+    if ((p.gap || p.zero) && (i[17] < 60 || i[17] >= 100 || ((p.flags & CUTIE_F_OUT_F32) && p.gap) || (p.Cout & 7) || (p.ldy & 7) || (p.res && (p.ldr & 7)))) {
+        cutie_set_error("conv: GAP accumulation / zero job need an LDS-DMA tile (60..99), bf16 output, Cout %% 8 == 0 (tile %d)", i[17]);
+        return -2;
+    }
     if (p.splitk > 1 && (!p.part || (long)p.splitk * p.M * p.ldp > (long)i[20] * 1024)) {
         cutie_set_error("conv: split-K %d needs the fp32 partial scratch (p6, capacity i20 KiB-floats)", p.splitk);
         return -2;

@@ -243,7 +243,8 @@ __global__ void gap_final_kernel(const float* __restrict__ part, float* __restri
 // channel conv + sigmoid once per block into LDS, then the block streams 32 pixels x C channels (16-B accesses).
 __global__ __launch_bounds__(256) void eca_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ part,
                                                         const float* __restrict__ wk, const bf16_t* __restrict__ r,
-                                                        bf16_t* __restrict__ y, float* __restrict__ gap_out, int HW, int C, int nchunk) {
+                                                        bf16_t* __restrict__ y, float* __restrict__ gap_out, int HW, int C, int nchunk,
+                                                        const long long* __restrict__ fixed) {
     __shared__ float gap[256 + 4], sc[256];
     const int b = blockIdx.y, tid = threadIdx.x;
     const float inv = 1.f / (float)HW;
@@ -263,6 +264,13 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const bf16_t* __restrict
         xv[it] = *reinterpret_cast<const uint4*>(x + o);
         rv[it] = *reinterpret_cast<const uint4*>(r + o);
     }
+    if (fixed) {                                          // sums accumulated by the producing conv (fixed point x 2^24, conv_dma.hip)
+        for (int c = tid; c < C; c += 256) {
+            const float mean = (float)((double)fixed[(long)b * C + c] * (1.0 / 16777216.0)) * inv;
+            gap[c + 2] = mean;
+            if (gap_out && blockIdx.x == 0) gap_out[(long)b * C + c] = mean;
+        }
+    } else
     for (int c = tid; c < C; c += 256) {
         // (8 partials in flight per round trip, summed in a fixed order: the plain loop ran nchunk DEPENDENT round trips -- 26 at
         // 480p -- and was 2/3 of this kernel's 11 us)
@@ -855,7 +863,7 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             if (i[2] > 256 || (i[2] & 7)) { cutie_set_error("eca: C <= 256, C %% 8"); return -2; }
             int nchunk = (i[1] + 63) / 64;
             hipLaunchKernelGGL(eca_apply_kernel, dim3((i[1] + 31) / 32, i[0]), dim3(256), 0, s, (const bf16_t*)p[0], (const float*)p[5], (const float*)p[2],
-                               (const bf16_t*)p[3], (bf16_t*)p[4], (float*)p[1], i[1], i[2], nchunk);
+                               (const bf16_t*)p[3], (bf16_t*)p[4], (float*)p[1], i[1], i[2], nchunk, (op->flags & 1) ? (const long long*)p[5] : nullptr);
             break;
         }
         case CUTIE_OP_GRU: {

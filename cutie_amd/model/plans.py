@@ -151,6 +151,8 @@ class Plan:
                 tuned_any = True
             if best[0] in O.DMA_TILES and not O.dma_tiles_enabled():
                 continue
+            if (arr['p'][n, 7] or arr['p'][n, 8]) and best[0] not in O.DMA_TILES:
+                continue                                     # GAP accumulation / zero job exist in conv_dma_kernel only
             arr['i'][n, 17], arr['i'][n, 19] = best
         self.tuned = True
         if tuned_any:
@@ -158,7 +160,7 @@ class Plan:
 
     # ---- conv helper ------------------------------------------------------------------
     def conv(self, wname, x, *, name=None, out=None, stride=1, pad=None, x2=None, res=None, res_bcast=False,
-             relu_in=False, act=O.ACT_NONE, out_f32=False, ldy=None):
+             relu_in=False, act=O.ACT_NONE, out_f32=False, ldy=None, gap_acc=None, zero=None):
         w = self.eng.w[wname]
         if pad is None:
             pad = (w.kh - 1) // 2
@@ -174,16 +176,28 @@ class Plan:
         self.ol.conv(x.t, w, out.t, B=x.B, H=x.H, W=x.W, C1=x.C, ldx1=x.ld, OH=OH, OW=OW, ldy=out.ld, stride=stride,
                      pad=pad, x2=None if x2 is None else x2.t, C2=0 if x2 is None else x2.C,
                      ldx2=0 if x2 is None else x2.ld, res=None if res is None else res.t,
-                     ldr=0 if res is None else res.ld, res_bcast=res_bcast, relu_in=relu_in, act=act, out_f32=out_f32)
+                     ldr=0 if res is None else res.ld, res_bcast=res_bcast, relu_in=relu_in, act=act, out_f32=out_f32,
+                     gap_acc=gap_acc, zero=zero)
         return out
 
     # ---- shared blocks ------------------------------------------------------------------
     def ca_block(self, prefix, x, name, out=None):
         """CAResBlock (channel_attn.py:7-39): conv3x3(relu) x2, ECA channel attention, residual."""
-        t1 = self.conv(prefix + '.conv1', x, name=name + '.t1', relu_in=True, act=O.ACT_RELU)
-        t2 = self.conv(prefix + '.conv2', t1, name=name + '.t2')
+        w = self.eng.w[prefix + '.conv2']
         gap = self.buf(name + '.gap', (x.B, x.C), F32)
         HW = x.H * x.W
+        if not UNFUSED and O.conv_side_jobs_ok(cin=x.C, cout=w.cout, kh=w.kh):
+            # ECA's global average pool rides on the convs: conv1 clears the accumulator, conv2 adds the per-object channel sums of
+            # what it stores (fixed point, integer atomics: order-independent), ECA_APPLY turns them into means -- no GAP launch
+            sums = self.buf(name + '.gapsum', (x.B, x.C), torch.int64)
+            t1 = self.conv(prefix + '.conv1', x, name=name + '.t1', relu_in=True, act=O.ACT_RELU, zero=sums)
+            t2 = self.conv(prefix + '.conv2', t1, name=name + '.t2', gap_acc=sums)
+            if out is None:
+                out = Act(self.buf(name + '.out', (x.B, x.H, x.W, x.C)), x.B, x.H, x.W, x.C)
+            self.ol.eca_apply(t2.t, gap, self.eng.w[prefix + '.conv.weight'], x.t, out.t, B=x.B, HW=HW, C=x.C, fixed_sums=sums)
+            return out
+        t1 = self.conv(prefix + '.conv1', x, name=name + '.t1', relu_in=True, act=O.ACT_RELU)
+        t2 = self.conv(prefix + '.conv2', t1, name=name + '.t2')
         self.ol.gap(t2.t, gap, B=x.B, HW=HW, C=x.C, partial_only=True)
         if out is None:
             out = Act(self.buf(name + '.out', (x.B, x.H, x.W, x.C)), x.B, x.H, x.W, x.C)

@@ -74,6 +74,11 @@ def dma_tile_ok(tile, *, cin, kh, c2=0):
     return cin % bk == 0 and (c2 == 0 or (c2 % bk == 0 and (cin - c2) % bk == 0)) and kh * kh <= 32
 
 
+def conv_side_jobs_ok(*, cin, cout, kh, c2=0):
+    """Can a conv of this geometry carry the GAP accumulation / zero job (conv_dma_kernel only)?"""
+    return dma_tiles_enabled() and dma_tile_ok(60, cin=cin, kh=kh, c2=c2) and cout % 8 == 0 and cout > 16
+
+
 def experimental_tiles_enabled():
     return os.environ.get('CUTIE_AMD_EXPERIMENTAL_TILES', '0') not in ('', '0')
 
@@ -273,18 +278,24 @@ class OpList:
 
     # ---- builders (argument order mirrors include/cutie_hip.h) -----------------------
     def conv(self, x1, w, y, *, B, H, W, C1, ldx1, OH, OW, ldy, stride=1, pad=0, x2=None, C2=0, ldx2=0,
-             res=None, ldr=0, res_bcast=False, relu_in=False, act=ACT_NONE, out_f32=False, tile=None, splitk=1):
-        """w: PackedConv (weights.py)."""
+             res=None, ldr=0, res_bcast=False, relu_in=False, act=ACT_NONE, out_f32=False, tile=None, splitk=1,
+             gap_acc=None, zero=None):
+        """w: PackedConv (weights.py).  gap_acc: int64 [B, Cout] -- the conv adds the per-(object, channel) sums of its stored output
+        (fixed point x 2^24) to it (ECA's global average pool without a launch of its own); zero: an int64 tensor cleared by this
+        launch (the accumulator of the NEXT conv).  Both need an LDS-DMA tile (the tile choice is restricted accordingly)."""
         flags = (F_RELU_IN if relu_in else 0) | (F_OUT_F32 if out_f32 else 0) | (F_RES_BCAST if res_bcast else 0) | (act << ACT_SHIFT)
         assert C1 + C2 == w.cin_padded, (C1, C2, w.cin_padded)
         M = B * OH * OW
+        side = gap_acc is not None or zero is not None
         if tile is None:
-            tile = COUT1_TILE if cout1_ok(w.cout, C1 + C2, C2, res is not None) else pick_tile(M, w.cout, C1 + C2, dict(kh=w.kh, c2=C2))
+            tile = COUT1_TILE if (cout1_ok(w.cout, C1 + C2, C2, res is not None) and not side) else pick_tile(M, w.cout, C1 + C2, dict(kh=w.kh, c2=C2))
+        if side:
+            assert tile in DMA_TILES and not out_f32 and w.cout % 8 == 0 and ldy % 8 == 0, 'GAP accumulation needs an LDS-DMA conv (see conv_side_jobs_ok)'
         part = splitk_scratch(w.weight.device, self.scratch_owner)
         return self.add(CONV, flags,
                         [B, H, W, C1, C2, ldx1, ldx2, OH, OW, w.cout, ldy, w.kh, w.kw, stride, pad, ldr, w.kpad, tile, w.cin_real,
-                         splitk, part.numel() // 1024],
-                        [], [x1, x2, w.weight, w.bias, res, y, part])
+                         splitk, part.numel() // 1024, 0 if zero is None else zero.numel()],
+                        [], [x1, x2, w.weight, w.bias, res, y, part, gap_acc, zero])
 
     def maxpool(self, x, y, *, B, H, W, C, relu=False):
         OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
@@ -308,8 +319,11 @@ class OpList:
         self._last_gap_scratch = scratch
         return self.add(GAP, 1 if partial_only else 0, [B, HW, C], [], [x, y, scratch])
 
-    def eca_apply(self, x, gap, wk, r, y, *, B, HW, C, part=None):
-        """part: the GAP partials of the preceding gap(..., partial_only=True) (defaults to the last gap scratch)."""
+    def eca_apply(self, x, gap, wk, r, y, *, B, HW, C, part=None, fixed_sums=None):
+        """part: the GAP partials of the preceding gap(..., partial_only=True) (defaults to the last gap scratch);
+        fixed_sums: int64 [B, C] sums accumulated by the producing conv (conv(gap_acc=...)) instead."""
+        if fixed_sums is not None:
+            return self.add(ECA_APPLY, 1, [B, HW, C], [], [x, gap, wk, r, y, fixed_sums])
         if part is None:
             part = self._last_gap_scratch
         return self.add(ECA_APPLY, 0, [B, HW, C], [], [x, gap, wk, r, y, part])

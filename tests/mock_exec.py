@@ -121,6 +121,11 @@ class MockExecutor:
         y = _act(y, (flags >> O.ACT_SHIFT) & 7)
         out = view(p[5], F32 if flags & O.F_OUT_F32 else BF16, (B, OH, OW, Cout), (OH * OW * ldy, OW * ldy, ldy, 1))
         out.copy_(y)
+        if len(p) > 8 and p[8]:                                         # side job: clear the next conv's GAP accumulator
+            view(p[8], I64, (i[21],)).zero_()
+        if len(p) > 7 and p[7]:                                         # GAP accumulation: fixed-point sums of the STORED values
+            stored = out.float().reshape(B, OH * OW, Cout)
+            view(p[7], I64, (B, Cout)).add_(torch.round(stored.double().sum(1) * 16777216.0).to(torch.int64))
 
     # ---- MAXPOOL --------------------------------------------------------------------
     def _op_2(self, flags, i, f, p):
@@ -196,7 +201,10 @@ class MockExecutor:
         x = view(p[0], BF16, (B, HW, C)).float()
         nchunk = -(-HW // 64)
         gap = view(p[1], F32, (B, C))
-        gap.copy_(view(p[5], F32, (B, nchunk, C)).sum(1) / HW)
+        if flags & 1:                                                   # fixed-point sums from the producing conv
+            gap.copy_((view(p[5], I64, (B, C)).double() / 16777216.0).float() / HW)
+        else:
+            gap.copy_(view(p[5], F32, (B, nchunk, C)).sum(1) / HW)
         wk = view(p[2], F32, (5,))
         sc = torch.sigmoid(F.conv1d(gap.view(B, 1, C), wk.view(1, 1, 5), None, 1, 2)).view(B, 1, C)
         r = view(p[3], BF16, (B, HW, C)).float()

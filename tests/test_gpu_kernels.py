@@ -348,6 +348,37 @@ def test_gap_eca():
     check(hip, ref, 'gap/eca')
 
 
+@pytest.mark.parametrize('tile', [66, 67, 63, 61, 70, 68, 82, 85])
+@pytest.mark.parametrize('geo', [(3, 30, 54), (5, 5, 7), (2, 9, 16)])
+def test_conv_gap_accumulation(tile, geo):
+    """ECA's average pool riding on the convs of a CAResBlock: conv1 clears the accumulator, conv2 adds the fixed-point channel sums of
+    its stored output (tiles straddling 1, 2 or several objects), ECA_APPLY turns them into means.  Against the interpreter, and the
+    sums against the stored tensor exactly (up to the fp32 partial-sum rounding)."""
+    B, H, W = geo
+    C = 256
+
+    def build(dev, g):
+        w1 = torch.randn(C, C, 3, 3, generator=g) / math.sqrt(C * 9)
+        w2 = torch.randn(C, C, 3, 3, generator=g) / math.sqrt(C * 9)
+        pc1, pc2 = pack_conv(w1, torch.randn(C, generator=g) * 0.1, dev, segs=[(C, C)]), pack_conv(w2, torch.randn(C, generator=g) * 0.1, dev, segs=[(C, C)])
+        x = rnd(g, (B, H, W, C), dev=dev)
+        t1, t2, y = (torch.zeros((B, H, W, C), dtype=BF16, device=dev) for _ in range(3))
+        sums = torch.full((B, C), 12345, dtype=torch.int64, device=dev)        # stale contents: conv1 must clear them
+        gap = torch.zeros((B, C), dtype=F32, device=dev)
+        wk = (torch.randn(5, generator=g) * 0.6).to(dev)
+        ol = O.OpList()
+        kw = dict(B=B, H=H, W=W, C1=C, ldx1=C, OH=H, OW=W, ldy=C, pad=1, tile=tile)
+        ol.conv(x, pc1, t1, relu_in=True, act=O.ACT_RELU, zero=sums, **kw)
+        ol.conv(t1, pc2, t2, gap_acc=sums, **kw)
+        ol.eca_apply(t2, gap, wk, x, y, B=B, HW=H * W, C=C, fixed_sums=sums)
+        return ol, {'t2': t2, 'sums': sums, 'gap': gap, 'y': y}
+    hip, ref = run_both(build, seed=31)
+    check({k: hip[k] for k in ('t2', 'gap', 'y')}, {k: ref[k] for k in ('t2', 'gap', 'y')}, f'conv gap tile{tile}')
+    exact = hip['t2'].float().reshape(B, H * W, C).double().sum(1)
+    got = hip['sums'].double().cpu() / 16777216.0
+    assert float((got - exact.cpu()).abs().max()) < 1e-3 * max(1.0, float(exact.abs().max())), 'sums of the stored tensor'
+
+
 def test_gru():
     def build(dev, g):
         n, C = 500, 256

@@ -243,6 +243,8 @@ def test_every_conv_candidate_agrees_on_the_real_layers(name, gpu_net):
             npx, nout = int(i[0]) * int(i[1]) * int(i[2]), int(i[7]) * int(i[8])
             x1 = (torch.randn(npx * int(i[5]) + 64, generator=g) * 0.5).to(torch.bfloat16).cuda()
             base = arr[n:n + 1].copy()
+            base['p'][0, 7] = base['p'][0, 8] = 0        # GAP accumulation / zero jobs (LDS-DMA tiles only): test_conv_gap_accumulation
+            base['i'][0, 21] = 0
             base['p'][0, 0] = x1.data_ptr()
             if int(i[4]):
                 x2 = (torch.randn(npx * int(i[6]) + 64, generator=g) * 0.5).to(torch.bfloat16).cuda()

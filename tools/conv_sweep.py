@@ -70,6 +70,8 @@ def main():
                 key = (M, cout, cin, int(i[11]), int(i[13]), int(ops['flags'][n]) & 3, int(i[1]), int(i[2]))
                 if key not in geoms:
                     geoms[key] = [ops[n:n + 1].copy(), 0]
+                    geoms[key][0]['p'][0, 7] = geoms[key][0]['p'][0, 8] = 0     # GAP accumulation / zero side jobs exist on the LDS-DMA tiles only
+                    geoms[key][0]['i'][0, 21] = 0
                 geoms[key][1] += 1
     rows, table = [], []
     for key, (one, count) in geoms.items():
