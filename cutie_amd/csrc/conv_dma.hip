@@ -487,6 +487,9 @@ int launch_conv_dma(const ConvParams& p, int tile, hipStream_t s) {
         case 83: return launch_dma<32, 64, 1, 4, 4, 128>(p, s);      // 96 KB
         case 84: return launch_dma<64, 128, 2, 4, 2, 128>(p, s);     // 8 waves, 96 KB
         case 85: return launch_dma<128, 64, 4, 2, 2, 128>(p, s);     // 8 waves, 96 KB
+        // 96 rows: M = 4860 (3 objects at stride 16) gives 51 x 4 = 204 blocks -- one round on 256 CUs where 64-row tiles need two
+        case 86: return launch_dma<96, 64, 2, 2, 3>(p, s);           // 60 KB
+        case 87: return launch_dma<96, 64, 2, 2, 2>(p, s);           // 40 KB
         default: cutie_set_error("conv: bad DMA tile id %d", tile); return -2;
     }
 }

@@ -232,7 +232,7 @@ class MemoryManager:
                 pixel_readout = network.pixel_fusion(pix_feat, visual_readout, this_sensory, this_last_mask)
                 a, b = self._rows(objects, self._objv_ids)
                 this_obj_mem = self._objv[a:b].unsqueeze(0).unsqueeze(2)                # [1,K,1,Q,C+1]
-                readout_memory, aux_features = network.readout_query(pixel_readout, this_obj_mem)
+                readout_memory, aux_features = network.readout_query(pixel_readout, this_obj_mem, _last_aux=self.save_aux or _UNFUSED)
                 for i, obj in enumerate(objects):
                     all_readout[obj] = readout_memory[:, i]
                 chunks.append((objects, readout_memory))

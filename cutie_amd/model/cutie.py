@@ -134,7 +134,14 @@ class Engine:
             W[q + '.ffn.linear1'] = pack_linear(sd[q + '.ffn.linear1.weight'], sd[q + '.ffn.linear1.bias'], dev)
             W[q + '.ffn.linear2'] = pack_linear(sd[q + '.ffn.linear2.weight'], sd[q + '.ffn.linear2.bias'], dev)
         # the positional term R_b = [Wk_b pe | 0 | Wq2_b pe] of every block depends only on pixel_pe: one conv for all blocks
-        W[t + '.pe_proj_all'] = linear_as_conv(torch.cat([self._pe_w.pop(b) for b in range(ot['num_blocks'])], 0), None, dev)
+        wpe_all = torch.cat([self._pe_w.pop(b) for b in range(ot['num_blocks'])], 0).float()        # [3C*nb, C]
+        self._wpe_all = wpe_all
+        W[t + '.pe_proj_all'] = linear_as_conv(wpe_all, None, dev)
+        # ... and since pixel_pe = pixel_emb_proj(x) + PE is consumed by nothing else, the two 1x1 maps are composed (in fp32, once):
+        # R_all = (Wpe We) x + Wpe be + Wpe PE.  One conv x -> [pixel | R_all]; the PE term is a per-pixel residual (Engine.pe_r)
+        we = sd[t + '.pixel_emb_proj.weight'].float().reshape(C, -1)
+        W[t + '.pixel_init_R'] = pack_conv(torch.cat([sd[t + '.pixel_init_proj.weight'].float(), (wpe_all @ we).reshape(-1, we.shape[1], 1, 1)], 0),
+                                           torch.cat([sd[t + '.pixel_init_proj.bias'].float(), wpe_all @ sd[t + '.pixel_emb_proj.bias'].float()], 0), dev)
         # pixel_init_proj | pixel_emb_proj read the same input: one conv with 2C output channels
         W[t + '.pixel_init_emb'] = pack_conv(torch.cat([sd[t + '.pixel_init_proj.weight'], sd[t + '.pixel_emb_proj.weight']], 0),
                                              torch.cat([sd[t + '.pixel_init_proj.bias'], sd[t + '.pixel_emb_proj.bias']], 0), dev)
@@ -163,6 +170,16 @@ class Engine:
         if key not in self._pe:
             e = self.pe(h, w)
             self._pe[key] = torch.cat([torch.zeros_like(e), e], 1).contiguous()
+        return self._pe[key]
+
+    def pe_r(self, h, w):
+        """bf16 [h*w, C + 3C*blocks]: [0 | Wpe PE] -- the broadcast residual of the composed pixel_init | R_all conv."""
+        key = ('pe_r', h, w)
+        if key not in self._pe:
+            e = plans.positional_encoding(h, w, self.m['embed_dim'], self.m['pixel_pe_scale'], self.m['pixel_pe_temperature'])
+            e = e.reshape(h * w, -1).float()
+            r = e @ self._wpe_all.t()
+            self._pe[key] = torch.cat([torch.zeros_like(e), r], 1).to(BF16).to(self.device).contiguous()
         return self._pe[key]
 
     def rep_embedding(self, which, K):
@@ -461,8 +478,10 @@ class CUTIE(nn.Module):
         P.run(pix_feat=pf, pixel=px, sensory_bf16=sb, last_mask=lm, fused=fused, **({} if xt is None else {'fuse_xt': xt}))
         return group_logical(fused)
 
-    def readout_query(self, pixel_readout, obj_memory, *, selector=None, need_weights=False):
-        """cutie.py:159-170 -> QueryTransformer.  obj_memory [1,K,T,Q,C+1] (T summed) -> (pixel [1,K,C,h,w], aux)"""
+    def readout_query(self, pixel_readout, obj_memory, *, selector=None, need_weights=False, _last_aux=True):
+        """cutie.py:159-170 -> QueryTransformer.  obj_memory [1,K,T,Q,C+1] (T summed) -> (pixel [1,K,C,h,w], aux).
+        _last_aux=False (MemoryManager, unless save_aux): the logits of the last block are not computed (aux['logits'] has one
+        entry less); they do not influence the read-out."""
         assert selector is None, 'selector is a training-time argument'
         eng = self.engine()
         px = group_nhwc_of(pixel_readout)
@@ -470,10 +489,11 @@ class CUTIE(nn.Module):
         om = obj_memory[0].to(F32)
         om = om.sum(dim=1) if om.shape[1] != 1 else om[:, 0]
         om = om.contiguous()
-        P = eng.plan(('rq', K, h, w), plans.build_readout_query, K, h, w)
+        P = eng.plan(('rq', K, h, w, bool(_last_aux)), plans.build_readout_query, K, h, w, bool(_last_aux))
         out = torch.empty((K, h, w, self.embed_dim), dtype=BF16, device=self.device)
         P.run(pixel=px, obj_mem=om, out=out)
-        aux = {'logits': [P.bufs['aux_logits'][i].view(1, K, h, w) for i in range(P.bufs['aux_logits'].shape[0])],
+        n_aux = P.bufs['aux_logits'].shape[0] - (0 if _last_aux else 1)
+        aux = {'logits': [P.bufs['aux_logits'][i].view(1, K, h, w) for i in range(n_aux)],
                'q_weights': None, 'p_weights': None}
         return group_logical(out), aux
 

@@ -304,10 +304,12 @@ def build_pixel_fusion(eng, K, h, w, pre=False):
     return P
 
 
-def build_readout_query(eng, K, h, w):
+def build_readout_query(eng, K, h, w, last_aux=True):
     """CUTIE.readout_query -> QueryTransformer.forward (object_transformer.py:114-177).
     dyn in: pixel bf16 [K,h,w,C], obj_mem f32 [K,Q,C+1].  dyn out: out bf16 [K,h,w,C].
-    Aux logits of every block are kept in bufs['aux_logits'] (f32 [blocks+1,K,hw]) for tests."""
+    Aux logits of every block are kept in bufs['aux_logits'] (f32 [blocks+1,K,hw]) for tests.  last_aux=False skips the mask_pred
+    head after the LAST block: its logits mask no attention any more (the reference computes them anyway, object_transformer.py:164,
+    and only save_aux / training read them)."""
     P = Plan(eng)
     m, ol, W = eng.m, P.ol, eng.w
     ot = m['object_transformer']
@@ -321,11 +323,20 @@ def build_readout_query(eng, K, h, w):
     ol.linear(vals, W[t + '.summary_to_query_init'], query, M=M, res=eng.rep_embedding('query_init', K))
     ol.linear(vals, W[t + '.summary_to_query_emb'], query_emb, M=M, res=eng.rep_embedding('query_emb', K))
     pix_in = Act(Dyn('pixel'), K, h, w, C)
-    # pixel = pixel_init_proj(x), pixel_pe = pixel_emb_proj(x) + PE: one conv, two channel slices of its output
-    both = P.conv(t + '.pixel_init_emb', pix_in, name='pixel_init_emb', res=Act(eng.pe0(h, w), 1, h, w, 2 * C), res_bcast=True)
-    pixel = Act(both.t, K, h, w, C, 2 * C)
-    pixel_pe = Act(both.t.view(-1)[C:], K, h, w, C, 2 * C)
-    R_all = P.conv(t + '.pe_proj_all', pixel_pe, name='R_all')                   # [Wk.pe | 0 | Wq2.pe] of every block
+    if UNFUSED:
+        # pixel = pixel_init_proj(x), pixel_pe = pixel_emb_proj(x) + PE: one conv, two channel slices of its output
+        both = P.conv(t + '.pixel_init_emb', pix_in, name='pixel_init_emb', res=Act(eng.pe0(h, w), 1, h, w, 2 * C), res_bcast=True)
+        pixel = Act(both.t, K, h, w, C, 2 * C)
+        pixel_pe = Act(both.t.view(-1)[C:], K, h, w, C, 2 * C)
+        R_all = P.conv(t + '.pe_proj_all', pixel_pe, name='R_all')               # [Wk.pe | 0 | Wq2.pe] of every block
+        R_of = lambda b: Act(R_all.t.view(-1)[b * 3 * C:], K, h, w, 3 * C, nb * 3 * C)
+    else:
+        # pixel_pe feeds nothing but the positional terms R_b, so its projection is composed with theirs at load time
+        # (Engine: '.pixel_init_R'): ONE conv x -> [pixel | R_0 | R_1 | ...], the PE part of R as a per-pixel broadcast residual
+        CR = C + nb * 3 * C
+        both = P.conv(t + '.pixel_init_R', pix_in, name='pixel_init_R', res=Act(eng.pe_r(h, w), 1, h, w, CR), res_bcast=True)
+        pixel = Act(both.t, K, h, w, C, CR)
+        R_of = lambda b: Act(both.t.view(-1)[C + b * 3 * C:], K, h, w, 3 * C, CR)
     aux = f('aux_logits', (nb + 1, K, HW))
     fused_mask = HW <= 24576 and not UNFUSED                      # ATTN_Q2P derives the foreground mask from the logits itself (flags in LDS)
     fg = None if fused_mask else P.buf('fg', (K, HW), torch.uint8)
@@ -337,7 +348,7 @@ def build_readout_query(eng, K, h, w):
     for b in range(nb):
         q = f'{t}.blocks.{b}'
         n = f'b{b}.'
-        R = Act(R_all.t.view(-1)[b * 3 * C:], K, h, w, 3 * C, nb * 3 * C)
+        R = R_of(b)
         kvq = P.conv(q + '.pixel_proj', pixel, name=n + 'kvq', res=R)            # k | v | q2 of the pixels
         # read_from_pixel (CrossAttention, transformer_layers.py:75-98): residual is the normed x.  Every LayerNorm of the
         # block is fused into the linear that consumes it (the normalised rows are kept where the reference reuses them).
@@ -372,7 +383,8 @@ def build_readout_query(eng, K, h, w):
         # PixelFFN (transformer_layers.py:121-136)
         last = b == nb - 1
         pixel = P.ca_block(q + '.pixel_ffn.conv', pf, n + 'ffn', out=Act(Dyn('out'), K, h, w, C) if last else None)
-        P.conv(f'{t}.mask_pred.{b + 1}.1', pixel, relu_in=True, out_f32=True, out=Act(aux[b + 1], K, h, w, 1))
+        if not last or last_aux:
+            P.conv(f'{t}.mask_pred.{b + 1}.1', pixel, relu_in=True, out_f32=True, out=Act(aux[b + 1], K, h, w, 1))
         if not last and not fused_mask:
             ol.aux_mask(aux[b + 1], fg, nfg, K=K, HW=HW)
     return P

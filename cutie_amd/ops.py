@@ -57,7 +57,8 @@ EXPERIMENTAL_TILES = {50: (128, 64, 64), 51: (64, 64, 64), 52: (64, 128, 64), 53
 DMA_TILES = {60: (128, 128, 64), 61: (128, 128, 64), 62: (128, 128, 64), 63: (128, 64, 64), 64: (64, 128, 64), 65: (64, 64, 64),
              66: (64, 64, 64), 67: (32, 64, 64), 68: (256, 128, 64), 69: (32, 128, 64), 70: (128, 128, 64), 71: (128, 64, 64),
              72: (64, 64, 64), 73: (64, 64, 64), 74: (64, 64, 64), 75: (32, 64, 64), 76: (128, 64, 64), 77: (64, 128, 64), 78: (32, 128, 64),
-             80: (64, 64, 128), 81: (64, 64, 128), 82: (32, 64, 128), 83: (32, 64, 128), 84: (64, 128, 128), 85: (128, 64, 128)}
+             80: (64, 64, 128), 81: (64, 64, 128), 82: (32, 64, 128), 83: (32, 64, 128), 84: (64, 128, 128), 85: (128, 64, 128),
+             86: (96, 64, 64), 87: (96, 64, 64)}
 
 
 ALL_TILES = {**TILES, **DMA_TILES}
