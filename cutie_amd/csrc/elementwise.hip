@@ -164,7 +164,8 @@ __global__ void mask_down_mean_kernel(const float* __restrict__ m, float* __rest
 }
 // Both steps in one launch: one wave per output pixel walks the K objects (means in object order, then the pairs from the means it
 // has just written).  Same sums in the same order as the two kernels below.
-__global__ void mask_down_pair_kernel(const float* __restrict__ m, float* __restrict__ m16, uint4* __restrict__ y, int K, int H, int W, int r) {
+__global__ void mask_down_pair_kernel(const float* __restrict__ m, float* __restrict__ m16, uint4* __restrict__ y, int K, int H, int W, int r,
+                                      int ld8) {          // ld8: 16-B units per pixel of y (1 = 8 channels; 8 = 64, channels 8.. stay as they are)
     const int h = H / r, w = W / r, hw = h * w;
     const long px = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -185,7 +186,7 @@ __global__ void mask_down_pair_kernel(const float* __restrict__ m, float* __rest
         for (int k = 0; k < K; ++k) {
             const float mk = m16[(long)k * hw + px];             // written by this lane above
             const float others = fminf(fmaxf(sum - mk, 0.f), 1.f);
-            y[(long)k * hw + px] = make_uint4(pack_bf2(mk, others), 0u, 0u, 0u);
+            y[((long)k * hw + px) * ld8] = make_uint4(pack_bf2(mk, others), 0u, 0u, 0u);
         }
 }
 // m16 f32 [K,hw] -> pair bf16 [K,hw,8] = (mask, others, 0...)
@@ -847,7 +848,8 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             long n = (long)K * h * w;
             float* m16 = (float*)p[2];
             if (!m16) { cutie_set_error("mask_down: m16 buffer required"); return -2; }
-            hipLaunchKernelGGL(mask_down_pair_kernel, GRID1D((long)h * w * 64, BS), dim3(BS), 0, s, (const float*)p[0], m16, (uint4*)p[1], K, i[1], i[2], r);
+            hipLaunchKernelGGL(mask_down_pair_kernel, GRID1D((long)h * w * 64, BS), dim3(BS), 0, s, (const float*)p[0], m16, (uint4*)p[1], K, i[1], i[2], r,
+                               i[4] > 8 ? i[4] / 8 : 1);
             break;
         }
         case CUTIE_OP_GAP: {

@@ -97,9 +97,15 @@ class Engine:
                      'mask_decoder.up_8_4.out_conv.conv2', 'mask_decoder.pred']:
             conv(name)
         conv('mask_decoder.sensory_update.g4_conv', segs=[(up[2], up[2]), (1, 8)])
+        # g16_conv(g16) + g8_conv(area(g8)) + g4_conv(area([g4 | logits])) of SensoryUpdater (modules.py:47-61) is ONE 1x1 conv over the
+        # virtual concat [g16 | g8' | g4' | logits' (1 -> 64 channels, so every source is a multiple of the 64-channel K tile)]
+        sg = 'mask_decoder.sensory_update.'
+        W[sg + 'g_all'] = pack_conv(torch.cat([sd[sg + 'g16_conv.weight'], sd[sg + 'g8_conv.weight'], sd[sg + 'g4_conv.weight']], 1),
+                                    sd[sg + 'g16_conv.bias'] + sd[sg + 'g8_conv.bias'] + sd[sg + 'g4_conv.bias'], dev,
+                                    segs=[(up[0], up[0]), (up[1], up[1]), (up[2], up[2]), (1, 64)])
         conv('mask_decoder.sensory_update.transform', segs=[(CS, CS), (CS, CS)])
         conv('mask_encoder.sensory_update.transform', segs=[(CV, CV), (CS, CS)])
-        conv('pixel_fuser.sensory_compress', segs=[(CS, CS), (2, 8)])
+        conv('pixel_fuser.sensory_compress', segs=[(CS, CS), (2, 64)])       # (mask, others) padded to a whole 64-channel K tile: LDS-DMA conv
         ca_blocks = []
         for fz in ('mask_encoder.fuser', 'pixel_fuser.fuser'):
             conv(fz + '.distributor.x_transform')

@@ -292,12 +292,12 @@ def build_pixel_fusion(eng, K, h, w, pre=False):
     dyn out: fused bf16 [K,h,w,CE]."""
     P = Plan(eng)
     m = eng.m
-    pair = P.buf('pair', (K, h, w, 8))
+    pair = P.buf('pair', (K, h, w, 64))           # (mask, others) in channels 0, 1 of a zeroed 64-channel tensor: a whole K tile
     m16 = P.buf('m16', (K, h, w), F32)
-    P.ol.mask_down(Dyn('last_mask'), pair, m16, K=K, H=16 * h, W=16 * w)
+    P.ol.mask_down(Dyn('last_mask'), pair, m16, K=K, H=16 * h, W=16 * w, pair_channels=64)
     pixel = Act(Dyn('pixel'), K, h, w, m['value_dim'])
     p16 = P.conv('pixel_fuser.sensory_compress', Act(Dyn('sensory_bf16'), K, h, w, m['sensory_dim']),
-                 x2=Act(pair, K, h, w, 8), res=pixel, name='p16')
+                 x2=Act(pair, K, h, w, 64), res=pixel, name='p16')
     xt = Act(Dyn('fuse_xt'), 1, h, w, eng.w['pixel_fuser.fuser.distributor.x_transform'].cout) if pre else None
     P.fusion_block('pixel_fuser.fuser', Act(Dyn('pix_feat'), 1, h, w, m['pixel_dim']), p16, 'fuse',
                    out=Act(Dyn('fused'), K, h, w, m['embed_dim']), xt=xt)
@@ -422,15 +422,14 @@ def build_segment(eng, K, h, w, update_sensory, pre=False):
     logits = P.buf('logits', (K, h4, w4), F32)
     P.conv('mask_decoder.pred', p4, relu_in=True, out_f32=True, out=Act(logits, K, h4, w4, 1))
     if update_sensory:
-        p8d = P.buf('p8d', (K, h, w, up[1]))
-        ol.area_down(p8.t, p8d, B=K, H=h8, W=w8, C=up[1], ldx=up[1], ldy=up[1], r=2)
-        p4d = P.buf('p4d', (K, h, w, up[2]))
-        ol.area_down(p4.t, p4d, B=K, H=h4, W=w4, C=up[2], ldx=up[2], ldy=up[2], r=4)
-        lgd = P.buf('lgd', (K, h, w, 8))
-        ol.area_down(logits, lgd, B=K, H=h4, W=w4, C=1, ldx=1, ldy=8, r=4, f32_in=True, Cz=8)
-        g1 = P.conv('mask_decoder.sensory_update.g16_conv', p16, name='g1')
-        g2 = P.conv('mask_decoder.sensory_update.g8_conv', Act(p8d, K, h, w, up[1]), res=g1, name='g2')
-        g3 = P.conv('mask_decoder.sensory_update.g4_conv', Act(p4d, K, h, w, up[2]), x2=Act(lgd, K, h, w, 8), res=g2, name='g3')
+        # area-pooled g8 / g4 / logits written side by side: the second source of the ONE conv that replaces g16_conv + g8_conv +
+        # g4_conv (Engine: '.g_all'); the logits take a whole 64-channel K tile (channel 0 written, the rest stays zero)
+        CT = up[1] + up[2] + 64
+        gcat = P.buf('gcat', (K, h, w, CT))
+        ol.area_down(p8.t, gcat, B=K, H=h8, W=w8, C=up[1], ldx=up[1], ldy=CT, r=2)
+        ol.area_down(p4.t, gcat.view(-1)[up[1]:], B=K, H=h4, W=w4, C=up[2], ldx=up[2], ldy=CT, r=4)
+        ol.area_down(logits, gcat.view(-1)[up[1] + up[2]:], B=K, H=h4, W=w4, C=1, ldx=1, ldy=CT, r=4, f32_in=True, Cz=8)
+        g3 = P.conv('mask_decoder.sensory_update.g_all', p16, x2=Act(gcat, K, h, w, CT), name='g3')
         vals = P.conv('mask_decoder.sensory_update.transform', g3, x2=Act(Dyn('sensory_bf16'), K, h, w, CS),
                       out_f32=True, name='gru_vals')
         ol.gru(vals.t, Dyn('sensory_f32'), Dyn('sensory_bf16'), n=K * h * w, C=CS)

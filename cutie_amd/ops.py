@@ -311,8 +311,10 @@ class OpList:
     def area_down(self, x, y, *, B, H, W, C, ldx, ldy, r, f32_in=False, Cz=None):
         return self.add(AREA_DOWN, 1 if f32_in else 0, [B, H, W, C, ldx, ldy, r, C if Cz is None else Cz], [], [x, y])
 
-    def mask_down(self, masks, pair, m16, *, K, H, W, r=16):
-        return self.add(MASK_DOWN, 0, [K, H, W, r], [], [masks, pair, m16])
+    def mask_down(self, masks, pair, m16, *, K, H, W, r=16, pair_channels=8):
+        """pair_channels: channel pitch of `pair` (8, or 64 when it is the second source of an LDS-DMA conv: channels 8.. are not written)."""
+        assert pair_channels % 8 == 0
+        return self.add(MASK_DOWN, 0, [K, H, W, r, pair_channels], [], [masks, pair, m16])
 
     def gap(self, x, y, *, B, HW, C, scratch=None, partial_only=False):
         if scratch is None:

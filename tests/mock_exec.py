@@ -183,7 +183,8 @@ class MockExecutor:
         out = torch.zeros(K, h, w, 8)
         out[..., 0] = m16
         out[..., 1] = (m16.sum(0, keepdim=True) - m16).clamp(0, 1)
-        view(p[1], BF16, (K, h, w, 8)).copy_(out)
+        ld = i[4] if len(i) > 4 and i[4] > 8 else 8
+        view(p[1], BF16, (K, h, w, 8), (h * w * ld, w * ld, ld, 1)).copy_(out)
 
     # ---- GAP / ECA ----------------------------------------------------------------------
     def _op_7(self, flags, i, f, p):
