@@ -172,15 +172,24 @@ __global__ void mask_down_pair_kernel(const float* __restrict__ m, float* __rest
     if (px >= hw) return;                                   // whole wave
     const int ox = px % w, oy = px / w;
     float sum = 0.f;
-    for (int k = 0; k < K; ++k) {
-        float acc = 0.f;
+    // four objects per round with all their loads in flight (one object after the other cost K dependent round trips: 21 us at K = 3)
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int e = lane; e < r * r; e += 64) {
             const int dy = e / r, dx = e - dy * r;
-            acc += m[((long)k * H + oy * r + dy) * W + ox * r + dx];
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = m[((long)min(k0 + u, K - 1) * H + oy * r + dy) * W + ox * r + dx];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += v[u];
         }
-        acc = wave_sum(acc) / (float)(r * r);
-        sum += acc;
-        if (lane == 0) m16[(long)k * hw + px] = acc;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k0 + u >= K) break;                       // wave-uniform
+            const float a = wave_sum(acc[u]) / (float)(r * r);
+            sum += a;
+            if (lane == 0) m16[(long)(k0 + u) * hw + px] = a;
+        }
     }
     if (lane == 0)
         for (int k = 0; k < K; ++k) {
@@ -555,18 +564,19 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
 // query side of the transformer is an fp32 island) and is split into bf16 hi + lo on the fly, W is bf16: two
 // v_mfma_f32_16x16x32_bf16 per 32 k (fp32-class accuracy), no cross-lane reduction, one memory round trip per wave.
 // A = x rows (lane: row l&15, k 8*(l>>4)..+7), B = W^T (lane: column l&15, same k: a contiguous 16-B piece of W's row).
-__global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xadd,
+template <int NW>                                       // waves per block: the K range is split over them (16 for long K: FFN linear2)
+__global__ __launch_bounds__(NW * 64) void linear_mfma_kernel(const float* __restrict__ x, const float* __restrict__ xadd,
                                                           const bf16_t* __restrict__ W, const float* __restrict__ bias,
                                                           const float* __restrict__ res, float* __restrict__ y, int M, int N,
                                                           int Kd, int ldx, int ldy, int add_rows, int relu, int add_cols,
                                                           const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                           float* __restrict__ ln_out, float eps) {
     typedef __attribute__((ext_vector_type(4))) unsigned int u4;
-    __shared__ f32x4 red[3][64];
+    __shared__ f32x4 red[NW - 1][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
     const int m = min(m0 + c, M - 1), n = min(n0 + c, N - 1);
-    const int per = (Kd >> 5) >> 2;                          // 32-wide k steps per wave (Kd % 128 == 0)
+    const int per = (Kd >> 5) / NW;                          // 32-wide k steps per wave (Kd % (32 NW) == 0)
     const float* xrow = x + (long)m * ldx;
     // fused LayerNorm over the Kd inputs of row m (flag: ln_g != 0; Kd == 256): lane (c, g) reads the 64 values
     // k = 64 g .. of its row, the 4 lanes of a row combine through permlane swaps; every wave does this for itself
@@ -626,7 +636,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
-        for (int w = 0; w < 3; ++w) { const f32x4 t = red[w][lane]; acc[0] += t[0]; acc[1] += t[1]; acc[2] += t[2]; acc[3] += t[3]; }
+        for (int w = 0; w < NW - 1; ++w) { const f32x4 t = red[w][lane]; acc[0] += t[0]; acc[1] += t[1]; acc[2] += t[2]; acc[3] += t[3]; }
         const int nn = n0 + c;
         if (nn < N) {
             const float bv = bias ? bias[nn] : 0.f;
@@ -903,8 +913,12 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             if (ln && (i[2] != 256 || !p[6] || !p[7] || (i[3] & 3))) { cutie_set_error("linear: fused LayerNorm needs Kd == 256, gamma and beta"); return -2; }
             if ((ln || i[6] > 0) && (i[2] & 127)) { cutie_set_error("linear: LayerNorm / add_cols need Kd %% 128 == 0"); return -2; }
             if (i[6] > 0 && (i[6] & 15)) { cutie_set_error("linear: add_cols must be a multiple of 16"); return -2; }
-            if ((i[2] & 127) == 0)
-                hipLaunchKernelGGL(linear_mfma_kernel, dim3((i[1] + 15) / 16, (i[0] + 15) / 16), dim3(256), 0, s, (const float*)p[0], (const float*)p[1], (const bf16_t*)p[2],
+            if ((i[2] & 511) == 0 && i[2] >= 1024 && !ln)                // long K (FFN linear2, K = 2048): 16 waves share it
+                hipLaunchKernelGGL(linear_mfma_kernel<16>, dim3((i[1] + 15) / 16, (i[0] + 15) / 16), dim3(1024), 0, s, (const float*)p[0], (const float*)p[1], (const bf16_t*)p[2],
+                                   (const float*)p[3], (const float*)p[4], (float*)p[5], i[0], i[1], i[2], i[3], i[4], add_rows, op->flags & 1, i[6],
+                                   (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 1e-5f);
+            else if ((i[2] & 127) == 0)
+                hipLaunchKernelGGL(linear_mfma_kernel<4>, dim3((i[1] + 15) / 16, (i[0] + 15) / 16), dim3(256), 0, s, (const float*)p[0], (const float*)p[1], (const bf16_t*)p[2],
                                    (const float*)p[3], (const float*)p[4], (float*)p[5], i[0], i[1], i[2], i[3], i[4], add_rows, op->flags & 1, i[6],
                                    ln ? (const float*)p[6] : nullptr, (const float*)p[7], (float*)p[8], op->f[0] > 0.f ? op->f[0] : 1e-5f);
             else if (i[2] >= 512)
