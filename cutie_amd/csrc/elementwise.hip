@@ -104,10 +104,9 @@ __global__ void upsample2x_add_kernel(const uint4* __restrict__ g, const uint4* 
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ void area_down_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int C,
-                                      int ldx, int ldy, int r) {
+__device__ __forceinline__ void area_down_bf16_body(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int C,
+                                                    int ldx, int ldy, int r, long idx) {
     int C8 = C >> 3, OH = H / r, OW = W / r;
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long total = (long)B * OH * OW * C8;
     if (idx >= total) return;
     int c = idx % C8; long t = idx / C8;
@@ -128,11 +127,14 @@ __global__ void area_down_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __re
                          pack_bf2(acc[4] * inv, acc[5] * inv), pack_bf2(acc[6] * inv, acc[7] * inv));
     *reinterpret_cast<uint4*>(y + (((long)b * OH + oy) * OW + ox) * ldy + c * 8) = o;
 }
+__global__ void area_down_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int C,
+                                      int ldx, int ldy, int r) {
+    area_down_bf16_body(x, y, B, H, W, C, ldx, ldy, r, (long)blockIdx.x * blockDim.x + threadIdx.x);
+}
 
-__global__ void area_down_f32_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int C,
-                                     int ldx, int ldy, int r, int Cz) {
+__device__ __forceinline__ void area_down_f32_body(const float* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int C,
+                                                   int ldx, int ldy, int r, int Cz, long idx) {
     int OH = H / r, OW = W / r;
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long total = (long)B * OH * OW;
     if (idx >= total) return;
     int ox = idx % OW; long t = idx / OW; int oy = t % OH; int b = t / OH;
@@ -145,6 +147,26 @@ __global__ void area_down_f32_kernel(const float* __restrict__ x, bf16_t* __rest
         yp[c] = f2bf(acc * inv);
     }
     for (int c = C; c < Cz; ++c) yp[c] = 0;
+}
+__global__ void area_down_f32_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int C,
+                                     int ldx, int ldy, int r, int Cz) {
+    area_down_f32_body(x, y, B, H, W, C, ldx, ldy, r, Cz, (long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// AREA_DOWN3: three area poolings in one launch (the g8 / g4 / logits inputs of the sensory update): thread ranges [0, n0), [n0, n0+n1), ...
+struct AreaSeg { const void* x; bf16_t* y; int B, H, W, C, ldx, ldy, r, Cz, f32; long n; };
+struct Area3 { AreaSeg s[3]; };
+__global__ void area_down3_kernel(Area3 a) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const AreaSeg& g = a.s[q];
+        if (idx < g.n) {
+            if (g.f32) area_down_f32_body((const float*)g.x, g.y, g.B, g.H, g.W, g.C, g.ldx, g.ldy, g.r, g.Cz, idx);
+            else area_down_bf16_body((const bf16_t*)g.x, g.y, g.B, g.H, g.W, g.C, g.ldx, g.ldy, g.r, idx);
+            return;
+        }
+        idx -= g.n;
+    }
 }
 
 // masks f32 [K,H,W] -> m16 f32 [K,h,w]: one wave per output pixel (r*r = 256 inputs, 4 per lane, row-coalesced)
@@ -851,6 +873,23 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
                 hipLaunchKernelGGL(area_down_f32_kernel, GRID1D(np, BS), dim3(BS), 0, s, (const float*)p[0], (bf16_t*)p[1], i[0], i[1], i[2], i[3], i[4], i[5], r, i[7]);
             else
                 hipLaunchKernelGGL(area_down_bf16_kernel, GRID1D(np * (i[3] / 8), BS), dim3(BS), 0, s, (const bf16_t*)p[0], (bf16_t*)p[1], i[0], i[1], i[2], i[3], i[4], i[5], r);
+            break;
+        }
+        case CUTIE_OP_AREA_DOWN3: {
+            Area3 a;
+            long total = 0;
+            for (int q = 0; q < 3; ++q) {
+                const int32_t* j = i + 8 * q;
+                AreaSeg& g = a.s[q];
+                g.x = (const void*)p[2 * q]; g.y = (bf16_t*)p[2 * q + 1];
+                g.B = j[0]; g.H = j[1]; g.W = j[2]; g.C = j[3]; g.ldx = j[4]; g.ldy = j[5]; g.r = j[6]; g.Cz = j[7];
+                g.f32 = (op->flags >> q) & 1;
+                if (g.r < 1 || (!g.f32 && (g.C & 7))) { cutie_set_error("area_down3: segment %d: r >= 1, C %% 8 for bf16 input", q); return -2; }
+                const long np = (long)g.B * (g.H / g.r) * (g.W / g.r);
+                g.n = g.f32 ? np : np * (g.C / 8);
+                total += g.n;
+            }
+            hipLaunchKernelGGL(area_down3_kernel, GRID1D(total, BS), dim3(BS), 0, s, a);
             break;
         }
         case CUTIE_OP_MASK_DOWN: {

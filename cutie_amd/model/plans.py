@@ -426,9 +426,9 @@ def build_segment(eng, K, h, w, update_sensory, pre=False):
         # g4_conv (Engine: '.g_all'); the logits take a whole 64-channel K tile (channel 0 written, the rest stays zero)
         CT = up[1] + up[2] + 64
         gcat = P.buf('gcat', (K, h, w, CT))
-        ol.area_down(p8.t, gcat, B=K, H=h8, W=w8, C=up[1], ldx=up[1], ldy=CT, r=2)
-        ol.area_down(p4.t, gcat.view(-1)[up[1]:], B=K, H=h4, W=w4, C=up[2], ldx=up[2], ldy=CT, r=4)
-        ol.area_down(logits, gcat.view(-1)[up[1] + up[2]:], B=K, H=h4, W=w4, C=1, ldx=1, ldy=CT, r=4, f32_in=True, Cz=8)
+        ol.area_down3([dict(x=p8.t, y=gcat, B=K, H=h8, W=w8, C=up[1], ldx=up[1], ldy=CT, r=2),
+                       dict(x=p4.t, y=gcat.view(-1)[up[1]:], B=K, H=h4, W=w4, C=up[2], ldx=up[2], ldy=CT, r=4),
+                       dict(x=logits, y=gcat.view(-1)[up[1] + up[2]:], B=K, H=h4, W=w4, C=1, ldx=1, ldy=CT, r=4, f32_in=True, Cz=8)])
         g3 = P.conv('mask_decoder.sensory_update.g_all', p16, x2=Act(gcat, K, h, w, CT), name='g3')
         vals = P.conv('mask_decoder.sensory_update.transform', g3, x2=Act(Dyn('sensory_bf16'), K, h, w, CS),
                       out_f32=True, name='gru_vals')

@@ -19,13 +19,13 @@ assert OP_DTYPE.itemsize == _lib.OP_STRUCT_SIZE
 (CONV, MAXPOOL, IMG_PREP, UPSAMPLE2X_ADD, AREA_DOWN, MASK_DOWN, GAP, ECA_APPLY, GRU, SEG_AGG, UP4_SOFTMAX,
  MASK_MERGE, AGG_SOFTMAX, LINEAR, LAYERNORM, QUERY_INIT, AUX_MASK, ATTN_Q2P, ATTN_SELF, ATTN_P2Q, SUMMARIZE,
  ADD_PE, KEY_PREP, AFF_SCORE, AFF_SELECT, AFF_READOUT, MEMSET32, COPY2D, AXPY, USAGE_TICK, RANK_SELECT,
- GATHER_ROWS, CONSOL_AFF, CONSOL_READ, CAST, PROB_TO_ID, RESIZE, FLIP_W) = range(1, 39)
+ GATHER_ROWS, CONSOL_AFF, CONSOL_READ, CAST, PROB_TO_ID, RESIZE, FLIP_W, AREA_DOWN3) = range(1, 40)
 
 KIND_NAMES = {}
 for _n in ('CONV MAXPOOL IMG_PREP UPSAMPLE2X_ADD AREA_DOWN MASK_DOWN GAP ECA_APPLY GRU SEG_AGG UP4_SOFTMAX MASK_MERGE '
            'AGG_SOFTMAX LINEAR LAYERNORM QUERY_INIT AUX_MASK ATTN_Q2P ATTN_SELF ATTN_P2Q SUMMARIZE ADD_PE KEY_PREP '
            'AFF_SCORE AFF_SELECT AFF_READOUT MEMSET32 COPY2D AXPY USAGE_TICK RANK_SELECT GATHER_ROWS CONSOL_AFF '
-           'CONSOL_READ CAST PROB_TO_ID RESIZE FLIP_W').split():
+           'CONSOL_READ CAST PROB_TO_ID RESIZE FLIP_W AREA_DOWN3').split():
     KIND_NAMES[globals()[_n]] = _n
 
 F_RELU_IN, F_OUT_F32, F_RES_BCAST = 1, 2, 4
@@ -310,6 +310,16 @@ class OpList:
 
     def area_down(self, x, y, *, B, H, W, C, ldx, ldy, r, f32_in=False, Cz=None):
         return self.add(AREA_DOWN, 1 if f32_in else 0, [B, H, W, C, ldx, ldy, r, C if Cz is None else Cz], [], [x, y])
+
+    def area_down3(self, segs):
+        """Three area poolings in one launch; segs = 3 x dict(x, y, B, H, W, C, ldx, ldy, r, f32_in=False, Cz=None)."""
+        assert len(segs) == 3
+        ints, ptrs, flags = [], [], 0
+        for q, g in enumerate(segs):
+            ints += [g['B'], g['H'], g['W'], g['C'], g['ldx'], g['ldy'], g['r'], g['C'] if g.get('Cz') is None else g['Cz']]
+            ptrs += [g['x'], g['y']]
+            flags |= (1 << q) if g.get('f32_in') else 0
+        return self.add(AREA_DOWN3, flags, ints, [], ptrs)
 
     def mask_down(self, masks, pair, m16, *, K, H, W, r=16, pair_channels=8):
         """pair_channels: channel pitch of `pair` (8, or 64 when it is the second source of an LDS-DMA conv: channels 8.. are not written)."""

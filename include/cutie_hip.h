@@ -223,6 +223,9 @@ enum {
      * of the two passes (inference_core.py:162-165,234-235,303-305).  src and dst must not overlap.
      * p0=src f32 [rows, W] (row stride i2) p1=dst f32 [rows, W] (row stride i3)   i: 0 rows 1 W 2 3   f: 0 alpha 1 beta */
     CUTIE_OP_FLIP_W = 38,
+    /* AREA_DOWN3: three AREA_DOWNs in one launch (SensoryUpdater's area poolings of g8 / g4 / logits, modules.py:59-60).
+     * segment q = 0..2: p[2q]=x p[2q+1]=y, i[8q..8q+7] = B H W C ldx ldy r Cz as in AREA_DOWN, flags bit q: f32 input */
+    CUTIE_OP_AREA_DOWN3 = 39,
     CUTIE_OP__COUNT
 };
 

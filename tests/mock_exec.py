@@ -173,6 +173,10 @@ class MockExecutor:
         if (flags & 1) and Cz > C:
             out[..., C:Cz] = 0
 
+    def _op_39(self, flags, i, f, p):                                   # AREA_DOWN3 = three AREA_DOWNs
+        for q in range(3):
+            self._op_5((flags >> q) & 1, i[8 * q:8 * q + 8], f, p[2 * q:2 * q + 2])
+
     # ---- MASK_DOWN --------------------------------------------------------------------
     def _op_6(self, flags, i, f, p):
         K, H, W, r = i[:4]

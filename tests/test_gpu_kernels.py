@@ -332,6 +332,30 @@ def test_mask_down():
     check(*run_both(build), name='mask_down', rtol=1e-2)
 
 
+def test_area_down3():
+    """Three area poolings in one launch, written side by side into one concat buffer (the sensory update's inputs)."""
+    def build(dev, g):
+        K, h, w = 3, 6, 10
+        p8 = rnd(g, (K, 2 * h, 2 * w, 128), dev=dev)
+        p4 = rnd(g, (K, 4 * h, 4 * w, 128), dev=dev)
+        lg = (torch.randn((K, 4 * h, 4 * w), generator=g) * 3).to(dev)
+        CT = 128 + 128 + 64
+        cat3 = torch.zeros((K, h, w, CT), dtype=BF16, device=dev)
+        cat1 = torch.zeros((K, h, w, CT), dtype=BF16, device=dev)
+        ol = O.OpList()
+        segs = lambda y: [dict(x=p8, y=y, B=K, H=2 * h, W=2 * w, C=128, ldx=128, ldy=CT, r=2),
+                          dict(x=p4, y=y.view(-1)[128:], B=K, H=4 * h, W=4 * w, C=128, ldx=128, ldy=CT, r=4),
+                          dict(x=lg, y=y.view(-1)[256:], B=K, H=4 * h, W=4 * w, C=1, ldx=1, ldy=CT, r=4, f32_in=True, Cz=8)]
+        ol.area_down3(segs(cat3))
+        for sgm in segs(cat1):
+            sgm = dict(sgm)
+            ol.area_down(sgm.pop('x'), sgm.pop('y'), **sgm)
+        return ol, {'cat3': cat3, 'cat1': cat1}
+    hip, ref = run_both(build)
+    check(hip, ref, 'area_down3')
+    assert torch.equal(hip['cat3'].view(torch.int16), hip['cat1'].view(torch.int16))
+
+
 def test_gap_eca():
     def build(dev, g):
         B, HW, C = 3, 1620, 256
