@@ -58,12 +58,86 @@ __device__ __forceinline__ void split_bf2(float a, float b, uint32_t& hi, uint32
     lo = (uint32_t)f2bf(a - bf2f(ha)) | ((uint32_t)f2bf(b - bf2f(hb)) << 16);
 }
 
+
+// ---- projections computed inside the attention kernels (round 2: one launch less per attention) ---------------------------------
+// The 16 query rows of one object are staged in LDS (LayerNorm'd and / or with the query embedding added, exactly the inputs the
+// LINEAR op would have read), and a 16 x 16 output tile of x . W^T runs on MFMA with x split into bf16 hi + lo (the arithmetic of
+// linear_mfma_kernel): lane (c, g) of the result holds rows 4g..4g+3 of column c.
+#define PROJ_XLD 260                                     // fp32 row pitch of the staged rows (256 + 4: staggers the banks)
+struct ProjIn {                                          // what a fused projection needs besides the attention operands
+    const float* x;                                      // [K*16, 256] fp32 rows (row stride ldx)
+    const float* add;                                    // query embedding [K*16, 256] or null
+    const float* ln_g; const float* ln_b;                // LayerNorm in front (null: none)
+    float* ln_out;                                       // [K*16, 256]: the normalised rows, written once per object (null: not kept)
+    const bf16_t* W; const float* bias;                  // packed linear [N][256] bf16, bias [N]
+    int ldx;
+};
+
+// rows of object k -> LDS.  xs_add: LN(x) + add (or x + add); xs_plain (nullable): LN(x) (or x).  Wave w takes rows w, w + NW, ...
+template <int NW>
+__device__ __forceinline__ void stage_rows16(const ProjIn& pi, int k, float* xs_add, float* xs_plain, bool write_ln_out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int RPW = 16 / NW;                         // rows per wave; all their loads go out first
+    float4 xv[RPW], av[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const long row = (long)k * 16 + wave + j * NW;
+        xv[j] = *reinterpret_cast<const float4*>(pi.x + row * pi.ldx + lane * 4);
+        av[j] = pi.add ? *reinterpret_cast<const float4*>(pi.add + row * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 gg = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pi.ln_g) { gg = *reinterpret_cast<const float4*>(pi.ln_g + lane * 4); bb = *reinterpret_cast<const float4*>(pi.ln_b + lane * 4); }
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int r = wave + j * NW;
+        float4 v = xv[j];
+        if (pi.ln_g) {
+            const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.f / 256.f);
+            const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+            const float rstd = rsqrtf(wave_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.f / 256.f) + 1e-5f);
+            v.x = dx * rstd * gg.x + bb.x; v.y = dy * rstd * gg.y + bb.y; v.z = dz * rstd * gg.z + bb.z; v.w = dw * rstd * gg.w + bb.w;
+            if (pi.ln_out && write_ln_out) *reinterpret_cast<float4*>(pi.ln_out + ((long)k * 16 + r) * 256 + lane * 4) = v;
+        }
+        if (xs_plain) *reinterpret_cast<float4*>(xs_plain + r * PROJ_XLD + lane * 4) = v;
+        v.x += av[j].x; v.y += av[j].y; v.z += av[j].z; v.w += av[j].w;
+        *reinterpret_cast<float4*>(xs_add + r * PROJ_XLD + lane * 4) = v;
+    }
+}
+
+// partial 16 x 16 tile: weight rows n0..n0+15, STEPS 32-wide k steps from ks0.  The weight fragments are requested first, all of
+// them (an L2 round trip each: issued one per step in front of its MFMAs they cost 12 dependent round trips in ATTN_SELF).
+typedef __attribute__((ext_vector_type(4))) unsigned int proj_u4;
+template <int STEPS>
+__device__ __forceinline__ void proj16_load(const bf16_t* __restrict__ W, int n0, int ks0, proj_u4* wv) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int s_ = 0; s_ < STEPS; ++s_) wv[s_] = *reinterpret_cast<const proj_u4*>(W + (long)(n0 + c) * 256 + (ks0 + s_) * 32 + 8 * g);
+}
+template <int STEPS>
+__device__ __forceinline__ f32x4 proj16_mma(const float* xs, int ks0, const proj_u4* wv) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s_ = 0; s_ < STEPS; ++s_) {
+        const int kw = (ks0 + s_) * 32 + 8 * g;
+        const float4 a = *reinterpret_cast<const float4*>(xs + c * PROJ_XLD + kw), b = *reinterpret_cast<const float4*>(xs + c * PROJ_XLD + kw + 4);
+        const float xv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        proj_u4 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { uint32_t h_, l_; split_bf2(xv[2 * i], xv[2 * i + 1], h_, l_); hi[i] = h_; lo[i] = l_; }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, lo), __builtin_bit_cast(bf16x8, wv[s_]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, hi), __builtin_bit_cast(bf16x8, wv[s_]), acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(1024) void attn_q2p_kernel(const float* __restrict__ q, const bf16_t* __restrict__ kv,
                                                         const uint8_t* __restrict__ fg, const int* __restrict__ nfg,
                                                         float* __restrict__ y, int Q, int HW, int C, int ldkv, int voff,
-                                                        const float* __restrict__ lg) {
+                                                        const float* __restrict__ lg, ProjIn pi) {
     __shared__ float sO[16][16][33];                       // [wave][query][dim]
     __shared__ float sM[16][16], sL[16][16];
+    __shared__ float sQ[16][33];                           // fused projection: this head's 32 query columns, scaled
     __shared__ int sCnt;
     extern __shared__ uint8_t sFg[];                       // HW flags (fused form only)
     const int hh = blockIdx.x, k = blockIdx.y;
@@ -71,7 +145,32 @@ __global__ __launch_bounds__(1024) void attn_q2p_kernel(const float* __restrict_
     const int c16 = lane & 15, g = lane >> 4;              // c16: query (B/D column) or pixel/dim (A row)
     const float scale = rsqrtf(32.f);
     q2p_frag qh, ql;
-    {
+    if (pi.W) {
+        // q = (LN(x) + emb) . Wq[head]^T + b computed here (flags&2: the LINEAR launch in front of this one is gone): the staging
+        // buffers alias sO, which is only used after the pixel loop.  16 waves = 2 column tiles x 8 k-steps, summed through LDS.
+        float* xs = &sO[0][0][0];
+        f32x4* red = reinterpret_cast<f32x4*>(xs + 16 * PROJ_XLD);
+        static_assert(sizeof(float) * 16 * PROJ_XLD + sizeof(f32x4) * 16 * 64 <= sizeof(float) * 16 * 16 * 33, "projection staging fits in sO");
+        const int tile = wave & 1, ks = wave >> 1;
+        proj_u4 wq[1];
+        proj16_load<1>(pi.W, hh * 32 + tile * 16, ks, wq);         // in flight while the rows are normalised
+        stage_rows16<16>(pi, k, xs, nullptr, hh == 0);
+        __syncthreads();
+        red[wave * 64 + lane] = proj16_mma<1>(xs, ks, wq);
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int t = threadIdx.x >> 6;
+            f32x4 a = red[t * 64 + lane];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) { const f32x4 b = red[(t + 2 * j) * 64 + lane]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
+            const float bv = pi.bias ? pi.bias[hh * 32 + t * 16 + c16] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sQ[4 * g + r][t * 16 + c16] = (a[r] + bv) * scale;
+        }
+        __syncthreads();                                   // sQ complete; xs / red (= sO) are free again
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { uint32_t h_, l_; split_bf2(sQ[c16][8 * g + 2 * j], sQ[c16][8 * g + 2 * j + 1], h_, l_); qh.u[j] = h_; ql.u[j] = l_; }
+    } else {
         const float* qr = q + ((long)k * Q + c16) * C + hh * 32 + 8 * g;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { uint32_t h_, l_; split_bf2(qr[2 * j] * scale, qr[2 * j + 1] * scale, h_, l_); qh.u[j] = h_; ql.u[j] = l_; }
@@ -177,18 +276,46 @@ __global__ __launch_bounds__(1024) void attn_q2p_kernel(const float* __restrict_
     }
 }
 
-// ATTN_SELF: grid (heads, K), block 64: lane = query*4 + part (8 dims each)
-__global__ void attn_self_kernel(const float* __restrict__ qk, const float* __restrict__ v, float* __restrict__ y, int Q, int C,
-                                 int ldqk, int ldv) {
-    const int hh = blockIdx.x, k = blockIdx.y, lane = threadIdx.x, qi = lane >> 2, part = lane & 3;
+// ATTN_SELF: grid (heads, K), block 64: lane = query*4 + part (8 dims each).
+// Fused form (pi.W != 0, block 256): q | k | v of this head are projected here from the object's 16 rows -- q and k from
+// LN(x) + emb, v from LN(x) (transformer_layers.py:28-41) -- instead of by a LINEAR launch: 4 waves x 2 k-steps x 6 column tiles,
+// summed through LDS; wave 0 then runs the 16 x 16 attention on the LDS copies.
+__global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict__ qk, const float* __restrict__ v, float* __restrict__ y, int Q, int C,
+                                                        int ldqk, int ldv, ProjIn pi) {
+    __shared__ float sX[2][16 * PROJ_XLD];                 // [LN(x)+emb | LN(x)]
+    __shared__ f32x4 sRed[4][6][64];
+    __shared__ float sP[3][16][33];                        // q (scaled) | k | v of this head
+    const int hh = blockIdx.x, k = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, qi = lane >> 2, part = lane & 3;
     const float scale = rsqrtf(32.f);
+    if (pi.W) {
+        proj_u4 wv[6][2];                                  // tiles 0,1: q  2,3: k  4,5: v (weight rows (t/2)*C + head*32 + (t&1)*16)
+#pragma unroll
+        for (int t = 0; t < 6; ++t) proj16_load<2>(pi.W, (t >> 1) * C + hh * 32 + (t & 1) * 16, 2 * wave, wv[t]);
+        stage_rows16<4>(pi, k, sX[0], sX[1], hh == 0);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 6; ++t) sRed[wave][t][lane] = proj16_mma<2>(sX[t < 4 ? 0 : 1], 2 * wave, wv[t]);
+        __syncthreads();
+        for (int e = threadIdx.x; e < 6 * 64; e += 256) {
+            const int t = e >> 6, l = e & 63, c = l & 15, g = l >> 4;
+            f32x4 a = sRed[0][t][l];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) { const f32x4 b = sRed[w][t][l]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
+            const int col = (t & 1) * 16 + c;
+            const float bv = pi.bias ? pi.bias[(t >> 1) * C + hh * 32 + col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sP[t >> 1][4 * g + r][col] = (a[r] + bv) * (t < 2 ? scale : 1.f);
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
     float qf[8];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) qf[d] = qk[((long)k * Q + qi) * ldqk + hh * 32 + part * 8 + d] * scale;
+    for (int d = 0; d < 8; ++d) qf[d] = pi.W ? sP[0][qi][part * 8 + d] : qk[((long)k * Q + qi) * ldqk + hh * 32 + part * 8 + d] * scale;
     float s[16], mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const float* kr = qk + ((long)k * Q + j) * ldqk + C + hh * 32 + part * 8;
+        const float* kr = pi.W ? &sP[1][j][part * 8] : qk + ((long)k * Q + j) * ldqk + C + hh * 32 + part * 8;
         float a = 0.f;
 #pragma unroll
         for (int d = 0; d < 8; ++d) a += qf[d] * kr[d];
@@ -204,7 +331,7 @@ __global__ void attn_self_kernel(const float* __restrict__ qk, const float* __re
     float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const float* vr = v + ((long)k * Q + j) * ldv + hh * 32 + part * 8;
+        const float* vr = pi.W ? &sP[2][j][part * 8] : v + ((long)k * Q + j) * ldv + hh * 32 + part * 8;
 #pragma unroll
         for (int d = 0; d < 8; ++d) o[d] += s[j] * vr[d];
     }
@@ -213,11 +340,26 @@ __global__ void attn_self_kernel(const float* __restrict__ qk, const float* __re
 }
 
 // ATTN_P2Q: grid (ceil(HW/256), heads, K): one thread per (pixel, head)
+// Fused form (pi.W != 0): k | v of the 16 object queries for this head are projected here (k from x + emb, v from x; the packed
+// [k | v] weight of read_from_query) instead of by a LINEAR launch: wave w computes column tile w (k: 0, 1; v: 2, 3) over all of K.
 __global__ __launch_bounds__(256) void attn_p2q_kernel(const bf16_t* __restrict__ q, const float* __restrict__ kq,
                                                        const float* __restrict__ vq, bf16_t* __restrict__ y, int Q, int HW,
-                                                       int C, int ldq, int ldkv) {
+                                                       int C, int ldq, int ldkv, ProjIn pi) {
     __shared__ float ks[16][32], vs[16][32];
+    __shared__ float sX[2][16 * PROJ_XLD];
     const int hh = blockIdx.y, k = blockIdx.z;
+    if (pi.W) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+        const int isv = wave >> 1, col = (wave & 1) * 16;
+        proj_u4 wv[8];
+        proj16_load<8>(pi.W, isv * C + hh * 32 + col, 0, wv);
+        stage_rows16<4>(pi, k, sX[0], sX[1], false);
+        __syncthreads();
+        const f32x4 a = proj16_mma<8>(sX[isv], 0, wv);
+        const float bv = pi.bias ? pi.bias[isv * C + hh * 32 + col + c] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) (isv ? vs : ks)[4 * g + r][col + c] = a[r] + bv;
+    } else
     for (int t = threadIdx.x; t < 512; t += 256) {
         int j = t >> 5, d = t & 31;
         ks[j][d] = kq[((long)k * Q + j) * ldkv + hh * 32 + d];
@@ -271,26 +413,48 @@ int launch_attention(const cutie_op* op, hipStream_t s) {
         case CUTIE_OP_AUX_MASK:
             hipLaunchKernelGGL(aux_mask_kernel, dim3((i[1] + 255) / 256), dim3(256), 0, s, (const float*)p[0], (uint8_t*)p[1], (int*)p[2], i[0], i[1]);
             break;
-        case CUTIE_OP_ATTN_Q2P:
+        case CUTIE_OP_ATTN_Q2P: {
             if (i[1] != 16 || i[3] != i[4] * 32) { cutie_set_error("attn_q2p: Q=16, head dim 32 only"); return -2; }
             if ((op->flags & 1) && i[2] > 24576) { cutie_set_error("attn_q2p: fused aux mask holds HW <= 24576 flags in LDS (HW=%d)", i[2]); return -2; }
+            ProjIn pi = {};
+            if (op->flags & 2) {                             // q projection fused: p0 = x (rows of i[7] floats), p3 = ln_out, p5..p9 = Wq, bq, emb, gamma, beta
+                if (!(op->flags & 1) || i[3] != 256) { cutie_set_error("attn_q2p: the fused q projection needs the fused mask form and C == 256"); return -2; }
+                pi.x = (const float*)p[0]; pi.ln_out = (float*)p[3]; pi.W = (const bf16_t*)p[5]; pi.bias = (const float*)p[6];
+                pi.add = (const float*)p[7]; pi.ln_g = (const float*)p[8]; pi.ln_b = (const float*)p[9]; pi.ldx = i[7] > 0 ? i[7] : 256;
+            }
             if (op->flags & 1)                               // p2 = mask_pred logits f32 [K,HW]; fg / nfg are not read
                 hipLaunchKernelGGL(attn_q2p_kernel, dim3(i[4], i[0]), dim3(1024), (size_t)((i[2] + 15) & ~15), s, (const float*)p[0], (const bf16_t*)p[1],
-                                   (const uint8_t*)nullptr, (const int*)nullptr, (float*)p[4], i[1], i[2], i[3], i[5], i[6], (const float*)p[2]);
+                                   (const uint8_t*)nullptr, (const int*)nullptr, (float*)p[4], i[1], i[2], i[3], i[5], i[6], (const float*)p[2], pi);
             else
                 hipLaunchKernelGGL(attn_q2p_kernel, dim3(i[4], i[0]), dim3(1024), 0, s, (const float*)p[0], (const bf16_t*)p[1], (const uint8_t*)p[2],
-                                   (const int*)p[3], (float*)p[4], i[1], i[2], i[3], i[5], i[6], (const float*)nullptr);
+                                   (const int*)p[3], (float*)p[4], i[1], i[2], i[3], i[5], i[6], (const float*)nullptr, pi);
             break;
+        }
         case CUTIE_OP_ATTN_SELF:
             if (i[1] != 16 || i[2] != i[3] * 32) { cutie_set_error("attn_self: Q=16, head dim 32 only"); return -2; }
+            if (op->flags & 2) {                             // qkv projection fused: p0 = x, p3 = ln_out, p5..p9 = Wqkv, b, emb, gamma, beta
+                if (i[2] != 256) { cutie_set_error("attn_self: the fused projection needs C == 256"); return -2; }
+                ProjIn pi = {};
+                pi.x = (const float*)p[0]; pi.ln_out = (float*)p[3]; pi.W = (const bf16_t*)p[5]; pi.bias = (const float*)p[6];
+                pi.add = (const float*)p[7]; pi.ln_g = (const float*)p[8]; pi.ln_b = (const float*)p[9]; pi.ldx = i[6] > 0 ? i[6] : 256;
+                hipLaunchKernelGGL(attn_self_kernel, dim3(i[3], i[0]), dim3(256), 0, s, (const float*)nullptr, (const float*)nullptr, (float*)p[2], i[1], i[2], 0, 0, pi);
+                break;
+            }
             hipLaunchKernelGGL(attn_self_kernel, dim3(i[3], i[0]), dim3(64), 0, s, (const float*)p[0], (const float*)p[1], (float*)p[2], i[1], i[2],
-                               i[4] > 0 ? i[4] : 2 * i[2], i[5] > 0 ? i[5] : i[2]);
+                               i[4] > 0 ? i[4] : 2 * i[2], i[5] > 0 ? i[5] : i[2], ProjIn{});
             break;
         case CUTIE_OP_ATTN_P2Q:
             if (i[1] != 16 || i[3] != i[4] * 32) { cutie_set_error("attn_p2q: Q=16, head dim 32 only"); return -2; }
+        {
+            ProjIn pi = {};
+            if (op->flags & 2) {                             // kv projection fused: p1 = x (query rows), p5..p7 = Wkv, b, emb
+                if (i[3] != 256) { cutie_set_error("attn_p2q: the fused projection needs C == 256"); return -2; }
+                pi.x = (const float*)p[1]; pi.W = (const bf16_t*)p[5]; pi.bias = (const float*)p[6]; pi.add = (const float*)p[7]; pi.ldx = i[7] > 0 ? i[7] : 256;
+            }
             hipLaunchKernelGGL(attn_p2q_kernel, dim3((i[2] + 255) / 256, i[4], i[0]), dim3(256), 0, s, (const bf16_t*)p[0], (const float*)p[1],
-                               (const float*)p[2], (bf16_t*)p[3], i[1], i[2], i[3], i[5], i[6] > 0 ? i[6] : i[3]);
+                               (const float*)p[2], (bf16_t*)p[3], i[1], i[2], i[3], i[5], i[6] > 0 ? i[6] : i[3], pi);
             break;
+        }
         default:
             cutie_set_error("attention: unknown op kind %d", op->kind);
             return -3;

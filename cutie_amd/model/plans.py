@@ -354,18 +354,27 @@ def build_readout_query(eng, K, h, w, last_aux=True):
         # block is fused into the linear that consumes it (the normalised rows are kept where the reference reuses them).
         ln = lambda name: (W[q + name + '.weight'], W[q + name + '.bias'])
         xn = f(n + 'xn', (M, C))
-        qp = f(n + 'qp', (M, C))
-        ol.linear(x, W[q + '.read_from_pixel.q'], qp, M=M, x_add=query_emb, add_rows=M, ln=ln('.read_from_pixel.norm'), ln_out=xn)
         att = f(n + 'att', (M, C))
-        ol.attn_q2p(qp, kvq.t, fg, nfg, att, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=aux[b] if fused_mask else None)
+        fuse_proj = fused_mask and C == 256 and not UNFUSED      # the small projections run inside the attention launches
+        if fuse_proj:
+            ol.attn_q2p(None, kvq.t, None, None, att, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=aux[b],
+                        proj=dict(x=x, W=W[q + '.read_from_pixel.q'], emb=query_emb, ln=ln('.read_from_pixel.norm'), ln_out=xn))
+        else:
+            qp = f(n + 'qp', (M, C))
+            ol.linear(x, W[q + '.read_from_pixel.q'], qp, M=M, x_add=query_emb, add_rows=M, ln=ln('.read_from_pixel.norm'), ln_out=xn)
+            ol.attn_q2p(qp, kvq.t, fg, nfg, att, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=aux[b] if fused_mask else None)
         x1 = f(n + 'x1', (M, C))
         ol.linear(att, W[q + '.read_from_pixel.out'], x1, M=M, res=xn)
         # self attention (transformer_layers.py:28-41): q | k | v in one launch, the query PE feeds q and k only
         y = f(n + 'y', (M, C))
-        qkv = f(n + 'qkv', (M, 3 * C))
-        ol.linear(x1, W[q + '.self_attn.qkv'], qkv, M=M, x_add=query_emb, add_rows=M, add_cols=2 * C, ln=ln('.self_attn.norm'), ln_out=y)
         sa = f(n + 'sa', (M, C))
-        ol.attn_self(qkv, qkv.view(-1)[2 * C:], sa, K=K, Q=Q, C=C, heads=heads, ldqk=3 * C, ldv=3 * C)
+        if fuse_proj:
+            ol.attn_self(None, None, sa, K=K, Q=Q, C=C, heads=heads,
+                         proj=dict(x=x1, W=W[q + '.self_attn.qkv'], emb=query_emb, ln=ln('.self_attn.norm'), ln_out=y))
+        else:
+            qkv = f(n + 'qkv', (M, 3 * C))
+            ol.linear(x1, W[q + '.self_attn.qkv'], qkv, M=M, x_add=query_emb, add_rows=M, add_cols=2 * C, ln=ln('.self_attn.norm'), ln_out=y)
+            ol.attn_self(qkv, qkv.view(-1)[2 * C:], sa, K=K, Q=Q, C=C, heads=heads, ldqk=3 * C, ldv=3 * C)
         x2 = f(n + 'x2', (M, C))
         ol.linear(sa, W[q + '.self_attn.out'], x2, M=M, res=y)
         # FFN (transformer_layers.py:113-118)
@@ -375,10 +384,14 @@ def build_readout_query(eng, K, h, w, last_aux=True):
         ol.linear(hid, W[q + '.ffn.linear2'], x3, M=M, res=x2)
         x = x3
         # read_from_query (no norm, residual on the pixels): k | v of the queries in one launch
-        kv2 = f(n + 'kv2', (M, 2 * C))
-        ol.linear(x, W[q + '.read_from_query.kv'], kv2, M=M, x_add=query_emb, add_rows=M, add_cols=C)
         pa = P.buf(n + 'pa', (K, h, w, C))
-        ol.attn_p2q(kvq.t.view(-1)[2 * C:], kv2, kv2.view(-1)[C:], pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C, ldkv=2 * C)
+        if fuse_proj:
+            ol.attn_p2q(kvq.t.view(-1)[2 * C:], None, None, pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C,
+                        proj=dict(x=x, W=W[q + '.read_from_query.kv'], emb=query_emb))
+        else:
+            kv2 = f(n + 'kv2', (M, 2 * C))
+            ol.linear(x, W[q + '.read_from_query.kv'], kv2, M=M, x_add=query_emb, add_rows=M, add_cols=C)
+            ol.attn_p2q(kvq.t.view(-1)[2 * C:], kv2, kv2.view(-1)[C:], pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C, ldkv=2 * C)
         pf = P.conv(q + '.read_from_query.out', Act(pa, K, h, w, C), name=n + 'pf', res=pixel)
         # PixelFFN (transformer_layers.py:121-136)
         last = b == nb - 1

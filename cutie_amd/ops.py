@@ -377,16 +377,37 @@ class OpList:
         self.memset32(nfg, K, 0)
         return self.add(AUX_MASK, 0, [K, HW], [], [logits, fg, nfg])
 
-    def attn_q2p(self, q, kv, fg, nfg, y, *, K, Q, HW, C, heads, ldkv, voff, logits=None):
-        """logits given: the foreground mask is derived inside the kernel from the mask_pred logits (AUX_MASK fused; fg / nfg unused)."""
+    @staticmethod
+    def _proj(proj):
+        """Fused-projection operands of the attention ops: proj = dict(x, W (PackedLinear), emb=None, ln=(gamma, beta) | None,
+        ln_out=None, ldx=256) -> (ldx, [ln_out], [W.weight, W.bias, emb, gamma, beta])."""
+        ln = proj.get('ln') or (None, None)
+        assert proj['W'].kd == 256
+        return proj.get('ldx', 256), proj.get('ln_out'), [proj['W'].weight, proj['W'].bias, proj.get('emb'), ln[0], ln[1]]
+
+    def attn_q2p(self, q, kv, fg, nfg, y, *, K, Q, HW, C, heads, ldkv, voff, logits=None, proj=None):
+        """logits given: the foreground mask is derived inside the kernel from the mask_pred logits (AUX_MASK fused; fg / nfg unused).
+        proj given (needs logits): q = (LN(x) + emb) Wq^T + b is computed inside the launch from the unprojected rows proj['x']."""
+        if proj is not None:
+            assert logits is not None
+            ldx, ln_out, tail = self._proj(proj)
+            return self.add(ATTN_Q2P, 3, [K, Q, HW, C, heads, ldkv, voff, ldx], [], [proj['x'], kv, logits, ln_out, y] + tail)
         if logits is not None:
             return self.add(ATTN_Q2P, 1, [K, Q, HW, C, heads, ldkv, voff], [], [q, kv, logits, None, y])
         return self.add(ATTN_Q2P, 0, [K, Q, HW, C, heads, ldkv, voff], [], [q, kv, fg, nfg, y])
 
-    def attn_self(self, qk, v, y, *, K, Q, C, heads, ldqk=0, ldv=0):
+    def attn_self(self, qk, v, y, *, K, Q, C, heads, ldqk=0, ldv=0, proj=None):
+        """proj given: q | k | v = packed in-projection of (LN(x) + emb | LN(x) + emb | LN(x)) computed inside the launch."""
+        if proj is not None:
+            ldx, ln_out, tail = self._proj(proj)
+            return self.add(ATTN_SELF, 2, [K, Q, C, heads, 0, 0, ldx], [], [proj['x'], None, y, ln_out, None] + tail)
         return self.add(ATTN_SELF, 0, [K, Q, C, heads, ldqk, ldv], [], [qk, v, y])
 
-    def attn_p2q(self, q, kq, vq, y, *, K, Q, HW, C, heads, ldq, ldkv=0):
+    def attn_p2q(self, q, kq, vq, y, *, K, Q, HW, C, heads, ldq, ldkv=0, proj=None):
+        """proj given: k | v of the object queries = packed [k | v] projection of (x + emb | x) computed inside the launch."""
+        if proj is not None:
+            ldx, _, tail = self._proj(proj)
+            return self.add(ATTN_P2Q, 2, [K, Q, HW, C, heads, ldq, ldkv, ldx], [], [q, proj['x'], None, y, None] + tail[:3])
         return self.add(ATTN_P2Q, 0, [K, Q, HW, C, heads, ldq, ldkv], [], [q, kq, vq, y])
 
     def summarize(self, feat, wl, m16, y, *, K, HW, C, Q, scratch=None):

@@ -138,15 +138,22 @@ enum {
      * transformer_layers.py:45-98 (nn.MultiheadAttention core), object_transformer.py:56-61
      * p0=q f32 [K,Q,C] (projected) p1=kv bf16 [K,HW,ldkv] (k at +0, v at +voff) p2=fg u8 [K,HW]
      * p3=nfg i32 [K] p4=y f32 [K,Q,C]   i: 0 K 1 Q 2 HW 3 C 4 heads 5 ldkv 6 voff
-     * flags&1: AUX_MASK fused -- p2=mask_pred logits f32 [K,HW] instead of fg, p3 unused (HW <= 24576) */
+     * flags&1: AUX_MASK fused -- p2=mask_pred logits f32 [K,HW] instead of fg, p3 unused (HW <= 24576)
+     * flags&2 (with flags&1, C == 256): the q projection runs inside the launch -- p0=x f32 [K*Q, i7] unprojected rows, p3=ln_out f32
+     *      [K*Q,256] (LayerNorm'd rows, may be 0), p5=Wq bf16 [C,256] p6=bias f32 [C] p7=query embedding f32 [K*Q,256] (may be 0)
+     *      p8/p9=LayerNorm gamma/beta (0: no norm): q = (LN(x) + emb) Wq^T + b   (the LINEAR op it replaces: transformer_layers.py:86-93) */
     CUTIE_OP_ATTN_Q2P = 18,
     /* ATTN_SELF: 16x16 self attention per object  transformer_layers.py:12-41
      * p0=qk f32 [K,Q,ldqk] (q at +0, k at +C) p1=v f32 [K,Q,ldv] p2=y f32 [K,Q,C]
-     * i: 0 K 1 Q 2 C 3 heads 4 ldqk (0: 2C) 5 ldv (0: C) */
+     * i: 0 K 1 Q 2 C 3 heads 4 ldqk (0: 2C) 5 ldv (0: C)
+     * flags&2 (C == 256): the packed q|k|v in-projection runs inside the launch -- p0=x f32 [K*Q, i6], p3=ln_out (may be 0),
+     *      p5=Wqkv bf16 [3C,256] p6=bias f32 [3C] p7=query embedding (q and k only) p8/p9=LayerNorm gamma/beta; p1 unused */
     CUTIE_OP_ATTN_SELF = 19,
     /* ATTN_P2Q: pixels <- 16 queries cross attention  object_transformer.py:66-70
      * p0=q bf16 [K,HW,ldq] p1=kq f32 [K,Q,ldkv] p2=vq f32 [K,Q,ldkv] p3=y bf16 [K,HW,C]
-     * i: 0 K 1 Q 2 HW 3 C 4 heads 5 ldq 6 ldkv (0: C) */
+     * i: 0 K 1 Q 2 HW 3 C 4 heads 5 ldq 6 ldkv (0: C)
+     * flags&2 (C == 256): the packed k|v projection of the object queries runs inside the launch -- p1=x f32 [K*Q, i7],
+     *      p5=Wkv bf16 [2C,256] p6=bias f32 [2C] p7=query embedding (k only); p2 unused */
     CUTIE_OP_ATTN_P2Q = 20,
     /* SUMMARIZE: weights=sigmoid(logits)*[m x8 | (1-m) x8]; sums=einsum; area   object_summarizer.py:11-23
      * p0=feature bf16 [K,HW,C] p1=wlogits f32 [K,HW,Q] p2=m16 f32 [K,HW] p3=y f32 [K,Q,C+1]

@@ -310,6 +310,17 @@ class MockExecutor:
         om = view(p[0], F32, (rows, C + 1))
         view(p[1], F32, (rows, C)).copy_(om[:, :C] / (om[:, C:] + 1e-4))
 
+    @staticmethod
+    def _proj_rows(p, M, ldx, ln_out_slot):
+        """Fused projection operands (ops.OpList._proj): -> (LN(x) + emb, LN(x), W [N,256] fp32, bias)."""
+        x = view(p[0 if ln_out_slot != -1 else 1], F32, (M, 256), (ldx, 1)).clone()
+        if p[8]:
+            x = F.layer_norm(x, (256,), view(p[8], F32, (256,)), view(p[9], F32, (256,)), 1e-5)
+            if ln_out_slot >= 0 and p[ln_out_slot]:
+                view(p[ln_out_slot], F32, (M, 256)).copy_(x)
+        xa = x + view(p[7], F32, (M, 256)) if p[7] else x
+        return xa, x
+
     # ---- AUX_MASK / attention ----------------------------------------------------------------------------
     def _op_17(self, flags, i, f, p):
         K, HW = i[:2]
@@ -323,7 +334,12 @@ class MockExecutor:
     def _op_18(self, flags, i, f, p):
         K, Q, HW, C, heads, ldkv, voff = i[:7]
         hd = C // heads
-        q = view(p[0], F32, (K, Q, C)).view(K, Q, heads, hd).transpose(1, 2)
+        if flags & 2:                                                   # q projection fused
+            xa, _ = self._proj_rows(p, K * Q, i[7] or 256, 3)
+            qp = xa @ view(p[5], BF16, (C, 256)).float().t() + (view(p[6], F32, (C,)) if p[6] else 0)
+            q = qp.view(K, Q, heads, hd).transpose(1, 2)
+        else:
+            q = view(p[0], F32, (K, Q, C)).view(K, Q, heads, hd).transpose(1, 2)
         k = view(p[1], BF16, (K, HW, C), (HW * ldkv, ldkv, 1)).float().view(K, HW, heads, hd).transpose(1, 2)
         v = view(p[1] + 2 * voff, BF16, (K, HW, C), (HW * ldkv, ldkv, 1)).float().view(K, HW, heads, hd).transpose(1, 2)
         if flags & 1:                                                   # AUX_MASK fused: p2 = logits
@@ -347,11 +363,19 @@ class MockExecutor:
     def _op_19(self, flags, i, f, p):
         K, Q, C, heads, ldqk, ldv = i[:6]
         hd = C // heads
-        ldqk, ldv = ldqk or 2 * C, ldv or C
-        qk = view(p[0], F32, (K, Q, 2 * C), (Q * ldqk, ldqk, 1))
-        q = qk[..., :C].reshape(K, Q, heads, hd).transpose(1, 2)
-        k = qk[..., C:].reshape(K, Q, heads, hd).transpose(1, 2)
-        v = view(p[1], F32, (K, Q, C), (Q * ldv, ldv, 1)).reshape(K, Q, heads, hd).transpose(1, 2)
+        if flags & 2:                                                   # qkv projection fused
+            xa, xp = self._proj_rows(p, K * Q, i[6] or 256, 3)
+            Wt = view(p[5], BF16, (3 * C, 256)).float()
+            b = view(p[6], F32, (3 * C,)) if p[6] else torch.zeros(3 * C)
+            q = (xa @ Wt[:C].t() + b[:C]).view(K, Q, heads, hd).transpose(1, 2)
+            k = (xa @ Wt[C:2 * C].t() + b[C:2 * C]).view(K, Q, heads, hd).transpose(1, 2)
+            v = (xp @ Wt[2 * C:].t() + b[2 * C:]).view(K, Q, heads, hd).transpose(1, 2)
+        else:
+            ldqk, ldv = ldqk or 2 * C, ldv or C
+            qk = view(p[0], F32, (K, Q, 2 * C), (Q * ldqk, ldqk, 1))
+            q = qk[..., :C].reshape(K, Q, heads, hd).transpose(1, 2)
+            k = qk[..., C:].reshape(K, Q, heads, hd).transpose(1, 2)
+            v = view(p[1], F32, (K, Q, C), (Q * ldv, ldv, 1)).reshape(K, Q, heads, hd).transpose(1, 2)
         att = ((q @ k.transpose(-1, -2)) / math.sqrt(hd)).softmax(-1)
         view(p[2], F32, (K, Q, C)).copy_((att @ v).transpose(1, 2).reshape(K, Q, C))
 
@@ -360,8 +384,16 @@ class MockExecutor:
         hd = C // heads
         ldkv = ldkv or C
         q = view(p[0], BF16, (K, HW, C), (HW * ldq, ldq, 1)).float().view(K, HW, heads, hd).transpose(1, 2)
-        k = view(p[1], F32, (K, Q, C), (Q * ldkv, ldkv, 1)).reshape(K, Q, heads, hd).transpose(1, 2)
-        v = view(p[2], F32, (K, Q, C), (Q * ldkv, ldkv, 1)).reshape(K, Q, heads, hd).transpose(1, 2)
+        if flags & 2:                                                   # kv projection fused (no LayerNorm; p1 = x)
+            x = view(p[1], F32, (K * Q, 256), (i[7] or 256, 1))
+            xa = x + view(p[7], F32, (K * Q, 256)) if p[7] else x
+            Wt = view(p[5], BF16, (2 * C, 256)).float()
+            b = view(p[6], F32, (2 * C,)) if p[6] else torch.zeros(2 * C)
+            k = (xa @ Wt[:C].t() + b[:C]).view(K, Q, heads, hd).transpose(1, 2)
+            v = (x @ Wt[C:].t() + b[C:]).view(K, Q, heads, hd).transpose(1, 2)
+        else:
+            k = view(p[1], F32, (K, Q, C), (Q * ldkv, ldkv, 1)).reshape(K, Q, heads, hd).transpose(1, 2)
+            v = view(p[2], F32, (K, Q, C), (Q * ldkv, ldkv, 1)).reshape(K, Q, heads, hd).transpose(1, 2)
         att = ((q @ k.transpose(-1, -2)) / math.sqrt(hd)).softmax(-1)
         view(p[3], BF16, (K, HW, C)).copy_((att @ v).transpose(1, 2).reshape(K, HW, C))
 

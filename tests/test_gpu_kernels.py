@@ -607,6 +607,55 @@ def test_attn_self_and_p2q():
     assert torch.equal(hip['y'], hip['y3']) and torch.equal(hip['y2'], hip['y4'])
 
 
+@pytest.mark.parametrize('K', [1, 3])
+def test_attention_with_fused_projections(K):
+    """The three attentions of a transformer block with their small projections computed inside the launch (LayerNorm + query
+    embedding + packed in-projection on MFMA from LDS-staged rows) against the LINEAR + attention pairs they replace: same results to
+    fp32 rounding, and both against the interpreter."""
+    def build(dev, g):
+        Q, HW, C, heads = 16, 1620, 256, 8
+        M = K * Q
+        x = torch.randn((M, C), generator=g).to(dev)
+        emb = (torch.randn((M, C), generator=g) * 0.5).to(dev)
+        gam, bet = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
+        mk = lambda n: pack_linear(torch.randn((n, C), generator=g) / 16, torch.randn(n, generator=g) * 0.1, dev)
+        Wq, Wqkv, Wkv = mk(C), mk(3 * C), mk(2 * C)
+        lg = _aux_inputs(g, K, HW, 'mixed').to(dev)
+        kvq = rnd(g, (K, HW, 3 * C), dev=dev)
+        z = lambda *shape, dt=F32: torch.zeros(shape, dtype=dt, device=dev)
+        ol = O.OpList()
+        ol.keep += [Wq.weight, Wqkv.weight, Wkv.weight]
+        out = {}
+        # read_from_pixel
+        qp, xn, att = z(M, C), z(M, C), z(M, C)
+        ol.linear(x, Wq, qp, M=M, x_add=emb, add_rows=M, ln=(gam, bet), ln_out=xn)
+        ol.attn_q2p(qp, kvq, None, None, att, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg)
+        xn_f, att_f = z(M, C), z(M, C)
+        ol.attn_q2p(None, kvq, None, None, att_f, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg,
+                    proj=dict(x=x, W=Wq, emb=emb, ln=(gam, bet), ln_out=xn_f))
+        out.update(xn=xn, att=att, xn_f=xn_f, att_f=att_f)
+        # self attention
+        qkv, y, sa = z(M, 3 * C), z(M, C), z(M, C)
+        ol.linear(x, Wqkv, qkv, M=M, x_add=emb, add_rows=M, add_cols=2 * C, ln=(gam, bet), ln_out=y)
+        ol.attn_self(qkv, qkv.view(-1)[2 * C:], sa, K=K, Q=Q, C=C, heads=heads, ldqk=3 * C, ldv=3 * C)
+        y_f, sa_f = z(M, C), z(M, C)
+        ol.attn_self(None, None, sa_f, K=K, Q=Q, C=C, heads=heads, proj=dict(x=x, W=Wqkv, emb=emb, ln=(gam, bet), ln_out=y_f))
+        out.update(y=y, sa=sa, y_f=y_f, sa_f=sa_f)
+        # read_from_query
+        kv2, pa, pa_f = z(M, 2 * C), z(K, HW, C, dt=BF16), z(K, HW, C, dt=BF16)
+        ol.linear(x, Wkv, kv2, M=M, x_add=emb, add_rows=M, add_cols=C)
+        ol.attn_p2q(kvq.view(-1)[2 * C:], kv2, kv2.view(-1)[C:], pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C, ldkv=2 * C)
+        ol.attn_p2q(kvq.view(-1)[2 * C:], None, None, pa_f, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C, proj=dict(x=x, W=Wkv, emb=emb))
+        out.update(pa=pa, pa_f=pa_f)
+        return ol, out
+    hip, ref = run_both(build, seed=77)
+    check(hip, ref, name='fused projections', rtol=3e-3)
+    for a, b, tol in (('xn', 'xn_f', 1e-5), ('att', 'att_f', 2e-3), ('y', 'y_f', 1e-5), ('sa', 'sa_f', 2e-3)):
+        d = float((hip[a] - hip[b]).abs().max())
+        assert d <= tol * max(1.0, float(hip[a].abs().max())), (a, d)
+    assert float((hip['pa'].float() - hip['pa_f'].float()).abs().max()) <= 2e-2 * float(hip['pa'].float().abs().max())
+
+
 def test_summarize_add_pe():
     def build(dev, g):
         K, HW, C, Q = 3, 1620, 256, 16
