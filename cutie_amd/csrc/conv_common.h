@@ -87,4 +87,5 @@ constexpr int conv_lds_bytes() {
 }
 
 int launch_conv_bufload(const ConvParams& p, int tile, hipStream_t s);   // conv_bufload.hip (experimental tiles 50..)
-int launch_conv_dma(const ConvParams& p, int tile, hipStream_t s);       // conv_dma.hip (LDS-DMA tiles 60..)
+int launch_conv_dma(const ConvParams& p, int tile, hipStream_t s);
+int launch_conv_strip(const ConvParams& p, int tile, hipStream_t s);      // conv_strip.hip: tiles 90..       // conv_dma.hip (LDS-DMA tiles 60..)

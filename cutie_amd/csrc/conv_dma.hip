@@ -490,6 +490,10 @@ int launch_conv_dma(const ConvParams& p, int tile, hipStream_t s) {
         // 96 rows: M = 4860 (3 objects at stride 16) gives 51 x 4 = 204 blocks -- one round on 256 CUs where 64-row tiles need two
         case 86: return launch_dma<96, 64, 2, 2, 3>(p, s);           // 60 KB
         case 87: return launch_dma<96, 64, 2, 2, 2>(p, s);           // 40 KB
+        // 8 waves on a 64 x 64 tile: one X and one W piece per wave and K tile -- the DMA issue cost (100-200 cycles of the issuing
+        // wave per 1-KiB piece) is the longest item of an iteration on the small tiles
+        case 88: return launch_dma<64, 64, 2, 4, 3>(p, s);           // 48 KB
+        case 89: return launch_dma<64, 64, 2, 4, 4>(p, s);           // 64 KB
         default: cutie_set_error("conv: bad DMA tile id %d", tile); return -2;
     }
 }

@@ -610,7 +610,8 @@ int launch_conv(const cutie_op* op, hipStream_t s) {
         return (int)hipGetLastError();
     }
     if (i[17] >= 50 && i[17] < 60) return launch_conv_bufload(p, i[17], s);     // experimental tiles (conv_bufload.hip)
-    if (i[17] >= 60 && i[17] < 100) return launch_conv_dma(p, i[17], s);        // LDS-DMA tiles (conv_dma.hip)
+    if (i[17] >= 60 && i[17] < 90) return launch_conv_dma(p, i[17], s);         // LDS-DMA tiles (conv_dma.hip)
+    if (i[17] >= 90 && i[17] < 100) return launch_conv_strip(p, i[17], s);      // LDS-DMA with the 3x3 input strip resident (conv_strip.hip)
     switch (i[17]) {
         case 0: return launch_cfg<128, 128, 2, 2, 32, 4, 2>(p, s);
         case 1: return launch_cfg<128, 64, 2, 2, 32, 4, 3>(p, s);

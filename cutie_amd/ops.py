@@ -58,10 +58,14 @@ DMA_TILES = {60: (128, 128, 64), 61: (128, 128, 64), 62: (128, 128, 64), 63: (12
              66: (64, 64, 64), 67: (32, 64, 64), 68: (256, 128, 64), 69: (32, 128, 64), 70: (128, 128, 64), 71: (128, 64, 64),
              72: (64, 64, 64), 73: (64, 64, 64), 74: (64, 64, 64), 75: (32, 64, 64), 76: (128, 64, 64), 77: (64, 128, 64), 78: (32, 128, 64),
              80: (64, 64, 128), 81: (64, 64, 128), 82: (32, 64, 128), 83: (32, 64, 128), 84: (64, 128, 128), 85: (128, 64, 128),
-             86: (96, 64, 64), 87: (96, 64, 64)}
+             86: (96, 64, 64), 87: (96, 64, 64), 88: (64, 64, 64), 89: (64, 64, 64)}
 
 
-ALL_TILES = {**TILES, **DMA_TILES}
+# 90+: conv_strip.hip -- 3x3 / stride 1 / pad 1 on narrow maps with the input strip resident in LDS: tile -> (BM, BN, BK) / waves
+STRIP_TILES = {90: (128, 64, 64), 91: (64, 64, 64), 92: (128, 128, 64), 93: (64, 128, 64), 94: (128, 64, 64), 95: (64, 64, 64)}
+STRIP_WAVES = {90: 4, 91: 4, 92: 8, 93: 4, 94: 8, 95: 8}
+
+ALL_TILES = {**TILES, **DMA_TILES, **STRIP_TILES}
 
 
 def dma_tiles_enabled():
@@ -73,6 +77,16 @@ def dma_tile_ok(tile, *, cin, kh, c2=0):
     source."""
     bk = DMA_TILES[tile][2]
     return cin % bk == 0 and (c2 == 0 or (c2 % bk == 0 and (cin - c2) % bk == 0)) and kh * kh <= 32
+
+
+def strip_tile_ok(tile, *, cin, kh, stride, pad, W, c2=0):
+    """conv_strip_kernel eligibility (mirrors launch_strip in conv_strip.hip)."""
+    bm, bn, _ = STRIP_TILES[tile]
+    srp = (bm + 2 * W + 2 + 7) & ~7
+    ppw = -(-(srp // 8) // STRIP_WAVES[tile])
+    lds = max(2 * srp * 128 + 3 * bn * 128, bm * (bn + 4) * 4)
+    return (kh == 3 and stride == 1 and pad == 1 and cin % 64 == 0 and (c2 == 0 or (c2 % 64 == 0 and (cin - c2) % 64 == 0))
+            and ppw <= 8 and lds <= 160 * 1024)
 
 
 def conv_side_jobs_ok(*, cin, cout, kh, c2=0):
@@ -138,6 +152,11 @@ def tile_candidates(M, cout, cin, kpad=None, geom=None):
             if not (bn == 128 and cout <= 64) and not (bm > 64 and bm > max(M, 64)) and not (bm == 256 and M < 16384) \
                     and dma_tile_ok(t, cin=cin, kh=geom['kh'], c2=geom.get('c2', 0)):
                 out.append(t)
+    if dma_tiles_enabled() and geom is not None and 'stride' in geom:
+        for t, (bm, bn, bk) in STRIP_TILES.items():
+            if strip_tile_ok(t, cin=cin, kh=geom['kh'], stride=geom['stride'], pad=geom['pad'], W=geom['W'], c2=geom.get('c2', 0)) \
+                    and not (bn == 128 and cout <= 64) and not (bm > 64 and bm > max(M, 64)):
+                out.append(t)
     if experimental_tiles_enabled() and geom is not None:
         for t, (bm, bn, bk) in EXPERIMENTAL_TILES.items():
             if bufload_tile_ok(t, cin=cin, kh=geom['kh'], c2=geom.get('c2', 0), kpad=kpad) and not (bn == 128 and cout <= 64) \
@@ -165,7 +184,7 @@ def splitk_scratch(device, owner=None):
 
 def splitk_candidates(M, cout, kpad, tile):
     """Split-K factors worth timing for a conv on a given tile: only when the plain grid leaves CUs idle."""
-    if tile == COUT1_TILE or tile == 3 or tile in PATCH_TILES or tile in EXPERIMENTAL_TILES or tile in DMA_TILES:
+    if tile == COUT1_TILE or tile == 3 or tile in PATCH_TILES or tile in EXPERIMENTAL_TILES or tile in DMA_TILES or tile in STRIP_TILES:
         return [1]
     bm, bn, bk = TILES[tile]
     blocks = -(-M // bm) * -(-cout // bn)
@@ -291,7 +310,7 @@ class OpList:
         if tile is None:
             tile = COUT1_TILE if (cout1_ok(w.cout, C1 + C2, C2, res is not None) and not side) else pick_tile(M, w.cout, C1 + C2, dict(kh=w.kh, c2=C2))
         if side:
-            assert tile in DMA_TILES and not out_f32 and w.cout % 8 == 0 and ldy % 8 == 0, 'GAP accumulation needs an LDS-DMA conv (see conv_side_jobs_ok)'
+            assert (tile in DMA_TILES or tile in STRIP_TILES) and not out_f32 and w.cout % 8 == 0 and ldy % 8 == 0, 'GAP accumulation needs an LDS-DMA conv (see conv_side_jobs_ok)'
         part = splitk_scratch(w.weight.device, self.scratch_owner)
         return self.add(CONV, flags,
                         [B, H, W, C1, C2, ldx1, ldx2, OH, OW, w.cout, ldy, w.kh, w.kw, stride, pad, ldr, w.kpad, tile, w.cin_real,

@@ -172,6 +172,29 @@ def test_conv_dma_tiles(ci, tile):
     check(hip, ref, f'dma[{ci}] tile{tile}')
 
 
+STRIP_CASES = [
+    dict(B=3, H=30, W=54, C1=256, Cout=256, k=3, relu_in=True, act=O.ACT_RELU),          # CAResBlock conv (480p, 3 objects)
+    dict(B=1, H=30, W=54, C1=256, Cout=64, k=3, out_f32=True, act=O.ACT_SIGMOID),        # key projection e_proj
+    dict(B=2, H=17, W=23, C1=64, Cout=96, k=3, res=True),                                 # ragged M and Cout, residual, one slice
+    dict(B=3, H=9, W=7, C1=128, Cout=40, k=3, res=True, res_bcast=True, out_f32=True),   # tiny map: several objects inside a strip
+    dict(B=1, H=40, W=60, C1=256, Cout=256, k=3),
+    dict(B=2, H=21, W=19, C1=64, C2=192, Cout=130, k=3, relu_in=True, out_f32=True),     # two sources
+    dict(B=3, H=30, W=54, C1=256, C2=256, Cout=768, k=3),                                 # sensory-update transform conv
+    dict(B=5, H=5, W=7, C1=256, Cout=256, k=3),                                           # M = 175: a tile holds whole objects
+]
+
+
+@pytest.mark.parametrize('tile', sorted(O.STRIP_TILES))
+@pytest.mark.parametrize('ci', range(len(STRIP_CASES)))
+def test_conv_strip_tiles(ci, tile):
+    """conv_strip_kernel (tiles 90..: the 3x3 input strip resident in LDS, taps as row shifts, border rows zeroed after the read)."""
+    c = STRIP_CASES[ci]
+    if not O.strip_tile_ok(tile, cin=c['C1'] + c.get('C2', 0), kh=3, stride=1, pad=1, W=c['W'], c2=c.get('C2', 0)):
+        pytest.skip('strip too long for this tile')
+    hip, ref = run_both(_conv_build(c, tile), seed=900 + ci)
+    check(hip, ref, f'strip conv[{ci}] tile{tile}')
+
+
 PATCH_CASES = [
     dict(B=3, H=30, W=54, C1=256, Cout=256, k=3, relu_in=True, act=O.ACT_RELU),          # CAResBlock conv (480p, 3 objects)
     dict(B=1, H=30, W=54, C1=256, Cout=64, k=3, out_f32=True, act=O.ACT_SIGMOID),        # key projection e_proj
@@ -372,7 +395,7 @@ def test_gap_eca():
     check(hip, ref, 'gap/eca')
 
 
-@pytest.mark.parametrize('tile', [66, 67, 63, 61, 70, 68, 82, 85, 86])
+@pytest.mark.parametrize('tile', [66, 67, 63, 61, 70, 68, 82, 85, 86, 90, 91, 92])
 @pytest.mark.parametrize('geo', [(3, 30, 54), (5, 5, 7), (2, 9, 16)])
 def test_conv_gap_accumulation(tile, geo):
     """ECA's average pool riding on the convs of a CAResBlock: conv1 clears the accumulator, conv2 adds the fixed-point channel sums of
