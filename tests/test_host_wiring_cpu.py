@@ -339,3 +339,52 @@ def test_rewrapped_tensors_take_the_slow_path(product_net):
         s1, _, p1 = net.segment(ms, ro, sens.clone(), update_sensory=True)
         s2, _, p2 = net.segment(ms, ro, sens.clone().contiguous(), update_sensory=True)
         assert torch.equal(p1, p2) and torch.equal(s1, s2)
+
+
+def test_save_aux_contents(product_net, oracle_net):
+    """cfg.save_aux: MemoryManager.aux carries the reference's keys (memory_manager.py:197-206; the reference itself raises there in
+    eval mode -- edge case save_aux_on_read).  The attention mask must be object_transformer.py:179-205 applied to the last block's
+    logits (checked against the oracle's restatement, head 0), the logits are copies, and the frame's result is unchanged."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.utils.synth import SyntheticClip
+    clip = SyntheticClip(96, 128, 3, 3, seed=21)
+    with torch.inference_mode():
+        outs = {}
+        for aux_on in (False, True):
+            p = InferenceCore(product_net, cfg=default_config(save_aux=aux_on))
+            p.step(clip.frame(0), clip.first_mask(), objects=clip.objects)
+            outs[aux_on] = p.step(clip.frame(1)).clone()
+        assert torch.equal(outs[False], outs[True])                       # the extra mask_pred head does not feed back
+        aux = p.memory.aux
+        assert sorted(aux) == ['attn_mask', 'p_weights', 'pixel_readout', 'q_logits', 'q_weights', 'sensory']
+        assert len(aux['q_logits']) == 4 and aux['q_weights'] is None and aux['p_weights'] is None
+        K, h, w = 3, 6, 8
+        assert aux['attn_mask'].shape == (1, K, 16, h, w) and aux['q_logits'][-1].shape == (1, K, h, w)
+        want = oracle_net._aux_mask(aux['q_logits'][-1]).view(K, oracle_net.m['num_heads'], 16, h, w)[:, 0].float()
+        assert torch.equal(aux['attn_mask'][0], want)
+        before = [t.clone() for t in aux['q_logits']]
+        p.step(clip.frame(2))                                              # the next frame rewrites the plan's buffers, not the copies
+        assert all(torch.equal(a, b) for a, b in zip(before, aux['q_logits'])) or aux is not p.memory.aux
+
+
+def test_frame_context_is_per_thread_and_capped():
+    """cutie_amd/frame_context.py: entries are found by storage address through any view, live per host thread (a clip is driven by one
+    thread: another clip's traffic cannot evict them), and large payload kinds keep only their last `cap` entries."""
+    import threading
+    from cutie_amd import frame_context as fc
+    a = torch.zeros(8, 4)
+    fc.remember('kind', a, 'payload')
+    assert fc.recall('kind', a[:, :]) == 'payload' and fc.recall('other', a) is None
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(fc.recall('kind', a)))
+    t.start(); t.join()
+    assert seen == [None]                                             # another thread: not found -> that caller's slow path
+    keep = [torch.zeros(4) for _ in range(6)]
+    for i, x in enumerate(keep):
+        fc.remember('big', x, i, cap=4)
+    assert [fc.recall('big', x) for x in keep] == [None, None, 2, 3, 4, 5]
+    for x in [torch.zeros(2) for _ in range(200)]:
+        fc.remember('flood', x, 0)
+    assert fc.recall('kind', a) is None                               # small LRU: old entries age out
+    fc.forget('big', keep[-1])
+    assert fc.recall('big', keep[-1]) is None
