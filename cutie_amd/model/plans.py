@@ -317,11 +317,15 @@ def build_readout_query(eng, K, h, w, last_aux=True):
     HW, M = h * w, K * Q
     t = 'object_transformer'
     f = lambda name, shape: P.buf(name, shape, F32)
-    vals = f('vals', (M, C))
-    ol.query_init(Dyn('obj_mem'), vals, rows=M, C=C)
     query, query_emb = f('query', (M, C)), f('query_emb', (M, C))
-    ol.linear(vals, W[t + '.summary_to_query_init'], query, M=M, res=eng.rep_embedding('query_init', K))
-    ol.linear(vals, W[t + '.summary_to_query_emb'], query_emb, M=M, res=eng.rep_embedding('query_emb', K))
+    if C == 256 and Q == 16 and not UNFUSED:
+        ol.query_init2(Dyn('obj_mem'), query, query_emb, rows=M, w_init=W[t + '.summary_to_query_init'], res_init=eng.rep_embedding('query_init', K),
+                       w_emb=W[t + '.summary_to_query_emb'], res_emb=eng.rep_embedding('query_emb', K))
+    else:
+        vals = f('vals', (M, C))
+        ol.query_init(Dyn('obj_mem'), vals, rows=M, C=C)
+        ol.linear(vals, W[t + '.summary_to_query_init'], query, M=M, res=eng.rep_embedding('query_init', K))
+        ol.linear(vals, W[t + '.summary_to_query_emb'], query_emb, M=M, res=eng.rep_embedding('query_emb', K))
     pix_in = Act(Dyn('pixel'), K, h, w, C)
     if UNFUSED:
         # pixel = pixel_init_proj(x), pixel_pe = pixel_emb_proj(x) + PE: one conv, two channel slices of its output

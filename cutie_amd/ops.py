@@ -392,6 +392,12 @@ class OpList:
     def query_init(self, obj_mem, y, *, rows, C):
         return self.add(QUERY_INIT, 0, [rows, C], [], [obj_mem, y])
 
+    def query_init2(self, obj_mem, query, query_emb, *, rows, w_init, res_init, w_emb, res_emb):
+        """QUERY_INIT and the two linears that consume it in one launch (C = 256, 16 summaries per object)."""
+        assert w_init.kd == 256 and w_init.n == 256 and w_emb.kd == 256 and w_emb.n == 256 and rows % 16 == 0
+        return self.add(QUERY_INIT, 1, [rows, 256], [], [obj_mem, query, query_emb, w_init.weight, w_init.bias, res_init,
+                                                         w_emb.weight, w_emb.bias, res_emb])
+
     def aux_mask(self, logits, fg, nfg, *, K, HW):
         self.memset32(nfg, K, 0)
         return self.add(AUX_MASK, 0, [K, HW], [], [logits, fg, nfg])

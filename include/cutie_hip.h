@@ -128,7 +128,9 @@ enum {
     /* LAYERNORM over the last dim (eps 1e-5)   p0=x f32 [M,C] p1=g p2=b f32[C] p3=y f32 [M,C]  i: 0 M 1 C */
     CUTIE_OP_LAYERNORM = 15,
     /* QUERY_INIT: obj_values = sums/(area+1e-4)   object_transformer.py:125-132
-     * p0=obj_mem f32 [K,Q,C+1] p1=y f32 [K*Q,C]   i: 0 K*Q 1 C */
+     * p0=obj_mem f32 [K,Q,C+1] p1=y f32 [K*Q,C]   i: 0 K*Q 1 C
+     * flags&1 (C == 256, Q == 16): with the two linears that consume it (:137-138) -- p1=query p2=query_emb f32 [K*Q,256],
+     *      p3/p4/p5 = W bf16 [256,256], bias, residual f32 [K*Q,256] of summary_to_query_init (+ query_init.weight), p6/p7/p8 of ..._emb */
     CUTIE_OP_QUERY_INIT = 16,
     /* AUX_MASK: foreground mask from mask_pred logits   object_transformer.py:179-205
      * p0=logits f32 [K,HW] p1=fg u8 [K,HW] p2=nfg i32 [K] (must be zeroed: MEMSET op before)

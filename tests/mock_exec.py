@@ -308,7 +308,17 @@ class MockExecutor:
     def _op_16(self, flags, i, f, p):
         rows, C = i[:2]
         om = view(p[0], F32, (rows, C + 1))
-        view(p[1], F32, (rows, C)).copy_(om[:, :C] / (om[:, C:] + 1e-4))
+        vals = om[:, :C] / (om[:, C:] + 1e-4)
+        if flags & 1:                                                   # with the two linears
+            for y, w, b, r in ((1, 3, 4, 5), (2, 6, 7, 8)):
+                out = vals @ view(p[w], BF16, (C, C)).float().t()
+                if p[b]:
+                    out = out + view(p[b], F32, (C,))
+                if p[r]:
+                    out = out + view(p[r], F32, (rows, C))
+                view(p[y], F32, (rows, C)).copy_(out)
+            return
+        view(p[1], F32, (rows, C)).copy_(vals)
 
     @staticmethod
     def _proj_rows(p, M, ldx, ln_out_slot):

@@ -679,6 +679,29 @@ def test_attention_with_fused_projections(K):
     assert float((hip['pa'].float() - hip['pa_f'].float()).abs().max()) <= 2e-2 * float(hip['pa'].float().abs().max())
 
 
+@pytest.mark.parametrize('K', [1, 3, 5])
+def test_query_init_with_its_linears(K):
+    def build(dev, g):
+        Q, C = 16, 256
+        M = K * Q
+        om = (torch.rand((M, C + 1), generator=g) + 0.1).to(dev)
+        mk = lambda: pack_linear(torch.randn((C, C), generator=g) / 16, torch.randn(C, generator=g) * 0.1, dev)
+        Wi, We = mk(), mk()
+        ri, re = torch.randn((M, C), generator=g).to(dev), torch.randn((M, C), generator=g).to(dev)
+        z = lambda: torch.zeros((M, C), dtype=F32, device=dev)
+        vals, q1, e1, q2, e2 = z(), z(), z(), z(), z()
+        ol = O.OpList()
+        ol.keep += [Wi.weight, We.weight]
+        ol.query_init(om, vals, rows=M, C=C)
+        ol.linear(vals, Wi, q1, M=M, res=ri)
+        ol.linear(vals, We, e1, M=M, res=re)
+        ol.query_init2(om, q2, e2, rows=M, w_init=Wi, res_init=ri, w_emb=We, res_emb=re)
+        return ol, {'q1': q1, 'e1': e1, 'q2': q2, 'e2': e2}
+    hip, ref = run_both(build, seed=5)
+    check(hip, ref, name='query_init2', rtol=2e-3)
+    assert float((hip['q1'] - hip['q2']).abs().max()) < 1e-4 and float((hip['e1'] - hip['e2']).abs().max()) < 1e-4
+
+
 def test_summarize_add_pe():
     def build(dev, g):
         K, HW, C, Q = 3, 1620, 256, 16
