@@ -72,6 +72,8 @@ CONV_CASES = [
     dict(B=2, H=17, W=23, C1=64, Cout=96, k=3),                       # ragged M and Cout
     dict(B=1, H=120, W=216, C1=64, Cout=64, k=1, act=O.ACT_RELU),
     dict(B=1, H=9, W=7, C1=32, Cout=40, k=3, stride=2),
+    dict(B=2, H=100, W=90, C1=128, Cout=1, k=3, relu_in=True, out_f32=True),             # Cout = 1 on a large map: LDS-patch kernel, ragged tiles
+    dict(B=1, H=130, W=131, C1=64, Cout=1, k=3, act=O.ACT_SIGMOID),                       # ... bf16 out, 8 lanes per pixel
 ]
 
 
