@@ -408,18 +408,19 @@ __global__ __launch_bounds__(256) void attn_p2q_kernel(const bf16_t* __restrict_
 
 // QUERY_INIT with its two linears (flags&1): per object, x = sums / (area + 1e-4) for the 16 summaries (object_transformer.py:125-132)
 // staged in LDS, then query = x Wi^T + bi + query_init and query_emb = x We^T + be + query_emb (:137-138) -- three launches in one.
-// grid (K), block 512: 8 waves x 4 column tiles (of the 32 = 2 x 16) each over all of K = 256.
+// grid (K, 4), block 256: a block computes 8 of the 32 column tiles (2 x 16: query_init | query_emb), 2 per wave over all of K = 256;
+// the rows are staged by every block (16 x 257 floats).  (One block per object with 4 tiles per wave took 16 us: 3 blocks, 208 VGPRs.)
 struct QInit2 { const float* om; float* y[2]; const bf16_t* W[2]; const float* b[2]; const float* res[2]; };
-__global__ __launch_bounds__(512) void query_init2_kernel(QInit2 a) {
+__global__ __launch_bounds__(256) void query_init2_kernel(QInit2 a) {
     __shared__ float sX[16 * PROJ_XLD];
     const int k = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    proj_u4 wv[4][8];
+    proj_u4 wv[2][8];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int tile = wave * 4 + t;                     // 0..15: query_init columns, 16..31: query_emb columns
+    for (int t = 0; t < 2; ++t) {
+        const int tile = blockIdx.y * 8 + wave * 2 + t;     // 0..15: query_init columns, 16..31: query_emb columns
         proj16_load<8>(a.W[tile >> 4], (tile & 15) * 16, 0, wv[t]);
     }
-    for (int r = wave; r < 16; r += 8) {
+    for (int r = wave; r < 16; r += 4) {
         const float* row = a.om + ((long)k * 16 + r) * 257;
         const float inv = 1.f / (row[256] + 1e-4f);
 #pragma unroll
@@ -427,8 +428,8 @@ __global__ __launch_bounds__(512) void query_init2_kernel(QInit2 a) {
     }
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int tile = wave * 4 + t, which = tile >> 4, col = (tile & 15) * 16 + c;
+    for (int t = 0; t < 2; ++t) {
+        const int tile = blockIdx.y * 8 + wave * 2 + t, which = tile >> 4, col = (tile & 15) * 16 + c;
         const f32x4 acc = proj16_mma<8>(sX, 0, wv[t]);
         const float bv = a.b[which] ? a.b[which][col] : 0.f;
 #pragma unroll
@@ -447,7 +448,7 @@ int launch_attention(const cutie_op* op, hipStream_t s) {
             if (i[1] != 256 || (i[0] & 15)) { cutie_set_error("query_init (fused): C == 256, rows %% 16 == 0"); return -2; }
             QInit2 a = {(const float*)p[0], {(float*)p[1], (float*)p[2]}, {(const bf16_t*)p[3], (const bf16_t*)p[6]}, {(const float*)p[4], (const float*)p[7]},
                         {(const float*)p[5], (const float*)p[8]}};
-            hipLaunchKernelGGL(query_init2_kernel, dim3(i[0] / 16), dim3(512), 0, s, a);
+            hipLaunchKernelGGL(query_init2_kernel, dim3(i[0] / 16, 4), dim3(256), 0, s, a);
             break;
         }
         case CUTIE_OP_AUX_MASK:
