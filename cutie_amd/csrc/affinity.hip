@@ -332,11 +332,11 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 // G > 4096, needed 11 us for 1620 columns of 667 values; this one ~3 us).
 // Side jobs riding on AFF_SELECT (two fill launches and two tick launches less per read-out): the candidate counters of pass 1 are
 // cleared (one int per query, stride AFF_CSTRIDE) and the life counters of up to two token ranges advance by one (USAGE_TICK).
-struct SelectSide { int* count; float* lifeA; float* lifeB; int nA, nB; };
+struct SelectSide { int* count; float* lifeA; float* lifeB; int nA, nB; int zeroA; };    // zeroA: range A is cleared, not advanced
 __device__ __forceinline__ void select_side_jobs(const SelectSide& sd, int HW) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     if (sd.count) for (int q = gid; q < HW; q += nth) sd.count[q * AFF_CSTRIDE] = 0;
-    if (sd.lifeA) for (int t = gid; t < sd.nA; t += nth) sd.lifeA[t] += 1.f;
+    if (sd.lifeA) for (int t = gid; t < sd.nA; t += nth) sd.lifeA[t] = sd.zeroA ? 0.f : sd.lifeA[t] + 1.f;
     if (sd.lifeB) for (int t = gid; t < sd.nB; t += nth) sd.lifeB[t] += 1.f;
 }
 
@@ -576,7 +576,7 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             break;
         }
         case CUTIE_OP_AFF_SELECT: {
-            SelectSide sd = {(int*)p[2], (float*)p[3], (float*)p[4], i[4], i[5]};
+            SelectSide sd = {(int*)p[2], (float*)p[3], (float*)p[4], i[4], i[5], op->flags & 1};
             const dim3 grid((i[0] + 3) / 4), block(256);
             const int Gld = (i[2] + 63) / 64 * 64;
             if (i[2] <= 1024) hipLaunchKernelGGL(aff_select_reg_kernel<16>, grid, block, 0, s, (const float*)p[0], (float*)p[1], i[0], Gld, i[2], i[3], sd);

@@ -86,6 +86,37 @@ constexpr int conv_lds_bytes() {
     return pipe > epi ? pipe : epi;
 }
 
+// ---- optional timeline (diagnostic libraries only: make timeline, -DCONV_TIMELINE; tools/conv_timeline.py) ----
+// s_memtime stamps of every wave of a few blocks (logical tile 0, 1, nb/2, nb-1), parked in TL_BYTES of extra dynamic LDS behind the
+// kernel's own (one ds_write per stamp: no VMEM traffic that would disturb the counted vmcnt waits) and copied to the split-K
+// scratch (ConvParams::part, unused by the LDS-DMA kernels) when the wave ends.  Record: [0] = 0x544c0000 | count, [1] = logical << 32 |
+// waves, then stamps (cycles << 8 | id).  Loop stamps stop at TL_MAX - 6 so that the closing stamps always fit.
+#ifdef CONV_TIMELINE
+#define TL_MAX 96
+#define TL_BYTES (16 * TL_MAX * 8)
+#define TL_DECL(...) unsigned long long* const tlp_ = reinterpret_cast<unsigned long long*>(__VA_ARGS__) + wave * TL_MAX; int tln_ = 0;
+#define TL_PUT_(ID, CAP) { if (tln_ < (CAP)) { const unsigned long long t_ = (__builtin_readcyclecounter() << 8) | (unsigned)(ID); if ((threadIdx.x & 63) == 0) tlp_[tln_] = t_; ++tln_; } }
+#define TL(ID) TL_PUT_(ID, TL_MAX - 6)
+#define TLE(ID) TL_PUT_(ID, TL_MAX)
+#define TL_DUMP(LOGICAL, NB, NWAVES)                                                                                        \
+    {                                                                                                                       \
+        const int slot_ = (LOGICAL) == 0 ? 0 : (LOGICAL) == 1 ? 1 : (LOGICAL) == (NB) / 2 ? 2 : (LOGICAL) == (NB) - 1 ? 3 : -1; \
+        if (slot_ >= 0 && p.part) {                                                                                         \
+            __builtin_amdgcn_s_waitcnt(0);                                                                                  \
+            unsigned long long* o_ = reinterpret_cast<unsigned long long*>(p.part) + ((long)slot_ * 16 + wave) * (TL_MAX + 2); \
+            if ((threadIdx.x & 63) == 0) { o_[0] = 0x544c0000ull | (unsigned)tln_; o_[1] = ((unsigned long long)(LOGICAL) << 32) | (unsigned)(NWAVES); } \
+            for (int q_ = threadIdx.x & 63; q_ < tln_; q_ += 64) o_[2 + q_] = tlp_[q_];                                     \
+        }                                                                                                                   \
+    }
+#else
+#define TL_BYTES 0
+#define TL_DECL(...)
+#define TL(ID)
+#define TLE(ID)
+#define TL_DUMP(LOGICAL, NB, NWAVES)
+#endif
+
 int launch_conv_bufload(const ConvParams& p, int tile, hipStream_t s);   // conv_bufload.hip (experimental tiles 50..)
 int launch_conv_dma(const ConvParams& p, int tile, hipStream_t s);
-int launch_conv_strip(const ConvParams& p, int tile, hipStream_t s);      // conv_strip.hip: tiles 90..       // conv_dma.hip (LDS-DMA tiles 60..)
+int launch_conv_strip(const ConvParams& p, int tile, hipStream_t s);
+int launch_conv_pc(const ConvParams& p, int tile, hipStream_t s);         // conv_pc.hip: producer / consumer tiles 100..      // conv_strip.hip: tiles 90..       // conv_dma.hip (LDS-DMA tiles 60..)

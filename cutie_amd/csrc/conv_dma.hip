@@ -84,7 +84,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // provably wave-uniform (LDS base of the DMA goes to M0)
+    TL_DECL(lds + dma_lds_bytes<BM, BN, NS, BK>())
+    TL(0)
     int m0, n0;                                          // XCD-aware tile mapping, as in conv_igemm_kernel
+    int tl_logical = 0, tl_nb = 0;                       // (timeline builds only)
     {
         const int nb = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
         const int xcd = id & 7, kq = id >> 3, q = nb >> 3, r = nb & 7;
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
         const int mt = logical / (int)gridDim.y;
         m0 = mt * BM;
         n0 = (logical - mt * (int)gridDim.y) * BN;
+        tl_logical = logical; tl_nb = nb;
     }
     if (p.zero && blockIdx.x == 0 && blockIdx.y == 0)      // side job: clear the GAP accumulator of the next conv
         for (int z = tid; z < p.nzero; z += NT) p.zero[z] = 0ull;
@@ -296,14 +300,20 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
     // has left through the barrier), then wait until this wave's pieces of tile t+1 have landed (only the pieces of the NS-2
     // younger tiles may still be in flight) and meet the other waves. ----
     int ld = 0;                                          // stage (byte offset) the next DMA goes to
+    TL(1)
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) { LOAD_TILE(ld) ld += STAGE_B; }
     if (nk >= NS - 1) { TILE_SYNC((NS - 2) * LPT) } else { TILE_SYNC(0) }
     int rd = 0;                                          // stage being multiplied
     int kt = 0;
+    TL(2)
     for (; kt < nk - (NS - 1); ++kt) {
+        TL(3)
         COMPUTE_TILE(rd, ld, true)
+        TL(4)
+        WAIT_VMCNT_LDS((NS - 2) * LPT);
+        TL(5)
         TILE_SYNC((NS - 2) * LPT)
         ld = ld == (NS - 1) * STAGE_B ? 0 : ld + STAGE_B;
         rd = rd == (NS - 1) * STAGE_B ? 0 : rd + STAGE_B;
@@ -327,6 +337,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
     if (acc[0][0][0] != 12345.678f) return;
 #endif
     // ---- epilogue: fp32 tile transposed through LDS, 16-B accesses along the channel axis; bias already in registers ----
+    TLE(6)
     float* ctile = reinterpret_cast<float*>(smem);       // the loop ended with a barrier: the operand ring is dead
 #pragma unroll
     for (int b = 0; b < TM; ++b)
@@ -336,6 +347,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
             *reinterpret_cast<f32x4*>(ctile + px * LDC + ch) = acc[a][b];
         }
     __syncthreads();
+    TLE(7)
     const bool active = ech0 < p.Cout;
     if (!active && !p.gap) return;                       // (GAP mode: every thread reaches the barrier below)
     const int act = (p.flags >> CUTIE_ACT_SHIFT) & 7;
@@ -389,6 +401,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
             }
         }
     }
+    TLE(8)
+    TL_DUMP(tl_logical, tl_nb, NW)
     if (p.gap) {
         // GAP partials of this tile: thread = (channel, row part); rows of one object summed in row order in fp32, each partial
         // converted to fixed point and added with an integer atomic (a tile may straddle objects: flush at every boundary)
@@ -416,7 +430,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
 
 template <int BM, int BN, int WM, int WN, int NS, int BK, bool HALO, bool RELU, bool TWO>
 static int launch_dma3(const ConvParams& p, hipStream_t s, int gy) {
-    constexpr int lds = dma_lds_bytes<BM, BN, NS, BK>();
+    constexpr int lds = dma_lds_bytes<BM, BN, NS, BK>() + TL_BYTES;
     static bool attr_set = false;                        // one flag per instantiation
     if (!attr_set) {
         if (lds > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<BM, BN, WM, WN, NS, BK, HALO, RELU, TWO>),

@@ -612,8 +612,8 @@ int launch_conv(const cutie_op* op, hipStream_t s) {
     p.splitk = i[19] > 1 ? i[19] : 1; p.part = (float*)op->p[6];
     p.ldp = (p.Cout + 7) & ~7;
     p.gap = (long long*)op->p[7]; p.zero = (unsigned long long*)op->p[8]; p.nzero = i[21];
-    if ((p.gap || p.zero) && (i[17] < 60 || i[17] >= 100 || ((p.flags & CUTIE_F_OUT_F32) && p.gap) || (p.Cout & 7) || (p.ldy & 7) || (p.res && (p.ldr & 7)))) {
-        cutie_set_error("conv: GAP accumulation / zero job need an LDS-DMA tile (60..99), bf16 output, Cout %% 8 == 0 (tile %d)", i[17]);
+    if ((p.gap || p.zero) && (i[17] < 60 || i[17] >= 200 || ((p.flags & CUTIE_F_OUT_F32) && p.gap) || (p.Cout & 7) || (p.ldy & 7) || (p.res && (p.ldr & 7)))) {
+        cutie_set_error("conv: GAP accumulation / zero job need an LDS-DMA tile (60..199), bf16 output, Cout %% 8 == 0 (tile %d)", i[17]);
         return -2;
     }
     if (p.splitk > 1 && (!p.part || (long)p.splitk * p.M * p.ldp > (long)i[20] * 1024)) {
@@ -638,6 +638,7 @@ int launch_conv(const cutie_op* op, hipStream_t s) {
     }
     if (i[17] >= 50 && i[17] < 60) return launch_conv_bufload(p, i[17], s);     // experimental tiles (conv_bufload.hip)
     if (i[17] >= 60 && i[17] < 90) return launch_conv_dma(p, i[17], s);         // LDS-DMA tiles (conv_dma.hip)
+    if (i[17] >= 100 && i[17] < 200) return launch_conv_pc(p, i[17], s);         // producer / consumer LDS-DMA tiles (conv_pc.hip)
     if (i[17] >= 90 && i[17] < 100) return launch_conv_strip(p, i[17], s);      // LDS-DMA with the 3x3 input strip resident (conv_strip.hip)
     switch (i[17]) {
         case 0: return launch_cfg<128, 128, 2, 2, 32, 4, 2>(p, s);

@@ -1,0 +1,639 @@
+// Producer / consumer implicit-GEMM convolution with LDS-DMA operand staging -- tiles 100..
+//
+// Why (round 3, profiles/r03_conv_timeline.md): in conv_dma_kernel every wave multiplies AND issues its share of the tile's LDS-DMA
+// pieces.  A 1-KiB piece occupies the CU's vector-memory path for >= 16 cycles (64 B/clk) and the issuing wave waits in that queue
+// for 60-180 cycles per piece -- in program order, between its own MFMAs.  With one block per CU (the small-M layers of a single
+// clip) a K step of the 64x64 tile therefore takes ~570 cycles for 128 cycles of MFMA, whatever the ring depth or the byte count
+// (conv_strip: 35 % fewer bytes, same time).  Here the two jobs belong to different waves of the workgroup:
+//   * NPW producer waves own the address state and issue every LDS-DMA piece; their queueing time is nobody's MFMA time;
+//   * WM x WN consumer waves read fragments and issue MFMAs, nothing else;
+//   * one raw s_barrier per K step joins them: producers arrive after a counted vmcnt (tile t+1 has landed), consumers after
+//     lgkmcnt(0) (their reads of tile t have returned) -- the ring protocol of conv_dma.hip with the roles split.
+// Two operand modes:
+//   * stream (TW = 0): im2col rows streamed per K tile as in conv_dma.hip (any kernel size / stride, halo by out-of-range offsets);
+//   * halo   (TW > 0): 3x3 / stride 1 / pad 1.  The block owns a TH x TW patch of output pixels of ONE image; the (TH+2) x (TW+2)
+//     input patch of a 64-channel slice is fetched ONCE (double-buffered across slices; pixels outside the image are out-of-range
+//     offsets = zeros, so the loop has no border logic at all) and the nine taps are fragment reads at shifted patch rows; only the
+//     weight tiles stream per tap: 9x fewer activation bytes through the L2 -> LDS path.
+// Epilogue: straight from the accumulators (no LDS transpose, no barrier).  The producers fetch the weight rows of each 32-channel
+// group in the order 0-3, 8-11, 16-19, 24-27 | 4-7, 12-15, 20-23, 28-31, so the two 16-row MFMA fragments of a group leave every
+// lane with 8 CONSECUTIVE output channels of one pixel: bias / residual / activation on registers, one 16-B store (bf16).  The
+// residual of the small tiles is requested before the K loop.  GAP side job: per-fragment column sums by lane shuffles, fixed-point
+// integer atomics (order-independent, like conv_dma.hip).
+// Requirements (checked at launch): Cin % 64 == 0 (C1 too for two sources), no split-K, operands < 2 GiB; halo mode: k = 3,
+// stride 1, pad 1.
+#include "conv_common.h"
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#define PC_WORD3 0x00020000
+#define PC_RECORDS 0x7fffffff
+#define PC_OOB 0x80000000u
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+// s_waitcnt with only one counter constrained (gfx9 encoding: vmcnt = simm16[3:0] | simm16[15:14] << 4, expcnt [6:4], lgkmcnt [11:8])
+#define PC_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (((N) >> 4) << 14) | (7 << 4) | (15 << 8))
+#define PC_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(15 | (3 << 14) | (7 << 4) | (0 << 8))
+#define PC_BARRIER() { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+#ifdef PC_ABL_NO_DMA
+#define PC_DMA(...) ((void)0)
+#else
+#define PC_DMA(...) __builtin_amdgcn_raw_ptr_buffer_load_lds(__VA_ARGS__)
+#endif
+
+__device__ __forceinline__ rsrc_t pc_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, PC_RECORDS, PC_WORD3);
+}
+
+typedef short pc_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pc_relu2(unsigned w) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(pc_s16x2, w), (pc_s16x2){0, 0}));
+}
+
+// row of the packed weight matrix that LDS weight row R of a tile holds (see the header: 8 consecutive channels per lane)
+__device__ __forceinline__ int pc_wrow(int R, bool pair) {
+    if (!pair) return R;
+    const int ii = R & 15, alo = (R >> 4) & 1;
+    return (R & ~31) | ((ii >> 2) << 3) | (alo << 2) | (ii & 3);
+}
+
+template <int BM, int BN, int NS, int TW>
+constexpr int pc_lds_bytes(int NPW) {
+    if (TW == 0) return NS * (BM + BN) * 128;
+    const int TH = BM / TW, npiece = ((TH + 2) * (TW + 2) + 7) / 8, nxp = (npiece + NPW - 1) / NPW;
+    return 2 * nxp * NPW * 1024 + NS * BN * 128;
+}
+
+// one slice of the epilogue: NCH (4 or 8) consecutive channels of one pixel
+template <int NCH>
+__device__ __forceinline__ void pc_finish(const ConvParams& p, float (&v)[NCH], int m, int ch0, bool vec_ok, bool have_res,
+                                          const unsigned (&rpre)[NCH / 2], float (&stored)[NCH]) {
+    const int act = (p.flags >> CUTIE_ACT_SHIFT) & 7;
+    const bool out_f32 = p.flags & CUTIE_F_OUT_F32;
+    const bool full = ch0 + NCH <= p.Cout;
+    if (p.res) {
+        if (have_res) {                                  // requested before the K loop
+#pragma unroll
+            for (int r = 0; r < NCH / 2; ++r) { v[2 * r] += __uint_as_float(rpre[r] << 16); v[2 * r + 1] += __uint_as_float(rpre[r] & 0xffff0000u); }
+        } else {
+            const int mres = (p.flags & CUTIE_F_RES_BCAST) ? (m % p.OHW) : m;
+            const bf16_t* rp = p.res + (long)mres * p.ldr + ch0;
+            if (full && vec_ok) {
+                unsigned rr[NCH / 2];
+                if constexpr (NCH == 8) { const uint4 t = *reinterpret_cast<const uint4*>(rp); rr[0] = t.x; rr[1] = t.y; rr[NCH / 2 - 2] = t.z; rr[NCH / 2 - 1] = t.w; }
+                else { const uint2 t = *reinterpret_cast<const uint2*>(rp); rr[0] = t.x; rr[1] = t.y; }
+#pragma unroll
+                for (int r = 0; r < NCH / 2; ++r) { v[2 * r] += __uint_as_float(rr[r] << 16); v[2 * r + 1] += __uint_as_float(rr[r] & 0xffff0000u); }
+            } else {
+#pragma unroll
+                for (int r = 0; r < NCH; ++r) if (ch0 + r < p.Cout) v[r] += bf2f(rp[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NCH; ++r) {
+        if (act == CUTIE_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+        else if (act == CUTIE_ACT_SIGMOID) v[r] = sigmoidf_(v[r]);
+        else if (act == CUTIE_ACT_SQ1) v[r] = v[r] * v[r] + 1.f;
+    }
+    if (out_f32) {
+        float* yp = reinterpret_cast<float*>(p.y) + (long)m * p.ldy + ch0;
+        if (full && vec_ok) {
+#pragma unroll
+            for (int r = 0; r < NCH; r += 4) *reinterpret_cast<float4*>(yp + r) = make_float4(v[r], v[r + 1], v[r + 2], v[r + 3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < NCH; ++r) if (ch0 + r < p.Cout) yp[r] = v[r];
+        }
+    } else {
+        bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + (long)m * p.ldy + ch0;
+        unsigned o[NCH / 2];
+#pragma unroll
+        for (int r = 0; r < NCH / 2; ++r) o[r] = pack_bf2(v[2 * r], v[2 * r + 1]);
+        if (full && vec_ok) {
+            if constexpr (NCH == 8) *reinterpret_cast<uint4*>(yp) = make_uint4(o[0], o[1], o[NCH / 2 - 2], o[NCH / 2 - 1]);
+            else *reinterpret_cast<uint2*>(yp) = make_uint2(o[0], o[1]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < NCH; ++r) if (ch0 + r < p.Cout) yp[r] = (bf16_t)(r & 1 ? o[r >> 1] >> 16 : o[r >> 1] & 0xffffu);
+        }
+        {                                                // GAP: the STORED (bf16-rounded) values (dead code without the side job)
+#pragma unroll
+            for (int r = 0; r < NCH / 2; ++r) { stored[2 * r] = __uint_as_float(o[r] << 16); stored[2 * r + 1] = __uint_as_float(o[r] & 0xffff0000u); }
+        }
+    }
+}
+
+// TW == 0: stream mode (TAPS: more than one tap and / or padding); TW > 0: halo mode (TAPS ignored)
+template <int BM, int BN, int WM, int WN, int NPW, int NS, int TW, bool TAPS, bool RELU, bool TWO>
+__global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParams p) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr bool HALO = TW > 0;
+    constexpr int NC = WM * WN, NTC = NC * 64;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr bool PAIR = (TN % 2) == 0;
+    constexpr int NCH = PAIR ? 8 : 4, TNP = PAIR ? TN / 2 : TN;          // channels per lane and epilogue slice, slices per pixel
+    constexpr int NXI = HALO ? 1 : BM / 8 / NPW;         // stream: X pieces per producer wave per K tile
+    constexpr int NWI = BN / 8 / NPW;                    // W pieces per producer wave per K tile
+    constexpr int LPT = HALO ? NWI : NXI + NWI;
+    constexpr int TH = HALO ? BM / (HALO ? TW : 1) : 1, PH = TH + 2, PW = TW + 2;
+    constexpr int NPIECE = (PH * PW + 7) / 8, NXP = (NPIECE + NPW - 1) / NPW, XBUF = NXP * NPW * 1024;
+    constexpr int WSTAGE = BN * 128, STAGE = HALO ? WSTAGE : (BM + BN) * 128;
+    constexpr int WBASE = HALO ? 2 * XBUF : 0;           // halo: [X slice buffer 0 | 1 | W ring]; stream: ring of [X | W] stages
+    constexpr bool PRE_RES = TM * TNP <= 4;              // residual requested before the K loop
+    static_assert(TM >= 1 && TN >= 1 && BM % (WM * 16) == 0 && BN % (WN * 16) == 0 && NWI >= 1 && NWI * 8 * NPW == BN && NS >= 2 && NS <= 8, "bad tile");
+    static_assert(HALO || (NXI >= 1 && NXI * 8 * NPW == BM), "bad stream tile");
+    static_assert(!HALO || (BM % TW == 0 && NS == 3 && NXP <= 8), "bad halo tile");
+    extern __shared__ __attribute__((aligned(16))) u32x4 pc_smem[];
+    char* const lds = reinterpret_cast<char*>(pc_smem);
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    TL_DECL(lds + pc_lds_bytes<BM, BN, NS, TW>(NPW))
+    TL(0)
+    // XCD-aware tile order (N inner), bijective for any grid
+    const int nb = gridDim.x * gridDim.y;
+    int logical;
+    {
+        const int id = blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = id & 7, kq = id >> 3, q = nb >> 3, r = nb & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kq;
+    }
+    const int mt = logical / (int)gridDim.y;
+    const int n0 = (logical - mt * (int)gridDim.y) * BN;
+    int m0 = 0, bimg = 0, ty0 = 0, tx0 = 0;              // stream: first row; halo: image and first output pixel of the patch
+    if (HALO) {
+        const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH, per = tiles_x * tiles_y;
+        bimg = mt / per;
+        const int r = mt - bimg * per, ty = r / tiles_x;
+        ty0 = ty * TH;
+        tx0 = (r - ty * tiles_x) * TW;
+    } else {
+        m0 = mt * BM;
+    }
+    if (p.zero && blockIdx.x == 0 && blockIdx.y == 0)      // side job: clear the GAP accumulator of the next conv
+        for (int z = tid; z < p.nzero; z += (NC + NPW) * 64) p.zero[z] = 0ull;
+    const int nslice = p.Cin / 64;
+#ifdef PC_ABL_NO_LOOP
+    const int nk = 0;
+#else
+    const int nk = HALO ? nslice * 9 : p.Kslice / 64;
+#endif
+
+    if (wave >= NC) {
+        // =========================================== producer waves ===========================================
+        const int pw = wave - NC;                        // wave-uniform
+        const int lr = lane >> 3;
+        const unsigned kcb = (unsigned)(((lane & 7) ^ lr) * 16);
+        constexpr unsigned PRE = 4096;                   // descriptors start PRE bytes early: instruction offsets i * 1024 stay legal
+        unsigned woff[NWI];
+#pragma unroll
+        for (int i = 0; i < NWI; ++i)
+            woff[i] = (unsigned)((n0 + pc_wrow((pw * NWI + i) * 8 + lr, PAIR)) * p.Kpad * 2) + kcb + (HALO ? 0u : PRE - (unsigned)i * 1024u);
+        const rsrc_t rw = pc_rsrc(reinterpret_cast<const char*>(p.w) - (HALO ? 0 : PRE));
+        const int wdst = WBASE + (HALO ? 0 : BM * 128) + pw * NWI * 1024;
+        if constexpr (!HALO) {
+            unsigned xoff1[NXI], xoff2[NXI], vmask[NXI];
+            {
+                int m = m0 + pw * NXI * 8 + lr;
+                const int mm = m < p.M ? m : p.M - 1;    // rows past the end recompute the last pixel (never stored)
+                int b = mm / p.OHW;
+                const int rem = mm - b * p.OHW;
+                int oh = rem / p.OW;
+                int ow = rem - oh * p.OW;
+#pragma unroll
+                for (int i = 0; i < NXI; ++i) {
+                    const int ih0 = oh * p.stride, iw0 = ow * p.stride;
+                    const unsigned pix = (unsigned)((b * p.H + ih0) * p.W + iw0);
+                    xoff1[i] = pix * (unsigned)(p.ldx1 * 2) + kcb + PRE - (unsigned)i * 1024u;
+                    xoff2[i] = TWO ? pix * (unsigned)(p.ldx2 * 2) + kcb + PRE - (unsigned)i * 1024u : 0u;
+                    unsigned mk = 0;
+                    if (TAPS) {
+                        unsigned cols = 0;
+                        for (int k = 0; k < p.KW; ++k) cols |= ((unsigned)(iw0 - p.pad + k) < (unsigned)p.W) ? (1u << k) : 0u;
+                        for (int k = 0; k < p.KH; ++k) mk |= ((unsigned)(ih0 - p.pad + k) < (unsigned)p.H) ? (cols << (k * p.KW)) : 0u;
+                    }
+                    vmask[i] = mk;
+                    if (i + 1 < NXI) {
+                        m += 8;
+                        if (m < p.M) {
+                            ow += 8;
+                            while (ow >= p.OW) { ow -= p.OW; ++oh; }
+                            while (oh >= p.OH) { oh -= p.OH; ++b; }
+                        }
+                    }
+                }
+            }
+            const long shift = (long)p.pad * p.W + p.pad;
+            const char* xb1 = reinterpret_cast<const char*>(p.x1 - shift * p.ldx1) - PRE;
+            const char* xb2 = TWO ? reinterpret_cast<const char*>(p.x2 - shift * p.ldx2) - PRE : xb1;
+            const rsrc_t rx1 = pc_rsrc(xb1), rx2 = pc_rsrc(xb2);
+            const int xdst = pw * NXI * 1024;
+            int tap = 0, kw = 0, cc = 0, pixA = 0, pixB = 0;
+            unsigned wsoff = 0;
+            const int cin2 = p.Cin * 2, c12 = p.C1 * 2;
+            const int stepA1 = p.ldx1 * 2, stepA2 = (p.W - p.KW + 1) * p.ldx1 * 2;
+            const int stepB1 = p.ldx2 * 2, stepB2 = (p.W - p.KW + 1) * p.ldx2 * 2;
+#define PCS_XPIECE(I, LD)                                                                                      \
+    if constexpr ((I) < NXI) {                                                                                 \
+        const unsigned v_ = in1_ ? xoff1[(I) < NXI ? (I) : 0] : xoff2[(I) < NXI ? (I) : 0];                   \
+        PC_DMA(rx_, LDS_PTR(lds + (LD) + xdst), 16, (!TAPS || (vmask[(I) < NXI ? (I) : 0] & tapbit_)) ? v_ : PC_OOB, soff_, (I) * 1024, 0); \
+    }
+#define PCS_WPIECE(I, LD)                                                                                      \
+    if constexpr ((I) < NWI) PC_DMA(rw, LDS_PTR(lds + (LD) + wdst), 16, woff[(I) < NWI ? (I) : 0], wsoff, (I) * 1024, 0);
+#define PCS_LOAD_TILE(LD)                                                                                      \
+    {                                                                                                          \
+        const unsigned tapbit_ = 1u << tap;                                                                    \
+        const bool in1_ = !TWO || cc < c12;                                                                    \
+        const unsigned soff_ = (unsigned)(in1_ ? pixA + cc : pixB + cc - c12);                                 \
+        const rsrc_t rx_ = in1_ ? rx1 : rx2;                                                                   \
+        PCS_XPIECE(0, LD) PCS_XPIECE(1, LD) PCS_XPIECE(2, LD) PCS_XPIECE(3, LD)                                \
+        PCS_WPIECE(0, LD) PCS_WPIECE(1, LD) PCS_WPIECE(2, LD) PCS_WPIECE(3, LD)                                \
+        wsoff += 128;                                                                                          \
+        cc += 128;                                                                                             \
+        if (TAPS || TWO) {                                                                                     \
+            const bool wrap_ = cc >= cin2;                                                                     \
+            cc = wrap_ ? 0 : cc;                                                                               \
+            if (TAPS) {                                                                                        \
+                tap += wrap_ ? 1 : 0;                                                                          \
+                kw += wrap_ ? 1 : 0;                                                                           \
+                const bool wrap2_ = kw == p.KW;                                                                \
+                kw = wrap2_ ? 0 : kw;                                                                          \
+                pixA += wrap_ ? (wrap2_ ? stepA2 : stepA1) : 0;                                                \
+                if (TWO) pixB += wrap_ ? (wrap2_ ? stepB2 : stepB1) : 0;                                       \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+            static_assert(NXI <= 4 && NWI <= 4, "pieces per producer wave");
+            int ld = 0;
+            TL(1)
+#pragma unroll
+            for (int s = 0; s < NS - 1; ++s)
+                if (s < nk) { PCS_LOAD_TILE(ld) ld += STAGE; }
+            if (nk >= NS - 1) { PC_WAIT_VM((NS - 2) * LPT); } else { PC_WAIT_VM(0); }
+            TL(2)
+            PC_BARRIER()
+            int kt = 0;
+            for (; kt < nk - (NS - 1); ++kt) {
+                TL(3)
+                PCS_LOAD_TILE(ld)
+                TL(4)
+                PC_WAIT_VM((NS - 2) * LPT);
+                TL(5)
+                PC_BARRIER()
+                ld = ld == (NS - 1) * STAGE ? 0 : ld + STAGE;
+            }
+            for (; kt < nk; ++kt) {
+                PC_WAIT_VM(0);
+                PC_BARRIER()
+            }
+#undef PCS_LOAD_TILE
+#undef PCS_WPIECE
+#undef PCS_XPIECE
+        } else {
+            // ---- halo mode: patch pieces of a slice (per-lane pixel offsets, computed once) + one weight tile per K step ----
+            unsigned xo1[NXP], xo2[NXP];
+#pragma unroll
+            for (int i = 0; i < NXP; ++i) {
+                const int pp = (pw + NPW * i) * 8 + lr;  // patch pixel of this lane's row
+                const int py = pp / PW, px = pp - py * PW;
+                const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
+                const bool ok = pp < PH * PW && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                const unsigned pix = (unsigned)((bimg * p.H + gy) * p.W + gx);
+                const unsigned kc = (unsigned)(((lane & 7) ^ (pp & 7)) * 16);
+                xo1[i] = ok ? pix * (unsigned)(p.ldx1 * 2) + kc : PC_OOB;
+                xo2[i] = TWO ? (ok ? pix * (unsigned)(p.ldx2 * 2) + kc : PC_OOB) : 0u;
+            }
+            const rsrc_t rx1 = pc_rsrc(p.x1), rx2 = TWO ? pc_rsrc(p.x2) : rx1;
+            const int cin2 = p.Cin * 2;
+            // one patch piece (slot I of this wave) of slice SL into slice buffer SL & 1
+#define PCH_XPIECE(I, SL)                                                                                      \
+    {                                                                                                          \
+        const bool f_ = !TWO || (SL) * 64 < p.C1;                                                              \
+        const int so_ = (f_ ? (SL) * 64 : (SL) * 64 - p.C1) * 2;                                               \
+        PC_DMA(f_ ? rx1 : rx2, LDS_PTR(lds + ((SL) & 1) * XBUF + (pw + NPW * (I)) * 1024), 16, f_ ? xo1[I] : xo2[I], so_, 0, 0); \
+    }
+            // weight tile of the K step whose state is (wsl, wtap) into ring stage offset wld, then advance that state
+            int wsl = 0, wtap = 0, wld = 0;
+            unsigned wso = 0;                            // (wtap * Cin + wsl * 64) * 2
+#define PCH_WTILE()                                                                                            \
+    {                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < NWI; ++i) PC_DMA(rw, LDS_PTR(lds + wld + wdst + i * 1024), 16, woff[i], wso, 0, 0); \
+        wld = wld == (NS - 1) * WSTAGE ? 0 : wld + WSTAGE;                                                     \
+        ++wtap; wso += (unsigned)cin2;                                                                         \
+        if (wtap == 9) { wtap = 0; ++wsl; wso = (unsigned)(wsl * 128); }                                       \
+    }
+            TL(1)
+#pragma unroll
+            for (int i = 0; i < NXP; ++i) PCH_XPIECE(i, 0)
+#pragma unroll
+            for (int s = 0; s < NS - 1; ++s)
+                if (s < nk) PCH_WTILE()
+            if (nk >= NS - 1) { PC_WAIT_VM((NS - 2) * NWI); } else { PC_WAIT_VM(0); }
+            TL(2)
+            PC_BARRIER()
+            int sl = 0, tap = 0;
+            int kt = 0;
+            for (; kt < nk - (NS - 1); ++kt) {
+                TL(3)
+                const bool xp = sl + 1 < nslice && tap < NXP;                 // wave-uniform
+                if (xp) {
+                    // slot `tap` of the next slice (a switch keeps the per-lane offsets in registers: no dynamic indexing)
+                    switch (tap) {
+                        case 0: if constexpr (NXP > 0) PCH_XPIECE(0, sl + 1) break;
+                        case 1: if constexpr (NXP > 1) PCH_XPIECE(NXP > 1 ? 1 : 0, sl + 1) break;
+                        case 2: if constexpr (NXP > 2) PCH_XPIECE(NXP > 2 ? 2 : 0, sl + 1) break;
+                        case 3: if constexpr (NXP > 3) PCH_XPIECE(NXP > 3 ? 3 : 0, sl + 1) break;
+                        case 4: if constexpr (NXP > 4) PCH_XPIECE(NXP > 4 ? 4 : 0, sl + 1) break;
+                        case 5: if constexpr (NXP > 5) PCH_XPIECE(NXP > 5 ? 5 : 0, sl + 1) break;
+                        case 6: if constexpr (NXP > 6) PCH_XPIECE(NXP > 6 ? 6 : 0, sl + 1) break;
+                        default: if constexpr (NXP > 7) PCH_XPIECE(NXP > 7 ? 7 : 0, sl + 1) break;
+                    }
+                }
+                PCH_WTILE()
+                TL(4)
+                if (xp) { PC_WAIT_VM(NWI + 1); } else { PC_WAIT_VM(NWI); }
+                TL(5)
+                PC_BARRIER()
+                ++tap;
+                if (tap == 9) { tap = 0; ++sl; }
+            }
+            for (; kt < nk; ++kt) {
+                PC_WAIT_VM(0);
+                PC_BARRIER()
+            }
+#undef PCH_WTILE
+#undef PCH_XPIECE
+        }
+        TLE(6)
+        TL_DUMP(logical, nb, NC + NPW)
+        return;
+    }
+
+    // =========================================== consumer waves ===========================================
+    const int wm = wave / WN, wn = wave % WN;
+    const int pm0 = wm * (BM / WM), cn0 = wn * (BN / WN);
+    // output pixel of this lane in fragment b
+    int mrow[TM];
+    bool mval[TM];
+    int xbase[TM];                                       // halo: patch pixel of tap (0, 0)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const int q = pm0 + b * 16 + l15;
+        if (HALO) {
+            const int qy = q / (HALO ? TW : 1), qx = q - qy * TW;
+            const int gy = ty0 + qy, gx = tx0 + qx;
+            mval[b] = gy < p.H && gx < p.W;
+            mrow[b] = (bimg * p.H + gy) * p.W + gx;
+            xbase[b] = qy * PW + qx;
+        } else {
+            mrow[b] = m0 + q;
+            mval[b] = mrow[b] < p.M;
+            xbase[b] = 0;
+        }
+    }
+    // epilogue operands requested up front: bias of this lane's channels, residual (small tiles)
+    const bool out_f32 = p.flags & CUTIE_F_OUT_F32;
+    const bool vec_ok = (out_f32 ? (p.ldy & 3) == 0 : (p.ldy & (NCH - 1)) == 0) && (!p.res || (p.ldr & (NCH - 1)) == 0);
+    float bias[TNP][NCH];
+#pragma unroll
+    for (int a = 0; a < TNP; ++a) {
+        const int ch0 = n0 + cn0 + a * (PAIR ? 32 : 16) + l4 * NCH;
+#pragma unroll
+        for (int r = 0; r < NCH; ++r) bias[a][r] = (p.bias && ch0 + r < p.Cout) ? p.bias[ch0 + r] : 0.f;
+    }
+    unsigned rpre[PRE_RES ? TM : 1][PRE_RES ? TNP : 1][NCH / 2];
+    const bool have_res = PRE_RES && p.res && vec_ok;
+    if (PRE_RES) {
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int a = 0; a < TNP; ++a) {
+                const int ch0 = n0 + cn0 + a * (PAIR ? 32 : 16) + l4 * NCH;
+#pragma unroll
+                for (int r = 0; r < NCH / 2; ++r) rpre[b][a][r] = 0u;
+                if (have_res && mval[b] && ch0 + NCH <= p.Cout) {
+                    const int mres = (p.flags & CUTIE_F_RES_BCAST) ? (mrow[b] % p.OHW) : mrow[b];
+                    const bf16_t* rp = p.res + (long)mres * p.ldr + ch0;
+                    if constexpr (NCH == 8) { const uint4 t = *reinterpret_cast<const uint4*>(rp); rpre[b][a][0] = t.x; rpre[b][a][1] = t.y; rpre[b][a][NCH / 2 - 2] = t.z; rpre[b][a][NCH / 2 - 1] = t.w; }
+                    else { const uint2 t = *reinterpret_cast<const uint2*>(rp); rpre[b][a][0] = t.x; rpre[b][a][1] = t.y; }
+                }
+            }
+    }
+    // fragment read offsets (bytes inside a stage / slice buffer)
+    const int c0 = l4 << 4, c1 = (4 + l4) << 4;          // unswizzled chunk byte offsets of the two MFMA k-steps
+    const int swl = (l15 & 7) << 4;
+    int rdw0, rdx0 = 0;                                  // W fragment a adds a * 2048; stream X fragment b adds b * 2048
+    rdw0 = (HALO ? 0 : BM * 128) + (cn0 + l15) * 128;
+    if (!HALO) rdx0 = (pm0 + l15) * 128;
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#ifdef PC_ABL_NO_MFMA
+#define PC_MFMA(AF, BF, ACC) ACC[0] += __uint_as_float(__builtin_bit_cast(u32x4, AF).x ^ __builtin_bit_cast(u32x4, BF).y)
+#else
+#define PC_MFMA(AF, BF, ACC) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF, BF, ACC, 0, 0, 0)
+#endif
+#define PC_RELU4(V) if (RELU) { V.x = pc_relu2(V.x); V.y = pc_relu2(V.y); V.z = pc_relu2(V.z); V.w = pc_relu2(V.w); }
+    TL(1)
+    PC_BARRIER()                                         // tile 0 (and the patch of slice 0) has landed
+    TL(2)
+    int rd = 0;                                          // ring stage of the tile being multiplied (byte offset)
+    int sl = 0, tap = 0, toff = 0;                       // halo: slice, tap, patch-pixel offset of the tap
+    for (int kt = 0; kt < nk; ++kt) {
+        TL(3)
+        bf16x8 xb0[TM], xb1[TM], wa0[TN], wa1[TN];
+        const char* const wst = lds + WBASE + rd + rdw0;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            wa0[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wst + a * 2048 + (c0 ^ swl)));
+            wa1[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wst + a * 2048 + (c1 ^ swl)));
+        }
+        if (HALO) {
+            const char* const xs = lds + (sl & 1) * XBUF;
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int pp = xbase[b] + toff;
+                const int sw = (pp & 7) << 4;
+                u32x4 v0 = *reinterpret_cast<const u32x4*>(xs + pp * 128 + (c0 ^ sw));
+                u32x4 v1 = *reinterpret_cast<const u32x4*>(xs + pp * 128 + (c1 ^ sw));
+                PC_RELU4(v0) PC_RELU4(v1)
+                xb0[b] = __builtin_bit_cast(bf16x8, v0); xb1[b] = __builtin_bit_cast(bf16x8, v1);
+            }
+        } else {
+            const char* const xs = lds + rd + rdx0;
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                u32x4 v0 = *reinterpret_cast<const u32x4*>(xs + b * 2048 + (c0 ^ swl));
+                u32x4 v1 = *reinterpret_cast<const u32x4*>(xs + b * 2048 + (c1 ^ swl));
+                PC_RELU4(v0) PC_RELU4(v1)
+                xb0[b] = __builtin_bit_cast(bf16x8, v0); xb1[b] = __builtin_bit_cast(bf16x8, v1);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b) PC_MFMA(wa0[a], xb0[b], acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b) PC_MFMA(wa1[a], xb1[b], acc[a][b]);
+        TL(4)
+        PC_WAIT_LGKM0();
+        PC_BARRIER()
+        rd = rd == (NS - 1) * STAGE ? 0 : rd + STAGE;
+        if (HALO) {
+            ++tap;
+            const bool w3 = tap == 3 || tap == 6;
+            toff += w3 ? PW - 2 : 1;
+            if (tap == 9) { tap = 0; toff = 0; ++sl; }
+        }
+    }
+    TLE(5)
+#ifdef PC_ABL_NO_EPILOGUE
+    if (acc[0][0][0] != 12345.678f) { TL_DUMP(logical, nb, NC + NPW) return; }
+#endif
+    // ---- epilogue straight from the accumulators: lane = (pixel l15 of fragment b, channels l4 * NCH .. + NCH of slice a) ----
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+#pragma unroll
+        for (int a = 0; a < TNP; ++a) {
+            const int ch0 = n0 + cn0 + a * (PAIR ? 32 : 16) + l4 * NCH;
+            const bool live = mval[b] && ch0 < p.Cout;
+            float v[NCH], st[NCH];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[PAIR ? 2 * a : a][b][r] + bias[a][r];
+                if (PAIR) v[(NCH - 4) + r] = acc[PAIR ? 2 * a + 1 : a][b][r] + bias[a][(NCH - 4) + r];
+            }
+#pragma unroll
+            for (int r = 0; r < NCH; ++r) st[r] = 0.f;
+            if (live) pc_finish<NCH>(p, v, mrow[b], ch0, vec_ok, have_res && ch0 + NCH <= p.Cout, rpre[PRE_RES ? b : 0][PRE_RES ? a : 0], st);
+            if (p.gap) {
+                // column sums of the stored values over the fragment's 16 pixels.  One object per fragment (always in halo mode):
+                // lane shuffles, then 8 atomics from the l15 == 0 lane of each channel group; a fragment that straddles two
+                // objects adds per lane.  Fixed point + integer atomics: the total does not depend on the order of arrival.
+                const unsigned long long vb = __ballot(mval[b]);                      // wave-uniform
+                const int ob = mval[b] ? mrow[b] / p.OHW : 0;
+                const int ob0 = vb ? __builtin_amdgcn_readfirstlane(__shfl(ob, __ffsll((long long)vb) - 1, 64)) : 0;
+                const bool one = __ballot(mval[b] && ob != ob0) == 0ull;           // wave-uniform
+                if (!vb) {
+                } else if (one) {
+#pragma unroll
+                    for (int r = 0; r < NCH; ++r) {
+                        float s = st[r];
+                        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+                        st[r] = s;
+                    }
+                    if (l15 == 0) {
+#pragma unroll
+                        for (int r = 0; r < NCH; ++r)
+                            if (ch0 + r < p.Cout)
+                                atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)ob0 * p.Cout + ch0 + r), (unsigned long long)__float2ll_rn(st[r] * GAP_FIXED_SCALE));
+                    }
+                } else if (live) {
+#pragma unroll
+                    for (int r = 0; r < NCH; ++r)
+                        if (ch0 + r < p.Cout)
+                            atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)ob * p.Cout + ch0 + r), (unsigned long long)__float2ll_rn(st[r] * GAP_FIXED_SCALE));
+                }
+            }
+        }
+    }
+    TLE(6)
+    TL_DUMP(logical, nb, NC + NPW)
+#undef PC_RELU4
+#undef PC_MFMA
+#endif
+}
+
+template <int BM, int BN, int WM, int WN, int NPW, int NS, int TW, bool TAPS, bool RELU, bool TWO>
+static int launch_pc3(const ConvParams& p, hipStream_t s) {
+    constexpr int lds = pc_lds_bytes<BM, BN, NS, TW>(NPW) + TL_BYTES;
+    static_assert(lds <= 160 * 1024, "LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (lds > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_kernel<BM, BN, WM, WN, NPW, NS, TW, TAPS, RELU, TWO>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            cutie_set_error("conv pc tile: cannot raise the dynamic LDS limit to %d bytes", lds);
+            return -2;
+        }
+        attr_set = true;
+    }
+    unsigned gx;
+    if (TW > 0) {
+        constexpr int TH = BM / (TW > 0 ? TW : 1);
+        gx = (unsigned)(p.B * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / (TW > 0 ? TW : 1)));
+    } else {
+        gx = (unsigned)((p.M + BM - 1) / BM);
+    }
+    hipLaunchKernelGGL((conv_pc_kernel<BM, BN, WM, WN, NPW, NS, TW, TAPS, RELU, TWO>), dim3(gx, (unsigned)((p.Cout + BN - 1) / BN)),
+                       dim3((WM * WN + NPW) * 64), lds, s, p);
+    return (int)hipGetLastError();
+}
+
+template <int BM, int BN, int WM, int WN, int NPW, int NS, int TW>
+static int launch_pc(ConvParams p, hipStream_t s) {
+    const long x1_bytes = (long)p.B * p.H * p.W * p.ldx1 * 2, x2_bytes = p.C2 ? (long)p.B * p.H * p.W * p.ldx2 * 2 : 0;
+    const long gy = (p.Cout + BN - 1) / BN, w_bytes = gy * BN * (long)p.Kpad * 2;
+    if (p.Cin % 64 || (p.C2 && p.C1 % 64) || p.KH > 5 || p.KW > 5 || p.splitk != 1 || p.Kpad < p.KH * p.KW * p.Cin ||
+        x1_bytes >= PC_RECORDS - 8192 || x2_bytes >= PC_RECORDS - 8192 || w_bytes >= PC_RECORDS - 8192) {
+        cutie_set_error("conv pc tile: needs Cin %% 64 == 0 (C1 too for two sources), KH, KW <= 5, no split-K, operands < 2 GiB "
+                        "(Cin=%d C1=%d Kpad=%d k=%dx%d splitk=%d)", p.Cin, p.C1, p.Kpad, p.KH, p.KW, p.splitk);
+        return -2;
+    }
+    if (TW > 0 && (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.OH != p.H || p.OW != p.W)) {
+        cutie_set_error("conv pc halo tile: needs 3x3 / stride 1 / pad 1 (k=%dx%d stride=%d pad=%d)", p.KH, p.KW, p.stride, p.pad);
+        return -2;
+    }
+    p.Kslice = p.KH * p.KW * p.Cin;
+    const bool relu = p.flags & CUTIE_F_RELU_IN, two = p.C2 != 0, taps = p.pad > 0 || p.KH * p.KW > 1;
+#define PC_GO(T_, R_, W_) return launch_pc3<BM, BN, WM, WN, NPW, NS, TW, T_, R_, W_>(p, s)
+    if constexpr (TW > 0) {
+        if (relu) { if (two) PC_GO(true, true, true); PC_GO(true, true, false); }
+        if (two) PC_GO(true, false, true);
+        PC_GO(true, false, false);
+    } else {
+        if (taps) {
+            if (relu) { if (two) PC_GO(true, true, true); PC_GO(true, true, false); }
+            if (two) PC_GO(true, false, true);
+            PC_GO(true, false, false);
+        }
+        if (relu) { if (two) PC_GO(false, true, true); PC_GO(false, true, false); }
+        if (two) PC_GO(false, false, true);
+        PC_GO(false, false, false);
+    }
+#undef PC_GO
+}
+
+// tile table (mirrored by cutie_amd/ops.py:PC_TILES): id -> BM, BN, consumer waves WM x WN, producer waves, ring depth, halo tile width
+int launch_conv_pc(const ConvParams& p, int tile, hipStream_t s) {
+    switch (tile) {
+        // ---- stream mode (any kernel size / stride) ----
+        case 100: return launch_pc<64, 64, 2, 2, 4, 3, 0>(p, s);        // 48 KB
+#ifndef PC_QUICK                                                         // (PC_QUICK: two tiles only, for quick compile checks)
+        case 101: return launch_pc<64, 64, 2, 2, 4, 4, 0>(p, s);        // 64 KB
+        case 102: return launch_pc<32, 64, 2, 2, 4, 4, 0>(p, s);        // 16 x 32 per consumer wave, 48 KB
+        case 103: return launch_pc<128, 64, 2, 2, 4, 3, 0>(p, s);       // 72 KB
+        case 104: return launch_pc<64, 128, 2, 2, 4, 3, 0>(p, s);       // 72 KB
+        case 105: return launch_pc<128, 128, 2, 2, 4, 3, 0>(p, s);      // 64 x 64 per consumer wave, 96 KB
+        case 106: return launch_pc<128, 128, 2, 2, 8, 3, 0>(p, s);      // 8 producers
+        case 107: return launch_pc<64, 64, 2, 2, 8, 3, 0>(p, s);        // 8 producers: one X + one W piece each
+        case 108: return launch_pc<128, 128, 2, 4, 8, 3, 0>(p, s);      // 8 consumers (64 x 32) + 8 producers
+        case 109: return launch_pc<32, 64, 2, 2, 4, 6, 0>(p, s);        // deep ring, 72 KB
+#endif
+        // ---- halo mode (3x3 / stride 1 / pad 1): TH x TW output patch ----
+        case 120: return launch_pc<64, 64, 2, 2, 4, 3, 8>(p, s);        // 8 x 8
+#ifndef PC_QUICK
+        case 121: return launch_pc<64, 64, 2, 2, 4, 3, 16>(p, s);       // 4 x 16
+        case 122: return launch_pc<128, 64, 2, 2, 4, 3, 16>(p, s);      // 8 x 16
+        case 123: return launch_pc<128, 128, 2, 2, 4, 3, 16>(p, s);     // 8 x 16, 64 x 64 per consumer wave
+        case 124: return launch_pc<64, 128, 2, 2, 4, 3, 8>(p, s);       // 8 x 8
+        case 125: return launch_pc<32, 64, 2, 2, 4, 3, 8>(p, s);        // 4 x 8
+        case 126: return launch_pc<128, 128, 2, 4, 8, 3, 16>(p, s);     // 8 x 16, 8 consumers + 8 producers
+        case 127: return launch_pc<64, 128, 2, 2, 4, 3, 16>(p, s);      // 4 x 16
+        case 128: return launch_pc<256, 128, 4, 2, 8, 3, 16>(p, s);     // 16 x 16, 8 consumers (64 x 64) + 8 producers
+#endif
+        default: cutie_set_error("conv: bad pc tile id %d", tile); return -2;
+    }
+}

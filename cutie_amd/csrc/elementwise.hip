@@ -780,9 +780,13 @@ __global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, 
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] += a * x[i];
 }
-__global__ void tick_kernel(float* life, long n) {
+// life counters of up to two token ranges advance by one; optionally use[i] += delta[i] (the usage a look-ahead read-out parked
+// in a side buffer, applied when -- and only when -- that read-out is consumed)
+__global__ void tick_kernel(float* lifeA, long nA, float* lifeB, long nB, float* use, const float* delta, long nU) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) life[i] += 1.f;
+    if (lifeA && i < nA) lifeA[i] += 1.f;
+    if (lifeB && i < nB) lifeB[i] += 1.f;
+    if (use && i < nU) use[i] += delta[i];
 }
 __global__ void cast_kernel(const void* s, void* d, long n, int to_f32) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1003,7 +1007,12 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             hipLaunchKernelGGL(axpy_kernel, GRID1D(i[0], BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (long)i[0], op->f[0]);
             break;
         case CUTIE_OP_USAGE_TICK:
-            hipLaunchKernelGGL(tick_kernel, GRID1D(i[0], BS), dim3(BS), 0, s, (float*)p[0], (long)i[0]);
+        {
+            const long nA = p[0] ? i[0] : 0, nB = p[1] ? i[1] : 0, nU = (p[2] && p[3]) ? i[2] : 0;
+            const long n = nA > nB ? (nA > nU ? nA : nU) : (nB > nU ? nB : nU);
+            if (n > 0)
+                hipLaunchKernelGGL(tick_kernel, GRID1D(n, BS), dim3(BS), 0, s, (float*)p[0], nA, (float*)p[1], nB, (float*)p[2], (const float*)p[3], nU);
+        }
             break;
         case CUTIE_OP_CAST:
             hipLaunchKernelGGL(cast_kernel, GRID1D(i[0], BS), dim3(BS), 0, s, (const void*)p[0], (void*)p[1], (long)i[0], op->flags & 1);

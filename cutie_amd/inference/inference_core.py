@@ -115,12 +115,11 @@ class InferenceCore:
         with torch.cuda.stream(enc):
             ms_features, pix_feat = self.network._encode_image_raw(prepared, *geometry)
             key, shrinkage, selection = self.network.transform_key(ms_features[0])
-            if affinity:
-                self.memory.prefetch_affinity(key, selection, self.network)
+            ro = self.memory.prefetch_affinity(key, selection, self.network) if affinity else None
             ev = torch.cuda.Event()
             ev.record(enc)
         feats = (ms_features, pix_feat, key, shrinkage, selection)
-        ahead = [r for r, _ in self.network._key_cache[1].get('_readouts', {}).values()]
+        ahead = [v[0] for v in (ro or {}).values()]
         for t in list(ms_features) + [pix_feat, key, shrinkage, selection] + ahead + list(self.network._key_cache[1].values()):
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(main)                          # allocated on the side stream, consumed on the main one
@@ -158,8 +157,13 @@ class InferenceCore:
     def clear_memory(self):
         self.curr_ti = -1
         self.last_mem_ti = 0
-        self.memory.check_overflow()
+        ovf = self.memory._scratch.get('overflow')              # (carried over: reported at the next step(end=True), no sync here)
         self.memory = MemoryManager(cfg=self.cfg, object_manager=self.object_manager)
+        if ovf is not None:
+            self.memory._scratch['overflow'] = ovf
+        if self._prefetched is not None:                        # a look-ahead of the old bank: order its buffers, drop it
+            torch.cuda.current_stream(self._prefetched[1].device).wait_event(self._prefetched[3])
+            self._prefetched = None
         if self._flip is not None:
             self._flip.clear_memory()
 

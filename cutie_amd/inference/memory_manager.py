@@ -10,6 +10,7 @@ Reference behaviour kept (with file:line):
   * object memory = streaming sum of the summaries (:252-271); sensory memory per object (:360-375)
 Per-object state lives in stacked tensors in tmp-id order (objects of one bucket are always contiguous there).
 """
+import itertools
 import logging
 import os
 from typing import Dict, List
@@ -25,6 +26,9 @@ BF16, F32 = torch.bfloat16, torch.float32
 CAND_CAP = 1024          # candidate slots per query column (typical fill ~35; see csrc/affinity.hip)
 _UNFUSED = os.environ.get('CUTIE_AMD_UNFUSED', '0') not in ('', '0')      # diagnostic A/B switch, see model/plans.py
 _VALIDATE = os.environ.get('CUTIE_AMD_VALIDATE', '0') not in ('', '0')
+# bank versions are drawn from one process-wide counter: a look-ahead read-out tagged with the version of one manager can never pass
+# the check of another (InferenceCore.clear_memory replaces the manager; per-manager counters would restart at 0 and collide)
+_VERSIONS = itertools.count(1)
 
 
 class MemoryManager:
@@ -54,7 +58,8 @@ class MemoryManager:
         self.config_stale = True
         self.engaged = False
         self.aux = None
-        self._version = 0            # bumped whenever the bank changes (invalidates look-ahead read-outs)
+        self._version = next(_VERSIONS)   # replaced whenever the bank changes (invalidates look-ahead read-outs)
+        self._ahead_parity = 0
 
     def _read_cfg(self, cfg):
         if self.use_long_term:
@@ -68,7 +73,7 @@ class MemoryManager:
 
     def update_config(self, cfg) -> None:
         self.config_stale = True
-        self._version += 1
+        self._version = next(_VERSIONS)
         self.top_k = cfg['top_k']
         assert self.use_long_term == cfg.use_long_term, 'cannot update this'
         assert self.count_long_term_usage == cfg.long_term.count_usage, 'cannot update this'
@@ -129,10 +134,14 @@ class MemoryManager:
 
     # ---- read (memory_manager.py:112-208) ---------------------------------------------------------------------
 
-    def _affinity(self, bucket: Bucket, q, h: int, w: int, dev, tag: str = '') -> torch.Tensor:
+    def _affinity(self, bucket: Bucket, q, h: int, w: int, dev, ahead: bool = False) -> torch.Tensor:
         """Affinity read-out of one bucket for the query operands q: similarity -> exact top-k -> softmax -> sparse value gather
-        (+ usage bookkeeping), 4 launches on the current stream.  Returns readout bf16 [K, h, w, CV].  `tag` selects a second set
-        of scratch buffers (the look-ahead lane of `prefetch_affinity` runs on another stream)."""
+        (+ usage bookkeeping), 4 launches on the current stream.  Returns readout bf16 [K, h, w, CV].
+        ahead (the look-ahead lane of `prefetch_affinity`, which runs on another stream, possibly for a frame that is never read): a
+        second set of scratch buffers, and NO bookkeeping on the bank -- the life counters are left alone and the usage of this read-out
+        is accumulated into a side buffer (cleared by the selection launch); `_commit_ahead` applies both on the caller's stream when,
+        and only when, the read-out is consumed."""
+        tag = '#ahead' if ahead else ''
         HW = h * w
         HWp = q['Bhi'].shape[0]
         K = len(bucket.objects)
@@ -153,9 +162,11 @@ class MemoryManager:
         # (host time matters once several clips share one interpreter).
         tick_work = self.use_long_term and bucket.n_work > 0
         tick_long = self.use_long_term and bucket.n_long > 0 and self.count_long_term_usage
+        nslots = int(bucket.use.shape[0]) if self.use_long_term else 0
         key = (tuple(ranges), K, HW, HWp, G, self.top_k, self.use_long_term, tick_work, tick_long, bucket.work_start,
-               bucket.n_work, bucket.n_long)
-        cached = getattr(bucket, '_aff_plan', None)
+               bucket.n_work, bucket.n_long, nslots)
+        plans_ = bucket.__dict__.setdefault('_aff_plans', {})
+        cached = plans_.get(ahead)
         if cached is None or cached[0] != key:
             D = O.Dyn
             ol = O.OpList()
@@ -164,11 +175,13 @@ class MemoryManager:
             # usage bookkeeping (kv_memory_store.py:151-162): life += 1 for every counted token -- rides on the selection launch,
             # as does the clearing of pass 1's candidate counters
             ticks = []
-            if tick_work:
+            if tick_work and not ahead:
                 ticks.append((D('life', 4 * bucket.work_start), bucket.n_work))
-            if tick_long:
+            if tick_long and not ahead:
                 ticks.append((D('life'), bucket.n_long))
-            if _UNFUSED:
+            if ahead and self.use_long_term:
+                ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), zero=(D('usage'), nslots))
+            elif _UNFUSED:
                 ol.memset32(D('count'), HW * O.OpList.AFF_CSTRIDE, 0)
                 ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k)
                 for life, n in ticks:
@@ -183,13 +196,34 @@ class MemoryManager:
                 # long_term.count_usage=False: the reference keeps no usage for long-term tokens (memory_manager.py:145-147);
                 # the read-out kernel accumulates usage for every slot, so the long-term part is cleared again
                 ol.memset32(D('usage'), bucket.n_long, 0)
-            bucket._aff_plan = cached = (key, ol)
+            plans_[ahead] = cached = (key, ol)
         dyn = dict(count=count, Ahi=bucket.Ahi, Alo=bucket.Alo, scale=bucket.scale, Bhi=q['Bhi'], Blo=q['Blo'], cq=q['cq'],
                    gmax=gmax, tau=tau, cval=cval, cidx=cidx, vptrs=bucket.vptrs(), readout=readout, ovf=ovf)
         if self.use_long_term:
-            dyn.update(life=bucket.life, usage=bucket.use)
+            if ahead:
+                # two side buffers, alternating: the next look-ahead (side stream) may start before the caller's stream has applied this one
+                self._ahead_parity ^= 1
+                udelta = self._buf(f'udelta{self._ahead_parity}#{bucket.id}', (nslots,), F32, dev)
+                dyn.update(life=bucket.life, usage=udelta)
+                self._last_udelta = udelta
+            else:
+                dyn.update(life=bucket.life, usage=bucket.use)
         cached[1].run(**dyn)
         return readout
+
+    def _commit_ahead(self, bucket: Bucket, udelta: torch.Tensor) -> None:
+        """Bookkeeping of a consumed look-ahead read-out, on the current (= the caller's) stream, one launch: the life counters of the
+        counted token ranges advance by one and the usage the read-out parked in its side buffer is added to the bank's
+        (kv_memory_store.py:151-162) -- exactly what `_affinity` does itself when it runs inside `read`."""
+        if not self.use_long_term:
+            return
+        tick_work = bucket.n_work > 0
+        tick_long = bucket.n_long > 0 and self.count_long_term_usage
+        ol = O.OpList()
+        ol.usage_tick(bucket.life[bucket.work_start:] if tick_work else None, bucket.n_work if tick_work else 0,
+                      bucket.life if tick_long else None, bucket.n_long if tick_long else 0,
+                      use=bucket.use, delta=udelta, n_use=int(udelta.shape[0]))
+        ol.run()
 
     def prefetch_affinity(self, query_key: torch.Tensor, selection: torch.Tensor, network) -> None:
         """Look-ahead lane (no counterpart in the reference): the affinity read-out of the NEXT frame depends only on that frame's
@@ -198,11 +232,16 @@ class MemoryManager:
         (`_version`).  Usage counters are updated here, exactly once (a later invalidation -- objects deleted between two steps --
         would count the frame's read twice; the reference's GUI path never deletes mid-propagation)."""
         if not self.engaged or self.CV is None:
-            return
+            return None
         q = network.query_operands(query_key, selection)
         h, w = q['h'], q['w']
         dev = q['Bhi'].device
-        q['_readouts'] = {bid: (self._affinity(b, q, h, w, dev, tag='#ahead'), self._version) for bid, b in self.buckets.items()}
+        out = {}
+        for bid, b in self.buckets.items():
+            r = self._affinity(b, q, h, w, dev, ahead=True)
+            out[bid] = (r, self._version, self._last_udelta if self.use_long_term else None)
+        q['_readouts'] = out
+        return out
 
     def read(self, pix_feat: torch.Tensor, query_key: torch.Tensor, selection: torch.Tensor, last_mask: torch.Tensor,
              network) -> Dict[int, torch.Tensor]:
@@ -216,6 +255,8 @@ class MemoryManager:
             pre = ahead.get(bucket.id)
             if pre is not None and pre[1] == self._version and pre[0].shape[0] == K:
                 readout = pre[0]                                        # computed ahead on the side stream (the caller has waited for it)
+                if pre[2] is not None:
+                    self._commit_ahead(bucket, pre[2])                  # its bookkeeping, now that it is used
             else:
                 readout = self._affinity(bucket, q, h, w, dev)
             # chunk_size > 0 (memory_manager.py:169-186): pixel fusion and the object transformer run per group of chunk_size
@@ -237,14 +278,14 @@ class MemoryManager:
                     all_readout[obj] = readout_memory[:, i]
                 chunks.append((objects, readout_memory))
                 if self.save_aux:
-                    self.aux = self._aux_output(this_sensory, pixel_readout, aux_features)
+                    self.aux = self._aux_output(this_sensory, pixel_readout, aux_features, Q=int(this_obj_mem.shape[3]))
             self._last_readout = chunks[0] if len(chunks) == 1 else (None, None)
         if _VALIDATE:
             self.check_overflow()
         return all_readout
 
     @staticmethod
-    def _aux_output(sensory, pixel_readout, aux_features) -> dict:
+    def _aux_output(sensory, pixel_readout, aux_features, Q: int = 16) -> dict:
         """cfg.save_aux (memory_manager.py:197-206): the intermediate tensors of the last object chunk, under the reference's keys.
         The reference itself cannot produce this dict in eval mode (it indexes aux_features['attn_mask'], which QueryTransformer
         only fills while training: KeyError on the first read -- tests/golden/edge_cases.json, save_aux_on_read), so this is the
@@ -260,7 +301,6 @@ class MemoryManager:
             pr = prob.clamp(1e-7, 1 - 1e-7)
             agg = torch.cat([torch.log(bg / (1 - bg)), torch.log(pr / (1 - pr))], 1)
             fg = agg[:, 1:] >= agg.max(dim=1, keepdim=True)[0]            # [1,K,h,w]
-            Q = 16
             m = torch.cat([(~fg).unsqueeze(2).expand(-1, -1, Q // 2, -1, -1), fg.unsqueeze(2).expand(-1, -1, Q // 2, -1, -1)], 2).clone()
             full = m.flatten(3).all(-1)                                   # a fully blocked row is un-blocked (:203)
             m[full] = False
@@ -296,7 +336,7 @@ class MemoryManager:
         # the default is the reference's (memory_manager.py:218) and just as unusable: its store asserts the same
         # (kv_memory_store.py:79); InferenceCore always passes 'no' / 'first' / 'all'
         assert as_permanent in ['no', 'first', 'all']
-        self._version += 1
+        self._version = next(_VERSIONS)
         bs = key.shape[0]
         assert bs == 1 and shrinkage.shape[0] == 1 and msk_value.shape[0] == 1
         self.engaged = True
@@ -477,7 +517,7 @@ class MemoryManager:
 
     # ---- object deletion / clearing ----------------------------------------------------------------------------------------
     def purge_except(self, obj_keep_idx: List[int]) -> None:
-        self._version += 1
+        self._version = next(_VERSIONS)
         keep = set(obj_keep_idx)
         for bid in list(self.buckets.keys()):
             b = self.buckets[bid]
@@ -505,7 +545,7 @@ class MemoryManager:
             self.engaged = False
 
     def clear_non_permanent_memory(self):
-        self._version += 1
+        self._version = next(_VERSIONS)
         for b in self.buckets.values():
             b.n_work = 0
             b.ring = 0

@@ -411,7 +411,12 @@ class CUTIE(nn.Module):
             P = eng.plan(('key', h, w), plans.build_transform_key, h, w)
             P.run(f16=f16, **{k: v for k, v in o.items() if k not in ('h', 'w')})
         key, shr, sel = self._key_views(o)
-        frame_context.remember('query', o['key'], o)     # the similarity operands of this key, found again by MemoryManager.read
+        # the similarity operands of this key, found again by MemoryManager.read: ONLY what the read-out needs (the whole encoder output
+        # would stay pinned -- ~40 MB per 480p frame -- for as long as the entry lives), and only the last few frames
+        qo = o.get('_qo')
+        if qo is None:
+            qo = o['_qo'] = dict(Bhi=o['Bhi'], Blo=o['Blo'], cq=o['cq'], h=o['h'], w=o['w'])
+        frame_context.remember('query', o['key'], qo, cap=4)
         return key, (shr if need_sk else None), (sel if need_ek else None)
 
     def query_operands(self, query_key: torch.Tensor, selection: torch.Tensor) -> dict:
@@ -433,7 +438,7 @@ class CUTIE(nn.Module):
         ol = O.OpList()
         ol.key_prep(kphys, ephys, o['Bhi'], o['Blo'], o['cq'], n=hw, query=True)
         ol.run()
-        frame_context.remember('query', query_key, o)
+        frame_context.remember('query', query_key, o, cap=4)
         return o
 
     @staticmethod

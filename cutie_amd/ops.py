@@ -65,7 +65,35 @@ DMA_TILES = {60: (128, 128, 64), 61: (128, 128, 64), 62: (128, 128, 64), 63: (12
 STRIP_TILES = {90: (128, 64, 64), 91: (64, 64, 64), 92: (128, 128, 64), 93: (64, 128, 64), 94: (128, 64, 64), 95: (64, 64, 64)}
 STRIP_WAVES = {90: 4, 91: 4, 92: 8, 93: 4, 94: 8, 95: 8}
 
-ALL_TILES = {**TILES, **DMA_TILES, **STRIP_TILES}
+# 100+: conv_pc.hip -- producer / consumer split (NPW producer waves issue every LDS-DMA piece, WM x WN consumer waves only read
+# fragments and issue MFMAs), epilogue straight from the accumulators.  100..: stream mode (any kernel size / stride);
+# 120..: halo mode, 3x3 / stride 1 / pad 1 with the (TH+2) x (TW+2) input patch of a 64-channel slice resident in LDS.
+# id -> (BM, BN, BK); PC_HALO: id -> (TH, TW)
+PC_TILES = {100: (64, 64, 64), 101: (64, 64, 64), 102: (32, 64, 64), 103: (128, 64, 64), 104: (64, 128, 64), 105: (128, 128, 64),
+            106: (128, 128, 64), 107: (64, 64, 64), 108: (128, 128, 64), 109: (32, 64, 64),
+            120: (64, 64, 64), 121: (64, 64, 64), 122: (128, 64, 64), 123: (128, 128, 64), 124: (64, 128, 64), 125: (32, 64, 64),
+            126: (128, 128, 64), 127: (64, 128, 64), 128: (256, 128, 64)}
+PC_HALO = {120: (8, 8), 121: (4, 16), 122: (8, 16), 123: (8, 16), 124: (8, 8), 125: (4, 8), 126: (8, 16), 127: (4, 16), 128: (16, 16)}
+
+ALL_TILES = {**TILES, **DMA_TILES, **STRIP_TILES, **PC_TILES}
+
+
+def pc_tile_ok(tile, *, cin, kh, stride=1, pad=None, c2=0):
+    """conv_pc_kernel eligibility (mirrors launch_pc in conv_pc.hip)."""
+    if cin % 64 or (c2 and (c2 % 64 or (cin - c2) % 64)) or kh > 5:
+        return False
+    if tile in PC_HALO:
+        return kh == 3 and stride == 1 and (pad is None or pad == 1)
+    return True
+
+
+def pc_blocks(tile, B, OH, OW, cout):
+    """Workgroups of a conv on a conv_pc tile."""
+    bm, bn, _ = PC_TILES[tile]
+    if tile in PC_HALO:
+        th, tw = PC_HALO[tile]
+        return B * -(-OH // th) * -(-OW // tw) * -(-cout // bn)
+    return -(-(B * OH * OW) // bm) * -(-cout // bn)
 
 
 def dma_tiles_enabled():
@@ -157,6 +185,11 @@ def tile_candidates(M, cout, cin, kpad=None, geom=None):
             if strip_tile_ok(t, cin=cin, kh=geom['kh'], stride=geom['stride'], pad=geom['pad'], W=geom['W'], c2=geom.get('c2', 0)) \
                     and not (bn == 128 and cout <= 64) and not (bm > 64 and bm > max(M, 64)):
                 out.append(t)
+    if dma_tiles_enabled() and geom is not None:
+        for t, (bm, bn, bk) in PC_TILES.items():
+            if pc_tile_ok(t, cin=cin, kh=geom['kh'], stride=geom.get('stride', 1), pad=geom.get('pad'), c2=geom.get('c2', 0)) \
+                    and not (bn == 128 and cout <= 64) and not (bm > 64 and bm > max(M, 64)) and not (bm == 256 and M < 16384):
+                out.append(t)
     if experimental_tiles_enabled() and geom is not None:
         for t, (bm, bn, bk) in EXPERIMENTAL_TILES.items():
             if bufload_tile_ok(t, cin=cin, kh=geom['kh'], c2=geom.get('c2', 0), kpad=kpad) and not (bn == 128 and cout <= 64) \
@@ -184,7 +217,7 @@ def splitk_scratch(device, owner=None):
 
 def splitk_candidates(M, cout, kpad, tile):
     """Split-K factors worth timing for a conv on a given tile: only when the plain grid leaves CUs idle."""
-    if tile == COUT1_TILE or tile == 3 or tile in PATCH_TILES or tile in EXPERIMENTAL_TILES or tile in DMA_TILES or tile in STRIP_TILES:
+    if tile == COUT1_TILE or tile == 3 or tile in PATCH_TILES or tile in EXPERIMENTAL_TILES or tile in DMA_TILES or tile in STRIP_TILES or tile in PC_TILES:
         return [1]
     bm, bn, bk = TILES[tile]
     blocks = -(-M // bm) * -(-cout // bn)
@@ -310,7 +343,7 @@ class OpList:
         if tile is None:
             tile = COUT1_TILE if (cout1_ok(w.cout, C1 + C2, C2, res is not None) and not side) else pick_tile(M, w.cout, C1 + C2, dict(kh=w.kh, c2=C2))
         if side:
-            assert (tile in DMA_TILES or tile in STRIP_TILES) and not out_f32 and w.cout % 8 == 0 and ldy % 8 == 0, 'GAP accumulation needs an LDS-DMA conv (see conv_side_jobs_ok)'
+            assert (tile in DMA_TILES or tile in STRIP_TILES or tile in PC_TILES) and not out_f32 and w.cout % 8 == 0 and ldy % 8 == 0, 'GAP accumulation needs an LDS-DMA conv (see conv_side_jobs_ok)'
         part = splitk_scratch(w.weight.device, self.scratch_owner)
         return self.add(CONV, flags,
                         [B, H, W, C1, C2, ldx1, ldx2, OH, OW, w.cout, ldy, w.kh, w.kw, stride, pad, ldr, w.kpad, tile, w.cin_real,
@@ -460,8 +493,12 @@ class OpList:
         ints += [G, cap, mode]
         return self.add(AFF_SCORE, 1 if (gmax_precedes_tau and mode == 1) else 0, ints, [], [Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count])
 
-    def aff_select(self, gmax, tau, *, HW, HWp, G, top_k, clear_count=None, ticks=()):
-        """clear_count: pass 1's candidate counters, zeroed here; ticks: up to two (life, n) ranges advanced by one (USAGE_TICK)."""
+    def aff_select(self, gmax, tau, *, HW, HWp, G, top_k, clear_count=None, ticks=(), zero=None):
+        """clear_count: pass 1's candidate counters, zeroed here; ticks: up to two (life, n) ranges advanced by one (USAGE_TICK);
+        zero = (buffer, n): f32 range cleared instead (excludes ticks: the usage side buffer of a look-ahead read-out)."""
+        if zero is not None:
+            assert not ticks
+            return self.add(AFF_SELECT, 1, [HW, HWp, G, top_k, zero[1], 0], [], [gmax, tau, clear_count, zero[0], None])
         ticks = list(ticks) + [(None, 0)] * (2 - len(ticks))
         assert len(ticks) == 2
         return self.add(AFF_SELECT, 0, [HW, HWp, G, top_k, ticks[0][1], ticks[1][1]], [], [gmax, tau, clear_count, ticks[0][0], ticks[1][0]])
@@ -479,8 +516,9 @@ class OpList:
     def axpy(self, x, y, *, n, a=1.0):
         return self.add(AXPY, 0, [n], [a], [x, y])
 
-    def usage_tick(self, life, n):
-        return self.add(USAGE_TICK, 0, [n], [], [life])
+    def usage_tick(self, life, n, life2=None, n2=0, use=None, delta=None, n_use=0):
+        """life[:n] += 1, life2[:n2] += 1, use[:n_use] += delta[:n_use] -- one launch (any part may be absent)."""
+        return self.add(USAGE_TICK, 0, [n, n2, n_use], [], [life, life2, use, delta])
 
     def rank_select(self, use, life, order, *, n, k):
         return self.add(RANK_SELECT, 0, [n, k], [], [use, life, order])

@@ -183,7 +183,8 @@ enum {
     /* AFF_SELECT: tau_j = top_k-th largest of gmax[:,j] (or -inf if G < top_k)
      * p0=gmax f32 [HWp,Gld] p1=tau f32 [HW]   i: 0 HW 1 HWp 2 G 3 top_k
      * optional side jobs (0 = none): p2=count i32 [HW*32]: count[32 q] = 0 for every query (pass 1's candidate counters);
-     *      p3=life f32 [i4], p4=life f32 [i5]: += 1 (USAGE_TICK of two token ranges) */
+     *      p3=life f32 [i4], p4=life f32 [i5]: += 1 (USAGE_TICK of two token ranges)
+     * flags&1: range p3 is CLEARED instead (the usage side buffer of a look-ahead read-out, see USAGE_TICK) */
     CUTIE_OP_AFF_SELECT = 25,
     /* AFF_READOUT: exact top-k of the candidates (ties -> lower slot), softmax, usage += w,
      * readout[o,j,:] = sum_i w_i V_o[i,:]    memory_utils.py:58-63,75; memory_manager.py:77-88
@@ -199,7 +200,9 @@ enum {
     /* AXPY: y[i] += a * x[i] (f32)  streaming object-memory sum, memory_manager.py:264-269
      * p0=x p1=y  i: 0 n  f: 0 a */
     CUTIE_OP_AXPY = 29,
-    /* USAGE_TICK: life[i] += 1 for i in [0,n)   kv_memory_store.py:161  p0=life  i: 0 n */
+    /* USAGE_TICK: life[i] += 1 for i in [0,n)   kv_memory_store.py:161  p0=life  i: 0 n
+     * optional (0 = none): p1=life2 f32 [i1]: += 1;  p2=use f32 [i2], p3=delta f32 [i2]: use += delta (the usage of a
+     * look-ahead read-out, accumulated into a side buffer by AFF_READOUT and applied when the read-out is consumed) */
     CUTIE_OP_USAGE_TICK = 30,
     /* RANK_SELECT: order[r] = index of the r-th largest of use/life (ties -> lower index), r < k
      * torch.topk(usage, k) of memory_manager.py:339 and kv_memory_store.py:222

@@ -500,7 +500,10 @@ class MockExecutor:
             view(p[2], I32, (HW, 32))[:, 0] = 0
         for slot, n in ((3, i[4]), (4, i[5])):
             if p[slot] and n > 0:
-                view(p[slot], F32, (n,)).add_(1.0)
+                if slot == 3 and (flags & 1):
+                    view(p[slot], F32, (n,)).zero_()                     # the usage side buffer of a look-ahead read-out
+                else:
+                    view(p[slot], F32, (n,)).add_(1.0)
         if G < k:
             tau.fill_(float('-inf'))
         else:
@@ -547,8 +550,12 @@ class MockExecutor:
         y += f[0] * view(p[0], F32, (n,))
 
     def _op_30(self, flags, i, f, p):
-        life = view(p[0], F32, (i[0],))
-        life += 1
+        if p[0] and i[0] > 0:
+            view(p[0], F32, (i[0],)).add_(1.0)
+        if p[1] and i[1] > 0:
+            view(p[1], F32, (i[1],)).add_(1.0)
+        if p[2] and p[3] and i[2] > 0:
+            view(p[2], F32, (i[2],)).add_(view(p[3], F32, (i[2],)))
 
     def _op_31(self, flags, i, f, p):
         n, k = i[:2]

@@ -197,6 +197,26 @@ def test_conv_strip_tiles(ci, tile):
     check(hip, ref, f'strip conv[{ci}] tile{tile}')
 
 
+PC_CASES = DMA_CASES + STRIP_CASES[3:5] + [STRIP_CASES[7]] + [
+    dict(B=2, H=13, W=37, C1=128, Cout=136, k=3, res=True, act=O.ACT_RELU),               # ragged patches in both directions, Cout % 8 == 0 but not % 32
+    dict(B=1, H=8, W=16, C1=64, Cout=64, k=3, relu_in=True),                              # exactly one 8 x 16 patch
+    dict(B=1, H=33, W=17, C1=192, Cout=100, k=3, out_f32=True, act=O.ACT_SQ1),            # three slices, ragged Cout (not % 4)
+    dict(B=3, H=30, W=54, C1=256, Cout=256, k=1, res=True, res_bcast=True, act=O.ACT_RELU),
+]
+
+
+@pytest.mark.parametrize('tile', sorted(O.PC_TILES))
+@pytest.mark.parametrize('ci', range(len(PC_CASES)))
+def test_conv_pc_tiles(ci, tile):
+    """conv_pc_kernel (tiles 100..: producer / consumer waves; 120..: 3x3 halo patch resident in LDS; epilogue straight from the
+    accumulators with the permuted weight-row fetch) against the interpreter."""
+    c = PC_CASES[ci]
+    if not O.pc_tile_ok(tile, cin=c['C1'] + c.get('C2', 0), kh=c['k'], stride=c.get('stride', 1), pad=c.get('pad', (c['k'] - 1) // 2), c2=c.get('C2', 0)):
+        pytest.skip('halo tiles: 3x3 / stride 1 / pad 1 only')
+    hip, ref = run_both(_conv_build(c, tile), seed=1100 + ci)
+    check(hip, ref, f'pc conv[{ci}] tile{tile}')
+
+
 PATCH_CASES = [
     dict(B=3, H=30, W=54, C1=256, Cout=256, k=3, relu_in=True, act=O.ACT_RELU),          # CAResBlock conv (480p, 3 objects)
     dict(B=1, H=30, W=54, C1=256, Cout=64, k=3, out_f32=True, act=O.ACT_SIGMOID),        # key projection e_proj
@@ -397,7 +417,7 @@ def test_gap_eca():
     check(hip, ref, 'gap/eca')
 
 
-@pytest.mark.parametrize('tile', [66, 67, 63, 61, 70, 68, 82, 85, 86, 90, 91, 92])
+@pytest.mark.parametrize('tile', [66, 67, 63, 61, 70, 68, 82, 85, 86, 90, 91, 92, 100, 102, 103, 105, 108, 120, 121, 123, 125, 128])
 @pytest.mark.parametrize('geo', [(3, 30, 54), (5, 5, 7), (2, 9, 16)])
 def test_conv_gap_accumulation(tile, geo):
     """ECA's average pool riding on the convs of a CAResBlock: conv1 clears the accumulator, conv2 adds the fixed-point channel sums of

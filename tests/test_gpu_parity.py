@@ -301,6 +301,46 @@ def test_lookahead_encoder_matches_plain_order(gpu_net):
     assert torch.equal(mixed, plain)
 
 
+def test_lookahead_keeps_long_term_bookkeeping(gpu_net):
+    """Long-term mode: the look-ahead affinity read-out runs on the side stream WITHOUT touching the bank's usage / life counters
+    (they are applied on the caller's stream when the read-out is consumed).  A clip that consolidates several times gives the same
+    counters, bank sizes and (to the order of the float atomics, which varies run to run anyway) probabilities with correct hints,
+    with wrong hints (the prefetched read-out is dropped, nothing may have been counted) and with no hints."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.utils.synth import SyntheticClip
+    clip = SyntheticClip(96, 160, 2, 40, seed=13)
+    n = 40
+    frames = torch.stack([clip.frame(t) for t in range(n)]).cuda()
+    decoy = torch.stack([clip.frame((t * 7 + 3) % n) for t in range(n)]).cuda()       # never passed to step()
+    mask = clip.first_mask().cuda()
+    cfg = default_config(use_long_term=True, mem_every=2, long_term=S.LT_SMALL)
+
+    def run(hint):
+        proc = InferenceCore(gpu_net, cfg=cfg)
+        outs = [proc.step(frames[0], mask, objects=clip.objects, next_image=hint(0))]
+        for t in range(1, n):
+            outs.append(proc.step(frames[t], next_image=hint(t)))
+        torch.cuda.synchronize()
+        b = next(iter(proc.memory.buckets.values()))
+        state = dict(n_long=b.n_long, n_work=b.n_work, n_perm=b.n_perm,
+                     life=b.life[:b.work_start + b.n_work].float().cpu().clone(), use=b.use[:b.work_start + b.n_work].float().cpu().clone())
+        return torch.stack(outs).cpu(), state
+
+    with torch.inference_mode():
+        plain, sp = run(lambda t: None)
+        piped, sq = run(lambda t: frames[t + 1] if t + 1 < n else None)
+        wrong, sw = run(lambda t: decoy[t])
+        mixed, sm = run(lambda t: decoy[t] if t % 3 == 0 else (frames[t + 1] if t + 1 < n and t % 3 == 1 else None))
+    assert sp['n_long'] > 0, 'the clip must consolidate'
+    for name, out, st in (('piped', piped, sq), ('wrong', wrong, sw), ('mixed', mixed, sm)):
+        assert (st['n_long'], st['n_work'], st['n_perm']) == (sp['n_long'], sp['n_work'], sp['n_perm']), name
+        # life counters of the live regions are integers + eps: exactly equal; usage sums float atomics: to rounding
+        lo, hi = 0, sp['n_long']
+        assert torch.equal(st['life'][lo:hi], sp['life'][lo:hi]), (name, 'long-term life')
+        assert torch.allclose(st['use'][lo:hi], sp['use'][lo:hi], rtol=1e-4, atol=1e-5), (name, 'long-term usage')
+        assert float((out - plain).abs().max()) < 1e-3, (name, float((out - plain).abs().max()))
+
+
 def test_concurrent_clips_match_sequential(gpu_net):
     """parallel.run_concurrent: 4 clips in flight on one GPU (host thread + HIP stream + CUTIE.fork() each) produce
     bit-identical probabilities to the same clips run one after another."""

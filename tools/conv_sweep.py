@@ -16,6 +16,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 
 
 def family(t, O):
+    if t in O.PC_HALO:
+        return 'halo'
+    if t in O.PC_TILES:
+        return 'pc'
+    if t in O.STRIP_TILES:
+        return 'strip'
     if t in O.DMA_TILES:
         return 'dma'
     if t in O.EXPERIMENTAL_TILES:
@@ -33,6 +39,7 @@ def main():
     ap.add_argument('--height', type=int, default=480)
     ap.add_argument('--width', type=int, default=854)
     ap.add_argument('--out', default='gpurun_out/conv_sweep')
+    ap.add_argument('--families', default='', help='comma list: time only tiles of these families (igemm,patch,bufload,dma,strip,pc,halo); default all')
     args = ap.parse_args()
     os.environ.setdefault('CUTIE_AMD_EXPERIMENTAL_TILES', '1')
     from bench import Recorder
@@ -80,6 +87,9 @@ def main():
         cands = O.tile_candidates(M, cout, cin, int(i[16]), geom=dict(kh=k, stride=int(i[13]), pad=int(i[14]), W=int(i[2]), c2=int(i[4])))
         if int(i[4]) or one['p'][0, 4]:
             cands = [t for t in cands if t != O.COUT1_TILE]
+        if args.families:
+            keep = set(args.families.split(','))
+            cands = [t for t in cands if family(t, O) in keep or t == int(i[17])]
         res = {}
         for t in cands:
             for sk in O.splitk_candidates(M, cout, int(i[16]), t):
@@ -104,7 +114,7 @@ def main():
     os.makedirs(os.path.dirname(args.out) or '.', exist_ok=True)
     json.dump(rows, open(args.out + '.json', 'w'))
     json.dump({'tiles': table}, open(args.out + '_tiles.json', 'w'))
-    fam = ['igemm', 'patch', 'bufload', 'dma']
+    fam = [f for f in ['igemm', 'patch', 'bufload', 'dma', 'strip', 'pc', 'halo'] if any(f in r['families'] for r in rows)]
     tot = {f: 0.0 for f in fam + ['best', 'old']}
     print(f'{"M":>6s} {"Cout":>5s} {"Cin":>5s} k s fl     HxW  n  GFLOP |' + ''.join(f' {f:>14s}' for f in fam) + ' |  best TFLOP/s')
     for r in sorted(rows, key=lambda r: -r['best'][2] * r['count']):
@@ -113,12 +123,12 @@ def main():
         for f in fam:
             v = r['families'].get(f)
             cells += f' {v[0]:3d}x{v[1]:<2d} {v[2]:7.1f}' if v else ' ' * 15
-        old = min(v[2] for f, v in r['families'].items() if f in ('igemm', 'patch'))
+        old = min([v[2] for f, v in r['families'].items() if f in ('igemm', 'patch', 'dma', 'strip')] or [r['best'][2]])
         tot['best'] += r['best'][2] * r['count']
         tot['old'] += old * r['count']
         print(f'{key[0]:6d} {key[1]:5d} {key[2]:5d} {key[3]} {key[4]} {key[5]} {key[6]:4d}x{key[7]:<4d} {r["count"]:2d} {r["gflop"]:6.2f} |{cells} | '
               f'{r["best"][0]:3d} {r["gflop"] / r["best"][2] * 1e3:7.1f}')
-    print(f'sum over the recorded frames: best-of-all {tot["best"]:.1f} us, best of igemm/patch {tot["old"]:.1f} us '
+    print(f'sum over the recorded frames: best-of-all {tot["best"]:.1f} us, best of the round-2 kernels (igemm/patch/dma/strip) {tot["old"]:.1f} us '
           f'({len(rows)} geometries, {sum(r["count"] for r in rows)} launches)')
 
 
