@@ -86,6 +86,19 @@ constexpr int conv_lds_bytes() {
     return pipe > epi ? pipe : epi;
 }
 
+// Every kernel argument this block will need, requested in ONE batch at kernel entry.  hipcc otherwise loads them where they are first used,
+// behind branches: three to four DEPENDENT scalar-memory round trips (cold scalar cache at kernel start: 400-800 cycles each) in the
+// prologue of every launch (profiles/r03_conv_timeline.md: 1.1-1.8 us from kernel entry to the first DMA).
+__device__ __forceinline__ void conv_preload_args(const ConvParams& p) {
+#ifndef CONV_NO_PRELOAD
+    // (one statement = one wait; 30 operands is the limit of an asm statement: x2 / gap / Kslice are loaded where the rarer paths use them)
+    asm volatile("" :: "s"(p.x1), "s"(p.w), "s"(p.bias), "s"(p.res), "s"(p.y), "s"(p.zero),
+                 "s"(p.B), "s"(p.H), "s"(p.W), "s"(p.C1), "s"(p.C2), "s"(p.ldx1), "s"(p.ldx2), "s"(p.OH), "s"(p.OW), "s"(p.Cout), "s"(p.ldy),
+                 "s"(p.KH), "s"(p.KW), "s"(p.stride), "s"(p.pad), "s"(p.ldr), "s"(p.Kpad), "s"(p.flags), "s"(p.M), "s"(p.Cin), "s"(p.OHW),
+                 "s"(p.nzero), "s"(gridDim.x), "s"(gridDim.y));
+#endif
+}
+
 // ---- optional timeline (diagnostic libraries only: make timeline, -DCONV_TIMELINE; tools/conv_timeline.py) ----
 // s_memtime stamps of every wave of a few blocks (logical tile 0, 1, nb/2, nb-1), parked in TL_BYTES of extra dynamic LDS behind the
 // kernel's own (one ds_write per stamp: no VMEM traffic that would disturb the counted vmcnt waits) and copied to the split-K

@@ -141,13 +141,15 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
     constexpr bool PRE_RES = TM * TNP <= 4;              // residual requested before the K loop
     static_assert(TM >= 1 && TN >= 1 && BM % (WM * 16) == 0 && BN % (WN * 16) == 0 && NWI >= 1 && NWI * 8 * NPW == BN && NS >= 2 && NS <= 8, "bad tile");
     static_assert(HALO || (NXI >= 1 && NXI * 8 * NPW == BM), "bad stream tile");
-    static_assert(!HALO || (BM % TW == 0 && NS == 3 && NXP <= 8), "bad halo tile");
+    static_assert(!HALO || (BM % TW == 0 && (NS == 3 || NS == 4) && NXP <= 10 - NS && NXP <= 8), "bad halo tile");
     extern __shared__ __attribute__((aligned(16))) u32x4 pc_smem[];
     char* const lds = reinterpret_cast<char*>(pc_smem);
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     TL_DECL(lds + pc_lds_bytes<BM, BN, NS, TW>(NPW))
     TL(0)
+    conv_preload_args(p);
+    TL(10)
     // XCD-aware tile order (N inner), bijective for any grid
     const int nb = gridDim.x * gridDim.y;
     int logical;
@@ -174,7 +176,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
 #ifdef PC_ABL_NO_LOOP
     const int nk = 0;
 #else
-    const int nk = HALO ? nslice * 9 : p.Kslice / 64;
+    const int nk = HALO ? nslice * 9 : p.KH * p.KW * nslice;
 #endif
 
     if (wave >= NC) {
@@ -189,6 +191,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
             woff[i] = (unsigned)((n0 + pc_wrow((pw * NWI + i) * 8 + lr, PAIR)) * p.Kpad * 2) + kcb + (HALO ? 0u : PRE - (unsigned)i * 1024u);
         const rsrc_t rw = pc_rsrc(reinterpret_cast<const char*>(p.w) - (HALO ? 0 : PRE));
         const int wdst = WBASE + (HALO ? 0 : BM * 128) + pw * NWI * 1024;
+        TL(11)
         if constexpr (!HALO) {
             unsigned xoff1[NXI], xoff2[NXI], vmask[NXI];
             {
@@ -262,16 +265,21 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
         }                                                                                                      \
     }
             static_assert(NXI <= 4 && NWI <= 4, "pieces per producer wave");
+            // Ring protocol (D = NS tiles of lead): iteration t issues tile t + NS into the stage of tile t (whose fragment reads -- issued by
+            // the consumers during iteration t - 1 -- have returned before barrier t - 1), then waits until tile t + 2 has landed: the
+            // consumers read the fragments of tile t + 1 during iteration t (while they multiply tile t), so tile t + 1 must be complete
+            // at barrier t - 1.
             int ld = 0;
             TL(1)
 #pragma unroll
-            for (int s = 0; s < NS - 1; ++s)
-                if (s < nk) { PCS_LOAD_TILE(ld) ld += STAGE; }
-            if (nk >= NS - 1) { PC_WAIT_VM((NS - 2) * LPT); } else { PC_WAIT_VM(0); }
+            for (int s = 0; s < NS; ++s)
+                if (s < nk) { PCS_LOAD_TILE(ld) ld = ld == (NS - 1) * STAGE ? 0 : ld + STAGE; }
+            if (nk >= NS) { PC_WAIT_VM((NS - 2) * LPT); } else { PC_WAIT_VM(0); }     // tiles 0 and 1 have landed
             TL(2)
             PC_BARRIER()
+            PC_BARRIER()                                 // the consumers have the fragments of tile 0 in registers: its stage is free
             int kt = 0;
-            for (; kt < nk - (NS - 1); ++kt) {
+            for (; kt < nk - NS; ++kt) {
                 TL(3)
                 PCS_LOAD_TILE(ld)
                 TL(4)
@@ -324,16 +332,23 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
 #pragma unroll
             for (int i = 0; i < NXP; ++i) PCH_XPIECE(i, 0)
 #pragma unroll
-            for (int s = 0; s < NS - 1; ++s)
+            for (int s = 0; s < NS; ++s)
                 if (s < nk) PCH_WTILE()
-            if (nk >= NS - 1) { PC_WAIT_VM((NS - 2) * NWI); } else { PC_WAIT_VM(0); }
+            if (nk >= NS) { PC_WAIT_VM((NS - 2) * NWI); } else { PC_WAIT_VM(0); }      // the patch of slice 0 and weight tiles 0, 1 have landed
             TL(2)
             PC_BARRIER()
+            PC_BARRIER()                                 // the consumers have the fragments of tile 0 in registers: its stage is free
+            // Patch pieces of the NEXT slice: one per K step during taps 0 .. NXP-1 of the current slice, issued BEFORE the step's weight
+            // tile.  The consumers start reading slice s + 1 in the last step of slice s, i.e. it must be complete at barrier 9 (s + 1) - 2,
+            // which the wait for weight tile 9 (s + 1) -- issued in step 9 (s + 1) - NS, after the last patch piece: NXP <= 10 - NS --
+            // implies (vmcnt retires in order).  The counted wait leaves the NS - 2 youngest weight tiles and the patch pieces of the
+            // last NS - 2 steps in flight.
             int sl = 0, tap = 0;
+            int xprev = 0;                               // patch piece issued in the previous step (NS == 4: it may still be in flight)
             int kt = 0;
-            for (; kt < nk - (NS - 1); ++kt) {
+            for (; kt < nk - NS; ++kt) {
                 TL(3)
-                const bool xp = sl + 1 < nslice && tap < NXP;                 // wave-uniform
+                const int xp = (sl + 1 < nslice && tap < NXP) ? 1 : 0;            // wave-uniform
                 if (xp) {
                     // slot `tap` of the next slice (a switch keeps the per-lane offsets in registers: no dynamic indexing)
                     switch (tap) {
@@ -349,9 +364,11 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
                 }
                 PCH_WTILE()
                 TL(4)
-                if (xp) { PC_WAIT_VM(NWI + 1); } else { PC_WAIT_VM(NWI); }
+                const int xin = NS == 3 ? xp : xp + xprev;                        // patch pieces younger than weight tile t + 2
+                if (xin == 0) { PC_WAIT_VM((NS - 2) * NWI); } else if (xin == 1) { PC_WAIT_VM((NS - 2) * NWI + 1); } else { PC_WAIT_VM((NS - 2) * NWI + 2); }
                 TL(5)
                 PC_BARRIER()
+                xprev = xp;
                 ++tap;
                 if (tap == 9) { tap = 0; ++sl; }
             }
@@ -389,6 +406,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
             xbase[b] = 0;
         }
     }
+    TL(11)
     // epilogue operands requested up front: bias of this lane's channels, residual (small tiles)
     const bool out_f32 = p.flags & CUTIE_F_OUT_F32;
     const bool vec_ok = (out_f32 ? (p.ldy & 3) == 0 : (p.ldy & (NCH - 1)) == 0) && (!p.res || (p.ldr & (NCH - 1)) == 0);
@@ -417,6 +435,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
                 }
             }
     }
+    TL(12)
     // fragment read offsets (bytes inside a stage / slice buffer)
     const int c0 = l4 << 4, c1 = (4 + l4) << 4;          // unswizzled chunk byte offsets of the two MFMA k-steps
     const int swl = (l15 & 7) << 4;
@@ -434,61 +453,70 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
 #else
 #define PC_MFMA(AF, BF, ACC) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF, BF, ACC, 0, 0, 0)
 #endif
-#define PC_RELU4(V) if (RELU) { V.x = pc_relu2(V.x); V.y = pc_relu2(V.y); V.z = pc_relu2(V.z); V.w = pc_relu2(V.w); }
-    TL(1)
-    PC_BARRIER()                                         // tile 0 (and the patch of slice 0) has landed
-    TL(2)
-    int rd = 0;                                          // ring stage of the tile being multiplied (byte offset)
-    int sl = 0, tap = 0, toff = 0;                       // halo: slice, tap, patch-pixel offset of the tap
-    for (int kt = 0; kt < nk; ++kt) {
-        TL(3)
-        bf16x8 xb0[TM], xb1[TM], wa0[TN], wa1[TN];
-        const char* const wst = lds + WBASE + rd + rdw0;
-#pragma unroll
-        for (int a = 0; a < TN; ++a) {
-            wa0[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wst + a * 2048 + (c0 ^ swl)));
-            wa1[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wst + a * 2048 + (c1 ^ swl)));
-        }
-        if (HALO) {
-            const char* const xs = lds + (sl & 1) * XBUF;
-#pragma unroll
-            for (int b = 0; b < TM; ++b) {
-                const int pp = xbase[b] + toff;
-                const int sw = (pp & 7) << 4;
-                u32x4 v0 = *reinterpret_cast<const u32x4*>(xs + pp * 128 + (c0 ^ sw));
-                u32x4 v1 = *reinterpret_cast<const u32x4*>(xs + pp * 128 + (c1 ^ sw));
-                PC_RELU4(v0) PC_RELU4(v1)
-                xb0[b] = __builtin_bit_cast(bf16x8, v0); xb1[b] = __builtin_bit_cast(bf16x8, v1);
-            }
-        } else {
-            const char* const xs = lds + rd + rdx0;
-#pragma unroll
-            for (int b = 0; b < TM; ++b) {
-                u32x4 v0 = *reinterpret_cast<const u32x4*>(xs + b * 2048 + (c0 ^ swl));
-                u32x4 v1 = *reinterpret_cast<const u32x4*>(xs + b * 2048 + (c1 ^ swl));
-                PC_RELU4(v0) PC_RELU4(v1)
-                xb0[b] = __builtin_bit_cast(bf16x8, v0); xb1[b] = __builtin_bit_cast(bf16x8, v1);
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < TN; ++a)
-#pragma unroll
-            for (int b = 0; b < TM; ++b) PC_MFMA(wa0[a], xb0[b], acc[a][b]);
-#pragma unroll
-        for (int a = 0; a < TN; ++a)
-#pragma unroll
-            for (int b = 0; b < TM; ++b) PC_MFMA(wa1[a], xb1[b], acc[a][b]);
-        TL(4)
-        PC_WAIT_LGKM0();
-        PC_BARRIER()
-        rd = rd == (NS - 1) * STAGE ? 0 : rd + STAGE;
-        if (HALO) {
-            ++tap;
-            const bool w3 = tap == 3 || tap == 6;
-            toff += w3 ? PW - 2 : 1;
-            if (tap == 9) { tap = 0; toff = 0; ++sl; }
-        }
+    // Fragment registers are double-buffered (sets A / B, the loop is unrolled by two): while the MFMAs of tile t run, the reads of
+    // tile t + 1 are in flight, so no LDS latency is exposed between the barrier and the first MFMA.  Read state = the tile whose
+    // fragments are requested NEXT: ring stage rd, and in halo mode (slice, tap) with the patch-pixel offset of the tap.
+    int rd = 0;
+    int sl = 0, tap = 0, toff = 0;
+    u32x4 xA0[TM], xA1[TM], xB0[TM], xB1[TM];
+    bf16x8 wA0[TN], wA1[TN], wB0[TN], wB1[TN];
+#define PC_READ(X0, X1, W0, W1)                                                                            \
+    {                                                                                                      \
+        const char* const wst = lds + WBASE + rd + rdw0;                                                   \
+        _Pragma("unroll") for (int a = 0; a < TN; ++a) {                                                   \
+            W0[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wst + a * 2048 + (c0 ^ swl))); \
+            W1[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wst + a * 2048 + (c1 ^ swl))); \
+        }                                                                                                  \
+        if (HALO) {                                                                                        \
+            const char* const xs = lds + (sl & 1) * XBUF;                                                  \
+            _Pragma("unroll") for (int b = 0; b < TM; ++b) {                                               \
+                const int pp = xbase[b] + toff;                                                            \
+                const int sw = (pp & 7) << 4;                                                              \
+                X0[b] = *reinterpret_cast<const u32x4*>(xs + pp * 128 + (c0 ^ sw));                        \
+                X1[b] = *reinterpret_cast<const u32x4*>(xs + pp * 128 + (c1 ^ sw));                        \
+            }                                                                                              \
+            ++tap;                                                                                         \
+            toff += (tap == 3 || tap == 6) ? PW - 2 : 1;                                                   \
+            if (tap == 9) { tap = 0; toff = 0; ++sl; }                                                     \
+        } else {                                                                                           \
+            const char* const xs = lds + rd + rdx0;                                                        \
+            _Pragma("unroll") for (int b = 0; b < TM; ++b) {                                               \
+                X0[b] = *reinterpret_cast<const u32x4*>(xs + b * 2048 + (c0 ^ swl));                       \
+                X1[b] = *reinterpret_cast<const u32x4*>(xs + b * 2048 + (c1 ^ swl));                       \
+            }                                                                                              \
+        }                                                                                                  \
+        rd = rd == (NS - 1) * STAGE ? 0 : rd + STAGE;                                                      \
     }
+#define PC_RELU4(V) { V.x = pc_relu2(V.x); V.y = pc_relu2(V.y); V.z = pc_relu2(V.z); V.w = pc_relu2(V.w); }
+    // one K step: (fused input ReLU on the fragments that have just arrived,) request the fragments of the next tile into the other
+    // set, multiply this one, meet the producers
+#define PC_STEP(X0, X1, W0, W1, NX0, NX1, NW0, NW1, MORE)                                                  \
+    {                                                                                                      \
+        TL(3)                                                                                              \
+        if (RELU) { _Pragma("unroll") for (int b = 0; b < TM; ++b) { PC_RELU4(X0[b]) PC_RELU4(X1[b]) } }   \
+        if (MORE) PC_READ(NX0, NX1, NW0, NW1)                                                              \
+        _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                     \
+            _Pragma("unroll") for (int b = 0; b < TM; ++b) PC_MFMA(W0[a], __builtin_bit_cast(bf16x8, X0[b]), acc[a][b]); \
+        _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                     \
+            _Pragma("unroll") for (int b = 0; b < TM; ++b) PC_MFMA(W1[a], __builtin_bit_cast(bf16x8, X1[b]), acc[a][b]); \
+        TL(4)                                                                                              \
+        PC_WAIT_LGKM0();                                                                                   \
+        PC_BARRIER()                                                                                       \
+    }
+    TL(1)
+    PC_BARRIER()                                         // tiles 0 and 1 (and the patch of slice 0) have landed
+    TL(2)
+    if (nk > 0) PC_READ(xA0, xA1, wA0, wA1)
+    PC_WAIT_LGKM0();
+    PC_BARRIER()                                         // (second prologue barrier: the producers may now overwrite the stage of tile 0)
+    int kt = 0;
+    for (; kt + 2 <= nk; kt += 2) {
+        PC_STEP(xA0, xA1, wA0, wA1, xB0, xB1, wB0, wB1, true)
+        PC_STEP(xB0, xB1, wB0, wB1, xA0, xA1, wA0, wA1, kt + 2 < nk)
+    }
+    if (kt < nk) PC_STEP(xA0, xA1, wA0, wA1, xB0, xB1, wB0, wB1, false)
+#undef PC_STEP
+#undef PC_READ
     TLE(5)
 #ifdef PC_ABL_NO_EPILOGUE
     if (acc[0][0][0] != 12345.678f) { TL_DUMP(logical, nb, NC + NPW) return; }
@@ -509,6 +537,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
 #pragma unroll
             for (int r = 0; r < NCH; ++r) st[r] = 0.f;
             if (live) pc_finish<NCH>(p, v, mrow[b], ch0, vec_ok, have_res && ch0 + NCH <= p.Cout, rpre[PRE_RES ? b : 0][PRE_RES ? a : 0], st);
+            TLE(20 + b * TNP + a)
             if (p.gap) {
                 // column sums of the stored values over the fragment's 16 pixels.  One object per fragment (always in halo mode):
                 // lane shuffles, then 8 atomics from the l15 == 0 lane of each channel group; a fragment that straddles two

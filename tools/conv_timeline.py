@@ -89,9 +89,11 @@ def main():
                 for wv, v in sorted(waves.items()):
                     st = v['stamps']
                     seg = segments(st)
-                    first = ' '.join(f'{i}@{t - t0}' for i, t in st[:3])
+                    nfirst = next((q for q, (i, _) in enumerate(st) if i == 3), 3)
+                    first = ' '.join(f'{i}@{t - t0}' for i, t in st[:nfirst])
                     loop = ' '.join(f'{a}>{b}:{m:.0f}x{n}' for (a, b), (m, n) in sorted(seg.items()) if n > 1)
-                    tail = ' '.join(f'{i}@{t - t0}' for i, t in st[-3:])
+                    nl = max(q for q, (i, _) in enumerate(st) if i in (3, 4, 5)) if any(i in (3, 4, 5) for i, _ in st) else 0
+                    tail = ' '.join(f'{i}@{t - t0}' for i, t in st[nl:])
                     print(f'    wave {wv:2d}: {first} | {loop} | {tail}')
 
 
