@@ -32,7 +32,25 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 // s_waitcnt with only one counter constrained (gfx9 encoding: vmcnt = simm16[3:0] | simm16[15:14] << 4, expcnt [6:4], lgkmcnt [11:8])
 #define PC_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (((N) >> 4) << 14) | (7 << 4) | (15 << 8))
 #define PC_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(15 | (3 << 14) | (7 << 4) | (0 << 8))
+// Ablation switches (diagnostic libraries of tools/build_diag.sh only; results are garbage with any of them): PC_ABL_NO_DMA, _NO_MFMA,
+// _NO_READ (no fragment reads), _SAME_TILE (every K step fetches the operands of step 0: L2-hot), _NO_LOOPBAR (no barrier inside the K
+// loop), _NO_WAIT (no counted vmcnt wait inside the K loop), _NO_LOOP, _NO_EPILOGUE
 #define PC_BARRIER() { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+#ifdef PC_ABL_NO_LOOPBAR
+#define PC_LOOP_BARRIER() { asm volatile("" ::: "memory"); }
+#else
+#define PC_LOOP_BARRIER() PC_BARRIER()
+#endif
+#ifdef PC_ABL_NO_WAIT
+#define PC_LOOP_WAIT_VM(N) ((void)0)
+#else
+#define PC_LOOP_WAIT_VM(N) PC_WAIT_VM(N)
+#endif
+#ifdef PC_ABL_SAME_TILE
+#define PC_SAME_TILE_GUARD(...)
+#else
+#define PC_SAME_TILE_GUARD(...) __VA_ARGS__
+#endif
 #ifdef PC_ABL_NO_DMA
 #define PC_DMA(...) ((void)0)
 #else
@@ -55,10 +73,11 @@ __device__ __forceinline__ int pc_wrow(int R, bool pair) {
     return (R & ~31) | ((ii >> 2) << 3) | (alo << 2) | (ii & 3);
 }
 
-template <int BM, int BN, int NS, int TW>
+#define PC_HT(TH, TW) ((TH) * 256 + (TW))              // halo tile TH x TW output pixels (<= BM) as one template argument; 0 = stream mode
+template <int BM, int BN, int NS, int HT>
 constexpr int pc_lds_bytes(int NPW) {
-    if (TW == 0) return NS * (BM + BN) * 128;
-    const int TH = BM / TW, npiece = ((TH + 2) * (TW + 2) + 7) / 8, nxp = (npiece + NPW - 1) / NPW;
+    if (HT == 0) return NS * (BM + BN) * 128;
+    const int TH = HT >> 8, TW = HT & 255, npiece = ((TH + 2) * (TW + 2) + 7) / 8, nxp = (npiece + NPW - 1) / NPW;
     return 2 * nxp * NPW * 1024 + NS * BN * 128;
 }
 
@@ -66,6 +85,19 @@ constexpr int pc_lds_bytes(int NPW) {
 template <int NCH>
 __device__ __forceinline__ void pc_finish(const ConvParams& p, float (&v)[NCH], int m, int ch0, bool vec_ok, bool have_res,
                                           const unsigned (&rpre)[NCH / 2], float (&stored)[NCH]) {
+#ifdef PC_ABL_FIXED_EPI                                    // (diagnostic: the epilogue of ONE configuration -- relu, bf16, no residual -- only)
+    {
+#pragma unroll
+        for (int r = 0; r < NCH; ++r) v[r] = fmaxf(v[r], 0.f);
+        bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + (long)m * p.ldy + ch0;
+        unsigned o[NCH / 2];
+#pragma unroll
+        for (int r = 0; r < NCH / 2; ++r) o[r] = pack_bf2(v[2 * r], v[2 * r + 1]);
+        if constexpr (NCH == 8) *reinterpret_cast<uint4*>(yp) = make_uint4(o[0], o[1], o[NCH / 2 - 2], o[NCH / 2 - 1]);
+        else *reinterpret_cast<uint2*>(yp) = make_uint2(o[0], o[1]);
+        return;
+    }
+#endif
     const int act = (p.flags >> CUTIE_ACT_SHIFT) & 7;
     const bool out_f32 = p.flags & CUTIE_F_OUT_F32;
     const bool full = ch0 + NCH <= p.Cout;
@@ -122,11 +154,88 @@ __device__ __forceinline__ void pc_finish(const ConvParams& p, float (&v)[NCH], 
     }
 }
 
-// TW == 0: stream mode (TAPS: more than one tap and / or padding); TW > 0: halo mode (TAPS ignored)
-template <int BM, int BN, int WM, int WN, int NPW, int NS, int TW, bool TAPS, bool RELU, bool TWO>
+// integer division by a positive runtime divisor on the float pipe (0 <= m < 2^23; rd = 1 / d to an ulp): ~8 instructions instead of the
+// ~35 of the exact 32-bit sequence -- the prologue is cold code, every instruction of it costs (profiles/r03_conv_ablation.md)
+__device__ __forceinline__ int pc_div(int m, int d, float rd) {
+    int q = (int)((float)m * rd);
+    int r = m - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
+
+// Fast epilogue of the common configurations, chosen ONCE per block by wave-uniform tests: whole tile inside Cout, aligned strides, no
+// GAP side job, activation none / relu.  Straight-line code per configuration -- the generic slice code (pc_finish) re-tests activation,
+// output type, residual kind and raggedness per element; measured on the 64x64 tile: 2.0 us of epilogue against 1.1 us
+// (profiles/r03_conv_ablation.md), most of it instruction fetch of code that is executed once per block.
+template <int NCH, int TM, int TNP, bool PAIR, bool RELU_OUT, bool F32, bool RES, bool PRE>
+__device__ __forceinline__ void pc_epilogue_fast(const ConvParams& p, const f32x4 (&acc)[PAIR ? 2 * TNP : TNP][TM], const float (&bias)[TNP][NCH],
+                                                 const int (&mrow)[TM], const bool (&mval)[TM], int chbase,
+                                                 const unsigned (&rpre)[PRE ? TM : 1][PRE ? TNP : 1][NCH / 2]) {
+    unsigned rr[TM][TNP][NCH / 2];
+    if (RES && !PRE) {                                   // all residual loads first: one exposed latency, not one per slice
+        const bool bc = p.flags & CUTIE_F_RES_BCAST;
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const int mres = bc ? mrow[b] - pc_div(mrow[b], p.OHW, __builtin_amdgcn_rcpf((float)p.OHW)) * p.OHW : mrow[b];
+#pragma unroll
+            for (int a = 0; a < TNP; ++a) {
+                const bf16_t* rp = p.res + (long)mres * p.ldr + chbase + a * (PAIR ? 32 : 16);
+#pragma unroll
+                for (int r = 0; r < NCH / 2; ++r) rr[b][a][r] = 0u;
+                if (mval[b]) {
+                    if constexpr (NCH == 8) { const uint4 t = *reinterpret_cast<const uint4*>(rp); rr[b][a][0] = t.x; rr[b][a][1] = t.y; rr[b][a][NCH / 2 - 2] = t.z; rr[b][a][NCH / 2 - 1] = t.w; }
+                    else { const uint2 t = *reinterpret_cast<const uint2*>(rp); rr[b][a][0] = t.x; rr[b][a][1] = t.y; }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+#pragma unroll
+        for (int a = 0; a < TNP; ++a) {
+            float v[NCH];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[PAIR ? 2 * a : a][b][r] + bias[a][r];
+                if (PAIR) v[(NCH - 4) + r] = acc[PAIR ? 2 * a + 1 : a][b][r] + bias[a][(NCH - 4) + r];
+            }
+            if (RES) {
+#pragma unroll
+                for (int r = 0; r < NCH / 2; ++r) {
+                    const unsigned w = PRE ? rpre[PRE ? b : 0][PRE ? a : 0][r] : rr[b][a][r];
+                    v[2 * r] += __uint_as_float(w << 16); v[2 * r + 1] += __uint_as_float(w & 0xffff0000u);
+                }
+            }
+            if (RELU_OUT) {
+#pragma unroll
+                for (int r = 0; r < NCH; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (mval[b]) {
+                const long off = (long)mrow[b] * p.ldy + chbase + a * (PAIR ? 32 : 16);
+                if (F32) {
+                    float* yp = reinterpret_cast<float*>(p.y) + off;
+#pragma unroll
+                    for (int r = 0; r < NCH; r += 4) *reinterpret_cast<float4*>(yp + r) = make_float4(v[r], v[r + 1], v[r + 2], v[r + 3]);
+                } else {
+                    bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + off;
+                    unsigned o[NCH / 2];
+#pragma unroll
+                    for (int r = 0; r < NCH / 2; ++r) o[r] = pack_bf2(v[2 * r], v[2 * r + 1]);
+                    if constexpr (NCH == 8) *reinterpret_cast<uint4*>(yp) = make_uint4(o[0], o[1], o[NCH / 2 - 2], o[NCH / 2 - 1]);
+                    else *reinterpret_cast<uint2*>(yp) = make_uint2(o[0], o[1]);
+                }
+            }
+        }
+    }
+}
+
+// HT == 0: stream mode (TAPS: more than one tap and / or padding); HT = PC_HT(TH, TW): halo mode (TAPS ignored)
+template <int BM, int BN, int WM, int WN, int NPW, int NS, int HT, bool TAPS, bool RELU, bool TWO>
 __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParams p) {
 #if __HIP_DEVICE_COMPILE__
-    constexpr bool HALO = TW > 0;
+    constexpr bool HALO = HT > 0;
+    constexpr int TH = HALO ? (HT >> 8) : 1, TW = HALO ? (HT & 255) : 1;
     constexpr int NC = WM * WN, NTC = NC * 64;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr bool PAIR = (TN % 2) == 0;
@@ -134,19 +243,19 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
     constexpr int NXI = HALO ? 1 : BM / 8 / NPW;         // stream: X pieces per producer wave per K tile
     constexpr int NWI = BN / 8 / NPW;                    // W pieces per producer wave per K tile
     constexpr int LPT = HALO ? NWI : NXI + NWI;
-    constexpr int TH = HALO ? BM / (HALO ? TW : 1) : 1, PH = TH + 2, PW = TW + 2;
+    constexpr int PH = TH + 2, PW = TW + 2;
     constexpr int NPIECE = (PH * PW + 7) / 8, NXP = (NPIECE + NPW - 1) / NPW, XBUF = NXP * NPW * 1024;
     constexpr int WSTAGE = BN * 128, STAGE = HALO ? WSTAGE : (BM + BN) * 128;
     constexpr int WBASE = HALO ? 2 * XBUF : 0;           // halo: [X slice buffer 0 | 1 | W ring]; stream: ring of [X | W] stages
     constexpr bool PRE_RES = TM * TNP <= 4;              // residual requested before the K loop
     static_assert(TM >= 1 && TN >= 1 && BM % (WM * 16) == 0 && BN % (WN * 16) == 0 && NWI >= 1 && NWI * 8 * NPW == BN && NS >= 2 && NS <= 8, "bad tile");
     static_assert(HALO || (NXI >= 1 && NXI * 8 * NPW == BM), "bad stream tile");
-    static_assert(!HALO || (BM % TW == 0 && (NS == 3 || NS == 4) && NXP <= 10 - NS && NXP <= 8), "bad halo tile");
+    static_assert(!HALO || (TH * TW <= BM && TH * TW > BM - 16 * WM && (NS == 3 || NS == 4) && NXP <= 11 - NS && NXP <= 8), "bad halo tile");
     extern __shared__ __attribute__((aligned(16))) u32x4 pc_smem[];
     char* const lds = reinterpret_cast<char*>(pc_smem);
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    TL_DECL(lds + pc_lds_bytes<BM, BN, NS, TW>(NPW))
+    TL_DECL(lds + pc_lds_bytes<BM, BN, NS, HT>(NPW))
     TL(0)
     conv_preload_args(p);
     TL(10)
@@ -193,18 +302,33 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
         const int wdst = WBASE + (HALO ? 0 : BM * 128) + pw * NWI * 1024;
         TL(11)
         if constexpr (!HALO) {
+            // the weight tiles of the first NS stages go out BEFORE the pixel offsets are computed (they need nothing but woff)
+            const int cin2 = p.Cin * 2, c12 = p.C1 * 2;
+            unsigned wsoff = 0;
+            int ldw = 0;
+#define PCS_WPIECE(I, LD)                                                                                      \
+    if constexpr ((I) < NWI) PC_DMA(rw, LDS_PTR(lds + (LD) + wdst), 16, woff[(I) < NWI ? (I) : 0], wsoff, (I) * 1024, 0);
+#define PCS_LOAD_W(LD) { PCS_WPIECE(0, LD) PCS_WPIECE(1, LD) PCS_WPIECE(2, LD) PCS_WPIECE(3, LD) PC_SAME_TILE_GUARD(wsoff += 128;) }
+            TL(1)
+#pragma unroll
+            for (int s = 0; s < NS - 1; ++s)
+                if (s < nk) { PCS_LOAD_W(ldw) ldw += STAGE; }
             unsigned xoff1[NXI], xoff2[NXI], vmask[NXI];
             {
                 int m = m0 + pw * NXI * 8 + lr;
                 const int mm = m < p.M ? m : p.M - 1;    // rows past the end recompute the last pixel (never stored)
-                int b = mm / p.OHW;
-                const int rem = mm - b * p.OHW;
-                int oh = rem / p.OW;
-                int ow = rem - oh * p.OW;
+                const bool linear = !TAPS && p.stride == 1;                     // 1x1 / stride 1: pixel index = row index, no divisions
+                int b = 0, oh = 0, ow = mm;
+                if (!linear) {
+                    b = pc_div(mm, p.OHW, __builtin_amdgcn_rcpf((float)p.OHW));
+                    const int rem = mm - b * p.OHW;
+                    oh = pc_div(rem, p.OW, __builtin_amdgcn_rcpf((float)p.OW));
+                    ow = rem - oh * p.OW;
+                }
 #pragma unroll
                 for (int i = 0; i < NXI; ++i) {
                     const int ih0 = oh * p.stride, iw0 = ow * p.stride;
-                    const unsigned pix = (unsigned)((b * p.H + ih0) * p.W + iw0);
+                    const unsigned pix = linear ? (unsigned)min(mm + 8 * i, p.M - 1) : (unsigned)((b * p.H + ih0) * p.W + iw0);
                     xoff1[i] = pix * (unsigned)(p.ldx1 * 2) + kcb + PRE - (unsigned)i * 1024u;
                     xoff2[i] = TWO ? pix * (unsigned)(p.ldx2 * 2) + kcb + PRE - (unsigned)i * 1024u : 0u;
                     unsigned mk = 0;
@@ -214,7 +338,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
                         for (int k = 0; k < p.KH; ++k) mk |= ((unsigned)(ih0 - p.pad + k) < (unsigned)p.H) ? (cols << (k * p.KW)) : 0u;
                     }
                     vmask[i] = mk;
-                    if (i + 1 < NXI) {
+                    if (i + 1 < NXI && !linear) {
                         m += 8;
                         if (m < p.M) {
                             ow += 8;
@@ -230,8 +354,6 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
             const rsrc_t rx1 = pc_rsrc(xb1), rx2 = pc_rsrc(xb2);
             const int xdst = pw * NXI * 1024;
             int tap = 0, kw = 0, cc = 0, pixA = 0, pixB = 0;
-            unsigned wsoff = 0;
-            const int cin2 = p.Cin * 2, c12 = p.C1 * 2;
             const int stepA1 = p.ldx1 * 2, stepA2 = (p.W - p.KW + 1) * p.ldx1 * 2;
             const int stepB1 = p.ldx2 * 2, stepB2 = (p.W - p.KW + 1) * p.ldx2 * 2;
 #define PCS_XPIECE(I, LD)                                                                                      \
@@ -239,18 +361,14 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
         const unsigned v_ = in1_ ? xoff1[(I) < NXI ? (I) : 0] : xoff2[(I) < NXI ? (I) : 0];                   \
         PC_DMA(rx_, LDS_PTR(lds + (LD) + xdst), 16, (!TAPS || (vmask[(I) < NXI ? (I) : 0] & tapbit_)) ? v_ : PC_OOB, soff_, (I) * 1024, 0); \
     }
-#define PCS_WPIECE(I, LD)                                                                                      \
-    if constexpr ((I) < NWI) PC_DMA(rw, LDS_PTR(lds + (LD) + wdst), 16, woff[(I) < NWI ? (I) : 0], wsoff, (I) * 1024, 0);
-#define PCS_LOAD_TILE(LD)                                                                                      \
+#define PCS_LOAD_X(LD)                                                                                         \
     {                                                                                                          \
         const unsigned tapbit_ = 1u << tap;                                                                    \
         const bool in1_ = !TWO || cc < c12;                                                                    \
         const unsigned soff_ = (unsigned)(in1_ ? pixA + cc : pixB + cc - c12);                                 \
         const rsrc_t rx_ = in1_ ? rx1 : rx2;                                                                   \
         PCS_XPIECE(0, LD) PCS_XPIECE(1, LD) PCS_XPIECE(2, LD) PCS_XPIECE(3, LD)                                \
-        PCS_WPIECE(0, LD) PCS_WPIECE(1, LD) PCS_WPIECE(2, LD) PCS_WPIECE(3, LD)                                \
-        wsoff += 128;                                                                                          \
-        cc += 128;                                                                                             \
+        PC_SAME_TILE_GUARD(cc += 128;)                                                                         \
         if (TAPS || TWO) {                                                                                     \
             const bool wrap_ = cc >= cin2;                                                                     \
             cc = wrap_ ? 0 : cc;                                                                               \
@@ -264,35 +382,35 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
             }                                                                                                  \
         }                                                                                                      \
     }
+#define PCS_LOAD_TILE(LD) { PCS_LOAD_X(LD) PCS_LOAD_W(LD) }
             static_assert(NXI <= 4 && NWI <= 4, "pieces per producer wave");
-            // Ring protocol (D = NS tiles of lead): iteration t issues tile t + NS into the stage of tile t (whose fragment reads -- issued by
-            // the consumers during iteration t - 1 -- have returned before barrier t - 1), then waits until tile t + 2 has landed: the
-            // consumers read the fragments of tile t + 1 during iteration t (while they multiply tile t), so tile t + 1 must be complete
-            // at barrier t - 1.
+            // Ring protocol: iteration t issues tile t + NS - 1 into the stage of tile t - 1 (read during iteration t - 1: every consumer
+            // has passed barrier t - 1 with its reads returned), then waits until tile t + 1 has landed.
             int ld = 0;
-            TL(1)
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-                if (s < nk) { PCS_LOAD_TILE(ld) ld = ld == (NS - 1) * STAGE ? 0 : ld + STAGE; }
-            if (nk >= NS) { PC_WAIT_VM((NS - 2) * LPT); } else { PC_WAIT_VM(0); }     // tiles 0 and 1 have landed
+            for (int s = 0; s < NS - 1; ++s)
+                if (s < nk) { PCS_LOAD_X(ld) ld += STAGE; }
+            // (queue order: W(0 .. NS-2), X(0 .. NS-2): tile 0 is complete once only the X pieces of tiles 1.. are outstanding)
+            if (nk >= NS - 1) { PC_WAIT_VM((NS - 2) * NXI); } else { PC_WAIT_VM(0); }
             TL(2)
             PC_BARRIER()
-            PC_BARRIER()                                 // the consumers have the fragments of tile 0 in registers: its stage is free
             int kt = 0;
-            for (; kt < nk - NS; ++kt) {
+            for (; kt < nk - (NS - 1); ++kt) {
                 TL(3)
                 PCS_LOAD_TILE(ld)
                 TL(4)
-                PC_WAIT_VM((NS - 2) * LPT);
+                PC_LOOP_WAIT_VM((NS - 2) * LPT);
                 TL(5)
-                PC_BARRIER()
+                PC_LOOP_BARRIER()
                 ld = ld == (NS - 1) * STAGE ? 0 : ld + STAGE;
             }
             for (; kt < nk; ++kt) {
                 PC_WAIT_VM(0);
-                PC_BARRIER()
+                PC_LOOP_BARRIER()
             }
 #undef PCS_LOAD_TILE
+#undef PCS_LOAD_X
+#undef PCS_LOAD_W
 #undef PCS_WPIECE
 #undef PCS_XPIECE
         } else {
@@ -325,28 +443,26 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
     {                                                                                                          \
         _Pragma("unroll") for (int i = 0; i < NWI; ++i) PC_DMA(rw, LDS_PTR(lds + wld + wdst + i * 1024), 16, woff[i], wso, 0, 0); \
         wld = wld == (NS - 1) * WSTAGE ? 0 : wld + WSTAGE;                                                     \
-        ++wtap; wso += (unsigned)cin2;                                                                         \
-        if (wtap == 9) { wtap = 0; ++wsl; wso = (unsigned)(wsl * 128); }                                       \
+        ++wtap; PC_SAME_TILE_GUARD(wso += (unsigned)cin2;)                                                     \
+        if (wtap == 9) { wtap = 0; ++wsl; PC_SAME_TILE_GUARD(wso = (unsigned)(wsl * 128);) }                                       \
     }
             TL(1)
 #pragma unroll
-            for (int i = 0; i < NXP; ++i) PCH_XPIECE(i, 0)
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
+            for (int s = 0; s < NS - 1; ++s)
                 if (s < nk) PCH_WTILE()
-            if (nk >= NS) { PC_WAIT_VM((NS - 2) * NWI); } else { PC_WAIT_VM(0); }      // the patch of slice 0 and weight tiles 0, 1 have landed
+#pragma unroll
+            for (int i = 0; i < NXP; ++i) PCH_XPIECE(i, 0)
+            PC_WAIT_VM(0);                               // the patch of slice 0 is the youngest request: everything has landed
             TL(2)
             PC_BARRIER()
-            PC_BARRIER()                                 // the consumers have the fragments of tile 0 in registers: its stage is free
             // Patch pieces of the NEXT slice: one per K step during taps 0 .. NXP-1 of the current slice, issued BEFORE the step's weight
-            // tile.  The consumers start reading slice s + 1 in the last step of slice s, i.e. it must be complete at barrier 9 (s + 1) - 2,
-            // which the wait for weight tile 9 (s + 1) -- issued in step 9 (s + 1) - NS, after the last patch piece: NXP <= 10 - NS --
-            // implies (vmcnt retires in order).  The counted wait leaves the NS - 2 youngest weight tiles and the patch pieces of the
-            // last NS - 2 steps in flight.
+            // tile; they are older than weight tile 9 (s + 1) (issued in step 9 (s + 1) - (NS - 1): NXP <= 11 - NS), whose counted wait
+            // -- before barrier 9 (s + 1) - 1 -- therefore covers them.  The wait of step t leaves the NS - 2 youngest weight tiles and the
+            // patch pieces issued in steps t - (NS - 3) .. t in flight.
             int sl = 0, tap = 0;
             int xprev = 0;                               // patch piece issued in the previous step (NS == 4: it may still be in flight)
             int kt = 0;
-            for (; kt < nk - NS; ++kt) {
+            for (; kt < nk - (NS - 1); ++kt) {
                 TL(3)
                 const int xp = (sl + 1 < nslice && tap < NXP) ? 1 : 0;            // wave-uniform
                 if (xp) {
@@ -364,17 +480,17 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
                 }
                 PCH_WTILE()
                 TL(4)
-                const int xin = NS == 3 ? xp : xp + xprev;                        // patch pieces younger than weight tile t + 2
-                if (xin == 0) { PC_WAIT_VM((NS - 2) * NWI); } else if (xin == 1) { PC_WAIT_VM((NS - 2) * NWI + 1); } else { PC_WAIT_VM((NS - 2) * NWI + 2); }
+                const int xin = NS == 3 ? xp : xp + xprev;                        // patch pieces younger than weight tile t + 1
+                if (xin == 0) { PC_LOOP_WAIT_VM((NS - 2) * NWI); } else if (xin == 1) { PC_LOOP_WAIT_VM((NS - 2) * NWI + 1); } else { PC_LOOP_WAIT_VM((NS - 2) * NWI + 2); }
                 TL(5)
-                PC_BARRIER()
+                PC_LOOP_BARRIER()
                 xprev = xp;
                 ++tap;
                 if (tap == 9) { tap = 0; ++sl; }
             }
             for (; kt < nk; ++kt) {
                 PC_WAIT_VM(0);
-                PC_BARRIER()
+                PC_LOOP_BARRIER()
             }
 #undef PCH_WTILE
 #undef PCH_XPIECE
@@ -395,10 +511,11 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
     for (int b = 0; b < TM; ++b) {
         const int q = pm0 + b * 16 + l15;
         if (HALO) {
-            const int qy = q / (HALO ? TW : 1), qx = q - qy * TW;
+            const int qq = q < TH * TW ? q : TH * TW - 1;              // rows past the patch (BM > TH * TW) recompute its last pixel
+            const int qy = qq / TW, qx = qq - qy * TW;
             const int gy = ty0 + qy, gx = tx0 + qx;
-            mval[b] = gy < p.H && gx < p.W;
-            mrow[b] = (bimg * p.H + gy) * p.W + gx;
+            mval[b] = q < TH * TW && gy < p.H && gx < p.W;
+            mrow[b] = (bimg * p.H + min(gy, p.H - 1)) * p.W + min(gx, p.W - 1);
             xbase[b] = qy * PW + qx;
         } else {
             mrow[b] = m0 + q;
@@ -411,11 +528,15 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
     const bool out_f32 = p.flags & CUTIE_F_OUT_F32;
     const bool vec_ok = (out_f32 ? (p.ldy & 3) == 0 : (p.ldy & (NCH - 1)) == 0) && (!p.res || (p.ldr & (NCH - 1)) == 0);
     float bias[TNP][NCH];
+    const float* const bias_p = p.bias ? p.bias : reinterpret_cast<const float*>(p.w);      // (any mapped address when there is no bias)
 #pragma unroll
     for (int a = 0; a < TNP; ++a) {
         const int ch0 = n0 + cn0 + a * (PAIR ? 32 : 16) + l4 * NCH;
 #pragma unroll
-        for (int r = 0; r < NCH; ++r) bias[a][r] = (p.bias && ch0 + r < p.Cout) ? p.bias[ch0 + r] : 0.f;
+        for (int r = 0; r < NCH; ++r) {                  // unconditional (clamped) loads, then a select: a load behind a per-element branch makes hipcc wait for each one
+            const float t = bias_p[min(ch0 + r, p.Cout - 1)];
+            bias[a][r] = (p.bias && ch0 + r < p.Cout) ? t : 0.f;
+        }
     }
     unsigned rpre[PRE_RES ? TM : 1][PRE_RES ? TNP : 1][NCH / 2];
     const bool have_res = PRE_RES && p.res && vec_ok;
@@ -428,7 +549,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
 #pragma unroll
                 for (int r = 0; r < NCH / 2; ++r) rpre[b][a][r] = 0u;
                 if (have_res && mval[b] && ch0 + NCH <= p.Cout) {
-                    const int mres = (p.flags & CUTIE_F_RES_BCAST) ? (mrow[b] % p.OHW) : mrow[b];
+                    const int mres = (p.flags & CUTIE_F_RES_BCAST) ? mrow[b] - pc_div(mrow[b], p.OHW, __builtin_amdgcn_rcpf((float)p.OHW)) * p.OHW : mrow[b];
                     const bf16_t* rp = p.res + (long)mres * p.ldr + ch0;
                     if constexpr (NCH == 8) { const uint4 t = *reinterpret_cast<const uint4*>(rp); rpre[b][a][0] = t.x; rpre[b][a][1] = t.y; rpre[b][a][NCH / 2 - 2] = t.z; rpre[b][a][NCH / 2 - 1] = t.w; }
                     else { const uint2 t = *reinterpret_cast<const uint2*>(rp); rpre[b][a][0] = t.x; rpre[b][a][1] = t.y; }
@@ -453,75 +574,90 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
 #else
 #define PC_MFMA(AF, BF, ACC) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF, BF, ACC, 0, 0, 0)
 #endif
-    // Fragment registers are double-buffered (sets A / B, the loop is unrolled by two): while the MFMAs of tile t run, the reads of
-    // tile t + 1 are in flight, so no LDS latency is exposed between the barrier and the first MFMA.  Read state = the tile whose
-    // fragments are requested NEXT: ring stage rd, and in halo mode (slice, tap) with the patch-pixel offset of the tap.
-    int rd = 0;
-    int sl = 0, tap = 0, toff = 0;
-    u32x4 xA0[TM], xA1[TM], xB0[TM], xB1[TM];
-    bf16x8 wA0[TN], wA1[TN], wB0[TN], wB1[TN];
-#define PC_READ(X0, X1, W0, W1)                                                                            \
-    {                                                                                                      \
-        const char* const wst = lds + WBASE + rd + rdw0;                                                   \
-        _Pragma("unroll") for (int a = 0; a < TN; ++a) {                                                   \
-            W0[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wst + a * 2048 + (c0 ^ swl))); \
-            W1[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wst + a * 2048 + (c1 ^ swl))); \
-        }                                                                                                  \
-        if (HALO) {                                                                                        \
-            const char* const xs = lds + (sl & 1) * XBUF;                                                  \
-            _Pragma("unroll") for (int b = 0; b < TM; ++b) {                                               \
-                const int pp = xbase[b] + toff;                                                            \
-                const int sw = (pp & 7) << 4;                                                              \
-                X0[b] = *reinterpret_cast<const u32x4*>(xs + pp * 128 + (c0 ^ sw));                        \
-                X1[b] = *reinterpret_cast<const u32x4*>(xs + pp * 128 + (c1 ^ sw));                        \
-            }                                                                                              \
-            ++tap;                                                                                         \
-            toff += (tap == 3 || tap == 6) ? PW - 2 : 1;                                                   \
-            if (tap == 9) { tap = 0; toff = 0; ++sl; }                                                     \
-        } else {                                                                                           \
-            const char* const xs = lds + rd + rdx0;                                                        \
-            _Pragma("unroll") for (int b = 0; b < TM; ++b) {                                               \
-                X0[b] = *reinterpret_cast<const u32x4*>(xs + b * 2048 + (c0 ^ swl));                       \
-                X1[b] = *reinterpret_cast<const u32x4*>(xs + b * 2048 + (c1 ^ swl));                       \
-            }                                                                                              \
-        }                                                                                                  \
-        rd = rd == (NS - 1) * STAGE ? 0 : rd + STAGE;                                                      \
-    }
 #define PC_RELU4(V) { V.x = pc_relu2(V.x); V.y = pc_relu2(V.y); V.z = pc_relu2(V.z); V.w = pc_relu2(V.w); }
-    // one K step: (fused input ReLU on the fragments that have just arrived,) request the fragments of the next tile into the other
-    // set, multiply this one, meet the producers
-#define PC_STEP(X0, X1, W0, W1, NX0, NX1, NW0, NW1, MORE)                                                  \
-    {                                                                                                      \
-        TL(3)                                                                                              \
-        if (RELU) { _Pragma("unroll") for (int b = 0; b < TM; ++b) { PC_RELU4(X0[b]) PC_RELU4(X1[b]) } }   \
-        if (MORE) PC_READ(NX0, NX1, NW0, NW1)                                                              \
-        _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                     \
-            _Pragma("unroll") for (int b = 0; b < TM; ++b) PC_MFMA(W0[a], __builtin_bit_cast(bf16x8, X0[b]), acc[a][b]); \
-        _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                     \
-            _Pragma("unroll") for (int b = 0; b < TM; ++b) PC_MFMA(W1[a], __builtin_bit_cast(bf16x8, X1[b]), acc[a][b]); \
-        TL(4)                                                                                              \
-        PC_WAIT_LGKM0();                                                                                   \
-        PC_BARRIER()                                                                                       \
-    }
+    // one K step: read the fragments of tile t (complete since the last barrier), multiply, meet the producers
+    int rd = 0;                                          // ring stage of the tile being multiplied (byte offset)
+    int sl = 0, tap = 0, toff = 0;                       // halo: slice, tap, patch-pixel offset of the tap
     TL(1)
-    PC_BARRIER()                                         // tiles 0 and 1 (and the patch of slice 0) have landed
+    PC_BARRIER()                                         // tile 0 (and the patch of slice 0) has landed
     TL(2)
-    if (nk > 0) PC_READ(xA0, xA1, wA0, wA1)
-    PC_WAIT_LGKM0();
-    PC_BARRIER()                                         // (second prologue barrier: the producers may now overwrite the stage of tile 0)
-    int kt = 0;
-    for (; kt + 2 <= nk; kt += 2) {
-        PC_STEP(xA0, xA1, wA0, wA1, xB0, xB1, wB0, wB1, true)
-        PC_STEP(xB0, xB1, wB0, wB1, xA0, xA1, wA0, wA1, kt + 2 < nk)
+    for (int kt = 0; kt < nk; ++kt) {
+        TL(3)
+        u32x4 x0[TM], x1[TM];
+        bf16x8 w0[TN], w1[TN];
+#ifdef PC_ABL_NO_READ
+#pragma unroll
+        for (int a = 0; a < TN; ++a) { u32x4 v = {(unsigned)rd + a, (unsigned)lane, 5u, 1u}; w0[a] = __builtin_bit_cast(bf16x8, v); v.w = 2u; w1[a] = __builtin_bit_cast(bf16x8, v); }
+#pragma unroll
+        for (int b = 0; b < TM; ++b) { x0[b] = (u32x4){(unsigned)rd + b, (unsigned)lane, 3u, 1u}; x1[b] = (u32x4){(unsigned)rd + b, (unsigned)lane, 3u, 2u}; }
+#else
+        const char* const wst = lds + WBASE + rd + rdw0;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            w0[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wst + a * 2048 + (c0 ^ swl)));
+            w1[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wst + a * 2048 + (c1 ^ swl)));
+        }
+        if (HALO) {
+            const char* const xs = lds + (sl & 1) * XBUF;
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int pp = xbase[b] + toff;
+                const int sw = (pp & 7) << 4;
+                x0[b] = *reinterpret_cast<const u32x4*>(xs + pp * 128 + (c0 ^ sw));
+                x1[b] = *reinterpret_cast<const u32x4*>(xs + pp * 128 + (c1 ^ sw));
+            }
+        } else {
+            const char* const xs = lds + rd + rdx0;
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                x0[b] = *reinterpret_cast<const u32x4*>(xs + b * 2048 + (c0 ^ swl));
+                x1[b] = *reinterpret_cast<const u32x4*>(xs + b * 2048 + (c1 ^ swl));
+            }
+        }
+#endif
+        if (RELU) {
+#pragma unroll
+            for (int b = 0; b < TM; ++b) { PC_RELU4(x0[b]) PC_RELU4(x1[b]) }
+        }
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b) PC_MFMA(w0[a], __builtin_bit_cast(bf16x8, x0[b]), acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b) PC_MFMA(w1[a], __builtin_bit_cast(bf16x8, x1[b]), acc[a][b]);
+        TL(4)
+        PC_WAIT_LGKM0();
+        PC_LOOP_BARRIER()
+        rd = rd == (NS - 1) * STAGE ? 0 : rd + STAGE;
+        if (HALO) {
+            ++tap;
+            toff += (tap == 3 || tap == 6) ? PW - 2 : 1;
+            if (tap == 9) { tap = 0; toff = 0; ++sl; }
+        }
     }
-    if (kt < nk) PC_STEP(xA0, xA1, wA0, wA1, xB0, xB1, wB0, wB1, false)
-#undef PC_STEP
-#undef PC_READ
     TLE(5)
 #ifdef PC_ABL_NO_EPILOGUE
     if (acc[0][0][0] != 12345.678f) { TL_DUMP(logical, nb, NC + NPW) return; }
 #endif
     // ---- epilogue straight from the accumulators: lane = (pixel l15 of fragment b, channels l4 * NCH .. + NCH of slice a) ----
+#ifndef PC_ABL_GENERIC_EPI
+    {
+        const int act_ = (p.flags >> CUTIE_ACT_SHIFT) & 7;
+        if (vec_ok && n0 + BN <= p.Cout && !p.gap && act_ <= CUTIE_ACT_RELU && !(out_f32 && (act_ || p.res))) {       // wave-uniform
+            const int chbase = n0 + cn0 + l4 * NCH;
+#define PC_FAST(RL, F, RS) pc_epilogue_fast<NCH, TM, TNP, PAIR, RL, F, RS, PRE_RES>(p, acc, bias, mrow, mval, chbase, rpre)
+            if (out_f32) PC_FAST(false, true, false);
+            else if (p.res) { if (act_) PC_FAST(true, false, true); else PC_FAST(false, false, true); }
+            else { if (act_) PC_FAST(true, false, false); else PC_FAST(false, false, false); }
+#undef PC_FAST
+            TLE(6)
+            TL_DUMP(logical, nb, NC + NPW)
+            return;
+        }
+    }
+#endif
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
 #pragma unroll
@@ -538,6 +674,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
             for (int r = 0; r < NCH; ++r) st[r] = 0.f;
             if (live) pc_finish<NCH>(p, v, mrow[b], ch0, vec_ok, have_res && ch0 + NCH <= p.Cout, rpre[PRE_RES ? b : 0][PRE_RES ? a : 0], st);
             TLE(20 + b * TNP + a)
+#ifndef PC_ABL_FIXED_EPI
             if (p.gap) {
                 // column sums of the stored values over the fragment's 16 pixels.  One object per fragment (always in halo mode):
                 // lane shuffles, then 8 atomics from the l15 == 0 lane of each channel group; a fragment that straddles two
@@ -567,6 +704,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
                             atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)ob * p.Cout + ch0 + r), (unsigned long long)__float2ll_rn(st[r] * GAP_FIXED_SCALE));
                 }
             }
+#endif
         }
     }
     TLE(6)
@@ -576,13 +714,13 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int NPW, int NS, int TW, bool TAPS, bool RELU, bool TWO>
+template <int BM, int BN, int WM, int WN, int NPW, int NS, int HT, bool TAPS, bool RELU, bool TWO>
 static int launch_pc3(const ConvParams& p, hipStream_t s) {
-    constexpr int lds = pc_lds_bytes<BM, BN, NS, TW>(NPW) + TL_BYTES;
+    constexpr int lds = pc_lds_bytes<BM, BN, NS, HT>(NPW) + TL_BYTES;
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        if (lds > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_kernel<BM, BN, WM, WN, NPW, NS, TW, TAPS, RELU, TWO>),
+        if (lds > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_kernel<BM, BN, WM, WN, NPW, NS, HT, TAPS, RELU, TWO>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             cutie_set_error("conv pc tile: cannot raise the dynamic LDS limit to %d bytes", lds);
             return -2;
@@ -590,18 +728,18 @@ static int launch_pc3(const ConvParams& p, hipStream_t s) {
         attr_set = true;
     }
     unsigned gx;
-    if (TW > 0) {
-        constexpr int TH = BM / (TW > 0 ? TW : 1);
-        gx = (unsigned)(p.B * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / (TW > 0 ? TW : 1)));
+    if (HT > 0) {
+        constexpr int TH = HT > 0 ? (HT >> 8) : 1, TW = HT > 0 ? (HT & 255) : 1;
+        gx = (unsigned)(p.B * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW));
     } else {
         gx = (unsigned)((p.M + BM - 1) / BM);
     }
-    hipLaunchKernelGGL((conv_pc_kernel<BM, BN, WM, WN, NPW, NS, TW, TAPS, RELU, TWO>), dim3(gx, (unsigned)((p.Cout + BN - 1) / BN)),
+    hipLaunchKernelGGL((conv_pc_kernel<BM, BN, WM, WN, NPW, NS, HT, TAPS, RELU, TWO>), dim3(gx, (unsigned)((p.Cout + BN - 1) / BN)),
                        dim3((WM * WN + NPW) * 64), lds, s, p);
     return (int)hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, int NPW, int NS, int TW>
+template <int BM, int BN, int WM, int WN, int NPW, int NS, int HT>
 static int launch_pc(ConvParams p, hipStream_t s) {
     const long x1_bytes = (long)p.B * p.H * p.W * p.ldx1 * 2, x2_bytes = p.C2 ? (long)p.B * p.H * p.W * p.ldx2 * 2 : 0;
     const long gy = (p.Cout + BN - 1) / BN, w_bytes = gy * BN * (long)p.Kpad * 2;
@@ -611,14 +749,14 @@ static int launch_pc(ConvParams p, hipStream_t s) {
                         "(Cin=%d C1=%d Kpad=%d k=%dx%d splitk=%d)", p.Cin, p.C1, p.Kpad, p.KH, p.KW, p.splitk);
         return -2;
     }
-    if (TW > 0 && (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.OH != p.H || p.OW != p.W)) {
+    if (HT > 0 && (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.OH != p.H || p.OW != p.W)) {
         cutie_set_error("conv pc halo tile: needs 3x3 / stride 1 / pad 1 (k=%dx%d stride=%d pad=%d)", p.KH, p.KW, p.stride, p.pad);
         return -2;
     }
     p.Kslice = p.KH * p.KW * p.Cin;
     const bool relu = p.flags & CUTIE_F_RELU_IN, two = p.C2 != 0, taps = p.pad > 0 || p.KH * p.KW > 1;
-#define PC_GO(T_, R_, W_) return launch_pc3<BM, BN, WM, WN, NPW, NS, TW, T_, R_, W_>(p, s)
-    if constexpr (TW > 0) {
+#define PC_GO(T_, R_, W_) return launch_pc3<BM, BN, WM, WN, NPW, NS, HT, T_, R_, W_>(p, s)
+    if constexpr (HT > 0) {
         if (relu) { if (two) PC_GO(true, true, true); PC_GO(true, true, false); }
         if (two) PC_GO(true, false, true);
         PC_GO(true, false, false);
@@ -650,18 +788,25 @@ int launch_conv_pc(const ConvParams& p, int tile, hipStream_t s) {
         case 107: return launch_pc<64, 64, 2, 2, 8, 3, 0>(p, s);        // 8 producers: one X + one W piece each
         case 108: return launch_pc<128, 128, 2, 4, 8, 3, 0>(p, s);      // 8 consumers (64 x 32) + 8 producers
         case 109: return launch_pc<32, 64, 2, 2, 4, 6, 0>(p, s);        // deep ring, 72 KB
+        case 110: return launch_pc<96, 64, 2, 2, 4, 3, 0>(p, s);        // 48 x 32 per consumer wave: M = 4860 in 51 row tiles
+        case 111: return launch_pc<96, 128, 2, 2, 4, 3, 0>(p, s);
 #endif
         // ---- halo mode (3x3 / stride 1 / pad 1): TH x TW output patch ----
-        case 120: return launch_pc<64, 64, 2, 2, 4, 3, 8>(p, s);        // 8 x 8
+        case 120: return launch_pc<64, 64, 2, 2, 4, 3, PC_HT(8, 8)>(p, s);
 #ifndef PC_QUICK
-        case 121: return launch_pc<64, 64, 2, 2, 4, 3, 16>(p, s);       // 4 x 16
-        case 122: return launch_pc<128, 64, 2, 2, 4, 3, 16>(p, s);      // 8 x 16
-        case 123: return launch_pc<128, 128, 2, 2, 4, 3, 16>(p, s);     // 8 x 16, 64 x 64 per consumer wave
-        case 124: return launch_pc<64, 128, 2, 2, 4, 3, 8>(p, s);       // 8 x 8
-        case 125: return launch_pc<32, 64, 2, 2, 4, 3, 8>(p, s);        // 4 x 8
-        case 126: return launch_pc<128, 128, 2, 4, 8, 3, 16>(p, s);     // 8 x 16, 8 consumers + 8 producers
-        case 127: return launch_pc<64, 128, 2, 2, 4, 3, 16>(p, s);      // 4 x 16
-        case 128: return launch_pc<256, 128, 4, 2, 8, 3, 16>(p, s);     // 16 x 16, 8 consumers (64 x 64) + 8 producers
+        case 121: return launch_pc<64, 64, 2, 2, 4, 3, PC_HT(4, 16)>(p, s);
+        case 122: return launch_pc<128, 64, 2, 2, 4, 3, PC_HT(8, 16)>(p, s);
+        case 123: return launch_pc<128, 128, 2, 2, 4, 3, PC_HT(8, 16)>(p, s);     // 64 x 64 per consumer wave
+        case 124: return launch_pc<64, 128, 2, 2, 4, 3, PC_HT(8, 8)>(p, s);
+        case 125: return launch_pc<32, 64, 2, 2, 4, 3, PC_HT(4, 8)>(p, s);
+        case 126: return launch_pc<128, 128, 2, 4, 8, 3, PC_HT(8, 16)>(p, s);     // 8 consumers + 8 producers
+        case 127: return launch_pc<64, 128, 2, 2, 4, 3, PC_HT(4, 16)>(p, s);
+        // patch shapes that tile the 30 x 54 (stride-16, 480p) maps into <= 256 workgroups
+        case 129: return launch_pc<96, 64, 2, 2, 4, 3, PC_HT(10, 9)>(p, s);       // 3 x 6 patches per object: 216 blocks at K = 3, Cout = 256
+        case 130: return launch_pc<32, 64, 2, 2, 4, 3, PC_HT(5, 6)>(p, s);        // 6 x 9 patches per object: 216 blocks at K = 1
+        case 131: return launch_pc<64, 128, 2, 2, 4, 3, PC_HT(6, 9)>(p, s);       // 5 x 6 patches: 180 blocks at K = 3, Cout = 256
+        case 132: return launch_pc<64, 64, 2, 2, 4, 3, PC_HT(6, 9)>(p, s);
+        case 133: return launch_pc<96, 128, 2, 2, 4, 3, PC_HT(10, 9)>(p, s);
 #endif
         default: cutie_set_error("conv: bad pc tile id %d", tile); return -2;
     }

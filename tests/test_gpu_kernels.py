@@ -417,7 +417,7 @@ def test_gap_eca():
     check(hip, ref, 'gap/eca')
 
 
-@pytest.mark.parametrize('tile', [66, 67, 63, 61, 70, 68, 82, 85, 86, 90, 91, 92, 100, 102, 103, 105, 108, 120, 121, 123, 125, 128])
+@pytest.mark.parametrize('tile', [66, 67, 63, 61, 70, 68, 82, 85, 86, 90, 91, 92, 100, 102, 103, 105, 108, 110, 120, 121, 123, 125, 129, 131])
 @pytest.mark.parametrize('geo', [(3, 30, 54), (5, 5, 7), (2, 9, 16)])
 def test_conv_gap_accumulation(tile, geo):
     """ECA's average pool riding on the convs of a CAResBlock: conv1 clears the accumulator, conv2 adds the fixed-point channel sums of

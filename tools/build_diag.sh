@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../cutie_amd/csrc"
 make -s -j8
 mkdir -p ../../tools/abl
-FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-variable -Wno-unused-value -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form"
+FL="$EXTRA --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-variable -Wno-unused-value -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form"
 for spec in ${@:-TL=CONV_TIMELINE}; do
   v=${spec%%=*}; defs=""; for m in $(echo ${spec#*=} | tr , ' '); do defs="$defs -D$m"; done
   /opt/rocm/bin/hipcc $FL $defs -c conv_pc.hip -o ../../tools/abl/conv_pc_$v.o &
