@@ -164,15 +164,58 @@ __device__ __forceinline__ int pc_div(int m, int d, float rd) {
     return q;
 }
 
+// GAP side job: column sums of s[0 .. NCH) over the 16 lanes (= 16 pixels) of a row group by a reduce-SCATTER butterfly: after NCH - 1
+// + 1 shuffles the lane holds the 16-pixel total of ONE channel (index returned in c; lanes come in pairs -- quadruples for NCH = 4 --
+// with the same value, the first of which writes).  One atomic instruction then carries 32 (16) different channels of a wave; issued
+// per lane and channel (round 3, first version) the same sums were 8 four-lane instructions per fragment whose requests serialise in
+// the L2 on the few lines of the accumulator: +21 us on the 4860 x 256 conv (profiles/r03_conv_ablation.md).
+template <int NCH>
+__device__ __forceinline__ float pc_colsum16(const float (&s)[NCH], int l15, int& c, bool& writer) {
+    const bool h8 = l15 & 8, h4 = l15 & 4, h2 = l15 & 2;
+    float w;
+    if constexpr (NCH == 8) {
+        float t[4], u[2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = (h8 ? s[4 + r] : s[r]) + __shfl_xor(h8 ? s[r] : s[4 + r], 8, 64);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) u[r] = (h4 ? t[2 + r] : t[r]) + __shfl_xor(h4 ? t[r] : t[2 + r], 4, 64);
+        w = (h2 ? u[1] : u[0]) + __shfl_xor(h2 ? u[0] : u[1], 2, 64);
+        w += __shfl_xor(w, 1, 64);
+        c = (h8 ? 4 : 0) + (h4 ? 2 : 0) + (h2 ? 1 : 0);
+        writer = (l15 & 1) == 0;
+    } else {
+        float t[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) t[r] = (h8 ? s[2 + r] : s[r]) + __shfl_xor(h8 ? s[r] : s[2 + r], 8, 64);
+        w = (h4 ? t[1] : t[0]) + __shfl_xor(h4 ? t[0] : t[1], 4, 64);
+        w += __shfl_xor(w, 2, 64);
+        w += __shfl_xor(w, 1, 64);
+        c = (h8 ? 2 : 0) + (h4 ? 1 : 0);
+        writer = (l15 & 3) == 0;
+    }
+    return w;
+}
+__device__ __forceinline__ void pc_gap_add(const ConvParams& p, int obj, int ch, float v) {
+    // fixed point + integer atomics: the total does not depend on the order of arrival (bit-reproducible)
+    if (ch < p.Cout) atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)obj * p.Cout + ch), (unsigned long long)__float2ll_rn(v * GAP_FIXED_SCALE));
+}
+
 // Fast epilogue of the common configurations, chosen ONCE per block by wave-uniform tests: whole tile inside Cout, aligned strides, no
 // GAP side job, activation none / relu.  Straight-line code per configuration -- the generic slice code (pc_finish) re-tests activation,
 // output type, residual kind and raggedness per element; measured on the 64x64 tile: 2.0 us of epilogue against 1.1 us
 // (profiles/r03_conv_ablation.md), most of it instruction fetch of code that is executed once per block.
-template <int NCH, int TM, int TNP, bool PAIR, bool RELU_OUT, bool F32, bool RES, bool PRE>
+template <int NCH, int TM, int TNP, bool PAIR, bool RELU_OUT, bool F32, bool RES, bool PRE, bool GAPJ = false>
 __device__ __forceinline__ void pc_epilogue_fast(const ConvParams& p, const f32x4 (&acc)[PAIR ? 2 * TNP : TNP][TM], const float (&bias)[TNP][NCH],
                                                  const int (&mrow)[TM], const bool (&mval)[TM], int chbase,
-                                                 const unsigned (&rpre)[PRE ? TM : 1][PRE ? TNP : 1][NCH / 2]) {
+                                                 const unsigned (&rpre)[PRE ? TM : 1][PRE ? TNP : 1][NCH / 2], int gap_obj = 0, int l15 = 0) {
     unsigned rr[TM][TNP][NCH / 2];
+    float gs[GAPJ ? TNP : 1][NCH];                       // GAPJ (the wave's rows lie in ONE object, gap_obj): stored values summed over its fragments
+    if (GAPJ) {
+#pragma unroll
+        for (int a = 0; a < TNP; ++a)
+#pragma unroll
+            for (int r = 0; r < NCH; ++r) gs[a][r] = 0.f;
+    }
     if (RES && !PRE) {                                   // all residual loads first: one exposed latency, not one per slice
         const bool bc = p.flags & CUTIE_F_RES_BCAST;
 #pragma unroll
@@ -224,8 +267,20 @@ __device__ __forceinline__ void pc_epilogue_fast(const ConvParams& p, const f32x
                     for (int r = 0; r < NCH / 2; ++r) o[r] = pack_bf2(v[2 * r], v[2 * r + 1]);
                     if constexpr (NCH == 8) *reinterpret_cast<uint4*>(yp) = make_uint4(o[0], o[1], o[NCH / 2 - 2], o[NCH / 2 - 1]);
                     else *reinterpret_cast<uint2*>(yp) = make_uint2(o[0], o[1]);
+                    if (GAPJ) {                          // the STORED (bf16-rounded) values
+#pragma unroll
+                        for (int r = 0; r < NCH / 2; ++r) { gs[GAPJ ? a : 0][2 * r] += __uint_as_float(o[r] << 16); gs[GAPJ ? a : 0][2 * r + 1] += __uint_as_float(o[r] & 0xffff0000u); }
+                    }
                 }
             }
+        }
+    }
+    if (GAPJ) {
+#pragma unroll
+        for (int a = 0; a < TNP; ++a) {
+            int c; bool writer;
+            const float tot = pc_colsum16<NCH>(gs[GAPJ ? a : 0], l15, c, writer);
+            if (writer) pc_gap_add(p, gap_obj, chbase + a * (PAIR ? 32 : 16) + c, tot);
         }
     }
 }
@@ -390,8 +445,10 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
 #pragma unroll
             for (int s = 0; s < NS - 1; ++s)
                 if (s < nk) { PCS_LOAD_X(ld) ld += STAGE; }
-            // (queue order: W(0 .. NS-2), X(0 .. NS-2): tile 0 is complete once only the X pieces of tiles 1.. are outstanding)
-            if (nk >= NS - 1) { PC_WAIT_VM((NS - 2) * NXI); } else { PC_WAIT_VM(0); }
+            // (queue order: W(0 .. NS-2), X(0 .. NS-2).  NS = 3: tile 0 is complete once only the X pieces of tile 1 are outstanding, and
+            // the in-order counts of the loop hold from step 0 on.  Deeper rings: the weights-first order would let X(1) hide behind the
+            // younger tiles in the first steps' counts, so the whole prologue burst -- issued back to back -- is awaited here.)
+            if (NS == 3 && nk >= NS - 1) { PC_WAIT_VM((NS - 2) * NXI); } else { PC_WAIT_VM(0); }
             TL(2)
             PC_BARRIER()
             int kt = 0;
@@ -642,13 +699,24 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
     if (acc[0][0][0] != 12345.678f) { TL_DUMP(logical, nb, NC + NPW) return; }
 #endif
     // ---- epilogue straight from the accumulators: lane = (pixel l15 of fragment b, channels l4 * NCH .. + NCH of slice a) ----
+    // GAP side job: do all rows of this wave lie in one object?  (halo mode: always; stream mode: first and last valid row)
+    int gap_obj = bimg;
+    bool gap_one = true;
+    if (p.gap && !HALO) {
+        const int mf = m0 + pm0, ml = min(mf + BM / WM - 1, p.M - 1);
+        const float rd = __builtin_amdgcn_rcpf((float)p.OHW);
+        gap_obj = pc_div(min(mf, p.M - 1), p.OHW, rd);
+        gap_one = pc_div(ml, p.OHW, rd) == gap_obj;
+    }
 #ifndef PC_ABL_GENERIC_EPI
     {
         const int act_ = (p.flags >> CUTIE_ACT_SHIFT) & 7;
-        if (vec_ok && n0 + BN <= p.Cout && !p.gap && act_ <= CUTIE_ACT_RELU && !(out_f32 && (act_ || p.res))) {       // wave-uniform
+        const bool gapfast = p.gap && gap_one && !act_ && !p.res && !out_f32;
+        if (vec_ok && n0 + BN <= p.Cout && (!p.gap || gapfast) && act_ <= CUTIE_ACT_RELU && !(out_f32 && (act_ || p.res))) {       // wave-uniform
             const int chbase = n0 + cn0 + l4 * NCH;
 #define PC_FAST(RL, F, RS) pc_epilogue_fast<NCH, TM, TNP, PAIR, RL, F, RS, PRE_RES>(p, acc, bias, mrow, mval, chbase, rpre)
-            if (out_f32) PC_FAST(false, true, false);
+            if (gapfast) pc_epilogue_fast<NCH, TM, TNP, PAIR, false, false, false, PRE_RES, true>(p, acc, bias, mrow, mval, chbase, rpre, gap_obj, l15);
+            else if (out_f32) PC_FAST(false, true, false);
             else if (p.res) { if (act_) PC_FAST(true, false, true); else PC_FAST(false, false, true); }
             else { if (act_) PC_FAST(true, false, false); else PC_FAST(false, false, false); }
 #undef PC_FAST
@@ -658,6 +726,11 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
         }
     }
 #endif
+    float gsum[TNP][NCH];                                // generic path, GAP with the wave in one object: stored values summed over its fragments
+#pragma unroll
+    for (int a = 0; a < TNP; ++a)
+#pragma unroll
+        for (int r = 0; r < NCH; ++r) gsum[a][r] = 0.f;
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
 #pragma unroll
@@ -676,37 +749,53 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
             TLE(20 + b * TNP + a)
 #ifndef PC_ABL_FIXED_EPI
             if (p.gap) {
-                // column sums of the stored values over the fragment's 16 pixels.  One object per fragment (always in halo mode):
-                // lane shuffles, then 8 atomics from the l15 == 0 lane of each channel group; a fragment that straddles two
-                // objects adds per lane.  Fixed point + integer atomics: the total does not depend on the order of arrival.
-                const unsigned long long vb = __ballot(mval[b]);                      // wave-uniform
-                const int ob = mval[b] ? mrow[b] / p.OHW : 0;
-                const int ob0 = vb ? __builtin_amdgcn_readfirstlane(__shfl(ob, __ffsll((long long)vb) - 1, 64)) : 0;
-                const bool one = __ballot(mval[b] && ob != ob0) == 0ull;           // wave-uniform
-                if (!vb) {
-                } else if (one) {
+                if (gap_one) {
 #pragma unroll
-                    for (int r = 0; r < NCH; ++r) {
-                        float s = st[r];
-                        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-                        st[r] = s;
+                    for (int r = 0; r < NCH; ++r) gsum[a][r] += st[r];
+                } else {
+                    // a wave that straddles an object boundary (at most K - 1 row tiles of a launch): per fragment, the lanes of the first
+                    // object and the lanes of the second are reduced separately (same-address atomics from 16 lanes of one instruction
+                    // serialise in the L2: ~10 us for one such wave); more than two objects in 16 rows (maps smaller than 16 pixels): per lane
+                    const unsigned long long vb = __ballot(mval[b]);                                  // wave-uniform
+                    if (vb) {
+                        const int ob = mval[b] ? pc_div(mrow[b], p.OHW, __builtin_amdgcn_rcpf((float)p.OHW)) : -1;
+                        const int o1 = __builtin_amdgcn_readfirstlane(__shfl(ob, __ffsll((long long)vb) - 1, 64));
+                        const unsigned long long rest = __ballot(mval[b] && ob != o1);
+                        const int o2 = rest ? __builtin_amdgcn_readfirstlane(__shfl(ob, __ffsll((long long)rest) - 1, 64)) : o1;
+                        if (__ballot(mval[b] && ob != o1 && ob != o2)) {
+                            if (live) {
+#pragma unroll
+                                for (int r = 0; r < NCH; ++r) pc_gap_add(p, ob, ch0 + r, st[r]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int pass = 0; pass < 2; ++pass) {
+                                const int oo = pass ? o2 : o1;
+                                if (pass && !rest) break;
+                                float part[NCH];
+#pragma unroll
+                                for (int r = 0; r < NCH; ++r) part[r] = (live && ob == oo) ? st[r] : 0.f;
+                                int c; bool writer;
+                                const float tot = pc_colsum16<NCH>(part, l15, c, writer);
+                                if (writer) pc_gap_add(p, oo, ch0 + c, tot);
+                            }
+                        }
                     }
-                    if (l15 == 0) {
-#pragma unroll
-                        for (int r = 0; r < NCH; ++r)
-                            if (ch0 + r < p.Cout)
-                                atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)ob0 * p.Cout + ch0 + r), (unsigned long long)__float2ll_rn(st[r] * GAP_FIXED_SCALE));
-                    }
-                } else if (live) {
-#pragma unroll
-                    for (int r = 0; r < NCH; ++r)
-                        if (ch0 + r < p.Cout)
-                            atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)ob * p.Cout + ch0 + r), (unsigned long long)__float2ll_rn(st[r] * GAP_FIXED_SCALE));
                 }
             }
 #endif
         }
     }
+#ifndef PC_ABL_FIXED_EPI
+    if (p.gap && gap_one) {
+#pragma unroll
+        for (int a = 0; a < TNP; ++a) {
+            int c; bool writer;
+            const float tot = pc_colsum16<NCH>(gsum[a], l15, c, writer);
+            if (writer) pc_gap_add(p, gap_obj, n0 + cn0 + a * (PAIR ? 32 : 16) + l4 * NCH + c, tot);
+        }
+    }
+#endif
     TLE(6)
     TL_DUMP(logical, nb, NC + NPW)
 #undef PC_RELU4

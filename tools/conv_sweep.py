@@ -39,6 +39,7 @@ def main():
     ap.add_argument('--height', type=int, default=480)
     ap.add_argument('--width', type=int, default=854)
     ap.add_argument('--out', default='gpurun_out/conv_sweep')
+    ap.add_argument('--cold', type=int, default=0, help='MiB copied through the device before every timed launch (evicts code and operands from the L2s: the state a layer finds inside a frame); 0 = warm back-to-back timing')
     ap.add_argument('--families', default='', help='comma list: time only tiles of these families (igemm,patch,bufload,dma,strip,pc,halo); default all')
     args = ap.parse_args()
     os.environ.setdefault('CUTIE_AMD_EXPERIMENTAL_TILES', '1')
@@ -80,6 +81,25 @@ def main():
                     geoms[key][0]['p'][0, 7] = geoms[key][0]['p'][0, 8] = 0     # GAP accumulation / zero side jobs exist on the LDS-DMA tiles only
                     geoms[key][0]['i'][0, 21] = 0
                 geoms[key][1] += 1
+    flush, t_flush = None, 0.0
+    if args.cold:
+        nb = args.cold << 20
+        fsrc, fdst = torch.zeros(nb, dtype=torch.uint8, device='cuda'), torch.zeros(nb, dtype=torch.uint8, device='cuda')
+        fl = O.OpList()
+        fl.copy2d(fsrc, fdst, rows=args.cold, rowbytes=1 << 20, src_stride=1 << 20, dst_stride=1 << 20)
+        flush = fl.finalize()
+        for _ in range(3):
+            rec.ex.run(flush)
+        torch.cuda.synchronize()
+        t_flush = min(rec.ex.time_ops(flush, 10) for _ in range(5)) * 1e3
+        print(f'cold mode: {args.cold} MiB flush = {t_flush:.1f} us before every launch')
+
+    def time_one(one):
+        if flush is None:
+            return min(rec.ex.time_ops(one, args.iters) for _ in range(args.reps)) * 1e3
+        seq = np.concatenate([flush, one])
+        return min(rec.ex.time_ops(seq, max(2, args.iters // 2)) for _ in range(args.reps)) * 1e3 - t_flush
+
     rows, table = [], []
     for key, (one, count) in geoms.items():
         i = one['i'][0]
@@ -95,7 +115,7 @@ def main():
             for sk in O.splitk_candidates(M, cout, int(i[16]), t):
                 one['i'][0, 17], one['i'][0, 19] = t, sk
                 try:
-                    us = min(rec.ex.time_ops(one, args.iters) for _ in range(args.reps)) * 1e3
+                    us = time_one(one)
                 except RuntimeError as e:
                     print('  tile', t, 'failed on', key, str(e)[:120])
                     continue
