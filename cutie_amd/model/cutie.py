@@ -201,6 +201,7 @@ class Engine:
         e = object.__new__(Engine)
         e.__dict__.update(self.__dict__)
         e._plans = {}
+        e._arenas = {}
         e.__dict__.pop('_splitk_part', None)
         e.__dict__.pop('_qpool', None)
         return e
@@ -210,6 +211,13 @@ class Engine:
         if p is None:
             p = builder(self, *args)
             p.ol.finalize()
+            if plans.ARENA:
+                # the image encoder (+ key projection) may run on the look-ahead stream next to everything else: its own arena
+                kind = 'side' if key[0] in ('enc', 'key') else 'main'
+                arenas = self.__dict__.setdefault('_arenas', {})
+                if kind not in arenas:
+                    arenas[kind] = plans.Arena(self.device)
+                p.pack_into(arenas[kind])
             self._plans[key] = p
         return p
 

@@ -8,6 +8,7 @@ Activations are NHWC bf16 ([B,H,W,C], B = objects), fp32 where the reference for
 import math
 import os
 
+import numpy as np
 import torch
 
 from .. import ops as O
@@ -88,6 +89,40 @@ def save_tile_cache(cache):
     os.replace(tmp, path)
 
 
+# Activation arenas.  A plan's scratch buffers used to be one allocation each, alive forever: ~450 MB of distinct addresses per 480p /
+# 3-object frame on top of 70 MB of weights -- twice the 256 MB Infinity Cache, so every layer found its operands (and the previous
+# layer's output) in HBM.  After a plan is built, its buffers are packed into an arena by live range (first / last launch that touches
+# them, read off the descriptors), and the plans that run one after the other on a stream share ONE arena: the frame then cycles through
+# ~150 MB of addresses and the memory-side cache keeps them (tools/cold_probe.py: a conv whose operands come from HBM costs 2-7 us
+# more than the same launch served from the Infinity Cache).  $CUTIE_AMD_ARENA=0 restores one allocation per buffer.
+ARENA = os.environ.get('CUTIE_AMD_ARENA', '1') not in ('', '0')
+ARENA_POISON = os.environ.get('CUTIE_AMD_ARENA_POISON', '0') not in ('', '0')      # tests: garbage in the arena before every run
+ARENA_ALIGN = 256
+
+
+class Arena:
+    """One growable device allocation shared by the plans of a stream class; plans re-bind their pointers when it moves."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensor = None
+        self.size = 0
+        self.plans = []
+
+    def require(self, nbytes):
+        if nbytes <= self.size:
+            return
+        self.size = -(-int(nbytes * 1.1) // (1 << 20)) * (1 << 20)
+        if self.tensor is not None:
+            self._old = getattr(self, '_old', []) + [self.tensor]       # launches in flight may still use it (growth happens during warm-up only)
+        self.tensor = torch.zeros(self.size, dtype=torch.uint8, device=self.device)
+        for p in self.plans:
+            p.rebind_arena()
+
+    def base(self):
+        return self.tensor.data_ptr()
+
+
 class Plan:
     def __init__(self, eng):
         self.eng = eng
@@ -96,17 +131,80 @@ class Plan:
         self.bufs = {}
         self.meta = {}
         self.tuned = False
+        self.persistent = set()          # buffers whose contents must survive between runs (zero padding written once, outputs read by the caller)
+        self.arena = None
+        self._arena_slots = []           # (op index, pointer slot, byte offset inside the arena)
+        self._arena_views = {}           # name -> (offset, shape, dtype)
 
-    def buf(self, name, shape, dtype=BF16):
+    def buf(self, name, shape, dtype=BF16, persistent=False):
         assert name not in self.bufs, name
         t = torch.zeros(tuple(int(s) for s in shape), dtype=dtype, device=self.dev)
         self.bufs[name] = t
+        if persistent:
+            self.persistent.add(name)
         return t
+
+    def pack_into(self, arena):
+        """Pack the non-persistent buffers into `arena` by live range and re-point the descriptors (called once, when the plan is built)."""
+        arr = self.ol.finalize()
+        ptrs = arr['p'].astype(np.int64)
+        items = []
+        for name, t in self.bufs.items():
+            if name in self.persistent or t.numel() == 0:
+                continue
+            base, nbytes = t.data_ptr(), t.numel() * t.element_size()
+            hit = (ptrs >= base) & (ptrs < base + nbytes)
+            if not hit.any():
+                continue
+            rows = np.nonzero(hit.any(axis=1))[0]
+            items.append(dict(name=name, base=base, nbytes=nbytes, first=int(rows[0]), last=int(rows[-1]), hit=hit, t=t))
+        # first-fit by start of life; a region is reusable by buffers whose first launch comes AFTER the last launch of its previous owner
+        items.sort(key=lambda b: (b['first'], -b['nbytes']))
+        placed = []                                       # (offset, end, last)
+        total = 0
+        for b in items:
+            size = -(-b['nbytes'] // ARENA_ALIGN) * ARENA_ALIGN
+            live = sorted((o, e) for (o, e, last) in placed if last >= b['first'])
+            off = 0
+            for o, e in live:
+                if off + size <= o:
+                    break
+                off = max(off, e)
+            b['off'] = off
+            placed.append((off, off + size, b['last']))
+            total = max(total, off + size)
+        self.arena = arena
+        self._arena_slots = []
+        for b in items:
+            idx, slot = np.nonzero(b['hit'])
+            for i, sl in zip(idx, slot):
+                self._arena_slots.append((int(i), int(sl), b['off'] + int(ptrs[i, sl] - b['base'])))
+            self._arena_views[b['name']] = (b['off'], tuple(b['t'].shape), b['t'].dtype)
+        self.ol.keep = [k for k in self.ol.keep if not any(k is b['t'] for b in items)]
+        arena.plans.append(self)
+        arena.require(total)
+        self.rebind_arena()
+        self.meta['arena_bytes'] = total
+        self.meta['unpacked_bytes'] = sum(b['nbytes'] for b in items)
+
+    def rebind_arena(self):
+        if self.arena is None or self.arena.tensor is None:
+            return
+        base = self.arena.base()
+        p = self.ol.arr['p']
+        for (i, sl, off) in self._arena_slots:
+            p[i, sl] = base + off
+            self.ol.recs[i][4][sl] = base + off          # (a later finalize() rebuilds the array from the records)
+        for name, (off, shape, dtype) in self._arena_views.items():
+            n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+            self.bufs[name] = self.arena.tensor[off:off + n].view(dtype).view(shape)
 
     def run(self, **dyn):
         if not self.tuned:
             self.tuned = True
             self.autotune_convs(**dyn)
+        if ARENA_POISON and self.arena is not None and self.arena.tensor is not None:
+            self.arena.tensor.fill_(0xFF)               # (tests) nothing may rely on what an earlier run or another plan left in the arena
         self.ol.run(**dyn)
 
     def autotune_convs(self, **dyn):
@@ -292,7 +390,7 @@ def build_pixel_fusion(eng, K, h, w, pre=False):
     dyn out: fused bf16 [K,h,w,CE]."""
     P = Plan(eng)
     m = eng.m
-    pair = P.buf('pair', (K, h, w, 64))           # (mask, others) in channels 0, 1 of a zeroed 64-channel tensor: a whole K tile
+    pair = P.buf('pair', (K, h, w, 64), persistent=True)           # (mask, others) in channels 0, 1 of a ZEROED 64-channel tensor: a whole K tile
     m16 = P.buf('m16', (K, h, w), F32)
     P.ol.mask_down(Dyn('last_mask'), pair, m16, K=K, H=16 * h, W=16 * w, pair_channels=64)
     pixel = Act(Dyn('pixel'), K, h, w, m['value_dim'])
@@ -341,7 +439,7 @@ def build_readout_query(eng, K, h, w, last_aux=True):
         both = P.conv(t + '.pixel_init_R', pix_in, name='pixel_init_R', res=Act(eng.pe_r(h, w), 1, h, w, CR), res_bcast=True)
         pixel = Act(both.t, K, h, w, C, CR)
         R_of = lambda b: Act(both.t.view(-1)[C + b * 3 * C:], K, h, w, 3 * C, CR)
-    aux = f('aux_logits', (nb + 1, K, HW))
+    aux = P.buf('aux_logits', (nb + 1, K, HW), F32, persistent=True)      # read by the caller after the run
     fused_mask = HW <= 24576 and not UNFUSED                      # ATTN_Q2P derives the foreground mask from the logits itself (flags in LDS)
     fg = None if fused_mask else P.buf('fg', (K, HW), torch.uint8)
     nfg = None if fused_mask else P.buf('nfg', (K,), torch.int32)
@@ -442,7 +540,7 @@ def build_segment(eng, K, h, w, update_sensory, pre=False):
         # area-pooled g8 / g4 / logits written side by side: the second source of the ONE conv that replaces g16_conv + g8_conv +
         # g4_conv (Engine: '.g_all'); the logits take a whole 64-channel K tile (channel 0 written, the rest stays zero)
         CT = up[1] + up[2] + 64
-        gcat = P.buf('gcat', (K, h, w, CT))
+        gcat = P.buf('gcat', (K, h, w, CT), persistent=True)          # (the padding channels of the logits tile are zero from the allocation)
         ol.area_down3([dict(x=p8.t, y=gcat, B=K, H=h8, W=w8, C=up[1], ldx=up[1], ldy=CT, r=2),
                        dict(x=p4.t, y=gcat.view(-1)[up[1]:], B=K, H=h4, W=w4, C=up[2], ldx=up[2], ldy=CT, r=4),
                        dict(x=logits, y=gcat.view(-1)[up[1] + up[2]:], B=K, H=h4, W=w4, C=1, ldx=1, ldy=CT, r=4, f32_in=True, Cz=8)])

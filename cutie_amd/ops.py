@@ -243,8 +243,8 @@ def pick_tile(M, cout, cin=64, geom=None):
     if cout <= 16:
         return 3
     if geom is not None and dma_tiles_enabled() and dma_tile_ok(60, cin=cin, kh=geom['kh'], c2=geom.get('c2', 0)):
-        # order fitted on the sweeps of the 480p (K = 1, 2, 3) and 1080p (K = 5) geometries: 4 % above the per-layer best
-        cands = [t for t in (70, 63, 66, 82, 67) if dma_tile_ok(t, cin=cin, kh=geom['kh'], c2=geom.get('c2', 0))]
+        # order fitted on the cold-cache sweeps of the 480p (K = 1, 2, 3) and 1080p (K = 5) geometries (producer / consumer tiles)
+        cands = [t for t in (108, 103, 110, 101, 102) if pc_tile_ok(t, cin=cin, kh=geom['kh'], c2=geom.get('c2', 0))]
     else:
         cands = [6, 5, 9] if cin >= 32 else [4, 2]
     if cout <= 64:
