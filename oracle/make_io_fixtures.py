@@ -10,7 +10,12 @@ tests/test_io_fixtures_cpu.py runs the product classes on the same folder with t
 
 Two imports of the reference are not installable in this image and are shimmed HERE, in this script only:
   * torchvision.transforms: ToTensor is restated (uint8 HWC -> float CHW / 255, torchvision/transforms/functional.py to_tensor);
-    Resize is NOT restated -- it raises, so only calls that do not resize are recorded (size=-1, no size_dir);
+    Resize(size: int) is restated with torchvision's semantics (transforms/functional.py resize, _compute_resized_output_size): the
+    short side becomes `size`, the long side int(size * long / short); a float TENSOR goes through
+    torch.nn.functional.interpolate(mode='bilinear', align_corners=False, antialias=True) (functional_tensor.resize), a PIL image
+    through Image.resize(NEAREST) (functional_pil.resize; PIL ignores `antialias`); an input whose short side already equals `size`
+    is returned as it is.  The reader resizes the image as a tensor (after ToTensor) and the mask as a PIL image
+    (video_reader.py:93-98,118-135);
   * pycocotools.mask: imported by results_utils.py for the BURST json writer only; a stub that raises if used.
 hickle (save_scores) is absent as well: that branch is not recorded.
 
@@ -47,6 +52,12 @@ READER_CASES = {
     'all_masks': ('Annotations', dict(use_all_masks=True)),
     'long_id': ('Annotations_long', {}),
     'greyscale': ('Annotations_L', {}),
+    # the `size` path (video_reader.py:93-98,118-135): antialiased bilinear image resize, nearest mask resize
+    'resize20': ('Annotations', dict(size=20)),
+    'resize20_all_masks': ('Annotations', dict(size=20, use_all_masks=True)),
+    'resize27_long_id': ('Annotations_long', dict(size=27)),
+    'size_not_smaller': ('Annotations', dict(size=32)),                # min side == size: no resize
+    'size_dir': ('Annotations', dict(size=20, size_dir='JPEGImages_half/v')),
 }
 
 
@@ -66,11 +77,26 @@ def install_shims():
             return torch.from_numpy(a).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
 
     class Resize:
-        def __init__(self, *a, **k):
-            pass
+        def __init__(self, size, interpolation=InterpolationMode.BILINEAR, max_size=None, antialias=True):
+            self.size, self.interpolation, self.antialias = size, interpolation, antialias
 
         def __call__(self, x):
-            raise NotImplementedError('torchvision.transforms.Resize is not restated by the fixture shim')
+            assert isinstance(self.size, int)
+            if isinstance(x, torch.Tensor):
+                h, w = x.shape[-2:]
+            else:
+                w, h = x.size
+            short, long = (w, h) if w <= h else (h, w)
+            if short == self.size:
+                return x
+            new_short, new_long = self.size, int(self.size * long / short)
+            nw, nh = (new_short, new_long) if w <= h else (new_long, new_short)
+            if isinstance(x, torch.Tensor):
+                assert x.is_floating_point() and self.interpolation == InterpolationMode.BILINEAR
+                return torch.nn.functional.interpolate(x.unsqueeze(0), size=[nh, nw], mode='bilinear', align_corners=False,
+                                                       antialias=bool(self.antialias))[0]
+            assert self.interpolation == InterpolationMode.NEAREST
+            return x.resize((nw, nh), Image.NEAREST)
 
     tr.ToTensor, tr.Resize, tr.InterpolationMode = ToTensor, Resize, InterpolationMode
     tv.transforms = tr
@@ -92,7 +118,7 @@ def make_video():
     """Deterministic 5-frame clip: smooth colour fields (JPEG-friendly), two moving boxes; annotations of frame 0 and frame 3."""
     if os.path.exists(VIDEO):
         shutil.rmtree(VIDEO)
-    for d in ('JPEGImages/v', 'Annotations/v', 'Annotations_long/v', 'Annotations_L/v'):
+    for d in ('JPEGImages/v', 'JPEGImages_half/v', 'Annotations/v', 'Annotations_long/v', 'Annotations_L/v'):
         os.makedirs(os.path.join(VIDEO, d))
     yy, xx = np.mgrid[0:H, 0:W]
     pal = []
@@ -106,6 +132,7 @@ def make_video():
         img[ids == 1] = (220, 40, 40)
         img[ids == 2] = (40, 60, 230)
         Image.fromarray(img).save(os.path.join(VIDEO, 'JPEGImages/v', f'{t:05d}.jpg'), quality=92)
+        Image.fromarray(img[::2, ::2]).save(os.path.join(VIDEO, 'JPEGImages_half/v', f'{t:05d}.jpg'), quality=92)      # (size_dir)
         if t in (0, 3):
             p = Image.fromarray(ids, mode='P')
             p.putpalette(pal)
@@ -171,6 +198,9 @@ def run_saver_case(ResultSaver, ObjectManager, VideoReader, name, out_root):
 def read_case(VideoReader, name):
     """Shared by the recorder and the test: everything a VideoReader hands out for one option combination, as flat arrays."""
     ann, kw = READER_CASES[name]
+    kw = dict(kw)
+    if 'size_dir' in kw:
+        kw['size_dir'] = os.path.join(VIDEO, kw['size_dir'])
     rd = VideoReader('v', os.path.join(VIDEO, 'JPEGImages/v'), os.path.join(VIDEO, ann, 'v'), **kw)
     out = {'len': np.array(len(rd)), 'use_long_id': np.array(bool(rd.use_long_id)),
            'palette': np.array(rd.get_palette() if rd.get_palette() is not None else [], dtype=np.int64)}

@@ -21,18 +21,25 @@ from cutie_amd.inference.object_manager import ObjectManager
 BF16, F32 = torch.bfloat16, torch.float32
 
 
-def inject_state(proc, o):
-    """Overwrite the recurrent state of the product ``InferenceCore`` with that of the ``OracleProcessor`` o."""
-    assert proc._flip is None and o._flip is None, 'teacher forcing covers the plain (non flip_aug) lane'
+def inject_state(proc, o, _om=None):
+    """Overwrite the recurrent state of the product ``InferenceCore`` with that of the ``OracleProcessor`` o -- both lanes when
+    flip_aug is on (the flipped lane has its own bank / sensory state / last mask and shares the object manager)."""
+    assert (proc._flip is None) == (o._flip is None), 'flip_aug must match'
     dev = proc.network.device
     lt = o.use_long_term
     proc.curr_ti, proc.last_mem_ti, proc.mem_every = o.curr_ti, o.last_mem_ti, o.mem_every
     proc._prefetched = None
     proc.image_feature_store._store.clear()
-    om = ObjectManager()
-    if o.obj_ids:
-        om.add_new_objects([int(x) for x in o.obj_ids])
+    if _om is None:
+        om = ObjectManager()
+        if o.obj_ids:
+            om.add_new_objects([int(x) for x in o.obj_ids])
+    else:
+        om = _om
     proc.object_manager = om
+    if o._flip is not None:
+        o._flip.obj_ids = list(o.obj_ids)
+        inject_state(proc._flip, o._flip, _om=om)
     mem = MemoryManager(cfg=proc.cfg, object_manager=om)
     proc.memory = mem
     mem.top_k = o.top_k

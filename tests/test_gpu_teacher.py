@@ -47,8 +47,24 @@ def nets(model):
     return _cache[model]
 
 
+# Ratchet: the worst per-frame deviations OBSERVED on the MI355X at the end of round 3 (tests/golden/observed_r03.json, written by
+# `CUTIE_RECORD_OBSERVED=path pytest tests/test_gpu_teacher.py`).  A run may exceed neither the reference's reduced-precision
+# envelope (above) nor 1.5 x what this build actually did -- a numerical regression that doubles the error inside the envelope fails.
+_OBS_PATH = os.path.join(S.GOLDEN_DIR, 'observed_r03.json')
+OBSERVED = json.load(open(_OBS_PATH)) if os.path.exists(_OBS_PATH) else {}
+_RECORD = os.environ.get('CUTIE_RECORD_OBSERVED')
+_recorded = {}
+
+
 def check_rows(rows, tag, model='base'):
     BOUNDS = ALL_BOUNDS[model]
+    wmax, wmean = max(r['max'] for r in rows), max(r['mean'] for r in rows)
+    if _RECORD:
+        _recorded[tag] = dict(max=wmax, mean=wmean, agree_all=min(r.get('agree_all', 1.0) for r in rows))
+        json.dump(_recorded, open(_RECORD, 'w'), indent=1, sort_keys=True)
+    if tag in OBSERVED:
+        o = OBSERVED[tag]
+        assert wmax <= 1.5 * o['max'] + 2e-3 and wmean <= 1.5 * o['mean'] + 2e-4, ('ratchet', tag, wmax, wmean, o)
     worst = max(rows, key=lambda r: r['max'])
     print(tag, 'worst frame', worst['t'], 'max %.4f' % worst['max'], 'worst mean %.5f' % max(r['mean'] for r in rows),
           'bound', BOUNDS['max'], BOUNDS['mean'], '| per frame:', [(r['t'], round(r['max'], 4), round(r['mean'], 5)) for r in rows])
@@ -64,7 +80,8 @@ def check_rows(rows, tag, model='base'):
 
 
 @pytest.mark.parametrize('model', ['base', 'small'])
-@pytest.mark.parametrize('name', ['small_fifo', 'small_lt', 'small_add_del', 'small_lt_overlap', 'small_clear:4', 'small_cfg_fifo:5'])
+@pytest.mark.parametrize('name', ['small_fifo', 'small_lt', 'small_add_del', 'small_lt_overlap', 'small_clear:4', 'small_cfg_fifo:5', 'small_flip', 'small_chunk',
+                                  'small_interactive:5', 'small_misc:5', 'small_video:6'])
 def test_teacher_forced_scenarios(name, model):
     """name[:n] = the first n frames of a scenario (the plain part before an event the harness does not replay)."""
     from cutie_amd.inference.inference_core import InferenceCore
@@ -106,3 +123,29 @@ def test_teacher_forced_1080p():
     rows = teacher.run_teacher_forced(_clip_steps(1080, 1920, 5, 7, seed=2), lambda: OracleProcessor(onet, dict(DEFAULT_CFG)),
                                       lambda: InferenceCore(net, cfg=cfgs({})), 'cuda', margins=(ALL_BOUNDS['base']['argmax_margin'],))
     check_rows(rows, '1080p K=5')
+
+
+def test_teacher_forced_480p_one_object():
+    """BASELINE configs[1]: 854x480, ONE object (M = 1620 per-object layers: other tile-table entries than the 3-object run), 30 frames
+    = 5 memory frames, every frame value-checked against the oracle from the oracle's state."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    net, onet, cfgs = nets('base')
+    rows = teacher.run_teacher_forced(_clip_steps(480, 854, 1, 30, seed=4), lambda: OracleProcessor(onet, dict(DEFAULT_CFG)),
+                                      lambda: InferenceCore(net, cfg=cfgs({})), 'cuda', margins=(ALL_BOUNDS['base']['argmax_margin'],))
+    assert len(rows) == 30
+    check_rows(rows, '480p K=1')
+
+
+@pytest.mark.parametrize('h,w,k,size,frames', [(1080, 1920, 2, 480, 6), (100, 120, 2, 80, 8)])
+def test_teacher_forced_internal_resize(h, w, k, size, frames):
+    """The max_internal_size path (inference_core.py:206-228, 321-326; scripting_demo.py:21): frame and index mask are resized on the
+    way in (bilinear / nearest-exact), the probabilities on the way out -- the RESIZE kernel on the GPU against the oracle's
+    F.interpolate, teacher-forced."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    net, onet, cfgs = nets('base')
+    over = dict(max_internal_size=size, mem_every=3)
+    rows = teacher.run_teacher_forced(_clip_steps(h, w, k, frames, seed=6), lambda: OracleProcessor(onet, dict(DEFAULT_CFG, **over)),
+                                      lambda: InferenceCore(net, cfg=cfgs(over)), 'cuda', margins=(ALL_BOUNDS['base']['argmax_margin'],))
+    check_rows(rows, f'resize {h}x{w}->{size}')
