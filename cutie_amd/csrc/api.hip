@@ -18,7 +18,7 @@ static int dispatch(const cutie_op* op, hipStream_t s) {
     switch (op->kind) {
         case CUTIE_OP_CONV: return launch_conv(op, s);
         case CUTIE_OP_QUERY_INIT: return (op->flags & 1) ? launch_attention(op, s) : launch_elementwise(op, s);
-        case CUTIE_OP_AUX_MASK: case CUTIE_OP_ATTN_Q2P: case CUTIE_OP_ATTN_SELF: case CUTIE_OP_ATTN_P2Q:
+        case CUTIE_OP_AUX_MASK: case CUTIE_OP_ATTN_Q2P: case CUTIE_OP_ATTN_SELF: case CUTIE_OP_ATTN_P2Q: case CUTIE_OP_QFFN:
             return launch_attention(op, s);
         case CUTIE_OP_KEY_PREP: case CUTIE_OP_AFF_SCORE: case CUTIE_OP_AFF_SELECT: case CUTIE_OP_AFF_READOUT:
             return launch_affinity(op, s);
@@ -105,7 +105,7 @@ float cutie_time_ops(const cutie_op* ops, int n, int iters, void* stream) {
 }
 
 const char* cutie_hip_last_error(void) { return g_err; }
-int cutie_hip_abi_version(void) { return 1; }
+int cutie_hip_abi_version(void) { return 2; }
 int cutie_op_struct_size(void) { return (int)sizeof(cutie_op); }
 
 }  // extern "C"

@@ -54,6 +54,7 @@ TUNE_REPS, TUNE_ITERS = (int(v) for v in os.environ.get('CUTIE_AMD_TUNE', '3x8')
 # geometries take the deterministic static choice of ops.pick_tile and results are bit-reproducible across processes.
 # diagnostic: $CUTIE_AMD_UNFUSED=1 restores the unfused launch sequences of round 1 for in-box A/B timing (tools/r2_call*.sh)
 UNFUSED = os.environ.get('CUTIE_AMD_UNFUSED', '0') not in ('', '0')
+QCHAIN = os.environ.get('CUTIE_AMD_QCHAIN', '1') not in ('', '0')     # query side of a transformer block in 4 launches (0: the round-2 seven)
 AUTOTUNE = os.environ.get('CUTIE_AMD_AUTOTUNE', '0') not in ('', '0')
 PACKAGED_TILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tiles_gfx950.json')
 
@@ -447,6 +448,7 @@ def build_readout_query(eng, K, h, w, last_aux=True):
     if not fused_mask:
         ol.aux_mask(aux[0], fg, nfg, K=K, HW=HW)
     x = query
+    prev_parts = None
     for b in range(nb):
         q = f'{t}.blocks.{b}'
         n = f'b{b}.'
@@ -456,44 +458,71 @@ def build_readout_query(eng, K, h, w, last_aux=True):
         # block is fused into the linear that consumes it (the normalised rows are kept where the reference reuses them).
         ln = lambda name: (W[q + name + '.weight'], W[q + name + '.bias'])
         xn = f(n + 'xn', (M, C))
-        att = f(n + 'att', (M, C))
         fuse_proj = fused_mask and C == 256 and not UNFUSED      # the small projections run inside the attention launches
-        if fuse_proj:
-            ol.attn_q2p(None, kvq.t, None, None, att, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=aux[b],
-                        proj=dict(x=x, W=W[q + '.read_from_pixel.q'], emb=query_emb, ln=ln('.read_from_pixel.norm'), ln_out=xn))
-        else:
-            qp = f(n + 'qp', (M, C))
-            ol.linear(x, W[q + '.read_from_pixel.q'], qp, M=M, x_add=query_emb, add_rows=M, ln=ln('.read_from_pixel.norm'), ln_out=xn)
-            ol.attn_q2p(qp, kvq.t, fg, nfg, att, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=aux[b] if fused_mask else None)
-        x1 = f(n + 'x1', (M, C))
-        ol.linear(att, W[q + '.read_from_pixel.out'], x1, M=M, res=xn)
-        # self attention (transformer_layers.py:28-41): q | k | v in one launch, the query PE feeds q and k only
-        y = f(n + 'y', (M, C))
-        sa = f(n + 'sa', (M, C))
-        if fuse_proj:
-            ol.attn_self(None, None, sa, K=K, Q=Q, C=C, heads=heads,
-                         proj=dict(x=x1, W=W[q + '.self_attn.qkv'], emb=query_emb, ln=ln('.self_attn.norm'), ln_out=y))
-        else:
-            qkv = f(n + 'qkv', (M, 3 * C))
-            ol.linear(x1, W[q + '.self_attn.qkv'], qkv, M=M, x_add=query_emb, add_rows=M, add_cols=2 * C, ln=ln('.self_attn.norm'), ln_out=y)
-            ol.attn_self(qkv, qkv.view(-1)[2 * C:], sa, K=K, Q=Q, C=C, heads=heads, ldqk=3 * C, ldv=3 * C)
-        x2 = f(n + 'x2', (M, C))
-        ol.linear(sa, W[q + '.self_attn.out'], x2, M=M, res=y)
-        # FFN (transformer_layers.py:113-118)
-        hid = f(n + 'hid', (M, ot['ff_dim']))
-        ol.linear(x2, W[q + '.ffn.linear1'], hid, M=M, relu=True, ln=ln('.ffn.norm'))
-        x3 = f(n + 'x3', (M, C))
-        ol.linear(hid, W[q + '.ffn.linear2'], x3, M=M, res=x2)
-        x = x3
-        # read_from_query (no norm, residual on the pixels): k | v of the queries in one launch
-        pa = P.buf(n + 'pa', (K, h, w, C))
-        if fuse_proj:
+        chain = fuse_proj and QCHAIN and heads == 8 and ot['ff_dim'] % 256 == 0
+        if chain:
+            # The query side of a block in FOUR launches (was seven): each attention launch also applies its output projection, per
+            # head, and hands the 8 partial products on; the consumer sums them (+ bias + residual) while it stages its rows.  The FFN
+            # is one launch over 8 slices of its hidden layer, handing on 8 partial sums the same way (ops.OpList._proj_extras, QFFN).
+            xparts = None if b == 0 else prev_parts                 # x = x2 + b2 + sum of the previous block's FFN parts
+            Wo1, Wo2 = W[q + '.read_from_pixel.out'], W[q + '.self_attn.out']
+            W1, W2 = W[q + '.ffn.linear1'], W[q + '.ffn.linear2']
+            S = ot['ff_dim'] // 256
+            p1 = f(n + 'parts_q2p', (heads, M, C))
+            ol.attn_q2p(None, kvq.t, None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=aux[b],
+                        proj=dict(x=x, W=W[q + '.read_from_pixel.q'], emb=query_emb, ln=ln('.read_from_pixel.norm'), ln_out=xn),
+                        parts=xparts, out_proj=(Wo1, p1))
+            y = f(n + 'y', (M, C))
+            p2 = f(n + 'parts_self', (heads, M, C))
+            ol.attn_self(None, None, None, K=K, Q=Q, C=C, heads=heads,
+                         proj=dict(x=xn, W=W[q + '.self_attn.qkv'], emb=query_emb, ln=ln('.self_attn.norm'), ln_out=y),
+                         parts=(p1, heads, Wo1.bias), out_proj=(Wo2, p2))
+            x2 = f(n + 'x2', (M, C))
+            p3 = f(n + 'parts_ffn', (S, M, C))
+            ol.qffn(y, x2, p3, rows=M, ln=ln('.ffn.norm'), W1=W1, W2=W2, parts=(p2, heads, Wo2.bias))
+            x = x2
+            prev_parts = (p3, S, W2.bias)
+            pa = P.buf(n + 'pa', (K, h, w, C))
             ol.attn_p2q(kvq.t.view(-1)[2 * C:], None, None, pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C,
-                        proj=dict(x=x, W=W[q + '.read_from_query.kv'], emb=query_emb))
+                        proj=dict(x=x, W=W[q + '.read_from_query.kv'], emb=query_emb), parts=prev_parts)
         else:
-            kv2 = f(n + 'kv2', (M, 2 * C))
-            ol.linear(x, W[q + '.read_from_query.kv'], kv2, M=M, x_add=query_emb, add_rows=M, add_cols=C)
-            ol.attn_p2q(kvq.t.view(-1)[2 * C:], kv2, kv2.view(-1)[C:], pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C, ldkv=2 * C)
+            att = f(n + 'att', (M, C))
+            if fuse_proj:
+                ol.attn_q2p(None, kvq.t, None, None, att, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=aux[b],
+                            proj=dict(x=x, W=W[q + '.read_from_pixel.q'], emb=query_emb, ln=ln('.read_from_pixel.norm'), ln_out=xn))
+            else:
+                qp = f(n + 'qp', (M, C))
+                ol.linear(x, W[q + '.read_from_pixel.q'], qp, M=M, x_add=query_emb, add_rows=M, ln=ln('.read_from_pixel.norm'), ln_out=xn)
+                ol.attn_q2p(qp, kvq.t, fg, nfg, att, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=aux[b] if fused_mask else None)
+            x1 = f(n + 'x1', (M, C))
+            ol.linear(att, W[q + '.read_from_pixel.out'], x1, M=M, res=xn)
+            # self attention (transformer_layers.py:28-41): q | k | v in one launch, the query PE feeds q and k only
+            y = f(n + 'y', (M, C))
+            sa = f(n + 'sa', (M, C))
+            if fuse_proj:
+                ol.attn_self(None, None, sa, K=K, Q=Q, C=C, heads=heads,
+                             proj=dict(x=x1, W=W[q + '.self_attn.qkv'], emb=query_emb, ln=ln('.self_attn.norm'), ln_out=y))
+            else:
+                qkv = f(n + 'qkv', (M, 3 * C))
+                ol.linear(x1, W[q + '.self_attn.qkv'], qkv, M=M, x_add=query_emb, add_rows=M, add_cols=2 * C, ln=ln('.self_attn.norm'), ln_out=y)
+                ol.attn_self(qkv, qkv.view(-1)[2 * C:], sa, K=K, Q=Q, C=C, heads=heads, ldqk=3 * C, ldv=3 * C)
+            x2 = f(n + 'x2', (M, C))
+            ol.linear(sa, W[q + '.self_attn.out'], x2, M=M, res=y)
+            # FFN (transformer_layers.py:113-118)
+            hid = f(n + 'hid', (M, ot['ff_dim']))
+            ol.linear(x2, W[q + '.ffn.linear1'], hid, M=M, relu=True, ln=ln('.ffn.norm'))
+            x3 = f(n + 'x3', (M, C))
+            ol.linear(hid, W[q + '.ffn.linear2'], x3, M=M, res=x2)
+            x = x3
+            # read_from_query (no norm, residual on the pixels): k | v of the queries in one launch
+            pa = P.buf(n + 'pa', (K, h, w, C))
+            if fuse_proj:
+                ol.attn_p2q(kvq.t.view(-1)[2 * C:], None, None, pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C,
+                            proj=dict(x=x, W=W[q + '.read_from_query.kv'], emb=query_emb))
+            else:
+                kv2 = f(n + 'kv2', (M, 2 * C))
+                ol.linear(x, W[q + '.read_from_query.kv'], kv2, M=M, x_add=query_emb, add_rows=M, add_cols=C)
+                ol.attn_p2q(kvq.t.view(-1)[2 * C:], kv2, kv2.view(-1)[C:], pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C, ldkv=2 * C)
         pf = P.conv(q + '.read_from_query.out', Act(pa, K, h, w, C), name=n + 'pf', res=pixel)
         # PixelFFN (transformer_layers.py:121-136)
         last = b == nb - 1

@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 
-NI, NF, NP = 24, 6, 10
+NI, NF, NP = 24, 6, 16
 OP_DTYPE = np.dtype([('kind', '<i4'), ('flags', '<i4'), ('i', '<i4', (NI,)), ('f', '<f4', (NF,)), ('p', '<u8', (NP,))])
 assert OP_DTYPE.itemsize == _lib.OP_STRUCT_SIZE
 
@@ -19,13 +19,13 @@ assert OP_DTYPE.itemsize == _lib.OP_STRUCT_SIZE
 (CONV, MAXPOOL, IMG_PREP, UPSAMPLE2X_ADD, AREA_DOWN, MASK_DOWN, GAP, ECA_APPLY, GRU, SEG_AGG, UP4_SOFTMAX,
  MASK_MERGE, AGG_SOFTMAX, LINEAR, LAYERNORM, QUERY_INIT, AUX_MASK, ATTN_Q2P, ATTN_SELF, ATTN_P2Q, SUMMARIZE,
  ADD_PE, KEY_PREP, AFF_SCORE, AFF_SELECT, AFF_READOUT, MEMSET32, COPY2D, AXPY, USAGE_TICK, RANK_SELECT,
- GATHER_ROWS, CONSOL_AFF, CONSOL_READ, CAST, PROB_TO_ID, RESIZE, FLIP_W, AREA_DOWN3) = range(1, 40)
+ GATHER_ROWS, CONSOL_AFF, CONSOL_READ, CAST, PROB_TO_ID, RESIZE, FLIP_W, AREA_DOWN3, QFFN) = range(1, 41)
 
 KIND_NAMES = {}
 for _n in ('CONV MAXPOOL IMG_PREP UPSAMPLE2X_ADD AREA_DOWN MASK_DOWN GAP ECA_APPLY GRU SEG_AGG UP4_SOFTMAX MASK_MERGE '
            'AGG_SOFTMAX LINEAR LAYERNORM QUERY_INIT AUX_MASK ATTN_Q2P ATTN_SELF ATTN_P2Q SUMMARIZE ADD_PE KEY_PREP '
            'AFF_SCORE AFF_SELECT AFF_READOUT MEMSET32 COPY2D AXPY USAGE_TICK RANK_SELECT GATHER_ROWS CONSOL_AFF '
-           'CONSOL_READ CAST PROB_TO_ID RESIZE FLIP_W AREA_DOWN3').split():
+           'CONSOL_READ CAST PROB_TO_ID RESIZE FLIP_W AREA_DOWN3 QFFN').split():
     KIND_NAMES[globals()[_n]] = _n
 
 F_RELU_IN, F_OUT_F32, F_RES_BCAST = 1, 2, 4
@@ -445,30 +445,64 @@ class OpList:
         assert proj['W'].kd == 256
         return proj.get('ldx', 256), proj.get('ln_out'), [proj['W'].weight, proj['W'].bias, proj.get('emb'), ln[0], ln[1]]
 
-    def attn_q2p(self, q, kv, fg, nfg, y, *, K, Q, HW, C, heads, ldkv, voff, logits=None, proj=None):
+    @staticmethod
+    def _proj_extras(flags, ints, ptrs, parts, out_proj):
+        """parts = (tensor f32 [n, K*Q, 256], n, bias | None): the rows are x + bias + sum of the parts (flags&4: p10, p11, i8).
+        out_proj = (PackedLinear Wo [256,256], part f32 [heads, K*Q, 256]): per-head output projection inside the launch (flags&8: p12, p13);
+        its bias is NOT applied -- the consumer adds it through its own parts=(..., bias)."""
+        ints = list(ints) + [0] * (9 - len(ints))
+        ptrs = list(ptrs) + [None] * (14 - len(ptrs))
+        if parts is not None:
+            flags |= 4
+            ptrs[10], ints[8], ptrs[11] = parts[0], parts[1], parts[2]
+        if out_proj is not None:
+            assert out_proj[0].kd == 256 and out_proj[0].n == 256
+            flags |= 8
+            ptrs[12], ptrs[13] = out_proj[0].weight, out_proj[1]
+        return flags, ints, ptrs
+
+    def attn_q2p(self, q, kv, fg, nfg, y, *, K, Q, HW, C, heads, ldkv, voff, logits=None, proj=None, parts=None, out_proj=None):
         """logits given: the foreground mask is derived inside the kernel from the mask_pred logits (AUX_MASK fused; fg / nfg unused).
-        proj given (needs logits): q = (LN(x) + emb) Wq^T + b is computed inside the launch from the unprojected rows proj['x']."""
+        proj given (needs logits): q = (LN(x) + emb) Wq^T + b is computed inside the launch from the unprojected rows proj['x'].
+        parts / out_proj (need proj): see _proj_extras; with out_proj, y may be None."""
         if proj is not None:
             assert logits is not None
             ldx, ln_out, tail = self._proj(proj)
-            return self.add(ATTN_Q2P, 3, [K, Q, HW, C, heads, ldkv, voff, ldx], [], [proj['x'], kv, logits, ln_out, y] + tail)
+            flags, ints, ptrs = self._proj_extras(3, [K, Q, HW, C, heads, ldkv, voff, ldx], [proj['x'], kv, logits, ln_out, y] + tail, parts, out_proj)
+            return self.add(ATTN_Q2P, flags, ints, [], ptrs)
+        assert parts is None and out_proj is None
         if logits is not None:
             return self.add(ATTN_Q2P, 1, [K, Q, HW, C, heads, ldkv, voff], [], [q, kv, logits, None, y])
         return self.add(ATTN_Q2P, 0, [K, Q, HW, C, heads, ldkv, voff], [], [q, kv, fg, nfg, y])
 
-    def attn_self(self, qk, v, y, *, K, Q, C, heads, ldqk=0, ldv=0, proj=None):
+    def attn_self(self, qk, v, y, *, K, Q, C, heads, ldqk=0, ldv=0, proj=None, parts=None, out_proj=None):
         """proj given: q | k | v = packed in-projection of (LN(x) + emb | LN(x) + emb | LN(x)) computed inside the launch."""
         if proj is not None:
             ldx, ln_out, tail = self._proj(proj)
-            return self.add(ATTN_SELF, 2, [K, Q, C, heads, 0, 0, ldx], [], [proj['x'], None, y, ln_out, None] + tail)
+            flags, ints, ptrs = self._proj_extras(2, [K, Q, C, heads, 0, 0, ldx], [proj['x'], None, y, ln_out, None] + tail, parts, out_proj)
+            return self.add(ATTN_SELF, flags, ints, [], ptrs)
+        assert parts is None and out_proj is None
         return self.add(ATTN_SELF, 0, [K, Q, C, heads, ldqk, ldv], [], [qk, v, y])
 
-    def attn_p2q(self, q, kq, vq, y, *, K, Q, HW, C, heads, ldq, ldkv=0, proj=None):
+    def attn_p2q(self, q, kq, vq, y, *, K, Q, HW, C, heads, ldq, ldkv=0, proj=None, parts=None):
         """proj given: k | v of the object queries = packed [k | v] projection of (x + emb | x) computed inside the launch."""
         if proj is not None:
             ldx, _, tail = self._proj(proj)
-            return self.add(ATTN_P2Q, 2, [K, Q, HW, C, heads, ldq, ldkv, ldx], [], [q, proj['x'], None, y, None] + tail[:3])
+            flags, ints, ptrs = self._proj_extras(2, [K, Q, HW, C, heads, ldq, ldkv, ldx], [q, proj['x'], None, y, None] + tail[:3], parts, None)
+            return self.add(ATTN_P2Q, flags, ints, [], ptrs)
+        assert parts is None
         return self.add(ATTN_P2Q, 0, [K, Q, HW, C, heads, ldq, ldkv], [], [q, kq, vq, y])
+
+    def qffn(self, x, x_out, part, *, rows, ln, W1, W2, parts=None):
+        """FFN of a transformer block in one launch: part[s] = relu(LN(x_eff) W1_s^T + b1_s) W2[:, s]^T for the S = FF/256 slices of the
+        hidden layer; x_eff = x (+ bias + sum of parts) is written to x_out.  W2's bias is left to the consumer (W2.bias)."""
+        FF = W1.n
+        assert W1.kd == 256 and W2.kd == FF and W2.n == 256 and FF % 256 == 0 and rows % 16 == 0
+        ints = [rows, FF] + [0] * 7
+        ptrs = [x, x_out, ln[0], ln[1], W1.weight, W1.bias, W2.weight, part] + [None] * 6
+        if parts is not None:
+            ptrs[10], ints[8], ptrs[11] = parts[0], parts[1], parts[2]
+        return self.add(QFFN, 0, ints, [], ptrs)
 
     def summarize(self, feat, wl, m16, y, *, K, HW, C, Q, scratch=None):
         if scratch is None:

@@ -321,9 +321,30 @@ class MockExecutor:
         view(p[1], F32, (rows, C)).copy_(vals)
 
     @staticmethod
-    def _proj_rows(p, M, ldx, ln_out_slot):
+    def _partial_sum(x, flags, i, p, M, always=False):
+        """flags&4 (QFFN: whenever p10 is given): x_eff = x + p11 + sum_s p10[s]."""
+        if (flags & 4 or always) and p[10]:
+            if p[11]:
+                x = x + view(p[11], F32, (256,))
+            parts = view(p[10], F32, (i[8], M, 256))
+            for s_ in range(i[8]):
+                x = x + parts[s_]
+        return x
+
+    @staticmethod
+    def _out_parts(flags, p, att, M, heads):
+        """flags&8: part[h] = att[:, 32h:32h+32] . Wo[:, 32h:32h+32]^T into p13 (f32 [heads, M, 256])."""
+        if flags & 8:
+            Wo = view(p[12], BF16, (256, 256)).float()
+            out = view(p[13], F32, (heads, M, 256))
+            a = att.reshape(M, 256)
+            for h in range(heads):
+                out[h].copy_(a[:, 32 * h:32 * h + 32] @ Wo[:, 32 * h:32 * h + 32].t())
+
+    def _proj_rows(self, p, M, ldx, ln_out_slot, flags=0, i=None):
         """Fused projection operands (ops.OpList._proj): -> (LN(x) + emb, LN(x), W [N,256] fp32, bias)."""
         x = view(p[0 if ln_out_slot != -1 else 1], F32, (M, 256), (ldx, 1)).clone()
+        x = self._partial_sum(x, flags, i, p, M)
         if p[8]:
             x = F.layer_norm(x, (256,), view(p[8], F32, (256,)), view(p[9], F32, (256,)), 1e-5)
             if ln_out_slot >= 0 and p[ln_out_slot]:
@@ -345,7 +366,7 @@ class MockExecutor:
         K, Q, HW, C, heads, ldkv, voff = i[:7]
         hd = C // heads
         if flags & 2:                                                   # q projection fused
-            xa, _ = self._proj_rows(p, K * Q, i[7] or 256, 3)
+            xa, _ = self._proj_rows(p, K * Q, i[7] or 256, 3, flags, i)
             qp = xa @ view(p[5], BF16, (C, 256)).float().t() + (view(p[6], F32, (C,)) if p[6] else 0)
             q = qp.view(K, Q, heads, hd).transpose(1, 2)
         else:
@@ -368,13 +389,15 @@ class MockExecutor:
             if n != HW:
                 att[kk, :, Q // 2:, :] = att[kk, :, Q // 2:, :].masked_fill(fg[kk], float('-inf'))
         out = (att.softmax(-1) @ v).transpose(1, 2).reshape(K, Q, C)
-        view(p[4], F32, (K, Q, C)).copy_(out)
+        if p[4]:
+            view(p[4], F32, (K, Q, C)).copy_(out)
+        self._out_parts(flags, p, out, K * Q, heads)
 
     def _op_19(self, flags, i, f, p):
         K, Q, C, heads, ldqk, ldv = i[:6]
         hd = C // heads
         if flags & 2:                                                   # qkv projection fused
-            xa, xp = self._proj_rows(p, K * Q, i[6] or 256, 3)
+            xa, xp = self._proj_rows(p, K * Q, i[6] or 256, 3, flags, i)
             Wt = view(p[5], BF16, (3 * C, 256)).float()
             b = view(p[6], F32, (3 * C,)) if p[6] else torch.zeros(3 * C)
             q = (xa @ Wt[:C].t() + b[:C]).view(K, Q, heads, hd).transpose(1, 2)
@@ -387,7 +410,10 @@ class MockExecutor:
             k = qk[..., C:].reshape(K, Q, heads, hd).transpose(1, 2)
             v = view(p[1], F32, (K, Q, C), (Q * ldv, ldv, 1)).reshape(K, Q, heads, hd).transpose(1, 2)
         att = ((q @ k.transpose(-1, -2)) / math.sqrt(hd)).softmax(-1)
-        view(p[2], F32, (K, Q, C)).copy_((att @ v).transpose(1, 2).reshape(K, Q, C))
+        out = (att @ v).transpose(1, 2).reshape(K, Q, C)
+        if p[2]:
+            view(p[2], F32, (K, Q, C)).copy_(out)
+        self._out_parts(flags, p, out, K * Q, heads)
 
     def _op_20(self, flags, i, f, p):
         K, Q, HW, C, heads, ldq, ldkv = i[:7]
@@ -395,7 +421,7 @@ class MockExecutor:
         ldkv = ldkv or C
         q = view(p[0], BF16, (K, HW, C), (HW * ldq, ldq, 1)).float().view(K, HW, heads, hd).transpose(1, 2)
         if flags & 2:                                                   # kv projection fused (no LayerNorm; p1 = x)
-            x = view(p[1], F32, (K * Q, 256), (i[7] or 256, 1))
+            x = self._partial_sum(view(p[1], F32, (K * Q, 256), (i[7] or 256, 1)), flags, i, p, K * Q)
             xa = x + view(p[7], F32, (K * Q, 256)) if p[7] else x
             Wt = view(p[5], BF16, (2 * C, 256)).float()
             b = view(p[6], F32, (2 * C,)) if p[6] else torch.zeros(2 * C)
@@ -586,6 +612,21 @@ class MockExecutor:
         dt = F32 if flags & 1 else BF16
         V = view(p[1], dt, (n, C), (ldv, 1)).float()
         view(p[2], dt, (P, C), (ldo, 1)).copy_(aff @ V)
+
+    def _op_40(self, flags, i, f, p):                                   # QFFN
+        rows, FF = i[:2]
+        S = FF // 256
+        x = self._partial_sum(view(p[0], F32, (rows, 256)).clone(), flags, i, p, rows, always=True)
+        if p[1]:
+            view(p[1], F32, (rows, 256)).copy_(x)
+        xn = F.layer_norm(x, (256,), view(p[2], F32, (256,)), view(p[3], F32, (256,)), 1e-5)
+        W1 = view(p[4], BF16, (FF, 256)).float()
+        b1 = view(p[5], F32, (FF,)) if p[5] else torch.zeros(FF)
+        W2 = view(p[6], BF16, (256, FF)).float()
+        hid = torch.relu(xn @ W1.t() + b1)
+        part = view(p[7], F32, (S, rows, 256))
+        for s_ in range(S):
+            part[s_].copy_(hid[:, 256 * s_:256 * s_ + 256] @ W2[:, 256 * s_:256 * s_ + 256].t())
 
     def _op_38(self, flags, i, f, p):
         rows, W, slds, dlds = i[:4]

@@ -701,6 +701,85 @@ def test_attention_with_fused_projections(K):
     assert float((hip['pa'].float() - hip['pa_f'].float()).abs().max()) <= 2e-2 * float(hip['pa'].float().abs().max())
 
 
+@pytest.mark.parametrize('K,HW', [(1, 1620), (3, 1620), (2, 700), (2, 8040), (1, 37)])
+def test_query_chain_in_four_launches(K, HW):
+    """The query side of a transformer block as the frame runs it (ATTN_Q2P + per-head out-projection parts -> ATTN_SELF summing them,
+    + parts -> QFFN -> parts -> ATTN_P2Q) against the seven-launch sequence it replaces (LINEAR out-projections, linear1, linear2),
+    with a second block behind it so that ATTN_Q2P's partial-sum input is covered as well; both against the interpreter.
+    HW = 8040 (1080p): the pixel loop of ATTN_Q2P runs past its prefetched chunks; HW = 37: ragged single chunk."""
+    def build(dev, g):
+        Q, C, heads, FF = 16, 256, 8, 2048
+        M = K * Q
+        x0 = torch.randn((M, C), generator=g).to(dev)
+        emb = (torch.randn((M, C), generator=g) * 0.5).to(dev)
+        lnp = lambda: ((torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev))
+        mk = lambda n, kd=C: pack_linear(torch.randn((n, kd), generator=g) / (kd ** 0.5), torch.randn(n, generator=g) * 0.1, dev)
+        z = lambda *shape, dt=F32: torch.zeros(shape, dtype=dt, device=dev)
+        lg = _aux_inputs(g, K, HW, 'mixed').to(dev)
+        ol = O.OpList()
+        out = {}
+        blocks = []
+        for b in range(2):
+            blocks.append(dict(Wq=mk(C), Wo1=mk(C), Wqkv=mk(3 * C), Wo2=mk(C), W1=mk(FF), W2=mk(C, FF), Wkv=mk(2 * C),
+                               ln1=lnp(), ln2=lnp(), ln3=lnp(), kvq=rnd(g, (K, HW, 3 * C), dev=dev)))
+            ol.keep += [v.weight for v in blocks[-1].values() if hasattr(v, 'weight')]
+        # seven launches per block
+        x = x0
+        for b, B in enumerate(blocks):
+            qp, xn, att, x1 = z(M, C), z(M, C), z(M, C), z(M, C)
+            ol.attn_q2p(None, B['kvq'], None, None, att, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg,
+                        proj=dict(x=x, W=B['Wq'], emb=emb, ln=B['ln1'], ln_out=xn))
+            ol.linear(att, B['Wo1'], x1, M=M, res=xn)
+            y, sa, x2 = z(M, C), z(M, C), z(M, C)
+            ol.attn_self(None, None, sa, K=K, Q=Q, C=C, heads=heads, proj=dict(x=x1, W=B['Wqkv'], emb=emb, ln=B['ln2'], ln_out=y))
+            ol.linear(sa, B['Wo2'], x2, M=M, res=y)
+            hid, x3 = z(M, FF), z(M, C)
+            ol.linear(x2, B['W1'], hid, M=M, relu=True, ln=B['ln3'])
+            ol.linear(hid, B['W2'], x3, M=M, res=x2)
+            pa = z(K, HW, C, dt=BF16)
+            ol.attn_p2q(B['kvq'].view(-1)[2 * C:], None, None, pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C, proj=dict(x=x3, W=B['Wkv'], emb=emb))
+            out.update({f'x2_{b}': x2, f'pa_{b}': pa, f'y_{b}': y})
+            x = x3
+        # four launches per block
+        x, parts = x0, None
+        for b, B in enumerate(blocks):
+            xn, y, x2 = z(M, C), z(M, C), z(M, C)
+            p1, p2, p3 = z(heads, M, C), z(heads, M, C), z(FF // 256, M, C)
+            ol.attn_q2p(None, B['kvq'], None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg,
+                        proj=dict(x=x, W=B['Wq'], emb=emb, ln=B['ln1'], ln_out=xn), parts=parts, out_proj=(B['Wo1'], p1))
+            ol.attn_self(None, None, None, K=K, Q=Q, C=C, heads=heads, proj=dict(x=xn, W=B['Wqkv'], emb=emb, ln=B['ln2'], ln_out=y),
+                         parts=(p1, heads, B['Wo1'].bias), out_proj=(B['Wo2'], p2))
+            ol.qffn(y, x2, p3, rows=M, ln=B['ln3'], W1=B['W1'], W2=B['W2'], parts=(p2, heads, B['Wo2'].bias))
+            parts = (p3, FF // 256, B['W2'].bias)
+            pa = z(K, HW, C, dt=BF16)
+            ol.attn_p2q(B['kvq'].view(-1)[2 * C:], None, None, pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C,
+                        proj=dict(x=x2, W=B['Wkv'], emb=emb), parts=parts)
+            out.update({f'x2c_{b}': x2, f'pac_{b}': pa, f'yc_{b}': y, f'p3_{b}': p3})
+            x = x2
+        return ol, out
+    hip, ref = run_both(build, seed=31 + K)
+    check(hip, ref, name='query chain', rtol=4e-3)
+    for b in range(2):
+        for a_, c_ in ((f'x2_{b}', f'x2c_{b}'), (f'y_{b}', f'yc_{b}')):
+            d = float((hip[a_] - hip[c_]).abs().max())
+            assert d <= 2e-3 * max(1.0, float(hip[a_].abs().max())), (a_, d)
+        assert float((hip[f'pa_{b}'].float() - hip[f'pac_{b}'].float()).abs().max()) <= 2e-2 * float(hip[f'pa_{b}'].float().abs().max())
+
+
+def test_query_chain_rejects_bad_forms():
+    """flags 4 / 8 without the fused projection, QFFN with a ragged hidden size: refused by the library, nothing launched."""
+    ex = _lib.HipExecutor()
+    ol = O.OpList()
+    y = torch.zeros((16, 256), device='cuda')
+    ol.add(O.ATTN_SELF, 4, [1, 16, 256, 8, 0, 0], [], [y, y, y])
+    with pytest.raises(RuntimeError, match="flags 4"):
+        ex.run(ol.finalize())
+    ol = O.OpList()
+    ol.add(O.QFFN, 0, [16, 300], [], [y, y, y, y, y, y, y, y])
+    with pytest.raises(RuntimeError, match="qffn"):
+        ex.run(ol.finalize())
+
+
 @pytest.mark.parametrize('K', [1, 3, 5])
 def test_query_init_with_its_linears(K):
     def build(dev, g):

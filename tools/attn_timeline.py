@@ -1,0 +1,119 @@
+"""Where the time goes inside the query-side launches of a transformer block (ATTN_Q2P, ATTN_SELF, QFFN, ATTN_P2Q): cycle stamps of
+every wave (cutie_amd/csrc/attention.hip ATL, diagnostic library only), warm (back to back) and cold (a 192 MB copy in front of every
+launch, as inside a frame).  Needs the MI355X and the timeline library:
+
+    (cd cutie_amd/csrc && hipcc ... -DATT_TIMELINE -c attention.hip -o ../../tools/abl/attention_ATL.o && link -> tools/abl/libcutie_hip_ATL.so)
+    CUTIE_AMD_LIB=tools/abl/libcutie_hip_ATL.so python tools/attn_timeline.py [--K 3] [--HW 1620]
+
+Per launch: the hipEvent time of the launch alone (warm / cold), and per stamp id the min / mean / max over waves of the time since
+the block's first stamp, in us (cycle counter calibrated against the 100 MHz wall clock of the same stamps).
+Stamp ids: see the ATL(n) calls in attention.hip (0 = kernel entry; the last id = stores issued)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from cutie_amd import _lib, ops as O
+from cutie_amd.model.weights import pack_linear
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--K', type=int, default=3)
+    ap.add_argument('--HW', type=int, default=1620)
+    args = ap.parse_args()
+    assert 'ATL' in os.path.basename(_lib.LIB_PATH), 'set CUTIE_AMD_LIB to the timeline library'
+    ex = _lib.get_executor()
+    g = torch.Generator().manual_seed(0)
+    K, HW, Q, C, heads, FF = args.K, args.HW, 16, 256, 8, 2048
+    M = K * Q
+    dev = 'cuda'
+    rn = lambda *s, sc=1.0: (torch.randn(s, generator=g) * sc).to(dev)
+    mk = lambda n, kd=C: pack_linear(torch.randn((n, kd), generator=g) / (kd ** 0.5), torch.randn(n, generator=g) * 0.1, dev)
+    z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=dev)
+    lnp = lambda: ((torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev))
+    x, emb = rn(M, C), rn(M, C, sc=0.5)
+    lg = rn(K, HW, sc=2.0)
+    kvq = rn(K, HW, 3 * C).to(torch.bfloat16)
+    Wq, Wo1, Wqkv, Wo2, W1, W2, Wkv = mk(C), mk(C), mk(3 * C), mk(C), mk(FF), mk(C, FF), mk(2 * C)
+    ln1, ln2, ln3 = lnp(), lnp(), lnp()
+    xn, y, x2 = z(M, C), z(M, C), z(M, C)
+    p0, p1, p2, p3 = rn(8, M, C, sc=0.1), z(heads, M, C), z(heads, M, C), z(FF // 256, M, C)
+    pa = z(K, HW, C, dt=torch.bfloat16)
+    launches = []
+
+    def one(name, fn, blocks):
+        ol = O.OpList()
+        fn(ol)
+        tl = torch.zeros((blocks, 16, 16), dtype=torch.int64, device=dev)
+        ol.recs[-1][4].extend([0] * (16 - len(ol.recs[-1][4])))
+        ol.recs[-1][4][15] = tl.data_ptr()
+        ol.keep.append(tl)
+        launches.append((name, ol, tl))
+
+    one('ATTN_Q2P (+parts in, +out-proj)', lambda ol: ol.attn_q2p(None, kvq, None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg,
+        proj=dict(x=x, W=Wq, emb=emb, ln=ln1, ln_out=xn), parts=(p0, 8, W2.bias), out_proj=(Wo1, p1)), heads * K)
+    one('ATTN_SELF (+parts in, +out-proj)', lambda ol: ol.attn_self(None, None, None, K=K, Q=Q, C=C, heads=heads,
+        proj=dict(x=xn, W=Wqkv, emb=emb, ln=ln2, ln_out=y), parts=(p1, heads, Wo1.bias), out_proj=(Wo2, p2)), heads * K)
+    one('QFFN', lambda ol: ol.qffn(y, x2, p3, rows=M, ln=ln3, W1=W1, W2=W2, parts=(p2, heads, Wo2.bias)), (FF // 256) * K)
+    one('ATTN_P2Q (+parts in)', lambda ol: ol.attn_p2q(kvq.view(-1)[2 * C:], None, None, pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C,
+        proj=dict(x=x2, W=Wkv, emb=emb), parts=(p3, FF // 256, W2.bias)), -(-HW // 256) * heads * K)
+
+    src = torch.zeros(192 << 20, dtype=torch.uint8, device=dev)
+    dst = torch.zeros(192 << 20, dtype=torch.uint8, device=dev)
+    fl = O.OpList()
+    fl.copy2d(src, dst, rows=192, rowbytes=1 << 20, src_stride=1 << 20, dst_stride=1 << 20)
+    flush = fl.finalize()
+    for _ in range(3):
+        ex.run(flush)
+    torch.cuda.synchronize()
+    t_flush = min(ex.time_ops(flush, 10) for _ in range(3)) * 1e3
+    for name, ol, tl in launches:
+        arr = ol.finalize()
+        for _ in range(3):
+            ex.run(arr)
+        torch.cuda.synchronize()
+        warm = min(ex.time_ops(arr, 30) for _ in range(3)) * 1e3
+        seq = np.concatenate([flush, arr])
+        cold = min(ex.time_ops(seq, 10) for _ in range(3)) * 1e3 - t_flush
+        print(f'\n{name}: launch alone warm {warm:.2f} us, cold {cold:.2f} us  (with stamps)')
+        for mode in ('warm', 'cold'):
+            acc = []
+            for rep in range(5):
+                tl.zero_()
+                torch.cuda.synchronize()
+                if mode == 'cold':
+                    ex.run(flush)
+                else:
+                    ex.run(arr)
+                    torch.cuda.synchronize()
+                    tl.zero_()
+                    torch.cuda.synchronize()
+                ex.run(arr)
+                torch.cuda.synchronize()
+                acc.append(tl.cpu().numpy().astype(np.float64))
+            t = acc[-1]
+            used = t[:, :, 0] > 0                                              # waves that stamped
+            # calibration: cycles per 100 MHz tick over the longest span
+            cyc = (np.nanmax(np.where(t[:, :, :14] > 0, t[:, :, :14], np.nan), axis=2) - t[:, :, 0])[used]
+            wall = (t[:, :, 15] - t[:, :, 14])[used]
+            ok = wall > 0
+            mhz = float(np.sum(cyc[ok]) / np.sum(wall[ok]) * 100.0) if ok.any() else float('nan')
+            t0 = np.where(used, t[:, :, 0], np.inf).min(axis=1, keepdims=True)  # first entry of the block
+            w0 = np.where(used, t[:, :, 14], np.inf).min()
+            spread = (np.where(used, t[:, :, 14], np.nan).max() - w0) / 100.0   # us between the first and the last wave entering
+            print(f'  {mode}: shader clock ~{mhz:.0f} MHz; waves enter over {spread:.2f} us; last stamp of the grid {float((np.where(used, t[:, :, 15], np.nan)).max() - w0) / 100.0:.2f} us after the first')
+            for sid in range(14):
+                v = t[:, :, sid]
+                m = used & (v > 0)
+                if not m.any():
+                    continue
+                d = ((v - t0) / mhz)[m]
+                print(f'    stamp {sid:2d}: min {d.min():6.2f}  mean {d.mean():6.2f}  max {d.max():6.2f} us  ({int(m.sum())} waves)')
+
+
+if __name__ == '__main__':
+    main()
