@@ -18,7 +18,10 @@ static int dispatch(const cutie_op* op, hipStream_t s) {
     switch (op->kind) {
         case CUTIE_OP_CONV: return launch_conv(op, s);
         case CUTIE_OP_QUERY_INIT: return (op->flags & 1) ? launch_attention(op, s) : launch_elementwise(op, s);
-        case CUTIE_OP_AUX_MASK: case CUTIE_OP_ATTN_Q2P: case CUTIE_OP_ATTN_SELF: case CUTIE_OP_ATTN_P2Q: case CUTIE_OP_QFFN:
+        case CUTIE_OP_QFFN: return launch_qchain(op, s);
+        case CUTIE_OP_ATTN_Q2P: case CUTIE_OP_ATTN_SELF: case CUTIE_OP_ATTN_P2Q:
+            return (op->flags & 12) ? launch_qchain(op, s) : launch_attention(op, s);
+        case CUTIE_OP_AUX_MASK:
             return launch_attention(op, s);
         case CUTIE_OP_KEY_PREP: case CUTIE_OP_AFF_SCORE: case CUTIE_OP_AFF_SELECT: case CUTIE_OP_AFF_READOUT:
             return launch_affinity(op, s);

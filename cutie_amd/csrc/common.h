@@ -73,6 +73,7 @@ __device__ __forceinline__ float wave_max(float v) {
 int launch_conv(const cutie_op* op, hipStream_t s);
 int launch_elementwise(const cutie_op* op, hipStream_t s);   // everything in elementwise.hip
 int launch_attention(const cutie_op* op, hipStream_t s);     // attention.hip
+int launch_qchain(const cutie_op* op, hipStream_t s);        // qchain.hip: attention ops with flags 4 / 8, QFFN
 int launch_affinity(const cutie_op* op, hipStream_t s);      // affinity.hip
 int launch_bank(const cutie_op* op, hipStream_t s);          // bank.hip
 void cutie_set_error(const char* fmt, ...);

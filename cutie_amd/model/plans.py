@@ -55,6 +55,7 @@ TUNE_REPS, TUNE_ITERS = (int(v) for v in os.environ.get('CUTIE_AMD_TUNE', '3x8')
 # diagnostic: $CUTIE_AMD_UNFUSED=1 restores the unfused launch sequences of round 1 for in-box A/B timing (tools/r2_call*.sh)
 UNFUSED = os.environ.get('CUTIE_AMD_UNFUSED', '0') not in ('', '0')
 QCHAIN = os.environ.get('CUTIE_AMD_QCHAIN', '1') not in ('', '0')     # query side of a transformer block in 4 launches (0: the round-2 seven)
+QFFN_SLICE = int(os.environ.get('CUTIE_AMD_QFFN_SLICE', '64'))       # hidden columns per QFFN block (64 | 128)
 AUTOTUNE = os.environ.get('CUTIE_AMD_AUTOTUNE', '0') not in ('', '0')
 PACKAGED_TILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tiles_gfx950.json')
 
@@ -417,9 +418,12 @@ def build_readout_query(eng, K, h, w, last_aux=True):
     t = 'object_transformer'
     f = lambda name, shape: P.buf(name, shape, F32)
     query, query_emb = f('query', (M, C)), f('query_emb', (M, C))
+    use_chain = QCHAIN and not UNFUSED and C == 256 and Q == 16 and heads == 8 and HW <= 24576 and ot['ff_dim'] % QFFN_SLICE == 0
+    # fixed-point accumulators of the query chain (three per block), cleared by the first launch of the plan
+    qacc = P.buf('qacc', (3 * nb, M, C), torch.int64) if use_chain else None
     if C == 256 and Q == 16 and not UNFUSED:
         ol.query_init2(Dyn('obj_mem'), query, query_emb, rows=M, w_init=W[t + '.summary_to_query_init'], res_init=eng.rep_embedding('query_init', K),
-                       w_emb=W[t + '.summary_to_query_emb'], res_emb=eng.rep_embedding('query_emb', K))
+                       w_emb=W[t + '.summary_to_query_emb'], res_emb=eng.rep_embedding('query_emb', K), zero=qacc)
     else:
         vals = f('vals', (M, C))
         ol.query_init(Dyn('obj_mem'), vals, rows=M, C=C)
@@ -448,7 +452,7 @@ def build_readout_query(eng, K, h, w, last_aux=True):
     if not fused_mask:
         ol.aux_mask(aux[0], fg, nfg, K=K, HW=HW)
     x = query
-    prev_parts = None
+    prev_acc = None
     for b in range(nb):
         q = f'{t}.blocks.{b}'
         n = f'b{b}.'
@@ -459,32 +463,28 @@ def build_readout_query(eng, K, h, w, last_aux=True):
         ln = lambda name: (W[q + name + '.weight'], W[q + name + '.bias'])
         xn = f(n + 'xn', (M, C))
         fuse_proj = fused_mask and C == 256 and not UNFUSED      # the small projections run inside the attention launches
-        chain = fuse_proj and QCHAIN and heads == 8 and ot['ff_dim'] % 256 == 0
+        chain = fuse_proj and use_chain
         if chain:
             # The query side of a block in FOUR launches (was seven): each attention launch also applies its output projection, per
-            # head, and hands the 8 partial products on; the consumer sums them (+ bias + residual) while it stages its rows.  The FFN
-            # is one launch over 8 slices of its hidden layer, handing on 8 partial sums the same way (ops.OpList._proj_extras, QFFN).
-            xparts = None if b == 0 else prev_parts                 # x = x2 + b2 + sum of the previous block's FFN parts
+            # head, summed over the heads into a fixed-point accumulator; the next launch adds it (+ bias + residual) while it stages
+            # its rows.  The FFN is one launch over slices of its hidden layer, summed the same way (csrc/qchain.hip).
             Wo1, Wo2 = W[q + '.read_from_pixel.out'], W[q + '.self_attn.out']
             W1, W2 = W[q + '.ffn.linear1'], W[q + '.ffn.linear2']
-            S = ot['ff_dim'] // 256
-            p1 = f(n + 'parts_q2p', (heads, M, C))
+            a1, a2, a3 = qacc[3 * b], qacc[3 * b + 1], qacc[3 * b + 2]
             ol.attn_q2p(None, kvq.t, None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=aux[b],
                         proj=dict(x=x, W=W[q + '.read_from_pixel.q'], emb=query_emb, ln=ln('.read_from_pixel.norm'), ln_out=xn),
-                        parts=xparts, out_proj=(Wo1, p1))
+                        acc_in=prev_acc, out_proj=(Wo1, a1))
             y = f(n + 'y', (M, C))
-            p2 = f(n + 'parts_self', (heads, M, C))
             ol.attn_self(None, None, None, K=K, Q=Q, C=C, heads=heads,
                          proj=dict(x=xn, W=W[q + '.self_attn.qkv'], emb=query_emb, ln=ln('.self_attn.norm'), ln_out=y),
-                         parts=(p1, heads, Wo1.bias), out_proj=(Wo2, p2))
+                         acc_in=(a1, Wo1.bias), out_proj=(Wo2, a2))
             x2 = f(n + 'x2', (M, C))
-            p3 = f(n + 'parts_ffn', (S, M, C))
-            ol.qffn(y, x2, p3, rows=M, ln=ln('.ffn.norm'), W1=W1, W2=W2, parts=(p2, heads, Wo2.bias))
-            x = x2
-            prev_parts = (p3, S, W2.bias)
+            ol.qffn(y, x2, a3, rows=M, ln=ln('.ffn.norm'), W1=W1, W2=W2, acc_in=(a2, Wo2.bias), hid_slice=QFFN_SLICE)
+            x = x2                                                 # + b2 + a3 / 2^32: added by whoever reads x
+            prev_acc = (a3, W2.bias)
             pa = P.buf(n + 'pa', (K, h, w, C))
             ol.attn_p2q(kvq.t.view(-1)[2 * C:], None, None, pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C,
-                        proj=dict(x=x, W=W[q + '.read_from_query.kv'], emb=query_emb), parts=prev_parts)
+                        proj=dict(x=x, W=W[q + '.read_from_query.kv'], emb=query_emb), acc_in=prev_acc)
         else:
             att = f(n + 'att', (M, C))
             if fuse_proj:

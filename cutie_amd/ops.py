@@ -427,11 +427,17 @@ class OpList:
     def query_init(self, obj_mem, y, *, rows, C):
         return self.add(QUERY_INIT, 0, [rows, C], [], [obj_mem, y])
 
-    def query_init2(self, obj_mem, query, query_emb, *, rows, w_init, res_init, w_emb, res_emb):
-        """QUERY_INIT and the two linears that consume it in one launch (C = 256, 16 summaries per object)."""
+    def query_init2(self, obj_mem, query, query_emb, *, rows, w_init, res_init, w_emb, res_emb, zero=None):
+        """QUERY_INIT and the two linears that consume it in one launch (C = 256, 16 summaries per object).
+        zero = tensor: cleared as a side job (the fixed-point accumulators of the transformer blocks behind; size % 16 bytes == 0)."""
         assert w_init.kd == 256 and w_init.n == 256 and w_emb.kd == 256 and w_emb.n == 256 and rows % 16 == 0
-        return self.add(QUERY_INIT, 1, [rows, 256], [], [obj_mem, query, query_emb, w_init.weight, w_init.bias, res_init,
-                                                         w_emb.weight, w_emb.bias, res_emb])
+        nz = 0
+        if zero is not None:
+            nb = zero.numel() * zero.element_size()
+            assert nb % 16 == 0 and zero.is_contiguous()
+            nz = nb // 16
+        return self.add(QUERY_INIT, 1, [rows, 256, nz], [], [obj_mem, query, query_emb, w_init.weight, w_init.bias, res_init,
+                                                             w_emb.weight, w_emb.bias, res_emb, zero])
 
     def aux_mask(self, logits, fg, nfg, *, K, HW):
         self.memset32(nfg, K, 0)
@@ -445,63 +451,73 @@ class OpList:
         assert proj['W'].kd == 256
         return proj.get('ldx', 256), proj.get('ln_out'), [proj['W'].weight, proj['W'].bias, proj.get('emb'), ln[0], ln[1]]
 
+    QACC_SCALE = 4294967296.0    # fixed-point scale of the accumulators of the query chain (csrc/qchain.hip)
+
     @staticmethod
-    def _proj_extras(flags, ints, ptrs, parts, out_proj):
-        """parts = (tensor f32 [n, K*Q, 256], n, bias | None): the rows are x + bias + sum of the parts (flags&4: p10, p11, i8).
-        out_proj = (PackedLinear Wo [256,256], part f32 [heads, K*Q, 256]): per-head output projection inside the launch (flags&8: p12, p13);
-        its bias is NOT applied -- the consumer adds it through its own parts=(..., bias)."""
+    def _proj_extras(flags, ints, ptrs, acc_in, out_proj):
+        """acc_in = (acc int64 [K*Q, 256], bias | None): the rows are x + bias + acc / 2^32 (flags&4: p10, p11) -- acc holds the products
+        of the launch in front, summed over its blocks in fixed point.
+        out_proj = (PackedLinear Wo [256,256], acc int64 [K*Q, 256]): the output projection runs inside the launch, per head, and is
+        ADDED to acc (flags&8: p12, p13; cleared beforehand, e.g. by QUERY_INIT); its bias is left to the consumer (acc_in=(acc, Wo.bias))."""
         ints = list(ints) + [0] * (9 - len(ints))
         ptrs = list(ptrs) + [None] * (14 - len(ptrs))
-        if parts is not None:
+        if acc_in is not None:
+            assert acc_in[0].dtype == torch.int64
             flags |= 4
-            ptrs[10], ints[8], ptrs[11] = parts[0], parts[1], parts[2]
+            ptrs[10], ptrs[11] = acc_in[0], acc_in[1]
         if out_proj is not None:
-            assert out_proj[0].kd == 256 and out_proj[0].n == 256
+            assert out_proj[0].kd == 256 and out_proj[0].n == 256 and out_proj[1].dtype == torch.int64
             flags |= 8
             ptrs[12], ptrs[13] = out_proj[0].weight, out_proj[1]
         return flags, ints, ptrs
 
-    def attn_q2p(self, q, kv, fg, nfg, y, *, K, Q, HW, C, heads, ldkv, voff, logits=None, proj=None, parts=None, out_proj=None):
+    def attn_q2p(self, q, kv, fg, nfg, y, *, K, Q, HW, C, heads, ldkv, voff, logits=None, proj=None, acc_in=None, out_proj=None):
         """logits given: the foreground mask is derived inside the kernel from the mask_pred logits (AUX_MASK fused; fg / nfg unused).
         proj given (needs logits): q = (LN(x) + emb) Wq^T + b is computed inside the launch from the unprojected rows proj['x'].
-        parts / out_proj (need proj): see _proj_extras; with out_proj, y may be None."""
+        out_proj (needs proj; chain form, see _proj_extras): y is not written; acc_in optional."""
         if proj is not None:
             assert logits is not None
             ldx, ln_out, tail = self._proj(proj)
-            flags, ints, ptrs = self._proj_extras(3, [K, Q, HW, C, heads, ldkv, voff, ldx], [proj['x'], kv, logits, ln_out, y] + tail, parts, out_proj)
+            assert out_proj is not None or acc_in is None, 'the chain form of ATTN_Q2P needs out_proj'
+            flags, ints, ptrs = self._proj_extras(3, [K, Q, HW, C, heads, ldkv, voff, ldx], [proj['x'], kv, logits, ln_out, y] + tail, acc_in, out_proj)
             return self.add(ATTN_Q2P, flags, ints, [], ptrs)
-        assert parts is None and out_proj is None
+        assert acc_in is None and out_proj is None
         if logits is not None:
             return self.add(ATTN_Q2P, 1, [K, Q, HW, C, heads, ldkv, voff], [], [q, kv, logits, None, y])
         return self.add(ATTN_Q2P, 0, [K, Q, HW, C, heads, ldkv, voff], [], [q, kv, fg, nfg, y])
 
-    def attn_self(self, qk, v, y, *, K, Q, C, heads, ldqk=0, ldv=0, proj=None, parts=None, out_proj=None):
-        """proj given: q | k | v = packed in-projection of (LN(x) + emb | LN(x) + emb | LN(x)) computed inside the launch."""
+    def attn_self(self, qk, v, y, *, K, Q, C, heads, ldqk=0, ldv=0, proj=None, acc_in=None, out_proj=None):
+        """proj given: q | k | v = packed in-projection of (LN(x) + emb | LN(x) + emb | LN(x)) computed inside the launch.
+        out_proj (needs proj; chain form): y is not written; acc_in optional."""
         if proj is not None:
             ldx, ln_out, tail = self._proj(proj)
-            flags, ints, ptrs = self._proj_extras(2, [K, Q, C, heads, 0, 0, ldx], [proj['x'], None, y, ln_out, None] + tail, parts, out_proj)
+            assert out_proj is not None or acc_in is None, 'the chain form of ATTN_SELF needs out_proj'
+            flags, ints, ptrs = self._proj_extras(2, [K, Q, C, heads, 0, 0, ldx], [proj['x'], None, y, ln_out, None] + tail, acc_in, out_proj)
             return self.add(ATTN_SELF, flags, ints, [], ptrs)
-        assert parts is None and out_proj is None
+        assert acc_in is None and out_proj is None
         return self.add(ATTN_SELF, 0, [K, Q, C, heads, ldqk, ldv], [], [qk, v, y])
 
-    def attn_p2q(self, q, kq, vq, y, *, K, Q, HW, C, heads, ldq, ldkv=0, proj=None, parts=None):
-        """proj given: k | v of the object queries = packed [k | v] projection of (x + emb | x) computed inside the launch."""
+    def attn_p2q(self, q, kq, vq, y, *, K, Q, HW, C, heads, ldq, ldkv=0, proj=None, acc_in=None):
+        """proj given: k | v of the object queries = packed [k | v] projection of (x + emb | x) computed inside the launch.
+        acc_in (needs proj): chain form."""
         if proj is not None:
             ldx, _, tail = self._proj(proj)
-            flags, ints, ptrs = self._proj_extras(2, [K, Q, HW, C, heads, ldq, ldkv, ldx], [q, proj['x'], None, y, None] + tail[:3], parts, None)
+            flags, ints, ptrs = self._proj_extras(2, [K, Q, HW, C, heads, ldq, ldkv, ldx], [q, proj['x'], None, y, None] + tail[:3], acc_in, None)
             return self.add(ATTN_P2Q, flags, ints, [], ptrs)
-        assert parts is None
+        assert acc_in is None
         return self.add(ATTN_P2Q, 0, [K, Q, HW, C, heads, ldq, ldkv], [], [q, kq, vq, y])
 
-    def qffn(self, x, x_out, part, *, rows, ln, W1, W2, parts=None):
-        """FFN of a transformer block in one launch: part[s] = relu(LN(x_eff) W1_s^T + b1_s) W2[:, s]^T for the S = FF/256 slices of the
-        hidden layer; x_eff = x (+ bias + sum of parts) is written to x_out.  W2's bias is left to the consumer (W2.bias)."""
+    def qffn(self, x, x_out, acc_out, *, rows, ln, W1, W2, acc_in=None, hid_slice=64):
+        """FFN of a transformer block in one launch: acc_out += relu(LN(x_eff) W1^T + b1) W2^T in fixed point, summed over the FF / hid_slice
+        blocks of an object; x_eff = x (+ acc_in) is written to x_out.  W2's bias is left to the consumer (acc_in=(acc_out, W2.bias))."""
         FF = W1.n
-        assert W1.kd == 256 and W2.kd == FF and W2.n == 256 and FF % 256 == 0 and rows % 16 == 0
-        ints = [rows, FF] + [0] * 7
-        ptrs = [x, x_out, ln[0], ln[1], W1.weight, W1.bias, W2.weight, part] + [None] * 6
-        if parts is not None:
-            ptrs[10], ints[8], ptrs[11] = parts[0], parts[1], parts[2]
+        assert W1.kd == 256 and W2.kd == FF and W2.n == 256 and FF % hid_slice == 0 and hid_slice in (64, 128) and rows % 16 == 0
+        assert acc_out.dtype == torch.int64
+        ints = [rows, FF, hid_slice]
+        ptrs = [x, x_out, ln[0], ln[1], W1.weight, W1.bias, W2.weight, acc_out] + [None] * 6
+        if acc_in is not None:
+            assert acc_in[0].dtype == torch.int64
+            ptrs[10], ptrs[11] = acc_in[0], acc_in[1]
         return self.add(QFFN, 0, ints, [], ptrs)
 
     def summarize(self, feat, wl, m16, y, *, K, HW, C, Q, scratch=None):

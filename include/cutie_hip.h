@@ -130,7 +130,8 @@ enum {
     /* QUERY_INIT: obj_values = sums/(area+1e-4)   object_transformer.py:125-132
      * p0=obj_mem f32 [K,Q,C+1] p1=y f32 [K*Q,C]   i: 0 K*Q 1 C
      * flags&1 (C == 256, Q == 16): with the two linears that consume it (:137-138) -- p1=query p2=query_emb f32 [K*Q,256],
-     *      p3/p4/p5 = W bf16 [256,256], bias, residual f32 [K*Q,256] of summary_to_query_init (+ query_init.weight), p6/p7/p8 of ..._emb */
+     *      p3/p4/p5 = W bf16 [256,256], bias, residual f32 [K*Q,256] of summary_to_query_init (+ query_init.weight), p6/p7/p8 of ..._emb
+     *      side job: p9 (may be 0, 16-byte aligned) = a range of i2 x 16 bytes that is cleared (the accumulators of the chain forms below) */
     CUTIE_OP_QUERY_INIT = 16,
     /* AUX_MASK: foreground mask from mask_pred logits   object_transformer.py:179-205
      * p0=logits f32 [K,HW] p1=fg u8 [K,HW] p2=nfg i32 [K] (must be zeroed: MEMSET op before)
@@ -144,25 +145,26 @@ enum {
      * flags&2 (with flags&1, C == 256): the q projection runs inside the launch -- p0=x f32 [K*Q, i7] unprojected rows, p3=ln_out f32
      *      [K*Q,256] (LayerNorm'd rows, may be 0), p5=Wq bf16 [C,256] p6=bias f32 [C] p7=query embedding f32 [K*Q,256] (may be 0)
      *      p8/p9=LayerNorm gamma/beta (0: no norm): q = (LN(x) + emb) Wq^T + b   (the LINEAR op it replaces: transformer_layers.py:86-93)
-     * flags&4 (with flags&2): the rows are given as a sum -- x_eff = x + p11 (f32 [256] bias, may be 0) + sum_{s < i8} p10[s] with
-     *      p10 = f32 [i8, K*Q, 256] partial products of the launch in front (QFFN's slices, or the per-head out-projection parts)
-     * flags&8 (with flags&2): the output projection of the attention runs inside the launch, per head -- p12 = Wo bf16 [256, 256],
-     *      p13 = f32 [heads, K*Q, 256]: part[h] = att[:, 32h:32h+32] . Wo[:, 32h:32h+32]^T (bias and residual are added by the consumer
-     *      through its flags&4 form); p4 (att itself) may then be 0 */
+     * Chain form (flags&8, with flags 1|2; csrc/qchain.hip): the output projection runs inside the launch, per head, and is ADDED in
+     *      fixed point to p13 = int64 [K*Q, 256] (value x 2^32; integer atomics: the sum is independent of the order of arrival; the
+     *      caller clears it beforehand, e.g. QUERY_INIT's side job); p12 = Wo bf16 [256,256]; p4 is not written.  Wo's bias and the
+     *      residual are added by the consumer through ITS flags&4:
+     * flags&4 (chain form): the rows are a sum, x_eff = p0 + p11 (bias f32 [256], may be 0) + p10 / 2^32 (p10 = int64 [K*Q, 256]) */
     CUTIE_OP_ATTN_Q2P = 18,
     /* ATTN_SELF: 16x16 self attention per object  transformer_layers.py:12-41
      * p0=qk f32 [K,Q,ldqk] (q at +0, k at +C) p1=v f32 [K,Q,ldv] p2=y f32 [K,Q,C]
      * i: 0 K 1 Q 2 C 3 heads 4 ldqk (0: 2C) 5 ldv (0: C)
      * flags&2 (C == 256): the packed q|k|v in-projection runs inside the launch -- p0=x f32 [K*Q, i6], p3=ln_out (may be 0),
      *      p5=Wqkv bf16 [3C,256] p6=bias f32 [3C] p7=query embedding (q and k only) p8/p9=LayerNorm gamma/beta; p1 unused
-     * flags&4 / flags&8: as ATTN_Q2P (p10, p11, i8 = partial-sum input; p12, p13 = per-head out-projection parts, p2 may then be 0) */
+     * flags&8 (+ optional flags&4): chain form as ATTN_Q2P (p10, p11 = accumulator input; p12, p13 = output projection into an accumulator;
+     *      p2 is not written) */
     CUTIE_OP_ATTN_SELF = 19,
     /* ATTN_P2Q: pixels <- 16 queries cross attention  object_transformer.py:66-70
      * p0=q bf16 [K,HW,ldq] p1=kq f32 [K,Q,ldkv] p2=vq f32 [K,Q,ldkv] p3=y bf16 [K,HW,C]
      * i: 0 K 1 Q 2 HW 3 C 4 heads 5 ldq 6 ldkv (0: C)
      * flags&2 (C == 256): the packed k|v projection of the object queries runs inside the launch -- p1=x f32 [K*Q, i7],
      *      p5=Wkv bf16 [2C,256] p6=bias f32 [2C] p7=query embedding (k only); p2 unused
-     * flags&4: partial-sum input as ATTN_Q2P (p10, p11, i8) */
+     * flags&4: chain form, accumulator input as ATTN_Q2P (p10, p11) */
     CUTIE_OP_ATTN_P2Q = 20,
     /* SUMMARIZE: weights=sigmoid(logits)*[m x8 | (1-m) x8]; sums=einsum; area   object_summarizer.py:11-23
      * p0=feature bf16 [K,HW,C] p1=wlogits f32 [K,HW,Q] p2=m16 f32 [K,HW] p3=y f32 [K,Q,C+1]
@@ -246,11 +248,13 @@ enum {
      * segment q = 0..2: p[2q]=x p[2q+1]=y, i[8q..8q+7] = B H W C ldx ldy r Cz as in AREA_DOWN, flags bit q: f32 input */
     CUTIE_OP_AREA_DOWN3 = 39,
     /* QFFN: the FFN of a QueryTransformerBlock in one launch (transformer_layers.py:101-118: x + linear2(relu(linear1(norm(x))))),
-     * split over S = FF/256 slices of the hidden layer: grid (S, K).  Input rows as a sum (the self-attention out-projection parts):
-     * x_eff = p0 (f32 [K*16,256], the residual) + p11 (bias f32 [256], may be 0) + sum_{s < i8} p10[s]  (p10 = f32 [i8, K*16, 256], may be 0)
+     * split over FF / i2 slices of the hidden layer: grid (FF / i2, K).  Input rows as a sum (the self-attention out-projection):
+     * x_eff = p0 (f32 [K*16,256], the residual) + p11 (bias f32 [256], may be 0) + p10 / 2^32 (p10 = int64 [K*16, 256], may be 0)
      * p1 = x_out f32 [K*16,256] (x_eff, written once: the residual of the FFN)  p2/p3 = LayerNorm gamma/beta
-     * p4 = W1 bf16 [FF,256] p5 = b1 f32 [FF]  p6 = W2 bf16 [256,FF]  p7 = part f32 [S, K*16, 256]: part[s] = relu(LN(x_eff) W1_s^T + b1_s) W2[:, s]^T
-     * (linear2's bias and the residual x_out are added by the consumer: flags&4 of the attention ops).   i: 0 rows (K*16) 1 FF 8 npart */
+     * p4 = W1 bf16 [FF,256] p5 = b1 f32 [FF]  p6 = W2 bf16 [256,FF]
+     * p7 = int64 [K*16, 256]: += relu(LN(x_eff) W1^T + b1) W2^T in fixed point (x 2^32), slice by slice (cleared by the caller).
+     * linear2's bias and the residual x_out are added by the consumer (flags&4 of the attention ops).
+     * i: 0 rows (K*16) 1 FF 2 hidden columns per block (64 | 128; 0: 64) */
     CUTIE_OP_QFFN = 40,
     CUTIE_OP__COUNT
 };

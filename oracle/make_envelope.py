@@ -181,7 +181,13 @@ def main():
 # kind of perturbation (the product pre-rounds weights and keeps other fp32 islands than CPU autocast does), and the max norm over
 # a few hundred frames of a recurrence with discontinuities (top-k membership, argmax-fed masks, usage-ranked pruning) is
 # heavy-tailed: per scenario the product / reference-bf16 ratio of the worst frame scatters between 0.5 and 1.9.
-SAFETY = 1.5         # free-running trajectories (errors compound through the recurrence)
+SAFETY = 1.5         # free-running trajectories (errors compound through the recurrence): mean, 99.9th percentile, argmax margin
+# The single worst pixel of a free-running trajectory is not a stable statistic: two builds of the product that differ ONLY in the fp32
+# summation order of the 16-query side (round 3: CUTIE_AMD_QCHAIN=0 / 1, both fp32-class there) differ from each other on late frames by
+# as much as either differs from the oracle -- small_fifo frame 4: 0.109 / 0.031, small_clear frame 4: 0.129 / 0.086, small_cfg_fifo
+# worst frame: 0.070 / 0.188 (gpurun r3c22).  The single-pixel maximum therefore gets SAFETY_MAX; the 99.9th
+# percentile of |dprob| per frame is held to SAFETY x the envelope's maximum (the bound the single pixel had in rounds 1-2).
+SAFETY_MAX = 2.0
 SAFETY_ONE_STEP = 1.25   # teacher-forced single steps
 
 
@@ -198,8 +204,8 @@ def finish(result, out_path):
         mx = max(r[a]['max'] for r in rows for a in ('bf16', 'fp16'))
         mn = max(r[a]['mean'] for r in rows for a in ('bf16', 'fp16'))
         bounds[model] = {'reference_envelope_max': mx, 'reference_envelope_mean': mn,
-                         'trajectory_max': round(SAFETY * mx, 4), 'trajectory_mean': round(SAFETY * mn, 4),
-                         'argmax_margin': round(2 * SAFETY * mx, 4)}
+                         'trajectory_max': round(SAFETY_MAX * mx, 4), 'trajectory_q999': round(SAFETY * mx, 4),
+                         'trajectory_mean': round(SAFETY * mn, 4), 'argmax_margin': round(2 * SAFETY * mx, 4)}
     # One-step bound (teacher-forced tests): the product stores activations in bf16, so it is held to the reference's own bf16
     # single-step deviation x SAFETY_ONE_STEP.  (The fp16 arm is recorded for information: with 10 mantissa bits it is usually
     # tighter, but its worst frame -- the GUI re-propagation step of small_clear -- is looser than any bf16 frame.)

@@ -71,12 +71,26 @@ SCENARIOS = {
 
 
 def trajectory_bounds(model='base'):
-    """(max |dprob|, mean |dprob|, argmax margin) a free-running trajectory of the product is held to: 1.5 x the deviation of the
-    reference's OWN bf16 / fp16 autocast runs from its fp32 run on these scenarios, measured by oracle/make_envelope.py and
-    committed in tests/golden/amp_envelope.json (per model variant; argmax margin = twice the max bound)."""
+    """(max |dprob|, mean |dprob|, argmax margin) a free-running trajectory of the product is held to, derived from the deviation of
+    the reference's OWN bf16 / fp16 autocast runs from its fp32 run on these scenarios (oracle/make_envelope.py, committed in
+    tests/golden/amp_envelope.json per model variant): mean and argmax margin at 1.5 x the envelope (margin = twice the per-class
+    bound), the single worst pixel at 2 x (it is not a stable statistic, see make_envelope.SAFETY_MAX); trajectory_q999() holds
+    the 99.9th percentile to 1.5 x the envelope's maximum."""
     import json
     b = json.load(open(os.path.join(GOLDEN_DIR, 'amp_envelope.json')))['bounds'][model]
     return b['trajectory_max'], b['trajectory_mean'], b['argmax_margin']
+
+
+def trajectory_q999(model='base'):
+    import json
+    return json.load(open(os.path.join(GOLDEN_DIR, 'amp_envelope.json')))['bounds'][model]['trajectory_q999']
+
+
+def q999(d):
+    """99.9th percentile of a tensor of absolute deviations (kthvalue: exact, no interpolation)."""
+    flat = d.reshape(-1)
+    k = max(1, int(round(0.999 * flat.numel())))
+    return float(flat.float().kthvalue(k)[0])
 
 
 def _bike_frames():

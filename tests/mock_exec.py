@@ -309,7 +309,9 @@ class MockExecutor:
         rows, C = i[:2]
         om = view(p[0], F32, (rows, C + 1))
         vals = om[:, :C] / (om[:, C:] + 1e-4)
-        if flags & 1:                                                   # with the two linears
+        if flags & 1:                                                   # with the two linears (+ side job: clear p9, i2 x 16 bytes)
+            if p[9] and i[2] > 0:
+                view(p[9], I64, (2 * i[2],)).zero_()
             for y, w, b, r in ((1, 3, 4, 5), (2, 6, 7, 8)):
                 out = vals @ view(p[w], BF16, (C, C)).float().t()
                 if p[b]:
@@ -320,26 +322,30 @@ class MockExecutor:
             return
         view(p[1], F32, (rows, C)).copy_(vals)
 
-    @staticmethod
-    def _partial_sum(x, flags, i, p, M, always=False):
-        """flags&4 (QFFN: whenever p10 is given): x_eff = x + p11 + sum_s p10[s]."""
+    QACC = 4294967296.0
+
+    @classmethod
+    def _partial_sum(cls, x, flags, i, p, M, always=False):
+        """flags&4 (QFFN: whenever p10 is given): x_eff = x + p11 + p10 / 2^32 (p10: int64 fixed-point accumulator [M, 256])."""
         if (flags & 4 or always) and p[10]:
             if p[11]:
                 x = x + view(p[11], F32, (256,))
-            parts = view(p[10], F32, (i[8], M, 256))
-            for s_ in range(i[8]):
-                x = x + parts[s_]
+            x = x + (view(p[10], I64, (M, 256)).double() / cls.QACC).float()
         return x
 
-    @staticmethod
-    def _out_parts(flags, p, att, M, heads):
-        """flags&8: part[h] = att[:, 32h:32h+32] . Wo[:, 32h:32h+32]^T into p13 (f32 [heads, M, 256])."""
+    @classmethod
+    def _acc_add(cls, ptr, M, val):
+        acc = view(ptr, I64, (M, 256))
+        acc += torch.round(val.double() * cls.QACC).to(torch.int64)
+
+    @classmethod
+    def _out_parts(cls, flags, p, att, M, heads):
+        """flags&8: p13 (int64 [M, 256]) += att . Wo^T in fixed point, head by head (the bias is the consumer's business)."""
         if flags & 8:
             Wo = view(p[12], BF16, (256, 256)).float()
-            out = view(p[13], F32, (heads, M, 256))
             a = att.reshape(M, 256)
             for h in range(heads):
-                out[h].copy_(a[:, 32 * h:32 * h + 32] @ Wo[:, 32 * h:32 * h + 32].t())
+                cls._acc_add(p[13], M, a[:, 32 * h:32 * h + 32] @ Wo[:, 32 * h:32 * h + 32].t())
 
     def _proj_rows(self, p, M, ldx, ln_out_slot, flags=0, i=None):
         """Fused projection operands (ops.OpList._proj): -> (LN(x) + emb, LN(x), W [N,256] fp32, bias)."""
@@ -615,7 +621,6 @@ class MockExecutor:
 
     def _op_40(self, flags, i, f, p):                                   # QFFN
         rows, FF = i[:2]
-        S = FF // 256
         x = self._partial_sum(view(p[0], F32, (rows, 256)).clone(), flags, i, p, rows, always=True)
         if p[1]:
             view(p[1], F32, (rows, 256)).copy_(x)
@@ -624,9 +629,9 @@ class MockExecutor:
         b1 = view(p[5], F32, (FF,)) if p[5] else torch.zeros(FF)
         W2 = view(p[6], BF16, (256, FF)).float()
         hid = torch.relu(xn @ W1.t() + b1)
-        part = view(p[7], F32, (S, rows, 256))
-        for s_ in range(S):
-            part[s_].copy_(hid[:, 256 * s_:256 * s_ + 256] @ W2[:, 256 * s_:256 * s_ + 256].t())
+        HS = i[2] or 64
+        for s_ in range(FF // HS):
+            self._acc_add(p[7], rows, hid[:, HS * s_:HS * s_ + HS] @ W2[:, HS * s_:HS * s_ + HS].t())
 
     def _op_38(self, flags, i, f, p):
         rows, W, slds, dlds = i[:4]

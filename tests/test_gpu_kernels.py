@@ -701,12 +701,13 @@ def test_attention_with_fused_projections(K):
     assert float((hip['pa'].float() - hip['pa_f'].float()).abs().max()) <= 2e-2 * float(hip['pa'].float().abs().max())
 
 
-@pytest.mark.parametrize('K,HW', [(1, 1620), (3, 1620), (2, 700), (2, 8040), (1, 37)])
-def test_query_chain_in_four_launches(K, HW):
-    """The query side of a transformer block as the frame runs it (ATTN_Q2P + per-head out-projection parts -> ATTN_SELF summing them,
-    + parts -> QFFN -> parts -> ATTN_P2Q) against the seven-launch sequence it replaces (LINEAR out-projections, linear1, linear2),
-    with a second block behind it so that ATTN_Q2P's partial-sum input is covered as well; both against the interpreter.
-    HW = 8040 (1080p): the pixel loop of ATTN_Q2P runs past its prefetched chunks; HW = 37: ragged single chunk."""
+@pytest.mark.parametrize('K,HW,hid_slice', [(1, 1620, 64), (3, 1620, 64), (3, 1620, 128), (2, 700, 64), (2, 8040, 64), (1, 37, 128), (9, 300, 64)])
+def test_query_chain_in_four_launches(K, HW, hid_slice):
+    """The query side of a transformer block as the frame runs it (csrc/qchain.hip: ATTN_Q2P with its out-projection summed into a
+    fixed-point accumulator -> ATTN_SELF adding it, + out-projection -> QFFN -> ATTN_P2Q) against the seven-launch sequence it replaces
+    (LINEAR out-projections, linear1, linear2), with a second block behind it so that ATTN_Q2P's accumulator input is covered as well;
+    both against the interpreter.  HW = 8040 (1080p): the pixel loop of ATTN_Q2P runs past its prefetched chunks; HW = 37: ragged single
+    chunk; K = 9: the mask logits are read late (more than 8 objects)."""
     def build(dev, g):
         Q, C, heads, FF = 16, 256, 8, 2048
         M = K * Q
@@ -740,21 +741,23 @@ def test_query_chain_in_four_launches(K, HW):
             ol.attn_p2q(B['kvq'].view(-1)[2 * C:], None, None, pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C, proj=dict(x=x3, W=B['Wkv'], emb=emb))
             out.update({f'x2_{b}': x2, f'pa_{b}': pa, f'y_{b}': y})
             x = x3
-        # four launches per block
-        x, parts = x0, None
+        # four launches per block; the products that mix blocks travel as fixed-point accumulators (cleared here by the allocation,
+        # in the frame by QUERY_INIT)
+        x, acc = x0, None
+        zi = lambda: torch.zeros((M, C), dtype=torch.int64, device=dev)
         for b, B in enumerate(blocks):
             xn, y, x2 = z(M, C), z(M, C), z(M, C)
-            p1, p2, p3 = z(heads, M, C), z(heads, M, C), z(FF // 256, M, C)
+            a1, a2, a3 = zi(), zi(), zi()
             ol.attn_q2p(None, B['kvq'], None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg,
-                        proj=dict(x=x, W=B['Wq'], emb=emb, ln=B['ln1'], ln_out=xn), parts=parts, out_proj=(B['Wo1'], p1))
+                        proj=dict(x=x, W=B['Wq'], emb=emb, ln=B['ln1'], ln_out=xn), acc_in=acc, out_proj=(B['Wo1'], a1))
             ol.attn_self(None, None, None, K=K, Q=Q, C=C, heads=heads, proj=dict(x=xn, W=B['Wqkv'], emb=emb, ln=B['ln2'], ln_out=y),
-                         parts=(p1, heads, B['Wo1'].bias), out_proj=(B['Wo2'], p2))
-            ol.qffn(y, x2, p3, rows=M, ln=B['ln3'], W1=B['W1'], W2=B['W2'], parts=(p2, heads, B['Wo2'].bias))
-            parts = (p3, FF // 256, B['W2'].bias)
+                         acc_in=(a1, B['Wo1'].bias), out_proj=(B['Wo2'], a2))
+            ol.qffn(y, x2, a3, rows=M, ln=B['ln3'], W1=B['W1'], W2=B['W2'], acc_in=(a2, B['Wo2'].bias), hid_slice=hid_slice)
+            acc = (a3, B['W2'].bias)
             pa = z(K, HW, C, dt=BF16)
             ol.attn_p2q(B['kvq'].view(-1)[2 * C:], None, None, pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C,
-                        proj=dict(x=x2, W=B['Wkv'], emb=emb), parts=parts)
-            out.update({f'x2c_{b}': x2, f'pac_{b}': pa, f'yc_{b}': y, f'p3_{b}': p3})
+                        proj=dict(x=x2, W=B['Wkv'], emb=emb), acc_in=acc)
+            out.update({f'x2c_{b}': x2, f'pac_{b}': pa, f'yc_{b}': y})
             x = x2
         return ol, out
     hip, ref = run_both(build, seed=31 + K)
@@ -772,10 +775,10 @@ def test_query_chain_rejects_bad_forms():
     ol = O.OpList()
     y = torch.zeros((16, 256), device='cuda')
     ol.add(O.ATTN_SELF, 4, [1, 16, 256, 8, 0, 0], [], [y, y, y])
-    with pytest.raises(RuntimeError, match="flags 4"):
+    with pytest.raises(RuntimeError, match="chain form"):
         ex.run(ol.finalize())
     ol = O.OpList()
-    ol.add(O.QFFN, 0, [16, 300], [], [y, y, y, y, y, y, y, y])
+    ol.add(O.QFFN, 0, [16, 300, 64], [], [y, y, y, y, y, y, y, y])
     with pytest.raises(RuntimeError, match="qffn"):
         ex.run(ol.finalize())
 

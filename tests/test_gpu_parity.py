@@ -23,6 +23,7 @@ from oracle.weights import make_state_dict
 
 pytestmark = pytest.mark.gpu
 BMAX, BMEAN, BMARGIN = S.trajectory_bounds('base')
+BQ999 = S.trajectory_q999('base')
 
 
 @pytest.fixture(scope='module')
@@ -117,6 +118,7 @@ def test_trajectory_matches_oracle_gpu(name, gpu_net, oracle_net):
         d = (p - o).abs()
         report.append((t, float(d.max()), float(d.mean())))
         assert float(d.max()) < BMAX and float(d.mean()) < BMEAN, (name, report)
+        assert S.q999(d) < BQ999, (name, t, S.q999(d))
         top2 = o.topk(2, dim=0)[0]
         confident = (top2[0] - top2[1]) > BMARGIN       # = 2 x the per-class bound: below it an argmax flip is within tolerance
         agree = (p.argmax(0) == o.argmax(0))

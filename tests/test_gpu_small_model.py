@@ -56,6 +56,7 @@ def test_small_model_on_gpu():
         d = (p - o).abs()
         bmax, bmean, bmargin = S.trajectory_bounds('small')
         assert float(d.max()) < bmax and float(d.mean()) < bmean, (t, float(d.max()), float(d.mean()))
+        assert S.q999(d) < S.trajectory_q999('small'), (t, S.q999(d))
         top2 = o.topk(2, dim=0)[0]
         confident = (top2[0] - top2[1]) > bmargin
         assert bool((p.argmax(0) == o.argmax(0))[confident].all()), t

@@ -1,13 +1,13 @@
 """Where the time goes inside the query-side launches of a transformer block (ATTN_Q2P, ATTN_SELF, QFFN, ATTN_P2Q): cycle stamps of
-every wave (cutie_amd/csrc/attention.hip ATL, diagnostic library only), warm (back to back) and cold (a 192 MB copy in front of every
+every wave (cutie_amd/csrc/qchain.hip ATL, diagnostic library only), warm (back to back) and cold (a 192 MB copy in front of every
 launch, as inside a frame).  Needs the MI355X and the timeline library:
 
-    (cd cutie_amd/csrc && hipcc ... -DATT_TIMELINE -c attention.hip -o ../../tools/abl/attention_ATL.o && link -> tools/abl/libcutie_hip_ATL.so)
+    bash tools/build_diag_attn.sh        # qchain.hip with -DATT_TIMELINE -> tools/abl/libcutie_hip_ATL.so
     CUTIE_AMD_LIB=tools/abl/libcutie_hip_ATL.so python tools/attn_timeline.py [--K 3] [--HW 1620]
 
 Per launch: the hipEvent time of the launch alone (warm / cold), and per stamp id the min / mean / max over waves of the time since
 the block's first stamp, in us (cycle counter calibrated against the 100 MHz wall clock of the same stamps).
-Stamp ids: see the ATL(n) calls in attention.hip (0 = kernel entry; the last id = stores issued)."""
+Stamp ids: see the ATL(n) calls in qchain.hip (0 = kernel entry; the last id = stores issued)."""
 import argparse
 import os
 import sys
@@ -41,7 +41,8 @@ def main():
     Wq, Wo1, Wqkv, Wo2, W1, W2, Wkv = mk(C), mk(C), mk(3 * C), mk(C), mk(FF), mk(C, FF), mk(2 * C)
     ln1, ln2, ln3 = lnp(), lnp(), lnp()
     xn, y, x2 = z(M, C), z(M, C), z(M, C)
-    p0, p1, p2, p3 = rn(8, M, C, sc=0.1), z(heads, M, C), z(heads, M, C), z(FF // 256, M, C)
+    zi = lambda: torch.zeros((M, C), dtype=torch.int64, device=dev)
+    a0, a1, a2, a3 = (torch.randn((M, C), generator=g) * 0.1 * 4294967296.0).to(torch.int64).to(dev), zi(), zi(), zi()
     pa = z(K, HW, C, dt=torch.bfloat16)
     launches = []
 
@@ -55,12 +56,13 @@ def main():
         launches.append((name, ol, tl))
 
     one('ATTN_Q2P (+parts in, +out-proj)', lambda ol: ol.attn_q2p(None, kvq, None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg,
-        proj=dict(x=x, W=Wq, emb=emb, ln=ln1, ln_out=xn), parts=(p0, 8, W2.bias), out_proj=(Wo1, p1)), heads * K)
+        proj=dict(x=x, W=Wq, emb=emb, ln=ln1, ln_out=xn), acc_in=(a0, W2.bias), out_proj=(Wo1, a1)), heads * K)
     one('ATTN_SELF (+parts in, +out-proj)', lambda ol: ol.attn_self(None, None, None, K=K, Q=Q, C=C, heads=heads,
-        proj=dict(x=xn, W=Wqkv, emb=emb, ln=ln2, ln_out=y), parts=(p1, heads, Wo1.bias), out_proj=(Wo2, p2)), heads * K)
-    one('QFFN', lambda ol: ol.qffn(y, x2, p3, rows=M, ln=ln3, W1=W1, W2=W2, parts=(p2, heads, Wo2.bias)), (FF // 256) * K)
+        proj=dict(x=xn, W=Wqkv, emb=emb, ln=ln2, ln_out=y), acc_in=(a1, Wo1.bias), out_proj=(Wo2, a2)), heads * K)
+    one('QFFN slice 64', lambda ol: ol.qffn(y, x2, a3, rows=M, ln=ln3, W1=W1, W2=W2, acc_in=(a2, Wo2.bias), hid_slice=64), (FF // 64) * K)
+    one('QFFN slice 128', lambda ol: ol.qffn(y, x2, a3, rows=M, ln=ln3, W1=W1, W2=W2, acc_in=(a2, Wo2.bias), hid_slice=128), (FF // 128) * K)
     one('ATTN_P2Q (+parts in)', lambda ol: ol.attn_p2q(kvq.view(-1)[2 * C:], None, None, pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C,
-        proj=dict(x=x2, W=Wkv, emb=emb), parts=(p3, FF // 256, W2.bias)), -(-HW // 256) * heads * K)
+        proj=dict(x=x2, W=Wkv, emb=emb), acc_in=(a3, W2.bias)), -(-HW // 256) * heads * K)
 
     src = torch.zeros(192 << 20, dtype=torch.uint8, device=dev)
     dst = torch.zeros(192 << 20, dtype=torch.uint8, device=dev)
