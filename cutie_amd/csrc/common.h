@@ -63,6 +63,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// the same sum on the DPP / permlane path (as wave_sum_i32): six dependent ds_bpermute round trips become six VALU instructions.
+// The order of the additions differs from wave_sum's butterfly, so the two are not bit-interchangeable.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xf, 0xf, false));
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4E, 0xf, 0xf, false));
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x141, 0xf, 0xf, false));
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x140, 0xf, 0xf, false));
+    return rows_sum(v);
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

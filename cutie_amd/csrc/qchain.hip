@@ -43,14 +43,24 @@ struct QOut { const bf16_t* W; long long* acc; };        // output projection Wo
 #define ATL(ID)
 #endif
 
+// Block-wide barrier for LDS hand-overs.  __syncthreads() also drains EVERY outstanding global load of the wave (s_waitcnt vmcnt(0) in
+// front of s_barrier): with all loads of a launch issued at entry, the first barrier then waits for the K / V prefetch or the weights
+// of a later phase (measured: 6 us from entry to the first hand-over of ATTN_Q2P although it needed 2 KB).  Only the LDS / scalar
+// counter is drained here; registers fed by global loads are waited for by the compiler where they are used.
+#define QSYNC() { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(15 | (3 << 14) | (7 << 4) | (0 << 8)); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+
 __device__ __forceinline__ void qacc_add(long long* a, float v) {
     atomicAdd(reinterpret_cast<unsigned long long*>(a), (unsigned long long)__float2ll_rn(v * QACC_SCALE));
 }
 
 // ---- the 16 rows of an object: loads (issue) and sum + LayerNorm + LDS copy (finish) ----------------------------------------------
+// ACC / ADD / LN are compile-time: with run-time tests ("if (in.acc) load") the compiler folded each row's accumulator load and its
+// use into ONE branch -- load, s_waitcnt vmcnt(0), convert -- i.e. a dependent memory round trip per row (4 per wave in QFFN), and a
+// load inside a branch makes every later counted wait conservative (the ISA showed vmcnt(0) in front of ATTN_Q2P's mask pass, which
+// then waited for the whole K / V prefetch).  Straight-line code keeps all loads in flight together.
 template <int RPW> struct QRows { float4 x[RPW], add[RPW]; longlong2 a[RPW][2]; float4 ab, gg, bb; };
 
-template <int NW, int RPW>
+template <int NW, int RPW, bool ACC, bool ADD, bool LN>
 __device__ __forceinline__ void qrows_issue(const QIn& in, int k, QRows<RPW>& R) {
     static_assert(NW * RPW == 16, "16 rows per object");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -58,19 +68,18 @@ __device__ __forceinline__ void qrows_issue(const QIn& in, int k, QRows<RPW>& R)
     for (int j = 0; j < RPW; ++j) {
         const long off = ((long)k * 16 + wave + j * NW) * 256 + lane * 4;
         R.x[j] = *reinterpret_cast<const float4*>(in.x + off);
-        if (in.acc) {
+        if (ACC) {
             const longlong2* ap = reinterpret_cast<const longlong2*>(in.acc + off);
             R.a[j][0] = ap[0]; R.a[j][1] = ap[1];
         }
-        if (in.add) R.add[j] = *reinterpret_cast<const float4*>(in.add + off);
+        if (ADD) R.add[j] = *reinterpret_cast<const float4*>(in.add + off);
     }
-    R.ab = in.abias ? *reinterpret_cast<const float4*>(in.abias + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    R.gg = make_float4(1.f, 1.f, 1.f, 1.f); R.bb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (in.ln_g) { R.gg = *reinterpret_cast<const float4*>(in.ln_g + lane * 4); R.bb = *reinterpret_cast<const float4*>(in.ln_b + lane * 4); }
+    if (ACC) R.ab = *reinterpret_cast<const float4*>(in.abias + lane * 4);
+    if (LN) { R.gg = *reinterpret_cast<const float4*>(in.ln_g + lane * 4); R.bb = *reinterpret_cast<const float4*>(in.ln_b + lane * 4); }
 }
 
 // xs_add: LN(x_eff) + add (or x_eff + add); xs_plain (nullable): LN(x_eff) (or x_eff).  Row pitch PROJ_XLD.
-template <int NW, int RPW>
+template <int NW, int RPW, bool ACC, bool ADD, bool LN>
 __device__ __forceinline__ void qrows_finish(const QIn& in, int k, const QRows<RPW>& R, float* xs_add, float* xs_plain, bool writer) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -78,20 +87,20 @@ __device__ __forceinline__ void qrows_finish(const QIn& in, int k, const QRows<R
         const int r = wave + j * NW;
         const long off = ((long)k * 16 + r) * 256 + lane * 4;
         float4 v = R.x[j];
-        if (in.acc) {
+        if (ACC) {
             v.x += R.ab.x + __ll2float_rn(R.a[j][0].x) * QACC_INV; v.y += R.ab.y + __ll2float_rn(R.a[j][0].y) * QACC_INV;
             v.z += R.ab.z + __ll2float_rn(R.a[j][1].x) * QACC_INV; v.w += R.ab.w + __ll2float_rn(R.a[j][1].y) * QACC_INV;
         }
         if (in.x_out && writer) *reinterpret_cast<float4*>(in.x_out + off) = v;
-        if (in.ln_g) {
-            const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.f / 256.f);
+        if (LN) {
+            const float mean = wave_sum_dpp((v.x + v.y) + (v.z + v.w)) * (1.f / 256.f);
             const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
-            const float rstd = rsqrtf(wave_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.f / 256.f) + 1e-5f);
+            const float rstd = rsqrtf(wave_sum_dpp((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.f / 256.f) + 1e-5f);
             v.x = dx * rstd * R.gg.x + R.bb.x; v.y = dy * rstd * R.gg.y + R.bb.y; v.z = dz * rstd * R.gg.z + R.bb.z; v.w = dw * rstd * R.gg.w + R.bb.w;
             if (in.ln_out && writer) *reinterpret_cast<float4*>(in.ln_out + off) = v;
         }
         if (xs_plain) *reinterpret_cast<float4*>(xs_plain + r * PROJ_XLD + lane * 4) = v;
-        if (in.add) { v.x += R.add[j].x; v.y += R.add[j].y; v.z += R.add[j].z; v.w += R.add[j].w; }
+        if (ADD) { v.x += R.add[j].x; v.y += R.add[j].y; v.z += R.add[j].z; v.w += R.add[j].w; }
         *reinterpret_cast<float4*>(xs_add + r * PROJ_XLD + lane * 4) = v;
     }
 }
@@ -133,23 +142,46 @@ __device__ __forceinline__ void q2c_load(Q2CChunk& L, const bf16_t* __restrict__
     L.v[1] = *reinterpret_cast<const q2p_u32x4*>(vp + 8);
 }
 
-__device__ __forceinline__ bool aux_fg_vals(const float* v, int K, int k) {
-    float bg = 1.f, mx = -INFINITY, mine = 0.f;
+// Foreground flag of object k at one pixel (object_transformer.py:179-205): L_k >= max(L_bg, max_j L_j) with L = logit(clamp(p, 1e-7,
+// 1 - 1e-7)).  logit is strictly increasing, so the clamped probabilities are compared directly -- no log, and the sigmoid through
+// v_exp / v_rcp: the exact form cost ~200 instructions per pixel and object, x 1620 pixels in EVERY head's block (3 us of a 20 us launch,
+// profiles/r03_qchain.md).  Decisions differ from the exact form only where two probabilities agree to fp32 rounding.
+__device__ __forceinline__ bool aux_fg_fast(float mine_l, const float* v, int K) {
+    float bg = 1.f, mx = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (j < K) {
-            const float pr = 1.f / (1.f + expf(-v[j]));
-            const float l = clamp_logit_(pr);
-            bg *= (1.f - pr);
-            mx = fmaxf(mx, l);
-            mine = j == k ? l : mine;
-        }
+    for (int j = 0; j < 8; ++j) {                          // slots >= K hold a copy of plane K - 1: selected away, no branches
+        const float pr = __frcp_rn(1.f + __expf(-v[j]));
+        bg *= j < K ? (1.f - pr) : 1.f;
+        mx = fmaxf(mx, j < K ? pr : 0.f);
     }
-    return mine >= fmaxf(mx, clamp_logit_(bg));
+    const float lo = 1e-7f, hi = 1.f - 1e-7f;
+    const float mine = fminf(fmaxf(__frcp_rn(1.f + __expf(-mine_l)), lo), hi);
+    return mine >= fminf(fmaxf(mx, lo), hi) && mine >= fminf(fmaxf(bg, lo), hi);
+}
+__device__ __forceinline__ bool aux_fg_vals(const float* v, int K, int k) {
+    float mine = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mine = j == k ? v[j] : mine;
+    return aux_fg_fast(mine, v, K);
+}
+__device__ __forceinline__ bool aux_fg_late(const float* __restrict__ lg, int K, int HW, int k, int p) {      // K > 8 or pixels >= 2048
+    float bg = 1.f, mx = 0.f, mine = 0.f;
+    for (int j = 0; j < K; ++j) {
+        const float pr = __frcp_rn(1.f + __expf(-lg[(long)j * HW + p]));
+        bg *= (1.f - pr);
+        mx = fmaxf(mx, pr);
+        mine = j == k ? pr : mine;
+    }
+    const float lo = 1e-7f, hi = 1.f - 1e-7f;
+    mine = fminf(fmaxf(mine, lo), hi);
+    return mine >= fminf(fmaxf(mx, lo), hi) && mine >= fminf(fmaxf(bg, lo), hi);
 }
 
+// qpre != null (flags&16): q of this launch was projected by the ATTN_P2Q launch of the previous block (its extra blocks, see below) --
+// the 80 KB of rows + weights and three block-wide barriers in front of the pixel loop are gone.
+template <bool QPRE, bool ACC, bool EARLY>                // EARLY: K <= 8, the mask logits of this thread's (up to) two pixels are fetched at entry
 __global__ __launch_bounds__(1024) void q2p_chain_kernel(QIn in, QOut out, const bf16_t* __restrict__ kv, const float* __restrict__ lg,
-                                                         int HW, int HWp, int ldkv, int voff) {
+                                                         int HW, int HWp, int ldkv, int voff, const float* __restrict__ qpre) {
     constexpr int Q = 16;
     __shared__ float sO[16][16][33];                       // [wave][query][dim]; the projection staging aliases it
     __shared__ float sM[16][16], sL[16][16];
@@ -165,48 +197,58 @@ __global__ __launch_bounds__(1024) void q2p_chain_kernel(QIn in, QOut out, const
     ATL(0)
     // ---- every global load of the launch, in the order of use ----
     QRows<1> R;
-    qrows_issue<16, 1>(in, k, R);
+    float4 qp0, qp1;
+    if (QPRE) {
+        const float* qr = qpre + ((long)k * 16 + c16) * 256 + hh * 32 + 8 * g;
+        qp0 = *reinterpret_cast<const float4*>(qr); qp1 = *reinterpret_cast<const float4*>(qr + 4);
+    } else {
+        qrows_issue<16, 1, ACC, true, true>(in, k, R);
+    }
     float lgv[2][8];
-    const bool early = K <= 8;
-    if (early) {
+    constexpr bool early = EARLY;
+    if (EARLY) {                                           // unconditional loads (plane index clamped): no branch around a load
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int p = min((int)threadIdx.x + 1024 * i, HW - 1);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) lgv[i][j] = j < K ? lg[(long)j * HW + p] : 0.f;
+            for (int j = 0; j < 8; ++j) lgv[i][j] = lg[(long)min(j, K - 1) * HW + p];
         }
     }
     const int tile = wave & 1, ks = wave >> 1;
     proj_u4 wq[1], wo[1];
-    proj16_load<1>(in.W, hh * 32 + tile * 16, ks, wq);
+    if (!QPRE) proj16_load<1>(in.W, hh * 32 + tile * 16, ks, wq);
     proj16_load<1>(out.W, wave * 16, hh, wo);              // Wo rows 16 wave.., the columns of this head (one 32-wide k step)
     const bf16_t* kvb = kv + (long)k * HW * ldkv + hh * 32;
     const int nchunk = (HW + 31) >> 5;
-    Q2CChunk pf[Q2C_PF];
-#pragma unroll
-    for (int j = 0; j < Q2C_PF; ++j)
-        if (wave + 16 * j < nchunk) q2c_load(pf[j], kvb, (wave + 16 * j) * 32, HW, ldkv, voff, lane);
     if (threadIdx.x == 0) sCnt = 0;
+    // The K / V prefetch (12 KB per wave) goes out only after EVERY wave has issued its small loads: the CU's memory pipeline serves
+    // requests in issue order across waves.  The barrier only waits for the issue, not for the data.
+    QSYNC();
+    Q2CChunk pf[Q2C_PF];                                   // unconditional (chunk index clamped): a load inside a branch costs the counted waits
+#pragma unroll
+    for (int j = 0; j < Q2C_PF; ++j) q2c_load(pf[j], kvb, min(wave + 16 * j, nchunk - 1) * 32, HW, ldkv, voff, lane);
     // ---- q = (LN(x_eff) + emb) . Wq[head]^T + b: 16 waves = 2 column tiles x 8 k-steps, summed through LDS (staging aliases sO) ----
     q2p_frag qh, ql;
-    {
+    if (!QPRE) {
         float* xs = &sO[0][0][0];
         f32x4* red = reinterpret_cast<f32x4*>(xs + 16 * PROJ_XLD);
         static_assert(sizeof(float) * 16 * PROJ_XLD + sizeof(f32x4) * 16 * 64 <= sizeof(float) * 16 * 16 * 33, "projection staging fits in sO");
-        qrows_finish<16, 1>(in, k, R, xs, nullptr, hh == 0);
+        qrows_finish<16, 1, ACC, true, true>(in, k, R, xs, nullptr, hh == 0);
         ATL(1)
-        __syncthreads();
+        QSYNC();
         red[wave * 64 + lane] = proj16_mma<1>(xs, ks, wq);
-        __syncthreads();
+        QSYNC();
         if (threadIdx.x < 128) {
             const int t = threadIdx.x >> 6;
             f32x4 a = red[t * 64 + lane];
 #pragma unroll
             for (int j = 1; j < 8; ++j) { const f32x4 b = red[(t + 2 * j) * 64 + lane]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
-            const float bv = in.bias ? in.bias[hh * 32 + t * 16 + c16] : 0.f;
+            const float bv = in.bias[hh * 32 + t * 16 + c16];
 #pragma unroll
             for (int r = 0; r < 4; ++r) sQ[4 * g + r][t * 16 + c16] = (a[r] + bv) * scale;
         }
+    }
+    {
         // ---- foreground flags of object k (AUX_MASK fused, object_transformer.py:179-205) while the reduction settles ----
         int cnt = 0;
 #pragma unroll
@@ -215,16 +257,22 @@ __global__ __launch_bounds__(1024) void q2p_chain_kernel(QIn in, QOut out, const
             if (early && p < HW) { const bool f = aux_fg_vals(lgv[i], K, k); sFg[p] = f ? 1 : 0; cnt += f ? 1 : 0; }
         }
         for (int p = threadIdx.x + (early ? 2048 : 0); p < HW; p += 1024) {
-            const bool f = aux_fg_(lg, K, HW, k, p);
+            const bool f = aux_fg_late(lg, K, HW, k, p);
             sFg[p] = f ? 1 : 0;
             cnt += f ? 1 : 0;
         }
         cnt = wave_sum_i32(cnt);
         if (lane == 0 && cnt) atomicAdd(&sCnt, cnt);
-        __syncthreads();                                   // sQ, sFg, sCnt complete; xs / red (= sO) are free again
+        QSYNC();                                   // sQ, sFg, sCnt complete; xs / red (= sO) are free again
         ATL(2)
+        if (QPRE) {
+            const float qv[8] = {qp0.x, qp0.y, qp0.z, qp0.w, qp1.x, qp1.y, qp1.z, qp1.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { uint32_t h_, l_; split_bf2(sQ[c16][8 * g + 2 * j], sQ[c16][8 * g + 2 * j + 1], h_, l_); qh.u[j] = h_; ql.u[j] = l_; }
+            for (int j = 0; j < 4; ++j) { uint32_t h_, l_; split_bf2(qv[2 * j], qv[2 * j + 1], h_, l_); qh.u[j] = h_; ql.u[j] = l_; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { uint32_t h_, l_; split_bf2(sQ[c16][8 * g + 2 * j], sQ[c16][8 * g + 2 * j + 1], h_, l_); qh.u[j] = h_; ql.u[j] = l_; }
+        }
     }
     const int n_fg = sCnt;
     const bool is_fg_query = c16 < Q / 2;                  // queries 0..7 attend foreground only
@@ -294,7 +342,7 @@ __global__ __launch_bounds__(1024) void q2p_chain_kernel(QIn in, QOut out, const
     if (g == 0) { sM[wave][c16] = m; sL[wave][c16] = l; }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { sO[wave][c16][4 * g + r] = o0[r]; sO[wave][c16][16 + 4 * g + r] = o1[r]; }
-    __syncthreads();
+    QSYNC();
     ATL(4)
     if (threadIdx.x < 512) {                               // (query i, dim d): merge the 16 waves
         const int i = threadIdx.x >> 5, d = threadIdx.x & 31;
@@ -310,7 +358,7 @@ __global__ __launch_bounds__(1024) void q2p_chain_kernel(QIn in, QOut out, const
         }
         sQ[i][d] = num / den;
     }
-    __syncthreads();
+    QSYNC();
     ATL(5)
     {   // per-head output projection: o (16 x 32) . Wo[:, 32 hh ..]^T -- wave w: output columns 16 w .. 16 w + 15, summed over the heads
         proj_u4 hi, lo;
@@ -340,7 +388,7 @@ __global__ __launch_bounds__(512) void self_chain_kernel(QIn in, QOut out) {
     const float scale = rsqrtf(32.f);
     ATL(0)
     QRows<2> R;
-    qrows_issue<8, 2>(in, k, R);
+    qrows_issue<8, 2, true, true, true>(in, k, R);
     proj_u4 wv[3][2];                                      // tiles 0,1: q  2,3: k  4,5: v (weight rows (t/2)*256 + head*32 + (t&1)*16)
 #pragma unroll
     for (int t = 0; t < 3; ++t) { const int tl_ = th * 3 + t; proj16_load<2>(in.W, (tl_ >> 1) * 256 + hh * 32 + (tl_ & 1) * 16, 2 * kq, wv[t]); }
@@ -352,12 +400,12 @@ __global__ __launch_bounds__(512) void self_chain_kernel(QIn in, QOut out) {
         const uint2 a = *reinterpret_cast<const uint2*>(wr), b = *reinterpret_cast<const uint2*>(wr + 16);
         wo[t][0] = a.x; wo[t][1] = a.y; wo[t][2] = b.x; wo[t][3] = b.y;
     }
-    qrows_finish<8, 2>(in, k, R, sX[0], sX[1], hh == 0);
+    qrows_finish<8, 2, true, true, true>(in, k, R, sX[0], sX[1], hh == 0);
     ATL(1)
-    __syncthreads();
+    QSYNC();
 #pragma unroll
     for (int t = 0; t < 3; ++t) sRed[kq][th * 3 + t][lane] = proj16_mma<2>(sX[th * 3 + t < 4 ? 0 : 1], 2 * kq, wv[t]);
-    __syncthreads();
+    QSYNC();
     ATL(2)
     if (threadIdx.x < 6 * 64) {
         const int t = threadIdx.x >> 6;
@@ -365,11 +413,11 @@ __global__ __launch_bounds__(512) void self_chain_kernel(QIn in, QOut out) {
 #pragma unroll
         for (int w = 1; w < 4; ++w) { const f32x4 b = sRed[w][t][lane]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
         const int col = (t & 1) * 16 + c;
-        const float bv = in.bias ? in.bias[(t >> 1) * 256 + hh * 32 + col] : 0.f;
+        const float bv = in.bias[(t >> 1) * 256 + hh * 32 + col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) sP[t >> 1][4 * g + r][col] = (a[r] + bv) * (t < 2 ? scale : 1.f);
     }
-    __syncthreads();
+    QSYNC();
     ATL(3)
     // S^T[key][query] = K . Q^T: A = K (lane: key c, dims 8g..), B = Q^T (lane: query c, dims 8g..); D: keys 4g..4g+3 of query c
     float kf[8], qf[8];
@@ -439,25 +487,25 @@ __global__ __launch_bounds__(256) void qffn_kernel(QIn in, QFfn a) {
     const int sl = blockIdx.x, k = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     ATL(0)
     QRows<4> R;
-    qrows_issue<4, 4>(in, k, R);
+    qrows_issue<4, 4, true, false, true>(in, k, R);
     proj_u4 w1[T1][8], w2[4][KS2];
 #pragma unroll
     for (int t = 0; t < T1; ++t) proj16_load<8>(a.W1, sl * HS + (wave * T1 + t) * 16, 0, w1[t]);
 #pragma unroll
     for (int t = 0; t < 4; ++t) proj16_load<KS2>(a.W2, (wave * 4 + t) * 16, sl * KS2, w2[t], a.FF);
-    qrows_finish<4, 4>(in, k, R, sX, nullptr, sl == 0);
+    qrows_finish<4, 4, true, false, true>(in, k, R, sX, nullptr, sl == 0);
     ATL(1)
-    __syncthreads();
+    QSYNC();
 #pragma unroll
     for (int t = 0; t < T1; ++t) {
         const f32x4 acc = proj16_mma<8>(sX, 0, w1[t]);
         const int col = (wave * T1 + t) * 16 + c;
-        const float bv = a.b1 ? a.b1[sl * HS + col] : 0.f;
+        const float bv = a.b1[sl * HS + col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) sH[(4 * g + r) * HLD + col] = fmaxf(acc[r] + bv, 0.f);
     }
     ATL(2)
-    __syncthreads();
+    QSYNC();
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const f32x4 acc = proj16_mma<KS2>(sH, 0, w2[t], HLD);
@@ -474,7 +522,11 @@ __global__ __launch_bounds__(256) void qffn_kernel(QIn in, QFfn a) {
 //     S^T[query][pixel] = K[query][dim] . Q^T[dim][pixel]   (B = the pixel rows as they lie in memory: one 16-byte load per lane)
 //     O^T[dim][pixel]   = V^T[dim][query] . P^T[query][pixel]
 // =====================================================================================================================================
-__global__ __launch_bounds__(256) void p2q_chain_kernel(QIn in, const bf16_t* __restrict__ q, bf16_t* __restrict__ y, int HW, int ldq) {
+// Extra blocks (flags&16, blockIdx.x == gridDim.x - 1): the q projection of the NEXT transformer block's ATTN_Q2P for (head, object) --
+// its input rows are the very rows staged here (x_eff), normalised with the next block's read_from_pixel.norm: q_out = ((LN(x_eff) +
+// emb) Wq^T + b) / sqrt(32), xn_out = LN(x_eff) (the residual of that attention).  24 blocks next to 168: free.
+struct NextQ { const float* ln_g; const float* ln_b; const bf16_t* W; const float* bias; float* q_out; float* xn_out; };
+__global__ __launch_bounds__(256) void p2q_chain_kernel(QIn in, const bf16_t* __restrict__ q, bf16_t* __restrict__ y, int HW, int ldq, NextQ nq) {
     constexpr int C = 256;
     __shared__ float sX[2][16 * PROJ_XLD];
     __shared__ float ks[16][36], vs[16][36];
@@ -483,8 +535,28 @@ __global__ __launch_bounds__(256) void p2q_chain_kernel(QIn in, const bf16_t* __
     const int isv = wave >> 1, col = (wave & 1) * 16;
     const float scale = rsqrtf(32.f);
     ATL(0)
+    if (nq.W && blockIdx.x == gridDim.x - 1) {
+        QIn in2 = in;
+        in2.ln_g = nq.ln_g; in2.ln_b = nq.ln_b; in2.ln_out = nq.xn_out;
+        QRows<4> R2;
+        qrows_issue<4, 4, true, true, true>(in2, k, R2);
+        proj_u4 wq[4];                                     // wave: column tile (w & 1), k steps 4 (w >> 1) ..
+        proj16_load<4>(nq.W, hh * 32 + col, 4 * isv, wq);
+        qrows_finish<4, 4, true, true, true>(in2, k, R2, sX[0], nullptr, hh == 0);
+        QSYNC();
+        f32x4* red = reinterpret_cast<f32x4*>(sX[1]);
+        red[wave * 64 + lane] = proj16_mma<4>(sX[0], 4 * isv, wq);
+        QSYNC();
+        if (wave < 2) {
+            const f32x4 a = red[wave * 64 + lane], b = red[(wave + 2) * 64 + lane];
+            const float bv = nq.bias[hh * 32 + col + c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nq.q_out[((long)k * 16 + 4 * g + r) * C + hh * 32 + col + c] = (a[r] + b[r] + bv) * scale;
+        }
+        return;
+    }
     QRows<4> R;
-    qrows_issue<4, 4>(in, k, R);
+    qrows_issue<4, 4, true, true, false>(in, k, R);
     proj_u4 wv[8];
     proj16_load<8>(in.W, isv * C + hh * 32 + col, 0, wv);
     const int pbase = blockIdx.x * 256 + wave * 64;
@@ -494,19 +566,19 @@ __global__ __launch_bounds__(256) void p2q_chain_kernel(QIn in, const bf16_t* __
         const int p = min(pbase + t * 16 + c, HW - 1);
         qv[t] = *reinterpret_cast<const proj_u4*>(q + ((long)k * HW + p) * ldq + hh * 32 + 8 * g);
     }
-    qrows_finish<4, 4>(in, k, R, sX[0], sX[1], false);
+    qrows_finish<4, 4, true, true, false>(in, k, R, sX[0], sX[1], false);
     ATL(1)
-    __syncthreads();
+    QSYNC();
     {
         const f32x4 a = proj16_mma<8>(sX[isv], 0, wv);
-        const float bv = in.bias ? in.bias[isv * C + hh * 32 + col + c] : 0.f;
+        const float bv = in.bias[isv * C + hh * 32 + col + c];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (isv) vs[4 * g + r][col + c] = a[r] + bv;
             else ks[4 * g + r][col + c] = (a[r] + bv) * scale;
         }
     }
-    __syncthreads();
+    QSYNC();
     ATL(2)
     if (pbase >= HW) return;
     float kf[8];
@@ -548,7 +620,7 @@ __global__ __launch_bounds__(256) void p2q_chain_kernel(QIn in, const bf16_t* __
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------------
-static bool qin_from_op(const cutie_op* op, QIn& in, QOut& out, const char* who, int xslot, int lnout_slot) {
+static bool qin_from_op(const cutie_op* op, QIn& in, QOut& out, const char* who, int xslot, int lnout_slot, bool no_proj = false) {
     const uint64_t* p = op->p;
     in = QIn{};
     out = QOut{};
@@ -567,7 +639,7 @@ static bool qin_from_op(const cutie_op* op, QIn& in, QOut& out, const char* who,
 #ifdef ATT_TIMELINE
     in.tl = (unsigned long long*)p[15];
 #endif
-    if (!in.x || !in.W) { cutie_set_error("%s: chain form needs the rows and the projection weight", who); return false; }
+    if (!in.x || (!in.W && !no_proj)) { cutie_set_error("%s: chain form needs the rows and the projection weight", who); return false; }
     return true;
 }
 
@@ -579,26 +651,40 @@ int launch_qchain(const cutie_op* op, hipStream_t s) {
         case CUTIE_OP_ATTN_Q2P: {
             if (i[1] != 16 || i[3] != 256 || i[4] != 8 || (i[7] > 0 && i[7] != 256)) { cutie_set_error("attn_q2p (chain form): Q = 16, C = 256, 8 heads, dense rows"); return -2; }
             if ((op->flags & 11) != 11) { cutie_set_error("attn_q2p (chain form): flags 1 | 2 | 8 required"); return -2; }
-            if (!qin_from_op(op, in, out, "attn_q2p", 0, 3)) return -2;
+            if (!qin_from_op(op, in, out, "attn_q2p", 0, 3, (op->flags & 16) != 0)) return -2;
             if (!p[1] || !p[2]) { cutie_set_error("attn_q2p (chain form): kv and the mask logits required"); return -2; }
             const int HWp = (i[2] + 15) & ~15;
             const size_t dyn = (size_t)HWp + 16 * 32 * Q2C_VLD * 2;
             if (dyn > 96 * 1024) { cutie_set_error("attn_q2p (chain form): HW = %d does not fit the LDS flag array", i[2]); return -2; }
-            static bool attr_set = false;
-            if (!attr_set) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(q2p_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
+            const bool qp = (op->flags & 16) != 0, ac = !qp && (op->flags & 4), early = i[0] <= 8;
+            const float* qpre = nullptr;
+            if (qp) { qpre = (const float*)p[0]; in.x = nullptr; in.W = nullptr; in.ln_out = nullptr; }   // p0 = q [K*16, 256], projected and scaled
+            else if (!in.add || !in.ln_g || !in.ln_b || !in.bias || (ac && !in.abias)) {
+                cutie_set_error("attn_q2p (chain form): query embedding, LayerNorm, the projection bias and (flags&4) the accumulator's bias are required");
+                return -2;
+            }
+            // one instantiation per (q handed in, accumulator input, logits fetched at entry): straight-line load sequences
+            const int var = (qp ? 4 : 0) | (ac ? 2 : 0) | (early ? 1 : 0);
+            void (*kern)(QIn, QOut, const bf16_t*, const float*, int, int, int, int, const float*) =
+                var == 7 || var == 5 ? q2p_chain_kernel<true, false, true> : var == 6 || var == 4 ? q2p_chain_kernel<true, false, false> :
+                var == 3 ? q2p_chain_kernel<false, true, true> : var == 2 ? q2p_chain_kernel<false, true, false> :
+                var == 1 ? q2p_chain_kernel<false, false, true> : q2p_chain_kernel<false, false, false>;
+            static bool attr_set[8] = {};
+            if (!attr_set[var]) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
                     cutie_set_error("attn_q2p (chain form): cannot raise the dynamic LDS limit");
                     return -2;
                 }
-                attr_set = true;
+                attr_set[var] = true;
             }
-            hipLaunchKernelGGL(q2p_chain_kernel, dim3(8, i[0]), dim3(1024), dyn, s, in, out, (const bf16_t*)p[1], (const float*)p[2], i[2], HWp, i[5], i[6]);
+            hipLaunchKernelGGL(kern, dim3(8, i[0]), dim3(1024), dyn, s, in, out, (const bf16_t*)p[1], (const float*)p[2], i[2], HWp, i[5], i[6], qpre);
             break;
         }
         case CUTIE_OP_ATTN_SELF:
             if (i[1] != 16 || i[2] != 256 || i[3] != 8 || (i[6] > 0 && i[6] != 256)) { cutie_set_error("attn_self (chain form): Q = 16, C = 256, 8 heads, dense rows"); return -2; }
-            if ((op->flags & 10) != 10) { cutie_set_error("attn_self (chain form): flags 2 | 8 required"); return -2; }
+            if ((op->flags & 14) != 14) { cutie_set_error("attn_self (chain form): flags 2 | 4 | 8 required"); return -2; }
             if (!qin_from_op(op, in, out, "attn_self", 0, 3)) return -2;
+            if (!in.add || !in.ln_g || !in.ln_b || !in.bias || !in.abias) { cutie_set_error("attn_self (chain form): query embedding, LayerNorm and both biases are required"); return -2; }
             hipLaunchKernelGGL(self_chain_kernel, dim3(8, i[0]), dim3(512), 0, s, in, out);
             break;
         case CUTIE_OP_ATTN_P2Q:
@@ -607,7 +693,15 @@ int launch_qchain(const cutie_op* op, hipStream_t s) {
             if (!qin_from_op(op, in, out, "attn_p2q", 1, -1)) return -2;
             in.ln_g = in.ln_b = nullptr;
             if (!p[0] || !p[3]) { cutie_set_error("attn_p2q (chain form): q and y required"); return -2; }
-            hipLaunchKernelGGL(p2q_chain_kernel, dim3((i[2] + 255) / 256, 8, i[0]), dim3(256), 0, s, in, (const bf16_t*)p[0], (bf16_t*)p[3], i[2], i[5]);
+            if (!in.add || !in.bias || !in.abias) { cutie_set_error("attn_p2q (chain form): query embedding and both biases are required"); return -2; }
+        {
+            NextQ nq = {};
+            if (op->flags & 16) {                            // p8/p9 = LayerNorm of the next block, p12 = its Wq, p13 = bias, p14 = q_out, p15 = xn_out
+                if (!p[8] || !p[9] || !p[12] || !p[13] || !p[14] || !p[15]) { cutie_set_error("attn_p2q (chain form): flags&16 needs p8, p9, p12, p13, p14, p15"); return -2; }
+                nq = NextQ{(const float*)p[8], (const float*)p[9], (const bf16_t*)p[12], (const float*)p[13], (float*)p[14], (float*)p[15]};
+            }
+            hipLaunchKernelGGL(p2q_chain_kernel, dim3((i[2] + 255) / 256 + (nq.W ? 1 : 0), 8, i[0]), dim3(256), 0, s, in, (const bf16_t*)p[0], (bf16_t*)p[3], i[2], i[5], nq);
+        }
             break;
         case CUTIE_OP_QFFN: {
             const int HS = i[2] > 0 ? i[2] : 64;
@@ -617,8 +711,8 @@ int launch_qchain(const cutie_op* op, hipStream_t s) {
             }
             in = QIn{};
             in.x = (const float*)p[0]; in.x_out = (float*)p[1]; in.ln_g = (const float*)p[2]; in.ln_b = (const float*)p[3];
-            if (p[10]) { in.acc = (const long long*)p[10]; in.abias = (const float*)p[11]; }
-            else if (p[11]) { cutie_set_error("qffn: a bias without its accumulator is not supported"); return -2; }
+            if (!p[10] || !p[11] || !p[5]) { cutie_set_error("qffn: the input accumulator, its bias and linear1's bias are required"); return -2; }
+            in.acc = (const long long*)p[10]; in.abias = (const float*)p[11];
 #ifdef ATT_TIMELINE
             in.tl = (unsigned long long*)p[15];
 #endif

@@ -56,6 +56,7 @@ TUNE_REPS, TUNE_ITERS = (int(v) for v in os.environ.get('CUTIE_AMD_TUNE', '3x8')
 UNFUSED = os.environ.get('CUTIE_AMD_UNFUSED', '0') not in ('', '0')
 QCHAIN = os.environ.get('CUTIE_AMD_QCHAIN', '1') not in ('', '0')     # query side of a transformer block in 4 launches (0: the round-2 seven)
 QFFN_SLICE = int(os.environ.get('CUTIE_AMD_QFFN_SLICE', '64'))       # hidden columns per QFFN block (64 | 128)
+QNEXT = os.environ.get('CUTIE_AMD_QNEXT', '1') not in ('', '0')       # ATTN_P2Q also projects the next block's ATTN_Q2P queries
 AUTOTUNE = os.environ.get('CUTIE_AMD_AUTOTUNE', '0') not in ('', '0')
 PACKAGED_TILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tiles_gfx950.json')
 
@@ -452,7 +453,7 @@ def build_readout_query(eng, K, h, w, last_aux=True):
     if not fused_mask:
         ol.aux_mask(aux[0], fg, nfg, K=K, HW=HW)
     x = query
-    prev_acc = None
+    prev_acc = q_pre = xn_next = None
     for b in range(nb):
         q = f'{t}.blocks.{b}'
         n = f'b{b}.'
@@ -461,7 +462,8 @@ def build_readout_query(eng, K, h, w, last_aux=True):
         # read_from_pixel (CrossAttention, transformer_layers.py:75-98): residual is the normed x.  Every LayerNorm of the
         # block is fused into the linear that consumes it (the normalised rows are kept where the reference reuses them).
         ln = lambda name: (W[q + name + '.weight'], W[q + name + '.bias'])
-        xn = f(n + 'xn', (M, C))
+        xn = xn_next if xn_next is not None else f(n + 'xn', (M, C))
+        xn_next = None
         fuse_proj = fused_mask and C == 256 and not UNFUSED      # the small projections run inside the attention launches
         chain = fuse_proj and use_chain
         if chain:
@@ -471,9 +473,13 @@ def build_readout_query(eng, K, h, w, last_aux=True):
             Wo1, Wo2 = W[q + '.read_from_pixel.out'], W[q + '.self_attn.out']
             W1, W2 = W[q + '.ffn.linear1'], W[q + '.ffn.linear2']
             a1, a2, a3 = qacc[3 * b], qacc[3 * b + 1], qacc[3 * b + 2]
-            ol.attn_q2p(None, kvq.t, None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=aux[b],
-                        proj=dict(x=x, W=W[q + '.read_from_pixel.q'], emb=query_emb, ln=ln('.read_from_pixel.norm'), ln_out=xn),
-                        acc_in=prev_acc, out_proj=(Wo1, a1))
+            if q_pre is not None:                                  # projected by the previous block's ATTN_P2Q launch (xn too)
+                ol.attn_q2p(None, kvq.t, None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=aux[b],
+                            q_pre=q_pre, out_proj=(Wo1, a1))
+            else:
+                ol.attn_q2p(None, kvq.t, None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=aux[b],
+                            proj=dict(x=x, W=W[q + '.read_from_pixel.q'], emb=query_emb, ln=ln('.read_from_pixel.norm'), ln_out=xn),
+                            acc_in=prev_acc, out_proj=(Wo1, a1))
             y = f(n + 'y', (M, C))
             ol.attn_self(None, None, None, K=K, Q=Q, C=C, heads=heads,
                          proj=dict(x=xn, W=W[q + '.self_attn.qkv'], emb=query_emb, ln=ln('.self_attn.norm'), ln_out=y),
@@ -483,8 +489,16 @@ def build_readout_query(eng, K, h, w, last_aux=True):
             x = x2                                                 # + b2 + a3 / 2^32: added by whoever reads x
             prev_acc = (a3, W2.bias)
             pa = P.buf(n + 'pa', (K, h, w, C))
+            next_q = None
+            if b + 1 < nb and QNEXT:
+                qn = f'{t}.blocks.{b + 1}'
+                q_pre, xn_next = f(f'b{b + 1}.q', (M, C)), f(f'b{b + 1}.xn', (M, C))
+                next_q = dict(ln=(W[qn + '.read_from_pixel.norm.weight'], W[qn + '.read_from_pixel.norm.bias']), W=W[qn + '.read_from_pixel.q'],
+                              q_out=q_pre, xn_out=xn_next)
+            else:
+                q_pre = None
             ol.attn_p2q(kvq.t.view(-1)[2 * C:], None, None, pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C,
-                        proj=dict(x=x, W=W[q + '.read_from_query.kv'], emb=query_emb), acc_in=prev_acc)
+                        proj=dict(x=x, W=W[q + '.read_from_query.kv'], emb=query_emb), acc_in=prev_acc, next_q=next_q)
         else:
             att = f(n + 'att', (M, C))
             if fuse_proj:

@@ -471,10 +471,16 @@ class OpList:
             ptrs[12], ptrs[13] = out_proj[0].weight, out_proj[1]
         return flags, ints, ptrs
 
-    def attn_q2p(self, q, kv, fg, nfg, y, *, K, Q, HW, C, heads, ldkv, voff, logits=None, proj=None, acc_in=None, out_proj=None):
+    def attn_q2p(self, q, kv, fg, nfg, y, *, K, Q, HW, C, heads, ldkv, voff, logits=None, proj=None, acc_in=None, out_proj=None, q_pre=None):
         """logits given: the foreground mask is derived inside the kernel from the mask_pred logits (AUX_MASK fused; fg / nfg unused).
         proj given (needs logits): q = (LN(x) + emb) Wq^T + b is computed inside the launch from the unprojected rows proj['x'].
-        out_proj (needs proj; chain form, see _proj_extras): y is not written; acc_in optional."""
+        out_proj (needs proj; chain form, see _proj_extras): y is not written; acc_in optional.
+        q_pre (chain form, instead of proj): q f32 [K*Q, 256], already projected and scaled by 1/sqrt(32) -- by the ATTN_P2Q launch of the
+        previous transformer block (attn_p2q(next_q=...))."""
+        if q_pre is not None:
+            assert proj is None and acc_in is None and out_proj is not None and logits is not None
+            flags, ints, ptrs = self._proj_extras(3 | 16, [K, Q, HW, C, heads, ldkv, voff, 256], [q_pre, kv, logits, None, None], None, out_proj)
+            return self.add(ATTN_Q2P, flags, ints, [], ptrs)
         if proj is not None:
             assert logits is not None
             ldx, ln_out, tail = self._proj(proj)
@@ -497,12 +503,19 @@ class OpList:
         assert acc_in is None and out_proj is None
         return self.add(ATTN_SELF, 0, [K, Q, C, heads, ldqk, ldv], [], [qk, v, y])
 
-    def attn_p2q(self, q, kq, vq, y, *, K, Q, HW, C, heads, ldq, ldkv=0, proj=None, acc_in=None):
+    def attn_p2q(self, q, kq, vq, y, *, K, Q, HW, C, heads, ldq, ldkv=0, proj=None, acc_in=None, next_q=None):
         """proj given: k | v of the object queries = packed [k | v] projection of (x + emb | x) computed inside the launch.
-        acc_in (needs proj): chain form."""
+        acc_in (needs proj): chain form.  next_q = dict(ln=(gamma, beta), W=PackedLinear Wq, q_out, xn_out) (chain form): extra blocks project
+        the NEXT transformer block's ATTN_Q2P queries from the same rows: xn_out = LN(x_eff), q_out = ((xn_out + emb) Wq^T + b) / sqrt(32)."""
         if proj is not None:
             ldx, _, tail = self._proj(proj)
             flags, ints, ptrs = self._proj_extras(2, [K, Q, HW, C, heads, ldq, ldkv, ldx], [q, proj['x'], None, y, None] + tail[:3], acc_in, None)
+            if next_q is not None:
+                assert acc_in is not None and next_q['W'].kd == 256 and next_q['W'].n == 256
+                flags |= 16
+                ptrs = ptrs + [None] * (16 - len(ptrs))
+                ptrs[8], ptrs[9] = next_q['ln']
+                ptrs[12], ptrs[13], ptrs[14], ptrs[15] = next_q['W'].weight, next_q['W'].bias, next_q['q_out'], next_q['xn_out']
             return self.add(ATTN_P2Q, flags, ints, [], ptrs)
         assert acc_in is None
         return self.add(ATTN_P2Q, 0, [K, Q, HW, C, heads, ldq, ldkv], [], [q, kq, vq, y])

@@ -149,7 +149,9 @@ enum {
      *      fixed point to p13 = int64 [K*Q, 256] (value x 2^32; integer atomics: the sum is independent of the order of arrival; the
      *      caller clears it beforehand, e.g. QUERY_INIT's side job); p12 = Wo bf16 [256,256]; p4 is not written.  Wo's bias and the
      *      residual are added by the consumer through ITS flags&4:
-     * flags&4 (chain form): the rows are a sum, x_eff = p0 + p11 (bias f32 [256], may be 0) + p10 / 2^32 (p10 = int64 [K*Q, 256]) */
+     * flags&4 (chain form): the rows are a sum, x_eff = p0 + p11 (bias f32 [256], may be 0) + p10 / 2^32 (p10 = int64 [K*Q, 256])
+     * flags&16 (chain form, instead of flags&4 and of the projection operands): p0 = q f32 [K*Q, 256], already projected and scaled by
+     *      1/sqrt(32) (ATTN_P2Q flags&16 of the previous transformer block produces it); p3, p5..p11 unused */
     CUTIE_OP_ATTN_Q2P = 18,
     /* ATTN_SELF: 16x16 self attention per object  transformer_layers.py:12-41
      * p0=qk f32 [K,Q,ldqk] (q at +0, k at +C) p1=v f32 [K,Q,ldv] p2=y f32 [K,Q,C]
@@ -164,7 +166,10 @@ enum {
      * i: 0 K 1 Q 2 HW 3 C 4 heads 5 ldq 6 ldkv (0: C)
      * flags&2 (C == 256): the packed k|v projection of the object queries runs inside the launch -- p1=x f32 [K*Q, i7],
      *      p5=Wkv bf16 [2C,256] p6=bias f32 [2C] p7=query embedding (k only); p2 unused
-     * flags&4: chain form, accumulator input as ATTN_Q2P (p10, p11) */
+     * flags&4: chain form, accumulator input as ATTN_Q2P (p10, p11)
+     * flags&16 (chain form): extra blocks also project the NEXT transformer block's ATTN_Q2P queries from the same rows x_eff:
+     *      p15 = xn_out f32 [K*Q,256] = LN(x_eff; p8 gamma, p9 beta), p14 = q_out f32 [K*Q,256] = ((xn_out + p7) p12^T + p13) / sqrt(32)
+     *      (p12 = Wq bf16 [256,256], p13 = bias) */
     CUTIE_OP_ATTN_P2Q = 20,
     /* SUMMARIZE: weights=sigmoid(logits)*[m x8 | (1-m) x8]; sums=einsum; area   object_summarizer.py:11-23
      * p0=feature bf16 [K,HW,C] p1=wlogits f32 [K,HW,Q] p2=m16 f32 [K,HW] p3=y f32 [K,Q,C+1]

@@ -371,7 +371,9 @@ class MockExecutor:
     def _op_18(self, flags, i, f, p):
         K, Q, HW, C, heads, ldkv, voff = i[:7]
         hd = C // heads
-        if flags & 2:                                                   # q projection fused
+        if flags & 16:                                                  # chain form: q given, projected and scaled by 1 / sqrt(hd)
+            q = (view(p[0], F32, (K, Q, C)) * math.sqrt(hd)).view(K, Q, heads, hd).transpose(1, 2)
+        elif flags & 2:                                                 # q projection fused
             xa, _ = self._proj_rows(p, K * Q, i[7] or 256, 3, flags, i)
             qp = xa @ view(p[5], BF16, (C, 256)).float().t() + (view(p[6], F32, (C,)) if p[6] else 0)
             q = qp.view(K, Q, heads, hd).transpose(1, 2)
@@ -429,6 +431,13 @@ class MockExecutor:
         if flags & 2:                                                   # kv projection fused (no LayerNorm; p1 = x)
             x = self._partial_sum(view(p[1], F32, (K * Q, 256), (i[7] or 256, 1)), flags, i, p, K * Q)
             xa = x + view(p[7], F32, (K * Q, 256)) if p[7] else x
+            if flags & 16:                                              # the next block's ATTN_Q2P queries from the same rows
+                xn = F.layer_norm(x, (256,), view(p[8], F32, (256,)), view(p[9], F32, (256,)), 1e-5)
+                view(p[15], F32, (K * Q, 256)).copy_(xn)
+                qn = (xn + view(p[7], F32, (K * Q, 256)) if p[7] else xn) @ view(p[12], BF16, (256, 256)).float().t()
+                if p[13]:
+                    qn = qn + view(p[13], F32, (256,))
+                view(p[14], F32, (K * Q, 256)).copy_(qn / math.sqrt(32))
             Wt = view(p[5], BF16, (2 * C, 256)).float()
             b = view(p[6], F32, (2 * C,)) if p[6] else torch.zeros(2 * C)
             k = (xa @ Wt[:C].t() + b[:C]).view(K, Q, heads, hd).transpose(1, 2)

@@ -701,13 +701,14 @@ def test_attention_with_fused_projections(K):
     assert float((hip['pa'].float() - hip['pa_f'].float()).abs().max()) <= 2e-2 * float(hip['pa'].float().abs().max())
 
 
-@pytest.mark.parametrize('K,HW,hid_slice', [(1, 1620, 64), (3, 1620, 64), (3, 1620, 128), (2, 700, 64), (2, 8040, 64), (1, 37, 128), (9, 300, 64)])
-def test_query_chain_in_four_launches(K, HW, hid_slice):
+@pytest.mark.parametrize('K,HW,hid_slice,qnext', [(1, 1620, 64, 1), (3, 1620, 64, 1), (3, 1620, 128, 0), (2, 700, 64, 1), (2, 8040, 64, 1), (1, 37, 128, 1), (9, 300, 64, 1), (3, 1620, 64, 0)])
+def test_query_chain_in_four_launches(K, HW, hid_slice, qnext):
     """The query side of a transformer block as the frame runs it (csrc/qchain.hip: ATTN_Q2P with its out-projection summed into a
     fixed-point accumulator -> ATTN_SELF adding it, + out-projection -> QFFN -> ATTN_P2Q) against the seven-launch sequence it replaces
     (LINEAR out-projections, linear1, linear2), with a second block behind it so that ATTN_Q2P's accumulator input is covered as well;
     both against the interpreter.  HW = 8040 (1080p): the pixel loop of ATTN_Q2P runs past its prefetched chunks; HW = 37: ragged single
-    chunk; K = 9: the mask logits are read late (more than 8 objects)."""
+    chunk; K = 9: the mask logits are read late (more than 8 objects); qnext: the second block's ATTN_Q2P gets its queries from the
+    first block's ATTN_P2Q launch (extra blocks) instead of projecting them itself."""
     def build(dev, g):
         Q, C, heads, FF = 16, 256, 8, 2048
         M = K * Q
@@ -745,18 +746,28 @@ def test_query_chain_in_four_launches(K, HW, hid_slice):
         # in the frame by QUERY_INIT)
         x, acc = x0, None
         zi = lambda: torch.zeros((M, C), dtype=torch.int64, device=dev)
+        q_pre = xn_pre = None
         for b, B in enumerate(blocks):
-            xn, y, x2 = z(M, C), z(M, C), z(M, C)
+            xn, y, x2 = (xn_pre if xn_pre is not None else z(M, C)), z(M, C), z(M, C)
             a1, a2, a3 = zi(), zi(), zi()
-            ol.attn_q2p(None, B['kvq'], None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg,
-                        proj=dict(x=x, W=B['Wq'], emb=emb, ln=B['ln1'], ln_out=xn), acc_in=acc, out_proj=(B['Wo1'], a1))
+            if q_pre is not None:
+                ol.attn_q2p(None, B['kvq'], None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg, q_pre=q_pre, out_proj=(B['Wo1'], a1))
+            else:
+                ol.attn_q2p(None, B['kvq'], None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg,
+                            proj=dict(x=x, W=B['Wq'], emb=emb, ln=B['ln1'], ln_out=xn), acc_in=acc, out_proj=(B['Wo1'], a1))
             ol.attn_self(None, None, None, K=K, Q=Q, C=C, heads=heads, proj=dict(x=xn, W=B['Wqkv'], emb=emb, ln=B['ln2'], ln_out=y),
                          acc_in=(a1, B['Wo1'].bias), out_proj=(B['Wo2'], a2))
             ol.qffn(y, x2, a3, rows=M, ln=B['ln3'], W1=B['W1'], W2=B['W2'], acc_in=(a2, B['Wo2'].bias), hid_slice=hid_slice)
             acc = (a3, B['W2'].bias)
             pa = z(K, HW, C, dt=BF16)
+            next_q = None
+            q_pre = xn_pre = None
+            if qnext and b + 1 < len(blocks):
+                q_pre, xn_pre = z(M, C), z(M, C)
+                next_q = dict(ln=blocks[b + 1]['ln1'], W=blocks[b + 1]['Wq'], q_out=q_pre, xn_out=xn_pre)
+                out.update({f'qpre_{b + 1}': q_pre, f'xnpre_{b + 1}': xn_pre})
             ol.attn_p2q(B['kvq'].view(-1)[2 * C:], None, None, pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C,
-                        proj=dict(x=x2, W=B['Wkv'], emb=emb), acc_in=acc)
+                        proj=dict(x=x2, W=B['Wkv'], emb=emb), acc_in=acc, next_q=next_q)
             out.update({f'x2c_{b}': x2, f'pac_{b}': pa, f'yc_{b}': y})
             x = x2
         return ol, out
@@ -781,6 +792,48 @@ def test_query_chain_rejects_bad_forms():
     ol.add(O.QFFN, 0, [16, 300, 64], [], [y, y, y, y, y, y, y, y])
     with pytest.raises(RuntimeError, match="qffn"):
         ex.run(ol.finalize())
+
+
+@pytest.mark.parametrize('mode', ['mixed', 'nofg', 'allfg'])
+@pytest.mark.parametrize('qpre', [0, 1])
+def test_q2p_chain_mask_modes(mode, qpre):
+    """Chain form of ATTN_Q2P on the degenerate masks (an object without foreground: its foreground queries attend everywhere; an
+    object that is foreground everywhere: its background queries do); qpre: with the queries handed in already projected."""
+    def build(dev, g):
+        K, Q, HW, C, heads = 3, 16, 1620, 256, 8
+        M = K * Q
+        lg = _aux_inputs(g, K, HW, mode).to(dev)
+        x = torch.randn((M, C), generator=g).to(dev)
+        emb = (torch.randn((M, C), generator=g) * 0.5).to(dev)
+        gam, bet = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
+        Wq = pack_linear(torch.randn((C, C), generator=g) / 16, torch.randn(C, generator=g) * 0.1, dev)
+        Wo = pack_linear(torch.randn((C, C), generator=g) / 16, torch.randn(C, generator=g) * 0.1, dev)
+        kvq = rnd(g, (K, HW, 3 * C), dev=dev)
+        xn = torch.zeros((M, C), dtype=F32, device=dev)
+        att = torch.zeros((M, C), dtype=F32, device=dev)
+        x1 = torch.zeros((M, C), dtype=F32, device=dev)
+        acc = torch.zeros((M, C), dtype=torch.int64, device=dev)
+        ol = O.OpList()
+        ol.keep += [Wq.weight, Wo.weight]
+        if qpre:                                       # the projection by a LINEAR launch, scaled the way ATTN_P2Q's extra blocks leave it
+            qp, qs = torch.zeros((M, C), dtype=F32, device=dev), torch.zeros((M, C), dtype=F32, device=dev)
+            ol.linear(x, Wq, qp, M=M, x_add=emb, add_rows=M, ln=(gam, bet), ln_out=xn)
+            ol.axpy(qp, qs, n=M * C, a=1.0 / 32 ** 0.5)
+            ol.attn_q2p(None, kvq, None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg, q_pre=qs, out_proj=(Wo, acc))
+        else:
+            ol.attn_q2p(None, kvq, None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg,
+                        proj=dict(x=x, W=Wq, emb=emb, ln=(gam, bet), ln_out=xn), out_proj=(Wo, acc))
+        # the unfused pair for comparison: attention output, then the LINEAR (without its bias: the accumulator does not hold it)
+        ol.attn_q2p(None, kvq, None, None, att, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg,
+                    proj=dict(x=x, W=Wq, emb=emb, ln=(gam, bet), ln_out=None))
+        return ol, {'acc': acc, 'att': att, 'xn': xn, '_Wo': Wo.weight}
+    hip, ref = run_both(build, seed=5)
+    fa, fb = hip['acc'].double() / O.OpList.QACC_SCALE, ref['acc'].double() / O.OpList.QACC_SCALE
+    assert float((fa - fb).abs().max()) <= 3e-3 * max(1.0, float(fb.abs().max())), float((fa - fb).abs().max())
+    # and against the kernel's own attention output pushed through Wo on the host
+    want = hip['att'].double() @ hip['_Wo'].double()[:256, :256].t()
+    assert float((fa - want).abs().max()) <= 3e-3 * max(1.0, float(want.abs().max()))
+    check({'xn': hip['xn'], 'att': hip['att']}, {'xn': ref['xn'], 'att': ref['att']}, name='q2p chain ' + mode, rtol=3e-3)
 
 
 @pytest.mark.parametrize('K', [1, 3, 5])

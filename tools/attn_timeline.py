@@ -46,23 +46,30 @@ def main():
     pa = z(K, HW, C, dt=torch.bfloat16)
     launches = []
 
-    def one(name, fn, blocks):
+    def one(name, fn, blocks, stamps=True):
         ol = O.OpList()
         fn(ol)
         tl = torch.zeros((blocks, 16, 16), dtype=torch.int64, device=dev)
         ol.recs[-1][4].extend([0] * (16 - len(ol.recs[-1][4])))
-        ol.recs[-1][4][15] = tl.data_ptr()
+        if stamps:                                         # (p15 is taken in the next-q form of ATTN_P2Q: launch time only)
+            ol.recs[-1][4][15] = tl.data_ptr()
         ol.keep.append(tl)
         launches.append((name, ol, tl))
 
     one('ATTN_Q2P (+parts in, +out-proj)', lambda ol: ol.attn_q2p(None, kvq, None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg,
         proj=dict(x=x, W=Wq, emb=emb, ln=ln1, ln_out=xn), acc_in=(a0, W2.bias), out_proj=(Wo1, a1)), heads * K)
+    qpre = rn(M, C, sc=0.2)
+    one('ATTN_Q2P with q handed in', lambda ol: ol.attn_q2p(None, kvq, None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg,
+        q_pre=qpre, out_proj=(Wo1, a1)), heads * K)
     one('ATTN_SELF (+parts in, +out-proj)', lambda ol: ol.attn_self(None, None, None, K=K, Q=Q, C=C, heads=heads,
         proj=dict(x=xn, W=Wqkv, emb=emb, ln=ln2, ln_out=y), acc_in=(a1, Wo1.bias), out_proj=(Wo2, a2)), heads * K)
     one('QFFN slice 64', lambda ol: ol.qffn(y, x2, a3, rows=M, ln=ln3, W1=W1, W2=W2, acc_in=(a2, Wo2.bias), hid_slice=64), (FF // 64) * K)
     one('QFFN slice 128', lambda ol: ol.qffn(y, x2, a3, rows=M, ln=ln3, W1=W1, W2=W2, acc_in=(a2, Wo2.bias), hid_slice=128), (FF // 128) * K)
     one('ATTN_P2Q (+parts in)', lambda ol: ol.attn_p2q(kvq.view(-1)[2 * C:], None, None, pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C,
         proj=dict(x=x2, W=Wkv, emb=emb), acc_in=(a3, W2.bias)), -(-HW // 256) * heads * K)
+    qo, xo = z(M, C), z(M, C)
+    one('ATTN_P2Q + next q', lambda ol: ol.attn_p2q(kvq.view(-1)[2 * C:], None, None, pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C,
+        proj=dict(x=x2, W=Wkv, emb=emb), acc_in=(a3, W2.bias), next_q=dict(ln=ln1, W=Wq, q_out=qo, xn_out=xo)), (-(-HW // 256) + 1) * heads * K, stamps=False)
 
     src = torch.zeros(192 << 20, dtype=torch.uint8, device=dev)
     dst = torch.zeros(192 << 20, dtype=torch.uint8, device=dev)
@@ -99,6 +106,8 @@ def main():
                 acc.append(tl.cpu().numpy().astype(np.float64))
             t = acc[-1]
             used = t[:, :, 0] > 0                                              # waves that stamped
+            if not used.any():
+                continue
             # calibration: cycles per 100 MHz tick over the longest span
             cyc = (np.nanmax(np.where(t[:, :, :14] > 0, t[:, :, :14], np.nan), axis=2) - t[:, :, 0])[used]
             wall = (t[:, :, 15] - t[:, :, 14])[used]
