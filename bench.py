@@ -152,6 +152,11 @@ class Recorder:
             self.rec.append(arr.copy())
         self.ex.run(arr)
 
+    def run_cached(self, arr, cache, head=0):             # plans: replayed as HIP graphs by the executor, except while recording
+        if self.on:
+            return self.run(arr)
+        self.ex.run_cached(arr, cache, head)
+
     def stream(self):
         return self.ex.stream()
 
@@ -423,6 +428,9 @@ def main():
                        'lookahead': 'off' if args.no_lookahead else 'step(next_image=...): the next frame\'s image encoder runs on a '
                                     'side stream (same kernels, bit-identical results)'},
         }
+        gs = getattr(rec.ex, 'graph_stats', None)
+        if gs is not None:
+            out['plans_eager_vs_graph_replay'] = list(gs)      # whole run (pre-roll included): plans issued launch by launch | as one HIP graph
         if no_la is not None:
             out['value_no_lookahead'] = no_la['value']
             out['no_lookahead'] = dict(no_la, note='same clip, step(image) without the next_image hint (an unchanged scripting_demo.py)')

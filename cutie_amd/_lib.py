@@ -66,6 +66,8 @@ class HipExecutor:
         if not torch.cuda.is_available():
             raise HipLibraryError('no HIP device visible: cutie_amd runs on MI355X only (no CPU fallback).')
         self._torch = torch
+        self.graph_stats = [0, 0]          # plans run launch by launch | replayed as a graph
+        self._warned = False
 
     def stream(self):
         return self._torch.cuda.current_stream().cuda_stream
@@ -74,6 +76,44 @@ class HipExecutor:
         rc = self.lib.cutie_exec(arr.ctypes.data, len(arr), self.stream())
         if rc != 0:
             raise RuntimeError('cutie_exec failed: ' + self.lib.cutie_hip_last_error().decode())
+
+    # ---- HIP-graph replay of launch plans -------------------------------------------------------------------------------------
+    # A plan is ~15-60 launches at 2.5-4.6 us of host time each; the frame's ~160 launches cost the host 0.65-1.1 ms, about as long as
+    # the device needs for them, so a second stream (look-ahead encoder, deferred memorising) could not be fed fast enough to overlap
+    # (profiles/r03_host.md).  A plan whose bound pointers repeat (the caching allocator hands the same blocks back in steady state)
+    # is captured the second time it is seen and replayed as ONE graph launch from then on.
+    GRAPH_CACHE_ENTRIES = 24
+
+    def run_cached(self, arr, cache, head=0):
+        """cache: dict owned by the plan (pointer signature -> 0 seen once | graph handle | -1 capture failed).  The first `head` launches
+        (they read caller-owned pointers that differ every frame, e.g. the image) always run as launches."""
+        if head:
+            self.run(arr[:head])
+            arr = arr[head:]
+        key = arr['p'].tobytes()
+        ent = cache.get(key)
+        if ent is None:
+            if len(cache) >= self.GRAPH_CACHE_ENTRIES:
+                old = cache.pop(next(iter(cache)))
+                if old not in (0, -1):
+                    self.lib.cutie_graph_destroy(old)
+            cache[key] = 0
+            self.graph_stats[0] += 1
+            return self.run(arr)
+        if ent == 0:
+            ent = self.lib.cutie_graph_capture(arr.ctypes.data, len(arr), self.stream()) or -1
+            cache[key] = ent
+            if ent == -1 and not self._warned:
+                self._warned = True
+                import warnings
+                warnings.warn('HIP graph capture of a launch plan failed (%s); such plans keep running launch by launch'
+                              % self.lib.cutie_hip_last_error().decode())
+        if ent == -1:
+            self.graph_stats[0] += 1
+            return self.run(arr)
+        self.graph_stats[1] += 1
+        if self.lib.cutie_graph_launch(ent, self.stream()) != 0:
+            raise RuntimeError('cutie_graph_launch failed: ' + self.lib.cutie_hip_last_error().decode())
 
     def time_ops(self, arr, iters):
         ms = self.lib.cutie_time_ops(arr.ctypes.data, len(arr), iters, self.stream())

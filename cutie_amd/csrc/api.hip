@@ -58,18 +58,37 @@ int cutie_exec_one(const cutie_op* op, void* stream) { return cutie_exec(op, 1, 
 struct GraphHandle { hipGraph_t graph; hipGraphExec_t exec; };
 
 void* cutie_graph_capture(const cutie_op* ops, int n, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
+    // Captured on a private stream of the calling thread (capture records, it does not execute): the caller's stream may be the legacy
+    // default stream, which cannot be captured, and must not change state.  The instantiated graph is launched on any stream.
+    (void)stream;
+    static thread_local hipStream_t cap = nullptr;
+    if (!cap && hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) != hipSuccess) {
+        cap = nullptr;
+        (void)hipGetLastError();
+        cutie_set_error("graph: cannot create the capture stream");
+        return nullptr;
+    }
     hipGraph_t graph = nullptr;
-    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { cutie_set_error("graph: begin capture failed"); return nullptr; }
-    int rc = cutie_exec(ops, n, stream);
-    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        cutie_set_error("graph: begin capture failed");
+        return nullptr;
+    }
+    int rc = cutie_exec(ops, n, (void*)cap);
+    hipError_t e = hipStreamEndCapture(cap, &graph);
     if (rc != 0 || e != hipSuccess || !graph) {
         if (graph) hipGraphDestroy(graph);
         if (rc == 0) cutie_set_error("graph: end capture failed (%d)", (int)e);
+        (void)hipGetLastError();                             // the failed capture must not leave a sticky error for the next launch check
         return nullptr;
     }
     hipGraphExec_t exec = nullptr;
-    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { hipGraphDestroy(graph); cutie_set_error("graph: instantiate failed"); return nullptr; }
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        cutie_set_error("graph: instantiate failed");
+        return nullptr;
+    }
     GraphHandle* h = new GraphHandle{graph, exec};
     return h;
 }

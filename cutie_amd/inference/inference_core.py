@@ -24,6 +24,9 @@ from .object_manager import ObjectManager
 log = logging.getLogger()
 F32 = torch.float32
 AHEAD_AFFINITY = os.environ.get('CUTIE_AMD_AHEAD_AFFINITY', '1') not in ('', '0')     # look-ahead of the affinity read-out (see prefetch)
+# memorising on the side stream when no look-ahead hint is given (step / _join_pending): opt-in -- measured neutral on the MI355X (726 against
+# 730 fps without hints, profiles/r03_host.md: by the time the host has issued the next frame's encoder the side stream is almost done)
+DEFER_MEM = os.environ.get('CUTIE_AMD_DEFER_MEM', '0') not in ('', '0')
 
 
 def pad_geometry(h, w, d=16):
@@ -57,6 +60,7 @@ class InferenceCore:
         # interact only through the averaged prediction, so the flipped one is a second lane (= a nested core sharing the
         # object manager, with its own memory bank / sensory state / feature store) instead of a batch dimension in every plan
         self.flip_aug = bool(cfg.flip_aug) and _lane_of is None
+        self._lane_of_other = _lane_of
         # chunk_size: in the mask encoder and the decoder (big_modules.py:141-180,267-302) the reference's object chunks are
         # equivalent to the batched form (the HIP plans always batch; 288 GB of HBM).  In MemoryManager.read
         # (memory_manager.py:169-186) they are not: fusion and object transformer see only the objects of a chunk, which is
@@ -74,8 +78,24 @@ class InferenceCore:
         self.image_feature_store = ImageFeatureStore(self.network) if image_feature_store is None else image_feature_store
         self.last_mask = None
         self.pad = (0, 0, 0, 0)
-        self._enc_stream = None        # side stream of the look-ahead image encoder (prefetch)
+        self._enc_stream = None        # side stream of the look-ahead image encoder (prefetch) / of a deferred _add_memory
         self._prefetched = None        # (key of the source frame, prepared image, features, event)
+        self._pending_mem = None       # event of an _add_memory still running on the side stream (see step)
+        self._pending_refs = None      # its inputs: kept referenced until it is joined (pooled buffers are recycled by reference count)
+
+    def _side_stream(self, dev):
+        if self._enc_stream is None:
+            self._enc_stream = torch.cuda.Stream(device=dev)
+        return self._enc_stream
+
+    def _join_pending(self):
+        """Memorising frame t (mask encoder + bank insertion, ~25 % of such a frame) does not feed the frame's returned probabilities;
+        when the caller gives no look-ahead hint it is queued on the side stream so that the NEXT frame's image encoder (which does not
+        read the bank) overlaps with it.  Everything that reads or writes the bank, the sensory state or the object table joins here."""
+        ev = self._pending_mem
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._pending_mem = self._pending_refs = None
 
     # ---- look-ahead image encoder (no counterpart in the reference) ---------------------------------------------
     @staticmethod
@@ -108,16 +128,19 @@ class InferenceCore:
         main = torch.cuda.current_stream(dev)
         prepared, (h0, w0, H, W, pad) = self._prepare_image(image)      # (conversion, if any, runs on the caller's stream)
         geometry = (h0, w0, H, W, pad[0], pad[2])
-        if self._enc_stream is None:
-            self._enc_stream = torch.cuda.Stream(device=dev)
-        enc = self._enc_stream
+        enc = self._side_stream(dev)
         enc.wait_stream(main)                                  # frame conversion + any earlier encoder run on the main stream
-        with torch.cuda.stream(enc):
-            ms_features, pix_feat = self.network._encode_image_raw(prepared, *geometry)
-            key, shrinkage, selection = self.network.transform_key(ms_features[0])
-            ro = self.memory.prefetch_affinity(key, selection, self.network) if affinity else None
-            ev = torch.cuda.Event()
-            ev.record(enc)
+        pool = self.network.engine().pool
+        pool.offset = 1                                        # these are the NEXT frame's tensors: its slot of the frame-slot pool
+        try:
+            with torch.cuda.stream(enc):
+                ms_features, pix_feat = self.network._encode_image_raw(prepared, *geometry)
+                key, shrinkage, selection = self.network.transform_key(ms_features[0])
+                ro = self.memory.prefetch_affinity(key, selection, self.network) if affinity else None
+                ev = torch.cuda.Event()
+                ev.record(enc)
+        finally:
+            pool.offset = 0
         feats = (ms_features, pix_feat, key, shrinkage, selection)
         ahead = [v[0] for v in (ro or {}).values()]
         for t in list(ms_features) + [pix_feat, key, shrinkage, selection] + ahead + list(self.network._key_cache[1].values()):
@@ -155,6 +178,7 @@ class InferenceCore:
         return out
 
     def clear_memory(self):
+        self._join_pending()
         self.curr_ti = -1
         self.last_mem_ti = 0
         ovf = self.memory._scratch.get('overflow')              # (carried over: reported at the next step(end=True), no sync here)
@@ -168,6 +192,7 @@ class InferenceCore:
             self._flip.clear_memory()
 
     def clear_non_permanent_memory(self):
+        self._join_pending()
         self.curr_ti = -1
         self.last_mem_ti = 0
         self.memory.clear_non_permanent_memory()
@@ -175,6 +200,7 @@ class InferenceCore:
             self._flip.clear_non_permanent_memory()
 
     def clear_sensory_memory(self):
+        self._join_pending()
         self.curr_ti = -1
         self.last_mem_ti = 0
         self.memory.clear_sensory_memory()
@@ -182,6 +208,7 @@ class InferenceCore:
             self._flip.clear_sensory_memory()
 
     def update_config(self, cfg):
+        self._join_pending()
         self.mem_every = cfg['mem_every']
         self.memory.update_config(cfg)
         if self._flip is not None:
@@ -249,6 +276,8 @@ class InferenceCore:
                         mask = self._resize(mask, (new_h, new_w))
 
         self.curr_ti += 1
+        if self._lane_of_other is None:
+            self.network.engine().pool.tick()                  # frame-slot pool: this frame's slot (plans.SlotPool)
         pre, self._prefetched = self._prefetched, None
         if pre is not None and not resize_needed and pre[0] == self._frame_key(image):
             # this frame's encoder already ran (or is running) on the side stream
@@ -270,6 +299,7 @@ class InferenceCore:
 
         ms_feat, pix_feat = self.image_feature_store.get_features(self.curr_ti, image)
         key, shrinkage, selection = self.image_feature_store.get_key(self.curr_ti, image)
+        self._join_pending()                                   # (the image encoder above overlapped with a deferred _add_memory)
         fl = self._flip
         if fl is not None:
             # the reference flips the PADDED frame (:231-235): flipping the raw frame swaps the left / right pads
@@ -306,7 +336,20 @@ class InferenceCore:
         if fl is not None:
             fl.last_mask = self._flip_w(self.last_mask)        # (:303-305)
 
-        if is_mem_frame or force_permanent:
+        if (is_mem_frame or force_permanent) and DEFER_MEM and fl is None and next_image is None and not end and image.is_cuda \
+                and self.last_mask.shape[1] > 0:
+            main = torch.cuda.current_stream(image.device)
+            side = self._side_stream(image.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._add_memory(image, pix_feat, self.last_mask, key, shrinkage, selection, force_permanent=force_permanent)
+                self._pending_mem = torch.cuda.Event()
+                self._pending_mem.record(side)
+            self._pending_refs = (image, pix_feat, self.last_mask, key, shrinkage, selection)
+            for t in self._pending_refs:                       # allocated on main, still read on the side stream
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(side)
+        elif is_mem_frame or force_permanent:
             self._add_memory(image, pix_feat, self.last_mask, key, shrinkage, selection, force_permanent=force_permanent)
             if fl is not None:
                 fl._add_memory(image_f, pix_f, fl.last_mask, key_f, shr_f, sel_f, force_permanent=force_permanent)
@@ -317,6 +360,7 @@ class InferenceCore:
                 fl.image_feature_store.delete(self.curr_ti)
 
         if end:
+            self._join_pending()
             self.memory.check_overflow()
         output_prob = unpad(pred_prob_with_bg, self.pad)
         if resize_needed:
@@ -361,6 +405,7 @@ class InferenceCore:
         return prob
 
     def delete_objects(self, objects: List[int]) -> None:
+        self._join_pending()
         self.object_manager.delete_objects(objects)
         self.memory.purge_except(self.object_manager.all_obj_ids)
         if self._flip is not None:

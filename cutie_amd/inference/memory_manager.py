@@ -156,7 +156,9 @@ class MemoryManager:
         cidx = self._buf('cand_idx' + tag, (HW, CAND_CAP), torch.int32, dev)
         count = self._buf('count' + tag, (HW * O.OpList.AFF_CSTRIDE,), torch.int32, dev)
         ovf = self._buf('overflow', (1,), torch.int32, dev)
-        readout = torch.empty((K, h, w, self.CV), dtype=BF16, device=dev)
+        pool = getattr(self, '_pool', None)                      # (set by read / prefetch_affinity: the engine's frame-slot pool)
+        readout = (pool.get(('readout', bucket.id, K, h, w, str(dev)), dict(r=((K, h, w, self.CV), BF16, False)), dev)['r'] if pool is not None
+                   else torch.empty((K, h, w, self.CV), dtype=BF16, device=dev))
         # The affinity plan of a bucket only changes when its token ranges do (memory frames, consolidation, purge) or a
         # setting is updated: the descriptors are built once per such state with named pointer slots and re-bound per frame
         # (host time matters once several clips share one interpreter).
@@ -236,6 +238,7 @@ class MemoryManager:
         q = network.query_operands(query_key, selection)
         h, w = q['h'], q['w']
         dev = q['Bhi'].device
+        self._pool = network.engine().pool
         out = {}
         for bid, b in self.buckets.items():
             r = self._affinity(b, q, h, w, dev, ahead=True)
@@ -248,6 +251,7 @@ class MemoryManager:
         q = network.query_operands(query_key, selection)
         h, w = pix_feat.shape[-2:]
         dev = pix_feat.device
+        self._pool = network.engine().pool
         ahead = q.pop('_readouts', None) or {}
         all_readout = {}
         for bucket in self.buckets.values():

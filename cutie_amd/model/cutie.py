@@ -60,6 +60,7 @@ class Engine:
         self.m, self.device = m, device
         self.w = {}
         self._plans = {}
+        self.pool = plans.SlotPool()                # per-frame plan outputs at stable addresses (HIP-graph replay)
         self.tile_cache = plans.load_tile_cache()   # conv geometry -> autotuned (tile id, split-K); optionally persisted
         self._pe = {}
         self._rep = {}
@@ -202,8 +203,8 @@ class Engine:
         e.__dict__.update(self.__dict__)
         e._plans = {}
         e._arenas = {}
+        e.pool = plans.SlotPool()
         e.__dict__.pop('_splitk_part', None)
-        e.__dict__.pop('_qpool', None)
         return e
 
     def plan(self, key, builder, *args):
@@ -353,26 +354,18 @@ class CUTIE(nn.Module):
         hw = h * w
         HWp = -(-hw // 64) * 64
         ms = self.ms_dims
-        e = lambda shape, dt=BF16: torch.empty(shape, dtype=dt, device=dev)
-        # query-side affinity operands: rows [hw, HWp) are padding that must stay zero and is never written, so a small
-        # rotating pool of buffers zeroed once replaces three fill launches per frame (at most two frames' features are
-        # alive at a time: the current one and the look-ahead)
-        pool = eng.__dict__.setdefault('_qpool', {}).setdefault((hw, HWp, str(dev)), {'n': 0, 'bufs': []})   # keyed by hw too: another
-        # resolution with the same padded size would leave its rows in the padding
-        if len(pool['bufs']) < 4:
-            pool['bufs'].append((torch.zeros((HWp, 128), dtype=BF16, device=dev), torch.zeros((HWp, 128), dtype=BF16, device=dev),
-                                 torch.zeros((HWp,), dtype=F32, device=dev)))
-            qb = pool['bufs'][-1]
-        else:
-            qb = pool['bufs'][pool['n'] % 4]
-        pool['n'] += 1
-        out = dict(f16=e((1, h, w, ms[0])), f8=e((1, 2 * h, 2 * w, ms[1])), f4=e((1, 4 * h, 4 * w, ms[2])),
-                   pix_feat=e((1, h, w, m['pixel_dim'])), key=e((hw, m['key_dim']), F32), shr=e((hw,), F32),
-                   sel=e((hw, m['key_dim']), F32), Bhi=qb[0], Blo=qb[1], cq=qb[2])
+        # Outputs from the frame-slot pool (stable addresses: the plan replays as a HIP graph).  The query-side affinity operands
+        # Bhi / Blo / cq have padding rows [hw, HWp) that must stay zero and are never written: every pooled tensor starts zeroed.
         W_ = eng.w
-        out.update(f8p=e((1, 2 * h, 2 * w, W_['mask_decoder.decoder_feat_proc.transforms.0'].cout)),
-                   f4p=e((1, 4 * h, 4 * w, W_['mask_decoder.decoder_feat_proc.transforms.1'].cout)),
-                   fuse_xt=e((1, h, w, W_['pixel_fuser.fuser.distributor.x_transform'].cout)))
+        Z = False
+        specs = dict(f16=((1, h, w, ms[0]), BF16, Z), f8=((1, 2 * h, 2 * w, ms[1]), BF16, Z), f4=((1, 4 * h, 4 * w, ms[2]), BF16, Z),
+                     pix_feat=((1, h, w, m['pixel_dim']), BF16, Z), key=((hw, m['key_dim']), F32, Z), shr=((hw,), F32, Z),
+                     sel=((hw, m['key_dim']), F32, Z), Bhi=((HWp, 128), BF16, True), Blo=((HWp, 128), BF16, True), cq=((HWp,), F32, True),
+                     f8p=((1, 2 * h, 2 * w, W_['mask_decoder.decoder_feat_proc.transforms.0'].cout), BF16, Z),
+                     f4p=((1, 4 * h, 4 * w, W_['mask_decoder.decoder_feat_proc.transforms.1'].cout), BF16, Z),
+                     fuse_xt=((1, h, w, W_['pixel_fuser.fuser.distributor.x_transform'].cout), BF16, Z))
+        out = eng.pool.get(('enc', h, w, str(dev)), specs, dev)
+        P.graph_head = 1                                       # IMG_PREP reads the caller's frame
         image = image.to(F32).contiguous()
         P.run(image=image, **out)
         out['h'], out['w'] = h, w
@@ -476,8 +469,10 @@ class CUTIE(nn.Module):
         mk = masks[0].to(F32).contiguous()
         P = eng.plan(('emask', K, h0, w0, H, W, pl, pt, bool(deep_update)), plans.build_encode_mask, K, h0, w0, H, W, pl, pt,
                      bool(deep_update))
-        value = torch.empty((K, h, w, self.value_dim), dtype=BF16, device=dev)
-        summ = torch.empty((K, self.model_cfg['object_summarizer']['num_summaries'], self.embed_dim + 1), dtype=F32, device=dev)
+        o = eng.pool.get(('emask', K, h, w, str(dev)),
+                         dict(value=((K, h, w, self.value_dim), BF16, False),
+                              summ=((K, self.model_cfg['object_summarizer']['num_summaries'], self.embed_dim + 1), F32, False)), dev)
+        value, summ = o['value'], o['summ']
         P.run(image=img.to(F32).contiguous(), masks=mk, pix_feat=pix, sensory_f32=sf, sensory_bf16=sb, value=value, summ=summ)
         new_sens = group_logical(sf)
         frame_context.remember('sensory_bf16', sf, sb)
@@ -493,7 +488,7 @@ class CUTIE(nn.Module):
         lm = last_mask[0].to(F32).contiguous()
         xt = None if plans.UNFUSED else frame_context.recall('fuse_xt', pf)             # x_transform(pix_feat), computed with the encoder (None: a caller's own features)
         P = eng.plan(('fuse', K, h, w, xt is not None), plans.build_pixel_fusion, K, h, w, xt is not None)
-        fused = torch.empty((K, h, w, self.embed_dim), dtype=BF16, device=self.device)
+        fused = eng.pool.get(('fuse', K, h, w, str(self.device)), dict(fused=((K, h, w, self.embed_dim), BF16, False)), self.device)['fused']
         P.run(pix_feat=pf, pixel=px, sensory_bf16=sb, last_mask=lm, fused=fused, **({} if xt is None else {'fuse_xt': xt}))
         return group_logical(fused)
 
@@ -509,7 +504,7 @@ class CUTIE(nn.Module):
         om = om.sum(dim=1) if om.shape[1] != 1 else om[:, 0]
         om = om.contiguous()
         P = eng.plan(('rq', K, h, w, bool(_last_aux)), plans.build_readout_query, K, h, w, bool(_last_aux))
-        out = torch.empty((K, h, w, self.embed_dim), dtype=BF16, device=self.device)
+        out = eng.pool.get(('rq', K, h, w, str(self.device)), dict(out=((K, h, w, self.embed_dim), BF16, False)), self.device)['out']
         P.run(pixel=px, obj_mem=om, out=out)
         n_aux = P.bufs['aux_logits'].shape[0] - (0 if _last_aux else 1)
         aux = {'logits': [P.bufs['aux_logits'][i].view(1, K, h, w) for i in range(n_aux)],
@@ -530,8 +525,11 @@ class CUTIE(nn.Module):
         if pre is not None and pre[2].data_ptr() != f4.data_ptr():
             pre = None                                         # (f8 of one frame with f4 of another: a caller's own mix)
         P = eng.plan(('seg', K, h, w, bool(update_sensory), pre is not None), plans.build_segment, K, h, w, bool(update_sensory), pre is not None)
-        prob = torch.empty((K + 1, 16 * h, 16 * w), dtype=F32, device=dev)
-        lup = torch.empty((K + 1, 16 * h, 16 * w), dtype=F32, device=dev) if _need_logits else None
+        sp = dict(prob=((K + 1, 16 * h, 16 * w), F32, False))
+        if _need_logits:
+            sp['lup'] = ((K + 1, 16 * h, 16 * w), F32, False)
+        o = eng.pool.get(('seg', K, h, w, bool(_need_logits), str(dev)), sp, dev)   # (a caller that keeps the probabilities keeps the slot: see SlotPool)
+        prob, lup = o['prob'], o.get('lup')
         feats = dict(f8=f8, f4=f4) if pre is None else dict(f8p=pre[0], f4p=pre[1])
         P.run(p16=p16, sensory_f32=sf, sensory_bf16=sb, prob=prob, logits_up=lup, **feats)
         new_sens = group_logical(sf)

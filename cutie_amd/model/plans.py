@@ -11,6 +11,7 @@ import os
 import numpy as np
 import torch
 
+from .. import _lib
 from .. import ops as O
 from ..ops import Dyn
 from .param_spec import resnet_layers
@@ -55,6 +56,11 @@ TUNE_REPS, TUNE_ITERS = (int(v) for v in os.environ.get('CUTIE_AMD_TUNE', '3x8')
 # diagnostic: $CUTIE_AMD_UNFUSED=1 restores the unfused launch sequences of round 1 for in-box A/B timing (tools/r2_call*.sh)
 UNFUSED = os.environ.get('CUTIE_AMD_UNFUSED', '0') not in ('', '0')
 QCHAIN = os.environ.get('CUTIE_AMD_QCHAIN', '1') not in ('', '0')     # query side of a transformer block in 4 launches (0: the round-2 seven)
+# Plans replayed as HIP graphs once their pointer signature repeats (_lib.HipExecutor.run_cached): opt-in.  Measured on the MI355X
+# (profiles/r03_host.md): 94 % of the plan runs replay, the frame rate does not move (995.8 against 1003.3 fps) -- the look-ahead frame
+# is bound by the two streams sharing the compute units, not by the host's ~650 us of launches.
+GRAPHS = os.environ.get('CUTIE_AMD_GRAPHS', '0') not in ('', '0')
+GRAPH_MIN_OPS = 8
 QFFN_SLICE = int(os.environ.get('CUTIE_AMD_QFFN_SLICE', '64'))       # hidden columns per QFFN block (64 | 128)
 QNEXT = os.environ.get('CUTIE_AMD_QNEXT', '1') not in ('', '0')       # ATTN_P2Q also projects the next block's ATTN_Q2P queries
 AUTOTUNE = os.environ.get('CUTIE_AMD_AUTOTUNE', '0') not in ('', '0')
@@ -126,6 +132,45 @@ class Arena:
         return self.tensor.data_ptr()
 
 
+def _storage_users(t):
+    """How many OTHER tensors / views share t's storage (0: nobody else holds it)."""
+    return torch._C._storage_Use_Count(t.untyped_storage()._cdata) - 2
+
+
+class SlotPool:
+    """Per-frame outputs of the plans at STABLE addresses, so that a plan's pointer signature repeats and it can be replayed as a HIP
+    graph (_lib.HipExecutor.run_cached).  Every group serves frame f from its slot f % SLOTS (InferenceCore.step ticks the frame
+    number; the look-ahead lane asks for the NEXT frame's slot through `offset`), so the signatures of plans that consume each other's
+    outputs repeat with period SLOTS.  A slot whose tensors are still referenced elsewhere (a caller that keeps results, the feature
+    store with delete_buffer=False, a deferred memorising that still reads them, the same frame encoded twice) is NOT recycled: that
+    call is served from fresh torch allocations, and the plan simply runs launch by launch.
+    Cross-stream order: a slot is reused SLOTS frames later; the look-ahead encoder starts behind stream.wait_stream(main), i.e.
+    behind every read of the frame that used the slot before."""
+    SLOTS = int(os.environ.get('CUTIE_AMD_POOL_SLOTS', '6'))
+
+    def __init__(self):
+        self.groups = {}                  # key -> {slot index: {name: tensor}}
+        self.frame = 0
+        self.offset = 0
+
+    def tick(self):
+        self.frame += 1
+
+    def get(self, key, specs, dev):
+        """specs: {name: (shape, dtype, zero)} -> {name: tensor}"""
+        fresh = lambda: {n: (torch.zeros if z else torch.empty)(sh, dtype=dt, device=dev) for n, (sh, dt, z) in specs.items()}
+        if self.SLOTS <= 0:
+            return fresh()
+        slots = self.groups.setdefault(key, {})
+        i = (self.frame + self.offset) % self.SLOTS
+        slot = slots.get(i)
+        if slot is None:
+            slot = slots[i] = {nm: torch.zeros(sh, dtype=dt, device=dev) for nm, (sh, dt, z) in specs.items()}
+        if all(_storage_users(t) == 0 for t in slot.values()):
+            return {nm: t.view(t.shape) for nm, t in slot.items()}      # aliases: whoever keeps one (or a view of it) keeps the slot busy
+        return fresh()
+
+
 class Plan:
     def __init__(self, eng):
         self.eng = eng
@@ -138,6 +183,7 @@ class Plan:
         self.arena = None
         self._arena_slots = []           # (op index, pointer slot, byte offset inside the arena)
         self._arena_views = {}           # name -> (offset, shape, dtype)
+        self._graphs = {}                # pointer signature -> HIP graph of this plan (_lib.HipExecutor.run_cached)
 
     def buf(self, name, shape, dtype=BF16, persistent=False):
         assert name not in self.bufs, name
@@ -202,13 +248,24 @@ class Plan:
             n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
             self.bufs[name] = self.arena.tensor[off:off + n].view(dtype).view(shape)
 
+    graph_head = 0                       # leading launches that read caller-owned (volatile) pointers: kept out of the graph
+
     def run(self, **dyn):
         if not self.tuned:
             self.tuned = True
             self.autotune_convs(**dyn)
         if ARENA_POISON and self.arena is not None and self.arena.tensor is not None:
             self.arena.tensor.fill_(0xFF)               # (tests) nothing may rely on what an earlier run or another plan left in the arena
-        self.ol.run(**dyn)
+        ol = self.ol
+        ex = _lib.get_executor()
+        if GRAPHS and len(ol.recs) >= GRAPH_MIN_OPS and hasattr(ex, 'run_cached'):
+            if ol.arr is None:
+                ol.finalize()
+            if dyn:
+                ol.bind(**dyn)
+            ex.run_cached(ol.arr, self._graphs, self.graph_head)   # replayed as one HIP graph once its pointer signature repeats
+        else:
+            ol.run(**dyn)
 
     def autotune_convs(self, **dyn):
         """Pick the fastest tile shape for every conv of this plan by timing the candidates on the device

@@ -395,6 +395,48 @@ def test_lookahead_keeps_long_term_bookkeeping(gpu_net):
         assert float((out - plain).abs().max()) < 1e-3, (name, float((out - plain).abs().max()))
 
 
+def test_deferred_memorising_matches_inline(gpu_net, monkeypatch):
+    """Without a look-ahead hint, step() queues the memorising of a frame (mask encoder + bank insertion) on the side stream so that
+    the next frame's image encoder overlaps with it (InferenceCore._join_pending).  Same clip with the deferral switched off: same
+    bank, same counters, same probabilities -- also across the calls that must join it (delete_objects, a new mask, clear_*)."""
+    from cutie_amd.inference import inference_core as IC
+    from cutie_amd.utils.synth import SyntheticClip
+    clip = SyntheticClip(96, 160, 3, 36, seed=21)
+    n = 36
+    frames = torch.stack([clip.frame(t) for t in range(n)]).cuda()
+    mask = clip.first_mask().cuda()
+    cfg = default_config(use_long_term=True, mem_every=2, long_term=S.LT_SMALL)
+
+    def run(defer):
+        monkeypatch.setattr(IC, 'DEFER_MEM', defer)
+        proc = IC.InferenceCore(gpu_net, cfg=cfg)
+        outs = [proc.step(frames[0], mask, objects=clip.objects)]
+        for t in range(1, n):
+            if t == 9:
+                proc.delete_objects([clip.objects[-1]])
+            if t == 15:
+                keep = clip.objects[:-1]                        # a corrected mask for every object that is left
+                outs.append(proc.step(frames[t], mask * (mask != clip.objects[-1]).long(), objects=keep))
+                continue
+            if t == 30:
+                proc.clear_non_permanent_memory()
+                outs.append(proc.step(frames[t], mask, objects=clip.objects[:2]))
+                continue
+            outs.append(proc.step(frames[t], end=(t == n - 1)))
+        torch.cuda.synchronize()
+        b = next(iter(proc.memory.buckets.values()))
+        state = (b.n_long, b.n_work, b.n_perm, b.life[:b.work_start + b.n_work].float().cpu().clone())
+        return outs, state, proc._pending_mem
+
+    with torch.inference_mode():
+        a, sa, pa = run(True)
+        b, sb, _ = run(False)
+    assert pa is None                                          # step(end=True) joined it
+    assert sa[:3] == sb[:3] and torch.equal(sa[3], sb[3])
+    for t, (x, y) in enumerate(zip(a, b)):
+        assert x.shape == y.shape and float((x - y).abs().max()) < 1e-3, (t, float((x - y).abs().max()))
+
+
 def test_concurrent_clips_match_sequential(gpu_net):
     """parallel.run_concurrent: 4 clips in flight on one GPU (host thread + HIP stream + CUTIE.fork() each) produce
     bit-identical probabilities to the same clips run one after another."""

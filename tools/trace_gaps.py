@@ -1,0 +1,38 @@
+"""Look-ahead frame: is the main stream device-bound or waiting (for launches / for the side stream)?  From a rocprofv3 --kernel-trace CSV
+of bench.py: frames are cut at query_init2_kernel (one per frame, main stream); for the frames [f0, f1) the main queue's busy time, its
+idle gaps by the kernel that FOLLOWS the gap, and the side queue's busy time per frame.
+    python tools/trace_gaps.py <kernel_trace.csv> f0 f1"""
+import csv, sys
+from collections import defaultdict
+rows = list(csv.DictReader(open(sys.argv[1])))
+f0, f1 = int(sys.argv[2]), int(sys.argv[3])
+q = defaultdict(list)
+for r in rows:
+    q[r['Queue_Id']].append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][:48]))
+main = max(q, key=lambda k: sum('query_init2' in n for _, _, n in q[k]))
+side = [k for k in q if k != main]
+for v in q.values():
+    v.sort()
+mq = q[main]
+marks = [s for s, e, n in mq if 'query_init2' in n]
+print('queues', {k: len(v) for k, v in q.items()}, 'main', main, 'frames', len(marks))
+t0, t1 = marks[f0], marks[f1]
+nf = f1 - f0
+win = [x for x in mq if t0 <= x[0] < t1]
+busy = sum(e - s for s, e, _ in win)
+print(f'frames {f0}..{f1}: {(t1 - t0) / nf / 1e3:.1f} us per frame; main queue busy {busy / nf / 1e3:.1f} us per frame ({busy / (t1 - t0) * 100:.1f} %), {len(win) / nf:.1f} launches per frame')
+gap_by = defaultdict(lambda: [0, 0])
+for a, b in zip(win[:-1], win[1:]):
+    g = b[0] - a[1]
+    if g > 1500:
+        gap_by[b[2]][0] += g; gap_by[b[2]][1] += 1
+tot = sum(v[0] for v in gap_by.values())
+print(f'idle in gaps > 1.5 us: {tot / nf / 1e3:.1f} us per frame; by the kernel after the gap:')
+for n, (g, c) in sorted(gap_by.items(), key=lambda kv: -kv[1][0])[:14]:
+    print(f'   {n:50s} {g / nf / 1e3:7.1f} us per frame in {c / nf:5.2f} gaps per frame (mean {g / c / 1e3:.1f} us)')
+small = [b[0] - a[1] for a, b in zip(win[:-1], win[1:]) if 0 < b[0] - a[1] <= 1500]
+print(f'gaps <= 1.5 us: {len(small) / nf:.1f} per frame, mean {sum(small) / max(1, len(small)) / 1e3:.2f} us, total {sum(small) / nf / 1e3:.1f} us per frame')
+for k in side:
+    w = [x for x in q[k] if t0 <= x[0] < t1]
+    if w:
+        print(f'queue {k}: {len(w) / nf:.1f} launches per frame, busy {sum(e - s for s, e, _ in w) / nf / 1e3:.1f} us per frame')
