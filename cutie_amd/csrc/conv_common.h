@@ -1,4 +1,4 @@
-// Pieces shared by the convolution kernels (conv_igemm.hip, conv_bufload.hip): launch parameters, 16-B global load,
+// Pieces shared by the convolution kernels (conv_igemm.hip, conv_dma.hip, conv_pc.hip): launch parameters, 16-B global load,
 // LDS chunk swizzle and the epilogue tail.
 #pragma once
 #include "common.h"
@@ -129,7 +129,5 @@ __device__ __forceinline__ void conv_preload_args(const ConvParams& p) {
 #define TL_DUMP(LOGICAL, NB, NWAVES)
 #endif
 
-int launch_conv_bufload(const ConvParams& p, int tile, hipStream_t s);   // conv_bufload.hip (experimental tiles 50..)
 int launch_conv_dma(const ConvParams& p, int tile, hipStream_t s);
-int launch_conv_strip(const ConvParams& p, int tile, hipStream_t s);
-int launch_conv_pc(const ConvParams& p, int tile, hipStream_t s);         // conv_pc.hip: producer / consumer tiles 100..      // conv_strip.hip: tiles 90..       // conv_dma.hip (LDS-DMA tiles 60..)
+int launch_conv_pc(const ConvParams& p, int tile, hipStream_t s);         // conv_pc.hip: producer / consumer tiles 100..

@@ -338,240 +338,6 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvParams p) {
     }
 }
 
-// ---- 3x3 / stride 1 / pad 1 convolutions on small feature maps: input patch resident in LDS ------------------------
-// The stride-16 layers of this model (30 x 54 pixels per object; CAResBlocks of the fuser and of the transformer's pixel
-// FFN, key projection) spend their time on instruction issue, not on MFMA or memory: rocprofv3 counts ~150 VALU/SALU
-// instructions per K tile and wave (im2col address arithmetic, halo predicates, staging) around 16 MFMAs.
-// Here the block keeps the *input neighbourhood* of its output pixels in LDS, in zero-padded image coordinates
-// ((H+2) x (W+2) per image): the 9 taps are 9 uniform row shifts of the MFMA pixel-operand fragment reads -- no im2col
-// gather, no halo predicates (out-of-image taps read the stored zero border), 3 VALU per fragment address.  ~10 % of the MFMA
-// rows are border positions whose results are dropped.  Only the weights stream: WK K groups, each with its own
-// double-buffered [BN][64] weight tiles and a 4-deep register ring, split the 9*Cin/64 K tiles and share the patch.
-// 4 waves (2 x 2) per K group; accumulators summed through LDS; epilogue = conv_finish on the real pixels.
-template <int BM, int BN, int WK>
-__global__ __launch_bounds__(WK * 256) void conv3x3_patch_kernel(ConvParams p, int NP) {
-    constexpr int NTB = WK * 256, BK = 64, CPRW = 8;
-    constexpr int TM = BM / 2 / 16, TN = BN / 2 / 16, NWC = (BN * CPRW) / 256;
-    constexpr int LDC = BN + 4;
-    static_assert(TM >= 1 && TN >= 1 && NWC >= 1, "bad patch tile");
-    extern __shared__ __attribute__((aligned(16))) u32x4 psm[];
-    const int CPR = p.Cin >> 3;                          // 16-B chunks per patch row (a power of two)
-    const int cmask = CPR - 1;                           // chunk c of row r lives in slot (c + r) & cmask (rotation swizzle)
-    u32x4* patch = psm;                                   // [NP][CPR]
-    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-    u32x4 (*wsm)[BN * CPRW] = reinterpret_cast<u32x4 (*)[BN * CPRW]>(psm + (long)NP * CPR + grp * 2 * BN * CPRW);   // [2][BN][8]
-    int m0, n0;
-    {
-        const int nb = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
-        const int xcd = id & 7, kq = id >> 3, q = nb >> 3, r = nb & 7;
-        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kq;
-        const int mt = logical / (int)gridDim.y;
-        m0 = mt * BM;                                     // first PADDED pixel of this block
-        n0 = (logical - mt * (int)gridDim.y) * BN;
-    }
-    const int W = p.W, H = p.H, Wp = W + 2, PHW = (H + 2) * Wp, MP = p.B * PHW;    // padded geometry
-    // ---- weights: this group's K tiles [kbeg, kbeg + nkg); register ring of R tiles ----
-    const int nkg = (p.Kslice / BK) / WK;                // (same "argument / constant" spelling as conv_igemm_kernel)
-    const int kbeg = grp * nkg;
-    const int wrow = tid >> 3, wkc = tid & 7;
-    const bf16_t* wp[NWC];
-#pragma unroll
-    for (int i = 0; i < NWC; ++i) wp[i] = p.w + (long)(n0 + wrow + i * 32) * p.Kpad + (long)kbeg * BK + wkc * 8;
-    constexpr int R = 4;                                  // the weights of tile it+R are requested at tile it
-    u32x4 wr[R][NWC];
-#pragma unroll
-    for (int t = 0; t < R; ++t)
-#pragma unroll
-        for (int i = 0; i < NWC; ++i) wr[t][i] = GLOAD16(wp[i] + (t < nkg ? t : nkg - 1) * BK);
-#pragma unroll
-    for (int i = 0; i < NWC; ++i) wp[i] += (R < nkg ? R : nkg - 1) * BK;
-    // ---- the input patch: padded pixels g = m0 - Wp - 1 + r, r = 0 .. NP-1; zero on the borders and outside [0, MP) ----
-    // A thread keeps one chunk column and walks down the rows; (image, padded y, padded x) of its row are advanced
-    // incrementally -- three integer divisions per chunk were 2/3 of this kernel's instructions (rocprofv3 SQ_INSTS_VALU).
-    {
-        const bool relu_in = p.flags & CUTIE_F_RELU_IN;
-        const int Hp = H + 2;
-        const int cshift = 31 - __clz(CPR);               // CPR is a power of two
-        const int rstep = NTB >> cshift;                  // rows between two chunks of a thread
-        const int c = threadIdx.x & cmask;
-        int r = threadIdx.x >> cshift;
-        int bb, yp, xp;
-        {
-            const int t = m0 - Wp - 1 + r + PHW;          // >= 0 (the first patch row is at most Wp + 1 before pixel 0)
-            bb = t / PHW - 1;
-            const int rem = t - (bb + 1) * PHW;
-            yp = rem / Wp;
-            xp = rem - yp * Wp;
-        }
-        while (r < NP) {
-            constexpr int PL = 16;                        // chunk loads in flight per thread (the whole patch in 1-2 rounds)
-            u32x4 v[PL];
-            int rr[PL];
-#pragma unroll
-            for (int u = 0; u < PL; ++u) {
-                const bool ok = r < NP && bb >= 0 && bb < p.B && yp >= 1 && yp <= H && xp >= 1 && xp <= W;
-                const long off = ok ? ((long)(bb * H + yp - 1) * W + (xp - 1)) * p.ldx1 + c * 8 : 0;   // (offset select: stays a global_load)
-                v[u] = GLOAD16(p.x1 + off);
-                if (!ok) v[u] = (u32x4){0u, 0u, 0u, 0u};
-                rr[u] = r;
-                r += rstep;
-                xp += rstep;
-                while (xp >= Wp) { xp -= Wp; ++yp; }
-                while (yp >= Hp) { yp -= Hp; ++bb; }
-            }
-#pragma unroll
-            for (int u = 0; u < PL; ++u) {
-                if (rr[u] < NP) {
-                    u32x4 t = v[u];
-                    if (relu_in) { t.x = relu_bf2(t.x); t.y = relu_bf2(t.y); t.z = relu_bf2(t.z); t.w = relu_bf2(t.w); }
-                    patch[rr[u] * CPR + ((c + rr[u]) & cmask)] = t;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NWC; ++i) { const int n = wrow + i * 32; wsm[0][n * CPRW + (wkc ^ (n & 7))] = wr[0][i]; }
-    __syncthreads();
-    const int wm = wave >> 1, wn = wave & 1;
-    const int pm0 = wm * (BM / 2), cn0 = wn * (BN / 2);
-    const int l15 = lane & 15, l4 = lane >> 4;
-    // fragment addressing: patch row of pixel t (before the tap shift) r_t; chunk index = (r_t + shift) * CPR + ((r_t + shift + c) & cmask)
-    int rowc[TM], rowl[TM];
-#pragma unroll
-    for (int t = 0; t < TM; ++t) {
-        const int r = (Wp + 1) + pm0 + t * 16 + l15;
-        rowc[t] = r * CPR;
-        rowl[t] = r + l4;
-    }
-    f32x4 acc[TN][TM];
-#pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int cpt = p.Cin / BK;                          // K tiles per tap
-    int tap = kbeg / cpt, cc = kbeg - tap * cpt;         // tap and channel tile of the current K tile
-    // One K tile.  SL (compile-time) = the register-ring slot of tile IT (IT % R), BUF = its LDS buffer (IT & 1).  Slot SL was
-    // copied to LDS one tile ago, so the loads of tile IT+R go straight into it: R-1 tiles of MFMA work cover the L2 latency.
-    // Static register indices on purpose: with a runtime slot index hipcc waits for every load right after issuing it.
-#define PATCH_TILE(IT, SL, BUF, STORE_NEXT)                                                                \
-    {                                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < NWC; ++i) {                                                  \
-            const bool more_ = (IT) + R < nkg;                                                             \
-            /* clamped at the end (harmless re-read); an offset select, not a pointer select (see GLOAD16) */ \
-            wr[SL][i] = GLOAD16(wp[i] - (more_ ? 0 : BK));                                                 \
-            wp[i] += more_ ? BK : 0;                                                                       \
-        }                                                                                                  \
-        const int shift = (tap / 3 - 1) * Wp + (tap % 3 - 1);                                              \
-        const int u1 = shift * CPR;                                                                        \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
-            const int u2 = shift + cc * 8 + j * 4;                                                         \
-            bf16x8 bfr[TM], afr[TN];                                                                       \
-            _Pragma("unroll") for (int t = 0; t < TM; ++t)                                                 \
-                bfr[t] = __builtin_bit_cast(bf16x8, patch[rowc[t] + u1 + ((rowl[t] + u2) & cmask)]);       \
-            _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                               \
-                const int row = cn0 + t * 16 + l15;                                                        \
-                afr[t] = __builtin_bit_cast(bf16x8, wsm[BUF][row * CPRW + ((j * 4 + l4) ^ (row & 7))]);    \
-            }                                                                                              \
-            _Pragma("unroll") for (int a = 0; a < TN; ++a)                                                 \
-                _Pragma("unroll") for (int b = 0; b < TM; ++b)                                             \
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[a], bfr[b], acc[a][b], 0, 0, 0); \
-        }                                                                                                  \
-        if (STORE_NEXT) {                                  /* tile IT+1 (next ring slot) -> the other LDS buffer */ \
-            _Pragma("unroll") for (int i = 0; i < NWC; ++i) {                                              \
-                const int n = wrow + i * 32;                                                               \
-                wsm[(BUF) ^ 1][n * CPRW + (wkc ^ (n & 7))] = wr[((SL) + 1) % R][i];                        \
-            }                                                                                              \
-        }                                                                                                  \
-        ++cc;                                                                                              \
-        if (cc == cpt) { cc = 0; ++tap; }                                                                  \
-        __syncthreads();                                                                                   \
-    }
-    int it = 0;
-    for (; it + R < nkg; it += R) {                      // (R == 4: slot and buffer parities are static inside the body)
-        PATCH_TILE(it, 0, 0, true)
-        PATCH_TILE(it + 1, 1, 1, true)
-        PATCH_TILE(it + 2, 2, 0, true)
-        PATCH_TILE(it + 3, 3, 1, true)
-    }
-    if (it < nkg) PATCH_TILE(it, 0, 0, it + 1 < nkg)     // the last 1..4 tiles (it is a multiple of 4 here)
-    if (it + 1 < nkg) PATCH_TILE(it + 1, 1, 1, it + 2 < nkg)
-    if (it + 2 < nkg) PATCH_TILE(it + 2, 2, 0, it + 3 < nkg)
-    if (it + 3 < nkg) PATCH_TILE(it + 3, 3, 1, false)
-#undef PATCH_TILE
-    // ---- K groups add their accumulators in a fixed order, then the shared epilogue on the real (non-border) pixels ----
-    float* ctile = reinterpret_cast<float*>(psm);
-#pragma unroll
-    for (int g = WK - 1; g >= 0; --g) {
-        if (grp == g) {
-#pragma unroll
-            for (int b = 0; b < TM; ++b)
-#pragma unroll
-                for (int a = 0; a < TN; ++a) {
-                    const int px = pm0 + b * 16 + l15, ch = cn0 + a * 16 + l4 * 4;
-                    f32x4* dst = reinterpret_cast<f32x4*>(ctile + px * LDC + ch);
-                    if (g == WK - 1) *dst = acc[a][b];
-                    else { f32x4 t = *dst; t[0] += acc[a][b][0]; t[1] += acc[a][b][1]; t[2] += acc[a][b][2]; t[3] += acc[a][b][3]; *dst = t; }
-                }
-        }
-        __syncthreads();
-    }
-    constexpr int CH8 = BN / 8, PSTEP = NTB / CH8;       // a thread keeps its 8-channel column and walks down the pixels
-    {
-        const int Hp = H + 2;
-        const int c8 = threadIdx.x % CH8, ch0 = n0 + c8 * 8;
-        int px = threadIdx.x / CH8;
-        int bb, yp, xp;
-        {
-            const int g = m0 + px;
-            bb = g / PHW;
-            const int rem = g - bb * PHW;
-            yp = rem / Wp;
-            xp = rem - yp * Wp;
-        }
-        for (; px < BM; px += PSTEP) {
-            if (bb < p.B && ch0 < p.Cout && yp >= 1 && yp <= H && xp >= 1 && xp <= W) {      // not a border position
-                const int m = (bb * H + yp - 1) * W + (xp - 1);
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(ctile + px * LDC + c8 * 8);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(ctile + px * LDC + c8 * 8 + 4);
-                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                conv_finish(p, v, m, ch0);
-            }
-            xp += PSTEP;
-            while (xp >= Wp) { xp -= Wp; ++yp; }
-            while (yp >= Hp) { yp -= Hp; ++bb; }
-        }
-    }
-}
-
-template <int BM, int BN, int WK>
-static int launch_patch(ConvParams p, hipStream_t s) {
-    const int nk = 9 * p.Cin / 64;
-    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.C2 != 0 || (p.Cin & 63) || (p.Cin & (p.Cin - 1)) || nk % WK || nk / WK < 2 ||
-        p.splitk != 1 || p.OH != p.H || p.OW != p.W) {
-        cutie_set_error("conv patch tile: needs a single-source 3x3 stride-1 pad-1 conv with Cin a power of two >= 64 and %d | 9 Cin/64 (Cin=%d)", WK, p.Cin);
-        return -2;
-    }
-    const int Wp = p.W + 2;
-    const int NP = BM + 2 * Wp + 2;
-    const long patch_b = (long)NP * p.Cin * 2, w_b = (long)WK * 2 * BN * 128, epi_b = (long)BM * (BN + 4) * 4;
-    const long lds = (patch_b + w_b > epi_b ? patch_b + w_b : epi_b);
-    if (lds > 160 * 1024) { cutie_set_error("conv patch tile: %ld bytes of LDS needed (W=%d, Cin=%d)", lds, p.W, p.Cin); return -2; }
-    static long attr_set = 0;                            // per instantiation: largest size granted so far
-    if (lds > attr_set) {
-        if (lds > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_patch_kernel<BM, BN, WK>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-            cutie_set_error("conv patch tile: cannot raise the dynamic LDS limit");
-            return -2;
-        }
-        attr_set = 160 * 1024;
-    }
-    p.Kslice = nk * 64;                                  // = 9 * Cin: the padded tail of Kpad is not visited
-    const long MP = (long)p.B * (p.H + 2) * Wp;          // padded pixel positions
-    dim3 grid((unsigned)((MP + BM - 1) / BM), (p.Cout + BN - 1) / BN);
-    hipLaunchKernelGGL((conv3x3_patch_kernel<BM, BN, WK>), grid, dim3(WK * 256), (size_t)lds, s, p, NP);
-    return (int)hipGetLastError();
-}
-
 template <int BM, int BN, int WM, int WN, int BK, int S, int OCC, int WK = 1>
 static int launch_cfg(ConvParams p, hipStream_t s) {
     if (p.Kpad % BK) { cutie_set_error("conv: Kpad %d not a multiple of BK %d", p.Kpad, BK); return -2; }
@@ -636,10 +402,8 @@ int launch_conv(const cutie_op* op, hipStream_t s) {
         hipLaunchKernelGGL(conv_cout1_kernel, dim3((p.M + ppb - 1) / ppb), dim3(256), (size_t)p.KH * p.KW * LP * 16, s, p);
         return (int)hipGetLastError();
     }
-    if (i[17] >= 50 && i[17] < 60) return launch_conv_bufload(p, i[17], s);     // experimental tiles (conv_bufload.hip)
     if (i[17] >= 60 && i[17] < 90) return launch_conv_dma(p, i[17], s);         // LDS-DMA tiles (conv_dma.hip)
     if (i[17] >= 100 && i[17] < 200) return launch_conv_pc(p, i[17], s);         // producer / consumer LDS-DMA tiles (conv_pc.hip)
-    if (i[17] >= 90 && i[17] < 100) return launch_conv_strip(p, i[17], s);      // LDS-DMA with the 3x3 input strip resident (conv_strip.hip)
     switch (i[17]) {
         case 0: return launch_cfg<128, 128, 2, 2, 32, 4, 2>(p, s);
         case 1: return launch_cfg<128, 64, 2, 2, 32, 4, 3>(p, s);
@@ -671,11 +435,6 @@ int launch_conv(const cutie_op* op, hipStream_t s) {
         case 27: return launch_cfg<64, 64, 2, 2, 64, 3, 3, 4>(p, s);
         case 28: return launch_cfg<32, 64, 2, 2, 64, 4, 4, 4>(p, s);
         // 40..: 3x3 convs with the input patch resident in LDS (small feature maps)
-        case 40: return launch_patch<128, 64, 2>(p, s);
-        case 41: return launch_patch<64, 64, 2>(p, s);
-        case 42: return launch_patch<64, 128, 2>(p, s);
-        case 43: return launch_patch<128, 64, 1>(p, s);
-        case 44: return launch_patch<64, 64, 1>(p, s);
         case 29: return launch_cfg<64, 128, 2, 2, 32, 4, 3, 2>(p, s);
         case 30: return launch_cfg<64, 64, 2, 2, 32, 4, 4, 2>(p, s);
         default: cutie_set_error("conv: bad tile id %d", i[17]); return -2;

@@ -307,9 +307,9 @@ class Plan:
                             best, best_t = (t, sk), ms
                 cache[key] = best
                 tuned_any = True
-            if (best[0] in O.DMA_TILES or best[0] in O.STRIP_TILES or best[0] in O.PC_TILES) and not O.dma_tiles_enabled():
+            if (best[0] in O.DMA_TILES or best[0] in O.PC_TILES) and not O.dma_tiles_enabled():
                 continue
-            if (arr['p'][n, 7] or arr['p'][n, 8]) and best[0] not in O.DMA_TILES and best[0] not in O.STRIP_TILES and best[0] not in O.PC_TILES:
+            if (arr['p'][n, 7] or arr['p'][n, 8]) and best[0] not in O.DMA_TILES and best[0] not in O.PC_TILES:
                 continue                                     # GAP accumulation / zero job exist in conv_dma_kernel only
             arr['i'][n, 17], arr['i'][n, 19] = best
         self.tuned = True

@@ -39,18 +39,11 @@ TILES = {0: (128, 128, 32), 1: (128, 64, 32), 2: (64, 64, 32), 3: (256, 16, 32),
          13: (64, 64, 64), 14: (128, 64, 64), 15: (64, 128, 64), 16: (128, 128, 64), 17: (64, 64, 128), 18: (128, 128, 32),   # 13+: 8 waves
          # 20+: WK K groups per block (intra-block split-K: WK copies of the 4-wave pipeline on one output tile)
          20: (64, 64, 64), 21: (64, 64, 128), 22: (32, 64, 128), 23: (128, 64, 64), 24: (64, 128, 64), 25: (128, 128, 64),
-         26: (32, 64, 64), 27: (64, 64, 64), 28: (32, 64, 64), 29: (64, 128, 32), 30: (64, 64, 32),
-         # 40+: 3x3 / stride 1 / pad 1 with the input patch resident in LDS (conv3x3_patch_kernel; small feature maps only)
-         40: (128, 64, 64), 41: (64, 64, 64), 42: (64, 128, 64), 43: (128, 64, 64), 44: (64, 64, 64)}
-TILE_WK = {20: 2, 21: 2, 22: 2, 23: 2, 24: 2, 25: 2, 26: 2, 27: 4, 28: 4, 29: 2, 30: 2, 40: 2, 41: 2, 42: 2, 43: 1, 44: 1}
-PATCH_TILES = (40, 41, 42, 43, 44)
-# 50+: EXPERIMENTAL buffer-load kernel (conv_bufload.hip): written after the last GPU minute of round 1 from the static
-# instruction mix of the default kernel (5-8 instead of 10-27 non-MFMA instructions per MFMA in the steady-state loop); its
-# integer logic is emulated on the CPU (tools/emulate_bufload_addressing.py) but it has not run on a GPU yet, so it takes part
-# in the autotuning ONLY with CUTIE_AMD_EXPERIMENTAL_TILES=1 (tests: test_gpu_kernels.py::test_conv_bufload_tiles, same switch).
-EXPERIMENTAL_TILES = {50: (128, 64, 64), 51: (64, 64, 64), 52: (64, 128, 64), 53: (32, 64, 128), 54: (64, 64, 128),
-                      55: (128, 128, 64), 56: (32, 64, 64)}
-
+         26: (32, 64, 64), 27: (64, 64, 64), 28: (32, 64, 64), 29: (64, 128, 32), 30: (64, 64, 32)}
+TILE_WK = {20: 2, 21: 2, 22: 2, 23: 2, 24: 2, 25: 2, 26: 2, 27: 4, 28: 4, 29: 2, 30: 2}
+# (Round 3 removed three kernel families that no geometry of the cold-cache sweeps selects any more -- profiles/r03_conv_sweep_cold.md:
+# 40..44 patch-resident 3x3 in the register-staged kernel, 50..56 buffer-load kernel, 90..95 strip-resident 3x3.  The halo tiles of
+# conv_pc.hip, 120.., are what became of the resident-input idea.)
 
 # 60+: LDS-DMA kernel (conv_dma.hip): operands global -> LDS by buffer_load ... lds, rolled K loop with ~2-4 non-MFMA
 # instructions per MFMA.  id -> (BM, BN, BK); needs Cin % 64 == 0 (both sources of a virtual concat), no split-K.
@@ -60,10 +53,6 @@ DMA_TILES = {60: (128, 128, 64), 61: (128, 128, 64), 62: (128, 128, 64), 63: (12
              80: (64, 64, 128), 81: (64, 64, 128), 82: (32, 64, 128), 83: (32, 64, 128), 84: (64, 128, 128), 85: (128, 64, 128),
              86: (96, 64, 64), 87: (96, 64, 64), 88: (64, 64, 64), 89: (64, 64, 64)}
 
-
-# 90+: conv_strip.hip -- 3x3 / stride 1 / pad 1 on narrow maps with the input strip resident in LDS: tile -> (BM, BN, BK) / waves
-STRIP_TILES = {90: (128, 64, 64), 91: (64, 64, 64), 92: (128, 128, 64), 93: (64, 128, 64), 94: (128, 64, 64), 95: (64, 64, 64)}
-STRIP_WAVES = {90: 4, 91: 4, 92: 8, 93: 4, 94: 8, 95: 8}
 
 # 100+: conv_pc.hip -- producer / consumer split (NPW producer waves issue every LDS-DMA piece, WM x WN consumer waves only read
 # fragments and issue MFMAs), epilogue straight from the accumulators.  100..: stream mode (any kernel size / stride);
@@ -77,7 +66,7 @@ PC_TILES = {100: (64, 64, 64), 101: (64, 64, 64), 102: (32, 64, 64), 103: (128, 
 PC_HALO = {120: (8, 8), 121: (4, 16), 122: (8, 16), 123: (8, 16), 124: (8, 8), 125: (4, 8), 126: (8, 16), 127: (4, 16),
            129: (10, 9), 130: (5, 6), 131: (6, 9), 132: (6, 9), 133: (10, 9)}
 
-ALL_TILES = {**TILES, **DMA_TILES, **STRIP_TILES, **PC_TILES}
+ALL_TILES = {**TILES, **DMA_TILES, **PC_TILES}
 
 
 def pc_tile_ok(tile, *, cin, kh, stride=1, pad=None, c2=0):
@@ -109,42 +98,11 @@ def dma_tile_ok(tile, *, cin, kh, c2=0):
     return cin % bk == 0 and (c2 == 0 or (c2 % bk == 0 and (cin - c2) % bk == 0)) and kh * kh <= 32
 
 
-def strip_tile_ok(tile, *, cin, kh, stride, pad, W, c2=0):
-    """conv_strip_kernel eligibility (mirrors launch_strip in conv_strip.hip)."""
-    bm, bn, _ = STRIP_TILES[tile]
-    srp = (bm + 2 * W + 2 + 7) & ~7
-    ppw = -(-(srp // 8) // STRIP_WAVES[tile])
-    lds = max(2 * srp * 128 + 3 * bn * 128, bm * (bn + 4) * 4)
-    return (kh == 3 and stride == 1 and pad == 1 and cin % 64 == 0 and (c2 == 0 or (c2 % 64 == 0 and (cin - c2) % 64 == 0))
-            and ppw <= 8 and lds <= 160 * 1024)
-
-
 def conv_side_jobs_ok(*, cin, cout, kh, c2=0):
     """Can a conv of this geometry carry the GAP accumulation / zero job (conv_dma_kernel only)?"""
     return dma_tiles_enabled() and dma_tile_ok(60, cin=cin, kh=kh, c2=c2) and cout % 8 == 0 and cout > 16
 
 
-def experimental_tiles_enabled():
-    return os.environ.get('CUTIE_AMD_EXPERIMENTAL_TILES', '0') not in ('', '0')
-
-
-def bufload_tile_ok(tile, *, cin, kh, c2=0, kpad=None):
-    """conv_bufload_kernel eligibility (mirrors launch_buf in conv_bufload.hip): a K tile must not straddle a tap or a source."""
-    bk = EXPERIMENTAL_TILES[tile][2]
-    return cin % bk == 0 and (c2 == 0 or (cin - c2) % bk == 0) and kh * kh <= 16 and (kpad is None or kpad % bk == 0)
-
-
-def patch_tile_ok(tile, *, cin, kh, stride, pad, W, c2=0):
-    """conv3x3_patch_kernel eligibility (mirrors launch_patch in conv_igemm.hip)."""
-    bm, bn, _ = TILES[tile]
-    wk = TILE_WK[tile]
-    if kh != 3 or stride != 1 or pad != 1 or c2 or cin < 64 or cin & (cin - 1):
-        return False
-    nk = 9 * cin // 64
-    if nk % wk or nk // wk < 2:
-        return False
-    lds = max((bm + 2 * (W + 2) + 2) * cin * 2 + wk * 2 * bn * 128, bm * (bn + 4) * 4)
-    return lds <= 160 * 1024
 NUM_CU = 256
 
 
@@ -158,16 +116,12 @@ def cout1_ok(cout, cin, c2=0, res=False):
 
 def tile_candidates(M, cout, cin, kpad=None, geom=None):
     """Tile ids that are legal for a conv (BK > 32 needs Cin >= 32; tiny Cout uses the 256x16 tile; the K groups of a
-    WK tile must divide the K tiles; geom = dict(kh, stride, pad, W, c2) enables the patch-resident 3x3 tiles)."""
+    WK tile must divide the K tiles; geom = dict(kh, stride, pad, W, c2) enables the LDS-DMA families)."""
     if cout <= 16:
         return [3] + ([COUT1_TILE] if cout1_ok(cout, cin) else [])
     out = []
     for t, (bm, bn, bk) in TILES.items():
         if t == 3 or (bk > 32 and cin < 32):
-            continue
-        if t in PATCH_TILES:
-            if geom is not None and patch_tile_ok(t, cin=cin, **geom) and not (bn == 128 and cout <= 64):
-                out.append(t)
             continue
         wk = TILE_WK.get(t, 1)
         if wk > 1 and (kpad is None or (kpad // bk) % wk or kpad // bk < 2 * wk):
@@ -182,20 +136,10 @@ def tile_candidates(M, cout, cin, kpad=None, geom=None):
             if not (bn == 128 and cout <= 64) and not (bm > 64 and bm > max(M, 64)) and not (bm == 256 and M < 16384) \
                     and dma_tile_ok(t, cin=cin, kh=geom['kh'], c2=geom.get('c2', 0)):
                 out.append(t)
-    if dma_tiles_enabled() and geom is not None and 'stride' in geom:
-        for t, (bm, bn, bk) in STRIP_TILES.items():
-            if strip_tile_ok(t, cin=cin, kh=geom['kh'], stride=geom['stride'], pad=geom['pad'], W=geom['W'], c2=geom.get('c2', 0)) \
-                    and not (bn == 128 and cout <= 64) and not (bm > 64 and bm > max(M, 64)):
-                out.append(t)
     if dma_tiles_enabled() and geom is not None:
         for t, (bm, bn, bk) in PC_TILES.items():
             if pc_tile_ok(t, cin=cin, kh=geom['kh'], stride=geom.get('stride', 1), pad=geom.get('pad'), c2=geom.get('c2', 0)) \
                     and not (bn == 128 and cout <= 64) and not (bm > 64 and bm > max(M, 64)) and not (bm == 256 and M < 16384):
-                out.append(t)
-    if experimental_tiles_enabled() and geom is not None:
-        for t, (bm, bn, bk) in EXPERIMENTAL_TILES.items():
-            if bufload_tile_ok(t, cin=cin, kh=geom['kh'], c2=geom.get('c2', 0), kpad=kpad) and not (bn == 128 and cout <= 64) \
-                    and not (bm > 64 and bm > max(M, 64)):
                 out.append(t)
     return out
 
@@ -219,7 +163,7 @@ def splitk_scratch(device, owner=None):
 
 def splitk_candidates(M, cout, kpad, tile):
     """Split-K factors worth timing for a conv on a given tile: only when the plain grid leaves CUs idle."""
-    if tile == COUT1_TILE or tile == 3 or tile in PATCH_TILES or tile in EXPERIMENTAL_TILES or tile in DMA_TILES or tile in STRIP_TILES or tile in PC_TILES:
+    if tile == COUT1_TILE or tile == 3 or tile in DMA_TILES or tile in PC_TILES:
         return [1]
     bm, bn, bk = TILES[tile]
     blocks = -(-M // bm) * -(-cout // bn)
@@ -345,7 +289,7 @@ class OpList:
         if tile is None:
             tile = COUT1_TILE if (cout1_ok(w.cout, C1 + C2, C2, res is not None) and not side) else pick_tile(M, w.cout, C1 + C2, dict(kh=w.kh, c2=C2))
         if side:
-            assert (tile in DMA_TILES or tile in STRIP_TILES or tile in PC_TILES) and not out_f32 and w.cout % 8 == 0 and ldy % 8 == 0, 'GAP accumulation needs an LDS-DMA conv (see conv_side_jobs_ok)'
+            assert (tile in DMA_TILES or tile in PC_TILES) and not out_f32 and w.cout % 8 == 0 and ldy % 8 == 0, 'GAP accumulation needs an LDS-DMA conv (see conv_side_jobs_ok)'
         part = splitk_scratch(w.weight.device, self.scratch_owner)
         return self.add(CONV, flags,
                         [B, H, W, C1, C2, ldx1, ldx2, OH, OW, w.cout, ldy, w.kh, w.kw, stride, pad, ldr, w.kpad, tile, w.cin_real,

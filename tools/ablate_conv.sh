@@ -9,7 +9,7 @@ for spec in ${SPECS:-NO_DMA=NO_DMA NO_DSREAD=NO_DSREAD NO_MFMA=NO_MFMA DMA_ONLY=
   v=${spec%%=*}; defs=""; for m in $(echo ${spec#*=} | tr , ' '); do defs="$defs -DDMA_ABL_$m"; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-variable -Wno-unused-value -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form \
       $defs -c conv_dma.hip -o ../../tools/abl/conv_dma_$v.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC conv_igemm.o conv_bufload.o ../../tools/abl/conv_dma_$v.o elementwise.o attention.o affinity.o bank.o api.o \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC conv_igemm.o conv_pc.o ../../tools/abl/conv_dma_$v.o elementwise.o attention.o qchain.o affinity.o bank.o api.o \
       -o ../../tools/abl/libcutie_hip_$v.so
 done
 ls -la ../../tools/abl/*.so

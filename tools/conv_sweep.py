@@ -20,14 +20,8 @@ def family(t, O):
         return 'halo'
     if t in O.PC_TILES:
         return 'pc'
-    if t in O.STRIP_TILES:
-        return 'strip'
     if t in O.DMA_TILES:
         return 'dma'
-    if t in O.EXPERIMENTAL_TILES:
-        return 'bufload'
-    if t in O.PATCH_TILES:
-        return 'patch'
     return 'igemm'
 
 
@@ -40,9 +34,8 @@ def main():
     ap.add_argument('--width', type=int, default=854)
     ap.add_argument('--out', default='gpurun_out/conv_sweep')
     ap.add_argument('--cold', type=int, default=0, help='MiB copied through the device before every timed launch (evicts code and operands from the L2s: the state a layer finds inside a frame); 0 = warm back-to-back timing')
-    ap.add_argument('--families', default='', help='comma list: time only tiles of these families (igemm,patch,bufload,dma,strip,pc,halo); default all')
+    ap.add_argument('--families', default='', help='comma list: time only tiles of these families (igemm,dma,pc,halo); default all')
     args = ap.parse_args()
-    os.environ.setdefault('CUTIE_AMD_EXPERIMENTAL_TILES', '1')
     from bench import Recorder
     from cutie_amd import _lib, ops as O
     from cutie_amd.config import default_config
@@ -134,7 +127,7 @@ def main():
     os.makedirs(os.path.dirname(args.out) or '.', exist_ok=True)
     json.dump(rows, open(args.out + '.json', 'w'))
     json.dump({'tiles': table}, open(args.out + '_tiles.json', 'w'))
-    fam = [f for f in ['igemm', 'patch', 'bufload', 'dma', 'strip', 'pc', 'halo'] if any(f in r['families'] for r in rows)]
+    fam = [f for f in ['igemm', 'dma', 'pc', 'halo'] if any(f in r['families'] for r in rows)]
     tot = {f: 0.0 for f in fam + ['best', 'old']}
     print(f'{"M":>6s} {"Cout":>5s} {"Cin":>5s} k s fl     HxW  n  GFLOP |' + ''.join(f' {f:>14s}' for f in fam) + ' |  best TFLOP/s')
     for r in sorted(rows, key=lambda r: -r['best'][2] * r['count']):
@@ -143,12 +136,12 @@ def main():
         for f in fam:
             v = r['families'].get(f)
             cells += f' {v[0]:3d}x{v[1]:<2d} {v[2]:7.1f}' if v else ' ' * 15
-        old = min([v[2] for f, v in r['families'].items() if f in ('igemm', 'patch', 'dma', 'strip')] or [r['best'][2]])
+        old = min([v[2] for f, v in r['families'].items() if f in ('igemm', 'dma')] or [r['best'][2]])
         tot['best'] += r['best'][2] * r['count']
         tot['old'] += old * r['count']
         print(f'{key[0]:6d} {key[1]:5d} {key[2]:5d} {key[3]} {key[4]} {key[5]} {key[6]:4d}x{key[7]:<4d} {r["count"]:2d} {r["gflop"]:6.2f} |{cells} | '
               f'{r["best"][0]:3d} {r["gflop"] / r["best"][2] * 1e3:7.1f}')
-    print(f'sum over the recorded frames: best-of-all {tot["best"]:.1f} us, best of the round-2 kernels (igemm/patch/dma/strip) {tot["old"]:.1f} us '
+    print(f'sum over the recorded frames: best-of-all {tot["best"]:.1f} us, best of the round-2 kernels that are left (igemm/dma) {tot["old"]:.1f} us '
           f'({len(rows)} geometries, {sum(r["count"] for r in rows)} launches)')
 
 

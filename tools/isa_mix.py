@@ -16,7 +16,7 @@ import sys
 import tempfile
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
-DEFAULT = ['conv_igemm', 'conv_bufload', 'affinity', 'attention', 'elementwise', 'bank']
+DEFAULT = ['conv_igemm', 'conv_dma', 'conv_pc', 'affinity', 'attention', 'qchain', 'elementwise', 'bank']
 
 
 def classify(op):

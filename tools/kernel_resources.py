@@ -7,7 +7,7 @@ import subprocess
 import tempfile
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
-SRCS = ['conv_igemm', 'conv_bufload', 'elementwise', 'attention', 'affinity', 'bank']
+SRCS = ['conv_igemm', 'conv_dma', 'conv_pc', 'elementwise', 'attention', 'qchain', 'affinity', 'bank']
 KEYS = ['VGPRs', 'AGPRs', 'TotalSGPRs', 'ScratchSize [bytes/lane]', 'VGPRs Spill', 'SGPRs Spill', 'LDS Size [bytes/block]',
         'Occupancy [waves/SIMD]']
 

@@ -7,7 +7,7 @@ os.makedirs('profiles', exist_ok=True)
 
 def short(name):
     name = re.sub(r'^void ', '', name)
-    m = re.match(r'(conv_igemm_kernel|conv_dma_kernel|conv_bufload_kernel|conv3x3_patch_kernel)<', name)
+    m = re.match(r'(conv_igemm_kernel|conv_dma_kernel|conv_pc_kernel)<', name)
     if m:
         return m.group(1) + '<*>'
     m = re.match(r'(\w+)<[^>]*>', name)

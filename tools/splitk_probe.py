@@ -23,7 +23,7 @@ def main():
         row = []
         for sk in (1, 2, 3):
             nk = pc.kpad // O.TILES[t][2] // O.TILE_WK.get(t, 1) if t in O.TILES else 0
-            if (t in O.PATCH_TILES and sk > 1) or t not in O.TILES or nk % sk or nk // sk < 1 or sk * B * H * W * Cout > O.SPLITK_PART_FLOATS:
+            if t not in O.TILES or nk % sk or nk // sk < 1 or sk * B * H * W * Cout > O.SPLITK_PART_FLOATS:
                 continue
             ol = O.OpList()
             ol.conv(x, pc, y, B=B, H=H, W=W, C1=Cin, ldx1=Cin, OH=H, OW=W, ldy=Cout, pad=(k - 1) // 2, tile=t, splitk=sk)
