@@ -330,23 +330,26 @@ def main():
                 lib.cutie_graph_destroy(g)
             # HBM traffic of the same kernel family from the committed rocprofv3 PMC passes (tools/profile_round.sh: FETCH_SIZE x2
             # per the gfx950 correction + WRITE_SIZE, bytes per launch); null when no profile summary is present
-            traffic = None
+            traffic = traffic_src = None
             try:
                 import glob
                 summ = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_summary.json')))
                 if summ:
-                    pmc = json.load(open(summ[-1]))['pmc']
-                    fam = [v for k, v in pmc.items() if k.startswith(('conv_igemm_kernel', 'conv_dma_kernel', 'conv3x3_patch_kernel'))
+                    sj = json.load(open(summ[-1]))
+                    pmc = sj['pmc']
+                    traffic_src = {'file': 'profiles/' + os.path.basename(summ[-1]), 'tree': sj.get('tree', 'unknown (summary predates the field)')}
+                    fam = [v for k, v in pmc.items() if k.startswith(('conv_igemm_kernel', 'conv_dma_kernel', 'conv_pc_kernel', 'conv_cout1'))
                            and 'fetch_MB_per_dispatch_x2_gfx950_corrected' in v and 'write_MB_per_dispatch' in v]
                     nd = sum(v['dispatches'] for v in fam)
                     traffic = round(sum((v['fetch_MB_per_dispatch_x2_gfx950_corrected'] + v['write_MB_per_dispatch']) * v['dispatches']
                                         for v in fam) / nd * 1e6) if nd else None
             except Exception:
                 traffic = None
-            roof = {'bound': 'mfma', 'kernel': 'conv_dma_kernel<*> + conv_igemm_kernel<*> + conv_cout1 (all conv launches of a frame)',
+            roof = {'bound': 'mfma', 'kernel': 'conv_pc_kernel<*> + conv_dma_kernel<*> + conv_igemm_kernel<*> + conv_cout1 (all conv launches of a frame)',
                     'achieved': round(conv_f / conv_t / 1e12, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(conv_f / conv_t / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
-                    'traffic_unit': 'HBM bytes per conv launch (rocprofv3 PMC, profiles/)',
+                    'traffic_unit': 'HBM bytes per conv launch (rocprofv3 PMC passes of tools/profile_round.sh, measured on the tree named in traffic_source)',
+                    'traffic_source': traffic_src,
                     'gflop_per_frame': round(conv_f / nrec / 1e9, 1), 'ms_per_frame': round(conv_t / nrec * 1e3, 3),
                     'launches_per_frame': n_conv}
             roof_aff = {'bound': 'mfma', 'kernel': 'aff_score x2 + aff_select + aff_readout',
@@ -389,12 +392,19 @@ def main():
         ocfg = dict(DEFAULT_CFG)
         ocfg['use_long_term'] = use_lt
         oproc = OracleProcessor(onet, ocfg)
+        # bank of the same size class as the timed device region (which starts after `preroll` frames, ~7 memory frames in the bank):
+        # memorise every frame for n_fill frames (mem_every = 1), then back to the configured cadence for the timed sample
+        n_fill = max(0, min(9, round(n_tok_start / max(1, (args.height // 16) * (-(-args.width // 16)))) - 1)) if use_lt else 4
         with torch.inference_mode():
             oproc.step(clip.frame(0), clip.first_mask(), objects=clip.objects)
-            oproc.step(clip.frame(1))                      # warm-up (lazy inits)
+            keep_every, oproc.mem_every = oproc.mem_every, 1
+            for tt in range(1, 1 + n_fill):
+                oproc.step(clip.frame(tt))
+            oproc.mem_every = keep_every
+            oproc.step(clip.frame(1 + n_fill))             # warm-up at the full bank
             c0 = time.perf_counter()
             n_cpu = 0
-            for tt in range(2, 2 + args.cpu_frames):
+            for tt in range(2 + n_fill, 2 + n_fill + args.cpu_frames):
                 oproc.step(clip.frame(tt))
                 n_cpu += 1
                 if time.perf_counter() - c0 > 30.0:            # bounded sample
@@ -412,8 +422,10 @@ def main():
                'port_over_reference_note': None if ratio is None else
                f"the live reference (/root/reference) and this port timed on the same {ratio['cores']} cores of the build container, same workload "
                f"(oracle/time_reference.py): reference {ratio['reference_fps']} frames/s, port {ratio['oracle_fps']} frames/s",
-               'sample': f'{args.cpu_frames} propagated frames (frames 2..{1 + args.cpu_frames}) of the same {args.width}x{args.height} '
-                         f'{K}-object clip, oracle (torch fp32 restatement of the reference) on host cores, frame 0/1 excluded'}
+               'sample': f'{args.cpu_frames} propagated frames of the same {args.width}x{args.height} {K}-object clip, oracle (torch fp32 '
+                         f'restatement of the reference) on host cores, timed with {1 + n_fill} memory frames in the bank '
+                         f'({(1 + n_fill) * (args.height // 16) * (-(-args.width // 16))} tokens: the size class of the device run, '
+                         f'{n_tok_start} tokens at the start of its timed region; filled by memorising every frame, cadence {keep_every} while timed)'}
 
     if rank == 0:
         fps = world * args.steps / tmax
@@ -425,8 +437,8 @@ def main():
                                    f'(SURVEY 8d C2/C3), eval_config defaults (mem_every=5, top_k=30), random-init weights',
                        'preroll_frames': args.preroll, 'memory_tokens_start': n_tok_start, 'memory_tokens_end': n_tok_end,
                        'parallelism': f'clip-shard x{world}', 'accumulate': 'fp32',
-                       'lookahead': 'off' if args.no_lookahead else 'step(next_image=...): the next frame\'s image encoder runs on a '
-                                    'side stream (same kernels, bit-identical results)'},
+                       'lookahead': 'off' if args.no_lookahead else 'step(next_image=...): the next frame\'s image encoder and, when the current '
+                                    'frame does not write the memory bank, its affinity read-out run on a side stream (same kernels, same results)'},
         }
         gs = getattr(rec.ex, 'graph_stats', None)
         if gs is not None:

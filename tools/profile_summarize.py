@@ -71,7 +71,8 @@ for k, c in pm.items():
     if d.get('SQ_LDS_IDX_ACTIVE'):
         out['lds_bank_conflict_frac'] = round(d.get('SQ_LDS_BANK_CONFLICT', 0.0) / d['SQ_LDS_IDX_ACTIVE'], 4)
     kern[k] = out
-json.dump({'command': 'rocprofv3 --kernel-trace --stats / --pmc <set> --kernel-trace -- python bench.py --steps 60 --warmup 10 --preroll 60 '
+json.dump({'tree': os.environ.get('CUTIE_TREE', 'unknown'),        # git revision the snapshot was taken from (the GPU box has no .git: passed in by the caller)
+           'command': 'rocprofv3 --kernel-trace --stats / --pmc <set> --kernel-trace -- python bench.py --steps 60 --warmup 10 --preroll 60 '
                       '--cpu-frames 0 --no-roofline --clips-in-flight 0 (tools/profile_round.sh; separate passes for the SQ set, FETCH_SIZE, WRITE_SIZE)',
            'notes': 'sums over every dispatch of the run (incl. the conv autotune trials at the first frames); GRBM_GUI_ACTIVE is summed over the 8 XCCs',
            'families_by_time': fam, 'streams_steady_state': streams, 'pmc': kern}, open(f'profiles/{rnd}_summary.json', 'w'), indent=1)
