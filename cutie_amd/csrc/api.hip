@@ -19,6 +19,7 @@ static int dispatch(const cutie_op* op, hipStream_t s) {
         case CUTIE_OP_CONV: return launch_conv(op, s);
         case CUTIE_OP_QUERY_INIT: return (op->flags & 1) ? launch_attention(op, s) : launch_elementwise(op, s);
         case CUTIE_OP_QFFN: return launch_qchain(op, s);
+        case CUTIE_OP_STEM: return launch_stem(op, s);
         case CUTIE_OP_ATTN_Q2P: case CUTIE_OP_ATTN_SELF: case CUTIE_OP_ATTN_P2Q:
             return (op->flags & 12) ? launch_qchain(op, s) : launch_attention(op, s);
         case CUTIE_OP_AUX_MASK:

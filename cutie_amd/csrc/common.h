@@ -82,6 +82,7 @@ __device__ __forceinline__ float wave_max(float v) {
 int launch_conv(const cutie_op* op, hipStream_t s);
 int launch_elementwise(const cutie_op* op, hipStream_t s);   // everything in elementwise.hip
 int launch_attention(const cutie_op* op, hipStream_t s);     // attention.hip
+int launch_stem(const cutie_op* op, hipStream_t s);          // stem.hip: IMG_PREP + 7x7 conv + max pool
 int launch_qchain(const cutie_op* op, hipStream_t s);        // qchain.hip: attention ops with flags 4 / 8, QFFN
 int launch_affinity(const cutie_op* op, hipStream_t s);      // affinity.hip
 int launch_bank(const cutie_op* op, hipStream_t s);          // bank.hip

@@ -1,0 +1,184 @@
+// STEM: the first three launches of the ResNet encoders in one -- IMG_PREP (normalise, pad, attach mask / others planes), the 7x7 /
+// stride-2 / pad-3 convolution with folded BatchNorm (pixel_encoder.conv1, mask_encoder.conv1: resnet.py conv1 + bn1; big_modules.py
+// 30-33, 95-100) and the 3x3 / stride-2 / pad-1 max pooling (+ ReLU: before the pool in the pixel encoder, after it in the mask
+// encoder -- the same thing, ReLU and max commute).  Round 2 ran them as three launches through two HBM round trips of a stride-2 map
+// (480p: 30.4 + 10.2 + 6.6 us per frame, the 7x7 conv at 2.6 % of the MFMA peak: Cin = 3 padded to 8, register-staged im2col).
+//
+// One block = 4 x 16 pooled pixels of one object: they need 9 x 33 conv pixels, which need a 23 x 71 input patch.
+//   1. the patch is built in LDS as [23][72] pixels x 8 bf16 channels (r, g, b, mask, others, 0, 0, 0), straight from the fp32 frame;
+//      pixels outside the padded frame are the conv's zero padding, the 72nd column is zero (the 8th "tap" of a row, see below);
+//   2. implicit GEMM on v_mfma_f32_16x16x32_bf16: a K step is half a kernel row = 4 taps x 8 channels, so a B fragment is ONE
+//      16-byte LDS read of the pixel the tap lands on (lane group g <-> tap 4 (s & 1) + g; the 8th tap has zero weights); A = the
+//      weights, 2 x 14 fragments per wave held in registers for the whole block; waves 2 (pixel halves) x 2 (channel halves);
+//   3. bias (+ nothing else: ReLU moves behind the pool), bf16, into an LDS tile [297][64] that aliases the patch; conv pixels outside
+//      the conv's output range are written as -inf (the pool's padding);
+//   4. 3 x 3 max over the tile, ReLU, 32-byte stores.
+// Results: identical rounding points as the three-launch form (bf16 after the conv, max of bf16 values); only the fp32 summation
+// order inside the conv differs.
+#include "common.h"
+#include <math.h>
+
+#define ST_PH 4
+#define ST_PW 16
+#define ST_CH (2 * ST_PH + 1)                            // conv rows of a block (9)
+#define ST_CW (2 * ST_PW + 1)                            // conv columns (33)
+#define ST_NCONV (ST_CH * ST_CW)                         // 297
+#define ST_MF ((ST_NCONV + 15) / 16)                     // 19 M fragments
+#define ST_IH (2 * ST_CH + 5)                            // input rows (23)
+#define ST_IW 72                                         // input columns: 71 + one zero column
+#define ST_CLD 72                                        // bf16 pitch of the conv tile (64 + 8: rows 144 B apart)
+
+typedef __attribute__((ext_vector_type(4))) unsigned int st_u4;
+
+struct StemParams {
+    const float* img; const float* masks; const bf16_t* W; const float* bias; bf16_t* y;
+    int h0, w0, H, W_, pl, pt, K, Kpad, relu;
+    float m0, m1, m2, s0, s1, s2;
+};
+
+__global__ __launch_bounds__(256) void stem_kernel(StemParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[ST_MF * 16 * ST_CLD * 2];   // 43776 B: conv tile; the 26496-B patch aliases its start
+    static_assert(ST_IH * ST_IW * 16 <= ST_MF * 16 * ST_CLD * 2, "patch fits");
+    st_u4* patch = reinterpret_cast<st_u4*>(lds);
+    bf16_t* ct = reinterpret_cast<bf16_t*>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int k = blockIdx.z;
+    const int OH = p.H >> 1, OW = p.W_ >> 1, PH = p.H >> 2, PW = p.W_ >> 2;
+    const int py0 = blockIdx.y * ST_PH, px0 = blockIdx.x * ST_PW;
+    const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;     // first conv pixel of the block
+    const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;     // first input pixel
+
+    // ---- weights of this wave's 32 output channels: 2 x 14 fragments (lane: channel row c, taps 4 (s & 1) + g of kernel row s >> 1) ----
+    st_u4 wa[2][14];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const bf16_t* wr = p.W + (long)((2 * wn + n) * 16 + c) * p.Kpad;
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+            const int kw = (s & 1) * 4 + g;
+            const st_u4 v = *reinterpret_cast<const st_u4*>(wr + ((s >> 1) * 7 + min(kw, 6)) * 8);
+            const st_u4 z = {0u, 0u, 0u, 0u};
+            wa[n][s] = kw < 7 ? v : z;
+        }
+    }
+    // ---- the input patch ----
+    const long plane = (long)p.h0 * p.w0, HWp = (long)p.H * p.W_;
+    for (int e = tid; e < ST_IH * ST_IW; e += 256) {
+        const int ry = e / ST_IW, rx = e - ry * ST_IW;
+        const int iy = iy0 + ry, ix = ix0 + rx;
+        const bool inpad = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W_ && rx < ST_IW - 1;
+        const int sy = iy - p.pt, sx = ix - p.pl;
+        const bool inimg = inpad && (unsigned)sy < (unsigned)p.h0 && (unsigned)sx < (unsigned)p.w0;
+        const long o = (long)min(max(sy, 0), p.h0 - 1) * p.w0 + min(max(sx, 0), p.w0 - 1);     // clamped: the loads are unconditional
+        float r = p.img[o], gg = p.img[plane + o], b = p.img[2 * plane + o];
+        r = inimg ? r : 0.f; gg = inimg ? gg : 0.f; b = inimg ? b : 0.f;
+        r = (r - p.m0) / p.s0; gg = (gg - p.m1) / p.s1; b = (b - p.m2) / p.s2;            // (the arithmetic of IMG_PREP, to the bit)
+        float mk = 0.f, others = 0.f;
+        if (p.masks) {
+            const long pix = (long)min(max(iy, 0), p.H - 1) * p.W_ + min(max(ix, 0), p.W_ - 1);
+            float sum = 0.f;
+            for (int j = 0; j < p.K; ++j) sum += p.masks[(long)j * HWp + pix];
+            mk = p.masks[(long)k * HWp + pix];
+            others = fminf(fmaxf(sum - mk, 0.f), 1.f);
+        }
+        st_u4 v = {pack_bf2(r, gg), pack_bf2(b, mk), pack_bf2(others, 0.f), 0u};
+        const st_u4 z = {0u, 0u, 0u, 0u};
+        patch[e] = inpad ? v : z;
+    }
+    __syncthreads();
+    // ---- implicit GEMM: 14 K steps; this wave: M fragments 10 wm .. (10 or 9 of them), N fragments 2 wn, 2 wn + 1 ----
+    constexpr int NB = 10;
+    const int nb = wm == 0 ? 10 : ST_MF - 10;
+    int boff[NB];                                        // patch index of (conv pixel, tap g) at kernel row 0, first half
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int idx = min((wm * 10 + b) * 16 + c, ST_NCONV - 1);
+        const int cyl = idx / ST_CW, cxl = idx - cyl * ST_CW;
+        boff[b] = 2 * cyl * ST_IW + 2 * cxl + g;
+    }
+    f32x4 acc[NB][2];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { acc[b][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[b][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        const int so = (s >> 1) * ST_IW + (s & 1) * 4;
+        st_u4 bf[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) bf[b] = patch[boff[b] + so];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b < nb) {
+                acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[0][s]), __builtin_bit_cast(bf16x8, bf[b]), acc[b][0], 0, 0, 0);
+                acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[1][s]), __builtin_bit_cast(bf16x8, bf[b]), acc[b][1], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                     // every wave has read its last patch fragment: the conv tile may overwrite it
+    // ---- bias, bf16, conv tile (lane: conv pixel c of the fragment, channels 4 g .. 4 g + 3 of the N fragment) ----
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int idx = (wm * 10 + b) * 16 + c;
+        if (b < nb && idx < ST_NCONV) {
+            const int cyl = idx / ST_CW, cxl = idx - cyl * ST_CW;
+            const bool valid = (unsigned)(cy0 + cyl) < (unsigned)OH && (unsigned)(cx0 + cxl) < (unsigned)OW;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int ch = (2 * wn + n) * 16 + 4 * g;
+                const float4 bv = *reinterpret_cast<const float4*>(p.bias + ch);
+                uint2 o = make_uint2(pack_bf2(acc[b][n][0] + bv.x, acc[b][n][1] + bv.y), pack_bf2(acc[b][n][2] + bv.z, acc[b][n][3] + bv.w));
+                if (!valid) o = make_uint2(0xff80ff80u, 0xff80ff80u);       // -inf: the pool's padding
+                *reinterpret_cast<uint2*>(ct + idx * ST_CLD + ch) = o;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 3 x 3 / stride 2 max pool (+ ReLU): thread = (pooled pixel, 16 channels) ----
+    {
+        const int pp = tid >> 2, q = tid & 3, ppy = pp >> 4, ppx = pp & 15;
+        const int py = py0 + ppy, px = px0 + ppx;
+        float m[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m[i] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const bf16_t* src = ct + ((2 * ppy + dy) * ST_CW + 2 * ppx + dx) * ST_CLD + q * 16;
+                const st_u4 a = *reinterpret_cast<const st_u4*>(src), b2 = *reinterpret_cast<const st_u4*>(src + 8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    m[2 * i] = fmaxf(m[2 * i], __uint_as_float(a[i] << 16));
+                    m[2 * i + 1] = fmaxf(m[2 * i + 1], __uint_as_float(a[i] & 0xffff0000u));
+                    m[8 + 2 * i] = fmaxf(m[8 + 2 * i], __uint_as_float(b2[i] << 16));
+                    m[8 + 2 * i + 1] = fmaxf(m[8 + 2 * i + 1], __uint_as_float(b2[i] & 0xffff0000u));
+                }
+            }
+        if (p.relu) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m[i] = fmaxf(m[i], 0.f);
+        }
+        if (py < PH && px < PW) {
+            bf16_t* dst = p.y + (((long)k * PH + py) * PW + px) * 64 + q * 16;
+            *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf2(m[0], m[1]), pack_bf2(m[2], m[3]), pack_bf2(m[4], m[5]), pack_bf2(m[6], m[7]));
+            *reinterpret_cast<uint4*>(dst + 8) = make_uint4(pack_bf2(m[8], m[9]), pack_bf2(m[10], m[11]), pack_bf2(m[12], m[13]), pack_bf2(m[14], m[15]));
+        }
+    }
+}
+
+int launch_stem(const cutie_op* op, hipStream_t s) {
+    const int32_t* i = op->i;
+    const uint64_t* q = op->p;
+    if (!q[0] || !q[2] || !q[3] || !q[4]) { cutie_set_error("stem: image, packed weights, bias and output required"); return -2; }
+    if ((i[2] & 15) || (i[3] & 15) || i[6] < 1 || i[7] < 392 || (i[7] & 7)) {
+        cutie_set_error("stem: H, W multiples of 16, K >= 1, Kpad >= 392 (H=%d W=%d K=%d Kpad=%d)", i[2], i[3], i[6], i[7]);
+        return -2;
+    }
+    StemParams p;
+    p.img = (const float*)q[0]; p.masks = (const float*)q[1]; p.W = (const bf16_t*)q[2]; p.bias = (const float*)q[3]; p.y = (bf16_t*)q[4];
+    p.h0 = i[0]; p.w0 = i[1]; p.H = i[2]; p.W_ = i[3]; p.pl = i[4]; p.pt = i[5]; p.K = q[1] ? i[6] : 1; p.Kpad = i[7]; p.relu = op->flags & 1;
+    p.m0 = op->f[0]; p.m1 = op->f[1]; p.m2 = op->f[2]; p.s0 = op->f[3]; p.s1 = op->f[4]; p.s2 = op->f[5];
+    const int PH = i[2] >> 2, PW = i[3] >> 2;
+    hipLaunchKernelGGL(stem_kernel, dim3((PW + ST_PW - 1) / ST_PW, (PH + ST_PH - 1) / ST_PH, p.K), dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+}

@@ -394,19 +394,33 @@ class Plan:
 
 
 # ---------------------------------------------------------------------------------------------------
+STEM = os.environ.get('CUTIE_AMD_STEM', '1') not in ('', '0')
+
+
+def stem_ok(eng, name):
+    w = eng.w.get(name)
+    return STEM and not UNFUSED and w is not None and w.cout == 64 and w.kh == 7 and w.kw == 7 and w.cin_padded == 8 and w.bias is not None
+
+
 def build_encode(eng, h0, w0, H, W, pad_left, pad_top):
     """CUTIE.encode_image + transform_key (cutie.py:61-64,92-98; big_modules.py:45-54,81-87) + query-side
     similarity operands.  dyn in: image f32 [3,h0,w0].  dyn out: f16,f8,f4,pix_feat (bf16 NHWC), key,shr,sel
     (f32 [hw,*]), Bhi,Blo (bf16 [HWp,128]), cq (f32 [HWp])."""
     P = Plan(eng)
     m = eng.m
-    img8 = P.buf('img8', (1, H, W, 8))
-    P.ol.img_prep(Dyn('image'), None, img8, h0=h0, w0=w0, H=H, W=W, pad_left=pad_left, pad_top=pad_top, K=1,
-                  mean=m['pixel_mean'], std=m['pixel_std'])
-    x = P.conv('pixel_encoder.conv1', Act(img8, 1, H, W, 8), stride=2, pad=3, act=O.ACT_RELU)
-    pool = P.buf('pool', (1, x.H // 2, x.W // 2, 64))
-    P.ol.maxpool(x.t, pool, B=1, H=x.H, W=x.W, C=64)
-    x = Act(pool, 1, x.H // 2, x.W // 2, 64)
+    if stem_ok(eng, 'pixel_encoder.conv1'):                 # IMG_PREP + 7x7 conv + max pool in one launch (csrc/stem.hip)
+        pool = P.buf('pool', (1, H // 4, W // 4, 64))
+        P.ol.stem(Dyn('image'), None, eng.w['pixel_encoder.conv1'], pool, h0=h0, w0=w0, H=H, W=W, pad_left=pad_left, pad_top=pad_top, K=1,
+                  mean=m['pixel_mean'], std=m['pixel_std'], relu=True)
+        x = Act(pool, 1, H // 4, W // 4, 64)
+    else:
+        img8 = P.buf('img8', (1, H, W, 8))
+        P.ol.img_prep(Dyn('image'), None, img8, h0=h0, w0=w0, H=H, W=W, pad_left=pad_left, pad_top=pad_top, K=1,
+                      mean=m['pixel_mean'], std=m['pixel_std'])
+        x = P.conv('pixel_encoder.conv1', Act(img8, 1, H, W, 8), stride=2, pad=3, act=O.ACT_RELU)
+        pool = P.buf('pool', (1, x.H // 2, x.W // 2, 64))
+        P.ol.maxpool(x.t, pool, B=1, H=x.H, W=x.W, C=64)
+        x = Act(pool, 1, x.H // 2, x.W // 2, 64)
     h4, w4, h8, w8, h, w = H // 4, W // 4, H // 8, W // 8, H // 16, W // 16
     ms = m['pixel_encoder']['ms_dims']
     taps = {'res2': Act(Dyn('f4'), 1, h4, w4, ms[2]), 'layer2': Act(Dyn('f8'), 1, h8, w8, ms[1]),
@@ -666,13 +680,18 @@ def build_encode_mask(eng, K, h0, w0, H, W, pad_left, pad_top, deep_update=True)
     m, ol = eng.m, P.ol
     h, w = H // 16, W // 16
     CV, CS, CE, Q = m['value_dim'], m['sensory_dim'], m['embed_dim'], m['object_summarizer']['num_summaries']
-    x8 = P.buf('x8', (K, H, W, 8))
-    ol.img_prep(Dyn('image'), Dyn('masks'), x8, h0=h0, w0=w0, H=H, W=W, pad_left=pad_left, pad_top=pad_top, K=K,
-                mean=m['pixel_mean'], std=m['pixel_std'])
-    x = P.conv('mask_encoder.conv1', Act(x8, K, H, W, 8), stride=2, pad=3)          # conv+bn, then maxpool, then relu
-    pool = P.buf('pool', (K, x.H // 2, x.W // 2, 64))
-    ol.maxpool(x.t, pool, B=K, H=x.H, W=x.W, C=64, relu=True)
-    g16, _ = P.resnet('mask_encoder', Act(pool, K, x.H // 2, x.W // 2, 64))
+    if stem_ok(eng, 'mask_encoder.conv1'):
+        pool = P.buf('pool', (K, H // 4, W // 4, 64))
+        ol.stem(Dyn('image'), Dyn('masks'), eng.w['mask_encoder.conv1'], pool, h0=h0, w0=w0, H=H, W=W, pad_left=pad_left, pad_top=pad_top, K=K,
+                mean=m['pixel_mean'], std=m['pixel_std'], relu=True)
+    else:
+        x8 = P.buf('x8', (K, H, W, 8))
+        ol.img_prep(Dyn('image'), Dyn('masks'), x8, h0=h0, w0=w0, H=H, W=W, pad_left=pad_left, pad_top=pad_top, K=K,
+                    mean=m['pixel_mean'], std=m['pixel_std'])
+        x = P.conv('mask_encoder.conv1', Act(x8, K, H, W, 8), stride=2, pad=3)          # conv+bn, then maxpool, then relu
+        pool = P.buf('pool', (K, x.H // 2, x.W // 2, 64))
+        ol.maxpool(x.t, pool, B=K, H=x.H, W=x.W, C=64, relu=True)
+    g16, _ = P.resnet('mask_encoder', Act(pool, K, H // 4, W // 4, 64))
     value = P.fusion_block('mask_encoder.fuser', Act(Dyn('pix_feat'), 1, h, w, m['pixel_dim']), g16, 'fuse',
                            out=Act(Dyn('value'), K, h, w, CV))
     if deep_update:

@@ -19,13 +19,13 @@ assert OP_DTYPE.itemsize == _lib.OP_STRUCT_SIZE
 (CONV, MAXPOOL, IMG_PREP, UPSAMPLE2X_ADD, AREA_DOWN, MASK_DOWN, GAP, ECA_APPLY, GRU, SEG_AGG, UP4_SOFTMAX,
  MASK_MERGE, AGG_SOFTMAX, LINEAR, LAYERNORM, QUERY_INIT, AUX_MASK, ATTN_Q2P, ATTN_SELF, ATTN_P2Q, SUMMARIZE,
  ADD_PE, KEY_PREP, AFF_SCORE, AFF_SELECT, AFF_READOUT, MEMSET32, COPY2D, AXPY, USAGE_TICK, RANK_SELECT,
- GATHER_ROWS, CONSOL_AFF, CONSOL_READ, CAST, PROB_TO_ID, RESIZE, FLIP_W, AREA_DOWN3, QFFN) = range(1, 41)
+ GATHER_ROWS, CONSOL_AFF, CONSOL_READ, CAST, PROB_TO_ID, RESIZE, FLIP_W, AREA_DOWN3, QFFN, STEM) = range(1, 42)
 
 KIND_NAMES = {}
 for _n in ('CONV MAXPOOL IMG_PREP UPSAMPLE2X_ADD AREA_DOWN MASK_DOWN GAP ECA_APPLY GRU SEG_AGG UP4_SOFTMAX MASK_MERGE '
            'AGG_SOFTMAX LINEAR LAYERNORM QUERY_INIT AUX_MASK ATTN_Q2P ATTN_SELF ATTN_P2Q SUMMARIZE ADD_PE KEY_PREP '
            'AFF_SCORE AFF_SELECT AFF_READOUT MEMSET32 COPY2D AXPY USAGE_TICK RANK_SELECT GATHER_ROWS CONSOL_AFF '
-           'CONSOL_READ CAST PROB_TO_ID RESIZE FLIP_W AREA_DOWN3 QFFN').split():
+           'CONSOL_READ CAST PROB_TO_ID RESIZE FLIP_W AREA_DOWN3 QFFN STEM').split():
     KIND_NAMES[globals()[_n]] = _n
 
 F_RELU_IN, F_OUT_F32, F_RES_BCAST = 1, 2, 4
@@ -299,6 +299,11 @@ class OpList:
     def maxpool(self, x, y, *, B, H, W, C, relu=False):
         OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         return self.add(MAXPOOL, 1 if relu else 0, [B, H, W, C, OH, OW], [], [x, y])
+
+    def stem(self, image, masks, w, y, *, h0, w0, H, W, pad_left, pad_top, K, mean, std, relu=True):
+        """IMG_PREP + 7x7 / stride-2 conv (w: PackedConv, Cin padded to 8, Cout 64) + 3x3 / stride-2 max pool (+ ReLU) in one launch."""
+        assert w.cout == 64 and w.kh == 7 and w.cin_padded == 8 and H % 16 == 0 and W % 16 == 0
+        return self.add(STEM, 1 if relu else 0, [h0, w0, H, W, pad_left, pad_top, K, w.kpad], list(mean) + list(std), [image, masks, w.weight, w.bias, y])
 
     def img_prep(self, image, masks, y, *, h0, w0, H, W, pad_left, pad_top, K, mean, std):
         return self.add(IMG_PREP, 0, [h0, w0, H, W, pad_left, pad_top, K], list(mean) + list(std), [image, masks, y])

@@ -261,6 +261,13 @@ enum {
      * linear2's bias and the residual x_out are added by the consumer (flags&4 of the attention ops).
      * i: 0 rows (K*16) 1 FF 2 hidden columns per block (64 | 128; 0: 64) */
     CUTIE_OP_QFFN = 40,
+    /* STEM: IMG_PREP + the 7x7 / stride-2 / pad-3 conv with folded BN (Cin 3 + mask + others padded to 8, Cout 64) + 3x3 / stride-2 /
+     * pad-1 max pool in one launch (resnet.py conv1, bn1, relu, maxpool; big_modules.py:30-33, 95-100): same rounding points as the
+     * three ops (bf16 after the conv, max of bf16 values).
+     * p0=image f32 [3,h0,w0] p1=masks f32 [K,H,W] (0: none, K = 1) p2=packed weights bf16 [64,Kpad] (k = (kh*7+kw)*8 + c)
+     * p3=bias f32 [64] p4=y bf16 [K,H/4,W/4,64]   i: 0 h0 1 w0 2 H 3 W (multiples of 16) 4 pad_left 5 pad_top 6 K 7 Kpad
+     * f: 0-2 mean 3-5 std   flags&1: ReLU (before or after the pool: the same) */
+    CUTIE_OP_STEM = 41,
     CUTIE_OP__COUNT
 };
 

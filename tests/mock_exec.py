@@ -628,6 +628,27 @@ class MockExecutor:
         V = view(p[1], dt, (n, C), (ldv, 1)).float()
         view(p[2], dt, (P, C), (ldo, 1)).copy_(aff @ V)
 
+    def _op_41(self, flags, i, f, p):                                   # STEM = IMG_PREP + conv 7x7 s2 p3 (+ bias) + maxpool 3x3 s2 p1 (+ relu)
+        h0, w0, H, W, pl, pt, K, Kpad = i[:8]
+        K = K if p[1] else 1
+        img = view(p[0], F32, (3, h0, w0))
+        full = torch.zeros(3, H, W)
+        full[:, pt:pt + h0, pl:pl + w0] = img
+        full = (full - torch.tensor(f[0:3]).view(3, 1, 1)) / torch.tensor(f[3:6]).view(3, 1, 1)
+        x = torch.zeros(K, 8, H, W)
+        x[:, 0:3] = full
+        if p[1]:
+            m = view(p[1], F32, (K, H, W))
+            x[:, 3] = m
+            x[:, 4] = (m.sum(0, keepdim=True) - m).clamp(0, 1)
+        x = x.to(torch.bfloat16).float()
+        wgt = unpack_conv_weight(view(p[2], BF16, (64, Kpad)), 64, 7, 7, 8)
+        y = F.conv2d(x, wgt, view(p[3], F32, (64,)), stride=2, padding=3).to(torch.bfloat16).float()
+        y = F.max_pool2d(y, 3, 2, 1)
+        if flags & 1:
+            y = F.relu(y)
+        view(p[4], BF16, (K, H // 4, W // 4, 64)).copy_(y.permute(0, 2, 3, 1))
+
     def _op_40(self, flags, i, f, p):                                   # QFFN
         rows, FF = i[:2]
         x = self._partial_sum(view(p[0], F32, (rows, 256)).clone(), flags, i, p, rows, always=True)

@@ -273,6 +273,44 @@ def test_maxpool():
         check(*run_both(build), name=f'maxpool relu={relu}', rtol=1e-6)
 
 
+@pytest.mark.parametrize('geo', [(480, 854, 480, 864, 5, 0, 3), (480, 854, 480, 864, 5, 0, 0), (100, 120, 112, 128, 4, 6, 2), (16, 16, 16, 16, 0, 0, 1),
+                                 (30, 43, 32, 48, 2, 1, 5), (1080, 1920, 1088, 1920, 0, 4, 0)])
+def test_stem_kernel(geo):
+    """STEM (IMG_PREP + 7x7 / stride-2 conv + 3x3 / stride-2 max pool in one launch, csrc/stem.hip) against the interpreter and against
+    the three launches it replaces: frame borders, pad geometry, ragged pooled tiles, mask / others planes of K objects, no masks."""
+    h0, w0, H, W, pl, pt, K = geo
+
+    def build(dev, g):
+        img = torch.rand((3, h0, w0), generator=g).to(dev)
+        masks = None
+        if K:
+            masks = torch.rand((K, H, W), generator=g)
+            masks = (masks * (torch.rand((K, H, W), generator=g) > 0.5)).to(dev)
+        Kk = max(K, 1)
+        wt = torch.randn((64, 8, 7, 7), generator=g) / math.sqrt(147)
+        wt[:, 5:] = 0
+        if not K:
+            wt[:, 3:] = 0
+        pc = pack_conv(wt, torch.randn(64, generator=g) * 0.1, dev)
+        mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+        y = torch.zeros((Kk, H // 4, W // 4, 64), dtype=BF16, device=dev)
+        y3 = torch.zeros((Kk, H // 4, W // 4, 64), dtype=BF16, device=dev)
+        x8 = torch.zeros((Kk, H, W, 8), dtype=BF16, device=dev)
+        cv = torch.zeros((Kk, H // 2, W // 2, 64), dtype=BF16, device=dev)
+        ol = O.OpList()
+        ol.keep += [pc.weight]
+        for relu, out in ((True, y),):
+            ol.stem(img, masks, pc, out, h0=h0, w0=w0, H=H, W=W, pad_left=pl, pad_top=pt, K=Kk, mean=mean, std=std, relu=relu)
+        ol.img_prep(img, masks, x8, h0=h0, w0=w0, H=H, W=W, pad_left=pl, pad_top=pt, K=Kk, mean=mean, std=std)
+        ol.conv(x8, pc, cv, B=Kk, H=H, W=W, C1=8, ldx1=8, OH=H // 2, OW=W // 2, ldy=64, stride=2, pad=3)
+        ol.maxpool(cv, y3, B=Kk, H=H // 2, W=W // 2, C=64, relu=True)
+        return ol, {'y': y, 'y3': y3}
+    hip, ref = run_both(build, seed=sum(geo))
+    check(hip, ref, name=f'stem {geo}')
+    d = float((hip['y'].float() - hip['y3'].float()).abs().max())
+    assert d <= 1.6e-2 * max(1.0, float(hip['y3'].float().abs().max())), d
+
+
 def test_img_prep():
     mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
     for K in (0, 3):
