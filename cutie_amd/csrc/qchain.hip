@@ -127,7 +127,7 @@ __device__ __forceinline__ void split4(const float* v, proj_u4& hi, proj_u4& lo)
 // ATTN_Q2P, chain form.  grid (heads, K), block 1024 = 16 waves; wave w owns the 32-pixel chunks w, w + 16, ...
 // S^T[pixel][query] = K[pixel][dim] . Q^T[dim][query];  O^T[dim][query] = V^T[dim][pixel] . P^T[pixel][query]  (as attention.hip's kernel)
 // =====================================================================================================================================
-#define Q2C_PF 3
+#define Q2C_PF 4
 #define Q2C_VLD 40                                       // bf16 pitch of the V tile (80 bytes: the four pixel groups of a read hit disjoint banks)
 struct Q2CChunk { q2p_u32x4 k[2], v[2]; };
 __device__ __forceinline__ void q2c_load(Q2CChunk& L, const bf16_t* __restrict__ kvb, int p0, int HW, int ldkv, int voff, int lane) {
@@ -146,23 +146,19 @@ __device__ __forceinline__ void q2c_load(Q2CChunk& L, const bf16_t* __restrict__
 // 1 - 1e-7)).  logit is strictly increasing, so the clamped probabilities are compared directly -- no log, and the sigmoid through
 // v_exp / v_rcp: the exact form cost ~200 instructions per pixel and object, x 1620 pixels in EVERY head's block (3 us of a 20 us launch,
 // profiles/r03_qchain.md).  Decisions differ from the exact form only where two probabilities agree to fp32 rounding.
-__device__ __forceinline__ bool aux_fg_fast(float mine_l, const float* v, int K) {
-    float bg = 1.f, mx = 0.f;
+template <int KT>
+__device__ __forceinline__ bool aux_fg_vals(const float* v, int K, int k) {
+    float bg = 1.f, mx = 0.f, mine_l = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {                          // slots >= K hold a copy of plane K - 1: selected away, no branches
+    for (int j = 0; j < KT; ++j) {                         // slots >= K hold a copy of plane K - 1: selected away, no branches
         const float pr = __frcp_rn(1.f + __expf(-v[j]));
         bg *= j < K ? (1.f - pr) : 1.f;
         mx = fmaxf(mx, j < K ? pr : 0.f);
+        mine_l = j == k ? v[j] : mine_l;
     }
     const float lo = 1e-7f, hi = 1.f - 1e-7f;
     const float mine = fminf(fmaxf(__frcp_rn(1.f + __expf(-mine_l)), lo), hi);
     return mine >= fminf(fmaxf(mx, lo), hi) && mine >= fminf(fmaxf(bg, lo), hi);
-}
-__device__ __forceinline__ bool aux_fg_vals(const float* v, int K, int k) {
-    float mine = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) mine = j == k ? v[j] : mine;
-    return aux_fg_fast(mine, v, K);
 }
 __device__ __forceinline__ bool aux_fg_late(const float* __restrict__ lg, int K, int HW, int k, int p) {      // K > 8 or pixels >= 2048
     float bg = 1.f, mx = 0.f, mine = 0.f;
@@ -179,15 +175,22 @@ __device__ __forceinline__ bool aux_fg_late(const float* __restrict__ lg, int K,
 
 // qpre != null (flags&16): q of this launch was projected by the ATTN_P2Q launch of the previous block (its extra blocks, see below) --
 // the 80 KB of rows + weights and three block-wide barriers in front of the pixel loop are gone.
-template <bool QPRE, bool ACC, bool EARLY>                // EARLY: K <= 8, the mask logits of this thread's (up to) two pixels are fetched at entry
-__global__ __launch_bounds__(1024) void q2p_chain_kernel(QIn in, QOut out, const bf16_t* __restrict__ kv, const float* __restrict__ lg,
-                                                         int HW, int HWp, int ldkv, int voff, const float* __restrict__ qpre) {
-    constexpr int Q = 16;
-    __shared__ float sO[16][16][33];                       // [wave][query][dim]; the projection staging aliases it
-    __shared__ float sM[16][16], sL[16][16];
+// NW waves per block (8: half the per-wave prologue instructions of the 16-wave form contend for the SIMDs; the pixel loop is bound by
+// the K / V bytes of the block either way).  KT: the mask logits of this thread's pixels are fetched at entry for K <= KT objects (0: late).
+template <bool QPRE, bool ACC, int KT, int NW>
+__global__ __launch_bounds__(NW * 64) void q2p_chain_kernel(QIn in, QOut out, const bf16_t* __restrict__ kv, const float* __restrict__ lg,
+                                                           int HW, int HWp, int ldkv, int voff, int hstride, const float* __restrict__ qpre) {
+    constexpr int Q = 16, NT = NW * 64;
+    constexpr bool EARLY = KT > 0;
+    constexpr int PPT = 2048 / NT;                         // pixels per thread with logits fetched at entry
+    constexpr int UPW = 16 / NW;                           // (column tile, k step) units of the q projection per wave; rows per wave; Wo tiles per wave
+    constexpr int SO_BYTES = NW * 16 * 33 * 4, ST_BYTES = 16 * PROJ_XLD * 4 + NW * 64 * 16;
+    __shared__ __attribute__((aligned(16))) unsigned char sbuf[SO_BYTES > ST_BYTES ? SO_BYTES : ST_BYTES];
+    float (*sO)[16][33] = reinterpret_cast<float (*)[16][33]>(sbuf);       // [wave][query][dim]; the projection staging aliases it
+    __shared__ float sM[NW][16], sL[NW][16];
     __shared__ float sQ[16][33];                           // this head's 32 query columns, scaled; later the head's output
     __shared__ int sCnt;
-    extern __shared__ uint8_t dynlds[];                    // [HWp foreground flags][16 waves x 32 pixels x 80 B of V]
+    extern __shared__ uint8_t dynlds[];                    // [HWp foreground flags][NW waves x 32 pixels x 80 B of V]
     const int hh = blockIdx.x, k = blockIdx.y, K = gridDim.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c16 = lane & 15, g = lane >> 4;
@@ -196,53 +199,52 @@ __global__ __launch_bounds__(1024) void q2p_chain_kernel(QIn in, QOut out, const
     const float scale = rsqrtf(32.f);
     ATL(0)
     // ---- every global load of the launch, in the order of use ----
-    QRows<1> R;
+    QRows<UPW> R;
     float4 qp0, qp1;
     if (QPRE) {
         const float* qr = qpre + ((long)k * 16 + c16) * 256 + hh * 32 + 8 * g;
         qp0 = *reinterpret_cast<const float4*>(qr); qp1 = *reinterpret_cast<const float4*>(qr + 4);
     } else {
-        qrows_issue<16, 1, ACC, true, true>(in, k, R);
+        qrows_issue<NW, UPW, ACC, true, true>(in, k, R);
     }
-    float lgv[2][8];
-    constexpr bool early = EARLY;
+    float lgv[EARLY ? PPT : 1][EARLY ? KT : 1];
     if (EARLY) {                                           // unconditional loads (plane index clamped): no branch around a load
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int p = min((int)threadIdx.x + 1024 * i, HW - 1);
+        for (int i = 0; i < PPT; ++i) {
+            const int p = min((int)threadIdx.x + NT * i, HW - 1);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) lgv[i][j] = lg[(long)min(j, K - 1) * HW + p];
+            for (int j = 0; j < KT; ++j) lgv[i][j] = lg[(long)min(j, K - 1) * HW + p];
         }
     }
-    const int tile = wave & 1, ks = wave >> 1;
-    proj_u4 wq[1], wo[1];
-    if (!QPRE) proj16_load<1>(in.W, hh * 32 + tile * 16, ks, wq);
-    proj16_load<1>(out.W, wave * 16, hh, wo);              // Wo rows 16 wave.., the columns of this head (one 32-wide k step)
-    const bf16_t* kvb = kv + (long)k * HW * ldkv + hh * 32;
+    const int tile = wave & 1, ks0 = (wave >> 1) * UPW;
+    proj_u4 wq[UPW], wo[UPW];
+    if (!QPRE) proj16_load<UPW>(in.W, hh * 32 + tile * 16, ks0, wq);
+#pragma unroll
+    for (int t = 0; t < UPW; ++t) proj16_load<1>(out.W, (wave * UPW + t) * 16, hh, &wo[t]);   // Wo rows of this wave's column tiles, the columns of this head
+    const bf16_t* kvb = kv + (long)k * HW * ldkv + hh * hstride;
     const int nchunk = (HW + 31) >> 5;
     if (threadIdx.x == 0) sCnt = 0;
-    // The K / V prefetch (12 KB per wave) goes out only after EVERY wave has issued its small loads: the CU's memory pipeline serves
-    // requests in issue order across waves.  The barrier only waits for the issue, not for the data.
+    // The K / V prefetch goes out only after EVERY wave has issued its small loads: the CU's memory pipeline serves requests in issue
+    // order across waves.  The barrier only waits for the issue, not for the data.
     QSYNC();
     Q2CChunk pf[Q2C_PF];                                   // unconditional (chunk index clamped): a load inside a branch costs the counted waits
 #pragma unroll
-    for (int j = 0; j < Q2C_PF; ++j) q2c_load(pf[j], kvb, min(wave + 16 * j, nchunk - 1) * 32, HW, ldkv, voff, lane);
-    // ---- q = (LN(x_eff) + emb) . Wq[head]^T + b: 16 waves = 2 column tiles x 8 k-steps, summed through LDS (staging aliases sO) ----
+    for (int j = 0; j < Q2C_PF; ++j) q2c_load(pf[j], kvb, min(wave + NW * j, nchunk - 1) * 32, HW, ldkv, voff, lane);
+    // ---- q = (LN(x_eff) + emb) . Wq[head]^T + b: 2 column tiles x 8 k-steps over the waves, summed through LDS (staging aliases sO) ----
     q2p_frag qh, ql;
     if (!QPRE) {
-        float* xs = &sO[0][0][0];
+        float* xs = reinterpret_cast<float*>(sbuf);
         f32x4* red = reinterpret_cast<f32x4*>(xs + 16 * PROJ_XLD);
-        static_assert(sizeof(float) * 16 * PROJ_XLD + sizeof(f32x4) * 16 * 64 <= sizeof(float) * 16 * 16 * 33, "projection staging fits in sO");
-        qrows_finish<16, 1, ACC, true, true>(in, k, R, xs, nullptr, hh == 0);
+        qrows_finish<NW, UPW, ACC, true, true>(in, k, R, xs, nullptr, hh == 0);
         ATL(1)
         QSYNC();
-        red[wave * 64 + lane] = proj16_mma<1>(xs, ks, wq);
+        red[wave * 64 + lane] = proj16_mma<UPW>(xs, ks0, wq);
         QSYNC();
         if (threadIdx.x < 128) {
             const int t = threadIdx.x >> 6;
             f32x4 a = red[t * 64 + lane];
 #pragma unroll
-            for (int j = 1; j < 8; ++j) { const f32x4 b = red[(t + 2 * j) * 64 + lane]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
+            for (int j = 1; j < NW / 2; ++j) { const f32x4 b = red[(t + 2 * j) * 64 + lane]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
             const float bv = in.bias[hh * 32 + t * 16 + c16];
 #pragma unroll
             for (int r = 0; r < 4; ++r) sQ[4 * g + r][t * 16 + c16] = (a[r] + bv) * scale;
@@ -251,19 +253,21 @@ __global__ __launch_bounds__(1024) void q2p_chain_kernel(QIn in, QOut out, const
     {
         // ---- foreground flags of object k (AUX_MASK fused, object_transformer.py:179-205) while the reduction settles ----
         int cnt = 0;
+        if (EARLY) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int p = threadIdx.x + 1024 * i;
-            if (early && p < HW) { const bool f = aux_fg_vals(lgv[i], K, k); sFg[p] = f ? 1 : 0; cnt += f ? 1 : 0; }
+            for (int i = 0; i < PPT; ++i) {
+                const int p = threadIdx.x + NT * i;
+                if (p < HW) { const bool f = aux_fg_vals<EARLY ? KT : 1>(lgv[i], K, k); sFg[p] = f ? 1 : 0; cnt += f ? 1 : 0; }
+            }
         }
-        for (int p = threadIdx.x + (early ? 2048 : 0); p < HW; p += 1024) {
+        for (int p = threadIdx.x + (EARLY ? 2048 : 0); p < HW; p += NT) {
             const bool f = aux_fg_late(lg, K, HW, k, p);
             sFg[p] = f ? 1 : 0;
             cnt += f ? 1 : 0;
         }
         cnt = wave_sum_i32(cnt);
         if (lane == 0 && cnt) atomicAdd(&sCnt, cnt);
-        QSYNC();                                   // sQ, sFg, sCnt complete; xs / red (= sO) are free again
+        QSYNC();                                           // sQ, sFg, sCnt complete; xs / red (= sO) are free again
         ATL(2)
         if (QPRE) {
             const float qv[8] = {qp0.x, qp0.y, qp0.z, qp0.w, qp1.x, qp1.y, qp1.z, qp1.w};
@@ -331,8 +335,8 @@ __global__ __launch_bounds__(1024) void q2p_chain_kernel(QIn in, QOut out, const
     };
 #pragma unroll
     for (int j = 0; j < Q2C_PF; ++j)
-        if (wave + 16 * j < nchunk) chunk(pf[j], (wave + 16 * j) * 32);
-    for (int ch = wave + 16 * Q2C_PF; ch < nchunk; ch += 16) {
+        if (wave + NW * j < nchunk) chunk(pf[j], (wave + NW * j) * 32);
+    for (int ch = wave + NW * Q2C_PF; ch < nchunk; ch += NW) {
         Q2CChunk L;
         q2c_load(L, kvb, ch * 32, HW, ldkv, voff, lane);
         chunk(L, ch * 32);
@@ -344,14 +348,14 @@ __global__ __launch_bounds__(1024) void q2p_chain_kernel(QIn in, QOut out, const
     for (int r = 0; r < 4; ++r) { sO[wave][c16][4 * g + r] = o0[r]; sO[wave][c16][16 + 4 * g + r] = o1[r]; }
     QSYNC();
     ATL(4)
-    if (threadIdx.x < 512) {                               // (query i, dim d): merge the 16 waves
-        const int i = threadIdx.x >> 5, d = threadIdx.x & 31;
+    for (int e = threadIdx.x; e < 512; e += NT) {          // (query i, dim d): merge the waves
+        const int i = e >> 5, d = e & 31;
         float Mg = -INFINITY;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) Mg = fmaxf(Mg, sM[w][i]);
+        for (int w = 0; w < NW; ++w) Mg = fmaxf(Mg, sM[w][i]);
         float num = 0.f, den = 0.f;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) {
+        for (int w = 0; w < NW; ++w) {
             const float f = (sM[w][i] == -INFINITY) ? 0.f : __expf(sM[w][i] - Mg);
             num += sO[w][i][d] * f;
             den += sL[w][i] * f;
@@ -360,16 +364,19 @@ __global__ __launch_bounds__(1024) void q2p_chain_kernel(QIn in, QOut out, const
     }
     QSYNC();
     ATL(5)
-    {   // per-head output projection: o (16 x 32) . Wo[:, 32 hh ..]^T -- wave w: output columns 16 w .. 16 w + 15, summed over the heads
+    {   // per-head output projection: o (16 x 32) . Wo[:, 32 hh ..]^T -- UPW 16-column tiles per wave, summed over the heads
         proj_u4 hi, lo;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { uint32_t h_, l_; split_bf2(sQ[c16][8 * g + 2 * j], sQ[c16][8 * g + 2 * j + 1], h_, l_); hi[j] = h_; lo[j] = l_; }
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(lo), as_frag(wo[0]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(hi), as_frag(wo[0]), acc, 0, 0, 0);
-        long long* ap = out.acc + ((long)k * 16 + 4 * g) * 256 + wave * 16 + c16;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) qacc_add(ap + r * 256, acc[r]);
+        for (int t = 0; t < UPW; ++t) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(lo), as_frag(wo[t]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(hi), as_frag(wo[t]), acc, 0, 0, 0);
+            long long* ap = out.acc + ((long)k * 16 + 4 * g) * 256 + (wave * UPW + t) * 16 + c16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qacc_add(ap + r * 256, acc[r]);
+        }
     }
     ATL(6)
 }
@@ -654,22 +661,26 @@ int launch_qchain(const cutie_op* op, hipStream_t s) {
             if (!qin_from_op(op, in, out, "attn_q2p", 0, 3, (op->flags & 16) != 0)) return -2;
             if (!p[1] || !p[2]) { cutie_set_error("attn_q2p (chain form): kv and the mask logits required"); return -2; }
             const int HWp = (i[2] + 15) & ~15;
-            const size_t dyn = (size_t)HWp + 16 * 32 * Q2C_VLD * 2;
-            if (dyn > 96 * 1024) { cutie_set_error("attn_q2p (chain form): HW = %d does not fit the LDS flag array", i[2]); return -2; }
-            const bool qp = (op->flags & 16) != 0, ac = !qp && (op->flags & 4), early = i[0] <= 8;
+            const bool qp = (op->flags & 16) != 0, ac = !qp && (op->flags & 4);
             const float* qpre = nullptr;
             if (qp) { qpre = (const float*)p[0]; in.x = nullptr; in.W = nullptr; in.ln_out = nullptr; }   // p0 = q [K*16, 256], projected and scaled
             else if (!in.add || !in.ln_g || !in.ln_b || !in.bias || (ac && !in.abias)) {
                 cutie_set_error("attn_q2p (chain form): query embedding, LayerNorm, the projection bias and (flags&4) the accumulator's bias are required");
                 return -2;
             }
-            // one instantiation per (q handed in, accumulator input, logits fetched at entry): straight-line load sequences
-            const int var = (qp ? 4 : 0) | (ac ? 2 : 0) | (early ? 1 : 0);
-            void (*kern)(QIn, QOut, const bf16_t*, const float*, int, int, int, int, const float*) =
-                var == 7 || var == 5 ? q2p_chain_kernel<true, false, true> : var == 6 || var == 4 ? q2p_chain_kernel<true, false, false> :
-                var == 3 ? q2p_chain_kernel<false, true, true> : var == 2 ? q2p_chain_kernel<false, true, false> :
-                var == 1 ? q2p_chain_kernel<false, false, true> : q2p_chain_kernel<false, false, false>;
-            static bool attr_set[8] = {};
+            // one instantiation per (q handed in, accumulator input, logits fetched at entry for <= 4 / <= 8 objects / late)
+            const int kt = i[0] <= 4 ? 1 : i[0] <= 8 ? 2 : 0;
+            const int var = (qp ? 6 : ac ? 3 : 0) + kt;
+            constexpr int NWV = 8;
+            typedef void (*Kern)(QIn, QOut, const bf16_t*, const float*, int, int, int, int, int, const float*);
+            static const Kern kerns[9] = {
+                q2p_chain_kernel<false, false, 0, NWV>, q2p_chain_kernel<false, false, 4, NWV>, q2p_chain_kernel<false, false, 8, NWV>,
+                q2p_chain_kernel<false, true, 0, NWV>, q2p_chain_kernel<false, true, 4, NWV>, q2p_chain_kernel<false, true, 8, NWV>,
+                q2p_chain_kernel<true, false, 0, NWV>, q2p_chain_kernel<true, false, 4, NWV>, q2p_chain_kernel<true, false, 8, NWV>};
+            const Kern kern = kerns[var];
+            const size_t dyn = (size_t)HWp + NWV * 32 * Q2C_VLD * 2;
+            if (dyn > 96 * 1024) { cutie_set_error("attn_q2p (chain form): HW = %d does not fit the LDS flag array", i[2]); return -2; }
+            static bool attr_set[9] = {};
             if (!attr_set[var]) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
                     cutie_set_error("attn_q2p (chain form): cannot raise the dynamic LDS limit");
@@ -677,7 +688,8 @@ int launch_qchain(const cutie_op* op, hipStream_t s) {
                 }
                 attr_set[var] = true;
             }
-            hipLaunchKernelGGL(kern, dim3(8, i[0]), dim3(1024), dyn, s, in, out, (const bf16_t*)p[1], (const float*)p[2], i[2], HWp, i[5], i[6], qpre);
+            const int hstride = i[8] > 0 ? i[8] : 32;       // elements between the heads of k / v inside a pixel row (32: [k | v | ..] by kind; 64: k | v interleaved per head)
+            hipLaunchKernelGGL(kern, dim3(8, i[0]), dim3(NWV * 64), dyn, s, in, out, (const bf16_t*)p[1], (const float*)p[2], i[2], HWp, i[5], i[6], hstride, qpre);
             break;
         }
         case CUTIE_OP_ATTN_SELF:

@@ -420,21 +420,25 @@ class OpList:
             ptrs[12], ptrs[13] = out_proj[0].weight, out_proj[1]
         return flags, ints, ptrs
 
-    def attn_q2p(self, q, kv, fg, nfg, y, *, K, Q, HW, C, heads, ldkv, voff, logits=None, proj=None, acc_in=None, out_proj=None, q_pre=None):
+    def attn_q2p(self, q, kv, fg, nfg, y, *, K, Q, HW, C, heads, ldkv, voff, logits=None, proj=None, acc_in=None, out_proj=None, q_pre=None, hstride=None):
         """logits given: the foreground mask is derived inside the kernel from the mask_pred logits (AUX_MASK fused; fg / nfg unused).
         proj given (needs logits): q = (LN(x) + emb) Wq^T + b is computed inside the launch from the unprojected rows proj['x'].
         out_proj (needs proj; chain form, see _proj_extras): y is not written; acc_in optional.
         q_pre (chain form, instead of proj): q f32 [K*Q, 256], already projected and scaled by 1/sqrt(32) -- by the ATTN_P2Q launch of the
         previous transformer block (attn_p2q(next_q=...))."""
+        hs = 0 if hstride in (None, C // heads) else hstride   # chain form only: elements between the heads' k (and v) inside a pixel row (i8)
         if q_pre is not None:
             assert proj is None and acc_in is None and out_proj is not None and logits is not None
             flags, ints, ptrs = self._proj_extras(3 | 16, [K, Q, HW, C, heads, ldkv, voff, 256], [q_pre, kv, logits, None, None], None, out_proj)
+            ints[8] = hs
             return self.add(ATTN_Q2P, flags, ints, [], ptrs)
         if proj is not None:
             assert logits is not None
             ldx, ln_out, tail = self._proj(proj)
             assert out_proj is not None or acc_in is None, 'the chain form of ATTN_Q2P needs out_proj'
             flags, ints, ptrs = self._proj_extras(3, [K, Q, HW, C, heads, ldkv, voff, ldx], [proj['x'], kv, logits, ln_out, y] + tail, acc_in, out_proj)
+            assert hs == 0 or out_proj is not None, 'a head stride needs the chain form'
+            ints[8] = hs
             return self.add(ATTN_Q2P, flags, ints, [], ptrs)
         assert acc_in is None and out_proj is None
         if logits is not None:

@@ -150,6 +150,8 @@ enum {
      *      caller clears it beforehand, e.g. QUERY_INIT's side job); p12 = Wo bf16 [256,256]; p4 is not written.  Wo's bias and the
      *      residual are added by the consumer through ITS flags&4:
      * flags&4 (chain form): the rows are a sum, x_eff = p0 + p11 (bias f32 [256], may be 0) + p10 / 2^32 (p10 = int64 [K*Q, 256])
+     * i8 (chain form; 0 = 32): elements between the heads' k (and v) slices inside a pixel row -- 64 with i6 = 32 reads k | v interleaved per
+     *      head (one 128-byte line per pixel and head)
      * flags&16 (chain form, instead of flags&4 and of the projection operands): p0 = q f32 [K*Q, 256], already projected and scaled by
      *      1/sqrt(32) (ATTN_P2Q flags&16 of the previous transformer block produces it); p3, p5..p11 unused */
     CUTIE_OP_ATTN_Q2P = 18,

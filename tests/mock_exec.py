@@ -379,8 +379,9 @@ class MockExecutor:
             q = qp.view(K, Q, heads, hd).transpose(1, 2)
         else:
             q = view(p[0], F32, (K, Q, C)).view(K, Q, heads, hd).transpose(1, 2)
-        k = view(p[1], BF16, (K, HW, C), (HW * ldkv, ldkv, 1)).float().view(K, HW, heads, hd).transpose(1, 2)
-        v = view(p[1] + 2 * voff, BF16, (K, HW, C), (HW * ldkv, ldkv, 1)).float().view(K, HW, heads, hd).transpose(1, 2)
+        hs = (i[8] if len(i) > 8 and i[8] > 0 and (flags & 8) else hd)          # chain form: elements between the heads inside a pixel row
+        k = view(p[1], BF16, (K, HW, heads, hd), (HW * ldkv, ldkv, hs, 1)).float().transpose(1, 2)
+        v = view(p[1] + 2 * voff, BF16, (K, HW, heads, hd), (HW * ldkv, ldkv, hs, 1)).float().transpose(1, 2)
         if flags & 1:                                                   # AUX_MASK fused: p2 = logits
             pr = torch.sigmoid(view(p[2], F32, (K, HW)))
             lg = torch.cat([_clamp_logit(torch.prod(1 - pr, dim=0, keepdim=True)), _clamp_logit(pr)], 0)

@@ -684,14 +684,16 @@ def test_attention_with_fused_projections(K):
     assert float((hip['pa'].float() - hip['pa_f'].float()).abs().max()) <= 2e-2 * float(hip['pa'].float().abs().max())
 
 
-@pytest.mark.parametrize('K,HW,hid_slice,qnext', [(1, 1620, 64, 1), (3, 1620, 64, 1), (3, 1620, 128, 0), (2, 700, 64, 1), (2, 8040, 64, 1), (1, 37, 128, 1), (9, 300, 64, 1), (3, 1620, 64, 0)])
-def test_query_chain_in_four_launches(K, HW, hid_slice, qnext):
+@pytest.mark.parametrize('K,HW,hid_slice,qnext,inter', [(1, 1620, 64, 1, 0), (3, 1620, 64, 1, 1), (3, 1620, 128, 0, 0), (2, 700, 64, 1, 1), (2, 8040, 64, 1, 0), (1, 37, 128, 1, 1),
+                                                       (9, 300, 64, 1, 0), (3, 1620, 64, 0, 1), (5, 2500, 64, 1, 1)])
+def test_query_chain_in_four_launches(K, HW, hid_slice, qnext, inter):
     """The query side of a transformer block as the frame runs it (csrc/qchain.hip: ATTN_Q2P with its out-projection summed into a
     fixed-point accumulator -> ATTN_SELF adding it, + out-projection -> QFFN -> ATTN_P2Q) against the seven-launch sequence it replaces
     (LINEAR out-projections, linear1, linear2), with a second block behind it so that ATTN_Q2P's accumulator input is covered as well;
     both against the interpreter.  HW = 8040 (1080p): the pixel loop of ATTN_Q2P runs past its prefetched chunks; HW = 37: ragged single
     chunk; K = 9: the mask logits are read late (more than 8 objects); qnext: the second block's ATTN_Q2P gets its queries from the
-    first block's ATTN_P2Q launch (extra blocks) instead of projecting them itself."""
+    first block's ATTN_P2Q launch (extra blocks) instead of projecting them itself; inter: k | v of the pixels interleaved per head
+    (head stride 64, v 32 behind k) as the frame's pixel projection leaves them."""
     def build(dev, g):
         Q, C, heads, FF = 16, 256, 8, 2048
         M = K * Q
@@ -733,11 +735,16 @@ def test_query_chain_in_four_launches(K, HW, hid_slice, qnext):
         for b, B in enumerate(blocks):
             xn, y, x2 = (xn_pre if xn_pre is not None else z(M, C)), z(M, C), z(M, C)
             a1, a2, a3 = zi(), zi(), zi()
+            kvc, lay = B['kvq'], dict(voff=C)
+            if inter:                                  # [k | v | q2] -> [k_0 v_0 | k_1 v_1 | ... | q2]
+                t = B['kvq'].cpu()
+                kv2 = torch.stack([t[..., :C].reshape(K, HW, heads, 32), t[..., C:2 * C].reshape(K, HW, heads, 32)], 3).reshape(K, HW, 2 * C)
+                kvc, lay = torch.cat([kv2, t[..., 2 * C:]], -1).contiguous().to(dev), dict(voff=32, hstride=64)
             if q_pre is not None:
-                ol.attn_q2p(None, B['kvq'], None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg, q_pre=q_pre, out_proj=(B['Wo1'], a1))
+                ol.attn_q2p(None, kvc, None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, logits=lg, q_pre=q_pre, out_proj=(B['Wo1'], a1), **lay)
             else:
-                ol.attn_q2p(None, B['kvq'], None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg,
-                            proj=dict(x=x, W=B['Wq'], emb=emb, ln=B['ln1'], ln_out=xn), acc_in=acc, out_proj=(B['Wo1'], a1))
+                ol.attn_q2p(None, kvc, None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, logits=lg,
+                            proj=dict(x=x, W=B['Wq'], emb=emb, ln=B['ln1'], ln_out=xn), acc_in=acc, out_proj=(B['Wo1'], a1), **lay)
             ol.attn_self(None, None, None, K=K, Q=Q, C=C, heads=heads, proj=dict(x=xn, W=B['Wqkv'], emb=emb, ln=B['ln2'], ln_out=y),
                          acc_in=(a1, B['Wo1'].bias), out_proj=(B['Wo2'], a2))
             ol.qffn(y, x2, a3, rows=M, ln=B['ln3'], W1=B['W1'], W2=B['W2'], acc_in=(a2, B['Wo2'].bias), hid_slice=hid_slice)
@@ -755,7 +762,9 @@ def test_query_chain_in_four_launches(K, HW, hid_slice, qnext):
             x = x2
         return ol, out
     hip, ref = run_both(build, seed=31 + K)
-    check(hip, ref, name='query chain', rtol=4e-3)
+    f32k = [k_ for k_ in ref if ref[k_].dtype == torch.float32]
+    check({k_: hip[k_] for k_ in f32k}, {k_: ref[k_] for k_ in f32k}, name='query chain', rtol=4e-3)
+    check({k_: hip[k_] for k_ in ref if k_ not in f32k}, {k_: ref[k_] for k_ in ref if k_ not in f32k}, name='query chain (bf16 outputs)')
     for b in range(2):
         for a_, c_ in ((f'x2_{b}', f'x2c_{b}'), (f'y_{b}', f'yc_{b}')):
             d = float((hip[a_] - hip[c_]).abs().max())

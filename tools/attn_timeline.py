@@ -61,6 +61,10 @@ def main():
     qpre = rn(M, C, sc=0.2)
     one('ATTN_Q2P with q handed in', lambda ol: ol.attn_q2p(None, kvq, None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=lg,
         q_pre=qpre, out_proj=(Wo1, a1)), heads * K)
+    t_ = kvq.cpu()
+    kvi = torch.cat([torch.stack([t_[..., :C].reshape(K, HW, heads, 32), t_[..., C:2 * C].reshape(K, HW, heads, 32)], 3).reshape(K, HW, 2 * C), t_[..., 2 * C:]], -1).contiguous().to(dev)
+    one('ATTN_Q2P with q handed in, k | v interleaved per head', lambda ol: ol.attn_q2p(None, kvi, None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=32, hstride=64, logits=lg,
+        q_pre=qpre, out_proj=(Wo1, a1)), heads * K)
     one('ATTN_SELF (+parts in, +out-proj)', lambda ol: ol.attn_self(None, None, None, K=K, Q=Q, C=C, heads=heads,
         proj=dict(x=xn, W=Wqkv, emb=emb, ln=ln2, ln_out=y), acc_in=(a1, Wo1.bias), out_proj=(Wo2, a2)), heads * K)
     one('QFFN slice 64', lambda ol: ol.qffn(y, x2, a3, rows=M, ln=ln3, W1=W1, W2=W2, acc_in=(a2, Wo2.bias), hid_slice=64), (FF // 64) * K)

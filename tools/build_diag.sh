@@ -12,7 +12,7 @@ for spec in ${@:-TL=CONV_TIMELINE}; do
   /opt/rocm/bin/hipcc $FL $defs -c conv_pc.hip -o ../../tools/abl/conv_pc_$v.o &
   /opt/rocm/bin/hipcc $FL $defs -c conv_dma.hip -o ../../tools/abl/conv_dma_$v.o &
   wait
-  objs=""; for o in conv_igemm elementwise attention qchain affinity bank api; do objs="$objs $o.o"; done
+  objs=""; for o in conv_igemm elementwise stem attention qchain affinity bank api; do objs="$objs $o.o"; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs ../../tools/abl/conv_pc_$v.o ../../tools/abl/conv_dma_$v.o -o ../../tools/abl/libcutie_hip_$v.so
 done
 ls -la ../../tools/abl/*.so
