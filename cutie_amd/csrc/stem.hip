@@ -9,7 +9,7 @@
 //      pixels outside the padded frame are the conv's zero padding, the 72nd column is zero (the 8th "tap" of a row, see below);
 //   2. implicit GEMM on v_mfma_f32_16x16x32_bf16: a K step is half a kernel row = 4 taps x 8 channels, so a B fragment is ONE
 //      16-byte LDS read of the pixel the tap lands on (lane group g <-> tap 4 (s & 1) + g; the 8th tap has zero weights); A = the
-//      weights, 2 x 14 fragments per wave held in registers for the whole block; waves 2 (pixel halves) x 2 (channel halves);
+//      weights, 2 x 14 fragments per wave held in registers for the whole block; 8 waves = 4 (pixel groups) x 2 (channel halves);
 //   3. bias (+ nothing else: ReLU moves behind the pool), bf16, into an LDS tile [297][64] that aliases the patch; conv pixels outside
 //      the conv's output range are written as -inf (the pool's padding);
 //   4. 3 x 3 max over the tile, ReLU, 32-byte stores.
@@ -36,13 +36,14 @@ struct StemParams {
     float m0, m1, m2, s0, s1, s2;
 };
 
-__global__ __launch_bounds__(256) void stem_kernel(StemParams p) {
+#define ST_NT 512                                        // 8 waves: 4 pixel groups x 2 channel halves (two waves per SIMD hide each other's LDS latency)
+__global__ __launch_bounds__(ST_NT) void stem_kernel(StemParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[ST_MF * 16 * ST_CLD * 2];   // 43776 B: conv tile; the 26496-B patch aliases its start
     static_assert(ST_IH * ST_IW * 16 <= ST_MF * 16 * ST_CLD * 2, "patch fits");
     st_u4* patch = reinterpret_cast<st_u4*>(lds);
     bf16_t* ct = reinterpret_cast<bf16_t*>(lds);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave & 3, wn = wave >> 2;
     const int k = blockIdx.z;
     const int OH = p.H >> 1, OW = p.W_ >> 1, PH = p.H >> 2, PW = p.W_ >> 2;
     const int py0 = blockIdx.y * ST_PH, px0 = blockIdx.x * ST_PW;
@@ -62,38 +63,47 @@ __global__ __launch_bounds__(256) void stem_kernel(StemParams p) {
             wa[n][s] = kw < 7 ? v : z;
         }
     }
-    // ---- the input patch ----
+    // ---- the input patch: 4 pixels per thread, all their loads issued before the first is used ----
     const long plane = (long)p.h0 * p.w0, HWp = (long)p.H * p.W_;
-    for (int e = tid; e < ST_IH * ST_IW; e += 256) {
+    constexpr int NPIX = (ST_IH * ST_IW + ST_NT - 1) / ST_NT;   // 4
+    float pr_[NPIX], pg_[NPIX], pb_[NPIX], pm_[NPIX], po_[NPIX];
+    bool pin_[NPIX], pim_[NPIX];
+#pragma unroll
+    for (int t = 0; t < NPIX; ++t) {
+        const int e = min(tid + ST_NT * t, ST_IH * ST_IW - 1);
         const int ry = e / ST_IW, rx = e - ry * ST_IW;
         const int iy = iy0 + ry, ix = ix0 + rx;
-        const bool inpad = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W_ && rx < ST_IW - 1;
+        pin_[t] = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W_ && rx < ST_IW - 1;
         const int sy = iy - p.pt, sx = ix - p.pl;
-        const bool inimg = inpad && (unsigned)sy < (unsigned)p.h0 && (unsigned)sx < (unsigned)p.w0;
+        pim_[t] = pin_[t] && (unsigned)sy < (unsigned)p.h0 && (unsigned)sx < (unsigned)p.w0;
         const long o = (long)min(max(sy, 0), p.h0 - 1) * p.w0 + min(max(sx, 0), p.w0 - 1);     // clamped: the loads are unconditional
-        float r = p.img[o], gg = p.img[plane + o], b = p.img[2 * plane + o];
-        r = inimg ? r : 0.f; gg = inimg ? gg : 0.f; b = inimg ? b : 0.f;
-        r = (r - p.m0) / p.s0; gg = (gg - p.m1) / p.s1; b = (b - p.m2) / p.s2;            // (the arithmetic of IMG_PREP, to the bit)
-        float mk = 0.f, others = 0.f;
-        if (p.masks) {
+        pr_[t] = p.img[o]; pg_[t] = p.img[plane + o]; pb_[t] = p.img[2 * plane + o];
+        pm_[t] = 0.f; po_[t] = 0.f;
+        if (p.masks) {                                   // (block-uniform)
             const long pix = (long)min(max(iy, 0), p.H - 1) * p.W_ + min(max(ix, 0), p.W_ - 1);
             float sum = 0.f;
             for (int j = 0; j < p.K; ++j) sum += p.masks[(long)j * HWp + pix];
-            mk = p.masks[(long)k * HWp + pix];
-            others = fminf(fmaxf(sum - mk, 0.f), 1.f);
+            pm_[t] = p.masks[(long)k * HWp + pix];
+            po_[t] = fminf(fmaxf(sum - pm_[t], 0.f), 1.f);
         }
-        st_u4 v = {pack_bf2(r, gg), pack_bf2(b, mk), pack_bf2(others, 0.f), 0u};
+    }
+#pragma unroll
+    for (int t = 0; t < NPIX; ++t) {
+        const int e = tid + ST_NT * t;
+        float r = pim_[t] ? pr_[t] : 0.f, gg = pim_[t] ? pg_[t] : 0.f, b = pim_[t] ? pb_[t] : 0.f;
+        r = (r - p.m0) / p.s0; gg = (gg - p.m1) / p.s1; b = (b - p.m2) / p.s2;            // (the arithmetic of IMG_PREP, to the bit)
+        const st_u4 v = {pack_bf2(r, gg), pack_bf2(b, pm_[t]), pack_bf2(po_[t], 0.f), 0u};
         const st_u4 z = {0u, 0u, 0u, 0u};
-        patch[e] = inpad ? v : z;
+        if (e < ST_IH * ST_IW) patch[e] = pin_[t] ? v : z;
     }
     __syncthreads();
-    // ---- implicit GEMM: 14 K steps; this wave: M fragments 10 wm .. (10 or 9 of them), N fragments 2 wn, 2 wn + 1 ----
-    constexpr int NB = 10;
-    const int nb = wm == 0 ? 10 : ST_MF - 10;
+    // ---- implicit GEMM: 14 K steps; this wave: M fragments 5 wm .. (5 or 4 of them), N fragments 2 wn, 2 wn + 1 ----
+    constexpr int NB = 5;
+    const int nb = min(NB, ST_MF - wm * NB);
     int boff[NB];                                        // patch index of (conv pixel, tap g) at kernel row 0, first half
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const int idx = min((wm * 10 + b) * 16 + c, ST_NCONV - 1);
+        const int idx = min((wm * NB + b) * 16 + c, ST_NCONV - 1);
         const int cyl = idx / ST_CW, cxl = idx - cyl * ST_CW;
         boff[b] = 2 * cyl * ST_IW + 2 * cxl + g;
     }
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemParams p) {
     // ---- bias, bf16, conv tile (lane: conv pixel c of the fragment, channels 4 g .. 4 g + 3 of the N fragment) ----
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const int idx = (wm * 10 + b) * 16 + c;
+        const int idx = (wm * NB + b) * 16 + c;
         if (b < nb && idx < ST_NCONV) {
             const int cyl = idx / ST_CW, cxl = idx - cyl * ST_CW;
             const bool valid = (unsigned)(cy0 + cyl) < (unsigned)OH && (unsigned)(cx0 + cxl) < (unsigned)OW;
@@ -133,36 +143,31 @@ __global__ __launch_bounds__(256) void stem_kernel(StemParams p) {
         }
     }
     __syncthreads();
-    // ---- 3 x 3 / stride 2 max pool (+ ReLU): thread = (pooled pixel, 16 channels) ----
+    // ---- 3 x 3 / stride 2 max pool (+ ReLU): thread = (pooled pixel, 8 channels) ----
     {
-        const int pp = tid >> 2, q = tid & 3, ppy = pp >> 4, ppx = pp & 15;
+        const int pp = tid >> 3, q = tid & 7, ppy = pp >> 4, ppx = pp & 15;
         const int py = py0 + ppy, px = px0 + ppx;
-        float m[16];
+        float m[8];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) m[i] = -INFINITY;
+        for (int i = 0; i < 8; ++i) m[i] = -INFINITY;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                const bf16_t* src = ct + ((2 * ppy + dy) * ST_CW + 2 * ppx + dx) * ST_CLD + q * 16;
-                const st_u4 a = *reinterpret_cast<const st_u4*>(src), b2 = *reinterpret_cast<const st_u4*>(src + 8);
+                const st_u4 a = *reinterpret_cast<const st_u4*>(ct + ((2 * ppy + dy) * ST_CW + 2 * ppx + dx) * ST_CLD + q * 8);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     m[2 * i] = fmaxf(m[2 * i], __uint_as_float(a[i] << 16));
                     m[2 * i + 1] = fmaxf(m[2 * i + 1], __uint_as_float(a[i] & 0xffff0000u));
-                    m[8 + 2 * i] = fmaxf(m[8 + 2 * i], __uint_as_float(b2[i] << 16));
-                    m[8 + 2 * i + 1] = fmaxf(m[8 + 2 * i + 1], __uint_as_float(b2[i] & 0xffff0000u));
                 }
             }
         if (p.relu) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) m[i] = fmaxf(m[i], 0.f);
+            for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], 0.f);
         }
-        if (py < PH && px < PW) {
-            bf16_t* dst = p.y + (((long)k * PH + py) * PW + px) * 64 + q * 16;
-            *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf2(m[0], m[1]), pack_bf2(m[2], m[3]), pack_bf2(m[4], m[5]), pack_bf2(m[6], m[7]));
-            *reinterpret_cast<uint4*>(dst + 8) = make_uint4(pack_bf2(m[8], m[9]), pack_bf2(m[10], m[11]), pack_bf2(m[12], m[13]), pack_bf2(m[14], m[15]));
-        }
+        if (py < PH && px < PW)
+            *reinterpret_cast<uint4*>(p.y + (((long)k * PH + py) * PW + px) * 64 + q * 8) =
+                make_uint4(pack_bf2(m[0], m[1]), pack_bf2(m[2], m[3]), pack_bf2(m[4], m[5]), pack_bf2(m[6], m[7]));
     }
 }
 
@@ -179,6 +184,6 @@ int launch_stem(const cutie_op* op, hipStream_t s) {
     p.h0 = i[0]; p.w0 = i[1]; p.H = i[2]; p.W_ = i[3]; p.pl = i[4]; p.pt = i[5]; p.K = q[1] ? i[6] : 1; p.Kpad = i[7]; p.relu = op->flags & 1;
     p.m0 = op->f[0]; p.m1 = op->f[1]; p.m2 = op->f[2]; p.s0 = op->f[3]; p.s1 = op->f[4]; p.s2 = op->f[5];
     const int PH = i[2] >> 2, PW = i[3] >> 2;
-    hipLaunchKernelGGL(stem_kernel, dim3((PW + ST_PW - 1) / ST_PW, (PH + ST_PH - 1) / ST_PH, p.K), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(stem_kernel, dim3((PW + ST_PW - 1) / ST_PW, (PH + ST_PH - 1) / ST_PH, p.K), dim3(ST_NT), 0, s, p);
     return (int)hipGetLastError();
 }
