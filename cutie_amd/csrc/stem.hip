@@ -32,7 +32,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int st_u4;
 
 struct StemParams {
     const float* img; const float* masks; const bf16_t* W; const float* bias; bf16_t* y;
-    int h0, w0, H, W_, pl, pt, K, Kpad, relu;
+    int h0, w0, H, W_, pl, pt, K, Kpad, relu, gx, nb;
     float m0, m1, m2, s0, s1, s2;
 };
 
@@ -46,7 +46,13 @@ __global__ __launch_bounds__(ST_NT) void stem_kernel(StemParams p) {
     const int wm = wave & 3, wn = wave >> 2;
     const int k = blockIdx.z;
     const int OH = p.H >> 1, OW = p.W_ >> 1, PH = p.H >> 2, PW = p.W_ >> 2;
-    const int py0 = blockIdx.y * ST_PH, px0 = blockIdx.x * ST_PW;
+    // XCD-aware order: hardware block b runs on XCD b % 8; every XCD gets one contiguous band of tiles, so the halo pixels that
+    // neighbouring tiles share are fetched into ONE L2 (round-robin order: 21.5 MB fetched per launch for a 4.9 MB frame, rocprofv3 PMC)
+    const int per = (p.nb + 7) >> 3;
+    const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (logical >= p.nb || (int)(blockIdx.x >> 3) >= per) return;
+    const int by = logical / p.gx, bx = logical - by * p.gx;
+    const int py0 = by * ST_PH, px0 = bx * ST_PW;
     const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;     // first conv pixel of the block
     const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;     // first input pixel
 
@@ -184,6 +190,8 @@ int launch_stem(const cutie_op* op, hipStream_t s) {
     p.h0 = i[0]; p.w0 = i[1]; p.H = i[2]; p.W_ = i[3]; p.pl = i[4]; p.pt = i[5]; p.K = q[1] ? i[6] : 1; p.Kpad = i[7]; p.relu = op->flags & 1;
     p.m0 = op->f[0]; p.m1 = op->f[1]; p.m2 = op->f[2]; p.s0 = op->f[3]; p.s1 = op->f[4]; p.s2 = op->f[5];
     const int PH = i[2] >> 2, PW = i[3] >> 2;
-    hipLaunchKernelGGL(stem_kernel, dim3((PW + ST_PW - 1) / ST_PW, (PH + ST_PH - 1) / ST_PH, p.K), dim3(ST_NT), 0, s, p);
+    p.gx = (PW + ST_PW - 1) / ST_PW;
+    p.nb = p.gx * ((PH + ST_PH - 1) / ST_PH);
+    hipLaunchKernelGGL(stem_kernel, dim3(((p.nb + 7) / 8) * 8, 1, p.K), dim3(ST_NT), 0, s, p);
     return (int)hipGetLastError();
 }
