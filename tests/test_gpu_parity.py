@@ -437,6 +437,39 @@ def test_deferred_memorising_matches_inline(gpu_net, monkeypatch):
         assert x.shape == y.shape and float((x - y).abs().max()) < 1e-3, (t, float((x - y).abs().max()))
 
 
+def test_graph_replay_matches_launches(gpu_net, monkeypatch):
+    """$CUTIE_AMD_GRAPHS=1 (opt-in): plans whose pointer signature repeats (frame-slot pool) are captured once and replayed as HIP graphs.
+    Same clip launch by launch and replayed: bit-identical probabilities (FIFO mode: no float atomics), and most plan runs of the second half
+    of the clip really are replays."""
+    from cutie_amd import _lib
+    from cutie_amd.inference import inference_core as IC
+    from cutie_amd.model import plans as PL
+    from cutie_amd.utils.synth import SyntheticClip
+    clip = SyntheticClip(96, 160, 2, 40, seed=5)
+    frames = torch.stack([clip.frame(t) for t in range(40)]).cuda()
+    mask = clip.first_mask().cuda()
+
+    def run(graphs):
+        monkeypatch.setattr(PL, 'GRAPHS', graphs)
+        net = gpu_net.fork() if hasattr(gpu_net, 'fork') else gpu_net           # own plans / pool: nothing captured by another test
+        proc = IC.InferenceCore(net, cfg=default_config(mem_every=3))
+        ex = _lib.get_executor()
+        outs = [proc.step(frames[0], mask, objects=clip.objects, next_image=frames[1])]
+        for t in range(1, 40):
+            if t == 20:
+                ex.graph_stats[:] = [0, 0]
+            outs.append(proc.step(frames[t], next_image=frames[t + 1] if t + 1 < 40 else None).clone())
+        torch.cuda.synchronize()
+        return torch.stack([o.float() for o in outs[1:]]).cpu(), list(ex.graph_stats)
+
+    with torch.inference_mode():
+        a, sa = run(False)
+        b, sb = run(True)
+    assert sa[1] == 0
+    assert sb[1] > sb[0], ('plans launch by launch / replayed over the second half of the clip', sb)
+    assert torch.equal(a, b)
+
+
 def test_concurrent_clips_match_sequential(gpu_net):
     """parallel.run_concurrent: 4 clips in flight on one GPU (host thread + HIP stream + CUTIE.fork() each) produce
     bit-identical probabilities to the same clips run one after another."""
