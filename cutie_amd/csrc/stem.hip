@@ -2,15 +2,17 @@
 // stride-2 / pad-3 convolution with folded BatchNorm (pixel_encoder.conv1, mask_encoder.conv1: resnet.py conv1 + bn1; big_modules.py
 // 30-33, 95-100) and the 3x3 / stride-2 / pad-1 max pooling (+ ReLU: before the pool in the pixel encoder, after it in the mask
 // encoder -- the same thing, ReLU and max commute).  Round 2 ran them as three launches through two HBM round trips of a stride-2 map
-// (480p: 30.4 + 10.2 + 6.6 us per frame, the 7x7 conv at 2.6 % of the MFMA peak: Cin = 3 padded to 8, register-staged im2col).
+// (480p: 30.4 + 10.2 + 6.6 us per frame, the 7x7 conv at 2.6 % of the MFMA peak: Cin = 3 padded to 8, register-staged im2col);
+// this kernel: 13.5 us (4 x 16 tiles with per-wave weight loads: 24 us; weights staged once per block: 17.7; 8 x 16 tiles, one round: 13.5).
 //
-// One block = 4 x 16 pooled pixels of one object: they need 9 x 33 conv pixels, which need a 23 x 71 input patch.
-//   1. the patch is built in LDS as [23][72] pixels x 8 bf16 channels (r, g, b, mask, others, 0, 0, 0), straight from the fp32 frame;
+// One block = ST_PH x 16 pooled pixels of one object (8 x 16: they need 17 x 33 conv pixels, which need a 39 x 71 input patch; 210 blocks
+// at 480p: one round on 256 CUs).
+//   1. the patch is built in LDS as [39][72] pixels x 8 bf16 channels (r, g, b, mask, others, 0, 0, 0), straight from the fp32 frame;
 //      pixels outside the padded frame are the conv's zero padding, the 72nd column is zero (the 8th "tap" of a row, see below);
 //   2. implicit GEMM on v_mfma_f32_16x16x32_bf16: a K step is half a kernel row = 4 taps x 8 channels, so a B fragment is ONE
 //      16-byte LDS read of the pixel the tap lands on (lane group g <-> tap 4 (s & 1) + g; the 8th tap has zero weights); A = the
-//      weights, 2 x 14 fragments per wave held in registers for the whole block; 8 waves = 4 (pixel groups) x 2 (channel halves);
-//   3. bias (+ nothing else: ReLU moves behind the pool), bf16, into an LDS tile [297][64] that aliases the patch; conv pixels outside
+//      weights (staged once per block in LDS in fragment order, then 2 x 14 fragments per wave in registers); 8 waves = 4 (pixel groups) x 2 (channel halves);
+//   3. bias (+ nothing else: ReLU moves behind the pool), bf16, into an LDS tile [561][64] that aliases the patch; conv pixels outside
 //      the conv's output range are written as -inf (the pool's padding);
 //   4. 3 x 3 max over the tile, ReLU, 32-byte stores.
 // Results: identical rounding points as the three-launch form (bf16 after the conv, max of bf16 values); only the fp32 summation
@@ -18,13 +20,15 @@
 #include "common.h"
 #include <math.h>
 
-#define ST_PH 4
+#ifndef ST_PH
+#define ST_PH 8
+#endif
 #define ST_PW 16
-#define ST_CH (2 * ST_PH + 1)                            // conv rows of a block (9)
+#define ST_CH (2 * ST_PH + 1)                            // conv rows of a block
 #define ST_CW (2 * ST_PW + 1)                            // conv columns (33)
-#define ST_NCONV (ST_CH * ST_CW)                         // 297
-#define ST_MF ((ST_NCONV + 15) / 16)                     // 19 M fragments
-#define ST_IH (2 * ST_CH + 5)                            // input rows (23)
+#define ST_NCONV (ST_CH * ST_CW)
+#define ST_MF ((ST_NCONV + 15) / 16)                     // M fragments
+#define ST_IH (2 * ST_CH + 5)                            // input rows
 #define ST_IW 72                                         // input columns: 71 + one zero column
 #define ST_CLD 72                                        // bf16 pitch of the conv tile (64 + 8: rows 144 B apart)
 
@@ -38,10 +42,12 @@ struct StemParams {
 
 #define ST_NT 512                                        // 8 waves: 4 pixel groups x 2 channel halves (two waves per SIMD hide each other's LDS latency)
 __global__ __launch_bounds__(ST_NT) void stem_kernel(StemParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[ST_MF * 16 * ST_CLD * 2];   // 43776 B: conv tile; the 26496-B patch aliases its start
+    // dynamic LDS: [conv tile 82944 B (the 44928-B patch aliases its start)][weights in fragment order 57344 B]
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     static_assert(ST_IH * ST_IW * 16 <= ST_MF * 16 * ST_CLD * 2, "patch fits");
     st_u4* patch = reinterpret_cast<st_u4*>(lds);
     bf16_t* ct = reinterpret_cast<bf16_t*>(lds);
+    st_u4* wl = reinterpret_cast<st_u4*>(lds + ST_MF * 16 * ST_CLD * 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
     const int wm = wave & 3, wn = wave >> 2;
     const int k = blockIdx.z;
@@ -56,22 +62,22 @@ __global__ __launch_bounds__(ST_NT) void stem_kernel(StemParams p) {
     const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;     // first conv pixel of the block
     const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;     // first input pixel
 
-    // ---- weights of this wave's 32 output channels: 2 x 14 fragments (lane: channel row c, taps 4 (s & 1) + g of kernel row s >> 1) ----
-    st_u4 wa[2][14];
+    // ---- weights -> LDS in fragment order, once per block (every wave loading its own 28 fragments from global memory pulled 224 KB
+    // per block through one CU: the bytes-per-CU bound of profiles/r03_qchain.md).  Piece (nf, s, lane): channel row 16 nf + (lane & 15),
+    // taps 4 (s & 1) + (lane >> 4) of kernel row s >> 1; the 8th tap of a row is zero ----
+    st_u4 wpre[7];
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const bf16_t* wr = p.W + (long)((2 * wn + n) * 16 + c) * p.Kpad;
-#pragma unroll
-        for (int s = 0; s < 14; ++s) {
-            const int kw = (s & 1) * 4 + g;
-            const st_u4 v = *reinterpret_cast<const st_u4*>(wr + ((s >> 1) * 7 + min(kw, 6)) * 8);
-            const st_u4 z = {0u, 0u, 0u, 0u};
-            wa[n][s] = kw < 7 ? v : z;
-        }
+    for (int i = 0; i < 7; ++i) {
+        const int pc = tid + ST_NT * i;                  // 0 .. 3583 = 4 x 14 x 64
+        const int l_ = pc & 63, fs = pc >> 6, nf = fs / 14, s_ = fs - nf * 14;
+        const int kw = (s_ & 1) * 4 + (l_ >> 4);
+        const st_u4 v = *reinterpret_cast<const st_u4*>(p.W + (long)(nf * 16 + (l_ & 15)) * p.Kpad + ((s_ >> 1) * 7 + min(kw, 6)) * 8);
+        const st_u4 z = {0u, 0u, 0u, 0u};
+        wpre[i] = kw < 7 ? v : z;
     }
-    // ---- the input patch: 4 pixels per thread, all their loads issued before the first is used ----
+    // ---- the input patch: 6 pixels per thread, all their loads issued before the first is used ----
     const long plane = (long)p.h0 * p.w0, HWp = (long)p.H * p.W_;
-    constexpr int NPIX = (ST_IH * ST_IW + ST_NT - 1) / ST_NT;   // 4
+    constexpr int NPIX = (ST_IH * ST_IW + ST_NT - 1) / ST_NT;   // 6
     float pr_[NPIX], pg_[NPIX], pb_[NPIX], pm_[NPIX], po_[NPIX];
     bool pin_[NPIX], pim_[NPIX];
 #pragma unroll
@@ -102,9 +108,16 @@ __global__ __launch_bounds__(ST_NT) void stem_kernel(StemParams p) {
         const st_u4 z = {0u, 0u, 0u, 0u};
         if (e < ST_IH * ST_IW) patch[e] = pin_[t] ? v : z;
     }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) wl[tid + ST_NT * i] = wpre[i];
     __syncthreads();
-    // ---- implicit GEMM: 14 K steps; this wave: M fragments 5 wm .. (5 or 4 of them), N fragments 2 wn, 2 wn + 1 ----
-    constexpr int NB = 5;
+    st_u4 wa[2][14];                                     // this wave's 2 x 14 weight fragments, held in registers for the whole block
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int s = 0; s < 14; ++s) wa[n][s] = wl[((2 * wn + n) * 14 + s) * 64 + lane];
+    // ---- implicit GEMM: 14 K steps; this wave: M fragments NB wm .. (9 or 8 of them), N fragments 2 wn, 2 wn + 1 ----
+    constexpr int NB = (ST_MF + 3) / 4;
     const int nb = min(NB, ST_MF - wm * NB);
     int boff[NB];                                        // patch index of (conv pixel, tap g) at kernel row 0, first half
 #pragma unroll
@@ -151,7 +164,8 @@ __global__ __launch_bounds__(ST_NT) void stem_kernel(StemParams p) {
     __syncthreads();
     // ---- 3 x 3 / stride 2 max pool (+ ReLU): thread = (pooled pixel, 8 channels) ----
     {
-        const int pp = tid >> 3, q = tid & 7, ppy = pp >> 4, ppx = pp & 15;
+        for (int task = tid; task < ST_PH * ST_PW * 8; task += ST_NT) {
+        const int pp = task >> 3, q = task & 7, ppy = pp >> 4, ppx = pp & 15;
         const int py = py0 + ppy, px = px0 + ppx;
         float m[8];
 #pragma unroll
@@ -174,6 +188,7 @@ __global__ __launch_bounds__(ST_NT) void stem_kernel(StemParams p) {
         if (py < PH && px < PW)
             *reinterpret_cast<uint4*>(p.y + (((long)k * PH + py) * PW + px) * 64 + q * 8) =
                 make_uint4(pack_bf2(m[0], m[1]), pack_bf2(m[2], m[3]), pack_bf2(m[4], m[5]), pack_bf2(m[6], m[7]));
+        }
     }
 }
 
@@ -192,6 +207,15 @@ int launch_stem(const cutie_op* op, hipStream_t s) {
     const int PH = i[2] >> 2, PW = i[3] >> 2;
     p.gx = (PW + ST_PW - 1) / ST_PW;
     p.nb = p.gx * ((PH + ST_PH - 1) / ST_PH);
-    hipLaunchKernelGGL(stem_kernel, dim3(((p.nb + 7) / 8) * 8, 1, p.K), dim3(ST_NT), 0, s, p);
+    constexpr size_t lds = ST_MF * 16 * ST_CLD * 2 + 4 * 14 * 64 * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            cutie_set_error("stem: cannot raise the dynamic LDS limit to %d bytes", (int)lds);
+            return -2;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(stem_kernel, dim3(((p.nb + 7) / 8) * 8, 1, p.K), dim3(ST_NT), lds, s, p);
     return (int)hipGetLastError();
 }
