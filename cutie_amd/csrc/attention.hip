@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void attn_p2q_kernel(const bf16_t* __restrict_
 
 // QUERY_INIT with its two linears (flags&1): per object, x = sums / (area + 1e-4) for the 16 summaries (object_transformer.py:125-132)
 // staged in LDS, then query = x Wi^T + bi + query_init and query_emb = x We^T + be + query_emb (:137-138) -- three launches in one.
-// grid (K, 4), block 256: a block computes 8 of the 32 column tiles (2 x 16: query_init | query_emb), 2 per wave over all of K = 256;
+// grid (K, 8), block 256: a block computes 4 of the 32 column tiles (2 x 16: query_init | query_emb), 1 per wave over all of K = 256;
 // the rows are staged by every block (16 x 257 floats).  (One block per object with 4 tiles per wave took 16 us: 3 blocks, 208 VGPRs.)
 struct QInit2 { const float* om; float* y[2]; const bf16_t* W[2]; const float* b[2]; const float* res[2]; uint4* zero; int nzero; };
 __global__ __launch_bounds__(256) void query_init2_kernel(QInit2 a) {
@@ -315,12 +315,15 @@ __global__ __launch_bounds__(256) void query_init2_kernel(QInit2 a) {
     const int k = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     // side job (p9, i2): clear the fixed-point accumulators of the transformer blocks behind this launch (qchain.hip)
     for (int e = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; e < a.nzero; e += gridDim.x * gridDim.y * 256) a.zero[e] = make_uint4(0u, 0u, 0u, 0u);
-    proj_u4 wv[2][8];
+    // one 16-column tile per wave (grid (K, 8): 24 blocks at K = 3, 32 KB of weights each -- a block with two tiles per wave pulled 64 KB
+    // through its CU); bias and residual are requested with the weights, not after the product
+    const int tile = blockIdx.y * 4 + wave, which = tile >> 4, col = (tile & 15) * 16 + c;     // 0..15: query_init columns, 16..31: query_emb columns
+    proj_u4 wv[8];
+    proj16_load<8>(a.W[which], (tile & 15) * 16, 0, wv);
+    const float bv = a.b[which] ? a.b[which][col] : 0.f;
+    float rv[4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int tile = blockIdx.y * 8 + wave * 2 + t;     // 0..15: query_init columns, 16..31: query_emb columns
-        proj16_load<8>(a.W[tile >> 4], (tile & 15) * 16, 0, wv[t]);
-    }
+    for (int r = 0; r < 4; ++r) rv[r] = a.res[which] ? a.res[which][((long)k * 16 + 4 * g + r) * 256 + col] : 0.f;
     for (int r = wave; r < 16; r += 4) {
         const float* row = a.om + ((long)k * 16 + r) * 257;
         const float inv = 1.f / (row[256] + 1e-4f);
@@ -328,17 +331,9 @@ __global__ __launch_bounds__(256) void query_init2_kernel(QInit2 a) {
         for (int j = 0; j < 4; ++j) sX[r * PROJ_XLD + lane * 4 + j] = row[lane * 4 + j] * inv;
     }
     __syncthreads();
+    const f32x4 acc = proj16_mma<8>(sX, 0, wv);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int tile = blockIdx.y * 8 + wave * 2 + t, which = tile >> 4, col = (tile & 15) * 16 + c;
-        const f32x4 acc = proj16_mma<8>(sX, 0, wv[t]);
-        const float bv = a.b[which] ? a.b[which][col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long m = (long)k * 16 + 4 * g + r;
-            a.y[which][m * 256 + col] = acc[r] + bv + (a.res[which] ? a.res[which][m * 256 + col] : 0.f);
-        }
-    }
+    for (int r = 0; r < 4; ++r) a.y[which][((long)k * 16 + 4 * g + r) * 256 + col] = acc[r] + bv + rv[r];
 }
 
 int launch_attention(const cutie_op* op, hipStream_t s) {
@@ -350,7 +345,7 @@ int launch_attention(const cutie_op* op, hipStream_t s) {
             QInit2 a = {(const float*)p[0], {(float*)p[1], (float*)p[2]}, {(const bf16_t*)p[3], (const bf16_t*)p[6]}, {(const float*)p[4], (const float*)p[7]},
                         {(const float*)p[5], (const float*)p[8]}, (uint4*)p[9], p[9] ? i[2] : 0};
             if (p[9] && (i[2] < 0 || (p[9] & 15))) { cutie_set_error("query_init (fused): the range to clear must be 16-byte aligned"); return -2; }
-            hipLaunchKernelGGL(query_init2_kernel, dim3(i[0] / 16, 4), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(query_init2_kernel, dim3(i[0] / 16, 8), dim3(256), 0, s, a);
             break;
         }
         case CUTIE_OP_AUX_MASK:
