@@ -273,28 +273,34 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvParams p) {
     u32x4* wlds = reinterpret_cast<u32x4*>(wlds_raw);                   // [KH*KW][Cin/8] chunks of the single filter
     const int LP = p.Cin >> 3;                                           // lanes per pixel (power of two, <= 64)
     const int ntap = p.KH * p.KW;
-    for (int t = threadIdx.x; t < ntap * LP; t += 256) wlds[t] = *reinterpret_cast<const u32x4*>(p.w + (long)t * 8);
-    __syncthreads();
     const int ppb = 256 / LP;                                            // pixels per block
     const int sub = threadIdx.x / LP, cl = threadIdx.x % LP;
     const int m = blockIdx.x * ppb + sub;
+    const bool is33 = p.KH == 3 && p.KW == 3;
+    const bool relu_in = p.flags & CUTIE_F_RELU_IN;
+    const float bias0 = p.bias ? p.bias[0] : 0.f;                        // requested with everything else, not after the reduction
+    // 3x3: the nine taps of this pixel are requested FIRST (clamped addresses, invalid taps multiplied by zero), then the filter is staged:
+    // staging + barrier in front of them made every launch two dependent memory round trips (8.2 us per launch at 4860 pixels)
+    u32x4 xv[9];
+    float ok[9];
+    if (is33) {
+        const int mc = min(m, p.M - 1);
+        const int b = mc / p.OHW, rem = mc - b * p.OHW, oh = rem / p.OW, ow = rem - oh * p.OW;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ih = oh * p.stride - p.pad + t / 3, iw = ow * p.stride - p.pad + t % 3;
+            const bool v = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
+            xv[t] = *reinterpret_cast<const u32x4*>(p.x1 + (((long)b * p.H + ihc) * p.W + iwc) * p.ldx1 + cl * 8);
+            ok[t] = v ? 1.f : 0.f;
+        }
+    }
+    for (int t = threadIdx.x; t < ntap * LP; t += 256) wlds[t] = *reinterpret_cast<const u32x4*>(p.w + (long)t * 8);
+    __syncthreads();
     float acc = 0.f;
     if (m < p.M) {
         const int b = m / p.OHW, rem = m - b * p.OHW, oh = rem / p.OW, ow = rem - oh * p.OW;
-        const bool relu_in = p.flags & CUTIE_F_RELU_IN;
-        if (p.KH == 3 && p.KW == 3) {
-            // 3x3: the nine taps are requested together (clamped addresses, invalid taps multiplied by zero): the loop below issues them
-            // one by one behind the border tests -- nine dependent round trips per pixel (23 us on the decoder's 77760-pixel pred head)
-            u32x4 xv[9];
-            float ok[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int ih = oh * p.stride - p.pad + t / 3, iw = ow * p.stride - p.pad + t % 3;
-                const bool v = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
-                xv[t] = *reinterpret_cast<const u32x4*>(p.x1 + (((long)b * p.H + ihc) * p.W + iwc) * p.ldx1 + cl * 8);
-                ok[t] = v ? 1.f : 0.f;
-            }
+        if (is33) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 u32x4 x = xv[t];
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvParams p) {
     }
     for (int o = LP >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if (cl == 0 && m < p.M) {
-        float v = acc + (p.bias ? p.bias[0] : 0.f);
+        float v = acc + bias0;
         const int act = (p.flags >> CUTIE_ACT_SHIFT) & 7;
         if (act == CUTIE_ACT_RELU) v = fmaxf(v, 0.f);
         else if (act == CUTIE_ACT_SIGMOID) v = sigmoidf_(v);
