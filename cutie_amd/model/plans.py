@@ -132,9 +132,12 @@ class Arena:
         return self.tensor.data_ptr()
 
 
+_USE_COUNT = getattr(torch._C, '_storage_Use_Count', None)     # private torch API: without it the pool hands out fresh tensors only
+
+
 def _storage_users(t):
     """How many OTHER tensors / views share t's storage (0: nobody else holds it)."""
-    return torch._C._storage_Use_Count(t.untyped_storage()._cdata) - 2
+    return _USE_COUNT(t.untyped_storage()._cdata) - 2
 
 
 class SlotPool:
@@ -159,7 +162,7 @@ class SlotPool:
     def get(self, key, specs, dev):
         """specs: {name: (shape, dtype, zero)} -> {name: tensor}"""
         fresh = lambda: {n: (torch.zeros if z else torch.empty)(sh, dtype=dt, device=dev) for n, (sh, dt, z) in specs.items()}
-        if self.SLOTS <= 0:
+        if self.SLOTS <= 0 or _USE_COUNT is None:
             return fresh()
         slots = self.groups.setdefault(key, {})
         i = (self.frame + self.offset) % self.SLOTS

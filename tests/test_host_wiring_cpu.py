@@ -388,3 +388,30 @@ def test_frame_context_is_per_thread_and_capped():
     assert fc.recall('kind', a) is None                               # small LRU: old entries age out
     fc.forget('big', keep[-1])
     assert fc.recall('big', keep[-1]) is None
+
+
+def test_slot_pool_never_recycles_what_is_still_referenced():
+    """plans.SlotPool: frame f is served from slot f % SLOTS; a slot whose tensors (or views of them) are still referenced is not handed
+    out again -- the call gets fresh tensors instead; the look-ahead offset addresses the next frame's slot."""
+    from cutie_amd.model import plans as PL
+    pool = PL.SlotPool()
+    spec = {'a': ((4, 8), torch.float32, False), 'z': ((16,), torch.float32, True)}
+    first = pool.get('g', spec, 'cpu')
+    first['z'].fill_(3.0)
+    base = first['a'].data_ptr()
+    keep = first['a'][1:]                                   # a view keeps the slot busy
+    del first
+    again = pool.get('g', spec, 'cpu')                      # same frame, slot busy -> fresh tensors, zero where asked
+    assert again['a'].data_ptr() != base and float(again['z'].abs().sum()) == 0.0
+    del keep, again
+    assert pool.get('g', spec, 'cpu')['a'].data_ptr() == base            # released: the slot comes back (contents are the caller's business)
+    ptrs = []
+    for f in range(2 * PL.SlotPool.SLOTS):
+        pool.tick()
+        ptrs.append(pool.get('g', spec, 'cpu')['a'].data_ptr())
+    assert len(set(ptrs)) == PL.SlotPool.SLOTS and ptrs[:PL.SlotPool.SLOTS] == ptrs[PL.SlotPool.SLOTS:]
+    pool.offset = 1
+    ahead = pool.get('g', spec, 'cpu')['a'].data_ptr()
+    pool.offset = 0
+    pool.tick()
+    assert pool.get('g', spec, 'cpu')['a'].data_ptr() == ahead
