@@ -12,6 +12,10 @@ struct ConvParams {
     // independent, so the GAP that ECA consumes stays bit-reproducible) accumulated into gap[B][Cout]; zero[0..nzero) is cleared by
     // block 0 (the buffer the NEXT conv of the block accumulates into)
     long long* gap; unsigned long long* zero; int nzero;
+    // conv_pc only: bytes [pf, pf + pf_bytes) = the weights of the NEXT conv of the plan, touched by the producer waves when their last
+    // DMA piece is out (every XCD covers the whole range: inside a frame every launch starts with its weights cold, r03_conv_ablation.md)
+    const unsigned char* pf; int pf_bytes;
+    const unsigned char* pf2; int pf2_bytes;             // a second range (the conv after next, when the next one has no producer waves)
 };
 #define GAP_FIXED_SCALE 16777216.f
 

@@ -384,6 +384,8 @@ int launch_conv(const cutie_op* op, hipStream_t s) {
     p.splitk = i[19] > 1 ? i[19] : 1; p.part = (float*)op->p[6];
     p.ldp = (p.Cout + 7) & ~7;
     p.gap = (long long*)op->p[7]; p.zero = (unsigned long long*)op->p[8]; p.nzero = i[21];
+    p.pf = (const unsigned char*)op->p[9]; p.pf_bytes = op->p[9] ? i[22] : 0;
+    p.pf2 = (const unsigned char*)op->p[10]; p.pf2_bytes = op->p[10] ? i[23] : 0;
     if ((p.gap || p.zero) && (i[17] < 60 || i[17] >= 200 || ((p.flags & CUTIE_F_OUT_F32) && p.gap) || (p.Cout & 7) || (p.ldy & 7) || (p.res && (p.ldr & 7)))) {
         cutie_set_error("conv: GAP accumulation / zero job need an LDS-DMA tile (60..199), bf16 output, Cout %% 8 == 0 (tile %d)", i[17]);
         return -2;

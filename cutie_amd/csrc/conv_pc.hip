@@ -554,6 +554,23 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
         }
         TLE(6)
         TL_DUMP(logical, nb, NC + NPW)
+        if (p.pf_bytes > 0) {
+            // side job: touch the next conv's weights.  Hardware block id % 8 = XCD: the blocks of one XCD split the range among them, so
+            // every L2 ends up with all of it (what the next launch's first K steps would otherwise wait for); results are discarded
+            const int id = blockIdx.y * gridDim.x + blockIdx.x;
+            const int nbx = (nb + 7) >> 3, kq = id >> 3;
+            u32x4 t = {0u, 0u, 0u, 0u};                      // one destination for all of them, alive until the wait (the data lands late)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const unsigned char* base = r ? p.pf2 : p.pf;
+                const int bytes = r ? p.pf2_bytes : p.pf_bytes;
+                const int chunk = (((bytes + nbx - 1) / nbx) + 1023) & ~1023;
+                const int b0 = kq * chunk, b1 = min(b0 + chunk, bytes & ~15);
+                for (int o = b0 + (pw * 64 + lane) * 16; o < b1; o += NPW * 1024)
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(t) : "v"(base + o) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(t) :: "memory");
+        }
         return;
     }
 

@@ -104,6 +104,9 @@ def conv_side_jobs_ok(*, cin, cout, kh, c2=0):
 
 
 NUM_CU = 256
+# bytes of the next conv's weights a conv_pc launch touches on its way out (0: off); CUTIE_AMD_WPF overrides
+WEIGHT_PREFETCH = int(os.environ.get('CUTIE_AMD_WPF', str(8 << 20)))
+WEIGHT_PREFETCH_2 = int(os.environ.get('CUTIE_AMD_WPF2', '1'))
 
 
 COUT1_TILE = 19          # dedicated per-pixel dot-product kernel (conv_cout1_kernel)
@@ -225,6 +228,7 @@ class OpList:
         self.scratch_owner = scratch_owner   # see splitk_scratch
         self.recs = []          # (kind, flags, ints, floats, ptrs)
         self.keep = []          # tensors kept alive
+        self.wbytes = {}        # conv op index -> bytes of its packed weights
         self.dyn = {}           # name -> [(op index, slot, offset)]
         self.arr = None
 
@@ -246,6 +250,21 @@ class OpList:
 
     def finalize(self):
         arr = np.zeros(len(self.recs), dtype=OP_DTYPE)
+        if WEIGHT_PREFETCH:
+            # a producer / consumer conv touches the weights of the conv behind it in the list when its own DMA is out (conv_pc.hip)
+            nxt, nxt2 = None, None                           # (weights, bytes) of the next conv / of the one after it
+            for n in range(len(self.recs) - 1, -1, -1):
+                kind, _, ints, _, ptrs = self.recs[n]
+                if kind != CONV:
+                    continue
+                pc = ints[17] in PC_TILES
+                if nxt is not None and pc and len(ptrs) == 9 and len(ints) == 22:
+                    ptrs.append(nxt[0])
+                    ints.append(min(nxt[1], WEIGHT_PREFETCH))
+                    if nxt2 is not None and not nxt[2] and WEIGHT_PREFETCH_2:     # the next conv cannot do it for its successor
+                        ptrs.append(nxt2[0])
+                        ints.append(min(nxt2[1], WEIGHT_PREFETCH))
+                nxt, nxt2 = (ptrs[2], self.wbytes[n], pc), nxt
         for n, (kind, flags, ints, floats, ptrs) in enumerate(self.recs):
             arr['kind'][n] = kind
             arr['flags'][n] = flags
@@ -291,6 +310,7 @@ class OpList:
         if side:
             assert (tile in DMA_TILES or tile in PC_TILES) and not out_f32 and w.cout % 8 == 0 and ldy % 8 == 0, 'GAP accumulation needs an LDS-DMA conv (see conv_side_jobs_ok)'
         part = splitk_scratch(w.weight.device, self.scratch_owner)
+        self.wbytes[len(self.recs)] = w.weight.numel() * w.weight.element_size()
         return self.add(CONV, flags,
                         [B, H, W, C1, C2, ldx1, ldx2, OH, OW, w.cout, ldy, w.kh, w.kw, stride, pad, ldr, w.kpad, tile, w.cin_real,
                          splitk, part.numel() // 1024, 0 if zero is None else zero.numel()],

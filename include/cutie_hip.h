@@ -56,12 +56,16 @@ enum {
      * p2=w bf16 [CoutPad][Kpad] (k = (kh*KW+kw)*Cin + c, zero padded)  p3=bias f32[Cout] (may be 0)
      * p4=res bf16 [B|1,OH,OW,ldr] (may be 0)  p5=y bf16|f32 [B,OH,OW,ldy]
      * i: 0 B 1 H 2 W 3 C1 4 C2 5 ldx1 6 ldx2 7 OH 8 OW 9 Cout 10 ldy 11 KH 12 KW 13 stride 14 pad
-     *    15 ldr 16 Kpad 17 tile id (table in conv_igemm.hip launch_conv / cutie_amd/ops.py TILES; 19 = Cout==1 kernel;
-     *       50..56 = experimental buffer-load kernel, conv_bufload.hip: Cin % BK == 0, no split-K, opt-in on the host side)
+     *    15 ldr 16 Kpad 17 tile id (table in conv_igemm.hip launch_conv / cutie_amd/ops.py TILES; 19 = Cout==1 kernel)
      *    18 real (un-padded) input channels: ignored by the kernel, used for flop accounting
      *    19 split-K factor (<=1: none; must divide Kpad/BK of the chosen tile).  grid.z slices the K tiles, every slice
      *       parks its fp32 partial tile in p6 and a second launch sums the slices in slice order (deterministic) and
-     *       runs the epilogue.  p6 = f32 scratch, capacity i20*1024 floats >= splitk*M*roundup(Cout,8). */
+     *       runs the epilogue.  p6 = f32 scratch, capacity i20*1024 floats >= splitk*M*roundup(Cout,8).
+     *    side jobs (LDS-DMA tiles only): p7 = int64 [B,Cout] GAP accumulator the stored output is added to (x 2^24);
+     *       p8 = int64 buffer of i21 words cleared by this launch.
+     *    p9 / i22, p10 / i23 (producer / consumer tiles 100.., else ignored; 0 = none): device ranges [p, p + bytes) that the
+     *       producer waves read and discard once their last DMA piece is out -- the packed weights of the following conv(s)
+     *       of the list, so that they are in every XCD's L2 when that launch starts.  Never changes a result. */
     CUTIE_OP_CONV = 1,
     /* MAXPOOL 3x3 s2 p1 (+relu if flags&1): resnet.py:131-134, big_modules.py:47-48,158-160
      * p0=x bf16 [B,H,W,C] p1=y bf16 [B,OH,OW,C]   i: 0 B 1 H 2 W 3 C 4 OH 5 OW */

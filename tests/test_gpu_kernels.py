@@ -431,6 +431,40 @@ def test_conv_gap_accumulation(tile, geo):
     assert float((got - exact.cpu()).abs().max()) < 1e-3 * max(1.0, float(exact.abs().max())), 'sums of the stored tensor'
 
 
+@pytest.mark.parametrize('tile', [100, 103, 105, 110, 120, 123, 131])
+@pytest.mark.parametrize('C3', [8, 40, 256])
+def test_conv_next_weights_touch_changes_nothing(tile, C3, monkeypatch):
+    """A producer / consumer conv reads (and discards) the packed weights of the next conv(s) of the list on its way out (p9 / i22,
+    p10 / i23): the outputs are bit-identical without, with whole tensors, and with ranges cut at 1000 bytes."""
+    B, H, W, C = 2, 30, 54, 256
+
+    def run(pf):
+        monkeypatch.setattr(O, 'WEIGHT_PREFETCH', pf)
+        g = _gen(77)
+        w1 = pack_conv(torch.randn(C, C, 3, 3, generator=g) / math.sqrt(C * 9), torch.randn(C, generator=g) * 0.1, 'cuda', segs=[(C, C)])
+        w2 = pack_conv(torch.randn(C, C, 1, 1, generator=g) / math.sqrt(C), None, 'cuda', segs=[(C, C)])
+        w3 = pack_conv(torch.randn(C3, C, 3, 3, generator=g) / math.sqrt(C * 9), torch.randn(C3, generator=g) * 0.1, 'cuda', segs=[(C, C)])
+        x = rnd(g, (B, H, W, C), dev='cuda')
+        t1, t2 = (torch.zeros((B, H, W, C), dtype=BF16, device='cuda') for _ in range(2))
+        t3 = torch.zeros((B, H, W, max(C3, 8)), dtype=BF16, device='cuda')
+        ol = O.OpList()
+        kw = dict(B=B, H=H, W=W, C1=C, ldx1=C, OH=H, OW=W)
+        ol.conv(x, w1, t1, ldy=C, pad=1, tile=tile, **kw)
+        ol.conv(t1, w2, t2, ldy=C, pad=0, tile=61, **kw)                     # no producer waves: its successor's weights ride on conv 1
+        ol.conv(t2, w3, t3, ldy=max(C3, 8), pad=1, **kw)
+        arr = ol.finalize()
+        assert bool(arr['p'][0, 9]) == bool(pf) and bool(arr['p'][0, 10]) == bool(pf)
+        ex = _lib.HipExecutor()
+        for _ in range(3):
+            ex.run(arr)
+        torch.cuda.synchronize()
+        return [t.cpu().clone() for t in (t1, t2, t3)]
+    off, on, small = run(0), run(8 << 20), run(1000)
+    for a, b, c in zip(off, on, small):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert float(off[2].float().abs().max()) > 0
+
+
 def test_gru():
     def build(dev, g):
         n, C = 500, 256

@@ -415,3 +415,40 @@ def test_slot_pool_never_recycles_what_is_still_referenced():
     pool.offset = 0
     pool.tick()
     assert pool.get('g', spec, 'cpu')['a'].data_ptr() == ahead
+
+
+def test_next_weights_ranges_are_wired_to_producer_consumer_convs(monkeypatch):
+    """OpList.finalize hands every conv on a producer / consumer tile the packed weights of the next conv of the list (p9 / i22) and,
+    when that one has no producer waves of its own, those of the conv after it (p10 / i23); nothing else changes, twice is once."""
+    from cutie_amd import ops as O
+    from cutie_amd.model.weights import pack_conv
+    g = torch.Generator().manual_seed(0)
+    C = 64
+    ws = [pack_conv(torch.randn(C, C, 3, 3, generator=g), torch.randn(C, generator=g), 'cpu', segs=[(C, C)]) for _ in range(4)]
+    x = [torch.zeros((1, 16, 16, C), dtype=torch.bfloat16) for _ in range(5)]
+    kw = dict(B=1, H=16, W=16, C1=C, ldx1=C, OH=16, OW=16, ldy=C, pad=1)
+
+    def build():
+        ol = O.OpList()
+        for n, tile in enumerate((100, 61, 100, 100)):           # 61: an LDS-DMA tile without producer waves
+            ol.conv(x[n], ws[n], x[n + 1], tile=tile, **kw)
+        return ol
+    monkeypatch.setattr(O, 'WEIGHT_PREFETCH', 1 << 20)
+    ol = build()
+    a = ol.finalize().copy()
+    b = ol.finalize()
+    assert a.tobytes() == b.tobytes()
+    nbytes = [w.weight.numel() * 2 for w in ws]
+    wp = [w.weight.data_ptr() for w in ws]
+    assert (a['p'][0, 9], a['i'][0, 22], a['p'][0, 10], a['i'][0, 23]) == (wp[1], nbytes[1], wp[2], nbytes[2])
+    assert (a['p'][1, 9], a['p'][1, 10]) == (0, 0)
+    assert (a['p'][2, 9], a['i'][2, 22], a['p'][2, 10]) == (wp[3], nbytes[3], 0)
+    assert (a['p'][3, 9], a['p'][3, 10]) == (0, 0)
+    monkeypatch.setattr(O, 'WEIGHT_PREFETCH', 4096)
+    assert build().finalize()['i'][0, 22] == 4096
+    monkeypatch.setattr(O, 'WEIGHT_PREFETCH', 0)
+    c = build().finalize()
+    assert not c['p'][:, 9:].any() and not c['i'][:, 22:].any()
+    c['p'][:, 9:11] = a['p'][:, 9:11]
+    c['i'][:, 22:24] = a['i'][:, 22:24]
+    assert a.tobytes() == c.tobytes()
