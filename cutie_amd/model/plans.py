@@ -174,11 +174,22 @@ class SlotPool:
         return fresh()
 
 
+def weights_go_cold(px16, K=None):
+    """Does it pay that a conv touches the weights of the next one on its way out (ops.OpList.finalize; conv_pc.hip)?  A frame of px16
+    stride-16 pixels and K objects moves ~0.18 MB x px16 x (1 + K) through HBM (1.2 GB at 480p / 3 objects against 256 MB of Infinity
+    Cache).  Small frames: the weights stay warm between two uses and the touch only lengthens every launch.  Large frames: they are
+    cold, but a launch runs for 50-300 us and its first K steps are noise against the tail the touch adds.  In between the launches are
+    short AND cold.  Measured in one box each (tools/r3_call44.sh, 47, 48, 49; frames/s without the look-ahead hint, touch on / off):
+    240p x 1 object 1270 / 1291, 240p x 3 1185 / 1197, 360p x 2 1025 / 1034, 480p x 1 945 / 943, 480p x 3 771 / 754,
+    1080p x 5 191.5 / 193.1.  Plans that do not know K (the image encoder) decide on the pixels alone."""
+    return 1400 <= px16 < 4500 if K is None else 4800 <= px16 * (1 + K) < 18000
+
+
 class Plan:
-    def __init__(self, eng):
+    def __init__(self, eng, touch=True):
         self.eng = eng
         self.dev = eng.device
-        self.ol = O.OpList(scratch_owner=eng)
+        self.ol = O.OpList(scratch_owner=eng, touch_next_weights=touch)
         self.bufs = {}
         self.meta = {}
         self.tuned = False
@@ -409,7 +420,7 @@ def build_encode(eng, h0, w0, H, W, pad_left, pad_top):
     """CUTIE.encode_image + transform_key (cutie.py:61-64,92-98; big_modules.py:45-54,81-87) + query-side
     similarity operands.  dyn in: image f32 [3,h0,w0].  dyn out: f16,f8,f4,pix_feat (bf16 NHWC), key,shr,sel
     (f32 [hw,*]), Bhi,Blo (bf16 [HWp,128]), cq (f32 [HWp])."""
-    P = Plan(eng)
+    P = Plan(eng, touch=weights_go_cold((H // 16) * (W // 16)))
     m = eng.m
     if stem_ok(eng, 'pixel_encoder.conv1'):                 # IMG_PREP + 7x7 conv + max pool in one launch (csrc/stem.hip)
         pool = P.buf('pool', (1, H // 4, W // 4, 64))
@@ -465,7 +476,7 @@ def build_pixel_fusion(eng, K, h, w, pre=False):
     dyn in: pix_feat, pixel (readout) bf16 [K,h,w,CV], sensory_bf16 [K,h,w,CS], last_mask f32 [K,16h,16w];
     pre: fuse_xt bf16 [1,h,w,CE] = x_transform(pix_feat) from the encoder plan instead of pix_feat.
     dyn out: fused bf16 [K,h,w,CE]."""
-    P = Plan(eng)
+    P = Plan(eng, touch=weights_go_cold(h * w, K))
     m = eng.m
     pair = P.buf('pair', (K, h, w, 64), persistent=True)           # (mask, others) in channels 0, 1 of a ZEROED 64-channel tensor: a whole K tile
     m16 = P.buf('m16', (K, h, w), F32)
@@ -485,7 +496,7 @@ def build_readout_query(eng, K, h, w, last_aux=True):
     Aux logits of every block are kept in bufs['aux_logits'] (f32 [blocks+1,K,hw]) for tests.  last_aux=False skips the mask_pred
     head after the LAST block: its logits mask no attention any more (the reference computes them anyway, object_transformer.py:164,
     and only save_aux / training read them)."""
-    P = Plan(eng)
+    P = Plan(eng, touch=weights_go_cold(h * w, K))
     m, ol, W = eng.m, P.ol, eng.w
     ot = m['object_transformer']
     C, Q, heads, nb = m['embed_dim'], ot['num_queries'], ot['num_heads'], ot['num_blocks']
@@ -628,7 +639,7 @@ def build_segment(eng, K, h, w, update_sensory, pre=False):
     dyn in: f8, f4 (bf16), p16 (memory readout) bf16 [K,h,w,C], sensory_f32 / sensory_bf16 [K,h,w,CS] (in-place).
     pre: f8p, f4p (decoder_feat_proc of f8 / f4, from the encoder plan) instead of f8, f4.
     dyn out: prob f32 [K+1,16h,16w] (+ logits_up if bound)."""
-    P = Plan(eng)
+    P = Plan(eng, touch=weights_go_cold(h * w, K))
     m, ol = eng.m, P.ol
     up = m['mask_decoder']['up_dims']
     ms = m['pixel_encoder']['ms_dims']
@@ -679,7 +690,7 @@ def build_encode_mask(eng, K, h0, w0, H, W, pad_left, pad_top, deep_update=True)
     big_modules.py:122-182; object_summarizer.py:55-89).
     dyn in: image f32 [3,h0,w0], masks f32 [K,H,W], pix_feat, sensory_f32/sensory_bf16 (in-place deep update).
     dyn out: value bf16 [K,h,w,CV], summ f32 [K,Q,C+1]."""
-    P = Plan(eng)
+    P = Plan(eng, touch=weights_go_cold((H // 16) * (W // 16), K))
     m, ol = eng.m, P.ol
     h, w = H // 16, W // 16
     CV, CS, CE, Q = m['value_dim'], m['sensory_dim'], m['embed_dim'], m['object_summarizer']['num_summaries']

@@ -107,6 +107,7 @@ NUM_CU = 256
 # bytes of the next conv's weights a conv_pc launch touches on its way out (0: off); CUTIE_AMD_WPF overrides
 WEIGHT_PREFETCH = int(os.environ.get('CUTIE_AMD_WPF', str(8 << 20)))
 WEIGHT_PREFETCH_2 = int(os.environ.get('CUTIE_AMD_WPF2', '1'))
+WEIGHT_PREFETCH_BLOCK = int(os.environ.get('CUTIE_AMD_WPF_BLOCK', str(48 << 10)))      # bytes per block (see OpList.finalize)
 
 
 COUT1_TILE = 19          # dedicated per-pixel dot-product kernel (conv_cout1_kernel)
@@ -224,8 +225,9 @@ def _ptr(t):
 
 
 class OpList:
-    def __init__(self, scratch_owner=None):
+    def __init__(self, scratch_owner=None, touch_next_weights=True):
         self.scratch_owner = scratch_owner   # see splitk_scratch
+        self.touch_next_weights = touch_next_weights   # see finalize (plans switch it off where weights stay warm between two uses)
         self.recs = []          # (kind, flags, ints, floats, ptrs)
         self.keep = []          # tensors kept alive
         self.wbytes = {}        # conv op index -> bytes of its packed weights
@@ -250,7 +252,7 @@ class OpList:
 
     def finalize(self):
         arr = np.zeros(len(self.recs), dtype=OP_DTYPE)
-        if WEIGHT_PREFETCH:
+        if WEIGHT_PREFETCH and self.touch_next_weights:
             # a producer / consumer conv touches the weights of the conv behind it in the list when its own DMA is out (conv_pc.hip)
             nxt, nxt2 = None, None                           # (weights, bytes) of the next conv / of the one after it
             for n in range(len(self.recs) - 1, -1, -1):
@@ -259,11 +261,16 @@ class OpList:
                     continue
                 pc = ints[17] in PC_TILES
                 if nxt is not None and pc and len(ptrs) == 9 and len(ints) == 22:
+                    # the blocks of one XCD share the range: a block that pulls much more than ~48 KB through its CU outlasts the
+                    # consumers' epilogue (bytes per CU), so small grids touch only the head of large weights
+                    budget = WEIGHT_PREFETCH_BLOCK * -(-pc_blocks(ints[17], ints[0], ints[7], ints[8], ints[9]) // 8)
+                    n1 = min(nxt[1], WEIGHT_PREFETCH, budget)
                     ptrs.append(nxt[0])
-                    ints.append(min(nxt[1], WEIGHT_PREFETCH))
-                    if nxt2 is not None and not nxt[2] and WEIGHT_PREFETCH_2:     # the next conv cannot do it for its successor
+                    ints.append(n1)
+                    n2 = min(nxt2[1], WEIGHT_PREFETCH, budget - n1) if (nxt2 is not None and not nxt[2] and WEIGHT_PREFETCH_2) else 0
+                    if n2 > 0:                                   # the next conv cannot do it for its successor
                         ptrs.append(nxt2[0])
-                        ints.append(min(nxt2[1], WEIGHT_PREFETCH))
+                        ints.append(n2)
                 nxt, nxt2 = (ptrs[2], self.wbytes[n], pc), nxt
         for n, (kind, flags, ints, floats, ptrs) in enumerate(self.recs):
             arr['kind'][n] = kind

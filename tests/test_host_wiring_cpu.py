@@ -434,6 +434,7 @@ def test_next_weights_ranges_are_wired_to_producer_consumer_convs(monkeypatch):
             ol.conv(x[n], ws[n], x[n + 1], tile=tile, **kw)
         return ol
     monkeypatch.setattr(O, 'WEIGHT_PREFETCH', 1 << 20)
+    monkeypatch.setattr(O, 'WEIGHT_PREFETCH_BLOCK', 1 << 20)
     ol = build()
     a = ol.finalize().copy()
     b = ol.finalize()
@@ -446,9 +447,30 @@ def test_next_weights_ranges_are_wired_to_producer_consumer_convs(monkeypatch):
     assert (a['p'][3, 9], a['p'][3, 10]) == (0, 0)
     monkeypatch.setattr(O, 'WEIGHT_PREFETCH', 4096)
     assert build().finalize()['i'][0, 22] == 4096
+    # 4 blocks = one per XCD at most: what is left of the per-block budget after the first range goes to the second
+    monkeypatch.setattr(O, 'WEIGHT_PREFETCH', 1 << 20)
+    monkeypatch.setattr(O, 'WEIGHT_PREFETCH_BLOCK', nbytes[1] + 3072 + 100)
+    c = build().finalize()
+    assert (c['i'][0, 22], c['i'][0, 23]) == (nbytes[1], 3172) and c['i'][2, 22] == nbytes[3]
+    monkeypatch.setattr(O, 'WEIGHT_PREFETCH_BLOCK', 8192)
+    c = build().finalize()
+    assert (c['i'][0, 22], c['p'][0, 10], c['i'][0, 23]) == (8192, 0, 0)
     monkeypatch.setattr(O, 'WEIGHT_PREFETCH', 0)
     c = build().finalize()
     assert not c['p'][:, 9:].any() and not c['i'][:, 22:].any()
     c['p'][:, 9:11] = a['p'][:, 9:11]
     c['i'][:, 22:24] = a['i'][:, 22:24]
     assert a.tobytes() == c.tobytes()
+
+
+def test_touch_is_planned_only_where_weights_go_cold(product_net):
+    """plans.weights_go_cold: the size classes measured on the MI355X (its docstring), and the flag reaches the plans' op lists."""
+    from cutie_amd.model import plans
+    assert plans.weights_go_cold(30 * 54, 3) and plans.weights_go_cold(30 * 54) and plans.weights_go_cold(45 * 80, 2)
+    assert not plans.weights_go_cold(30 * 54, 1) and not plans.weights_go_cold(23 * 40, 2) and not plans.weights_go_cold(15 * 27)
+    assert not plans.weights_go_cold(68 * 120, 5) and not plans.weights_go_cold(68 * 120)
+    eng = product_net.engine()
+    small = plans.build_pixel_fusion(eng, 2, 4, 6)
+    big = plans.build_pixel_fusion(eng, 3, 30, 54)
+    assert not small.ol.touch_next_weights and big.ol.touch_next_weights
+    assert not small.ol.finalize()['p'][:, 9:11].any()
