@@ -913,6 +913,8 @@ int launch_conv_pc(const ConvParams& p, int tile, hipStream_t s) {
         case 131: return launch_pc<64, 128, 2, 2, 4, 3, PC_HT(6, 9)>(p, s);       // 5 x 6 patches: 180 blocks at K = 3, Cout = 256
         case 132: return launch_pc<64, 64, 2, 2, 4, 3, PC_HT(6, 9)>(p, s);
         case 133: return launch_pc<96, 128, 2, 2, 4, 3, PC_HT(10, 9)>(p, s);
+        // 20 x 16 patches: the 120 x 216 (stride-4, 480p) maps of 3 objects in 3 x 6 x 14 = 252 workgroups per 64 channels (one round of the 256 CUs)
+        case 134: return launch_pc<320, 64, 4, 2, 8, 3, PC_HT(20, 16)>(p, s);     // 80 x 32 per consumer wave, 8 + 8 waves, 136 KB
 #endif
         default: cutie_set_error("conv: bad pc tile id %d", tile); return -2;
     }

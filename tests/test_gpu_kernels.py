@@ -400,7 +400,7 @@ def test_gap_eca():
     check(hip, ref, 'gap/eca')
 
 
-@pytest.mark.parametrize('tile', [66, 67, 63, 61, 70, 68, 82, 85, 86, 100, 102, 103, 105, 108, 110, 120, 121, 123, 125, 129, 131])
+@pytest.mark.parametrize('tile', [66, 67, 63, 61, 70, 68, 82, 85, 86, 100, 102, 103, 105, 108, 110, 120, 121, 123, 125, 129, 131, 134])
 @pytest.mark.parametrize('geo', [(3, 30, 54), (5, 5, 7), (2, 9, 16)])
 def test_conv_gap_accumulation(tile, geo):
     """ECA's average pool riding on the convs of a CAResBlock: conv1 clears the accumulator, conv2 adds the fixed-point channel sums of
@@ -431,7 +431,7 @@ def test_conv_gap_accumulation(tile, geo):
     assert float((got - exact.cpu()).abs().max()) < 1e-3 * max(1.0, float(exact.abs().max())), 'sums of the stored tensor'
 
 
-@pytest.mark.parametrize('tile', [100, 103, 105, 110, 120, 123, 131])
+@pytest.mark.parametrize('tile', [100, 103, 105, 110, 120, 123, 131, 134])
 @pytest.mark.parametrize('C3', [8, 40, 256])
 def test_conv_next_weights_touch_changes_nothing(tile, C3, monkeypatch):
     """A producer / consumer conv reads (and discards) the packed weights of the next conv(s) of the list on its way out (p9 / i22,
