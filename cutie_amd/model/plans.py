@@ -326,6 +326,7 @@ class Plan:
             if (arr['p'][n, 7] or arr['p'][n, 8]) and best[0] not in O.DMA_TILES and best[0] not in O.PC_TILES:
                 continue                                     # GAP accumulation / zero job exist in conv_dma_kernel only
             arr['i'][n, 17], arr['i'][n, 19] = best
+        ol.wire_next_weights()                               # the touch ranges follow the tiles the table has just put in place
         self.tuned = True
         if tuned_any:
             save_tile_cache(cache)
