@@ -252,26 +252,6 @@ class OpList:
 
     def finalize(self):
         arr = np.zeros(len(self.recs), dtype=OP_DTYPE)
-        if WEIGHT_PREFETCH and self.touch_next_weights:
-            # a producer / consumer conv touches the weights of the conv behind it in the list when its own DMA is out (conv_pc.hip)
-            nxt, nxt2 = None, None                           # (weights, bytes) of the next conv / of the one after it
-            for n in range(len(self.recs) - 1, -1, -1):
-                kind, _, ints, _, ptrs = self.recs[n]
-                if kind != CONV:
-                    continue
-                pc = ints[17] in PC_TILES
-                if nxt is not None and pc and len(ptrs) == 9 and len(ints) == 22:
-                    # the blocks of one XCD share the range: a block that pulls much more than ~48 KB through its CU outlasts the
-                    # consumers' epilogue (bytes per CU), so small grids touch only the head of large weights
-                    budget = WEIGHT_PREFETCH_BLOCK * -(-pc_blocks(ints[17], ints[0], ints[7], ints[8], ints[9]) // 8)
-                    n1 = min(nxt[1], WEIGHT_PREFETCH, budget)
-                    ptrs.append(nxt[0])
-                    ints.append(n1)
-                    n2 = min(nxt2[1], WEIGHT_PREFETCH, budget - n1) if (nxt2 is not None and not nxt[2] and WEIGHT_PREFETCH_2) else 0
-                    if n2 > 0:                                   # the next conv cannot do it for its successor
-                        ptrs.append(nxt2[0])
-                        ints.append(n2)
-                nxt, nxt2 = (ptrs[2], self.wbytes[n], pc), nxt
         for n, (kind, flags, ints, floats, ptrs) in enumerate(self.recs):
             arr['kind'][n] = kind
             arr['flags'][n] = flags
@@ -279,7 +259,34 @@ class OpList:
             arr['f'][n, :len(floats)] = floats
             arr['p'][n, :len(ptrs)] = ptrs
         self.arr = arr
+        self.wire_next_weights()
         return arr
+
+    def wire_next_weights(self):
+        """CONV p9 / i22, p10 / i23 of the finalized array, from the tiles it carries NOW (plans call this again once the tile table
+        has been applied): a producer / consumer conv touches the packed weights of the conv behind it in the list when its own DMA
+        is out, and those of the conv after that one when the next conv has no producer waves (conv_pc.hip)."""
+        arr = self.arr
+        convs = [n for n in range(len(arr)) if arr['kind'][n] == CONV]
+        for n in convs:
+            arr['p'][n, 9:11] = 0
+            arr['i'][n, 22:24] = 0
+        if not (WEIGHT_PREFETCH and self.touch_next_weights):
+            return
+        nxt, nxt2 = None, None                               # (weights, bytes, has producer waves) of the next conv / of the one after it
+        for n in reversed(convs):
+            i = arr['i'][n]
+            pc = int(i[17]) in PC_TILES
+            if nxt is not None and pc:
+                # the blocks of one XCD share the range: a block that pulls much more than ~48 KB through its CU outlasts the
+                # consumers' epilogue (bytes per CU, DESIGN.md 4.2b), so small grids touch only the head of large weights
+                budget = WEIGHT_PREFETCH_BLOCK * -(-pc_blocks(int(i[17]), int(i[0]), int(i[7]), int(i[8]), int(i[9])) // 8)
+                n1 = min(nxt[1], WEIGHT_PREFETCH, budget)
+                arr['p'][n, 9], arr['i'][n, 22] = nxt[0], n1
+                n2 = min(nxt2[1], WEIGHT_PREFETCH, budget - n1) if (nxt2 is not None and not nxt[2] and WEIGHT_PREFETCH_2) else 0
+                if n2 > 0:                                   # the next conv cannot do it for its successor
+                    arr['p'][n, 10], arr['i'][n, 23] = nxt2[0], n2
+            nxt, nxt2 = (int(arr['p'][n, 2]), self.wbytes[n], pc), nxt
 
     def bind(self, **tensors):
         """Patch dynamic pointer slots.  Values: torch tensors or raw ints."""
