@@ -62,9 +62,13 @@ PC_TILES = {100: (64, 64, 64), 101: (64, 64, 64), 102: (32, 64, 64), 103: (128, 
             106: (128, 128, 64), 107: (64, 64, 64), 108: (128, 128, 64), 109: (32, 64, 64), 110: (96, 64, 64), 111: (96, 128, 64),
             120: (64, 64, 64), 121: (64, 64, 64), 122: (128, 64, 64), 123: (128, 128, 64), 124: (64, 128, 64), 125: (32, 64, 64),
             126: (128, 128, 64), 127: (64, 128, 64), 129: (96, 64, 64), 130: (32, 64, 64), 131: (64, 128, 64),
-            132: (64, 64, 64), 133: (96, 128, 64), 134: (320, 64, 64)}
+            132: (64, 64, 64), 133: (96, 128, 64), 134: (320, 64, 64),
+            # pair steps (two K tiles per barrier): UNMEASURED, branch next/pc-pairstep
+            140: (64, 64, 64), 141: (96, 64, 64), 142: (96, 64, 64), 143: (32, 64, 64), 144: (128, 64, 64),
+            145: (96, 64, 64), 146: (128, 64, 64), 147: (32, 64, 64)}
 PC_HALO = {120: (8, 8), 121: (4, 16), 122: (8, 16), 123: (8, 16), 124: (8, 8), 125: (4, 8), 126: (8, 16), 127: (4, 16),
-           129: (10, 9), 130: (5, 6), 131: (6, 9), 132: (6, 9), 133: (10, 9), 134: (20, 16)}
+           129: (10, 9), 130: (5, 6), 131: (6, 9), 132: (6, 9), 133: (10, 9), 134: (20, 16),
+           145: (10, 9), 146: (8, 16), 147: (5, 6)}
 
 ALL_TILES = {**TILES, **DMA_TILES, **PC_TILES}
 
