@@ -424,18 +424,18 @@ class MemoryManager:
             region_end = (b.perm_start + b.P) if to_perm else (b.work_start + b.Wc)
             assert slot + HW <= region_end, ('memory bank overrun', slot, HW, region_end)
             ol.key_prep(kphys, sphys, b.Ahi[slot:], b.Alo[slot:], b.scale[slot:], n=HW, query=False)
+            copies, fills = [], []                                      # every tensor of the insertion in one launch (BANK_WRITE)
             if self.use_long_term:
-                ol.copy2d(kphys, b.rawkey[slot:], rows=HW, rowbytes=4 * self.CK, src_stride=4 * self.CK, dst_stride=4 * self.CK)
-                ol.copy2d(sphys, b.rawshr[slot:], rows=1, rowbytes=4 * HW, src_stride=4 * HW, dst_stride=4 * HW)
+                copies.append((kphys, b.rawkey[slot:], 4 * self.CK * HW))
+                copies.append((sphys, b.rawshr[slot:], 4 * HW))
                 if ephys is not None:
-                    ol.copy2d(ephys, b.rawsel[slot:], rows=HW, rowbytes=4 * self.CK, src_stride=4 * self.CK, dst_stride=4 * self.CK)
-                ol.memset32(b.use[slot:], HW, 0)
-                ol.memset32(b.life[slot:], HW, LIFE_EPS_BITS)
+                    copies.append((ephys, b.rawsel[slot:], 4 * self.CK * HW))
+                fills.append((b.use[slot:], HW, 0))
+                fills.append((b.life[slot:], HW, LIFE_EPS_BITS))
             for o in b.objects:
                 if o in objects:
-                    i = objects.index(o)
-                    ol.copy2d(vphys[i], b.values[o][slot:], rows=1, rowbytes=2 * HW * self.CV, src_stride=2 * HW * self.CV,
-                              dst_stride=2 * HW * self.CV)
+                    copies.append((vphys[objects.index(o)], b.values[o][slot:], 2 * HW * self.CV))
+            ol.bank_write(copies, fills)
         if len(ol):
             ol.run()
 
