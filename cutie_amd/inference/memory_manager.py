@@ -26,6 +26,7 @@ BF16, F32 = torch.bfloat16, torch.float32
 CAND_CAP = 1024          # candidate slots per query column (typical fill ~35; see csrc/affinity.hip)
 _UNFUSED = os.environ.get('CUTIE_AMD_UNFUSED', '0') not in ('', '0')      # diagnostic A/B switch, see model/plans.py
 _VALIDATE = os.environ.get('CUTIE_AMD_VALIDATE', '0') not in ('', '0')
+BANK_WRITE = os.environ.get('CUTIE_AMD_BANK_WRITE', '1') not in ('', '0')      # the copies / fills of an insertion in one launch (A/B switch)
 # bank versions are drawn from one process-wide counter: a look-ahead read-out tagged with the version of one manager can never pass
 # the check of another (InferenceCore.clear_memory replaces the manager; per-manager counters would restart at 0 and collide)
 _VERSIONS = itertools.count(1)
@@ -435,7 +436,13 @@ class MemoryManager:
             for o in b.objects:
                 if o in objects:
                     copies.append((vphys[objects.index(o)], b.values[o][slot:], 2 * HW * self.CV))
-            ol.bank_write(copies, fills)
+            if BANK_WRITE:
+                ol.bank_write(copies, fills)
+            else:                                                       # (A/B switch: one launch per tensor, as before)
+                for src, dst, nbytes in copies:
+                    ol.copy2d(src, dst, rows=1, rowbytes=nbytes, src_stride=nbytes, dst_stride=nbytes)
+                for dst, words, pattern in fills:
+                    ol.memset32(dst, words, pattern)
         if len(ol):
             ol.run()
 
