@@ -776,6 +776,23 @@ __global__ void copy2d_kernel(const uint32_t* __restrict__ s, uint32_t* __restri
     long r = i / roww; int c = i - r * roww;
     d[r * ds + c] = s[r * ss + c];
 }
+// BANK_WRITE: blockIdx.y = segment (0..5 copies, 6..7 fills), blockIdx.x strides over its words
+struct BankWrite { const uint32_t* src[6]; uint32_t* dst[8]; int words[8]; uint32_t pattern[2]; };
+__global__ __launch_bounds__(256) void bank_write_kernel(BankWrite w) {
+    const int seg = blockIdx.y;
+    const int n = w.words[seg];
+    uint32_t* const d = w.dst[seg];
+    if (seg < 6) {
+        const uint32_t* const s = w.src[seg];
+        for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (i + r * 256 < n) d[i + r * 256] = s[i + r * 256];
+        }
+    } else {
+        const uint32_t v = w.pattern[seg - 6];
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d[i] = v;
+    }
+}
 __global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float a) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] += a * x[i];
@@ -1001,6 +1018,26 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             int roww = i[1] / 4;
             long n = (long)i[0] * roww;
             hipLaunchKernelGGL(copy2d_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const uint32_t*)p[0], (uint32_t*)p[1], (long)i[0], roww, (long)i[2] / 4, (long)i[3] / 4);
+            break;
+        }
+        case CUTIE_OP_BANK_WRITE: {
+            BankWrite w;
+            int most = 0;
+            for (int k = 0; k < 6; ++k) {
+                w.src[k] = (const uint32_t*)p[2 * k]; w.dst[k] = (uint32_t*)p[2 * k + 1]; w.words[k] = (p[2 * k] && p[2 * k + 1]) ? i[k] : 0;
+                if (w.words[k] < 0) { cutie_set_error("bank_write: negative size"); return -2; }
+                most = w.words[k] > most ? w.words[k] : most;
+            }
+            for (int k = 0; k < 2; ++k) {
+                w.dst[6 + k] = (uint32_t*)p[12 + k]; w.words[6 + k] = p[12 + k] ? i[6 + k] : 0; w.pattern[k] = (uint32_t)i[8 + k];
+                if (w.words[6 + k] < 0) { cutie_set_error("bank_write: negative size"); return -2; }
+                most = w.words[6 + k] > most ? w.words[6 + k] : most;
+            }
+            if (most > 0) {
+                int gx = (most + 1023) / 1024;
+                gx = gx > 128 ? 128 : gx;                 // 8 segments x 128 blocks: every CU gets work, a block moves >= 4 KB per pass
+                hipLaunchKernelGGL(bank_write_kernel, dim3(gx, 8), dim3(256), 0, s, w);
+            }
             break;
         }
         case CUTIE_OP_AXPY:

@@ -19,7 +19,7 @@ assert OP_DTYPE.itemsize == _lib.OP_STRUCT_SIZE
 (CONV, MAXPOOL, IMG_PREP, UPSAMPLE2X_ADD, AREA_DOWN, MASK_DOWN, GAP, ECA_APPLY, GRU, SEG_AGG, UP4_SOFTMAX,
  MASK_MERGE, AGG_SOFTMAX, LINEAR, LAYERNORM, QUERY_INIT, AUX_MASK, ATTN_Q2P, ATTN_SELF, ATTN_P2Q, SUMMARIZE,
  ADD_PE, KEY_PREP, AFF_SCORE, AFF_SELECT, AFF_READOUT, MEMSET32, COPY2D, AXPY, USAGE_TICK, RANK_SELECT,
- GATHER_ROWS, CONSOL_AFF, CONSOL_READ, CAST, PROB_TO_ID, RESIZE, FLIP_W, AREA_DOWN3, QFFN, STEM) = range(1, 42)
+ GATHER_ROWS, CONSOL_AFF, CONSOL_READ, CAST, PROB_TO_ID, RESIZE, FLIP_W, AREA_DOWN3, QFFN, STEM, BANK_WRITE) = range(1, 43)
 
 KIND_NAMES = {}
 for _n in ('CONV MAXPOOL IMG_PREP UPSAMPLE2X_ADD AREA_DOWN MASK_DOWN GAP ECA_APPLY GRU SEG_AGG UP4_SOFTMAX MASK_MERGE '
@@ -564,6 +564,23 @@ class OpList:
 
     def memset32(self, dst, n, value=0):
         return self.add(MEMSET32, 0, [n, value], [], [dst])
+
+    def bank_write(self, copies=(), fills=()):
+        """One launch for the contiguous copies [(src, dst, nbytes)] (<= 6) and 32-bit fills [(dst, words, pattern)] (<= 2) of a memory
+        insertion; more of either spill into further launches."""
+        copies, fills = list(copies), list(fills)
+        idx = None
+        while copies or fills:
+            c, copies = copies[:6], copies[6:]
+            fl, fills = fills[:2], fills[2:]
+            ints, ptrs = [0] * 10, [0] * 14
+            for s, (src, dst, nbytes) in enumerate(c):
+                assert nbytes % 4 == 0 and nbytes > 0
+                ints[s], ptrs[2 * s], ptrs[2 * s + 1] = nbytes // 4, src, dst
+            for t, (dst, words, pattern) in enumerate(fl):
+                ints[6 + t], ints[8 + t], ptrs[12 + t] = words, pattern, dst
+            idx = self.add(BANK_WRITE, 0, ints, [], ptrs)
+        return idx
 
     def copy2d(self, src, dst, *, rows, rowbytes, src_stride, dst_stride):
         assert rowbytes % 4 == 0 and src_stride % 4 == 0 and dst_stride % 4 == 0

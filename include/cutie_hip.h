@@ -274,6 +274,11 @@ enum {
      * p3=bias f32 [64] p4=y bf16 [K,H/4,W/4,64]   i: 0 h0 1 w0 2 H 3 W (multiples of 16) 4 pad_left 5 pad_top 6 K 7 Kpad
      * f: 0-2 mean 3-5 std   flags&1: ReLU (before or after the pool: the same) */
     CUTIE_OP_STEM = 41,
+    /* BANK_WRITE: the contiguous copies and fills of one memory insertion (memory_manager.py:210-296, kv_memory_store.py:55-149: the
+     * reference torch.cat's every tensor of the bank; here a frame's keys / shrinkage / selection / per-object values go to their slot)
+     * in ONE launch.  Up to 6 copies: p[2s] = src, p[2s+1] = dst, i[s] = 32-bit words (0: unused), s = 0..5; up to 2 fills:
+     * p[12+t] = dst, i[6+t] = words, i[8+t] = the 32-bit pattern, t = 0..1.  Sources and destinations must not overlap. */
+    CUTIE_OP_BANK_WRITE = 42,
     CUTIE_OP__COUNT
 };
 

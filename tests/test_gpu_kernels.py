@@ -465,6 +465,32 @@ def test_conv_next_weights_touch_changes_nothing(tile, C3, monkeypatch):
     assert float(off[2].float().abs().max()) > 0
 
 
+def test_bank_write():
+    """BANK_WRITE: six copies of very different lengths (one word ... 200k words, odd tails) and two fills in one launch; a second op
+    with fewer segments; untouched neighbours stay untouched."""
+    def build(dev, g):
+        sizes = [1, 1620, 103680, 207361, 255, 1024]
+        srcs = [torch.randint(-2 ** 31, 2 ** 31 - 1, (n,), generator=g, dtype=torch.int64).to(torch.int32).to(dev) for n in sizes]
+        dsts = [torch.full((n + 8,), 7, dtype=torch.int32, device=dev) for n in sizes]
+        f0, f1 = torch.full((1620 + 8,), 7, dtype=torch.int32, device=dev), torch.full((5 + 8,), 7, dtype=torch.int32, device=dev)
+        ol = O.OpList()
+        ol.bank_write([(srcs[k], dsts[k].view(-1)[4:], 4 * sizes[k]) for k in range(6)], [(f0.view(-1)[4:], 1620, 0), (f1.view(-1)[4:], 5, 0x33D6BF95)])
+        e0 = torch.full((40,), 7, dtype=torch.int32, device=dev)
+        ol.bank_write([(srcs[1], e0.view(-1)[4:], 4 * 30)], [])
+        e1 = torch.full((40,), 7, dtype=torch.int32, device=dev)
+        ol.bank_write([], [(e1.view(-1)[4:], 30, -1)])
+        outs = {f'd{k}': dsts[k] for k in range(6)}
+        outs.update(f0=f0, f1=f1, e0=e0, e1=e1)
+        for k in range(6):
+            outs[f's{k}'] = srcs[k]
+        return ol, outs
+    hip, ref = run_both(build, seed=5)
+    check(hip, ref, 'bank_write')
+    for k, n in enumerate([1, 1620, 103680, 207361, 255, 1024]):
+        assert torch.equal(hip[f'd{k}'][4:4 + n], hip[f's{k}']) and int((hip[f'd{k}'][:4] != 7).sum()) == 0 and int((hip[f'd{k}'][4 + n:] != 7).sum()) == 0
+    assert int((hip['f0'][4:1624] != 0).sum()) == 0 and int((hip['f1'][4:9] != 0x33D6BF95).sum()) == 0 and int((hip['f1'][9:] != 7).sum()) == 0
+
+
 def test_gru():
     def build(dev, g):
         n, C = 500, 256
