@@ -479,7 +479,7 @@ int launch_conv(const cutie_op* op, hipStream_t s) {
             return -2;
         }
         const int ppb = 256 / LP;
-        if (p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W && LP >= 8 && LP <= 32 && p.H * p.W >= 4096) {
+        if (!(p.flags & CUTIE_F_PLAIN) && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W && LP >= 8 && LP <= 32 && p.H * p.W >= 4096) {
             constexpr int R = 4;                         // large maps: one thread per (column, 8-channel lane) walks R output rows
             const int blocks = p.B * ((p.H + R - 1) / R) * ((p.W + ppb - 1) / ppb);
             hipLaunchKernelGGL(conv_cout1_rows_kernel<R>, dim3(blocks), dim3(256), 0, s, p);
