@@ -240,6 +240,19 @@ def test_conv_cout1_kernel(ci):
     check(hip, ref, f'conv cout1 [{ci}]')
 
 
+ROWS_CASES = [CONV_CASES[15], CONV_CASES[16],
+              dict(B=3, H=120, W=216, C1=128, Cout=1, k=3, relu_in=True, out_f32=True),      # the decoder's logits head at 480p, 3 objects
+              dict(B=1, H=65, W=64, C1=256, Cout=1, k=3, act=O.ACT_RELU)]                    # 32 lanes per pixel, ragged rows
+
+
+@pytest.mark.parametrize('ci', range(len(ROWS_CASES)))
+def test_conv_cout1_rows_kernel(ci):
+    """Cout = 1, 3x3 on maps of >= 4096 pixels: conv_cout1_rows_kernel (a thread walks 4 output rows of a column) against the
+    interpreter: ragged rows and columns, 8 / 16 / 32 lanes per pixel, ReLU on the input, every output form."""
+    hip, ref = run_both(_conv_build(ROWS_CASES[ci], O.COUT1_TILE), seed=700 + ci)
+    check(hip, ref, f'conv cout1 rows [{ci}]')
+
+
 def test_conv_cout1_1x1_relu_in():
     c = dict(B=3, H=30, W=54, C1=256, Cout=1, k=1, relu_in=True, out_f32=True)
     hip, ref = run_both(_conv_build(c, O.COUT1_TILE), seed=9)
