@@ -32,6 +32,7 @@ F_RELU_IN, F_OUT_F32, F_RES_BCAST = 1, 2, 4
 F_PLAIN = 8 if os.environ.get('CUTIE_AMD_COUT1_ROWS', '1') in ('', '0') else 0      # A/B switch of conv_cout1_rows_kernel
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQ1 = 0, 1, 2, 3
 ACT_SHIFT = 4
+UP4_SCALAR = 2 if os.environ.get('CUTIE_AMD_UP4_VEC', '1') in ('', '0') else 0       # UP4_SOFTMAX flags&2: one pixel per thread (A/B switch)
 
 # conv tile table (mirrors the switch in csrc/conv_igemm.hip): id -> (BM, BN, BK)
 TILES = {0: (128, 128, 32), 1: (128, 64, 32), 2: (64, 64, 32), 3: (256, 16, 32), 4: (64, 128, 32),
@@ -391,7 +392,7 @@ class OpList:
 
     def up4_softmax(self, agg, prob, logits_up, *, P, h, w, from_logits=False):
         """from_logits: `agg` holds the K = P - 1 raw logit planes and the aggregation (SEG_AGG) runs inside the launch (P <= 16)."""
-        return self.add(UP4_SOFTMAX, 1 if from_logits else 0, [P, h, w], [], [agg, prob, logits_up])
+        return self.add(UP4_SOFTMAX, (1 | UP4_SCALAR) if from_logits else 0, [P, h, w], [], [agg, prob, logits_up])
 
     def mask_merge(self, inmask, pred, src, planes, *, h0, w0, H, W, pad_left, pad_top, Knew, Kold, nfloat, float_mode):
         return self.add(MASK_MERGE, 1 if float_mode else 0, [h0, w0, H, W, pad_left, pad_top, Knew, Kold, nfloat], [],

@@ -108,7 +108,8 @@ enum {
     /* UP4_SOFTMAX: bilinear x4 (align_corners=False) of the K+1 logit planes, softmax over planes
      * cutie.py:199-200   p0=agg f32 [K+1,h,w] p1=prob f32 [K+1,4h,4w] p2=logits_up f32 (may be 0)
      * i: 0 K+1 1 h 2 w
-     * flags&1: SEG_AGG fused -- p0 = raw logits f32 [K,h,w], the aggregation runs per tap inside the launch (K+1 <= 16) */
+     * flags&1: SEG_AGG fused -- p0 = raw logits f32 [K,h,w], the aggregation runs per tap inside the launch (K+1 <= 16) 
+     * flags&2 (with flags&1): the one-pixel-per-thread form (A/B switch; default: four pixels per thread, P <= 8) */
     CUTIE_OP_UP4_SOFTMAX = 11,
     /* MASK_MERGE: build the per-object mask planes of a frame with an input mask
      * inference_core.py:259-300.  plane t: src[t] >= 0 -> (idx==src[t]) [idx mode] / fmask[src[t]] [float

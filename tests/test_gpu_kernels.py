@@ -531,9 +531,9 @@ def test_seg_epilogue():
         return ol, {'agg': agg, 'prob': prob, 'lup': lup}
     check(*run_both(build), name='seg epilogue', rtol=2e-4)
 
-    for K in (3, 9):                                   # the fused form (<= 8 and <= 16 planes): bit-identical to the two launches
+    # the fused forms (<= 8 planes: four pixels per thread; <= 16: one): bit-identical to the two launches, also on one-column and odd maps
+    for K, h, w in ((3, 12, 20), (9, 12, 20), (1, 7, 1), (7, 5, 3), (3, 30, 54), (2, 1, 9)):
         def build2(dev, g):
-            h, w = 12, 20
             lg = (torch.randn((K, h, w), generator=g) * 3).to(dev)
             agg = torch.zeros((K + 1, h, w), dtype=F32, device=dev)
             o = [torch.zeros((K + 1, 4 * h, 4 * w), dtype=F32, device=dev) for _ in range(4)]
