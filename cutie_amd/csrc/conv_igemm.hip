@@ -344,6 +344,78 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvParams p) {
     }
 }
 
+// Cout == 1, 3x3 / stride 1 / pad 1 on a large map (the decoder's logits head: 3 x 120 x 216 pixels x 128 channels): a thread column.
+// conv_cout1_kernel fetches the nine taps of every pixel separately -- 9 vector requests per output, 180 MB through the texture path for
+// 20 MB of input.  Here a thread (pixel column x, 8-channel lane) walks R output rows: each of the R + 2 input rows is requested ONCE
+// per column tap (3 (R + 2) requests for R outputs: 3.75 instead of 9 at R = 8), all of them up front, the nine filter chunks of the lane
+// live in registers (no LDS, no barrier).  Per output the products are summed in conv_cout1_kernel's order (tap by tap, padding taps
+// as a * 0, then the same lane butterfly): bit-identical results.
+template <int R>
+__global__ __launch_bounds__(256) void conv_cout1_rows_kernel(ConvParams p) {
+    const int LP = p.Cin >> 3;                                           // lanes per pixel (8, 16 or 32)
+    const int ppb = 256 / LP;                                            // pixel columns per block
+    const int sub = threadIdx.x / LP, cl = threadIdx.x % LP;
+    const int tiles_x = (p.W + ppb - 1) / ppb, tiles_y = (p.H + R - 1) / R;
+    const int b = blockIdx.x / (tiles_x * tiles_y), rem = blockIdx.x - b * tiles_x * tiles_y;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int x = tx * ppb + sub, y0 = ty * R;
+    const bool relu_in = p.flags & CUTIE_F_RELU_IN;
+    const float bias0 = p.bias ? p.bias[0] : 0.f;
+    u32x4 wv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const u32x4*>(p.w + (long)(t * LP + cl) * 8);
+    u32x4 xv[R + 2][3];
+    float okc[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) okc[kx] = ((unsigned)(x + kx - 1) < (unsigned)p.W) ? 1.f : 0.f;
+#pragma unroll
+    for (int r = 0; r < R + 2; ++r) {
+        const int iy = min(max(y0 + r - 1, 0), p.H - 1);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = min(max(x + kx - 1, 0), p.W - 1);
+            xv[r][kx] = *reinterpret_cast<const u32x4*>(p.x1 + (((long)b * p.H + iy) * p.W + ix) * p.ldx1 + cl * 8);
+        }
+    }
+    if (relu_in) {
+#pragma unroll
+        for (int r = 0; r < R + 2; ++r)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) { u32x4& v = xv[r][kx]; v.x = relu_bf2(v.x); v.y = relu_bf2(v.y); v.z = relu_bf2(v.z); v.w = relu_bf2(v.w); }
+    }
+    const int act = (p.flags >> CUTIE_ACT_SHIFT) & 7;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int oy = y0 + j;
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float okr = ((unsigned)(oy + ky - 1) < (unsigned)p.H) ? 1.f : 0.f;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const u32x4 xx = xv[j + ky][kx], ww = wv[ky * 3 + kx];
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a += __uint_as_float(xx[i] << 16) * __uint_as_float(ww[i] << 16);
+                    a += __uint_as_float(xx[i] & 0xffff0000u) * __uint_as_float(ww[i] & 0xffff0000u);
+                }
+                acc += a * (okr * okc[kx]);
+            }
+        }
+        for (int o = LP >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (cl == 0 && x < p.W && oy < p.H) {
+            float v = acc + bias0;
+            if (act == CUTIE_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (act == CUTIE_ACT_SIGMOID) v = sigmoidf_(v);
+            else if (act == CUTIE_ACT_SQ1) v = v * v + 1.f;
+            const long m = ((long)b * p.H + oy) * p.W + x;
+            if (p.flags & CUTIE_F_OUT_F32) reinterpret_cast<float*>(p.y)[m * p.ldy] = v;
+            else reinterpret_cast<bf16_t*>(p.y)[m * p.ldy] = f2bf(v);
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int BK, int S, int OCC, int WK = 1>
 static int launch_cfg(ConvParams p, hipStream_t s) {
     if (p.Kpad % BK) { cutie_set_error("conv: Kpad %d not a multiple of BK %d", p.Kpad, BK); return -2; }
@@ -407,6 +479,12 @@ int launch_conv(const cutie_op* op, hipStream_t s) {
             return -2;
         }
         const int ppb = 256 / LP;
+        if (!(p.flags & CUTIE_F_PLAIN) && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W && LP >= 8 && LP <= 32 && p.H * p.W >= 4096) {
+            constexpr int R = 4;                         // large maps: one thread per (column, 8-channel lane) walks R output rows
+            const int blocks = p.B * ((p.H + R - 1) / R) * ((p.W + ppb - 1) / ppb);
+            hipLaunchKernelGGL(conv_cout1_rows_kernel<R>, dim3(blocks), dim3(256), 0, s, p);
+            return (int)hipGetLastError();
+        }
         hipLaunchKernelGGL(conv_cout1_kernel, dim3((p.M + ppb - 1) / ppb), dim3(256), (size_t)p.KH * p.KW * LP * 16, s, p);
         return (int)hipGetLastError();
     }

@@ -286,7 +286,8 @@ __device__ __forceinline__ void pc_epilogue_fast(const ConvParams& p, const f32x
 }
 
 // HT == 0: stream mode (TAPS: more than one tap and / or padding); HT = PC_HT(TH, TW): halo mode (TAPS ignored)
-template <int BM, int BN, int WM, int WN, int NPW, int NS, int HT, bool TAPS, bool RELU, bool TWO>
+// KP: K tiles per barrier (1, or 2 = "pair steps": the ring then holds NS / 2 pairs; see the pair-step notes at the producer loops)
+template <int BM, int BN, int WM, int WN, int NPW, int NS, int HT, bool TAPS, bool RELU, bool TWO, int KP = 1>
 __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParams p) {
 #if __HIP_DEVICE_COMPILE__
     constexpr bool HALO = HT > 0;
@@ -306,6 +307,8 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
     static_assert(TM >= 1 && TN >= 1 && BM % (WM * 16) == 0 && BN % (WN * 16) == 0 && NWI >= 1 && NWI * 8 * NPW == BN && NS >= 2 && NS <= 8, "bad tile");
     static_assert(HALO || (NXI >= 1 && NXI * 8 * NPW == BM), "bad stream tile");
     static_assert(!HALO || (TH * TW <= BM && TH * TW > BM - 16 * WM && (NS == 3 || NS == 4) && NXP <= 11 - NS && NXP <= 8), "bad halo tile");
+    static_assert(KP == 1 || (KP == 2 && (NS == 4 || NS == 6)), "pair steps: a ring of 2 or 3 pairs");
+    constexpr int NP = NS / 2;                           // (pair steps) pairs the ring holds
     extern __shared__ __attribute__((aligned(16))) u32x4 pc_smem[];
     char* const lds = reinterpret_cast<char*>(pc_smem);
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
@@ -448,6 +451,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
             // (queue order: W(0 .. NS-2), X(0 .. NS-2).  NS = 3: tile 0 is complete once only the X pieces of tile 1 are outstanding, and
             // the in-order counts of the loop hold from step 0 on.  Deeper rings: the weights-first order would let X(1) hide behind the
             // younger tiles in the first steps' counts, so the whole prologue burst -- issued back to back -- is awaited here.)
+            if constexpr (KP == 1) {
             if (NS == 3 && nk >= NS - 1) { PC_WAIT_VM((NS - 2) * NXI); } else { PC_WAIT_VM(0); }
             TL(2)
             PC_BARRIER()
@@ -464,6 +468,35 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
             for (; kt < nk; ++kt) {
                 PC_WAIT_VM(0);
                 PC_LOOP_BARRIER()
+            }
+            } else {
+            // Pair steps.  The consumers multiply tiles 2u and 2u + 1 between barriers u and u + 1 (P = ceil(nk / 2) iterations, P + 1
+            // barriers).  The prologues above have issued tiles 0 .. min(nk, NS - 1) - 1 -- one tile more than the NP - 1 pairs this
+            // protocol wants in flight; that tile (NS - 2, the first of pair NP - 1) stays counted as issued: `t` below is the next tile
+            // to issue, tiles go out strictly in order, so tile t always lands in stage t % NS.  Iteration u runs after barrier u: every
+            // consumer has finished reading pair u - 1, whose two stages are the ones tiles 2 (u + NP - 1) and 2 (u + NP - 1) + 1 go
+            // to.  Only FULL pairs are issued in the counted part (an odd last tile goes out in the drain, behind vmcnt(0)), so
+            // "at most NP - 2 pairs outstanding" really means pair u + 1 has landed.
+            PC_WAIT_VM(0);
+            TL(2)
+            PC_BARRIER()
+            int t = nk < NS - 1 ? nk : NS - 1;           // next tile to issue
+            const int P = (nk + 1) >> 1;
+            int u = 0;
+            for (; 2 * (u + NP - 1) + 1 < nk; ++u) {
+                TL(3)
+                // (tile 2 (u + NP - 1) is already out in iteration 0: the prologue's extra tile)
+                for (; t <= 2 * (u + NP - 1) + 1; ++t) { PCS_LOAD_TILE(ld) ld = ld == (NS - 1) * STAGE ? 0 : ld + STAGE; }
+                TL(4)
+                PC_LOOP_WAIT_VM((NP - 2) * 2 * LPT);
+                TL(5)
+                PC_LOOP_BARRIER()
+            }
+            for (; u < P; ++u) {
+                for (; t < nk && t <= 2 * (u + NP - 1) + 1; ++t) { PCS_LOAD_TILE(ld) ld = ld == (NS - 1) * STAGE ? 0 : ld + STAGE; }
+                PC_WAIT_VM(0);
+                PC_LOOP_BARRIER()
+            }
             }
 #undef PCS_LOAD_TILE
 #undef PCS_LOAD_X
@@ -512,6 +545,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
             PC_WAIT_VM(0);                               // the patch of slice 0 is the youngest request: everything has landed
             TL(2)
             PC_BARRIER()
+            if constexpr (KP == 1) {
             // Patch pieces of the NEXT slice: one per K step during taps 0 .. NXP-1 of the current slice, issued BEFORE the step's weight
             // tile; they are older than weight tile 9 (s + 1) (issued in step 9 (s + 1) - (NS - 1): NXP <= 11 - NS), whose counted wait
             // -- before barrier 9 (s + 1) - 1 -- therefore covers them.  The wait of step t leaves the NS - 2 youngest weight tiles and the
@@ -548,6 +582,42 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
             for (; kt < nk; ++kt) {
                 PC_WAIT_VM(0);
                 PC_LOOP_BARRIER()
+            }
+            } else {
+            // Pair steps (see the stream-mode loop).  The prologue above has issued the weight tiles of steps 0 .. min(nk, NS - 1) - 1; `t`
+            // is the next one.  Patch pieces of slice s + 1 go to the buffer of slice s - 1: free once the consumers are past step
+            // 9 s - 1, i.e. from iteration ceil(9 s / 2) on, and needed at step 9 s + 9, i.e. landed by the end of iteration
+            // floor((9 s + 9) / 2) - 1 -- a window of exactly four iterations for every s, two pieces per iteration (NXP <= 8), issued
+            // BEFORE the iteration's weight tiles so that the counted wait ("at most NP - 2 weight pairs outstanding") covers them.
+            // 9 (nslice - 1) / 2 + 4 <= P - (NP - 1) for NP <= 3: the last window closes inside the counted loop.
+            static_assert(NXP <= 8 && NP <= 3, "pair steps: two patch pieces per iteration over four iterations");
+            int t = nk < NS - 1 ? nk : NS - 1;
+            const int P = (nk + 1) >> 1;
+            int ps = 0, pk = 0, pnext = 5;               // slice whose successor is being fetched, iteration inside its window, first iteration of the next window
+            int u = 0;
+            for (; 2 * (u + NP - 1) + 1 < nk; ++u) {
+                TL(3)
+                if (u == pnext) { ++ps; pk = 0; pnext += (ps & 1) ? 4 : 5; }           // ceil(9 s / 2) = 0, 5, 9, 14, 18, ...
+                if (ps + 1 < nslice && pk < 4) {
+                    switch (pk) {
+                        case 0: if constexpr (NXP > 0) PCH_XPIECE(0, ps + 1) if constexpr (NXP > 1) PCH_XPIECE(NXP > 1 ? 1 : 0, ps + 1) break;
+                        case 1: if constexpr (NXP > 2) PCH_XPIECE(NXP > 2 ? 2 : 0, ps + 1) if constexpr (NXP > 3) PCH_XPIECE(NXP > 3 ? 3 : 0, ps + 1) break;
+                        case 2: if constexpr (NXP > 4) PCH_XPIECE(NXP > 4 ? 4 : 0, ps + 1) if constexpr (NXP > 5) PCH_XPIECE(NXP > 5 ? 5 : 0, ps + 1) break;
+                        default: if constexpr (NXP > 6) PCH_XPIECE(NXP > 6 ? 6 : 0, ps + 1) if constexpr (NXP > 7) PCH_XPIECE(NXP > 7 ? 7 : 0, ps + 1) break;
+                    }
+                    ++pk;
+                }
+                for (; t <= 2 * (u + NP - 1) + 1; ++t) PCH_WTILE()
+                TL(4)
+                PC_LOOP_WAIT_VM((NP - 2) * 2 * NWI);
+                TL(5)
+                PC_LOOP_BARRIER()
+            }
+            for (; u < P; ++u) {
+                for (; t < nk && t <= 2 * (u + NP - 1) + 1; ++t) PCH_WTILE()
+                PC_WAIT_VM(0);
+                PC_LOOP_BARRIER()
+            }
             }
 #undef PCH_WTILE
 #undef PCH_XPIECE
@@ -702,8 +772,10 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
 #pragma unroll
             for (int b = 0; b < TM; ++b) PC_MFMA(w1[a], __builtin_bit_cast(bf16x8, x1[b]), acc[a][b]);
         TL(4)
-        PC_WAIT_LGKM0();
-        PC_LOOP_BARRIER()
+        if (KP == 1 || (kt & 1) || kt == nk - 1) {       // pair steps: tiles 2u and 2u + 1 between two barriers
+            PC_WAIT_LGKM0();
+            PC_LOOP_BARRIER()
+        }
         rd = rd == (NS - 1) * STAGE ? 0 : rd + STAGE;
         if (HALO) {
             ++tap;
@@ -820,13 +892,13 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int NPW, int NS, int HT, bool TAPS, bool RELU, bool TWO>
+template <int BM, int BN, int WM, int WN, int NPW, int NS, int HT, bool TAPS, bool RELU, bool TWO, int KP>
 static int launch_pc3(const ConvParams& p, hipStream_t s) {
     constexpr int lds = pc_lds_bytes<BM, BN, NS, HT>(NPW) + TL_BYTES;
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        if (lds > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_kernel<BM, BN, WM, WN, NPW, NS, HT, TAPS, RELU, TWO>),
+        if (lds > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pc_kernel<BM, BN, WM, WN, NPW, NS, HT, TAPS, RELU, TWO, KP>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             cutie_set_error("conv pc tile: cannot raise the dynamic LDS limit to %d bytes", lds);
             return -2;
@@ -840,12 +912,12 @@ static int launch_pc3(const ConvParams& p, hipStream_t s) {
     } else {
         gx = (unsigned)((p.M + BM - 1) / BM);
     }
-    hipLaunchKernelGGL((conv_pc_kernel<BM, BN, WM, WN, NPW, NS, HT, TAPS, RELU, TWO>), dim3(gx, (unsigned)((p.Cout + BN - 1) / BN)),
+    hipLaunchKernelGGL((conv_pc_kernel<BM, BN, WM, WN, NPW, NS, HT, TAPS, RELU, TWO, KP>), dim3(gx, (unsigned)((p.Cout + BN - 1) / BN)),
                        dim3((WM * WN + NPW) * 64), lds, s, p);
     return (int)hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, int NPW, int NS, int HT>
+template <int BM, int BN, int WM, int WN, int NPW, int NS, int HT, int KP = 1>
 static int launch_pc(ConvParams p, hipStream_t s) {
     const long x1_bytes = (long)p.B * p.H * p.W * p.ldx1 * 2, x2_bytes = p.C2 ? (long)p.B * p.H * p.W * p.ldx2 * 2 : 0;
     const long gy = (p.Cout + BN - 1) / BN, w_bytes = gy * BN * (long)p.Kpad * 2;
@@ -861,7 +933,7 @@ static int launch_pc(ConvParams p, hipStream_t s) {
     }
     p.Kslice = p.KH * p.KW * p.Cin;
     const bool relu = p.flags & CUTIE_F_RELU_IN, two = p.C2 != 0, taps = p.pad > 0 || p.KH * p.KW > 1;
-#define PC_GO(T_, R_, W_) return launch_pc3<BM, BN, WM, WN, NPW, NS, HT, T_, R_, W_>(p, s)
+#define PC_GO(T_, R_, W_) return launch_pc3<BM, BN, WM, WN, NPW, NS, HT, T_, R_, W_, KP>(p, s)
     if constexpr (HT > 0) {
         if (relu) { if (two) PC_GO(true, true, true); PC_GO(true, true, false); }
         if (two) PC_GO(true, false, true);
@@ -915,6 +987,15 @@ int launch_conv_pc(const ConvParams& p, int tile, hipStream_t s) {
         case 133: return launch_pc<96, 128, 2, 2, 4, 3, PC_HT(10, 9)>(p, s);
         // 20 x 16 patches: the 120 x 216 (stride-4, 480p) maps of 3 objects in 3 x 6 x 14 = 252 workgroups per 64 channels (one round of the 256 CUs)
         case 134: return launch_pc<320, 64, 4, 2, 8, 3, PC_HT(20, 16)>(p, s);     // 80 x 32 per consumer wave, 8 + 8 waves, 136 KB
+        // ---- pair steps (two K tiles per barrier; UNMEASURED, branch next/pc-pairstep) ----
+        case 140: return launch_pc<64, 64, 2, 2, 4, 4, 0, 2>(p, s);               // tile 101's ring as 2 pairs
+        case 141: return launch_pc<96, 64, 2, 2, 4, 4, 0, 2>(p, s);               // tile 110 + one stage
+        case 142: return launch_pc<96, 64, 2, 2, 4, 6, 0, 2>(p, s);               // 3 pairs, 120 KB
+        case 143: return launch_pc<32, 64, 2, 2, 4, 4, 0, 2>(p, s);               // tile 102
+        case 144: return launch_pc<128, 64, 2, 2, 4, 4, 0, 2>(p, s);              // tile 103 + one stage
+        case 145: return launch_pc<96, 64, 2, 2, 4, 4, PC_HT(10, 9), 2>(p, s);    // tile 129 + one weight stage
+        case 146: return launch_pc<128, 64, 2, 2, 4, 4, PC_HT(8, 16), 2>(p, s);   // tile 122 + one weight stage
+        case 147: return launch_pc<32, 64, 2, 2, 4, 4, PC_HT(5, 6), 2>(p, s);     // tile 130 + one weight stage
 #endif
         default: cutie_set_error("conv: bad pc tile id %d", tile); return -2;
     }

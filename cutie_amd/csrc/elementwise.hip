@@ -455,6 +455,82 @@ __global__ void up4_softmax_fused_kernel(const float* __restrict__ lg, float* __
         if (c <= K) prob[c * OHW + idx] = v[c] * inv;
 }
 
+// The same, four consecutive output pixels of a row per thread: their taps lie in two rows x three columns of the stride-4 map, so the
+// logits are fetched (and turned into clamped logits) once per source pixel instead of once per tap -- 6 K loads for 4 pixels instead
+// of 48 -- and every plane is written with 16-byte stores.  Per pixel the arithmetic and its order are those of the kernel above
+// (bit-identical results; flags&2 of the op keeps the one-pixel form for the comparison in tests).
+template <int PMAX>
+__global__ __launch_bounds__(256) void up4_softmax_fused4_kernel(const float* __restrict__ lg, float* __restrict__ prob, float* __restrict__ lup,
+                                                                 int K, int h, int w) {
+    const int OH = 4 * h, OW = 4 * w;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;             // (oy, j): output pixels (oy, 4j .. 4j + 3)
+    if (idx >= (long)OH * w) return;
+    const int j = idx % w, oy = idx / w;
+    int y0, y1; float ly;
+    up_coord(oy, h, 0.25f, y0, y1, ly);
+    const int col[3] = {max(j - 1, 0), j, min(j + 1, w - 1)};
+    const long hw = (long)h * w, OHW = (long)OH * OW;
+    // clamped logits of the six source pixels: L[r][c][plane], plane 0 = background
+    float L[2][3][PMAX];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const long o = (long)(r ? y1 : y0) * w + col[c];
+            float bg = 1.f;
+#pragma unroll
+            for (int k = 0; k < PMAX - 1; ++k)
+                if (k < K) {
+                    const float pr = 1.f / (1.f + expf(-lg[(long)k * hw + o]));
+                    bg *= (1.f - pr);
+                    L[r][c][k + 1] = clamp_logit(pr);
+                }
+            L[r][c][0] = clamp_logit(bg);
+        }
+    float out[PMAX][4];
+    float lo[PMAX][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int x0, x1; float lx;
+        up_coord(4 * j + q, w, 0.25f, x0, x1, lx);
+        const int c0 = x0 == j ? 1 : (x0 < j ? 0 : 2), c1 = x1 == j ? 1 : (x1 < j ? 0 : 2);
+        const float wt[4] = {(1.f - ly) * (1.f - lx), (1.f - ly) * lx, ly * (1.f - lx), ly * lx};
+        float v[PMAX];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p)
+            if (p <= K) {
+                // (selects instead of dynamic indexing: c0, c1 are 0..2)
+                const float a00 = c0 == 0 ? L[0][0][p] : (c0 == 1 ? L[0][1][p] : L[0][2][p]);
+                const float a01 = c1 == 0 ? L[0][0][p] : (c1 == 1 ? L[0][1][p] : L[0][2][p]);
+                const float a10 = c0 == 0 ? L[1][0][p] : (c0 == 1 ? L[1][1][p] : L[1][2][p]);
+                const float a11 = c1 == 0 ? L[1][0][p] : (c1 == 1 ? L[1][1][p] : L[1][2][p]);
+                float t = wt[0] * a00;
+                t = t + wt[1] * a01;
+                t = t + wt[2] * a10;
+                t = t + wt[3] * a11;
+                v[p] = t;
+                lo[p][q] = t;
+                mx = fmaxf(mx, t);
+            }
+        float sum = 0.f;
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p)
+            if (p <= K) { v[p] = expf(v[p] - mx); sum += v[p]; }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p)
+            if (p <= K) out[p][q] = v[p] * inv;
+    }
+    const long base = (long)oy * OW + 4 * j;
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p)
+        if (p <= K) {
+            if (lup) *reinterpret_cast<float4*>(lup + p * OHW + base) = make_float4(lo[p][0], lo[p][1], lo[p][2], lo[p][3]);
+            *reinterpret_cast<float4*>(prob + p * OHW + base) = make_float4(out[p][0], out[p][1], out[p][2], out[p][3]);
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 __global__ void mask_merge_kernel(const void* __restrict__ inmask, const float* __restrict__ pred, const int* __restrict__ src,
                                   float* __restrict__ planes, int h0, int w0, int H, int W, int pl, int pt, int Knew,
@@ -776,6 +852,23 @@ __global__ void copy2d_kernel(const uint32_t* __restrict__ s, uint32_t* __restri
     long r = i / roww; int c = i - r * roww;
     d[r * ds + c] = s[r * ss + c];
 }
+// BANK_WRITE: blockIdx.y = segment (0..5 copies, 6..7 fills), blockIdx.x strides over its words
+struct BankWrite { const uint32_t* src[6]; uint32_t* dst[8]; int words[8]; uint32_t pattern[2]; };
+__global__ __launch_bounds__(256) void bank_write_kernel(BankWrite w) {
+    const int seg = blockIdx.y;
+    const int n = w.words[seg];
+    uint32_t* const d = w.dst[seg];
+    if (seg < 6) {
+        const uint32_t* const s = w.src[seg];
+        for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (i + r * 256 < n) d[i + r * 256] = s[i + r * 256];
+        }
+    } else {
+        const uint32_t v = w.pattern[seg - 6];
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d[i] = v;
+    }
+}
 __global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float a) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] += a * x[i];
@@ -933,6 +1026,12 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             long n = (long)16 * i[1] * i[2];
             if (op->flags & 1) {                              // p0 = raw logits [K,h,w] (K = P - 1): SEG_AGG fused
                 if (i[0] > 16) { cutie_set_error("up4_softmax: the fused form holds P <= 16 planes in registers (P=%d)", i[0]); return -2; }
+                const bool vec = !(op->flags & 2) && i[0] <= 8 && (((uintptr_t)p[1] | (uintptr_t)p[2]) & 15) == 0;      // four pixels per thread, 16-byte stores
+                if (vec) {
+                    const long n4 = (long)4 * i[1] * i[2];
+                    hipLaunchKernelGGL(up4_softmax_fused4_kernel<8>, GRID1D(n4, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, i[1], i[2]);
+                    break;
+                }
                 if (i[0] <= 8) hipLaunchKernelGGL(up4_softmax_fused_kernel<8>, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, i[1], i[2]);
                 else hipLaunchKernelGGL(up4_softmax_fused_kernel<16>, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, i[1], i[2]);
                 break;
@@ -1001,6 +1100,26 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             int roww = i[1] / 4;
             long n = (long)i[0] * roww;
             hipLaunchKernelGGL(copy2d_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const uint32_t*)p[0], (uint32_t*)p[1], (long)i[0], roww, (long)i[2] / 4, (long)i[3] / 4);
+            break;
+        }
+        case CUTIE_OP_BANK_WRITE: {
+            BankWrite w;
+            int most = 0;
+            for (int k = 0; k < 6; ++k) {
+                w.src[k] = (const uint32_t*)p[2 * k]; w.dst[k] = (uint32_t*)p[2 * k + 1]; w.words[k] = (p[2 * k] && p[2 * k + 1]) ? i[k] : 0;
+                if (w.words[k] < 0) { cutie_set_error("bank_write: negative size"); return -2; }
+                most = w.words[k] > most ? w.words[k] : most;
+            }
+            for (int k = 0; k < 2; ++k) {
+                w.dst[6 + k] = (uint32_t*)p[12 + k]; w.words[6 + k] = p[12 + k] ? i[6 + k] : 0; w.pattern[k] = (uint32_t)i[8 + k];
+                if (w.words[6 + k] < 0) { cutie_set_error("bank_write: negative size"); return -2; }
+                most = w.words[6 + k] > most ? w.words[6 + k] : most;
+            }
+            if (most > 0) {
+                int gx = (most + 1023) / 1024;
+                gx = gx > 128 ? 128 : gx;                 // 8 segments x 128 blocks: every CU gets work, a block moves >= 4 KB per pass
+                hipLaunchKernelGGL(bank_write_kernel, dim3(gx, 8), dim3(256), 0, s, w);
+            }
             break;
         }
         case CUTIE_OP_AXPY:

@@ -26,6 +26,7 @@ BF16, F32 = torch.bfloat16, torch.float32
 CAND_CAP = 1024          # candidate slots per query column (typical fill ~35; see csrc/affinity.hip)
 _UNFUSED = os.environ.get('CUTIE_AMD_UNFUSED', '0') not in ('', '0')      # diagnostic A/B switch, see model/plans.py
 _VALIDATE = os.environ.get('CUTIE_AMD_VALIDATE', '0') not in ('', '0')
+BANK_WRITE = os.environ.get('CUTIE_AMD_BANK_WRITE', '1') not in ('', '0')      # the copies / fills of an insertion in one launch (A/B switch)
 # bank versions are drawn from one process-wide counter: a look-ahead read-out tagged with the version of one manager can never pass
 # the check of another (InferenceCore.clear_memory replaces the manager; per-manager counters would restart at 0 and collide)
 _VERSIONS = itertools.count(1)
@@ -424,18 +425,24 @@ class MemoryManager:
             region_end = (b.perm_start + b.P) if to_perm else (b.work_start + b.Wc)
             assert slot + HW <= region_end, ('memory bank overrun', slot, HW, region_end)
             ol.key_prep(kphys, sphys, b.Ahi[slot:], b.Alo[slot:], b.scale[slot:], n=HW, query=False)
+            copies, fills = [], []                                      # every tensor of the insertion in one launch (BANK_WRITE)
             if self.use_long_term:
-                ol.copy2d(kphys, b.rawkey[slot:], rows=HW, rowbytes=4 * self.CK, src_stride=4 * self.CK, dst_stride=4 * self.CK)
-                ol.copy2d(sphys, b.rawshr[slot:], rows=1, rowbytes=4 * HW, src_stride=4 * HW, dst_stride=4 * HW)
+                copies.append((kphys, b.rawkey[slot:], 4 * self.CK * HW))
+                copies.append((sphys, b.rawshr[slot:], 4 * HW))
                 if ephys is not None:
-                    ol.copy2d(ephys, b.rawsel[slot:], rows=HW, rowbytes=4 * self.CK, src_stride=4 * self.CK, dst_stride=4 * self.CK)
-                ol.memset32(b.use[slot:], HW, 0)
-                ol.memset32(b.life[slot:], HW, LIFE_EPS_BITS)
+                    copies.append((ephys, b.rawsel[slot:], 4 * self.CK * HW))
+                fills.append((b.use[slot:], HW, 0))
+                fills.append((b.life[slot:], HW, LIFE_EPS_BITS))
             for o in b.objects:
                 if o in objects:
-                    i = objects.index(o)
-                    ol.copy2d(vphys[i], b.values[o][slot:], rows=1, rowbytes=2 * HW * self.CV, src_stride=2 * HW * self.CV,
-                              dst_stride=2 * HW * self.CV)
+                    copies.append((vphys[objects.index(o)], b.values[o][slot:], 2 * HW * self.CV))
+            if BANK_WRITE:
+                ol.bank_write(copies, fills)
+            else:                                                       # (A/B switch: one launch per tensor, as before)
+                for src, dst, nbytes in copies:
+                    ol.copy2d(src, dst, rows=1, rowbytes=nbytes, src_stride=nbytes, dst_stride=nbytes)
+                for dst, words, pattern in fills:
+                    ol.memset32(dst, words, pattern)
         if len(ol):
             ol.run()
 

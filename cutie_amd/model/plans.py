@@ -64,6 +64,7 @@ GRAPH_MIN_OPS = 8
 QFFN_SLICE = int(os.environ.get('CUTIE_AMD_QFFN_SLICE', '64'))       # hidden columns per QFFN block (64 | 128)
 QNEXT = os.environ.get('CUTIE_AMD_QNEXT', '1') not in ('', '0')       # ATTN_P2Q also projects the next block's ATTN_Q2P queries
 AUTOTUNE = os.environ.get('CUTIE_AMD_AUTOTUNE', '0') not in ('', '0')
+TOUCH_REWIRE = os.environ.get('CUTIE_AMD_WPF_REWIRE', '1') not in ('', '0')       # A/B switch: next-weights ranges recomputed after the tile table
 PACKAGED_TILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tiles_gfx950.json')
 
 
@@ -326,6 +327,8 @@ class Plan:
             if (arr['p'][n, 7] or arr['p'][n, 8]) and best[0] not in O.DMA_TILES and best[0] not in O.PC_TILES:
                 continue                                     # GAP accumulation / zero job exist in conv_dma_kernel only
             arr['i'][n, 17], arr['i'][n, 19] = best
+        if TOUCH_REWIRE:
+            ol.wire_next_weights()                           # the touch ranges follow the tiles the table has just put in place
         self.tuned = True
         if tuned_any:
             save_tile_cache(cache)

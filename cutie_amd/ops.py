@@ -19,7 +19,7 @@ assert OP_DTYPE.itemsize == _lib.OP_STRUCT_SIZE
 (CONV, MAXPOOL, IMG_PREP, UPSAMPLE2X_ADD, AREA_DOWN, MASK_DOWN, GAP, ECA_APPLY, GRU, SEG_AGG, UP4_SOFTMAX,
  MASK_MERGE, AGG_SOFTMAX, LINEAR, LAYERNORM, QUERY_INIT, AUX_MASK, ATTN_Q2P, ATTN_SELF, ATTN_P2Q, SUMMARIZE,
  ADD_PE, KEY_PREP, AFF_SCORE, AFF_SELECT, AFF_READOUT, MEMSET32, COPY2D, AXPY, USAGE_TICK, RANK_SELECT,
- GATHER_ROWS, CONSOL_AFF, CONSOL_READ, CAST, PROB_TO_ID, RESIZE, FLIP_W, AREA_DOWN3, QFFN, STEM) = range(1, 42)
+ GATHER_ROWS, CONSOL_AFF, CONSOL_READ, CAST, PROB_TO_ID, RESIZE, FLIP_W, AREA_DOWN3, QFFN, STEM, BANK_WRITE) = range(1, 43)
 
 KIND_NAMES = {}
 for _n in ('CONV MAXPOOL IMG_PREP UPSAMPLE2X_ADD AREA_DOWN MASK_DOWN GAP ECA_APPLY GRU SEG_AGG UP4_SOFTMAX MASK_MERGE '
@@ -29,8 +29,10 @@ for _n in ('CONV MAXPOOL IMG_PREP UPSAMPLE2X_ADD AREA_DOWN MASK_DOWN GAP ECA_APP
     KIND_NAMES[globals()[_n]] = _n
 
 F_RELU_IN, F_OUT_F32, F_RES_BCAST = 1, 2, 4
+F_PLAIN = 8 if os.environ.get('CUTIE_AMD_COUT1_ROWS', '1') in ('', '0') else 0      # A/B switch of conv_cout1_rows_kernel
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQ1 = 0, 1, 2, 3
 ACT_SHIFT = 4
+UP4_SCALAR = 2 if os.environ.get('CUTIE_AMD_UP4_VEC', '1') in ('', '0') else 0       # UP4_SOFTMAX flags&2: one pixel per thread (A/B switch)
 
 # conv tile table (mirrors the switch in csrc/conv_igemm.hip): id -> (BM, BN, BK)
 TILES = {0: (128, 128, 32), 1: (128, 64, 32), 2: (64, 64, 32), 3: (256, 16, 32), 4: (64, 128, 32),
@@ -62,9 +64,13 @@ PC_TILES = {100: (64, 64, 64), 101: (64, 64, 64), 102: (32, 64, 64), 103: (128, 
             106: (128, 128, 64), 107: (64, 64, 64), 108: (128, 128, 64), 109: (32, 64, 64), 110: (96, 64, 64), 111: (96, 128, 64),
             120: (64, 64, 64), 121: (64, 64, 64), 122: (128, 64, 64), 123: (128, 128, 64), 124: (64, 128, 64), 125: (32, 64, 64),
             126: (128, 128, 64), 127: (64, 128, 64), 129: (96, 64, 64), 130: (32, 64, 64), 131: (64, 128, 64),
-            132: (64, 64, 64), 133: (96, 128, 64), 134: (320, 64, 64)}
+            132: (64, 64, 64), 133: (96, 128, 64), 134: (320, 64, 64),
+            # pair steps (two K tiles per barrier): UNMEASURED, branch next/pc-pairstep
+            140: (64, 64, 64), 141: (96, 64, 64), 142: (96, 64, 64), 143: (32, 64, 64), 144: (128, 64, 64),
+            145: (96, 64, 64), 146: (128, 64, 64), 147: (32, 64, 64)}
 PC_HALO = {120: (8, 8), 121: (4, 16), 122: (8, 16), 123: (8, 16), 124: (8, 8), 125: (4, 8), 126: (8, 16), 127: (4, 16),
-           129: (10, 9), 130: (5, 6), 131: (6, 9), 132: (6, 9), 133: (10, 9), 134: (20, 16)}
+           129: (10, 9), 130: (5, 6), 131: (6, 9), 132: (6, 9), 133: (10, 9), 134: (20, 16),
+           145: (10, 9), 146: (8, 16), 147: (5, 6)}
 
 ALL_TILES = {**TILES, **DMA_TILES, **PC_TILES}
 
@@ -252,26 +258,6 @@ class OpList:
 
     def finalize(self):
         arr = np.zeros(len(self.recs), dtype=OP_DTYPE)
-        if WEIGHT_PREFETCH and self.touch_next_weights:
-            # a producer / consumer conv touches the weights of the conv behind it in the list when its own DMA is out (conv_pc.hip)
-            nxt, nxt2 = None, None                           # (weights, bytes) of the next conv / of the one after it
-            for n in range(len(self.recs) - 1, -1, -1):
-                kind, _, ints, _, ptrs = self.recs[n]
-                if kind != CONV:
-                    continue
-                pc = ints[17] in PC_TILES
-                if nxt is not None and pc and len(ptrs) == 9 and len(ints) == 22:
-                    # the blocks of one XCD share the range: a block that pulls much more than ~48 KB through its CU outlasts the
-                    # consumers' epilogue (bytes per CU), so small grids touch only the head of large weights
-                    budget = WEIGHT_PREFETCH_BLOCK * -(-pc_blocks(ints[17], ints[0], ints[7], ints[8], ints[9]) // 8)
-                    n1 = min(nxt[1], WEIGHT_PREFETCH, budget)
-                    ptrs.append(nxt[0])
-                    ints.append(n1)
-                    n2 = min(nxt2[1], WEIGHT_PREFETCH, budget - n1) if (nxt2 is not None and not nxt[2] and WEIGHT_PREFETCH_2) else 0
-                    if n2 > 0:                                   # the next conv cannot do it for its successor
-                        ptrs.append(nxt2[0])
-                        ints.append(n2)
-                nxt, nxt2 = (ptrs[2], self.wbytes[n], pc), nxt
         for n, (kind, flags, ints, floats, ptrs) in enumerate(self.recs):
             arr['kind'][n] = kind
             arr['flags'][n] = flags
@@ -279,7 +265,34 @@ class OpList:
             arr['f'][n, :len(floats)] = floats
             arr['p'][n, :len(ptrs)] = ptrs
         self.arr = arr
+        self.wire_next_weights()
         return arr
+
+    def wire_next_weights(self):
+        """CONV p9 / i22, p10 / i23 of the finalized array, from the tiles it carries NOW (plans call this again once the tile table
+        has been applied): a producer / consumer conv touches the packed weights of the conv behind it in the list when its own DMA
+        is out, and those of the conv after that one when the next conv has no producer waves (conv_pc.hip)."""
+        arr = self.arr
+        convs = [n for n in range(len(arr)) if arr['kind'][n] == CONV]
+        for n in convs:
+            arr['p'][n, 9:11] = 0
+            arr['i'][n, 22:24] = 0
+        if not (WEIGHT_PREFETCH and self.touch_next_weights):
+            return
+        nxt, nxt2 = None, None                               # (weights, bytes, has producer waves) of the next conv / of the one after it
+        for n in reversed(convs):
+            i = arr['i'][n]
+            pc = int(i[17]) in PC_TILES
+            if nxt is not None and pc:
+                # the blocks of one XCD share the range: a block that pulls much more than ~48 KB through its CU outlasts the
+                # consumers' epilogue (bytes per CU, DESIGN.md 4.2b), so small grids touch only the head of large weights
+                budget = WEIGHT_PREFETCH_BLOCK * -(-pc_blocks(int(i[17]), int(i[0]), int(i[7]), int(i[8]), int(i[9])) // 8)
+                n1 = min(nxt[1], WEIGHT_PREFETCH, budget)
+                arr['p'][n, 9], arr['i'][n, 22] = nxt[0], n1
+                n2 = min(nxt2[1], WEIGHT_PREFETCH, budget - n1) if (nxt2 is not None and not nxt[2] and WEIGHT_PREFETCH_2) else 0
+                if n2 > 0:                                   # the next conv cannot do it for its successor
+                    arr['p'][n, 10], arr['i'][n, 23] = nxt2[0], n2
+            nxt, nxt2 = (int(arr['p'][n, 2]), self.wbytes[n], pc), nxt
 
     def bind(self, **tensors):
         """Patch dynamic pointer slots.  Values: torch tensors or raw ints."""
@@ -308,7 +321,7 @@ class OpList:
         """w: PackedConv (weights.py).  gap_acc: int64 [B, Cout] -- the conv adds the per-(object, channel) sums of its stored output
         (fixed point x 2^24) to it (ECA's global average pool without a launch of its own); zero: an int64 tensor cleared by this
         launch (the accumulator of the NEXT conv).  Both need an LDS-DMA tile (the tile choice is restricted accordingly)."""
-        flags = (F_RELU_IN if relu_in else 0) | (F_OUT_F32 if out_f32 else 0) | (F_RES_BCAST if res_bcast else 0) | (act << ACT_SHIFT)
+        flags = (F_RELU_IN if relu_in else 0) | (F_OUT_F32 if out_f32 else 0) | (F_RES_BCAST if res_bcast else 0) | (act << ACT_SHIFT) | F_PLAIN
         assert C1 + C2 == w.cin_padded, (C1, C2, w.cin_padded)
         M = B * OH * OW
         side = gap_acc is not None or zero is not None
@@ -379,7 +392,7 @@ class OpList:
 
     def up4_softmax(self, agg, prob, logits_up, *, P, h, w, from_logits=False):
         """from_logits: `agg` holds the K = P - 1 raw logit planes and the aggregation (SEG_AGG) runs inside the launch (P <= 16)."""
-        return self.add(UP4_SOFTMAX, 1 if from_logits else 0, [P, h, w], [], [agg, prob, logits_up])
+        return self.add(UP4_SOFTMAX, (1 | UP4_SCALAR) if from_logits else 0, [P, h, w], [], [agg, prob, logits_up])
 
     def mask_merge(self, inmask, pred, src, planes, *, h0, w0, H, W, pad_left, pad_top, Knew, Kold, nfloat, float_mode):
         return self.add(MASK_MERGE, 1 if float_mode else 0, [h0, w0, H, W, pad_left, pad_top, Knew, Kold, nfloat], [],
@@ -553,6 +566,23 @@ class OpList:
 
     def memset32(self, dst, n, value=0):
         return self.add(MEMSET32, 0, [n, value], [], [dst])
+
+    def bank_write(self, copies=(), fills=()):
+        """One launch for the contiguous copies [(src, dst, nbytes)] (<= 6) and 32-bit fills [(dst, words, pattern)] (<= 2) of a memory
+        insertion; more of either spill into further launches."""
+        copies, fills = list(copies), list(fills)
+        idx = None
+        while copies or fills:
+            c, copies = copies[:6], copies[6:]
+            fl, fills = fills[:2], fills[2:]
+            ints, ptrs = [0] * 10, [0] * 14
+            for s, (src, dst, nbytes) in enumerate(c):
+                assert nbytes % 4 == 0 and nbytes > 0
+                ints[s], ptrs[2 * s], ptrs[2 * s + 1] = nbytes // 4, src, dst
+            for t, (dst, words, pattern) in enumerate(fl):
+                ints[6 + t], ints[8 + t], ptrs[12 + t] = words, pattern, dst
+            idx = self.add(BANK_WRITE, 0, ints, [], ptrs)
+        return idx
 
     def copy2d(self, src, dst, *, rows, rowbytes, src_stride, dst_stride):
         assert rowbytes % 4 == 0 and src_stride % 4 == 0 and dst_stride % 4 == 0

@@ -40,6 +40,7 @@ typedef struct cutie_op {
 #define CUTIE_F_RELU_IN   1   /* relu applied to the input while loading (conv(F.relu(x))) */
 #define CUTIE_F_OUT_F32   2   /* output stored as f32 (default bf16) */
 #define CUTIE_F_RES_BCAST 4   /* residual has batch 1 and is broadcast over the B objects */
+#define CUTIE_F_PLAIN     8   /* A/B switch: the general kernel where a specialised one exists (Cout == 1 on large maps) */
 #define CUTIE_ACT_SHIFT   4   /* activation code in bits 4..6 */
 #define CUTIE_ACT_NONE    0
 #define CUTIE_ACT_RELU    1
@@ -107,7 +108,8 @@ enum {
     /* UP4_SOFTMAX: bilinear x4 (align_corners=False) of the K+1 logit planes, softmax over planes
      * cutie.py:199-200   p0=agg f32 [K+1,h,w] p1=prob f32 [K+1,4h,4w] p2=logits_up f32 (may be 0)
      * i: 0 K+1 1 h 2 w
-     * flags&1: SEG_AGG fused -- p0 = raw logits f32 [K,h,w], the aggregation runs per tap inside the launch (K+1 <= 16) */
+     * flags&1: SEG_AGG fused -- p0 = raw logits f32 [K,h,w], the aggregation runs per tap inside the launch (K+1 <= 16) 
+     * flags&2 (with flags&1): the one-pixel-per-thread form (A/B switch; default: four pixels per thread, P <= 8) */
     CUTIE_OP_UP4_SOFTMAX = 11,
     /* MASK_MERGE: build the per-object mask planes of a frame with an input mask
      * inference_core.py:259-300.  plane t: src[t] >= 0 -> (idx==src[t]) [idx mode] / fmask[src[t]] [float
@@ -274,6 +276,11 @@ enum {
      * p3=bias f32 [64] p4=y bf16 [K,H/4,W/4,64]   i: 0 h0 1 w0 2 H 3 W (multiples of 16) 4 pad_left 5 pad_top 6 K 7 Kpad
      * f: 0-2 mean 3-5 std   flags&1: ReLU (before or after the pool: the same) */
     CUTIE_OP_STEM = 41,
+    /* BANK_WRITE: the contiguous copies and fills of one memory insertion (memory_manager.py:210-296, kv_memory_store.py:55-149: the
+     * reference torch.cat's every tensor of the bank; here a frame's keys / shrinkage / selection / per-object values go to their slot)
+     * in ONE launch.  Up to 6 copies: p[2s] = src, p[2s+1] = dst, i[s] = 32-bit words (0: unused), s = 0..5; up to 2 fills:
+     * p[12+t] = dst, i[6+t] = words, i[8+t] = the 32-bit pattern, t = 0..1.  Sources and destinations must not overlap. */
+    CUTIE_OP_BANK_WRITE = 42,
     CUTIE_OP__COUNT
 };
 

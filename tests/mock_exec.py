@@ -586,6 +586,14 @@ class MockExecutor:
         src = view(p[0], U8, (rows, rb), (ss, 1)).clone()
         view(p[1], U8, (rows, rb), (ds, 1)).copy_(src)
 
+    def _op_42(self, flags, i, f, p):                    # BANK_WRITE
+        for k in range(6):
+            if p[2 * k] and p[2 * k + 1] and i[k] > 0:
+                view(p[2 * k + 1], I32, (i[k],)).copy_(view(p[2 * k], I32, (i[k],)).clone())
+        for k in range(2):
+            if p[12 + k] and i[6 + k] > 0:
+                view(p[12 + k], I32, (i[6 + k],)).fill_(i[8 + k])
+
     def _op_29(self, flags, i, f, p):
         n = i[0]
         y = view(p[1], F32, (n,))

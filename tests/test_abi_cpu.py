@@ -36,7 +36,7 @@ def test_descriptor_layout_matches_header():
     for name, explicit in names:
         val = int(explicit) if explicit else val + 1
         assert getattr(O, name[len('CUTIE_OP_'):]) == val, name
-    assert len(names) == 41
+    assert len(names) == 42
     for flag in ('F_RELU_IN', 'F_OUT_F32', 'F_RES_BCAST', 'ACT_SHIFT', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_SQ1'):
         assert int(re.search(r'#define CUTIE_%s\s+(\d+)' % flag, src).group(1)) == getattr(O, flag)
 

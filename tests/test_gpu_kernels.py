@@ -240,6 +240,19 @@ def test_conv_cout1_kernel(ci):
     check(hip, ref, f'conv cout1 [{ci}]')
 
 
+ROWS_CASES = [CONV_CASES[15], CONV_CASES[16],
+              dict(B=3, H=120, W=216, C1=128, Cout=1, k=3, relu_in=True, out_f32=True),      # the decoder's logits head at 480p, 3 objects
+              dict(B=1, H=65, W=64, C1=256, Cout=1, k=3, act=O.ACT_RELU)]                    # 32 lanes per pixel, ragged rows
+
+
+@pytest.mark.parametrize('ci', range(len(ROWS_CASES)))
+def test_conv_cout1_rows_kernel(ci):
+    """Cout = 1, 3x3 on maps of >= 4096 pixels: conv_cout1_rows_kernel (a thread walks 4 output rows of a column) against the
+    interpreter: ragged rows and columns, 8 / 16 / 32 lanes per pixel, ReLU on the input, every output form."""
+    hip, ref = run_both(_conv_build(ROWS_CASES[ci], O.COUT1_TILE), seed=700 + ci)
+    check(hip, ref, f'conv cout1 rows [{ci}]')
+
+
 def test_conv_cout1_1x1_relu_in():
     c = dict(B=3, H=30, W=54, C1=256, Cout=1, k=1, relu_in=True, out_f32=True)
     hip, ref = run_both(_conv_build(c, O.COUT1_TILE), seed=9)
@@ -465,6 +478,32 @@ def test_conv_next_weights_touch_changes_nothing(tile, C3, monkeypatch):
     assert float(off[2].float().abs().max()) > 0
 
 
+def test_bank_write():
+    """BANK_WRITE: six copies of very different lengths (one word ... 200k words, odd tails) and two fills in one launch; a second op
+    with fewer segments; untouched neighbours stay untouched."""
+    def build(dev, g):
+        sizes = [1, 1620, 103680, 207361, 255, 1024]
+        srcs = [torch.randint(-2 ** 31, 2 ** 31 - 1, (n,), generator=g, dtype=torch.int64).to(torch.int32).to(dev) for n in sizes]
+        dsts = [torch.full((n + 8,), 7, dtype=torch.int32, device=dev) for n in sizes]
+        f0, f1 = torch.full((1620 + 8,), 7, dtype=torch.int32, device=dev), torch.full((5 + 8,), 7, dtype=torch.int32, device=dev)
+        ol = O.OpList()
+        ol.bank_write([(srcs[k], dsts[k].view(-1)[4:], 4 * sizes[k]) for k in range(6)], [(f0.view(-1)[4:], 1620, 0), (f1.view(-1)[4:], 5, 0x33D6BF95)])
+        e0 = torch.full((40,), 7, dtype=torch.int32, device=dev)
+        ol.bank_write([(srcs[1], e0.view(-1)[4:], 4 * 30)], [])
+        e1 = torch.full((40,), 7, dtype=torch.int32, device=dev)
+        ol.bank_write([], [(e1.view(-1)[4:], 30, -1)])
+        outs = {f'd{k}': dsts[k] for k in range(6)}
+        outs.update(f0=f0, f1=f1, e0=e0, e1=e1)
+        for k in range(6):
+            outs[f's{k}'] = srcs[k]
+        return ol, outs
+    hip, ref = run_both(build, seed=5)
+    check(hip, ref, 'bank_write')
+    for k, n in enumerate([1, 1620, 103680, 207361, 255, 1024]):
+        assert torch.equal(hip[f'd{k}'][4:4 + n], hip[f's{k}']) and int((hip[f'd{k}'][:4] != 7).sum()) == 0 and int((hip[f'd{k}'][4 + n:] != 7).sum()) == 0
+    assert int((hip['f0'][4:1624] != 0).sum()) == 0 and int((hip['f1'][4:9] != 0x33D6BF95).sum()) == 0 and int((hip['f1'][9:] != 7).sum()) == 0
+
+
 def test_gru():
     def build(dev, g):
         n, C = 500, 256
@@ -492,9 +531,9 @@ def test_seg_epilogue():
         return ol, {'agg': agg, 'prob': prob, 'lup': lup}
     check(*run_both(build), name='seg epilogue', rtol=2e-4)
 
-    for K in (3, 9):                                   # the fused form (<= 8 and <= 16 planes): bit-identical to the two launches
+    # the fused forms (<= 8 planes: four pixels per thread; <= 16: one): bit-identical to the two launches, also on one-column and odd maps
+    for K, h, w in ((3, 12, 20), (9, 12, 20), (1, 7, 1), (7, 5, 3), (3, 30, 54), (2, 1, 9)):
         def build2(dev, g):
-            h, w = 12, 20
             lg = (torch.randn((K, h, w), generator=g) * 3).to(dev)
             agg = torch.zeros((K + 1, h, w), dtype=F32, device=dev)
             o = [torch.zeros((K + 1, 4 * h, 4 * w), dtype=F32, device=dev) for _ in range(4)]

@@ -474,3 +474,32 @@ def test_touch_is_planned_only_where_weights_go_cold(product_net):
     big = plans.build_pixel_fusion(eng, 3, 30, 54)
     assert not small.ol.touch_next_weights and big.ol.touch_next_weights
     assert not small.ol.finalize()['p'][:, 9:11].any()
+
+
+def test_touch_ranges_follow_a_later_tile_change(monkeypatch):
+    """Plans apply the tile table AFTER the list is finalized (Plan.autotune_convs); wire_next_weights then recomputes every range from
+    the tiles in place and clears the ones that no longer apply."""
+    from cutie_amd import ops as O
+    from cutie_amd.model.weights import pack_conv
+    g = torch.Generator().manual_seed(0)
+    C = 64
+    ws = [pack_conv(torch.randn(C, C, 3, 3, generator=g), torch.randn(C, generator=g), 'cpu', segs=[(C, C)]) for _ in range(4)]
+    x = [torch.zeros((1, 16, 16, C), dtype=torch.bfloat16) for _ in range(5)]
+    kw = dict(B=1, H=16, W=16, C1=C, ldx1=C, OH=16, OW=16, ldy=C, pad=1)
+    monkeypatch.setattr(O, 'WEIGHT_PREFETCH', 1 << 20)
+    monkeypatch.setattr(O, 'WEIGHT_PREFETCH_BLOCK', 1 << 20)
+    ol = O.OpList()
+    for n, tile in enumerate((100, 61, 100, 100)):
+        ol.conv(x[n], ws[n], x[n + 1], tile=tile, **kw)
+    arr = ol.finalize()
+    wp = [w.weight.data_ptr() for w in ws]
+    nbytes = [w.weight.numel() * 2 for w in ws]
+    assert (arr['p'][0, 9], arr['p'][0, 10], arr['p'][1, 9], arr['p'][2, 9]) == (wp[1], wp[2], 0, wp[3])
+    arr['i'][:, 17] = (61, 100, 61, 100)                  # what a tile table might do
+    ol.wire_next_weights()
+    assert (arr['p'][0, 9], arr['p'][0, 10], arr['i'][0, 22], arr['i'][0, 23]) == (0, 0, 0, 0)
+    assert (arr['p'][1, 9], arr['i'][1, 22], arr['p'][1, 10], arr['i'][1, 23]) == (wp[2], nbytes[2], wp[3], nbytes[3])
+    assert (arr['p'][2, 9], arr['p'][2, 10], arr['p'][3, 9], arr['p'][3, 10]) == (0, 0, 0, 0)
+    ol.touch_next_weights = False
+    ol.wire_next_weights()
+    assert not arr['p'][:, 9:11].any() and not arr['i'][:, 22:24].any()
