@@ -204,8 +204,9 @@ class MemoryManager:
                    gmax=gmax, tau=tau, cval=cval, cidx=cidx, vptrs=bucket.vptrs(), readout=readout, ovf=ovf)
         if self.use_long_term:
             if ahead:
-                # two side buffers, alternating: the next look-ahead (side stream) may start before the caller's stream has applied this one
-                self._ahead_parity ^= 1
+                # two side buffers per bucket, alternating PER FRAME (prefetch_affinity flips the parity once per call, not once per
+                # bucket: with an even number of buckets a per-bucket flip handed every bucket the same buffer on every frame): the next
+                # look-ahead (side stream) may start before the caller's stream has applied this one
                 udelta = self._buf(f'udelta{self._ahead_parity}#{bucket.id}', (nslots,), F32, dev)
                 dyn.update(life=bucket.life, usage=udelta)
                 self._last_udelta = udelta
@@ -240,6 +241,7 @@ class MemoryManager:
         h, w = q['h'], q['w']
         dev = q['Bhi'].device
         self._pool = network.engine().pool
+        self._ahead_parity ^= 1
         out = {}
         for bid, b in self.buckets.items():
             r = self._affinity(b, q, h, w, dev, ahead=True)

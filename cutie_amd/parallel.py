@@ -8,7 +8,9 @@ gather of per-clip results to rank 0 -- a direct (non-ring) gather, since the pa
 Inside one GPU, several clips can be *in flight* at once (``run_concurrent``): one host thread + HIP stream +
 ``CUTIE.fork()`` per clip.  A single clip is a chain of ~200 dependent small launches per frame and leaves most of the 256
 CUs idle most of the time (kernel-boundary bubbles, layers with < 256 workgroups); four independent chains interleave on
-the hardware queues and nearly double the frames/s of the GPU.
+the hardware queues.  Measured on the MI355X: since the look-ahead lane overlaps a clip with itself the
+gain of four clips in flight over one is small (round 3: 1102 against 1006 frames/s, 1.09x) -- one clip already saturates the
+compute units with this launch mix; it mattered more before (round 2: 1000-1090 against 840).
 """
 import queue
 import threading
@@ -109,12 +111,24 @@ def run_concurrent(net, clip_ids: Sequence[int], run_clip: Callable, *, streams:
     return results
 
 
-def run_sharded(clip_ids: Sequence[int], run_clip: Callable[[int], Dict], *, gather_masks: bool = False):
+def _comm_device() -> torch.device:
+    """Where point-to-point payloads of the default process group must live: the rank's GPU under RCCL ("nccl"), host memory under gloo."""
+    if dist.is_initialized() and dist.get_backend() == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
+
+
+def run_sharded(clip_ids: Sequence[int], run_clip: Callable[[int], Dict], *, gather_masks: bool = False,
+                owner_of: Callable[[int], int] = None):
     """Run ``run_clip(clip_id) -> {'frames': int, 'seconds': float, 'masks': uint8 tensor [T,H,W] (optional)}`` for
-    this rank's share of ``clip_ids`` and gather the results on rank 0.  Returns {clip_id: result} on rank 0, None elsewhere."""
+    this rank's share of ``clip_ids`` and gather the results on rank 0.  Returns {clip_id: result} on rank 0, None elsewhere.
+    owner_of(i) -> rank of the i-th clip (default: round robin, i mod world size); rank 0 need not own any clip."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
-    mine = [c for i, c in enumerate(clip_ids) if i % world == rank]
+    if owner_of is None:
+        owner_of = lambda i: i % world
+    owners = [int(owner_of(i)) % world for i in range(len(clip_ids))]
+    mine = [c for i, c in enumerate(clip_ids) if owners[i] == rank]
     local = {}
     for c in mine:
         r = run_clip(c)
@@ -131,18 +145,18 @@ def run_sharded(clip_ids: Sequence[int], run_clip: Callable[[int], Dict], *, gat
     for g in gathered:
         result.update(g)
     if gather_masks:
+        dev = _comm_device()                 # (NOT the device of a local result: rank 0 may own no clip at all)
         for i, c in enumerate(clip_ids):
-            owner = i % world
+            owner = owners[i]
             if rank == owner and owner != 0:
-                m = local[c]['masks'].contiguous()
-                meta = torch.tensor(list(m.shape), dtype=torch.int64, device=m.device)
+                m = local[c]['masks'].to(dev).contiguous()
+                meta = torch.tensor(list(m.shape), dtype=torch.int64, device=dev)
                 dist.send(meta, dst=0)
                 dist.send(m, dst=0)
             elif rank == 0:
                 if owner == 0:
                     result[c]['masks'] = local[c]['masks']
                 else:
-                    dev = local[next(iter(local))]['masks'].device if local else torch.device('cpu')
                     meta = torch.zeros(3, dtype=torch.int64, device=dev)
                     dist.recv(meta, src=owner)
                     m = torch.empty(tuple(int(v) for v in meta.tolist()), dtype=torch.uint8, device=dev)

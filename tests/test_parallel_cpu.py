@@ -29,6 +29,17 @@ def _worker(rank, world, port, out):
             g = torch.Generator().manual_seed(c)
             want = torch.randint(0, 4, (3, 8, 10), generator=g).to(torch.uint8)
             assert res[c]['frames'] == 3 + c and torch.equal(res[c]['masks'], want)
+    else:
+        assert res is None
+    # rank 0 owns NO clip (custom placement): it must still receive every mask -- the receive buffers live on the communication
+    # device of the backend, not on the device of some local result
+    res = run_sharded([7, 8, 9], run_clip, gather_masks=True, owner_of=lambda i: 1)
+    if rank == 0:
+        assert sorted(res.keys()) == [7, 8, 9]
+        for c in (7, 8, 9):
+            g = torch.Generator().manual_seed(c)
+            want = torch.randint(0, 4, (3, 8, 10), generator=g).to(torch.uint8)
+            assert res[c]['frames'] == 3 + c and torch.equal(res[c]['masks'], want)
         out.put('ok')
     else:
         assert res is None
