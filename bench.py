@@ -57,6 +57,12 @@ def parse():
                          'before its timed steps (SURVEY C2: 18-26k tokens, pruning fires near frame 1995); 0 = skip')
     ap.add_argument('--no-lookahead', action='store_true',
                     help='do not pass next_image to step (no overlap of the next frame\'s image encoder on a side stream)')
+    ap.add_argument('--window', type=int, default=int(os.environ.get('CUTIE_AMD_WINDOW', '4')),
+                    help='frames per batched look-ahead encoder plan (step(next_images=...), InferenceCore.prefetch_window); '
+                         '<= 1: one frame ahead (step(next_image=...))')
+    ap.add_argument('--repeats', type=int, default=5,
+                    help='the timed region of --steps frames is repeated this many times; "value" is the FIRST one (the protocol-conform '
+                         'measurement), the spread goes to "repeats"')
     ap.add_argument('--clips-in-flight', type=int, default=4,
                     help='also measure the aggregate frames/s with this many independent clips in flight per GPU '
                          '(one host thread + HIP stream + CUTIE.fork() each; reported as "multi_clip"; 0 = skip)')
@@ -84,16 +90,16 @@ def multi_clip_throughput(net, cfg, args, K, rank, dist, dev):
         try:
             with torch.inference_mode(), torch.cuda.stream(stream):
                 proc = InferenceCore(views[i], cfg=cfg)
-                nxt = (lambda t: None) if args.no_lookahead else (lambda t: frames[(t + 1) % NF])
-                proc.step(frames[0], mask, objects=objs, next_image=nxt(0))
+                nxt = make_hint(args, frames, NF)
+                proc.step(frames[0], mask, objects=objs, **nxt(0))
                 for t in range(1, 1 + args.preroll + args.warmup):
-                    proc.step(frames[t % NF], next_image=nxt(t))
+                    proc.step(frames[t % NF], **nxt(t))
                 torch.cuda.synchronize()
                 ready.wait()                                # pre-roll done on this clip
                 start.wait()                                # released once every rank is ready
                 for t in range(args.steps):
                     tt = 1 + args.preroll + args.warmup + t
-                    proc.step(frames[tt % NF], next_image=nxt(tt))
+                    proc.step(frames[tt % NF], **nxt(tt))
                 torch.cuda.synchronize()
                 finish[i] = time.perf_counter()
         except BaseException as e:
@@ -138,6 +144,16 @@ def multi_clip_throughput(net, cfg, args, K, rank, dist, dev):
     if errors:
         raise errors[0]
     return max(finish) - t0
+
+
+def make_hint(args, frames, n):
+    """t -> the look-ahead keyword arguments of step(frame t): what a video reader knows about the frames that follow."""
+    if args.no_lookahead:
+        return lambda t: {}
+    if args.window > 1:
+        depth = args.window + 2
+        return lambda t: {'next_images': [frames[(t + 1 + j) % n] for j in range(depth)]}
+    return lambda t: {'next_image': frames[(t + 1) % n]}
 
 
 class Recorder:
@@ -201,7 +217,9 @@ def main():
 
     from cutie_amd import _lib, ops as O
     from cutie_amd.config import default_config
+    from cutie_amd.inference import inference_core as IC
     from cutie_amd.inference.inference_core import InferenceCore
+    IC.WINDOW = args.window
     from cutie_amd.model.cutie import CUTIE
     from cutie_amd.utils.synth import SyntheticClip
 
@@ -222,11 +240,11 @@ def main():
     proc = InferenceCore(net, cfg=cfg)
     side = torch.cuda.Stream(device=dev)                   # a real (capturable) stream, not the legacy null stream
     with torch.inference_mode(), torch.cuda.stream(side):
-        la = (lambda t: None) if args.no_lookahead else (lambda t: frames[(t + 1) % 128])   # the next frame, as a video reader knows it
-        proc.step(frames[0], mask, objects=clip.objects, next_image=la(0))
+        la = make_hint(args, frames, 128)                  # the next frames, as a video reader knows them
+        proc.step(frames[0], mask, objects=clip.objects, **la(0))
         t_idx = 1
         for _ in range(args.preroll):
-            proc.step(frames[t_idx % 128], next_image=la(t_idx))
+            proc.step(frames[t_idx % 128], **la(t_idx))
             t_idx += 1
         torch.cuda.synchronize()
         n_tok_start = sum(b.size() for b in proc.memory.buckets.values())
@@ -234,11 +252,17 @@ def main():
         base = t_idx
 
         def one_step(i):
-            proc.step(frames[(base + i) % 128], next_image=la(base + i))
+            proc.step(frames[(base + i) % 128], **la(base + i))
 
         # W warm-up steps, then exactly K timed steps between barrier + synchronize, MAX over the ranks (cutie_amd/parallel.py)
         elapsed = timed_steps(one_step, args.steps, args.warmup, dev)
         t_idx = base + args.warmup + args.steps
+        # the same timed region again (no warm-up: the clip simply goes on): the spread of a short sample on this box
+        rep_vals = [round(world * args.steps / elapsed, 2)]
+        for _ in range(max(0, args.repeats - 1)):
+            base = t_idx
+            rep_vals.append(round(world * args.steps / timed_steps(one_step, args.steps, 0, dev), 2))
+            t_idx = base + args.steps
         n_tok_end = sum(b.size() for b in proc.memory.buckets.values())
         # ---- the same clip WITHOUT the next_image hint: what an unchanged scripting_demo.py / eval loop of the reference gets ----
         no_la = None
@@ -251,13 +275,13 @@ def main():
         full_bank = None
         if args.full_bank_preroll > 0 and use_lt:
             proc_fb = InferenceCore(net, cfg=cfg)
-            proc_fb.step(frames[0], mask, objects=clip.objects, next_image=la(0))
+            proc_fb.step(frames[0], mask, objects=clip.objects, **la(0))
             for t in range(1, args.full_bank_preroll):
-                proc_fb.step(frames[t % 128], next_image=la(t))
+                proc_fb.step(frames[t % 128], **la(t))
             torch.cuda.synchronize()
             fb0 = args.full_bank_preroll
             nfb = min(args.steps, 200)
-            t_fb = timed_steps(lambda i: proc_fb.step(frames[(fb0 + i) % 128], next_image=la(fb0 + i)), nfb, 5, dev)
+            t_fb = timed_steps(lambda i: proc_fb.step(frames[(fb0 + i) % 128], **la(fb0 + i)), nfb, 5, dev)
             full_bank = {'preroll_frames': args.full_bank_preroll, 'memory_tokens': sum(b.size() for b in proc_fb.memory.buckets.values()),
                          'value': round(world * nfb / t_fb, 2), 'ms_per_step': round(t_fb / nfb * 1e3, 4), 'steps': nfb}
             del proc_fb
@@ -266,25 +290,28 @@ def main():
         roof = roof_aff = None
         if not args.no_roofline and rank == 0:
             conv_t = conv_f = aff_t = aff_f = 0.0
-            nrec = 5                                        # one mem_every cycle: 4 plain + 1 memory frame
+            # 20 frames of the timed workload, driven exactly like the timed region (same hints): 4 memory frames, and with the look-ahead
+            # window 5 batched encoder plans -- their conv launches are replayed back to back and divided by the frames
+            nrec = 20
+            rec.rec, rec.on = [], True
             for _ in range(nrec):
-                rec.rec, rec.on = [], True
-                proc.step(frames[t_idx % 128])
+                proc.step(frames[t_idx % 128], **la(t_idx))
                 t_idx += 1
-                rec.on = False
-                torch.cuda.synchronize()
-                allops = np.concatenate(rec.rec)
-                convs = allops[allops['kind'] == O.CONV]
-                # the affinity plan = [memset(count), score/0, select, score/1, (usage ticks), readout]; keep the memset so the
-                # candidate lists are rebuilt from empty on every timed replay
-                affs = np.concatenate([a[a['kind'] != O.USAGE_TICK] for a in rec.rec if (a['kind'] == O.AFF_SCORE).any()])
-                conv_t += rec.ex.time_ops(convs, 3) * 1e-3
-                conv_f += conv_flops(convs)
-                aff_t += rec.ex.time_ops(affs, 3) * 1e-3
-                HW = (proc.memory.H * proc.memory.W)
-                for b in proc.memory.buckets.values():
-                    aff_f += (256 + 512 * len(b.objects)) * float(b.size()) * HW
-            n_conv = int((allops['kind'] == O.CONV).sum())
+            rec.on = False
+            torch.cuda.synchronize()
+            allops = np.concatenate(rec.rec)
+            convs = allops[allops['kind'] == O.CONV]
+            # the affinity plan = [score/0, select (+ counter clear, usage ticks), score/1, readout]
+            aff_arrs = [a[a['kind'] != O.USAGE_TICK] for a in rec.rec if (a['kind'] == O.AFF_SCORE).any()]
+            affs_all = np.concatenate(aff_arrs)
+            affs = aff_arrs[-1]
+            conv_t += rec.ex.time_ops(convs, 3) * 1e-3
+            conv_f += conv_flops(convs)
+            aff_t += rec.ex.time_ops(affs_all, 3) * 1e-3
+            HW = (proc.memory.H * proc.memory.W)
+            for b in proc.memory.buckets.values():
+                aff_f += (256 + 512 * len(b.objects)) * float(b.size()) * HW * len(aff_arrs) / max(1, len(proc.memory.buckets))
+            n_conv = round(int((allops['kind'] == O.CONV).sum()) / nrec, 1)
             # the affinity matmul on its own (score pass 0 = the S = A.B^T tiles + tile maxima; valid in isolation), and the
             # other stages by prefix differences of the plan [score/0, select (+ counter clear, usage ticks), score/1, readout]
             # (round-1 form, $CUTIE_AMD_UNFUSED: a memset in front)
@@ -310,15 +337,24 @@ def main():
             names = O.KIND_NAMES
             breakdown = {}
             aff_kinds = (O.AFF_SCORE, O.AFF_SELECT, O.AFF_READOUT)
+            # [launches, device us] PER FRAME, averaged over the nrec recorded frames (back-to-back replays of each kind)
             if not args.no_breakdown:
-                breakdown['AFFINITY(score x2+select+readout)'] = [int(len(affs)), round(rec.ex.time_ops(affs, 3) * 1e3, 1)]
+                breakdown['AFFINITY(score x2+select+readout)'] = [round(len(affs_all) / nrec, 2), round(rec.ex.time_ops(affs_all, 3) * 1e3 / nrec, 1)]
             for kind in ([] if args.no_breakdown else sorted(set(int(k) for k in allops['kind']) - set(aff_kinds))):
                 sel = allops[allops['kind'] == kind]
                 if os.environ.get('BENCH_DEBUG'):
                     print('replay kind', kind, names.get(kind), len(sel), file=sys.stderr, flush=True)
-                breakdown[names.get(kind, str(kind))] = [int(len(sel)), round(rec.ex.time_ops(sel, 3) * 1e3, 1)]
+                breakdown[names.get(kind, str(kind))] = [round(len(sel) / nrec, 2), round(rec.ex.time_ops(sel, 3) * 1e3 / nrec, 1)]
             lib = rec.ex.lib
-            g = None if args.no_graph else lib.cutie_graph_capture(allops.ctypes.data, len(allops), rec.ex.stream())
+            # one frame without hints (all of its launches in one list) as ONE HIP graph
+            proc.step(frames[t_idx % 128])                  # (consumes the pending look-ahead; the next frame runs its own encoder)
+            rec.rec, rec.on = [], True
+            proc.step(frames[(t_idx + 1) % 128])
+            t_idx += 2
+            rec.on = False
+            torch.cuda.synchronize()
+            oneframe = np.concatenate(rec.rec)
+            g = None if args.no_graph else lib.cutie_graph_capture(oneframe.ctypes.data, len(oneframe), rec.ex.stream())
             graph_ms = None
             if g:
                 torch.cuda.synchronize()
@@ -437,12 +473,18 @@ def main():
                                    f'(SURVEY 8d C2/C3), eval_config defaults (mem_every=5, top_k=30), random-init weights',
                        'preroll_frames': args.preroll, 'memory_tokens_start': n_tok_start, 'memory_tokens_end': n_tok_end,
                        'parallelism': f'clip-shard x{world}', 'accumulate': 'fp32',
-                       'lookahead': 'off' if args.no_lookahead else 'step(next_image=...): the next frame\'s image encoder and, when the current '
-                                    'frame does not write the memory bank, its affinity read-out run on a side stream (same kernels, same results)'},
+                       'lookahead': 'off' if args.no_lookahead else
+                                    (f'step(next_images=...): the image encoder runs over a window of {args.window} upcoming frames as one batched plan on a '
+                                     'third stream (tiles of the same K-order class: bit-identical features)' if args.window > 1 else
+                                     'step(next_image=...): the next frame\'s image encoder runs on a side stream') +
+                                    '; when the current frame does not write the memory bank, the next frame\'s affinity read-out runs ahead on a side stream'},
         }
         gs = getattr(rec.ex, 'graph_stats', None)
         if gs is not None:
             out['plans_eager_vs_graph_replay'] = list(gs)      # whole run (pre-roll included): plans issued launch by launch | as one HIP graph
+        rv = sorted(rep_vals)
+        out['repeats'] = {'values': rep_vals, 'median': rv[len(rv) // 2], 'min': rv[0], 'max': rv[-1],
+                          'note': f'{len(rep_vals)} consecutive timed regions of {args.steps} steps on this box; "value" is the first'}
         if no_la is not None:
             out['value_no_lookahead'] = no_la['value']
             out['no_lookahead'] = dict(no_la, note='same clip, step(image) without the next_image hint (an unchanged scripting_demo.py)')

@@ -27,6 +27,10 @@ AHEAD_AFFINITY = os.environ.get('CUTIE_AMD_AHEAD_AFFINITY', '1') not in ('', '0'
 # memorising on the side stream when no look-ahead hint is given (step / _join_pending): opt-in -- measured neutral on the MI355X (726 against
 # 730 fps without hints, profiles/r03_host.md: by the time the host has issued the next frame's encoder the side stream is almost done)
 DEFER_MEM = os.environ.get('CUTIE_AMD_DEFER_MEM', '0') not in ('', '0')
+# look-ahead WINDOW of the image encoder (step(next_images=...)): frames per batched encoder plan (<= 1: one frame at a time, as with
+# next_image), and how many already-encoded frames may be left ahead when the next batch is started
+WINDOW = int(os.environ.get('CUTIE_AMD_WINDOW', '4'))
+WINDOW_LEAD = int(os.environ.get('CUTIE_AMD_WINDOW_LEAD', '1'))
 
 
 def pad_geometry(h, w, d=16):
@@ -82,10 +86,21 @@ class InferenceCore:
         self._prefetched = None        # (key of the source frame, prepared image, features, event)
         self._pending_mem = None       # event of an _add_memory still running on the side stream (see step)
         self._pending_refs = None      # its inputs: kept referenced until it is joined (pooled buffers are recycled by reference count)
+        self._win_stream = None        # third stream: the batched image encoder of the look-ahead window (prefetch_window)
+        self._window = {}              # frame key -> (prepared image, record of CUTIE._encode_window, event, source image, geometry)
+
+    def _engine_stream(self, name, dev):
+        """The look-ahead streams belong to the ENGINE (= one set of plan buffers / arenas), not to the processor: two processors that
+        drive the same network one after the other (clip after clip, a flip lane) then order their look-ahead work on the shared plan
+        buffers by stream order.  (CUTIE.fork() gives a concurrent clip its own engine, hence its own streams.)"""
+        st = self.network.engine().__dict__.setdefault('_streams', {})
+        if name not in st:
+            st[name] = torch.cuda.Stream(device=dev)
+        return st[name]
 
     def _side_stream(self, dev):
         if self._enc_stream is None:
-            self._enc_stream = torch.cuda.Stream(device=dev)
+            self._enc_stream = self._engine_stream('side', dev)
         return self._enc_stream
 
     def _join_pending(self):
@@ -148,6 +163,85 @@ class InferenceCore:
                 t.record_stream(main)                          # allocated on the side stream, consumed on the main one
         # (the source tensor is kept referenced until the next step: its address cannot be recycled for another frame)
         self._prefetched = (src_key, prepared, feats, ev, image, geometry)
+
+    def prefetch_window(self, images, *, affinity: bool = False) -> None:
+        """Look-ahead over SEVERAL frames (no counterpart in the reference): ``images`` are the frames of the following ``step`` calls,
+        in order (a list of tensors or one stacked tensor; a video reader / ``bench.py`` knows them).  The image encoder is object- and
+        memory-independent, and at 480p one frame gives its stride-16 layers 1620 rows -- a third of one round of workgroups on 256 CUs.
+        So whenever no more than WINDOW_LEAD already-encoded frames are left ahead, the next WINDOW frames go through ONE plan on a third
+        stream (CUTIE._encode_window: every conv with WINDOW x the rows, tiles of the same K-order class, so every frame's features are
+        bit-identical to the one-frame plan's).  The next frame's record then takes the place of ``prefetch``'s result, including the
+        look-ahead of its affinity read-out on the side stream (``affinity=True``).  Frames are matched by storage like ``prefetch``;
+        wrong hints only lose the overlap."""
+        n = len(images)
+        if n == 0:
+            return
+        first = images[0]
+        dev = self.network.device
+        if WINDOW <= 1 or dev.type != 'cuda' or (self.max_internal_size > 0 and min(first.shape[-2:]) > self.max_internal_size):
+            return self.prefetch(first, affinity=affinity)
+        main = torch.cuda.current_stream(dev)
+        keys = [self._frame_key(images[j]) for j in range(min(n, WINDOW + WINDOW_LEAD + 1))]
+        # encoded frames that are no longer announced (a changed schedule): dropped -- their buffers are only ever re-written by the
+        # window stream itself, in its own order
+        for k in [k for k in self._window if k not in keys]:
+            del self._window[k]
+        ahead = 0
+        while ahead < len(keys) and keys[ahead] in self._window:
+            ahead += 1
+        if ahead <= WINDOW_LEAD and ahead < len(keys):
+            todo = [j for j in range(ahead, min(len(keys), ahead + WINDOW)) if keys[j] not in self._window]
+            # one geometry per batch (frames of one clip); a frame of another size ends the batch
+            shape0 = tuple(images[todo[0]].shape[-2:])
+            todo = [j for j in todo if tuple(images[j].shape[-2:]) == shape0]
+            preps = [self._prepare_image(images[j]) for j in todo]          # (conversion, if any, runs on the caller's stream)
+            h0, w0, H, W, pad = preps[0][1]
+            geometry = (h0, w0, H, W, pad[0], pad[2])
+            if self._win_stream is None:
+                self._win_stream = self._engine_stream('window', dev)
+            win = self._win_stream
+            win.wait_stream(main)                              # frame conversions; every read of the output set that is being recycled ...
+            if self._enc_stream is not None:
+                win.wait_stream(self._enc_stream)              # ... also those of the look-ahead read-outs on the side stream
+            with torch.cuda.stream(win):
+                recs = self.network._encode_window([p[0] for p in preps], *geometry)
+                ev = torch.cuda.Event()
+                ev.record(win)
+            for j, (prepared, _), o in zip(todo, preps, recs):
+                for t in o.values():
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(main)
+                        if self._enc_stream is not None:
+                            t.record_stream(self._enc_stream)
+                self._window[keys[j]] = (prepared, o, ev, images[j], geometry)
+        ent = self._window.get(keys[0])
+        if ent is None:
+            return
+        # the next frame: its record becomes the pending look-ahead of `step`
+        prepared, o, ev, src, geometry = ent
+        ms_features, pix_feat, key, shrinkage, selection = self.network._adopt_encoded(o)
+        frame_context.remember('geometry', prepared, geometry)
+        ro = None
+        if affinity:
+            enc = self._side_stream(dev)
+            enc.wait_stream(main)
+            enc.wait_event(ev)
+            pool = self.network.engine().pool
+            pool.offset = 1
+            try:
+                with torch.cuda.stream(enc):
+                    ro = self.memory.prefetch_affinity(key, selection, self.network)
+                    ev = torch.cuda.Event()
+                    ev.record(enc)
+            finally:
+                pool.offset = 0
+            for v in (ro or {}).values():
+                if isinstance(v[0], torch.Tensor) and v[0].is_cuda:
+                    v[0].record_stream(main)
+            for t in o.values():
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(enc)
+        self._prefetched = (keys[0], prepared, (ms_features, pix_feat, key, shrinkage, selection), ev, src, geometry)
 
     def _resize(self, x: torch.Tensor, size, *, nearest: bool = False) -> torch.Tensor:
         """F.interpolate(x[None], size, bilinear align_corners=False | nearest-exact)[0] for f32 [C,H,W] as the RESIZE kernel."""
@@ -252,9 +346,11 @@ class InferenceCore:
     # ---- step (inference_core.py:172-328) ------------------------------------------------------------------------------
     def step(self, image: torch.Tensor, mask: Optional[torch.Tensor] = None, objects: Optional[List[int]] = None, *,
              idx_mask: bool = True, end: bool = False, delete_buffer: bool = True, force_permanent: bool = False,
-             next_image: Optional[torch.Tensor] = None) -> torch.Tensor:
+             next_image: Optional[torch.Tensor] = None, next_images=None) -> torch.Tensor:
         """Same contract as the reference (inference_core.py:172-328).  ``next_image`` (optional, not in the reference): the
-        frame of the following ``step``; its image encoder is started on a side stream (see ``prefetch``)."""
+        frame of the following ``step``; its image encoder is started on a side stream (see ``prefetch``).  ``next_images``
+        (optional): the frames of the following ``step`` calls, in order -- the encoder runs over a window of them at once
+        (see ``prefetch_window``); results are bit-identical with or without either hint."""
         if objects is None and mask is not None:
             assert not idx_mask
             objects = list(range(1, mask.shape[0] + 1))
@@ -284,6 +380,7 @@ class InferenceCore:
             image = pre[1]
             torch.cuda.current_stream(image.device).wait_event(pre[3])
             self.image_feature_store._store[self.curr_ti] = pre[2]
+            self._window.pop(pre[0], None)                     # (a frame of the look-ahead window: consumed)
             h0, w0, H, W, pl, pt = pre[5]
             frame_context.remember('geometry', image, pre[5])    # (for _add_memory / a third-party consumer of this frame)
             self.pad = pad_geometry(h0, w0, 16)[2]
@@ -308,9 +405,13 @@ class InferenceCore:
             frame_context.remember('geometry', image_f, (h0, w0, H, W, self.pad[1], pt))
             ms_f, pix_f = fl.image_feature_store.get_features(self.curr_ti, image_f)
             key_f, shr_f, sel_f = fl.image_feature_store.get_key(self.curr_ti, image_f)
-        elif next_image is not None and not end:
+        elif (next_image is not None or (next_images is not None and len(next_images) > 0)) and not end:
             # (the next frame's read-out may run ahead only if this frame leaves the bank alone)
-            self.prefetch(next_image, affinity=AHEAD_AFFINITY and not (is_mem_frame or force_permanent) and self.memory.engaged)
+            aff = AHEAD_AFFINITY and not (is_mem_frame or force_permanent) and self.memory.engaged
+            if next_images is not None and len(next_images) > 0:
+                self.prefetch_window(next_images, affinity=aff)
+            else:
+                self.prefetch(next_image, affinity=aff)
 
         if need_segment:
             pred_prob_with_bg = self._segment(key, selection, pix_feat, ms_feat, update_sensory=update_sensory)

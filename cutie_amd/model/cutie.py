@@ -205,6 +205,7 @@ class Engine:
         e._arenas = {}
         e.pool = plans.SlotPool()
         e.__dict__.pop('_splitk_part', None)
+        e.__dict__.pop('_streams', None)            # (the look-ahead streams of InferenceCore: one set per engine)
         return e
 
     def plan(self, key, builder, *args):
@@ -214,7 +215,7 @@ class Engine:
             p.ol.finalize()
             if plans.ARENA:
                 # the image encoder (+ key projection) may run on the look-ahead stream next to everything else: its own arena
-                kind = 'side' if key[0] in ('enc', 'key') else 'main'
+                kind = 'side' if key[0] in ('enc', 'key') else ('win' if key[0] == 'encw' else 'main')     # (the window encoder: a third stream)
                 arenas = self.__dict__.setdefault('_arenas', {})
                 if kind not in arenas:
                     arenas[kind] = plans.Arena(self.device)
@@ -373,6 +374,50 @@ class CUTIE(nn.Module):
         frame_context.remember('decoder_feats', out['f8'], (out['f8p'], out['f4p'], out['f4']), cap=4)
         frame_context.remember('fuse_xt', out['pix_feat'], out['fuse_xt'], cap=4)
         return out
+
+    def _encode_window(self, images, h0, w0, H, W, pad_left, pad_top):
+        """B un-padded frames f32 [3,h0,w0] of one geometry through ONE plan (plans.build_encode(B=...)) -> a list of B records shaped
+        like `_encode`'s (views of the [B, ...] outputs).  Frame b's record is bit-identical to `_encode(images[b], ...)`.  The
+        frame_context entries of a record are NOT made here: `_adopt_encoded` registers them when the frame is about to be consumed
+        (the tables keep the last few frames only)."""
+        eng = self.engine()
+        dev = self.device
+        m = self.model_cfg
+        B = len(images)
+        P = eng.plan(('encw', B, h0, w0, H, W, pad_left, pad_top), plans.build_encode, h0, w0, H, W, pad_left, pad_top, B)
+        h, w = H // 16, W // 16
+        hw = h * w
+        HWp = -(-hw // 64) * 64
+        ms = self.ms_dims
+        W_ = eng.w
+        Z = False
+        specs = dict(f16=((B, h, w, ms[0]), BF16, Z), f8=((B, 2 * h, 2 * w, ms[1]), BF16, Z), f4=((B, 4 * h, 4 * w, ms[2]), BF16, Z),
+                     pix_feat=((B, h, w, m['pixel_dim']), BF16, Z), key=((B, hw, m['key_dim']), F32, Z), shr=((B, hw), F32, Z),
+                     sel=((B, hw, m['key_dim']), F32, Z), Bhi=((B, HWp, 128), BF16, True), Blo=((B, HWp, 128), BF16, True), cq=((B, HWp), F32, True),
+                     f8p=((B, 2 * h, 2 * w, W_['mask_decoder.decoder_feat_proc.transforms.0'].cout), BF16, Z),
+                     f4p=((B, 4 * h, 4 * w, W_['mask_decoder.decoder_feat_proc.transforms.1'].cout), BF16, Z),
+                     fuse_xt=((B, h, w, W_['pixel_fuser.fuser.distributor.x_transform'].cout), BF16, Z))
+        out = eng.pool.get_ring(('encw', B, h, w, str(dev)), specs, dev, ring=4)
+        P.run(**({'image': images[0]} if B == 1 else {'image%d' % b: images[b] for b in range(B)}), **out)
+        recs = []
+        for b in range(B):
+            o = {k: (v[b:b + 1] if k in ('f16', 'f8', 'f4', 'pix_feat', 'f8p', 'f4p', 'fuse_xt') else v[b]) for k, v in out.items()}
+            o['h'], o['w'] = h, w
+            recs.append(o)
+        return recs
+
+    def _adopt_encoded(self, o):
+        """A record of `_encode_window` -> what `_encode_image_raw` + `transform_key` return for that frame, with the companions of
+        the results registered (decoder / fuser convolutions, similarity operands of the key)."""
+        frame_context.remember('decoder_feats', o['f8'], (o['f8p'], o['f4p'], o['f4']), cap=4)
+        frame_context.remember('fuse_xt', o['pix_feat'], o['fuse_xt'], cap=4)
+        ms = (logical(o['f16']), logical(o['f8']), logical(o['f4']))
+        key, shr, sel = self._key_views(o)
+        qo = o.get('_qo')
+        if qo is None:
+            qo = o['_qo'] = dict(Bhi=o['Bhi'], Blo=o['Blo'], cq=o['cq'], h=o['h'], w=o['w'])
+        frame_context.remember('query', o['key'], qo, cap=4)
+        return ms, logical(o['pix_feat']), key, shr, sel
 
     def encode_image(self, image: torch.Tensor) -> (Iterable[torch.Tensor], torch.Tensor):
         """image [1,3,H,W] in [0,1] (already padded to /16) -> ((f16, f8, f4), pix_feat); cutie.py:61-64"""

@@ -174,6 +174,22 @@ class SlotPool:
             return {nm: t.view(t.shape) for nm, t in slot.items()}      # aliases: whoever keeps one (or a view of it) keeps the slot busy
         return fresh()
 
+    def get_ring(self, key, specs, dev, ring=3):
+        """Like `get`, for outputs that are not produced once per frame (the look-ahead window of the image encoder: one set per
+        batch of frames): the group cycles through `ring` sets of its own; a set somebody still holds is not recycled."""
+        fresh = lambda: {n: (torch.zeros if z else torch.empty)(sh, dtype=dt, device=dev) for n, (sh, dt, z) in specs.items()}
+        if self.SLOTS <= 0 or _USE_COUNT is None:
+            return fresh()
+        slots = self.groups.setdefault(key, {'next': 0})
+        i = slots['next'] % ring
+        slots['next'] = i + 1
+        slot = slots.get(i)
+        if slot is None:
+            slot = slots[i] = {nm: torch.zeros(sh, dtype=dt, device=dev) for nm, (sh, dt, z) in specs.items()}
+        if all(_storage_users(t) == 0 for t in slot.values()):
+            return {nm: t.view(t.shape) for nm, t in slot.items()}
+        return fresh()
+
 
 def weights_go_cold(px16, K=None):
     """Does it pay that a conv touches the weights of the next one on its way out (ops.OpList.finalize; conv_pc.hip)?  A frame of px16
@@ -199,6 +215,7 @@ class Plan:
         self._arena_slots = []           # (op index, pointer slot, byte offset inside the arena)
         self._arena_views = {}           # name -> (offset, shape, dtype)
         self._graphs = {}                # pointer signature -> HIP graph of this plan (_lib.HipExecutor.run_cached)
+        self.korder_ref = 0              # B > 1: a batched twin of a B = 1 plan -- tiles from the K-order class the B = 1 plan uses (autotune_convs)
 
     def buf(self, name, shape, dtype=BF16, persistent=False):
         assert name not in self.bufs, name
@@ -305,6 +322,18 @@ class Plan:
             M, cout, cin = int(i[0]) * int(i[7]) * int(i[8]), int(i[9]), int(i[3]) + int(i[4])
             key = (M, cout, cin, int(i[11]), int(i[13]), int(arr['flags'][n]) & 3, int(i[1]), int(i[2]))
             best = cache.get(key)
+            if self.korder_ref:
+                # batched twin of a B = 1 plan (the look-ahead window of the image encoder): whatever the table says for the batched
+                # geometry, the tile must sum over K in the order of the tile the B = 1 plan runs for this layer -- that keeps frame b
+                # of the batch bit-identical to the same frame through the B = 1 plan
+                Bk = self.korder_ref
+                key1 = (M // Bk,) + key[1:]
+                ref = cache.get(key1) or (O.COUT1_TILE if (int(i[17]) == O.COUT1_TILE) else
+                                          O.pick_tile(M // Bk, cout, cin, dict(kh=int(i[11]), c2=int(i[4]))), 1)
+                want = O.korder_class(*ref)
+                if best is None or O.korder_class(*best) != want:
+                    best = (int(i[17]), 1) if O.korder_class(int(i[17]), int(i[19])) == want else tuple(ref)
+                assert O.korder_class(*best) == want, (key, best, ref)
             if best is None and not getattr(self.eng, 'autotune', AUTOTUNE):
                 continue                                     # keep the deterministic static choice made when the plan was built
             if best is None:
@@ -419,31 +448,39 @@ def stem_ok(eng, name):
     return STEM and not UNFUSED and w is not None and w.cout == 64 and w.kh == 7 and w.kw == 7 and w.cin_padded == 8 and w.bias is not None
 
 
-def build_encode(eng, h0, w0, H, W, pad_left, pad_top):
+def build_encode(eng, h0, w0, H, W, pad_left, pad_top, B=1):
     """CUTIE.encode_image + transform_key (cutie.py:61-64,92-98; big_modules.py:45-54,81-87) + query-side
     similarity operands.  dyn in: image f32 [3,h0,w0].  dyn out: f16,f8,f4,pix_feat (bf16 NHWC), key,shr,sel
-    (f32 [hw,*]), Bhi,Blo (bf16 [HWp,128]), cq (f32 [HWp])."""
-    P = Plan(eng, touch=weights_go_cold((H // 16) * (W // 16)))
+    (f32 [hw,*]), Bhi,Blo (bf16 [HWp,128]), cq (f32 [HWp]).
+    B > 1 (the look-ahead WINDOW of InferenceCore, no counterpart in the reference): B frames `image0` .. `image<B-1>` through ONE
+    plan -- every conv sees B x the rows (M = B * OH * OW; at 480p the stride-16 layers of one frame have 1620 rows, a third of a
+    round of workgroups), the outputs are [B, ...] with frame b's slice laid out exactly like the B = 1 output.  Rows of different
+    frames never meet (batch = outermost dimension of NHWC) and the tiles are taken from the same K-order class as the B = 1 plan's
+    (Plan.korder_ref), so frame b's results are bit-identical to the B = 1 plan's."""
+    P = Plan(eng, touch=weights_go_cold(B * (H // 16) * (W // 16)))
     m = eng.m
+    img = (lambda b: Dyn('image')) if B == 1 else (lambda b: Dyn('image%d' % b))
     if stem_ok(eng, 'pixel_encoder.conv1'):                 # IMG_PREP + 7x7 conv + max pool in one launch (csrc/stem.hip)
-        pool = P.buf('pool', (1, H // 4, W // 4, 64))
-        P.ol.stem(Dyn('image'), None, eng.w['pixel_encoder.conv1'], pool, h0=h0, w0=w0, H=H, W=W, pad_left=pad_left, pad_top=pad_top, K=1,
-                  mean=m['pixel_mean'], std=m['pixel_std'], relu=True)
-        x = Act(pool, 1, H // 4, W // 4, 64)
+        pool = P.buf('pool', (B, H // 4, W // 4, 64))
+        for b in range(B):
+            P.ol.stem(img(b), None, eng.w['pixel_encoder.conv1'], pool[b], h0=h0, w0=w0, H=H, W=W, pad_left=pad_left, pad_top=pad_top, K=1,
+                      mean=m['pixel_mean'], std=m['pixel_std'], relu=True)
+        x = Act(pool, B, H // 4, W // 4, 64)
     else:
-        img8 = P.buf('img8', (1, H, W, 8))
-        P.ol.img_prep(Dyn('image'), None, img8, h0=h0, w0=w0, H=H, W=W, pad_left=pad_left, pad_top=pad_top, K=1,
-                      mean=m['pixel_mean'], std=m['pixel_std'])
-        x = P.conv('pixel_encoder.conv1', Act(img8, 1, H, W, 8), stride=2, pad=3, act=O.ACT_RELU)
-        pool = P.buf('pool', (1, x.H // 2, x.W // 2, 64))
-        P.ol.maxpool(x.t, pool, B=1, H=x.H, W=x.W, C=64)
-        x = Act(pool, 1, x.H // 2, x.W // 2, 64)
+        img8 = P.buf('img8', (B, H, W, 8))
+        for b in range(B):
+            P.ol.img_prep(img(b), None, img8[b], h0=h0, w0=w0, H=H, W=W, pad_left=pad_left, pad_top=pad_top, K=1,
+                          mean=m['pixel_mean'], std=m['pixel_std'])
+        x = P.conv('pixel_encoder.conv1', Act(img8, B, H, W, 8), stride=2, pad=3, act=O.ACT_RELU)
+        pool = P.buf('pool', (B, x.H // 2, x.W // 2, 64))
+        P.ol.maxpool(x.t, pool, B=B, H=x.H, W=x.W, C=64)
+        x = Act(pool, B, x.H // 2, x.W // 2, 64)
     h4, w4, h8, w8, h, w = H // 4, W // 4, H // 8, W // 8, H // 16, W // 16
     ms = m['pixel_encoder']['ms_dims']
-    taps = {'res2': Act(Dyn('f4'), 1, h4, w4, ms[2]), 'layer2': Act(Dyn('f8'), 1, h8, w8, ms[1]),
-            'layer3': Act(Dyn('f16'), 1, h, w, ms[0])}
+    taps = {'res2': Act(Dyn('f4'), B, h4, w4, ms[2]), 'layer2': Act(Dyn('f8'), B, h8, w8, ms[1]),
+            'layer3': Act(Dyn('f16'), B, h, w, ms[0])}
     f16, _ = P.resnet('pixel_encoder', x, taps)
-    pix = P.conv('pix_feat_proj', f16, out=Act(Dyn('pix_feat'), 1, h, w, m['pixel_dim']))
+    pix = P.conv('pix_feat_proj', f16, out=Act(Dyn('pix_feat'), B, h, w, m['pixel_dim']))
     build_key_ops(P, f16, h, w)
     # Image-only convolutions of the mask decoder and the pixel fuser (DecoderFeatureProcessor, big_modules.py:244-255; the
     # x_transform of MainToGroupDistributor, group_modules.py:112-115): they do not depend on the memory, so they run here -- with the
@@ -452,19 +489,25 @@ def build_encode(eng, h0, w0, H, W, pad_left, pad_top):
     for wname, src, dname in (('mask_decoder.decoder_feat_proc.transforms.0', taps['layer2'], 'f8p'),
                               ('mask_decoder.decoder_feat_proc.transforms.1', taps['res2'], 'f4p'),
                               ('pixel_fuser.fuser.distributor.x_transform', pix, 'fuse_xt')):
-        P.conv(wname, src, out=Act(Dyn(dname), 1, src.H, src.W, W_[wname].cout))
-    P.meta.update(h=h, w=w)
+        P.conv(wname, src, out=Act(Dyn(dname), B, src.H, src.W, W_[wname].cout))
+    P.meta.update(h=h, w=w, B=B)
+    if B > 1:
+        P.korder_ref = B
     return P
 
 
 def build_key_ops(P, f16, h, w):
     m = P.eng.m
     CK = m['key_dim']
+    B = f16.B
     kx = P.conv('key_proj.pix_feat_proj', f16, name='keyx')
-    P.conv('key_proj.key_proj', kx, out=Act(Dyn('key'), 1, h, w, CK), out_f32=True)
-    P.conv('key_proj.d_proj', kx, out=Act(Dyn('shr'), 1, h, w, 1), out_f32=True, act=O.ACT_SQ1)
-    P.conv('key_proj.e_proj', kx, out=Act(Dyn('sel'), 1, h, w, CK), out_f32=True, act=O.ACT_SIGMOID)
-    P.ol.key_prep(Dyn('key'), Dyn('sel'), Dyn('Bhi'), Dyn('Blo'), Dyn('cq'), n=h * w, query=True)
+    P.conv('key_proj.key_proj', kx, out=Act(Dyn('key'), B, h, w, CK), out_f32=True)
+    P.conv('key_proj.d_proj', kx, out=Act(Dyn('shr'), B, h, w, 1), out_f32=True, act=O.ACT_SQ1)
+    P.conv('key_proj.e_proj', kx, out=Act(Dyn('sel'), B, h, w, CK), out_f32=True, act=O.ACT_SIGMOID)
+    hw, HWp = h * w, -(-h * w // 64) * 64
+    for b in range(B):                                       # (the padding rows [hw, HWp) of every frame's operands stay zero)
+        P.ol.key_prep(Dyn('key', b * hw * CK * 4), Dyn('sel', b * hw * CK * 4), Dyn('Bhi', b * HWp * 128 * 2), Dyn('Blo', b * HWp * 128 * 2),
+                      Dyn('cq', b * HWp * 4), n=hw, query=True)
 
 
 def build_transform_key(eng, h, w):

@@ -75,6 +75,21 @@ PC_HALO = {120: (8, 8), 121: (4, 16), 122: (8, 16), 123: (8, 16), 124: (8, 8), 1
 ALL_TILES = {**TILES, **DMA_TILES, **PC_TILES}
 
 
+def korder_class(tile, splitk=1):
+    """Which fp32 summation order over K a conv tile implements -- two tiles of one class give bit-identical outputs on the same
+    operands (tests/test_gpu_kernels.py::test_tiles_of_a_korder_class_agree_bitwise).  'stream': K tiles in the packed order
+    k = (kh * KW + kw) * Cin + c, two v_mfma_f32_16x16x32_bf16 per 64 channels in ascending k (conv_dma.hip, the stream tiles of
+    conv_pc.hip); 'igemm': the register-staged tiles without split-K (same order, not asserted against 'stream'); 'halo': 64-channel slice outermost, its nine taps inside
+    (conv_pc.hip, tiles 120..); anything that splits K (WK tiles, split-K) is a class of its own."""
+    if tile in PC_HALO:
+        return 'halo'
+    if tile in TILE_WK or splitk != 1:
+        return ('split', tile, splitk)
+    if tile in (3, COUT1_TILE):
+        return ('small', tile)
+    return 'stream' if (tile in DMA_TILES or tile in PC_TILES) else 'igemm'
+
+
 def pc_tile_ok(tile, *, cin, kh, stride=1, pad=None, c2=0):
     """conv_pc_kernel eligibility (mirrors launch_pc in conv_pc.hip)."""
     if cin % 64 or (c2 and (c2 % 64 or (cin - c2) % 64)) or kh > 5:

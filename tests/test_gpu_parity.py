@@ -308,6 +308,7 @@ def test_every_conv_candidate_agrees_on_the_real_layers(name, gpu_net):
                 res = (torch.randn(nb * nout * int(i[15]) + 64, generator=g) * 0.5).to(torch.bfloat16).cuda()
                 base['p'][0, 4] = res.data_ptr()
             ref = None
+            by_class = {}                                # K-order class (ops.korder_class) -> (tile, its output): members agree BITWISE
             for t in ([2] if cout > 16 else [3]) + cands:
                 for sk in O.splitk_candidates(M, cout, int(i[16]), t):
                     one = base.copy()
@@ -317,6 +318,11 @@ def test_every_conv_candidate_agrees_on_the_real_layers(name, gpu_net):
                     real.run(one)
                     torch.cuda.synchronize()
                     got = out[:M * ldy].view(M, ldy)[:, :cout].float()
+                    cls = O.korder_class(t, sk)
+                    if cls in ('stream', 'halo'):
+                        first = by_class.setdefault(cls, (t, got))
+                        if not torch.equal(first[1], got):
+                            bad.append((key, 'bitwise', cls, first[0], t, float((got - first[1]).abs().max())))
                     if ref is None:
                         ref = got
                         assert torch.isfinite(ref).all(), key
@@ -353,6 +359,89 @@ def test_lookahead_encoder_matches_plain_order(gpu_net):
     assert torch.isfinite(plain).all()
     assert torch.equal(piped, plain)
     assert torch.equal(mixed, plain)
+
+
+@pytest.mark.parametrize('size,K', [((240, 432), 3), ((480, 854), 2)])
+def test_lookahead_window_matches_plain_order(gpu_net, size, K):
+    """step(next_images=...) encodes a WINDOW of upcoming frames through one batched plan on a third stream (tiles of the K-order
+    class of the one-frame plan): bit-identical probabilities to the plain order -- with complete hints, with windows shorter than
+    WINDOW (the tail of the clip), with a schedule that changes under way (announced frames that never arrive), with the hints
+    given as one stacked tensor, and when window hints and next_image hints alternate."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.utils.synth import SyntheticClip
+    n = 19
+    clip = SyntheticClip(size[0], size[1], K, n, seed=78)
+    frames = torch.stack([clip.frame(t) for t in range(n)]).cuda()
+    decoy = torch.stack([clip.frame((t * 5 + 2) % n) for t in range(n)]).cuda()
+    mask = clip.first_mask().cuda()
+
+    def run(hints):
+        proc = InferenceCore(gpu_net, cfg=default_config(mem_every=3))
+        outs = []
+        for t in range(n):
+            kw = hints(t)
+            outs.append(proc.step(frames[t], *((mask,) if t == 0 else ()), **(dict(objects=clip.objects) if t == 0 else {}), **kw))
+        torch.cuda.synchronize()
+        assert len(proc._window) == 0 or hints is not full, 'every announced frame was consumed'
+        return torch.stack(outs).cpu()
+
+    full = lambda t: dict(next_images=[frames[j] for j in range(t + 1, min(n, t + 9))])
+    stacked = lambda t: dict(next_images=frames[t + 1:t + 7]) if t + 1 < n else {}
+    short = lambda t: dict(next_images=[frames[j] for j in range(t + 1, min(n, t + 3))])
+    changing = lambda t: dict(next_images=[frames[t + 1]] + [decoy[j] for j in range(t + 2, min(n, t + 6))]) if t + 1 < n and t % 4 == 1 else full(t)
+    mixed = lambda t: ({} if t % 5 == 0 else dict(next_image=frames[t + 1]) if (t % 5 == 1 and t + 1 < n) else full(t))
+    with torch.inference_mode():
+        plain = run(lambda t: {})
+        assert torch.isfinite(plain).all()
+        for name, h in (('full', full), ('stacked', stacked), ('short', short), ('changing', changing), ('mixed', mixed)):
+            got = run(h)
+            assert torch.equal(got, plain), (name, float((got - plain).abs().max()))
+
+
+def test_lookahead_window_with_long_term_and_two_buckets(gpu_net):
+    """Long-term memory, objects added at different times (two buckets: ADVICE r03 -- the look-ahead usage side buffers must
+    alternate per frame, not per bucket) and window hints: the usage / life counters of every bucket and the bank sizes equal the
+    unpipelined run's."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.utils.synth import SyntheticClip
+    n = 36
+    clip = SyntheticClip(96, 160, 3, n, seed=14)
+    frames = torch.stack([clip.frame(t) for t in range(n)]).cuda()
+    mask = clip.first_mask().cuda()
+    cfg = default_config(use_long_term=True, mem_every=2, long_term=S.LT_SMALL)
+    first, late = clip.objects[:2], clip.objects[2:]
+
+    def run(hints):
+        proc = InferenceCore(gpu_net, cfg=cfg)
+        outs = []
+        for t in range(n):
+            kw = hints(t)
+            if t == 0:
+                m0 = mask * (mask != late[0]).long()
+                outs.append(proc.step(frames[0], m0, objects=first, **kw))
+            elif t == 7:
+                m1 = mask * (mask == late[0]).long()
+                outs.append(proc.step(frames[t], m1, objects=late, **kw))
+            else:
+                outs.append(proc.step(frames[t], **kw))
+        torch.cuda.synchronize()
+        st = []
+        for b in proc.memory.buckets.values():
+            st.append(dict(n_long=b.n_long, n_work=b.n_work, n_perm=b.n_perm, life=b.life[:b.work_start + b.n_work].float().cpu().clone(),
+                           use=b.use[:b.work_start + b.n_work].float().cpu().clone()))
+        return torch.stack(outs[7:]).cpu(), st
+
+    with torch.inference_mode():
+        plain, sp = run(lambda t: {})
+        win, sw = run(lambda t: dict(next_images=[frames[j] for j in range(t + 1, min(n, t + 9))]))
+        one, so = run(lambda t: dict(next_image=frames[t + 1]) if t + 1 < n else {})
+    assert len(sp) == 2 and sp[0]['n_long'] > 0, 'two buckets, and the clip must consolidate'
+    for name, out, st in (('window', win, sw), ('next_image', one, so)):
+        for a, b in zip(st, sp):
+            assert (a['n_long'], a['n_work'], a['n_perm']) == (b['n_long'], b['n_work'], b['n_perm']), name
+            assert torch.equal(a['life'][:b['n_long']], b['life'][:b['n_long']]), (name, 'long-term life')
+            assert torch.allclose(a['use'][:b['n_long']], b['use'][:b['n_long']], rtol=1e-4, atol=1e-5), (name, 'long-term usage')
+        assert float((out - plain).abs().max()) < 1e-3, (name, float((out - plain).abs().max()))
 
 
 def test_lookahead_keeps_long_term_bookkeeping(gpu_net):

@@ -503,3 +503,34 @@ def test_touch_ranges_follow_a_later_tile_change(monkeypatch):
     ol.touch_next_weights = False
     ol.wire_next_weights()
     assert not arr['p'][:, 9:11].any() and not arr['i'][:, 22:24].any()
+
+
+def test_window_encoder_plan_matches_single_frame_plan(product_net):
+    """CUTIE._encode_window (B frames through one plan: the look-ahead window of InferenceCore.prefetch_window) against B runs of the
+    one-frame plan, through the descriptor interpreter: every output of every frame, including the zero padding rows of the
+    similarity operands, and the frame_context companions registered by _adopt_encoded."""
+    from cutie_amd import frame_context
+    from cutie_amd.utils.synth import SyntheticClip
+    net = product_net
+    clip = SyntheticClip(90, 120, 2, 4, seed=3)                 # un-padded 90 x 120 -> 96 x 128
+    imgs = [clip.frame(t).float().contiguous() for t in range(3)]
+    geom = (90, 120, 96, 128, 4, 3)
+    with torch.inference_mode():
+        recs = net._encode_window(imgs, *geom)
+        assert len(recs) == 3
+        for b in range(3):
+            one = net._encode(imgs[b], *geom)
+            for k in ('f16', 'f8', 'f4', 'pix_feat', 'key', 'shr', 'sel', 'B', 'cq', 'f8p', 'f4p', 'fuse_xt'):
+                # (the interpreter's batched fp32 convs may round differently from its one-frame ones; the split-bf16 similarity
+                # operand is compared as hi + lo: the low half alone is the rounding residue of the high one)
+                a, c = (recs[b][k].float(), one[k].float()) if k != 'B' else (recs[b]['Bhi'].float() + recs[b]['Blo'].float(),
+                                                                               one['Bhi'].float() + one['Blo'].float())
+                assert a.shape == c.shape, (k, a.shape, c.shape)
+                assert float((a - c).abs().max()) <= 2e-2 * float(c.abs().max()) + 1e-6, (b, k, float((a - c).abs().max()))
+            hw = recs[b]['h'] * recs[b]['w']
+            assert float(recs[b]['Bhi'][hw:].abs().max()) == 0 and float(recs[b]['cq'][hw:].abs().max()) == 0
+            ms, pix, key, shr, sel = net._adopt_encoded(recs[b])
+            assert key.shape == (1, 64, 6, 8) and shr.shape == (1, 1, 6, 8) and ms[2].shape == (1, 256, 24, 32)
+            assert frame_context.recall('query', key) is not None and frame_context.recall('fuse_xt', pix) is not None
+        one1 = net._encode_window(imgs[:1], *geom)              # a window of one frame: the B = 1 plan under its own key / arena
+        assert float((one1[0]['key'] - recs[0]['key']).abs().max()) <= 2e-2 * float(recs[0]['key'].abs().max())
