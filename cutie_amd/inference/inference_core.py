@@ -8,6 +8,7 @@ output_prob_to_mask (:337-345).
 flip_aug (the reference's batch of [frame, flipped frame], :142-143,162-165,234-235,303-305) runs as a second lane with its
 own memory bank; chunk_size > 0 groups the objects in the memory read-out like the reference.
 """
+import contextlib
 import logging
 import os
 from typing import List, Optional
@@ -15,7 +16,7 @@ from typing import List, Optional
 import numpy as np
 import torch
 
-from .. import frame_context, ops as O
+from .. import _lib, frame_context, ops as O
 from ..model import plans
 from .image_feature_store import ImageFeatureStore
 from .memory_manager import MemoryManager
@@ -178,9 +179,13 @@ class InferenceCore:
             return
         first = images[0]
         dev = self.network.device
-        if WINDOW <= 1 or dev.type != 'cuda' or (self.max_internal_size > 0 and min(first.shape[-2:]) > self.max_internal_size):
+        gpu = dev.type == 'cuda'
+        if not gpu and not _lib.get_executor().is_mock:        # (the descriptor interpreter of the tests walks through the same bookkeeping, without streams)
+            return
+        if WINDOW <= 1 or (self.max_internal_size > 0 and min(first.shape[-2:]) > self.max_internal_size):
             return self.prefetch(first, affinity=affinity)
-        main = torch.cuda.current_stream(dev)
+        on = (lambda st: torch.cuda.stream(st)) if gpu else (lambda st: contextlib.nullcontext())
+        main = torch.cuda.current_stream(dev) if gpu else None
         keys = [self._frame_key(images[j]) for j in range(min(n, WINDOW + WINDOW_LEAD + 1))]
         # encoded frames that are no longer announced (a changed schedule): dropped -- their buffers are only ever re-written by the
         # window stream itself, in its own order
@@ -190,23 +195,30 @@ class InferenceCore:
         while ahead < len(keys) and keys[ahead] in self._window:
             ahead += 1
         if ahead <= WINDOW_LEAD and ahead < len(keys):
-            todo = [j for j in range(ahead, min(len(keys), ahead + WINDOW)) if keys[j] not in self._window]
+            todo = []
+            for j in range(ahead, min(len(keys), ahead + WINDOW)):
+                if keys[j] not in self._window and keys[j] not in [keys[i] for i in todo]:
+                    todo.append(j)
             # one geometry per batch (frames of one clip); a frame of another size ends the batch
             shape0 = tuple(images[todo[0]].shape[-2:])
             todo = [j for j in todo if tuple(images[j].shape[-2:]) == shape0]
             preps = [self._prepare_image(images[j]) for j in todo]          # (conversion, if any, runs on the caller's stream)
             h0, w0, H, W, pad = preps[0][1]
             geometry = (h0, w0, H, W, pad[0], pad[2])
-            if self._win_stream is None:
-                self._win_stream = self._engine_stream('window', dev)
-            win = self._win_stream
-            win.wait_stream(main)                              # frame conversions; every read of the output set that is being recycled ...
-            if self._enc_stream is not None:
-                win.wait_stream(self._enc_stream)              # ... also those of the look-ahead read-outs on the side stream
-            with torch.cuda.stream(win):
+            win = None
+            if gpu:
+                if self._win_stream is None:
+                    self._win_stream = self._engine_stream('window', dev)
+                win = self._win_stream
+                win.wait_stream(main)                          # frame conversions; every read of the output set that is being recycled ...
+                if self._enc_stream is not None:
+                    win.wait_stream(self._enc_stream)          # ... also those of the look-ahead read-outs on the side stream
+            with on(win):
                 recs = self.network._encode_window([p[0] for p in preps], *geometry)
-                ev = torch.cuda.Event()
-                ev.record(win)
+                ev = None
+                if gpu:
+                    ev = torch.cuda.Event()
+                    ev.record(win)
             for j, (prepared, _), o in zip(todo, preps, recs):
                 for t in o.values():
                     if isinstance(t, torch.Tensor) and t.is_cuda:
@@ -221,18 +233,20 @@ class InferenceCore:
         prepared, o, ev, src, geometry = ent
         ms_features, pix_feat, key, shrinkage, selection = self.network._adopt_encoded(o)
         frame_context.remember('geometry', prepared, geometry)
-        ro = None
         if affinity:
-            enc = self._side_stream(dev)
-            enc.wait_stream(main)
-            enc.wait_event(ev)
+            enc = None
+            if gpu:
+                enc = self._side_stream(dev)
+                enc.wait_stream(main)
+                enc.wait_event(ev)
             pool = self.network.engine().pool
             pool.offset = 1
             try:
-                with torch.cuda.stream(enc):
+                with on(enc):
                     ro = self.memory.prefetch_affinity(key, selection, self.network)
-                    ev = torch.cuda.Event()
-                    ev.record(enc)
+                    if gpu:
+                        ev = torch.cuda.Event()
+                        ev.record(enc)
             finally:
                 pool.offset = 0
             for v in (ro or {}).values():
@@ -280,7 +294,8 @@ class InferenceCore:
         if ovf is not None:
             self.memory._scratch['overflow'] = ovf
         if self._prefetched is not None:                        # a look-ahead of the old bank: order its buffers, drop it
-            torch.cuda.current_stream(self._prefetched[1].device).wait_event(self._prefetched[3])
+            if self._prefetched[3] is not None:
+                torch.cuda.current_stream(self._prefetched[1].device).wait_event(self._prefetched[3])
             self._prefetched = None
         if self._flip is not None:
             self._flip.clear_memory()
@@ -375,17 +390,24 @@ class InferenceCore:
         if self._lane_of_other is None:
             self.network.engine().pool.tick()                  # frame-slot pool: this frame's slot (plans.SlotPool)
         pre, self._prefetched = self._prefetched, None
+        if self._window and not resize_needed and (pre is None or pre[0] != self._frame_key(image)):
+            ent = self._window.get(self._frame_key(image))
+            if ent is not None:                                # encoded ahead by the window, but not announced as the next frame
+                if pre is not None and pre[3] is not None:
+                    torch.cuda.current_stream(pre[1].device).wait_event(pre[3])
+                pre = (self._frame_key(image), ent[0], self.network._adopt_encoded(ent[1]), ent[2], ent[3], ent[4])
         if pre is not None and not resize_needed and pre[0] == self._frame_key(image):
             # this frame's encoder already ran (or is running) on the side stream
             image = pre[1]
-            torch.cuda.current_stream(image.device).wait_event(pre[3])
+            if pre[3] is not None:
+                torch.cuda.current_stream(image.device).wait_event(pre[3])
             self.image_feature_store._store[self.curr_ti] = pre[2]
             self._window.pop(pre[0], None)                     # (a frame of the look-ahead window: consumed)
             h0, w0, H, W, pl, pt = pre[5]
             frame_context.remember('geometry', image, pre[5])    # (for _add_memory / a third-party consumer of this frame)
             self.pad = pad_geometry(h0, w0, 16)[2]
         else:
-            if pre is not None:                                # stale look-ahead: order the encoder plan's buffers, drop it
+            if pre is not None and pre[3] is not None:         # stale look-ahead: order the encoder plan's buffers, drop it
                 torch.cuda.current_stream(pre[1].device).wait_event(pre[3])
             image, (h0, w0, H, W, self.pad) = self._prepare_image(image)
             pl, pt = self.pad[0], self.pad[2]

@@ -113,7 +113,10 @@ class MockExecutor:
         coutpad = -(-Cout // 128) * 128
         w = unpack_conv_weight(view(p[2], BF16, (coutpad, Kpad)), Cout, KH, KW, Cin)
         bias = view(p[3], F32, (Cout,)).clone() if p[3] else None
-        y = F.conv2d(x.permute(0, 3, 1, 2), w, bias, stride, pad).permute(0, 2, 3, 1)
+        if getattr(self, 'per_sample_conv', False):      # batch-invariant rounding (torch's CPU conv may sum differently per batch size)
+            y = torch.cat([F.conv2d(x[b:b + 1].permute(0, 3, 1, 2), w, bias, stride, pad) for b in range(B)]).permute(0, 2, 3, 1)
+        else:
+            y = F.conv2d(x.permute(0, 3, 1, 2), w, bias, stride, pad).permute(0, 2, 3, 1)
         assert y.shape[1] == OH and y.shape[2] == OW, (y.shape, OH, OW)
         if p[4]:
             rb = 1 if flags & O.F_RES_BCAST else B

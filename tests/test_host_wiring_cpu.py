@@ -534,3 +534,52 @@ def test_window_encoder_plan_matches_single_frame_plan(product_net):
             assert frame_context.recall('query', key) is not None and frame_context.recall('fuse_xt', pix) is not None
         one1 = net._encode_window(imgs[:1], *geom)              # a window of one frame: the B = 1 plan under its own key / arena
         assert float((one1[0]['key'] - recs[0]['key']).abs().max()) <= 2e-2 * float(recs[0]['key'].abs().max())
+
+
+def test_lookahead_window_bookkeeping_matches_plain_order():
+    """InferenceCore.prefetch_window through the descriptor interpreter (no streams; convs per sample, so that the interpreter's fp32
+    convs round the same whatever the batch): complete window hints, hints shorter than the window, a schedule that changes under
+    way, window and next_image hints alternating, long-term memory with the look-ahead read-out -- all bit-identical to no hints,
+    and no encoded frame is left behind."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.model.cutie import CUTIE
+    from cutie_amd.utils.synth import SyntheticClip
+    mx = MockExecutor()
+    mx.per_sample_conv = True
+    _lib.set_executor_for_testing(mx)
+    try:
+        net = CUTIE(default_config())
+        net.load_weights(make_state_dict(seed=0))
+        n = 13
+        clip = SyntheticClip(64, 96, 2, n, seed=3)
+        frames = [clip.frame(t) for t in range(n)]
+        decoy = [clip.frame((5 * t + 2) % n) + 0.01 for t in range(n)]
+        mask = clip.first_mask()
+
+        def run(hint, **cfg):
+            proc = InferenceCore(net, cfg=default_config(mem_every=3, **cfg))
+            outs = []
+            for t in range(n):
+                outs.append(proc.step(frames[t], *((mask,) if t == 0 else ()), **(dict(objects=clip.objects) if t == 0 else {}), **hint(t)))
+            return torch.stack(outs), proc
+
+        full = lambda t: dict(next_images=frames[t + 1:t + 9])
+        short = lambda t: dict(next_images=frames[t + 1:t + 3])
+        changing = lambda t: dict(next_images=[frames[t + 1]] + decoy[t + 2:t + 6]) if (t + 1 < n and t % 4 == 1) else full(t)
+        mixed = lambda t: {} if t % 5 == 0 else (dict(next_image=frames[t + 1]) if (t % 5 == 1 and t + 1 < n) else full(t))
+        with torch.inference_mode():
+            plain, _ = run(lambda t: {})
+            for name, h in (('full', full), ('short', short), ('changing', changing), ('mixed', mixed)):
+                got, proc = run(h)
+                assert torch.equal(got, plain), (name, float((got - plain).abs().max()))
+                assert len(proc._window) == 0, name
+            plain, p0 = run(lambda t: {}, use_long_term=True, long_term=S.LT_SMALL)
+            got, p1 = run(full, use_long_term=True, long_term=S.LT_SMALL)
+            assert torch.equal(got, plain)
+            b0, b1 = next(iter(p0.memory.buckets.values())), next(iter(p1.memory.buckets.values()))
+            assert (b0.n_long, b0.n_work, b0.n_perm) == (b1.n_long, b1.n_work, b1.n_perm)
+            # (usage of a look-ahead read-out is parked in a side buffer and added as one number: a different fp32 rounding)
+            assert torch.allclose(b0.use[:b0.work_start + b0.n_work], b1.use[:b1.work_start + b1.n_work], rtol=1e-5, atol=1e-6)
+            assert torch.equal(b0.life[:b0.work_start + b0.n_work], b1.life[:b1.work_start + b1.n_work])
+    finally:
+        _lib.set_executor_for_testing(None)
