@@ -513,6 +513,15 @@ class InferenceCore:
                 src = list(range(n_planes))
             k_pred = 0
         src = src[:n_planes] + [-1] * (n_planes - len(src))
+        # the mask is padded on its own (inference_core.py:263: pad_divide_by(mask, 16)): a mask one pixel narrower than the frame
+        # (examples/masks/judo/00005.png is 480 x 853 against 480 x 854 frames) lands with ITS pad offsets in the same padded size
+        mh0, mw0 = int(mask.shape[-2]), int(mask.shape[-1])
+        if (mh0, mw0) != (h0, w0):
+            mH, mW, mpad = pad_geometry(mh0, mw0, 16)
+            if (mH, mW) != (H, W):
+                raise RuntimeError(f'The size of the mask ({mh0} x {mw0}, padded {mH} x {mW}) must match the size of the frame '
+                                   f'({h0} x {w0}, padded {H} x {W})')
+            h0, w0, pl, pt = mh0, mw0, mpad[0], mpad[2]
         if idx_mask:
             inmask = mask.to(device=dev, dtype=torch.int32).contiguous()
             nfloat = 0

@@ -9,6 +9,7 @@ hydra-free shim of SURVEY.md section 8c / Appendix B, loaded with the determinis
 of oracle/weights.py, and driven through the scenarios of oracle/scenarios.py.  Outputs:
 
   tests/golden/bike/*.jpg, 00000.png   input frames of examples/images/bike (data fixture)
+  tests/golden/judo/*.jpg, *.png       examples/images/judo and examples/masks/judo (data fixture)
   tests/golden/<scenario>.npz          sub-sampled per-frame probabilities, argmax md5, memory sizes
   tests/golden/stages.npz              sampled per-stage tensors of the CUTIE facade methods
   tests/golden/state_dict_spec.json    reference state_dict key -> shape (pins oracle/weights.py)
@@ -148,6 +149,11 @@ def main():
     shutil.copyfile(f'{REF}/examples/masks/bike/00000.png', os.path.join(GOLDEN, 'bike', '00000.png'))
     for n in os.listdir(os.path.join(GOLDEN, 'bike')):
         os.chmod(os.path.join(GOLDEN, 'bike', n), 0o644)
+    os.makedirs(os.path.join(GOLDEN, 'judo'), exist_ok=True)       # examples/images/judo + its four mask files (data fixture, C0b)
+    for sub in ('images', 'masks'):
+        for n in sorted(os.listdir(f'{REF}/examples/{sub}/judo')):
+            shutil.copyfile(f'{REF}/examples/{sub}/judo/{n}', os.path.join(GOLDEN, 'judo', n))
+            os.chmod(os.path.join(GOLDEN, 'judo', n), 0o644)
 
     CUTIE, InferenceCore = import_reference()
     from oracle.weights import make_state_dict, param_spec

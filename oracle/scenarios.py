@@ -20,6 +20,10 @@ LT_SMALL = dict(count_usage=True, max_mem_frames=4, min_mem_frames=2, num_protot
 SCENARIOS = {
     # configs[0] of BASELINE.json: examples/bike, 480p, (2) objects, scripting_demo.py settings
     'bike': dict(cfg=dict(max_internal_size=480), kind='bike', frames=4, sub=8),
+    # examples/images/judo through scripting_demo_add_del_objects.py:21-64 -- 16 real 480p frames, ids 1..4
+    # given by the mask files of frames 0, 5, 8, 13 (three buckets of objects added at different times), id 1 deleted before frame 10.
+    # (masks/judo/00005.png is 480 x 853 against 480 x 854 frames: the reference pads the mask on its own, inference_core.py:263)
+    'judo': dict(cfg=dict(max_internal_size=480), kind='judo', frames=16, sub=8, delete_at={10: [1]}),
     # small clip, 3 objects, FIFO working memory wraps (mem_every=2, max_mem_frames=3)
     'small_fifo': dict(cfg=dict(mem_every=2, max_mem_frames=3, stagger_updates=1),
                        kind='synth', h=96, w=136, k=3, frames=14, sub=2),
@@ -103,9 +107,29 @@ def _bike_frames():
     return imgs, mask
 
 
+def _judo_steps():
+    """The inputs of scripting_demo_add_del_objects.py:29-60: every frame of examples/images/judo, with the mask file of the same
+    name where one exists; objects = the unique non-zero values of that mask."""
+    from PIL import Image
+    d = os.path.join(GOLDEN_DIR, 'judo')
+    steps = []
+    for n in sorted(x for x in os.listdir(d) if x.endswith('.jpg')):
+        img = torch.from_numpy(np.array(Image.open(os.path.join(d, n)).convert('RGB'))).permute(2, 0, 1).float() / 255
+        mp = os.path.join(d, n[:-4] + '.png')
+        if os.path.exists(mp):
+            m = np.array(Image.open(mp))
+            objs = [int(o) for o in np.unique(m) if o != 0]
+            steps.append((img, torch.from_numpy(m).long(), objs))
+        else:
+            steps.append((img, None, None))
+    return steps
+
+
 def scenario_inputs(name):
     """-> list of (image, mask_or_None, objects_or_None), dict frame->objects to delete (before the step)"""
     sc = SCENARIOS[name]
+    if sc['kind'] == 'judo':
+        return _judo_steps(), sc.get('delete_at', {})
     if sc['kind'] == 'bike':
         imgs, mask = _bike_frames()
         objs = [int(o) for o in np.unique(mask.numpy()) if o != 0]

@@ -35,6 +35,9 @@ def main():
     ap.add_argument('--out', default='gpurun_out/conv_sweep')
     ap.add_argument('--cold', type=int, default=0, help='MiB copied through the device before every timed launch (evicts code and operands from the L2s: the state a layer finds inside a frame); 0 = warm back-to-back timing')
     ap.add_argument('--families', default='', help='comma list: time only tiles of these families (igemm,dma,pc,halo); default all')
+    ap.add_argument('--window', type=int, nargs='*', default=[], help='sweep the convs of the BATCHED image encoder (CUTIE._encode_window, the look-ahead '
+                    'window of InferenceCore) for these batch sizes instead of the frame\'s convs; candidates are restricted to the K-order class of '
+                    'the one-frame plan\'s tile (ops.korder_class), the only tiles the window plan may use')
     args = ap.parse_args()
     from bench import Recorder
     from cutie_amd import _lib, ops as O
@@ -49,8 +52,37 @@ def main():
     rec = Recorder(_lib.get_executor())
     _lib.set_executor_for_testing(rec)
     geoms = {}
+    want_class = {}
     with torch.inference_mode():
-        for K in args.objects:
+        for B in args.window:
+            clip = SyntheticClip(args.height, args.width, 1, 16, seed=1)
+            imgs = [clip.frame(t).cuda().float().contiguous() for t in range(B)]
+            from cutie_amd.inference.inference_core import pad_geometry
+            H, W, pad = pad_geometry(args.height, args.width, 16)
+            g = (args.height, args.width, H, W, pad[0], pad[2])
+            net._encode_window(imgs, *g)                  # builds the plan (and applies the table with the class rule)
+            net._encode(imgs[0], *g)
+            torch.cuda.synchronize()
+            rec.rec, rec.on = [], True
+            net._encode(imgs[0], *g)
+            one_ops = np.concatenate(rec.rec)
+            rec.rec = []
+            net._encode_window(imgs, *g)
+            rec.on = False
+            torch.cuda.synchronize()
+            ops = np.concatenate(rec.rec)
+            c1 = [n for n in range(len(one_ops)) if one_ops['kind'][n] == O.CONV]
+            cB = [n for n in range(len(ops)) if ops['kind'][n] == O.CONV]
+            assert len(c1) == len(cB)
+            for n1, n in zip(c1, cB):
+                i = ops['i'][n]
+                M, cout, cin = int(i[0]) * int(i[7]) * int(i[8]), int(i[9]), int(i[3]) + int(i[4])
+                key = (M, cout, cin, int(i[11]), int(i[13]), int(ops['flags'][n]) & 3, int(i[1]), int(i[2]))
+                want_class[key] = O.korder_class(int(one_ops['i'][n1][17]), int(one_ops['i'][n1][19]))
+                if key not in geoms:
+                    geoms[key] = [ops[n:n + 1].copy(), 0]
+                geoms[key][1] += 1
+        for K in ([] if args.window else args.objects):
             clip = SyntheticClip(args.height, args.width, K, 16, seed=1)
             proc = InferenceCore(net, cfg=cfg)
             proc.step(clip.frame(0).cuda(), clip.first_mask().cuda(), objects=clip.objects)
@@ -103,6 +135,8 @@ def main():
         if args.families:
             keep = set(args.families.split(','))
             cands = [t for t in cands if family(t, O) in keep or t == int(i[17])]
+        if key in want_class:
+            cands = [t for t in cands if O.korder_class(t) == want_class[key]] or [int(i[17])]
         res = {}
         for t in cands:
             for sk in O.splitk_candidates(M, cout, int(i[16]), t):
