@@ -92,7 +92,7 @@ def _mem_sizes(p):
             sum(b.n_long for b in m.buckets.values()), len(m.buckets)]
 
 
-@pytest.mark.parametrize('name', ['small_fifo', 'small_add_del', 'small_lt', 'small_interactive', 'small_flip', 'small_chunk', 'small_misc', 'small_clear', 'small_video', 'small_lt_overlap', 'small_cfg_fifo', 'small_cfg_lt', 'bike'])
+@pytest.mark.parametrize('name', ['small_fifo', 'small_add_del', 'small_lt', 'small_interactive', 'small_flip', 'small_chunk', 'small_misc', 'small_clear', 'small_video', 'small_lt_overlap', 'small_cfg_fifo', 'small_cfg_lt', 'bike', 'judo'])
 def test_trajectory_matches_oracle_gpu(name, gpu_net, oracle_net):
     from cutie_amd.inference.inference_core import InferenceCore
     gold = np.load(S.GOLDEN_DIR + f'/{name}.npz')

@@ -115,6 +115,22 @@ def test_teacher_forced_480p_long_term():
     check_rows(rows, '480p K=3 LT')
 
 
+def test_teacher_forced_judo():
+    """examples/images/judo driven like scripting_demo_add_del_objects.py -- 16 real 480p frames, ids 1..4 given
+    by the mask files of frames 0, 5, 8, 13 (three buckets; the mask of frame 5 is one pixel narrower than the frames), id 1 deleted
+    before frame 10 -- every frame value-checked against the oracle from the oracle's state, bank sizes exact."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    net, onet, cfgs = nets('base')
+    over = S.SCENARIOS['judo']['cfg']
+    steps, deletes = S.scenario_inputs('judo')
+    assert len(steps) == 16 and [t for t, s_ in enumerate(steps) if s_[1] is not None] == [0, 5, 8, 13] and deletes == {10: [1]}
+    rows = teacher.run_teacher_forced(steps, lambda: OracleProcessor(onet, dict(DEFAULT_CFG, **over)),
+                                      lambda: InferenceCore(net, cfg=cfgs(over)), 'cuda', deletes=deletes, margins=(ALL_BOUNDS['base']['argmax_margin'],))
+    assert len(rows) == 16
+    check_rows(rows, 'judo')
+
+
 def test_teacher_forced_1080p():
     """BASELINE C4 size: 1920x1080, 5 objects (8160 queries per frame), 7 frames incl. the second memory frame."""
     from cutie_amd.inference.inference_core import InferenceCore

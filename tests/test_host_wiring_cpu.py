@@ -583,3 +583,26 @@ def test_lookahead_window_bookkeeping_matches_plain_order():
             assert torch.equal(b0.life[:b0.work_start + b0.n_work], b1.life[:b1.work_start + b1.n_work])
     finally:
         _lib.set_executor_for_testing(None)
+
+
+def test_mask_narrower_than_the_frame_is_padded_on_its_own(product_net, oracle_net):
+    """examples/masks/judo/00005.png is 480 x 853 while the frames are 480 x 854: the reference pads frame and mask separately
+    (inference_core.py:231,263), so the mask lands with ITS pad offsets in the common padded size.  Same at a small size: frame
+    96 x 122 (pads 3 | 3), first mask 96 x 121 (3 | 4), a later mask for a new object 96 x 120 (4 | 4)."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.utils.synth import SyntheticClip
+    clip = SyntheticClip(96, 122, 3, 6, seed=9)
+    full = clip.first_mask()
+    m0 = (full * (full != 3).long())[:, :121].contiguous()
+    m3 = (full * (full == 3).long())[:, 1:121].contiguous()
+    proc = InferenceCore(product_net, cfg=default_config(mem_every=2))
+    oproc = OracleProcessor(oracle_net, dict(DEFAULT_CFG, mem_every=2))
+    with torch.inference_mode():
+        for t in range(6):
+            args = (m0, [1, 2]) if t == 0 else ((m3, [3]) if t == 3 else ())
+            p = proc.step(clip.frame(t), *args[:1], **(dict(objects=args[1]) if args else {}))
+            o = oproc.step(clip.frame(t), *args[:1], **(dict(objects=args[1]) if args else {}))
+            assert p.shape == o.shape == (4 if t >= 3 else 3, 96, 122)
+            assert float((p.float() - o).abs().max()) < (1e-5 if t == 0 else 6e-2), (t, float((p.float() - o).abs().max()))
+        with pytest.raises(RuntimeError):
+            proc.step(clip.frame(0), full[:, :100].contiguous(), objects=[1, 2, 3])     # pads to 96 x 112: no common padded size

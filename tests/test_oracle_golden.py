@@ -41,7 +41,7 @@ def test_state_dict_spec_matches_reference():
         assert tuple(shp) == tuple(spec[k][0]), k
 
 
-@pytest.mark.parametrize('name', ['small_fifo', 'small_lt', 'small_add_del', 'small_interactive', 'small_flip', 'small_chunk', 'small_misc', 'small_clear', 'small_video', 'small_lt_overlap', 'small_cfg_fifo', 'small_cfg_lt', 'bike'])
+@pytest.mark.parametrize('name', ['small_fifo', 'small_lt', 'small_add_del', 'small_interactive', 'small_flip', 'small_chunk', 'small_misc', 'small_clear', 'small_video', 'small_lt_overlap', 'small_cfg_fifo', 'small_cfg_lt', 'bike', 'judo'])
 def test_oracle_matches_reference_trajectory(name, oracle_net):
     gold = np.load(os.path.join(GOLDEN, name + '.npz'))
     sub = S.SCENARIOS[name]['sub']
