@@ -57,7 +57,7 @@ def parse():
                          'before its timed steps (SURVEY C2: 18-26k tokens, pruning fires near frame 1995); 0 = skip')
     ap.add_argument('--no-lookahead', action='store_true',
                     help='do not pass next_image to step (no overlap of the next frame\'s image encoder on a side stream)')
-    ap.add_argument('--window', type=int, default=int(os.environ.get('CUTIE_AMD_WINDOW', '4')),
+    ap.add_argument('--window', type=int, default=int(os.environ.get('CUTIE_AMD_WINDOW', '8')),
                     help='frames per batched look-ahead encoder plan (step(next_images=...), InferenceCore.prefetch_window); '
                          '<= 1: one frame ahead (step(next_image=...))')
     ap.add_argument('--repeats', type=int, default=5,
@@ -151,7 +151,7 @@ def make_hint(args, frames, n):
     if args.no_lookahead:
         return lambda t: {}
     if args.window > 1:
-        depth = args.window + 2
+        depth = args.window + 4                            # >= WINDOW + WINDOW_LEAD + 1 frames: a full batch can always be formed
         return lambda t: {'next_images': [frames[(t + 1 + j) % n] for j in range(depth)]}
     return lambda t: {'next_image': frames[(t + 1) % n]}
 

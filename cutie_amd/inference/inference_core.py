@@ -30,8 +30,8 @@ AHEAD_AFFINITY = os.environ.get('CUTIE_AMD_AHEAD_AFFINITY', '1') not in ('', '0'
 DEFER_MEM = os.environ.get('CUTIE_AMD_DEFER_MEM', '0') not in ('', '0')
 # look-ahead WINDOW of the image encoder (step(next_images=...)): frames per batched encoder plan (<= 1: one frame at a time, as with
 # next_image), and how many already-encoded frames may be left ahead when the next batch is started
-WINDOW = int(os.environ.get('CUTIE_AMD_WINDOW', '4'))
-WINDOW_LEAD = int(os.environ.get('CUTIE_AMD_WINDOW_LEAD', '1'))
+WINDOW = int(os.environ.get('CUTIE_AMD_WINDOW', '8'))
+WINDOW_LEAD = int(os.environ.get('CUTIE_AMD_WINDOW_LEAD', '2'))
 
 
 def pad_geometry(h, w, d=16):

@@ -1,7 +1,7 @@
 """Look-ahead frame: is the main stream device-bound or waiting (for launches / for the side stream)?  From a rocprofv3 --kernel-trace CSV
 of bench.py: frames are cut at query_init2_kernel (one per frame, main stream); for the frames [f0, f1) the main queue's busy time, its
 idle gaps by the kernel that FOLLOWS the gap, and the side queue's busy time per frame.
-    python tools/trace_gaps.py <kernel_trace.csv> f0 f1"""
+    python tools/trace_gaps.py <kernel_trace.csv> f0 f1 [--dump f]      (--dump f: every launch of frame f on the main queue: gap before, duration)"""
 import csv, sys
 from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -36,3 +36,23 @@ for k in side:
     w = [x for x in q[k] if t0 <= x[0] < t1]
     if w:
         print(f'queue {k}: {len(w) / nf:.1f} launches per frame, busy {sum(e - s for s, e, _ in w) / nf / 1e3:.1f} us per frame')
+
+if '--dump' in sys.argv:
+    f = int(sys.argv[sys.argv.index('--dump') + 1])
+    a, b = marks[f], marks[f + 1]
+    win = [x for x in mq if a <= x[0] < b]
+    prev = None
+    print(f'--- main queue, frame {f}: {(b - a) / 1e3:.1f} us, {len(win)} launches (gap before | duration | kernel)')
+    agg = defaultdict(lambda: [0, 0, 0])
+    for s_, e_, n_ in win:
+        g = 0 if prev is None else s_ - prev
+        print(f'  {g / 1e3:7.2f} {(e_ - s_) / 1e3:8.2f}  {n_}')
+        agg[n_][0] += 1; agg[n_][1] += e_ - s_; agg[n_][2] += max(g, 0)
+        prev = e_
+    print('--- by kernel: launches, busy us, gaps-before us')
+    for n_, (c, d, g) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f'  {c:3d} {d / 1e3:8.1f} {g / 1e3:7.1f}  {n_}')
+    for k in side:
+        w = [x for x in q[k] if a <= x[0] < b]
+        if w:
+            print(f'--- queue {k} during frame {f}: {len(w)} launches, busy {sum(e - s for s, e, _ in w) / 1e3:.1f} us, first at +{(w[0][0] - a) / 1e3:.1f} us, last ends +{(w[-1][1] - a) / 1e3:.1f} us')
