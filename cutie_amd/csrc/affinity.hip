@@ -317,6 +317,230 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
     }
 }
 
+// ---- AFF_SCORE with 64 queries per wave (round 4; i[12] == 4) ---------------------------------------------------------------------
+// Why: in aff_score_kernel<2, *> one set of 8 A-fragment reads (8 KB per wave and tile) feeds 24 MFMAs; with the two resident blocks of
+// a CU that is 0.67 LDS-port cycles per MFMA cycle before the ds_write staging (+25 %) and the bank conflicts (0.23 of the accesses,
+// profiles/r03_summary.json): the loop ran at the LDS port, not at the matrix pipe (MFMA utilisation 0.33).  Here
+//   * a wave owns FOUR 16-query column sets (its B fragments: 128 VGPRs, loaded straight from global in fragment layout -- one
+//     round trip, together with the first A group), so the same 8 reads feed 48 MFMAs and a 256-query block streams the memory
+//     operand 7 times per frame instead of 13;
+//   * the A tiles go L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB = 4 rows per instruction, the XOR swizzle applied to the
+//     per-lane SOURCE chunk as in conv_dma.hip): no staging registers, no ds_write traffic, 8 DMA instructions per wave and group
+//     instead of 8 loads + 8 ds_writes per THREAD;
+//   * same arithmetic per (tile, query set) as aff_score_kernel: -c_j as the accumulator's start, cross terms first, one fma per score.
+typedef __amdgpu_buffer_rsrc_t aff_rsrc_t;
+#define AF4_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define AF4_STAGE (2 * 64 * 256)                      // [hi | lo] x 64 rows x 256 B
+#define AF4_LDS_BYTES (2 * AF4_STAGE + AFF_LCAP * 12 + 16 + 2 * 2 * 64 * 4)
+typedef const __attribute__((address_space(1))) au32x4* aff_gptr16;
+
+template <int AFF_MODE>
+__global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr int mode = AFF_MODE, NQ = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char aff_smem[];
+    int* l_j = reinterpret_cast<int*>(aff_smem + 2 * AF4_STAGE);
+    int* l_idx = l_j + AFF_LCAP;
+    float* l_val = reinterpret_cast<float*>(l_idx + AFF_LCAP);
+    int* l_n = reinterpret_cast<int*>(l_val + AFF_LCAP);
+    float (*lsc)[64] = reinterpret_cast<float (*)[64]>(l_n + 4);        // [stage][row of the group]: scale_i (0 for padding rows)
+    float (*lpad)[64] = lsc + 2;                                        // [stage][row]: 0, or -inf for padding rows
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx, by;                                                         // XCD-aware mapping: consecutive logical blocks share the token chunk
+    {
+        const int nb = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = id & 7, kq = id >> 3, q = nb >> 3, r = nb & 7;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kq;
+        by = logical / (int)gridDim.x;
+        bx = logical - by * (int)gridDim.x;
+    }
+    const int g0 = by * p.tiles_per_block;
+    const int g1 = min(g0 + p.tiles_per_block, p.G);
+    const int T0 = (p.rn[0] + 15) >> 4, T1 = (p.nranges > 1) ? ((p.rn[1] + 15) >> 4) : 0;
+    auto tile_slot = [&](int g, int& slot0, int& nvalid) {              // token slot of the first row / valid rows of tile g (wave-uniform)
+        int start, n, lt;
+        if (g < T0) { lt = g; start = p.rs[0]; n = p.rn[0]; }
+        else if (g < T0 + T1) { lt = g - T0; start = p.rs[1]; n = p.rn[1]; }
+        else { lt = g - T0 - T1; start = p.rs[2]; n = p.rn[2]; }
+        slot0 = start + lt * 16;
+        nvalid = min(16, n - lt * 16);
+    };
+    const aff_rsrc_t rhi = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.Ahi), 0, 0x7fffffff, 0x00020000);
+    const aff_rsrc_t rlo = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.Alo), 0, 0x7fffffff, 0x00020000);
+    float st_sc = 0.f, st_pad = 0.f;
+    f32x4 gq[NQ];                                                       // pass-0 maxima of the NEXT group's 4 tiles (mode 1 + skip)
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) gq[u] = (f32x4){INFINITY, INFINITY, INFINITY, INFINITY};
+    const bool skip = mode == 1 && (p.mode & 2);                        // pass-0 maxima available: skip tiles without candidates
+    const float* tau_p = p.gmax_or_tau;
+    const float* gmax_p = p.gmax_or_tau - (long)p.HWp * p.Gld;
+    const int wq0 = bx * 256 + wave * 64;                               // first query of this wave
+    const bool wave_on = wq0 < p.HWp;                                   // (the last query block may be half empty: such waves only stage)
+    int jq[NQ];
+    bool jvalid[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) { jq[u] = wq0 + u * 16 + l15; jvalid[u] = jq[u] < p.HW; }
+    // wave w stages tile w of a group: 4 + 4 DMA pieces of 4 rows x 256 B; lane -> (row pc * 4 + (lane >> 4), chunk position lane & 15),
+    // which holds source chunk (lane & 15) ^ row (the fragment reads apply the same XOR)
+// s_waitcnt vmcnt(0) lgkmcnt(0) + raw s_barrier.  Explicit: hipcc does not count an LDS-DMA as something a __syncthreads() has to
+// wait for (it emitted vmcnt(32) here: only the loads it knows the LDS readers depend on), see conv_dma.hip WAIT_VMCNT_LDS.
+#define AF4_SYNC() { __builtin_amdgcn_s_waitcnt(0x0070); asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+#define AF4_PIECE(PC)                                                                                      \
+        {                                                                                                  \
+            const int rr_ = (PC) * 4 + l4;                                                                 \
+            const unsigned vo_ = (unsigned)(min(rr_, nv_ - 1) * 256 + ((l15 ^ rr_) << 4));                 \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rhi, AF4_LDS_PTR(dst_), 16, vo_, so_, (PC) * 1024, 0);  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rlo, AF4_LDS_PTR(dst_ + 16384), 16, vo_, so_, (PC) * 1024, 0); \
+        }
+#define AF4_LOAD(GRP, STG)                                                                                 \
+    {                                                                                                      \
+        int gt_ = (GRP) + wave;                                                                            \
+        gt_ = gt_ < g1 ? gt_ : g1 - 1;                         /* clamp: rows of missing tiles are never used */ \
+        int slot0_, nv_;                                                                                   \
+        tile_slot(gt_, slot0_, nv_);                                                                       \
+        const unsigned so_ = (unsigned)slot0_ * 256u;                                                      \
+        unsigned char* const dst_ = aff_smem + (STG) * AF4_STAGE + wave * 4096;                            \
+        AF4_PIECE(0) AF4_PIECE(1) AF4_PIECE(2) AF4_PIECE(3)                                                \
+        const bool rv_ = l15 < nv_;                                                                        \
+        const float scl_ = p.scale[slot0_ + min(l15, nv_ - 1)];      /* unconditional (clamped) load, then a select */ \
+        st_sc = rv_ ? scl_ : 0.f;                                                                          \
+        st_pad = rv_ ? 0.f : -INFINITY;                                                                    \
+        if (skip && wave_on) {                                                                             \
+            _Pragma("unroll") for (int u = 0; u < NQ; ++u)                                                 \
+                gq[u] = *reinterpret_cast<const f32x4*>(gmax_p + (long)min(jq[u], p.HWp - 1) * p.Gld + (GRP)); \
+        }                                                                                                  \
+    }
+    AF4_LOAD(g0, 0);
+    // B fragments of the wave's 64 queries, straight into registers (fragment layout: lane = (query l15, k chunk ks * 4 + l4))
+    bf16x8 bh[NQ][4], bl[NQ][4];
+    float ncj[NQ], thr[NQ];
+    {
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const long row = min(jq[u], p.HWp - 1);                     // B rows exist up to HWp
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bh[u][ks] = __builtin_bit_cast(bf16x8, *(aff_gptr16)(p.Bhi + row * 128 + (ks * 4 + l4) * 8));
+                bl[u][ks] = __builtin_bit_cast(bf16x8, *(aff_gptr16)(p.Blo + row * 128 + (ks * 4 + l4) * 8));
+            }
+            const float cj = p.c[min(jq[u], p.HWp - 1)];               // (c has HWp entries; unconditional loads, selects afterwards)
+            ncj[u] = jvalid[u] ? -cj : 0.f;
+            thr[u] = INFINITY;
+            if (mode == 1) {
+                const float tau = tau_p[min(jq[u], p.HW - 1)];
+                thr[u] = jvalid[u] ? tau - fabsf(tau) * 1e-6f - 1e-30f : INFINITY;     // never lose the k-th element to 1 ulp
+            }
+        }
+    }
+    int* wl_j = l_j + wave * AFF_WCAP; int* wl_idx = l_idx + wave * AFF_WCAP; float* wl_val = l_val + wave * AFF_WCAP;
+    int wcount = 0;                                                     // wave-uniform fill of the wave's list
+    f32x4 gcur[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) gcur[u] = gq[u];
+    if (l4 == 0) { lsc[0][wave * 16 + l15] = st_sc; lpad[0][wave * 16 + l15] = st_pad; }
+    int buf = 0;
+    for (int gg = g0; gg < g1; gg += AFF_TG) {
+        AF4_SYNC();                                                     // group gg has landed (vmcnt(0)); everybody is done with the other stage
+        const bool more = gg + AFF_TG < g1;
+        if (more) AF4_LOAD(gg + AFF_TG, buf ^ 1);
+        const au32x4* const lA = reinterpret_cast<const au32x4*>(aff_smem + buf * AF4_STAGE);
+        float gm[NQ][AFF_TG];
+        if (wave_on) {
+#pragma unroll
+            for (int t = 0; t < AFF_TG; ++t) {
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) gm[u][t] = -INFINITY;
+                const int g = gg + t;
+                if (g < g1) {                                           // block-uniform
+                    bool need[NQ];
+                    bool any = false;
+#pragma unroll
+                    for (int u = 0; u < NQ; ++u) {
+                        need[u] = !skip || __ballot(jvalid[u] && gcur[u][t] >= thr[u]) != 0;      // wave-uniform
+                        any |= need[u];
+                    }
+                    if (any) {
+                        int slot0 = 0, nvalid = 0;
+                        if (mode == 1) tile_slot(g, slot0, nvalid);
+                        const int row = t * 16 + l15;
+                        bf16x8 ah[4], al[4];
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            ah[ks] = __builtin_bit_cast(bf16x8, lA[row * 16 + ((ks * 4 + l4) ^ l15)]);
+                            al[ks] = __builtin_bit_cast(bf16x8, lA[1024 + row * 16 + ((ks * 4 + l4) ^ l15)]);
+                        }
+                        // lane holds tokens l4*4 + q (q = 0..3) of the tile for its query
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(&lsc[buf][t * 16 + l4 * 4]);
+                        const f32x4 pd = *reinterpret_cast<const f32x4*>(&lpad[buf][t * 16 + l4 * 4]);
+#pragma unroll
+                        for (int u = 0; u < NQ; ++u) {
+                            if (mode == 1 && !need[u]) continue;
+                            f32x4 acc = {ncj[u], ncj[u], ncj[u], ncj[u]};
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks) {            // small cross terms first
+                                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bl[u][ks], acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], bh[u][ks], acc, 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bh[u][ks], acc, 0, 0, 0);
+                            float s[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) s[q] = fmaf(sc[q], acc[q], pd[q]);      // scale_i (A.B - c_j), -inf on padding rows
+                            const float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+                            if (mode == 0) {
+                                gm[u][t] = rows_max(mx);
+                            } else if (__ballot(jvalid[u] && mx >= thr[u])) {   // wave-uniform: some lane has a candidate in this tile
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const bool hit = jvalid[u] && s[q] >= thr[u] && s[q] > -INFINITY;
+                                    const unsigned long long m = __ballot(hit);
+                                    if (m) {
+                                        const int pos = wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                        if (hit) {
+                                            const int tok = slot0 + l4 * 4 + q;
+                                            if (pos < AFF_WCAP) { wl_j[pos] = jq[u]; wl_idx[pos] = tok; wl_val[pos] = s[q]; }
+                                            else {                          // wave list full: straight to the global list
+                                                const int gp = atomicAdd(&p.count[jq[u] * AFF_CSTRIDE], 1);
+                                                if (gp < p.cap) { p.cand_val[(long)jq[u] * p.cap + gp] = s[q]; p.cand_idx[(long)jq[u] * p.cap + gp] = tok; }
+                                            }
+                                        }
+                                        wcount += __popcll(m);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (mode == 0 && l4 == 0) {                               // 4 tile maxima per query: one 16-B store
+#pragma unroll
+                for (int u = 0; u < NQ; ++u)
+                    if (jq[u] < p.HWp)
+                        *reinterpret_cast<f32x4*>(p.gmax_or_tau + (long)jq[u] * p.Gld + gg) = (f32x4){gm[u][0], gm[u][1], gm[u][2], gm[u][3]};
+            }
+        }
+        if (more) {
+            if (l4 == 0) { lsc[buf ^ 1][wave * 16 + l15] = st_sc; lpad[buf ^ 1][wave * 16 + l15] = st_pad; }
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) gcur[u] = gq[u];
+        }
+        buf ^= 1;
+    }
+#undef AF4_LOAD
+#undef AF4_PIECE
+#undef AF4_SYNC
+    if (mode == 1) {                                                    // flush this wave's candidates: one dense burst of global atomics
+        const int n = min(wcount, AFF_WCAP);
+        for (int e = lane; e < n; e += 64) {
+            const int j = wl_j[e];
+            const int pos = atomicAdd(&p.count[j * AFF_CSTRIDE], 1);
+            if (pos < p.cap) { p.cand_val[(long)j * p.cap + pos] = wl_val[e]; p.cand_idx[(long)j * p.cap + pos] = wl_idx[e]; }
+        }
+    }
+#endif
+}
+
 __device__ __forceinline__ uint32_t f2key(float f) {
     uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -545,15 +769,17 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             int G = 0;
             for (int r = 0; r < 3; ++r) G += (sp.rn[r] + 15) / 16;
             if (G != sp.G || (sp.HWp & 63) || sp.nranges < 1 || sp.nranges > 3 || (sp.Gld & 3)) { cutie_set_error("aff_score: bad ranges (G=%d vs %d, HWp=%d)", G, sp.G, sp.HWp); return -2; }
-            const int nq = i[12] == 1 ? 1 : 2;
+            const int nq = i[12] == 1 ? 1 : (i[12] == 4 ? 4 : 2);
             int qb = (sp.HWp + 64 * nq - 1) / (64 * nq);
             if (sp.mode != 0 && sp.mode != 1) { cutie_set_error("aff_score: mode %d", sp.mode); return -2; }
             const int pass = sp.mode;
             if (pass == 1 && (op->flags & 1)) sp.mode |= 2;     // pass-0 maxima precede tau in memory: tiles without candidates are skipped
             static bool lds_attr_set = false;
             if (!lds_attr_set) {
-                const void* ks[4] = {reinterpret_cast<const void*>(aff_score_kernel<1, 0>), reinterpret_cast<const void*>(aff_score_kernel<1, 1>),
-                                     reinterpret_cast<const void*>(aff_score_kernel<2, 0>), reinterpret_cast<const void*>(aff_score_kernel<2, 1>)};
+                const void* ks[6] = {reinterpret_cast<const void*>(aff_score_kernel<1, 0>), reinterpret_cast<const void*>(aff_score_kernel<1, 1>),
+                                     reinterpret_cast<const void*>(aff_score_kernel<2, 0>), reinterpret_cast<const void*>(aff_score_kernel<2, 1>),
+                                     reinterpret_cast<const void*>(aff_score4_kernel<0>), reinterpret_cast<const void*>(aff_score4_kernel<1>)};
+                static_assert(AF4_LDS_BYTES == AFF_LDS_BYTES, "one dynamic-LDS size for all score kernels");
                 for (const void* k : ks)
                     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, AFF_LDS_BYTES) != hipSuccess) {
                         cutie_set_error("aff_score: cannot raise the dynamic LDS limit to %d bytes", AFF_LDS_BYTES);
@@ -563,13 +789,16 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             }
             // ~2 resident blocks per CU (512 blocks), at least 8 tiles per block: the block prologue (its query operand,
             // 64 KB through LDS) is amortised over the tiles, measured best around 16 tiles at 11k tokens x 1620 queries
-            int tpb = (int)(((long)G * qb + 511) / 512);
+            const int resident = (nq == 4 && pass == 1) ? 256 : 512;    // (aff_score4_kernel<1> needs > 256 registers: one block per CU)
+            int tpb = (int)(((long)G * qb + resident - 1) / resident);
             if (tpb < 8) tpb = 8;
             if (i[13] > 0) tpb = i[13];                          // (tuning override: tiles per block)
             tpb = (tpb + AFF_TG - 1) / AFF_TG * AFF_TG;
             sp.tiles_per_block = tpb;
             const dim3 grid(qb, (G + tpb - 1) / tpb);
-            if (nq == 1 && pass == 0) hipLaunchKernelGGL((aff_score_kernel<1, 0>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
+            if (nq == 4 && pass == 0) hipLaunchKernelGGL((aff_score4_kernel<0>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
+            else if (nq == 4) hipLaunchKernelGGL((aff_score4_kernel<1>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
+            else if (nq == 1 && pass == 0) hipLaunchKernelGGL((aff_score_kernel<1, 0>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
             else if (nq == 1) hipLaunchKernelGGL((aff_score_kernel<1, 1>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
             else if (pass == 0) hipLaunchKernelGGL((aff_score_kernel<2, 0>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
             else hipLaunchKernelGGL((aff_score_kernel<2, 1>), grid, dim3(256), AFF_LDS_BYTES, s, sp);

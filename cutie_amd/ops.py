@@ -554,16 +554,19 @@ class OpList:
 
     AFF_CSTRIDE = 32          # ints between the candidate counters of consecutive queries (one cache line each)
 
-    def aff_score(self, Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count, *, HW, HWp, ranges, cap, mode, gmax_precedes_tau=False):
+    AFF_NQ = int(os.environ.get('CUTIE_AMD_AFF_NQ', '4'))      # 16-query column sets per wave of AFF_SCORE (1, 2: aff_score_kernel; 4: aff_score4_kernel)
+
+    def aff_score(self, Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count, *, HW, HWp, ranges, cap, mode, gmax_precedes_tau=False, nq=None):
         """gmax_precedes_tau (mode 1): `out` (= tau) sits right behind the [HWp, Gld] maxima of pass 0 in memory; the kernel then
-        skips every (tile, 16-query set) that cannot hold a candidate."""
+        skips every (tile, 16-query set) that cannot hold a candidate.  nq: query column sets per wave (default AFF_NQ; every
+        choice computes the same bits)."""
         ranges = [(s, n) for (s, n) in ranges if n > 0]
         assert 1 <= len(ranges) <= 3
         G = sum(-(-n // 16) for _, n in ranges)
         ints = [HW, HWp, len(ranges)]
         for r in range(3):
             ints += list(ranges[r]) if r < len(ranges) else [0, 0]
-        ints += [G, cap, mode]
+        ints += [G, cap, mode, self.AFF_NQ if nq is None else nq]
         return self.add(AFF_SCORE, 1 if (gmax_precedes_tau and mode == 1) else 0, ints, [], [Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count])
 
     def aff_select(self, gmax, tau, *, HW, HWp, G, top_k, clear_count=None, ticks=(), zero=None):

@@ -941,7 +941,7 @@ def test_summarize_add_pe():
 
 
 # ---- affinity pipeline ---------------------------------------------------------------------------------------
-def _affinity_build(HW, ranges, slots, K, top_k, with_usage, dup=False, skip=True):
+def _affinity_build(HW, ranges, slots, K, top_k, with_usage, dup=False, skip=True, nq=None):
     def build(dev, g):
         CV, cap = 256, 1024
         HWp = -(-HW // 64) * 64
@@ -975,13 +975,13 @@ def _affinity_build(HW, ranges, slots, K, top_k, with_usage, dup=False, skip=Tru
             count += 5
         else:
             ol.memset32(count, HW * 32, 0)
-        ol.aff_score(Ahi, Alo, scale, Bhi, Blo, cq, gmax, None, None, None, mode=0, **common)
+        ol.aff_score(Ahi, Alo, scale, Bhi, Blo, cq, gmax, None, None, None, mode=0, nq=nq, **common)
         if skip:
             ol.aff_select(gmax, tau, HW=HW, HWp=HWp, G=G, top_k=top_k, clear_count=count,
                           ticks=[(life[8:], slots // 2), (life, 5)])
         else:
             ol.aff_select(gmax, tau, HW=HW, HWp=HWp, G=G, top_k=top_k)
-        ol.aff_score(Ahi, Alo, scale, Bhi, Blo, cq, tau, cval, cidx, count, mode=1, gmax_precedes_tau=skip, **common)
+        ol.aff_score(Ahi, Alo, scale, Bhi, Blo, cq, tau, cval, cidx, count, mode=1, gmax_precedes_tau=skip, nq=nq, **common)
         ol.aff_readout(cval, cidx, count, vptrs, usage, y, ovf, HW=HW, cap=cap, top_k=top_k, K=K, CV=CV)
         outs = {'Ahi': Ahi, 'Alo': Alo, 'scale': scale, 'Bhi': Bhi, 'Blo': Blo, 'cq': cq, 'tau': tau, 'y': y, 'ovf': ovf,
                 'gmax': gmax[:HW, :G], 'count': count.view(HW, 32)[:, 0], 'life': life}
@@ -1000,10 +1000,13 @@ def _affinity_build(HW, ranges, slots, K, top_k, with_usage, dup=False, skip=Tru
     dict(HW=1620, ranges=[(0, 300), (1000, 1620), (3000, 4000)], slots=7100, K=2, top_k=30, usage=True),
     dict(HW=48, ranges=[(0, 48)], slots=48, K=3, top_k=30, usage=True),               # G < top_k
     dict(HW=100, ranges=[(0, 1003)], slots=1003, K=1, top_k=5, usage=False),           # ragged tail tile
+    dict(HW=1620, ranges=[(0, 2000), (2100, 1620), (4000, 8097)], slots=12200, K=3, top_k=30, usage=True),   # the bench's size class; half-empty last 256-query block
+    dict(HW=700, ranges=[(16, 37), (64, 5)], slots=100, K=2, top_k=30, usage=False),   # three tiles, two of them ragged (G < top_k)
 ])
 @pytest.mark.parametrize('skip', [True, False])
-def test_affinity_pipeline(case, skip):
-    build = _affinity_build(case['HW'], case['ranges'], case['slots'], case['K'], case['top_k'], case['usage'], skip=skip)
+@pytest.mark.parametrize('nq', [1, 2, 4])
+def test_affinity_pipeline(case, skip, nq):
+    build = _affinity_build(case['HW'], case['ranges'], case['slots'], case['K'], case['top_k'], case['usage'], skip=skip, nq=nq)
     hip, ref = run_both(build, seed=7)
     exact = ['Ahi', 'Alo', 'Bhi', 'Blo']
     for k in exact:
