@@ -330,6 +330,7 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
 //   * same arithmetic per (tile, query set) as aff_score_kernel: -c_j as the accumulator's start, cross terms first, one fma per score.
 typedef __amdgpu_buffer_rsrc_t aff_rsrc_t;
 #define AF4_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define AF4_PRE 4096
 #define AF4_STAGE (2 * 64 * 256)                      // [hi | lo] x 64 rows x 256 B
 #define AF4_LDS_BYTES (2 * AF4_STAGE + AFF_LCAP * 12 + 16 + 2 * 2 * 64 * 4)
 typedef const __attribute__((address_space(1))) au32x4* aff_gptr16;
@@ -366,9 +367,10 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
         slot0 = start + lt * 16;
         nvalid = min(16, n - lt * 16);
     };
-    const aff_rsrc_t rhi = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.Ahi), 0, 0x7fffffff, 0x00020000);
-    const aff_rsrc_t rlo = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.Alo), 0, 0x7fffffff, 0x00020000);
-    float st_sc = 0.f, st_pad = 0.f;
+    const aff_rsrc_t rhi = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(const_cast<bf16_t*>(p.Ahi)) - AF4_PRE, 0, 0x7fffffff, 0x00020000);
+    const aff_rsrc_t rlo = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(const_cast<bf16_t*>(p.Alo)) - AF4_PRE, 0, 0x7fffffff, 0x00020000);
+    float st_sc = 0.f;
+    int st_nv = 0;
     f32x4 gq[NQ];                                                       // pass-0 maxima of the NEXT group's 4 tiles (mode 1 + skip)
 #pragma unroll
     for (int u = 0; u < NQ; ++u) gq[u] = (f32x4){INFINITY, INFINITY, INFINITY, INFINITY};
@@ -389,7 +391,9 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
 #define AF4_PIECE(PC)                                                                                      \
         {                                                                                                  \
             const int rr_ = (PC) * 4 + l4;                                                                 \
-            const unsigned vo_ = (unsigned)(min(rr_, nv_ - 1) * 256 + ((l15 ^ rr_) << 4));                 \
+            /* (the instruction offset PC * 1024 moves the LDS address AND the global one: taken out of the latter again; the */ \
+            /* descriptors start AF4_PRE bytes in front of the banks so that the offset of a clamped row stays positive) */ \
+            const unsigned vo_ = (unsigned)(min(rr_, nv_ - 1) * 256 + ((l15 ^ rr_) << 4) + (AF4_PRE - (PC) * 1024)); \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rhi, AF4_LDS_PTR(dst_), 16, vo_, so_, (PC) * 1024, 0);  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rlo, AF4_LDS_PTR(dst_ + 16384), 16, vo_, so_, (PC) * 1024, 0); \
         }
@@ -401,11 +405,11 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
         tile_slot(gt_, slot0_, nv_);                                                                       \
         const unsigned so_ = (unsigned)slot0_ * 256u;                                                      \
         unsigned char* const dst_ = aff_smem + (STG) * AF4_STAGE + wave * 4096;                            \
+        /* the per-token scale: an unconditional (clamped) load whose value is looked at only where it is written to LDS, one */ \
+        /* group later (a select right here made hipcc wait -- vmcnt(0) -- in the middle of the DMA pieces) */ \
+        st_sc = p.scale[slot0_ + min(l15, nv_ - 1)];                                                       \
+        st_nv = nv_;                                                                                       \
         AF4_PIECE(0) AF4_PIECE(1) AF4_PIECE(2) AF4_PIECE(3)                                                \
-        const bool rv_ = l15 < nv_;                                                                        \
-        const float scl_ = p.scale[slot0_ + min(l15, nv_ - 1)];      /* unconditional (clamped) load, then a select */ \
-        st_sc = rv_ ? scl_ : 0.f;                                                                          \
-        st_pad = rv_ ? 0.f : -INFINITY;                                                                    \
         if (skip && wave_on) {                                                                             \
             _Pragma("unroll") for (int u = 0; u < NQ; ++u)                                                 \
                 gq[u] = *reinterpret_cast<const f32x4*>(gmax_p + (long)min(jq[u], p.HWp - 1) * p.Gld + (GRP)); \
@@ -438,20 +442,29 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
     f32x4 gcur[NQ];
 #pragma unroll
     for (int u = 0; u < NQ; ++u) gcur[u] = gq[u];
-    if (l4 == 0) { lsc[0][wave * 16 + l15] = st_sc; lpad[0][wave * 16 + l15] = st_pad; }
+    if (l4 == 0) { lsc[0][wave * 16 + l15] = l15 < st_nv ? st_sc : 0.f; lpad[0][wave * 16 + l15] = l15 < st_nv ? 0.f : -INFINITY; }
     int buf = 0;
+    f32x4* const gmh = reinterpret_cast<f32x4*>(l_j);                   // [256 queries]: the maxima of the group just computed (mode 0)
+    float* const gmf = reinterpret_cast<float*>(l_j);
+#define AF4_FLUSH(GRP)                                                                                     \
+    if (wave_on && l4 == 0) {                                                                              \
+        _Pragma("unroll") for (int u = 0; u < NQ; ++u)                                                     \
+            if (jq[u] < p.HWp) *reinterpret_cast<f32x4*>(p.gmax_or_tau + (long)jq[u] * p.Gld + (GRP)) = gmh[wave * 64 + u * 16 + l15]; \
+    }
     for (int gg = g0; gg < g1; gg += AFF_TG) {
         AF4_SYNC();                                                     // group gg has landed (vmcnt(0)); everybody is done with the other stage
         const bool more = gg + AFF_TG < g1;
         if (more) AF4_LOAD(gg + AFF_TG, buf ^ 1);
+        if (mode == 0 && gg > g0) AF4_FLUSH(gg - AFF_TG);
         const au32x4* const lA = reinterpret_cast<const au32x4*>(aff_smem + buf * AF4_STAGE);
-        float gm[NQ][AFF_TG];
         if (wave_on) {
 #pragma unroll
             for (int t = 0; t < AFF_TG; ++t) {
-#pragma unroll
-                for (int u = 0; u < NQ; ++u) gm[u][t] = -INFINITY;
                 const int g = gg + t;
+                if (mode == 0 && g >= g1 && l4 == 0) {                  // (a tile past the block's range: -inf, as aff_score_kernel stores)
+#pragma unroll
+                    for (int u = 0; u < NQ; ++u) gmf[(wave * 64 + u * 16 + l15) * 4 + t] = -INFINITY;
+                }
                 if (g < g1) {                                           // block-uniform
                     bool need[NQ];
                     bool any = false;
@@ -489,7 +502,8 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
                             for (int q = 0; q < 4; ++q) s[q] = fmaf(sc[q], acc[q], pd[q]);      // scale_i (A.B - c_j), -inf on padding rows
                             const float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
                             if (mode == 0) {
-                                gm[u][t] = rows_max(mx);
+                                const float m_ = rows_max(mx);
+                                if (l4 == 0) gmf[(wave * 64 + u * 16 + l15) * 4 + t] = m_;      // parked in LDS until AF4_FLUSH
                             } else if (__ballot(jvalid[u] && mx >= thr[u])) {   // wave-uniform: some lane has a candidate in this tile
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
@@ -513,20 +527,23 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
                     }
                 }
             }
-            if (mode == 0 && l4 == 0) {                               // 4 tile maxima per query: one 16-B store
-#pragma unroll
-                for (int u = 0; u < NQ; ++u)
-                    if (jq[u] < p.HWp)
-                        *reinterpret_cast<f32x4*>(p.gmax_or_tau + (long)jq[u] * p.Gld + gg) = (f32x4){gm[u][0], gm[u][1], gm[u][2], gm[u][3]};
-            }
+            // 4 tile maxima per query = one 16-B global store -- issued one iteration LATER (AF4_FLUSH): the barrier at the top of
+            // the loop waits with vmcnt(0) for this group's DMA, and a store issued here would be waited for as well (a write round trip
+            // per group: measured 3.5 us per group against 1.3 us of MFMA).  The maxima wait in the (mode-1 only) candidate-list area.
         }
         if (more) {
-            if (l4 == 0) { lsc[buf ^ 1][wave * 16 + l15] = st_sc; lpad[buf ^ 1][wave * 16 + l15] = st_pad; }
+            if (l4 == 0) { lsc[buf ^ 1][wave * 16 + l15] = l15 < st_nv ? st_sc : 0.f; lpad[buf ^ 1][wave * 16 + l15] = l15 < st_nv ? 0.f : -INFINITY; }
 #pragma unroll
             for (int u = 0; u < NQ; ++u) gcur[u] = gq[u];
         }
         buf ^= 1;
     }
+    if (mode == 0 && g1 > g0) {                                         // the last group's maxima (each lane reads back what it wrote)
+        __builtin_amdgcn_s_waitcnt(0xc07f);                             // lgkmcnt(0)
+        const int last = g0 + ((g1 - g0 - 1) / AFF_TG) * AFF_TG;
+        AF4_FLUSH(last);
+    }
+#undef AF4_FLUSH
 #undef AF4_LOAD
 #undef AF4_PIECE
 #undef AF4_SYNC
@@ -651,6 +668,7 @@ typedef __attribute__((ext_vector_type(4))) int ro_i32x4;
 // gather with every LDS read of the selection lists)
 typedef const __attribute__((address_space(1))) ro_u32x4* ro_gptr;
 #define RO_MAXK 64
+#define RO_PRUNE 64                                    // lists longer than this are cut to the entries >= the top_k-th value before ranking
 // one block per query column
 __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
                                                                  const int* __restrict__ count, const uint64_t* __restrict__ vptrs,
@@ -662,6 +680,8 @@ __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __
     __shared__ __attribute__((aligned(16))) float sel_v[RO_MAXK];
     __shared__ __attribute__((aligned(16))) int sel_i[RO_MAXK];
     __shared__ __attribute__((aligned(16))) float sel_w[RO_MAXK];
+    __shared__ uint32_t prune_key;
+    __shared__ int prune_n;
     // XCD-aware: hardware block b runs on XCD b % 8; give each XCD one contiguous stripe of queries (neighbouring pixels
     // select overlapping memory tokens, so a stripe's value rows stay in that XCD's L2 instead of all 8 L2s fetching all)
     const int per = (HW + 7) >> 3;
@@ -687,16 +707,59 @@ __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __
     // padding / unassigned ranks: any valid slot (gathered with weight 0)
     if (tid < RO_MAXK) { sel_v[tid] = -INFINITY; sel_i[tid] = cnt > 0 ? first : 0; sel_w[tid] = 0.f; }
     __syncthreads();
+    // Long lists are cut first.  The threshold of pass 1 is the top_k-th largest TILE maximum, so a query whose best tiles are
+    // homogeneous brings hundreds of candidates (measured on the bench clip: median 32, 1 % of the queries ~270) and the all-pairs
+    // ranking below is quadratic: those few blocks were the kernel (49 us; 17 us with every list cut to 64, tools/aff_ab.py).
+    // Wave 0 finds the exact top_k-th largest VALUE of the list (bitwise construction on order-preserving keys, as aff_select_reg_kernel),
+    // the block keeps the entries >= it (>= top_k of them, all ties included), and the ranking -- value descending, ties -> lower slot --
+    // runs on what is left: the same top_k in the same order.
+    int ncand = cnt, ncand4 = cnt4;
+    if (cnt > RO_PRUNE && cnt <= 1024) {                       // block-uniform
+        if (tid < 64) {
+            uint32_t key[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) key[r] = r * 64 + tid < cnt ? f2key(cv[min(r * 64 + tid, cnt - 1)]) : 0u;   // padding sorts below -inf
+            uint32_t x = 0;
+            for (int b = 31; b >= 0; --b) {
+                const uint32_t t = x | (1u << b);
+                int c = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c += key[r] >= t ? 1 : 0;
+                c = wave_sum_i32(c);
+                x = c >= nsel ? t : x;                         // wave-uniform
+            }
+            if (tid == 0) { prune_key = x; prune_n = 0; }
+        }
+        __syncthreads();
+        const uint32_t x = prune_key;
+        float mv[8]; int mi[8]; bool keep[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int t = tid + r * RO_THREADS, tc = min(t, cnt - 1);
+            mv[r] = cv[tc]; mi[r] = ci[tc];
+            keep[r] = t < cnt && f2key(mv[r]) >= x;
+        }
+        __syncthreads();                                       // everybody holds its entries: the list is rebuilt in place
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (keep[r]) { const int pos = atomicAdd(&prune_n, 1); cv[pos] = mv[r]; ci[pos] = mi[r]; }     // (order is irrelevant: ranked below)
+        __syncthreads();
+        ncand = prune_n;
+        ncand4 = (ncand + 3) & ~3;
+        if (tid < ncand4 - ncand) { cv[ncand + tid] = -INFINITY; ci[ncand + tid] = 0x7fffffff; }
+        __syncthreads();
+    }
     // exact rank of every candidate (descending value, ties -> lower slot); the lists are read 4 entries per ds_read_b128
-    for (int t = tid; t < cnt; t += RO_THREADS) {
+    // (bitwise | and &: the short-circuit forms compiled to a branch per entry)
+    for (int t = tid; t < ncand; t += RO_THREADS) {
         const float v = cv[t]; const int id = ci[t];
         int rank = 0;
 #pragma unroll 2
-        for (int u = 0; u < cnt4; u += 4) {
+        for (int u = 0; u < ncand4; u += 4) {
             const f32x4 w = *reinterpret_cast<const f32x4*>(cv + u);
             const ro_i32x4 d = *reinterpret_cast<const ro_i32x4*>(ci + u);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) rank += (w[e] > v) || (w[e] == v && d[e] < id);
+            for (int e = 0; e < 4; ++e) rank += (int)(w[e] > v) | ((int)(w[e] == v) & (int)(d[e] < id));
         }
         if (rank < nsel) { sel_v[rank] = v; sel_i[rank] = id; }
     }

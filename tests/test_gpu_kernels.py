@@ -941,11 +941,13 @@ def test_summarize_add_pe():
 
 
 # ---- affinity pipeline ---------------------------------------------------------------------------------------
-def _affinity_build(HW, ranges, slots, K, top_k, with_usage, dup=False, skip=True, nq=None):
+def _affinity_build(HW, ranges, slots, K, top_k, with_usage, dup=False, skip=True, nq=None, cluster=False):
     def build(dev, g):
         CV, cap = 256, 1024
         HWp = -(-HW // 64) * 64
         mkey = torch.randn((slots, 64), generator=g) * 0.8
+        if cluster:                                # runs of 16 nearly identical tokens: a query's best TILES are full of candidates
+            mkey = mkey[torch.arange(slots) // 16] + torch.randn((slots, 64), generator=g) * 1e-5
         if dup:                                    # duplicated memory frames -> exact score ties
             half = slots // 2
             mkey[half:2 * half] = mkey[:half]
@@ -1035,6 +1037,25 @@ def test_affinity_pipeline(case, skip, nq):
         u = torch.zeros_like(hip['usage'])
         u[slots] = usage
         assert float((hip['usage'] - u).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize('nq', [2, 4])
+def test_affinity_long_candidate_lists(nq):
+    """Homogeneous memory (runs of 16 nearly identical tokens): the tile-maximum threshold of pass 1 lets hundreds of candidates
+    through per query; AFF_READOUT cuts such lists to the entries >= the top_k-th value before it ranks them -- same top-k, same order
+    as the interpreter's full sort and as the dense reference."""
+    from oracle.net import get_similarity, topk_softmax
+    build = _affinity_build(700, [(0, 3000), (3200, 1000)], 4300, 2, 30, True, nq=nq, cluster=True)
+    hip, ref = run_both(build, seed=11)
+    assert int(hip['count'].max()) > 200 and int(hip['ovf']) == 0, int(hip['count'].max())
+    check({'y': hip['y']}, {'y': ref['y']}, 'aff long lists')
+    check({'usage': hip['usage']}, {'usage': ref['usage']}, 'aff long lists usage', rtol=1e-4)
+    slots = torch.cat([torch.arange(0, 3000), torch.arange(3200, 4200)])
+    sim = get_similarity(hip['_mkey'][slots].t().float(), hip['_mshr'][slots].float(), hip['_qkey'].t().float(), hip['_qsel'].t().float())
+    aff, _ = topk_softmax(sim, 30)
+    for o in range(2):
+        dense = (hip[f'_v{o}'][slots].float().t() @ aff).t()
+        assert float((hip['y'][o].float() - dense).abs().max()) < 2e-2 * float(dense.abs().max())
 
 
 def test_affinity_exact_ties_are_deterministic():

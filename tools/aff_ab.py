@@ -47,7 +47,40 @@ with torch.inference_mode(), torch.cuda.stream(torch.cuda.Stream()):
         a = affs.copy(); a['i'][0, 12] = n0; a['i'][2, 12] = n1
         s = stages(a)
         print('score0 nq %d, score1 nq %d: score0 %.2f  score1 %.2f | plan %.1f us' % (n0, n1, s[0], s[2], s[4]))
+    # what bounds the read-out?  without the usage atomics (p4 = 0), with one object instead of three (a third of the gather bytes),
+    # with top_k = 8 (a quarter of the rows, one gather round instead of two)
+    a = affs.copy(); base = t1(a[3:4])
+    a = affs.copy(); a['p'][3, 4] = 0; no_usage = t1(a[3:4])
+    a = affs.copy(); a['i'][3, 3] = 1; one_obj = t1(a[3:4])
+    a = affs.copy(); a['i'][3, 2] = 8; k8 = t1(a[3:4])
+    a = affs.copy(); a['i'][3, 2] = 8; a['p'][3, 4] = 0; a['i'][3, 3] = 1; mini = t1(a[3:4])
+    # the heavy tail of the candidate lists (1 % of the queries hold ~260 candidates): the same launch with every list cut to 40 / 32
     rec.ex.run(affs); torch.cuda.synchronize()
+    cnt_t = proc.memory._scratch['count']
+    for cut in (64, 40, 32):
+        c2 = cnt_t.clone().clamp_(max=cut)
+        a = affs.copy(); a['p'][3, 2] = c2.data_ptr()
+        print('readout with the candidate lists cut to <= %d: %.1f us' % (cut, t1(a[3:4])))
+    print('readout alone %.1f us | no usage atomics %.1f | K = 1 %.1f | top_k = 8 %.1f | K = 1, top_k = 8, no usage %.1f' % (base, no_usage, one_obj, k8, mini))
+    rec.ex.run(affs); torch.cuda.synchronize()
+    # overlap of the selected tokens between neighbouring queries: unique tokens among the top-30 of 16 consecutive queries (of 480)
+    sc = proc.memory._scratch
+    cv, ci, cn = sc['cand_val'].float().cpu(), sc['cand_idx'].cpu(), sc['count'].view(-1, 32)[:, 0].cpu()
+    uni, uni4 = [], []
+    sets = []
+    for j in range(cv.shape[0]):
+        n = int(cn[j])
+        v, i_ = cv[j, :n], ci[j, :n]
+        top = i_[torch.argsort(v, descending=True)[:30]]
+        sets.append(set(int(x) for x in top))
+    for j0 in range(0, len(sets) - 15, 16):
+        uni.append(len(set().union(*sets[j0:j0 + 16])))
+    W = proc.memory.W
+    for y in range(0, proc.memory.H - 3, 4):
+        for x in range(0, W - 3, 4):
+            uni4.append(len(set().union(*[sets[(y + dy) * W + x + dx] for dy in range(4) for dx in range(4)])))
+    print('unique selected tokens per 16 consecutive queries: mean %.1f max %d (of 480); per 4 x 4 pixel block: mean %.1f max %d' %
+          (sum(uni) / len(uni), max(uni), sum(uni4) / len(uni4), max(uni4)))
     for k, v in proc.memory._scratch.items():
         if 'count' in str(k):
             c = v.float().view(-1, 32)[:, 0]
