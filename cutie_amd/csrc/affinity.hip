@@ -88,6 +88,28 @@ typedef __attribute__((ext_vector_type(4))) unsigned int au32x4;
 //     one v_fma (was: compare, subtract, multiply, select);
 //   * pass 1 skips every (16-token tile, 16-query set) whose pass-0 maximum is below the set's thresholds (flags & 1: the gmax
 //     matrix of pass 0 precedes tau in memory): ~85 % of the MFMA work of the second pass.
+// Optional timeline (diagnostic library only: -DAFF_TIMELINE, tools/aff_timeline.py): s_memtime stamps of every wave of the logical
+// blocks 0 and nb / 2, parked in LDS (4 KB behind the maxima of mode 0: no VMEM traffic that would disturb the vmcnt waits) and copied
+// to p.cand_val (unused in mode 0; the tool hands in a buffer) when the wave ends.  Record: [count, stamps (cycles << 8 | id) ...].
+#ifdef AFF_TIMELINE
+#define ATL_MAX 120
+#define ATL_DECL(BASE) unsigned long long* const atl_ = reinterpret_cast<unsigned long long*>(BASE) + wave * ATL_MAX; int atn_ = 0;
+#define ATL(ID) { if (atn_ < ATL_MAX) { const unsigned long long t_ = (__builtin_readcyclecounter() << 8) | (unsigned)(ID); if ((threadIdx.x & 63) == 0) atl_[atn_] = t_; ++atn_; } }
+#define ATL_DUMP(LOGICAL, NB)                                                                              \
+    {                                                                                                      \
+        const int slot_ = (LOGICAL) == 0 ? 0 : (LOGICAL) == (NB) / 2 ? 1 : -1;                             \
+        if (slot_ >= 0 && p.cand_val) {                                                                    \
+            __builtin_amdgcn_s_waitcnt(0);                                                                 \
+            unsigned long long* o_ = reinterpret_cast<unsigned long long*>(p.cand_val) + ((long)slot_ * 4 + wave) * (ATL_MAX + 1); \
+            if ((threadIdx.x & 63) == 0) o_[0] = 0x41540000ull | (unsigned)atn_;                           \
+            for (int q_ = threadIdx.x & 63; q_ < atn_; q_ += 64) o_[1 + q_] = atl_[q_];                    \
+        }                                                                                                  \
+    }
+#else
+#define ATL_DECL(BASE)
+#define ATL(ID) {}
+#define ATL_DUMP(LOGICAL, NB) {}
+#endif
 template <int AFF_NQ, int AFF_MODE>                   // 16-query column sets per wave (1 or 2)
 __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
     constexpr int mode = AFF_MODE;
@@ -103,13 +125,17 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware mapping (see conv_igemm.hip): consecutive logical blocks share the token chunk (query block fastest)
     int bx, by;
+    const int nb = gridDim.x * gridDim.y;
+    int logical;
     {
-        const int nb = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+        const int id = blockIdx.y * gridDim.x + blockIdx.x;
         const int xcd = id & 7, kq = id >> 3, q = nb >> 3, r = nb & 7;
-        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kq;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kq;
         by = logical / (int)gridDim.x;
         bx = logical - by * (int)gridDim.x;
     }
+    ATL_DECL(aff_smem + 2 * 2 * 64 * 16 * 16 + 4096)       // (timeline builds, mode 0 only: the candidate-list area is unused there)
+    ATL(0)
     int* wl_j = l_j + wave * AFF_WCAP; int* wl_idx = l_idx + wave * AFF_WCAP; float* wl_val = l_val + wave * AFF_WCAP;
     int wcount = 0;                                                     // wave-uniform fill of the wave's list
     int jq[AFF_NQ];                                                     // query column of this lane, per set
@@ -149,6 +175,7 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
         }
         __syncthreads();                                                // the A staging below overwrites this area
     }
+    ATL(2)
     const bool skip = mode == 1 && (p.mode & 2);                        // pass-0 maxima available: skip tiles without candidates
     const float* tau_p = p.gmax_or_tau;
     const float* gmax_p = p.gmax_or_tau - (long)p.HWp * p.Gld;
@@ -217,17 +244,21 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
 #pragma unroll
     for (int u = 0; u < AFF_NQ; ++u) gcur[u] = gq[u];
     AFF_STORE(0);
+    ATL(3)
     __syncthreads();
     int buf = 0;
     for (int gg = g0; gg < g1; gg += AFF_TG) {
+        ATL(4)
         const bool more = gg + AFF_TG < g1;
         if (more) AFF_LOAD(gg + AFF_TG);
+        ATL(5)
         float gm[AFF_NQ][AFF_TG];
 #pragma unroll
         for (int t = 0; t < AFF_TG; ++t) {
 #pragma unroll
             for (int u = 0; u < AFF_NQ; ++u) gm[u][t] = -INFINITY;
             const int g = gg + t;
+            ATL(6 + t)
             if (g < g1) {                                               // block-uniform
                 bool need[AFF_NQ];
                 bool any = false;
@@ -297,14 +328,18 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
                 if (jq[u] < p.HWp)
                     *reinterpret_cast<f32x4*>(p.gmax_or_tau + (long)jq[u] * p.Gld + gg) = (f32x4){gm[u][0], gm[u][1], gm[u][2], gm[u][3]};
         }
+        ATL(10)
         if (more) {
             AFF_STORE(buf ^ 1);
 #pragma unroll
             for (int u = 0; u < AFF_NQ; ++u) gcur[u] = gq[u];
         }
+        ATL(3)
         __syncthreads();
         buf ^= 1;
     }
+    ATL(11)
+    if (mode == 0) { ATL_DUMP(logical, nb) }
 #undef AFF_LOAD
 #undef AFF_STORE
     if (mode == 1) {                                                    // flush this wave's candidates: one dense burst of global atomics
@@ -335,10 +370,10 @@ typedef __amdgpu_buffer_rsrc_t aff_rsrc_t;
 #define AF4_LDS_BYTES (2 * AF4_STAGE + AFF_LCAP * 12 + 16 + 2 * 2 * 64 * 4)
 typedef const __attribute__((address_space(1))) au32x4* aff_gptr16;
 
-template <int AFF_MODE>
+template <int NQ, int AFF_MODE>                       // NQ: 16-query column sets per wave (2 or 4)
 __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
 #if __HIP_DEVICE_COMPILE__
-    constexpr int mode = AFF_MODE, NQ = 4;
+    constexpr int mode = AFF_MODE, WQ = 16 * NQ;          // WQ: queries per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char aff_smem[];
     int* l_j = reinterpret_cast<int*>(aff_smem + 2 * AF4_STAGE);
     int* l_idx = l_j + AFF_LCAP;
@@ -349,13 +384,17 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bx, by;                                                         // XCD-aware mapping: consecutive logical blocks share the token chunk
+    const int nb = gridDim.x * gridDim.y;
+    int logical;
     {
-        const int nb = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+        const int id = blockIdx.y * gridDim.x + blockIdx.x;
         const int xcd = id & 7, kq = id >> 3, q = nb >> 3, r = nb & 7;
-        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kq;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kq;
         by = logical / (int)gridDim.x;
         bx = logical - by * (int)gridDim.x;
     }
+    ATL_DECL(aff_smem + 2 * AF4_STAGE + 4096)
+    ATL(0)
     const int g0 = by * p.tiles_per_block;
     const int g1 = min(g0 + p.tiles_per_block, p.G);
     const int T0 = (p.rn[0] + 15) >> 4, T1 = (p.nranges > 1) ? ((p.rn[1] + 15) >> 4) : 0;
@@ -377,7 +416,7 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
     const bool skip = mode == 1 && (p.mode & 2);                        // pass-0 maxima available: skip tiles without candidates
     const float* tau_p = p.gmax_or_tau;
     const float* gmax_p = p.gmax_or_tau - (long)p.HWp * p.Gld;
-    const int wq0 = bx * 256 + wave * 64;                               // first query of this wave
+    const int wq0 = bx * (4 * WQ) + wave * WQ;                               // first query of this wave
     const bool wave_on = wq0 < p.HWp;                                   // (the last query block may be half empty: such waves only stage)
     int jq[NQ];
     bool jvalid[NQ];
@@ -416,6 +455,7 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
         }                                                                                                  \
     }
     AF4_LOAD(g0, 0);
+    ATL(1)
     // B fragments of the wave's 64 queries, straight into registers (fragment layout: lane = (query l15, k chunk ks * 4 + l4))
     bf16x8 bh[NQ][4], bl[NQ][4];
     float ncj[NQ], thr[NQ];
@@ -437,6 +477,7 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
             }
         }
     }
+    ATL(2)
     int* wl_j = l_j + wave * AFF_WCAP; int* wl_idx = l_idx + wave * AFF_WCAP; float* wl_val = l_val + wave * AFF_WCAP;
     int wcount = 0;                                                     // wave-uniform fill of the wave's list
     f32x4 gcur[NQ];
@@ -449,21 +490,25 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
 #define AF4_FLUSH(GRP)                                                                                     \
     if (wave_on && l4 == 0) {                                                                              \
         _Pragma("unroll") for (int u = 0; u < NQ; ++u)                                                     \
-            if (jq[u] < p.HWp) *reinterpret_cast<f32x4*>(p.gmax_or_tau + (long)jq[u] * p.Gld + (GRP)) = gmh[wave * 64 + u * 16 + l15]; \
+            if (jq[u] < p.HWp) *reinterpret_cast<f32x4*>(p.gmax_or_tau + (long)jq[u] * p.Gld + (GRP)) = gmh[wave * WQ + u * 16 + l15]; \
     }
     for (int gg = g0; gg < g1; gg += AFF_TG) {
+        ATL(3)
         AF4_SYNC();                                                     // group gg has landed (vmcnt(0)); everybody is done with the other stage
+        ATL(4)
         const bool more = gg + AFF_TG < g1;
         if (more) AF4_LOAD(gg + AFF_TG, buf ^ 1);
         if (mode == 0 && gg > g0) AF4_FLUSH(gg - AFF_TG);
+        ATL(5)
         const au32x4* const lA = reinterpret_cast<const au32x4*>(aff_smem + buf * AF4_STAGE);
         if (wave_on) {
 #pragma unroll
             for (int t = 0; t < AFF_TG; ++t) {
                 const int g = gg + t;
+                ATL(6 + t)
                 if (mode == 0 && g >= g1 && l4 == 0) {                  // (a tile past the block's range: -inf, as aff_score_kernel stores)
 #pragma unroll
-                    for (int u = 0; u < NQ; ++u) gmf[(wave * 64 + u * 16 + l15) * 4 + t] = -INFINITY;
+                    for (int u = 0; u < NQ; ++u) gmf[(wave * WQ + u * 16 + l15) * 4 + t] = -INFINITY;
                 }
                 if (g < g1) {                                           // block-uniform
                     bool need[NQ];
@@ -503,7 +548,7 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
                             const float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
                             if (mode == 0) {
                                 const float m_ = rows_max(mx);
-                                if (l4 == 0) gmf[(wave * 64 + u * 16 + l15) * 4 + t] = m_;      // parked in LDS until AF4_FLUSH
+                                if (l4 == 0) gmf[(wave * WQ + u * 16 + l15) * 4 + t] = m_;      // parked in LDS until AF4_FLUSH
                             } else if (__ballot(jvalid[u] && mx >= thr[u])) {   // wave-uniform: some lane has a candidate in this tile
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
@@ -531,6 +576,7 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
             // the loop waits with vmcnt(0) for this group's DMA, and a store issued here would be waited for as well (a write round trip
             // per group: measured 3.5 us per group against 1.3 us of MFMA).  The maxima wait in the (mode-1 only) candidate-list area.
         }
+        ATL(10)
         if (more) {
             if (l4 == 0) { lsc[buf ^ 1][wave * 16 + l15] = l15 < st_nv ? st_sc : 0.f; lpad[buf ^ 1][wave * 16 + l15] = l15 < st_nv ? 0.f : -INFINITY; }
 #pragma unroll
@@ -543,6 +589,8 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
         const int last = g0 + ((g1 - g0 - 1) / AFF_TG) * AFF_TG;
         AF4_FLUSH(last);
     }
+    ATL(11)
+    if (mode == 0) { ATL_DUMP(logical, nb) }
 #undef AF4_FLUSH
 #undef AF4_LOAD
 #undef AF4_PIECE
@@ -832,6 +880,7 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             int G = 0;
             for (int r = 0; r < 3; ++r) G += (sp.rn[r] + 15) / 16;
             if (G != sp.G || (sp.HWp & 63) || sp.nranges < 1 || sp.nranges > 3 || (sp.Gld & 3)) { cutie_set_error("aff_score: bad ranges (G=%d vs %d, HWp=%d)", G, sp.G, sp.HWp); return -2; }
+            const bool dma = i[12] == 4 || i[15] == 1;          // aff_score4_kernel (LDS-DMA staging): always for 4 sets per wave, for 2 when i[15] = 1
             const int nq = i[12] == 1 ? 1 : (i[12] == 4 ? 4 : 2);
             int qb = (sp.HWp + 64 * nq - 1) / (64 * nq);
             if (sp.mode != 0 && sp.mode != 1) { cutie_set_error("aff_score: mode %d", sp.mode); return -2; }
@@ -839,12 +888,13 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             if (pass == 1 && (op->flags & 1)) sp.mode |= 2;     // pass-0 maxima precede tau in memory: tiles without candidates are skipped
             static bool lds_attr_set = false;
             if (!lds_attr_set) {
-                const void* ks[6] = {reinterpret_cast<const void*>(aff_score_kernel<1, 0>), reinterpret_cast<const void*>(aff_score_kernel<1, 1>),
+                const void* ks[8] = {reinterpret_cast<const void*>(aff_score_kernel<1, 0>), reinterpret_cast<const void*>(aff_score_kernel<1, 1>),
                                      reinterpret_cast<const void*>(aff_score_kernel<2, 0>), reinterpret_cast<const void*>(aff_score_kernel<2, 1>),
-                                     reinterpret_cast<const void*>(aff_score4_kernel<0>), reinterpret_cast<const void*>(aff_score4_kernel<1>)};
+                                     reinterpret_cast<const void*>(aff_score4_kernel<4, 0>), reinterpret_cast<const void*>(aff_score4_kernel<4, 1>),
+                                     reinterpret_cast<const void*>(aff_score4_kernel<2, 0>), reinterpret_cast<const void*>(aff_score4_kernel<2, 1>)};
                 static_assert(AF4_LDS_BYTES == AFF_LDS_BYTES, "one dynamic-LDS size for all score kernels");
                 for (const void* k : ks)
-                    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, AFF_LDS_BYTES) != hipSuccess) {
+                    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                         cutie_set_error("aff_score: cannot raise the dynamic LDS limit to %d bytes", AFF_LDS_BYTES);
                         return -2;
                     }
@@ -859,8 +909,11 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             tpb = (tpb + AFF_TG - 1) / AFF_TG * AFF_TG;
             sp.tiles_per_block = tpb;
             const dim3 grid(qb, (G + tpb - 1) / tpb);
-            if (nq == 4 && pass == 0) hipLaunchKernelGGL((aff_score4_kernel<0>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
-            else if (nq == 4) hipLaunchKernelGGL((aff_score4_kernel<1>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
+            const int lds4 = AFF_LDS_BYTES + (i[14] > 0 && i[14] <= 80 ? i[14] * 1024 : 0);       // (diagnostic: extra dynamic LDS = fewer resident blocks per CU)
+            if (nq == 4 && pass == 0) hipLaunchKernelGGL((aff_score4_kernel<4, 0>), grid, dim3(256), lds4, s, sp);
+            else if (nq == 4) hipLaunchKernelGGL((aff_score4_kernel<4, 1>), grid, dim3(256), lds4, s, sp);
+            else if (dma && nq == 2 && pass == 0) hipLaunchKernelGGL((aff_score4_kernel<2, 0>), grid, dim3(256), lds4, s, sp);
+            else if (dma && nq == 2) hipLaunchKernelGGL((aff_score4_kernel<2, 1>), grid, dim3(256), lds4, s, sp);
             else if (nq == 1 && pass == 0) hipLaunchKernelGGL((aff_score_kernel<1, 0>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
             else if (nq == 1) hipLaunchKernelGGL((aff_score_kernel<1, 1>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
             else if (pass == 0) hipLaunchKernelGGL((aff_score_kernel<2, 0>), grid, dim3(256), AFF_LDS_BYTES, s, sp);

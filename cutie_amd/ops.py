@@ -554,9 +554,10 @@ class OpList:
 
     AFF_CSTRIDE = 32          # ints between the candidate counters of consecutive queries (one cache line each)
 
-    AFF_NQ = int(os.environ.get('CUTIE_AMD_AFF_NQ', '4'))      # 16-query column sets per wave of AFF_SCORE (1, 2: aff_score_kernel; 4: aff_score4_kernel)
+    AFF_DMA = int(os.environ.get('CUTIE_AMD_AFF_DMA', '0'))    # 1: the LDS-DMA kernel (aff_score4_kernel) also for 2 sets per wave
+    AFF_NQ = int(os.environ.get('CUTIE_AMD_AFF_NQ', '2'))      # 16-query column sets per wave of AFF_SCORE (1, 2: aff_score_kernel; 4: aff_score4_kernel)
 
-    def aff_score(self, Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count, *, HW, HWp, ranges, cap, mode, gmax_precedes_tau=False, nq=None):
+    def aff_score(self, Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count, *, HW, HWp, ranges, cap, mode, gmax_precedes_tau=False, nq=None, dma=None):
         """gmax_precedes_tau (mode 1): `out` (= tau) sits right behind the [HWp, Gld] maxima of pass 0 in memory; the kernel then
         skips every (tile, 16-query set) that cannot hold a candidate.  nq: query column sets per wave (default AFF_NQ; every
         choice computes the same bits)."""
@@ -566,7 +567,7 @@ class OpList:
         ints = [HW, HWp, len(ranges)]
         for r in range(3):
             ints += list(ranges[r]) if r < len(ranges) else [0, 0]
-        ints += [G, cap, mode, self.AFF_NQ if nq is None else nq]
+        ints += [G, cap, mode, self.AFF_NQ if nq is None else nq, 0, 0, self.AFF_DMA if dma is None else int(dma)]
         return self.add(AFF_SCORE, 1 if (gmax_precedes_tau and mode == 1) else 0, ints, [], [Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count])
 
     def aff_select(self, gmax, tau, *, HW, HWp, G, top_k, clear_count=None, ticks=(), zero=None):

@@ -199,7 +199,7 @@ enum {
      * p0=A_hi p1=A_lo p2=scale (bank base pointers, rows = physical token slots) p3=B_hi p4=B_lo p5=c
      * p6=gmax | tau f32 [HW]  p7=cand_val p8=cand_idx p9=count
      * i: 0 HW 1 HWp 2 nranges 3.. (start,n) x3  9 G 10 cap 11 mode  12 query column sets (of 16) per wave: 1 | 2 (0 = 2) | 4 (aff_score4_kernel:
-     *      256-query blocks, LDS-DMA staging; same bits for every choice)  13 tiles per block (0 = heuristic)
+     *      256-query blocks, LDS-DMA staging; same bits for every choice)  13 tiles per block (0 = heuristic)  14 (diagnostic) KB of extra dynamic LDS  15 = 1: aff_score4_kernel (LDS-DMA staging) also for 2 sets per wave
      * flags&1 (mode 1): the gmax matrix of the mode-0 pass lies directly in front of tau in memory (p6 - HWp*Gld floats): every
      *      (16-token tile, 16-query set) whose maximum is below the set's thresholds is skipped (same result, ~1/6 of the MFMA work) */
     CUTIE_OP_AFF_SCORE = 24,

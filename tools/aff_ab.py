@@ -36,9 +36,10 @@ with torch.inference_mode(), torch.cuda.stream(torch.cuda.Stream()):
         s0, s01, s012, s0123 = t1(a[0:1]), t1(a[0:2]), t1(a[0:3]), t1(a)
         return s0, s01 - s0, s012 - s01, s0123 - s012, s0123
 
-    for nq in (2, 4, 1):
-        for tpb in ((0,) if nq != 4 else (0, 8, 12, 16, 24)):
-            a = affs.copy(); a['i'][0, 12] = nq; a['i'][2, 12] = nq; a['i'][0, 13] = tpb; a['i'][2, 13] = tpb
+    for nq in (2, 12, 4, 1):
+        for tpb in ((0,) if nq not in (4, 12) else (0, 8, 12, 16, 24)):
+            a = affs.copy(); a['i'][0, 12] = nq % 10; a['i'][2, 12] = nq % 10; a['i'][0, 13] = tpb; a['i'][2, 13] = tpb
+            a['i'][0, 15] = a['i'][2, 15] = int(nq >= 10)
             s = stages(a)
             print('nq %d tpb %2d: score0 %.2f (mfma util %.3f)  select %.2f  score1 %.2f  readout %.2f  | plan %.1f us' %
                   (nq, tpb, s[0], issued / (s[0] * 1e-6) / 1e12 / PEAK, s[1], s[2], s[3], s[4]))
