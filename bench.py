@@ -152,7 +152,9 @@ def make_hint(args, frames, n):
         return lambda t: {}
     if args.window > 1:
         depth = args.window + 4                            # >= WINDOW + WINDOW_LEAD + 1 frames: a full batch can always be formed
-        return lambda t: {'next_images': [frames[(t + 1 + j) % n] for j in range(depth)]}
+        views = [frames[i] for i in range(n)]              # (what a reader holds anyway: no per-step tensor construction in the timed loop)
+        views = views + views[:depth + 1]
+        return lambda t: {'next_images': views[(t + 1) % n:(t + 1) % n + depth]}
     return lambda t: {'next_image': frames[(t + 1) % n]}
 
 

@@ -276,7 +276,8 @@ __global__ void gap_final_kernel(const float* __restrict__ part, float* __restri
 __global__ __launch_bounds__(256) void eca_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ part,
                                                         const float* __restrict__ wk, const bf16_t* __restrict__ r,
                                                         bf16_t* __restrict__ y, float* __restrict__ gap_out, int HW, int C, int nchunk,
-                                                        const long long* __restrict__ fixed) {
+                                                        const long long* __restrict__ fixed, const bf16_t* __restrict__ pw,
+                                                        const float* __restrict__ pb, float* __restrict__ plog) {
     __shared__ float gap[256 + 4], sc[256];
     const int b = blockIdx.y, tid = threadIdx.x;
     const float inv = 1.f / (float)HW;
@@ -338,6 +339,40 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const bf16_t* __restrict
             o[i] = pack_bf2(lo, hi);
         }
         *reinterpret_cast<uint4*>(y + offs[it]) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    // Optional head riding on the store (pw != 0; C = 256): logit[b, p] = bias + sum_c relu(y[b, p, c]) * w[c] -- the 1x1 conv with fused
+    // input ReLU that the object transformer applies to a block's output (mask_pred, object_transformer.py:151-164) on what was just
+    // STORED (bf16-rounded, like the conv launch it replaces).  A pixel's 256 channels sit in the 32 lanes of half a wave.
+    if (pw) {
+        const int c8 = tid & 31;
+        const uint4 wv = *reinterpret_cast<const uint4*>(pw + c8 * 8);
+        const uint32_t* wu = &wv.x;
+        const float bias = pb ? pb[0] : 0.f;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            float part = 0.f;
+            if (offs[it] >= 0) {
+                const uint32_t* xu = &xv[it].x; const uint32_t* ru = &rv[it].x;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float lo = __uint_as_float(xu[i] << 16) * sc[c8 * 8 + 2 * i] + __uint_as_float(ru[i] << 16);
+                    const float hi = __uint_as_float(xu[i] & 0xffff0000u) * sc[c8 * 8 + 2 * i + 1] + __uint_as_float(ru[i] & 0xffff0000u);
+                    const uint32_t st = pack_bf2(lo, hi);                  // the stored pair
+                    part += fmaxf(__uint_as_float(st << 16), 0.f) * __uint_as_float(wu[i] << 16);
+                    part += fmaxf(__uint_as_float(st & 0xffff0000u), 0.f) * __uint_as_float(wu[i] & 0xffff0000u);
+                }
+            }
+            // sum over the 32 lanes of the pixel: 16-lane rows on the DPP path, then the row pair {l, l ^ 16}
+            part += __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(part), 0xB1, 0xf, 0xf, false));
+            part += __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(part), 0x4E, 0xf, 0xf, false));
+            part += __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(part), 0x141, 0xf, 0xf, false));
+            part += __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(part), 0x140, 0xf, 0xf, false));
+            const unsigned pu = __float_as_uint(part);
+            const auto rr = __builtin_amdgcn_permlane16_swap(pu, pu, false, false);
+            const float tot = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);
+            const int q = tid + it * 256, p = p0 + q / C8;
+            if (c8 == 0 && offs[it] >= 0) plog[(long)b * HW + p] = tot + bias;
+        }
     }
 }
 
@@ -1009,9 +1044,11 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
         }
         case CUTIE_OP_ECA_APPLY: {
             if (i[2] > 256 || (i[2] & 7)) { cutie_set_error("eca: C <= 256, C %% 8"); return -2; }
+            if (p[6] && (i[2] != 256 || !p[8])) { cutie_set_error("eca: the fused 1x1 head needs C = 256 and an output"); return -2; }
             int nchunk = (i[1] + 63) / 64;
             hipLaunchKernelGGL(eca_apply_kernel, dim3((i[1] + 31) / 32, i[0]), dim3(256), 0, s, (const bf16_t*)p[0], (const float*)p[5], (const float*)p[2],
-                               (const bf16_t*)p[3], (bf16_t*)p[4], (float*)p[1], i[1], i[2], nchunk, (op->flags & 1) ? (const long long*)p[5] : nullptr);
+                               (const bf16_t*)p[3], (bf16_t*)p[4], (float*)p[1], i[1], i[2], nchunk, (op->flags & 1) ? (const long long*)p[5] : nullptr,
+                               (const bf16_t*)p[6], (const float*)p[7], (float*)p[8]);
             break;
         }
         case CUTIE_OP_GRU: {

@@ -12,6 +12,7 @@ import argparse
 import logging
 import os
 import time
+from collections import deque
 from os import path
 from typing import Dict
 
@@ -41,13 +42,26 @@ def process_video(network, cfg, vid_reader, mask_output_root, *, dataset='generi
     total, frames, first_mask_loaded = 0.0, 0, False
     try:
         loader = iter(ReadAhead(vid_reader, workers=read_workers))      # decode runs ahead on threads (eval_vos.py:92)
-        nxt = next(loader, None)
+        # the frames of the following steps, already on the device: step(next_images=...) runs the image encoder over a window of them
+        # (InferenceCore.prefetch_window); the SAME tensors are handed to the later steps (the look-ahead matches frames by storage)
+        from .inference import inference_core as IC
+        depth = (IC.WINDOW + IC.WINDOW_LEAD + 1) if lookahead else 1
+        ahead = deque()
+
+        def fill():
+            while len(ahead) < depth:
+                d = next(loader, None)
+                if d is None:
+                    break
+                d['rgb'] = d['rgb'].to(dev)
+                ahead.append(d)
+
+        fill()
         for ti in range(n):
-            data, nxt = nxt, next(loader, None)
-            image = data['rgb'].to(dev)
-            next_image = nxt['rgb'].to(dev) if (nxt is not None and lookahead) else None
-            if nxt is not None and next_image is not None:
-                nxt['rgb'] = next_image                       # the same tensor is handed to the next step (look-ahead match)
+            data = ahead.popleft()
+            fill()
+            image = data['rgb']
+            next_images = [d['rgb'] for d in ahead] if (lookahead and ahead) else None
             mask = data.get('mask')
             mask = mask.to(dev) if mask is not None else None
             valid = data.get('valid_labels')
@@ -63,7 +77,7 @@ def process_video(network, cfg, vid_reader, mask_output_root, *, dataset='generi
                 e0.record()
             else:
                 t0 = time.perf_counter()
-            prob = processor.step(image, mask, valid, end=(ti == n - 1), next_image=next_image)
+            prob = processor.step(image, mask, valid, end=(ti == n - 1), next_images=next_images)
             if on_gpu:
                 e1.record()
                 torch.cuda.synchronize()

@@ -30,6 +30,7 @@ AHEAD_AFFINITY = os.environ.get('CUTIE_AMD_AHEAD_AFFINITY', '1') not in ('', '0'
 DEFER_MEM = os.environ.get('CUTIE_AMD_DEFER_MEM', '0') not in ('', '0')
 # look-ahead WINDOW of the image encoder (step(next_images=...)): frames per batched encoder plan (<= 1: one frame at a time, as with
 # next_image), and how many already-encoded frames may be left ahead when the next batch is started
+WAIT_TRACE = None                                          # a list: step() brackets its wait for the look-ahead with timing events (diagnostic)
 WINDOW = int(os.environ.get('CUTIE_AMD_WINDOW', '8'))
 WINDOW_LEAD = int(os.environ.get('CUTIE_AMD_WINDOW_LEAD', '2'))
 
@@ -186,11 +187,17 @@ class InferenceCore:
             return self.prefetch(first, affinity=affinity)
         on = (lambda st: torch.cuda.stream(st)) if gpu else (lambda st: contextlib.nullcontext())
         main = torch.cuda.current_stream(dev) if gpu else None
-        keys = [self._frame_key(images[j]) for j in range(min(n, WINDOW + WINDOW_LEAD + 1))]
+        # (host time: the common step finds its next frames encoded -- the first WINDOW_LEAD + 1 keys decide that, the rest of the
+        # announcement is only looked at when a batch has to be formed)
+        nlook = min(n, WINDOW_LEAD + 1)
+        keys = [self._frame_key(images[j]) for j in range(nlook)]
+        if not (nlook == WINDOW_LEAD + 1 and all(k in self._window for k in keys) and len(self._window) <= WINDOW + WINDOW_LEAD + 1):
+            keys += [self._frame_key(images[j]) for j in range(nlook, min(n, WINDOW + WINDOW_LEAD + 1))]
         # encoded frames that are no longer announced (a changed schedule): dropped -- their buffers are only ever re-written by the
         # window stream itself, in its own order
-        for k in [k for k in self._window if k not in keys]:
-            del self._window[k]
+        if len(keys) > nlook or len(keys) == n:                # (the whole announcement was read)
+            for k in [k for k in self._window if k not in keys]:
+                del self._window[k]
         ahead = 0
         while ahead < len(keys) and keys[ahead] in self._window:
             ahead += 1
@@ -400,7 +407,14 @@ class InferenceCore:
             # this frame's encoder already ran (or is running) on the side stream
             image = pre[1]
             if pre[3] is not None:
-                torch.cuda.current_stream(image.device).wait_event(pre[3])
+                if WAIT_TRACE is not None:                     # (tools/stream_waits.py: how long does the caller's stream wait for the look-ahead?)
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    torch.cuda.current_stream(image.device).wait_event(pre[3])
+                    b.record()
+                    WAIT_TRACE.append((self.curr_ti, a, b))
+                else:
+                    torch.cuda.current_stream(image.device).wait_event(pre[3])
             self.image_feature_store._store[self.curr_ti] = pre[2]
             self._window.pop(pre[0], None)                     # (a frame of the look-ahead window: consumed)
             h0, w0, H, W, pl, pt = pre[5]

@@ -62,6 +62,7 @@ QCHAIN = os.environ.get('CUTIE_AMD_QCHAIN', '1') not in ('', '0')     # query si
 GRAPHS = os.environ.get('CUTIE_AMD_GRAPHS', '0') not in ('', '0')
 GRAPH_MIN_OPS = 8
 QFFN_SLICE = int(os.environ.get('CUTIE_AMD_QFFN_SLICE', '64'))       # hidden columns per QFFN block (64 | 128)
+ECA_HEAD = os.environ.get('CUTIE_AMD_ECA_HEAD', '1') not in ('', '0')   # mask_pred of a transformer block inside the ECA launch (A/B switch)
 QNEXT = os.environ.get('CUTIE_AMD_QNEXT', '1') not in ('', '0')       # ATTN_P2Q also projects the next block's ATTN_Q2P queries
 AUTOTUNE = os.environ.get('CUTIE_AMD_AUTOTUNE', '0') not in ('', '0')
 TOUCH_REWIRE = os.environ.get('CUTIE_AMD_WPF_REWIRE', '1') not in ('', '0')       # A/B switch: next-weights ranges recomputed after the tile table
@@ -385,8 +386,11 @@ class Plan:
         return out
 
     # ---- shared blocks ------------------------------------------------------------------
-    def ca_block(self, prefix, x, name, out=None):
-        """CAResBlock (channel_attn.py:7-39): conv3x3(relu) x2, ECA channel attention, residual."""
+    def ca_block(self, prefix, x, name, out=None, head=None):
+        """CAResBlock (channel_attn.py:7-39): conv3x3(relu) x2, ECA channel attention, residual.
+        head = (weight name of a Cout = 1, 1x1 conv with fused input ReLU, its f32 output tensor): computed by the ECA launch."""
+        if head is not None:
+            head = (self.eng.w[head[0]], head[1])
         w = self.eng.w[prefix + '.conv2']
         gap = self.buf(name + '.gap', (x.B, x.C), F32)
         HW = x.H * x.W
@@ -398,14 +402,14 @@ class Plan:
             t2 = self.conv(prefix + '.conv2', t1, name=name + '.t2', gap_acc=sums)
             if out is None:
                 out = Act(self.buf(name + '.out', (x.B, x.H, x.W, x.C)), x.B, x.H, x.W, x.C)
-            self.ol.eca_apply(t2.t, gap, self.eng.w[prefix + '.conv.weight'], x.t, out.t, B=x.B, HW=HW, C=x.C, fixed_sums=sums)
+            self.ol.eca_apply(t2.t, gap, self.eng.w[prefix + '.conv.weight'], x.t, out.t, B=x.B, HW=HW, C=x.C, fixed_sums=sums, head=head)
             return out
         t1 = self.conv(prefix + '.conv1', x, name=name + '.t1', relu_in=True, act=O.ACT_RELU)
         t2 = self.conv(prefix + '.conv2', t1, name=name + '.t2')
         self.ol.gap(t2.t, gap, B=x.B, HW=HW, C=x.C, partial_only=True)
         if out is None:
             out = Act(self.buf(name + '.out', (x.B, x.H, x.W, x.C)), x.B, x.H, x.W, x.C)
-        self.ol.eca_apply(t2.t, gap, self.eng.w[prefix + '.conv.weight'], x.t, out.t, B=x.B, HW=HW, C=x.C)
+        self.ol.eca_apply(t2.t, gap, self.eng.w[prefix + '.conv.weight'], x.t, out.t, B=x.B, HW=HW, C=x.C, head=head)
         return out
 
     def fusion_block(self, prefix, x, g, name, out=None, xt=None):
@@ -671,8 +675,11 @@ def build_readout_query(eng, K, h, w, last_aux=True):
         pf = P.conv(q + '.read_from_query.out', Act(pa, K, h, w, C), name=n + 'pf', res=pixel)
         # PixelFFN (transformer_layers.py:121-136)
         last = b == nb - 1
-        pixel = P.ca_block(q + '.pixel_ffn.conv', pf, n + 'ffn', out=Act(Dyn('out'), K, h, w, C) if last else None)
-        if not last or last_aux:
+        want_aux = not last or last_aux
+        fuse_head = want_aux and ECA_HEAD and C == 256 and not UNFUSED        # the mask_pred head rides on the block's ECA launch
+        pixel = P.ca_block(q + '.pixel_ffn.conv', pf, n + 'ffn', out=Act(Dyn('out'), K, h, w, C) if last else None,
+                           head=(f'{t}.mask_pred.{b + 1}.1', aux[b + 1]) if fuse_head else None)
+        if want_aux and not fuse_head:
             P.conv(f'{t}.mask_pred.{b + 1}.1', pixel, relu_in=True, out_f32=True, out=Act(aux[b + 1], K, h, w, 1))
         if not last and not fused_mask:
             ol.aux_mask(aux[b + 1], fg, nfg, K=K, HW=HW)

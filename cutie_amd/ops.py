@@ -390,14 +390,20 @@ class OpList:
         self._last_gap_scratch = scratch
         return self.add(GAP, 1 if partial_only else 0, [B, HW, C], [], [x, y, scratch])
 
-    def eca_apply(self, x, gap, wk, r, y, *, B, HW, C, part=None, fixed_sums=None):
+    def eca_apply(self, x, gap, wk, r, y, *, B, HW, C, part=None, fixed_sums=None, head=None):
         """part: the GAP partials of the preceding gap(..., partial_only=True) (defaults to the last gap scratch);
-        fixed_sums: int64 [B, C] sums accumulated by the producing conv (conv(gap_acc=...)) instead."""
+        fixed_sums: int64 [B, C] sums accumulated by the producing conv (conv(gap_acc=...)) instead.
+        head = (PackedConv w of a Cout = 1, 1x1 conv, out f32 [B, HW]): relu(y) . w + bias computed by the same launch (C = 256)."""
+        tail = []
+        if head is not None:
+            w, out = head
+            assert C == 256 and w.cout == 1 and w.kh == 1 and w.cin_padded == 256
+            tail = [w.weight, w.bias, out]
         if fixed_sums is not None:
-            return self.add(ECA_APPLY, 1, [B, HW, C], [], [x, gap, wk, r, y, fixed_sums])
+            return self.add(ECA_APPLY, 1, [B, HW, C], [], [x, gap, wk, r, y, fixed_sums] + tail)
         if part is None:
             part = self._last_gap_scratch
-        return self.add(ECA_APPLY, 0, [B, HW, C], [], [x, gap, wk, r, y, part])
+        return self.add(ECA_APPLY, 0, [B, HW, C], [], [x, gap, wk, r, y, part] + tail)
 
     def gru(self, values, h, hb, *, n, C):
         return self.add(GRU, 0, [n, C], [], [values, h, hb])

@@ -97,7 +97,9 @@ enum {
     CUTIE_OP_GAP = 7,
     /* ECA_APPLY: y = x * sigmoid(conv1d_k5(gap))[c] + r    channel_attn.py:33-37
      * p0=x bf16 [B,HW,C] p1=gap f32 [B,C] (written: the finished means) p2=w f32[5] p3=r bf16 [B,HW,C] p4=y bf16
-     * p5=part f32 [B,ceil(HW/64),C] (GAP partials)   i: 0 B 1 HW 2 C */
+     * p5=part f32 [B,ceil(HW/64),C] (GAP partials)   i: 0 B 1 HW 2 C
+     * p6 (optional, C = 256) = packed weights bf16 [256] of a Cout = 1, 1x1 conv with fused input ReLU applied to y as stored, p7 = its bias f32 [1]
+     *      (may be 0), p8 = its output f32 [B,HW]: the mask_pred head of a transformer block (object_transformer.py:151-164) without a launch */
     CUTIE_OP_ECA_APPLY = 8,
     /* GRU: h' = sig(f)*h*(1-sig(u)) + sig(u)*tanh(n), values=[f|u|n] f32   modules.py:35-43
      * p0=values f32 [B,HW,3C] p1=h f32 [B,HW,C] (in/out) p2=h_bf16 bf16 [B,HW,C] (out)  i: 0 n=B*HW 1 C */

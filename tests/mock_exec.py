@@ -216,7 +216,12 @@ class MockExecutor:
         wk = view(p[2], F32, (5,))
         sc = torch.sigmoid(F.conv1d(gap.view(B, 1, C), wk.view(1, 1, 5), None, 1, 2)).view(B, 1, C)
         r = view(p[3], BF16, (B, HW, C)).float()
-        view(p[4], BF16, (B, HW, C)).copy_(x * sc + r)
+        out = view(p[4], BF16, (B, HW, C))
+        out.copy_(x * sc + r)
+        if len(p) > 8 and p[6]:                                         # fused Cout = 1 head on the stored output
+            w = view(p[6], BF16, (C,)).float()
+            bias = view(p[7], F32, (1,)) if p[7] else torch.zeros(1)
+            view(p[8], F32, (B, HW)).copy_((F.relu(out.float()) * w).sum(-1) + bias)
 
     # ---- GRU ------------------------------------------------------------------------------
     def _op_9(self, flags, i, f, p):
