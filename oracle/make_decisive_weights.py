@@ -10,7 +10,11 @@ the synthetic state dict alone, and stores the changed tensors (fp32, a few KB .
 The recurrence makes the features depend on the head (masks are fed back through the memory), so a few rounds of
 {run the oracle free, collect the decoder inputs, fit the head} are made.
 
-    python -m oracle.make_decisive_weights [--rounds 3] [--steps 300] [--train-up]
+    python -m oracle.make_decisive_weights [--rounds 2] [--steps 400] [--lr 2e-3] [--gain 3] [--train-up]
+
+Committed delta: the defaults above (head only: 1153 numbers; class-balanced loss).  Measured here: oracle margin > 0.33 on
+100 / 97.9 / 99.7 / 95.6 % of the pixels of the four bike frames (27.7 / 24.2 / 56.9 % with the plain synthetic weights), both objects
+still present in every frame.  --train-up (also fitting up_8_4) tracked the synthetic clips better and bike worse: not used.
 
 Prints, per round, the training loss and the fraction of pixels of every bike frame (and of held-out synthetic frames) whose oracle
 margin exceeds 0.33.  TEST INFRASTRUCTURE (see oracle/__init__.py); the recipe is deterministic up to torch's CPU reduction order --
@@ -108,12 +112,14 @@ def margins(onet, name, hist=False):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--rounds', type=int, default=3)
-    ap.add_argument('--steps', type=int, default=300)
+    ap.add_argument('--rounds', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=400)
     ap.add_argument('--frames', type=int, default=8)
     ap.add_argument('--clips', type=int, default=6)
     ap.add_argument('--train-up', action='store_true', help='also fit mask_decoder.up_8_4.out_conv (conv1, conv2)')
-    ap.add_argument('--lr', type=float, default=3e-3)
+    ap.add_argument('--lr', type=float, default=2e-3)
+    ap.add_argument('--gain', type=float, default=3.0, help='the fitted head is scaled by this before it is stored: sharper sigmoids -> wider margins '
+                    '(the argmax of one frame is scale-invariant; through the recurrence the objects shrink a little). 1: 86-92 %% of bike decisive, 3: 96-100 %%')
     ap.add_argument('--out', default=OUT)
     args = ap.parse_args()
     torch.manual_seed(0)
@@ -149,7 +155,9 @@ def main():
             onet.W[k] = W[k].detach().clone()
         print(f'round {rnd}: bike decisive fraction per frame', [round(v, 3) for v in margins(onet, 'bike')],
               ' small_fifo', [round(v, 3) for v in margins(onet, 'small_fifo')][:8])
-    margins(onet, 'bike', hist=True)
+    for k in names:
+        onet.W[k] = onet.W[k] * args.gain
+    print(f'gain {args.gain}: bike decisive fraction per frame', [round(v, 3) for v in margins(onet, 'bike', hist=True)])
     np.savez_compressed(args.out, **{k: onet.W[k].numpy() for k in names})
     print('wrote', args.out, {k: tuple(onet.W[k].shape) for k in names})
 

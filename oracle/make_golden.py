@@ -177,8 +177,12 @@ def main():
         if (only or 'model_small' in sys.argv[1:]) and name not in only:
             continue
         sizes = []
+        net_sc = net
+        if sc.get('weights') == 'decisive':                          # the reference under the decisive weights (oracle/make_decisive_weights.py)
+            net_sc = CUTIE(reference_cfg()).eval()
+            net_sc.load_weights({k: v.clone() for k, v in S.decisive_state_dict().items()})
 
-        def make(over):
+        def make(over, net=net_sc):
             proc = InferenceCore(net, cfg=reference_cfg(**{k: (_wrap(v) if isinstance(v, dict) else v)
                                                            for k, v in over.items()}))
             if 'max_internal_size' in over:

@@ -20,6 +20,8 @@ LT_SMALL = dict(count_usage=True, max_mem_frames=4, min_mem_frames=2, num_protot
 SCENARIOS = {
     # configs[0] of BASELINE.json: examples/bike, 480p, (2) objects, scripting_demo.py settings
     'bike': dict(cfg=dict(max_internal_size=480), kind='bike', frames=4, sub=8),
+    # the same clip under the DECISIVE weights (decisive_state_dict): the oracle's margin exceeds 0.33 on >= 95 % of every frame
+    'bike_decisive': dict(cfg=dict(max_internal_size=480), kind='bike', frames=4, sub=8, weights='decisive'),
     # examples/images/judo through scripting_demo_add_del_objects.py:21-64 -- 16 real 480p frames, ids 1..4
     # given by the mask files of frames 0, 5, 8, 13 (three buckets of objects added at different times), id 1 deleted before frame 10.
     # (masks/judo/00005.png is 480 x 853 against 480 x 854 frames: the reference pads the mask on its own, inference_core.py:263)
@@ -72,6 +74,18 @@ SCENARIOS = {
     'small_flip': dict(cfg=dict(mem_every=2, flip_aug=True, use_long_term=True, long_term=LT_SMALL),
                        kind='synth', h=96, w=121, k=2, frames=26, sub=2),
 }
+
+
+def decisive_state_dict(seed=0):
+    """The synthetic state dict with the fitted mask-decoder head of oracle/make_decisive_weights.py (tests/golden/decisive_delta.npz):
+    weights under which the oracle is decisive on almost every pixel, so that argmax object ids can be compared over whole frames."""
+    from oracle.weights import make_state_dict
+    sd = make_state_dict(seed=seed)
+    d = np.load(os.path.join(GOLDEN_DIR, 'decisive_delta.npz'))
+    for k in d.files:
+        assert k in sd and tuple(sd[k].shape) == tuple(d[k].shape), k
+        sd[k] = torch.from_numpy(d[k]).clone()
+    return sd
 
 
 def trajectory_bounds(model='base'):

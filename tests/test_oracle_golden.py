@@ -41,11 +41,15 @@ def test_state_dict_spec_matches_reference():
         assert tuple(shp) == tuple(spec[k][0]), k
 
 
-@pytest.mark.parametrize('name', ['small_fifo', 'small_lt', 'small_add_del', 'small_interactive', 'small_flip', 'small_chunk', 'small_misc', 'small_clear', 'small_video', 'small_lt_overlap', 'small_cfg_fifo', 'small_cfg_lt', 'bike', 'judo'])
+@pytest.mark.parametrize('name', ['small_fifo', 'small_lt', 'small_add_del', 'small_interactive', 'small_flip', 'small_chunk', 'small_misc', 'small_clear', 'small_video', 'small_lt_overlap', 'small_cfg_fifo', 'small_cfg_lt', 'bike', 'judo', 'bike_decisive'])
 def test_oracle_matches_reference_trajectory(name, oracle_net):
     gold = np.load(os.path.join(GOLDEN, name + '.npz'))
     sub = S.SCENARIOS[name]['sub']
     sizes = []
+
+    if S.SCENARIOS[name].get('weights') == 'decisive':               # the fitted mask-decoder head (oracle/make_decisive_weights.py)
+        from oracle.net import OracleNet
+        oracle_net = OracleNet(S.decisive_state_dict())
 
     def make(over):
         cfg = dict(DEFAULT_CFG)
@@ -54,6 +58,9 @@ def test_oracle_matches_reference_trajectory(name, oracle_net):
 
     outs, proc = S.run_scenario(make, name, record=lambda t, p: sizes.append(_mem_sizes(p)))
     assert np.array_equal(np.array(sizes), gold['mem_sizes'])
+    if name == 'bike_decisive':                                          # what the weights are for: the reference itself is decisive on >= 95 % of every frame
+        for t in range(len(outs)):
+            assert float((gold[f'margin_{t}'].astype(np.float32) > 0.33).mean()) >= 0.95, t
     for t, p in enumerate(outs):
         ref = torch.from_numpy(gold[f'prob_{t}'].astype(np.float32))
         got = p[:, ::sub, ::sub]
