@@ -97,8 +97,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
         n0 = (logical - mt * (int)gridDim.y) * BN;
         tl_logical = logical; tl_nb = nb;
     }
-    if (p.zero && blockIdx.x == 0 && blockIdx.y == 0)      // side job: clear the GAP accumulator of the next conv
-        for (int z = tid; z < p.nzero; z += NT) p.zero[z] = 0ull;
+    if (p.zero) {                                          // side job: clear an accumulator (the next conv's GAP sums; the transformer's fixed-point sums: 0.9 MB, so every block takes a slice)
+        for (int z = (blockIdx.y * gridDim.x + blockIdx.x) * NT + tid; z < p.nzero; z += gridDim.x * gridDim.y * NT) p.zero[z] = 0ull;
+    }
     // ---- epilogue operands fetched up front (their latency hides behind the whole K loop): this thread's 8-channel column ----
     constexpr int CH8 = BN / 8, PSTEP = NT / CH8;        // a thread keeps its channel chunk and walks down the pixels
     const int ec8 = tid % CH8, epx0 = tid / CH8, ech0 = n0 + ec8 * 8;

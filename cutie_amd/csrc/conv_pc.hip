@@ -337,8 +337,10 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
     } else {
         m0 = mt * BM;
     }
-    if (p.zero && blockIdx.x == 0 && blockIdx.y == 0)      // side job: clear the GAP accumulator of the next conv
-        for (int z = tid; z < p.nzero; z += (NC + NPW) * 64) p.zero[z] = 0ull;
+    if (p.zero) {                                          // side job: clear an accumulator (the next conv's GAP sums; the transformer's fixed-point sums: 0.9 MB, so every block takes a slice)
+        const int nthr = (NC + NPW) * 64;
+        for (int z = (blockIdx.y * gridDim.x + blockIdx.x) * nthr + tid; z < p.nzero; z += gridDim.x * gridDim.y * nthr) p.zero[z] = 0ull;
+    }
     const int nslice = p.Cin / 64;
 #ifdef PC_ABL_NO_LOOP
     const int nk = 0;

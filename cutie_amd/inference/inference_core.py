@@ -30,6 +30,8 @@ AHEAD_AFFINITY = os.environ.get('CUTIE_AMD_AHEAD_AFFINITY', '1') not in ('', '0'
 DEFER_MEM = os.environ.get('CUTIE_AMD_DEFER_MEM', '0') not in ('', '0')
 # look-ahead WINDOW of the image encoder (step(next_images=...)): frames per batched encoder plan (<= 1: one frame at a time, as with
 # next_image), and how many already-encoded frames may be left ahead when the next batch is started
+# memory frames in two parts when the next frame is encoded already: its affinity read-out overlaps the summarizer (A/B switch)
+MEM_SPLIT = os.environ.get('CUTIE_AMD_MEM_SPLIT', '1') not in ('', '0')
 WAIT_TRACE = None                                          # a list: step() brackets its wait for the look-ahead with timing events (diagnostic)
 WINDOW = int(os.environ.get('CUTIE_AMD_WINDOW', '8'))
 WINDOW_LEAD = int(os.environ.get('CUTIE_AMD_WINDOW_LEAD', '2'))
@@ -90,6 +92,7 @@ class InferenceCore:
         self._pending_refs = None      # its inputs: kept referenced until it is joined (pooled buffers are recycled by reference count)
         self._win_stream = None        # third stream: the batched image encoder of the look-ahead window (prefetch_window)
         self._window = {}              # frame key -> (prepared image, record of CUTIE._encode_window, event, source image, geometry)
+        self._prefetched_rec = None    # the encoder record behind _prefetched (window path): lets _add_memory start that frame's read-out
 
     def _engine_stream(self, name, dev):
         """The look-ahead streams belong to the ENGINE (= one set of plan buffers / arenas), not to the processor: two processors that
@@ -241,28 +244,39 @@ class InferenceCore:
         ms_features, pix_feat, key, shrinkage, selection = self.network._adopt_encoded(o)
         frame_context.remember('geometry', prepared, geometry)
         if affinity:
-            enc = None
-            if gpu:
-                enc = self._side_stream(dev)
-                enc.wait_stream(main)
-                enc.wait_event(ev)
-            pool = self.network.engine().pool
-            pool.offset = 1
-            try:
-                with on(enc):
-                    ro = self.memory.prefetch_affinity(key, selection, self.network)
-                    if gpu:
-                        ev = torch.cuda.Event()
-                        ev.record(enc)
-            finally:
-                pool.offset = 0
-            for v in (ro or {}).values():
-                if isinstance(v[0], torch.Tensor) and v[0].is_cuda:
-                    v[0].record_stream(main)
-            for t in o.values():
-                if isinstance(t, torch.Tensor) and t.is_cuda:
-                    t.record_stream(enc)
+            ev = self._ahead_affinity(key, selection, ev, o)
         self._prefetched = (keys[0], prepared, (ms_features, pix_feat, key, shrinkage, selection), ev, src, geometry)
+        self._prefetched_rec = o
+
+    def _ahead_affinity(self, key, selection, ev, o):
+        """The NEXT frame's affinity read-out on the side stream, against the bank as the caller's stream leaves it at this point
+        (key / selection: that frame's, ready behind `ev`).  Returns the event `step` has to wait for instead of `ev`."""
+        dev = self.network.device
+        gpu = dev.type == 'cuda'
+        enc = main = None
+        if gpu:
+            main = torch.cuda.current_stream(dev)
+            enc = self._side_stream(dev)
+            enc.wait_stream(main)
+            if ev is not None:
+                enc.wait_event(ev)
+        pool = self.network.engine().pool
+        pool.offset = 1
+        try:
+            with (torch.cuda.stream(enc) if gpu else contextlib.nullcontext()):
+                ro = self.memory.prefetch_affinity(key, selection, self.network)
+                if gpu:
+                    ev = torch.cuda.Event()
+                    ev.record(enc)
+        finally:
+            pool.offset = 0
+        for v in (ro or {}).values():
+            if isinstance(v[0], torch.Tensor) and v[0].is_cuda:
+                v[0].record_stream(main)
+        for t in o.values():
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(enc)
+        return ev
 
     def _resize(self, x: torch.Tensor, size, *, nearest: bool = False) -> torch.Tensor:
         """F.interpolate(x[None], size, bilinear align_corners=False | nearest-exact)[0] for f32 [C,H,W] as the RESIZE kernel."""
@@ -303,7 +317,7 @@ class InferenceCore:
         if self._prefetched is not None:                        # a look-ahead of the old bank: order its buffers, drop it
             if self._prefetched[3] is not None:
                 torch.cuda.current_stream(self._prefetched[1].device).wait_event(self._prefetched[3])
-            self._prefetched = None
+            self._prefetched = self._prefetched_rec = None
         if self._flip is not None:
             self._flip.clear_memory()
 
@@ -340,10 +354,27 @@ class InferenceCore:
         self.memory.initialize_sensory_if_needed(key, ids)
         g = frame_context.recall('geometry', image)            # (h0, w0, H, W, pad_left, pad_top) of the un-padded frame
         raw = (image, g[0], g[1], g[4], g[5]) if g is not None else None
-        msk_value, sensory, obj_value, _ = self.network.encode_mask(
-            image, pix_feat, self.memory.get_sensory(ids), prob, deep_update=is_deep_update, chunk_size=self.chunk_size,
-            need_weights=self.save_aux, _raw=raw)
-        self.memory.add_memory(key, shrinkage, msk_value, obj_value, ids, selection=selection, as_permanent=as_permanent)
+        pre = self._prefetched
+        if (MEM_SPLIT and AHEAD_AFFINITY and pre is not None and self._prefetched_rec is not None and self._flip is None
+                and self._lane_of_other is None):
+            # The next frame is encoded already (window hints): memorise in two parts.  The mask VALUES go into the bank first; then that
+            # frame's affinity read-out -- which a memory frame cannot run ahead of its own insertion -- starts on the side stream against
+            # the updated bank, while this stream computes the rest of encode_mask (sensory deep update, object summaries: they touch
+            # neither the bank nor the read-out).  Same launches, same inputs: bit-identical to the one-part order.
+            msk_value, finish = self.network.encode_mask(
+                image, pix_feat, self.memory.get_sensory(ids), prob, deep_update=is_deep_update, chunk_size=self.chunk_size,
+                need_weights=self.save_aux, _raw=raw, _split=True)
+            self.memory.add_memory(key, shrinkage, msk_value, None, ids, selection=selection, as_permanent=as_permanent)
+            feats = pre[2]
+            ev = self._ahead_affinity(feats[2], feats[4], pre[3], self._prefetched_rec)
+            self._prefetched = pre[:3] + (ev,) + pre[4:]
+            sensory, obj_value = finish()
+            self.memory.add_object_values(obj_value, ids)
+        else:
+            msk_value, sensory, obj_value, _ = self.network.encode_mask(
+                image, pix_feat, self.memory.get_sensory(ids), prob, deep_update=is_deep_update, chunk_size=self.chunk_size,
+                need_weights=self.save_aux, _raw=raw)
+            self.memory.add_memory(key, shrinkage, msk_value, obj_value, ids, selection=selection, as_permanent=as_permanent)
         self.last_mem_ti = self.curr_ti
         if is_deep_update:
             self.memory.update_sensory(sensory, ids)
@@ -396,7 +427,7 @@ class InferenceCore:
         self.curr_ti += 1
         if self._lane_of_other is None:
             self.network.engine().pool.tick()                  # frame-slot pool: this frame's slot (plans.SlotPool)
-        pre, self._prefetched = self._prefetched, None
+        pre, self._prefetched, self._prefetched_rec = self._prefetched, None, None
         if self._window and not resize_needed and (pre is None or pre[0] != self._frame_key(image)):
             ent = self._window.get(self._frame_key(image))
             if ent is not None:                                # encoded ahead by the window, but not announced as the next frame

@@ -52,7 +52,7 @@ class MemoryManager:
         self._ids: List[int] = []
         self._sens_f32 = None        # [K,h,w,CS]
         self._sens_bf16 = None
-        self._objv = None            # [K,Q,C+1] f32
+        self._objv = None            # [K,Q,C+1] f32 (a property: every assignment takes a new content token, see _objv_token)
         self._objv_ids: List[int] = []
         self._orphan_objv = {}       # summaries of deleted objects (the reference never purges obj_v, :298-307)
         self._scratch = {}
@@ -61,6 +61,20 @@ class MemoryManager:
         self.aux = None
         self._version = next(_VERSIONS)   # replaced whenever the bank changes (invalidates look-ahead read-outs)
         self._ahead_parity = 0
+
+    # The object summaries change only when a frame is memorised (or objects are purged); the transformer's query initialisation
+    # depends on nothing else, so CUTIE.readout_query skips it while the token it is handed stays the same (tokens are process-wide
+    # unique: an engine may serve several managers one after the other).
+    _TOKENS = itertools.count(1)
+
+    @property
+    def _objv(self):
+        return self.__dict__.get('_objv_t')
+
+    @_objv.setter
+    def _objv(self, v):
+        self.__dict__['_objv_t'] = v
+        self._objv_token = next(MemoryManager._TOKENS)
 
     def _read_cfg(self, cfg):
         if self.use_long_term:
@@ -280,7 +294,8 @@ class MemoryManager:
                 pixel_readout = network.pixel_fusion(pix_feat, visual_readout, this_sensory, this_last_mask)
                 a, b = self._rows(objects, self._objv_ids)
                 this_obj_mem = self._objv[a:b].unsqueeze(0).unsqueeze(2)                # [1,K,1,Q,C+1]
-                readout_memory, aux_features = network.readout_query(pixel_readout, this_obj_mem, _last_aux=self.save_aux or _UNFUSED)
+                readout_memory, aux_features = network.readout_query(pixel_readout, this_obj_mem, _last_aux=self.save_aux or _UNFUSED,
+                                                                     _summary_token=(self._objv_token, a, b))
                 for i, obj in enumerate(objects):
                     all_readout[obj] = readout_memory[:, i]
                 chunks.append((objects, readout_memory))
@@ -375,21 +390,7 @@ class MemoryManager:
         ol = O.OpList()
         # ---- object memory: streaming sum (:252-271)
         if obj_value is not None:
-            ov = obj_value[0].to(F32).contiguous()                     # [K,Q,C+1]
-            known = [o for o in objects if o in self._objv_ids]
-            new = [o for o in objects if o not in self._objv_ids]
-            if known:
-                ka, kb = self._rows(known, self._objv_ids)
-                ia = objects.index(known[0])
-                ol.axpy(ov[ia:ia + len(known)], self._objv[ka:kb], n=len(known) * ov.shape[1] * ov.shape[2], a=1.0)
-            if new:
-                ia = objects.index(new[0])
-                rows = ov[ia:ia + len(new)].clone()
-                for j, o in enumerate(new):
-                    if o in self._orphan_objv:                        # object re-added after deletion
-                        rows[j] += self._orphan_objv.pop(o)
-                self._objv = rows if (self._objv is None or not self._objv_ids) else torch.cat([self._objv, rows], 0)
-                self._objv_ids = self._objv_ids + new
+            self.add_object_values(obj_value, objects, ol)
 
         # ---- bucket assignment (kv_memory_store.py:96-117)
         enabled = []
@@ -455,6 +456,31 @@ class MemoryManager:
                     if b.n_long >= self.max_long_tokens - self.num_prototypes:
                         self._remove_obsolete(b, self.max_long_tokens - self.num_prototypes - self.buffer_tokens)
                     self._compress(b)
+
+    def add_object_values(self, obj_value, objects: List[int], ol=None) -> None:
+        """The object-memory half of add_memory (memory_manager.py:252-271: the summaries of a memorised frame are added to the
+        running sums).  On its own when InferenceCore memorises in two parts (add_memory(obj_value=None) first)."""
+        own = ol is None
+        if own:
+            ol = O.OpList()
+        ov = obj_value[0].to(F32).contiguous()                         # [K,Q,C+1]
+        known = [o for o in objects if o in self._objv_ids]
+        new = [o for o in objects if o not in self._objv_ids]
+        if known:
+            ka, kb = self._rows(known, self._objv_ids)
+            ia = objects.index(known[0])
+            ol.axpy(ov[ia:ia + len(known)], self._objv[ka:kb], n=len(known) * ov.shape[1] * ov.shape[2], a=1.0)
+            self._objv_token = next(MemoryManager._TOKENS)               # (updated in place)
+        if new:
+            ia = objects.index(new[0])
+            rows = ov[ia:ia + len(new)].clone()
+            for j, o in enumerate(new):
+                if o in self._orphan_objv:                            # object re-added after deletion
+                    rows[j] += self._orphan_objv.pop(o)
+            self._objv = rows if (self._objv is None or not self._objv_ids) else torch.cat([self._objv, rows], 0)
+            self._objv_ids = self._objv_ids + new
+        if own and len(ol):
+            ol.run()
 
     def _fit_bucket(self, b: Bucket, extra_work: int = 0):
         """Make the slab capacities of a bucket match the current memory settings (they are sized when the bucket is created;

@@ -62,6 +62,10 @@ QCHAIN = os.environ.get('CUTIE_AMD_QCHAIN', '1') not in ('', '0')     # query si
 GRAPHS = os.environ.get('CUTIE_AMD_GRAPHS', '0') not in ('', '0')
 GRAPH_MIN_OPS = 8
 QFFN_SLICE = int(os.environ.get('CUTIE_AMD_QFFN_SLICE', '64'))       # hidden columns per QFFN block (64 | 128)
+# the decoder's last launch (up-sampling + softmax of the logits) on an auxiliary stream next to the sensory update (4 launches that
+# depend on the logits as well, not on each other's branch): A/B switch
+SEG_FORK = os.environ.get('CUTIE_AMD_SEG_FORK', '1') not in ('', '0')
+QINIT_SKIP = os.environ.get('CUTIE_AMD_QINIT_SKIP', '1') not in ('', '0')   # query initialisation only when the object summaries changed (A/B switch)
 ECA_HEAD = os.environ.get('CUTIE_AMD_ECA_HEAD', '1') not in ('', '0')   # mask_pred of a transformer block inside the ECA launch (A/B switch)
 QNEXT = os.environ.get('CUTIE_AMD_QNEXT', '1') not in ('', '0')       # ATTN_P2Q also projects the next block's ATTN_Q2P queries
 AUTOTUNE = os.environ.get('CUTIE_AMD_AUTOTUNE', '0') not in ('', '0')
@@ -299,6 +303,21 @@ class Plan:
             ex.run_cached(ol.arr, self._graphs, self.graph_head)   # replayed as one HIP graph once its pointer signature repeats
         else:
             ol.run(**dyn)
+
+    def run_part(self, lo, hi, first=True, **dyn):
+        """Launches [lo, hi) of the plan (None = to the end): a caller that has something to do between two parts of a stage
+        (InferenceCore._add_memory: the bank insertion between the value encoder and the summarizer).  No graph replay."""
+        if not self.tuned:
+            self.tuned = True
+            self.autotune_convs(**dyn)
+        if first and ARENA_POISON and self.arena is not None and self.arena.tensor is not None:
+            self.arena.tensor.fill_(0xFF)
+        ol = self.ol
+        if ol.arr is None:
+            ol.finalize()
+        if dyn:
+            ol.bind(**dyn)
+        _lib.get_executor().run(ol.arr[lo:hi])
 
     def autotune_convs(self, **dyn):
         """Pick the fastest tile shape for every conv of this plan by timing the candidates on the device
@@ -540,7 +559,7 @@ def build_pixel_fusion(eng, K, h, w, pre=False):
     return P
 
 
-def build_readout_query(eng, K, h, w, last_aux=True):
+def build_readout_query(eng, K, h, w, last_aux=True, fresh=True):
     """CUTIE.readout_query -> QueryTransformer.forward (object_transformer.py:114-177).
     dyn in: pixel bf16 [K,h,w,C], obj_mem f32 [K,Q,C+1].  dyn out: out bf16 [K,h,w,C].
     Aux logits of every block are kept in bufs['aux_logits'] (f32 [blocks+1,K,hw]) for tests.  last_aux=False skips the mask_pred
@@ -553,13 +572,18 @@ def build_readout_query(eng, K, h, w, last_aux=True):
     HW, M = h * w, K * Q
     t = 'object_transformer'
     f = lambda name, shape: P.buf(name, shape, F32)
-    query, query_emb = f('query', (M, C)), f('query_emb', (M, C))
+    query, query_emb = eng.query_bufs(K)                  # (engine-level: the variant with fresh=False reads what the other one wrote)
     use_chain = QCHAIN and not UNFUSED and C == 256 and Q == 16 and heads == 8 and HW <= 24576 and ot['ff_dim'] % QFFN_SLICE == 0
     # fixed-point accumulators of the query chain (three per block), cleared by the first launch of the plan
     qacc = P.buf('qacc', (3 * nb, M, C), torch.int64) if use_chain else None
+    zero_on_conv = None
     if C == 256 and Q == 16 and not UNFUSED:
-        ol.query_init2(Dyn('obj_mem'), query, query_emb, rows=M, w_init=W[t + '.summary_to_query_init'], res_init=eng.rep_embedding('query_init', K),
-                       w_emb=W[t + '.summary_to_query_emb'], res_emb=eng.rep_embedding('query_emb', K), zero=qacc)
+        if fresh or not use_chain:
+            ol.query_init2(Dyn('obj_mem'), query, query_emb, rows=M, w_init=W[t + '.summary_to_query_init'], res_init=eng.rep_embedding('query_init', K),
+                           w_emb=W[t + '.summary_to_query_emb'], res_emb=eng.rep_embedding('query_emb', K), zero=qacc)
+        else:
+            zero_on_conv = qacc        # fresh=False: the summaries have not changed since the last run -- the queries in query_bufs are
+                                       # still theirs; the accumulators are cleared by the first conv of the plan instead
     else:
         vals = f('vals', (M, C))
         ol.query_init(Dyn('obj_mem'), vals, rows=M, C=C)
@@ -577,7 +601,7 @@ def build_readout_query(eng, K, h, w, last_aux=True):
         # pixel_pe feeds nothing but the positional terms R_b, so its projection is composed with theirs at load time
         # (Engine: '.pixel_init_R'): ONE conv x -> [pixel | R_0 | R_1 | ...], the PE part of R as a per-pixel broadcast residual
         CR = C + nb * 3 * C
-        both = P.conv(t + '.pixel_init_R', pix_in, name='pixel_init_R', res=Act(eng.pe_r(h, w), 1, h, w, CR), res_bcast=True)
+        both = P.conv(t + '.pixel_init_R', pix_in, name='pixel_init_R', res=Act(eng.pe_r(h, w), 1, h, w, CR), res_bcast=True, zero=zero_on_conv)
         pixel = Act(both.t, K, h, w, C, CR)
         R_of = lambda b: Act(both.t.view(-1)[C + b * 3 * C:], K, h, w, 3 * C, CR)
     aux = P.buf('aux_logits', (nb + 1, K, HW), F32, persistent=True)      # read by the caller after the run
@@ -717,6 +741,7 @@ def build_segment(eng, K, h, w, update_sensory, pre=False):
     p4 = P.conv('mask_decoder.up_8_4.out_conv.conv2', t2, res=u4, name='p4')
     logits = P.buf('logits', (K, h4, w4), F32)
     P.conv('mask_decoder.pred', p4, relu_in=True, out_f32=True, out=Act(logits, K, h4, w4, 1))
+    P.meta['logits_done'] = len(ol.recs)              # two independent branches follow: the sensory update, and the up-sampling + softmax (LAST launch)
     if update_sensory:
         # area-pooled g8 / g4 / logits written side by side: the second source of the ONE conv that replaces g16_conv + g8_conv +
         # g4_conv (Engine: '.g_all'); the logits take a whole 64-channel K tile (channel 0 written, the rest stays zero)
@@ -761,6 +786,7 @@ def build_encode_mask(eng, K, h0, w0, H, W, pad_left, pad_top, deep_update=True)
     g16, _ = P.resnet('mask_encoder', Act(pool, K, H // 4, W // 4, 64))
     value = P.fusion_block('mask_encoder.fuser', Act(Dyn('pix_feat'), 1, h, w, m['pixel_dim']), g16, 'fuse',
                            out=Act(Dyn('value'), K, h, w, CV))
+    P.meta['value_done'] = len(ol.recs)               # what follows reads named tensors only (value, masks, sensory): see CUTIE._encode_mask_split
     if deep_update:
         vals = P.conv('mask_encoder.sensory_update.transform', value, x2=Act(Dyn('sensory_bf16'), K, h, w, CS),
                       out_f32=True, name='gru_vals')

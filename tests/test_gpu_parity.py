@@ -418,6 +418,44 @@ def test_lookahead_window_matches_plain_order(gpu_net, size, K):
             assert torch.equal(got, plain), (name, float((got - plain).abs().max()))
 
 
+def test_query_init_only_when_the_summaries_changed(gpu_net, monkeypatch):
+    """The transformer's query initialisation (object summaries -> queries) runs only when the summaries changed (memory frames,
+    purges); in between the plan variant without that launch reads the queries of the last run.  Same clip with the switch off:
+    bit-identical probabilities -- across objects added later (a second bucket), a deletion, and a processor that follows another one
+    on the same engine."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.model import plans
+    from cutie_amd.utils.synth import SyntheticClip
+    n = 17
+    clip = SyntheticClip(144, 208, 3, n, seed=31)
+    frames = torch.stack([clip.frame(t) for t in range(n)]).cuda()
+    mask = clip.first_mask().cuda()
+
+    def run(skip):
+        monkeypatch.setattr(plans, 'QINIT_SKIP', skip)
+        outs = []
+        for rep in range(2):                                  # (the second processor meets the first one's state on the engine)
+            proc = InferenceCore(gpu_net, cfg=default_config(mem_every=4))
+            for t in range(n):
+                if t == 0:
+                    outs.append(proc.step(frames[0], mask * (mask != 3).long(), objects=[1, 2]))
+                elif t == 6:
+                    outs.append(proc.step(frames[t], mask * (mask == 3).long(), objects=[3]))
+                else:
+                    if t == 11:
+                        proc.delete_objects([1])
+                    outs.append(proc.step(frames[t]))
+        torch.cuda.synchronize()
+        return [o.cpu() for o in outs]
+
+    with torch.inference_mode():
+        a = run(False)
+        b = run(True)
+    assert any(k[0] == 'rq' and k[-1] is False for k in gpu_net.engine()._plans), 'the variant without QUERY_INIT was never used'
+    for t, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y), (t, float((x - y).abs().max()))
+
+
 def test_lookahead_window_with_long_term_and_two_buckets(gpu_net):
     """Long-term memory, objects added at different times (two buckets: ADVICE r03 -- the look-ahead usage side buffers must
     alternate per frame, not per bucket) and window hints: the usage / life counters of every bucket and the bank sizes equal the

@@ -546,6 +546,7 @@ def test_lookahead_window_bookkeeping_matches_plain_order():
     from cutie_amd.utils.synth import SyntheticClip
     mx = MockExecutor()
     mx.per_sample_conv = True
+    prev = _lib._executor                                       # (the module fixture's interpreter: put back afterwards)
     _lib.set_executor_for_testing(mx)
     try:
         net = CUTIE(default_config())
@@ -582,7 +583,7 @@ def test_lookahead_window_bookkeeping_matches_plain_order():
             assert torch.allclose(b0.use[:b0.work_start + b0.n_work], b1.use[:b1.work_start + b1.n_work], rtol=1e-5, atol=1e-6)
             assert torch.equal(b0.life[:b0.work_start + b0.n_work], b1.life[:b1.work_start + b1.n_work])
     finally:
-        _lib.set_executor_for_testing(None)
+        _lib.set_executor_for_testing(prev)
 
 
 def test_mask_narrower_than_the_frame_is_padded_on_its_own(product_net, oracle_net):
