@@ -92,6 +92,7 @@ class InferenceCore:
         self._pending_refs = None      # its inputs: kept referenced until it is joined (pooled buffers are recycled by reference count)
         self._win_stream = None        # third stream: the batched image encoder of the look-ahead window (prefetch_window)
         self._window = {}              # frame key -> (prepared image, record of CUTIE._encode_window, event, source image, geometry)
+        self._hinted = False           # this step came with look-ahead hints (CUTIE.segment forks its last launch only then)
         self._prefetched_rec = None    # the encoder record behind _prefetched (window path): lets _add_memory start that frame's read-out
 
     def _engine_stream(self, name, dev):
@@ -390,7 +391,7 @@ class InferenceCore:
         memory_readout = stacked if stacked is not None else self.object_manager.realize_dict(memory_readout)
         sensory, _, pred_prob_with_bg = self.network.segment(ms_features, memory_readout, self.memory.get_sensory(ids),
                                                              chunk_size=self.chunk_size, update_sensory=update_sensory,
-                                                             _need_logits=False)
+                                                             _need_logits=False, _fork=self._hinted)
         pred_prob_with_bg = pred_prob_with_bg[0]
         if update_sensory:
             self.memory.update_sensory(sensory, ids)
@@ -457,6 +458,7 @@ class InferenceCore:
             image, (h0, w0, H, W, self.pad) = self._prepare_image(image)
             pl, pt = self.pad[0], self.pad[2]
 
+        self._hinted = (next_image is not None or (next_images is not None and len(next_images) > 0)) and self._flip is None
         is_mem_frame = ((self.curr_ti - self.last_mem_ti >= self.mem_every) or (mask is not None)) and (not end)
         need_segment = (mask is None) or (self.object_manager.num_obj > 0 and not self.object_manager.has_all(objects))
         update_sensory = ((self.curr_ti - self.last_mem_ti) in self.stagger_ti) and (not end)

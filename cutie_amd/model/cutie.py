@@ -586,8 +586,9 @@ class CUTIE(nn.Module):
         return group_logical(out), aux
 
     def segment(self, ms_image_feat: List[torch.Tensor], memory_readout, sensory, *, selector=None, chunk_size=-1,
-                update_sensory=True, _need_logits=True):
-        """cutie.py:172-203.  -> (sensory [1,K,CS,h,w], logits [1,K+1,H,W], prob [1,K+1,H,W]) fp32"""
+                update_sensory=True, _need_logits=True, _fork=False):
+        """cutie.py:172-203.  -> (sensory [1,K,CS,h,w], logits [1,K+1,H,W], prob [1,K+1,H,W]) fp32
+        _fork (InferenceCore, when the caller announces its next frames): the softmax launch on an auxiliary stream, see below."""
         assert selector is None, 'selector is a training-time argument'
         eng = self.engine()
         dev = self.device
@@ -607,11 +608,13 @@ class CUTIE(nn.Module):
         feats = dict(f8=f8, f4=f4) if pre is None else dict(f8p=pre[0], f4p=pre[1])
         dyn = dict(p16=p16, sensory_f32=sf, sensory_bf16=sb, prob=prob, logits_up=lup, **feats)
         n_ops, cut = len(P.ol.recs), P.meta.get('logits_done', 0)
-        if plans.SEG_FORK and update_sensory and dev.type == 'cuda' and not plans.GRAPHS and 0 < cut < n_ops - 1 and not plans.UNFUSED and K + 1 <= 16:
+        if _fork and plans.SEG_FORK and update_sensory and dev.type == 'cuda' and not plans.GRAPHS and 0 < cut < n_ops - 1 and not plans.UNFUSED and K + 1 <= 16:
             # Behind the logits the plan forks: [area pooling, two convs, GRU] update the sensory state, the LAST launch up-samples the
             # logits and takes the softmax.  Neither branch reads what the other writes, and every launch is a serial step of the
             # frame's critical path (~3.4 us of launch boundary on top of its run time): the softmax launch goes to an auxiliary
             # stream of the engine, the caller's stream takes it back in behind the sensory update.  Same launches, same inputs.
+            # Measured in one box (tools/r4_call18.sh): +1.1 % with look-ahead hints, -4 % without them (there the frame is one
+            # stream and the host's extra calls cost more than the overlap returns) -- hence only on the caller's request.
             main = torch.cuda.current_stream(dev)
             st = eng.__dict__.setdefault('_streams', {})
             if 'aux' not in st:
