@@ -57,7 +57,7 @@ def parse():
                          'before its timed steps (SURVEY C2: 18-26k tokens, pruning fires near frame 1995); 0 = skip')
     ap.add_argument('--no-lookahead', action='store_true',
                     help='do not pass next_image to step (no overlap of the next frame\'s image encoder on a side stream)')
-    ap.add_argument('--window', type=int, default=int(os.environ.get('CUTIE_AMD_WINDOW', '8')),
+    ap.add_argument('--window', type=int, default=int(os.environ.get('CUTIE_AMD_WINDOW', '12')),
                     help='frames per batched look-ahead encoder plan (step(next_images=...), InferenceCore.prefetch_window); '
                          '<= 1: one frame ahead (step(next_image=...))')
     ap.add_argument('--repeats', type=int, default=5,
@@ -151,7 +151,8 @@ def make_hint(args, frames, n):
     if args.no_lookahead:
         return lambda t: {}
     if args.window > 1:
-        depth = args.window + 4                            # >= WINDOW + WINDOW_LEAD + 1 frames: a full batch can always be formed
+        from cutie_amd.inference import inference_core as IC
+        depth = args.window + IC.WINDOW_LEAD + 2           # >= WINDOW + WINDOW_LEAD + 1 frames: a full batch can always be formed
         views = [frames[i] for i in range(n)]              # (what a reader holds anyway: no per-step tensor construction in the timed loop)
         views = views + views[:depth + 1]
         return lambda t: {'next_images': views[(t + 1) % n:(t + 1) % n + depth]}
@@ -292,9 +293,9 @@ def main():
         roof = roof_aff = None
         if not args.no_roofline and rank == 0:
             conv_t = conv_f = aff_t = aff_f = 0.0
-            # 20 frames of the timed workload, driven exactly like the timed region (same hints): 4 memory frames, and with the look-ahead
-            # window 5 batched encoder plans -- their conv launches are replayed back to back and divided by the frames
-            nrec = 20
+            # nrec frames of the timed workload, driven exactly like the timed region (same hints): with the look-ahead window 5 batched
+            # encoder plans and `window` memory frames -- their conv launches are replayed back to back and divided by the frames
+            nrec = 20 if args.window <= 1 or args.no_lookahead else 5 * args.window      # whole encoder batches and whole memory cycles
             rec.rec, rec.on = [], True
             for _ in range(nrec):
                 proc.step(frames[t_idx % 128], **la(t_idx))

@@ -494,17 +494,13 @@ __global__ void up4_softmax_fused_kernel(const float* __restrict__ lg, float* __
 // logits are fetched (and turned into clamped logits) once per source pixel instead of once per tap -- 6 K loads for 4 pixels instead
 // of 48 -- and every plane is written with 16-byte stores.  Per pixel the arithmetic and its order are those of the kernel above
 // (bit-identical results; flags&2 of the op keeps the one-pixel form for the comparison in tests).
+// The four output pixels (oy, 4j .. 4j + 3) of the fused up-sampling + softmax: out[plane][q] = probabilities, lo[plane][q] = up-sampled logits.
 template <int PMAX>
-__global__ __launch_bounds__(256) void up4_softmax_fused4_kernel(const float* __restrict__ lg, float* __restrict__ prob, float* __restrict__ lup,
-                                                                 int K, int h, int w) {
-    const int OH = 4 * h, OW = 4 * w;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;             // (oy, j): output pixels (oy, 4j .. 4j + 3)
-    if (idx >= (long)OH * w) return;
-    const int j = idx % w, oy = idx / w;
+__device__ __forceinline__ void up4_four(const float* __restrict__ lg, int K, int h, int w, int oy, int j, float (&out)[PMAX][4], float (&lo)[PMAX][4]) {
     int y0, y1; float ly;
     up_coord(oy, h, 0.25f, y0, y1, ly);
     const int col[3] = {max(j - 1, 0), j, min(j + 1, w - 1)};
-    const long hw = (long)h * w, OHW = (long)OH * OW;
+    const long hw = (long)h * w;
     // clamped logits of the six source pixels: L[r][c][plane], plane 0 = background
     float L[2][3][PMAX];
 #pragma unroll
@@ -522,8 +518,6 @@ __global__ __launch_bounds__(256) void up4_softmax_fused4_kernel(const float* __
                 }
             L[r][c][0] = clamp_logit(bg);
         }
-    float out[PMAX][4];
-    float lo[PMAX][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         int x0, x1; float lx;
@@ -557,6 +551,19 @@ __global__ __launch_bounds__(256) void up4_softmax_fused4_kernel(const float* __
         for (int p = 0; p < PMAX; ++p)
             if (p <= K) out[p][q] = v[p] * inv;
     }
+}
+
+template <int PMAX>
+__global__ __launch_bounds__(256) void up4_softmax_fused4_kernel(const float* __restrict__ lg, float* __restrict__ prob, float* __restrict__ lup,
+                                                                 int K, int h, int w) {
+    const int OH = 4 * h, OW = 4 * w;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;             // (oy, j): output pixels (oy, 4j .. 4j + 3)
+    if (idx >= (long)OH * w) return;
+    const int j = idx % w, oy = idx / w;
+    const long OHW = (long)OH * OW;
+    float out[PMAX][4];
+    float lo[PMAX][4];
+    up4_four<PMAX>(lg, K, h, w, oy, j, out, lo);
     const long base = (long)oy * OW + 4 * j;
 #pragma unroll
     for (int p = 0; p < PMAX; ++p)
@@ -564,6 +571,58 @@ __global__ __launch_bounds__(256) void up4_softmax_fused4_kernel(const float* __
             if (lup) *reinterpret_cast<float4*>(lup + p * OHW + base) = make_float4(lo[p][0], lo[p][1], lo[p][2], lo[p][3]);
             *reinterpret_cast<float4*>(prob + p * OHW + base) = make_float4(out[p][0], out[p][1], out[p][2], out[p][3]);
         }
+}
+
+// The same, one WAVE per 16 x 16 output cell (= one stride-16 pixel), which lets the launch also produce what MASK_DOWN derives from
+// these probabilities for the NEXT frame's pixel fusion: m16[k] = mean of object plane k over the cell, pair = (m16[k], clamp(sum of
+// the others)).  The cell's values go through LDS so that every lane sums the same four entries in the same order as
+// mask_down_pair_kernel (entries lane, lane + 64, +128, +192 of the row-major cell) and the same wave_sum follows: bit-identical to the
+// MASK_DOWN launch it replaces.  4 waves (cells) per block; needs H, W multiples of 16 and K + 1 <= PMAX.
+template <int PMAX>
+__global__ __launch_bounds__(256) void up4_softmax_md_kernel(const float* __restrict__ lg, float* __restrict__ prob, float* __restrict__ lup,
+                                                             int K, int h, int w, float* __restrict__ m16, uint4* __restrict__ pair, int ld8) {
+    __shared__ float cell[4][PMAX - 1][256];
+    const int OH = 4 * h, OW = 4 * w, ch = OH >> 4, cw = OW >> 4, ncell = ch * cw;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cid = blockIdx.x * 4 + wave;
+    if (cid >= ncell) return;                               // whole wave
+    const int cy = cid / cw, cx = cid - cy * cw;
+    const int r = lane >> 2, q4 = lane & 3;
+    const int oy = cy * 16 + r, j = cx * 4 + q4;
+    const long OHW = (long)OH * OW;
+    float out[PMAX][4];
+    float lo[PMAX][4];
+    up4_four<PMAX>(lg, K, h, w, oy, j, out, lo);
+    const long base = (long)oy * OW + 4 * j;
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p)
+        if (p <= K) {
+            if (lup) *reinterpret_cast<float4*>(lup + p * OHW + base) = make_float4(lo[p][0], lo[p][1], lo[p][2], lo[p][3]);
+            *reinterpret_cast<float4*>(prob + p * OHW + base) = make_float4(out[p][0], out[p][1], out[p][2], out[p][3]);
+            if (p >= 1) *reinterpret_cast<float4*>(&cell[wave][p - 1][r * 16 + 4 * q4]) = make_float4(out[p][0], out[p][1], out[p][2], out[p][3]);
+        }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): the cell is wave-private
+    float sum = 0.f, mk[PMAX - 1];
+#pragma unroll
+    for (int k = 0; k < PMAX - 1; ++k)
+        if (k < K) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc += cell[wave][k][lane + 64 * i];
+            const float a = wave_sum(acc) / 256.f;
+            sum += a;
+            mk[k] = a;
+        }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < PMAX - 1; ++k)
+            if (k < K) {
+                m16[(long)k * ncell + cid] = mk[k];
+                const float others = fminf(fmaxf(sum - mk[k], 0.f), 1.f);
+                pair[((long)k * ncell + cid) * ld8] = make_uint4(pack_bf2(mk[k], others), 0u, 0u, 0u);
+            }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1064,6 +1123,13 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             if (op->flags & 1) {                              // p0 = raw logits [K,h,w] (K = P - 1): SEG_AGG fused
                 if (i[0] > 16) { cutie_set_error("up4_softmax: the fused form holds P <= 16 planes in registers (P=%d)", i[0]); return -2; }
                 const bool vec = !(op->flags & 2) && i[0] <= 8 && (((uintptr_t)p[1] | (uintptr_t)p[2]) & 15) == 0;      // four pixels per thread, 16-byte stores
+                if (op->flags & 4) {                              // + MASK_DOWN of the probabilities (p3 = m16, p4 = pair, i3 = channel pitch of pair)
+                    if (!vec || !p[3] || !p[4] || (i[1] & 3) || (i[2] & 3) || i[3] < 8 || (i[3] & 7)) { cutie_set_error("up4_softmax: the mask-down form needs P <= 8, h, w multiples of 4, m16 and pair"); return -2; }
+                    const int ncell = (i[1] / 4) * (i[2] / 4);
+                    hipLaunchKernelGGL(up4_softmax_md_kernel<8>, dim3((ncell + 3) / 4), dim3(256), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, i[1], i[2],
+                                       (float*)p[3], (uint4*)p[4], i[3] / 8);
+                    break;
+                }
                 if (vec) {
                     const long n4 = (long)4 * i[1] * i[2];
                     hipLaunchKernelGGL(up4_softmax_fused4_kernel<8>, GRID1D(n4, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, i[1], i[2]);

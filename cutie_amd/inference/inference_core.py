@@ -33,8 +33,8 @@ DEFER_MEM = os.environ.get('CUTIE_AMD_DEFER_MEM', '0') not in ('', '0')
 # memory frames in two parts when the next frame is encoded already: its affinity read-out overlaps the summarizer (A/B switch)
 MEM_SPLIT = os.environ.get('CUTIE_AMD_MEM_SPLIT', '1') not in ('', '0')
 WAIT_TRACE = None                                          # a list: step() brackets its wait for the look-ahead with timing events (diagnostic)
-WINDOW = int(os.environ.get('CUTIE_AMD_WINDOW', '8'))
-WINDOW_LEAD = int(os.environ.get('CUTIE_AMD_WINDOW_LEAD', '2'))
+WINDOW = int(os.environ.get('CUTIE_AMD_WINDOW', '12'))
+WINDOW_LEAD = int(os.environ.get('CUTIE_AMD_WINDOW_LEAD', '3'))
 
 
 def pad_geometry(h, w, d=16):

@@ -196,6 +196,14 @@ class Engine:
             self._rep[key] = e.repeat(K, 1).to(self.device).contiguous()
         return self._rep[key]
 
+    def mask_down_bufs(self, K, h, w):
+        """(pair bf16 [K, h, w, 64] -- channels 0, 1 = (mask, others), the rest stays zero --, m16 f32 [K, h, w]): MASK_DOWN results that
+        the decoder's last launch of one frame leaves for the pixel fusion of the next (plans.build_segment(md) / build_pixel_fusion(pre_md))."""
+        mb = self.__dict__.setdefault('_md_bufs', {})
+        if (K, h, w) not in mb:
+            mb[(K, h, w)] = (torch.zeros((K, h, w, 64), dtype=BF16, device=self.device), torch.zeros((K, h, w), dtype=F32, device=self.device))
+        return mb[(K, h, w)]
+
     def query_bufs(self, K):
         """f32 [K * Q, C] x 2: the initial object queries / query embeddings of the transformer, shared by the plan variants that write
         and that only read them (CUTIE.readout_query); outside the activation arena, so they survive between frames."""
@@ -216,6 +224,7 @@ class Engine:
         e.__dict__.pop('_splitk_part', None)
         e.__dict__.pop('_streams', None)            # (the look-ahead streams of InferenceCore: one set per engine)
         e.__dict__.pop('_query_bufs', None)
+        e.__dict__.pop('_md_bufs', None)
         e.__dict__.pop('_qinit_state', None)
         return e
 
@@ -555,7 +564,9 @@ class CUTIE(nn.Module):
         _, sb = self._sensory_pair(sensory)
         lm = last_mask[0].to(F32).contiguous()
         xt = None if plans.UNFUSED else frame_context.recall('fuse_xt', pf)             # x_transform(pix_feat), computed with the encoder (None: a caller's own features)
-        P = eng.plan(('fuse', K, h, w, xt is not None), plans.build_pixel_fusion, K, h, w, xt is not None)
+        md = frame_context.recall('mask_down', lm)          # MASK_DOWN(last_mask), left by the segment() that produced this very tensor ...
+        md = md is not None and md == (K, h, w, eng.__dict__.get('_md_gen'))      # ... if no later segment() has overwritten it
+        P = eng.plan(('fuse', K, h, w, xt is not None, md), plans.build_pixel_fusion, K, h, w, xt is not None, md)
         fused = eng.pool.get(('fuse', K, h, w, str(self.device)), dict(fused=((K, h, w, self.embed_dim), BF16, False)), self.device)['fused']
         P.run(pix_feat=pf, pixel=px, sensory_bf16=sb, last_mask=lm, fused=fused, **({} if xt is None else {'fuse_xt': xt}))
         return group_logical(fused)
@@ -599,7 +610,8 @@ class CUTIE(nn.Module):
         pre = None if plans.UNFUSED else frame_context.recall('decoder_feats', f8)     # decoder_feat_proc(f8, f4), computed with the encoder
         if pre is not None and pre[2].data_ptr() != f4.data_ptr():
             pre = None                                         # (f8 of one frame with f4 of another: a caller's own mix)
-        P = eng.plan(('seg', K, h, w, bool(update_sensory), pre is not None), plans.build_segment, K, h, w, bool(update_sensory), pre is not None)
+        md = bool(_fork) and plans.SEG_MD and not plans.UNFUSED and K + 1 <= 8 and dev.type == 'cuda'
+        P = eng.plan(('seg', K, h, w, bool(update_sensory), pre is not None, md), plans.build_segment, K, h, w, bool(update_sensory), pre is not None, md)
         sp = dict(prob=((K + 1, 16 * h, 16 * w), F32, False))
         if _need_logits:
             sp['lup'] = ((K + 1, 16 * h, 16 * w), F32, False)
@@ -630,6 +642,11 @@ class CUTIE(nn.Module):
             P.run(**dyn)
         new_sens = group_logical(sf)
         frame_context.remember('sensory_bf16', sf, sb)
+        if md:
+            eng._md_gen = eng.__dict__.get('_md_gen', 0) + 1
+            frame_context.remember('mask_down', prob[1:], (K, h, w, eng._md_gen), cap=2)   # found again by pixel_fusion through last_mask = prob[1:]
+        else:
+            frame_context.forget('mask_down', prob[1:])                           # (the slot may carry the entry of an earlier frame)
         return new_sens, (lup.unsqueeze(0) if lup is not None else None), prob.unsqueeze(0)
 
     def read_memory(self, *a, **k):

@@ -65,6 +65,8 @@ QFFN_SLICE = int(os.environ.get('CUTIE_AMD_QFFN_SLICE', '64'))       # hidden co
 # the decoder's last launch (up-sampling + softmax of the logits) on an auxiliary stream next to the sensory update (4 launches that
 # depend on the logits as well, not on each other's branch): A/B switch
 SEG_FORK = os.environ.get('CUTIE_AMD_SEG_FORK', '1') not in ('', '0')
+# MASK_DOWN of the next frame's pixel fusion inside the up-sampling launch of the current one (A/B switch)
+SEG_MD = os.environ.get('CUTIE_AMD_SEG_MD', '1') not in ('', '0')
 QINIT_SKIP = os.environ.get('CUTIE_AMD_QINIT_SKIP', '1') not in ('', '0')   # query initialisation only when the object summaries changed (A/B switch)
 ECA_HEAD = os.environ.get('CUTIE_AMD_ECA_HEAD', '1') not in ('', '0')   # mask_pred of a transformer block inside the ECA launch (A/B switch)
 QNEXT = os.environ.get('CUTIE_AMD_QNEXT', '1') not in ('', '0')       # ATTN_P2Q also projects the next block's ATTN_Q2P queries
@@ -540,16 +542,20 @@ def build_transform_key(eng, h, w):
     return P
 
 
-def build_pixel_fusion(eng, K, h, w, pre=False):
+def build_pixel_fusion(eng, K, h, w, pre=False, pre_md=False):
     """CUTIE.pixel_fusion (cutie.py:142-157; big_modules.py:207-235).
     dyn in: pix_feat, pixel (readout) bf16 [K,h,w,CV], sensory_bf16 [K,h,w,CS], last_mask f32 [K,16h,16w];
     pre: fuse_xt bf16 [1,h,w,CE] = x_transform(pix_feat) from the encoder plan instead of pix_feat.
     dyn out: fused bf16 [K,h,w,CE]."""
     P = Plan(eng, touch=weights_go_cold(h * w, K))
     m = eng.m
-    pair = P.buf('pair', (K, h, w, 64), persistent=True)           # (mask, others) in channels 0, 1 of a ZEROED 64-channel tensor: a whole K tile
-    m16 = P.buf('m16', (K, h, w), F32)
-    P.ol.mask_down(Dyn('last_mask'), pair, m16, K=K, H=16 * h, W=16 * w, pair_channels=64)
+    if pre_md:                                           # written by the previous frame's up-sampling launch (build_segment(md=True))
+        pair = eng.mask_down_bufs(K, h, w)[0]
+        P.ol.keep.append(pair)
+    else:
+        pair = P.buf('pair', (K, h, w, 64), persistent=True)       # (mask, others) in channels 0, 1 of a ZEROED 64-channel tensor: a whole K tile
+        m16 = P.buf('m16', (K, h, w), F32)
+        P.ol.mask_down(Dyn('last_mask'), pair, m16, K=K, H=16 * h, W=16 * w, pair_channels=64)
     pixel = Act(Dyn('pixel'), K, h, w, m['value_dim'])
     p16 = P.conv('pixel_fuser.sensory_compress', Act(Dyn('sensory_bf16'), K, h, w, m['sensory_dim']),
                  x2=Act(pair, K, h, w, 64), res=pixel, name='p16')
@@ -710,7 +716,7 @@ def build_readout_query(eng, K, h, w, last_aux=True, fresh=True):
     return P
 
 
-def build_segment(eng, K, h, w, update_sensory, pre=False):
+def build_segment(eng, K, h, w, update_sensory, pre=False, md=False):
     """CUTIE.segment -> MaskDecoder.forward + sigmoid/aggregate/x4/softmax (cutie.py:172-203;
     big_modules.py:257-306; modules.py:8-68).
     dyn in: f8, f4 (bf16), p16 (memory readout) bf16 [K,h,w,C], sensory_f32 / sensory_bf16 [K,h,w,CS] (in-place).
@@ -755,7 +761,10 @@ def build_segment(eng, K, h, w, update_sensory, pre=False):
                       out_f32=True, name='gru_vals')
         ol.gru(vals.t, Dyn('sensory_f32'), Dyn('sensory_bf16'), n=K * h * w, C=CS)
     if K + 1 <= 16 and not UNFUSED:               # aggregation recomputed per bilinear tap inside the up-sampling launch
-        ol.up4_softmax(logits, Dyn('prob'), Dyn('logits_up'), P=K + 1, h=h4, w=w4, from_logits=True)
+        # md: the launch also derives what the NEXT frame's pixel fusion needs from these probabilities (MASK_DOWN: the stride-16 means
+        # of the object planes and the (mask, others) pairs), into buffers both plans know (Engine.mask_down_bufs)
+        ol.up4_softmax(logits, Dyn('prob'), Dyn('logits_up'), P=K + 1, h=h4, w=w4, from_logits=True,
+                       mask_down=(eng.mask_down_bufs(K, h, w)[1], eng.mask_down_bufs(K, h, w)[0], 64) if md else None)
     else:
         agg = P.buf('agg', (K + 1, h4, w4), F32)
         ol.seg_agg(logits, agg, K=K, hw=h4 * w4)

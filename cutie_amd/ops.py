@@ -411,8 +411,13 @@ class OpList:
     def seg_agg(self, logits, agg, *, K, hw):
         return self.add(SEG_AGG, 0, [K, hw], [], [logits, agg])
 
-    def up4_softmax(self, agg, prob, logits_up, *, P, h, w, from_logits=False):
-        """from_logits: `agg` holds the K = P - 1 raw logit planes and the aggregation (SEG_AGG) runs inside the launch (P <= 16)."""
+    def up4_softmax(self, agg, prob, logits_up, *, P, h, w, from_logits=False, mask_down=None):
+        """from_logits: `agg` holds the K = P - 1 raw logit planes and the aggregation (SEG_AGG) runs inside the launch (P <= 16).
+        mask_down = (m16 f32 [K, hw16], pair bf16 [K, h16, w16, pitch], pitch): the launch also writes MASK_DOWN(prob[1:], r = 16)."""
+        if mask_down is not None:
+            assert from_logits and not UP4_SCALAR and P <= 8 and h % 4 == 0 and w % 4 == 0
+            m16, pair, pitch = mask_down
+            return self.add(UP4_SOFTMAX, 1 | 4, [P, h, w, pitch], [], [agg, prob, logits_up, m16, pair])
         return self.add(UP4_SOFTMAX, (1 | UP4_SCALAR) if from_logits else 0, [P, h, w], [], [agg, prob, logits_up])
 
     def mask_merge(self, inmask, pred, src, planes, *, h0, w0, H, W, pad_left, pad_top, Knew, Kold, nfloat, float_mode):

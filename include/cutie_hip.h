@@ -111,7 +111,10 @@ enum {
      * cutie.py:199-200   p0=agg f32 [K+1,h,w] p1=prob f32 [K+1,4h,4w] p2=logits_up f32 (may be 0)
      * i: 0 K+1 1 h 2 w
      * flags&1: SEG_AGG fused -- p0 = raw logits f32 [K,h,w], the aggregation runs per tap inside the launch (K+1 <= 16) 
-     * flags&2 (with flags&1): the one-pixel-per-thread form (A/B switch; default: four pixels per thread, P <= 8) */
+     * flags&2 (with flags&1): the one-pixel-per-thread form (A/B switch; default: four pixels per thread, P <= 8)
+     * flags&4 (with flags&1, P <= 8, h, w % 4 == 0): the launch also produces MASK_DOWN(prob[1:], r = 16) for the next frame's pixel fusion:
+     *      p3 = m16 f32 [K, H/16 * W/16], p4 = pair bf16 [K, H/16, W/16, i3] (channels 0, 1 written), i3 = channel pitch of pair (8 | 64);
+     *      bit-identical to a MASK_DOWN launch on the stored probabilities */
     CUTIE_OP_UP4_SOFTMAX = 11,
     /* MASK_MERGE: build the per-object mask planes of a frame with an input mask
      * inference_core.py:259-300.  plane t: src[t] >= 0 -> (idx==src[t]) [idx mode] / fmask[src[t]] [float

@@ -251,7 +251,16 @@ class MockExecutor:
         up = _bilinear(agg, 0.25)
         if p[2]:
             view(p[2], F32, (P, 4 * h, 4 * w)).copy_(up)
-        view(p[1], F32, (P, 4 * h, 4 * w)).copy_(torch.softmax(up, dim=0))
+        prob = view(p[1], F32, (P, 4 * h, 4 * w))
+        prob.copy_(torch.softmax(up, dim=0))
+        if flags & 4:                                                   # + MASK_DOWN of prob[1:] (r = 16)
+            K, H, W = P - 1, 4 * h, 4 * w
+            m16 = F.avg_pool2d(prob[1:].unsqueeze(0), 16)[0]
+            view(p[3], F32, (K, H // 16, W // 16)).copy_(m16)
+            ld = i[3]
+            out = view(p[4], BF16, (K, H // 16, W // 16, 2), ((H // 16) * (W // 16) * ld, (W // 16) * ld, ld, 1))
+            out[..., 0] = m16
+            out[..., 1] = (m16.sum(0, keepdim=True) - m16).clamp(0, 1)
 
     # ---- MASK_MERGE / AGG_SOFTMAX ----------------------------------------------------------------
     def _op_12(self, flags, i, f, p):

@@ -1182,3 +1182,26 @@ def test_flip_w():
     hip, ref = run_both(build)
     assert torch.equal(hip['dst'], ref['dst'])
     check(hip, ref, name='flip_w', rtol=1e-6)
+
+
+@pytest.mark.parametrize('K,h,w', [(3, 120, 216), (1, 24, 32), (5, 8, 12)])
+def test_up4_softmax_with_mask_down(K, h, w):
+    """UP4_SOFTMAX flags&4: the launch also writes MASK_DOWN(prob[1:], r = 16) -- bit-identical to the MASK_DOWN launch on the stored
+    probabilities (same per-lane sums, same wave reduction), probabilities identical to the plain form."""
+    g = torch.Generator().manual_seed(5)
+    lg = (torch.randn((K, h, w), generator=g) * 3).cuda()
+    H, W = 4 * h, 4 * w
+    assert H % 16 == 0 and W % 16 == 0
+    hw16 = (H // 16) * (W // 16)
+    prob_a, prob_b = torch.zeros((K + 1, H, W), device='cuda'), torch.zeros((K + 1, H, W), device='cuda')
+    pair_a, pair_b = torch.zeros((K, hw16, 64), dtype=BF16, device='cuda'), torch.zeros((K, hw16, 64), dtype=BF16, device='cuda')
+    m_a, m_b = torch.zeros((K, hw16), device='cuda'), torch.zeros((K, hw16), device='cuda')
+    ol = O.OpList()
+    ol.up4_softmax(lg, prob_a, None, P=K + 1, h=h, w=w, from_logits=True, mask_down=(m_a, pair_a, 64))
+    ol.up4_softmax(lg, prob_b, None, P=K + 1, h=h, w=w, from_logits=True)
+    ol.mask_down(prob_b[1:], pair_b, m_b, K=K, H=H, W=W, pair_channels=64)
+    ol.run()
+    torch.cuda.synchronize()
+    assert torch.equal(prob_a, prob_b)
+    assert torch.equal(m_a, m_b)
+    assert torch.equal(pair_a.view(torch.int16), pair_b.view(torch.int16))
