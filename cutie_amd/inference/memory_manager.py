@@ -27,6 +27,7 @@ CAND_CAP = 1024          # candidate slots per query column (typical fill ~35; s
 _UNFUSED = os.environ.get('CUTIE_AMD_UNFUSED', '0') not in ('', '0')      # diagnostic A/B switch, see model/plans.py
 _VALIDATE = os.environ.get('CUTIE_AMD_VALIDATE', '0') not in ('', '0')
 BANK_WRITE = os.environ.get('CUTIE_AMD_BANK_WRITE', '1') not in ('', '0')      # the copies / fills of an insertion in one launch (A/B switch)
+COMMIT_ON_SIDE = os.environ.get('CUTIE_AMD_COMMIT_SIDE', '1') not in ('', '0')  # bookkeeping of a consumed look-ahead read-out on the look-ahead stream (A/B switch)
 # bank versions are drawn from one process-wide counter: a look-ahead read-out tagged with the version of one manager can never pass
 # the check of another (InferenceCore.clear_memory replaces the manager; per-manager counters would restart at 0 and collide)
 _VERSIONS = itertools.count(1)
@@ -87,6 +88,7 @@ class MemoryManager:
             self.max_mem_frames = cfg.max_mem_frames - 1
 
     def update_config(self, cfg) -> None:
+        self._join_side()
         self.config_stale = True
         self._version = next(_VERSIONS)
         self.top_k = cfg['top_k']
@@ -229,10 +231,13 @@ class MemoryManager:
         cached[1].run(**dyn)
         return readout
 
-    def _commit_ahead(self, bucket: Bucket, udelta: torch.Tensor) -> None:
-        """Bookkeeping of a consumed look-ahead read-out, on the current (= the caller's) stream, one launch: the life counters of the
-        counted token ranges advance by one and the usage the read-out parked in its side buffer is added to the bank's
-        (kv_memory_store.py:151-162) -- exactly what `_affinity` does itself when it runs inside `read`."""
+    def _commit_ahead(self, bucket: Bucket, udelta: torch.Tensor, network=None) -> None:
+        """Bookkeeping of a consumed look-ahead read-out, one launch: the life counters of the counted token ranges advance by one and
+        the usage the read-out parked in its side buffer is added to the bank's (kv_memory_store.py:151-162) -- exactly what `_affinity`
+        does itself when it runs inside `read`.  Issued when, and only when, `read` consumes the read-out (a dropped look-ahead has
+        counted nothing) -- but on the look-ahead's OWN stream: nothing on the caller's stream needs the counters before the next
+        memory frame (`_join_side`), the read-outs that follow on that stream see them in order, and the frame's critical path is one
+        launch shorter."""
         if not self.use_long_term:
             return
         tick_work = bucket.n_work > 0
@@ -241,7 +246,23 @@ class MemoryManager:
         ol.usage_tick(bucket.life[bucket.work_start:] if tick_work else None, bucket.n_work if tick_work else 0,
                       bucket.life if tick_long else None, bucket.n_long if tick_long else 0,
                       use=bucket.use, delta=udelta, n_use=int(udelta.shape[0]))
-        ol.run()
+        side = None
+        if COMMIT_ON_SIDE and network is not None and udelta.is_cuda:
+            side = network.engine().__dict__.get('_streams', {}).get('side')
+        if side is None:
+            ol.run()
+            return
+        with torch.cuda.stream(side):                            # (the read-out that filled udelta ran on this stream: in order)
+            ol.run()
+        self._side_pending = side
+
+    def _join_side(self) -> None:
+        """The caller's stream waits for bookkeeping launches that `_commit_ahead` left on the look-ahead stream: before anything on it
+        reads or rewrites the usage / life counters (memorising with its long-term maintenance, a read-out that counts on the bank
+        directly, purges)."""
+        side = self.__dict__.pop('_side_pending', None)
+        if side is not None:
+            torch.cuda.current_stream(side.device).wait_stream(side)
 
     def prefetch_affinity(self, query_key: torch.Tensor, selection: torch.Tensor, network) -> None:
         """Look-ahead lane (no counterpart in the reference): the affinity read-out of the NEXT frame depends only on that frame's
@@ -277,8 +298,9 @@ class MemoryManager:
             if pre is not None and pre[1] == self._version and pre[0].shape[0] == K:
                 readout = pre[0]                                        # computed ahead on the side stream (the caller has waited for it)
                 if pre[2] is not None:
-                    self._commit_ahead(bucket, pre[2])                  # its bookkeeping, now that it is used
+                    self._commit_ahead(bucket, pre[2], network)         # its bookkeeping, now that it is used
             else:
+                self._join_side()
                 readout = self._affinity(bucket, q, h, w, dev)
             # chunk_size > 0 (memory_manager.py:169-186): pixel fusion and the object transformer run per group of chunk_size
             # objects -- this is NOT only a memory knob: the "others" mask of the fusion and the foreground / background
@@ -358,6 +380,7 @@ class MemoryManager:
         # the default is the reference's (memory_manager.py:218) and just as unusable: its store asserts the same
         # (kv_memory_store.py:79); InferenceCore always passes 'no' / 'first' / 'all'
         assert as_permanent in ['no', 'first', 'all']
+        self._join_side()
         self._version = next(_VERSIONS)
         bs = key.shape[0]
         assert bs == 1 and shrinkage.shape[0] == 1 and msk_value.shape[0] == 1
@@ -556,6 +579,7 @@ class MemoryManager:
 
     # ---- object deletion / clearing ----------------------------------------------------------------------------------------
     def purge_except(self, obj_keep_idx: List[int]) -> None:
+        self._join_side()
         self._version = next(_VERSIONS)
         keep = set(obj_keep_idx)
         for bid in list(self.buckets.keys()):
@@ -584,6 +608,7 @@ class MemoryManager:
             self.engaged = False
 
     def clear_non_permanent_memory(self):
+        self._join_side()
         self._version = next(_VERSIONS)
         for b in self.buckets.values():
             b.n_work = 0
