@@ -131,7 +131,9 @@ class Arena:
             return
         self.size = -(-int(nbytes * 1.1) // (1 << 20)) * (1 << 20)
         if self.tensor is not None:
-            self._old = getattr(self, '_old', []) + [self.tensor]       # launches in flight may still use it (growth happens during warm-up only)
+            # launches in flight may still use the arena that is being outgrown: it is kept until the NEXT growth (by then every
+            # launch that was issued against it has long been followed by others in stream order), not forever
+            self._old = [self.tensor]
         self.tensor = torch.zeros(self.size, dtype=torch.uint8, device=self.device)
         for p in self.plans:
             p.rebind_arena()
@@ -159,13 +161,23 @@ class SlotPool:
     behind every read of the frame that used the slot before."""
     SLOTS = int(os.environ.get('CUTIE_AMD_POOL_SLOTS', '6'))
 
+    IDLE_FRAMES = int(os.environ.get('CUTIE_AMD_POOL_IDLE', '512'))      # a group nobody asked for in this many frames is dropped
+
     def __init__(self):
         self.groups = {}                  # key -> {slot index: {name: tensor}}
+        self.last_used = {}               # key -> frame number of the last request
         self.frame = 0
         self.offset = 0
 
     def tick(self):
         self.frame += 1
+        if self.frame % 64 == 0 and self.IDLE_FRAMES > 0:
+            # groups are keyed by (stage, objects, resolution, ...): an interactive session that adds / removes objects, or a multi-scale
+            # evaluation, would otherwise pin SLOTS copies of every shape it has ever seen (ADVICE r03).  Tensors still referenced
+            # elsewhere simply stay alive with their holders.
+            for k in [k for k, f in self.last_used.items() if self.frame - f > self.IDLE_FRAMES]:
+                self.groups.pop(k, None)
+                del self.last_used[k]
 
     def get(self, key, specs, dev):
         """specs: {name: (shape, dtype, zero)} -> {name: tensor}"""
@@ -173,6 +185,7 @@ class SlotPool:
         if self.SLOTS <= 0 or _USE_COUNT is None:
             return fresh()
         slots = self.groups.setdefault(key, {})
+        self.last_used[key] = self.frame
         i = (self.frame + self.offset) % self.SLOTS
         slot = slots.get(i)
         if slot is None:
@@ -188,6 +201,7 @@ class SlotPool:
         if self.SLOTS <= 0 or _USE_COUNT is None:
             return fresh()
         slots = self.groups.setdefault(key, {'next': 0})
+        self.last_used[key] = self.frame
         i = slots['next'] % ring
         slots['next'] = i + 1
         slot = slots.get(i)

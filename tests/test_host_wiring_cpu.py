@@ -607,3 +607,19 @@ def test_mask_narrower_than_the_frame_is_padded_on_its_own(product_net, oracle_n
             assert float((p.float() - o).abs().max()) < (1e-5 if t == 0 else 6e-2), (t, float((p.float() - o).abs().max()))
         with pytest.raises(RuntimeError):
             proc.step(clip.frame(0), full[:, :100].contiguous(), objects=[1, 2, 3])     # pads to 96 x 112: no common padded size
+
+
+def test_slot_pool_drops_idle_groups():
+    """plans.SlotPool: a group (stage x objects x resolution) nobody has asked for in IDLE_FRAMES frames is dropped; live ones stay."""
+    from cutie_amd.model import plans
+    if plans._USE_COUNT is None:
+        pytest.skip('needs the storage use count')
+    pool = plans.SlotPool()
+    pool.IDLE_FRAMES = 100
+    spec = dict(x=((4, 4), torch.float32, False))
+    a = pool.get(('a',), spec, 'cpu')['x']
+    for f in range(300):
+        pool.tick()
+        b = pool.get(('b',), spec, 'cpu')['x']
+    assert ('a',) not in pool.groups and ('b',) in pool.groups and ('a',) not in pool.last_used
+    assert a.shape == (4, 4)                                  # (a caller that still holds a tensor keeps it)
