@@ -129,6 +129,14 @@ class Engine:
             # the same projections applied to the (block-invariant) pixel positional term; v gets none
             wpe = torch.cat([Wp[C:2 * C], torch.zeros(C, C), Wq[:C]], 0)
             self._pe_w[b] = wpe
+            self._pe_wb = getattr(self, '_pe_wb', {})
+            self._pe_wb[b] = wpe.float()
+            # ... or inside the block's own projection (round 4): kvq_b = Wm_b pixel_b + Wpe_b (We x + be + PE) as ONE conv over the virtual
+            # concat [pixel_b | x] with the composed weights [Wm_b | Wpe_b We]; only the PE term is left as a per-pixel residual (pe_rb).
+            # Same flops as one conv x -> [R_0 | R_1 | R_2] in front, without writing and re-reading 3 x 768 channels per pixel and object.
+            we_ = sd[t + '.pixel_emb_proj.weight'].float().reshape(C, -1)
+            W[q + '.pixel_proj_x'] = pack_conv(torch.cat([wm.float(), wpe.float() @ we_], 1).reshape(3 * C, 2 * C, 1, 1),
+                                               bm.float() + wpe.float() @ sd[t + '.pixel_emb_proj.bias'].float(), dev, segs=[(C, C), (C, C)])
             W[q + '.read_from_pixel.q'] = pack_linear(Wp[:C], bp[:C], dev)
             W[q + '.read_from_pixel.out'] = pack_linear(sd[rp + '.out_proj.weight'], sd[rp + '.out_proj.bias'], dev)
             W[q + '.self_attn.qkv'] = pack_linear(Ws, bs, dev)                    # one launch; the query PE feeds q and k only
@@ -149,6 +157,7 @@ class Engine:
         we = sd[t + '.pixel_emb_proj.weight'].float().reshape(C, -1)
         W[t + '.pixel_init_R'] = pack_conv(torch.cat([sd[t + '.pixel_init_proj.weight'].float(), (wpe_all @ we).reshape(-1, we.shape[1], 1, 1)], 0),
                                            torch.cat([sd[t + '.pixel_init_proj.bias'].float(), wpe_all @ sd[t + '.pixel_emb_proj.bias'].float()], 0), dev)
+        conv(t + '.pixel_init_proj')
         # pixel_init_proj | pixel_emb_proj read the same input: one conv with 2C output channels
         W[t + '.pixel_init_emb'] = pack_conv(torch.cat([sd[t + '.pixel_init_proj.weight'], sd[t + '.pixel_emb_proj.weight']], 0),
                                              torch.cat([sd[t + '.pixel_init_proj.bias'], sd[t + '.pixel_emb_proj.bias']], 0), dev)
@@ -187,6 +196,15 @@ class Engine:
             e = e.reshape(h * w, -1).float()
             r = e @ self._wpe_all.t()
             self._pe[key] = torch.cat([torch.zeros_like(e), r], 1).to(BF16).to(self.device).contiguous()
+        return self._pe[key]
+
+    def pe_rb(self, h, w, b):
+        """bf16 [h*w, 3C]: Wpe_b PE -- the broadcast residual of block b's composed pixel projection (Engine: '.pixel_proj_x')."""
+        key = ('pe_rb', h, w, b)
+        if key not in self._pe:
+            e = plans.positional_encoding(h, w, self.m['embed_dim'], self.m['pixel_pe_scale'], self.m['pixel_pe_temperature'])
+            e = e.reshape(h * w, -1).float()
+            self._pe[key] = (e @ self._pe_wb[b].t()).to(BF16).to(self.device).contiguous()
         return self._pe[key]
 
     def rep_embedding(self, which, K):
@@ -610,6 +628,8 @@ class CUTIE(nn.Module):
         pre = None if plans.UNFUSED else frame_context.recall('decoder_feats', f8)     # decoder_feat_proc(f8, f4), computed with the encoder
         if pre is not None and pre[2].data_ptr() != f4.data_ptr():
             pre = None                                         # (f8 of one frame with f4 of another: a caller's own mix)
+        # (only on the caller's announcement: its contract -- do not modify handed-out tensors between steps -- is what makes the
+        # MASK_DOWN computed here valid for the next frame; inference tensors carry no version counter to check it with)
         md = bool(_fork) and plans.SEG_MD and not plans.UNFUSED and K + 1 <= 8 and dev.type == 'cuda'
         P = eng.plan(('seg', K, h, w, bool(update_sensory), pre is not None, md), plans.build_segment, K, h, w, bool(update_sensory), pre is not None, md)
         sp = dict(prob=((K + 1, 16 * h, 16 * w), F32, False))

@@ -64,6 +64,9 @@ GRAPH_MIN_OPS = 8
 QFFN_SLICE = int(os.environ.get('CUTIE_AMD_QFFN_SLICE', '64'))       # hidden columns per QFFN block (64 | 128)
 # the decoder's last launch (up-sampling + softmax of the logits) on an auxiliary stream next to the sensory update (4 launches that
 # depend on the logits as well, not on each other's branch): A/B switch
+# positional terms of the transformer's pixel projections composed INTO each block's projection conv ([pixel_b | x] -> k | v | q2) instead
+# of one conv x -> [pixel | R_0 | R_1 | R_2] in front of the blocks (A/B switch)
+PROJ_X = os.environ.get('CUTIE_AMD_PROJ_X', '1') not in ('', '0')
 SEG_FORK = os.environ.get('CUTIE_AMD_SEG_FORK', '1') not in ('', '0')
 # MASK_DOWN of the next frame's pixel fusion inside the up-sampling launch of the current one (A/B switch)
 SEG_MD = os.environ.get('CUTIE_AMD_SEG_MD', '1') not in ('', '0')
@@ -617,6 +620,10 @@ def build_readout_query(eng, K, h, w, last_aux=True, fresh=True):
         pixel_pe = Act(both.t.view(-1)[C:], K, h, w, C, 2 * C)
         R_all = P.conv(t + '.pe_proj_all', pixel_pe, name='R_all')               # [Wk.pe | 0 | Wq2.pe] of every block
         R_of = lambda b: Act(R_all.t.view(-1)[b * 3 * C:], K, h, w, 3 * C, nb * 3 * C)
+    elif PROJ_X:
+        # the positional terms live inside each block's projection (Engine: '.pixel_proj_x'): only pixel = pixel_init_proj(x) here
+        pixel = P.conv(t + '.pixel_init_proj', pix_in, name='pixel_init', zero=zero_on_conv)
+        R_of = None
     else:
         # pixel_pe feeds nothing but the positional terms R_b, so its projection is composed with theirs at load time
         # (Engine: '.pixel_init_R'): ONE conv x -> [pixel | R_0 | R_1 | ...], the PE part of R as a per-pixel broadcast residual
@@ -636,8 +643,10 @@ def build_readout_query(eng, K, h, w, last_aux=True, fresh=True):
     for b in range(nb):
         q = f'{t}.blocks.{b}'
         n = f'b{b}.'
-        R = R_of(b)
-        kvq = P.conv(q + '.pixel_proj', pixel, name=n + 'kvq', res=R)            # k | v | q2 of the pixels
+        if R_of is None:                                         # k | v | q2 of the pixels, positional terms included: [pixel_b | x] -> 3C
+            kvq = P.conv(q + '.pixel_proj_x', pixel, x2=pix_in, name=n + 'kvq', res=Act(eng.pe_rb(h, w, b), 1, h, w, 3 * C), res_bcast=True)
+        else:
+            kvq = P.conv(q + '.pixel_proj', pixel, name=n + 'kvq', res=R_of(b))    # k | v | q2 of the pixels
         # read_from_pixel (CrossAttention, transformer_layers.py:75-98): residual is the normed x.  Every LayerNorm of the
         # block is fused into the linear that consumes it (the normalised rows are kept where the reference reuses them).
         ln = lambda name: (W[q + name + '.weight'], W[q + name + '.bias'])
