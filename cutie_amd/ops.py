@@ -30,6 +30,7 @@ for _n in ('CONV MAXPOOL IMG_PREP UPSAMPLE2X_ADD AREA_DOWN MASK_DOWN GAP ECA_APP
 
 F_RELU_IN, F_OUT_F32, F_RES_BCAST = 1, 2, 4
 F_PLAIN = 8 if os.environ.get('CUTIE_AMD_COUT1_ROWS', '1') in ('', '0') else 0      # A/B switch of conv_cout1_rows_kernel
+F_TILE_OFF = 128 if os.environ.get('CUTIE_AMD_COUT1_TILE', '1') in ('', '0') else 0  # A/B switch of conv_cout1_tile_kernel
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQ1 = 0, 1, 2, 3
 ACT_SHIFT = 4
 UP4_SCALAR = 2 if os.environ.get('CUTIE_AMD_UP4_VEC', '1') in ('', '0') else 0       # UP4_SOFTMAX flags&2: one pixel per thread (A/B switch)
@@ -336,7 +337,7 @@ class OpList:
         """w: PackedConv (weights.py).  gap_acc: int64 [B, Cout] -- the conv adds the per-(object, channel) sums of its stored output
         (fixed point x 2^24) to it (ECA's global average pool without a launch of its own); zero: an int64 tensor cleared by this
         launch (the accumulator of the NEXT conv).  Both need an LDS-DMA tile (the tile choice is restricted accordingly)."""
-        flags = (F_RELU_IN if relu_in else 0) | (F_OUT_F32 if out_f32 else 0) | (F_RES_BCAST if res_bcast else 0) | (act << ACT_SHIFT) | F_PLAIN
+        flags = (F_RELU_IN if relu_in else 0) | (F_OUT_F32 if out_f32 else 0) | (F_RES_BCAST if res_bcast else 0) | (act << ACT_SHIFT) | F_PLAIN | F_TILE_OFF
         assert C1 + C2 == w.cin_padded, (C1, C2, w.cin_padded)
         M = B * OH * OW
         side = gap_acc is not None or zero is not None

@@ -41,6 +41,7 @@ typedef struct cutie_op {
 #define CUTIE_F_OUT_F32   2   /* output stored as f32 (default bf16) */
 #define CUTIE_F_RES_BCAST 4   /* residual has batch 1 and is broadcast over the B objects */
 #define CUTIE_F_PLAIN     8   /* A/B switch: the general kernel where a specialised one exists (Cout == 1 on large maps) */
+#define CUTIE_F_TILE_OFF  128 /* A/B switch: Cout == 1, Cin == 128 on large maps without the LDS-tiled kernel (conv_cout1_tile_kernel) */
 #define CUTIE_ACT_SHIFT   4   /* activation code in bits 4..6 */
 #define CUTIE_ACT_NONE    0
 #define CUTIE_ACT_RELU    1

@@ -253,6 +253,21 @@ def test_conv_cout1_rows_kernel(ci):
     check(hip, ref, f'conv cout1 rows [{ci}]')
 
 
+@pytest.mark.parametrize('ci', [0, 2])
+def test_conv_cout1_tile_kernel_matches_rows_kernel_bitwise(ci, monkeypatch):
+    """Cin = 128: conv_cout1_tile_kernel (input tile in LDS) against conv_cout1_rows_kernel (flags & CUTIE_F_TILE_OFF): the same products
+    in the same order -- identical bits, ragged tiles and image borders included."""
+    outs = []
+    for off in (0, 128):
+        monkeypatch.setattr(O, 'F_TILE_OFF', off)
+        ol, t = _conv_build(ROWS_CASES[ci], O.COUT1_TILE)('cuda', torch.Generator().manual_seed(41))
+        ol.run()
+        torch.cuda.synchronize()
+        outs.append({k: v.clone() for k, v in t.items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
+
 def test_conv_cout1_1x1_relu_in():
     c = dict(B=3, H=30, W=54, C1=256, Cout=1, k=1, relu_in=True, out_f32=True)
     hip, ref = run_both(_conv_build(c, O.COUT1_TILE), seed=9)
