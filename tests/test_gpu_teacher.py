@@ -47,12 +47,14 @@ def nets(model):
     return _cache[model]
 
 
-# Ratchet: the worst per-frame deviations OBSERVED on the MI355X at the end of round 3 (tests/golden/observed_r03.json, written by
+# Ratchet: the worst per-frame deviations OBSERVED on the MI355X at the end of round 4 (tests/golden/observed_r04.json, written by
 # `CUTIE_RECORD_OBSERVED=path pytest tests/test_gpu_teacher.py`).  A run may exceed neither the reference's reduced-precision
 # envelope (above) nor 1.5 x what this build actually did -- a numerical regression that doubles the error inside the envelope fails.
-_OBS_PATH = os.path.join(S.GOLDEN_DIR, 'observed_r03.json')
-OBSERVED = json.load(open(_OBS_PATH)) if os.path.exists(_OBS_PATH) else {}
+_OBS_PATH = os.path.join(S.GOLDEN_DIR, 'observed_r04.json')
 _RECORD = os.environ.get('CUTIE_RECORD_OBSERVED')
+# (re-recording the baseline after a change that moves roundings -- round 4: the positional terms inside the transformer's projection
+# convs, errors moved by a few per cent in both directions -- runs without the old baseline; the envelope bounds stay in force)
+OBSERVED = json.load(open(_OBS_PATH)) if (os.path.exists(_OBS_PATH) and not (_RECORD and os.environ.get('CUTIE_REBASE_OBSERVED'))) else {}
 _recorded = {}
 
 
