@@ -564,22 +564,6 @@ class CUTIE(nn.Module):
             P.run_part(0, cut, **dyn)
 
             def finish():
-                mid = P.meta.get('deep_done', cut)
-                if plans.SUM_FORK and deep_update and dev.type == 'cuda' and cut < mid < len(P.ol.recs) and not plans.UNFUSED:
-                    # the deep update (conv + GRU) on this stream, the summarizer (9 launches) on the engine's auxiliary stream
-                    main = torch.cuda.current_stream(dev)
-                    st = eng.__dict__.setdefault('_streams', {})
-                    if 'aux' not in st:
-                        st['aux'] = torch.cuda.Stream(device=dev)
-                    aux = st['aux']
-                    P.ol.bind(**dyn)
-                    aux.wait_stream(main)
-                    with torch.cuda.stream(aux):
-                        P.run_part(mid, None, first=False)
-                    P.run_part(cut, mid, first=False)
-                    main.wait_stream(aux)
-                    frame_context.remember('sensory_bf16', sf, sb)
-                    return group_logical(sf), summ.unsqueeze(0)
                 P.run_part(cut, None, first=False, **dyn)
                 frame_context.remember('sensory_bf16', sf, sb)
                 return group_logical(sf), summ.unsqueeze(0)

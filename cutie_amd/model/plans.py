@@ -68,7 +68,6 @@ QFFN_SLICE = int(os.environ.get('CUTIE_AMD_QFFN_SLICE', '64'))       # hidden co
 # of one conv x -> [pixel | R_0 | R_1 | R_2] in front of the blocks (A/B switch)
 PROJ_X = os.environ.get('CUTIE_AMD_PROJ_X', '1') not in ('', '0')
 SEG_FORK = os.environ.get('CUTIE_AMD_SEG_FORK', '1') not in ('', '0')
-SUM_FORK = os.environ.get('CUTIE_AMD_SUM_FORK', '1') not in ('', '0')   # memory frames: the object summarizer on an auxiliary stream next to the deep update
 # MASK_DOWN of the next frame's pixel fusion inside the up-sampling launch of the current one (A/B switch)
 SEG_MD = os.environ.get('CUTIE_AMD_SEG_MD', '1') not in ('', '0')
 QINIT_SKIP = os.environ.get('CUTIE_AMD_QINIT_SKIP', '1') not in ('', '0')   # query initialisation only when the object summaries changed (A/B switch)
@@ -824,19 +823,16 @@ def build_encode_mask(eng, K, h0, w0, H, W, pad_left, pad_top, deep_update=True)
         vals = P.conv('mask_encoder.sensory_update.transform', value, x2=Act(Dyn('sensory_bf16'), K, h, w, CS),
                       out_f32=True, name='gru_vals')
         ol.gru(vals.t, Dyn('sensory_f32'), Dyn('sensory_bf16'), n=K * h * w, C=CS)
-    # object summarizer.  (Its buffers are kept out of the arena: with look-ahead hints these launches run on an auxiliary stream NEXT to
-    # the deep update above -- both read `value` and nothing of each other --, and arena slots are shared by launch order.)
-    P.meta['deep_done'] = len(ol.recs)
-    pst = dict(persistent=True)
-    pair = P.buf('pair', (K, h, w, 8), **pst)
-    m16 = P.buf('m16', (K, h, w), F32, **pst)
+    # object summarizer
+    pair = P.buf('pair', (K, h, w, 8))
+    m16 = P.buf('m16', (K, h, w), F32)
     ol.mask_down(Dyn('masks'), pair, m16, K=K, H=H, W=W)
     pe = Act(eng.pe(h, w), 1, h, w, CE)
-    v1 = P.conv('object_summarizer.input_proj', value, res=pe, res_bcast=True, name='sum.v1', persistent=True)
-    f1 = P.conv('object_summarizer.feature_pred.0', v1, act=O.ACT_RELU, name='sum.f1', persistent=True)
-    feat = P.conv('object_summarizer.feature_pred.2', f1, name='sum.feat', persistent=True)
-    w1 = P.conv('object_summarizer.weights_pred.0', v1, act=O.ACT_RELU, name='sum.w1', persistent=True)
-    wl = P.conv('object_summarizer.weights_pred.2', w1, out_f32=True, name='sum.wl', persistent=True)
+    v1 = P.conv('object_summarizer.input_proj', value, res=pe, res_bcast=True, name='sum.v1')
+    f1 = P.conv('object_summarizer.feature_pred.0', v1, act=O.ACT_RELU, name='sum.f1')
+    feat = P.conv('object_summarizer.feature_pred.2', f1, name='sum.feat')
+    w1 = P.conv('object_summarizer.weights_pred.0', v1, act=O.ACT_RELU, name='sum.w1')
+    wl = P.conv('object_summarizer.weights_pred.2', w1, out_f32=True, name='sum.wl')
     ol.summarize(feat.t, wl.t, m16, Dyn('summ'), K=K, HW=h * w, C=CE, Q=Q)
     return P
 
