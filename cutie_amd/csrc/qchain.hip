@@ -626,6 +626,192 @@ __global__ __launch_bounds__(256) void p2q_chain_kernel(QIn in, const bf16_t* __
     ATL(3)
 }
 
+// =====================================================================================================================================
+// ATTN_P2Q + the output projection of read_from_query + the residual (flags&32): pixel = pixel + Wo . attn + bo in the SAME launch -- the
+// 1x1 conv behind ATTN_P2Q (6.6 us + a launch boundary, three times per frame) is gone, and so is the bf16 round trip of the attention
+// output through HBM.  grid (ceil(HW / 64) [+ 8 with flags&16], K), block 512: wave h IS head h for the block's 64 pixels --
+//   1. the 16 rows of the object are staged once (8 waves x 2 rows); wave h projects ITS head's k (2 column tiles, from x_eff + emb) and v
+//      (2 tiles, from x_eff): per tile the MFMA sequence of p2q_chain_kernel (lo, hi per 32-wide k step), so k / v are bit-identical;
+//   2. the attention of p2q_chain_kernel on four 16-pixel tiles; O^T (dims x pixels) goes to an LDS tile [64 pixels][256] in bf16 --
+//      the value ATTN_P2Q stores;
+//   3. Y^T[out][pixel] = Wo[out][:] . O[pixel][:]: wave h computes output channels 32h .. 32h + 31 of all 64 pixels, eight 32-wide k steps
+//      in ascending order into one accumulator per output (the 'stream' K order of the conv kernels, ops.korder_class), then + bias,
+//      + residual, round -- the conv epilogue's order: bit-identical to ATTN_P2Q followed by the conv on a stream tile.
+// MEASURED AND NOT USED BY THE FRAME (plans.P2Q_OUT = 0): a block pulls 64 KB of rows + 256 KB of Wkv + 128 KB of Wo + 64 KB of pixels
+// through ONE compute unit -- at the ~25 GB/s a CU sustains on fragment-shaped loads that is 21.6 us (rows staged after 7 us, k / v projected
+// after 14 us; tools/attn_timeline.py) against 7.0 us + 4.8 us + one launch boundary for the head-split kernel and the conv: frame -1.8 %.
+// Kept as the tested reference point of "a fusion that concentrates weights in few workgroups loses" (profiles/r04_frame_chain.md section 6).
+// =====================================================================================================================================
+struct P2QOut { const bf16_t* Wo; const float* bo; const bf16_t* res; };   // Wo [256][256] (out, in); res / y: [K, HW, 256]
+#define P2O_LD 264                                       // bf16 pitch of the attention tile: the 16 rows of a fragment read start 4 banks apart
+#define P2O_LDS_BYTES (2 * 16 * PROJ_XLD * 4 + 8 * 2 * 16 * 36 * 4 + 64 * P2O_LD * 2)
+__global__ __launch_bounds__(512) void p2q_out_kernel(QIn in, const bf16_t* __restrict__ q, bf16_t* __restrict__ y, int HW, int ldq, NextQ nq, P2QOut po, int ntiles) {
+    constexpr int C = 256;
+    extern __shared__ uint8_t dynlds[];
+    float* const sX0 = reinterpret_cast<float*>(dynlds);
+    float* const sX1 = sX0 + 16 * PROJ_XLD;
+    float (*sKV)[16][36] = reinterpret_cast<float (*)[16][36]>(dynlds + 2 * 16 * PROJ_XLD * 4);        // [head * 2 + isv][query][dim]
+    bf16_t* const sO = reinterpret_cast<bf16_t*>(dynlds + 2 * 16 * PROJ_XLD * 4 + 8 * 2 * 16 * 36 * 4);
+    const int k = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const float scale = rsqrtf(32.f);
+    ATL(0)
+    if ((int)blockIdx.x >= ntiles) {                       // the next block's q projection for head blockIdx.x - ntiles (see p2q_chain_kernel)
+        const int hh = blockIdx.x - ntiles, isv = (wave >> 1) & 1, col = (wave & 1) * 16;
+        QIn in2 = in;
+        in2.ln_g = nq.ln_g; in2.ln_b = nq.ln_b; in2.ln_out = nq.xn_out;
+        QRows<2> R2;
+        qrows_issue<8, 2, true, true, true>(in2, k, R2);
+        proj_u4 wq[4];
+        if (wave < 4) proj16_load<4>(nq.W, hh * 32 + col, 4 * isv, wq);
+        qrows_finish<8, 2, true, true, true>(in2, k, R2, sX0, nullptr, hh == 0);
+        QSYNC();
+        f32x4* red = reinterpret_cast<f32x4*>(sX1);
+        if (wave < 4) red[wave * 64 + lane] = proj16_mma<4>(sX0, 4 * isv, wq);
+        QSYNC();
+        if (wave < 2) {
+            const f32x4 a = red[wave * 64 + lane], b = red[(wave + 2) * 64 + lane];
+            const float bv = nq.bias[hh * 32 + col + c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nq.q_out[((long)k * 16 + 4 * g + r) * C + hh * 32 + col + c] = (a[r] + b[r] + bv) * scale;
+        }
+        return;
+    }
+    const int hh = wave;
+    QRows<2> R;
+    qrows_issue<8, 2, true, true, false>(in, k, R);
+    proj_u4 wk[2][8], wv[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) proj16_load<8>(in.W, hh * 32 + t * 16, 0, wk[t]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) proj16_load<8>(in.W, C + hh * 32 + t * 16, 0, wv[t]);
+    const int pbase = blockIdx.x * 64;
+    proj_u4 qv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int p = min(pbase + t * 16 + c, HW - 1);
+        qv[t] = *reinterpret_cast<const proj_u4*>(q + ((long)k * HW + p) * ldq + hh * 32 + 8 * g);
+    }
+    float bk[2], bv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { bk[t] = in.bias[hh * 32 + t * 16 + c]; bv[t] = in.bias[C + hh * 32 + t * 16 + c]; }
+    qrows_finish<8, 2, true, true, false>(in, k, R, sX0, sX1, false);
+    ATL(1)
+    QSYNC();
+    {
+        f32x4 ak[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, av[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            const int kw = s_ * 32 + 8 * g;
+#pragma unroll
+            for (int isv = 0; isv < 2; ++isv) {
+                const float* xs = isv ? sX1 : sX0;
+                const float4 a = *reinterpret_cast<const float4*>(xs + c * PROJ_XLD + kw), b = *reinterpret_cast<const float4*>(xs + c * PROJ_XLD + kw + 4);
+                const float xv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                proj_u4 hi, lo;
+                split8(xv, hi, lo);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4& acc = isv ? av[t] : ak[t];
+                    const proj_u4& w = isv ? wv[t][s_] : wk[t][s_];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(lo), as_frag(w), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(hi), as_frag(w), acc, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sKV[hh * 2][4 * g + r][t * 16 + c] = (ak[t][r] + bk[t]) * scale;
+                sKV[hh * 2 + 1][4 * g + r][t * 16 + c] = av[t][r] + bv[t];
+            }
+    }
+    // the out-projection's operands: requested now, consumed after the attention
+    proj_u4 wo[2][8];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) proj16_load<8>(po.Wo, hh * 32 + ct * 16, 0, wo[ct]);
+    uint2 rs[2][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int p = min(pbase + t * 16 + c, HW - 1);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) rs[ct][t] = *reinterpret_cast<const uint2*>(po.res + ((long)k * HW + p) * C + hh * 32 + ct * 16 + 4 * g);
+    }
+    float4 bo[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) bo[ct] = *reinterpret_cast<const float4*>(po.bo + hh * 32 + ct * 16 + 4 * g);
+    ATL(2)
+    // k / v of this head were written by this wave: the LDS queue of a wave is in order, no barrier
+    asm volatile("" ::: "memory");
+    {
+        float kf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kf[j] = sKV[hh * 2][c][8 * g + j];
+        proj_u4 khi, klo, vhi[2], vlo[2];
+        split8(kf, khi, klo);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            float vf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vf[j] = sKV[hh * 2 + 1][4 * g + j][dt * 16 + c];
+            split4(vf, vhi[dt], vlo[dt]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(klo), as_frag(qv[t]), s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(khi), as_frag(qv[t]), s, 0, 0, 0);
+            const float mx = rows_max(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+            float pe[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pe[r] = __expf(s[r] - mx);
+            const float inv = 1.f / rows_sum((pe[0] + pe[1]) + (pe[2] + pe[3]));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pe[r] *= inv;
+            proj_u4 phi, plo;
+            split4(pe, phi, plo);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                o = mfma3(vhi[dt], vlo[dt], phi, plo, o);      // dims dt*16 + 4g .. + 3 of pixel c
+                *reinterpret_cast<uint2*>(sO + (t * 16 + c) * P2O_LD + hh * 32 + dt * 16 + 4 * g) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            }
+        }
+    }
+    ATL(3)
+    QSYNC();
+    {
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[ct][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const proj_u4 b = *reinterpret_cast<const proj_u4*>(sO + (t * 16 + c) * P2O_LD + s_ * 32 + 8 * g);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(wo[ct][s_]), as_frag(b), acc[ct][t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int p = pbase + t * 16 + c;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                float v[4] = {acc[ct][t][0] + bo[ct].x, acc[ct][t][1] + bo[ct].y, acc[ct][t][2] + bo[ct].z, acc[ct][t][3] + bo[ct].w};
+                v[0] += __uint_as_float(rs[ct][t].x << 16); v[1] += __uint_as_float(rs[ct][t].x & 0xffff0000u);
+                v[2] += __uint_as_float(rs[ct][t].y << 16); v[3] += __uint_as_float(rs[ct][t].y & 0xffff0000u);
+                if (p < HW)
+                    *reinterpret_cast<uint2*>(y + ((long)k * HW + p) * C + hh * 32 + ct * 16 + 4 * g) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            }
+        }
+    }
+    ATL(4)
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------------------
 static bool qin_from_op(const cutie_op* op, QIn& in, QOut& out, const char* who, int xslot, int lnout_slot, bool no_proj = false) {
     const uint64_t* p = op->p;
@@ -711,6 +897,22 @@ int launch_qchain(const cutie_op* op, hipStream_t s) {
             if (op->flags & 16) {                            // p8/p9 = LayerNorm of the next block, p12 = its Wq, p13 = bias, p14 = q_out, p15 = xn_out
                 if (!p[8] || !p[9] || !p[12] || !p[13] || !p[14] || !p[15]) { cutie_set_error("attn_p2q (chain form): flags&16 needs p8, p9, p12, p13, p14, p15"); return -2; }
                 nq = NextQ{(const float*)p[8], (const float*)p[9], (const bf16_t*)p[12], (const float*)p[13], (float*)p[14], (float*)p[15]};
+            }
+            if (op->flags & 32) {                            // + read_from_query's output projection and the residual: p2 = [Wo bf16 [256,256] | bias f32 [256]], p4 = residual
+                if (!p[2] || !p[4] || (p[2] & 15) || (p[4] & 7) || (p[3] & 7) || p[3] == p[0]) { cutie_set_error("attn_p2q (flags&32): p2 = Wo | bias (16-byte aligned), p4 = residual, y 8-byte aligned required"); return -2; }
+                static bool attr_set = false;
+                if (!attr_set) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(p2q_out_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P2O_LDS_BYTES) != hipSuccess) {
+                        cutie_set_error("attn_p2q (flags&32): cannot raise the dynamic LDS limit");
+                        return -2;
+                    }
+                    attr_set = true;
+                }
+                const bf16_t* Wo = (const bf16_t*)p[2];
+                const P2QOut po = {Wo, reinterpret_cast<const float*>(Wo + 256 * 256), (const bf16_t*)p[4]};
+                const int ntiles = (i[2] + 63) / 64;
+                hipLaunchKernelGGL(p2q_out_kernel, dim3(ntiles + (nq.W ? 8 : 0), i[0]), dim3(512), P2O_LDS_BYTES, s, in, (const bf16_t*)p[0], (bf16_t*)p[3], i[2], i[5], nq, po, ntiles);
+                break;
             }
             hipLaunchKernelGGL(p2q_chain_kernel, dim3((i[2] + 255) / 256 + (nq.W ? 1 : 0), 8, i[0]), dim3(256), 0, s, in, (const bf16_t*)p[0], (bf16_t*)p[3], i[2], i[5], nq);
         }

@@ -19,7 +19,7 @@ import torch.nn as nn
 from .. import _lib, frame_context
 from . import plans
 from .param_spec import build_spec
-from .weights import fold_bn, pack_conv, pack_linear, linear_as_conv
+from .weights import fold_bn, pack_conv, pack_linear, linear_as_conv, out_proj_blob
 
 log = logging.getLogger()
 BF16, F32 = torch.bfloat16, torch.float32
@@ -143,6 +143,8 @@ class Engine:
             W[q + '.self_attn.out'] = pack_linear(sd[sa + '.out_proj.weight'], sd[sa + '.out_proj.bias'], dev)
             W[q + '.read_from_query.kv'] = pack_linear(Wq[C:], bq[C:], dev)        # [k | v]; the query PE feeds k only
             W[q + '.read_from_query.out'] = linear_as_conv(sd[rq + '.out_proj.weight'], sd[rq + '.out_proj.bias'], dev)
+            if C == 256:
+                W[q + '.read_from_query.out_blob'] = out_proj_blob(W[q + '.read_from_query.out'])       # ATTN_P2Q applies it itself (plans.P2Q_OUT)
             for ln in ('.read_from_pixel.norm', '.self_attn.norm', '.ffn.norm'):
                 W[q + ln + '.weight'] = sd[q + ln + '.weight'].to(dev).contiguous()
                 W[q + ln + '.bias'] = sd[q + ln + '.bias'].to(dev).contiguous()

@@ -70,6 +70,10 @@ PROJ_X = os.environ.get('CUTIE_AMD_PROJ_X', '1') not in ('', '0')
 SEG_FORK = os.environ.get('CUTIE_AMD_SEG_FORK', '1') not in ('', '0')
 # MASK_DOWN of the next frame's pixel fusion inside the up-sampling launch of the current one (A/B switch)
 SEG_MD = os.environ.get('CUTIE_AMD_SEG_MD', '1') not in ('', '0')
+# read_from_query's output projection + residual inside the ATTN_P2Q launch (csrc/qchain.hip: p2q_out_kernel).  Bit-identical and OFF: the
+# fused launch needs every head of a pixel in one workgroup, i.e. all of Wkv + Wo (384 KB) through ONE compute unit -- 21.6 us against
+# 7.0 + 4.8 us + a boundary for the two launches (frame: -1.8 %; profiles/r04_frame_chain.md section 6)
+P2Q_OUT = os.environ.get('CUTIE_AMD_P2Q_OUT', '0') not in ('', '0')
 QINIT_SKIP = os.environ.get('CUTIE_AMD_QINIT_SKIP', '1') not in ('', '0')   # query initialisation only when the object summaries changed (A/B switch)
 ECA_HEAD = os.environ.get('CUTIE_AMD_ECA_HEAD', '1') not in ('', '0')   # mask_pred of a transformer block inside the ECA launch (A/B switch)
 QNEXT = os.environ.get('CUTIE_AMD_QNEXT', '1') not in ('', '0')       # ATTN_P2Q also projects the next block's ATTN_Q2P queries
@@ -676,7 +680,6 @@ def build_readout_query(eng, K, h, w, last_aux=True, fresh=True):
             ol.qffn(y, x2, a3, rows=M, ln=ln('.ffn.norm'), W1=W1, W2=W2, acc_in=(a2, Wo2.bias), hid_slice=QFFN_SLICE)
             x = x2                                                 # + b2 + a3 / 2^32: added by whoever reads x
             prev_acc = (a3, W2.bias)
-            pa = P.buf(n + 'pa', (K, h, w, C))
             next_q = None
             if b + 1 < nb and QNEXT:
                 qn = f'{t}.blocks.{b + 1}'
@@ -685,9 +688,14 @@ def build_readout_query(eng, K, h, w, last_aux=True, fresh=True):
                               q_out=q_pre, xn_out=xn_next)
             else:
                 q_pre = None
-            ol.attn_p2q(kvq.t.view(-1)[2 * C:], None, None, pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C,
-                        proj=dict(x=x, W=W[q + '.read_from_query.kv'], emb=query_emb), acc_in=prev_acc, next_q=next_q)
+            fuse_out = P2Q_OUT and pixel.ld == C and pixel.B == K          # pixel + out_proj(attention) by the same launch: no 1x1 conv behind it
+            pf = Act(P.buf(n + 'pf', (K, h, w, C)), K, h, w, C) if fuse_out else None
+            pa = None if fuse_out else P.buf(n + 'pa', (K, h, w, C))
+            ol.attn_p2q(kvq.t.view(-1)[2 * C:], None, None, pf.t if fuse_out else pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C,
+                        proj=dict(x=x, W=W[q + '.read_from_query.kv'], emb=query_emb), acc_in=prev_acc, next_q=next_q,
+                        out=dict(Wo=W[q + '.read_from_query.out_blob'], res=pixel.t) if fuse_out else None)
         else:
+            pf = None
             att = f(n + 'att', (M, C))
             if fuse_proj:
                 ol.attn_q2p(None, kvq.t, None, None, att, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=aux[b],
@@ -725,7 +733,8 @@ def build_readout_query(eng, K, h, w, last_aux=True, fresh=True):
                 kv2 = f(n + 'kv2', (M, 2 * C))
                 ol.linear(x, W[q + '.read_from_query.kv'], kv2, M=M, x_add=query_emb, add_rows=M, add_cols=C)
                 ol.attn_p2q(kvq.t.view(-1)[2 * C:], kv2, kv2.view(-1)[C:], pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C, ldkv=2 * C)
-        pf = P.conv(q + '.read_from_query.out', Act(pa, K, h, w, C), name=n + 'pf', res=pixel)
+        if pf is None:
+            pf = P.conv(q + '.read_from_query.out', Act(pa, K, h, w, C), name=n + 'pf', res=pixel)
         # PixelFFN (transformer_layers.py:121-136)
         last = b == nb - 1
         want_aux = not last or last_aux

@@ -73,3 +73,10 @@ def pack_linear(w, bias, device):
 def linear_as_conv(w, bias, device):
     """nn.Linear applied to pixel tokens == 1x1 conv."""
     return pack_conv(w.float().view(w.shape[0], w.shape[1], 1, 1), bias, device)
+
+
+def out_proj_blob(w):
+    """[Wo bf16 [256, 256] (out, in) | bias f32 [256]] as ONE byte tensor: the operand of ATTN_P2Q's fused output projection (flags&32;
+    the op has two free pointer slots, the residual takes the other).  w: the PackedConv of the 1x1 conv it replaces."""
+    assert w.cout == 256 and w.kh == 1 and w.kw == 1 and w.cin_padded == 256 and w.bias is not None
+    return torch.cat([w.weight[:256, :256].contiguous().view(torch.uint8).reshape(-1), w.bias.contiguous().view(torch.uint8).reshape(-1)]).contiguous()

@@ -523,13 +523,19 @@ class OpList:
         assert acc_in is None and out_proj is None
         return self.add(ATTN_SELF, 0, [K, Q, C, heads, ldqk, ldv], [], [qk, v, y])
 
-    def attn_p2q(self, q, kq, vq, y, *, K, Q, HW, C, heads, ldq, ldkv=0, proj=None, acc_in=None, next_q=None):
+    def attn_p2q(self, q, kq, vq, y, *, K, Q, HW, C, heads, ldq, ldkv=0, proj=None, acc_in=None, next_q=None, out=None):
         """proj given: k | v of the object queries = packed [k | v] projection of (x + emb | x) computed inside the launch.
         acc_in (needs proj): chain form.  next_q = dict(ln=(gamma, beta), W=PackedLinear Wq, q_out, xn_out) (chain form): extra blocks project
-        the NEXT transformer block's ATTN_Q2P queries from the same rows: xn_out = LN(x_eff), q_out = ((xn_out + emb) Wq^T + b) / sqrt(32)."""
+        the NEXT transformer block's ATTN_Q2P queries from the same rows: xn_out = LN(x_eff), q_out = ((xn_out + emb) Wq^T + b) / sqrt(32).
+        out = dict(Wo=weights.out_proj_blob(...), res=bf16 [K, HW, 256]) (chain form): y = res + Wo . attention + bias -- the 1x1 conv behind
+        the attention (read_from_query's out_proj, object_transformer.py:66-70) inside the launch; the attention itself is not stored."""
         if proj is not None:
             ldx, _, tail = self._proj(proj)
             flags, ints, ptrs = self._proj_extras(2, [K, Q, HW, C, heads, ldq, ldkv, ldx], [q, proj['x'], None, y, None] + tail[:3], acc_in, None)
+            if out is not None:
+                assert acc_in is not None and out['Wo'].dtype == torch.uint8 and out['Wo'].numel() == 256 * 256 * 2 + 256 * 4
+                flags |= 32
+                ptrs[2], ptrs[4] = out['Wo'], out['res']
             if next_q is not None:
                 assert acc_in is not None and next_q['W'].kd == 256 and next_q['W'].n == 256
                 flags |= 16

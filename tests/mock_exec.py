@@ -464,7 +464,12 @@ class MockExecutor:
             k = view(p[1], F32, (K, Q, C), (Q * ldkv, ldkv, 1)).reshape(K, Q, heads, hd).transpose(1, 2)
             v = view(p[2], F32, (K, Q, C), (Q * ldkv, ldkv, 1)).reshape(K, Q, heads, hd).transpose(1, 2)
         att = ((q @ k.transpose(-1, -2)) / math.sqrt(hd)).softmax(-1)
-        view(p[3], BF16, (K, HW, C)).copy_((att @ v).transpose(1, 2).reshape(K, HW, C))
+        o = (att @ v).transpose(1, 2).reshape(K, HW, C)
+        if flags & 32:                                                  # + the 1x1 conv behind it and the residual: p2 = [Wo bf16 | bias f32], p4 = residual
+            Wo = view(p[2], BF16, (C, C)).float()
+            bo = view(p[2] + 2 * C * C, F32, (C,))
+            o = o.to(torch.bfloat16).float() @ Wo.t() + bo + view(p[4], BF16, (K, HW, C)).float()
+        view(p[3], BF16, (K, HW, C)).copy_(o)
 
     # ---- SUMMARIZE / ADD_PE ---------------------------------------------------------------------------------
     def _op_21(self, flags, i, f, p):

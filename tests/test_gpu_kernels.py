@@ -860,6 +860,55 @@ def test_query_chain_in_four_launches(K, HW, hid_slice, qnext, inter):
         assert float((hip[f'pa_{b}'].float() - hip[f'pac_{b}'].float()).abs().max()) <= 2e-2 * float(hip[f'pa_{b}'].float().abs().max())
 
 
+@pytest.mark.parametrize('K,HW,qnext,tile', [(1, 1620, 1, 110), (3, 1620, 1, 63), (2, 700, 0, 100), (1, 37, 1, 102), (5, 2500, 1, 110), (2, 8040, 0, 105), (9, 300, 1, 65)])
+def test_p2q_with_the_output_projection_inside(K, HW, qnext, tile):
+    """ATTN_P2Q flags&32 (csrc/qchain.hip: p2q_out_kernel -- pixel + out_proj(attention) in the attention launch) against the two
+    launches it replaces, ATTN_P2Q (chain form) and the 1x1 conv with the residual on a tile of the 'stream' K-order class: bit-identical
+    pixels and, with qnext, bit-identical projected queries for the next block; both forms against the interpreter."""
+    from cutie_amd.model.weights import linear_as_conv, out_proj_blob
+    assert O.korder_class(tile) == 'stream'
+
+    def build(dev, g):
+        Q, C, heads = 16, 256, 8
+        M = K * Q
+        x = torch.randn((M, C), generator=g).to(dev)
+        emb = (torch.randn((M, C), generator=g) * 0.5).to(dev)
+        acc = torch.round(torch.randn((M, C), generator=g).double() * 0.3 * 4294967296.0).to(torch.int64).to(dev)
+        abias = (torch.randn(C, generator=g) * 0.1).to(dev)
+        mk = lambda n, kd=C: pack_linear(torch.randn((n, kd), generator=g) / (kd ** 0.5), torch.randn(n, generator=g) * 0.1, dev)
+        Wkv, Wq = mk(2 * C), mk(C)
+        ln = ((torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev))
+        Wo = linear_as_conv(torch.randn((C, C), generator=g) / 16, torch.randn(C, generator=g) * 0.1, dev)
+        blob = out_proj_blob(Wo)
+        kvq = rnd(g, (K, HW, 3 * C), dev=dev)
+        pixel = rnd(g, (K, HW, C), dev=dev)
+        z = lambda *shape, dt=F32: torch.zeros(shape, dtype=dt, device=dev)
+        ol = O.OpList()
+        ol.keep += [Wkv.weight, Wq.weight, Wo.weight, blob]
+        out = {}
+        for form in ('two', 'one'):
+            nq = None
+            if qnext:
+                out['q_' + form], out['xn_' + form] = z(M, C), z(M, C)
+                nq = dict(ln=ln, W=Wq, q_out=out['q_' + form], xn_out=out['xn_' + form])
+            pf = z(K, HW, C, dt=BF16)
+            kw = dict(K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C, proj=dict(x=x, W=Wkv, emb=emb), acc_in=(acc, abias), next_q=nq)
+            if form == 'two':
+                pa = z(K, HW, C, dt=BF16)
+                ol.attn_p2q(kvq.view(-1)[2 * C:], None, None, pa, **kw)
+                ol.conv(pa, Wo, pf, B=K, H=1, W=HW, C1=C, ldx1=C, OH=1, OW=HW, ldy=C, res=pixel, ldr=C, tile=tile)
+            else:
+                ol.attn_p2q(kvq.view(-1)[2 * C:], None, None, pf, out=dict(Wo=blob, res=pixel), **kw)
+            out['pf_' + form] = pf
+        return ol, out
+    hip, ref = run_both(build, seed=57 + K)
+    check({k_: hip[k_] for k_ in ref if ref[k_].dtype == torch.float32}, {k_: ref[k_] for k_ in ref if ref[k_].dtype == torch.float32}, name='p2q + out', rtol=4e-3)
+    check({k_: hip[k_] for k_ in ref if ref[k_].dtype != torch.float32}, {k_: ref[k_] for k_ in ref if ref[k_].dtype != torch.float32}, name='p2q + out (bf16 outputs)')
+    assert torch.equal(hip['pf_one'].view(torch.int16), hip['pf_two'].view(torch.int16)), int((hip['pf_one'].view(torch.int16) != hip['pf_two'].view(torch.int16)).sum())
+    if qnext:
+        assert torch.equal(hip['q_one'], hip['q_two']) and torch.equal(hip['xn_one'], hip['xn_two'])
+
+
 def test_query_chain_rejects_bad_forms():
     """flags 4 / 8 without the fused projection, QFFN with a ragged hidden size: refused by the library, nothing launched."""
     ex = _lib.HipExecutor()

@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--K', type=int, default=3)
     ap.add_argument('--HW', type=int, default=1620)
+    ap.add_argument('--only', default='', help='substring of the launch names to run')
     args = ap.parse_args()
     assert 'ATL' in os.path.basename(_lib.LIB_PATH), 'set CUTIE_AMD_LIB to the timeline library'
     ex = _lib.get_executor()
@@ -74,6 +75,17 @@ def main():
     qo, xo = z(M, C), z(M, C)
     one('ATTN_P2Q + next q', lambda ol: ol.attn_p2q(kvq.view(-1)[2 * C:], None, None, pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C,
         proj=dict(x=x2, W=Wkv, emb=emb), acc_in=(a3, W2.bias), next_q=dict(ln=ln1, W=Wq, q_out=qo, xn_out=xo)), (-(-HW // 256) + 1) * heads * K, stamps=False)
+
+    from cutie_amd.model.weights import linear_as_conv, out_proj_blob
+    Woc = linear_as_conv(torch.randn((C, C), generator=g) / 16, torch.randn(C, generator=g) * 0.1, dev)
+    blob = out_proj_blob(Woc)
+    pixel, pf = rn(K, HW, C).to(torch.bfloat16), z(K, HW, C, dt=torch.bfloat16)
+    one('ATTN_P2Q + output projection + residual (flags&32)', lambda ol: ol.attn_p2q(kvq.view(-1)[2 * C:], None, None, pf, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C,
+        proj=dict(x=x2, W=Wkv, emb=emb), acc_in=(a3, W2.bias), out=dict(Wo=blob, res=pixel)), -(-HW // 64) * K)
+    one('the 1x1 conv behind ATTN_P2Q (tile 110)', lambda ol: ol.conv(pa, Woc, pf, B=K, H=1, W=HW, C1=C, ldx1=C, OH=1, OW=HW, ldy=C, res=pixel, ldr=C, tile=110),
+        1, stamps=False)
+    if args.only:
+        launches[:] = [l for l in launches if args.only in l[0]]
 
     src = torch.zeros(192 << 20, dtype=torch.uint8, device=dev)
     dst = torch.zeros(192 << 20, dtype=torch.uint8, device=dev)
