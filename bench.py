@@ -71,11 +71,12 @@ def parse():
 
 def multi_clip_throughput(net, cfg, args, K, rank, dist, dev):
     """Same workload, C independent clips in flight on this GPU (cutie_amd/parallel.py:run_concurrent's scheme with a
-    common start line): returns the seconds the slowest clip needed for args.steps frames after the pre-roll."""
+    common start line): returns the seconds the slowest clip needed for multi_clip_steps(args) frames after the pre-roll."""
     import threading
     from cutie_amd.inference.inference_core import InferenceCore
     from cutie_amd.utils.synth import SyntheticClip
     C, NF = args.clips_in_flight, 48
+    steps = multi_clip_steps(args)
     data = []
     for c in range(C):
         clip = SyntheticClip(args.height, args.width, K, NF, seed=101 + 16 * rank + c)
@@ -97,7 +98,7 @@ def multi_clip_throughput(net, cfg, args, K, rank, dist, dev):
                 torch.cuda.synchronize()
                 ready.wait()                                # pre-roll done on this clip
                 start.wait()                                # released once every rank is ready
-                for t in range(args.steps):
+                for t in range(steps):
                     tt = 1 + args.preroll + args.warmup + t
                     proc.step(frames[tt % NF], **nxt(tt))
                 torch.cuda.synchronize()
@@ -144,6 +145,12 @@ def multi_clip_throughput(net, cfg, args, K, rank, dist, dev):
     if errors:
         raise errors[0]
     return max(finish) - t0
+
+
+def multi_clip_steps(args):
+    """Frames per clip of the multi-clip leg: at least 100 -- with the driver's 20 steps the leg measured the start-up of four host threads
+    (690 frames/s next to 1070 for one clip, same box)."""
+    return max(args.steps, 100)
 
 
 def make_hint(args, frames, n):
@@ -271,8 +278,12 @@ def main():
         no_la = None
         if not args.no_lookahead:
             base2 = t_idx
-            t_nola = timed_steps(lambda i: proc.step(frames[(base2 + i) % 128]), args.steps, 2, dev)
-            t_idx = base2 + 2 + args.steps
+            # un-timed steps first, enough of them to use up every frame the hinted steps before have already encoded ahead (a look-ahead
+            # window and its lead): with 2 of them a 20-step region still ran on left-over window entries (1023 frames/s instead of ~820)
+            drain = 2 if args.window <= 1 else args.window + IC.WINDOW_LEAD + 2
+            t_nola = timed_steps(lambda i: proc.step(frames[(base2 + i) % 128]), args.steps, drain, dev)
+            t_idx = base2 + drain + args.steps
+            assert not getattr(proc, '_window', None), 'the un-hinted region must not find frames encoded ahead'
             no_la = {'value': round(world * args.steps / t_nola, 2), 'ms_per_step': round(t_nola / args.steps * 1e3, 4)}
         # ---- full-bank point: long-term memory at its steady-state size ----
         full_bank = None
@@ -416,8 +427,9 @@ def main():
             multi = {'clips_in_flight_per_gpu': args.clips_in_flight, 'error': leg_err or 'failed on another rank'}
         else:
             mt = float(mt[0].item())
-            multi = {'clips_in_flight_per_gpu': args.clips_in_flight, 'value': round(world * args.clips_in_flight * args.steps / mt, 2),
-                     'unit': 'frames/s', 'ms_per_step': round(mt / args.steps * 1e3, 4),
+            msteps = multi_clip_steps(args)
+            multi = {'clips_in_flight_per_gpu': args.clips_in_flight, 'value': round(world * args.clips_in_flight * msteps / mt, 2),
+                     'unit': 'frames/s', 'steps_per_clip': msteps, 'ms_per_step': round(mt / msteps * 1e3, 4),
                      'note': 'same workload, independent clips interleaved on one GPU (one host thread + HIP stream + CUTIE.fork() per '
                              'clip, cutie_amd/parallel.py); "value" above stays one clip per GPU'}
 
