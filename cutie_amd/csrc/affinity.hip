@@ -33,14 +33,24 @@ __global__ void key_prep_kernel(const float* __restrict__ key, const float* __re
         if (c8 == 0) sc[row] = aux[row] * 0.125f;       // shrinkage / sqrt(64)
     } else {
         const float* e = aux + (long)row * 64 + (c8 & 7) * 8;
+        float pe[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (c8 < 8) ? -e[i] : 2.f * k[i] * e[i];
-        if (c8 == 0) {
-            const float* kk = key + (long)row * 64; const float* ee = aux + (long)row * 64;
-            float c = 0.f;
-            for (int i = 0; i < 64; ++i) c += ee[i] * kk[i] * kk[i];
-            sc[row] = c;
+        for (int i = 0; i < 8; ++i) { v[i] = (c8 < 8) ? -e[i] : 2.f * k[i] * e[i]; pe[i] = e[i] * k[i] * k[i]; }
+        // c_j = sum_i e_i k_i^2, summed in channel order i = 0..63 as before -- but from the values the row's lanes hold anyway: lane c8 (< 8)
+        // adds its eight products to the running sum of lane c8 - 1.  (One lane per row walking the 64 channels was 128 loads in a loop
+        // that waits for each of them: tools/isa_waits.py; the row's 16 lanes sit in one wave, n * 16 threads exit as whole rows.)
+        float c = 0.f;
+#pragma unroll
+        for (int step = 0; step < 8; ++step) {
+            const float cin = __shfl(c, (threadIdx.x & 48) | (step > 0 ? step - 1 : 0), 64);
+            if (c8 == step) {
+                c = step > 0 ? cin : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) c += pe[i];
+            }
         }
+        c = __shfl(c, (threadIdx.x & 48) | 7, 64);
+        if (c8 == 0) sc[row] = c;
     }
     uint32_t h[4], l[4];
 #pragma unroll
@@ -142,53 +152,20 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
     bool jvalid[AFF_NQ];
     float ncj[AFF_NQ], thr[AFF_NQ];
     bf16x8 bh[AFF_NQ][4], bl[AFF_NQ][4];
-    // The block's query operand (64*AFF_NQ rows x [hi|lo] x 256 B) is one contiguous run per array: copy it through LDS
-    // with whole-line loads (fragment-shaped global loads touch 16 half-used lines per instruction and were most of this
-    // kernel's fixed cost), then pull each wave's B fragments into registers.  Uses the A buffers before the K loop.
-    {
-        constexpr int QROWS = 64 * AFF_NQ, NCH = QROWS * 16 / 256;      // 16-B chunks per thread per array
-        const int q0 = bx * QROWS;
-        au32x4 tb[2][NCH];
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int q = tid + 256 * i, row = q >> 4;
-            const int jr = min(q0 + row, p.HWp - 1);                    // B rows exist up to HWp
-            tb[0][i] = *reinterpret_cast<const au32x4*>(p.Bhi + (long)jr * 128 + (q & 15) * 8);
-            tb[1][i] = *reinterpret_cast<const au32x4*>(p.Blo + (long)jr * 128 + (q & 15) * 8);
-        }
-        au32x4* lb = reinterpret_cast<au32x4*>(aff_smem);               // [hi|lo][QROWS][16 chunks], chunk ^ (row & 15)
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int q = tid + 256 * i, row = q >> 4;
-            lb[row * 16 + ((q & 15) ^ (row & 15))] = tb[0][i];
-            lb[QROWS * 16 + row * 16 + ((q & 15) ^ (row & 15))] = tb[1][i];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < AFF_NQ; ++u) {
-            const int row = wave * (16 * AFF_NQ) + u * 16 + l15;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                bh[u][ks] = __builtin_bit_cast(bf16x8, lb[row * 16 + ((ks * 4 + l4) ^ l15)]);
-                bl[u][ks] = __builtin_bit_cast(bf16x8, lb[QROWS * 16 + row * 16 + ((ks * 4 + l4) ^ l15)]);
-            }
-        }
-        __syncthreads();                                                // the A staging below overwrites this area
-    }
-    ATL(2)
     const bool skip = mode == 1 && (p.mode & 2);                        // pass-0 maxima available: skip tiles without candidates
     const float* tau_p = p.gmax_or_tau;
     const float* gmax_p = p.gmax_or_tau - (long)p.HWp * p.Gld;
+    // c_j and tau_j: unconditional loads of a clamped row, looked at only behind the prologue's barriers.  (The conditional form --
+    // `jvalid ? -p.c[jq] : 0` -- compiled to a divergent branch with its own s_waitcnt vmcnt(0) per query set: two (pass 1: four)
+    // serialized global round trips in front of every block's first operand load.)
+    float craw[AFF_NQ], traw[AFF_NQ];
 #pragma unroll
     for (int u = 0; u < AFF_NQ; ++u) {
         jq[u] = bx * (64 * AFF_NQ) + wave * (16 * AFF_NQ) + u * 16 + l15;
         jvalid[u] = jq[u] < p.HW;
-        ncj[u] = jvalid[u] ? -p.c[jq[u]] : 0.f;
-        thr[u] = INFINITY;
-        if (mode == 1 && jvalid[u]) {
-            float tau = tau_p[jq[u]];
-            thr[u] = tau - fabsf(tau) * 1e-6f - 1e-30f;                 // never lose the k-th element to 1 ulp
-        }
+        const int jc = min(jq[u], p.HW - 1);
+        craw[u] = p.c[jc];
+        traw[u] = mode == 1 ? tau_p[jc] : 0.f;
     }
     const int g0 = by * p.tiles_per_block;
     const int g1 = min(g0 + p.tiles_per_block, p.G);
@@ -240,7 +217,56 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
         if (qd == 0) { lsc[BUF][row_] = st_sc; lpad[BUF][row_] = st_pad; }                                 \
     }
     f32x4 gcur[AFF_NQ];
+    // Prologue order (round 4): the first memory group's loads are in flight BEFORE the query operand is pulled through LDS, so the
+    // block pays one global round trip in front of its first MFMA instead of two (vmcnt is in-order: the LDS writes of the query
+    // rows wait for both).  Same bits: only the order of independent loads changed.  -DAFF_OLD_PROLOGUE (diagnostic library) keeps the
+    // old order for the in-box A/B.
+#ifndef AFF_OLD_PROLOGUE
     AFF_LOAD(g0);
+#endif
+    // The block's query operand (64*AFF_NQ rows x [hi|lo] x 256 B) is one contiguous run per array: copy it through LDS
+    // with whole-line loads (fragment-shaped global loads touch 16 half-used lines per instruction and were most of this
+    // kernel's fixed cost), then pull each wave's B fragments into registers.  Uses the A buffers before the K loop.
+    {
+        constexpr int QROWS = 64 * AFF_NQ, NCH = QROWS * 16 / 256;      // 16-B chunks per thread per array
+        const int q0 = bx * QROWS;
+        au32x4 tb[2][NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int q = tid + 256 * i, row = q >> 4;
+            const int jr = min(q0 + row, p.HWp - 1);                    // B rows exist up to HWp
+            tb[0][i] = *reinterpret_cast<const au32x4*>(p.Bhi + (long)jr * 128 + (q & 15) * 8);
+            tb[1][i] = *reinterpret_cast<const au32x4*>(p.Blo + (long)jr * 128 + (q & 15) * 8);
+        }
+        au32x4* lb = reinterpret_cast<au32x4*>(aff_smem);               // [hi|lo][QROWS][16 chunks], chunk ^ (row & 15)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int q = tid + 256 * i, row = q >> 4;
+            lb[row * 16 + ((q & 15) ^ (row & 15))] = tb[0][i];
+            lb[QROWS * 16 + row * 16 + ((q & 15) ^ (row & 15))] = tb[1][i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < AFF_NQ; ++u) {
+            const int row = wave * (16 * AFF_NQ) + u * 16 + l15;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bh[u][ks] = __builtin_bit_cast(bf16x8, lb[row * 16 + ((ks * 4 + l4) ^ l15)]);
+                bl[u][ks] = __builtin_bit_cast(bf16x8, lb[QROWS * 16 + row * 16 + ((ks * 4 + l4) ^ l15)]);
+            }
+        }
+        __syncthreads();                                                // the A staging below overwrites this area
+    }
+    ATL(2)
+#ifdef AFF_OLD_PROLOGUE
+    AFF_LOAD(g0);
+#endif
+#pragma unroll
+    for (int u = 0; u < AFF_NQ; ++u) {
+        ncj[u] = jvalid[u] ? -craw[u] : 0.f;
+        const float tcut = traw[u] - fabsf(traw[u]) * 1e-6f - 1e-30f;   // never lose the k-th element to 1 ulp
+        thr[u] = (mode == 1 && jvalid[u]) ? tcut : INFINITY;
+    }
 #pragma unroll
     for (int u = 0; u < AFF_NQ; ++u) gcur[u] = gq[u];
     AFF_STORE(0);

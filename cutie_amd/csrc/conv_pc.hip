@@ -675,13 +675,18 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
     const bool vec_ok = (out_f32 ? (p.ldy & 3) == 0 : (p.ldy & (NCH - 1)) == 0) && (!p.res || (p.ldr & (NCH - 1)) == 0);
     float bias[TNP][NCH];
     const float* const bias_p = p.bias ? p.bias : reinterpret_cast<const float*>(p.w);      // (any mapped address when there is no bias)
+    const int bias_lim = p.bias ? p.Cout : 0;
+    typedef const __attribute__((address_space(1))) float* pc_gf32;       // (a select of two kernel-argument pointers is a flat pointer to hipcc: say global)
+    const pc_gf32 bias_g = (pc_gf32)bias_p;
 #pragma unroll
     for (int a = 0; a < TNP; ++a) {
         const int ch0 = n0 + cn0 + a * (PAIR ? 32 : 16) + l4 * NCH;
 #pragma unroll
         for (int r = 0; r < NCH; ++r) {                  // unconditional (clamped) loads, then a select: a load behind a per-element branch makes hipcc wait for each one
-            const float t = bias_p[min(ch0 + r, p.Cout - 1)];
-            bias[a][r] = (p.bias && ch0 + r < p.Cout) ? t : 0.f;
+            // (the select must not name p.bias: `(p.bias && ch < Cout) ? t : 0` let hipcc sink every load into its own `if (p.bias)` block,
+            // each ending in s_waitcnt vmcnt(0) -- TNP * NCH dependent round trips in front of the consumers' first MFMA, tools/isa_waits.py)
+            const float t = bias_g[min(ch0 + r, p.Cout - 1)];
+            bias[a][r] = ch0 + r < bias_lim ? t : 0.f;
         }
     }
     unsigned rpre[PRE_RES ? TM : 1][PRE_RES ? TNP : 1][NCH / 2];

@@ -104,14 +104,36 @@ __global__ void upsample2x_add_kernel(const uint4* __restrict__ g, const uint4* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// R > 0: the pooling ratio as a compile-time constant (2, 4): the R x R loads are issued together and summed in the same (dy, dx) order.
+// With a run-time r the compiler keeps `load; s_waitcnt vmcnt(0); add` per tap -- r * r dependent round trips per thread
+// (tools/isa_waits.py); same bits either way.
+template <int R = 0>
 __device__ __forceinline__ void area_down_bf16_body(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int C,
-                                                    int ldx, int ldy, int r, long idx) {
+                                                    int ldx, int ldy, int rrt, long idx) {
+    const int r = R > 0 ? R : rrt;
     int C8 = C >> 3, OH = H / r, OW = W / r;
     long total = (long)B * OH * OW * C8;
     if (idx >= total) return;
     int c = idx % C8; long t = idx / C8;
     int ox = t % OW; t /= OW; int oy = t % OH; int b = t / OH;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (R > 0) {
+        uint4 v[R > 0 ? R * R : 1];
+#pragma unroll
+        for (int dy = 0; dy < R; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < R; ++dx)
+                v[dy * R + dx] = *reinterpret_cast<const uint4*>(x + (((long)b * H + oy * R + dy) * W + ox * R + dx) * ldx + c * 8);
+#pragma unroll
+        for (int e = 0; e < R * R; ++e) {
+            const uint32_t* u = &v[e].x;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[2 * i] += __uint_as_float(u[i] << 16);
+                acc[2 * i + 1] += __uint_as_float(u[i] & 0xffff0000u);
+            }
+        }
+    } else
     for (int dy = 0; dy < r; ++dy)
         for (int dx = 0; dx < r; ++dx) {
             const uint4 v = *reinterpret_cast<const uint4*>(x + (((long)b * H + oy * r + dy) * W + ox * r + dx) * ldx + c * 8);
@@ -132,8 +154,10 @@ __global__ void area_down_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __re
     area_down_bf16_body(x, y, B, H, W, C, ldx, ldy, r, (long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+template <int R = 0>
 __device__ __forceinline__ void area_down_f32_body(const float* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int C,
-                                                   int ldx, int ldy, int r, int Cz, long idx) {
+                                                   int ldx, int ldy, int rrt, int Cz, long idx) {
+    const int r = R > 0 ? R : rrt;
     int OH = H / r, OW = W / r;
     long total = (long)B * OH * OW;
     if (idx >= total) return;
@@ -142,6 +166,15 @@ __device__ __forceinline__ void area_down_f32_body(const float* __restrict__ x, 
     bf16_t* yp = y + idx * ldy;
     for (int c = 0; c < C; ++c) {
         float acc = 0.f;
+        if (R > 0) {
+            float v[R > 0 ? R * R : 1];
+#pragma unroll
+            for (int dy = 0; dy < R; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < R; ++dx) v[dy * R + dx] = x[(((long)b * H + oy * R + dy) * W + ox * R + dx) * ldx + c];
+#pragma unroll
+            for (int e = 0; e < R * R; ++e) acc += v[e];
+        } else
         for (int dy = 0; dy < r; ++dy)
             for (int dx = 0; dx < r; ++dx) acc += x[(((long)b * H + oy * r + dy) * W + ox * r + dx) * ldx + c];
         yp[c] = f2bf(acc * inv);
@@ -154,15 +187,23 @@ __global__ void area_down_f32_kernel(const float* __restrict__ x, bf16_t* __rest
 }
 // AREA_DOWN3: three area poolings in one launch (the g8 / g4 / logits inputs of the sensory update): thread ranges [0, n0), [n0, n0+n1), ...
 struct AreaSeg { const void* x; bf16_t* y; int B, H, W, C, ldx, ldy, r, Cz, f32; long n; };
-struct Area3 { AreaSeg s[3]; };
+struct Area3 { AreaSeg s[3]; int rt; };
 __global__ void area_down3_kernel(Area3 a) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const AreaSeg& g = a.s[q];
         if (idx < g.n) {
-            if (g.f32) area_down_f32_body((const float*)g.x, g.y, g.B, g.H, g.W, g.C, g.ldx, g.ldy, g.r, g.Cz, idx);
-            else area_down_bf16_body((const bf16_t*)g.x, g.y, g.B, g.H, g.W, g.C, g.ldx, g.ldy, g.r, idx);
+            const int rr = a.rt ? 0 : g.r;                  // (a.rt: the run-time-r bodies, A/B switch)
+            if (g.f32) {
+                if (rr == 2) area_down_f32_body<2>((const float*)g.x, g.y, g.B, g.H, g.W, g.C, g.ldx, g.ldy, 2, g.Cz, idx);
+                else if (rr == 4) area_down_f32_body<4>((const float*)g.x, g.y, g.B, g.H, g.W, g.C, g.ldx, g.ldy, 4, g.Cz, idx);
+                else area_down_f32_body<0>((const float*)g.x, g.y, g.B, g.H, g.W, g.C, g.ldx, g.ldy, g.r, g.Cz, idx);
+            } else {
+                if (rr == 2) area_down_bf16_body<2>((const bf16_t*)g.x, g.y, g.B, g.H, g.W, g.C, g.ldx, g.ldy, 2, idx);
+                else if (rr == 4) area_down_bf16_body<4>((const bf16_t*)g.x, g.y, g.B, g.H, g.W, g.C, g.ldx, g.ldy, 4, idx);
+                else area_down_bf16_body<0>((const bf16_t*)g.x, g.y, g.B, g.H, g.W, g.C, g.ldx, g.ldy, g.r, idx);
+            }
             return;
         }
         idx -= g.n;
@@ -495,24 +536,38 @@ __global__ void up4_softmax_fused_kernel(const float* __restrict__ lg, float* __
 // of 48 -- and every plane is written with 16-byte stores.  Per pixel the arithmetic and its order are those of the kernel above
 // (bit-identical results; flags&2 of the op keeps the one-pixel form for the comparison in tests).
 // The four output pixels (oy, 4j .. 4j + 3) of the fused up-sampling + softmax: out[plane][q] = probabilities, lo[plane][q] = up-sampled logits.
-template <int PMAX>
-__device__ __forceinline__ void up4_four(const float* __restrict__ lg, int K, int h, int w, int oy, int j, float (&out)[PMAX][4], float (&lo)[PMAX][4]) {
+// KC > 0: the object count as a compile-time constant.  With a run-time K every `if (k < K)` around a load is a (uniform) branch that ends
+// in its own s_waitcnt vmcnt(0): the 6 x K source logits came in one after the other, 18 dependent L2 round trips in front of the
+// first exp at K = 3 (tools/isa_waits.py).  With KC the loop bodies are straight-line code and all loads are in flight together; the
+// arithmetic and its order are the same, so are the bits.
+template <int PMAX, int KC = 0>
+__device__ __forceinline__ void up4_four(const float* __restrict__ lg, int Krt, int h, int w, int oy, int j, float (&out)[PMAX][4], float (&lo)[PMAX][4]) {
+    const int K = KC > 0 ? KC : Krt;
     int y0, y1; float ly;
     up_coord(oy, h, 0.25f, y0, y1, ly);
     const int col[3] = {max(j - 1, 0), j, min(j + 1, w - 1)};
     const long hw = (long)h * w;
     // clamped logits of the six source pixels: L[r][c][plane], plane 0 = background
     float L[2][3][PMAX];
+    float raw[2][3][PMAX - 1];                           // (all 6 x K loads first: one round trip)
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const long o = (long)(r ? y1 : y0) * w + col[c];
+#pragma unroll
+            for (int k = 0; k < PMAX - 1; ++k)
+                if (k < K) raw[r][c][k] = lg[(long)k * hw + o];
+        }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
             float bg = 1.f;
 #pragma unroll
             for (int k = 0; k < PMAX - 1; ++k)
                 if (k < K) {
-                    const float pr = 1.f / (1.f + expf(-lg[(long)k * hw + o]));
+                    const float pr = 1.f / (1.f + expf(-raw[r][c][k]));
                     bg *= (1.f - pr);
                     L[r][c][k + 1] = clamp_logit(pr);
                 }
@@ -553,9 +608,10 @@ __device__ __forceinline__ void up4_four(const float* __restrict__ lg, int K, in
     }
 }
 
-template <int PMAX>
+template <int PMAX, int KC = 0>
 __global__ __launch_bounds__(256) void up4_softmax_fused4_kernel(const float* __restrict__ lg, float* __restrict__ prob, float* __restrict__ lup,
-                                                                 int K, int h, int w) {
+                                                                 int Krt, int h, int w) {
+    const int K = KC > 0 ? KC : Krt;
     const int OH = 4 * h, OW = 4 * w;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;             // (oy, j): output pixels (oy, 4j .. 4j + 3)
     if (idx >= (long)OH * w) return;
@@ -563,7 +619,7 @@ __global__ __launch_bounds__(256) void up4_softmax_fused4_kernel(const float* __
     const long OHW = (long)OH * OW;
     float out[PMAX][4];
     float lo[PMAX][4];
-    up4_four<PMAX>(lg, K, h, w, oy, j, out, lo);
+    up4_four<PMAX, KC>(lg, K, h, w, oy, j, out, lo);
     const long base = (long)oy * OW + 4 * j;
 #pragma unroll
     for (int p = 0; p < PMAX; ++p)
@@ -578,9 +634,10 @@ __global__ __launch_bounds__(256) void up4_softmax_fused4_kernel(const float* __
 // the others)).  The cell's values go through LDS so that every lane sums the same four entries in the same order as
 // mask_down_pair_kernel (entries lane, lane + 64, +128, +192 of the row-major cell) and the same wave_sum follows: bit-identical to the
 // MASK_DOWN launch it replaces.  4 waves (cells) per block; needs H, W multiples of 16 and K + 1 <= PMAX.
-template <int PMAX>
+template <int PMAX, int KC = 0>
 __global__ __launch_bounds__(256) void up4_softmax_md_kernel(const float* __restrict__ lg, float* __restrict__ prob, float* __restrict__ lup,
-                                                             int K, int h, int w, float* __restrict__ m16, uint4* __restrict__ pair, int ld8) {
+                                                             int Krt, int h, int w, float* __restrict__ m16, uint4* __restrict__ pair, int ld8) {
+    const int K = KC > 0 ? KC : Krt;
     __shared__ float cell[4][PMAX - 1][256];
     const int OH = 4 * h, OW = 4 * w, ch = OH >> 4, cw = OW >> 4, ncell = ch * cw;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -592,7 +649,7 @@ __global__ __launch_bounds__(256) void up4_softmax_md_kernel(const float* __rest
     const long OHW = (long)OH * OW;
     float out[PMAX][4];
     float lo[PMAX][4];
-    up4_four<PMAX>(lg, K, h, w, oy, j, out, lo);
+    up4_four<PMAX, KC>(lg, K, h, w, oy, j, out, lo);
     const long base = (long)oy * OW + 4 * j;
 #pragma unroll
     for (int p = 0; p < PMAX; ++p)
@@ -918,7 +975,14 @@ __global__ void summarize_final_kernel(const float* __restrict__ part, float* __
     int e = blockIdx.x * blockDim.x + threadIdx.x;          // element of [Q, C+1]
     if (e >= n) return;
     float sum = 0.f;
-    for (int c = 0; c < nchunk; ++c) sum += part[((long)k * nchunk + c) * n + e];
+    for (int c0 = 0; c0 < nchunk; c0 += 8) {                 // eight partials in flight, added in chunk order (was: one dependent round trip per chunk)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[((long)k * nchunk + min(c0 + u, nchunk - 1)) * n + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c0 + u < nchunk) sum += v[u];
+    }
     y[(long)k * n + e] = sum;
 }
 
@@ -1080,6 +1144,7 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
                 g.n = g.f32 ? np : np * (g.C / 8);
                 total += g.n;
             }
+            a.rt = (op->flags >> 3) & 1;
             hipLaunchKernelGGL(area_down3_kernel, GRID1D(total, BS), dim3(BS), 0, s, a);
             break;
         }
@@ -1126,13 +1191,23 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
                 if (op->flags & 4) {                              // + MASK_DOWN of the probabilities (p3 = m16, p4 = pair, i3 = channel pitch of pair)
                     if (!vec || !p[3] || !p[4] || (i[1] & 3) || (i[2] & 3) || i[3] < 8 || (i[3] & 7)) { cutie_set_error("up4_softmax: the mask-down form needs P <= 8, h, w multiples of 4, m16 and pair"); return -2; }
                     const int ncell = (i[1] / 4) * (i[2] / 4);
-                    hipLaunchKernelGGL(up4_softmax_md_kernel<8>, dim3((ncell + 3) / 4), dim3(256), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, i[1], i[2],
-                                       (float*)p[3], (uint4*)p[4], i[3] / 8);
+#define UP4_MD(KC) hipLaunchKernelGGL((up4_softmax_md_kernel<8, KC>), dim3((ncell + 3) / 4), dim3(256), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, \
+                                       i[1], i[2], (float*)p[3], (uint4*)p[4], i[3] / 8)
+                    switch ((op->flags & 8) ? 0 : i[0] - 1) {          // object count as a compile-time constant (see up4_four); flags&8: run-time K
+                        case 1: UP4_MD(1); break; case 2: UP4_MD(2); break; case 3: UP4_MD(3); break; case 4: UP4_MD(4); break;
+                        case 5: UP4_MD(5); break; case 6: UP4_MD(6); break; case 7: UP4_MD(7); break; default: UP4_MD(0); break;
+                    }
+#undef UP4_MD
                     break;
                 }
                 if (vec) {
                     const long n4 = (long)4 * i[1] * i[2];
-                    hipLaunchKernelGGL(up4_softmax_fused4_kernel<8>, GRID1D(n4, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, i[1], i[2]);
+#define UP4_F4(KC) hipLaunchKernelGGL((up4_softmax_fused4_kernel<8, KC>), GRID1D(n4, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, i[1], i[2])
+                    switch ((op->flags & 8) ? 0 : i[0] - 1) {
+                        case 1: UP4_F4(1); break; case 2: UP4_F4(2); break; case 3: UP4_F4(3); break; case 4: UP4_F4(4); break;
+                        case 5: UP4_F4(5); break; case 6: UP4_F4(6); break; case 7: UP4_F4(7); break; default: UP4_F4(0); break;
+                    }
+#undef UP4_F4
                     break;
                 }
                 if (i[0] <= 8) hipLaunchKernelGGL(up4_softmax_fused_kernel<8>, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, i[1], i[2]);

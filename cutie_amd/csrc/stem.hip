@@ -80,6 +80,7 @@ __global__ __launch_bounds__(ST_NT) void stem_kernel(StemParams p) {
     constexpr int NPIX = (ST_IH * ST_IW + ST_NT - 1) / ST_NT;   // 6
     float pr_[NPIX], pg_[NPIX], pb_[NPIX], pm_[NPIX], po_[NPIX];
     bool pin_[NPIX], pim_[NPIX];
+    long mpix_[NPIX];
 #pragma unroll
     for (int t = 0; t < NPIX; ++t) {
         const int e = min(tid + ST_NT * t, ST_IH * ST_IW - 1);
@@ -91,13 +92,30 @@ __global__ __launch_bounds__(ST_NT) void stem_kernel(StemParams p) {
         const long o = (long)min(max(sy, 0), p.h0 - 1) * p.w0 + min(max(sx, 0), p.w0 - 1);     // clamped: the loads are unconditional
         pr_[t] = p.img[o]; pg_[t] = p.img[plane + o]; pb_[t] = p.img[2 * plane + o];
         pm_[t] = 0.f; po_[t] = 0.f;
-        if (p.masks) {                                   // (block-uniform)
-            const long pix = (long)min(max(iy, 0), p.H - 1) * p.W_ + min(max(ix, 0), p.W_ - 1);
-            float sum = 0.f;
-            for (int j = 0; j < p.K; ++j) sum += p.masks[(long)j * HWp + pix];
-            pm_[t] = p.masks[(long)k * HWp + pix];
-            po_[t] = fminf(fmaxf(sum - pm_[t], 0.f), 1.f);
+        mpix_[t] = (long)min(max(iy, 0), p.H - 1) * p.W_ + min(max(ix, 0), p.W_ - 1);
+    }
+    if (p.masks) {                                       // (block-uniform)
+        // four objects per round, the loads of all six pixels in flight together (a `for (j < K) sum += masks[j]` per pixel compiled to
+        // one dependent round trip per object and pixel: 6 (K + 1) of them in front of the first MFMA; tools/isa_waits.py).  Same
+        // summation order per pixel: objects ascending.
+        float msum[NPIX];
+#pragma unroll
+        for (int t = 0; t < NPIX; ++t) { msum[t] = 0.f; pm_[t] = p.masks[(long)k * HWp + mpix_[t]]; }
+        for (int j0 = 0; j0 < p.K; j0 += 4) {
+            float mv[NPIX][4];
+#pragma unroll
+            for (int t = 0; t < NPIX; ++t)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) mv[t][u] = p.masks[(long)min(j0 + u, p.K - 1) * HWp + mpix_[t]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j0 + u < p.K) {
+#pragma unroll
+                    for (int t = 0; t < NPIX; ++t) msum[t] += mv[t][u];
+                }
         }
+#pragma unroll
+        for (int t = 0; t < NPIX; ++t) po_[t] = fminf(fmaxf(msum[t] - pm_[t], 0.f), 1.f);
     }
 #pragma unroll
     for (int t = 0; t < NPIX; ++t) {

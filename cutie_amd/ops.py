@@ -34,6 +34,8 @@ F_TILE_OFF = 128 if os.environ.get('CUTIE_AMD_COUT1_TILE', '1') in ('', '0') els
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQ1 = 0, 1, 2, 3
 ACT_SHIFT = 4
 UP4_SCALAR = 2 if os.environ.get('CUTIE_AMD_UP4_VEC', '1') in ('', '0') else 0       # UP4_SOFTMAX flags&2: one pixel per thread (A/B switch)
+AREA_RT = 8 if os.environ.get('CUTIE_AMD_AREA_R', '1') in ('', '0') else 0          # AREA_DOWN3 flags&8: bodies with a run-time pooling ratio (A/B switch)
+UP4_RTK = 8 if os.environ.get('CUTIE_AMD_UP4_KC', '1') in ('', '0') else 0           # UP4_SOFTMAX flags&8: kernels with a run-time object count (A/B switch)
 
 # conv tile table (mirrors the switch in csrc/conv_igemm.hip): id -> (BM, BN, BK)
 TILES = {0: (128, 128, 32), 1: (128, 64, 32), 2: (64, 64, 32), 3: (256, 16, 32), 4: (64, 128, 32),
@@ -378,7 +380,7 @@ class OpList:
             ints += [g['B'], g['H'], g['W'], g['C'], g['ldx'], g['ldy'], g['r'], g['C'] if g.get('Cz') is None else g['Cz']]
             ptrs += [g['x'], g['y']]
             flags |= (1 << q) if g.get('f32_in') else 0
-        return self.add(AREA_DOWN3, flags, ints, [], ptrs)
+        return self.add(AREA_DOWN3, flags | AREA_RT, ints, [], ptrs)
 
     def mask_down(self, masks, pair, m16, *, K, H, W, r=16, pair_channels=8):
         """pair_channels: channel pitch of `pair` (8, or 64 when it is the second source of an LDS-DMA conv: channels 8.. are not written)."""
@@ -418,8 +420,8 @@ class OpList:
         if mask_down is not None:
             assert from_logits and not UP4_SCALAR and P <= 8 and h % 4 == 0 and w % 4 == 0
             m16, pair, pitch = mask_down
-            return self.add(UP4_SOFTMAX, 1 | 4, [P, h, w, pitch], [], [agg, prob, logits_up, m16, pair])
-        return self.add(UP4_SOFTMAX, (1 | UP4_SCALAR) if from_logits else 0, [P, h, w], [], [agg, prob, logits_up])
+            return self.add(UP4_SOFTMAX, 1 | 4 | UP4_RTK, [P, h, w, pitch], [], [agg, prob, logits_up, m16, pair])
+        return self.add(UP4_SOFTMAX, (1 | UP4_SCALAR | UP4_RTK) if from_logits else 0, [P, h, w], [], [agg, prob, logits_up])
 
     def mask_merge(self, inmask, pred, src, planes, *, h0, w0, H, W, pad_left, pad_top, Knew, Kold, nfloat, float_mode):
         return self.add(MASK_MERGE, 1 if float_mode else 0, [h0, w0, H, W, pad_left, pad_top, Knew, Kold, nfloat], [],

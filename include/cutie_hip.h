@@ -115,7 +115,9 @@ enum {
      * flags&2 (with flags&1): the one-pixel-per-thread form (A/B switch; default: four pixels per thread, P <= 8)
      * flags&4 (with flags&1, P <= 8, h, w % 4 == 0): the launch also produces MASK_DOWN(prob[1:], r = 16) for the next frame's pixel fusion:
      *      p3 = m16 f32 [K, H/16 * W/16], p4 = pair bf16 [K, H/16, W/16, i3] (channels 0, 1 written), i3 = channel pitch of pair (8 | 64);
-     *      bit-identical to a MASK_DOWN launch on the stored probabilities */
+     *      bit-identical to a MASK_DOWN launch on the stored probabilities
+     * flags&8 (with flags&1): the kernels with a run-time object count (A/B switch; default: one instantiation per K = 1..7, whose loads are
+     *      all in flight together -- same bits) */
     CUTIE_OP_UP4_SOFTMAX = 11,
     /* MASK_MERGE: build the per-object mask planes of a frame with an input mask
      * inference_core.py:259-300.  plane t: src[t] >= 0 -> (idx==src[t]) [idx mode] / fmask[src[t]] [float
@@ -265,7 +267,8 @@ enum {
      * p0=src f32 [rows, W] (row stride i2) p1=dst f32 [rows, W] (row stride i3)   i: 0 rows 1 W 2 3   f: 0 alpha 1 beta */
     CUTIE_OP_FLIP_W = 38,
     /* AREA_DOWN3: three AREA_DOWNs in one launch (SensoryUpdater's area poolings of g8 / g4 / logits, modules.py:59-60).
-     * segment q = 0..2: p[2q]=x p[2q+1]=y, i[8q..8q+7] = B H W C ldx ldy r Cz as in AREA_DOWN, flags bit q: f32 input */
+     * segment q = 0..2: p[2q]=x p[2q+1]=y, i[8q..8q+7] = B H W C ldx ldy r Cz as in AREA_DOWN, flags bit q: f32 input;
+     * flags&8: the bodies with a run-time r also for r = 2, 4 (A/B switch; default: r as a compile-time constant, all taps in flight -- same bits) */
     CUTIE_OP_AREA_DOWN3 = 39,
     /* QFFN: the FFN of a QueryTransformerBlock in one launch (transformer_layers.py:101-118: x + linear2(relu(linear1(norm(x))))),
      * split over FF / i2 slices of the hidden layer: grid (FF / i2, K).  Input rows as a sum (the self-attention out-projection):

@@ -1269,3 +1269,102 @@ def test_up4_softmax_with_mask_down(K, h, w):
     assert torch.equal(prob_a, prob_b)
     assert torch.equal(m_a, m_b)
     assert torch.equal(pair_a.view(torch.int16), pair_b.view(torch.int16))
+
+
+# ---- round 4: loads that used to come in one after the other (tools/isa_waits.py).  Every change keeps the arithmetic and its order,
+# ---- so the old form (still selectable) and an exact host emulation must agree to the bit.
+@pytest.mark.parametrize('K', [1, 2, 3, 5, 7])
+def test_up4_softmax_compile_time_object_count(K, monkeypatch):
+    """UP4_SOFTMAX: one kernel instantiation per object count (all 6 x K source logits in flight together) against the kernels with a
+    run-time K (flags&8), plain and with the MASK_DOWN side job."""
+    h, w = 12, 20
+    g = torch.Generator().manual_seed(11 + K)
+    lg = (torch.randn((K, h, w), generator=g) * 3).cuda()
+    H, W = 4 * h, 4 * w
+    hw16 = (H // 16) * (W // 16)
+    res = []
+    for rtk in (0, 8):
+        monkeypatch.setattr(O, 'UP4_RTK', rtk)
+        prob, lup, prob_m = (torch.zeros((K + 1, H, W), device='cuda') for _ in range(3))
+        pair, m16 = torch.zeros((K, hw16, 64), dtype=BF16, device='cuda'), torch.zeros((K, hw16), device='cuda')
+        ol = O.OpList()
+        ol.up4_softmax(lg, prob, lup, P=K + 1, h=h, w=w, from_logits=True)
+        ol.up4_softmax(lg, prob_m, None, P=K + 1, h=h, w=w, from_logits=True, mask_down=(m16, pair, 64))
+        assert all((int(f) & 8) == rtk for f in ol.finalize()['flags'])
+        ol.run()
+        torch.cuda.synchronize()
+        res.append((prob, lup, prob_m, pair.view(torch.int16), m16))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert torch.equal(res[0][0], res[0][2])
+
+
+def test_area_down3_compile_time_ratio(monkeypatch):
+    """AREA_DOWN3 with the pooling ratio as a compile-time constant (r = 2, 4: all taps in flight) against the run-time loops (flags&8)."""
+    K, h, w = 3, 30, 54
+    g = torch.Generator().manual_seed(3)
+    p8 = rnd(g, (K, 2 * h, 2 * w, 256), dev='cuda')
+    p4 = rnd(g, (K, 4 * h, 4 * w, 256), dev='cuda')
+    lg = (torch.randn((K, 4 * h, 4 * w), generator=g) * 3).cuda()
+    CT = 256 + 256 + 64
+    outs = []
+    for rt in (0, 8):
+        monkeypatch.setattr(O, 'AREA_RT', rt)
+        cat = torch.zeros((K, h, w, CT), dtype=BF16, device='cuda')
+        ol = O.OpList()
+        ol.area_down3([dict(x=p8, y=cat, B=K, H=2 * h, W=2 * w, C=256, ldx=256, ldy=CT, r=2),
+                       dict(x=p4, y=cat.view(-1)[256:], B=K, H=4 * h, W=4 * w, C=256, ldx=256, ldy=CT, r=4),
+                       dict(x=lg, y=cat.view(-1)[512:], B=K, H=4 * h, W=4 * w, C=1, ldx=1, ldy=CT, r=4, f32_in=True, Cz=8)])
+        assert (int(ol.finalize()['flags'][0]) & 8) == rt
+        ol.run()
+        torch.cuda.synchronize()
+        outs.append(cat.view(torch.int16).clone())
+    assert torch.equal(outs[0], outs[1])
+    assert float(outs[0].float().abs().max()) > 0
+
+
+def test_key_prep_query_constant_is_the_channel_ordered_sum():
+    """KEY_PREP (query side): c_j = sum_i e_i k_i^2 is summed in channel order i = 0..63 with separate multiplies and adds (the row's lanes
+    hand the running sum on) -- emulated exactly in numpy float32."""
+    g = torch.Generator().manual_seed(9)
+    for HW in (1620, 100, 7):
+        HWp = -(-HW // 64) * 64
+        qkey = torch.randn((HW, 64), generator=g) * 0.8
+        qsel = torch.rand((HW, 64), generator=g)
+        Bhi, Blo, cq = (torch.zeros((HWp, 128), dtype=BF16, device='cuda'), torch.zeros((HWp, 128), dtype=BF16, device='cuda'),
+                        torch.zeros((HWp,), dtype=F32, device='cuda'))
+        ol = O.OpList()
+        kd, sd = qkey.cuda(), qsel.cuda()
+        ol.key_prep(kd, sd, Bhi, Blo, cq, n=HW, query=True)
+        ol.run()
+        torch.cuda.synchronize()
+        k, e = qkey.numpy().astype(np.float32), qsel.numpy().astype(np.float32)
+        c = np.zeros((HW,), np.float32)
+        for i in range(64):
+            c = (c + ((e[:, i] * k[:, i]).astype(np.float32) * k[:, i]).astype(np.float32)).astype(np.float32)
+        got = cq.cpu().numpy()
+        assert np.array_equal(got[:HW].view(np.int32), c.view(np.int32)), float(np.abs(got[:HW] - c).max())
+        assert not got[HW:].any()
+
+
+def test_summarize_partials_are_added_in_chunk_order():
+    """SUMMARIZE's final sum takes the per-chunk partials eight at a time; the order of the additions is the chunk order (13 chunks at
+    480p, 64 at 1080p: one and eight rounds), so the result equals a sequential float32 sum of the scratch buffer."""
+    g = torch.Generator().manual_seed(4)
+    for HW in (1620, 8160, 100):
+        K, C, Q = 2, 256, 16
+        feat = rnd(g, (K, HW, C), dev='cuda')
+        wl = (torch.randn((K, HW, Q), generator=g)).cuda()
+        m16 = torch.rand((K, HW), generator=g).cuda()
+        nchunk, n = (HW + 127) // 128, Q * (C + 1)
+        y = torch.zeros((K, Q, C + 1), device='cuda')
+        scratch = torch.zeros((K, nchunk, n), device='cuda')
+        ol = O.OpList()
+        ol.summarize(feat, wl, m16, y, K=K, HW=HW, C=C, Q=Q, scratch=scratch)
+        ol.run()
+        torch.cuda.synchronize()
+        part = scratch.cpu().numpy()
+        acc = np.zeros((K, n), np.float32)
+        for c in range(nchunk):
+            acc = (acc + part[:, c]).astype(np.float32)
+        assert np.array_equal(y.cpu().numpy().reshape(K, n).view(np.int32), acc.view(np.int32))

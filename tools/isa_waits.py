@@ -1,0 +1,86 @@
+"""Static scan of the device ISA for SERIALIZED global round trips: a `global_load` / `buffer_load` whose result is waited for
+(`s_waitcnt vmcnt(0)`) before any other load is issued.  Every such pair in the straight-line part of a kernel (its prologue, or a
+divergent `if (valid) x = p[i]` block) is a full L2 / HBM latency in front of the kernel's first useful instruction; in a frame of
+5-15 us launches that is 5-10 % of a launch each (found with this: aff_score_kernel's c_j / tau_j loads, round 4).
+Usage: hipcc ... --cuda-device-only -S file.hip -o file.s ; python tools/isa_waits.py file.s [kernel-name-substring]"""
+import re, sys
+
+
+def kernels(path):
+    name, body = None, []
+    for line in open(path):
+        m = re.match(r'^(_Z\w+|\w+):\s*; @', line)
+        if m:
+            if name:
+                yield name, body
+            name, body = m.group(1), []
+        elif name is not None:
+            if line.startswith('.Lfunc_end'):
+                yield name, body
+                name, body = None, []
+            else:
+                body.append(line.rstrip())
+    if name:
+        yield name, body
+
+
+def scan(body):
+    """-> list of (line index, load text, instructions between load and wait, inside a loop?)"""
+    labels = {}
+    for n, l in enumerate(body):
+        m = re.match(r'^(\.LBB\w+):', l)
+        if m:
+            labels[m.group(1)] = n
+    loops = []                                                    # (start, end) of backward branches
+    for n, l in enumerate(body):
+        m = re.search(r's_cbranch_\w+\s+(\.LBB\w+)|s_branch\s+(\.LBB\w+)', l)
+        if m:
+            t = labels.get(m.group(1) or m.group(2))
+            if t is not None and t < n:
+                loops.append((t, n))
+    out = []
+    pending = None                                                # (index, text, other instructions since)
+    outstanding = 0
+    for n, l in enumerate(body):
+        s = l.strip()
+        if not s or s.startswith(';') or s.endswith(':') or s.startswith('.'):
+            continue
+        if re.match(r'(global_load|buffer_load|flat_load|scratch_load)', s):
+            if 'lds' in s.split()[-1:]:
+                pass
+            outstanding += 1
+            pending = (n, s, 0) if outstanding == 1 else None
+            continue
+        m = re.match(r's_waitcnt.*vmcnt\((\d+)\)', s)
+        if m and int(m.group(1)) == 0:
+            if pending is not None and outstanding == 1:
+                out.append((pending[0], pending[1], pending[2], any(a <= pending[0] <= b for a, b in loops)))
+            outstanding = 0
+            pending = None
+            continue
+        if m:
+            outstanding = min(outstanding, int(m.group(1)))
+            continue
+        if pending is not None:
+            pending = (pending[0], pending[1], pending[2] + 1)
+    return out
+
+
+if __name__ == '__main__':
+    path = sys.argv[1]
+    sub = sys.argv[2] if len(sys.argv) > 2 else ''
+    import subprocess
+    for name, body in kernels(path):
+        if sub and sub not in name:
+            continue
+        hits = scan(body)
+        if not hits:
+            continue
+        try:
+            dem = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt', name], capture_output=True, text=True).stdout.strip()
+        except Exception:
+            dem = name
+        pro = [h for h in hits if not h[3]]
+        print(f'{dem[:110]}: {len(pro)} lone load+wait outside loops, {len(hits) - len(pro)} inside loops')
+        for n, s, gap, inloop in hits[:12]:
+            print(f'    line {n:5d} {"loop" if inloop else "    "} {gap:3d} instr before the wait: {s}')
