@@ -25,14 +25,20 @@ __global__ void key_prep_kernel(const float* __restrict__ key, const float* __re
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)n * 16) return;
     int row = idx >> 4, c8 = idx & 15;                  // 16 chunks of 8 -> 128 operand channels
-    const float* k = key + (long)row * 64 + (c8 & 7) * 8;
+    // the lane's eight channels as two 16-byte loads, BEFORE any select on c8: `(c8 < 8) ? -e[i] : 2 k[i] e[i]` on pointers compiled to a
+    // divergent branch per channel with the loads inside its arms -- eight dependent round trips (tools/isa_waits.py)
+    const float* kp = key + (long)row * 64 + (c8 & 7) * 8;
+    const float4 ka = *reinterpret_cast<const float4*>(kp), kb = *reinterpret_cast<const float4*>(kp + 4);
+    const float k[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
     float v[8];
     if (!query) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (c8 < 8) ? k[i] * k[i] : k[i];
         if (c8 == 0) sc[row] = aux[row] * 0.125f;       // shrinkage / sqrt(64)
     } else {
-        const float* e = aux + (long)row * 64 + (c8 & 7) * 8;
+        const float* ep = aux + (long)row * 64 + (c8 & 7) * 8;
+        const float4 ea = *reinterpret_cast<const float4*>(ep), eb = *reinterpret_cast<const float4*>(ep + 4);
+        const float e[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
         float pe[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { v[i] = (c8 < 8) ? -e[i] : 2.f * k[i] * e[i]; pe[i] = e[i] * k[i] * k[i]; }
