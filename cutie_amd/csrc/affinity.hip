@@ -31,7 +31,7 @@ __global__ void key_prep_kernel(const float* __restrict__ key, const float* __re
     const float4 ka = *reinterpret_cast<const float4*>(kp), kb = *reinterpret_cast<const float4*>(kp + 4);
     const float k[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
     float v[8];
-    if (!query) {
+    if (!(query & 1)) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (c8 < 8) ? k[i] * k[i] : k[i];
         if (c8 == 0) sc[row] = aux[row] * 0.125f;       // shrinkage / sqrt(64)
@@ -46,17 +46,25 @@ __global__ void key_prep_kernel(const float* __restrict__ key, const float* __re
         // adds its eight products to the running sum of lane c8 - 1.  (One lane per row walking the 64 channels was 128 loads in a loop
         // that waits for each of them: tools/isa_waits.py; the row's 16 lanes sit in one wave, n * 16 threads exit as whole rows.)
         float c = 0.f;
-#pragma unroll
-        for (int step = 0; step < 8; ++step) {
-            const float cin = __shfl(c, (threadIdx.x & 48) | (step > 0 ? step - 1 : 0), 64);
-            if (c8 == step) {
-                c = step > 0 ? cin : 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) c += pe[i];
+        if (query & 2) {                                 // (A/B switch: the one-lane-per-row loop of rounds 1-3)
+            if (c8 == 0) {
+                const float* kk = key + (long)row * 64; const float* ee = aux + (long)row * 64;
+                for (int i = 0; i < 64; ++i) c += ee[i] * kk[i] * kk[i];
+                sc[row] = c;
             }
+        } else {
+#pragma unroll
+            for (int step = 0; step < 8; ++step) {
+                const float cin = __shfl(c, (threadIdx.x & 48) | (step > 0 ? step - 1 : 0), 64);
+                if (c8 == step) {
+                    c = step > 0 ? cin : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) c += pe[i];
+                }
+            }
+            c = __shfl(c, (threadIdx.x & 48) | 7, 64);
+            if (c8 == 0) sc[row] = c;
         }
-        c = __shfl(c, (threadIdx.x & 48) | 7, 64);
-        if (c8 == 0) sc[row] = c;
     }
     uint32_t h[4], l[4];
 #pragma unroll
@@ -898,7 +906,7 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
         case CUTIE_OP_KEY_PREP: {
             long n = (long)i[0] * 16;
             hipLaunchKernelGGL(key_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)p[0], (const float*)p[1],
-                               (bf16_t*)p[2], (bf16_t*)p[3], (float*)p[4], i[0], op->flags & 1);
+                               (bf16_t*)p[2], (bf16_t*)p[3], (float*)p[4], i[0], op->flags & 3);
             break;
         }
         case CUTIE_OP_AFF_SCORE: {

@@ -40,8 +40,13 @@ __device__ __forceinline__ void conv_finish(const ConvParams& p, float* v, int m
     const bool vec_r = (p.ldr & 7) == 0;
     const bool full = ch0 + 7 < p.Cout;
     if (p.bias) {
+        if (full && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) {      // two 16-byte loads (the per-channel form waits for each of its eight loads)
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + ch0), b1 = *reinterpret_cast<const float4*>(p.bias + ch0 + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        } else {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) v[r] += p.bias[ch0 + r];
+            for (int r = 0; r < 8; ++r) if (ch0 + r < p.Cout) v[r] += p.bias[ch0 + r];
+        }
     }
     if (p.res) {
         const int mres = res_bcast ? (m % p.OHW) : m;

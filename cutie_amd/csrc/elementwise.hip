@@ -418,6 +418,27 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const bf16_t* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// four channels per thread: 16-byte loads of the three gate rows and of h, a 16-byte store of h and an 8-byte store of its bf16 shadow
+// (one channel per thread wrote the shadow in 2-byte pieces); the same expression per element as gru_kernel
+__global__ void gru4_kernel(const float* __restrict__ v, float* __restrict__ h, bf16_t* __restrict__ hb, long n, int C) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;             // (row, channel quad)
+    const int C4 = C >> 2;
+    if (idx >= n * C4) return;
+    const long row = idx / C4; const int c = (int)(idx - row * C4) * 4;
+    const float* vr = v + row * 3 * C + c;
+    const float4 f4 = *reinterpret_cast<const float4*>(vr), u4 = *reinterpret_cast<const float4*>(vr + C), n4 = *reinterpret_cast<const float4*>(vr + 2 * C);
+    const float4 h4 = *reinterpret_cast<const float4*>(h + row * C + c);
+    const float fa[4] = {f4.x, f4.y, f4.z, f4.w}, ua[4] = {u4.x, u4.y, u4.z, u4.w}, na[4] = {n4.x, n4.y, n4.z, n4.w}, ha[4] = {h4.x, h4.y, h4.z, h4.w};
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float f = sigmoidf_(fa[i]), u = sigmoidf_(ua[i]), nv = tanhf(na[i]);
+        o[i] = f * ha[i] * (1.f - u) + u * nv;
+    }
+    *reinterpret_cast<float4*>(h + row * C + c) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<uint2*>(hb + row * C + c) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+}
+
 __global__ void gru_kernel(const float* __restrict__ v, float* __restrict__ h, bf16_t* __restrict__ hb, long n, int C) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * C) return;
@@ -1177,7 +1198,10 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
         }
         case CUTIE_OP_GRU: {
             long n = (long)i[0] * i[1];
-            hipLaunchKernelGGL(gru_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (bf16_t*)p[2], (long)i[0], i[1]);
+            if (!(op->flags & 1) && (i[1] & 3) == 0 && (((uintptr_t)p[0] | (uintptr_t)p[1]) & 15) == 0 && ((uintptr_t)p[2] & 7) == 0)      // flags&1: one channel per thread (A/B switch)
+                hipLaunchKernelGGL(gru4_kernel, GRID1D(n / 4, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (bf16_t*)p[2], (long)i[0], i[1]);
+            else
+                hipLaunchKernelGGL(gru_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (bf16_t*)p[2], (long)i[0], i[1]);
             break;
         }
         case CUTIE_OP_SEG_AGG:

@@ -35,6 +35,8 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQ1 = 0, 1, 2, 3
 ACT_SHIFT = 4
 UP4_SCALAR = 2 if os.environ.get('CUTIE_AMD_UP4_VEC', '1') in ('', '0') else 0       # UP4_SOFTMAX flags&2: one pixel per thread (A/B switch)
 AREA_RT = 8 if os.environ.get('CUTIE_AMD_AREA_R', '1') in ('', '0') else 0          # AREA_DOWN3 flags&8: bodies with a run-time pooling ratio (A/B switch)
+GRU_SCALAR = 1 if os.environ.get('CUTIE_AMD_GRU4', '1') in ('', '0') else 0            # GRU flags&1: one channel per thread (A/B switch)
+KEYPREP_LOOP = 2 if os.environ.get('CUTIE_AMD_KEYPREP_LOOP', '0') not in ('', '0') else 0   # KEY_PREP flags&2: c_j by one lane per row (A/B switch)
 UP4_RTK = 8 if os.environ.get('CUTIE_AMD_UP4_KC', '1') in ('', '0') else 0           # UP4_SOFTMAX flags&8: kernels with a run-time object count (A/B switch)
 
 # conv tile table (mirrors the switch in csrc/conv_igemm.hip): id -> (BM, BN, BK)
@@ -409,7 +411,7 @@ class OpList:
         return self.add(ECA_APPLY, 0, [B, HW, C], [], [x, gap, wk, r, y, part] + tail)
 
     def gru(self, values, h, hb, *, n, C):
-        return self.add(GRU, 0, [n, C], [], [values, h, hb])
+        return self.add(GRU, GRU_SCALAR, [n, C], [], [values, h, hb])
 
     def seg_agg(self, logits, agg, *, K, hw):
         return self.add(SEG_AGG, 0, [K, hw], [], [logits, agg])
@@ -570,7 +572,7 @@ class OpList:
         return self.add(ADD_PE, 0, [B, n], [], [x, pe, y])
 
     def key_prep(self, key, aux, hi, lo, sc, *, n, query):
-        return self.add(KEY_PREP, 1 if query else 0, [n], [], [key, aux, hi, lo, sc])
+        return self.add(KEY_PREP, (1 | KEYPREP_LOOP) if query else 0, [n], [], [key, aux, hi, lo, sc])
 
     AFF_CSTRIDE = 32          # ints between the candidate counters of consecutive queries (one cache line each)
 

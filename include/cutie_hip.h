@@ -103,7 +103,8 @@ enum {
      *      (may be 0), p8 = its output f32 [B,HW]: the mask_pred head of a transformer block (object_transformer.py:151-164) without a launch */
     CUTIE_OP_ECA_APPLY = 8,
     /* GRU: h' = sig(f)*h*(1-sig(u)) + sig(u)*tanh(n), values=[f|u|n] f32   modules.py:35-43
-     * p0=values f32 [B,HW,3C] p1=h f32 [B,HW,C] (in/out) p2=h_bf16 bf16 [B,HW,C] (out)  i: 0 n=B*HW 1 C */
+     * p0=values f32 [B,HW,3C] p1=h f32 [B,HW,C] (in/out) p2=h_bf16 bf16 [B,HW,C] (out)  i: 0 n=B*HW 1 C
+     * flags&1: one channel per thread (A/B switch; default: four, 16-byte accesses, when C % 4 == 0 and the buffers are aligned -- same bits) */
     CUTIE_OP_GRU = 9,
     /* SEG_AGG: prob=sigmoid(logit); aggregate -> (K+1) logits at 1/4 res   cutie.py:193-198,
      * tensor_utils.py:47-55      p0=logits f32 [K,h,w] p1=agg f32 [K+1,h,w]   i: 0 K 1 h*w */
@@ -198,7 +199,9 @@ enum {
     /* KEY_PREP: split-bf16 MFMA operands of the anisotropic-L2 similarity  memory_utils.py:30-42
      * memory side (flags=0): A=[k^2|k] -> A_hi,A_lo bf16 [n,128], scale=shrinkage/sqrt(CK) f32 [n]
      * query side  (flags=1): B=[-e|2*k*e] -> B_hi,B_lo, c=sum(e*k^2)
-     * p0=key f32 [n,64] p1=shr f32 [n] (mem) | sel f32 [n,64] (query) p2=hi p3=lo p4=scale|c   i: 0 n */
+     * p0=key f32 [n,64] p1=shr f32 [n] (mem) | sel f32 [n,64] (query) p2=hi p3=lo p4=scale|c   i: 0 n
+     * flags&2 (query side): c summed by one lane per row in a 64-step loop (A/B switch; default: the row's lanes hand the running sum on --
+     *      the same additions in the same order) */
     CUTIE_OP_KEY_PREP = 23,
     /* AFF_SCORE: S = scale_i*(A_i.B_j - c_j) tiles on MFMA (3-term split bf16, fp32-class accuracy)
      * mode 0: per-(16-token tile, query) maxima -> gmax f32 [HWp, Gld] (query-major, Gld = G rounded up to 64)

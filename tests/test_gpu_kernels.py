@@ -1323,11 +1323,12 @@ def test_area_down3_compile_time_ratio(monkeypatch):
     assert float(outs[0].float().abs().max()) > 0
 
 
-def test_key_prep_query_constant_is_the_channel_ordered_sum():
+def test_key_prep_query_constant_is_the_channel_ordered_sum(monkeypatch):
     """KEY_PREP (query side): c_j = sum_i e_i k_i^2 is summed in channel order i = 0..63 with separate multiplies and adds (the row's lanes
     hand the running sum on) -- emulated exactly in numpy float32."""
     g = torch.Generator().manual_seed(9)
-    for HW in (1620, 100, 7):
+    for HW, loop in ((1620, 0), (100, 0), (7, 0), (1620, 2), (33, 2)):          # loop = 2: the one-lane-per-row form (A/B switch)
+        monkeypatch.setattr(O, 'KEYPREP_LOOP', loop)
         HWp = -(-HW // 64) * 64
         qkey = torch.randn((HW, 64), generator=g) * 0.8
         qsel = torch.rand((HW, 64), generator=g)
@@ -1368,3 +1369,23 @@ def test_summarize_partials_are_added_in_chunk_order():
         for c in range(nchunk):
             acc = (acc + part[:, c]).astype(np.float32)
         assert np.array_equal(y.cpu().numpy().reshape(K, n).view(np.int32), acc.view(np.int32))
+
+
+def test_gru_four_channels_per_thread(monkeypatch):
+    """GRU with four channels per thread (16-byte accesses) against the one-channel form (flags&1): same expression per element."""
+    g = torch.Generator().manual_seed(21)
+    n, C = 4860, 256
+    v0 = (torch.randn((n, 3 * C), generator=g) * 2).cuda()
+    h0 = torch.randn((n, C), generator=g).cuda()
+    outs = []
+    for scalar in (0, 1):
+        monkeypatch.setattr(O, 'GRU_SCALAR', scalar)
+        h, hb = h0.clone(), torch.zeros((n, C), dtype=BF16, device='cuda')
+        ol = O.OpList()
+        ol.gru(v0, h, hb, n=n, C=C)
+        assert int(ol.finalize()['flags'][0]) == scalar
+        ol.run()
+        torch.cuda.synchronize()
+        outs.append((h, hb.view(torch.int16)))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert not torch.equal(outs[0][0], h0)

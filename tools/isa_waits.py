@@ -66,7 +66,42 @@ def scan(body):
     return out
 
 
+def wait_groups(body):
+    """(before the first loop, whole kernel): number of vmcnt waits -- of any count -- with at least one load issued since the previous
+    one.  A kernel whose loads are all in flight together has 1-3; `load, wait, load, wait ...` shows up as one group per load."""
+    labels = {}
+    for n, l in enumerate(body):
+        m = re.match(r'^(\.LBB\w+):', l)
+        if m:
+            labels[m.group(1)] = n
+    firstloop = len(body)
+    for n, l in enumerate(body):
+        m = re.search(r's_c?branch\w*\s+(\.LBB\w+)', l)
+        if m:
+            t = labels.get(m.group(1))
+            if t is not None and t < n:
+                firstloop = min(firstloop, t)
+    pre = tot = since = 0
+    for n, l in enumerate(body):
+        s = l.strip()
+        if re.match(r'(global_load|buffer_load|flat_load)', s):
+            since += 1
+        elif re.match(r's_waitcnt.*vmcnt\(', s):
+            if since:
+                tot += 1
+                pre += n < firstloop
+            since = 0
+    return pre, tot
+
+
 if __name__ == '__main__':
+    if sys.argv[1] == '--groups':                              # python tools/isa_waits.py --groups file.s [name substrings ...]
+        for name, body in kernels(sys.argv[2]):
+            if len(sys.argv) > 3 and not any(s in name for s in sys.argv[3:]):
+                continue
+            pre, tot = wait_groups(body)
+            print(f'{pre:3d} wait groups before the first loop, {tot:3d} in all   {name[:110]}')
+        sys.exit(0)
     path = sys.argv[1]
     sub = sys.argv[2] if len(sys.argv) > 2 else ''
     import subprocess
