@@ -561,8 +561,27 @@ __global__ void up4_softmax_fused_kernel(const float* __restrict__ lg, float* __
 // in its own s_waitcnt vmcnt(0): the 6 x K source logits came in one after the other, 18 dependent L2 round trips in front of the
 // first exp at K = 3 (tools/isa_waits.py).  With KC the loop bodies are straight-line code and all loads are in flight together; the
 // arithmetic and its order are the same, so are the bits.
-template <int PMAX, int KC = 0>
-__device__ __forceinline__ void up4_four(const float* __restrict__ lg, int Krt, int h, int w, int oy, int j, float (&out)[PMAX][4], float (&lo)[PMAX][4]) {
+// The aggregated, clamped logits of ONE source pixel from its K raw logits (SEG_AGG, cutie.py:199-200): Lp[0] = background.
+template <int PMAX>
+__device__ __forceinline__ void up4_src(const float (&raw)[PMAX - 1], int K, float (&Lp)[PMAX]) {
+    float bg = 1.f;
+#pragma unroll
+    for (int k = 0; k < PMAX - 1; ++k)
+        if (k < K) {
+            const float pr = 1.f / (1.f + expf(-raw[k]));
+            bg *= (1.f - pr);
+            Lp[k + 1] = clamp_logit(pr);
+        }
+    Lp[0] = clamp_logit(bg);
+}
+
+// SHARED: the source pixels' aggregated logits come from Lsh[plane][6 x 6] (the 4 x 4 source pixels under a 16 x 16 output cell and one
+// ring around them, first pixel (sy0, sx0), coordinates clamped to the map), computed once per wave by up4_softmax_md_kernel -- every lane
+// recomputing its six source pixels was 18 exp + 24 log + 42 divisions per thread at K = 3, 1800 VALU instructions in all: the kernel
+// ran at the VALU, not at its 6.6 MB of stores.  Same values from the same expression, whoever computes them.
+template <int PMAX, int KC = 0, bool SHARED = false>
+__device__ __forceinline__ void up4_four(const float* __restrict__ lg, int Krt, int h, int w, int oy, int j, float (&out)[PMAX][4], float (&lo)[PMAX][4],
+                                         const float* Lsh = nullptr, int sy0 = 0, int sx0 = 0) {
     const int K = KC > 0 ? KC : Krt;
     int y0, y1; float ly;
     up_coord(oy, h, 0.25f, y0, y1, ly);
@@ -570,30 +589,32 @@ __device__ __forceinline__ void up4_four(const float* __restrict__ lg, int Krt, 
     const long hw = (long)h * w;
     // clamped logits of the six source pixels: L[r][c][plane], plane 0 = background
     float L[2][3][PMAX];
-    float raw[2][3][PMAX - 1];                           // (all 6 x K loads first: one round trip)
+    if (SHARED) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const long o = (long)(r ? y1 : y0) * w + col[c];
+            for (int c = 0; c < 3; ++c) {
+                const int slot = ((r ? y1 : y0) - sy0) * 6 + (col[c] - sx0);
 #pragma unroll
-            for (int k = 0; k < PMAX - 1; ++k)
-                if (k < K) raw[r][c][k] = lg[(long)k * hw + o];
-        }
+                for (int p = 0; p < PMAX; ++p)
+                    if (p <= K) L[r][c][p] = Lsh[p * 36 + slot];
+            }
+    } else {
+        float raw[2][3][PMAX - 1];                       // (all 6 x K loads first: one round trip)
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float bg = 1.f;
+            for (int c = 0; c < 3; ++c) {
+                const long o = (long)(r ? y1 : y0) * w + col[c];
 #pragma unroll
-            for (int k = 0; k < PMAX - 1; ++k)
-                if (k < K) {
-                    const float pr = 1.f / (1.f + expf(-raw[r][c][k]));
-                    bg *= (1.f - pr);
-                    L[r][c][k + 1] = clamp_logit(pr);
-                }
-            L[r][c][0] = clamp_logit(bg);
-        }
+                for (int k = 0; k < PMAX - 1; ++k)
+                    if (k < K) raw[r][c][k] = lg[(long)k * hw + o];
+            }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) up4_src<PMAX>(raw[r][c], K, L[r][c]);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         int x0, x1; float lx;
@@ -655,11 +676,12 @@ __global__ __launch_bounds__(256) void up4_softmax_fused4_kernel(const float* __
 // the others)).  The cell's values go through LDS so that every lane sums the same four entries in the same order as
 // mask_down_pair_kernel (entries lane, lane + 64, +128, +192 of the row-major cell) and the same wave_sum follows: bit-identical to the
 // MASK_DOWN launch it replaces.  4 waves (cells) per block; needs H, W multiples of 16 and K + 1 <= PMAX.
-template <int PMAX, int KC = 0>
+template <int PMAX, int KC = 0, bool SH = false>
 __global__ __launch_bounds__(256) void up4_softmax_md_kernel(const float* __restrict__ lg, float* __restrict__ prob, float* __restrict__ lup,
                                                              int Krt, int h, int w, float* __restrict__ m16, uint4* __restrict__ pair, int ld8) {
     const int K = KC > 0 ? KC : Krt;
     __shared__ float cell[4][PMAX - 1][256];
+    __shared__ float srcL[4][SH ? PMAX : 1][36];
     const int OH = 4 * h, OW = 4 * w, ch = OH >> 4, cw = OW >> 4, ncell = ch * cw;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int cid = blockIdx.x * 4 + wave;
@@ -670,7 +692,25 @@ __global__ __launch_bounds__(256) void up4_softmax_md_kernel(const float* __rest
     const long OHW = (long)OH * OW;
     float out[PMAX][4];
     float lo[PMAX][4];
-    up4_four<PMAX, KC>(lg, K, h, w, oy, j, out, lo);
+    if (SH) {
+        // the 6 x 6 source pixels of this cell, one per lane (36 of 64), aggregated once
+        if (lane < 36) {
+            const int sly = lane / 6, slx = lane - sly * 6;
+            const long o = (long)min(max(4 * cy - 1 + sly, 0), h - 1) * w + min(max(4 * cx - 1 + slx, 0), w - 1);
+            float raw[PMAX - 1], Lp[PMAX];
+#pragma unroll
+            for (int k = 0; k < PMAX - 1; ++k)
+                if (k < K) raw[k] = lg[(long)k * h * w + o];
+            up4_src<PMAX>(raw, K, Lp);
+#pragma unroll
+            for (int p = 0; p < PMAX; ++p)
+                if (p <= K) srcL[wave][SH ? p : 0][lane] = Lp[p];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): srcL is wave-private
+        __builtin_amdgcn_wave_barrier();
+    }
+    up4_four<PMAX, KC, SH>(lg, K, h, w, oy, j, out, lo, &srcL[wave][0][0], 4 * cy - 1, 4 * cx - 1);
     const long base = (long)oy * OW + 4 * j;
 #pragma unroll
     for (int p = 0; p < PMAX; ++p)
@@ -1215,13 +1255,15 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
                 if (op->flags & 4) {                              // + MASK_DOWN of the probabilities (p3 = m16, p4 = pair, i3 = channel pitch of pair)
                     if (!vec || !p[3] || !p[4] || (i[1] & 3) || (i[2] & 3) || i[3] < 8 || (i[3] & 7)) { cutie_set_error("up4_softmax: the mask-down form needs P <= 8, h, w multiples of 4, m16 and pair"); return -2; }
                     const int ncell = (i[1] / 4) * (i[2] / 4);
-#define UP4_MD(KC) hipLaunchKernelGGL((up4_softmax_md_kernel<8, KC>), dim3((ncell + 3) / 4), dim3(256), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, \
+#define UP4_MD_(KC, SH) hipLaunchKernelGGL((up4_softmax_md_kernel<8, KC, SH>), dim3((ncell + 3) / 4), dim3(256), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, \
                                        i[1], i[2], (float*)p[3], (uint4*)p[4], i[3] / 8)
+#define UP4_MD(KC) { if (op->flags & 16) UP4_MD_(KC, false); else UP4_MD_(KC, true); }      /* flags&16: every lane aggregates its own source pixels (A/B switch) */
                     switch ((op->flags & 8) ? 0 : i[0] - 1) {          // object count as a compile-time constant (see up4_four); flags&8: run-time K
                         case 1: UP4_MD(1); break; case 2: UP4_MD(2); break; case 3: UP4_MD(3); break; case 4: UP4_MD(4); break;
                         case 5: UP4_MD(5); break; case 6: UP4_MD(6); break; case 7: UP4_MD(7); break; default: UP4_MD(0); break;
                     }
 #undef UP4_MD
+#undef UP4_MD_
                     break;
                 }
                 if (vec) {

@@ -37,6 +37,7 @@ UP4_SCALAR = 2 if os.environ.get('CUTIE_AMD_UP4_VEC', '1') in ('', '0') else 0  
 AREA_RT = 8 if os.environ.get('CUTIE_AMD_AREA_R', '1') in ('', '0') else 0          # AREA_DOWN3 flags&8: bodies with a run-time pooling ratio (A/B switch)
 GRU_SCALAR = 1 if os.environ.get('CUTIE_AMD_GRU4', '1') in ('', '0') else 0            # GRU flags&1: one channel per thread (A/B switch)
 KEYPREP_LOOP = 2 if os.environ.get('CUTIE_AMD_KEYPREP_LOOP', '0') not in ('', '0') else 0   # KEY_PREP flags&2: c_j by one lane per row (A/B switch)
+UP4_LANES = 16 if os.environ.get('CUTIE_AMD_UP4_SHARED', '1') in ('', '0') else 0     # UP4_SOFTMAX flags&16 (mask-down form): every lane aggregates its own six source pixels (A/B switch)
 UP4_RTK = 8 if os.environ.get('CUTIE_AMD_UP4_KC', '1') in ('', '0') else 0           # UP4_SOFTMAX flags&8: kernels with a run-time object count (A/B switch)
 
 # conv tile table (mirrors the switch in csrc/conv_igemm.hip): id -> (BM, BN, BK)
@@ -422,7 +423,7 @@ class OpList:
         if mask_down is not None:
             assert from_logits and not UP4_SCALAR and P <= 8 and h % 4 == 0 and w % 4 == 0
             m16, pair, pitch = mask_down
-            return self.add(UP4_SOFTMAX, 1 | 4 | UP4_RTK, [P, h, w, pitch], [], [agg, prob, logits_up, m16, pair])
+            return self.add(UP4_SOFTMAX, 1 | 4 | UP4_RTK | UP4_LANES, [P, h, w, pitch], [], [agg, prob, logits_up, m16, pair])
         return self.add(UP4_SOFTMAX, (1 | UP4_SCALAR | UP4_RTK) if from_logits else 0, [P, h, w], [], [agg, prob, logits_up])
 
     def mask_merge(self, inmask, pred, src, planes, *, h0, w0, H, W, pad_left, pad_top, Knew, Kold, nfloat, float_mode):

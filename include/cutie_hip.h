@@ -117,6 +117,8 @@ enum {
      * flags&4 (with flags&1, P <= 8, h, w % 4 == 0): the launch also produces MASK_DOWN(prob[1:], r = 16) for the next frame's pixel fusion:
      *      p3 = m16 f32 [K, H/16 * W/16], p4 = pair bf16 [K, H/16, W/16, i3] (channels 0, 1 written), i3 = channel pitch of pair (8 | 64);
      *      bit-identical to a MASK_DOWN launch on the stored probabilities
+     * flags&16 (with flags&4): every lane aggregates its own six source pixels (A/B switch; default: the 6 x 6 source pixels under a 16 x 16
+     *      output cell are aggregated once per wave and shared through LDS -- half the VALU instructions, same bits)
      * flags&8 (with flags&1): the kernels with a run-time object count (A/B switch; default: one instantiation per K = 1..7, whose loads are
      *      all in flight together -- same bits) */
     CUTIE_OP_UP4_SOFTMAX = 11,

@@ -1248,7 +1248,7 @@ def test_flip_w():
     check(hip, ref, name='flip_w', rtol=1e-6)
 
 
-@pytest.mark.parametrize('K,h,w', [(3, 120, 216), (1, 24, 32), (5, 8, 12)])
+@pytest.mark.parametrize('K,h,w', [(3, 120, 216), (1, 24, 32), (5, 8, 12), (2, 4, 4), (7, 4, 28), (3, 272, 480)])
 def test_up4_softmax_with_mask_down(K, h, w):
     """UP4_SOFTMAX flags&4: the launch also writes MASK_DOWN(prob[1:], r = 16) -- bit-identical to the MASK_DOWN launch on the stored
     probabilities (same per-lane sums, same wave reduction), probabilities identical to the plain form."""
@@ -1283,19 +1283,22 @@ def test_up4_softmax_compile_time_object_count(K, monkeypatch):
     H, W = 4 * h, 4 * w
     hw16 = (H // 16) * (W // 16)
     res = []
-    for rtk in (0, 8):
+    for rtk, lanes in ((0, 0), (8, 0), (0, 16), (8, 16)):    # lanes = 16: per-lane aggregation instead of the wave's shared 6 x 6 source pixels
         monkeypatch.setattr(O, 'UP4_RTK', rtk)
+        monkeypatch.setattr(O, 'UP4_LANES', lanes)
         prob, lup, prob_m = (torch.zeros((K + 1, H, W), device='cuda') for _ in range(3))
         pair, m16 = torch.zeros((K, hw16, 64), dtype=BF16, device='cuda'), torch.zeros((K, hw16), device='cuda')
         ol = O.OpList()
         ol.up4_softmax(lg, prob, lup, P=K + 1, h=h, w=w, from_logits=True)
         ol.up4_softmax(lg, prob_m, None, P=K + 1, h=h, w=w, from_logits=True, mask_down=(m16, pair, 64))
-        assert all((int(f) & 8) == rtk for f in ol.finalize()['flags'])
+        fl = [int(f) for f in ol.finalize()['flags']]
+        assert all((f & 8) == rtk for f in fl) and (fl[1] & 16) == lanes
         ol.run()
         torch.cuda.synchronize()
         res.append((prob, lup, prob_m, pair.view(torch.int16), m16))
-    for a, b in zip(*res):
-        assert torch.equal(a, b)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
     assert torch.equal(res[0][0], res[0][2])
 
 
