@@ -964,10 +964,16 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             SelectSide sd = {(int*)p[2], (float*)p[3], (float*)p[4], i[4], i[5], op->flags & 1};
             const dim3 grid((i[0] + 3) / 4), block(256);
             const int Gld = (i[2] + 63) / 64 * 64;
-            if (i[2] <= 1024) hipLaunchKernelGGL(aff_select_reg_kernel<16>, grid, block, 0, s, (const float*)p[0], (float*)p[1], i[0], Gld, i[2], i[3], sd);
-            else if (i[2] <= 2048) hipLaunchKernelGGL(aff_select_reg_kernel<32>, grid, block, 0, s, (const float*)p[0], (float*)p[1], i[0], Gld, i[2], i[3], sd);
-            else if (i[2] <= 4096) hipLaunchKernelGGL(aff_select_reg_kernel<64>, grid, block, 0, s, (const float*)p[0], (float*)p[1], i[0], Gld, i[2], i[3], sd);
-            else hipLaunchKernelGGL(aff_select_kernel, grid, block, 0, s, (const float*)p[0], (float*)p[1], i[0], Gld, i[2], i[3], sd);
+            // values per lane: the kernel counts MAXV compares per lane and bit, so MAXV follows the number of tiles in steps of 4 x 64 tiles
+            // (16 | 32 | 64 only: 10.7 us at 700 tiles, 16.5 us from 1025 tiles on -- the bench clip crosses that line at 16.4 k tokens);
+            // flags&2: the three coarse sizes (A/B switch).  Exact selection either way.
+            const int need = (op->flags & 2) ? (i[2] <= 1024 ? 16 : i[2] <= 2048 ? 32 : 64) : (i[2] + 63) / 64;
+#define AFF_SEL(MV) hipLaunchKernelGGL(aff_select_reg_kernel<MV>, grid, block, 0, s, (const float*)p[0], (float*)p[1], i[0], Gld, i[2], i[3], sd)
+            if (i[2] > 4096) hipLaunchKernelGGL(aff_select_kernel, grid, block, 0, s, (const float*)p[0], (float*)p[1], i[0], Gld, i[2], i[3], sd);
+            else if (need <= 4) AFF_SEL(4); else if (need <= 8) AFF_SEL(8); else if (need <= 12) AFF_SEL(12); else if (need <= 16) AFF_SEL(16);
+            else if (need <= 20) AFF_SEL(20); else if (need <= 24) AFF_SEL(24); else if (need <= 28) AFF_SEL(28); else if (need <= 32) AFF_SEL(32);
+            else if (need <= 40) AFF_SEL(40); else if (need <= 48) AFF_SEL(48); else if (need <= 56) AFF_SEL(56); else AFF_SEL(64);
+#undef AFF_SEL
             break;
         }
         case CUTIE_OP_AFF_READOUT: {

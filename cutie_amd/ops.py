@@ -38,6 +38,7 @@ AREA_RT = 8 if os.environ.get('CUTIE_AMD_AREA_R', '1') in ('', '0') else 0      
 GRU_SCALAR = 1 if os.environ.get('CUTIE_AMD_GRU4', '1') in ('', '0') else 0            # GRU flags&1: one channel per thread (A/B switch)
 KEYPREP_LOOP = 2 if os.environ.get('CUTIE_AMD_KEYPREP_LOOP', '0') not in ('', '0') else 0   # KEY_PREP flags&2: c_j by one lane per row (A/B switch)
 UP4_LANES = 16 if os.environ.get('CUTIE_AMD_UP4_SHARED', '1') in ('', '0') else 0     # UP4_SOFTMAX flags&16 (mask-down form): every lane aggregates its own six source pixels (A/B switch)
+SELECT_COARSE = 2 if os.environ.get('CUTIE_AMD_SELECT_FINE', '1') in ('', '0') else 0    # AFF_SELECT flags&2: 16 | 32 | 64 values per lane only (A/B switch)
 UP4_RTK = 8 if os.environ.get('CUTIE_AMD_UP4_KC', '1') in ('', '0') else 0           # UP4_SOFTMAX flags&8: kernels with a run-time object count (A/B switch)
 
 # conv tile table (mirrors the switch in csrc/conv_igemm.hip): id -> (BM, BN, BK)
@@ -598,10 +599,10 @@ class OpList:
         zero = (buffer, n): f32 range cleared instead (excludes ticks: the usage side buffer of a look-ahead read-out)."""
         if zero is not None:
             assert not ticks
-            return self.add(AFF_SELECT, 1, [HW, HWp, G, top_k, zero[1], 0], [], [gmax, tau, clear_count, zero[0], None])
+            return self.add(AFF_SELECT, 1 | SELECT_COARSE, [HW, HWp, G, top_k, zero[1], 0], [], [gmax, tau, clear_count, zero[0], None])
         ticks = list(ticks) + [(None, 0)] * (2 - len(ticks))
         assert len(ticks) == 2
-        return self.add(AFF_SELECT, 0, [HW, HWp, G, top_k, ticks[0][1], ticks[1][1]], [], [gmax, tau, clear_count, ticks[0][0], ticks[1][0]])
+        return self.add(AFF_SELECT, SELECT_COARSE, [HW, HWp, G, top_k, ticks[0][1], ticks[1][1]], [], [gmax, tau, clear_count, ticks[0][0], ticks[1][0]])
 
     def aff_readout(self, cand_val, cand_idx, count, vptrs, usage, y, overflow, *, HW, cap, top_k, K, CV):
         return self.add(AFF_READOUT, 0, [HW, cap, top_k, K, CV], [], [cand_val, cand_idx, count, vptrs, usage, y, overflow])

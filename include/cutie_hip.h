@@ -220,7 +220,8 @@ enum {
      * p0=gmax f32 [HWp,Gld] p1=tau f32 [HW]   i: 0 HW 1 HWp 2 G 3 top_k
      * optional side jobs (0 = none): p2=count i32 [HW*32]: count[32 q] = 0 for every query (pass 1's candidate counters);
      *      p3=life f32 [i4], p4=life f32 [i5]: += 1 (USAGE_TICK of two token ranges)
-     * flags&1: range p3 is CLEARED instead (the usage side buffer of a look-ahead read-out, see USAGE_TICK) */
+     * flags&1: range p3 is CLEARED instead (the usage side buffer of a look-ahead read-out, see USAGE_TICK)
+     * flags&2: values per lane in the three sizes 16 | 32 | 64 only (A/B switch; default: ceil(G / 64) rounded up to a multiple of 4) */
     CUTIE_OP_AFF_SELECT = 25,
     /* AFF_READOUT: exact top-k of the candidates (ties -> lower slot), softmax, usage += w,
      * readout[o,j,:] = sum_i w_i V_o[i,:]    memory_utils.py:58-63,75; memory_manager.py:77-88

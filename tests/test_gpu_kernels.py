@@ -1392,3 +1392,30 @@ def test_gru_four_channels_per_thread(monkeypatch):
         outs.append((h, hb.view(torch.int16)))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert not torch.equal(outs[0][0], h0)
+
+
+@pytest.mark.parametrize('G', [30, 64, 257, 700, 1040, 1290, 1800, 2300, 2900, 3700, 4096])
+def test_aff_select_values_per_lane_follow_the_tile_count(G, monkeypatch):
+    """AFF_SELECT holds ceil(G / 64) values per lane in steps of 4 (12 sizes) instead of 16 | 32 | 64 (flags&2): the same exact top_k-th
+    largest tile maximum, also with ties and with -inf entries."""
+    g = torch.Generator().manual_seed(G)
+    HW, top_k = 203, 30
+    HWp, Gld = -(-HW // 64) * 64, -(-G // 64) * 64
+    gm = torch.randn((HWp, Gld), generator=g) * 20
+    nt = gm[:, 1::7].shape[1]
+    gm[:, 0:7 * nt:7] = gm[:, 1::7]                               # exact ties
+    gm[5] = float('-inf'); gm[6, : G // 2] = float('-inf')
+    gm = gm.cuda()
+    taus = []
+    for coarse in (0, 2):
+        monkeypatch.setattr(O, 'SELECT_COARSE', coarse)
+        tau = torch.full((HW,), 7.0, device='cuda')
+        ol = O.OpList()
+        ol.aff_select(gm, tau, HW=HW, HWp=HWp, G=G, top_k=top_k)
+        assert (int(ol.finalize()['flags'][0]) & 2) == coarse
+        ol.run()
+        torch.cuda.synchronize()
+        taus.append(tau.cpu())
+    ref = torch.topk(gm[:HW, :G].float().cpu(), top_k, dim=1).values[:, -1] if G >= top_k else torch.full((HW,), float('-inf'))
+    assert torch.equal(taus[0], taus[1])
+    assert torch.equal(taus[0], ref)
