@@ -12,6 +12,7 @@ Stated tolerance (bf16 activation/weight storage, fp32 accumulation, fp32 keys/l
 Full-size (480p) runs are checked through size-independent properties as well.
 """
 import json
+import os
 import numpy as np
 import pytest
 import torch
@@ -49,6 +50,15 @@ def test_native_library_is_loaded(gpu_net):
     assert ctypes.CDLL(_lib.LIB_PATH).cutie_hip_abi_version() == _lib.ABI_VERSION
 
 
+# Ratchet of the stage test: the relative errors OBSERVED on the MI355X on the final tree of round 4
+# (tests/golden/observed_stages_r04.json, written by `CUTIE_RECORD_STAGES=path pytest tests/test_gpu_parity.py -k stages`).  The fixed
+# bounds (3e-2 / 5e-2: bf16 storage, fp32 accumulation, three to forty layers deep) stay; a stage may additionally not exceed 1.5 x what
+# this build did + 1e-3 -- the kernels are deterministic, so a change that doubles a stage's error inside its bound fails here.
+_STAGE_OBS_PATH = os.path.join(S.GOLDEN_DIR, 'observed_stages_r04.json')
+_STAGE_RECORD = os.environ.get('CUTIE_RECORD_STAGES')
+STAGE_OBSERVED = json.load(open(_STAGE_OBS_PATH)) if (os.path.exists(_STAGE_OBS_PATH) and not _STAGE_RECORD) else {}
+
+
 def test_stages_match_oracle_gpu(gpu_net, oracle_net):
     from cutie_amd.utils.synth import SyntheticClip
     net, onet = gpu_net, oracle_net
@@ -56,35 +66,47 @@ def test_stages_match_oracle_gpu(gpu_net, oracle_net):
     g = torch.Generator().manual_seed(11)
     K, h, w = 3, 8, 12
     dev = 'cuda'
+    errs = {}
+
+    def stage(name, a, b, bound, absolute=False):
+        e = float((a.float().cpu() - b.float().cpu()).abs().max()) if absolute else rel_err(a, b)
+        errs[name] = e
+        assert e < bound, (name, e, bound)
+        if name in STAGE_OBSERVED:
+            assert e <= 1.5 * STAGE_OBSERVED[name] + 1e-3, ('ratchet', name, e, STAGE_OBSERVED[name])
+
     with torch.inference_mode():
         img = clip.frame(0).unsqueeze(0)
         ms, pix = net.encode_image(img.to(dev))
         oms, opix = onet.encode_image(img)
         for a, b, n in zip(ms, oms, ['f16', 'f8', 'f4']):
-            assert rel_err(a, b) < 3e-2, (n, rel_err(a, b))
-        assert rel_err(pix, opix) < 3e-2
+            stage(n, a, b, 3e-2)
+        stage('pix', pix, opix, 3e-2)
         key, shr, sel = net.transform_key(ms[0])
         okey, oshr, osel = onet.transform_key(oms[0])
-        assert rel_err(key, okey) < 3e-2 and rel_err(shr, oshr) < 3e-2 and rel_err(sel, osel) < 3e-2
+        stage('key', key, okey, 3e-2); stage('shrinkage', shr, oshr, 3e-2); stage('selection', sel, osel, 3e-2)
         masks = torch.stack([(clip.first_mask() == i + 1).float() for i in range(K)], 0).unsqueeze(0) * 0.9 + 0.05
         sens0 = torch.randn(1, K, 256, h, w, generator=g) * 0.5
         val, nsens, summ, _ = net.encode_mask(img.to(dev), opix.to(dev), sens0.clone().to(dev), masks.to(dev))
         oval, onsens, osumm = onet.encode_mask(img, opix, sens0, masks)
-        assert rel_err(val, oval) < 3e-2 and rel_err(nsens, onsens) < 3e-2 and rel_err(summ, osumm) < 3e-2
+        stage('mask_value', val, oval, 3e-2); stage('mask_sensory', nsens, onsens, 3e-2); stage('summaries', summ, osumm, 3e-2)
         ro = torch.randn(1, K, 256, h, w, generator=g) * 0.5
         fused = net.pixel_fusion(opix.to(dev), ro.to(dev), sens0.clone().to(dev), masks.to(dev))
         ofused = onet.pixel_fusion(opix, ro, sens0, masks)
-        assert rel_err(fused, ofused) < 3e-2
+        stage('pixel_fusion', fused, ofused, 3e-2)
         rq, aux = net.readout_query(ofused.to(dev), osumm.unsqueeze(2).to(dev))
         orq, oaux = onet.readout_query(ofused, osumm.unsqueeze(2), return_aux=True)
         for i in range(4):
-            assert rel_err(aux['logits'][i], oaux[i]) < 5e-2, i
-        assert rel_err(rq, orq) < 5e-2
+            stage(f'aux_logits_{i}', aux['logits'][i], oaux[i], 5e-2)
+        stage('readout_query', rq, orq, 5e-2)
         s2, lg, prob = net.segment([t.to(dev) for t in oms], orq.to(dev), sens0.clone().to(dev), update_sensory=True)
         os2, olg, oprob = onet.segment(oms, orq, sens0, update_sensory=True)
-        assert rel_err(s2, os2) < 3e-2
-        assert float((prob.cpu() - oprob).abs().max()) < 3e-2
-        assert rel_err(lg, olg) < 3e-2
+        stage('segment_sensory', s2, os2, 3e-2)
+        stage('segment_prob_abs', prob, oprob, 3e-2, absolute=True)
+        stage('segment_logits', lg, olg, 3e-2)
+    print('stage errors:', {k: round(v, 5) for k, v in errs.items()})
+    if _STAGE_RECORD:
+        json.dump(errs, open(_STAGE_RECORD, 'w'), indent=1, sort_keys=True)
 
 
 def _mem_sizes(p):
