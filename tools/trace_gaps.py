@@ -1,5 +1,5 @@
 """Look-ahead frame: is the main stream device-bound or waiting (for launches / for the side stream)?  From a rocprofv3 --kernel-trace CSV
-of bench.py: frames are cut at query_init2_kernel (one per frame, main stream); for the frames [f0, f1) the main queue's busy time, its
+of bench.py: frames are cut at the decoder's up4_softmax launch (one per frame, main stream); for the frames [f0, f1) the main queue's busy time, its
 idle gaps by the kernel that FOLLOWS the gap, and the side queue's busy time per frame.
     python tools/trace_gaps.py <kernel_trace.csv> f0 f1 [--dump f]      (--dump f: every launch of frame f on the main queue: gap before, duration)"""
 import csv, sys
@@ -9,12 +9,15 @@ f0, f1 = int(sys.argv[2]), int(sys.argv[3])
 q = defaultdict(list)
 for r in rows:
     q[r['Queue_Id']].append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][:48]))
-main = max(q, key=lambda k: sum('query_init2' in n for _, _, n in q[k]))
+# frame marker: a kernel that runs exactly once per propagated frame on the caller's queue.  (Round 3 used query_init2_kernel; since round 4
+# QUERY_INIT runs only when the object summaries changed, so the decoder's last launch -- up4_softmax -- marks the frames.)
+MARK = 'up4_softmax'
+main = max(q, key=lambda k: sum(MARK in n for _, _, n in q[k]))
 side = [k for k in q if k != main]
 for v in q.values():
     v.sort()
 mq = q[main]
-marks = [s for s, e, n in mq if 'query_init2' in n]
+marks = [s for s, e, n in mq if MARK in n]
 print('queues', {k: len(v) for k, v in q.items()}, 'main', main, 'frames', len(marks))
 t0, t1 = marks[f0], marks[f1]
 nf = f1 - f0
