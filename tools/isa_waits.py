@@ -2,7 +2,8 @@
 (`s_waitcnt vmcnt(0)`) before any other load is issued.  Every such pair in the straight-line part of a kernel (its prologue, or a
 divergent `if (valid) x = p[i]` block) is a full L2 / HBM latency in front of the kernel's first useful instruction; in a frame of
 5-15 us launches that is 5-10 % of a launch each (found with this: aff_score_kernel's c_j / tau_j loads, round 4).
-Usage: hipcc ... --cuda-device-only -S file.hip -o file.s ; python tools/isa_waits.py file.s [kernel-name-substring]"""
+Usage: hipcc ... --cuda-device-only -S file.hip -o file.s ; python tools/isa_waits.py file.s [kernel-name-substring]
+       python tools/isa_waits.py cutie_amd/csrc/affinity.o [kernel-name-substring]      (a built object: disassembled, no recompile)"""
 import re, sys
 
 
@@ -21,6 +22,42 @@ def kernels(path):
             else:
                 body.append(line.rstrip())
     if name:
+        yield name, body
+
+
+LLVM = '/opt/rocm/lib/llvm/bin/'
+
+
+def kernels_of_object(obj):
+    """The same (name, body) pairs from a built object file (cutie_amd/csrc/*.o after `make`): the gfx950 code object is taken out of the
+    fat binary and disassembled (llvm-objdump --symbolize-operands), labels and branch operands rewritten to the `.LBB` form of `hipcc -S`
+    so that scan() / wait_groups() see the same text.  No GPU and no recompile: this is what tests/test_isa_guard_cpu.py runs."""
+    import os, subprocess, tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        fb, co = os.path.join(tmp, 'fb'), os.path.join(tmp, 'co')
+        subprocess.run([LLVM + 'llvm-objcopy', '--dump-section', '.hip_fatbin=' + fb, obj], check=True)
+        subprocess.run([LLVM + 'clang-offload-bundler', '--unbundle', '--type=o', '--targets=hipv4-amdgcn-amd-amdhsa--gfx950',
+                        '--input=' + fb, '--output=' + co], check=True)
+        txt = subprocess.run([LLVM + 'llvm-objdump', '-d', '--symbolize-operands', co], capture_output=True, text=True, check=True).stdout
+    name, body = None, []
+    for line in txt.split('\n'):
+        m = re.match(r'^[0-9a-f]+ <([^>]+)>:', line)
+        if m:
+            lab = m.group(1)
+            if re.fullmatch(r'L\d+', lab):
+                if name is not None:
+                    body.append('.LBB_' + lab[1:] + ':')
+                continue
+            if name is not None:
+                yield name, body
+            name, body = lab, []
+            continue
+        if name is None or not line.startswith('\t'):
+            continue
+        ins = line.split('//')[0].rstrip()
+        ins = re.sub(r'\bL(\d+)\b', r'.LBB_\1', ins) if re.match(r'\s*s_c?branch', ins) else ins
+        body.append(ins)
+    if name is not None:
         yield name, body
 
 
@@ -105,7 +142,7 @@ if __name__ == '__main__':
     path = sys.argv[1]
     sub = sys.argv[2] if len(sys.argv) > 2 else ''
     import subprocess
-    for name, body in kernels(path):
+    for name, body in (kernels_of_object(path) if path.endswith('.o') else kernels(path)):
         if sub and sub not in name:
             continue
         hits = scan(body)
