@@ -83,6 +83,9 @@ struct ScoreParams {
     const bf16_t* Bhi; const bf16_t* Blo; const float* c;
     float* gmax_or_tau; float* cand_val; int* cand_idx; int* count;
     int HW, HWp, nranges, rs[3], rn[3], G, cap, mode, tiles_per_block, Gld;
+#ifdef AFF_TIMELINE
+    unsigned long long* tl;                              // (diagnostic library only: where the cycle stamps go; p10 of the op)
+#endif
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int au32x4;
@@ -116,15 +119,16 @@ typedef __attribute__((ext_vector_type(4))) unsigned int au32x4;
 // blocks 0 and nb / 2, parked in LDS (4 KB behind the maxima of mode 0: no VMEM traffic that would disturb the vmcnt waits) and copied
 // to p.cand_val (unused in mode 0; the tool hands in a buffer) when the wave ends.  Record: [count, stamps (cycles << 8 | id) ...].
 #ifdef AFF_TIMELINE
-#define ATL_MAX 120
+#define ATL_MAX 95                                        // (4 waves x 95 stamps x 8 B = 3040 B: two blocks with it still fit the CU's 160 KB of LDS in pass 1)
 #define ATL_DECL(BASE) unsigned long long* const atl_ = reinterpret_cast<unsigned long long*>(BASE) + wave * ATL_MAX; int atn_ = 0;
 #define ATL(ID) { if (atn_ < ATL_MAX) { const unsigned long long t_ = (__builtin_readcyclecounter() << 8) | (unsigned)(ID); if ((threadIdx.x & 63) == 0) atl_[atn_] = t_; ++atn_; } }
 #define ATL_DUMP(LOGICAL, NB)                                                                              \
     {                                                                                                      \
         const int slot_ = (LOGICAL) == 0 ? 0 : (LOGICAL) == (NB) / 2 ? 1 : -1;                             \
-        if (slot_ >= 0 && p.cand_val) {                                                                    \
+        unsigned long long* const tl_ = p.tl ? p.tl : (mode == 0 ? reinterpret_cast<unsigned long long*>(p.cand_val) : nullptr); \
+        if (slot_ >= 0 && tl_) {                                                                           \
             __builtin_amdgcn_s_waitcnt(0);                                                                 \
-            unsigned long long* o_ = reinterpret_cast<unsigned long long*>(p.cand_val) + ((long)slot_ * 4 + wave) * (ATL_MAX + 1); \
+            unsigned long long* o_ = tl_ + ((long)slot_ * 4 + wave) * (ATL_MAX + 1);                       \
             if ((threadIdx.x & 63) == 0) o_[0] = 0x41540000ull | (unsigned)atn_;                           \
             for (int q_ = threadIdx.x & 63; q_ < atn_; q_ += 64) o_[1 + q_] = atl_[q_];                    \
         }                                                                                                  \
@@ -158,7 +162,8 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
         by = logical / (int)gridDim.x;
         bx = logical - by * (int)gridDim.x;
     }
-    ATL_DECL(aff_smem + 2 * 2 * 64 * 16 * 16 + 4096)       // (timeline builds, mode 0 only: the candidate-list area is unused there)
+    // (timeline builds: mode 0 parks the stamps in the unused candidate-list area, mode 1 in 3040 B the launch adds behind the regular LDS)
+    ATL_DECL(mode == 0 ? aff_smem + 2 * 2 * 64 * 16 * 16 + 4096 : aff_smem + AFF_LDS_BYTES)
     ATL(0)
     int* wl_j = l_j + wave * AFF_WCAP; int* wl_idx = l_idx + wave * AFF_WCAP; float* wl_val = l_val + wave * AFF_WCAP;
     int wcount = 0;                                                     // wave-uniform fill of the wave's list
@@ -389,6 +394,12 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
             const int pos = atomicAdd(&p.count[j * AFF_CSTRIDE], 1);
             if (pos < p.cap) { p.cand_val[(long)j * p.cap + pos] = wl_val[e]; p.cand_idx[(long)j * p.cap + pos] = wl_idx[e]; }
         }
+#ifdef AFF_TIMELINE
+        __builtin_amdgcn_s_waitcnt(0);                                  // (the stamp behind the flush counts the atomics' round trips)
+        ATL(12)
+        ATL(13 + (min(wcount, 240) >> 4 << 4))                          // (id 13 + 16 * (candidates of this wave / 16): how long was its list)
+        ATL_DUMP(logical, nb)
+#endif
     }
 }
 
@@ -950,14 +961,20 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             sp.tiles_per_block = tpb;
             const dim3 grid(qb, (G + tpb - 1) / tpb);
             const int lds4 = AFF_LDS_BYTES + (i[14] > 0 && i[14] <= 80 ? i[14] * 1024 : 0);       // (diagnostic: extra dynamic LDS = fewer resident blocks per CU)
+#ifdef AFF_TIMELINE
+            sp.tl = (unsigned long long*)p[10];
+            const int lds2 = AFF_LDS_BYTES + (pass == 1 ? 4 * ATL_MAX * 8 : 0);      // (pass 1 parks its stamps behind the regular LDS: 3040 B, still two blocks per CU)
+#else
+            const int lds2 = AFF_LDS_BYTES;
+#endif
             if (nq == 4 && pass == 0) hipLaunchKernelGGL((aff_score4_kernel<4, 0>), grid, dim3(256), lds4, s, sp);
             else if (nq == 4) hipLaunchKernelGGL((aff_score4_kernel<4, 1>), grid, dim3(256), lds4, s, sp);
             else if (dma && nq == 2 && pass == 0) hipLaunchKernelGGL((aff_score4_kernel<2, 0>), grid, dim3(256), lds4, s, sp);
             else if (dma && nq == 2) hipLaunchKernelGGL((aff_score4_kernel<2, 1>), grid, dim3(256), lds4, s, sp);
-            else if (nq == 1 && pass == 0) hipLaunchKernelGGL((aff_score_kernel<1, 0>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
-            else if (nq == 1) hipLaunchKernelGGL((aff_score_kernel<1, 1>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
-            else if (pass == 0) hipLaunchKernelGGL((aff_score_kernel<2, 0>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
-            else hipLaunchKernelGGL((aff_score_kernel<2, 1>), grid, dim3(256), AFF_LDS_BYTES, s, sp);
+            else if (nq == 1 && pass == 0) hipLaunchKernelGGL((aff_score_kernel<1, 0>), grid, dim3(256), lds2, s, sp);
+            else if (nq == 1) hipLaunchKernelGGL((aff_score_kernel<1, 1>), grid, dim3(256), lds2, s, sp);
+            else if (pass == 0) hipLaunchKernelGGL((aff_score_kernel<2, 0>), grid, dim3(256), lds2, s, sp);
+            else hipLaunchKernelGGL((aff_score_kernel<2, 1>), grid, dim3(256), lds2, s, sp);
             break;
         }
         case CUTIE_OP_AFF_SELECT: {
