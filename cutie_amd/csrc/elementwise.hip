@@ -103,70 +103,6 @@ __global__ void upsample2x_add_kernel(const uint4* __restrict__ g, const uint4* 
     y[idx] = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
-// The same, one thread per SOURCE pixel and channel octet: the 2 x 2 output quad of source pixel (i, j) needs the 3 x 3 (clamped)
-// neighbourhood -- 9 + 4 loads for 4 output vectors instead of 5 per output, all in flight together, and a quarter of the threads
-// (the one-output form is latency-bound: 20 MB written in ~10 us, 19 waves per SIMD in 2-3 rounds of five dependent-free loads each).
-// Tap indices and weights come from the same up_coord() calls and the sum has the same order: bit-identical (also the sign of a zero).
-__device__ __forceinline__ uint4 sel3_u4(int k, const uint4& a, const uint4& b, const uint4& c) {
-    return k == 0 ? a : (k == 1 ? b : c);
-}
-__global__ __launch_bounds__(256) void upsample2x_add_quad_kernel(const uint4* __restrict__ g, const uint4* __restrict__ skip, uint4* __restrict__ y,
-                                           int B, int h, int w, int C8) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)B * h * w * C8) return;
-    const int c = idx % C8; long t = idx / C8;
-    const int j = t % w; t /= w; const int i = t % h; const int b = t / h;
-    const int OH = 2 * h, OW = 2 * w;
-    const int rows[3] = {max(i - 1, 0), i, min(i + 1, h - 1)}, cols[3] = {max(j - 1, 0), j, min(j + 1, w - 1)};
-    const uint4* gb = g + (long)b * h * w * C8;
-    uint4 v[3][3], sk[2][2];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) v[r][q] = gb[((long)rows[r] * w + cols[q]) * C8 + c];
-#pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) sk[dy][dx] = skip[((long)(2 * i + dy) * OW + 2 * j + dx) * C8 + c];
-    // (pin all 13 loads in front of the arithmetic: hipcc otherwise sinks the second row's skip loads behind the first stores -- a
-    // second round trip in the middle of the thread)
-#pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) asm volatile("" : "+v"(sk[dy][dx].x), "+v"(sk[dy][dx].y), "+v"(sk[dy][dx].z), "+v"(sk[dy][dx].w));
-#pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
-        int y0, y1; float ly;
-        up_coord(2 * i + dy, h, 0.5f, y0, y1, ly);
-        // (y0, y1 lie in rows[]; equal rows hold equal data, so any matching slot is the right one)
-        const int r0 = y0 == rows[1] ? 1 : (y0 < rows[1] ? 0 : 2), r1 = y1 == rows[1] ? 1 : (y1 < rows[1] ? 0 : 2);
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            int x0, x1; float lx;
-            up_coord(2 * j + dx, w, 0.5f, x0, x1, lx);
-            const int q0 = x0 == cols[1] ? 1 : (x0 < cols[1] ? 0 : 2), q1 = x1 == cols[1] ? 1 : (x1 < cols[1] ? 0 : 2);
-            const uint4 ra0 = sel3_u4(r0, v[0][0], v[1][0], v[2][0]), ra1 = sel3_u4(r0, v[0][1], v[1][1], v[2][1]), ra2 = sel3_u4(r0, v[0][2], v[1][2], v[2][2]);
-            const uint4 rb0 = sel3_u4(r1, v[0][0], v[1][0], v[2][0]), rb1 = sel3_u4(r1, v[0][1], v[1][1], v[2][1]), rb2 = sel3_u4(r1, v[0][2], v[1][2], v[2][2]);
-            const uint4 v00 = sel3_u4(q0, ra0, ra1, ra2), v01 = sel3_u4(q1, ra0, ra1, ra2);
-            const uint4 v10 = sel3_u4(q0, rb0, rb1, rb2), v11 = sel3_u4(q1, rb0, rb1, rb2);
-            const uint32_t* a = &v00.x; const uint32_t* bq = &v01.x; const uint32_t* cq = &v10.x; const uint32_t* d = &v11.x;
-            const uint32_t* s = &sk[dy][dx].x;
-            const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
-            uint32_t out[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float lo = w00 * __uint_as_float(a[e] << 16) + w01 * __uint_as_float(bq[e] << 16) +
-                           w10 * __uint_as_float(cq[e] << 16) + w11 * __uint_as_float(d[e] << 16) + __uint_as_float(s[e] << 16);
-                float hi = w00 * __uint_as_float(a[e] & 0xffff0000u) + w01 * __uint_as_float(bq[e] & 0xffff0000u) +
-                           w10 * __uint_as_float(cq[e] & 0xffff0000u) + w11 * __uint_as_float(d[e] & 0xffff0000u) +
-                           __uint_as_float(s[e] & 0xffff0000u);
-                out[e] = pack_bf2(lo, hi);
-            }
-            y[(((long)b * OH + 2 * i + dy) * OW + 2 * j + dx) * C8 + c] = make_uint4(out[0], out[1], out[2], out[3]);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // R > 0: the pooling ratio as a compile-time constant (2, 4): the R x R loads are issued together and summed in the same (dy, dx) order.
 // With a run-time r the compiler keeps `load; s_waitcnt vmcnt(0); add` per tap -- r * r dependent round trips per thread
@@ -1243,10 +1179,7 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
         case CUTIE_OP_UPSAMPLE2X_ADD: {
             int C8 = i[3] / 8;
             long n = (long)i[0] * 4 * i[1] * i[2] * C8;
-            if (op->flags & 1)                                  // flags&1: one thread per source pixel writes its 2 x 2 output quad (same bits)
-                hipLaunchKernelGGL(upsample2x_add_quad_kernel, GRID1D(n / 4, BS), dim3(BS), 0, s, (const uint4*)p[0], (const uint4*)p[1], (uint4*)p[2], i[0], i[1], i[2], C8);
-            else
-                hipLaunchKernelGGL(upsample2x_add_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const uint4*)p[0], (const uint4*)p[1], (uint4*)p[2], i[0], i[1], i[2], C8);
+            hipLaunchKernelGGL(upsample2x_add_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const uint4*)p[0], (const uint4*)p[1], (uint4*)p[2], i[0], i[1], i[2], C8);
             break;
         }
         case CUTIE_OP_AREA_DOWN: {

@@ -39,7 +39,6 @@ GRU_SCALAR = 1 if os.environ.get('CUTIE_AMD_GRU4', '1') in ('', '0') else 0     
 KEYPREP_LOOP = 2 if os.environ.get('CUTIE_AMD_KEYPREP_LOOP', '0') not in ('', '0') else 0   # KEY_PREP flags&2: c_j by one lane per row (A/B switch)
 UP4_LANES = 16 if os.environ.get('CUTIE_AMD_UP4_SHARED', '1') in ('', '0') else 0     # UP4_SOFTMAX flags&16 (mask-down form): every lane aggregates its own six source pixels (A/B switch)
 SELECT_COARSE = 2 if os.environ.get('CUTIE_AMD_SELECT_FINE', '1') in ('', '0') else 0    # AFF_SELECT flags&2: 16 | 32 | 64 values per lane only (A/B switch)
-UP2_QUAD = 1 if os.environ.get('CUTIE_AMD_UP2_QUAD', '0') not in ('', '0') else 0      # UPSAMPLE2X_ADD flags&1: one thread per source pixel (2 x 2 output quad); UNMEASURED, default off
 UP4_RTK = 8 if os.environ.get('CUTIE_AMD_UP4_KC', '1') in ('', '0') else 0           # UP4_SOFTMAX flags&8: kernels with a run-time object count (A/B switch)
 
 # conv tile table (mirrors the switch in csrc/conv_igemm.hip): id -> (BM, BN, BK)
@@ -372,7 +371,7 @@ class OpList:
         return self.add(IMG_PREP, 0, [h0, w0, H, W, pad_left, pad_top, K], list(mean) + list(std), [image, masks, y])
 
     def upsample2x_add(self, g, skip, y, *, B, h, w, C):
-        return self.add(UPSAMPLE2X_ADD, UP2_QUAD, [B, h, w, C], [], [g, skip, y])
+        return self.add(UPSAMPLE2X_ADD, 0, [B, h, w, C], [], [g, skip, y])
 
     def area_down(self, x, y, *, B, H, W, C, ldx, ldy, r, f32_in=False, Cz=None):
         return self.add(AREA_DOWN, 1 if f32_in else 0, [B, H, W, C, ldx, ldy, r, C if Cz is None else Cz], [], [x, y])

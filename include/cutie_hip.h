@@ -80,8 +80,7 @@ enum {
     CUTIE_OP_IMG_PREP = 3,
     /* UPSAMPLE2X_ADD: y = bilinear_x2(g, align_corners=False) + skip (broadcast over objects)
      * group_modules.py:19-23 + MainToGroupDistributor('add') modules.py:15-18
-     * p0=g bf16 [B,h,w,C] p1=skip bf16 [1,2h,2w,C] p2=y bf16 [B,2h,2w,C]   i: 0 B 1 h 2 w 3 C
-     * flags&1: one thread per SOURCE pixel and channel octet writes its 2 x 2 output quad (13 loads for 4 output vectors; same bits) */
+     * p0=g bf16 [B,h,w,C] p1=skip bf16 [1,2h,2w,C] p2=y bf16 [B,2h,2w,C]   i: 0 B 1 h 2 w 3 C */
     CUTIE_OP_UPSAMPLE2X_ADD = 4,
     /* AREA_DOWN: r x r mean (F.interpolate mode='area', integer ratio) on NHWC bf16|f32 input
      * group_modules.py:26-30 (modules.py:59-60)

@@ -1419,25 +1419,3 @@ def test_aff_select_values_per_lane_follow_the_tile_count(G, monkeypatch):
     ref = torch.topk(gm[:HW, :G].float().cpu(), top_k, dim=1).values[:, -1] if G >= top_k else torch.full((HW,), float('-inf'))
     assert torch.equal(taus[0], taus[1])
     assert torch.equal(taus[0], ref)
-
-
-@pytest.mark.parametrize('B,h,w,C', [(1, 1, 1, 8), (1, 1, 5, 64), (2, 7, 1, 128), (3, 30, 54, 512), (3, 60, 108, 128), (1, 2, 3, 16)])
-def test_upsample2x_add_quad_form(B, h, w, C, monkeypatch):
-    """UPSAMPLE2X_ADD, one thread per source pixel (flags&1) against one thread per output pixel: same taps, weights and summation
-    order -- identical bits, including the clamped borders and one-row / one-column maps."""
-    g = torch.Generator().manual_seed(B * 1000 + h * 10 + w)
-    src = rnd(g, (B, h, w, C), dev='cuda')
-    src[..., 0] = 0.0                                        # zeros (and their signs) on the taps
-    skip = rnd(g, (1, 2 * h, 2 * w, C), dev='cuda')
-    skip[..., 1] = -0.0
-    outs = []
-    for quad in (0, 1):
-        monkeypatch.setattr(O, 'UP2_QUAD', quad)
-        y = torch.full((B, 2 * h, 2 * w, C), 7.0, dtype=BF16, device='cuda')
-        ol = O.OpList()
-        ol.upsample2x_add(src, skip, y, B=B, h=h, w=w, C=C)
-        assert int(ol.finalize()['flags'][0]) == quad
-        ol.run()
-        torch.cuda.synchronize()
-        outs.append(y.view(torch.int16).clone())
-    assert torch.equal(outs[0], outs[1])
