@@ -315,37 +315,61 @@ def main():
             torch.cuda.synchronize()
             allops = np.concatenate(rec.rec)
             convs = allops[allops['kind'] == O.CONV]
-            # the affinity plan = [score/0, select (+ counter clear, usage ticks), score/1, readout]
+            # the affinity plan = [score/0, select (+ counter clear, usage ticks), score/1, readout]; since round 5 one plan serves every
+            # announced frame up to the next memory frame (one read-out per bank version): frames of a plan = stacked rows / rows per frame
             aff_arrs = [a[a['kind'] != O.USAGE_TICK] for a in rec.rec if (a['kind'] == O.AFF_SCORE).any()]
             affs_all = np.concatenate(aff_arrs)
-            affs = aff_arrs[-1]
+
+            def plan_frames(a):
+                ii = a[a['kind'] == O.AFF_SCORE]['i'][0]
+                return int(ii[1]) // int(ii[16]) if int(ii[16]) > 0 else 1
+
+            def plan_tokens(a):
+                ii = a[a['kind'] == O.AFF_SCORE]['i'][0]
+                return sum(int(ii[4 + 2 * r]) for r in range(int(ii[2])))
             conv_t += rec.ex.time_ops(convs, 3) * 1e-3
             conv_f += conv_flops(convs)
             aff_t += rec.ex.time_ops(affs_all, 3) * 1e-3
             HW = (proc.memory.H * proc.memory.W)
-            for b in proc.memory.buckets.values():
-                aff_f += (256 + 512 * len(b.objects)) * float(b.size()) * HW * len(aff_arrs) / max(1, len(proc.memory.buckets))
+            kb = {len(b.objects) for b in proc.memory.buckets.values()}
+            assert len(proc.memory.buckets) == 1 and len(kb) == 1, 'the bench clip has one bucket'
+            frames_read = sum(plan_frames(a) for a in aff_arrs)
+            for a in aff_arrs:                             # the reference's dense flops of every frame a plan reads, at that plan's bank size
+                aff_f += (256 + 512 * K) * float(plan_tokens(a)) * HW * plan_frames(a)
             n_conv = round(int((allops['kind'] == O.CONV).sum()) / nrec, 1)
-            # the affinity matmul on its own (score pass 0 = the S = A.B^T tiles + tile maxima; valid in isolation), and the
-            # other stages by prefix differences of the plan [score/0, select (+ counter clear, usage ticks), score/1, readout]
-            # (round-1 form, $CUTIE_AMD_UNFUSED: a memset in front)
+            # the affinity matmul on its own (score pass 0 = the S = A.B^T tiles + tile maxima; valid in isolation): ALL pass-0 launches of
+            # the recorded frames replayed back to back (mfma_util = their issued split-bf16 flops / their time), and the stages of the
+            # most common plan by prefix differences of [score/0, select (+ counter clear, usage ticks), score/1, readout]
             aff_parts = None
-            s0 = next((k for k in range(len(affs)) if int(affs['kind'][k]) == O.AFF_SCORE), None)
-            if s0 is not None and len(affs) - s0 >= 4:
-                sc = affs[s0:s0 + 1]
-                t_mm = min(rec.ex.time_ops(sc, 10) for _ in range(3)) * 1e-3
-                ii = sc['i'][0]
-                n_tok, hw = sum(int(ii[4 + 2 * r]) for r in range(int(ii[2]))), int(ii[0])
-                issued = 3 * 2.0 * 128 * (int(ii[9]) * 16) * int(ii[1])      # 3 split-bf16 terms, padded tiles
+            pass0 = np.concatenate([a[(a['kind'] == O.AFF_SCORE) & (a['i'][:, 11] == 0)] for a in aff_arrs])
+            if len(pass0):
+                issued = sum(3 * 2.0 * 128 * (int(r['i'][9]) * 16) * int(r['i'][1]) for r in pass0)     # 3 split-bf16 terms, padded tiles x stacked rows
+                dense32 = sum(2.0 * 128 * sum(int(r['i'][4 + 2 * q]) for q in range(int(r['i'][2]))) * int(r['i'][0]) *
+                              (int(r['i'][1]) // int(r['i'][16]) if int(r['i'][16]) > 0 else 1) for r in pass0)
+                t_mm = min(rec.ex.time_ops(pass0, 5) for _ in range(3)) * 1e-3
+                by_f = {}
+                for a in aff_arrs:
+                    by_f.setdefault(plan_frames(a), []).append(a)
+                common_f = max(by_f, key=lambda f_: len(by_f[f_]) * f_)
+                affs = by_f[common_f][-1]
+                s0 = next(k for k in range(len(affs)) if int(affs['kind'][k]) == O.AFF_SCORE)
                 pre = [0.0] * (1 - s0) + [min(rec.ex.time_ops(affs[:k], 10) for _ in range(3)) * 1e3 for k in range(1, s0 + 5)]
+                ii = affs[s0]['i']
                 aff_parts = {'kernel': 'aff_score_kernel mode 0 (S = A.B^T on v_mfma_f32_16x16x32_bf16, 3 split terms)',
-                             'us': round(t_mm * 1e6, 2), 'tokens': n_tok, 'queries': hw,
+                             'launches': int(len(pass0)), 'frames_read': frames_read, 'recorded_frames': nrec,
+                             'frames_per_launch': {str(f_): len(v) for f_, v in sorted(by_f.items())},
+                             'us': round(t_mm * 1e6 / len(pass0), 2), 'us_per_frame': round(t_mm * 1e6 / frames_read, 2),
                              'mfma_issued_tflops': round(issued / t_mm / 1e12, 1),
                              'mfma_util': round(issued / t_mm / 1e12 / PEAK_BF16_TFLOPS, 4),
-                             'fp32_equivalent_tflops': round(2.0 * 128 * n_tok * hw / t_mm / 1e12, 1),
+                             'mfma_util_note': 'issued split-bf16 MFMA flops of ALL score-pass launches of the recorded frames / their device time '
+                                               '(back-to-back replay, hipEvents) / 2.5 PFLOP/s',
+                             'fp32_equivalent_tflops': round(dense32 / t_mm / 1e12, 1),
+                             'stage_plan': {'frames': common_f, 'tokens': plan_tokens(affs), 'queries': int(ii[0]) * common_f},
                              'stage_us': {'memset': round(pre[0], 1), 'score0': round(pre[1] - pre[0], 1),
                                           'select': round(pre[2] - pre[1], 1), 'score1': round(pre[3] - pre[2], 1),
-                                          'readout': round(pre[4] - pre[3], 1)}}
+                                          'readout': round(pre[4] - pre[3], 1)},
+                             'stage_us_per_frame': {'score0': round((pre[1] - pre[0]) / common_f, 1), 'select': round((pre[2] - pre[1]) / common_f, 1),
+                                                    'score1': round((pre[3] - pre[2]) / common_f, 1), 'readout': round((pre[4] - pre[3]) / common_f, 1)}}
             # device-time breakdown of the last recorded frame by op kind (back-to-back replays, hipEvents), and the
             # whole frame replayed as ONE HIP graph (no host involvement): shows how much of the step is launch gaps
             names = O.KIND_NAMES
@@ -360,14 +384,24 @@ def main():
                     print('replay kind', kind, names.get(kind), len(sel), file=sys.stderr, flush=True)
                 breakdown[names.get(kind, str(kind))] = [round(len(sel) / nrec, 2), round(rec.ex.time_ops(sel, 3) * 1e3 / nrec, 1)]
             lib = rec.ex.lib
-            # one frame without hints (all of its launches in one list) as ONE HIP graph
-            proc.step(frames[t_idx % 128])                  # (consumes the pending look-ahead; the next frame runs its own encoder)
+            # one frame without hints (all of its launches in one list, its own image encoder included) as ONE HIP graph: un-hinted
+            # steps first until nothing encoded ahead by the hinted frames above is left (round 4 recorded a frame that found its encoder
+            # output in the look-ahead window: 0.733 ms for a graph without an encoder)
+            for _ in range(2 if args.window <= 1 or args.no_lookahead else args.window + IC.WINDOW_LEAD + 2):
+                proc.step(frames[t_idx % 128])
+                t_idx += 1
+            assert not getattr(proc, '_window', None) and proc._prefetched is None, 'the graph frame must run its own encoder'
+            while (proc.curr_ti + 1 - proc.last_mem_ti) >= proc.mem_every:     # record a plain (non-memory) frame
+                proc.step(frames[t_idx % 128])
+                t_idx += 1
             rec.rec, rec.on = [], True
-            proc.step(frames[(t_idx + 1) % 128])
-            t_idx += 2
+            proc.step(frames[t_idx % 128])
+            t_idx += 1
             rec.on = False
             torch.cuda.synchronize()
             oneframe = np.concatenate(rec.rec)
+            assert int((oneframe['kind'] == O.STEM).sum()) >= 1, 'the graph frame has no image encoder'
+            graph_launches = int(len(oneframe))
             g = None if args.no_graph else lib.cutie_graph_capture(oneframe.ctypes.data, len(oneframe), rec.ex.stream())
             graph_ms = None
             if g:
@@ -395,9 +429,19 @@ def main():
                                         for v in fam) / nd * 1e6) if nd else None
             except Exception:
                 traffic = None
+            # algorithmic flops per frame: SURVEY.md section 8(d) (60.2 G shared + 56.1 G x K per frame + 44.7 G x K per memory frame, at
+            # 414 720 padded pixels); the executed count is ~5 % higher (the composed [pixel | x] projections of the transformer blocks,
+            # K = 512) -- `frac` is priced with the ALGORITHMIC flops
+            px = (-(-args.height // 16) * 16) * (-(-args.width // 16) * 16) / 414720.0
+            alg_f = (60.2 + 56.1 * K + 44.7 * K / cfg.mem_every) * px * 1e9
+            ms_conv = conv_t / nrec * 1e3
             roof = {'bound': 'mfma', 'kernel': 'conv_pc_kernel<*> + conv_dma_kernel<*> + conv_igemm_kernel<*> + conv_cout1 (all conv launches of a frame)',
-                    'achieved': round(conv_f / conv_t / 1e12, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(conv_f / conv_t / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+                    'achieved': round(alg_f / (conv_t / nrec) / 1e12, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(alg_f / (conv_t / nrec) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                    'algorithmic_gflop_per_frame': round(alg_f / 1e9, 1),
+                    'executed_frac': round(conv_f / conv_t / 1e12 / PEAK_BF16_TFLOPS, 4),
+                    'hbm_frac': None if traffic is None else round(traffic * n_conv / (conv_t / nrec) / 1e9 / PEAK_HBM_GBS, 4),
+                    'traffic': traffic,
                     'traffic_unit': 'HBM bytes per conv launch (rocprofv3 PMC passes of tools/profile_round.sh, measured on the tree named in traffic_source)',
                     'traffic_source': traffic_src,
                     'gflop_per_frame': round(conv_f / nrec / 1e9, 1), 'ms_per_frame': round(conv_t / nrec * 1e3, 3),
@@ -406,6 +450,7 @@ def main():
                         'achieved': round(aff_f / aff_t / 1e12, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': round(aff_f / aff_t / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': None,
                         'algorithmic_gflop_per_frame': round(aff_f / nrec / 1e9, 1), 'ms_per_frame': round(aff_t / nrec * 1e3, 4),
+                        'launches_per_frame': round(len(affs_all) / nrec, 2), 'frames_read_per_recorded_frame': round(frames_read / nrec, 2),
                         'memory_tokens': n_tok_end, 'matmul': aff_parts,
                         'note': 'algorithmic = dense (256+512K)*N*HW of the reference; the kernels do the top-k readout sparsely'}
 
@@ -499,7 +544,10 @@ def main():
             out['plans_eager_vs_graph_replay'] = list(gs)      # whole run (pre-roll included): plans issued launch by launch | as one HIP graph
         rv = sorted(rep_vals)
         out['repeats'] = {'values': rep_vals, 'median': rv[len(rv) // 2], 'min': rv[0], 'max': rv[-1],
-                          'note': f'{len(rep_vals)} consecutive timed regions of {args.steps} steps on this box; "value" is the first'}
+                          'mean_fps_all_regions': round(len(rep_vals) / sum(1.0 / v for v in rep_vals), 2),
+                          'note': f'{len(rep_vals)} consecutive timed regions of {args.steps} steps on this box; "value" is the first (the protocol-conform '
+                                  f'one).  A region of {args.steps} frames holds 1-2 batched encoder plans of {args.window} frames each, so single regions '
+                                  'scatter with the phase of the batches; mean_fps_all_regions = all frames / all time'}
         if no_la is not None:
             out['value_no_lookahead'] = no_la['value']
             out['no_lookahead'] = dict(no_la, note='same clip, step(image) without the next_image hint (an unchanged scripting_demo.py)')
@@ -510,6 +558,7 @@ def main():
             out['roofline_affinity'] = roof_aff
             out['device_us_by_kind'] = breakdown
             out['frame_as_one_hip_graph_ms'] = None if graph_ms is None else round(graph_ms, 3)
+            out['frame_as_one_hip_graph_launches'] = graph_launches
         if multi is not None:
             out['multi_clip'] = multi
         if cpu is not None:

@@ -83,6 +83,7 @@ struct ScoreParams {
     const bf16_t* Bhi; const bf16_t* Blo; const float* c;
     float* gmax_or_tau; float* cand_val; int* cand_idx; int* count;
     int HW, HWp, nranges, rs[3], rn[3], G, cap, mode, tiles_per_block, Gld;
+    int HWpf;                                            // query rows per frame (HWp = frames x HWpf; row j is a real query iff j % HWpf < HW)
 #ifdef AFF_TIMELINE
     unsigned long long* tl;                              // (diagnostic library only: where the cycle stamps go; p10 of the op)
 #endif
@@ -93,7 +94,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned int au32x4;
 // grid (ceil(HWp/128), ceil(G/tiles_per_block)); wave w of the block owns queries j0 + 32w .. +31 (two MFMA column sets).
 // The memory operands of 4 consecutive 16-token tiles (64 rows x [hi|lo] x 256 B = 32 KB) are staged ONCE per block in
 // LDS (double-buffered, register prefetch of the next group) and shared by the 4 waves; rows are XOR-swizzled by
-// (row & 15) so the ds_read_b128 fragment reads are conflict-free.  The B fragments of the wave's 32 queries stay in
+// (row & 15) so the ds_read_b128 fragment reads are conflict-free (each of the instruction's four 16-lane groups covers the 16 slots of
+// the 256-B bank row once; the conflicts the PMC counted in rounds 3-4 were the staging STORES, see `sr8` below).  The B fragments of the wave's 32 queries stay in
 // registers, so one set of 8 A-fragment reads feeds 24 MFMAs (with 16 queries per wave the loop was LDS-bound).
 // mode 1 appends through wave-private LDS lists (ballot + mbcnt positions, no atomics in the loop; one dense burst of
 // global atomics per wave at the end).
@@ -181,16 +183,23 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
 #pragma unroll
     for (int u = 0; u < AFF_NQ; ++u) {
         jq[u] = bx * (64 * AFF_NQ) + wave * (16 * AFF_NQ) + u * 16 + l15;
-        jvalid[u] = jq[u] < p.HW;
-        const int jc = min(jq[u], p.HW - 1);
+        // several frames' queries in one launch (one read-out per BANK VERSION, memory_manager.py `prefetch_affinity_batch`): the operand
+        // rows of frame f are [f * HWpf, f * HWpf + HW), the rest of each frame's HWpf rows is zero padding
+        jvalid[u] = jq[u] < p.HWp && jq[u] % p.HWpf < p.HW;
+        const int jc = jvalid[u] ? jq[u] : 0;
         craw[u] = p.c[jc];
         traw[u] = mode == 1 ? tau_p[jc] : 0.f;
     }
     const int g0 = by * p.tiles_per_block;
     const int g1 = min(g0 + p.tiles_per_block, p.G);
     const int T0 = (p.rn[0] + 15) >> 4, T1 = (p.nranges > 1) ? ((p.rn[1] + 15) >> 4) : 0;
-    // staging: wave w stages tile w of the group; thread = (row r, quarter qd of the 256-B row): 4 + 4 chunks of 16 B
-    const int sr = (lane >> 2), qd = lane & 3;
+    // staging: wave w stages tile w of the group.  Eight consecutive lanes take eight consecutive 16-B chunks of ONE row (a whole 128-B
+    // line per lane octet in the global load, and -- ds_write_b128 is served in groups of 8 contiguous lanes on 32 banks -- eight
+    // distinct 16-B slots of the swizzled LDS row per group: (c ^ row) & 7 runs through 0..7).  Rounds 1-4 gave a lane four
+    // consecutive chunks of a row (lane = row * 4 + quarter): each store group hit every slot twice, the 2-way conflict the PMC showed
+    // as SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.23 (profiles/r04_summary.json), and every load instruction touched 32 lines for
+    // a quarter of their bytes.  Same LDS image, same reads, same bits.
+    const int sr8 = lane >> 3, c8l = lane & 7;
     au32x4 st[8];
     float st_sc = 0.f, st_pad = 0.f;
     f32x4 gq[AFF_NQ];                                                   // pass-0 maxima of the NEXT group's 4 tiles (mode 1 + skip)
@@ -211,16 +220,17 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
         gt_ = gt_ < g1 ? gt_ : g1 - 1;                         /* clamp: rows of missing tiles are never used */ \
         int slot0_, nv_;                                                                                   \
         tile_slot(gt_, slot0_, nv_);                                                                       \
-        const bool rv_ = sr < nv_;                                                                         \
-        const long off_ = (long)(slot0_ + (rv_ ? sr : nv_ - 1)) * 128 + qd * 32;                           \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
-            st[e] = *reinterpret_cast<const au32x4*>(p.Ahi + off_ + e * 8);                                \
-            st[4 + e] = *reinterpret_cast<const au32x4*>(p.Alo + off_ + e * 8);                            \
+            const int row_ = sr8 + 8 * (e & 1);                                                            \
+            const long off_ = (long)(slot0_ + min(row_, nv_ - 1)) * 128 + (c8l + 8 * (e >> 1)) * 8;        \
+            st[e] = *reinterpret_cast<const au32x4*>(p.Ahi + off_);                                        \
+            st[4 + e] = *reinterpret_cast<const au32x4*>(p.Alo + off_);                                    \
         }                                                                                                  \
         /* the per-token scale rides along: a global load inside the MFMA loop would make every tile wait for this whole */ \
-        /* prefetch (vmcnt is in-order) */                                                                 \
-        st_sc = rv_ ? p.scale[slot0_ + (rv_ ? sr : 0)] : 0.f;                                              \
-        st_pad = rv_ ? 0.f : -INFINITY;                                                                    \
+        /* prefetch (vmcnt is in-order); unconditional load of a clamped row, selected afterwards */       \
+        const float sc_ = p.scale[slot0_ + min(l15, nv_ - 1)];                                             \
+        st_sc = l15 < nv_ ? sc_ : 0.f;                                                                     \
+        st_pad = l15 < nv_ ? 0.f : -INFINITY;                                                              \
         if (skip) {                                                                                        \
             _Pragma("unroll") for (int u = 0; u < AFF_NQ; ++u)                                             \
                 gq[u] = *reinterpret_cast<const f32x4*>(gmax_p + (long)min(jq[u], p.HWp - 1) * p.Gld + (GRP)); \
@@ -228,12 +238,13 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
     }
 #define AFF_STORE(BUF)                                                                                     \
     {                                                                                                      \
-        const int row_ = wave * 16 + sr;                                                                   \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
-            lds[BUF][row_ * 16 + ((qd * 4 + e) ^ sr)] = st[e];                                             \
-            lds[BUF][1024 + row_ * 16 + ((qd * 4 + e) ^ sr)] = st[4 + e];                                  \
+            const int r16_ = sr8 + 8 * (e & 1), row_ = wave * 16 + r16_;                                   \
+            const int ch_ = (c8l + 8 * (e >> 1)) ^ r16_;                                                   \
+            lds[BUF][row_ * 16 + ch_] = st[e];                                                             \
+            lds[BUF][1024 + row_ * 16 + ch_] = st[4 + e];                                                  \
         }                                                                                                  \
-        if (qd == 0) { lsc[BUF][row_] = st_sc; lpad[BUF][row_] = st_pad; }                                 \
+        if (l4 == 0) { lsc[BUF][wave * 16 + l15] = st_sc; lpad[BUF][wave * 16 + l15] = st_pad; }           \
     }
     f32x4 gcur[AFF_NQ];
     // Prologue order (round 4): the first memory group's loads are in flight BEFORE the query operand is pulled through LDS, so the
@@ -472,7 +483,7 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
     int jq[NQ];
     bool jvalid[NQ];
 #pragma unroll
-    for (int u = 0; u < NQ; ++u) { jq[u] = wq0 + u * 16 + l15; jvalid[u] = jq[u] < p.HW; }
+    for (int u = 0; u < NQ; ++u) { jq[u] = wq0 + u * 16 + l15; jvalid[u] = jq[u] < p.HWp && jq[u] % p.HWpf < p.HW; }
     // wave w stages tile w of a group: 4 + 4 DMA pieces of 4 rows x 256 B; lane -> (row pc * 4 + (lane >> 4), chunk position lane & 15),
     // which holds source chunk (lane & 15) ^ row (the fragment reads apply the same XOR)
 // s_waitcnt vmcnt(0) lgkmcnt(0) + raw s_barrier.  Explicit: hipcc does not count an LDS-DMA as something a __syncthreads() has to
@@ -523,7 +534,7 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
             ncj[u] = jvalid[u] ? -cj : 0.f;
             thr[u] = INFINITY;
             if (mode == 1) {
-                const float tau = tau_p[min(jq[u], p.HW - 1)];
+                const float tau = tau_p[min(jq[u], p.HWp - 1)];
                 thr[u] = jvalid[u] ? tau - fabsf(tau) * 1e-6f - 1e-30f : INFINITY;     // never lose the k-th element to 1 ulp
             }
         }
@@ -672,10 +683,11 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 // G > 4096, needed 11 us for 1620 columns of 667 values; this one ~3 us).
 // Side jobs riding on AFF_SELECT (two fill launches and two tick launches less per read-out): the candidate counters of pass 1 are
 // cleared (one int per query, stride AFF_CSTRIDE) and the life counters of up to two token ranges advance by one (USAGE_TICK).
-struct SelectSide { int* count; float* lifeA; float* lifeB; int nA, nB; int zeroA; };    // zeroA: range A is cleared, not advanced
+struct SelectSide { int* count; float* lifeA; float* lifeB; int nA, nB; int zeroA; int HWpf, nrows; };    // zeroA: range A is cleared, not advanced
+// HWpf / nrows: query rows per frame / in total (several frames per launch: row j is a real query iff j % HWpf < HW; one frame: nrows = HW)
 __device__ __forceinline__ void select_side_jobs(const SelectSide& sd, int HW) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
-    if (sd.count) for (int q = gid; q < HW; q += nth) sd.count[q * AFF_CSTRIDE] = 0;
+    if (sd.count) for (int q = gid; q < sd.nrows; q += nth) sd.count[q * AFF_CSTRIDE] = 0;
     if (sd.lifeA) for (int t = gid; t < sd.nA; t += nth) sd.lifeA[t] = sd.zeroA ? 0.f : sd.lifeA[t] + 1.f;
     if (sd.lifeB) for (int t = gid; t < sd.nB; t += nth) sd.lifeB[t] += 1.f;
 }
@@ -686,7 +698,7 @@ __global__ __launch_bounds__(256) void aff_select_reg_kernel(const float* __rest
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + wave;
     select_side_jobs(sd, HW);
-    if (j >= HW) return;                                    // whole wave exits together
+    if (j >= sd.nrows || j % sd.HWpf >= HW) return;          // whole wave exits together
     if (G < k) { if (lane == 0) tau[j] = -INFINITY; return; }
     uint32_t key[MAXV];
     float raw[MAXV];
@@ -716,7 +728,7 @@ __global__ __launch_bounds__(256) void aff_select_kernel(const float* __restrict
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + wave;
     select_side_jobs(sd, HW);
-    if (j >= HW) return;                                    // whole wave exits together
+    if (j >= sd.nrows || j % sd.HWpf >= HW) return;          // whole wave exits together
     if (G < k) { if (lane == 0) tau[j] = -INFINITY; return; }
     uint32_t prefix = 0, mask = 0;
     int remaining = k;
@@ -772,7 +784,7 @@ typedef const __attribute__((address_space(1))) ro_u32x4* ro_gptr;
 __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
                                                                  const int* __restrict__ count, const uint64_t* __restrict__ vptrs,
                                                                  float* __restrict__ usage, bf16_t* __restrict__ y, int* __restrict__ overflow,
-                                                                 int HW, int cap, int topk, int K, int CV) {
+                                                                 int HW, int cap, int topk, int K, int CV, int HWpf, int nrows, int ustride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float* cv = reinterpret_cast<float*>(lds_raw);             // [cap]
     int* ci = reinterpret_cast<int*>(lds_raw + (size_t)cap * 4);  // [cap]
@@ -783,10 +795,16 @@ __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __
     __shared__ int prune_n;
     // XCD-aware: hardware block b runs on XCD b % 8; give each XCD one contiguous stripe of queries (neighbouring pixels
     // select overlapping memory tokens, so a stripe's value rows stay in that XCD's L2 instead of all 8 L2s fetching all)
-    const int per = (HW + 7) >> 3;
+    // Several frames per launch (nrows = frames x HWpf query rows, row j real iff j % HWpf < HW): frame f's read-out goes to
+    // y + f * K * HW * CV and its usage to usage + f * ustride (per-frame side buffers: committed frame by frame, memory_manager.py).
+    const int per = (nrows + 7) >> 3;
     const int j = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     const int tid = threadIdx.x;
-    if (j >= HW || (int)(blockIdx.x >> 3) >= per) return;
+    if (j >= nrows || (int)(blockIdx.x >> 3) >= per) return;
+    const int fr = j / HWpf, jl = j - fr * HWpf;
+    if (jl >= HW) return;
+    y += (long)fr * K * HW * CV;
+    if (usage) usage += (long)fr * ustride;
     // every global round trip that does not depend on another is issued up front: the count, the first RO_THREADS
     // candidates (typical fill is 30-50 of the 1024 slots), the bank base pointer of this thread's object
     const int C8 = CV >> 3;
@@ -901,7 +919,7 @@ __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __
                 }
             }
         }
-        *reinterpret_cast<uint4*>(y + ((long)o * HW + j) * CV + c8 * 8) =
+        *reinterpret_cast<uint4*>(y + ((long)o * HW + jl) * CV + c8 * 8) =
             make_uint4(pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3]), pack_bf2(acc[4], acc[5]), pack_bf2(acc[6], acc[7]));
     }
     // usage += softmax weight of every selected token (kv_memory_store.py:151-162).  Last on purpose: on gfx950 an atomic counts in
@@ -928,6 +946,8 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             sp.HW = i[0]; sp.HWp = i[1]; sp.nranges = i[2];
             for (int r = 0; r < 3; ++r) { sp.rs[r] = i[3 + 2 * r]; sp.rn[r] = (r < sp.nranges) ? i[4 + 2 * r] : 0; }
             sp.G = i[9]; sp.cap = i[10]; sp.mode = i[11]; sp.Gld = (sp.G + 63) / 64 * 64;
+            sp.HWpf = i[16] > 0 ? i[16] : sp.HWp;              // i[16]: query rows per frame when one launch serves several frames (HWp = frames x i[16])
+            if (sp.HWp % sp.HWpf || sp.HW > sp.HWpf) { cutie_set_error("aff_score: HWp=%d is not a multiple of the rows per frame %d (HW=%d)", sp.HWp, sp.HWpf, sp.HW); return -2; }
             int G = 0;
             for (int r = 0; r < 3; ++r) G += (sp.rn[r] + 15) / 16;
             if (G != sp.G || (sp.HWp & 63) || sp.nranges < 1 || sp.nranges > 3 || (sp.Gld & 3)) { cutie_set_error("aff_score: bad ranges (G=%d vs %d, HWp=%d)", G, sp.G, sp.HWp); return -2; }
@@ -978,8 +998,11 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             break;
         }
         case CUTIE_OP_AFF_SELECT: {
-            SelectSide sd = {(int*)p[2], (float*)p[3], (float*)p[4], i[4], i[5], op->flags & 1};
-            const dim3 grid((i[0] + 3) / 4), block(256);
+            // i[6] > 1: that many frames of i[1] query rows each (gmax / tau / the counters are indexed by row; i[0] real queries per frame)
+            const int frames = i[6] > 1 ? i[6] : 1;
+            const int nrows = frames > 1 ? frames * i[1] : i[0];
+            SelectSide sd = {(int*)p[2], (float*)p[3], (float*)p[4], i[4], i[5], op->flags & 1, frames > 1 ? i[1] : nrows, nrows};
+            const dim3 grid((nrows + 3) / 4), block(256);
             const int Gld = (i[2] + 63) / 64 * 64;
             // values per lane: the kernel counts MAXV compares per lane and bit, so MAXV follows the number of tiles in steps of 4 x 64 tiles
             // (16 | 32 | 64 only: 10.7 us at 700 tiles, 16.5 us from 1025 tiles on -- the bench clip crosses that line at 16.4 k tokens);
@@ -996,8 +1019,12 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
         case CUTIE_OP_AFF_READOUT: {
             if (i[2] > RO_MAXK || (i[4] & 7) || (i[1] & 3)) { cutie_set_error("aff_readout: top_k <= %d, CV %% 8, cap %% 4", RO_MAXK); return -2; }
             size_t lds = (size_t)i[1] * 8;
-            hipLaunchKernelGGL(aff_readout_kernel, dim3(((i[0] + 7) / 8) * 8), dim3(RO_THREADS), lds, s, (const float*)p[0], (const int*)p[1], (const int*)p[2],
-                               (const uint64_t*)p[3], (float*)p[4], (bf16_t*)p[5], (int*)p[6], i[0], i[1], i[2], i[3], i[4]);
+            // i[5] > 1: that many frames of i[6] query rows each; i[7] = floats between the frames' usage buffers
+            const int frames = i[5] > 1 ? i[5] : 1;
+            const int nrows = frames > 1 ? frames * i[6] : i[0];
+            hipLaunchKernelGGL(aff_readout_kernel, dim3(((nrows + 7) / 8) * 8), dim3(RO_THREADS), lds, s, (const float*)p[0], (const int*)p[1], (const int*)p[2],
+                               (const uint64_t*)p[3], (float*)p[4], (bf16_t*)p[5], (int*)p[6], i[0], i[1], i[2], i[3], i[4],
+                               frames > 1 ? i[6] : nrows, nrows, i[7]);
             break;
         }
         default:

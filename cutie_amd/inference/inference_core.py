@@ -33,6 +33,9 @@ DEFER_MEM = os.environ.get('CUTIE_AMD_DEFER_MEM', '0') not in ('', '0')
 # memory frames in two parts when the next frame is encoded already: its affinity read-out overlaps the summarizer (A/B switch)
 MEM_SPLIT = os.environ.get('CUTIE_AMD_MEM_SPLIT', '1') not in ('', '0')
 WAIT_TRACE = None                                          # a list: step() brackets its wait for the look-ahead with timing events (diagnostic)
+# one affinity read-out per BANK VERSION: the look-ahead read-out covers up to this many announced frames at once -- all frames up to and
+# including the next memory frame that sit in one encoder batch of the window (MemoryManager.prefetch_affinity_batch; <= 1: frame by frame)
+AFF_BATCH = int(os.environ.get('CUTIE_AMD_AFF_BATCH', '8'))
 WINDOW = int(os.environ.get('CUTIE_AMD_WINDOW', '12'))
 WINDOW_LEAD = int(os.environ.get('CUTIE_AMD_WINDOW_LEAD', '3'))
 
@@ -94,6 +97,7 @@ class InferenceCore:
         self._window = {}              # frame key -> (prepared image, record of CUTIE._encode_window, event, source image, geometry)
         self._hinted = False           # this step came with look-ahead hints (CUTIE.segment forks its last launch only then)
         self._prefetched_rec = None    # the encoder record behind _prefetched (window path): lets _add_memory start that frame's read-out
+        self._prefetched_group = None  # window entries of the announced frames, next frame first (candidates of a batched read-out)
 
     def _engine_stream(self, name, dev):
         """The look-ahead streams belong to the ENGINE (= one set of plan buffers / arenas), not to the processor: two processors that
@@ -244,16 +248,42 @@ class InferenceCore:
         prepared, o, ev, src, geometry = ent
         ms_features, pix_feat, key, shrinkage, selection = self.network._adopt_encoded(o)
         frame_context.remember('geometry', prepared, geometry)
+        group = []
+        for k in keys:                                          # (entries of the announced frames, in order, as far as they are encoded)
+            e = self._window.get(k)
+            if e is None or len(group) >= max(AFF_BATCH, 1):
+                break
+            group.append(e)
+        self._prefetched_group = group
         if affinity:
-            ev = self._ahead_affinity(key, selection, ev, o)
+            ev = self._ahead_affinity(key, selection, ev, o, next_mem_ti=self.last_mem_ti + self.mem_every)
         self._prefetched = (keys[0], prepared, (ms_features, pix_feat, key, shrinkage, selection), ev, src, geometry)
         self._prefetched_rec = o
 
-    def _ahead_affinity(self, key, selection, ev, o):
+    def _ahead_affinity(self, key, selection, ev, o, next_mem_ti=None):
         """The NEXT frame's affinity read-out on the side stream, against the bank as the caller's stream leaves it at this point
-        (key / selection: that frame's, ready behind `ev`).  Returns the event `step` has to wait for instead of `ev`."""
+        (key / selection: that frame's, ready behind `ev`).  Returns the event `step` has to wait for instead of `ev`.
+        Batched (AFF_BATCH > 1, window hints): the bank only changes on memory frames, so the read-outs of ALL announced frames up to and
+        including the next memory frame `next_mem_ti` (the schedule of inference_core.py:238 if the caller brings no mask in between: a
+        bank that changed after all invalidates them through its version) run as ONE pass over the bank, as far as those frames sit
+        behind each other in one encoder batch.  A frame that already carries a read-out of the current bank version is not read again."""
         dev = self.network.device
         gpu = dev.type == 'cuda'
+        mem = self.memory
+        qo = o.get('_qo')
+        done = qo.get('_readouts') if qo is not None else None
+        if done and all(v[1] == mem._version for v in done.values()) and set(done) == set(mem.buckets):
+            return qo.get('_readouts_ev') or ev                 # computed by an earlier batch (the consumer waits for that batch's event)
+        recs = [o]
+        if AFF_BATCH > 1 and next_mem_ti is not None and self._prefetched_group and self._prefetched_group[0][1] is o:
+            n = min(AFF_BATCH, next_mem_ti - self.curr_ti)      # frames curr_ti + 1 .. next_mem_ti read this bank version
+            hwp = o['Bhi'].shape[0]
+            for e in self._prefetched_group[1:max(n, 1)]:
+                r, last = e[1], recs[-1]
+                if e[2] is not ev or r['Bhi'].data_ptr() != last['Bhi'].data_ptr() + hwp * 256 or r['Blo'].data_ptr() != last['Blo'].data_ptr() + hwp * 256 \
+                        or r['cq'].data_ptr() != last['cq'].data_ptr() + hwp * 4:
+                    break                                       # another encoder batch: its frames are read when their turn comes
+                recs.append(r)
         enc = main = None
         if gpu:
             main = torch.cuda.current_stream(dev)
@@ -265,18 +295,42 @@ class InferenceCore:
         pool.offset = 1
         try:
             with (torch.cuda.stream(enc) if gpu else contextlib.nullcontext()):
-                ro = self.memory.prefetch_affinity(key, selection, self.network)
-                if gpu:
-                    ev = torch.cuda.Event()
-                    ev.record(enc)
+                if len(recs) > 1:
+                    qs = []
+                    for r in recs:
+                        q = r.get('_qo')
+                        if q is None:
+                            q = r['_qo'] = dict(Bhi=r['Bhi'], Blo=r['Blo'], cq=r['cq'], h=r['h'], w=r['w'])
+                        qs.append(q)
+
+                    def record():
+                        if not gpu:
+                            return None
+                        e = torch.cuda.Event()
+                        e.record(enc)
+                        return e
+                    per_frame = mem.prefetch_affinity_batch(qs, self.network, event_factory=record)
+                    ro = per_frame[0] if per_frame else None
+                    if per_frame:
+                        ev = qs[0].get('_readouts_ev') or ev
+                        for pf in per_frame[1:]:
+                            for v in pf.values():
+                                if isinstance(v[0], torch.Tensor) and v[0].is_cuda:
+                                    v[0].record_stream(main)
+                else:
+                    ro = mem.prefetch_affinity(key, selection, self.network)
+                    if gpu:
+                        ev = torch.cuda.Event()
+                        ev.record(enc)
         finally:
             pool.offset = 0
         for v in (ro or {}).values():
             if isinstance(v[0], torch.Tensor) and v[0].is_cuda:
                 v[0].record_stream(main)
-        for t in o.values():
-            if isinstance(t, torch.Tensor) and t.is_cuda:
-                t.record_stream(enc)
+        for r in recs:
+            for t in r.values():
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(enc)
         return ev
 
     def _resize(self, x: torch.Tensor, size, *, nearest: bool = False) -> torch.Tensor:
@@ -312,13 +366,14 @@ class InferenceCore:
         self.curr_ti = -1
         self.last_mem_ti = 0
         ovf = self.memory._scratch.get('overflow')              # (carried over: reported at the next step(end=True), no sync here)
+        self.memory._join_side()                                # bookkeeping launches still pending on the look-ahead stream write the old bank's counters
         self.memory = MemoryManager(cfg=self.cfg, object_manager=self.object_manager)
         if ovf is not None:
             self.memory._scratch['overflow'] = ovf
         if self._prefetched is not None:                        # a look-ahead of the old bank: order its buffers, drop it
             if self._prefetched[3] is not None:
                 torch.cuda.current_stream(self._prefetched[1].device).wait_event(self._prefetched[3])
-            self._prefetched = self._prefetched_rec = None
+            self._prefetched = self._prefetched_rec = self._prefetched_group = None
         if self._flip is not None:
             self._flip.clear_memory()
 
@@ -367,7 +422,7 @@ class InferenceCore:
                 need_weights=self.save_aux, _raw=raw, _split=True)
             self.memory.add_memory(key, shrinkage, msk_value, None, ids, selection=selection, as_permanent=as_permanent)
             feats = pre[2]
-            ev = self._ahead_affinity(feats[2], feats[4], pre[3], self._prefetched_rec)
+            ev = self._ahead_affinity(feats[2], feats[4], pre[3], self._prefetched_rec, next_mem_ti=self.curr_ti + self.mem_every)
             self._prefetched = pre[:3] + (ev,) + pre[4:]
             sensory, obj_value = finish()
             self.memory.add_object_values(obj_value, ids)
@@ -429,6 +484,7 @@ class InferenceCore:
         if self._lane_of_other is None:
             self.network.engine().pool.tick()                  # frame-slot pool: this frame's slot (plans.SlotPool)
         pre, self._prefetched, self._prefetched_rec = self._prefetched, None, None
+        self._prefetched_group = None
         if self._window and not resize_needed and (pre is None or pre[0] != self._frame_key(image)):
             ent = self._window.get(self._frame_key(image))
             if ent is not None:                                # encoded ahead by the window, but not announced as the next frame
@@ -506,7 +562,7 @@ class InferenceCore:
         if fl is not None:
             fl.last_mask = self._flip_w(self.last_mask)        # (:303-305)
 
-        if (is_mem_frame or force_permanent) and DEFER_MEM and fl is None and next_image is None and not end and image.is_cuda \
+        if (is_mem_frame or force_permanent) and DEFER_MEM and fl is None and next_image is None and (next_images is None or len(next_images) == 0) and not end and image.is_cuda \
                 and self.last_mask.shape[1] > 0:
             main = torch.cuda.current_stream(image.device)
             side = self._side_stream(image.device)
@@ -531,6 +587,7 @@ class InferenceCore:
 
         if end:
             self._join_pending()
+            self.memory._join_side()
             self.memory.check_overflow()
         output_prob = unpad(pred_prob_with_bg, self.pad)
         if resize_needed:

@@ -151,13 +151,26 @@ class MemoryManager:
 
     # ---- read (memory_manager.py:112-208) ---------------------------------------------------------------------
 
-    def _affinity(self, bucket: Bucket, q, h: int, w: int, dev, ahead: bool = False) -> torch.Tensor:
+    def _buf_rows(self, name, rows, row_shape, dtype, dev):
+        """Scratch of at least `rows` rows (grow-only: the frame count of a batched read-out varies between 1 and mem_every)."""
+        t = self._scratch.get(name)
+        if t is None or t.shape[0] < rows or tuple(t.shape[1:]) != tuple(row_shape) or t.device != dev:
+            t = torch.zeros((rows,) + tuple(row_shape), dtype=dtype, device=dev)
+            self._scratch[name] = t
+        return t[:rows]
+
+    def _affinity(self, bucket: Bucket, q, h: int, w: int, dev, ahead: bool = False, frames: int = 1):
         """Affinity read-out of one bucket for the query operands q: similarity -> exact top-k -> softmax -> sparse value gather
         (+ usage bookkeeping), 4 launches on the current stream.  Returns readout bf16 [K, h, w, CV].
         ahead (the look-ahead lane of `prefetch_affinity`, which runs on another stream, possibly for a frame that is never read): a
         second set of scratch buffers, and NO bookkeeping on the bank -- the life counters are left alone and the usage of this read-out
         is accumulated into a side buffer (cleared by the selection launch); `_commit_ahead` applies both on the caller's stream when,
-        and only when, the read-out is consumed."""
+        and only when, the read-out is consumed.
+        frames > 1 (ahead only; `prefetch_affinity_batch`): q are the operands of the FIRST of `frames` consecutive frames of one
+        encoder batch (their Bhi / Blo / cq rows follow each other in memory, HWp rows per frame): one pass over the bank for all of
+        them.  Returns [(readout, usage side buffer)] per frame instead of one read-out."""
+        if frames > 1:
+            return self._affinity_batch(bucket, q, h, w, dev, frames)
         tag = '#ahead' if ahead else ''
         HW = h * w
         HWp = q['Bhi'].shape[0]
@@ -231,6 +244,60 @@ class MemoryManager:
         cached[1].run(**dyn)
         return readout
 
+    def _affinity_batch(self, bucket: Bucket, q, h: int, w: int, dev, frames: int):
+        """One read-out per BANK VERSION instead of one per frame (no counterpart in the reference, which reads once per frame,
+        memory_manager.py:112-208): the bank changes on memory frames only (inference_core.py:238), and what frame t + j reads depends on
+        nothing but (bank, key_{t+j}, selection_{t+j}) (memory_utils.py:7-77).  The stacked query operands of `frames` consecutive frames
+        go through the same four launches; per query the arithmetic is that of the one-frame plan (same bits).  Every frame gets its own
+        read-out tensor and its own usage side buffer: `read` commits a frame's usage when, and only when, it consumes that frame."""
+        F = frames
+        HW = h * w
+        HWp = q['Bhi'].shape[0]
+        K = len(bucket.objects)
+        ranges = [r for r in bucket.ranges() if r[1] > 0]
+        G = sum(-(-n // 16) for _, n in ranges)
+        Gld = -(-max(G, 1) // 64) * 64
+        rows = F * HWp
+        gbuf = self._buf_rows('gmax_tau#batch', rows * Gld + rows, (), F32, dev)     # (pass 0 writes every entry pass 1 / the selection read)
+        gmax, tau = gbuf[:rows * Gld], gbuf[rows * Gld:]
+        cval = self._buf_rows('cand_val#batch', rows, (CAND_CAP,), F32, dev)
+        cidx = self._buf_rows('cand_idx#batch', rows, (CAND_CAP,), torch.int32, dev)
+        count = self._buf_rows('count#batch', rows, (O.OpList.AFF_CSTRIDE,), torch.int32, dev)
+        ovf = self._buf('overflow', (1,), torch.int32, dev)
+        pool = getattr(self, '_pool', None)
+        spec = dict(r=((F, K, h, w, self.CV), BF16, False))
+        readout = (pool.get_ring(('readout#batch', bucket.id, F, K, h, w, str(dev)), spec, dev, ring=3)['r'] if pool is not None
+                   else torch.empty(spec['r'][0], dtype=BF16, device=dev))
+        nslots = int(bucket.use.shape[0]) if self.use_long_term else 0
+        key = (tuple(ranges), K, HW, HWp, G, self.top_k, self.use_long_term, self.count_long_term_usage, bucket.n_long, nslots, F)
+        plans_ = bucket.__dict__.setdefault('_aff_plans', {})
+        cached = plans_.get(('batch', F))
+        if cached is None or cached[0] != key:
+            D = O.Dyn
+            ol = O.OpList()
+            common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=CAND_CAP, frames=F)
+            ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('gmax'), None, None, None, mode=0, **common)
+            ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), frames=F,
+                          zero=(D('usage'), F * nslots) if self.use_long_term else None)
+            ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('tau'), D('cval'), D('cidx'), D('count'),
+                         mode=1, gmax_precedes_tau=True, **common)
+            ol.aff_readout(D('cval'), D('cidx'), D('count'), D('vptrs'), D('usage') if self.use_long_term else None, D('readout'),
+                           D('ovf'), HW=HW, cap=CAND_CAP, top_k=self.top_k, K=K, CV=self.CV, frames=F, HWp=HWp, usage_stride=nslots)
+            if self.use_long_term and bucket.n_long > 0 and not self.count_long_term_usage:
+                for f in range(F):                                      # (memory_manager.py:145-147, as in the one-frame plan)
+                    ol.memset32(D('usage', 4 * f * nslots), bucket.n_long, 0)
+            plans_[('batch', F)] = cached = (key, ol)
+        dyn = dict(count=count, Ahi=bucket.Ahi, Alo=bucket.Alo, scale=bucket.scale, Bhi=q['Bhi'], Blo=q['Blo'], cq=q['cq'],
+                   gmax=gmax, tau=tau, cval=cval, cidx=cidx, vptrs=bucket.vptrs(), readout=readout, ovf=ovf)
+        udelta = None
+        if self.use_long_term:
+            # two sets of side buffers per bucket, alternating per batch: the next batch (side stream) may start before the caller's
+            # stream has applied the last frame of this one
+            udelta = self._buf_rows(f'udelta#batch{self._ahead_parity}#{bucket.id}', F, (nslots,), F32, dev)
+            dyn.update(usage=udelta)
+        cached[1].run(**dyn)
+        return [(readout[f], udelta[f] if udelta is not None else None) for f in range(F)]
+
     def _commit_ahead(self, bucket: Bucket, udelta: torch.Tensor, network=None) -> None:
         """Bookkeeping of a consumed look-ahead read-out, one launch: the life counters of the counted token ranges advance by one and
         the usage the read-out parked in its side buffer is added to the bank's (kv_memory_store.py:151-162) -- exactly what `_affinity`
@@ -284,6 +351,33 @@ class MemoryManager:
         q['_readouts'] = out
         return out
 
+    def prefetch_affinity_batch(self, qs: List[dict], network, event_factory=None):
+        """Look-ahead read-out of SEVERAL frames against one bank version (`_affinity_batch`).  qs: the query-operand dicts (the `_qo` of
+        the encoder records) of consecutive frames of one encoder batch, next frame first.  Each dict receives its `_readouts` exactly
+        as `prefetch_affinity` attaches them, plus `_readouts_ev` -- the event `read` waits for before it touches them."""
+        if not self.engaged or self.CV is None or not qs:
+            return None
+        if len(qs) == 1:
+            return None
+        q0 = qs[0]
+        h, w = q0['h'], q0['w']
+        dev = q0['Bhi'].device
+        HWp = q0['Bhi'].shape[0]
+        for a, b in zip(qs, qs[1:]):                                    # stacked operands: frame f + 1 right behind frame f
+            assert b['Bhi'].data_ptr() == a['Bhi'].data_ptr() + HWp * 256 and b['Blo'].data_ptr() == a['Blo'].data_ptr() + HWp * 256 \
+                and b['cq'].data_ptr() == a['cq'].data_ptr() + HWp * 4, 'frames of a batched read-out must come from one encoder batch'
+        self._pool = network.engine().pool
+        self._ahead_parity ^= 1
+        per_frame = [dict() for _ in qs]
+        for bid, b in self.buckets.items():
+            for f, (r, ud) in enumerate(self._affinity_batch(b, q0, h, w, dev, len(qs))):
+                per_frame[f][bid] = (r, self._version, ud)
+        ev = event_factory() if event_factory is not None else None
+        for q, out in zip(qs, per_frame):
+            q['_readouts'] = out
+            q['_readouts_ev'] = ev
+        return per_frame
+
     def read(self, pix_feat: torch.Tensor, query_key: torch.Tensor, selection: torch.Tensor, last_mask: torch.Tensor,
              network) -> Dict[int, torch.Tensor]:
         q = network.query_operands(query_key, selection)
@@ -291,6 +385,9 @@ class MemoryManager:
         dev = pix_feat.device
         self._pool = network.engine().pool
         ahead = q.pop('_readouts', None) or {}
+        ahead_ev = q.pop('_readouts_ev', None)
+        if ahead_ev is not None and ahead:                              # a batched look-ahead: ordered behind its own event
+            torch.cuda.current_stream(dev).wait_event(ahead_ev)
         all_readout = {}
         for bucket in self.buckets.values():
             K = len(bucket.objects)

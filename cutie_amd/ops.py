@@ -581,10 +581,12 @@ class OpList:
     AFF_DMA = int(os.environ.get('CUTIE_AMD_AFF_DMA', '0'))    # 1: the LDS-DMA kernel (aff_score4_kernel) also for 2 sets per wave
     AFF_NQ = int(os.environ.get('CUTIE_AMD_AFF_NQ', '2'))      # 16-query column sets per wave of AFF_SCORE (1, 2: aff_score_kernel; 4: aff_score4_kernel)
 
-    def aff_score(self, Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count, *, HW, HWp, ranges, cap, mode, gmax_precedes_tau=False, nq=None, dma=None):
+    def aff_score(self, Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count, *, HW, HWp, ranges, cap, mode, gmax_precedes_tau=False, nq=None, dma=None,
+                  frames=1):
         """gmax_precedes_tau (mode 1): `out` (= tau) sits right behind the [HWp, Gld] maxima of pass 0 in memory; the kernel then
         skips every (tile, 16-query set) that cannot hold a candidate.  nq: query column sets per wave (default AFF_NQ; every
-        choice computes the same bits)."""
+        choice computes the same bits).  frames > 1: the query operands of that many frames, HWp rows each (HW real ones), stacked -- every
+        per-query array (c, maxima, tau, candidate lists, counters) is then indexed by the stacked row."""
         ranges = [(s, n) for (s, n) in ranges if n > 0]
         assert 1 <= len(ranges) <= 3
         G = sum(-(-n // 16) for _, n in ranges)
@@ -592,20 +594,26 @@ class OpList:
         for r in range(3):
             ints += list(ranges[r]) if r < len(ranges) else [0, 0]
         ints += [G, cap, mode, self.AFF_NQ if nq is None else nq, 0, 0, self.AFF_DMA if dma is None else int(dma)]
+        if frames > 1:
+            ints[1] = frames * HWp
+            ints += [HWp]
         return self.add(AFF_SCORE, 1 if (gmax_precedes_tau and mode == 1) else 0, ints, [], [Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count])
 
-    def aff_select(self, gmax, tau, *, HW, HWp, G, top_k, clear_count=None, ticks=(), zero=None):
+    def aff_select(self, gmax, tau, *, HW, HWp, G, top_k, clear_count=None, ticks=(), zero=None, frames=1):
         """clear_count: pass 1's candidate counters, zeroed here; ticks: up to two (life, n) ranges advanced by one (USAGE_TICK);
-        zero = (buffer, n): f32 range cleared instead (excludes ticks: the usage side buffer of a look-ahead read-out)."""
+        zero = (buffer, n): f32 range cleared instead (excludes ticks: the usage side buffer of a look-ahead read-out).
+        frames > 1: stacked queries, see aff_score."""
         if zero is not None:
             assert not ticks
-            return self.add(AFF_SELECT, 1 | SELECT_COARSE, [HW, HWp, G, top_k, zero[1], 0], [], [gmax, tau, clear_count, zero[0], None])
+            return self.add(AFF_SELECT, 1 | SELECT_COARSE, [HW, HWp, G, top_k, zero[1], 0, frames], [], [gmax, tau, clear_count, zero[0], None])
         ticks = list(ticks) + [(None, 0)] * (2 - len(ticks))
         assert len(ticks) == 2
-        return self.add(AFF_SELECT, SELECT_COARSE, [HW, HWp, G, top_k, ticks[0][1], ticks[1][1]], [], [gmax, tau, clear_count, ticks[0][0], ticks[1][0]])
+        return self.add(AFF_SELECT, SELECT_COARSE, [HW, HWp, G, top_k, ticks[0][1], ticks[1][1], frames], [], [gmax, tau, clear_count, ticks[0][0], ticks[1][0]])
 
-    def aff_readout(self, cand_val, cand_idx, count, vptrs, usage, y, overflow, *, HW, cap, top_k, K, CV):
-        return self.add(AFF_READOUT, 0, [HW, cap, top_k, K, CV], [], [cand_val, cand_idx, count, vptrs, usage, y, overflow])
+    def aff_readout(self, cand_val, cand_idx, count, vptrs, usage, y, overflow, *, HW, cap, top_k, K, CV, frames=1, HWp=0, usage_stride=0):
+        """frames > 1: stacked queries (HWp rows per frame, see aff_score); frame f's read-out goes to y[f] ([frames, K, HW, CV]) and its
+        usage to usage + f * usage_stride floats."""
+        return self.add(AFF_READOUT, 0, [HW, cap, top_k, K, CV, frames, HWp, usage_stride], [], [cand_val, cand_idx, count, vptrs, usage, y, overflow])
 
     def memset32(self, dst, n, value=0):
         return self.add(MEMSET32, 0, [n, value], [], [dst])

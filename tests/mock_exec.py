@@ -525,79 +525,93 @@ class MockExecutor:
         return out
 
     def _op_24(self, flags, i, f, p):
+        """AFF_SCORE.  i[16] > 0: i[1] / i[16] frames of i[16] query rows each (i[0] real ones), every per-query array indexed by the
+        stacked row -- interpreted frame by frame with the pointers advanced."""
         HW, HWp = i[0], i[1]
         G, cap, mode = i[9], i[10], i[11]
-        sc = self._scores(i, p)
-        if mode == 0:
-            Gld = -(-G // 64) * 64
-            gmax = view(p[6], F32, (HWp, Gld))
-            g = 0
-            for (_, S) in sc:
-                n = S.shape[0]
-                T = -(-n // 16)
-                Sp = torch.full((T * 16, HW), float('-inf'))
-                Sp[:n] = S
-                gmax[:HW, g:g + T] = Sp.view(T, 16, HW).max(1)[0].t()
-                g += T
-        else:
-            tau = view(p[6], F32, (HW,))
-            thr = tau - tau.abs() * 1e-6 - 1e-30
-            thr = torch.where(torch.isinf(tau), torch.full_like(tau, float('-inf')), thr)
-            cv = view(p[7], F32, (HW, cap))
-            ci = view(p[8], I32, (HW, cap))
-            cnt = view(p[9], I32, (HW, 32))[:, 0]
-            for (slots, S) in sc:
-                for j in range(HW):
-                    sel = torch.nonzero(S[:, j] >= thr[j]).flatten()
-                    c0 = int(cnt[j])
-                    m = min(len(sel), max(cap - c0, 0))
-                    cv[j, c0:c0 + m] = S[sel[:m], j]
-                    ci[j, c0:c0 + m] = slots[sel[:m]].to(torch.int32)
-                    cnt[j] = c0 + len(sel)
+        HWpf = i[16] if i[16] > 0 else HWp
+        Gld = -(-G // 64) * 64
+        for fr in range(HWp // HWpf):
+            r0 = fr * HWpf
+            pf = list(p)
+            pf[3], pf[4], pf[5] = p[3] + 256 * r0, p[4] + 256 * r0, p[5] + 4 * r0
+            sc = self._scores(i, pf)
+            if mode == 0:
+                gmax = view(p[6] + 4 * r0 * Gld, F32, (HWpf, Gld))
+                g = 0
+                for (_, S) in sc:
+                    n = S.shape[0]
+                    T = -(-n // 16)
+                    Sp = torch.full((T * 16, HW), float('-inf'))
+                    Sp[:n] = S
+                    gmax[:HW, g:g + T] = Sp.view(T, 16, HW).max(1)[0].t()
+                    g += T
+            else:
+                tau = view(p[6] + 4 * r0, F32, (HW,))
+                thr = tau - tau.abs() * 1e-6 - 1e-30
+                thr = torch.where(torch.isinf(tau), torch.full_like(tau, float('-inf')), thr)
+                cv = view(p[7] + 4 * r0 * cap, F32, (HW, cap))
+                ci = view(p[8] + 4 * r0 * cap, I32, (HW, cap))
+                cnt = view(p[9] + 4 * 32 * r0, I32, (HW, 32))[:, 0]
+                for (slots, S) in sc:
+                    for j in range(HW):
+                        sel = torch.nonzero(S[:, j] >= thr[j]).flatten()
+                        c0 = int(cnt[j])
+                        m = min(len(sel), max(cap - c0, 0))
+                        cv[j, c0:c0 + m] = S[sel[:m], j]
+                        ci[j, c0:c0 + m] = slots[sel[:m]].to(torch.int32)
+                        cnt[j] = c0 + len(sel)
 
     def _op_25(self, flags, i, f, p):
         HW, HWp, G, k = i[:4]
+        frames = i[6] if i[6] > 1 else 1
         Gld = -(-G // 64) * 64
-        gmax = view(p[0], F32, (HWp, Gld))[:HW, :G]
-        tau = view(p[1], F32, (HW,))
         if p[2]:                                                        # side jobs: clear pass 1's counters, advance life counters
-            view(p[2], I32, (HW, 32))[:, 0] = 0
+            view(p[2], I32, (HW if frames == 1 else frames * HWp, 32))[:, 0] = 0
         for slot, n in ((3, i[4]), (4, i[5])):
             if p[slot] and n > 0:
                 if slot == 3 and (flags & 1):
                     view(p[slot], F32, (n,)).zero_()                     # the usage side buffer of a look-ahead read-out
                 else:
                     view(p[slot], F32, (n,)).add_(1.0)
-        if G < k:
-            tau.fill_(float('-inf'))
-        else:
-            tau.copy_(gmax.topk(k, dim=1)[0][:, -1])
+        for fr in range(frames):
+            r0 = fr * HWp
+            gmax = view(p[0] + 4 * r0 * Gld, F32, (HWp, Gld))[:HW, :G]
+            tau = view(p[1] + 4 * r0, F32, (HW,))
+            if G < k:
+                tau.fill_(float('-inf'))
+            else:
+                tau.copy_(gmax.topk(k, dim=1)[0][:, -1])
 
     def _op_26(self, flags, i, f, p):
         HW, cap, topk, K, CV = i[:5]
-        cv = view(p[0], F32, (HW, cap))
-        ci = view(p[1], I32, (HW, cap))
-        cnt = view(p[2], I32, (HW, 32))[:, 0]
+        frames = i[5] if i[5] > 1 else 1
+        HWpf, ustride = (i[6], i[7]) if frames > 1 else (HW, 0)
         vptrs = view(p[3], U64, (K,))
-        usage = p[4]
-        out = view(p[5], BF16, (K, HW, CV))
-        for j in range(HW):
-            n = min(int(cnt[j]), cap)
-            if int(cnt[j]) > cap:
-                view(p[6], I32, (1,))[0] += 1
-            v, idx = cv[j, :n], ci[j, :n].long()
-            # descending by value, ties -> lower slot
-            order = sorted(range(n), key=lambda t: (-float(v[t]), int(idx[t])))[:topk]
-            order = torch.tensor(order, dtype=torch.long)
-            sv, si = v[order], idx[order]
-            w = torch.exp(sv - sv[0])
-            w = w / w.sum()
-            if usage:
-                u = view(usage, F32, (int(si.max()) + 1,))
-                u.index_add_(0, si, w)
-            for o in range(K):
-                V = view(int(vptrs[o]), BF16, (int(si.max()) + 1, CV)).float()
-                out[o, j] = (w[:, None] * V[si]).sum(0).to(torch.bfloat16)
+        for fr in range(frames):
+            r0 = fr * HWpf
+            cv = view(p[0] + 4 * r0 * cap, F32, (HW, cap))
+            ci = view(p[1] + 4 * r0 * cap, I32, (HW, cap))
+            cnt = view(p[2] + 4 * 32 * r0, I32, (HW, 32))[:, 0]
+            usage = p[4] + 4 * fr * ustride if p[4] else 0
+            out = view(p[5] + 2 * fr * K * HW * CV, BF16, (K, HW, CV))
+            for j in range(HW):
+                n = min(int(cnt[j]), cap)
+                if int(cnt[j]) > cap:
+                    view(p[6], I32, (1,))[0] += 1
+                v, idx = cv[j, :n], ci[j, :n].long()
+                # descending by value, ties -> lower slot
+                order = sorted(range(n), key=lambda t: (-float(v[t]), int(idx[t])))[:topk]
+                order = torch.tensor(order, dtype=torch.long)
+                sv, si = v[order], idx[order]
+                w = torch.exp(sv - sv[0])
+                w = w / w.sum()
+                if usage:
+                    u = view(usage, F32, (int(si.max()) + 1,))
+                    u.index_add_(0, si, w)
+                for o in range(K):
+                    V = view(int(vptrs[o]), BF16, (int(si.max()) + 1, CV)).float()
+                    out[o, j] = (w[:, None] * V[si]).sum(0).to(torch.bfloat16)
 
     # ---- misc --------------------------------------------------------------------------------------------------------
     def _op_27(self, flags, i, f, p):

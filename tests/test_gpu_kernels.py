@@ -1103,6 +1103,84 @@ def test_affinity_pipeline(case, skip, nq):
         assert float((hip['usage'] - u).abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize('case', [
+    dict(HW=1620, F=5, ranges=[(0, 2000), (2100, 1620), (4000, 8097)], slots=12200, K=3, top_k=30),     # a memory cycle of the bench clip: 5 x 1664 query rows
+    dict(HW=1620, F=2, ranges=[(0, 1620)], slots=1620, K=1, top_k=30),
+    dict(HW=100, F=3, ranges=[(0, 1003)], slots=1003, K=2, top_k=5),                                   # ragged tail tile, 128 rows per frame
+    dict(HW=48, F=4, ranges=[(0, 48)], slots=48, K=3, top_k=30),                                       # G < top_k: "take everything"
+])
+@pytest.mark.parametrize('nq', [2, 4])
+def test_affinity_batched_frames_match_one_frame_plans(case, nq):
+    """One read-out per bank version (MemoryManager._affinity_batch): the stacked query operands of F frames through ONE
+    score / select / score / read-out sequence against the F one-frame sequences of the frame's plan -- identical thresholds, candidate
+    counts and read-out bits per frame, per-frame usage side buffers (cleared by the selection launch) equal up to the order of the
+    float atomics; and both against the descriptor interpreter."""
+    HW, F, ranges, slots, K, top_k = case['HW'], case['F'], case['ranges'], case['slots'], case['K'], case['top_k']
+
+    def build(dev, g):
+        CV, cap = 256, 1024
+        HWp = -(-HW // 64) * 64
+        mkey = (torch.randn((slots, 64), generator=g) * 0.8).to(dev)
+        mshr = (torch.rand((slots,), generator=g) * 2 + 1).to(dev)
+        qkey = (torch.randn((F, HW, 64), generator=g) * 0.8).to(dev)
+        qsel = torch.rand((F, HW, 64), generator=g).to(dev)
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        Ahi, Alo, scale = z((slots + 16, 128), BF16), z((slots + 16, 128), BF16), z((slots + 16,), F32)
+        Bhi, Blo, cq = z((F, HWp, 128), BF16), z((F, HWp, 128), BF16), z((F, HWp), F32)
+        G = sum(-(-n // 16) for _, n in ranges if n > 0)
+        Gld = -(-G // 64) * 64
+        vals = [rnd(g, (slots + 16, CV), dev=dev) for _ in range(K)]
+        vptrs = torch.tensor([v.data_ptr() for v in vals], dtype=torch.int64).to(dev)
+        nslots = slots + 16
+        ovf = z((1,), torch.int32)
+        ol = O.OpList()
+        ol.keep += vals
+        ol.key_prep(mkey, mshr, Ahi, Alo, scale, n=slots, query=False)
+        for f in range(F):
+            ol.key_prep(qkey[f], qsel[f], Bhi[f], Blo[f], cq[f], n=HW, query=True)
+        # (a) frame by frame, as MemoryManager._affinity(ahead=True) issues it
+        y1, use1 = z((F, K, HW, CV), BF16), z((F, nslots), F32) + 3.0
+        tau1, cnt1 = z((F, HW), F32), z((F, HW), torch.int32)
+        keep = []
+        for f in range(F):
+            gbuf = z((HWp * Gld + HWp,), F32)
+            gmax, tau = gbuf[:HWp * Gld], gbuf[HWp * Gld:]
+            cval, cidx, count = z((HW, cap), F32), z((HW, cap), torch.int32), z((HW * 32,), torch.int32) + 7
+            keep += [gbuf, cval, cidx, count]
+            common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=cap, nq=nq)
+            ol.aff_score(Ahi, Alo, scale, Bhi[f], Blo[f], cq[f], gmax, None, None, None, mode=0, **common)
+            ol.aff_select(gmax, tau, HW=HW, HWp=HWp, G=G, top_k=top_k, clear_count=count, zero=(use1[f], nslots))
+            ol.aff_score(Ahi, Alo, scale, Bhi[f], Blo[f], cq[f], tau, cval, cidx, count, mode=1, gmax_precedes_tau=True, **common)
+            ol.aff_readout(cval, cidx, count, vptrs, use1[f], y1[f], ovf, HW=HW, cap=cap, top_k=top_k, K=K, CV=CV)
+            ol.copy2d(tau, tau1[f], rows=1, rowbytes=4 * HW, src_stride=4 * HW, dst_stride=4 * HW)
+            ol.copy2d(count, cnt1[f], rows=HW, rowbytes=4, src_stride=128, dst_stride=4)
+        # (b) the F frames stacked
+        rows = F * HWp
+        yb, useb = z((F, K, HW, CV), BF16), z((F, nslots), F32) + 3.0
+        gbuf = z((rows * Gld + rows,), F32)
+        gmax, tau = gbuf[:rows * Gld], gbuf[rows * Gld:]
+        cval, cidx, count = z((rows, cap), F32), z((rows, cap), torch.int32), z((rows * 32,), torch.int32) + 7
+        common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=cap, nq=nq, frames=F)
+        ol.aff_score(Ahi, Alo, scale, Bhi, Blo, cq, gmax, None, None, None, mode=0, **common)
+        ol.aff_select(gmax, tau, HW=HW, HWp=HWp, G=G, top_k=top_k, clear_count=count, zero=(useb, F * nslots), frames=F)
+        ol.aff_score(Ahi, Alo, scale, Bhi, Blo, cq, tau, cval, cidx, count, mode=1, gmax_precedes_tau=True, **common)
+        ol.aff_readout(cval, cidx, count, vptrs, useb, yb, ovf, HW=HW, cap=cap, top_k=top_k, K=K, CV=CV, frames=F, HWp=HWp, usage_stride=nslots)
+        ol.keep += keep + [gbuf, cval, cidx, count]
+        return ol, {'y1': y1, 'yb': yb, 'use1': use1, 'useb': useb, 'tau1': tau1, 'taub': tau.view(F, HWp)[:, :HW],
+                    'cnt1': cnt1, 'cntb': count.view(F, HWp, 32)[:, :HW, 0], 'cnt_pad': count.view(F, HWp, 32)[:, HW:, 0], 'ovf': ovf}
+
+    hip, ref = run_both(build, seed=5)
+    assert torch.equal(hip['yb'].view(torch.int16), hip['y1'].view(torch.int16))
+    assert torch.equal(hip['taub'], hip['tau1'])
+    assert torch.equal(hip['cntb'], hip['cnt1'])
+    assert int(hip['cnt_pad'].abs().max() if hip['cnt_pad'].numel() else 0) == 0      # padding rows: counters cleared, nothing appended
+    assert int(hip['ovf']) == 0
+    assert torch.allclose(hip['useb'], hip['use1'], rtol=1e-5, atol=1e-6)
+    assert float(hip['useb'].sum()) > 0.99 * case['F'] * case['HW']                   # (every query's weights sum to one; the + 3.0 was cleared)
+    check({'yb': hip['yb']}, {'yb': ref['yb']}, 'aff batched')
+    check({'useb': hip['useb']}, {'useb': ref['useb']}, 'aff batched usage', rtol=1e-4)
+
+
 @pytest.mark.parametrize('nq', [2, 4])
 def test_affinity_long_candidate_lists(nq):
     """Homogeneous memory (runs of 16 nearly identical tokens): the tile-maximum threshold of pass 1 lets hundreds of candidates

@@ -568,14 +568,29 @@ def test_lookahead_window_bookkeeping_matches_plain_order():
         short = lambda t: dict(next_images=frames[t + 1:t + 3])
         changing = lambda t: dict(next_images=[frames[t + 1]] + decoy[t + 2:t + 6]) if (t + 1 < n and t % 4 == 1) else full(t)
         mixed = lambda t: {} if t % 5 == 0 else (dict(next_image=frames[t + 1]) if (t % 5 == 1 and t + 1 < n) else full(t))
+        # one read-out per bank version (MemoryManager._affinity_batch): how many frames did each batched read-out cover?
+        from cutie_amd.inference.memory_manager import MemoryManager
+        batches = []
+        orig_batch = MemoryManager._affinity_batch
+
+        def counting(self, bucket, q, h, w, dev, frames):
+            batches.append(frames)
+            return orig_batch(self, bucket, q, h, w, dev, frames)
+        MemoryManager._affinity_batch = counting
         with torch.inference_mode():
             plain, _ = run(lambda t: {})
+            assert not batches                                  # (no hints: every frame reads on its own)
             for name, h in (('full', full), ('short', short), ('changing', changing), ('mixed', mixed)):
+                del batches[:]
                 got, proc = run(h)
                 assert torch.equal(got, plain), (name, float((got - plain).abs().max()))
                 assert len(proc._window) == 0, name
+                if name == 'full':                              # mem_every = 3: the three frames of a memory cycle in one pass over the bank
+                    assert batches and max(batches) == 3 and sum(batches) >= 8, batches
             plain, p0 = run(lambda t: {}, use_long_term=True, long_term=S.LT_SMALL)
+            del batches[:]
             got, p1 = run(full, use_long_term=True, long_term=S.LT_SMALL)
+            assert batches and max(batches) == 3, batches
             assert torch.equal(got, plain)
             b0, b1 = next(iter(p0.memory.buckets.values())), next(iter(p1.memory.buckets.values()))
             assert (b0.n_long, b0.n_work, b0.n_perm) == (b1.n_long, b1.n_work, b1.n_perm)
@@ -583,6 +598,7 @@ def test_lookahead_window_bookkeeping_matches_plain_order():
             assert torch.allclose(b0.use[:b0.work_start + b0.n_work], b1.use[:b1.work_start + b1.n_work], rtol=1e-5, atol=1e-6)
             assert torch.equal(b0.life[:b0.work_start + b0.n_work], b1.life[:b1.work_start + b1.n_work])
     finally:
+        MemoryManager._affinity_batch = orig_batch
         _lib.set_executor_for_testing(prev)
 
 
