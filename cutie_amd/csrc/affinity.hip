@@ -83,6 +83,7 @@ struct ScoreParams {
     const bf16_t* Bhi; const bf16_t* Blo; const float* c;
     float* gmax_or_tau; float* cand_val; int* cand_idx; int* count;
     int HW, HWp, nranges, rs[3], rn[3], G, cap, mode, tiles_per_block, Gld;
+    int gbase, grem;                                     // 4-tile groups per block row: row by owns gbase (+ 1 if by < grem) groups
     int HWpf;                                            // query rows per frame (HWp = frames x HWpf; row j is a real query iff j % HWpf < HW)
 #ifdef AFF_TIMELINE
     unsigned long long* tl;                              // (diagnostic library only: where the cycle stamps go; p10 of the op)
@@ -140,6 +141,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned int au32x4;
 #define ATL(ID) {}
 #define ATL_DUMP(LOGICAL, NB) {}
 #endif
+// The hand-over of a staged group: LDS counter drained + raw barrier.  __syncthreads() also drains vmcnt, i.e. it waited every group for
+// the write acknowledgement of the tile maxima stored just before it (pass 0) and for the NEXT group's operand loads issued at the top
+// of the iteration (both passes: the prefetch never overlapped the barrier).  Registers fed by global loads are waited for by the
+// compiler where AFF_STORE uses them.
+#define AFF_SYNC() { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(15 | (3 << 14) | (7 << 4) | (0 << 8)); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 template <int AFF_NQ, int AFF_MODE>                   // 16-query column sets per wave (1 or 2)
 __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
     constexpr int mode = AFF_MODE;
@@ -190,8 +196,8 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
         craw[u] = p.c[jc];
         traw[u] = mode == 1 ? tau_p[jc] : 0.f;
     }
-    const int g0 = by * p.tiles_per_block;
-    const int g1 = min(g0 + p.tiles_per_block, p.G);
+    const int g0 = AFF_TG * (by * p.gbase + min(by, p.grem));
+    const int g1 = min(g0 + AFF_TG * (p.gbase + (by < p.grem ? 1 : 0)), p.G);
     const int T0 = (p.rn[0] + 15) >> 4, T1 = (p.nranges > 1) ? ((p.rn[1] + 15) >> 4) : 0;
     // staging: wave w stages tile w of the group.  Eight consecutive lanes take eight consecutive 16-B chunks of ONE row (a whole 128-B
     // line per lane octet in the global load, and -- ds_write_b128 is served in groups of 8 contiguous lanes on 32 banks -- eight
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
     for (int u = 0; u < AFF_NQ; ++u) gcur[u] = gq[u];
     AFF_STORE(0);
     ATL(3)
-    __syncthreads();
+    AFF_SYNC();
     int buf = 0;
     for (int gg = g0; gg < g1; gg += AFF_TG) {
         ATL(4)
@@ -309,6 +315,62 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
         if (more) AFF_LOAD(gg + AFF_TG);
         ATL(5)
         float gm[AFF_NQ][AFF_TG];
+        if constexpr (mode == 0 && AFF_NQ == 2) {
+            // Pass 0 works on TWO tiles at a time: 2 tiles x 2 query sets = four independent accumulator chains of 12 dependent MFMAs each
+            // (one chain is latency-bound: the timeline showed ~950 cycles per tile for 384 cycles of MFMA issue per wave, two waves per
+            // SIMD).  Every chain runs its MFMAs in the order of the one-tile form (cross terms ks = 0..3, then hi * hi), so the bits are
+            // those of rounds 1-4.  A tile past the block's range (only behind g1, in the last group) reads the clamped copy that AFF_LOAD
+            // staged in its place; its maxima are replaced by -inf.
+#pragma unroll
+            for (int tp = 0; tp < AFF_TG; tp += 2) {
+                ATL(6 + tp)
+                bf16x8 ah[2][4], al[2][4];
+                f32x4 sc[2], pd[2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int row = (tp + tt) * 16 + l15;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        ah[tt][ks] = __builtin_bit_cast(bf16x8, lds[buf][row * 16 + ((ks * 4 + l4) ^ l15)]);
+                        al[tt][ks] = __builtin_bit_cast(bf16x8, lds[buf][1024 + row * 16 + ((ks * 4 + l4) ^ l15)]);
+                    }
+                    sc[tt] = *reinterpret_cast<const f32x4*>(&lsc[buf][(tp + tt) * 16 + l4 * 4]);
+                    pd[tt] = *reinterpret_cast<const f32x4*>(&lpad[buf][(tp + tt) * 16 + l4 * 4]);
+                }
+                f32x4 acc[2][2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) acc[u][tt] = (f32x4){ncj[u], ncj[u], ncj[u], ncj[u]};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {                        // small cross terms first
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) acc[u][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tt][ks], bl[u][ks], acc[u][tt], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) acc[u][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tt][ks], bh[u][ks], acc[u][tt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) acc[u][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tt][ks], bh[u][ks], acc[u][tt], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        float sv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) sv[q] = fmaf(sc[tt][q], acc[u][tt][q], pd[tt][q]);      // scale_i (A.B - c_j), -inf on padding rows
+                        const float m_ = rows_max(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
+                        gm[u][tp + tt] = gg + tp + tt < g1 ? m_ : -INFINITY;
+                    }
+            }
+        } else
 #pragma unroll
         for (int t = 0; t < AFF_TG; ++t) {
 #pragma unroll
@@ -391,7 +453,7 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
             for (int u = 0; u < AFF_NQ; ++u) gcur[u] = gq[u];
         }
         ATL(3)
-        __syncthreads();
+        AFF_SYNC();
         buf ^= 1;
     }
     ATL(11)
@@ -457,8 +519,8 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
     }
     ATL_DECL(aff_smem + 2 * AF4_STAGE + 4096)
     ATL(0)
-    const int g0 = by * p.tiles_per_block;
-    const int g1 = min(g0 + p.tiles_per_block, p.G);
+    const int g0 = AFF_TG * (by * p.gbase + min(by, p.grem));
+    const int g1 = min(g0 + AFF_TG * (p.gbase + (by < p.grem ? 1 : 0)), p.G);
     const int T0 = (p.rn[0] + 15) >> 4, T1 = (p.nranges > 1) ? ((p.rn[1] + 15) >> 4) : 0;
     auto tile_slot = [&](int g, int& slot0, int& nvalid) {              // token slot of the first row / valid rows of tile g (wave-uniform)
         int start, n, lt;
@@ -971,15 +1033,20 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
                     }
                 lds_attr_set = true;
             }
-            // ~2 resident blocks per CU (512 blocks), at least 8 tiles per block: the block prologue (its query operand,
-            // 64 KB through LDS) is amortised over the tiles, measured best around 16 tiles at 11k tokens x 1620 queries
+            // ONE round of blocks: at most `resident` of them (2 per CU), the 4-tile groups of the memory operand split evenly over the
+            // block rows (gbase or gbase + 1 groups each).  Rounds 1-4 sized a block as ceil(G * qb / resident) tiles and let the grid
+            // follow: 520 blocks on 512 slots whenever the last row was not short -- the eight late blocks doubled the launch (stacked
+            // frames: 160 us for 4 x 29 us of work, tools/r5_call2.sh).  At least 8 tiles per block: the block prologue (its query
+            // operand, 64 KB through LDS) is amortised over the tiles.
             const int resident = (nq == 4 && pass == 1) ? 256 : 512;    // (aff_score4_kernel<1> needs > 256 registers: one block per CU)
-            int tpb = (int)(((long)G * qb + resident - 1) / resident);
-            if (tpb < 8) tpb = 8;
-            if (i[13] > 0) tpb = i[13];                          // (tuning override: tiles per block)
-            tpb = (tpb + AFF_TG - 1) / AFF_TG * AFF_TG;
-            sp.tiles_per_block = tpb;
-            const dim3 grid(qb, (G + tpb - 1) / tpb);
+            const int NG = (G + AFF_TG - 1) / AFF_TG;
+            int ny = resident / qb;
+            if (ny > NG / 2) ny = NG / 2;
+            if (ny < 1) ny = 1;
+            if (i[13] > 0) ny = (NG + (i[13] + AFF_TG - 1) / AFF_TG - 1) / ((i[13] + AFF_TG - 1) / AFF_TG);   // (tuning override: tiles per block)
+            sp.gbase = NG / ny; sp.grem = NG % ny;
+            sp.tiles_per_block = AFF_TG * (sp.gbase + (sp.grem ? 1 : 0));
+            const dim3 grid(qb, ny);
             const int lds4 = AFF_LDS_BYTES + (i[14] > 0 && i[14] <= 80 ? i[14] * 1024 : 0);       // (diagnostic: extra dynamic LDS = fewer resident blocks per CU)
 #ifdef AFF_TIMELINE
             sp.tl = (unsigned long long*)p[10];

@@ -36,6 +36,7 @@ WAIT_TRACE = None                                          # a list: step() brac
 # one affinity read-out per BANK VERSION: the look-ahead read-out covers up to this many announced frames at once -- all frames up to and
 # including the next memory frame that sit in one encoder batch of the window (MemoryManager.prefetch_affinity_batch; <= 1: frame by frame)
 AFF_BATCH = int(os.environ.get('CUTIE_AMD_AFF_BATCH', '8'))
+AFF_FIRST_ALONE = os.environ.get('CUTIE_AMD_AFF_FIRST_ALONE', '1') not in ('', '0')     # (A/B switch: a memory frame's successor read on its own, see _ahead_affinity)
 WINDOW = int(os.environ.get('CUTIE_AMD_WINDOW', '12'))
 WINDOW_LEAD = int(os.environ.get('CUTIE_AMD_WINDOW_LEAD', '3'))
 
@@ -125,7 +126,17 @@ class InferenceCore:
     # ---- look-ahead image encoder (no counterpart in the reference) ---------------------------------------------
     @staticmethod
     def _frame_key(image):
-        return (image.data_ptr(), tuple(image.shape), tuple(image.stride()), image.dtype)
+        """Identity of an announced frame: its storage (address / shape / strides / dtype) AND the version counter of the tensor -- a
+        caller that announces frames and then overwrites one in place (a reused decode buffer) changes the counter, the frame no longer
+        matches what was encoded ahead and goes through its own encoder (matched by address alone the OLD frame's features
+        were returned).  The counter is shared by all views of a tensor: overwriting any part of a stacked clip tensor drops every
+        pending look-ahead of its frames (lost overlap, never a wrong result).  Tensors created under torch.inference_mode carry no
+        counter; for those the storage identity is all there is -- do not modify them between the announcement and their step."""
+        try:
+            version = image._version
+        except RuntimeError:                                    # inference tensor: no version counter
+            version = None
+        return (image.data_ptr(), tuple(image.shape), tuple(image.stride()), image.dtype, version)
 
     def _prepare_image(self, image):
         """Frame -> (f32 contiguous device tensor carrying the pad geometry, geometry).  Zero-padding to /16 is fused into
@@ -248,25 +259,21 @@ class InferenceCore:
         prepared, o, ev, src, geometry = ent
         ms_features, pix_feat, key, shrinkage, selection = self.network._adopt_encoded(o)
         frame_context.remember('geometry', prepared, geometry)
-        group = []
-        for k in keys:                                          # (entries of the announced frames, in order, as far as they are encoded)
-            e = self._window.get(k)
-            if e is None or len(group) >= max(AFF_BATCH, 1):
-                break
-            group.append(e)
-        self._prefetched_group = group
+        self._prefetched_group = (images, keys)                 # (the announcement: _ahead_affinity looks further into it when it forms a batch)
         if affinity:
             ev = self._ahead_affinity(key, selection, ev, o, next_mem_ti=self.last_mem_ti + self.mem_every)
         self._prefetched = (keys[0], prepared, (ms_features, pix_feat, key, shrinkage, selection), ev, src, geometry)
         self._prefetched_rec = o
 
-    def _ahead_affinity(self, key, selection, ev, o, next_mem_ti=None):
+    def _ahead_affinity(self, key, selection, ev, o, next_mem_ti=None, first_alone=False):
         """The NEXT frame's affinity read-out on the side stream, against the bank as the caller's stream leaves it at this point
         (key / selection: that frame's, ready behind `ev`).  Returns the event `step` has to wait for instead of `ev`.
         Batched (AFF_BATCH > 1, window hints): the bank only changes on memory frames, so the read-outs of ALL announced frames up to and
         including the next memory frame `next_mem_ti` (the schedule of inference_core.py:238 if the caller brings no mask in between: a
         bank that changed after all invalidates them through its version) run as ONE pass over the bank, as far as those frames sit
-        behind each other in one encoder batch.  A frame that already carries a read-out of the current bank version is not read again."""
+        behind each other in one encoder batch.  A frame that already carries a read-out of the current bank version is not read again.
+        first_alone (a memory frame, whose successor waits for this read-out right behind the insertion): the next frame is read on its
+        own, the frames behind it as one batch after it -- they have a whole frame time of slack."""
         dev = self.network.device
         gpu = dev.type == 'cuda'
         mem = self.memory
@@ -274,16 +281,35 @@ class InferenceCore:
         done = qo.get('_readouts') if qo is not None else None
         if done and all(v[1] == mem._version for v in done.values()) and set(done) == set(mem.buckets):
             return qo.get('_readouts_ev') or ev                 # computed by an earlier batch (the consumer waits for that batch's event)
-        recs = [o]
-        if AFF_BATCH > 1 and next_mem_ti is not None and self._prefetched_group and self._prefetched_group[0][1] is o:
+        recs, rest, rest_ev = [o], [], None
+        group = []
+        if AFF_BATCH > 1 and next_mem_ti is not None and self._prefetched_group is not None:
             n = min(AFF_BATCH, next_mem_ti - self.curr_ti)      # frames curr_ti + 1 .. next_mem_ti read this bank version
+            images, keys = self._prefetched_group
+            for j in range(min(n, len(images))):                # window entries of the announced frames, in order, as far as they are encoded
+                e = self._window.get(keys[j] if j < len(keys) else self._frame_key(images[j]))
+                if e is None:
+                    break
+                group.append(e)
+        if group and group[0][1] is o:
             hwp = o['Bhi'].shape[0]
-            for e in self._prefetched_group[1:max(n, 1)]:
-                r, last = e[1], recs[-1]
-                if e[2] is not ev or r['Bhi'].data_ptr() != last['Bhi'].data_ptr() + hwp * 256 or r['Blo'].data_ptr() != last['Blo'].data_ptr() + hwp * 256 \
-                        or r['cq'].data_ptr() != last['cq'].data_ptr() + hwp * 4:
-                    break                                       # another encoder batch: its frames are read when their turn comes
-                recs.append(r)
+
+            def behind(r, last):                                # stacked operands: r's rows right behind last's
+                return r['Bhi'].data_ptr() == last['Bhi'].data_ptr() + hwp * 256 and r['Blo'].data_ptr() == last['Blo'].data_ptr() + hwp * 256 \
+                    and r['cq'].data_ptr() == last['cq'].data_ptr() + hwp * 4
+            cand = group[1:]
+            if first_alone:
+                for e in cand:
+                    if rest and (e[2] is not rest_ev or not behind(e[1], rest[-1])):
+                        break                                   # another encoder batch: its frames are read when their turn comes
+                    if not rest:
+                        rest_ev = e[2]
+                    rest.append(e[1])
+            else:
+                for e in cand:
+                    if e[2] is not ev or not behind(e[1], recs[-1]):
+                        break
+                    recs.append(e[1])
         enc = main = None
         if gpu:
             main = torch.cuda.current_stream(dev)
@@ -293,41 +319,45 @@ class InferenceCore:
                 enc.wait_event(ev)
         pool = self.network.engine().pool
         pool.offset = 1
+
+        def record():
+            if not gpu:
+                return None
+            e = torch.cuda.Event()
+            e.record(enc)
+            return e
+
+        def operands(r):
+            q = r.get('_qo')
+            if q is None:
+                q = r['_qo'] = dict(Bhi=r['Bhi'], Blo=r['Blo'], cq=r['cq'], h=r['h'], w=r['w'])
+            return q
+        held = []
         try:
             with (torch.cuda.stream(enc) if gpu else contextlib.nullcontext()):
                 if len(recs) > 1:
-                    qs = []
-                    for r in recs:
-                        q = r.get('_qo')
-                        if q is None:
-                            q = r['_qo'] = dict(Bhi=r['Bhi'], Blo=r['Blo'], cq=r['cq'], h=r['h'], w=r['w'])
-                        qs.append(q)
-
-                    def record():
-                        if not gpu:
-                            return None
-                        e = torch.cuda.Event()
-                        e.record(enc)
-                        return e
+                    qs = [operands(r) for r in recs]
                     per_frame = mem.prefetch_affinity_batch(qs, self.network, event_factory=record)
-                    ro = per_frame[0] if per_frame else None
                     if per_frame:
                         ev = qs[0].get('_readouts_ev') or ev
-                        for pf in per_frame[1:]:
-                            for v in pf.values():
-                                if isinstance(v[0], torch.Tensor) and v[0].is_cuda:
-                                    v[0].record_stream(main)
+                        held += per_frame
                 else:
                     ro = mem.prefetch_affinity(key, selection, self.network)
                     if gpu:
                         ev = torch.cuda.Event()
                         ev.record(enc)
+                    held.append(ro or {})
+                if rest:
+                    if gpu and rest_ev is not None:
+                        enc.wait_event(rest_ev)
+                    held += mem.prefetch_affinity_batch([operands(r) for r in rest], self.network, event_factory=record) or []
         finally:
             pool.offset = 0
-        for v in (ro or {}).values():
-            if isinstance(v[0], torch.Tensor) and v[0].is_cuda:
-                v[0].record_stream(main)
-        for r in recs:
+        for pf in held:
+            for v in pf.values():
+                if isinstance(v[0], torch.Tensor) and v[0].is_cuda:
+                    v[0].record_stream(main)
+        for r in recs + rest:
             for t in r.values():
                 if isinstance(t, torch.Tensor) and t.is_cuda:
                     t.record_stream(enc)
@@ -422,7 +452,7 @@ class InferenceCore:
                 need_weights=self.save_aux, _raw=raw, _split=True)
             self.memory.add_memory(key, shrinkage, msk_value, None, ids, selection=selection, as_permanent=as_permanent)
             feats = pre[2]
-            ev = self._ahead_affinity(feats[2], feats[4], pre[3], self._prefetched_rec, next_mem_ti=self.curr_ti + self.mem_every)
+            ev = self._ahead_affinity(feats[2], feats[4], pre[3], self._prefetched_rec, next_mem_ti=self.curr_ti + self.mem_every, first_alone=AFF_FIRST_ALONE)
             self._prefetched = pre[:3] + (ev,) + pre[4:]
             sensory, obj_value = finish()
             self.memory.add_object_values(obj_value, ids)

@@ -27,6 +27,7 @@ CAND_CAP = 1024          # candidate slots per query column (typical fill ~35; s
 _UNFUSED = os.environ.get('CUTIE_AMD_UNFUSED', '0') not in ('', '0')      # diagnostic A/B switch, see model/plans.py
 _VALIDATE = os.environ.get('CUTIE_AMD_VALIDATE', '0') not in ('', '0')
 BANK_WRITE = os.environ.get('CUTIE_AMD_BANK_WRITE', '1') not in ('', '0')      # the copies / fills of an insertion in one launch (A/B switch)
+BATCH_FORMS = os.environ.get('CUTIE_AMD_AFF_BATCH_FORMS', '1') not in ('', '0')   # stacked read-outs pick their score kernels by frame count (A/B switch)
 COMMIT_ON_SIDE = os.environ.get('CUTIE_AMD_COMMIT_SIDE', '1') not in ('', '0')  # bookkeeping of a consumed look-ahead read-out on the look-ahead stream (A/B switch)
 # bank versions are drawn from one process-wide counter: a look-ahead read-out tagged with the version of one manager can never pass
 # the check of another (InferenceCore.clear_memory replaces the manager; per-manager counters would restart at 0 and collide)
@@ -276,11 +277,17 @@ class MemoryManager:
             D = O.Dyn
             ol = O.OpList()
             common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=CAND_CAP, frames=F)
-            ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('gmax'), None, None, None, mode=0, **common)
+            # kernel forms by the number of stacked frames (same bits whatever the form, tests/test_gpu_kernels.py; isolated stage
+            # times at 12.2 k tokens, tools/aff_batch_ab.py, profiles/r05_affinity.md): from three frames on the score pass runs 64 queries
+            # per wave on the LDS-DMA kernel (its longer prologue is amortised: 70.6 against 80.0 us at F = 5, MFMA utilisation 0.44
+            # against 0.39) and the candidate pass stages its memory tiles by LDS-DMA (94 against 103 us)
+            big = F >= 3 and BATCH_FORMS
+            nq0, dma1 = (4, True) if big else (None, None)
+            ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('gmax'), None, None, None, mode=0, nq=nq0, **common)
             ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), frames=F,
                           zero=(D('usage'), F * nslots) if self.use_long_term else None)
             ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('tau'), D('cval'), D('cidx'), D('count'),
-                         mode=1, gmax_precedes_tau=True, **common)
+                         mode=1, gmax_precedes_tau=True, nq=2 if big else None, dma=dma1, **common)
             ol.aff_readout(D('cval'), D('cidx'), D('count'), D('vptrs'), D('usage') if self.use_long_term else None, D('readout'),
                            D('ovf'), HW=HW, cap=CAND_CAP, top_k=self.top_k, K=K, CV=self.CV, frames=F, HWp=HWp, usage_stride=nslots)
             if self.use_long_term and bucket.n_long > 0 and not self.count_long_term_usage:
@@ -356,8 +363,6 @@ class MemoryManager:
         the encoder records) of consecutive frames of one encoder batch, next frame first.  Each dict receives its `_readouts` exactly
         as `prefetch_affinity` attaches them, plus `_readouts_ev` -- the event `read` waits for before it touches them."""
         if not self.engaged or self.CV is None or not qs:
-            return None
-        if len(qs) == 1:
             return None
         q0 = qs[0]
         h, w = q0['h'], q0['w']

@@ -608,9 +608,13 @@ def build_readout_query(eng, K, h, w, last_aux=True, fresh=True):
         if fresh or not use_chain:
             ol.query_init2(Dyn('obj_mem'), query, query_emb, rows=M, w_init=W[t + '.summary_to_query_init'], res_init=eng.rep_embedding('query_init', K),
                            w_emb=W[t + '.summary_to_query_emb'], res_emb=eng.rep_embedding('query_emb', K), zero=qacc)
-        else:
+        elif O.conv_side_jobs_ok(cin=C, cout=C, kh=1):
             zero_on_conv = qacc        # fresh=False: the summaries have not changed since the last run -- the queries in query_bufs are
                                        # still theirs; the accumulators are cleared by the first conv of the plan instead
+        else:
+            # (with $CUTIE_AMD_DMA_TILES=0 that conv runs on a register-staged tile, which has no side jobs -- the clearing
+            # gets a small launch of its own, like ca_block does for its GAP accumulators)
+            ol.memset32(qacc, 2 * qacc.numel(), 0)
     else:
         vals = f('vals', (M, C))
         ol.query_init(Dyn('obj_mem'), vals, rows=M, C=C)

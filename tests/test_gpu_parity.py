@@ -442,6 +442,35 @@ def test_lookahead_window_matches_plain_order(gpu_net, size, K):
             assert torch.equal(got, plain), (name, float((got - plain).abs().max()))
 
 
+def test_announced_frame_overwritten_in_place_is_encoded_again(gpu_net):
+    """a caller announces the next frames and then overwrites one of them in place (a reused decode buffer).  The
+    look-ahead matches frames by storage AND tensor version, so the modified frame goes through its own encoder: results equal the
+    un-hinted run on the frames as they are when they are stepped, and differ from what the stale encoding would have produced."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.utils.synth import SyntheticClip
+    n = 14
+    clip = SyntheticClip(96, 136, 2, n + 2, seed=12)
+    mask = clip.first_mask().cuda()
+
+    def run(hinted):
+        frames = [clip.frame(t).cuda() for t in range(n)]       # separate tensors: one version counter per frame
+        proc = InferenceCore(gpu_net, cfg=default_config(mem_every=3))
+        outs = []
+        for t in range(n):
+            if t == 2:                                           # frames 6 and 7 are announced (and encoded ahead) by now
+                frames[6].copy_(clip.frame(n).cuda())
+                frames[7].mul_(0.5)
+            kw = dict(next_images=frames[t + 1:t + 13]) if hinted and t + 1 < n else {}
+            outs.append(proc.step(frames[t], *((mask,) if t == 0 else ()), **(dict(objects=clip.objects) if t == 0 else {}), **kw))
+        torch.cuda.synchronize()
+        return torch.stack(outs).cpu()
+
+    plain = run(False)
+    got = run(True)
+    assert torch.equal(got, plain), float((got - plain).abs().max())
+    assert InferenceCore._frame_key(mask)[-1] == mask._version
+
+
 def test_query_init_only_when_the_summaries_changed(gpu_net, monkeypatch):
     """The transformer's query initialisation (object summaries -> queries) runs only when the summaries changed (memory frames,
     purges); in between the plan variant without that launch reads the queries of the last run.  Same clip with the switch off:

@@ -585,12 +585,21 @@ def test_lookahead_window_bookkeeping_matches_plain_order():
                 got, proc = run(h)
                 assert torch.equal(got, plain), (name, float((got - plain).abs().max()))
                 assert len(proc._window) == 0, name
-                if name == 'full':                              # mem_every = 3: the three frames of a memory cycle in one pass over the bank
-                    assert batches and max(batches) == 3 and sum(batches) >= 8, batches
+                if name == 'full':                              # mem_every = 3: a memory frame's successor alone, the two frames behind it in one pass
+                    assert batches and max(batches) == 2 and sum(batches) >= 6, batches
+            from cutie_amd.inference import inference_core as IC
+            IC.AFF_FIRST_ALONE = False                          # the whole memory cycle in one pass over the bank
+            try:
+                del batches[:]
+                got, proc = run(full)
+                assert torch.equal(got, plain) and len(proc._window) == 0
+                assert batches and max(batches) == 3 and sum(batches) >= 8, batches
+            finally:
+                IC.AFF_FIRST_ALONE = True
             plain, p0 = run(lambda t: {}, use_long_term=True, long_term=S.LT_SMALL)
             del batches[:]
             got, p1 = run(full, use_long_term=True, long_term=S.LT_SMALL)
-            assert batches and max(batches) == 3, batches
+            assert batches and max(batches) == 2, batches
             assert torch.equal(got, plain)
             b0, b1 = next(iter(p0.memory.buckets.values())), next(iter(p1.memory.buckets.values()))
             assert (b0.n_long, b0.n_work, b0.n_perm) == (b1.n_long, b1.n_work, b1.n_perm)
@@ -599,6 +608,39 @@ def test_lookahead_window_bookkeeping_matches_plain_order():
             assert torch.equal(b0.life[:b0.work_start + b0.n_work], b1.life[:b1.work_start + b1.n_work])
     finally:
         MemoryManager._affinity_batch = orig_batch
+        _lib.set_executor_for_testing(prev)
+
+
+def test_announced_frame_overwritten_in_place_is_encoded_again_cpu():
+    """CPU twin (descriptor interpreter) of tests/test_gpu_parity.py::test_announced_frame_overwritten_in_place_is_encoded_again: frames
+    are matched by storage AND tensor version, an announced frame that is overwritten in place goes through its own encoder."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.model.cutie import CUTIE
+    from cutie_amd.utils.synth import SyntheticClip
+    mx = MockExecutor()
+    mx.per_sample_conv = True
+    prev = _lib._executor
+    _lib.set_executor_for_testing(mx)
+    try:
+        net = CUTIE(default_config())
+        net.load_weights(make_state_dict(seed=0))
+        n = 9
+        clip = SyntheticClip(64, 96, 2, n + 1, seed=3)
+        mask = clip.first_mask()
+
+        def run(hinted):
+            frames = [clip.frame(t) for t in range(n)]
+            proc = InferenceCore(net, cfg=default_config(mem_every=3))
+            outs = []
+            for t in range(n):
+                if t == 2:
+                    frames[5].copy_(clip.frame(n))
+                kw = dict(next_images=frames[t + 1:t + 9]) if hinted and t + 1 < n else {}
+                outs.append(proc.step(frames[t], *((mask,) if t == 0 else ()), **(dict(objects=clip.objects) if t == 0 else {}), **kw))
+            return torch.stack(outs)
+        plain, got = run(False), run(True)                       # (no inference_mode: the frames keep their version counters)
+        assert torch.equal(got, plain)
+    finally:
         _lib.set_executor_for_testing(prev)
 
 
@@ -639,3 +681,15 @@ def test_slot_pool_drops_idle_groups():
         b = pool.get(('b',), spec, 'cpu')['x']
     assert ('a',) not in pool.groups and ('b',) in pool.groups and ('a',) not in pool.last_used
     assert a.shape == (4, 4)                                  # (a caller that still holds a tensor keeps it)
+
+
+def test_trajectory_without_lds_dma_tiles():
+    """ADVICE r04: $CUTIE_AMD_DMA_TILES=0 (a documented A/B switch) puts every conv on a register-staged tile, which carries no side jobs;
+    the plan variant that skips QUERY_INIT used to hang the clearing of its accumulators on the first conv regardless and died on the
+    second read-out.  The switch is read at import time, hence a child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, CUTIE_AMD_DMA_TILES='0')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k', 'test_trajectory_matches_oracle and small_fifo',
+                        '-p', 'no:cacheprovider'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
