@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
     // a quarter of their bytes.  Same LDS image, same reads, same bits.
     const int sr8 = lane >> 3, c8l = lane & 7;
     au32x4 st[8];
-    float st_sc = 0.f, st_pad = 0.f;
+    float st_sc = 0.f;
+    int st_nv = 0;
     f32x4 gq[AFF_NQ];                                                   // pass-0 maxima of the NEXT group's 4 tiles (mode 1 + skip)
 #pragma unroll
     for (int u = 0; u < AFF_NQ; ++u) gq[u] = (f32x4){INFINITY, INFINITY, INFINITY, INFINITY};
@@ -234,9 +235,8 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
         }                                                                                                  \
         /* the per-token scale rides along: a global load inside the MFMA loop would make every tile wait for this whole */ \
         /* prefetch (vmcnt is in-order); unconditional load of a clamped row, selected afterwards */       \
-        const float sc_ = p.scale[slot0_ + min(l15, nv_ - 1)];                                             \
-        st_sc = l15 < nv_ ? sc_ : 0.f;                                                                     \
-        st_pad = l15 < nv_ ? 0.f : -INFINITY;                                                              \
+        st_sc = p.scale[slot0_ + min(l15, nv_ - 1)];           /* (looked at in AFF_STORE: a select here waits for it) */ \
+        st_nv = nv_;                                                                                       \
         if (skip) {                                                                                        \
             _Pragma("unroll") for (int u = 0; u < AFF_NQ; ++u)                                             \
                 gq[u] = *reinterpret_cast<const f32x4*>(gmax_p + (long)min(jq[u], p.HWp - 1) * p.Gld + (GRP)); \
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
             lds[BUF][row_ * 16 + ch_] = st[e];                                                             \
             lds[BUF][1024 + row_ * 16 + ch_] = st[4 + e];                                                  \
         }                                                                                                  \
-        if (l4 == 0) { lsc[BUF][wave * 16 + l15] = st_sc; lpad[BUF][wave * 16 + l15] = st_pad; }           \
+        if (l4 == 0) { lsc[BUF][wave * 16 + l15] = l15 < st_nv ? st_sc : 0.f; lpad[BUF][wave * 16 + l15] = l15 < st_nv ? 0.f : -INFINITY; } \
     }
     f32x4 gcur[AFF_NQ];
     // Prologue order (round 4): the first memory group's loads are in flight BEFORE the query operand is pulled through LDS, so the
@@ -259,6 +259,9 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
     // old order for the in-box A/B.
 #ifndef AFF_OLD_PROLOGUE
     AFF_LOAD(g0);
+    // (the machine scheduler otherwise sinks the last operand load and the scale load of the group behind the first waits of the query
+    // copy below -- a second round trip in front of the first MFMA; tests/test_isa_guard_cpu.py)
+    __builtin_amdgcn_sched_barrier(0);
 #endif
     // The block's query operand (64*AFF_NQ rows x [hi|lo] x 256 B) is one contiguous run per array: copy it through LDS
     // with whole-line loads (fragment-shaped global loads touch 16 half-used lines per instruction and were most of this

@@ -633,30 +633,38 @@ class MemoryManager:
         assert b.n_long + P <= b.L, ('long-term region overrun', b.n_long, P, b.L)
         ws = b.work_start
         ol = O.OpList()
+        K = len(b.objects)
         order = self._buf('proto_order', (P,), torch.int32, dev)
-        ol.rank_select(b.use[ws:], b.life[ws:], order, n=n, k=P)                          # topk(usage, P) (:339)
-        dst = b.n_long                                                                    # prototypes appended to the LT region
-        ol.gather_rows(b.rawkey[ws:], order, b.rawkey[dst:], k=P, rowbytes=4 * b.CK, src_stride=4 * b.CK, dst_stride=4 * b.CK)
         psel = self._buf('proto_sel', (P, b.CK), F32, dev)
-        ol.gather_rows(b.rawsel[ws:], order, psel, k=P, rowbytes=4 * b.CK, src_stride=4 * b.CK, dst_stride=4 * b.CK)
-        aff = self._buf('consol_aff', (P, n), F32, dev)
-        ol.consol_aff(b.rawkey[ws:], b.rawshr[ws:], b.rawkey[dst:], psel, aff, n=n, P=P)     # potentiation (:347-350)
-        for o in b.objects:
-            ol.consol_read(aff, b.values[o][ws:], b.values[o][dst:], n=n, P=P, C=b.CV, ldv=b.CV, ldo=b.CV,
-                           scratch=self._buf('consol_part', (16 * P * b.CV,), F32, dev))
-        ol.consol_read(aff, b.rawshr[ws:], b.rawshr[dst:], n=n, P=P, C=1, ldv=1, ldo=1, f32=True)
+        colmax = self._buf('consol_colmax', (P,), torch.int32, dev)
+        ldS = O.OpList.consol_lds(n)
+        S = self._buf_rows('consol_S', P * ldS, (), F32, dev)
+        dst = b.n_long                                                                    # prototypes appended to the LT region
+        # topk(usage, P) (:339); the launch that scatters the order also gathers the prototypes' keys (into the LT region) and
+        # selections through it (:341-345) and clears the column maxima of the similarity pass
+        ol.rank_select(b.use[ws:], b.life[ws:], order, n=n, k=P, scratch=self._buf_rows('rank_scratch', O.OpList.RS_SPLIT * n, (), torch.int32, dev),
+                       gathers=[(b.rawkey[ws:], b.rawkey[dst:], 4 * b.CK), (b.rawsel[ws:], psel, 4 * b.CK)], zero=(colmax, P))
+        # potentiation (:347-356): similarities candidates x prototypes, softmax over the candidates, applied to the values of every
+        # object and to the shrinkage -- three launches (csrc/bank.hip)
+        ol.consol_aff(b.rawkey[ws:], b.rawshr[ws:], b.rawkey[dst:], psel, S, colmax, n=n, P=P)
+        ol.consol_read(S, colmax, b.vptrs(), b.rawshr[ws:], self._buf_rows('consol_part', O.OpList.consol_scratch_floats(n, P, b.CV, K), (), F32, dev),
+                       b.rawshr[dst:], n=n, P=P, C=b.CV, K=K, src=ws, dst=dst)
         ol.key_prep(b.rawkey[dst:], b.rawshr[dst:], b.Ahi[dst:], b.Alo[dst:], b.scale[dst:], n=P, query=False)
-        ol.memset32(b.use[dst:], P, 0)
-        ol.memset32(b.life[dst:], P, LIFE_EPS_BITS)
-        # drop the consolidated tokens: keep the newest min_work_tokens, moved to the region start
-        # (COPY2D is a parallel copy: source and destination must not overlap.  When fewer tokens are dropped than kept --
-        # min_mem_frames > max_mem_frames / 2 -- the move is issued as stream-ordered chunks of at most n rows, ascending, so
-        # that every chunk's destination ends where its source begins.)
+        fills = [(b.use[dst:], P, 0), (b.life[dst:], P, LIFE_EPS_BITS)]
+        # drop the consolidated tokens: keep the newest min_work_tokens, moved to the region start.  The copies are parallel: source and
+        # destination must not overlap.  Fewer tokens kept than dropped (the default: 4 of 9 frames stay): every array in one go, six
+        # arrays per launch, the counters of the new prototypes set by the first of them.  Otherwise -- min_mem_frames > max_mem_frames / 2
+        # -- the move is issued as stream-ordered chunks of at most n rows, ascending, so that every chunk's destination ends where its
+        # source begins.
         keep = self.min_work_tokens
-        for t, rowbytes in b.arrays():
-            for c0 in range(0, keep, n):
-                nb = rowbytes * min(n, keep - c0)
-                ol.copy2d(t[ws + n + c0:], t[ws + c0:], rows=1, rowbytes=nb, src_stride=nb, dst_stride=nb)
+        if keep <= n and BANK_WRITE:
+            ol.bank_write([(t[ws + n:], t[ws:], rowbytes * keep) for t, rowbytes in b.arrays()] if keep > 0 else [], fills)
+        else:
+            ol.bank_write([], fills)
+            for t, rowbytes in b.arrays():
+                for c0 in range(0, keep, n):
+                    nb = rowbytes * min(n, keep - c0)
+                    ol.copy2d(t[ws + n + c0:], t[ws + c0:], rows=1, rowbytes=nb, src_stride=nb, dst_stride=nb)
         ol.run()
         b.n_long += P
         b.n_work = keep

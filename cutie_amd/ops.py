@@ -646,18 +646,39 @@ class OpList:
         """life[:n] += 1, life2[:n2] += 1, use[:n_use] += delta[:n_use] -- one launch (any part may be absent)."""
         return self.add(USAGE_TICK, 0, [n, n2, n_use], [], [life, life2, use, delta])
 
-    def rank_select(self, use, life, order, *, n, k):
-        return self.add(RANK_SELECT, 0, [n, k], [], [use, life, order])
+    RS_SPLIT = 16             # chunks of the all-pairs rank count (csrc/bank.hip)
+
+    def rank_select(self, use, life, order, *, n, k, scratch=None, gathers=(), zero=None):
+        """scratch: i32 [16 * n] partial ranks (allocated here when not given); gathers: up to two (src, dst, row bytes) -- dst[r] =
+        src[order[r]] for r < k, done by the launch that scatters the order; zero = (u32 buffer, words) cleared by that launch."""
+        if scratch is None:
+            scratch = torch.empty((self.RS_SPLIT * n,), dtype=torch.int32, device=use.device)
+            self.keep.append(scratch)
+        gathers = list(gathers) + [(None, None, 0)] * (2 - len(gathers))
+        assert len(gathers) == 2 and all(g[2] % 16 == 0 for g in gathers)
+        z = zero if zero is not None else (None, 0)
+        return self.add(RANK_SELECT, 0, [n, k, gathers[0][2] // 4, gathers[1][2] // 4, z[1]], [],
+                        [use, life, order, scratch, gathers[0][0], gathers[0][1], gathers[1][0], gathers[1][1], z[0]])
 
     def gather_rows(self, src, order, dst, *, k, rowbytes, src_stride, dst_stride):
         return self.add(GATHER_ROWS, 0, [k, rowbytes, src_stride, dst_stride], [], [src, order, dst])
 
-    def consol_aff(self, ckey, cshr, pkey, psel, aff, *, n, P):
-        return self.add(CONSOL_AFF, 0, [n, P], [], [ckey, cshr, pkey, psel, aff])
+    @staticmethod
+    def consol_lds(n):
+        """Row length of the similarity matrix of a consolidation: n rounded up to a multiple of 32."""
+        return -(-n // 32) * 32
 
-    def consol_read(self, aff, V, out, *, n, P, C, ldv, ldo, f32=False, scratch=None):
-        """scratch: f32 [16 * P * C] -> split-n fast path for bf16 value banks."""
-        return self.add(CONSOL_READ, 1 if f32 else 0, [n, P, C, ldv, ldo], [], [aff, V, out, scratch])
+    def consol_aff(self, ckey, cshr, pkey, psel, S, colmax, *, n, P):
+        """S f32 [P, consol_lds(n)] (similarities, -inf in the padding), colmax u32 [P] (cleared by the caller)."""
+        return self.add(CONSOL_AFF, 0, [n, P, self.consol_lds(n)], [], [ckey, cshr, pkey, psel, S, colmax])
+
+    @staticmethod
+    def consol_scratch_floats(n, P, C, K):
+        nchunk = -(-OpList.consol_lds(n) // 256)
+        return nchunk * (K * P * C + 2 * P)
+
+    def consol_read(self, S, colmax, vptrs, cshr, scratch, out_shr, *, n, P, C, K, src, dst):
+        return self.add(CONSOL_READ, 0, [n, P, C, K, self.consol_lds(n), src, dst], [], [S, colmax, vptrs, cshr, scratch, out_shr])
 
     def prob_to_id(self, prob, lut, out, *, P, H, W, plane, ldrow):
         """out dtype picks the kernel: uint8 / int32 / int64."""

@@ -243,18 +243,27 @@ enum {
     CUTIE_OP_USAGE_TICK = 30,
     /* RANK_SELECT: order[r] = index of the r-th largest of use/life (ties -> lower index), r < k
      * torch.topk(usage, k) of memory_manager.py:339 and kv_memory_store.py:222
-     * p0=use f32[n] p1=life f32[n] p2=order i32[k]   i: 0 n 1 k */
+     * p0=use f32[n] p1=life f32[n] p2=order i32[k] p3=scratch i32[16*n] (partial ranks; required since ABI 3)
+     * optional side jobs of the scattering launch: p4/p5, p6/p7 = src/dst of up to two row gathers dst[r,:] = src[order[r],:]
+     * (rows of i2 / i3 32-bit words, multiples of 4: the prototype keys / selections of memory_manager.py:341-345);
+     * p8 = u32 buffer of i4 words cleared (the column maxima of CONSOL_AFF)
+     * i: 0 n 1 k 2 row words of gather 1 3 row words of gather 2 4 words to clear */
     CUTIE_OP_RANK_SELECT = 31,
     /* GATHER_ROWS: dst[r,:] = src[order[r],:]   p0=src p1=order i32 p2=dst  i: 0 k 1 rowbytes 2 src_stride 3 dst_stride */
     CUTIE_OP_GATHER_ROWS = 32,
-    /* CONSOL_AFF: dense-softmax potentiation of long-term consolidation  memory_manager.py:347-350
-     * aff[p,i] = softmax_i( sim(cand_i, proto_p) )   (with max shift, memory_utils.py:68-71)
-     * p0=ckey f32 [n,64] p1=cshr f32 [n] p2=pkey f32 [P,64] p3=psel f32 [P,64] p4=aff f32 [P,n]  i: 0 n 1 P */
+    /* CONSOL_AFF (ABI 3): similarities of long-term consolidation, memory_manager.py:347-350 / memory_utils.py:30-42
+     * S[p,i] = sim(cand_i, proto_p) for i < n, -inf for n <= i < ldS; colmax[p] = max_i S[p,i] as an order-preserving u32 key,
+     * accumulated by atomicMax into a buffer the caller cleared (RANK_SELECT p8)
+     * p0=ckey f32 [n,64] p1=cshr f32 [n] p2=pkey f32 [P,64] p3=psel f32 [P,64] p4=S f32 [P,ldS] p5=colmax u32 [P]
+     * i: 0 n 1 P 2 ldS (multiple of 32, >= n) */
     CUTIE_OP_CONSOL_AFF = 33,
-    /* CONSOL_READ: out[p,:] = sum_i aff[p,i] * V[i,:]    memory_manager.py:352-356
-     * p0=aff f32 [P,n] p1=V (bf16 [n,C], or f32 if flags&1) p2=out (bf16|f32 like V) [P,C]
-     * p3=scratch f32 [16*P*C] (optional: enables the split-n fast path for bf16 V with C % 8 == 0, C <= 256)
-     * i: 0 n 1 P 2 C 3 ldv 4 ldo */
+    /* CONSOL_READ (ABI 3): prototypes = softmax_i(S[p,:]) applied to the candidates' values of every object and to their shrinkage
+     * memory_manager.py:347-356 (softmax over the candidates with max shift, memory_utils.py:68-71; aff @ values)
+     * value rows of object o: candidates at vptrs[o] + (src + i) * C, prototypes written to vptrs[o] + (dst + p) * C (bf16);
+     * out_shr[p] = sum_i softmax(S)[p,i] * cshr[i]
+     * p0=S f32 [P,ldS] p1=colmax u32 [P] p2=vptrs u64 [K] p3=cshr f32 [n] p4=scratch f32 [nchunk * (K*P*C + 2*P)], nchunk = ceil(ldS/256)
+     * p5=out_shr f32 [P] (or 0)
+     * i: 0 n 1 P 2 C (multiple of 128) 3 K 4 ldS 5 src slot 6 dst slot */
     CUTIE_OP_CONSOL_READ = 34,
     /* CAST: f32 [n] -> bf16 [n] (flags=0) or bf16 -> f32 (flags=1)   p0=src p1=dst  i: 0 n */
     CUTIE_OP_CAST = 35,

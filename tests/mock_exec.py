@@ -647,7 +647,14 @@ class MockExecutor:
         n, k = i[:2]
         u = view(p[0], F32, (n,)) / view(p[1], F32, (n,))
         order = sorted(range(n), key=lambda t: (-float(u[t]), t))[:k]
-        view(p[2], I32, (k,)).copy_(torch.tensor(order, dtype=torch.int32))
+        order_t = torch.tensor(order, dtype=torch.int32)
+        view(p[2], I32, (k,)).copy_(order_t)
+        for slot, words in ((4, i[2]), (6, i[3])):                       # side jobs: row gathers through the new order, a cleared buffer
+            if p[slot] and words > 0:
+                src = view(p[slot], I32, (n, words))
+                view(p[slot + 1], I32, (k, words)).copy_(src[order_t.long()].clone())
+        if p[8] and i[4] > 0:
+            view(p[8], I32, (i[4],)).zero_()
 
     def _op_32(self, flags, i, f, p):
         k, rb, ss, ds = i[:4]
@@ -657,21 +664,30 @@ class MockExecutor:
         view(p[2], U8, (k, rb), (ds, 1)).copy_(src[order])
 
     def _op_33(self, flags, i, f, p):
-        n, P = i[:2]
+        """CONSOL_AFF: S[p, i] = similarity of candidate i and prototype p, -inf in the padding up to ldS (the column maxima p5 are an
+        internal hand-over to CONSOL_READ: the interpreter's CONSOL_READ takes its maxima from S)."""
+        n, P, ldS = i[:3]
         ck, cs = view(p[0], F32, (n, 64)), view(p[1], F32, (n,))
         pk, pe = view(p[2], F32, (P, 64)), view(p[3], F32, (P, 64))
         a_sq = (ck * ck) @ pe.t()
         two_ab = 2 * (ck @ (pk * pe).t())
         b_sq = (pe * pk * pk).sum(1)[None, :]
         sim = (-a_sq + two_ab - b_sq) * cs[:, None] * 0.125           # [n,P]
-        view(p[4], F32, (P, n)).copy_(torch.softmax(sim, dim=0).t())
+        S = view(p[4], F32, (P, ldS))
+        S.fill_(float('-inf'))
+        S[:, :n] = sim.t()
 
     def _op_34(self, flags, i, f, p):
-        n, P, C, ldv, ldo = i[:5]
-        aff = view(p[0], F32, (P, n))
-        dt = F32 if flags & 1 else BF16
-        V = view(p[1], dt, (n, C), (ldv, 1)).float()
-        view(p[2], dt, (P, C), (ldo, 1)).copy_(aff @ V)
+        """CONSOL_READ: softmax over the candidates, applied to every object's values and to the shrinkage."""
+        n, P, C, K, ldS, src, dst = i[:7]
+        aff = torch.softmax(view(p[0], F32, (P, ldS))[:, :n], dim=1)
+        vptrs = view(p[2], U64, (K,))
+        for o in range(K):
+            bank = view(int(vptrs[o]), BF16, (max(src + n, dst + P), C))
+            proto = (aff @ bank[src:src + n].float()).to(torch.bfloat16)
+            bank[dst:dst + P] = proto
+        if p[5]:
+            view(p[5], F32, (P,)).copy_(aff @ view(p[3], F32, (n,)))
 
     def _op_41(self, flags, i, f, p):                                   # STEM = IMG_PREP + conv 7x7 s2 p3 (+ bias) + maxpool 3x3 s2 p1 (+ relu)
         h0, w0, H, W, pl, pt, K, Kpad = i[:8]

@@ -1236,9 +1236,11 @@ def test_bank_misc():
     check(*run_both(build), name='bank misc', rtol=1e-6)
 
 
-def test_rank_select_gather():
+@pytest.mark.parametrize('n,k', [(5000, 700), (8100, 128), (9872, 7872), (270, 16), (17, 17)])
+def test_rank_select_gather(n, k):
+    """torch.topk(usage, k) order (ties -> lower index) by split all-pairs counting; row gathers through the order, by GATHER_ROWS and
+    as side jobs of the scattering launch; the cleared side buffer."""
     def build(dev, g):
-        n, k = 5000, 700
         use = torch.rand((n,), generator=g)
         use[::7] = 0.0                                       # ties
         life = torch.rand((n,), generator=g) + 0.5
@@ -1246,35 +1248,58 @@ def test_rank_select_gather():
         use, life = use.to(dev), life.to(dev)
         order = torch.zeros((k,), dtype=torch.int32, device=dev)
         src = torch.randn((n, 64), generator=g).to(dev)
+        src2 = torch.randn((n, 8), generator=g).to(dev)
         dst = torch.zeros((k, 64), dtype=F32, device=dev)
+        side1, side2 = torch.zeros((k, 64), dtype=F32, device=dev), torch.zeros((k, 8), dtype=F32, device=dev)
+        cleared = torch.full((37,), 5, dtype=torch.int32, device=dev)
         ol = O.OpList()
-        ol.rank_select(use, life, order, n=n, k=k)
+        ol.rank_select(use, life, order, n=n, k=k, gathers=[(src, side1, 256), (src2, side2, 32)], zero=(cleared, 30))
         ol.gather_rows(src, order, dst, k=k, rowbytes=256, src_stride=256, dst_stride=256)
-        return ol, {'order': order, 'dst': dst}
+        return ol, {'order': order, 'dst': dst, 'side1': side1, 'side2': side2, 'cleared': cleared, '_use': use, '_life': life}
     hip, ref = run_both(build)
-    assert torch.equal(hip['order'], ref['order'])
-    assert torch.equal(hip['dst'], ref['dst'])
+    for name in ('order', 'dst', 'side1', 'side2', 'cleared'):
+        assert torch.equal(hip[name], ref[name]), name
+    assert torch.equal(hip['side1'], hip['dst'])
+    u = hip['_use'] / hip['_life']
+    assert torch.equal(u[hip['order'].long()], torch.topk(u, k).values)      # the reference's torch.topk values, in its order
 
 
-def test_consolidation_kernels():
+@pytest.mark.parametrize('n,P,K', [(2000, 128, 2), (8100, 128, 3), (270, 16, 1), (1000, 136, 1)])
+def test_consolidation_kernels(n, P, K):
+    """CONSOL_AFF + CONSOL_READ (memory_manager.py:347-356): similarities on fp32 MFMA, softmax over the candidates, prototypes of every
+    object's values (bf16 MFMA on split weights) and of the shrinkage -- against the interpreter's dense fp32 form."""
     def build(dev, g):
-        n, P, C = 2000, 128, 256
+        C, src, dst = 256, 40, 3
         ck = (torch.randn((n, 64), generator=g) * 0.8).to(dev)
         cs = (torch.rand((n,), generator=g) * 2 + 1).to(dev)
         pk = (torch.randn((P, 64), generator=g) * 0.8).to(dev)
+        pk[:P // 2] = ck.cpu()[torch.arange(P // 2) * (n // P)].to(dev)          # prototypes ARE candidates (as in a consolidation): peaked columns
         pe = torch.rand((P, 64), generator=g).to(dev)
-        aff = torch.zeros((P, n), dtype=F32, device=dev)
-        V = rnd(g, (n, C), dev=dev)
-        out = torch.zeros((P, C), dtype=BF16, device=dev)
-        outs = torch.zeros((P,), dtype=F32, device=dev)
+        ldS = O.OpList.consol_lds(n)
+        S = torch.full((P, ldS), 7.0, dtype=F32, device=dev)
+        colmax = torch.zeros((P,), dtype=torch.int32, device=dev)
+        banks = [rnd(g, (src + n + 8, C), dev=dev) for _ in range(K)]
+        before = [b_.clone() for b_ in banks]
+        vptrs = torch.tensor([b_.data_ptr() for b_ in banks], dtype=torch.int64).to(dev)
+        part = torch.zeros((O.OpList.consol_scratch_floats(n, P, C, K),), dtype=F32, device=dev)
+        oshr = torch.zeros((P,), dtype=F32, device=dev)
         ol = O.OpList()
-        ol.consol_aff(ck, cs, pk, pe, aff, n=n, P=P)
-        ol.consol_read(aff, V, out, n=n, P=P, C=C, ldv=C, ldo=C)
-        ol.consol_read(aff, cs, outs, n=n, P=P, C=1, ldv=1, ldo=1, f32=True)
-        out2 = torch.zeros((P, C), dtype=BF16, device=dev)                  # split-n fast path (scratch given)
-        ol.consol_read(aff, V, out2, n=n, P=P, C=C, ldv=C, ldo=C, scratch=torch.zeros(16 * P * C, dtype=F32, device=dev))
-        return ol, {'aff': aff, 'out': out, 'outs': outs, 'out2': out2}
-    check(*run_both(build), name='consolidation', rtol=None)
+        ol.keep += banks
+        ol.consol_aff(ck, cs, pk, pe, S, colmax, n=n, P=P)
+        ol.consol_read(S, colmax, vptrs, cs, part, oshr, n=n, P=P, C=C, K=K, src=src, dst=dst)
+        outs = {'S': S[:, :n], 'pad': S[:, n:], 'oshr': oshr}
+        for o in range(K):
+            outs[f'proto{o}'] = banks[o][dst:dst + P]
+            outs[f'rest{o}'] = banks[o][dst + P:]
+            outs[f'_rest_before{o}'] = before[o][dst + P:]
+        return ol, outs
+    hip, ref = run_both(build)
+    assert bool(torch.isinf(hip['pad']).all()) and bool((hip['pad'] < 0).all())
+    check({'S': hip['S']}, {'S': ref['S']}, 'consol sim', rtol=2e-5)
+    check({'oshr': hip['oshr']}, {'oshr': ref['oshr']}, 'consol shrinkage', rtol=1e-4)
+    for o in range(K):
+        check({'p': hip[f'proto{o}']}, {'p': ref[f'proto{o}']}, f'consol values {o}', rtol=6e-3)      # bf16 results: half an ulp of rounding
+        assert torch.equal(hip[f'rest{o}'].view(torch.int16), hip[f'_rest_before{o}'].view(torch.int16))      # nothing else in the bank is touched
 
 
 @pytest.mark.parametrize('dt', [torch.uint8, torch.int32, torch.int64])

@@ -167,9 +167,11 @@ def test_bike_argmax_decisive():
     """north_star: "bit-exact argmax object IDs on the bike example".  Under the DECISIVE weights (tests/golden/decisive_delta.npz: the
     synthetic state dict with a fitted mask-decoder head, oracle/make_decisive_weights.py; pinned to the executed reference by the
     `bike_decisive` golden scenario) the oracle's top-1 / top-2 margin exceeds 0.33 on >= 95 % of the pixels of every bike frame, so the
-    comparison means something everywhere: identical object ids on >= 99.5 % of ALL pixels of every frame, and on every pixel whose
-    margin exceeds the tolerance."""
-    _bike_argmax(S.decisive_state_dict(), min_agree_all=0.995, min_decisive=0.95, tag='bike decisive')
+    comparison means something everywhere: identical object ids on >= 99.8 % of ALL pixels of every frame (round 5: the floor follows what
+    round 4 observed, 726 differing pixels of 409 920 on the worst frame, all of them near-tied -- the honest limit of bf16 storage), on
+    every pixel whose margin exceeds the tolerance, and the COUNT of differing pixels per frame is printed and held to 1.1 x the count of
+    the frozen round-4 record (tests/golden/observed_r04.json)."""
+    _bike_argmax(S.decisive_state_dict(), min_agree_all=0.998, min_decisive=0.95, tag='bike decisive')
 
 
 def _bike_argmax(sd, min_agree_all=0.97, min_decisive=0.0, tag=None):
@@ -183,7 +185,7 @@ def _bike_argmax(sd, min_agree_all=0.97, min_decisive=0.0, tag=None):
     over = S.SCENARIOS['bike']['cfg']
     oproc = OracleProcessor(onet, dict(DEFAULT_CFG, **over))
     proc = InferenceCore(net, cfg=default_config(**over))
-    worst = 1.0
+    worst, worst_count, npix = 1.0, 0, 1
     with torch.inference_mode():
         for t, (img, mask, objs) in enumerate(steps):
             if mask is not None:
@@ -197,8 +199,11 @@ def _bike_argmax(sd, min_agree_all=0.97, min_decisive=0.0, tag=None):
             confident = (top2[0] - top2[1]) > BMARGIN
             agree = proc.output_prob_to_mask(p.cuda()).cpu() == oproc.output_prob_to_mask(o)
             cover = float(confident.float().mean())
+            ndiff = int((~agree).sum())
             print(f'bike frame {t}: decisive pixels {cover:.4f}, argmax agreement on them {float(agree[confident].float().mean()):.6f}, '
-                  f'on all pixels {float(agree.float().mean()):.6f}')
+                  f'on all pixels {float(agree.float().mean()):.6f} = {ndiff} differing pixels of {agree.numel()}')
+            worst_count = max(worst_count, ndiff)
+            npix = agree.numel()
             assert float(agree.float().mean()) >= min_agree_all, (t, float(agree.float().mean()))
             # every decisive pixel; under the decisive weights that is ~99 % of a frame, a free-running one: a single pixel in 10^4 may sit
             # right at the margin after four frames (observed with an experimental build: 1 of 405 000)
@@ -212,6 +217,9 @@ def _bike_argmax(sd, min_agree_all=0.97, min_decisive=0.0, tag=None):
             json.dump(T._recorded, open(T._RECORD, 'w'), indent=1, sort_keys=True)
         if tag in T.OBSERVED and 'agree_all' in T.OBSERVED[tag]:
             assert worst >= T.OBSERVED[tag]['agree_all'] - 2e-3, ('ratchet', tag, worst, T.OBSERVED[tag])
+            recorded = round((1.0 - T.OBSERVED[tag]['agree_all']) * npix)          # differing pixels of the worst frame in the frozen record
+            print(f'{tag}: worst frame {worst_count} differing pixels (frozen record: {recorded})')
+            assert worst_count <= int(1.1 * recorded) + 1, ('count ratchet', tag, worst_count, recorded)
 
 
 def test_bike_argmax_real_checkpoint():

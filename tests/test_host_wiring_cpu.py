@@ -687,6 +687,7 @@ def test_trajectory_without_lds_dma_tiles():
     """ADVICE r04: $CUTIE_AMD_DMA_TILES=0 (a documented A/B switch) puts every conv on a register-staged tile, which carries no side jobs;
     the plan variant that skips QUERY_INIT used to hang the clearing of its accumulators on the first conv regardless and died on the
     second read-out.  The switch is read at import time, hence a child process."""
+    import os
     import subprocess
     import sys
     env = dict(os.environ, CUTIE_AMD_DMA_TILES='0')
