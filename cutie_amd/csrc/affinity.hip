@@ -1041,7 +1041,8 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             // follow: 520 blocks on 512 slots whenever the last row was not short -- the eight late blocks doubled the launch (stacked
             // frames: 160 us for 4 x 29 us of work, tools/r5_call2.sh).  At least 8 tiles per block: the block prologue (its query
             // operand, 64 KB through LDS) is amortised over the tiles.
-            const int resident = (nq == 4 && pass == 1) ? 256 : 512;    // (aff_score4_kernel<1> needs > 256 registers: one block per CU)
+            int resident = (nq == 4 && pass == 1) ? 256 : 512;    // (aff_score4_kernel<1> needs > 256 registers: one block per CU)
+            if (i[14] > 0) resident = 256;                              // (extra LDS requested: one block per CU)
             const int NG = (G + AFF_TG - 1) / AFF_TG;
             int ny = resident / qb;
             if (ny > NG / 2) ny = NG / 2;

@@ -989,8 +989,10 @@ __global__ void query_init_kernel(const float* __restrict__ om, float* __restric
 // SUMMARIZE: grid (C/64, K, ceil(HW/128)); block 256 = 4 pixel slices x 64 channels over a 128-pixel chunk; the
 // per-pixel weights sigmoid(logit)*mask are computed once per block into LDS; per-chunk partial sums go to
 // part[k][chunk][q][C+1] and are summed in chunk order by summarize_final_kernel (deterministic, no float atomics).
-__global__ __launch_bounds__(256) void summarize_kernel(const bf16_t* __restrict__ feat, const float* __restrict__ wl,
-                                                        const float* __restrict__ m16, float* __restrict__ y, int HW, int C, int Q) {
+// F32: the features are fp32 with a row stride of ldf elements (one conv output [feature | weight logits], ldw = its row stride too)
+template <bool F32>
+__global__ __launch_bounds__(256) void summarize_kernel(const void* __restrict__ feat_, const float* __restrict__ wl,
+                                                        const float* __restrict__ m16, float* __restrict__ y, int HW, int C, int Q, int ldf, int ldw) {
     __shared__ float wsm[128][17];
     __shared__ float red[4][64][17];
     const int k = blockIdx.y, cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, s = threadIdx.x >> 6;
@@ -1001,7 +1003,7 @@ __global__ __launch_bounds__(256) void summarize_kernel(const bf16_t* __restrict
         if (p < HW) {
             long row = (long)k * HW + p;
             float m = m16[row];
-            wgt = (1.f / (1.f + expf(-wl[row * Q + q]))) * (q < 8 ? m : 1.f - m);
+            wgt = (1.f / (1.f + expf(-wl[row * ldw + q]))) * (q < 8 ? m : 1.f - m);
         }
         wsm[pp][q] = wgt;
     }
@@ -1010,13 +1012,23 @@ __global__ __launch_bounds__(256) void summarize_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     float area = 0.f;
-    for (int pp = s; pp < 128; pp += 4) {
-        int p = p0 + pp;
-        if (p >= HW) break;
-        float f = bf2f(feat[((long)k * HW + p) * C + c]);
+    // the thread's 32 feature values are requested together (clamped rows, looked at behind the loads): the loop used to issue one
+    // global load per iteration and wait for it -- 32 dependent round trips, 40 us for a launch that moves 2.5 MB (profiles/r05_frame_chain.md)
+    float fv[32];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] += wsm[pp][q] * f;
-        if (cl < 16) area += wsm[pp][cl];
+    for (int it = 0; it < 32; ++it) {
+        const int p = min(p0 + s + 4 * it, HW - 1);
+        const long fo = ((long)k * HW + p) * ldf + c;
+        fv[it] = F32 ? reinterpret_cast<const float*>(feat_)[fo] : bf2f(reinterpret_cast<const bf16_t*>(feat_)[fo]);
+    }
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+        const int pp = s + 4 * it;
+        if (p0 + pp < HW) {                                     // (same additions in the same order as the rolled loop)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] += wsm[pp][q] * fv[it];
+            if (cl < 16) area += wsm[pp][cl];
+        }
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) red[s][cl][q] = acc[q];
@@ -1328,7 +1340,9 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             {
                 if (!p[4]) { cutie_set_error("summarize: scratch buffer required"); return -2; }
                 int nchunk = (i[1] + 127) / 128, n = i[3] * (i[2] + 1);
-                hipLaunchKernelGGL(summarize_kernel, dim3(i[2] / 64, i[0], nchunk), dim3(256), 0, s, (const bf16_t*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[4], i[1], i[2], i[3]);
+                const int ldf = i[4] > 0 ? i[4] : i[2], ldw = i[5] > 0 ? i[5] : i[3];
+                if (op->flags & 1) hipLaunchKernelGGL(summarize_kernel<true>, dim3(i[2] / 64, i[0], nchunk), dim3(256), 0, s, (const void*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[4], i[1], i[2], i[3], ldf, ldw);
+                else hipLaunchKernelGGL(summarize_kernel<false>, dim3(i[2] / 64, i[0], nchunk), dim3(256), 0, s, (const void*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[4], i[1], i[2], i[3], ldf, ldw);
                 hipLaunchKernelGGL(summarize_final_kernel, dim3((n + 255) / 256, i[0]), dim3(256), 0, s, (const float*)p[4], (float*)p[3], nchunk, n);
             }
             break;

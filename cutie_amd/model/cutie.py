@@ -174,6 +174,22 @@ class Engine:
         u = 'object_summarizer'
         for name in ('.input_proj', '.feature_pred.0', '.feature_pred.2', '.weights_pred.0', '.weights_pred.2'):
             W[u + name] = linear_as_conv(sd[u + name + '.weight'], sd[u + name + '.bias'], dev)
+        # The summarizer's five per-pixel linears as TWO launches (round 5; object_summarizer.py:55-89).  input_proj feeds nothing but the
+        # first layers of the two MLPs (feature_pred.0, weights_pred.0), and the positional encoding is added in between, so the maps are
+        # composed in fp32: [f1 | w1] = relu(W0 W_in value + W0 (b_in + PE) + b0), W0 = [Wf0 ; Ww0] -- one conv value -> 2C channels with the
+        # PE term as a per-pixel broadcast residual (Engine.pe_sum).  The second layers are one block-diagonal conv [f1 | w1] ->
+        # [feature (C) | weight logits (Q)], stored in fp32 (the reference's fp32 island), read by SUMMARIZE with a row stride.
+        w_in, b_in = sd[u + '.input_proj.weight'].float(), sd[u + '.input_proj.bias'].float()
+        w0 = torch.cat([sd[u + '.feature_pred.0.weight'].float(), sd[u + '.weights_pred.0.weight'].float()], 0)
+        b0 = torch.cat([sd[u + '.feature_pred.0.bias'].float(), sd[u + '.weights_pred.0.bias'].float()], 0)
+        self._sum_w0 = w0
+        W[u + '.in_fw0'] = linear_as_conv(w0 @ w_in, b0 + w0 @ b_in, dev)
+        wf2, ww2 = sd[u + '.feature_pred.2.weight'].float(), sd[u + '.weights_pred.2.weight'].float()
+        cf, cw = wf2.shape[1], ww2.shape[1]
+        w2 = torch.zeros(wf2.shape[0] + ww2.shape[0], cf + cw)
+        w2[:wf2.shape[0], :cf] = wf2
+        w2[wf2.shape[0]:, cf:] = ww2
+        W[u + '.fw2'] = linear_as_conv(w2, torch.cat([sd[u + '.feature_pred.2.bias'].float(), sd[u + '.weights_pred.2.bias'].float()], 0), dev)
 
     def pe(self, h, w):
         """bf16 [h*w, C] positional encoding (both PositionalEncoding instances use the same formula)."""
@@ -207,6 +223,14 @@ class Engine:
             e = plans.positional_encoding(h, w, self.m['embed_dim'], self.m['pixel_pe_scale'], self.m['pixel_pe_temperature'])
             e = e.reshape(h * w, -1).float()
             self._pe[key] = (e @ self._pe_wb[b].t()).to(BF16).to(self.device).contiguous()
+        return self._pe[key]
+
+    def pe_sum(self, h, w):
+        """bf16 [h*w, 2C]: [Wf0 ; Ww0] PE -- the broadcast residual of the summarizer's composed first conv (Engine: '.in_fw0')."""
+        key = ('pe_sum', h, w)
+        if key not in self._pe:
+            e = plans.positional_encoding(h, w, self.m['embed_dim'], self.m['pixel_pe_scale'], self.m['pixel_pe_temperature'])
+            self._pe[key] = (e.reshape(h * w, -1).float() @ self._sum_w0.t()).to(BF16).to(self.device).contiguous()
         return self._pe[key]
 
     def rep_embedding(self, which, K):
@@ -552,8 +576,12 @@ class CUTIE(nn.Module):
         pix = nhwc_of(ms_features)
         sf, sb = self._sensory_pair(sensory)
         mk = masks[0].to(F32).contiguous()
-        P = eng.plan(('emask', K, h0, w0, H, W, pl, pt, bool(deep_update)), plans.build_encode_mask, K, h0, w0, H, W, pl, pt,
-                     bool(deep_update))
+        # MASK_DOWN(masks) is already there when these masks are the probabilities the last segment() returned (every memory frame of a
+        # propagation): its up-sampling launch left them for the next frame's pixel fusion (see segment / pixel_fusion)
+        md = frame_context.recall('mask_down', mk)
+        md = md is not None and md == (K, h, w, eng.__dict__.get('_md_gen')) and plans.SUM_FUSED and not plans.UNFUSED
+        P = eng.plan(('emask', K, h0, w0, H, W, pl, pt, bool(deep_update), md), plans.build_encode_mask, K, h0, w0, H, W, pl, pt,
+                     bool(deep_update), md)
         o = eng.pool.get(('emask', K, h, w, str(dev)),
                          dict(value=((K, h, w, self.value_dim), BF16, False),
                               summ=((K, self.model_cfg['object_summarizer']['num_summaries'], self.embed_dim + 1), F32, False)), dev)

@@ -68,6 +68,8 @@ QFFN_SLICE = int(os.environ.get('CUTIE_AMD_QFFN_SLICE', '64'))       # hidden co
 # of one conv x -> [pixel | R_0 | R_1 | R_2] in front of the blocks (A/B switch)
 PROJ_X = os.environ.get('CUTIE_AMD_PROJ_X', '1') not in ('', '0')
 SEG_FORK = os.environ.get('CUTIE_AMD_SEG_FORK', '1') not in ('', '0')
+# the object summarizer's five per-pixel linears as two composed launches (A/B switch; Engine '.in_fw0' / '.fw2')
+SUM_FUSED = os.environ.get('CUTIE_AMD_SUM_FUSED', '1') not in ('', '0')
 # MASK_DOWN of the next frame's pixel fusion inside the up-sampling launch of the current one (A/B switch)
 SEG_MD = os.environ.get('CUTIE_AMD_SEG_MD', '1') not in ('', '0')
 # read_from_query's output projection + residual inside the ATTN_P2Q launch (csrc/qchain.hip: p2q_out_kernel).  Bit-identical and OFF: the
@@ -808,7 +810,7 @@ def build_segment(eng, K, h, w, update_sensory, pre=False, md=False):
     return P
 
 
-def build_encode_mask(eng, K, h0, w0, H, W, pad_left, pad_top, deep_update=True):
+def build_encode_mask(eng, K, h0, w0, H, W, pad_left, pad_top, deep_update=True, pre_md=False):
     """CUTIE.encode_mask -> MaskEncoder.forward + ObjectSummarizer.forward (cutie.py:66-90;
     big_modules.py:122-182; object_summarizer.py:55-89).
     dyn in: image f32 [3,h0,w0], masks f32 [K,H,W], pix_feat, sensory_f32/sensory_bf16 (in-place deep update).
@@ -837,9 +839,19 @@ def build_encode_mask(eng, K, h0, w0, H, W, pad_left, pad_top, deep_update=True)
                       out_f32=True, name='gru_vals')
         ol.gru(vals.t, Dyn('sensory_f32'), Dyn('sensory_bf16'), n=K * h * w, C=CS)
     # object summarizer
-    pair = P.buf('pair', (K, h, w, 8))
-    m16 = P.buf('m16', (K, h, w), F32)
-    ol.mask_down(Dyn('masks'), pair, m16, K=K, H=H, W=W)
+    if pre_md:                                           # written by the last segment's up-sampling launch (build_segment(md=True)): these very masks
+        m16 = eng.mask_down_bufs(K, h, w)[1]
+    else:
+        pair = P.buf('pair', (K, h, w, 8))
+        m16 = P.buf('m16', (K, h, w), F32)
+        ol.mask_down(Dyn('masks'), pair, m16, K=K, H=H, W=W)
+    if SUM_FUSED and not UNFUSED:
+        # two launches instead of five (Engine: '.in_fw0', '.fw2'): value -> [f1 | w1] with the composed weights, then the block-diagonal
+        # second layers -> fp32 [feature | weight logits]
+        fw1 = P.conv('object_summarizer.in_fw0', value, res=Act(eng.pe_sum(h, w), 1, h, w, 2 * CE), res_bcast=True, act=O.ACT_RELU, name='sum.fw1')
+        fw2 = P.conv('object_summarizer.fw2', fw1, out_f32=True, name='sum.fw2')
+        ol.summarize(fw2.t, fw2.t.view(-1)[CE:], m16, Dyn('summ'), K=K, HW=h * w, C=CE, Q=Q, feat_f32=True, ldf=CE + Q, ldw=CE + Q)
+        return P
     pe = Act(eng.pe(h, w), 1, h, w, CE)
     v1 = P.conv('object_summarizer.input_proj', value, res=pe, res_bcast=True, name='sum.v1')
     f1 = P.conv('object_summarizer.feature_pred.0', v1, act=O.ACT_RELU, name='sum.f1')

@@ -565,10 +565,12 @@ class OpList:
             ptrs[10], ptrs[11] = acc_in[0], acc_in[1]
         return self.add(QFFN, 0, ints, [], ptrs)
 
-    def summarize(self, feat, wl, m16, y, *, K, HW, C, Q, scratch=None):
+    def summarize(self, feat, wl, m16, y, *, K, HW, C, Q, scratch=None, feat_f32=False, ldf=None, ldw=None):
+        """feat_f32 / ldf / ldw: the features in fp32 with a row stride of ldf elements, the weight logits with a row stride of ldw (both
+        live in one conv output [feature | logits]); default: bf16 [K*HW, C] and f32 [K*HW, Q]."""
         if scratch is None:
             scratch = torch.zeros((K, -(-HW // 128), Q, C + 1), dtype=torch.float32, device=m16.device)
-        return self.add(SUMMARIZE, 0, [K, HW, C, Q], [], [feat, wl, m16, y, scratch])
+        return self.add(SUMMARIZE, 1 if feat_f32 else 0, [K, HW, C, Q, C if ldf is None else ldf, Q if ldw is None else ldw], [], [feat, wl, m16, y, scratch])
 
     def add_pe(self, x, pe, y, *, B, n):
         return self.add(ADD_PE, 0, [B, n], [], [x, pe, y])
@@ -582,7 +584,7 @@ class OpList:
     AFF_NQ = int(os.environ.get('CUTIE_AMD_AFF_NQ', '2'))      # 16-query column sets per wave of AFF_SCORE (1, 2: aff_score_kernel; 4: aff_score4_kernel)
 
     def aff_score(self, Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count, *, HW, HWp, ranges, cap, mode, gmax_precedes_tau=False, nq=None, dma=None,
-                  frames=1):
+                  frames=1, extra_lds_kb=0):
         """gmax_precedes_tau (mode 1): `out` (= tau) sits right behind the [HWp, Gld] maxima of pass 0 in memory; the kernel then
         skips every (tile, 16-query set) that cannot hold a candidate.  nq: query column sets per wave (default AFF_NQ; every
         choice computes the same bits).  frames > 1: the query operands of that many frames, HWp rows each (HW real ones), stacked -- every
@@ -593,7 +595,7 @@ class OpList:
         ints = [HW, HWp, len(ranges)]
         for r in range(3):
             ints += list(ranges[r]) if r < len(ranges) else [0, 0]
-        ints += [G, cap, mode, self.AFF_NQ if nq is None else nq, 0, 0, self.AFF_DMA if dma is None else int(dma)]
+        ints += [G, cap, mode, self.AFF_NQ if nq is None else nq, 0, int(extra_lds_kb), self.AFF_DMA if dma is None else int(dma)]
         if frames > 1:
             ints[1] = frames * HWp
             ints += [HWp]

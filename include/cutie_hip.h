@@ -193,7 +193,9 @@ enum {
     /* SUMMARIZE: weights=sigmoid(logits)*[m x8 | (1-m) x8]; sums=einsum; area   object_summarizer.py:11-23
      * p0=feature bf16 [K,HW,C] p1=wlogits f32 [K,HW,Q] p2=m16 f32 [K,HW] p3=y f32 [K,Q,C+1]
      * p4=scratch f32 [K,ceil(HW/128),Q,C+1] (deterministic 2-stage sum)
-     * i: 0 K 1 HW 2 C 3 Q */
+     * flags&1: p0 is f32 with a row stride of i4 elements (0 = C); i5 = row stride of the logits (0 = Q) -- both read from one conv output
+     * [feature | logits] (ABI 3)
+     * i: 0 K 1 HW 2 C 3 Q 4 ldf 5 ldw */
     CUTIE_OP_SUMMARIZE = 21,
     /* ADD_PE: y = x + pe (broadcast over objects), bf16     object_summarizer.py:74-76
      * p0=x bf16 [B,HW,C] p1=pe bf16 [HW,C] p2=y   i: 0 B 1 HW*C */

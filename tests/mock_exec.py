@@ -474,8 +474,9 @@ class MockExecutor:
     # ---- SUMMARIZE / ADD_PE ---------------------------------------------------------------------------------
     def _op_21(self, flags, i, f, p):
         K, HW, C, Q = i[:4]
-        feat = view(p[0], BF16, (K, HW, C)).float()
-        wl = view(p[1], F32, (K, HW, Q))
+        ldf, ldw = (i[4] or C), (i[5] or Q)
+        feat = view(p[0], F32 if flags & 1 else BF16, (K, HW, C), (HW * ldf, ldf, 1)).float()
+        wl = view(p[1], F32, (K, HW, Q), (HW * ldw, ldw, 1))
         m = view(p[2], F32, (K, HW)).unsqueeze(-1)
         rep = torch.cat([m.expand(-1, -1, Q // 2), (1 - m).expand(-1, -1, Q // 2)], -1)
         wgt = torch.sigmoid(wl) * rep
