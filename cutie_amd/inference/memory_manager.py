@@ -27,7 +27,6 @@ CAND_CAP = 1024          # candidate slots per query column (typical fill ~35; s
 _UNFUSED = os.environ.get('CUTIE_AMD_UNFUSED', '0') not in ('', '0')      # diagnostic A/B switch, see model/plans.py
 _VALIDATE = os.environ.get('CUTIE_AMD_VALIDATE', '0') not in ('', '0')
 BANK_WRITE = os.environ.get('CUTIE_AMD_BANK_WRITE', '1') not in ('', '0')      # the copies / fills of an insertion in one launch (A/B switch)
-BATCH_EXTRA_LDS = int(os.environ.get('CUTIE_AMD_AFF_BATCH_LDS', '0'))      # experiment: extra dynamic LDS (KB) of the stacked score launches = one block per CU
 BATCH_FORMS = os.environ.get('CUTIE_AMD_AFF_BATCH_FORMS', '1') not in ('', '0')   # stacked read-outs pick their score kernels by frame count (A/B switch)
 COMMIT_ON_SIDE = os.environ.get('CUTIE_AMD_COMMIT_SIDE', '1') not in ('', '0')  # bookkeeping of a consumed look-ahead read-out on the look-ahead stream (A/B switch)
 # bank versions are drawn from one process-wide counter: a look-ahead read-out tagged with the version of one manager can never pass
@@ -277,7 +276,7 @@ class MemoryManager:
         if cached is None or cached[0] != key:
             D = O.Dyn
             ol = O.OpList()
-            common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=CAND_CAP, frames=F, extra_lds_kb=BATCH_EXTRA_LDS)
+            common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=CAND_CAP, frames=F)
             # kernel forms by the number of stacked frames (same bits whatever the form, tests/test_gpu_kernels.py; isolated stage
             # times at 12.2 k tokens, tools/aff_batch_ab.py, profiles/r05_affinity.md): from three frames on the score pass runs 64 queries
             # per wave on the LDS-DMA kernel (its longer prologue is amortised: 70.6 against 80.0 us at F = 5, MFMA utilisation 0.44
