@@ -219,7 +219,22 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
+    pinned = None
     if world > 1:
+        # One rank per GPU, each with its own slice of the host cores: a rank's frame is ~0.8 ms of Python + launch calls, and N ranks
+        # hopping over the same cores (or all landing on one NUMA node's first cores) is the one visible risk to clip-shard scaling.
+        # LOCAL_WORLD_SIZE ranks share this host; rank r takes the r-th contiguous slice of the cores this job may use.
+        try:
+            cores = sorted(os.sched_getaffinity(0))
+            lws = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
+            per = len(cores) // lws
+            if per >= 1:
+                mine = cores[local * per:(local + 1) * per]
+                os.sched_setaffinity(0, mine)
+                torch.set_num_threads(max(1, min(per, 4)))
+                pinned = [mine[0], mine[-1], len(mine)]
+        except (AttributeError, OSError, ValueError):
+            pinned = None
         import torch.distributed as dist
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
     torch.cuda.set_device(local)
@@ -533,6 +548,7 @@ def main():
                                    f'(SURVEY 8d C2/C3), eval_config defaults (mem_every=5, top_k=30), random-init weights',
                        'preroll_frames': args.preroll, 'memory_tokens_start': n_tok_start, 'memory_tokens_end': n_tok_end,
                        'parallelism': f'clip-shard x{world}', 'accumulate': 'fp32',
+                       'host_cores_of_rank0': pinned,
                        'lookahead': 'off' if args.no_lookahead else
                                     (f'step(next_images=...): the image encoder runs over a window of {args.window} upcoming frames as one batched plan on a '
                                      'third stream (tiles of the same K-order class: bit-identical features)' if args.window > 1 else

@@ -44,6 +44,7 @@ def load():
     lib.cutie_hip_last_error.restype = ctypes.c_char_p
     lib.cutie_hip_abi_version.restype = ctypes.c_int
     lib.cutie_op_struct_size.restype = ctypes.c_int
+    lib.cutie_hip_build_flags.restype = ctypes.c_int
     if lib.cutie_hip_abi_version() != ABI_VERSION or lib.cutie_op_struct_size() != OP_STRUCT_SIZE:
         raise HipLibraryError(f'{LIB_PATH} is stale (ABI {lib.cutie_hip_abi_version()}, '
                               f'op size {lib.cutie_op_struct_size()}); rebuild it.')
@@ -53,7 +54,12 @@ def load():
 
 EXPORTED_SYMBOLS = ['cutie_exec', 'cutie_exec_one', 'cutie_graph_capture', 'cutie_graph_launch',
                     'cutie_graph_destroy', 'cutie_time_ops', 'cutie_hip_last_error',
-                    'cutie_hip_abi_version', 'cutie_op_struct_size']
+                    'cutie_hip_abi_version', 'cutie_op_struct_size', 'cutie_hip_build_flags']
+
+
+def has_diag_kernels():
+    """Was the loaded library built with -DCUTIE_DIAG (make DIAG=1: measured-and-lost kernel variants present)?"""
+    return bool(load().cutie_hip_build_flags() & 1)
 
 
 class HipExecutor:

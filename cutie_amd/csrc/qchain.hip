@@ -626,6 +626,7 @@ __global__ __launch_bounds__(256) void p2q_chain_kernel(QIn in, const bf16_t* __
     ATL(3)
 }
 
+#ifdef CUTIE_DIAG     // a measured-and-lost variant: only in the diagnostic library (make DIAG=1), never in the product .so
 // =====================================================================================================================================
 // ATTN_P2Q + the output projection of read_from_query + the residual (flags&32): pixel = pixel + Wo . attn + bo in the SAME launch -- the
 // 1x1 conv behind ATTN_P2Q (6.6 us + a launch boundary, three times per frame) is gone, and so is the bf16 round trip of the attention
@@ -812,6 +813,8 @@ __global__ __launch_bounds__(512) void p2q_out_kernel(QIn in, const bf16_t* __re
     ATL(4)
 }
 
+#endif  // CUTIE_DIAG
+
 // ---- host side ------------------------------------------------------------------------------------------------------------------------
 static bool qin_from_op(const cutie_op* op, QIn& in, QOut& out, const char* who, int xslot, int lnout_slot, bool no_proj = false) {
     const uint64_t* p = op->p;
@@ -898,6 +901,7 @@ int launch_qchain(const cutie_op* op, hipStream_t s) {
                 if (!p[8] || !p[9] || !p[12] || !p[13] || !p[14] || !p[15]) { cutie_set_error("attn_p2q (chain form): flags&16 needs p8, p9, p12, p13, p14, p15"); return -2; }
                 nq = NextQ{(const float*)p[8], (const float*)p[9], (const bf16_t*)p[12], (const float*)p[13], (float*)p[14], (float*)p[15]};
             }
+#ifdef CUTIE_DIAG
             if (op->flags & 32) {                            // + read_from_query's output projection and the residual: p2 = [Wo bf16 [256,256] | bias f32 [256]], p4 = residual
                 if (!p[2] || !p[4] || (p[2] & 15) || (p[4] & 7) || (p[3] & 7) || p[3] == p[0]) { cutie_set_error("attn_p2q (flags&32): p2 = Wo | bias (16-byte aligned), p4 = residual, y 8-byte aligned required"); return -2; }
                 static bool attr_set = false;
@@ -914,6 +918,9 @@ int launch_qchain(const cutie_op* op, hipStream_t s) {
                 hipLaunchKernelGGL(p2q_out_kernel, dim3(ntiles + (nq.W ? 8 : 0), i[0]), dim3(512), P2O_LDS_BYTES, s, in, (const bf16_t*)p[0], (bf16_t*)p[3], i[2], i[5], nq, po, ntiles);
                 break;
             }
+#else
+            if (op->flags & 32) { cutie_set_error("attn_p2q (flags&32: output projection inside): only in the diagnostic library (make DIAG=1)"); return -2; }
+#endif
             hipLaunchKernelGGL(p2q_chain_kernel, dim3((i[2] + 255) / 256 + (nq.W ? 1 : 0), 8, i[0]), dim3(256), 0, s, in, (const bf16_t*)p[0], (bf16_t*)p[3], i[2], i[5], nq);
         }
             break;

@@ -396,11 +396,17 @@ class Plan:
                             best, best_t = (t, sk), ms
                 cache[key] = best
                 tuned_any = True
+            apply = True
             if (best[0] in O.DMA_TILES or best[0] in O.PC_TILES) and not O.dma_tiles_enabled():
-                continue
+                apply = False
             if (arr['p'][n, 7] or arr['p'][n, 8]) and best[0] not in O.DMA_TILES and best[0] not in O.PC_TILES:
-                continue                                     # GAP accumulation / zero job exist in conv_dma_kernel only
-            arr['i'][n, 17], arr['i'][n, 19] = best
+                apply = False                                # GAP accumulation / zero job exist in conv_dma_kernel only
+            if apply:
+                arr['i'][n, 17], arr['i'][n, 19] = best
+            if self.korder_ref:
+                #  whatever path was taken above -- table entry, static choice kept, a skipped assignment --, the tile this
+                # conv RUNS must sum over K like the one-frame plan's: that is what keeps a frame of the batch bit-identical to it
+                assert O.korder_class(int(arr['i'][n, 17]), int(arr['i'][n, 19])) == want, (key, int(arr['i'][n, 17]), int(arr['i'][n, 19]), want)
         if TOUCH_REWIRE:
             ol.wire_next_weights()                           # the touch ranges follow the tiles the table has just put in place
         self.tuned = True

@@ -325,6 +325,9 @@ float cutie_time_ops(const cutie_op* ops, int n, int iters, void* stream);
 const char* cutie_hip_last_error(void);
 int cutie_hip_abi_version(void);
 int cutie_op_struct_size(void);
+/* bit 0: the library was built with -DCUTIE_DIAG (make DIAG=1): measured-and-lost kernel variants (ATTN_P2Q flags&32) are present.
+ * The product library returns 0 and rejects those descriptors. */
+int cutie_hip_build_flags(void);
 
 #ifdef __cplusplus
 }

@@ -866,6 +866,8 @@ def test_p2q_with_the_output_projection_inside(K, HW, qnext, tile):
     launches it replaces, ATTN_P2Q (chain form) and the 1x1 conv with the residual on a tile of the 'stream' K-order class: bit-identical
     pixels and, with qnext, bit-identical projected queries for the next block; both forms against the interpreter."""
     from cutie_amd.model.weights import linear_as_conv, out_proj_blob
+    if not _lib.has_diag_kernels():
+        pytest.skip('p2q_out_kernel is a measured-and-lost variant: only in the diagnostic library (make -C cutie_amd/csrc DIAG=1)')
     assert O.korder_class(tile) == 'stream'
 
     def build(dev, g):
