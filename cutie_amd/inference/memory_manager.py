@@ -181,7 +181,9 @@ class MemoryManager:
         # pass-0 tile maxima [HWp, Gld] with the per-query thresholds right behind them (pass 1 reads both: it skips the tiles
         # that cannot hold a candidate)
         Gld = -(-max(G, 1) // 64) * 64
-        gbuf = self._buf('gmax_tau' + tag, (HWp * Gld + HWp,), F32, dev)
+        # (grow-only: the tile count changes with every memorised frame, and an exact-size buffer was re-allocated -- and zero-filled, 5-10 MB
+        # -- each time its padded width crossed a multiple of 64 tiles; pass 0 writes every entry that the selection and pass 1 read)
+        gbuf = self._buf_rows('gmax_tau' + tag, HWp * Gld + HWp, (), F32, dev)
         gmax, tau = gbuf[:HWp * Gld], gbuf[HWp * Gld:]
         cval = self._buf('cand_val' + tag, (HW, CAND_CAP), F32, dev)
         cidx = self._buf('cand_idx' + tag, (HW, CAND_CAP), torch.int32, dev)
