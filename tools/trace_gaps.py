@@ -1,5 +1,6 @@
 """Look-ahead frame: is the main stream device-bound or waiting (for launches / for the side stream)?  From a rocprofv3 --kernel-trace CSV
-of bench.py: frames are cut at the decoder's up4_softmax launch (one per frame, main stream); for the frames [f0, f1) the main queue's busy time, its
+of bench.py: frames are cut at the sensory update's first launch (AREA_DOWN3: one per frame, caller's queue; a 'frame' therefore runs from
+the tail of frame t -- sensory update, memorising -- to the decoder of frame t + 1); for the frames [f0, f1) the main queue's busy time, its
 idle gaps by the kernel that FOLLOWS the gap, and the side queue's busy time per frame.
     python tools/trace_gaps.py <kernel_trace.csv> f0 f1 [--dump f]      (--dump f: every launch of frame f on the main queue: gap before, duration)"""
 import csv, sys
@@ -11,7 +12,8 @@ for r in rows:
     q[r['Queue_Id']].append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][:48]))
 # frame marker: a kernel that runs exactly once per propagated frame on the caller's queue.  (Round 3 used query_init2_kernel; since round 4
 # QUERY_INIT runs only when the object summaries changed, so the decoder's last launch -- up4_softmax -- marks the frames.)
-MARK = 'up4_softmax'
+MARK = 'area_down3'                                       # (round 5: up4_softmax runs on the auxiliary stream when the caller gives hints;
+                                                          # AREA_DOWN3 opens the sensory update of every frame on the caller's queue)
 main = max(q, key=lambda k: sum(MARK in n for _, _, n in q[k]))
 side = [k for k in q if k != main]
 for v in q.values():
