@@ -216,20 +216,27 @@ enum {
      * i: 0 HW 1 HWp 2 nranges 3.. (start,n) x3  9 G 10 cap 11 mode  12 query column sets (of 16) per wave: 1 | 2 (0 = 2) | 4 (aff_score4_kernel:
      *      256-query blocks, LDS-DMA staging; same bits for every choice)  13 tiles per block (0 = heuristic)  14 (diagnostic) KB of extra dynamic LDS  15 = 1: aff_score4_kernel (LDS-DMA staging) also for 2 sets per wave
      * flags&1 (mode 1): the gmax matrix of the mode-0 pass lies directly in front of tau in memory (p6 - HWp*Gld floats): every
-     *      (16-token tile, 16-query set) whose maximum is below the set's thresholds is skipped (same result, ~1/6 of the MFMA work) */
+     *      (16-token tile, 16-query set) whose maximum is below the set's thresholds is skipped (same result, ~1/6 of the MFMA work)
+     * ABI 3 -- one read-out per bank version (memory_manager.py:112-208 reads once per frame; the bank changes on memory frames only,
+     *      inference_core.py:238): i16 > 0 = query rows per frame; i1 (HWp) is then frames x i16 and the query operands of the frames are
+     *      stacked (row j is a real query iff j % i16 < i0); c, gmax, tau, the candidate lists and counters are indexed by the stacked row.
+     *      Per query the arithmetic is that of the one-frame launch (same bits). */
     CUTIE_OP_AFF_SCORE = 24,
     /* AFF_SELECT: tau_j = top_k-th largest of gmax[:,j] (or -inf if G < top_k)
      * p0=gmax f32 [HWp,Gld] p1=tau f32 [HW]   i: 0 HW 1 HWp 2 G 3 top_k
      * optional side jobs (0 = none): p2=count i32 [HW*32]: count[32 q] = 0 for every query (pass 1's candidate counters);
      *      p3=life f32 [i4], p4=life f32 [i5]: += 1 (USAGE_TICK of two token ranges)
      * flags&1: range p3 is CLEARED instead (the usage side buffer of a look-ahead read-out, see USAGE_TICK)
-     * flags&2: values per lane in the three sizes 16 | 32 | 64 only (A/B switch; default: ceil(G / 64) rounded up to a multiple of 4) */
+     * flags&2: values per lane in the three sizes 16 | 32 | 64 only (A/B switch; default: ceil(G / 64) rounded up to a multiple of 4)
+     * ABI 3: i6 > 1 = that many stacked frames of i1 query rows each (i0 real ones): gmax, tau and the counters are indexed by the stacked row */
     CUTIE_OP_AFF_SELECT = 25,
     /* AFF_READOUT: exact top-k of the candidates (ties -> lower slot), softmax, usage += w,
      * readout[o,j,:] = sum_i w_i V_o[i,:]    memory_utils.py:58-63,75; memory_manager.py:77-88
      * p0=cand_val p1=cand_idx p2=count p3=vptrs u64[K] (device array of per-object value-bank bases,
      * bf16 [slots,CV]) p4=usage f32 [slots] (may be 0) p5=y bf16 [K,HW,CV] p6=overflow i32[1]
-     * i: 0 HW 1 cap 2 top_k 3 K 4 CV */
+     * i: 0 HW 1 cap 2 top_k 3 K 4 CV
+     * ABI 3: i5 > 1 = that many stacked frames of i6 query rows each; frame f's read-out goes to y + f * K*HW*CV and its usage to
+     *      p4 + f * i7 floats (per-frame side buffers: a look-ahead read-out is counted when -- and only when -- its frame is consumed) */
     CUTIE_OP_AFF_READOUT = 26,
     /* MEMSET32: fill n 32-bit words with value i[1]   p0=dst   i: 0 n 1 value */
     CUTIE_OP_MEMSET32 = 27,
