@@ -83,6 +83,7 @@ struct ScoreParams {
     const bf16_t* Bhi; const bf16_t* Blo; const float* c;
     float* gmax_or_tau; float* cand_val; int* cand_idx; int* count;
     int HW, HWp, nranges, rs[3], rn[3], G, cap, mode, tiles_per_block, Gld;
+    int prio;                                            // 1: s_setprio 1 (a read-out the caller's stream waits for; the stacked look-ahead passes stay at 0)
     int gbase, grem;                                     // 4-tile groups per block row: row by owns gbase (+ 1 if by < grem) groups
     int HWpf;                                            // query rows per frame (HWp = frames x HWpf; row j is a real query iff j % HWpf < HW)
 #ifdef AFF_TIMELINE
@@ -148,6 +149,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int au32x4;
 #define AFF_SYNC() { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(15 | (3 << 14) | (7 << 4) | (0 << 8)); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 template <int AFF_NQ, int AFF_MODE>                   // 16-query column sets per wave (1 or 2)
 __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
+    if (p.prio) __builtin_amdgcn_s_setprio(1);
     constexpr int mode = AFF_MODE;
     extern __shared__ __attribute__((aligned(16))) unsigned char aff_smem[];
     au32x4 (*lds)[2 * 64 * 16] = reinterpret_cast<au32x4 (*)[2 * 64 * 16]>(aff_smem);   // [buffer][hi/lo][row][16 chunks]
@@ -500,6 +502,7 @@ typedef const __attribute__((address_space(1))) au32x4* aff_gptr16;
 template <int NQ, int AFF_MODE>                       // NQ: 16-query column sets per wave (2 or 4)
 __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
 #if __HIP_DEVICE_COMPILE__
+    if (p.prio) __builtin_amdgcn_s_setprio(1);
     constexpr int mode = AFF_MODE, WQ = 16 * NQ;          // WQ: queries per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char aff_smem[];
     int* l_j = reinterpret_cast<int*>(aff_smem + 2 * AF4_STAGE);
@@ -748,9 +751,10 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 // G > 4096, needed 11 us for 1620 columns of 667 values; this one ~3 us).
 // Side jobs riding on AFF_SELECT (two fill launches and two tick launches less per read-out): the candidate counters of pass 1 are
 // cleared (one int per query, stride AFF_CSTRIDE) and the life counters of up to two token ranges advance by one (USAGE_TICK).
-struct SelectSide { int* count; float* lifeA; float* lifeB; int nA, nB; int zeroA; int HWpf, nrows; };    // zeroA: range A is cleared, not advanced
+struct SelectSide { int* count; float* lifeA; float* lifeB; int nA, nB; int zeroA; int HWpf, nrows; int prio; };    // zeroA: range A is cleared, not advanced
 // HWpf / nrows: query rows per frame / in total (several frames per launch: row j is a real query iff j % HWpf < HW; one frame: nrows = HW)
 __device__ __forceinline__ void select_side_jobs(const SelectSide& sd, int HW) {
+    if (sd.prio) __builtin_amdgcn_s_setprio(1);
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     if (sd.count) for (int q = gid; q < sd.nrows; q += nth) sd.count[q * AFF_CSTRIDE] = 0;
     if (sd.lifeA) for (int t = gid; t < sd.nA; t += nth) sd.lifeA[t] = sd.zeroA ? 0.f : sd.lifeA[t] + 1.f;
@@ -849,7 +853,8 @@ typedef const __attribute__((address_space(1))) ro_u32x4* ro_gptr;
 __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
                                                                  const int* __restrict__ count, const uint64_t* __restrict__ vptrs,
                                                                  float* __restrict__ usage, bf16_t* __restrict__ y, int* __restrict__ overflow,
-                                                                 int HW, int cap, int topk, int K, int CV, int HWpf, int nrows, int ustride) {
+                                                                 int HW, int cap, int topk, int K, int CV, int HWpf, int nrows, int ustride, int prio) {
+    if (prio) __builtin_amdgcn_s_setprio(1);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float* cv = reinterpret_cast<float*>(lds_raw);             // [cap]
     int* ci = reinterpret_cast<int*>(lds_raw + (size_t)cap * 4);  // [cap]
@@ -1011,6 +1016,7 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             sp.HW = i[0]; sp.HWp = i[1]; sp.nranges = i[2];
             for (int r = 0; r < 3; ++r) { sp.rs[r] = i[3 + 2 * r]; sp.rn[r] = (r < sp.nranges) ? i[4 + 2 * r] : 0; }
             sp.G = i[9]; sp.cap = i[10]; sp.mode = i[11]; sp.Gld = (sp.G + 63) / 64 * 64;
+            sp.prio = (op->flags & 64) ? 1 : 0;
             sp.HWpf = i[16] > 0 ? i[16] : sp.HWp;              // i[16]: query rows per frame when one launch serves several frames (HWp = frames x i[16])
             if (sp.HWp % sp.HWpf || sp.HW > sp.HWpf) { cutie_set_error("aff_score: HWp=%d is not a multiple of the rows per frame %d (HW=%d)", sp.HWp, sp.HWpf, sp.HW); return -2; }
             int G = 0;
@@ -1072,7 +1078,7 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             // i[6] > 1: that many frames of i[1] query rows each (gmax / tau / the counters are indexed by row; i[0] real queries per frame)
             const int frames = i[6] > 1 ? i[6] : 1;
             const int nrows = frames > 1 ? frames * i[1] : i[0];
-            SelectSide sd = {(int*)p[2], (float*)p[3], (float*)p[4], i[4], i[5], op->flags & 1, frames > 1 ? i[1] : nrows, nrows};
+            SelectSide sd = {(int*)p[2], (float*)p[3], (float*)p[4], i[4], i[5], op->flags & 1, frames > 1 ? i[1] : nrows, nrows, (op->flags & 64) ? 1 : 0};
             const dim3 grid((nrows + 3) / 4), block(256);
             const int Gld = (i[2] + 63) / 64 * 64;
             // values per lane: the kernel counts MAXV compares per lane and bit, so MAXV follows the number of tiles in steps of 4 x 64 tiles
@@ -1095,7 +1101,7 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             const int nrows = frames > 1 ? frames * i[6] : i[0];
             hipLaunchKernelGGL(aff_readout_kernel, dim3(((nrows + 7) / 8) * 8), dim3(RO_THREADS), lds, s, (const float*)p[0], (const int*)p[1], (const int*)p[2],
                                (const uint64_t*)p[3], (float*)p[4], (bf16_t*)p[5], (int*)p[6], i[0], i[1], i[2], i[3], i[4],
-                               frames > 1 ? i[6] : nrows, nrows, i[7]);
+                               frames > 1 ? i[6] : nrows, nrows, i[7], (op->flags & 64) ? 1 : 0);
             break;
         }
         default:

@@ -177,10 +177,13 @@ __global__ __launch_bounds__(256) void consol_read_part_kernel(ConsolRead a) {
     };
     auto store = [&](int buf) {                              // transposed: vt[channel][candidate]
         const uint32_t w[8] = {st0.x, st0.y, st0.z, st0.w, st1.x, st1.y, st1.z, st1.w};
+        // (16 channel rows x 80 B = 20 x 64 banks: the eight channel segments of a wave would all land on one bank -- the PMC showed
+        // SQ_LDS_BANK_CONFLICT / IDX_ACTIVE = 0.83 for this kernel; the 8-candidate column groups of a row are XOR-ed with the row's segment)
+        const int col = (((ii >> 3) ^ (cseg & 3)) << 3) | (ii & 7);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            vt[buf][(cseg * 16 + 2 * e) * CR_VT + ii] = (bf16_t)(w[e] & 0xffffu);
-            vt[buf][(cseg * 16 + 2 * e + 1) * CR_VT + ii] = (bf16_t)(w[e] >> 16);
+            vt[buf][(cseg * 16 + 2 * e) * CR_VT + col] = (bf16_t)(w[e] & 0xffffu);
+            vt[buf][(cseg * 16 + 2 * e + 1) * CR_VT + col] = (bf16_t)(w[e] >> 16);
         }
     };
     load(0);
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256) void consol_read_part_kernel(ConsolRead a) {
         bf16x8 av[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
-            av[ct] = *reinterpret_cast<const bf16x8*>(&vt[buf][(wave * 32 + ct * 16 + r) * CR_VT + 8 * g]);
+            av[ct] = *reinterpret_cast<const bf16x8*>(&vt[buf][(wave * 32 + ct * 16 + r) * CR_VT + 8 * (g ^ ((wave * 2 + ct) & 3))]);   // (row's segment = channel >> 4)
         f32x4 sr0 = {0.f, 0.f, 0.f, 0.f}, sr1 = {0.f, 0.f, 0.f, 0.f};
         if (lead) {
 #pragma unroll

@@ -68,6 +68,7 @@ constexpr int dma_lds_bytes() {
 template <int BM, int BN, int WM, int WN, int NS, int BK, bool HALO, bool RELU, bool TWO>
 __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
 #if __HIP_DEVICE_COMPILE__     // (the host pass only needs the launch stub; the LDS-DMA builtin and the LDS address space exist on the device side)
+    if (p.flags & CUTIE_F_PRIO) __builtin_amdgcn_s_setprio(1);      // a launch of the frame's critical path: see include/cutie_hip.h
     constexpr int NW = WM * WN, NT = NW * 64, CPR = BK / 8;     // 16-B chunks per LDS row
     constexpr int RPP = 64 / CPR;                       // rows per DMA piece (8 at BK = 64, 4 at BK = 128)
     constexpr int ROWB = BK * 2, KSTEPS = BK / 32;      // bytes per LDS row, MFMA k-steps per tile

@@ -27,6 +27,7 @@
 // flight per block unchanged, splitting K doubles them.
 template <int BM, int BN, int WM, int WN, int BK, int S, int OCC, int WK>
 __global__ __launch_bounds__(WM * WN * WK * 64) void conv_igemm_kernel(ConvParams p) {
+    if (p.flags & CUTIE_F_PRIO) __builtin_amdgcn_s_setprio(1);      // a launch of the frame's critical path: see include/cutie_hip.h
     constexpr int NTB = WM * WN * WK * 64;              // threads per block
     constexpr int NT = WM * WN * 64;                    // threads per K group: 4 or 8 waves
     constexpr int CPR = BK / 8;                         // 16-B chunks per LDS row

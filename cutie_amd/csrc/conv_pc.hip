@@ -290,6 +290,7 @@ __device__ __forceinline__ void pc_epilogue_fast(const ConvParams& p, const f32x
 template <int BM, int BN, int WM, int WN, int NPW, int NS, int HT, bool TAPS, bool RELU, bool TWO, int KP = 1>
 __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParams p) {
 #if __HIP_DEVICE_COMPILE__
+    if (p.flags & CUTIE_F_PRIO) __builtin_amdgcn_s_setprio(1);      // a launch of the frame's critical path: see include/cutie_hip.h
     constexpr bool HALO = HT > 0;
     constexpr int TH = HALO ? (HT >> 8) : 1, TW = HALO ? (HT & 255) : 1;
     constexpr int NC = WM * WN, NTC = NC * 64;

@@ -205,7 +205,9 @@ class MemoryManager:
         if cached is None or cached[0] != key:
             D = O.Dyn
             ol = O.OpList()
-            common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=CAND_CAP)
+            # (prio: a one-frame read-out is waited for by the caller's stream -- its waves take issue priority over the window encoder
+            # and the stacked read-outs that share the compute units)
+            common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=CAND_CAP, prio=True)
             ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('gmax'), None, None, None, mode=0, **common)
             # usage bookkeeping (kv_memory_store.py:151-162): life += 1 for every counted token -- rides on the selection launch,
             # as does the clearing of pass 1's candidate counters
@@ -215,18 +217,18 @@ class MemoryManager:
             if tick_long and not ahead:
                 ticks.append((D('life'), bucket.n_long))
             if ahead and self.use_long_term:
-                ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), zero=(D('usage'), nslots))
+                ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), zero=(D('usage'), nslots), prio=True)
             elif _UNFUSED:
                 ol.memset32(D('count'), HW * O.OpList.AFF_CSTRIDE, 0)
                 ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k)
                 for life, n in ticks:
                     ol.usage_tick(life, n)
             else:
-                ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), ticks=ticks)
+                ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), ticks=ticks, prio=True)
             ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('tau'), D('cval'), D('cidx'), D('count'),
                          mode=1, gmax_precedes_tau=True, **common)
             ol.aff_readout(D('cval'), D('cidx'), D('count'), D('vptrs'), D('usage') if self.use_long_term else None, D('readout'),
-                           D('ovf'), HW=HW, cap=CAND_CAP, top_k=self.top_k, K=K, CV=self.CV)
+                           D('ovf'), HW=HW, cap=CAND_CAP, top_k=self.top_k, K=K, CV=self.CV, prio=True)
             if self.use_long_term and bucket.n_long > 0 and not self.count_long_term_usage:
                 # long_term.count_usage=False: the reference keeps no usage for long-term tokens (memory_manager.py:145-147);
                 # the read-out kernel accumulates usage for every slot, so the long-term part is cleared again

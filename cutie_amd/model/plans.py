@@ -233,8 +233,9 @@ def weights_go_cold(px16, K=None):
 
 
 class Plan:
-    def __init__(self, eng, touch=True):
+    def __init__(self, eng, touch=True, prio=True):
         self.eng = eng
+        self.prio = prio                 # its convs belong to the frame's critical path (ops.F_PRIO); the look-ahead encoder plans: False
         self.dev = eng.device
         self.ol = O.OpList(scratch_owner=eng, touch_next_weights=touch)
         self.bufs = {}
@@ -432,7 +433,7 @@ class Plan:
                      pad=pad, x2=None if x2 is None else x2.t, C2=0 if x2 is None else x2.C,
                      ldx2=0 if x2 is None else x2.ld, res=None if res is None else res.t,
                      ldr=0 if res is None else res.ld, res_bcast=res_bcast, relu_in=relu_in, act=act, out_f32=out_f32,
-                     gap_acc=gap_acc, zero=zero)
+                     gap_acc=gap_acc, zero=zero, prio=self.prio)
         return out
 
     # ---- shared blocks ------------------------------------------------------------------
@@ -511,7 +512,7 @@ def build_encode(eng, h0, w0, H, W, pad_left, pad_top, B=1):
     round of workgroups), the outputs are [B, ...] with frame b's slice laid out exactly like the B = 1 output.  Rows of different
     frames never meet (batch = outermost dimension of NHWC) and the tiles are taken from the same K-order class as the B = 1 plan's
     (Plan.korder_ref), so frame b's results are bit-identical to the B = 1 plan's."""
-    P = Plan(eng, touch=weights_go_cold(B * (H // 16) * (W // 16)))
+    P = Plan(eng, touch=weights_go_cold(B * (H // 16) * (W // 16)), prio=False)      # (mostly on a look-ahead stream: yields to the frame's own launches)
     m = eng.m
     img = (lambda b: Dyn('image')) if B == 1 else (lambda b: Dyn('image%d' % b))
     if stem_ok(eng, 'pixel_encoder.conv1'):                 # IMG_PREP + 7x7 conv + max pool in one launch (csrc/stem.hip)

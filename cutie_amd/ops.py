@@ -29,6 +29,9 @@ for _n in ('CONV MAXPOOL IMG_PREP UPSAMPLE2X_ADD AREA_DOWN MASK_DOWN GAP ECA_APP
     KIND_NAMES[globals()[_n]] = _n
 
 F_RELU_IN, F_OUT_F32, F_RES_BCAST = 1, 2, 4
+# launches of the frame's critical path raise their waves' issue priority (include/cutie_hip.h CUTIE_F_PRIO; A/B switch)
+PRIO = os.environ.get('CUTIE_AMD_PRIO', '1') not in ('', '0')
+F_PRIO, F_AFF_PRIO = 256, 64
 F_PLAIN = 8 if os.environ.get('CUTIE_AMD_COUT1_ROWS', '1') in ('', '0') else 0      # A/B switch of conv_cout1_rows_kernel
 F_TILE_OFF = 128 if os.environ.get('CUTIE_AMD_COUT1_TILE', '1') in ('', '0') else 0  # A/B switch of conv_cout1_tile_kernel
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQ1 = 0, 1, 2, 3
@@ -339,11 +342,12 @@ class OpList:
     # ---- builders (argument order mirrors include/cutie_hip.h) -----------------------
     def conv(self, x1, w, y, *, B, H, W, C1, ldx1, OH, OW, ldy, stride=1, pad=0, x2=None, C2=0, ldx2=0,
              res=None, ldr=0, res_bcast=False, relu_in=False, act=ACT_NONE, out_f32=False, tile=None, splitk=1,
-             gap_acc=None, zero=None):
+             gap_acc=None, zero=None, prio=False):
         """w: PackedConv (weights.py).  gap_acc: int64 [B, Cout] -- the conv adds the per-(object, channel) sums of its stored output
         (fixed point x 2^24) to it (ECA's global average pool without a launch of its own); zero: an int64 tensor cleared by this
         launch (the accumulator of the NEXT conv).  Both need an LDS-DMA tile (the tile choice is restricted accordingly)."""
-        flags = (F_RELU_IN if relu_in else 0) | (F_OUT_F32 if out_f32 else 0) | (F_RES_BCAST if res_bcast else 0) | (act << ACT_SHIFT) | F_PLAIN | F_TILE_OFF
+        flags = (F_RELU_IN if relu_in else 0) | (F_OUT_F32 if out_f32 else 0) | (F_RES_BCAST if res_bcast else 0) | (act << ACT_SHIFT) | F_PLAIN | F_TILE_OFF | \
+            (F_PRIO if (prio and PRIO) else 0)
         assert C1 + C2 == w.cin_padded, (C1, C2, w.cin_padded)
         M = B * OH * OW
         side = gap_acc is not None or zero is not None
@@ -584,7 +588,7 @@ class OpList:
     AFF_NQ = int(os.environ.get('CUTIE_AMD_AFF_NQ', '2'))      # 16-query column sets per wave of AFF_SCORE (1, 2: aff_score_kernel; 4: aff_score4_kernel)
 
     def aff_score(self, Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count, *, HW, HWp, ranges, cap, mode, gmax_precedes_tau=False, nq=None, dma=None,
-                  frames=1, extra_lds_kb=0):
+                  frames=1, extra_lds_kb=0, prio=False):
         """gmax_precedes_tau (mode 1): `out` (= tau) sits right behind the [HWp, Gld] maxima of pass 0 in memory; the kernel then
         skips every (tile, 16-query set) that cannot hold a candidate.  nq: query column sets per wave (default AFF_NQ; every
         choice computes the same bits).  frames > 1: the query operands of that many frames, HWp rows each (HW real ones), stacked -- every
@@ -599,23 +603,23 @@ class OpList:
         if frames > 1:
             ints[1] = frames * HWp
             ints += [HWp]
-        return self.add(AFF_SCORE, 1 if (gmax_precedes_tau and mode == 1) else 0, ints, [], [Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count])
+        return self.add(AFF_SCORE, (1 if (gmax_precedes_tau and mode == 1) else 0) | (F_AFF_PRIO if (prio and PRIO) else 0), ints, [], [Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count])
 
-    def aff_select(self, gmax, tau, *, HW, HWp, G, top_k, clear_count=None, ticks=(), zero=None, frames=1):
+    def aff_select(self, gmax, tau, *, HW, HWp, G, top_k, clear_count=None, ticks=(), zero=None, frames=1, prio=False):
         """clear_count: pass 1's candidate counters, zeroed here; ticks: up to two (life, n) ranges advanced by one (USAGE_TICK);
         zero = (buffer, n): f32 range cleared instead (excludes ticks: the usage side buffer of a look-ahead read-out).
         frames > 1: stacked queries, see aff_score."""
         if zero is not None:
             assert not ticks
-            return self.add(AFF_SELECT, 1 | SELECT_COARSE, [HW, HWp, G, top_k, zero[1], 0, frames], [], [gmax, tau, clear_count, zero[0], None])
+            return self.add(AFF_SELECT, 1 | SELECT_COARSE | (F_AFF_PRIO if (prio and PRIO) else 0), [HW, HWp, G, top_k, zero[1], 0, frames], [], [gmax, tau, clear_count, zero[0], None])
         ticks = list(ticks) + [(None, 0)] * (2 - len(ticks))
         assert len(ticks) == 2
-        return self.add(AFF_SELECT, SELECT_COARSE, [HW, HWp, G, top_k, ticks[0][1], ticks[1][1], frames], [], [gmax, tau, clear_count, ticks[0][0], ticks[1][0]])
+        return self.add(AFF_SELECT, SELECT_COARSE | (F_AFF_PRIO if (prio and PRIO) else 0), [HW, HWp, G, top_k, ticks[0][1], ticks[1][1], frames], [], [gmax, tau, clear_count, ticks[0][0], ticks[1][0]])
 
-    def aff_readout(self, cand_val, cand_idx, count, vptrs, usage, y, overflow, *, HW, cap, top_k, K, CV, frames=1, HWp=0, usage_stride=0):
+    def aff_readout(self, cand_val, cand_idx, count, vptrs, usage, y, overflow, *, HW, cap, top_k, K, CV, frames=1, HWp=0, usage_stride=0, prio=False):
         """frames > 1: stacked queries (HWp rows per frame, see aff_score); frame f's read-out goes to y[f] ([frames, K, HW, CV]) and its
         usage to usage + f * usage_stride floats."""
-        return self.add(AFF_READOUT, 0, [HW, cap, top_k, K, CV, frames, HWp, usage_stride], [], [cand_val, cand_idx, count, vptrs, usage, y, overflow])
+        return self.add(AFF_READOUT, F_AFF_PRIO if (prio and PRIO) else 0, [HW, cap, top_k, K, CV, frames, HWp, usage_stride], [], [cand_val, cand_idx, count, vptrs, usage, y, overflow])
 
     def memset32(self, dst, n, value=0):
         return self.add(MEMSET32, 0, [n, value], [], [dst])

@@ -8,8 +8,9 @@ gather of per-clip results to rank 0 -- a direct (non-ring) gather, since the pa
 Inside one GPU, several clips can be *in flight* at once (``run_concurrent``): one host thread + HIP stream +
 ``CUTIE.fork()`` per clip.  A single clip is a chain of ~200 dependent small launches per frame and leaves most of the 256
 CUs idle most of the time (kernel-boundary bubbles, layers with < 256 workgroups); four independent chains interleave on
-the hardware queues.  Measured on the MI355X: round 4, four clips in flight 1165-1375 frames/s against 1100 for one
-clip (same box, host-bound and noisy: four Python threads; round 3: 1102 against 1006) -- a single clip is a latency chain of ~50 dependent launches per frame on its own stream,
+the hardware queues.  Measured on the MI355X (the bench line's `multi_clip`; one number per box, boxes differ): round 5, four clips in flight
+1348 frames/s against 1116 for one clip in the driver's box -- host-bound (four Python threads behind one interpreter lock: 923 on a box
+with a slower host).  A single clip is a latency chain of ~50 dependent launches per frame on its own stream,
 the look-ahead lanes already fill part of the idle compute units, and the rest is what several clips in flight can still use.
 """
 import queue
