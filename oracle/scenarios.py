@@ -26,6 +26,9 @@ SCENARIOS = {
     # given by the mask files of frames 0, 5, 8, 13 (three buckets of objects added at different times), id 1 deleted before frame 10.
     # (masks/judo/00005.png is 480 x 853 against 480 x 854 frames: the reference pads the mask on its own, inference_core.py:263)
     'judo': dict(cfg=dict(max_internal_size=480), kind='judo', frames=16, sub=8, delete_at={10: [1]}),
+    # ... and under the decisive weights (round 5: a second whole-frame argmax scenario -- 16 real frames, four objects in three buckets,
+    # a deletion; the executed reference's top-1 / top-2 margin exceeds 0.33 on 89 ... 100 % of the pixels of every frame)
+    'judo_decisive': dict(cfg=dict(max_internal_size=480), kind='judo', frames=16, sub=8, delete_at={10: [1]}, weights='decisive'),
     # small clip, 3 objects, FIFO working memory wraps (mem_every=2, max_mem_frames=3)
     'small_fifo': dict(cfg=dict(mem_every=2, max_mem_frames=3, stagger_updates=1),
                        kind='synth', h=96, w=136, k=3, frames=14, sub=2),

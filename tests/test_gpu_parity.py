@@ -174,6 +174,57 @@ def test_bike_argmax_decisive():
     _bike_argmax(S.decisive_state_dict(), min_agree_all=0.998, min_decisive=0.95, tag='bike decisive')
 
 
+def test_judo_argmax_decisive(gpu_net):
+    """A second whole-frame argmax scenario (only `bike_decisive` could fail on an argmax regression): the judo
+    example -- 16 real 480p frames, objects 1..4 given by the mask files of frames 0 / 5 / 8 / 13 (three buckets), id 1 deleted before
+    frame 10 -- under the DECISIVE weights, pinned to the executed reference by the golden scenario `judo_decisive`
+    (tests/test_oracle_golden.py).  Object ids through the public API (`output_prob_to_mask`) against the oracle's: identical on
+    >= 99.8 % of the pixels whose margin exceeds the per-class tolerance and on >= 98 % of all pixels of every frame; the count of differing
+    pixels per frame is printed and ratcheted."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.model.cutie import CUTIE
+    from oracle.net import OracleNet
+    sd = S.decisive_state_dict()
+    net = CUTIE(default_config()).cuda().eval()
+    net.load_weights(sd)
+    onet = OracleNet({k: v for k, v in sd.items()})
+    ids = {}
+
+    def make_o(over):
+        p = OracleProcessor(onet, dict(DEFAULT_CFG, **over))
+        ids['o'] = p
+        return p
+
+    def make_p(over):
+        p = InferenceCore(net, cfg=default_config(**over))
+        ids['p'] = p
+        return p
+    oouts, oproc = S.run_scenario(make_o, 'judo_decisive')
+    outs, proc = S.run_scenario(make_p, 'judo_decisive', device='cuda', make_cfg=lambda over: default_config(**over))
+    worst, worst_count, bad = 1.0, 0, []
+    for t, (p, o) in enumerate(zip(outs, oouts)):
+        assert p.shape == o.shape and torch.isfinite(p).all()
+        top2 = o.topk(2, dim=0)[0]
+        confident = (top2[0] - top2[1]) > BMARGIN
+        agree = p.argmax(0) == o.argmax(0)                       # (tmp-id planes: the id tables of both processors are the same by construction)
+        ndiff = int((~agree).sum())
+        print(f'judo frame {t}: decisive pixels {float(confident.float().mean()):.4f}, agreement on them {float(agree[confident].float().mean()):.6f}, '
+              f'on all pixels {float(agree.float().mean()):.6f} = {ndiff} differing pixels of {agree.numel()}')
+        undecided = int((~confident).sum())
+        bad.append((t, ndiff, undecided, float(agree[confident].float().mean())))
+        worst, worst_count = min(worst, float(agree.float().mean())), max(worst_count, ndiff)
+    print(f'judo decisive: worst frame {worst_count} differing pixels ({worst:.6f})')
+    # Free-running over 16 real frames the two trajectories drift apart inside the stated envelope, so a few hundred decided pixels near
+    # object borders flip late in the clip (observed: >= 99.85 % of the decided pixels, >= 98.5 % of all pixels agree on every frame).
+    # Floors + a ratchet on the COUNT of differing pixels per frame (tests/golden/observed_r05_judo_argmax.json, recorded in round 5).
+    obs_path = os.path.join(S.GOLDEN_DIR, 'observed_r05_judo_argmax.json')
+    obs = json.load(open(obs_path))['frames'] if os.path.exists(obs_path) else {}
+    for t, ndiff, undecided, dec in bad:
+        assert dec >= 0.998 and ndiff <= 0.02 * 409920, (t, ndiff, undecided, dec)
+        if str(t) in obs:
+            assert ndiff <= int(1.25 * obs[str(t)]['differing']) + 60, ('count ratchet', t, ndiff, obs[str(t)]['differing'])
+
+
 def _bike_argmax(sd, min_agree_all=0.97, min_decisive=0.0, tag=None):
     from cutie_amd.inference.inference_core import InferenceCore
     from cutie_amd.model.cutie import CUTIE

@@ -41,7 +41,7 @@ def test_state_dict_spec_matches_reference():
         assert tuple(shp) == tuple(spec[k][0]), k
 
 
-@pytest.mark.parametrize('name', ['small_fifo', 'small_lt', 'small_add_del', 'small_interactive', 'small_flip', 'small_chunk', 'small_misc', 'small_clear', 'small_video', 'small_lt_overlap', 'small_cfg_fifo', 'small_cfg_lt', 'bike', 'judo', 'bike_decisive'])
+@pytest.mark.parametrize('name', ['small_fifo', 'small_lt', 'small_add_del', 'small_interactive', 'small_flip', 'small_chunk', 'small_misc', 'small_clear', 'small_video', 'small_lt_overlap', 'small_cfg_fifo', 'small_cfg_lt', 'bike', 'judo', 'bike_decisive', 'judo_decisive'])
 def test_oracle_matches_reference_trajectory(name, oracle_net):
     gold = np.load(os.path.join(GOLDEN, name + '.npz'))
     sub = S.SCENARIOS[name]['sub']
@@ -58,9 +58,10 @@ def test_oracle_matches_reference_trajectory(name, oracle_net):
 
     outs, proc = S.run_scenario(make, name, record=lambda t, p: sizes.append(_mem_sizes(p)))
     assert np.array_equal(np.array(sizes), gold['mem_sizes'])
-    if name == 'bike_decisive':                                          # what the weights are for: the reference itself is decisive on >= 95 % of every frame
+    if name in ('bike_decisive', 'judo_decisive'):                       # what the weights are for: the reference itself is decisive on >= 95 % of every bike frame
+        floor = 0.95 if name == 'bike_decisive' else 0.87                # (judo: 16 real frames, objects appearing / deleted: 89 ... 100 %)
         for t in range(len(outs)):
-            assert float((gold[f'margin_{t}'].astype(np.float32) > 0.33).mean()) >= 0.95, t
+            assert float((gold[f'margin_{t}'].astype(np.float32) > 0.33).mean()) >= floor, t
     for t, p in enumerate(outs):
         ref = torch.from_numpy(gold[f'prob_{t}'].astype(np.float32))
         got = p[:, ::sub, ::sub]
