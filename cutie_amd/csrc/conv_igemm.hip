@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvParams p) {
 // would waste 15/16 of its columns and (at M = 1620) leave 249 CUs idle, so: LP = Cin/8 lanes per output pixel, each lane
 // owns 8 channels (one 16-B load per tap), weights staged once per block in LDS, shuffle reduction over the LP lanes.
 __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvParams p) {
+    if (p.flags & CUTIE_F_PRIO) __builtin_amdgcn_s_setprio(1);
     extern __shared__ __attribute__((aligned(16))) unsigned char wlds_raw[];
     u32x4* wlds = reinterpret_cast<u32x4*>(wlds_raw);                   // [KH*KW][Cin/8] chunks of the single filter
     const int LP = p.Cin >> 3;                                           // lanes per pixel (power of two, <= 64)
@@ -352,6 +353,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvParams p) {
 // same lane butterfly): bit-identical results.
 template <int TR>
 __global__ __launch_bounds__(256) void conv_cout1_tile_kernel(ConvParams p) {
+    if (p.flags & CUTIE_F_PRIO) __builtin_amdgcn_s_setprio(1);
     constexpr int TC = 16, PW = TC + 2, NPIX = (TR + 2) * PW;
     __shared__ u32x4 tile[NPIX * 16];
     const int tid = threadIdx.x, sub = tid >> 4, cl = tid & 15;
@@ -428,6 +430,7 @@ __global__ __launch_bounds__(256) void conv_cout1_tile_kernel(ConvParams p) {
 // as a * 0, then the same lane butterfly): bit-identical results.
 template <int R>
 __global__ __launch_bounds__(256) void conv_cout1_rows_kernel(ConvParams p) {
+    if (p.flags & CUTIE_F_PRIO) __builtin_amdgcn_s_setprio(1);
     const int LP = p.Cin >> 3;                                           // lanes per pixel (8, 16 or 32)
     const int ppb = 256 / LP;                                            // pixel columns per block
     const int sub = threadIdx.x / LP, cl = threadIdx.x % LP;

@@ -74,6 +74,7 @@ __device__ __forceinline__ void up_coord(int o, int n_in, float scale, int& i0, 
 
 __global__ void upsample2x_add_kernel(const uint4* __restrict__ g, const uint4* __restrict__ skip, uint4* __restrict__ y,
                                       int B, int h, int w, int C8) {
+    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     int OH = 2 * h, OW = 2 * w;
     long total = (long)B * OH * OW * C8;
@@ -189,6 +190,7 @@ __global__ void area_down_f32_kernel(const float* __restrict__ x, bf16_t* __rest
 struct AreaSeg { const void* x; bf16_t* y; int B, H, W, C, ldx, ldy, r, Cz, f32; long n; };
 struct Area3 { AreaSeg s[3]; int rt; };
 __global__ void area_down3_kernel(Area3 a) {
+    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -319,6 +321,7 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const bf16_t* __restrict
                                                         bf16_t* __restrict__ y, float* __restrict__ gap_out, int HW, int C, int nchunk,
                                                         const long long* __restrict__ fixed, const bf16_t* __restrict__ pw,
                                                         const float* __restrict__ pb, float* __restrict__ plog) {
+    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
     __shared__ float gap[256 + 4], sc[256];
     const int b = blockIdx.y, tid = threadIdx.x;
     const float inv = 1.f / (float)HW;
@@ -421,6 +424,7 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const bf16_t* __restrict
 // four channels per thread: 16-byte loads of the three gate rows and of h, a 16-byte store of h and an 8-byte store of its bf16 shadow
 // (one channel per thread wrote the shadow in 2-byte pieces); the same expression per element as gru_kernel
 __global__ void gru4_kernel(const float* __restrict__ v, float* __restrict__ h, bf16_t* __restrict__ hb, long n, int C) {
+    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;             // (row, channel quad)
     const int C4 = C >> 2;
     if (idx >= n * C4) return;
@@ -653,6 +657,7 @@ __device__ __forceinline__ void up4_four(const float* __restrict__ lg, int Krt, 
 template <int PMAX, int KC = 0>
 __global__ __launch_bounds__(256) void up4_softmax_fused4_kernel(const float* __restrict__ lg, float* __restrict__ prob, float* __restrict__ lup,
                                                                  int Krt, int h, int w) {
+    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
     const int K = KC > 0 ? KC : Krt;
     const int OH = 4 * h, OW = 4 * w;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;             // (oy, j): output pixels (oy, 4j .. 4j + 3)
@@ -679,6 +684,7 @@ __global__ __launch_bounds__(256) void up4_softmax_fused4_kernel(const float* __
 template <int PMAX, int KC = 0, bool SH = false>
 __global__ __launch_bounds__(256) void up4_softmax_md_kernel(const float* __restrict__ lg, float* __restrict__ prob, float* __restrict__ lup,
                                                              int Krt, int h, int w, float* __restrict__ m16, uint4* __restrict__ pair, int ld8) {
+    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
     const int K = KC > 0 ? KC : Krt;
     __shared__ float cell[4][PMAX - 1][256];
     __shared__ float srcL[4][SH ? PMAX : 1][36];

@@ -180,6 +180,7 @@ __device__ __forceinline__ bool aux_fg_late(const float* __restrict__ lg, int K,
 template <bool QPRE, bool ACC, int KT, int NW>
 __global__ __launch_bounds__(NW * 64) void q2p_chain_kernel(QIn in, QOut out, const bf16_t* __restrict__ kv, const float* __restrict__ lg,
                                                            int HW, int HWp, int ldkv, int voff, int hstride, const float* __restrict__ qpre) {
+    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
     constexpr int Q = 16, NT = NW * 64;
     constexpr bool EARLY = KT > 0;
     constexpr int PPT = 2048 / NT;                         // pixels per thread with logits fetched at entry
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(NW * 64) void q2p_chain_kernel(QIn in, QOut out, co
 // instructions: cheaper than handing one wave's result around) and projects it onto ITS two 16-column tiles of Wo.
 // =====================================================================================================================================
 __global__ __launch_bounds__(512) void self_chain_kernel(QIn in, QOut out) {
+    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
     __shared__ float sX[2][16 * PROJ_XLD];                 // [LN(x)+emb | LN(x)]
     __shared__ f32x4 sRed[4][6][64];
     __shared__ float sP[3][16][33];                        // q (scaled) | k | v of this head
@@ -486,6 +488,7 @@ __global__ __launch_bounds__(512) void self_chain_kernel(QIn in, QOut out) {
 struct QFfn { const bf16_t* W1; const float* b1; const bf16_t* W2; long long* acc; int FF; };
 template <int HS>
 __global__ __launch_bounds__(256) void qffn_kernel(QIn in, QFfn a) {
+    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
     constexpr int T1 = HS / 64;                            // hidden 16-column tiles per wave
     constexpr int KS2 = HS / 32;                           // k steps of the second product
     constexpr int HLD = HS + 4;
@@ -534,6 +537,7 @@ __global__ __launch_bounds__(256) void qffn_kernel(QIn in, QFfn a) {
 // emb) Wq^T + b) / sqrt(32), xn_out = LN(x_eff) (the residual of that attention).  24 blocks next to 168: free.
 struct NextQ { const float* ln_g; const float* ln_b; const bf16_t* W; const float* bias; float* q_out; float* xn_out; };
 __global__ __launch_bounds__(256) void p2q_chain_kernel(QIn in, const bf16_t* __restrict__ q, bf16_t* __restrict__ y, int HW, int ldq, NextQ nq) {
+    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
     constexpr int C = 256;
     __shared__ float sX[2][16 * PROJ_XLD];
     __shared__ float ks[16][36], vs[16][36];
