@@ -346,26 +346,34 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvParams p) {
     }
 }
 
-// The same layer with the input TILE in LDS (round 4; Cin = 128: 16 lanes per pixel): a block owns TR x 16 output pixels, stages the
-// (TR + 2) x 18 input pixels once (coalesced 256-byte rows, fused input ReLU applied on the way in, zeros outside the image) and every
-// lane reads its nine taps from there -- 1.4 input reads per block and pixel instead of 4.5 vector requests per output through the
-// texture path.  Per output the same products in the same order as conv_cout1_kernel (tap by tap, a * (row valid * column valid), the
-// same lane butterfly): bit-identical results.
+// The same layer with the input TILE in LDS and the dot products on the matrix cores (Cin = 128; round 4: LDS tile + VALU, round 5: MFMA).
+// A block owns TR x 16 output pixels and stages the (TR + 2) x 18 input pixels once (coalesced 256-byte rows, fused input ReLU applied on
+// the way in, zeros outside the image = the conv's padding).  The VALU form then spent 72 x (unpack + 16 FMA) per thread -- 8.4 us of pure
+// VALU issue per launch at 2.5 blocks per CU, for 90 MFLOP -- so the nine taps x 128 channels run as 36 k-steps of
+// v_mfma_f32_16x16x32_bf16: M = the 16 pixels of an output row, K = 32 channels of one tap, N = 16 with ONE real column (the filter; the
+// other fifteen B columns are zero): 15/16 of the matrix work is wasted and it is still ~10x cheaper than the VALU loop.  A fragment =
+// one ds_read_b128 of the pixel the tap lands on; the 16-B chunks of a pixel are XOR-swizzled with the pixel index (the 16 pixels of a
+// fragment read sit 256 B apart: without it, 8 lanes per bank group).  fp32 accumulation in MFMA order (k ascending per tap): results agree
+// with conv_cout1_rows_kernel / conv_cout1_kernel to fp32 rounding, not bit for bit.
 template <int TR>
 __global__ __launch_bounds__(256) void conv_cout1_tile_kernel(ConvParams p) {
     if (p.flags & CUTIE_F_PRIO) __builtin_amdgcn_s_setprio(1);
-    constexpr int TC = 16, PW = TC + 2, NPIX = (TR + 2) * PW;
+    static_assert(TR % 4 == 0, "rows per wave");
+    constexpr int TC = 16, PW = TC + 2, NPIX = (TR + 2) * PW, RW = TR / 4;
     __shared__ u32x4 tile[NPIX * 16];
-    const int tid = threadIdx.x, sub = tid >> 4, cl = tid & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
     const int tiles_x = (p.W + TC - 1) / TC, tiles_y = (p.H + TR - 1) / TR;
     const int b = blockIdx.x / (tiles_x * tiles_y), rem = blockIdx.x - b * tiles_x * tiles_y;
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
     const int x0 = tx * TC, y0 = ty * TR;
     const bool relu_in = p.flags & CUTIE_F_RELU_IN;
     const float bias0 = p.bias ? p.bias[0] : 0.f;
-    u32x4 wv[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const u32x4*>(p.w + (long)(t * 16 + cl) * 8);
+    // the filter as the B operand: k-step s = (tap s >> 2, channels 32 (s & 3) ..), lane (column n, k group g) holds channels + 8 g .. + 7 of
+    // column n -- the filter for n == 0, zeros otherwise.
+    // (kept in LDS, 2.3 KB, not in 144 registers per lane: with them the kernel held 240 VGPRs = two blocks per CU, and 630 blocks on 512
+    // slots is two rounds; three blocks per CU take the 480p head in one)
+    __shared__ u32x4 wl[36 * 4];
+    const u32x4 wmine = tid < 144 ? *reinterpret_cast<const u32x4*>(p.w + (long)((tid >> 4) * 16 + (tid & 15)) * 8) : (u32x4){0u, 0u, 0u, 0u};
     constexpr int NCH = (NPIX * 16 + 255) / 256;
     u32x4 st[NCH];
 #pragma unroll
@@ -379,45 +387,48 @@ __global__ __launch_bounds__(256) void conv_cout1_tile_kernel(ConvParams p) {
     }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int q = tid + 256 * i;
+        const int q = tid + 256 * i, px = q >> 4, c = q & 15;
         u32x4 v = st[i];
         if (relu_in) { v.x = relu_bf2(v.x); v.y = relu_bf2(v.y); v.z = relu_bf2(v.z); v.w = relu_bf2(v.w); }
-        if (q < NPIX * 16) tile[q] = v;
+        if (q < NPIX * 16) tile[px * 16 + (c ^ (px & 15))] = v;
     }
+    if (tid < 144) wl[tid] = wmine;                           // [tap][16 chunks of 8 channels] = [k-step][k group] in order
     __syncthreads();
-    const int act = (p.flags >> CUTIE_ACT_SHIFT) & 7;
-    const int x = x0 + sub;
-    float okc[3];
+    f32x4 acc[RW];
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) okc[kx] = ((unsigned)(x + kx - 1) < (unsigned)p.W) ? 1.f : 0.f;
+    for (int r = 0; r < RW; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int j = 0; j < TR; ++j) {
-        const int oy = y0 + j;
-        float acc = 0.f;
+    for (int sidx = 0; sidx < 36; ++sidx) {
+        const int tap = sidx >> 2, ky = tap / 3, kx = tap - 3 * ky, ch = (sidx & 3) * 4 + g;
+        const u32x4 wv = wl[sidx * 4 + g];
+        const bf16x8 wb = __builtin_bit_cast(bf16x8, n == 0 ? wv : zero4);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const float okr = ((unsigned)(oy + ky - 1) < (unsigned)p.H) ? 1.f : 0.f;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const u32x4 xx = tile[((j + ky) * PW + sub + kx) * 16 + cl], ww = wv[ky * 3 + kx];
-                float a = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    a += __uint_as_float(xx[i] << 16) * __uint_as_float(ww[i] << 16);
-                    a += __uint_as_float(xx[i] & 0xffff0000u) * __uint_as_float(ww[i] & 0xffff0000u);
-                }
-                acc += a * (okr * okc[kx]);
-            }
+        for (int r = 0; r < RW; ++r) {
+            const int px = (wave * RW + r + ky) * PW + n + kx;          // A: row m = lane & 15 = the output column, its tap pixel
+            const bf16x8 a = __builtin_bit_cast(bf16x8, tile[px * 16 + (ch ^ (px & 15))]);
+            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wb, acc[r], 0, 0, 0);
         }
-        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (cl == 0 && x < p.W && oy < p.H) {
-            float v = acc + bias0;
-            if (act == CUTIE_ACT_RELU) v = fmaxf(v, 0.f);
-            else if (act == CUTIE_ACT_SIGMOID) v = sigmoidf_(v);
-            else if (act == CUTIE_ACT_SQ1) v = v * v + 1.f;
-            const long m = ((long)b * p.H + oy) * p.W + x;
-            if (p.flags & CUTIE_F_OUT_F32) reinterpret_cast<float*>(p.y)[m * p.ldy] = v;
-            else reinterpret_cast<bf16_t*>(p.y)[m * p.ldy] = f2bf(v);
+    }
+    // D[m = 4 g + q][n]: the lanes of column n == 0 hold four output pixels of each of the wave's rows
+    if (n == 0) {
+        const int act = (p.flags >> CUTIE_ACT_SHIFT) & 7;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int oy = y0 + wave * RW + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int x = x0 + 4 * g + q;
+                if (x < p.W && oy < p.H) {
+                    float v = acc[r][q] + bias0;
+                    if (act == CUTIE_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (act == CUTIE_ACT_SIGMOID) v = sigmoidf_(v);
+                    else if (act == CUTIE_ACT_SQ1) v = v * v + 1.f;
+                    const long m = ((long)b * p.H + oy) * p.W + x;
+                    if (p.flags & CUTIE_F_OUT_F32) reinterpret_cast<float*>(p.y)[m * p.ldy] = v;
+                    else reinterpret_cast<bf16_t*>(p.y)[m * p.ldy] = f2bf(v);
+                }
+            }
         }
     }
 }

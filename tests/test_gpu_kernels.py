@@ -254,9 +254,10 @@ def test_conv_cout1_rows_kernel(ci):
 
 
 @pytest.mark.parametrize('ci', [0, 2])
-def test_conv_cout1_tile_kernel_matches_rows_kernel_bitwise(ci, monkeypatch):
-    """Cin = 128: conv_cout1_tile_kernel (input tile in LDS) against conv_cout1_rows_kernel (flags & CUTIE_F_TILE_OFF): the same products
-    in the same order -- identical bits, ragged tiles and image borders included."""
+def test_conv_cout1_tile_kernel_matches_rows_kernel(ci, monkeypatch):
+    """Cin = 128: conv_cout1_tile_kernel (input tile in LDS, dot products on MFMA since round 5) against conv_cout1_rows_kernel (flags &
+    CUTIE_F_TILE_OFF: fp32 VALU, tap by tap): the same bf16 products summed in fp32 in another order -- equal to fp32 rounding (bf16 outputs:
+    at most one ulp), ragged tiles and image borders included."""
     outs = []
     for off in (0, 128):
         monkeypatch.setattr(O, 'F_TILE_OFF', off)
@@ -265,7 +266,10 @@ def test_conv_cout1_tile_kernel_matches_rows_kernel_bitwise(ci, monkeypatch):
         torch.cuda.synchronize()
         outs.append({k: v.clone() for k, v in t.items()})
     for k in outs[0]:
-        assert torch.equal(outs[0][k], outs[1][k]), k
+        a, b = outs[0][k].float(), outs[1][k].float()
+        tol = 1e-5 if outs[0][k].dtype == F32 else 8e-3          # (fp32 outputs: summation order; bf16 outputs: one ulp where the rounding flips)
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max().clamp(min=1.0)), (k, float((a - b).abs().max()))
 
 
 def test_conv_cout1_1x1_relu_in():
