@@ -300,6 +300,22 @@ def main():
             t_idx = base2 + drain + args.steps
             assert not getattr(proc, '_window', None), 'the un-hinted region must not find frames encoded ahead'
             no_la = {'value': round(world * args.steps / t_nola, 2), 'ms_per_step': round(t_nola / args.steps * 1e3, 4)}
+            # the reference's own FPS protocol (cutie/eval_vos.py:126-145): synchronize, start event, step, end event, synchronize, and
+            # FPS = frames / the sum of the event intervals -- the host never runs ahead of the device, every frame starts on an idle GPU
+            ev_ms, t0 = 0.0, time.perf_counter()
+            for i in range(args.steps):
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                proc.step(frames[t_idx % 128])
+                e1.record()
+                torch.cuda.synchronize()
+                ev_ms += e0.elapsed_time(e1)
+                t_idx += 1
+            wall = time.perf_counter() - t0
+            no_la['eval_vos_protocol'] = {'fps': round(args.steps / ev_ms * 1e3, 2), 'wall_fps': round(args.steps / wall, 2), 'steps': args.steps,
+                                          'note': 'per frame: synchronize, event, step(image), event, synchronize (cutie/eval_vos.py:126-145); fps = frames / sum of the '
+                                                  'event intervals (what the reference logs as FPS), wall_fps includes the two host synchronisations per frame'}
         # ---- full-bank point: long-term memory at its steady-state size ----
         full_bank = None
         if args.full_bank_preroll > 0 and use_lt:

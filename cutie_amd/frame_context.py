@@ -21,6 +21,7 @@ def _table():
     t = getattr(_local, 'table', None)
     if t is None:
         t = _local.table = OrderedDict()          # (kind, data_ptr) -> (payload, pinned tensors)
+        _local.capped = {}                        # kind -> OrderedDict of this kind's keys, oldest first (kinds remembered with a cap)
     return t
 
 
@@ -31,12 +32,19 @@ def remember(kind, tensor, payload, pin=(), cap=None):
     t = _table()
     t.pop(key, None)
     if cap is not None:
-        same = [k for k in t if k[0] == kind]
-        for k in same[:max(0, len(same) - cap + 1)]:
-            del t[k]
+        ko = _local.capped.get(kind)
+        if ko is None:
+            ko = _local.capped[kind] = OrderedDict()
+        ko.pop(key, None)
+        ko[key] = None
+        while len(ko) > cap:                      # (the order of a kind's keys, kept beside the table: no scan of the table per call)
+            t.pop(ko.popitem(last=False)[0], None)
     t[key] = (payload, (tensor,) + tuple(pin))
     while len(t) > _MAX:
-        t.popitem(last=False)
+        old = t.popitem(last=False)[0]
+        ko = _local.capped.get(old[0])
+        if ko is not None:
+            ko.pop(old, None)
 
 
 def recall(kind, tensor):
@@ -46,4 +54,8 @@ def recall(kind, tensor):
 
 
 def forget(kind, tensor):
-    _table().pop((kind, tensor.data_ptr()), None)
+    key = (kind, tensor.data_ptr())
+    if _table().pop(key, None) is not None:
+        ko = _local.capped.get(kind)
+        if ko is not None:
+            ko.pop(key, None)

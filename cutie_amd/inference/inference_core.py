@@ -143,7 +143,11 @@ class InferenceCore:
         the first kernel of each plan: the raw frame + geometry are handed over instead of a padded copy."""
         h0, w0 = image.shape[-2:]
         H, W, pad = pad_geometry(h0, w0, 16)
-        image = image.to(device=self.network.device, dtype=F32).contiguous()
+        dev = self.network.device
+        if image.dtype != F32 or image.device != dev:          # (a frame that is already what the first kernel reads costs no torch call)
+            image = image.to(device=dev, dtype=F32)
+        if not image.is_contiguous():
+            image = image.contiguous()
         frame_context.remember('geometry', image, (h0, w0, H, W, pad[0], pad[2]))     # un-padded frame + pad geometry (see ImageFeatureStore)
         return image, (h0, w0, H, W, pad)
 

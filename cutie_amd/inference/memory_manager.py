@@ -58,6 +58,7 @@ class MemoryManager:
         self._objv_ids: List[int] = []
         self._orphan_objv = {}       # summaries of deleted objects (the reference never purges obj_v, :298-307)
         self._scratch = {}
+        self._commit_plans = {}      # bucket id -> (signature, one-launch OpList) of _commit_ahead
         self.config_stale = True
         self.engaged = False
         self.aux = None
@@ -320,18 +321,23 @@ class MemoryManager:
             return
         tick_work = bucket.n_work > 0
         tick_long = bucket.n_long > 0 and self.count_long_term_usage
-        ol = O.OpList()
-        ol.usage_tick(bucket.life[bucket.work_start:] if tick_work else None, bucket.n_work if tick_work else 0,
-                      bucket.life if tick_long else None, bucket.n_long if tick_long else 0,
-                      use=bucket.use, delta=udelta, n_use=int(udelta.shape[0]))
+        # (host time: the launch is the same until the bank changes -- every mem_every-th frame -- so its descriptor is kept)
+        sig = (bucket.life.data_ptr(), bucket.use.data_ptr(), bucket.work_start, bucket.n_work if tick_work else 0,
+               bucket.n_long if tick_long else 0, int(udelta.shape[0]))
+        cached = self._commit_plans.get(bucket.id)
+        if cached is None or cached[0] != sig:
+            ol = O.OpList()
+            ol.usage_tick(bucket.life[bucket.work_start:] if tick_work else None, sig[3], bucket.life if tick_long else None, sig[4],
+                          use=bucket.use, delta=O.Dyn('delta'), n_use=sig[5])
+            cached = self._commit_plans[bucket.id] = (sig, ol)
+        ol = cached[1]
         side = None
         if COMMIT_ON_SIDE and network is not None and udelta.is_cuda:
             side = network.engine().__dict__.get('_streams', {}).get('side')
         if side is None:
-            ol.run()
+            ol.run(delta=udelta)
             return
-        with torch.cuda.stream(side):                            # (the read-out that filled udelta ran on this stream: in order)
-            ol.run()
+        ol.run(_stream=side, delta=udelta)                       # (the read-out that filled udelta ran on this stream: in order)
         self._side_pending = side
 
     def _join_side(self) -> None:

@@ -43,6 +43,13 @@ def group_nhwc_of(t, dtype=BF16):
     return p
 
 
+def f32c(t):
+    """t as contiguous fp32 -- without a torch call when it already is (host time: a no-op .to() costs ~1 us, five per frame)."""
+    if t.dtype != F32:
+        t = t.to(F32)
+    return t if t.is_contiguous() else t.contiguous()
+
+
 def logical(p):
     """physical [B,H,W,C] -> logical [B,C,H,W] view."""
     return p.permute(0, 3, 1, 2)
@@ -58,9 +65,11 @@ class Engine:
 
     def __init__(self, sd: Dict[str, torch.Tensor], m, device):
         self.m, self.device = m, device
+        self.devstr = str(device)                   # (pool keys; str(device) per call is host time)
         self.w = {}
         self._plans = {}
         self.pool = plans.SlotPool()                # per-frame plan outputs at stable addresses (HIP-graph replay)
+        self.enc_specs = {}                         # (h, w) -> (pool key, output specs) of the image encoder: built once (host time)
         self.tile_cache = plans.load_tile_cache()   # conv geometry -> autotuned (tile id, split-K); optionally persisted
         self._pe = {}
         self._rep = {}
@@ -387,7 +396,14 @@ class CUTIE(nn.Module):
 
     @property
     def device(self) -> torch.device:
-        return self.pixel_mean.device
+        d = self.__dict__.get('_device_cache')     # (asked a dozen times per frame; nn.Module's buffer look-up is ~1 us)
+        if d is None:
+            d = self.__dict__['_device_cache'] = self.pixel_mean.device
+        return d
+
+    def _apply(self, fn, *args, **kwargs):         # .cuda() / .to() / .cpu(): the module may have moved
+        self.__dict__.pop('_device_cache', None)
+        return super()._apply(fn, *args, **kwargs)
 
     def fork(self) -> 'CUTIE':
         """A view of this network for a second concurrent clip (own HIP stream / host thread): shares the parameters, the
@@ -412,26 +428,30 @@ class CUTIE(nn.Module):
     def _encode(self, image, h0, w0, H, W, pad_left, pad_top):
         """image f32 [3,h0,w0] (un-padded) -> dict of physical outputs (fused encode_image + transform_key)."""
         eng = self.engine()
-        dev = self.device
+        dev = eng.device
         m = self.model_cfg
         P = eng.plan(('enc', h0, w0, H, W, pad_left, pad_top), plans.build_encode, h0, w0, H, W, pad_left, pad_top)
         h, w = H // 16, W // 16
-        hw = h * w
-        HWp = -(-hw // 64) * 64
-        ms = self.ms_dims
         # Outputs from the frame-slot pool (stable addresses: the plan replays as a HIP graph).  The query-side affinity operands
         # Bhi / Blo / cq have padding rows [hw, HWp) that must stay zero and are never written: every pooled tensor starts zeroed.
-        W_ = eng.w
-        Z = False
-        specs = dict(f16=((1, h, w, ms[0]), BF16, Z), f8=((1, 2 * h, 2 * w, ms[1]), BF16, Z), f4=((1, 4 * h, 4 * w, ms[2]), BF16, Z),
-                     pix_feat=((1, h, w, m['pixel_dim']), BF16, Z), key=((hw, m['key_dim']), F32, Z), shr=((hw,), F32, Z),
-                     sel=((hw, m['key_dim']), F32, Z), Bhi=((HWp, 128), BF16, True), Blo=((HWp, 128), BF16, True), cq=((HWp,), F32, True),
-                     f8p=((1, 2 * h, 2 * w, W_['mask_decoder.decoder_feat_proc.transforms.0'].cout), BF16, Z),
-                     f4p=((1, 4 * h, 4 * w, W_['mask_decoder.decoder_feat_proc.transforms.1'].cout), BF16, Z),
-                     fuse_xt=((1, h, w, W_['pixel_fuser.fuser.distributor.x_transform'].cout), BF16, Z))
-        out = eng.pool.get(('enc', h, w, str(dev)), specs, dev)
+        cached = eng.enc_specs.get((h, w))
+        if cached is None:
+            hw = h * w
+            HWp = -(-hw // 64) * 64
+            ms = self.ms_dims
+            W_ = eng.w
+            Z = False
+            specs = dict(f16=((1, h, w, ms[0]), BF16, Z), f8=((1, 2 * h, 2 * w, ms[1]), BF16, Z), f4=((1, 4 * h, 4 * w, ms[2]), BF16, Z),
+                         pix_feat=((1, h, w, m['pixel_dim']), BF16, Z), key=((hw, m['key_dim']), F32, Z), shr=((hw,), F32, Z),
+                         sel=((hw, m['key_dim']), F32, Z), Bhi=((HWp, 128), BF16, True), Blo=((HWp, 128), BF16, True), cq=((HWp,), F32, True),
+                         f8p=((1, 2 * h, 2 * w, W_['mask_decoder.decoder_feat_proc.transforms.0'].cout), BF16, Z),
+                         f4p=((1, 4 * h, 4 * w, W_['mask_decoder.decoder_feat_proc.transforms.1'].cout), BF16, Z),
+                         fuse_xt=((1, h, w, W_['pixel_fuser.fuser.distributor.x_transform'].cout), BF16, Z))
+            cached = eng.enc_specs[(h, w)] = (('enc', h, w, eng.devstr), specs)
+        pool_key, specs = cached
+        out = eng.pool.get(pool_key, specs, dev)
         P.graph_head = 1                                       # IMG_PREP reads the caller's frame
-        image = image.to(F32).contiguous()
+        image = f32c(image)
         P.run(image=image, **out)
         out['h'], out['w'] = h, w
         # image-only results that the decoder / pixel fuser consume (found by the address of the feature they derive from)
@@ -445,7 +465,7 @@ class CUTIE(nn.Module):
         frame_context entries of a record are NOT made here: `_adopt_encoded` registers them when the frame is about to be consumed
         (the tables keep the last few frames only)."""
         eng = self.engine()
-        dev = self.device
+        dev = eng.device
         m = self.model_cfg
         B = len(images)
         P = eng.plan(('encw', B, h0, w0, H, W, pad_left, pad_top), plans.build_encode, h0, w0, H, W, pad_left, pad_top, B)
@@ -461,7 +481,7 @@ class CUTIE(nn.Module):
                      f8p=((B, 2 * h, 2 * w, W_['mask_decoder.decoder_feat_proc.transforms.0'].cout), BF16, Z),
                      f4p=((B, 4 * h, 4 * w, W_['mask_decoder.decoder_feat_proc.transforms.1'].cout), BF16, Z),
                      fuse_xt=((B, h, w, W_['pixel_fuser.fuser.distributor.x_transform'].cout), BF16, Z))
-        out = eng.pool.get_ring(('encw', B, h, w, str(dev)), specs, dev, ring=4)
+        out = eng.pool.get_ring(('encw', B, h, w, eng.devstr), specs, dev, ring=4)
         P.run(**({'image': images[0]} if B == 1 else {'image%d' % b: images[b] for b in range(B)}), **out)
         recs = []
         for b in range(B):
@@ -565,7 +585,7 @@ class CUTIE(nn.Module):
         """cutie.py:66-90.  image [1,3,H,W]; ms_features = stride-16 pix_feat; sensory [1,K,CS,h,w] fp32 (updated in
         place when deep_update); masks [1,K,H,W] -> (value, sensory, summaries [1,K,Q,C+1], None)."""
         eng = self.engine()
-        dev = self.device
+        dev = eng.device
         K = masks.shape[1]
         H, W = masks.shape[-2:]
         h, w = H // 16, W // 16
@@ -575,18 +595,18 @@ class CUTIE(nn.Module):
             img, h0, w0, pl, pt = image[0], H, W, 0, 0
         pix = nhwc_of(ms_features)
         sf, sb = self._sensory_pair(sensory)
-        mk = masks[0].to(F32).contiguous()
+        mk = f32c(masks[0])
         # MASK_DOWN(masks) is already there when these masks are the probabilities the last segment() returned (every memory frame of a
         # propagation): its up-sampling launch left them for the next frame's pixel fusion (see segment / pixel_fusion)
         md = frame_context.recall('mask_down', mk)
         md = md is not None and md == (K, h, w, eng.__dict__.get('_md_gen')) and plans.SUM_FUSED and not plans.UNFUSED
         P = eng.plan(('emask', K, h0, w0, H, W, pl, pt, bool(deep_update), md), plans.build_encode_mask, K, h0, w0, H, W, pl, pt,
                      bool(deep_update), md)
-        o = eng.pool.get(('emask', K, h, w, str(dev)),
+        o = eng.pool.get(('emask', K, h, w, eng.devstr),
                          dict(value=((K, h, w, self.value_dim), BF16, False),
                               summ=((K, self.model_cfg['object_summarizer']['num_summaries'], self.embed_dim + 1), F32, False)), dev)
         value, summ = o['value'], o['summ']
-        dyn = dict(image=img.to(F32).contiguous(), masks=mk, pix_feat=pix, sensory_f32=sf, sensory_bf16=sb, value=value, summ=summ)
+        dyn = dict(image=f32c(img), masks=mk, pix_feat=pix, sensory_f32=sf, sensory_bf16=sb, value=value, summ=summ)
         if _split:
             # two parts: the mask values first (what the memory bank needs), the sensory deep update + object summaries when the caller
             # asks for them -- InferenceCore inserts the values and starts the NEXT frame's affinity read-out on its side stream in between
@@ -610,12 +630,12 @@ class CUTIE(nn.Module):
         px = group_nhwc_of(pixel)
         K, h, w = px.shape[:3]
         _, sb = self._sensory_pair(sensory)
-        lm = last_mask[0].to(F32).contiguous()
+        lm = f32c(last_mask[0])
         xt = None if plans.UNFUSED else frame_context.recall('fuse_xt', pf)             # x_transform(pix_feat), computed with the encoder (None: a caller's own features)
         md = frame_context.recall('mask_down', lm)          # MASK_DOWN(last_mask), left by the segment() that produced this very tensor ...
         md = md is not None and md == (K, h, w, eng.__dict__.get('_md_gen'))      # ... if no later segment() has overwritten it
         P = eng.plan(('fuse', K, h, w, xt is not None, md), plans.build_pixel_fusion, K, h, w, xt is not None, md)
-        fused = eng.pool.get(('fuse', K, h, w, str(self.device)), dict(fused=((K, h, w, self.embed_dim), BF16, False)), self.device)['fused']
+        fused = eng.pool.get(('fuse', K, h, w, eng.devstr), dict(fused=((K, h, w, self.embed_dim), BF16, False)), eng.device)['fused']
         P.run(pix_feat=pf, pixel=px, sensory_bf16=sb, last_mask=lm, fused=fused, **({} if xt is None else {'fuse_xt': xt}))
         return group_logical(fused)
 
@@ -627,9 +647,12 @@ class CUTIE(nn.Module):
         eng = self.engine()
         px = group_nhwc_of(pixel_readout)
         K, h, w = px.shape[:3]
-        om = obj_memory[0].to(F32)
+        om = obj_memory[0]
+        if om.dtype != F32:
+            om = om.to(F32)
         om = om.sum(dim=1) if om.shape[1] != 1 else om[:, 0]
-        om = om.contiguous()
+        if not om.is_contiguous():
+            om = om.contiguous()
         # _summary_token (MemoryManager): identifies the CONTENT of obj_memory.  The query initialisation (summaries -> queries, two
         # linears) depends on nothing else; while the token repeats, the plan variant without that launch runs on the queries of the
         # last call (object_transformer.py:118-127 recomputes them every frame; they change on memory frames only).
@@ -637,7 +660,7 @@ class CUTIE(nn.Module):
         fresh = _summary_token is None or st.get(K) != _summary_token or not plans.QINIT_SKIP
         st[K] = _summary_token
         P = eng.plan(('rq', K, h, w, bool(_last_aux), fresh), plans.build_readout_query, K, h, w, bool(_last_aux), fresh)
-        out = eng.pool.get(('rq', K, h, w, str(self.device)), dict(out=((K, h, w, self.embed_dim), BF16, False)), self.device)['out']
+        out = eng.pool.get(('rq', K, h, w, eng.devstr), dict(out=((K, h, w, self.embed_dim), BF16, False)), eng.device)['out']
         P.run(pixel=px, obj_mem=om, out=out)
         n_aux = P.bufs['aux_logits'].shape[0] - (0 if _last_aux else 1)
         aux = {'logits': [P.bufs['aux_logits'][i].view(1, K, h, w) for i in range(n_aux)],
@@ -650,7 +673,7 @@ class CUTIE(nn.Module):
         _fork (InferenceCore, when the caller announces its next frames): the softmax launch on an auxiliary stream, see below."""
         assert selector is None, 'selector is a training-time argument'
         eng = self.engine()
-        dev = self.device
+        dev = eng.device
         p16 = group_nhwc_of(memory_readout)
         K, h, w = p16.shape[:3]
         f8, f4 = nhwc_of(ms_image_feat[1]), nhwc_of(ms_image_feat[2])
@@ -665,7 +688,7 @@ class CUTIE(nn.Module):
         sp = dict(prob=((K + 1, 16 * h, 16 * w), F32, False))
         if _need_logits:
             sp['lup'] = ((K + 1, 16 * h, 16 * w), F32, False)
-        o = eng.pool.get(('seg', K, h, w, bool(_need_logits), str(dev)), sp, dev)   # (a caller that keeps the probabilities keeps the slot: see SlotPool)
+        o = eng.pool.get(('seg', K, h, w, bool(_need_logits), eng.devstr), sp, dev)   # (a caller that keeps the probabilities keeps the slot: see SlotPool)
         prob, lup = o['prob'], o.get('lup')
         feats = dict(f8=f8, f4=f4) if pre is None else dict(f8p=pre[0], f4p=pre[1])
         dyn = dict(p16=p16, sensory_f32=sf, sensory_bf16=sb, prob=prob, logits_up=lup, **feats)

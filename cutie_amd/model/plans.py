@@ -173,7 +173,7 @@ class SlotPool:
     IDLE_FRAMES = int(os.environ.get('CUTIE_AMD_POOL_IDLE', '512'))      # a group nobody asked for in this many frames is dropped
 
     def __init__(self):
-        self.groups = {}                  # key -> {slot index: {name: tensor}}
+        self.groups = {}                  # key -> {slot index: (names, tensors, storages, storage handles)}
         self.last_used = {}               # key -> frame number of the last request
         self.frame = 0
         self.offset = 0
@@ -188,37 +188,60 @@ class SlotPool:
                 self.groups.pop(k, None)
                 del self.last_used[k]
 
+    @staticmethod
+    def _make_slot(specs, dev):
+        """One set of tensors + what `_free` needs: the storages are kept referenced here (that is the 2 of `_free`: this wrapper and
+        the tensor) so that asking for their use count does not build a Python storage object per tensor and request."""
+        names = tuple(specs)
+        tensors = [torch.zeros(sh, dtype=dt, device=dev) for (sh, dt, z) in specs.values()]
+        stores = [t.untyped_storage() for t in tensors]
+        return names, tensors, stores, [st._cdata for st in stores]
+
+    @staticmethod
+    def _free(slot):
+        """Nobody else holds a tensor of the slot or a view of one (aliases are what `_hand_out` returns)."""
+        for c in slot[3]:
+            if _USE_COUNT(c) != 2:
+                return False
+        return True
+
+    @staticmethod
+    def _hand_out(slot):
+        # aliases (detach: same storage, shape and strides; a third of the cost of view(shape)): whoever keeps one -- or a view of
+        # it -- keeps the slot busy
+        return {nm: t.detach() for nm, t in zip(slot[0], slot[1])}
+
     def get(self, key, specs, dev):
         """specs: {name: (shape, dtype, zero)} -> {name: tensor}"""
-        fresh = lambda: {n: (torch.zeros if z else torch.empty)(sh, dtype=dt, device=dev) for n, (sh, dt, z) in specs.items()}
         if self.SLOTS <= 0 or _USE_COUNT is None:
-            return fresh()
-        slots = self.groups.setdefault(key, {})
+            return {n: (torch.zeros if z else torch.empty)(sh, dtype=dt, device=dev) for n, (sh, dt, z) in specs.items()}
+        slots = self.groups.get(key)
+        if slots is None:
+            slots = self.groups[key] = {}
         self.last_used[key] = self.frame
         i = (self.frame + self.offset) % self.SLOTS
         slot = slots.get(i)
         if slot is None:
-            slot = slots[i] = {nm: torch.zeros(sh, dtype=dt, device=dev) for nm, (sh, dt, z) in specs.items()}
-        if all(_storage_users(t) == 0 for t in slot.values()):
-            return {nm: t.view(t.shape) for nm, t in slot.items()}      # aliases: whoever keeps one (or a view of it) keeps the slot busy
-        return fresh()
+            slot = slots[i] = self._make_slot(specs, dev)
+        if self._free(slot):
+            return self._hand_out(slot)
+        return {n: (torch.zeros if z else torch.empty)(sh, dtype=dt, device=dev) for n, (sh, dt, z) in specs.items()}
 
     def get_ring(self, key, specs, dev, ring=3):
         """Like `get`, for outputs that are not produced once per frame (the look-ahead window of the image encoder: one set per
         batch of frames): the group cycles through `ring` sets of its own; a set somebody still holds is not recycled."""
-        fresh = lambda: {n: (torch.zeros if z else torch.empty)(sh, dtype=dt, device=dev) for n, (sh, dt, z) in specs.items()}
         if self.SLOTS <= 0 or _USE_COUNT is None:
-            return fresh()
+            return {n: (torch.zeros if z else torch.empty)(sh, dtype=dt, device=dev) for n, (sh, dt, z) in specs.items()}
         slots = self.groups.setdefault(key, {'next': 0})
         self.last_used[key] = self.frame
         i = slots['next'] % ring
         slots['next'] = i + 1
         slot = slots.get(i)
         if slot is None:
-            slot = slots[i] = {nm: torch.zeros(sh, dtype=dt, device=dev) for nm, (sh, dt, z) in specs.items()}
-        if all(_storage_users(t) == 0 for t in slot.values()):
-            return {nm: t.view(t.shape) for nm, t in slot.items()}
-        return fresh()
+            slot = slots[i] = self._make_slot(specs, dev)
+        if self._free(slot):
+            return self._hand_out(slot)
+        return {n: (torch.zeros if z else torch.empty)(sh, dtype=dt, device=dev) for n, (sh, dt, z) in specs.items()}
 
 
 def weights_go_cold(px16, K=None):

@@ -264,6 +264,7 @@ class OpList:
         self.wbytes = {}        # conv op index -> bytes of its packed weights
         self.dyn = {}           # name -> [(op index, slot, offset)]
         self.arr = None
+        self._words = None      # bind's view of `dyn` and `arr` (rebuilt with the array)
 
     # ---- generic ------------------------------------------------------------------
     def add(self, kind, flags=0, ints=(), floats=(), ptrs=()):
@@ -278,7 +279,7 @@ class OpList:
                     self.keep.append(t)
                 pl.append(_ptr(t))
         self.recs.append((kind, flags, [int(v) for v in ints], [float(v) for v in floats], pl))
-        self.arr = None
+        self.arr = self._words = None
         return idx
 
     def finalize(self):
@@ -290,6 +291,7 @@ class OpList:
             arr['f'][n, :len(floats)] = floats
             arr['p'][n, :len(ptrs)] = ptrs
         self.arr = arr
+        self._words = None
         self.wire_next_weights()
         return arr
 
@@ -320,21 +322,44 @@ class OpList:
             nxt, nxt2 = (int(arr['p'][n, 2]), self.wbytes[n], pc), nxt
 
     def bind(self, **tensors):
-        """Patch dynamic pointer slots.  Values: torch tensors or raw ints."""
+        """Patch dynamic pointer slots.  Values: torch tensors or raw ints.  (Host time: this runs five times per frame with a dozen
+        names each -- the slots of a name are 64-bit word indices into the descriptor array, written through one memoryview.)"""
         if self.arr is None:
             self.finalize()
-        p = self.arr['p']
+        words = self._words
+        if words is None:
+            # a descriptor is 32 words; its pointer field starts at word 16 (include/cutie_hip.h, asserted against the dtype)
+            assert OP_DTYPE.itemsize == 256 and OP_DTYPE.fields['p'][1] == 128
+            words = self._words = ({name: tuple((idx * 32 + 16 + slot, off) for (idx, slot, off) in sl) for name, sl in self.dyn.items()},
+                                   memoryview(self.arr).cast('B').cast('Q'))
+        table, mv = words
         for name, t in tensors.items():
-            base = _ptr(t)
-            for (idx, slot, off) in self.dyn.get(name, ()):
-                p[idx, slot] = base + off if base else 0
+            sl = table.get(name)
+            if sl is None:
+                continue
+            base = 0 if t is None else (t if type(t) is int else t.data_ptr())
+            if base:
+                for w, off in sl:
+                    mv[w] = base + off
+            else:
+                for w, off in sl:
+                    mv[w] = 0
 
-    def run(self, **tensors):
+    def run(self, _stream=None, **tensors):
+        """_stream: a torch stream other than the current one to launch on (the executor is handed its raw handle; an executor
+        without `run_on` -- the recording shims, the interpreter of the tests -- runs inside torch's stream context instead)."""
         if self.arr is None:
             self.finalize()
         if tensors:
             self.bind(**tensors)
-        _lib.get_executor().run(self.arr)
+        ex = _lib.get_executor()
+        if _stream is None:
+            ex.run(self.arr)
+        elif hasattr(ex, 'run_on'):
+            ex.run_on(self.arr, _stream)
+        else:
+            with torch.cuda.stream(_stream):
+                ex.run(self.arr)
 
     def __len__(self):
         return len(self.recs)
