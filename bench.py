@@ -63,10 +63,36 @@ def parse():
     ap.add_argument('--repeats', type=int, default=5,
                     help='the timed region of --steps frames is repeated this many times; "value" is the FIRST one (the protocol-conform '
                          'measurement), the spread goes to "repeats"')
-    ap.add_argument('--clips-in-flight', type=int, default=4,
+    ap.add_argument('--clips-in-flight', type=int, default=2,
                     help='also measure the aggregate frames/s with this many independent clips in flight per GPU '
                          '(one host thread + HIP stream + CUTIE.fork() each; reported as "multi_clip"; 0 = skip)')
+    ap.add_argument('--multi-hw-queues', type=int, default=0,
+                    help='> 0 (one GPU): the clips-in-flight leg runs in a child process started with GPU_MAX_HW_QUEUES set to this (HIP maps '
+                         'its streams onto 4 hardware queues by default).  Experimental: 3-4 clips then reach 1700-1865 frames/s in some '
+                         'runs and 900-1050 in others (profiles/r05_clips_in_flight.txt); 0 = in this process, default environment')
+    ap.add_argument('--multi-only', action='store_true', help='(internal) run the clips-in-flight leg only and print its seconds')
+    ap.add_argument('--device-index', type=int, default=None, help='(internal) GPU of a --multi-only child')
     return ap.parse_args()
+
+
+def multi_clip_child(args, local):
+    """The clips-in-flight leg in a child process of its own (one GPU, no process group): same workload arguments, GPU_MAX_HW_QUEUES
+    set before the HIP runtime starts.  Returns (seconds, hardware queues) or raises."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT',
+                                                            'GROUP_RANK', 'ROLE_RANK', 'TORCHELASTIC_RUN_ID')}
+    env['GPU_MAX_HW_QUEUES'] = str(args.multi_hw_queues)
+    cmd = [sys.executable, os.path.abspath(__file__), '--multi-only', '--device-index', str(local), '--clips-in-flight', str(args.clips_in_flight),
+           '--steps', str(args.steps), '--warmup', str(args.warmup), '--preroll', str(args.preroll), '--objects', str(args.objects),
+           '--height', str(args.height), '--width', str(args.width), '--window', str(args.window)]
+    if args.no_long_term:
+        cmd.append('--no-long-term')
+    if args.no_lookahead:
+        cmd.append('--no-lookahead')
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError('clips-in-flight child failed: ' + r.stderr[-800:])
+    return float(json.loads(r.stdout.strip().splitlines()[-1])['seconds'])
 
 
 def multi_clip_throughput(net, cfg, args, K, rank, dist, dev):
@@ -82,6 +108,8 @@ def multi_clip_throughput(net, cfg, args, K, rank, dist, dev):
         clip = SyntheticClip(args.height, args.width, K, NF, seed=101 + 16 * rank + c)
         data.append((torch.stack([clip.frame(t) for t in range(NF)]).to(dev), clip.first_mask().to(dev), clip.objects))
     views = [net] + [net.fork() for _ in range(C - 1)]
+    for v in views:
+        v.engine().one_lane = True                          # one stream per clip, as cutie_amd/parallel.py:run_concurrent runs them
     ready, start, done = threading.Barrier(C + 1), threading.Barrier(C + 1), threading.Barrier(C + 1)
     finish, errors = [0.0] * C, []
 
@@ -142,6 +170,7 @@ def multi_clip_throughput(net, cfg, args, K, rank, dist, dev):
         give_up()
     for t in threads:
         t.join()
+    net.engine().one_lane = False
     if errors:
         raise errors[0]
     return max(finish) - t0
@@ -237,6 +266,8 @@ def main():
             pinned = None
         import torch.distributed as dist
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
+    if args.multi_only:
+        local = args.device_index if args.device_index is not None else local
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -256,6 +287,10 @@ def main():
     from cutie_amd.utils.synth_weights import make_state_dict   # same deterministic synthetic weights as the parity tests
     sd = make_state_dict(seed=0)
     net.load_weights(sd)
+    if args.multi_only:                                    # (the child of multi_clip_child: this leg and nothing else)
+        secs = multi_clip_throughput(net, cfg, args, K, rank, None, dev)
+        print(json.dumps({'seconds': secs, 'steps_per_clip': multi_clip_steps(args), 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES')}))
+        return
     rec = Recorder(_lib.get_executor())
     _lib.set_executor_for_testing(rec)                     # only a recording shim around the HIP executor
 
@@ -491,8 +526,9 @@ def main():
     multi = None
     if args.clips_in_flight > 1:
         # an extra leg: a failure here is reported in the line, it must not take the headline measurement with it
+        in_child = world == 1 and args.multi_hw_queues > 0
         try:
-            leg, leg_err = multi_clip_throughput(net, cfg, args, K, rank, dist, dev), None
+            leg, leg_err = (multi_clip_child(args, local) if in_child else multi_clip_throughput(net, cfg, args, K, rank, dist, dev)), None
         except Exception as e:
             import traceback
             traceback.print_exc()
@@ -507,8 +543,11 @@ def main():
             msteps = multi_clip_steps(args)
             multi = {'clips_in_flight_per_gpu': args.clips_in_flight, 'value': round(world * args.clips_in_flight * msteps / mt, 2),
                      'unit': 'frames/s', 'steps_per_clip': msteps, 'ms_per_step': round(mt / msteps * 1e3, 4),
-                     'note': 'same workload, independent clips interleaved on one GPU (one host thread + HIP stream + CUTIE.fork() per '
-                             'clip, cutie_amd/parallel.py); "value" above stays one clip per GPU'}
+                     'hw_queues': (args.multi_hw_queues if in_child else os.environ.get('GPU_MAX_HW_QUEUES', 'default (4)')),
+                     'note': 'same workload, independent clips interleaved on one GPU (one host thread + ONE HIP stream + CUTIE.fork() per '
+                             'clip, cutie_amd/parallel.py:run_concurrent' + ('; measured in a child process started with GPU_MAX_HW_QUEUES=%d: '
+                             'HIP maps streams onto 4 hardware queues by default and clips that share one serialise' % args.multi_hw_queues if in_child else '')
+                             + '); "value" above stays one clip per GPU, default environment'}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:

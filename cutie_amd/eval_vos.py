@@ -3,7 +3,7 @@ first-mask alignment, ``end`` on the last frame, FPS = frames / sum of device-ev
 ``VOSTestDataset`` / ``VideoReader`` / ``ResultSaver``.
 
     python -m cutie_amd.eval_vos --images DIR/JPEGImages --masks DIR/Annotations --output OUT [--weights ckpt.pth]
-        [--size 480] [--use-all-masks] [--long-term] [--dataset d17-val] [--visualize] [--clips-in-flight 4]
+        [--size 480] [--use-all-masks] [--long-term] [--dataset d17-val] [--visualize] [--clips-in-flight 2]
         [--model small] [--flip-aug] [--save-scores]      (multi-scale testing: one run per --size with --save-scores, then
                                            python -m cutie_amd.merge_multi_scale --list OUT_a OUT_b --output MERGED)
 

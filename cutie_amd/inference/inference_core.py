@@ -104,7 +104,13 @@ class InferenceCore:
         """The look-ahead streams belong to the ENGINE (= one set of plan buffers / arenas), not to the processor: two processors that
         drive the same network one after the other (clip after clip, a flip lane) then order their look-ahead work on the shared plan
         buffers by stream order.  (CUTIE.fork() gives a concurrent clip its own engine, hence its own streams.)"""
-        st = self.network.engine().__dict__.setdefault('_streams', {})
+        eng = self.network.engine()
+        if plans.ONE_LANE or eng.one_lane:
+            # several clips in flight on one GPU (cutie_amd/parallel.py): the look-ahead lanes of a clip keep their batching (one
+            # encoder plan per 12 frames, one read-out per bank version) but run on the clip's own stream -- the other clips are what
+            # fills the device next to it, and a clip that brings four streams of its own only competes for the hardware queues
+            return torch.cuda.current_stream(dev)
+        st = eng.__dict__.setdefault('_streams', {})
         if name not in st:
             st[name] = torch.cuda.Stream(device=dev)
         return st[name]

@@ -333,7 +333,8 @@ class MemoryManager:
         ol = cached[1]
         side = None
         if COMMIT_ON_SIDE and network is not None and udelta.is_cuda:
-            side = network.engine().__dict__.get('_streams', {}).get('side')
+            eng = network.engine()
+            side = None if eng.one_lane else eng.__dict__.get('_streams', {}).get('side')
         if side is None:
             ol.run(delta=udelta)
             return

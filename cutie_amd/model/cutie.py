@@ -66,6 +66,7 @@ class Engine:
     def __init__(self, sd: Dict[str, torch.Tensor], m, device):
         self.m, self.device = m, device
         self.devstr = str(device)                   # (pool keys; str(device) per call is host time)
+        self.one_lane = False                       # the look-ahead lanes on the caller's own stream (parallel.run_concurrent sets it)
         self.w = {}
         self._plans = {}
         self.pool = plans.SlotPool()                # per-frame plan outputs at stable addresses (HIP-graph replay)
@@ -693,7 +694,7 @@ class CUTIE(nn.Module):
         feats = dict(f8=f8, f4=f4) if pre is None else dict(f8p=pre[0], f4p=pre[1])
         dyn = dict(p16=p16, sensory_f32=sf, sensory_bf16=sb, prob=prob, logits_up=lup, **feats)
         n_ops, cut = len(P.ol.recs), P.meta.get('logits_done', 0)
-        if _fork and plans.SEG_FORK and update_sensory and dev.type == 'cuda' and not plans.GRAPHS and 0 < cut < n_ops - 1 and not plans.UNFUSED and K + 1 <= 16:
+        if _fork and plans.SEG_FORK and not (plans.ONE_LANE or eng.one_lane) and update_sensory and dev.type == 'cuda' and not plans.GRAPHS and 0 < cut < n_ops - 1 and not plans.UNFUSED and K + 1 <= 16:
             # Behind the logits the plan forks: [area pooling, two convs, GRU] update the sensory state, the LAST launch up-samples the
             # logits and takes the softmax.  Neither branch reads what the other writes, and every launch is a serial step of the
             # frame's critical path (~3.4 us of launch boundary on top of its run time): the softmax launch goes to an auxiliary

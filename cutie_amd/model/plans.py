@@ -77,6 +77,7 @@ SEG_MD = os.environ.get('CUTIE_AMD_SEG_MD', '1') not in ('', '0')
 # 7.0 + 4.8 us + a boundary for the two launches (frame: -1.8 %; profiles/r04_frame_chain.md section 6)
 P2Q_OUT = os.environ.get('CUTIE_AMD_P2Q_OUT', '0') not in ('', '0')
 QINIT_SKIP = os.environ.get('CUTIE_AMD_QINIT_SKIP', '1') not in ('', '0')   # query initialisation only when the object summaries changed (A/B switch)
+ONE_LANE = os.environ.get('CUTIE_AMD_ONE_LANE', '0') not in ('', '0')   # every look-ahead lane of a clip on the caller's own stream (several clips in flight: see cutie_amd/parallel.py)
 ECA_HEAD = os.environ.get('CUTIE_AMD_ECA_HEAD', '1') not in ('', '0')   # mask_pred of a transformer block inside the ECA launch (A/B switch)
 QNEXT = os.environ.get('CUTIE_AMD_QNEXT', '1') not in ('', '0')       # ATTN_P2Q also projects the next block's ATTN_Q2P queries
 AUTOTUNE = os.environ.get('CUTIE_AMD_AUTOTUNE', '0') not in ('', '0')

@@ -5,13 +5,15 @@ distributed round-robin, one process per GPU (``torch.distributed``; backend "nc
 "gloo" in the CPU tests).  There is no collective on the per-frame path: the only communication is the final
 gather of per-clip results to rank 0 -- a direct (non-ring) gather, since the payload is small and latency-bound.
 
-Inside one GPU, several clips can be *in flight* at once (``run_concurrent``): one host thread + HIP stream +
-``CUTIE.fork()`` per clip.  A single clip is a chain of ~200 dependent small launches per frame and leaves most of the 256
-CUs idle most of the time (kernel-boundary bubbles, layers with < 256 workgroups); four independent chains interleave on
-the hardware queues.  Measured on the MI355X (the bench line's `multi_clip`; one number per box, boxes differ): round 5, four clips in flight
-1348 frames/s against 1116 for one clip in the driver's box -- host-bound (four Python threads behind one interpreter lock: 923 on a box
-with a slower host).  A single clip is a latency chain of ~50 dependent launches per frame on its own stream,
-the look-ahead lanes already fill part of the idle compute units, and the rest is what several clips in flight can still use.
+Inside one GPU, several clips can be *in flight* at once (``run_concurrent``): one host thread + ONE HIP stream +
+``CUTIE.fork()`` per clip.  A single clip is a chain of dependent small launches per frame and leaves compute units idle
+(kernel-boundary bubbles, layers with < 256 workgroups); independent chains interleave on the hardware queues.  A clip in flight keeps
+the batching of its look-ahead lanes (one encoder plan per 12 frames, one read-out per bank version) but runs them on its own stream
+(``Engine.one_lane``): next to other clips its extra streams only compete for the hardware queues.  Measured on the MI355X (round 5,
+`profiles/r05_clips_in_flight.txt`, `profiles/r05_host_trims_ab.txt`; the bench line's `multi_clip`): two clips in flight 1536-1565
+frames/s against 1115-1180 for one clip; three or four clips reach 1700-1865 when the process is started with GPU_MAX_HW_QUEUES >= 8 --
+or 900-1050 in the next run of the same command (not understood; with the default four hardware queues four clips give ~1240), hence the
+default of two.
 """
 import queue
 import threading
@@ -57,7 +59,7 @@ def timed_steps(step: Callable[[int], None], steps: int, warmup: int, device) ->
     return float(t.item())
 
 
-def run_concurrent(net, clip_ids: Sequence[int], run_clip: Callable, *, streams: int = 4) -> Dict[int, Dict]:
+def run_concurrent(net, clip_ids: Sequence[int], run_clip: Callable, *, streams: int = 2) -> Dict[int, Dict]:
     """Run ``run_clip(net_view, clip_id) -> result`` for every clip with up to ``streams`` clips in flight on the GPU of
     ``net``.  Every worker owns a host thread, a HIP stream and a ``net.fork()`` (shared weights, private launch plans and
     activation buffers); clips are pulled from a common queue.  The first clip runs alone when the conv tiles are not
@@ -102,11 +104,20 @@ def run_concurrent(net, clip_ids: Sequence[int], run_clip: Callable, *, streams:
             tuned.set()
 
     views = [net] + [net.fork() for _ in range(n - 1)]
-    threads = [threading.Thread(target=work, args=(views[i], i == 0), daemon=True) for i in range(n)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    # One stream per clip (see the module docstring): the other clips are what runs next to a clip's chain, and n x 4 streams only share
+    # the device's hardware queues (HIP maps streams onto $GPU_MAX_HW_QUEUES = 4 of them by default).
+    lanes = [(v.engine(), v.engine().one_lane) for v in views] if n > 1 else []
+    for eng, _ in lanes:
+        eng.one_lane = True
+    try:
+        threads = [threading.Thread(target=work, args=(views[i], i == 0), daemon=True) for i in range(n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        for eng, was in lanes:
+            eng.one_lane = was
     if errors:
         raise errors[0]
     return results

@@ -532,6 +532,14 @@ def test_lookahead_window_matches_plain_order(gpu_net, size, K):
         for name, h in (('full', full), ('stacked', stacked), ('short', short), ('changing', changing), ('mixed', mixed)):
             got = run(h)
             assert torch.equal(got, plain), (name, float((got - plain).abs().max()))
+        eng = gpu_net.engine()
+        eng.one_lane = True                                  # the lanes of a clip in flight next to others: all on the caller's stream
+        try:
+            for name, h in (('full', full), ('mixed', mixed)):
+                got = run(h)
+                assert torch.equal(got, plain), ('one lane', name, float((got - plain).abs().max()))
+        finally:
+            eng.one_lane = False
 
 
 def test_announced_frame_overwritten_in_place_is_encoded_again(gpu_net):
@@ -769,19 +777,32 @@ def test_concurrent_clips_match_sequential(gpu_net):
     from cutie_amd.parallel import run_concurrent
     from cutie_amd.utils.synth import SyntheticClip
 
-    def run_clip(net, c):
+    lanes_seen = []
+
+    def run_clip(net, c, hinted=False):
         clip = SyntheticClip(240, 432, 3, 12, seed=40 + c)
+        frames = [clip.frame(t).cuda() for t in range(12)]
         proc = InferenceCore(net, cfg=default_config(mem_every=3))
-        outs = [proc.step(clip.frame(0).cuda(), clip.first_mask().cuda(), objects=clip.objects)]
+        lanes_seen.append(net.engine().one_lane)
+        hint = (lambda t: dict(next_images=frames[t + 1:t + 9])) if hinted else (lambda t: {})
+        outs = [proc.step(frames[0], clip.first_mask().cuda(), objects=clip.objects, **hint(0))]
         for t in range(1, 12):
-            outs.append(proc.step(clip.frame(t).cuda()))
+            outs.append(proc.step(frames[t], **hint(t)))
         return torch.stack(outs).cpu()
 
     with torch.inference_mode():
         seq = {c: run_clip(gpu_net, c) for c in range(5)}
+    assert not any(lanes_seen)
     conc = run_concurrent(gpu_net, list(range(5)), run_clip, streams=4)
     for c in range(5):
         assert torch.isfinite(conc[c]).all()
+        assert torch.equal(conc[c], seq[c]), (c, float((conc[c] - seq[c]).abs().max()))
+    # clips in flight keep their look-ahead lanes on their own stream (Engine.one_lane, set for the duration of run_concurrent): the
+    # window encoder and the stacked read-outs run in line -- same launches, same results
+    del lanes_seen[:]
+    conc = run_concurrent(gpu_net, list(range(5)), lambda net, c: run_clip(net, c, hinted=True), streams=2)
+    assert all(lanes_seen) and len(lanes_seen) == 5 and not gpu_net.engine().one_lane
+    for c in range(5):
         assert torch.equal(conc[c], seq[c]), (c, float((conc[c] - seq[c]).abs().max()))
 
 
