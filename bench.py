@@ -63,13 +63,15 @@ def parse():
     ap.add_argument('--repeats', type=int, default=5,
                     help='the timed region of --steps frames is repeated this many times; "value" is the FIRST one (the protocol-conform '
                          'measurement), the spread goes to "repeats"')
-    ap.add_argument('--clips-in-flight', type=int, default=2,
+    ap.add_argument('--clips-in-flight', type=int, default=4,
                     help='also measure the aggregate frames/s with this many independent clips in flight per GPU '
-                         '(one host thread + HIP stream + CUTIE.fork() each; reported as "multi_clip"; 0 = skip)')
+                         '(one HIP stream + CUTIE.fork() each, see --multi-mode; reported as "multi_clip"; 0 = skip)')
     ap.add_argument('--multi-hw-queues', type=int, default=0,
                     help='> 0 (one GPU): the clips-in-flight leg runs in a child process started with GPU_MAX_HW_QUEUES set to this (HIP maps '
                          'its streams onto 4 hardware queues by default).  Experimental: 3-4 clips then reach 1700-1865 frames/s in some '
                          'runs and 900-1050 in others (profiles/r05_clips_in_flight.txt); 0 = in this process, default environment')
+    ap.add_argument('--multi-mode', choices=('threads', 'interleaved'), default='interleaved',
+                    help='clips in flight driven by one host thread per clip, or by ONE thread that issues a step of every clip in turn')
     ap.add_argument('--multi-only', action='store_true', help='(internal) run the clips-in-flight leg only and print its seconds')
     ap.add_argument('--device-index', type=int, default=None, help='(internal) GPU of a --multi-only child')
     return ap.parse_args()
@@ -84,7 +86,7 @@ def multi_clip_child(args, local):
     env['GPU_MAX_HW_QUEUES'] = str(args.multi_hw_queues)
     cmd = [sys.executable, os.path.abspath(__file__), '--multi-only', '--device-index', str(local), '--clips-in-flight', str(args.clips_in_flight),
            '--steps', str(args.steps), '--warmup', str(args.warmup), '--preroll', str(args.preroll), '--objects', str(args.objects),
-           '--height', str(args.height), '--width', str(args.width), '--window', str(args.window)]
+           '--height', str(args.height), '--width', str(args.width), '--window', str(args.window), '--multi-mode', args.multi_mode]
     if args.no_long_term:
         cmd.append('--no-long-term')
     if args.no_lookahead:
@@ -174,6 +176,49 @@ def multi_clip_throughput(net, cfg, args, K, rank, dist, dev):
     if errors:
         raise errors[0]
     return max(finish) - t0
+
+
+def multi_clip_interleaved(net, cfg, args, K, rank, dist, dev):
+    """Same workload, C clips in flight driven by THIS thread in turn (cutie_amd/parallel.py:run_interleaved's scheme): one stream, one
+    net.fork() and one frame_context table per clip; returns the seconds for multi_clip_steps(args) frames of every clip."""
+    from cutie_amd import frame_context
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.utils.synth import SyntheticClip
+    C, NF = args.clips_in_flight, 48
+    steps = multi_clip_steps(args)
+    views = [net] + [net.fork() for _ in range(C - 1)]
+    for v in views:
+        v.engine().one_lane = True
+    clips = []
+    try:
+        with torch.inference_mode():
+            for c in range(C):
+                clip = SyntheticClip(args.height, args.width, K, NF, seed=101 + 16 * rank + c)
+                frames = torch.stack([clip.frame(t) for t in range(NF)]).to(dev)
+                st, ctx = torch.cuda.Stream(device=dev), frame_context.new_context()
+                with frame_context.context(ctx), torch.cuda.stream(st):
+                    proc = InferenceCore(views[c], cfg=cfg)
+                    nxt = make_hint(args, frames, NF)
+                    proc.step(frames[0], clip.first_mask().to(dev), objects=clip.objects, **nxt(0))
+                clips.append((proc, frames, nxt, st, ctx))
+
+            def round_(t):
+                for proc, frames, nxt, st, ctx in clips:
+                    with frame_context.context(ctx), torch.cuda.stream(st):
+                        proc.step(frames[t % NF], **nxt(t))
+
+            for t in range(1, 1 + args.preroll + args.warmup):
+                round_(t)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for t in range(steps):
+                round_(1 + args.preroll + args.warmup + t)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+    finally:
+        net.engine().one_lane = False
 
 
 def multi_clip_steps(args):
@@ -288,7 +333,7 @@ def main():
     sd = make_state_dict(seed=0)
     net.load_weights(sd)
     if args.multi_only:                                    # (the child of multi_clip_child: this leg and nothing else)
-        secs = multi_clip_throughput(net, cfg, args, K, rank, None, dev)
+        secs = (multi_clip_interleaved if args.multi_mode == 'interleaved' else multi_clip_throughput)(net, cfg, args, K, rank, None, dev)
         print(json.dumps({'seconds': secs, 'steps_per_clip': multi_clip_steps(args), 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES')}))
         return
     rec = Recorder(_lib.get_executor())
@@ -528,7 +573,8 @@ def main():
         # an extra leg: a failure here is reported in the line, it must not take the headline measurement with it
         in_child = world == 1 and args.multi_hw_queues > 0
         try:
-            leg, leg_err = (multi_clip_child(args, local) if in_child else multi_clip_throughput(net, cfg, args, K, rank, dist, dev)), None
+            leg, leg_err = (multi_clip_child(args, local) if in_child else
+                            (multi_clip_interleaved if args.multi_mode == 'interleaved' else multi_clip_throughput)(net, cfg, args, K, rank, dist, dev)), None
         except Exception as e:
             import traceback
             traceback.print_exc()
@@ -544,8 +590,9 @@ def main():
             multi = {'clips_in_flight_per_gpu': args.clips_in_flight, 'value': round(world * args.clips_in_flight * msteps / mt, 2),
                      'unit': 'frames/s', 'steps_per_clip': msteps, 'ms_per_step': round(mt / msteps * 1e3, 4),
                      'hw_queues': (args.multi_hw_queues if in_child else os.environ.get('GPU_MAX_HW_QUEUES', 'default (4)')),
-                     'note': 'same workload, independent clips interleaved on one GPU (one host thread + ONE HIP stream + CUTIE.fork() per '
-                             'clip, cutie_amd/parallel.py:run_concurrent' + ('; measured in a child process started with GPU_MAX_HW_QUEUES=%d: '
+                     'host': ('one thread issues a step of every clip in turn (cutie_amd/parallel.py:run_interleaved)' if args.multi_mode == 'interleaved'
+                              else 'one host thread per clip (cutie_amd/parallel.py:run_concurrent)'),
+                     'note': 'same workload, independent clips in flight on one GPU (ONE HIP stream + CUTIE.fork() per clip' + ('; measured in a child process started with GPU_MAX_HW_QUEUES=%d: '
                              'HIP maps streams onto 4 hardware queues by default and clips that share one serialise' % args.multi_hw_queues if in_child else '')
                              + '); "value" above stays one clip per GPU, default environment'}
 

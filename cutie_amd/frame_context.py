@@ -25,6 +25,29 @@ def _table():
     return t
 
 
+def new_context():
+    """An empty table of its own for `context`: one per clip when ONE host thread drives several clips in turn
+    (cutie_amd/parallel.py:run_interleaved) -- the per-kind caps are sized for the frames in flight of one clip."""
+    return (OrderedDict(), {})
+
+
+class context:
+    """with context(ctx): the calling thread's table is `ctx` (from `new_context`) inside the block."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        _table()
+        self.old = (_local.table, _local.capped)
+        _local.table, _local.capped = self.ctx
+        return self
+
+    def __exit__(self, *exc):
+        _local.table, _local.capped = self.old
+        return False
+
+
 def remember(kind, tensor, payload, pin=(), cap=None):
     """Attach `payload` to the storage address of `tensor` (a later entry for the same address replaces it).  cap: keep at most this
     many entries of `kind` (large payloads -- whole feature maps -- of which only the last frames can still be asked for)."""

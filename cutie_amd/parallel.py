@@ -5,15 +5,18 @@ distributed round-robin, one process per GPU (``torch.distributed``; backend "nc
 "gloo" in the CPU tests).  There is no collective on the per-frame path: the only communication is the final
 gather of per-clip results to rank 0 -- a direct (non-ring) gather, since the payload is small and latency-bound.
 
-Inside one GPU, several clips can be *in flight* at once (``run_concurrent``): one host thread + ONE HIP stream +
-``CUTIE.fork()`` per clip.  A single clip is a chain of dependent small launches per frame and leaves compute units idle
-(kernel-boundary bubbles, layers with < 256 workgroups); independent chains interleave on the hardware queues.  A clip in flight keeps
-the batching of its look-ahead lanes (one encoder plan per 12 frames, one read-out per bank version) but runs them on its own stream
-(``Engine.one_lane``): next to other clips its extra streams only compete for the hardware queues.  Measured on the MI355X (round 5,
-`profiles/r05_clips_in_flight.txt`, `profiles/r05_host_trims_ab.txt`; the bench line's `multi_clip`): two clips in flight 1536-1565
-frames/s against 1115-1180 for one clip; three or four clips reach 1700-1865 when the process is started with GPU_MAX_HW_QUEUES >= 8 --
-or 900-1050 in the next run of the same command (not understood; with the default four hardware queues four clips give ~1240), hence the
-default of two.
+Inside one GPU, several clips can be *in flight* at once: ONE HIP stream + ``CUTIE.fork()`` per clip.  A single clip is a chain of
+dependent small launches per frame and leaves compute units idle (kernel-boundary bubbles, layers with < 256 workgroups); independent
+chains interleave on the hardware queues.  A clip in flight keeps the batching of its look-ahead lanes (one encoder plan per 12 frames,
+one read-out per bank version) but runs them on its own stream (``Engine.one_lane``): next to other clips its extra streams only
+compete for the hardware queues.  Two drivers:
+* ``run_interleaved`` -- ONE host thread issues a step of every clip in turn (generator clips).  ``step`` never waits for the device,
+  so one thread keeps four streams fed: **1811 / 1826 / 1820 frames/s with four clips in flight against 1163 for one clip** (MI355X,
+  480p / 3 objects, round 5, `profiles/r05_clips_in_flight.txt`; 2 clips 1525, 3: 1718, 8: 1769) -- bound by the host's issue time
+  per frame (~0.55 ms);
+* ``run_concurrent`` -- one host thread per clip (clips that also read / write files).  Two threads: 1525-1565; three or four threads
+  hand the interpreter lock around at every launch call and vary between 770 and 1865 from run to run of one command, hence its
+  default of two.
 """
 import queue
 import threading
@@ -120,6 +123,67 @@ def run_concurrent(net, clip_ids: Sequence[int], run_clip: Callable, *, streams:
             eng.one_lane = was
     if errors:
         raise errors[0]
+    return results
+
+
+def run_interleaved(net, clip_ids: Sequence[int], run_clip: Callable, *, streams: int = 4) -> Dict[int, Dict]:
+    """Like ``run_concurrent`` with ONE host thread: ``run_clip(net_view, clip_id)`` is a GENERATOR function that yields after every
+    ``step`` and returns the clip's result; up to ``streams`` clips are in flight, each on its own HIP stream and ``net.fork()``, and the
+    calling thread issues one step of each in turn.  ``step`` never waits for the device, so one thread keeps several streams fed; there
+    is no interpreter lock to hand around (three or four Python threads do that at every launch call, and their throughput varies by
+    2 x from run to run: profiles/r05_clips_in_flight.txt).  Bound by the host's issue time per frame.  Results are bit-identical to
+    running the clips one after another.  A generator that ends should have fetched what it returns (``.cpu()``): its slot is
+    re-used by the next clip at once."""
+    import contextlib
+    from . import frame_context
+    clip_ids = list(clip_ids)
+    results: Dict[int, Dict] = {}
+    if not clip_ids:
+        return results
+    on_gpu = net.device.type == 'cuda'
+    n = max(1, min(streams, len(clip_ids)))
+    views = [net] + [net.fork() for _ in range(n - 1)]
+    lanes = [(v.engine(), v.engine().one_lane) for v in views] if n > 1 else []
+    for eng, _ in lanes:
+        eng.one_lane = True
+    pending = list(reversed(clip_ids))
+    slots = [dict(view=v, stream=torch.cuda.Stream(device=net.device) if on_gpu else None, ctx=frame_context.new_context(), gen=None, clip=None)
+             for v in views]
+
+    def enter(slot):
+        return torch.cuda.stream(slot['stream']) if slot['stream'] is not None else contextlib.nullcontext()
+
+    def advance(slot):
+        """One step of the slot's clip (starting the next clip of the queue when the slot is free); False when there is nothing left."""
+        if slot['gen'] is None:
+            if not pending:
+                return False
+            slot['clip'] = pending.pop()
+            slot['gen'] = run_clip(slot['view'], slot['clip'])
+        with frame_context.context(slot['ctx']), enter(slot):
+            try:
+                next(slot['gen'])
+            except StopIteration as e:
+                results[slot['clip']] = e.value
+                slot['gen'] = None
+        return True
+
+    try:
+        with torch.inference_mode():
+            if on_gpu and not net.engine().tile_cache:
+                # the conv tiles are not tuned yet: the first clip runs alone, so the autotuner times kernels on a quiet device
+                while advance(slots[0]) and slots[0]['gen'] is not None:
+                    pass
+            busy = True
+            while busy:
+                busy = False
+                for slot in slots:
+                    busy = advance(slot) or busy
+        if on_gpu:
+            torch.cuda.synchronize(net.device)
+    finally:
+        for eng, was in lanes:
+            eng.one_lane = was
     return results
 
 

@@ -806,6 +806,41 @@ def test_concurrent_clips_match_sequential(gpu_net):
         assert torch.equal(conc[c], seq[c]), (c, float((conc[c] - seq[c]).abs().max()))
 
 
+def test_interleaved_clips_match_sequential(gpu_net):
+    """parallel.run_interleaved: one host thread, a step of every clip in flight in turn (each clip on its own stream / fork /
+    frame_context table, look-ahead lanes in line): bit-identical to the clips one after another."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.parallel import run_interleaved
+    from cutie_amd.utils.synth import SyntheticClip
+
+    def gen(net, c, hinted=True):
+        clip = SyntheticClip(240, 432, 3, 14, seed=40 + c)
+        frames = [clip.frame(t).cuda() for t in range(14)]
+        proc = InferenceCore(net, cfg=default_config(mem_every=3))
+        hint = (lambda t: dict(next_images=frames[t + 1:t + 9])) if hinted else (lambda t: {})
+        outs = [proc.step(frames[0], clip.first_mask().cuda(), objects=clip.objects, **hint(0))]
+        yield
+        for t in range(1, 14):
+            outs.append(proc.step(frames[t], **hint(t)))
+            yield
+        return torch.stack(outs).cpu()
+
+    def whole(g):
+        try:
+            while True:
+                next(g)
+        except StopIteration as e:
+            return e.value
+
+    with torch.inference_mode():
+        seq = {c: whole(gen(gpu_net, c, False)) for c in range(5)}
+    got = run_interleaved(gpu_net, list(range(5)), gen, streams=4)
+    assert not gpu_net.engine().one_lane
+    for c in range(5):
+        assert torch.isfinite(got[c]).all()
+        assert torch.equal(got[c], seq[c]), (c, float((got[c] - seq[c]).abs().max()))
+
+
 def test_eval_driver_on_bike_example(gpu_net, tmp_path):
     """Section 8(f) rank 1: the bike frames through VideoReader -> InferenceCore -> fused argmax/remap -> PNG writer; the first
     PNG reproduces the annotation, every PNG equals output_prob_to_mask of a second pass."""

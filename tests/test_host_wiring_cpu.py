@@ -157,6 +157,56 @@ def test_fork_and_concurrent_clips_match_sequential(product_net):
         assert torch.equal(conc[c], seq[c]), c
 
 
+def test_interleaved_clips_match_sequential(product_net):
+    """parallel.run_interleaved: ONE host thread issues a step of every clip in flight in turn (generator clips, own fork / stream /
+    frame_context table each): the sequential results, with and without look-ahead hints; frame_context.context swaps the thread's
+    table and puts it back."""
+    from cutie_amd import frame_context as fc
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.parallel import run_interleaved
+    from cutie_amd.utils.synth import SyntheticClip
+
+    def gen(view, c, hinted):
+        clip = SyntheticClip(48, 80, 2, 9, seed=20 + c)
+        frames = [clip.frame(t) for t in range(9)]
+        proc = InferenceCore(view, cfg=default_config(mem_every=3))
+        outs = []
+        for t in range(9):
+            kw = dict(next_images=frames[t + 1:t + 7]) if hinted and t + 1 < 9 else {}
+            outs.append(proc.step(frames[t], *((clip.first_mask(),) if t == 0 else ()), **(dict(objects=clip.objects) if t == 0 else {}), **kw))
+            yield
+        return torch.stack(outs)
+
+    def whole(g):
+        try:
+            while True:
+                next(g)
+        except StopIteration as e:
+            return e.value
+
+    ex = _lib.get_executor()
+    ex.per_sample_conv = True          # (torch's CPU conv may sum differently per batch size; the HIP tiles of one K-order class do not)
+    try:
+        with torch.inference_mode():
+            seq = {c: whole(gen(product_net, c, False)) for c in range(4)}
+        for hinted in (False, True):
+            got = run_interleaved(product_net, list(range(4)), lambda v, c: gen(v, c, hinted), streams=3)
+            assert sorted(got) == [0, 1, 2, 3] and not product_net.engine().one_lane
+            for c in range(4):
+                assert torch.equal(got[c], seq[c]), (hinted, c)
+    finally:
+        ex.per_sample_conv = False
+    a = torch.zeros(3)
+    fc.remember('k', a, 1)
+    ctx = fc.new_context()
+    with fc.context(ctx):
+        assert fc.recall('k', a) is None
+        fc.remember('k', a, 2)
+    assert fc.recall('k', a) == 1
+    with fc.context(ctx):
+        assert fc.recall('k', a) == 2
+
+
 def test_max_internal_size_path(product_net):
     """The internal-resolution path (inference_core.py:206-228, 321-326): frames larger than max_internal_size are processed
     at the reduced size and the probabilities are resized back; index masks use nearest-exact."""
