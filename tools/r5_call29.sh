@@ -1,4 +1,5 @@
 # Round 5, call 29: host-side trims, old tree (_ab_old = HEAD's package) against the working tree in ONE box, interleaved:
+# (_ab_old/ = `git archive HEAD cutie_amd bench.py` + the built library, created for this call and removed after it)
 # frames/s with / without hints, the reference's FPS protocol, four clips in flight
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r5c29

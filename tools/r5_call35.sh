@@ -1,4 +1,5 @@
 # Round 5, call 35: clips in flight on streams with dedicated hardware queues (hipExtStreamCreateWithCUMask, all CUs)
+# (the CUTIE_BENCH_DEDICATED switch lived in bench.py for this call only: hipExtStreamCreateWithCUMask through ctypes, torch.cuda.ExternalStream)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r5c35
 mkdir -p $O

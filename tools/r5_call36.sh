@@ -1,4 +1,5 @@
 # Round 5, call 36: clips in flight with staggered schedules (clip i is i * 3 frames further into its encoder batches / memory cycles)
+# (the CUTIE_BENCH_STAGGER switch lived in bench.py for this call only)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r5c36
 mkdir -p $O
