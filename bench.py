@@ -68,8 +68,8 @@ def parse():
                          '(one HIP stream + CUTIE.fork() each, see --multi-mode; reported as "multi_clip"; 0 = skip)')
     ap.add_argument('--multi-hw-queues', type=int, default=0,
                     help='> 0 (one GPU): the clips-in-flight leg runs in a child process started with GPU_MAX_HW_QUEUES set to this (HIP maps '
-                         'its streams onto 4 hardware queues by default).  Experimental: 3-4 clips then reach 1700-1865 frames/s in some '
-                         'runs and 900-1050 in others (profiles/r05_clips_in_flight.txt); 0 = in this process, default environment')
+                         'its streams onto 4 hardware queues by default).  An experiment of round 5 with --multi-mode threads '
+                         '(profiles/r05_clips_in_flight.txt: no stable gain); 0 = in this process, default environment')
     ap.add_argument('--multi-mode', choices=('threads', 'interleaved'), default='interleaved',
                     help='clips in flight driven by one host thread per clip, or by ONE thread that issues a step of every clip in turn')
     ap.add_argument('--multi-only', action='store_true', help='(internal) run the clips-in-flight leg only and print its seconds')
