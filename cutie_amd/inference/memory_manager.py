@@ -199,17 +199,35 @@ class MemoryManager:
         tick_work = self.use_long_term and bucket.n_work > 0
         tick_long = self.use_long_term and bucket.n_long > 0 and self.count_long_term_usage
         nslots = int(bucket.use.shape[0]) if self.use_long_term else 0
-        key = (tuple(ranges), K, HW, HWp, G, self.top_k, self.use_long_term, tick_work, tick_long, bucket.work_start,
-               bucket.n_work, bucket.n_long, nslots)
+        clear_long = self.use_long_term and bucket.n_long > 0 and not self.count_long_term_usage
+        # `key`: what decides WHICH launches the plan holds; `vals`: the sizes inside them, which change with every memorised frame --
+        # those are patched into the descriptors (host time: a rebuild is ~0.1 ms of Python on every memory frame)
+        flat = [v for r in ranges for v in r] + [0] * (6 - 2 * len(ranges))
+        key = (len(ranges), K, HW, HWp, self.top_k, self.use_long_term, tick_work, tick_long, clear_long, bucket.work_start, nslots)
+        vals = (tuple(flat), G, bucket.n_work, bucket.n_long)
         plans_ = bucket.__dict__.setdefault('_aff_plans', {})
         cached = plans_.get(ahead)
-        if cached is None or cached[0] != key:
+        if cached is not None and cached[0] == key and (cached[1] == vals or not _UNFUSED):
+            if cached[1] != vals:
+                ol, ops_ = cached[2], cached[3]
+                for op in (ops_['score0'], ops_['score1']):
+                    ol.patch_ints(op, 3, flat + [G])               # AFF_SCORE i3..8 = the token ranges, i9 = their 16-token tiles
+                ol.patch_ints(ops_['select'], 2, [G])
+                if not ahead:
+                    ticks_n = ([bucket.n_work] if tick_work else []) + ([bucket.n_long] if tick_long else [])
+                    if ticks_n:
+                        ol.patch_ints(ops_['select'], 4, ticks_n)  # AFF_SELECT i4, i5 = the counted ranges (in the order they were given)
+                if ops_['clear'] is not None:
+                    ol.patch_ints(ops_['clear'], 0, [bucket.n_long])
+                plans_[ahead] = cached = (key, vals, ol, ops_)
+        else:
             D = O.Dyn
             ol = O.OpList()
+            ops_ = dict(clear=None)
             # (prio: a one-frame read-out is waited for by the caller's stream -- its waves take issue priority over the window encoder
             # and the stacked read-outs that share the compute units)
             common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=CAND_CAP, prio=True)
-            ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('gmax'), None, None, None, mode=0, **common)
+            ops_['score0'] = ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('gmax'), None, None, None, mode=0, **common)
             # usage bookkeeping (kv_memory_store.py:151-162): life += 1 for every counted token -- rides on the selection launch,
             # as does the clearing of pass 1's candidate counters
             ticks = []
@@ -218,23 +236,23 @@ class MemoryManager:
             if tick_long and not ahead:
                 ticks.append((D('life'), bucket.n_long))
             if ahead and self.use_long_term:
-                ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), zero=(D('usage'), nslots), prio=True)
+                ops_['select'] = ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), zero=(D('usage'), nslots), prio=True)
             elif _UNFUSED:
                 ol.memset32(D('count'), HW * O.OpList.AFF_CSTRIDE, 0)
-                ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k)
+                ops_['select'] = ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k)
                 for life, n in ticks:
                     ol.usage_tick(life, n)
             else:
-                ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), ticks=ticks, prio=True)
-            ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('tau'), D('cval'), D('cidx'), D('count'),
-                         mode=1, gmax_precedes_tau=True, **common)
+                ops_['select'] = ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), ticks=ticks, prio=True)
+            ops_['score1'] = ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('tau'), D('cval'), D('cidx'), D('count'),
+                                          mode=1, gmax_precedes_tau=True, **common)
             ol.aff_readout(D('cval'), D('cidx'), D('count'), D('vptrs'), D('usage') if self.use_long_term else None, D('readout'),
                            D('ovf'), HW=HW, cap=CAND_CAP, top_k=self.top_k, K=K, CV=self.CV, prio=True)
-            if self.use_long_term and bucket.n_long > 0 and not self.count_long_term_usage:
+            if clear_long:
                 # long_term.count_usage=False: the reference keeps no usage for long-term tokens (memory_manager.py:145-147);
                 # the read-out kernel accumulates usage for every slot, so the long-term part is cleared again
-                ol.memset32(D('usage'), bucket.n_long, 0)
-            plans_[ahead] = cached = (key, ol)
+                ops_['clear'] = ol.memset32(D('usage'), bucket.n_long, 0)
+            plans_[ahead] = cached = (key, vals, ol, ops_)
         dyn = dict(count=count, Ahi=bucket.Ahi, Alo=bucket.Alo, scale=bucket.scale, Bhi=q['Bhi'], Blo=q['Blo'], cq=q['cq'],
                    gmax=gmax, tau=tau, cval=cval, cidx=cidx, vptrs=bucket.vptrs(), readout=readout, ovf=ovf)
         if self.use_long_term:
@@ -247,7 +265,7 @@ class MemoryManager:
                 self._last_udelta = udelta
             else:
                 dyn.update(life=bucket.life, usage=bucket.use)
-        cached[1].run(**dyn)
+        cached[2].run(**dyn)
         return readout
 
     def _affinity_batch(self, bucket: Bucket, q, h: int, w: int, dev, frames: int):
@@ -275,12 +293,25 @@ class MemoryManager:
         readout = (pool.get_ring(('readout#batch', bucket.id, F, K, h, w, str(dev)), spec, dev, ring=3)['r'] if pool is not None
                    else torch.empty(spec['r'][0], dtype=BF16, device=dev))
         nslots = int(bucket.use.shape[0]) if self.use_long_term else 0
-        key = (tuple(ranges), K, HW, HWp, G, self.top_k, self.use_long_term, self.count_long_term_usage, bucket.n_long, nslots, F)
+        clear_long = self.use_long_term and bucket.n_long > 0 and not self.count_long_term_usage
+        flat = [v for r in ranges for v in r] + [0] * (6 - 2 * len(ranges))
+        key = (len(ranges), K, HW, HWp, self.top_k, self.use_long_term, clear_long, nslots, F, BATCH_FORMS)     # (see _affinity: launches / sizes)
+        vals = (tuple(flat), G, bucket.n_long)
         plans_ = bucket.__dict__.setdefault('_aff_plans', {})
         cached = plans_.get(('batch', F))
-        if cached is None or cached[0] != key:
+        if cached is not None and cached[0] == key:
+            if cached[1] != vals:
+                ol, ops_ = cached[2], cached[3]
+                for op in (ops_['score0'], ops_['score1']):
+                    ol.patch_ints(op, 3, flat + [G])
+                ol.patch_ints(ops_['select'], 2, [G])
+                for op in ops_['clear']:
+                    ol.patch_ints(op, 0, [bucket.n_long])
+                plans_[('batch', F)] = cached = (key, vals, ol, ops_)
+        else:
             D = O.Dyn
             ol = O.OpList()
+            ops_ = dict(clear=[])
             common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=CAND_CAP, frames=F)
             # kernel forms by the number of stacked frames (same bits whatever the form, tests/test_gpu_kernels.py; isolated stage
             # times at 12.2 k tokens, tools/aff_batch_ab.py, profiles/r05_affinity.md): from three frames on the score pass runs 64 queries
@@ -288,17 +319,17 @@ class MemoryManager:
             # against 0.39) and the candidate pass stages its memory tiles by LDS-DMA (94 against 103 us)
             big = F >= 3 and BATCH_FORMS
             nq0, dma1 = (4, True) if big else (None, None)
-            ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('gmax'), None, None, None, mode=0, nq=nq0, **common)
-            ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), frames=F,
-                          zero=(D('usage'), F * nslots) if self.use_long_term else None)
-            ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('tau'), D('cval'), D('cidx'), D('count'),
-                         mode=1, gmax_precedes_tau=True, nq=2 if big else None, dma=dma1, **common)
+            ops_['score0'] = ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('gmax'), None, None, None, mode=0, nq=nq0, **common)
+            ops_['select'] = ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), frames=F,
+                                           zero=(D('usage'), F * nslots) if self.use_long_term else None)
+            ops_['score1'] = ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('tau'), D('cval'), D('cidx'), D('count'),
+                                          mode=1, gmax_precedes_tau=True, nq=2 if big else None, dma=dma1, **common)
             ol.aff_readout(D('cval'), D('cidx'), D('count'), D('vptrs'), D('usage') if self.use_long_term else None, D('readout'),
                            D('ovf'), HW=HW, cap=CAND_CAP, top_k=self.top_k, K=K, CV=self.CV, frames=F, HWp=HWp, usage_stride=nslots)
-            if self.use_long_term and bucket.n_long > 0 and not self.count_long_term_usage:
+            if clear_long:
                 for f in range(F):                                      # (memory_manager.py:145-147, as in the one-frame plan)
-                    ol.memset32(D('usage', 4 * f * nslots), bucket.n_long, 0)
-            plans_[('batch', F)] = cached = (key, ol)
+                    ops_['clear'].append(ol.memset32(D('usage', 4 * f * nslots), bucket.n_long, 0))
+            plans_[('batch', F)] = cached = (key, vals, ol, ops_)
         dyn = dict(count=count, Ahi=bucket.Ahi, Alo=bucket.Alo, scale=bucket.scale, Bhi=q['Bhi'], Blo=q['Blo'], cq=q['cq'],
                    gmax=gmax, tau=tau, cval=cval, cidx=cidx, vptrs=bucket.vptrs(), readout=readout, ovf=ovf)
         udelta = None
@@ -307,7 +338,7 @@ class MemoryManager:
             # stream has applied the last frame of this one
             udelta = self._buf_rows(f'udelta#batch{self._ahead_parity}#{bucket.id}', F, (nslots,), F32, dev)
             dyn.update(usage=udelta)
-        cached[1].run(**dyn)
+        cached[2].run(**dyn)
         return [(readout[f], udelta[f] if udelta is not None else None) for f in range(F)]
 
     def _commit_ahead(self, bucket: Bucket, udelta: torch.Tensor, network=None) -> None:
@@ -321,15 +352,18 @@ class MemoryManager:
             return
         tick_work = bucket.n_work > 0
         tick_long = bucket.n_long > 0 and self.count_long_term_usage
-        # (host time: the launch is the same until the bank changes -- every mem_every-th frame -- so its descriptor is kept)
-        sig = (bucket.life.data_ptr(), bucket.use.data_ptr(), bucket.work_start, bucket.n_work if tick_work else 0,
-               bucket.n_long if tick_long else 0, int(udelta.shape[0]))
+        # (host time: the launch stays the same while the bank's arrays do; the two counted lengths are patched into its descriptor)
+        sig = (bucket.life.data_ptr(), bucket.use.data_ptr(), bucket.work_start, tick_work, tick_long, int(udelta.shape[0]))
+        counts = (bucket.n_work if tick_work else 0, bucket.n_long if tick_long else 0)
         cached = self._commit_plans.get(bucket.id)
         if cached is None or cached[0] != sig:
             ol = O.OpList()
-            ol.usage_tick(bucket.life[bucket.work_start:] if tick_work else None, sig[3], bucket.life if tick_long else None, sig[4],
+            ol.usage_tick(bucket.life[bucket.work_start:] if tick_work else None, counts[0], bucket.life if tick_long else None, counts[1],
                           use=bucket.use, delta=O.Dyn('delta'), n_use=sig[5])
-            cached = self._commit_plans[bucket.id] = (sig, ol)
+            cached = self._commit_plans[bucket.id] = (sig, ol, counts)
+        elif cached[2] != counts:
+            cached[1].patch_ints(0, 0, counts)                   # USAGE_TICK i0, i1
+            cached = self._commit_plans[bucket.id] = (sig, cached[1], counts)
         ol = cached[1]
         side = None
         if COMMIT_ON_SIDE and network is not None and udelta.is_cuda:

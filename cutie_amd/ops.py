@@ -321,6 +321,18 @@ class OpList:
                     arr['p'][n, 10], arr['i'][n, 23] = nxt2[0], n2
             nxt, nxt2 = (int(arr['p'][n, 2]), self.wbytes[n], pc), nxt
 
+    def patch_ints(self, op, start, values):
+        """Overwrite ints [start, start + len(values)) of record `op` -- in the recorded list and, when the array exists, in place (a
+        plan whose launches stay the same while a few sizes change: the affinity plans of a bucket between two memory frames)."""
+        values = [int(v) for v in values]
+        ints = self.recs[op][2]
+        end = start + len(values)
+        if len(ints) < end:
+            ints.extend([0] * (end - len(ints)))
+        ints[start:end] = values
+        if self.arr is not None:
+            self.arr['i'][op, start:end] = values
+
     def bind(self, **tensors):
         """Patch dynamic pointer slots.  Values: torch tensors or raw ints.  (Host time: this runs five times per frame with a dozen
         names each -- the slots of a name are 64-bit word indices into the descriptor array, written through one memoryview.)"""
