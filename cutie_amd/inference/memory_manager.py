@@ -28,6 +28,7 @@ _UNFUSED = os.environ.get('CUTIE_AMD_UNFUSED', '0') not in ('', '0')      # diag
 _VALIDATE = os.environ.get('CUTIE_AMD_VALIDATE', '0') not in ('', '0')
 BANK_WRITE = os.environ.get('CUTIE_AMD_BANK_WRITE', '1') not in ('', '0')      # the copies / fills of an insertion in one launch (A/B switch)
 BATCH_FORMS = os.environ.get('CUTIE_AMD_AFF_BATCH_FORMS', '1') not in ('', '0')   # stacked read-outs pick their score kernels by frame count (A/B switch)
+PATCH_PLANS = os.environ.get('CUTIE_AMD_PATCH_PLANS', '1') not in ('', '0')    # sizes that a memory frame changes are patched into the cached affinity / commit plans (off: rebuilt; A/B + test switch)
 COMMIT_ON_SIDE = os.environ.get('CUTIE_AMD_COMMIT_SIDE', '1') not in ('', '0')  # bookkeeping of a consumed look-ahead read-out on the look-ahead stream (A/B switch)
 # bank versions are drawn from one process-wide counter: a look-ahead read-out tagged with the version of one manager can never pass
 # the check of another (InferenceCore.clear_memory replaces the manager; per-manager counters would restart at 0 and collide)
@@ -207,7 +208,7 @@ class MemoryManager:
         vals = (tuple(flat), G, bucket.n_work, bucket.n_long)
         plans_ = bucket.__dict__.setdefault('_aff_plans', {})
         cached = plans_.get(ahead)
-        if cached is not None and cached[0] == key and (cached[1] == vals or not _UNFUSED):
+        if cached is not None and cached[0] == key and (cached[1] == vals or (PATCH_PLANS and not _UNFUSED)):
             if cached[1] != vals:
                 ol, ops_ = cached[2], cached[3]
                 for op in (ops_['score0'], ops_['score1']):
@@ -299,7 +300,7 @@ class MemoryManager:
         vals = (tuple(flat), G, bucket.n_long)
         plans_ = bucket.__dict__.setdefault('_aff_plans', {})
         cached = plans_.get(('batch', F))
-        if cached is not None and cached[0] == key:
+        if cached is not None and cached[0] == key and (cached[1] == vals or PATCH_PLANS):
             if cached[1] != vals:
                 ol, ops_ = cached[2], cached[3]
                 for op in (ops_['score0'], ops_['score1']):
@@ -362,8 +363,12 @@ class MemoryManager:
                           use=bucket.use, delta=O.Dyn('delta'), n_use=sig[5])
             cached = self._commit_plans[bucket.id] = (sig, ol, counts)
         elif cached[2] != counts:
-            cached[1].patch_ints(0, 0, counts)                   # USAGE_TICK i0, i1
-            cached = self._commit_plans[bucket.id] = (sig, cached[1], counts)
+            if PATCH_PLANS:
+                cached[1].patch_ints(0, 0, counts)               # USAGE_TICK i0, i1
+                cached = self._commit_plans[bucket.id] = (sig, cached[1], counts)
+            else:
+                self._commit_plans.pop(bucket.id)
+                return self._commit_ahead(bucket, udelta, network)
         ol = cached[1]
         side = None
         if COMMIT_ON_SIDE and network is not None and udelta.is_cuda:

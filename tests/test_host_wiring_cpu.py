@@ -661,6 +661,78 @@ def test_lookahead_window_bookkeeping_matches_plain_order():
         _lib.set_executor_for_testing(prev)
 
 
+def test_patched_affinity_plans_equal_rebuilt_ones():
+    """MemoryManager keeps the affinity / commit plans of a bucket across memory frames and patches the sizes that changed (token
+    ranges, tile count, counted lengths) into their descriptors.  Every descriptor array handed to the executor -- kinds, flags, ints,
+    floats; pointers left out, they depend on the allocator -- must equal what a run that REBUILDS the plans hands over, frame by frame:
+    long-term memory (growing ranges, a consolidation, counted long-term usage on and off), FIFO memory, with and without hints."""
+    from cutie_amd.inference import memory_manager as MM
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.model.cutie import CUTIE
+    from cutie_amd.utils.synth import SyntheticClip
+
+    class Recording(MockExecutor):
+        def __init__(self):
+            self.seen = []
+
+        def run(self, arr):
+            self.seen.append([(int(r['kind']), int(r['flags']), r['i'].tolist(), r['f'].tolist()) for r in arr])
+            super().run(arr)
+
+    prev = _lib._executor
+    n = 16
+    clip = SyntheticClip(48, 80, 2, n, seed=5)
+    frames = [clip.frame(t) for t in range(n)]
+
+    def run(patch, hinted, **cfg):
+        rec = Recording()
+        rec.per_sample_conv = True
+        _lib.set_executor_for_testing(rec)
+        MM.PATCH_PLANS = patch
+        net = CUTIE(default_config())
+        net.load_weights(make_state_dict(seed=0))
+        proc = InferenceCore(net, cfg=default_config(mem_every=2, **cfg))
+        outs = []
+        with torch.inference_mode():
+            for t in range(n):
+                kw = dict(next_images=frames[t + 1:t + 9]) if hinted and t + 1 < n else {}
+                outs.append(proc.step(frames[t], *((clip.first_mask(),) if t == 0 else ()), **(dict(objects=clip.objects) if t == 0 else {}), **kw))
+        return torch.stack(outs), rec.seen
+
+    lt = dict(use_long_term=True, long_term=dict(max_mem_frames=4, min_mem_frames=2, num_prototypes=16, max_num_tokens=64, buffer_tokens=32, count_usage=True))
+    lt_nocount = dict(lt, long_term=dict(lt['long_term'], count_usage=False))
+    from cutie_amd import ops as O
+    patched = []
+    orig_patch = O.OpList.patch_ints
+
+    def counting(self, op, start, values):
+        patched.append((int(self.recs[op][0]), start, len(values)))
+        return orig_patch(self, op, start, values)
+    O.OpList.patch_ints = counting
+    try:
+        for cfg in (lt, lt_nocount, dict(max_mem_frames=3)):
+            for hinted in (False, True):
+                del patched[:]
+                out_a, seen_a = run(True, hinted, **cfg)
+                kinds = {k for k, _, _ in patched}
+                assert O.AFF_SCORE in kinds and O.AFF_SELECT in kinds, (cfg, hinted, kinds)       # the plans really were patched
+                if hinted and cfg.get('use_long_term'):
+                    assert O.USAGE_TICK in kinds, (cfg, kinds)
+                if cfg is lt_nocount:
+                    assert O.MEMSET32 in kinds, kinds
+                del patched[:]
+                out_b, seen_b = run(False, hinted, **cfg)
+                assert not patched
+                assert torch.equal(out_a, out_b), (cfg, hinted)
+                assert len(seen_a) == len(seen_b), (cfg, hinted, len(seen_a), len(seen_b))
+                for k, (a, b) in enumerate(zip(seen_a, seen_b)):
+                    assert a == b, (cfg, hinted, k, [x for x, y in zip(a, b) if x != y][:1], [y for x, y in zip(a, b) if x != y][:1])
+    finally:
+        O.OpList.patch_ints = orig_patch
+        MM.PATCH_PLANS = True
+        _lib.set_executor_for_testing(prev)
+
+
 def test_announced_frame_overwritten_in_place_is_encoded_again_cpu():
     """CPU twin (descriptor interpreter) of tests/test_gpu_parity.py::test_announced_frame_overwritten_in_place_is_encoded_again: frames
     are matched by storage AND tensor version, an announced frame that is overwritten in place goes through its own encoder."""
