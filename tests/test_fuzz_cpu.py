@@ -72,3 +72,54 @@ def test_product_matches_oracle_on_random_scripts(seed, product_net, oracle_net)
         d = (p - o).abs()
         bmax, bmean, _ = S.trajectory_bounds('base')
         assert float(d.max()) < bmax and float(d.mean()) < bmean, (seed, t, float(d.max()), float(d.mean()))
+
+
+@pytest.mark.parametrize('seed', [201, 216])          # FIFO memory with deletions / re-specified masks; long-term memory + flip_aug
+def test_hints_change_nothing_on_random_scripts(seed):
+    """The same random event scripts with `next_images` hints on every step (the frames that follow in the script -- wrong ones where
+    the script re-propagates or pre-commits) against no hints, through the descriptor interpreter: bit-identical probabilities, with
+    the look-ahead lanes on their own streams' bookkeeping and in one lane (Engine.one_lane).  Round 5 ran seeds 200-215 this way."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.model.cutie import CUTIE
+    mx = MockExecutor()
+    mx.per_sample_conv = True          # (torch's CPU conv may sum differently per batch size; the HIP tiles of one K-order class do not)
+    prev = _lib._executor
+    _lib.set_executor_for_testing(mx)
+
+    class Hinted:
+        def __init__(self, proc, imgs):
+            self.__dict__.update(p=proc, imgs=imgs)
+
+        def step(self, img, *a, **k):
+            idx = [i for i, x in enumerate(self.imgs) if x is img]
+            if idx and not k.get('end') and self.imgs[idx[0] + 1:idx[0] + 9]:
+                k['next_images'] = self.imgs[idx[0] + 1:idx[0] + 9]
+            return self.p.step(img, *a, **k)
+
+        def __getattr__(self, n):
+            return getattr(self.p, n)
+
+        def __setattr__(self, n, v):
+            setattr(self.p, n, v)
+
+    S.SCENARIOS['_fuzz'] = random_scenario(seed, 16)
+    orig = S.scenario_inputs
+    try:
+        cache = orig('_fuzz')
+        S.scenario_inputs = lambda name: cache        # (the same frame tensors for every run: hints are matched by storage)
+        imgs = [st[0] for st in cache[0]]
+        net = CUTIE(default_config())
+        net.load_weights(make_state_dict(seed=0))
+        mk = lambda over: default_config(**over)
+        plain, _ = S.run_scenario(lambda over: InferenceCore(net, cfg=mk(over)), '_fuzz', make_cfg=mk)
+        for lane in (False, True):
+            net.engine().one_lane = lane
+            got, _ = S.run_scenario(lambda over: Hinted(InferenceCore(net, cfg=mk(over)), imgs), '_fuzz', make_cfg=mk)
+            assert len(got) == len(plain)
+            for t, (a, b) in enumerate(zip(got, plain)):
+                assert torch.equal(a, b), (seed, lane, t, float((a - b).abs().max()))
+    finally:
+        S.scenario_inputs = orig
+        del S.SCENARIOS['_fuzz']
+        _lib.set_executor_for_testing(prev)
+
