@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CUTIE_AMD_LIB') or os.path.join(_HERE, 'libcutie_hip.so')     # ($CUTIE_AMD_LIB: diagnostic builds, tools/ablate_conv.sh)
-ABI_VERSION = 3
+ABI_VERSION = 4
 OP_STRUCT_SIZE = 256
 
 _lib = None

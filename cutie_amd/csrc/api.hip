@@ -128,7 +128,7 @@ float cutie_time_ops(const cutie_op* ops, int n, int iters, void* stream) {
 }
 
 const char* cutie_hip_last_error(void) { return g_err; }
-int cutie_hip_abi_version(void) { return 3; }
+int cutie_hip_abi_version(void) { return 4; }
 int cutie_op_struct_size(void) { return (int)sizeof(cutie_op); }
 int cutie_hip_build_flags(void) {
 #ifdef CUTIE_DIAG

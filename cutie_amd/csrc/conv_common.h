@@ -16,6 +16,9 @@ struct ConvParams {
     // DMA piece is out (every XCD covers the whole range: inside a frame every launch starts with its weights cold, r03_conv_ablation.md)
     const unsigned char* pf; int pf_bytes;
     const unsigned char* pf2; int pf2_bytes;             // a second range (the conv after next, when the next one has no producer waves)
+    // broadcast residual of a launch that holds several CLIPS (CUTIE_F_RES_BCAST with f0 > 0): the objects come in groups of f0 (one clip
+    // each), every group has its own residual map; res_grp_rows = f0 * OHW output rows per group, res_grp_stride = rows between the maps
+    int res_grp_rows, res_grp_stride;
 };
 #define GAP_FIXED_SCALE 16777216.f
 
@@ -31,11 +34,18 @@ __device__ __forceinline__ int swz(int row) {
     return CPR == 4 ? ((row >> 3) & 1) * 3 : (row & (CPR - 1));
 }
 
+// Row of the residual that output row m adds: itself, or -- broadcast -- the pixel's row inside the (group's) one map.
+__device__ __forceinline__ int conv_res_row(const ConvParams& p, int m) {
+    if (!(p.flags & CUTIE_F_RES_BCAST)) return m;
+    int r = m % p.OHW;
+    if (p.res_grp_rows > 0) r += (m / p.res_grp_rows) * p.res_grp_stride;
+    return r;
+}
+
 // Epilogue tail for 8 consecutive output channels of one pixel: bias, residual, activation, 16-B stores.
 __device__ __forceinline__ void conv_finish(const ConvParams& p, float* v, int m, int ch0) {
     const int act = (p.flags >> CUTIE_ACT_SHIFT) & 7;
     const bool out_f32 = p.flags & CUTIE_F_OUT_F32;
-    const bool res_bcast = p.flags & CUTIE_F_RES_BCAST;
     const bool vec_y = out_f32 ? ((p.ldy & 3) == 0) : ((p.ldy & 7) == 0);
     const bool vec_r = (p.ldr & 7) == 0;
     const bool full = ch0 + 7 < p.Cout;
@@ -49,7 +59,7 @@ __device__ __forceinline__ void conv_finish(const ConvParams& p, float* v, int m
         }
     }
     if (p.res) {
-        const int mres = res_bcast ? (m % p.OHW) : m;
+        const int mres = conv_res_row(p, m);
         const bf16_t* rp = p.res + (long)mres * p.ldr + ch0;
         if (full && vec_r) {
             const uint4 rr = *reinterpret_cast<const uint4*>(rp);

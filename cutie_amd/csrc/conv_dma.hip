@@ -353,7 +353,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
     const bool active = ech0 < p.Cout;
     if (!active && !p.gap) return;                       // (GAP mode: every thread reaches the barrier below)
     const int act = (p.flags >> CUTIE_ACT_SHIFT) & 7;
-    const bool out_f32 = p.flags & CUTIE_F_OUT_F32, res_bcast = p.flags & CUTIE_F_RES_BCAST;
+    const bool out_f32 = p.flags & CUTIE_F_OUT_F32;
     const bool fast = ech0 + 7 < p.Cout && (out_f32 ? (p.ldy & 3) == 0 : (p.ldy & 7) == 0) && (!p.res || (p.ldr & 7) == 0);
     if (active)
     for (int px = epx0; px < BM; px += PSTEP) {
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
             continue;
         }
         if (p.res) {
-            const int mres = res_bcast ? (m % p.OHW) : m;
+            const int mres = conv_res_row(p, m);
             const uint4 rr = *reinterpret_cast<const uint4*>(p.res + (long)mres * p.ldr + ech0);
             v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
             v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);

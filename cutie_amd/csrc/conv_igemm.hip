@@ -548,6 +548,12 @@ int launch_conv(const cutie_op* op, hipStream_t s) {
     p.gap = (long long*)op->p[7]; p.zero = (unsigned long long*)op->p[8]; p.nzero = i[21];
     p.pf = (const unsigned char*)op->p[9]; p.pf_bytes = op->p[9] ? i[22] : 0;
     p.pf2 = (const unsigned char*)op->p[10]; p.pf2_bytes = op->p[10] ? i[23] : 0;
+    p.res_grp_rows = p.res_grp_stride = 0;
+    if ((p.flags & CUTIE_F_RES_BCAST) && op->f[0] > 0.f) {  // clips in lock step: objects in groups of f0, one residual map per group, f1 rows apart
+        const int kg = (int)op->f[0];
+        if (kg <= 0 || p.B % kg || op->f[1] < (float)p.OHW || op->f[1] != (float)(int)op->f[1]) { cutie_set_error("conv: residual groups of %d objects do not divide B = %d (or stride %g < OH*OW)", kg, p.B, (double)op->f[1]); return -2; }
+        p.res_grp_rows = kg * p.OHW; p.res_grp_stride = (int)op->f[1];
+    }
     if ((p.gap || p.zero) && (i[17] < 60 || i[17] >= 200 || ((p.flags & CUTIE_F_OUT_F32) && p.gap) || (p.Cout & 7) || (p.ldy & 7) || (p.res && (p.ldr & 7)))) {
         cutie_set_error("conv: GAP accumulation / zero job need an LDS-DMA tile (60..199), bf16 output, Cout %% 8 == 0 (tile %d)", i[17]);
         return -2;

@@ -106,7 +106,7 @@ __device__ __forceinline__ void pc_finish(const ConvParams& p, float (&v)[NCH], 
 #pragma unroll
             for (int r = 0; r < NCH / 2; ++r) { v[2 * r] += __uint_as_float(rpre[r] << 16); v[2 * r + 1] += __uint_as_float(rpre[r] & 0xffff0000u); }
         } else {
-            const int mres = (p.flags & CUTIE_F_RES_BCAST) ? (m % p.OHW) : m;
+            const int mres = conv_res_row(p, m);
             const bf16_t* rp = p.res + (long)mres * p.ldr + ch0;
             if (full && vec_ok) {
                 unsigned rr[NCH / 2];
@@ -164,6 +164,14 @@ __device__ __forceinline__ int pc_div(int m, int d, float rd) {
     return q;
 }
 
+// conv_res_row (conv_common.h) on the float pipe
+__device__ __forceinline__ int pc_res_row(const ConvParams& p, int m) {
+    if (!(p.flags & CUTIE_F_RES_BCAST)) return m;
+    int r = m - pc_div(m, p.OHW, __builtin_amdgcn_rcpf((float)p.OHW)) * p.OHW;
+    if (p.res_grp_rows > 0) r += pc_div(m, p.res_grp_rows, __builtin_amdgcn_rcpf((float)p.res_grp_rows)) * p.res_grp_stride;
+    return r;
+}
+
 // GAP side job: column sums of s[0 .. NCH) over the 16 lanes (= 16 pixels) of a row group by a reduce-SCATTER butterfly: after NCH - 1
 // + 1 shuffles the lane holds the 16-pixel total of ONE channel (index returned in c; lanes come in pairs -- quadruples for NCH = 4 --
 // with the same value, the first of which writes).  One atomic instruction then carries 32 (16) different channels of a wave; issued
@@ -217,10 +225,9 @@ __device__ __forceinline__ void pc_epilogue_fast(const ConvParams& p, const f32x
             for (int r = 0; r < NCH; ++r) gs[a][r] = 0.f;
     }
     if (RES && !PRE) {                                   // all residual loads first: one exposed latency, not one per slice
-        const bool bc = p.flags & CUTIE_F_RES_BCAST;
 #pragma unroll
         for (int b = 0; b < TM; ++b) {
-            const int mres = bc ? mrow[b] - pc_div(mrow[b], p.OHW, __builtin_amdgcn_rcpf((float)p.OHW)) * p.OHW : mrow[b];
+            const int mres = pc_res_row(p, mrow[b]);
 #pragma unroll
             for (int a = 0; a < TNP; ++a) {
                 const bf16_t* rp = p.res + (long)mres * p.ldr + chbase + a * (PAIR ? 32 : 16);
@@ -701,7 +708,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
 #pragma unroll
                 for (int r = 0; r < NCH / 2; ++r) rpre[b][a][r] = 0u;
                 if (have_res && mval[b] && ch0 + NCH <= p.Cout) {
-                    const int mres = (p.flags & CUTIE_F_RES_BCAST) ? mrow[b] - pc_div(mrow[b], p.OHW, __builtin_amdgcn_rcpf((float)p.OHW)) * p.OHW : mrow[b];
+                    const int mres = pc_res_row(p, mrow[b]);
                     const bf16_t* rp = p.res + (long)mres * p.ldr + ch0;
                     if constexpr (NCH == 8) { const uint4 t = *reinterpret_cast<const uint4*>(rp); rpre[b][a][0] = t.x; rpre[b][a][1] = t.y; rpre[b][a][NCH / 2 - 2] = t.z; rpre[b][a][NCH / 2 - 1] = t.w; }
                     else { const uint2 t = *reinterpret_cast<const uint2*>(rp); rpre[b][a][0] = t.x; rpre[b][a][1] = t.y; }

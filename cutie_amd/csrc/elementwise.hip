@@ -72,8 +72,9 @@ __device__ __forceinline__ void up_coord(int o, int n_in, float scale, int& i0, 
     lam = src - (float)i0;
 }
 
+// Kg > 0 (clips in lock step): the objects come in groups of Kg, group q adds the skip map at skip + q * gstride pixels (Kg = 0: one map for all)
 __global__ void upsample2x_add_kernel(const uint4* __restrict__ g, const uint4* __restrict__ skip, uint4* __restrict__ y,
-                                      int B, int h, int w, int C8) {
+                                      int B, int h, int w, int C8, int Kg, long gstride) {
     __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     int OH = 2 * h, OW = 2 * w;
@@ -87,7 +88,7 @@ __global__ void upsample2x_add_kernel(const uint4* __restrict__ g, const uint4* 
     const uint4* gb = g + (long)b * h * w * C8;
     uint4 v00 = gb[((long)y0 * w + x0) * C8 + c], v01 = gb[((long)y0 * w + x1) * C8 + c];
     uint4 v10 = gb[((long)y1 * w + x0) * C8 + c], v11 = gb[((long)y1 * w + x1) * C8 + c];
-    uint4 sk = skip[((long)oy * OW + ox) * C8 + c];
+    uint4 sk = skip[((Kg > 0 ? (b / Kg) * gstride : 0l) + (long)oy * OW + ox) * C8 + c];
     const uint32_t* a = &v00.x; const uint32_t* bq = &v01.x; const uint32_t* cq = &v10.x; const uint32_t* d = &v11.x;
     const uint32_t* s = &sk.x;
     float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
@@ -664,6 +665,11 @@ __global__ __launch_bounds__(256) void up4_softmax_fused4_kernel(const float* __
     if (idx >= (long)OH * w) return;
     const int j = idx % w, oy = idx / w;
     const long OHW = (long)OH * OW;
+    {                                                      // blockIdx.y = clip (clips in lock step: K logit planes in, K + 1 planes out per clip)
+        const long cl = blockIdx.y;
+        lg += cl * K * h * w; prob += cl * (K + 1) * OHW;
+        if (lup) lup += cl * (K + 1) * OHW;
+    }
     float out[PMAX][4];
     float lo[PMAX][4];
     up4_four<PMAX, KC>(lg, K, h, w, oy, j, out, lo);
@@ -692,6 +698,12 @@ __global__ __launch_bounds__(256) void up4_softmax_md_kernel(const float* __rest
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int cid = blockIdx.x * 4 + wave;
     if (cid >= ncell) return;                               // whole wave
+    {                                                      // blockIdx.y = clip (clips in lock step: every per-clip array advances by one clip's extent)
+        const long cl = blockIdx.y;
+        lg += cl * K * h * w; prob += cl * (K + 1) * (long)OH * OW;
+        if (lup) lup += cl * (K + 1) * (long)OH * OW;
+        m16 += cl * K * ncell; pair += cl * K * ncell * ld8;
+    }
     const int cy = cid / cw, cx = cid - cy * cw;
     const int r = lane >> 2, q4 = lane & 3;
     const int oy = cy * 16 + r, j = cx * 4 + q4;
@@ -1197,7 +1209,8 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
         case CUTIE_OP_UPSAMPLE2X_ADD: {
             int C8 = i[3] / 8;
             long n = (long)i[0] * 4 * i[1] * i[2] * C8;
-            hipLaunchKernelGGL(upsample2x_add_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const uint4*)p[0], (const uint4*)p[1], (uint4*)p[2], i[0], i[1], i[2], C8);
+            if (i[4] < 0 || (i[4] > 0 && (i[0] % i[4] || i[5] < 4 * i[1] * i[2]))) { cutie_set_error("upsample2x_add: skip groups of %d objects do not divide B = %d (or their stride is below one map)", i[4], i[0]); return -2; }
+            hipLaunchKernelGGL(upsample2x_add_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const uint4*)p[0], (const uint4*)p[1], (uint4*)p[2], i[0], i[1], i[2], C8, i[4], (long)i[5]);
             break;
         }
         case CUTIE_OP_AREA_DOWN: {
@@ -1270,10 +1283,12 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             if (op->flags & 1) {                              // p0 = raw logits [K,h,w] (K = P - 1): SEG_AGG fused
                 if (i[0] > 16) { cutie_set_error("up4_softmax: the fused form holds P <= 16 planes in registers (P=%d)", i[0]); return -2; }
                 const bool vec = !(op->flags & 2) && i[0] <= 8 && (((uintptr_t)p[1] | (uintptr_t)p[2]) & 15) == 0;      // four pixels per thread, 16-byte stores
+                const int nclip = i[4] > 1 ? i[4] : 1;           // clips in lock step: grid.y (the four-pixel forms only)
+                if (nclip > 1 && !vec) { cutie_set_error("up4_softmax: several clips per launch need the four-pixel form (P <= 8, aligned outputs)"); return -2; }
                 if (op->flags & 4) {                              // + MASK_DOWN of the probabilities (p3 = m16, p4 = pair, i3 = channel pitch of pair)
                     if (!vec || !p[3] || !p[4] || (i[1] & 3) || (i[2] & 3) || i[3] < 8 || (i[3] & 7)) { cutie_set_error("up4_softmax: the mask-down form needs P <= 8, h, w multiples of 4, m16 and pair"); return -2; }
                     const int ncell = (i[1] / 4) * (i[2] / 4);
-#define UP4_MD_(KC, SH) hipLaunchKernelGGL((up4_softmax_md_kernel<8, KC, SH>), dim3((ncell + 3) / 4), dim3(256), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, \
+#define UP4_MD_(KC, SH) hipLaunchKernelGGL((up4_softmax_md_kernel<8, KC, SH>), dim3((ncell + 3) / 4, nclip), dim3(256), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, \
                                        i[1], i[2], (float*)p[3], (uint4*)p[4], i[3] / 8)
 #define UP4_MD(KC) { if (op->flags & 16) UP4_MD_(KC, false); else UP4_MD_(KC, true); }      /* flags&16: every lane aggregates its own source pixels (A/B switch) */
                     switch ((op->flags & 8) ? 0 : i[0] - 1) {          // object count as a compile-time constant (see up4_four); flags&8: run-time K
@@ -1286,7 +1301,7 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
                 }
                 if (vec) {
                     const long n4 = (long)4 * i[1] * i[2];
-#define UP4_F4(KC) hipLaunchKernelGGL((up4_softmax_fused4_kernel<8, KC>), GRID1D(n4, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, i[1], i[2])
+#define UP4_F4(KC) hipLaunchKernelGGL((up4_softmax_fused4_kernel<8, KC>), dim3((unsigned)((n4 + BS - 1) / BS), nclip), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, i[1], i[2])
                     switch ((op->flags & 8) ? 0 : i[0] - 1) {
                         case 1: UP4_F4(1); break; case 2: UP4_F4(2); break; case 3: UP4_F4(3); break; case 4: UP4_F4(4); break;
                         case 5: UP4_F4(5); break; case 6: UP4_F4(6); break; case 7: UP4_F4(7); break; default: UP4_F4(0); break;

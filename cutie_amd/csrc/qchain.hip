@@ -179,7 +179,7 @@ __device__ __forceinline__ bool aux_fg_late(const float* __restrict__ lg, int K,
 // the K / V bytes of the block either way).  KT: the mask logits of this thread's pixels are fetched at entry for K <= KT objects (0: late).
 template <bool QPRE, bool ACC, int KT, int NW>
 __global__ __launch_bounds__(NW * 64) void q2p_chain_kernel(QIn in, QOut out, const bf16_t* __restrict__ kv, const float* __restrict__ lg,
-                                                           int HW, int HWp, int ldkv, int voff, int hstride, const float* __restrict__ qpre) {
+                                                           int HW, int HWp, int ldkv, int voff, int hstride, const float* __restrict__ qpre, int Kg) {
     __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
     constexpr int Q = 16, NT = NW * 64;
     constexpr bool EARLY = KT > 0;
@@ -192,7 +192,10 @@ __global__ __launch_bounds__(NW * 64) void q2p_chain_kernel(QIn in, QOut out, co
     __shared__ float sQ[16][33];                           // this head's 32 query columns, scaled; later the head's output
     __shared__ int sCnt;
     extern __shared__ uint8_t dynlds[];                    // [HWp foreground flags][NW waves x 32 pixels x 80 B of V]
-    const int hh = blockIdx.x, k = blockIdx.y, K = gridDim.y;
+    // Kg: objects per clip (clips in lock step: the grid holds gridDim.y / Kg clips).  The foreground mask is decided among the Kg objects of
+    // object k's clip (planes lg[clip * Kg ..]); everything else of the launch is per object.
+    const int hh = blockIdx.x, k = blockIdx.y, K = Kg, kin = k % Kg;
+    lg += (long)(k - kin) * HW;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c16 = lane & 15, g = lane >> 4;
     uint8_t* sFg = dynlds;
@@ -258,11 +261,11 @@ __global__ __launch_bounds__(NW * 64) void q2p_chain_kernel(QIn in, QOut out, co
 #pragma unroll
             for (int i = 0; i < PPT; ++i) {
                 const int p = threadIdx.x + NT * i;
-                if (p < HW) { const bool f = aux_fg_vals<EARLY ? KT : 1>(lgv[i], K, k); sFg[p] = f ? 1 : 0; cnt += f ? 1 : 0; }
+                if (p < HW) { const bool f = aux_fg_vals<EARLY ? KT : 1>(lgv[i], K, kin); sFg[p] = f ? 1 : 0; cnt += f ? 1 : 0; }
             }
         }
         for (int p = threadIdx.x + (EARLY ? 2048 : 0); p < HW; p += NT) {
-            const bool f = aux_fg_late(lg, K, HW, k, p);
+            const bool f = aux_fg_late(lg, K, HW, kin, p);
             sFg[p] = f ? 1 : 0;
             cnt += f ? 1 : 0;
         }
@@ -862,10 +865,12 @@ int launch_qchain(const cutie_op* op, hipStream_t s) {
                 return -2;
             }
             // one instantiation per (q handed in, accumulator input, logits fetched at entry for <= 4 / <= 8 objects / late)
-            const int kt = i[0] <= 4 ? 1 : i[0] <= 8 ? 2 : 0;
+            const int Kg = i[9] > 0 ? i[9] : i[0];            // i9: objects per clip (0: one clip holds all i0 objects)
+            if (i[0] % Kg) { cutie_set_error("attn_q2p (chain form): clips of %d objects do not divide K = %d", Kg, i[0]); return -2; }
+            const int kt = Kg <= 4 ? 1 : Kg <= 8 ? 2 : 0;
             const int var = (qp ? 6 : ac ? 3 : 0) + kt;
             constexpr int NWV = 8;
-            typedef void (*Kern)(QIn, QOut, const bf16_t*, const float*, int, int, int, int, int, const float*);
+            typedef void (*Kern)(QIn, QOut, const bf16_t*, const float*, int, int, int, int, int, const float*, int);
             static const Kern kerns[9] = {
                 q2p_chain_kernel<false, false, 0, NWV>, q2p_chain_kernel<false, false, 4, NWV>, q2p_chain_kernel<false, false, 8, NWV>,
                 q2p_chain_kernel<false, true, 0, NWV>, q2p_chain_kernel<false, true, 4, NWV>, q2p_chain_kernel<false, true, 8, NWV>,
@@ -882,7 +887,7 @@ int launch_qchain(const cutie_op* op, hipStream_t s) {
                 attr_set[var] = true;
             }
             const int hstride = i[8] > 0 ? i[8] : 32;       // elements between the heads of k / v inside a pixel row (32: [k | v | ..] by kind; 64: k | v interleaved per head)
-            hipLaunchKernelGGL(kern, dim3(8, i[0]), dim3(NWV * 64), dyn, s, in, out, (const bf16_t*)p[1], (const float*)p[2], i[2], HWp, i[5], i[6], hstride, qpre);
+            hipLaunchKernelGGL(kern, dim3(8, i[0]), dim3(NWV * 64), dyn, s, in, out, (const bf16_t*)p[1], (const float*)p[2], i[2], HWp, i[5], i[6], hstride, qpre, Kg);
             break;
         }
         case CUTIE_OP_ATTN_SELF:

@@ -275,7 +275,7 @@ class InferenceCore:
         self._prefetched = (keys[0], prepared, (ms_features, pix_feat, key, shrinkage, selection), ev, src, geometry)
         self._prefetched_rec = o
 
-    def _ahead_affinity(self, key, selection, ev, o, next_mem_ti=None, first_alone=False):
+    def _ahead_affinity(self, key, selection, ev, o, next_mem_ti=None, first_alone=False, part=None):
         """The NEXT frame's affinity read-out on the side stream, against the bank as the caller's stream leaves it at this point
         (key / selection: that frame's, ready behind `ev`).  Returns the event `step` has to wait for instead of `ev`.
         Batched (AFF_BATCH > 1, window hints): the bank only changes on memory frames, so the read-outs of ALL announced frames up to and
@@ -283,13 +283,15 @@ class InferenceCore:
         bank that changed after all invalidates them through its version) run as ONE pass over the bank, as far as those frames sit
         behind each other in one encoder batch.  A frame that already carries a read-out of the current bank version is not read again.
         first_alone (a memory frame, whose successor waits for this read-out right behind the insertion): the next frame is read on its
-        own, the frames behind it as one batch after it -- they have a whole frame time of slack."""
+        own, the frames behind it as one batch after it -- they have a whole frame time of slack.
+        part (with first_alone; clips in lock step, inference/lockstep.py: the side stream serves several banks): 'first' = only the next
+        frame's own read-out, 'rest' = only the stacked pass behind it -- the driver issues every clip's 'first' before any 'rest'."""
         dev = self.network.device
         gpu = dev.type == 'cuda'
         mem = self.memory
         qo = o.get('_qo')
         done = qo.get('_readouts') if qo is not None else None
-        if done and all(v[1] == mem._version for v in done.values()) and set(done) == set(mem.buckets):
+        if part != 'rest' and done and all(v[1] == mem._version for v in done.values()) and set(done) == set(mem.buckets):
             return qo.get('_readouts_ev') or ev                 # computed by an earlier batch (the consumer waits for that batch's event)
         recs, rest, rest_ev = [o], [], None
         group = []
@@ -343,9 +345,13 @@ class InferenceCore:
                 q = r['_qo'] = dict(Bhi=r['Bhi'], Blo=r['Blo'], cq=r['cq'], h=r['h'], w=r['w'])
             return q
         held = []
+        if part == 'first':
+            rest = []
         try:
             with (torch.cuda.stream(enc) if gpu else contextlib.nullcontext()):
-                if len(recs) > 1:
+                if part == 'rest':
+                    pass                                        # (the next frame's own read-out was issued by the 'first' call)
+                elif len(recs) > 1:
                     qs = [operands(r) for r in recs]
                     per_frame = mem.prefetch_affinity_batch(qs, self.network, event_factory=record)
                     if per_frame:
@@ -356,6 +362,8 @@ class InferenceCore:
                     if gpu:
                         ev = torch.cuda.Event()
                         ev.record(enc)
+                        if ro and qo is not None and qo.get('_readouts') is ro:
+                            qo['_readouts_ev'] = ev                 #  `read` orders itself behind the read-out, as it does for a batch
                     held.append(ro or {})
                 if rest:
                     if gpu and rest_ev is not None:

@@ -65,6 +65,8 @@ class MemoryManager:
         self.aux = None
         self._version = next(_VERSIONS)   # replaced whenever the bank changes (invalidates look-ahead read-outs)
         self._ahead_parity = 0
+        self._batch_parity = 0       # (the stacked read-outs alternate between two sets of usage side buffers of their own)
+        self._clip_tag = 0           # which clip of a lock-step group this bank belongs to (inference/lockstep.py): its own read-out slots in the engine's pool
 
     # The object summaries change only when a frame is memorised (or objects are purged); the transformer's query initialisation
     # depends on nothing else, so CUTIE.readout_query skips it while the token it is handed stays the same (tokens are process-wide
@@ -192,7 +194,7 @@ class MemoryManager:
         count = self._buf('count' + tag, (HW * O.OpList.AFF_CSTRIDE,), torch.int32, dev)
         ovf = self._buf('overflow', (1,), torch.int32, dev)
         pool = getattr(self, '_pool', None)                      # (set by read / prefetch_affinity: the engine's frame-slot pool)
-        readout = (pool.get(('readout', bucket.id, K, h, w, str(dev)), dict(r=((K, h, w, self.CV), BF16, False)), dev)['r'] if pool is not None
+        readout = (pool.get(('readout', self._clip_tag, bucket.id, K, h, w, str(dev)), dict(r=((K, h, w, self.CV), BF16, False)), dev)['r'] if pool is not None
                    else torch.empty((K, h, w, self.CV), dtype=BF16, device=dev))
         # The affinity plan of a bucket only changes when its token ranges do (memory frames, consolidation, purge) or a
         # setting is updated: the descriptors are built once per such state with named pointer slots and re-bound per frame
@@ -291,7 +293,7 @@ class MemoryManager:
         ovf = self._buf('overflow', (1,), torch.int32, dev)
         pool = getattr(self, '_pool', None)
         spec = dict(r=((F, K, h, w, self.CV), BF16, False))
-        readout = (pool.get_ring(('readout#batch', bucket.id, F, K, h, w, str(dev)), spec, dev, ring=3)['r'] if pool is not None
+        readout = (pool.get_ring(('readout#batch', self._clip_tag, bucket.id, F, K, h, w, str(dev)), spec, dev, ring=3)['r'] if pool is not None
                    else torch.empty(spec['r'][0], dtype=BF16, device=dev))
         nslots = int(bucket.use.shape[0]) if self.use_long_term else 0
         clear_long = self.use_long_term and bucket.n_long > 0 and not self.count_long_term_usage
@@ -335,9 +337,10 @@ class MemoryManager:
                    gmax=gmax, tau=tau, cval=cval, cidx=cidx, vptrs=bucket.vptrs(), readout=readout, ovf=ovf)
         udelta = None
         if self.use_long_term:
-            # two sets of side buffers per bucket, alternating per batch: the next batch (side stream) may start before the caller's
-            # stream has applied the last frame of this one
-            udelta = self._buf_rows(f'udelta#batch{self._ahead_parity}#{bucket.id}', F, (nslots,), F32, dev)
+            # two sets of side buffers per bucket, alternating per BATCH (a counter of the stacked read-outs alone -- ADVICE r05: on the
+            # shared counter of the one-frame look-ahead, which flips once more per memory cycle, every batch landed on the same set):
+            # the next batch (side stream) may start before the caller's stream has applied the last frame of this one
+            udelta = self._buf_rows(f'udelta#batch{self._batch_parity}#{bucket.id}', F, (nslots,), F32, dev)
             dyn.update(usage=udelta)
         cached[2].run(**dyn)
         return [(readout[f], udelta[f] if udelta is not None else None) for f in range(F)]
@@ -422,7 +425,7 @@ class MemoryManager:
             assert b['Bhi'].data_ptr() == a['Bhi'].data_ptr() + HWp * 256 and b['Blo'].data_ptr() == a['Blo'].data_ptr() + HWp * 256 \
                 and b['cq'].data_ptr() == a['cq'].data_ptr() + HWp * 4, 'frames of a batched read-out must come from one encoder batch'
         self._pool = network.engine().pool
-        self._ahead_parity ^= 1
+        self._batch_parity ^= 1
         per_frame = [dict() for _ in qs]
         for bid, b in self.buckets.items():
             for f, (r, ud) in enumerate(self._affinity_batch(b, q0, h, w, dev, len(qs))):
@@ -433,27 +436,38 @@ class MemoryManager:
             q['_readouts_ev'] = ev
         return per_frame
 
+    def read_visual(self, q: dict, h: int, w: int, dev, network) -> Dict[int, torch.Tensor]:
+        """The affinity half of `read` (memory_manager.py:126-167: similarity, top-k softmax, value read-out): bucket id -> read-out
+        bf16 [K, h, w, CV] for the query operands q.  A read-out that the look-ahead lane computed against this very bank version is taken
+        over -- and only now counted (`_commit_ahead`); otherwise it is computed here, on the caller's stream."""
+        self._pool = network.engine().pool
+        ahead = q.pop('_readouts', None) or {}
+        ahead_ev = q.pop('_readouts_ev', None)
+        if ahead_ev is not None and ahead:                              # a look-ahead read-out: ordered behind its own event
+            torch.cuda.current_stream(dev).wait_event(ahead_ev)
+        out = {}
+        for bucket in self.buckets.values():
+            K = len(bucket.objects)
+            pre = ahead.get(bucket.id)
+            if pre is not None and pre[1] == self._version and pre[0].shape[0] == K:
+                out[bucket.id] = pre[0]                                 # computed ahead on the side stream (the caller has waited for it)
+                if pre[2] is not None:
+                    self._commit_ahead(bucket, pre[2], network)         # its bookkeeping, now that it is used
+            else:
+                self._join_side()
+                out[bucket.id] = self._affinity(bucket, q, h, w, dev)
+        return out
+
     def read(self, pix_feat: torch.Tensor, query_key: torch.Tensor, selection: torch.Tensor, last_mask: torch.Tensor,
              network) -> Dict[int, torch.Tensor]:
         q = network.query_operands(query_key, selection)
         h, w = pix_feat.shape[-2:]
         dev = pix_feat.device
-        self._pool = network.engine().pool
-        ahead = q.pop('_readouts', None) or {}
-        ahead_ev = q.pop('_readouts_ev', None)
-        if ahead_ev is not None and ahead:                              # a batched look-ahead: ordered behind its own event
-            torch.cuda.current_stream(dev).wait_event(ahead_ev)
+        visual = self.read_visual(q, h, w, dev, network)
         all_readout = {}
         for bucket in self.buckets.values():
             K = len(bucket.objects)
-            pre = ahead.get(bucket.id)
-            if pre is not None and pre[1] == self._version and pre[0].shape[0] == K:
-                readout = pre[0]                                        # computed ahead on the side stream (the caller has waited for it)
-                if pre[2] is not None:
-                    self._commit_ahead(bucket, pre[2], network)         # its bookkeeping, now that it is used
-            else:
-                self._join_side()
-                readout = self._affinity(bucket, q, h, w, dev)
+            readout = visual[bucket.id]
             # chunk_size > 0 (memory_manager.py:169-186): pixel fusion and the object transformer run per group of chunk_size
             # objects -- this is NOT only a memory knob: the "others" mask of the fusion and the foreground / background
             # attention masks of the transformer are computed inside a group.  (encode_mask / segment chunks are equivalent

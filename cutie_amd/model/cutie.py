@@ -250,13 +250,14 @@ class Engine:
             self._rep[key] = e.repeat(K, 1).to(self.device).contiguous()
         return self._rep[key]
 
-    def mask_down_bufs(self, K, h, w):
+    def mask_down_bufs(self, K, h, w, clips=1):
         """(pair bf16 [K, h, w, 64] -- channels 0, 1 = (mask, others), the rest stays zero --, m16 f32 [K, h, w]): MASK_DOWN results that
-        the decoder's last launch of one frame leaves for the pixel fusion of the next (plans.build_segment(md) / build_pixel_fusion(pre_md))."""
+        the decoder's last launch of one frame leaves for the pixel fusion of the next (plans.build_segment(md) / build_pixel_fusion(pre_md)).
+        clips > 1: the buffers of the lock-step plans (K = clips x objects per clip), a set of their own."""
         mb = self.__dict__.setdefault('_md_bufs', {})
-        if (K, h, w) not in mb:
-            mb[(K, h, w)] = (torch.zeros((K, h, w, 64), dtype=BF16, device=self.device), torch.zeros((K, h, w), dtype=F32, device=self.device))
-        return mb[(K, h, w)]
+        if (K, h, w, clips) not in mb:
+            mb[(K, h, w, clips)] = (torch.zeros((K, h, w, 64), dtype=BF16, device=self.device), torch.zeros((K, h, w), dtype=F32, device=self.device))
+        return mb[(K, h, w, clips)]
 
     def query_bufs(self, K):
         """f32 [K * Q, C] x 2: the initial object queries / query embeddings of the transformer, shared by the plan variants that write

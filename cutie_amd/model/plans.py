@@ -392,7 +392,8 @@ class Plan:
             M, cout, cin = int(i[0]) * int(i[7]) * int(i[8]), int(i[9]), int(i[3]) + int(i[4])
             key = (M, cout, cin, int(i[11]), int(i[13]), int(arr['flags'][n]) & 3, int(i[1]), int(i[2]))
             best = cache.get(key)
-            if self.korder_ref:
+            twin = self.korder_ref and int(i[0]) % self.korder_ref == 0     # (a lock-step plan also holds launches of ONE clip, B = 1: those are the one-clip plan's own geometry)
+            if twin:
                 # batched twin of a B = 1 plan (the look-ahead window of the image encoder): whatever the table says for the batched
                 # geometry, the tile must sum over K in the order of the tile the B = 1 plan runs for this layer -- that keeps frame b
                 # of the batch bit-identical to the same frame through the B = 1 plan
@@ -428,7 +429,7 @@ class Plan:
                 apply = False                                # GAP accumulation / zero job exist in conv_dma_kernel only
             if apply:
                 arr['i'][n, 17], arr['i'][n, 19] = best
-            if self.korder_ref:
+            if twin:
                 #  whatever path was taken above -- table entry, static choice kept, a skipped assignment --, the tile this
                 # conv RUNS must sum over K like the one-frame plan's: that is what keeps a frame of the batch bit-identical to it
                 assert O.korder_class(int(arr['i'][n, 17]), int(arr['i'][n, 19])) == want, (key, int(arr['i'][n, 17]), int(arr['i'][n, 19]), want)
@@ -440,7 +441,7 @@ class Plan:
 
     # ---- conv helper ------------------------------------------------------------------
     def conv(self, wname, x, *, name=None, out=None, stride=1, pad=None, x2=None, res=None, res_bcast=False,
-             relu_in=False, act=O.ACT_NONE, out_f32=False, ldy=None, gap_acc=None, zero=None, persistent=False):
+             relu_in=False, act=O.ACT_NONE, out_f32=False, ldy=None, gap_acc=None, zero=None, persistent=False, res_group=None):
         w = self.eng.w[wname]
         if pad is None:
             pad = (w.kh - 1) // 2
@@ -457,7 +458,7 @@ class Plan:
                      pad=pad, x2=None if x2 is None else x2.t, C2=0 if x2 is None else x2.C,
                      ldx2=0 if x2 is None else x2.ld, res=None if res is None else res.t,
                      ldr=0 if res is None else res.ld, res_bcast=res_bcast, relu_in=relu_in, act=act, out_f32=out_f32,
-                     gap_acc=gap_acc, zero=zero, prio=self.prio)
+                     gap_acc=gap_acc, zero=zero, prio=self.prio, res_group=res_group)
         return out
 
     # ---- shared blocks ------------------------------------------------------------------
@@ -487,11 +488,12 @@ class Plan:
         self.ol.eca_apply(t2.t, gap, self.eng.w[prefix + '.conv.weight'], x.t, out.t, B=x.B, HW=HW, C=x.C, head=head)
         return out
 
-    def fusion_block(self, prefix, x, g, name, out=None, xt=None):
-        """GroupFeatureFusionBlock (group_modules.py:102-127).  xt: x_transform(x) computed elsewhere (the encoder plan)."""
+    def fusion_block(self, prefix, x, g, name, out=None, xt=None, xt_group=None):
+        """GroupFeatureFusionBlock (group_modules.py:102-127).  xt: x_transform(x) computed elsewhere (the encoder plan).
+        xt_group = (objects per clip, rows between the clips' xt maps): clips in lock step -- every clip's objects add their clip's map."""
         if xt is None:
             xt = self.conv(prefix + '.distributor.x_transform', x, name=name + '.xt')
-        g0 = self.conv(prefix + '.distributor.g_transform', g, name=name + '.g0', res=xt, res_bcast=True)
+        g0 = self.conv(prefix + '.distributor.g_transform', g, name=name + '.g0', res=xt, res_bcast=True, res_group=xt_group)
         g1 = self.ca_block(prefix + '.block1', g0, name + '.b1')
         return self.ca_block(prefix + '.block2', g1, name + '.b2', out=out)
 
@@ -596,36 +598,59 @@ def build_transform_key(eng, h, w):
     return P
 
 
-def build_pixel_fusion(eng, K, h, w, pre=False, pre_md=False):
+def build_pixel_fusion(eng, K, h, w, pre=False, pre_md=False, clips=1, wstride=1):
     """CUTIE.pixel_fusion (cutie.py:142-157; big_modules.py:207-235).
     dyn in: pix_feat, pixel (readout) bf16 [K,h,w,CV], sensory_bf16 [K,h,w,CS], last_mask f32 [K,16h,16w];
     pre: fuse_xt bf16 [1,h,w,CE] = x_transform(pix_feat) from the encoder plan instead of pix_feat.
-    dyn out: fused bf16 [K,h,w,CE]."""
+    dyn out: fused bf16 [K,h,w,CE].
+    clips > 1 (clips in lock step, cutie_amd/inference/lockstep.py; no counterpart in the reference, which runs one InferenceCore per
+    video): `clips` independent clips of K objects each through ONE plan -- every per-object tensor has clips * K rows (clip-major), the
+    per-clip tensors (fuse_xt: needs pre) are the slices of one frame in the encoder window's output, `wstride` frames apart; the read-outs
+    of the clips (dyn in pixel0 .. pixel<clips-1>, one tensor per memory bank) are gathered by the first launch; dyn in last_mask0.. when
+    the masks were not down-sampled by the segment in front (pre_md).  Per clip the launches compute what the one-clip plan computes."""
+    G, Kc = clips, K
+    K = G * Kc
+    assert G == 1 or pre, 'clips in lock step take x_transform(pix_feat) from the encoder plan'
     P = Plan(eng, touch=weights_go_cold(h * w, K))
     m = eng.m
     if pre_md:                                           # written by the previous frame's up-sampling launch (build_segment(md=True))
-        pair = eng.mask_down_bufs(K, h, w)[0]
+        pair = eng.mask_down_bufs(K, h, w, G)[0]
         P.ol.keep.append(pair)
     else:
         pair = P.buf('pair', (K, h, w, 64), persistent=True)       # (mask, others) in channels 0, 1 of a ZEROED 64-channel tensor: a whole K tile
         m16 = P.buf('m16', (K, h, w), F32)
-        P.ol.mask_down(Dyn('last_mask'), pair, m16, K=K, H=16 * h, W=16 * w, pair_channels=64)
-    pixel = Act(Dyn('pixel'), K, h, w, m['value_dim'])
+        for c in range(G):                               # ("others" = the other objects of the SAME clip: one launch per clip)
+            P.ol.mask_down(Dyn('last_mask' if G == 1 else 'last_mask%d' % c), pair[c * Kc:], m16[c * Kc:], K=Kc, H=16 * h, W=16 * w, pair_channels=64)
+    if G > 1:
+        px = P.buf('pixel_all', (K, h, w, m['value_dim']))
+        nb = Kc * h * w * m['value_dim'] * 2
+        P.ol.bank_write([(Dyn('pixel%d' % c), px[c * Kc:], nb) for c in range(G)])
+        pixel = Act(px, K, h, w, m['value_dim'])
+    else:
+        pixel = Act(Dyn('pixel'), K, h, w, m['value_dim'])
     p16 = P.conv('pixel_fuser.sensory_compress', Act(Dyn('sensory_bf16'), K, h, w, m['sensory_dim']),
                  x2=Act(pair, K, h, w, 64), res=pixel, name='p16')
-    xt = Act(Dyn('fuse_xt'), 1, h, w, eng.w['pixel_fuser.fuser.distributor.x_transform'].cout) if pre else None
+    xt = Act(Dyn('fuse_xt'), G, h, w, eng.w['pixel_fuser.fuser.distributor.x_transform'].cout) if pre else None
     P.fusion_block('pixel_fuser.fuser', Act(Dyn('pix_feat'), 1, h, w, m['pixel_dim']), p16, 'fuse',
-                   out=Act(Dyn('fused'), K, h, w, m['embed_dim']), xt=xt)
+                   out=Act(Dyn('fused'), K, h, w, m['embed_dim']), xt=xt, xt_group=(Kc, wstride * h * w) if G > 1 else None)
+    if G > 1:
+        P.korder_ref = G                                 # tiles from the K-order class of the one-clip plan's: same bits per clip
     return P
 
 
-def build_readout_query(eng, K, h, w, last_aux=True, fresh=True):
+def build_readout_query(eng, K, h, w, last_aux=True, fresh=True, clips=1):
     """CUTIE.readout_query -> QueryTransformer.forward (object_transformer.py:114-177).
     dyn in: pixel bf16 [K,h,w,C], obj_mem f32 [K,Q,C+1].  dyn out: out bf16 [K,h,w,C].
     Aux logits of every block are kept in bufs['aux_logits'] (f32 [blocks+1,K,hw]) for tests.  last_aux=False skips the mask_pred
     head after the LAST block: its logits mask no attention any more (the reference computes them anyway, object_transformer.py:164,
-    and only save_aux / training read them)."""
+    and only save_aux / training read them).
+    clips > 1: that many clips of K objects in lock step (see build_pixel_fusion) -- every launch of the transformer is per object; the
+    foreground masks are decided among the objects of one clip (ATTN_Q2P i9)."""
+    G, Kc = clips, K
+    K = G * Kc
     P = Plan(eng, touch=weights_go_cold(h * w, K))
+    if G > 1:
+        P.korder_ref = G
     m, ol, W = eng.m, P.ol, eng.w
     ot = m['object_transformer']
     C, Q, heads, nb = m['embed_dim'], ot['num_queries'], ot['num_heads'], ot['num_blocks']
@@ -634,6 +659,7 @@ def build_readout_query(eng, K, h, w, last_aux=True, fresh=True):
     f = lambda name, shape: P.buf(name, shape, F32)
     query, query_emb = eng.query_bufs(K)                  # (engine-level: the variant with fresh=False reads what the other one wrote)
     use_chain = QCHAIN and not UNFUSED and C == 256 and Q == 16 and heads == 8 and HW <= 24576 and ot['ff_dim'] % QFFN_SLICE == 0
+    assert G == 1 or use_chain, 'clips in lock step need the chain form of the query side'
     # fixed-point accumulators of the query chain (three per block), cleared by the first launch of the plan
     qacc = P.buf('qacc', (3 * nb, M, C), torch.int64) if use_chain else None
     zero_on_conv = None
@@ -704,11 +730,11 @@ def build_readout_query(eng, K, h, w, last_aux=True, fresh=True):
             a1, a2, a3 = qacc[3 * b], qacc[3 * b + 1], qacc[3 * b + 2]
             if q_pre is not None:                                  # projected by the previous block's ATTN_P2Q launch (xn too)
                 ol.attn_q2p(None, kvq.t, None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=aux[b],
-                            q_pre=q_pre, out_proj=(Wo1, a1))
+                            q_pre=q_pre, out_proj=(Wo1, a1), clip_objects=Kc)
             else:
                 ol.attn_q2p(None, kvq.t, None, None, None, K=K, Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C, logits=aux[b],
                             proj=dict(x=x, W=W[q + '.read_from_pixel.q'], emb=query_emb, ln=ln('.read_from_pixel.norm'), ln_out=xn),
-                            acc_in=prev_acc, out_proj=(Wo1, a1))
+                            acc_in=prev_acc, out_proj=(Wo1, a1), clip_objects=Kc)
             y = f(n + 'y', (M, C))
             ol.attn_self(None, None, None, K=K, Q=Q, C=C, heads=heads,
                          proj=dict(x=xn, W=W[q + '.self_attn.qkv'], emb=query_emb, ln=ln('.self_attn.norm'), ln_out=y),
@@ -785,32 +811,39 @@ def build_readout_query(eng, K, h, w, last_aux=True, fresh=True):
     return P
 
 
-def build_segment(eng, K, h, w, update_sensory, pre=False, md=False):
+def build_segment(eng, K, h, w, update_sensory, pre=False, md=False, clips=1, wstride=1):
     """CUTIE.segment -> MaskDecoder.forward + sigmoid/aggregate/x4/softmax (cutie.py:172-203;
     big_modules.py:257-306; modules.py:8-68).
     dyn in: f8, f4 (bf16), p16 (memory readout) bf16 [K,h,w,C], sensory_f32 / sensory_bf16 [K,h,w,CS] (in-place).
     pre: f8p, f4p (decoder_feat_proc of f8 / f4, from the encoder plan) instead of f8, f4.
-    dyn out: prob f32 [K+1,16h,16w] (+ logits_up if bound)."""
+    dyn out: prob f32 [K+1,16h,16w] (+ logits_up if bound).
+    clips > 1: that many clips of K objects in lock step (see build_pixel_fusion; needs pre): f8p / f4p are the slices of one frame in the
+    encoder window's output, `wstride` frames apart; dyn out prob f32 [clips, K+1, 16h, 16w]."""
+    G, Kc = clips, K
+    K = G * Kc
+    assert G == 1 or (pre and Kc + 1 <= 8 and not UNFUSED), 'clips in lock step: image-only decoder convs from the encoder plan, <= 7 objects per clip'
     P = Plan(eng, touch=weights_go_cold(h * w, K))
+    if G > 1:
+        P.korder_ref = G
     m, ol = eng.m, P.ol
     up = m['mask_decoder']['up_dims']
     ms = m['pixel_encoder']['ms_dims']
     CS = m['sensory_dim']
     h8, w8, h4, w4 = 2 * h, 2 * w, 4 * h, 4 * w
     if pre:
-        f8p, f4p = Act(Dyn('f8p'), 1, h8, w8, up[0]), Act(Dyn('f4p'), 1, h4, w4, up[1])
+        f8p, f4p = Act(Dyn('f8p'), G, h8, w8, up[0]), Act(Dyn('f4p'), G, h4, w4, up[1])
     else:
         f8p = P.conv('mask_decoder.decoder_feat_proc.transforms.0', Act(Dyn('f8'), 1, h8, w8, ms[1]), name='f8p')
         f4p = P.conv('mask_decoder.decoder_feat_proc.transforms.1', Act(Dyn('f4'), 1, h4, w4, ms[2]), name='f4p')
     p16 = Act(Dyn('p16'), K, h, w, up[0])
     u8 = P.buf('u8', (K, h8, w8, up[0]))
-    ol.upsample2x_add(p16.t, f8p.t, u8, B=K, h=h, w=w, C=up[0])
+    ol.upsample2x_add(p16.t, f8p.t, u8, B=K, h=h, w=w, C=up[0], skip_group=(Kc, wstride * h8 * w8) if G > 1 else None)
     u8 = Act(u8, K, h8, w8, up[0])
     t1 = P.conv('mask_decoder.up_16_8.out_conv.conv1', u8, relu_in=True, act=O.ACT_RELU)
     ds = P.conv('mask_decoder.up_16_8.out_conv.downsample', u8)
     p8 = P.conv('mask_decoder.up_16_8.out_conv.conv2', t1, res=ds, name='p8')
     u4 = P.buf('u4', (K, h4, w4, up[1]))
-    ol.upsample2x_add(p8.t, f4p.t, u4, B=K, h=h8, w=w8, C=up[1])
+    ol.upsample2x_add(p8.t, f4p.t, u4, B=K, h=h8, w=w8, C=up[1], skip_group=(Kc, wstride * h4 * w4) if G > 1 else None)
     u4 = Act(u4, K, h4, w4, up[1])
     t2 = P.conv('mask_decoder.up_8_4.out_conv.conv1', u4, relu_in=True, act=O.ACT_RELU)
     p4 = P.conv('mask_decoder.up_8_4.out_conv.conv2', t2, res=u4, name='p4')
@@ -829,11 +862,11 @@ def build_segment(eng, K, h, w, update_sensory, pre=False, md=False):
         vals = P.conv('mask_decoder.sensory_update.transform', g3, x2=Act(Dyn('sensory_bf16'), K, h, w, CS),
                       out_f32=True, name='gru_vals')
         ol.gru(vals.t, Dyn('sensory_f32'), Dyn('sensory_bf16'), n=K * h * w, C=CS)
-    if K + 1 <= 16 and not UNFUSED:               # aggregation recomputed per bilinear tap inside the up-sampling launch
+    if Kc + 1 <= 16 and not UNFUSED:              # aggregation recomputed per bilinear tap inside the up-sampling launch
         # md: the launch also derives what the NEXT frame's pixel fusion needs from these probabilities (MASK_DOWN: the stride-16 means
         # of the object planes and the (mask, others) pairs), into buffers both plans know (Engine.mask_down_bufs)
-        ol.up4_softmax(logits, Dyn('prob'), Dyn('logits_up'), P=K + 1, h=h4, w=w4, from_logits=True,
-                       mask_down=(eng.mask_down_bufs(K, h, w)[1], eng.mask_down_bufs(K, h, w)[0], 64) if md else None)
+        ol.up4_softmax(logits, Dyn('prob'), Dyn('logits_up'), P=Kc + 1, h=h4, w=w4, from_logits=True, clips=G,
+                       mask_down=(eng.mask_down_bufs(K, h, w, G)[1], eng.mask_down_bufs(K, h, w, G)[0], 64) if md else None)
     else:
         agg = P.buf('agg', (K + 1, h4, w4), F32)
         ol.seg_agg(logits, agg, K=K, hw=h4 * w4)
@@ -841,19 +874,29 @@ def build_segment(eng, K, h, w, update_sensory, pre=False, md=False):
     return P
 
 
-def build_encode_mask(eng, K, h0, w0, H, W, pad_left, pad_top, deep_update=True, pre_md=False):
+def build_encode_mask(eng, K, h0, w0, H, W, pad_left, pad_top, deep_update=True, pre_md=False, clips=1, wstride=1):
     """CUTIE.encode_mask -> MaskEncoder.forward + ObjectSummarizer.forward (cutie.py:66-90;
     big_modules.py:122-182; object_summarizer.py:55-89).
     dyn in: image f32 [3,h0,w0], masks f32 [K,H,W], pix_feat, sensory_f32/sensory_bf16 (in-place deep update).
-    dyn out: value bf16 [K,h,w,CV], summ f32 [K,Q,C+1]."""
+    dyn out: value bf16 [K,h,w,CV], summ f32 [K,Q,C+1].
+    clips > 1: that many clips of K objects in lock step (see build_pixel_fusion): dyn in image0 .., masks = the probabilities
+    f32 [clips, K+1, H, W] of the segment in front (clip c's object planes at [c, 1:]), pix_feat = clip 0's slice of the encoder window's
+    output (`wstride` frames between the clips); value / summ / the sensory state hold clips * K objects."""
+    G, Kc = clips, K
+    K = G * Kc
     P = Plan(eng, touch=weights_go_cold((H // 16) * (W // 16), K))
+    if G > 1:
+        P.korder_ref = G
     m, ol = eng.m, P.ol
     h, w = H // 16, W // 16
     CV, CS, CE, Q = m['value_dim'], m['sensory_dim'], m['embed_dim'], m['object_summarizer']['num_summaries']
+    masks_of = (lambda c: Dyn('masks')) if G == 1 else (lambda c: Dyn('masks', 4 * (c * (Kc + 1) + 1) * H * W))
+    assert G == 1 or stem_ok(eng, 'mask_encoder.conv1')
     if stem_ok(eng, 'mask_encoder.conv1'):
         pool = P.buf('pool', (K, H // 4, W // 4, 64))
-        ol.stem(Dyn('image'), Dyn('masks'), eng.w['mask_encoder.conv1'], pool, h0=h0, w0=w0, H=H, W=W, pad_left=pad_left, pad_top=pad_top, K=K,
-                mean=m['pixel_mean'], std=m['pixel_std'], relu=True)
+        for c in range(G):                               # ("others" = the other objects of the same clip, one frame per clip: a launch per clip)
+            ol.stem(Dyn('image' if G == 1 else 'image%d' % c), masks_of(c), eng.w['mask_encoder.conv1'], pool[c * Kc:], h0=h0, w0=w0, H=H, W=W,
+                    pad_left=pad_left, pad_top=pad_top, K=Kc, mean=m['pixel_mean'], std=m['pixel_std'], relu=True)
     else:
         x8 = P.buf('x8', (K, H, W, 8))
         ol.img_prep(Dyn('image'), Dyn('masks'), x8, h0=h0, w0=w0, H=H, W=W, pad_left=pad_left, pad_top=pad_top, K=K,
@@ -862,8 +905,16 @@ def build_encode_mask(eng, K, h0, w0, H, W, pad_left, pad_top, deep_update=True,
         pool = P.buf('pool', (K, x.H // 2, x.W // 2, 64))
         ol.maxpool(x.t, pool, B=K, H=x.H, W=x.W, C=64, relu=True)
     g16, _ = P.resnet('mask_encoder', Act(pool, K, H // 4, W // 4, 64))
+    xt = xt_group = None
+    if G > 1:                                            # x_transform of every clip's pix_feat (rows of one clip only: M = hw each)
+        wx = eng.w['mask_encoder.fuser.distributor.x_transform']
+        xt_t = P.buf('fuse.xt', (G, h, w, wx.cout))
+        for c in range(G):
+            P.conv('mask_encoder.fuser.distributor.x_transform', Act(Dyn('pix_feat', 2 * c * wstride * h * w * m['pixel_dim']), 1, h, w, m['pixel_dim']),
+                   out=Act(xt_t[c:c + 1], 1, h, w, wx.cout))
+        xt, xt_group = Act(xt_t, G, h, w, wx.cout), (Kc, h * w)
     value = P.fusion_block('mask_encoder.fuser', Act(Dyn('pix_feat'), 1, h, w, m['pixel_dim']), g16, 'fuse',
-                           out=Act(Dyn('value'), K, h, w, CV))
+                           out=Act(Dyn('value'), K, h, w, CV), xt=xt, xt_group=xt_group)
     P.meta['value_done'] = len(ol.recs)               # what follows reads named tensors only (value, masks, sensory): see CUTIE._encode_mask_split
     if deep_update:
         vals = P.conv('mask_encoder.sensory_update.transform', value, x2=Act(Dyn('sensory_bf16'), K, h, w, CS),
@@ -871,11 +922,12 @@ def build_encode_mask(eng, K, h0, w0, H, W, pad_left, pad_top, deep_update=True,
         ol.gru(vals.t, Dyn('sensory_f32'), Dyn('sensory_bf16'), n=K * h * w, C=CS)
     # object summarizer
     if pre_md:                                           # written by the last segment's up-sampling launch (build_segment(md=True)): these very masks
-        m16 = eng.mask_down_bufs(K, h, w)[1]
+        m16 = eng.mask_down_bufs(K, h, w, G)[1]
     else:
         pair = P.buf('pair', (K, h, w, 8))
         m16 = P.buf('m16', (K, h, w), F32)
-        ol.mask_down(Dyn('masks'), pair, m16, K=K, H=H, W=W)
+        for c in range(G):
+            ol.mask_down(masks_of(c), pair[c * Kc:], m16[c * Kc:], K=Kc, H=H, W=W)
     if SUM_FUSED and not UNFUSED:
         # two launches instead of five (Engine: '.in_fw0', '.fw2'): value -> [f1 | w1] with the composed weights, then the block-diagonal
         # second layers -> fp32 [feature | weight logits]

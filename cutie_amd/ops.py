@@ -379,8 +379,9 @@ class OpList:
     # ---- builders (argument order mirrors include/cutie_hip.h) -----------------------
     def conv(self, x1, w, y, *, B, H, W, C1, ldx1, OH, OW, ldy, stride=1, pad=0, x2=None, C2=0, ldx2=0,
              res=None, ldr=0, res_bcast=False, relu_in=False, act=ACT_NONE, out_f32=False, tile=None, splitk=1,
-             gap_acc=None, zero=None, prio=False):
-        """w: PackedConv (weights.py).  gap_acc: int64 [B, Cout] -- the conv adds the per-(object, channel) sums of its stored output
+             gap_acc=None, zero=None, prio=False, res_group=None):
+        """w: PackedConv (weights.py).  res_group = (objects per clip, rows between the clips' residual maps) with res_bcast: clips in lock step
+        (include/cutie_hip.h CONV, ABI 4) -- the B objects come in groups, every group adds its own broadcast residual.  gap_acc: int64 [B, Cout] -- the conv adds the per-(object, channel) sums of its stored output
         (fixed point x 2^24) to it (ECA's global average pool without a launch of its own); zero: an int64 tensor cleared by this
         launch (the accumulator of the NEXT conv).  Both need an LDS-DMA tile (the tile choice is restricted accordingly)."""
         flags = (F_RELU_IN if relu_in else 0) | (F_OUT_F32 if out_f32 else 0) | (F_RES_BCAST if res_bcast else 0) | (act << ACT_SHIFT) | F_PLAIN | F_TILE_OFF | \
@@ -397,7 +398,15 @@ class OpList:
         return self.add(CONV, flags,
                         [B, H, W, C1, C2, ldx1, ldx2, OH, OW, w.cout, ldy, w.kh, w.kw, stride, pad, ldr, w.kpad, tile, w.cin_real,
                          splitk, part.numel() // 1024, 0 if zero is None else zero.numel()],
-                        [], [x1, x2, w.weight, w.bias, res, y, part, gap_acc, zero])
+                        self._res_group(res_group, res_bcast, B, OH * OW), [x1, x2, w.weight, w.bias, res, y, part, gap_acc, zero])
+
+    @staticmethod
+    def _res_group(res_group, res_bcast, B, OHW):
+        if res_group is None:
+            return []
+        kg, stride = int(res_group[0]), int(res_group[1])
+        assert res_bcast and kg > 0 and B % kg == 0 and stride >= OHW and stride < (1 << 24), (res_group, B, OHW)
+        return [float(kg), float(stride)]
 
     def maxpool(self, x, y, *, B, H, W, C, relu=False):
         OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
@@ -411,8 +420,14 @@ class OpList:
     def img_prep(self, image, masks, y, *, h0, w0, H, W, pad_left, pad_top, K, mean, std):
         return self.add(IMG_PREP, 0, [h0, w0, H, W, pad_left, pad_top, K], list(mean) + list(std), [image, masks, y])
 
-    def upsample2x_add(self, g, skip, y, *, B, h, w, C):
-        return self.add(UPSAMPLE2X_ADD, 0, [B, h, w, C], [], [g, skip, y])
+    def upsample2x_add(self, g, skip, y, *, B, h, w, C, skip_group=None):
+        """skip_group = (objects per clip, pixels between the clips' skip maps): clips in lock step (ABI 4)."""
+        ints = [B, h, w, C]
+        if skip_group is not None:
+            kg, stride = int(skip_group[0]), int(skip_group[1])
+            assert kg > 0 and B % kg == 0 and stride >= 4 * h * w
+            ints += [kg, stride]
+        return self.add(UPSAMPLE2X_ADD, 0, ints, [], [g, skip, y])
 
     def area_down(self, x, y, *, B, H, W, C, ldx, ldy, r, f32_in=False, Cz=None):
         return self.add(AREA_DOWN, 1 if f32_in else 0, [B, H, W, C, ldx, ldy, r, C if Cz is None else Cz], [], [x, y])
@@ -459,14 +474,16 @@ class OpList:
     def seg_agg(self, logits, agg, *, K, hw):
         return self.add(SEG_AGG, 0, [K, hw], [], [logits, agg])
 
-    def up4_softmax(self, agg, prob, logits_up, *, P, h, w, from_logits=False, mask_down=None):
+    def up4_softmax(self, agg, prob, logits_up, *, P, h, w, from_logits=False, mask_down=None, clips=1):
         """from_logits: `agg` holds the K = P - 1 raw logit planes and the aggregation (SEG_AGG) runs inside the launch (P <= 16).
-        mask_down = (m16 f32 [K, hw16], pair bf16 [K, h16, w16, pitch], pitch): the launch also writes MASK_DOWN(prob[1:], r = 16)."""
+        mask_down = (m16 f32 [K, hw16], pair bf16 [K, h16, w16, pitch], pitch): the launch also writes MASK_DOWN(prob[1:], r = 16).
+        clips > 1 (clips in lock step, ABI 4; the four-pixel forms): every array holds that many clips, P planes out / P - 1 in each."""
         if mask_down is not None:
             assert from_logits and not UP4_SCALAR and P <= 8 and h % 4 == 0 and w % 4 == 0
             m16, pair, pitch = mask_down
-            return self.add(UP4_SOFTMAX, 1 | 4 | UP4_RTK | UP4_LANES, [P, h, w, pitch], [], [agg, prob, logits_up, m16, pair])
-        return self.add(UP4_SOFTMAX, (1 | UP4_SCALAR | UP4_RTK) if from_logits else 0, [P, h, w], [], [agg, prob, logits_up])
+            return self.add(UP4_SOFTMAX, 1 | 4 | UP4_RTK | UP4_LANES, [P, h, w, pitch, clips], [], [agg, prob, logits_up, m16, pair])
+        assert clips == 1 or (from_logits and not UP4_SCALAR and P <= 8)
+        return self.add(UP4_SOFTMAX, (1 | UP4_SCALAR | UP4_RTK) if from_logits else 0, [P, h, w, 0, clips], [], [agg, prob, logits_up])
 
     def mask_merge(self, inmask, pred, src, planes, *, h0, w0, H, W, pad_left, pad_top, Knew, Kold, nfloat, float_mode):
         return self.add(MASK_MERGE, 1 if float_mode else 0, [h0, w0, H, W, pad_left, pad_top, Knew, Kold, nfloat], [],
@@ -534,18 +551,22 @@ class OpList:
             ptrs[12], ptrs[13] = out_proj[0].weight, out_proj[1]
         return flags, ints, ptrs
 
-    def attn_q2p(self, q, kv, fg, nfg, y, *, K, Q, HW, C, heads, ldkv, voff, logits=None, proj=None, acc_in=None, out_proj=None, q_pre=None, hstride=None):
+    def attn_q2p(self, q, kv, fg, nfg, y, *, K, Q, HW, C, heads, ldkv, voff, logits=None, proj=None, acc_in=None, out_proj=None, q_pre=None, hstride=None,
+                 clip_objects=None):
         """logits given: the foreground mask is derived inside the kernel from the mask_pred logits (AUX_MASK fused; fg / nfg unused).
         proj given (needs logits): q = (LN(x) + emb) Wq^T + b is computed inside the launch from the unprojected rows proj['x'].
         out_proj (needs proj; chain form, see _proj_extras): y is not written; acc_in optional.
         q_pre (chain form, instead of proj): q f32 [K*Q, 256], already projected and scaled by 1/sqrt(32) -- by the ATTN_P2Q launch of the
-        previous transformer block (attn_p2q(next_q=...))."""
+        previous transformer block (attn_p2q(next_q=...)).
+        clip_objects (chain form, ABI 4): objects per clip when the K objects are those of several clips in lock step (i9)."""
         hs = 0 if hstride in (None, C // heads) else hstride   # chain form only: elements between the heads' k (and v) inside a pixel row (i8)
+        kg = 0 if clip_objects in (None, K) else int(clip_objects)
+        assert kg == 0 or (out_proj is not None and K % kg == 0), 'clips in lock step need the chain form'
         if q_pre is not None:
             assert proj is None and acc_in is None and out_proj is not None and logits is not None
             flags, ints, ptrs = self._proj_extras(3 | 16, [K, Q, HW, C, heads, ldkv, voff, 256], [q_pre, kv, logits, None, None], None, out_proj)
             ints[8] = hs
-            return self.add(ATTN_Q2P, flags, ints, [], ptrs)
+            return self.add(ATTN_Q2P, flags, ints + [kg], [], ptrs)
         if proj is not None:
             assert logits is not None
             ldx, ln_out, tail = self._proj(proj)
@@ -553,7 +574,7 @@ class OpList:
             flags, ints, ptrs = self._proj_extras(3, [K, Q, HW, C, heads, ldkv, voff, ldx], [proj['x'], kv, logits, ln_out, y] + tail, acc_in, out_proj)
             assert hs == 0 or out_proj is not None, 'a head stride needs the chain form'
             ints[8] = hs
-            return self.add(ATTN_Q2P, flags, ints, [], ptrs)
+            return self.add(ATTN_Q2P, flags, ints + [kg], [], ptrs)
         assert acc_in is None and out_proj is None
         if logits is not None:
             return self.add(ATTN_Q2P, 1, [K, Q, HW, C, heads, ldkv, voff], [], [q, kv, logits, None, y])

@@ -70,7 +70,11 @@ enum {
      *       p8 = int64 buffer of i21 words cleared by this launch.
      *    p9 / i22, p10 / i23 (producer / consumer tiles 100.., else ignored; 0 = none): device ranges [p, p + bytes) that the
      *       producer waves read and discard once their last DMA piece is out -- the packed weights of the following conv(s)
-     *       of the list, so that they are in every XCD's L2 when that launch starts.  Never changes a result. */
+     *       of the list, so that they are in every XCD's L2 when that launch starts.  Never changes a result.
+     *    ABI 4 -- clips in lock step (several independent clips through one launch, batch = clips x objects; the reference runs one
+     *       InferenceCore per video, eval_vos.py:97): with CUTIE_F_RES_BCAST and f0 > 0 the B objects come in groups of (int)f0 -- one clip
+     *       each -- and group q adds ITS residual map [OH,OW,ldr] at p4 + q * (int)f1 rows (f1 >= OH*OW, a whole number; what
+     *       MainToGroupDistributor('add') broadcasts per clip, group_modules.py:61-99).  f0 = 0: one map for all objects, as before. */
     CUTIE_OP_CONV = 1,
     /* MAXPOOL 3x3 s2 p1 (+relu if flags&1): resnet.py:131-134, big_modules.py:47-48,158-160
      * p0=x bf16 [B,H,W,C] p1=y bf16 [B,OH,OW,C]   i: 0 B 1 H 2 W 3 C 4 OH 5 OW */
@@ -83,7 +87,8 @@ enum {
     CUTIE_OP_IMG_PREP = 3,
     /* UPSAMPLE2X_ADD: y = bilinear_x2(g, align_corners=False) + skip (broadcast over objects)
      * group_modules.py:19-23 + MainToGroupDistributor('add') modules.py:15-18
-     * p0=g bf16 [B,h,w,C] p1=skip bf16 [1,2h,2w,C] p2=y bf16 [B,2h,2w,C]   i: 0 B 1 h 2 w 3 C */
+     * p0=g bf16 [B,h,w,C] p1=skip bf16 [1,2h,2w,C] p2=y bf16 [B,2h,2w,C]   i: 0 B 1 h 2 w 3 C
+     * ABI 4: i4 > 0 = objects per clip (clips in lock step, see CONV): group q = b / i4 adds the skip map at p1 + q * i5 pixels (i5 >= 4hw) */
     CUTIE_OP_UPSAMPLE2X_ADD = 4,
     /* AREA_DOWN: r x r mean (F.interpolate mode='area', integer ratio) on NHWC bf16|f32 input
      * group_modules.py:26-30 (modules.py:59-60)
@@ -123,7 +128,9 @@ enum {
      * flags&16 (with flags&4): every lane aggregates its own six source pixels (A/B switch; default: the 6 x 6 source pixels under a 16 x 16
      *      output cell are aggregated once per wave and shared through LDS -- half the VALU instructions, same bits)
      * flags&8 (with flags&1): the kernels with a run-time object count (A/B switch; default: one instantiation per K = 1..7, whose loads are
-     *      all in flight together -- same bits) */
+     *      all in flight together -- same bits)
+     * ABI 4: i4 > 1 = clips per launch (grid.y; the four-pixel forms only): clip c reads logits p0 + c*K*h*w and writes prob / logits_up
+     *      + c*(K+1)*16hw, m16 + c*K*(hw/16), pair + c*K*(hw/16)*i3 -- per clip exactly the one-clip launch */
     CUTIE_OP_UP4_SOFTMAX = 11,
     /* MASK_MERGE: build the per-object mask planes of a frame with an input mask
      * inference_core.py:259-300.  plane t: src[t] >= 0 -> (idx==src[t]) [idx mode] / fmask[src[t]] [float
@@ -173,7 +180,9 @@ enum {
      * i8 (chain form; 0 = 32): elements between the heads' k (and v) slices inside a pixel row -- 64 with i6 = 32 reads k | v interleaved per
      *      head (one 128-byte line per pixel and head)
      * flags&16 (chain form, instead of flags&4 and of the projection operands): p0 = q f32 [K*Q, 256], already projected and scaled by
-     *      1/sqrt(32) (ATTN_P2Q flags&16 of the previous transformer block produces it); p3, p5..p11 unused */
+     *      1/sqrt(32) (ATTN_P2Q flags&16 of the previous transformer block produces it); p3, p5..p11 unused
+     * ABI 4 (chain form): i9 > 0 = objects per clip (clips in lock step): the foreground mask of object k is decided among the i9 objects
+     *      of its own clip (logit planes (k / i9) * i9 ...), as object_transformer.py:179-205 aggregates over one video's objects */
     CUTIE_OP_ATTN_Q2P = 18,
     /* ATTN_SELF: 16x16 self attention per object  transformer_layers.py:12-41
      * p0=qk f32 [K,Q,ldqk] (q at +0, k at +C) p1=v f32 [K,Q,ldv] p2=y f32 [K,Q,C]

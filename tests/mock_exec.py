@@ -119,8 +119,13 @@ class MockExecutor:
             y = F.conv2d(x.permute(0, 3, 1, 2), w, bias, stride, pad).permute(0, 2, 3, 1)
         assert y.shape[1] == OH and y.shape[2] == OW, (y.shape, OH, OW)
         if p[4]:
-            rb = 1 if flags & O.F_RES_BCAST else B
-            y = y + view(p[4], BF16, (rb, OH, OW, Cout), (OH * OW * ldr, OW * ldr, ldr, 1)).float()
+            if (flags & O.F_RES_BCAST) and f[0] > 0:                    # clips in lock step: one broadcast residual per group of f0 objects, f1 rows apart
+                kg, gs = int(f[0]), int(f[1])
+                r = view(p[4], BF16, (B // kg, OH, OW, Cout), (gs * ldr, OW * ldr, ldr, 1)).float()
+                y = y + r.repeat_interleave(kg, 0)
+            else:
+                rb = 1 if flags & O.F_RES_BCAST else B
+                y = y + view(p[4], BF16, (rb, OH, OW, Cout), (OH * OW * ldr, OW * ldr, ldr, 1)).float()
         y = _act(y, (flags >> O.ACT_SHIFT) & 7)
         out = view(p[5], F32 if flags & O.F_OUT_F32 else BF16, (B, OH, OW, Cout), (OH * OW * ldy, OW * ldy, ldy, 1))
         out.copy_(y)
@@ -161,7 +166,10 @@ class MockExecutor:
     def _op_4(self, flags, i, f, p):
         B, h, w, C = i[:4]
         g = view(p[0], BF16, (B, h, w, C)).float().permute(0, 3, 1, 2)
-        skip = view(p[1], BF16, (1, 2 * h, 2 * w, C)).float()
+        if len(i) > 4 and i[4] > 0:                                     # clips in lock step: one skip map per group of i4 objects, i5 pixels apart
+            skip = view(p[1], BF16, (B // i[4], 2 * h, 2 * w, C), (i[5] * C, 2 * w * C, C, 1)).float().repeat_interleave(i[4], 0)
+        else:
+            skip = view(p[1], BF16, (1, 2 * h, 2 * w, C)).float()
         y = _bilinear(g, 0.5).permute(0, 2, 3, 1) + skip
         view(p[2], BF16, (B, 2 * h, 2 * w, C)).copy_(y)
 
@@ -243,6 +251,16 @@ class MockExecutor:
 
     def _op_11(self, flags, i, f, p):
         P, h, w = i[:3]
+        if len(i) > 4 and i[4] > 1:                                     # clips in lock step: clip by clip with the pointers advanced
+            K, ncell = P - 1, (h // 4) * (w // 4)
+            for c in range(i[4]):
+                pc = list(p)
+                pc[0], pc[1] = p[0] + 4 * c * K * h * w, p[1] + 4 * c * P * 16 * h * w
+                pc[2] = p[2] + 4 * c * P * 16 * h * w if p[2] else 0
+                if flags & 4:
+                    pc[3], pc[4] = p[3] + 4 * c * K * ncell, p[4] + 2 * c * K * ncell * i[3]
+                self._op_11(flags, i[:4] + [1] + i[5:], f, pc)
+            return
         if flags & 1:                                                   # SEG_AGG fused: p0 = raw logits [P-1,h,w]
             pr = torch.sigmoid(view(p[0], F32, (P - 1, h * w)))
             agg = torch.cat([_clamp_logit(torch.prod(1 - pr, dim=0, keepdim=True)), _clamp_logit(pr)], 0).view(P, h, w)
@@ -400,9 +418,10 @@ class MockExecutor:
         k = view(p[1], BF16, (K, HW, heads, hd), (HW * ldkv, ldkv, hs, 1)).float().transpose(1, 2)
         v = view(p[1] + 2 * voff, BF16, (K, HW, heads, hd), (HW * ldkv, ldkv, hs, 1)).float().transpose(1, 2)
         if flags & 1:                                                   # AUX_MASK fused: p2 = logits
-            pr = torch.sigmoid(view(p[2], F32, (K, HW)))
-            lg = torch.cat([_clamp_logit(torch.prod(1 - pr, dim=0, keepdim=True)), _clamp_logit(pr)], 0)
-            fg = lg[1:] >= lg.max(0, keepdim=True)[0]
+            kg = i[9] if (len(i) > 9 and i[9] > 0 and (flags & 8)) else K   # chain form: objects per clip (clips in lock step)
+            pr = torch.sigmoid(view(p[2], F32, (K // kg, kg, HW)))
+            lg = torch.cat([_clamp_logit(torch.prod(1 - pr, dim=1, keepdim=True)), _clamp_logit(pr)], 1)
+            fg = (lg[:, 1:] >= lg.max(1, keepdim=True)[0]).reshape(K, HW)
             nfg = fg.sum(1).to(torch.int32)
         else:
             fg = view(p[2], U8, (K, HW)).bool()

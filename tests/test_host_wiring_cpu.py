@@ -207,6 +207,52 @@ def test_interleaved_clips_match_sequential(product_net):
         assert fc.recall('k', a) == 2
 
 
+def _lockstep_case(net, cfg_kw, C=3, K=2, T=14, hinted=True, size=(48, 80), window=None):
+    """(sequential per-clip probabilities, lock-step probabilities, LockstepCores) for C synthetic clips."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.inference.lockstep import LockstepCores
+    from cutie_amd.utils.synth import SyntheticClip
+    clips = [SyntheticClip(size[0], size[1], K, T, seed=40 + c) for c in range(C)]
+    frames = [[cl.frame(t) for t in range(T)] for cl in clips]
+    seq = []
+    for c, cl in enumerate(clips):
+        proc = InferenceCore(net, cfg=default_config(**cfg_kw))
+        outs = [proc.step(frames[c][0], cl.first_mask(), objects=cl.objects)]
+        for t in range(1, T):
+            outs.append(proc.step(frames[c][t], end=(t == T - 1)))
+        seq.append((torch.stack(outs), {k: (b.n_long, b.n_perm, b.n_work) for k, b in proc.memory.buckets.items()}))
+    ls = LockstepCores(net, default_config(**cfg_kw), C)
+    if window is not None:
+        ls.WINDOW, ls.WINDOW_LEAD = window
+    outs = [ls.step([f[0] for f in frames], [cl.first_mask() for cl in clips], [cl.objects for cl in clips])]
+    for t in range(1, T):
+        hint = dict(next_images=[f[t + 1:t + 10] for f in frames]) if hinted and t + 1 < T else {}
+        outs.append(ls.step([f[t] for f in frames], end=(t == T - 1), **hint))
+    got = [(torch.stack([o[c] for o in outs]), {k: (b.n_long, b.n_perm, b.n_work) for k, b in ls.cores[c].memory.buckets.items()}) for c in range(C)]
+    return seq, got, ls
+
+
+@pytest.mark.parametrize('hinted', [False, True])
+def test_lockstep_clips_match_sequential(product_net, hinted):
+    """inference/lockstep.py: C clips advanced in lock step through ONE plan per stage (batch = C x K objects; the per-clip couplings --
+    "others" masks, foreground masks, soft aggregation, per-clip image features -- grouped inside the launches, ABI 4) give every clip the
+    probabilities and the bank of its own InferenceCore run, bit for bit: FIFO memory and long-term memory with consolidations, with and
+    without look-ahead hints (joint encoder windows of all clips, per-clip stacked read-outs)."""
+    ex = _lib.get_executor()
+    ex.per_sample_conv = True          # (torch's CPU conv may sum differently per batch size; the HIP tiles of one K-order class do not)
+    try:
+        with torch.inference_mode():
+            for cfg_kw, T in ((dict(mem_every=3), 11),
+                              (dict(mem_every=2, use_long_term=True, long_term=dict(S.LT_SMALL)), 24)):
+                seq, got, ls = _lockstep_case(product_net, cfg_kw, T=T, hinted=hinted, window=(4, 1) if hinted else None)
+                assert ls.batched_steps == T - 2, ls.batched_steps       # every frame but the first (masks) and the last (end=True)
+                for c in range(len(seq)):
+                    assert seq[c][1] == got[c][1], (cfg_kw, c, seq[c][1], got[c][1])
+                    assert torch.equal(seq[c][0], got[c][0]), (cfg_kw, hinted, c, float((seq[c][0] - got[c][0]).abs().max()))
+    finally:
+        ex.per_sample_conv = False
+
+
 def test_max_internal_size_path(product_net):
     """The internal-resolution path (inference_core.py:206-228, 321-326): frames larger than max_internal_size are processed
     at the reduced size and the probabilities are resized back; index masks use nearest-exact."""
