@@ -70,8 +70,9 @@ def parse():
                     help='> 0 (one GPU): the clips-in-flight leg runs in a child process started with GPU_MAX_HW_QUEUES set to this (HIP maps '
                          'its streams onto 4 hardware queues by default).  An experiment of round 5 with --multi-mode threads '
                          '(profiles/r05_clips_in_flight.txt: no stable gain); 0 = in this process, default environment')
-    ap.add_argument('--multi-mode', choices=('threads', 'interleaved'), default='interleaved',
-                    help='clips in flight driven by one host thread per clip, or by ONE thread that issues a step of every clip in turn')
+    ap.add_argument('--multi-mode', choices=('threads', 'interleaved', 'lockstep'), default='lockstep',
+                    help='several clips per GPU: in LOCK STEP through one launch plan per stage (cutie_amd/inference/lockstep.py), or in flight on a '
+                         'stream each, driven by ONE thread that issues a step of every clip in turn, or by one host thread per clip')
     ap.add_argument('--multi-only', action='store_true', help='(internal) run the clips-in-flight leg only and print its seconds')
     ap.add_argument('--device-index', type=int, default=None, help='(internal) GPU of a --multi-only child')
     return ap.parse_args()
@@ -112,6 +113,17 @@ def multi_clip_throughput(net, cfg, args, K, rank, dist, dev):
     views = [net] + [net.fork() for _ in range(C - 1)]
     for v in views:
         v.engine().one_lane = True                          # one stream per clip, as cutie_amd/parallel.py:run_concurrent runs them
+    try:
+        return _multi_clip_threads(net, cfg, args, K, rank, dist, dev, views, data, steps)
+    finally:
+        for v in views:                                     # (every view, also when a worker or a barrier failed)
+            v.engine().one_lane = False
+
+
+def _multi_clip_threads(net, cfg, args, K, rank, dist, dev, views, data, steps):
+    import threading
+    from cutie_amd.inference.inference_core import InferenceCore
+    C, NF = args.clips_in_flight, 48
     ready, start, done = threading.Barrier(C + 1), threading.Barrier(C + 1), threading.Barrier(C + 1)
     finish, errors = [0.0] * C, []
 
@@ -172,7 +184,6 @@ def multi_clip_throughput(net, cfg, args, K, rank, dist, dev):
         give_up()
     for t in threads:
         t.join()
-    net.engine().one_lane = False
     if errors:
         raise errors[0]
     return max(finish) - t0
@@ -218,7 +229,79 @@ def multi_clip_interleaved(net, cfg, args, K, rank, dist, dev):
             torch.cuda.synchronize()
             return time.perf_counter() - t0
     finally:
-        net.engine().one_lane = False
+        for v in views:
+            v.engine().one_lane = False
+
+
+def multi_clip_lockstep(net, cfg, args, K, rank, dist, dev, rec=None):
+    """Same workload, C clips advanced in LOCK STEP (cutie_amd/inference/lockstep.py): one launch plan per stage for the C x K objects of
+    all clips, one joint encoder window, one memory bank and one look-ahead read-out lane per clip.  Returns (seconds for
+    multi_clip_steps(args) frames of every clip, roofline object of the conv launches of the lock-step frames or None)."""
+    from cutie_amd import ops as O
+    from cutie_amd.inference.lockstep import LockstepCores
+    from cutie_amd.utils.synth import SyntheticClip
+    C, NF = args.clips_in_flight, 48
+    steps = multi_clip_steps(args)
+    with torch.inference_mode():
+        clips = [SyntheticClip(args.height, args.width, K, NF, seed=101 + 16 * rank + c) for c in range(C)]
+        frames = [torch.stack([cl.frame(t) for t in range(NF)]).to(dev) for cl in clips]
+        views = []
+        for fr in frames:
+            v = [fr[i] for i in range(NF)]
+            views.append(v + v[:32])
+        depth = 0 if args.no_lookahead else 16
+        hint = (lambda t: {}) if depth == 0 else (lambda t: {'next_images': [v[(t + 1) % NF:(t + 1) % NF + depth] for v in views]})
+        ls = LockstepCores(net, cfg, C)
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            ls.step([v[0] for v in views], [cl.first_mask().to(dev) for cl in clips], [cl.objects for cl in clips])
+            for t in range(1, 1 + args.preroll + args.warmup):
+                ls.step([v[t % NF] for v in views], **hint(t))
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            t0 = time.perf_counter()
+            base = 1 + args.preroll + args.warmup
+            for t in range(base, base + steps):
+                ls.step([v[t % NF] for v in views], **hint(t))
+            issue = time.perf_counter() - t0                # (the host has issued every launch; the device may still be running)
+            torch.cuda.synchronize()
+            secs = time.perf_counter() - t0
+            assert ls.batched_steps == args.preroll + args.warmup + steps, 'every propagated frame of the leg must run as one plan per stage'
+            roof = None
+            if rec is not None and not args.no_roofline:
+                # the conv launches of whole encoder batches / memory cycles of lock-step frames, replayed back to back (hipEvents)
+                nrec = 30
+                rec.rec, rec.on = [], True
+                for t in range(base + steps, base + steps + nrec):
+                    ls.step([v[t % NF] for v in views], **hint(t))
+                rec.on = False
+                torch.cuda.synchronize()
+                allops = np.concatenate(rec.rec)
+                convs = allops[allops['kind'] == O.CONV]
+                conv_t = rec.ex.time_ops(convs, 3) * 1e-3
+                enc = [a for a in rec.rec if (a['kind'] == O.STEM).any() and (a['kind'] == O.KEY_PREP).any()]      # the joint encoder windows
+                enc_convs = np.concatenate([a[a['kind'] == O.CONV] for a in enc]) if enc else convs[:0]
+                enc_t = rec.ex.time_ops(enc_convs, 3) * 1e-3 if len(enc_convs) else 0.0
+                others = allops[(allops['kind'] != O.CONV)]
+                oth_t = rec.ex.time_ops(others, 3) * 1e-3
+                px = (-(-args.height // 16) * 16) * (-(-args.width // 16) * 16) / 414720.0
+                alg_f = (60.2 + 56.1 * K + 44.7 * K / cfg.mem_every) * px * 1e9 * C      # SURVEY 8(d), per lock-step frame = C clip frames
+                roof = {'bound': 'mfma', 'kernel': 'all conv launches of a lock-step frame (C clips: batch = C x K objects, joint encoder window)',
+                        'achieved': round(alg_f / (conv_t / nrec) / 1e12, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(alg_f / (conv_t / nrec) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                        'executed_frac': round(conv_flops(convs) / conv_t / 1e12 / PEAK_BF16_TFLOPS, 4),
+                        'ms_per_lockstep_frame': round(conv_t / nrec * 1e3, 3), 'ms_per_clip_frame': round(conv_t / nrec / C * 1e3, 3),
+                        'launches_per_lockstep_frame': round(len(convs) / nrec, 1), 'launches_per_clip_frame': round(len(convs) / nrec / C, 1),
+                        'all_launches_per_clip_frame': round(len(allops) / nrec / C, 1), 'recorded_lockstep_frames': nrec, 'traffic': None,
+                        'encoder_convs_ms_per_lockstep_frame': round(enc_t / nrec * 1e3, 3), 'encoder_conv_launches_per_lockstep_frame': round(len(enc_convs) / nrec, 1),
+                        'other_kernels_ms_per_lockstep_frame': round(oth_t / nrec * 1e3, 3),
+                        'host_issue_ms_per_lockstep_frame': round(issue / steps * 1e3, 3), 'wall_ms_per_lockstep_frame': round(secs / steps * 1e3, 3)}
+    return secs, roof
+
+
+def multi_leg(args):
+    return {'lockstep': multi_clip_lockstep, 'interleaved': multi_clip_interleaved, 'threads': multi_clip_throughput}[args.multi_mode]
 
 
 def multi_clip_steps(args):
@@ -333,7 +416,8 @@ def main():
     sd = make_state_dict(seed=0)
     net.load_weights(sd)
     if args.multi_only:                                    # (the child of multi_clip_child: this leg and nothing else)
-        secs = (multi_clip_interleaved if args.multi_mode == 'interleaved' else multi_clip_throughput)(net, cfg, args, K, rank, None, dev)
+        secs = multi_leg(args)(net, cfg, args, K, rank, None, dev)
+        secs = secs[0] if isinstance(secs, tuple) else secs
         print(json.dumps({'seconds': secs, 'steps_per_clip': multi_clip_steps(args), 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES')}))
         return
     rec = Recorder(_lib.get_executor())
@@ -572,9 +656,15 @@ def main():
     if args.clips_in_flight > 1:
         # an extra leg: a failure here is reported in the line, it must not take the headline measurement with it
         in_child = world == 1 and args.multi_hw_queues > 0
+        multi_roof = None
         try:
-            leg, leg_err = (multi_clip_child(args, local) if in_child else
-                            (multi_clip_interleaved if args.multi_mode == 'interleaved' else multi_clip_throughput)(net, cfg, args, K, rank, dist, dev)), None
+            if in_child:
+                leg = multi_clip_child(args, local)
+            elif args.multi_mode == 'lockstep':
+                leg, multi_roof = multi_clip_lockstep(net, cfg, args, K, rank, dist, dev, rec if rank == 0 else None)
+            else:
+                leg = multi_leg(args)(net, cfg, args, K, rank, dist, dev)
+            leg_err = None
         except Exception as e:
             import traceback
             traceback.print_exc()
@@ -590,11 +680,17 @@ def main():
             multi = {'clips_in_flight_per_gpu': args.clips_in_flight, 'value': round(world * args.clips_in_flight * msteps / mt, 2),
                      'unit': 'frames/s', 'steps_per_clip': msteps, 'ms_per_step': round(mt / msteps * 1e3, 4),
                      'hw_queues': (args.multi_hw_queues if in_child else os.environ.get('GPU_MAX_HW_QUEUES', 'default (4)')),
-                     'host': ('one thread issues a step of every clip in turn (cutie_amd/parallel.py:run_interleaved)' if args.multi_mode == 'interleaved'
-                              else 'one host thread per clip (cutie_amd/parallel.py:run_concurrent)'),
-                     'note': 'same workload, independent clips in flight on one GPU (ONE HIP stream + CUTIE.fork() per clip' + ('; measured in a child process started with GPU_MAX_HW_QUEUES=%d: '
-                             'HIP maps streams onto 4 hardware queues by default and clips that share one serialise' % args.multi_hw_queues if in_child else '')
-                             + '); "value" above stays one clip per GPU, default environment'}
+                     'mode': args.multi_mode,
+                     'host': {'lockstep': 'ONE launch plan per stage for the C x K objects of all clips (cutie_amd/inference/lockstep.py: joint encoder window, one bank + one '
+                                          'look-ahead read-out lane per clip); per clip bit-identical to its own InferenceCore run',
+                              'interleaved': 'one thread issues a step of every clip in turn (cutie_amd/parallel.py:run_interleaved)',
+                              'threads': 'one host thread per clip (cutie_amd/parallel.py:run_concurrent)'}[args.multi_mode],
+                     'note': ('same workload, C independent clips per GPU advanced in lock step' if args.multi_mode == 'lockstep' else
+                              'same workload, independent clips in flight on one GPU (ONE HIP stream + CUTIE.fork() per clip' + ('; measured in a child process started with GPU_MAX_HW_QUEUES=%d: '
+                              'HIP maps streams onto 4 hardware queues by default and clips that share one serialise' % args.multi_hw_queues if in_child else '') + ')')
+                             + '; "value" above stays one clip per GPU, default environment'}
+            if multi_roof is not None:
+                multi['roofline'] = multi_roof
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:

@@ -74,8 +74,8 @@ __device__ __forceinline__ void up_coord(int o, int n_in, float scale, int& i0, 
 
 // Kg > 0 (clips in lock step): the objects come in groups of Kg, group q adds the skip map at skip + q * gstride pixels (Kg = 0: one map for all)
 __global__ void upsample2x_add_kernel(const uint4* __restrict__ g, const uint4* __restrict__ skip, uint4* __restrict__ y,
-                                      int B, int h, int w, int C8, int Kg, long gstride) {
-    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
+                                      int B, int h, int w, int C8, int Kg, long gstride, int prio) {
+    if (prio) __builtin_amdgcn_s_setprio(1);               // CUTIE_F_PRIO: a launch of the frame's critical path (the plan decides, ops.OpList.prio)
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     int OH = 2 * h, OW = 2 * w;
     long total = (long)B * OH * OW * C8;
@@ -189,9 +189,10 @@ __global__ void area_down_f32_kernel(const float* __restrict__ x, bf16_t* __rest
 }
 // AREA_DOWN3: three area poolings in one launch (the g8 / g4 / logits inputs of the sensory update): thread ranges [0, n0), [n0, n0+n1), ...
 struct AreaSeg { const void* x; bf16_t* y; int B, H, W, C, ldx, ldy, r, Cz, f32; long n; };
-struct Area3 { AreaSeg s[3]; int rt; };
+struct Area3 { AreaSeg s[3]; int rt; int prio; };
 __global__ void area_down3_kernel(Area3 a) {
-    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
+    const int prio = a.prio;
+    if (prio) __builtin_amdgcn_s_setprio(1);               // CUTIE_F_PRIO: a launch of the frame's critical path (the plan decides, ops.OpList.prio)
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -321,8 +322,8 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const bf16_t* __restrict
                                                         const float* __restrict__ wk, const bf16_t* __restrict__ r,
                                                         bf16_t* __restrict__ y, float* __restrict__ gap_out, int HW, int C, int nchunk,
                                                         const long long* __restrict__ fixed, const bf16_t* __restrict__ pw,
-                                                        const float* __restrict__ pb, float* __restrict__ plog) {
-    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
+                                                        const float* __restrict__ pb, float* __restrict__ plog, int prio) {
+    if (prio) __builtin_amdgcn_s_setprio(1);               // CUTIE_F_PRIO: a launch of the frame's critical path (the plan decides, ops.OpList.prio)
     __shared__ float gap[256 + 4], sc[256];
     const int b = blockIdx.y, tid = threadIdx.x;
     const float inv = 1.f / (float)HW;
@@ -424,8 +425,8 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const bf16_t* __restrict
 // ---------------------------------------------------------------------------------------------
 // four channels per thread: 16-byte loads of the three gate rows and of h, a 16-byte store of h and an 8-byte store of its bf16 shadow
 // (one channel per thread wrote the shadow in 2-byte pieces); the same expression per element as gru_kernel
-__global__ void gru4_kernel(const float* __restrict__ v, float* __restrict__ h, bf16_t* __restrict__ hb, long n, int C) {
-    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
+__global__ void gru4_kernel(const float* __restrict__ v, float* __restrict__ h, bf16_t* __restrict__ hb, long n, int C, int prio) {
+    if (prio) __builtin_amdgcn_s_setprio(1);               // CUTIE_F_PRIO: a launch of the frame's critical path (the plan decides, ops.OpList.prio)
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;             // (row, channel quad)
     const int C4 = C >> 2;
     if (idx >= n * C4) return;
@@ -657,8 +658,8 @@ __device__ __forceinline__ void up4_four(const float* __restrict__ lg, int Krt, 
 
 template <int PMAX, int KC = 0>
 __global__ __launch_bounds__(256) void up4_softmax_fused4_kernel(const float* __restrict__ lg, float* __restrict__ prob, float* __restrict__ lup,
-                                                                 int Krt, int h, int w) {
-    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
+                                                                 int Krt, int h, int w, int prio) {
+    if (prio) __builtin_amdgcn_s_setprio(1);               // CUTIE_F_PRIO: a launch of the frame's critical path (the plan decides, ops.OpList.prio)
     const int K = KC > 0 ? KC : Krt;
     const int OH = 4 * h, OW = 4 * w;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;             // (oy, j): output pixels (oy, 4j .. 4j + 3)
@@ -689,8 +690,8 @@ __global__ __launch_bounds__(256) void up4_softmax_fused4_kernel(const float* __
 // MASK_DOWN launch it replaces.  4 waves (cells) per block; needs H, W multiples of 16 and K + 1 <= PMAX.
 template <int PMAX, int KC = 0, bool SH = false>
 __global__ __launch_bounds__(256) void up4_softmax_md_kernel(const float* __restrict__ lg, float* __restrict__ prob, float* __restrict__ lup,
-                                                             int Krt, int h, int w, float* __restrict__ m16, uint4* __restrict__ pair, int ld8) {
-    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
+                                                             int Krt, int h, int w, float* __restrict__ m16, uint4* __restrict__ pair, int ld8, int prio) {
+    if (prio) __builtin_amdgcn_s_setprio(1);               // CUTIE_F_PRIO: a launch of the frame's critical path (the plan decides, ops.OpList.prio)
     const int K = KC > 0 ? KC : Krt;
     __shared__ float cell[4][PMAX - 1][256];
     __shared__ float srcL[4][SH ? PMAX : 1][36];
@@ -1192,6 +1193,7 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     const uint64_t* p = op->p;
     const int BS = 256;
+    const int PRIO = (op->flags & CUTIE_F_PRIO) ? 1 : 0;     // the launch belongs to the frame's critical path (kernels that honour it: see include/cutie_hip.h)
     switch (op->kind) {
         case CUTIE_OP_MAXPOOL: {
             int C8 = i[3] / 8;
@@ -1210,7 +1212,7 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             int C8 = i[3] / 8;
             long n = (long)i[0] * 4 * i[1] * i[2] * C8;
             if (i[4] < 0 || (i[4] > 0 && (i[0] % i[4] || i[5] < 4 * i[1] * i[2]))) { cutie_set_error("upsample2x_add: skip groups of %d objects do not divide B = %d (or their stride is below one map)", i[4], i[0]); return -2; }
-            hipLaunchKernelGGL(upsample2x_add_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const uint4*)p[0], (const uint4*)p[1], (uint4*)p[2], i[0], i[1], i[2], C8, i[4], (long)i[5]);
+            hipLaunchKernelGGL(upsample2x_add_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const uint4*)p[0], (const uint4*)p[1], (uint4*)p[2], i[0], i[1], i[2], C8, i[4], (long)i[5], PRIO);
             break;
         }
         case CUTIE_OP_AREA_DOWN: {
@@ -1237,6 +1239,7 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
                 total += g.n;
             }
             a.rt = (op->flags >> 3) & 1;
+            a.prio = PRIO;
             hipLaunchKernelGGL(area_down3_kernel, GRID1D(total, BS), dim3(BS), 0, s, a);
             break;
         }
@@ -1264,13 +1267,13 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             int nchunk = (i[1] + 63) / 64;
             hipLaunchKernelGGL(eca_apply_kernel, dim3((i[1] + 31) / 32, i[0]), dim3(256), 0, s, (const bf16_t*)p[0], (const float*)p[5], (const float*)p[2],
                                (const bf16_t*)p[3], (bf16_t*)p[4], (float*)p[1], i[1], i[2], nchunk, (op->flags & 1) ? (const long long*)p[5] : nullptr,
-                               (const bf16_t*)p[6], (const float*)p[7], (float*)p[8]);
+                               (const bf16_t*)p[6], (const float*)p[7], (float*)p[8], PRIO);
             break;
         }
         case CUTIE_OP_GRU: {
             long n = (long)i[0] * i[1];
             if (!(op->flags & 1) && (i[1] & 3) == 0 && (((uintptr_t)p[0] | (uintptr_t)p[1]) & 15) == 0 && ((uintptr_t)p[2] & 7) == 0)      // flags&1: one channel per thread (A/B switch)
-                hipLaunchKernelGGL(gru4_kernel, GRID1D(n / 4, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (bf16_t*)p[2], (long)i[0], i[1]);
+                hipLaunchKernelGGL(gru4_kernel, GRID1D(n / 4, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (bf16_t*)p[2], (long)i[0], i[1], PRIO);
             else
                 hipLaunchKernelGGL(gru_kernel, GRID1D(n, BS), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (bf16_t*)p[2], (long)i[0], i[1]);
             break;
@@ -1289,7 +1292,7 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
                     if (!vec || !p[3] || !p[4] || (i[1] & 3) || (i[2] & 3) || i[3] < 8 || (i[3] & 7)) { cutie_set_error("up4_softmax: the mask-down form needs P <= 8, h, w multiples of 4, m16 and pair"); return -2; }
                     const int ncell = (i[1] / 4) * (i[2] / 4);
 #define UP4_MD_(KC, SH) hipLaunchKernelGGL((up4_softmax_md_kernel<8, KC, SH>), dim3((ncell + 3) / 4, nclip), dim3(256), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, \
-                                       i[1], i[2], (float*)p[3], (uint4*)p[4], i[3] / 8)
+                                       i[1], i[2], (float*)p[3], (uint4*)p[4], i[3] / 8, PRIO)
 #define UP4_MD(KC) { if (op->flags & 16) UP4_MD_(KC, false); else UP4_MD_(KC, true); }      /* flags&16: every lane aggregates its own source pixels (A/B switch) */
                     switch ((op->flags & 8) ? 0 : i[0] - 1) {          // object count as a compile-time constant (see up4_four); flags&8: run-time K
                         case 1: UP4_MD(1); break; case 2: UP4_MD(2); break; case 3: UP4_MD(3); break; case 4: UP4_MD(4); break;
@@ -1301,7 +1304,7 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
                 }
                 if (vec) {
                     const long n4 = (long)4 * i[1] * i[2];
-#define UP4_F4(KC) hipLaunchKernelGGL((up4_softmax_fused4_kernel<8, KC>), dim3((unsigned)((n4 + BS - 1) / BS), nclip), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, i[1], i[2])
+#define UP4_F4(KC) hipLaunchKernelGGL((up4_softmax_fused4_kernel<8, KC>), dim3((unsigned)((n4 + BS - 1) / BS), nclip), dim3(BS), 0, s, (const float*)p[0], (float*)p[1], (float*)p[2], i[0] - 1, i[1], i[2], PRIO)
                     switch ((op->flags & 8) ? 0 : i[0] - 1) {
                         case 1: UP4_F4(1); break; case 2: UP4_F4(2); break; case 3: UP4_F4(3); break; case 4: UP4_F4(4); break;
                         case 5: UP4_F4(5); break; case 6: UP4_F4(6); break; case 7: UP4_F4(7); break; default: UP4_F4(0); break;

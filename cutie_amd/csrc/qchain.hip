@@ -32,6 +32,7 @@ struct QIn {
     float* x_out;                                        // x_eff, written once per object (null: not kept)
     const bf16_t* W; const float* bias;                  // the packed projection of this launch [N][256] bf16, bias [N]
     unsigned long long* tl;                              // diagnostic builds: stamp buffer (tools/attn_timeline.py)
+    int prio;                                            // CUTIE_F_PRIO: the launch belongs to the frame's critical path -- s_setprio 1
 };
 struct QOut { const bf16_t* W; long long* acc; };        // output projection Wo [256][256] bf16; acc [K*16, 256] fixed point
 
@@ -180,7 +181,7 @@ __device__ __forceinline__ bool aux_fg_late(const float* __restrict__ lg, int K,
 template <bool QPRE, bool ACC, int KT, int NW>
 __global__ __launch_bounds__(NW * 64) void q2p_chain_kernel(QIn in, QOut out, const bf16_t* __restrict__ kv, const float* __restrict__ lg,
                                                            int HW, int HWp, int ldkv, int voff, int hstride, const float* __restrict__ qpre, int Kg) {
-    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
+    if (in.prio) __builtin_amdgcn_s_setprio(1);            // CUTIE_F_PRIO: a launch of the frame's critical path (the plan decides, ops.OpList.prio)
     constexpr int Q = 16, NT = NW * 64;
     constexpr bool EARLY = KT > 0;
     constexpr int PPT = 2048 / NT;                         // pixels per thread with logits fetched at entry
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(NW * 64) void q2p_chain_kernel(QIn in, QOut out, co
 // instructions: cheaper than handing one wave's result around) and projects it onto ITS two 16-column tiles of Wo.
 // =====================================================================================================================================
 __global__ __launch_bounds__(512) void self_chain_kernel(QIn in, QOut out) {
-    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
+    if (in.prio) __builtin_amdgcn_s_setprio(1);            // CUTIE_F_PRIO: a launch of the frame's critical path (the plan decides, ops.OpList.prio)
     __shared__ float sX[2][16 * PROJ_XLD];                 // [LN(x)+emb | LN(x)]
     __shared__ f32x4 sRed[4][6][64];
     __shared__ float sP[3][16][33];                        // q (scaled) | k | v of this head
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(512) void self_chain_kernel(QIn in, QOut out) {
 struct QFfn { const bf16_t* W1; const float* b1; const bf16_t* W2; long long* acc; int FF; };
 template <int HS>
 __global__ __launch_bounds__(256) void qffn_kernel(QIn in, QFfn a) {
-    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
+    if (in.prio) __builtin_amdgcn_s_setprio(1);            // CUTIE_F_PRIO: a launch of the frame's critical path (the plan decides, ops.OpList.prio)
     constexpr int T1 = HS / 64;                            // hidden 16-column tiles per wave
     constexpr int KS2 = HS / 32;                           // k steps of the second product
     constexpr int HLD = HS + 4;
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(256) void qffn_kernel(QIn in, QFfn a) {
 // emb) Wq^T + b) / sqrt(32), xn_out = LN(x_eff) (the residual of that attention).  24 blocks next to 168: free.
 struct NextQ { const float* ln_g; const float* ln_b; const bf16_t* W; const float* bias; float* q_out; float* xn_out; };
 __global__ __launch_bounds__(256) void p2q_chain_kernel(QIn in, const bf16_t* __restrict__ q, bf16_t* __restrict__ y, int HW, int ldq, NextQ nq) {
-    __builtin_amdgcn_s_setprio(1);                         // a launch of the frame's critical path (only ever on the caller's / auxiliary stream)
+    if (in.prio) __builtin_amdgcn_s_setprio(1);            // CUTIE_F_PRIO: a launch of the frame's critical path (the plan decides, ops.OpList.prio)
     constexpr int C = 256;
     __shared__ float sX[2][16 * PROJ_XLD];
     __shared__ float ks[16][36], vs[16][36];
@@ -827,6 +828,7 @@ static bool qin_from_op(const cutie_op* op, QIn& in, QOut& out, const char* who,
     const uint64_t* p = op->p;
     in = QIn{};
     out = QOut{};
+    in.prio = (op->flags & CUTIE_F_PRIO) ? 1 : 0;
     in.x = (const float*)p[xslot];
     in.ln_out = lnout_slot >= 0 ? (float*)p[lnout_slot] : nullptr;
     in.W = (const bf16_t*)p[5]; in.bias = (const float*)p[6]; in.add = (const float*)p[7];
@@ -940,6 +942,7 @@ int launch_qchain(const cutie_op* op, hipStream_t s) {
                 return -2;
             }
             in = QIn{};
+            in.prio = (op->flags & CUTIE_F_PRIO) ? 1 : 0;
             in.x = (const float*)p[0]; in.x_out = (float*)p[1]; in.ln_g = (const float*)p[2]; in.ln_b = (const float*)p[3];
             if (!p[10] || !p[11] || !p[5]) { cutie_set_error("qffn: the input accumulator, its bias and linear1's bias are required"); return -2; }
             in.acc = (const long long*)p[10]; in.abias = (const float*)p[11];

@@ -25,6 +25,7 @@ same frame / memory schedule and geometry, no mask, no ``end``); anything else -
 runs clip by clip through the cores' own ``step``.
 """
 import contextlib
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -40,13 +41,16 @@ BF16, F32 = torch.bfloat16, torch.float32
 
 class LockstepCores:
     # frames of every clip per batched encoder plan (C x WINDOW frames per plan) / encoded frames left ahead when the next batch starts
-    WINDOW = 6
-    WINDOW_LEAD = 2
+    # (defaults set per group size in __init__: clips x WINDOW ~ 12 frames per plan, the batch the conv tile table was swept for)
+    WINDOW = int(os.environ.get('CUTIE_AMD_LS_WINDOW', '0'))
+    WINDOW_LEAD = int(os.environ.get('CUTIE_AMD_LS_LEAD', '1'))
 
     def __init__(self, network, cfg, clips: int):
         self.network = network
         self.cfg = cfg
         self.cores = [InferenceCore(network, cfg) for _ in range(clips)]
+        if self.WINDOW <= 0:
+            self.WINDOW = max(1, round(12 / clips))
         for c, core in enumerate(self.cores):
             core.memory._clip_tag = c
         self._ctx = [frame_context.new_context() for _ in range(clips)]

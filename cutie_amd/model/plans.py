@@ -75,7 +75,7 @@ SEG_MD = os.environ.get('CUTIE_AMD_SEG_MD', '1') not in ('', '0')
 # read_from_query's output projection + residual inside the ATTN_P2Q launch (csrc/qchain.hip: p2q_out_kernel).  Bit-identical and OFF: the
 # fused launch needs every head of a pixel in one workgroup, i.e. all of Wkv + Wo (384 KB) through ONE compute unit -- 21.6 us against
 # 7.0 + 4.8 us + a boundary for the two launches (frame: -1.8 %; profiles/r04_frame_chain.md section 6)
-P2Q_OUT = os.environ.get('CUTIE_AMD_P2Q_OUT', '0') not in ('', '0')
+P2Q_OUT = os.environ.get('CUTIE_AMD_P2Q_OUT', '0') not in ('', '0')       # (honoured only by the diagnostic library, see build_readout_query)
 QINIT_SKIP = os.environ.get('CUTIE_AMD_QINIT_SKIP', '1') not in ('', '0')   # query initialisation only when the object summaries changed (A/B switch)
 ONE_LANE = os.environ.get('CUTIE_AMD_ONE_LANE', '0') not in ('', '0')   # every look-ahead lane of a clip on the caller's own stream (several clips in flight: see cutie_amd/parallel.py)
 ECA_HEAD = os.environ.get('CUTIE_AMD_ECA_HEAD', '1') not in ('', '0')   # mask_pred of a transformer block inside the ECA launch (A/B switch)
@@ -83,6 +83,19 @@ QNEXT = os.environ.get('CUTIE_AMD_QNEXT', '1') not in ('', '0')       # ATTN_P2Q
 AUTOTUNE = os.environ.get('CUTIE_AMD_AUTOTUNE', '0') not in ('', '0')
 TOUCH_REWIRE = os.environ.get('CUTIE_AMD_WPF_REWIRE', '1') not in ('', '0')       # A/B switch: next-weights ranges recomputed after the tile table
 PACKAGED_TILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tiles_gfx950.json')
+
+
+_p2q_warned = []
+
+
+def _p2q_out_available():
+    ex = _lib.get_executor()
+    ok = ex.is_mock or _lib.has_diag_kernels()
+    if not ok and not _p2q_warned:
+        _p2q_warned.append(1)
+        import warnings
+        warnings.warn('CUTIE_AMD_P2Q_OUT=1 needs the diagnostic kernel library (make -C cutie_amd/csrc DIAG=1); ignored')
+    return ok
 
 
 def load_tile_cache():
@@ -261,7 +274,7 @@ class Plan:
         self.eng = eng
         self.prio = prio                 # its convs belong to the frame's critical path (ops.F_PRIO); the look-ahead encoder plans: False
         self.dev = eng.device
-        self.ol = O.OpList(scratch_owner=eng, touch_next_weights=touch)
+        self.ol = O.OpList(scratch_owner=eng, touch_next_weights=touch, prio=prio)
         self.bufs = {}
         self.meta = {}
         self.tuned = False
@@ -402,6 +415,8 @@ class Plan:
                 ref = cache.get(key1) or (O.COUT1_TILE if (int(i[17]) == O.COUT1_TILE) else
                                           O.pick_tile(M // Bk, cout, cin, dict(kh=int(i[11]), c2=int(i[4]))), 1)
                 want = O.korder_class(*ref)
+                if isinstance(want, str) and cache.get(key + (want,)) is not None:
+                    best = cache[key + (want,)]              # a table entry FOR this class (two layers of one batched geometry may need different classes)
                 if best is None or O.korder_class(*best) != want:
                     best = (int(i[17]), 1) if O.korder_class(int(i[17]), int(i[19])) == want else tuple(ref)
                 assert O.korder_class(*best) == want, (key, best, ref)
@@ -751,7 +766,9 @@ def build_readout_query(eng, K, h, w, last_aux=True, fresh=True, clips=1):
                               q_out=q_pre, xn_out=xn_next)
             else:
                 q_pre = None
-            fuse_out = P2Q_OUT and pixel.ld == C and pixel.B == K          # pixel + out_proj(attention) by the same launch: no 1x1 conv behind it
+            # pixel + out_proj(attention) by the same launch: no 1x1 conv behind it.  The kernel exists in the diagnostic library only (make DIAG=1):
+            # with the product library the switch is ignored, with a warning (it used to fail at launch time in the middle of a frame)
+            fuse_out = P2Q_OUT and pixel.ld == C and pixel.B == K and _p2q_out_available()
             pf = Act(P.buf(n + 'pf', (K, h, w, C)), K, h, w, C) if fuse_out else None
             pa = None if fuse_out else P.buf(n + 'pa', (K, h, w, C))
             ol.attn_p2q(kvq.t.view(-1)[2 * C:], None, None, pf.t if fuse_out else pa, K=K, Q=Q, HW=HW, C=C, heads=heads, ldq=3 * C,

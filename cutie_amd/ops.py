@@ -256,7 +256,11 @@ def _ptr(t):
 
 
 class OpList:
-    def __init__(self, scratch_owner=None, touch_next_weights=True):
+    # kinds whose kernels raise their waves' issue priority under F_PRIO (include/cutie_hip.h); CONV and the affinity ops carry a `prio` argument
+    PRIO_KINDS = frozenset((UPSAMPLE2X_ADD, AREA_DOWN3, ECA_APPLY, GRU, UP4_SOFTMAX, ATTN_Q2P, ATTN_SELF, ATTN_P2Q, QFFN))
+
+    def __init__(self, scratch_owner=None, touch_next_weights=True, prio=True):
+        self.prio = prio                     # the launches of this list belong to the frame's critical path (plans.Plan.prio; $CUTIE_AMD_PRIO=0: nobody's do)
         self.scratch_owner = scratch_owner   # see splitk_scratch
         self.touch_next_weights = touch_next_weights   # see finalize (plans switch it off where weights stay warm between two uses)
         self.recs = []          # (kind, flags, ints, floats, ptrs)
@@ -269,6 +273,8 @@ class OpList:
     # ---- generic ------------------------------------------------------------------
     def add(self, kind, flags=0, ints=(), floats=(), ptrs=()):
         idx = len(self.recs)
+        if kind in self.PRIO_KINDS and self.prio and PRIO:
+            flags |= F_PRIO
         pl = []
         for slot, t in enumerate(ptrs):
             if isinstance(t, Dyn):

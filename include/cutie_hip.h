@@ -44,7 +44,9 @@ typedef struct cutie_op {
 #define CUTIE_F_TILE_OFF  128 /* A/B switch: Cout == 1, Cin == 128 on large maps without the LDS-tiled kernel (conv_cout1_tile_kernel) */
 #define CUTIE_F_PRIO      256 /* the launch belongs to the frame's critical path (the caller's stream): its waves raise their issue priority
                                * (s_setprio 1), so that look-ahead work sharing the compute units (window encoder, stacked read-outs) fills
-                               * the gaps instead of taking every other issue slot.  CONV; AFF_SCORE / AFF_SELECT / AFF_READOUT use flags&64 */
+                               * the gaps instead of taking every other issue slot.  CONV, and since ABI 4 UPSAMPLE2X_ADD, AREA_DOWN3, ECA_APPLY,
+                               * GRU (four-channel form), UP4_SOFTMAX (four-pixel forms) and the chain forms of ATTN_Q2P / ATTN_SELF / ATTN_P2Q / QFFN
+                               * (ABI 3 raised it unconditionally there); AFF_SCORE / AFF_SELECT / AFF_READOUT use flags&64 */
 #define CUTIE_ACT_SHIFT   4   /* activation code in bits 4..6 */
 #define CUTIE_ACT_NONE    0
 #define CUTIE_ACT_RELU    1

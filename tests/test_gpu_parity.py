@@ -841,6 +841,46 @@ def test_interleaved_clips_match_sequential(gpu_net):
         assert torch.equal(got[c], seq[c]), (c, float((got[c] - seq[c]).abs().max()))
 
 
+@pytest.mark.parametrize('size,K,C,T,cfg_kw', [
+    ((240, 432), 3, 4, 14, dict(mem_every=3)),
+    ((480, 854), 3, 4, 27, dict(use_long_term=True, long_term=dict(count_usage=True, max_mem_frames=4, min_mem_frames=2, num_prototypes=128,
+                                                                  max_num_tokens=600, buffer_tokens=200))),
+    ((480, 854), 1, 3, 12, dict(mem_every=5)),
+    ((200, 300), 2, 2, 13, dict(mem_every=2, use_long_term=True, long_term=dict(S.LT_SMALL))),
+])
+@pytest.mark.parametrize('hinted', [True, False])
+def test_lockstep_clips_match_sequential(gpu_net, size, K, C, T, cfg_kw, hinted):
+    """inference/lockstep.py: C clips in lock step through ONE plan per stage (batch = C x K objects, conv tiles of the one-clip plans'
+    K-order classes, per-clip couplings grouped inside the launches: ABI 4) -- every clip gets the probabilities and the bank of its own
+    InferenceCore run, bit for bit.  480p / 3 objects / long-term memory with consolidations and a pruning is the bench's multi_clip leg."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.inference.lockstep import LockstepCores
+    from cutie_amd.utils.synth import SyntheticClip
+    clips = [SyntheticClip(size[0], size[1], K, T, seed=60 + c) for c in range(C)]
+    frames = [[cl.frame(t).cuda() for t in range(T)] for cl in clips]
+    sizes = lambda mm: {k: (b.n_long, b.n_perm, b.n_work) for k, b in mm.buckets.items()}
+    with torch.inference_mode():
+        seq = []
+        for c, cl in enumerate(clips):
+            proc = InferenceCore(gpu_net, cfg=default_config(**cfg_kw))
+            outs = [proc.step(frames[c][0], cl.first_mask().cuda(), objects=cl.objects)]
+            for t in range(1, T):
+                outs.append(proc.step(frames[c][t], end=(t == T - 1)))
+            seq.append((torch.stack(outs).cpu(), sizes(proc.memory)))
+        ls = LockstepCores(gpu_net, default_config(**cfg_kw), C)
+        outs = [ls.step([f[0] for f in frames], [cl.first_mask().cuda() for cl in clips], [cl.objects for cl in clips])]
+        for t in range(1, T):
+            hint = dict(next_images=[f[t + 1:t + 12] for f in frames]) if hinted and t + 1 < T else {}
+            outs.append(ls.step([f[t] for f in frames], end=(t == T - 1), **hint))
+        torch.cuda.synchronize()
+    assert ls.batched_steps == T - 2
+    for c in range(C):
+        got = torch.stack([o[c] for o in outs]).cpu()
+        assert torch.isfinite(got).all()
+        assert sizes(ls.cores[c].memory) == seq[c][1], (c, sizes(ls.cores[c].memory), seq[c][1])
+        assert torch.equal(got, seq[c][0]), (c, [float((got[t] - seq[c][0][t]).abs().max()) for t in range(T)])
+
+
 def test_eval_driver_on_bike_example(gpu_net, tmp_path):
     """Section 8(f) rank 1: the bike frames through VideoReader -> InferenceCore -> fused argmax/remap -> PNG writer; the first
     PNG reproduces the annotation, every PNG equals output_prob_to_mask of a second pass."""

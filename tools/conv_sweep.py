@@ -38,6 +38,8 @@ def main():
     ap.add_argument('--window', type=int, nargs='*', default=[], help='sweep the convs of the BATCHED image encoder (CUTIE._encode_window, the look-ahead '
                     'window of InferenceCore) for these batch sizes instead of the frame\'s convs; candidates are restricted to the K-order class of '
                     'the one-frame plan\'s tile (ops.korder_class), the only tiles the window plan may use')
+    ap.add_argument('--lockstep', type=int, default=0, help='sweep the convs of LOCK-STEP frames of this many clips (cutie_amd/inference/lockstep.py: batch = clips x '
+                    'objects, joint encoder windows) instead; candidates are restricted to the K-order class of the tile the plan runs (that of the one-clip plan)')
     args = ap.parse_args()
     from bench import Recorder
     from cutie_amd import _lib, ops as O
@@ -82,7 +84,36 @@ def main():
                 if key not in geoms:
                     geoms[key] = [ops[n:n + 1].copy(), 0]
                 geoms[key][1] += 1
-        for K in ([] if args.window else args.objects):
+        for K in (args.objects if args.lockstep else []):
+            from cutie_amd.inference.lockstep import LockstepCores
+            C, NF = args.lockstep, 40
+            clips = [SyntheticClip(args.height, args.width, K, NF, seed=1 + c) for c in range(C)]
+            frames = [[cl.frame(t).cuda() for t in range(NF)] for cl in clips]
+            ls = LockstepCores(net, cfg, C)
+            ls.step([f[0] for f in frames], [cl.first_mask().cuda() for cl in clips], [cl.objects for cl in clips])
+            hint = lambda t: dict(next_images=[f[t + 1:t + 14] for f in frames])
+            for t in range(1, 14):
+                ls.step([f[t] for f in frames], **hint(t))
+            torch.cuda.synchronize()
+            rec.rec, rec.on = [], True
+            for t in range(14, 26):                      # whole encoder batches and two memory frames
+                ls.step([f[t] for f in frames], **hint(t))
+            rec.on = False
+            torch.cuda.synchronize()
+            ops = np.concatenate(rec.rec)
+            for n in range(len(ops)):
+                if ops['kind'][n] != O.CONV:
+                    continue
+                i = ops['i'][n]
+                M, cout, cin = int(i[0]) * int(i[7]) * int(i[8]), int(i[9]), int(i[3]) + int(i[4])
+                key = (M, cout, cin, int(i[11]), int(i[13]), int(ops['flags'][n]) & 3, int(i[1]), int(i[2]))
+                if key not in geoms:
+                    geoms[key] = [ops[n:n + 1].copy(), 0]
+                    geoms[key][0]['p'][0, 7] = geoms[key][0]['p'][0, 8] = 0
+                    geoms[key][0]['i'][0, 21] = 0
+                    want_class[key] = O.korder_class(int(i[17]), int(i[19]))       # (enforced by Plan.autotune_convs: the one-clip plan's class)
+                geoms[key][1] += 1
+        for K in ([] if (args.window or args.lockstep) else args.objects):
             clip = SyntheticClip(args.height, args.width, K, 16, seed=1)
             proc = InferenceCore(net, cfg=cfg)
             proc.step(clip.frame(0).cuda(), clip.first_mask().cuda(), objects=clip.objects)
@@ -154,7 +185,8 @@ def main():
             if f not in best or us < best[f][1]:
                 best[f] = ((t, sk), us)
         (bt, bsk), bus = min(res.items(), key=lambda kv: kv[1])
-        table.append([list(key), [bt, bsk]])
+        # lock-step geometries: keyed with their K-order class (a batched geometry may be shared by layers of different classes; Plan.autotune_convs)
+        table.append([list(key) + ([want_class[key]] if (args.lockstep and isinstance(want_class.get(key), str)) else []), [bt, bsk]])
         rows.append(dict(key=list(key), count=count, gflop=fl / 1e9, best=[bt, bsk, bus],
                          families={f: [v[0][0], v[0][1], v[1]] for f, v in best.items()},
                          all={f'{t}x{sk}': us for (t, sk), us in res.items()}))
