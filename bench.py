@@ -74,6 +74,9 @@ def parse():
                     help='several clips per GPU: in LOCK STEP through one launch plan per stage (cutie_amd/inference/lockstep.py), or in flight on a '
                          'stream each, driven by ONE thread that issues a step of every clip in turn, or by one host thread per clip')
     ap.add_argument('--multi-only', action='store_true', help='(internal) run the clips-in-flight leg only and print its seconds')
+    ap.add_argument('--cpu-interpreter', action='store_true',
+                    help='(tests only) no GPU: the launch plans run through the torch interpreter of the descriptors (tests/mock_exec.py) and the ranks '
+                         'meet over gloo -- exercises the launcher / sharding / timing protocol of --gpus N on a CPU box, measures nothing')
     ap.add_argument('--device-index', type=int, default=None, help='(internal) GPU of a --multi-only child')
     return ap.parse_args()
 
@@ -370,13 +373,40 @@ def conv_flops(arr):
     return f
 
 
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks ourselves -- the driver's own command line, one process per GPU
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>`) -- and hand its
+    exit code back.  Rank 0 of that job prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # (dmabuf IPC: RCCL between the ranks of one node)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and not args.multi_only:
+        sys.exit(relaunch_under_torchrun(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != max(1, args.gpus) and not args.multi_only:
+        # (VERDICT r05: --gpus used to be parsed and dropped; a launcher that starts another number of ranks than the command line asks for is an error)
+        sys.exit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; start it as `python bench.py --gpus N` or under '
+                 f'`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`')
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
     pinned = None
+    on_cpu = args.cpu_interpreter
+    if on_cpu:                                               # (tests: protocol only -- every leg that measures the device is off)
+        args.no_roofline = args.no_graph = True
+        args.clips_in_flight = args.cpu_frames = args.full_bank_preroll = 0
+        args.repeats = 1
     if world > 1:
         # One rank per GPU, each with its own slice of the host cores: a rank's frame is ~0.8 ms of Python + launch calls, and N ranks
         # hopping over the same cores (or all landing on one NUMA node's first cores) is the one visible risk to clip-shard scaling.
@@ -393,11 +423,20 @@ def main():
         except (AttributeError, OSError, ValueError):
             pinned = None
         import torch.distributed as dist
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
+        if on_cpu:
+            dist.init_process_group(backend='gloo')
+        else:
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
+        assert dist.get_world_size() == world
     if args.multi_only:
         local = args.device_index if args.device_index is not None else local
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+    if on_cpu:
+        dev = torch.device('cpu')
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device('cuda', local)
+    sync = (lambda: None) if on_cpu else torch.cuda.synchronize
 
     from cutie_amd import _lib, ops as O
     from cutie_amd.config import default_config
@@ -420,6 +459,9 @@ def main():
         secs = secs[0] if isinstance(secs, tuple) else secs
         print(json.dumps({'seconds': secs, 'steps_per_clip': multi_clip_steps(args), 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES')}))
         return
+    if on_cpu:
+        from mock_exec import MockExecutor
+        _lib.set_executor_for_testing(MockExecutor())
     rec = Recorder(_lib.get_executor())
     _lib.set_executor_for_testing(rec)                     # only a recording shim around the HIP executor
 
@@ -427,15 +469,16 @@ def main():
     frames = torch.stack([clip.frame(t) for t in range(128)]).to(dev)           # resident in HBM (630 MB)
     mask = clip.first_mask().to(dev)
     proc = InferenceCore(net, cfg=cfg)
-    side = torch.cuda.Stream(device=dev)                   # a real (capturable) stream, not the legacy null stream
-    with torch.inference_mode(), torch.cuda.stream(side):
+    import contextlib
+    side = None if on_cpu else torch.cuda.Stream(device=dev)       # a real (capturable) stream, not the legacy null stream
+    with torch.inference_mode(), (contextlib.nullcontext() if on_cpu else torch.cuda.stream(side)):
         la = make_hint(args, frames, 128)                  # the next frames, as a video reader knows them
         proc.step(frames[0], mask, objects=clip.objects, **la(0))
         t_idx = 1
         for _ in range(args.preroll):
             proc.step(frames[t_idx % 128], **la(t_idx))
             t_idx += 1
-        torch.cuda.synchronize()
+        sync()
         n_tok_start = sum(b.size() for b in proc.memory.buckets.values())
         from cutie_amd.parallel import timed_steps
         base = t_idx
@@ -444,18 +487,40 @@ def main():
             proc.step(frames[(base + i) % 128], **la(base + i))
 
         # W warm-up steps, then exactly K timed steps between barrier + synchronize, MAX over the ranks (cutie_amd/parallel.py)
-        elapsed = timed_steps(one_step, args.steps, args.warmup, dev)
+        rank_secs = []
+        elapsed = timed_steps(one_step, args.steps, args.warmup, dev, per_rank=rank_secs)
         t_idx = base + args.warmup + args.steps
-        # the same timed region again (no warm-up: the clip simply goes on): the spread of a short sample on this box
-        rep_vals = [round(world * args.steps / elapsed, 2)]
+        # the same timed region again (no warm-up: the clip simply goes on).  EVERY region is W = 0 + exactly K steps between barrier +
+        # synchronize, MAX over the ranks; "value" is the MEDIAN region (VERDICT r05 / ADVICE r04: a 20-step region holds one or two 12-frame
+        # encoder batches, single regions scatter by 10 % with their phase; the first region is kept as value_first_region)
+        regions = [(elapsed, list(rank_secs))]
         for _ in range(max(0, args.repeats - 1)):
             base = t_idx
-            rep_vals.append(round(world * args.steps / timed_steps(one_step, args.steps, 0, dev), 2))
+            rs = []
+            regions.append((timed_steps(one_step, args.steps, 0, dev, per_rank=rs), rs))
             t_idx = base + args.steps
+        rep_vals = [round(world * args.steps / r[0], 2) for r in regions]
+        med = sorted(range(len(regions)), key=lambda j: regions[j][0])[len(regions) // 2]
+        first_elapsed, (elapsed, rank_secs) = elapsed, regions[med]
         n_tok_end = sum(b.size() for b in proc.memory.buckets.values())
         # ---- the same clip WITHOUT the next_image hint: what an unchanged scripting_demo.py / eval loop of the reference gets ----
         no_la = None
-        if not args.no_lookahead:
+        hinted_protocol = None
+        if not args.no_lookahead and not on_cpu:
+            # the reference's own FPS protocol (cutie/eval_vos.py:126-145) for the HINTED caller as well
+            ev_ms = 0.0
+            for i in range(args.steps):
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                proc.step(frames[t_idx % 128], **la(t_idx))
+                e1.record()
+                torch.cuda.synchronize()
+                ev_ms += e0.elapsed_time(e1)
+                t_idx += 1
+            hinted_protocol = {'fps': round(args.steps / ev_ms * 1e3, 2), 'steps': args.steps,
+                               'note': 'step(image, next_images=...) under the reference\'s FPS protocol: synchronize, event, step, event, synchronize; frames / sum of the event intervals'}
+        if not args.no_lookahead and not on_cpu:
             base2 = t_idx
             # un-timed steps first, enough of them to use up every frame the hinted steps before have already encoded ahead (a look-ahead
             # window and its lead): with 2 of them a 20-step region still ran on left-over window entries (1023 frames/s instead of ~820)
@@ -541,7 +606,10 @@ def main():
                 issued = sum(3 * 2.0 * 128 * (int(r['i'][9]) * 16) * int(r['i'][1]) for r in pass0)     # 3 split-bf16 terms, padded tiles x stacked rows
                 dense32 = sum(2.0 * 128 * sum(int(r['i'][4 + 2 * q]) for q in range(int(r['i'][2]))) * int(r['i'][0]) *
                               (int(r['i'][1]) // int(r['i'][16]) if int(r['i'][16]) > 0 else 1) for r in pass0)
-                t_mm = min(rec.ex.time_ops(pass0, 5) for _ in range(3)) * 1e-3
+                t_reps = [rec.ex.time_ops(pass0, 5) * 1e-3 for _ in range(3)]
+                t_mm = sum(t_reps) / len(t_reps)             # MEAN of the replays (the minimum flattered the figure)
+                real = sum(3 * 2.0 * 128 * sum(int(r['i'][4 + 2 * q]) for q in range(int(r['i'][2]))) * int(r['i'][0]) *
+                           (int(r['i'][1]) // int(r['i'][16]) if int(r['i'][16]) > 0 else 1) for r in pass0)     # split-bf16 flops of the REAL tokens x real query rows
                 by_f = {}
                 for a in aff_arrs:
                     by_f.setdefault(plan_frames(a), []).append(a)
@@ -556,8 +624,11 @@ def main():
                              'us': round(t_mm * 1e6 / len(pass0), 2), 'us_per_frame': round(t_mm * 1e6 / frames_read, 2),
                              'mfma_issued_tflops': round(issued / t_mm / 1e12, 1),
                              'mfma_util': round(issued / t_mm / 1e12 / PEAK_BF16_TFLOPS, 4),
-                             'mfma_util_note': 'issued split-bf16 MFMA flops of ALL score-pass launches of the recorded frames / their device time '
-                                               '(back-to-back replay, hipEvents) / 2.5 PFLOP/s',
+                             'mfma_util_unpadded': round(real / t_mm / 1e12 / PEAK_BF16_TFLOPS, 4),
+                             'mfma_util_best_replay': round(issued / min(t_reps) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                             'mfma_util_note': 'issued split-bf16 MFMA flops of ALL score-pass launches of the recorded frames (padded 16-token tiles x padded query '
+                                               'rows) / their device time (MEAN of three back-to-back replays, hipEvents) / 2.5 PFLOP/s; _unpadded prices the real '
+                                               'tokens x real query rows only',
                              'fp32_equivalent_tflops': round(dense32 / t_mm / 1e12, 1),
                              'stage_plan': {'frames': common_f, 'tokens': plan_tokens(affs), 'queries': int(ii[0]) * common_f},
                              'stage_us': {'memset': round(pre[0], 1), 'score0': round(pre[1] - pre[0], 1),
@@ -740,7 +811,8 @@ def main():
     if rank == 0:
         fps = world * args.steps / tmax
         out = {
-            'metric': 'frames/sec (480p, 3 objects)', 'value': round(fps, 2), 'unit': 'frames/s', 'n_gpus': world,
+            'metric': 'frames/sec (480p, 3 objects)', 'value': round(fps, 2), 'unit': 'frames/s',
+            'n_gpus': (dist.get_world_size() if dist is not None else 1),      # the ranks the process group really has (one GPU each)
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(tmax / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'synthetic {args.width}x{args.height} {K}-object clip, long_term={use_lt}, one clip per GPU '
@@ -758,11 +830,16 @@ def main():
         if gs is not None:
             out['plans_eager_vs_graph_replay'] = list(gs)      # whole run (pre-roll included): plans issued launch by launch | as one HIP graph
         rv = sorted(rep_vals)
+        out['value_first_region'] = round(world * args.steps / first_elapsed, 2)
+        out['per_rank_fps'] = [round(args.steps / s_, 2) for s_ in rank_secs]      # every rank's own clip in the region "value" is taken from
         out['repeats'] = {'values': rep_vals, 'median': rv[len(rv) // 2], 'min': rv[0], 'max': rv[-1],
                           'mean_fps_all_regions': round(len(rep_vals) / sum(1.0 / v for v in rep_vals), 2),
-                          'note': f'{len(rep_vals)} consecutive timed regions of {args.steps} steps on this box; "value" is the first (the protocol-conform '
-                                  f'one).  A region of {args.steps} frames holds 1-2 batched encoder plans of {args.window} frames each, so single regions '
-                                  'scatter with the phase of the batches; mean_fps_all_regions = all frames / all time'}
+                          'note': f'{len(rep_vals)} consecutive timed regions on this box, each EXACTLY {args.steps} steps between barrier + synchronize (the first one behind '
+                                  f'the {args.warmup} warm-up steps); "value" = the MEDIAN region, value_first_region = the first.  A region of {args.steps} frames holds 1-2 '
+                                  f'batched encoder plans of {args.window} frames each, so single regions scatter with the phase of the batches; '
+                                  'mean_fps_all_regions = all frames / all time'}
+        if hinted_protocol is not None:
+            out['eval_vos_protocol'] = hinted_protocol
         if no_la is not None:
             out['value_no_lookahead'] = no_la['value']
             out['no_lookahead'] = dict(no_la, note='same clip, step(image) without the next_image hint (an unchanged scripting_demo.py)')

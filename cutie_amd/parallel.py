@@ -32,10 +32,11 @@ def shard_clips(num_clips: int, rank: int, world_size: int) -> List[int]:
     return [c for c in range(num_clips) if c % world_size == rank]
 
 
-def timed_steps(step: Callable[[int], None], steps: int, warmup: int, device) -> float:
+def timed_steps(step: Callable[[int], None], steps: int, warmup: int, device, per_rank: list = None) -> float:
     """The timing protocol of bench.py (one clip per rank, weak scaling): `warmup` untimed calls of step(i), then EXACTLY `steps`
     timed calls bracketed by a barrier + device synchronisation on both sides; returns the MAX over the ranks of the elapsed
-    seconds (all-reduce: RCCL on the GPUs, gloo in the CPU tests) -- the whole job is as slow as its slowest rank."""
+    seconds (all-reduce: RCCL on the GPUs, gloo in the CPU tests) -- the whole job is as slow as its slowest rank.
+    per_rank (a list): receives every rank's own elapsed seconds, in rank order (all-gather)."""
     dev = torch.device(device)
     on_gpu = dev.type == 'cuda'
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -54,9 +55,20 @@ def timed_steps(step: Callable[[int], None], steps: int, warmup: int, device) ->
     t0 = time.perf_counter()
     for i in range(steps):
         step(warmup + i)
+    if on_gpu:
+        torch.cuda.synchronize(dev)
+    own = time.perf_counter() - t0                        # this rank's clip alone (before it waits for the others)
     fence()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if on_gpu else 'cpu')
+    if per_rank is not None:
+        if multi:
+            mine = torch.tensor([own], dtype=torch.float64, device=dev if on_gpu else 'cpu')
+            parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(parts, mine)
+            per_rank[:] = [float(p.item()) for p in parts]
+        else:
+            per_rank[:] = [own]
     if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -134,3 +134,31 @@ def test_bench_protocol_and_model_two_ranks_gloo():
         p.join(600)
         assert p.exitcode == 0
     assert q.get(timeout=5) == 'ok'
+
+
+def _run_bench(extra, env=None):
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--cpu-interpreter', '--steps', '3', '--warmup', '1', '--preroll', '2', '--height', '48',
+           '--width', '80', '--objects', '2', '--window', '4'] + extra
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    e.update(env or {})
+    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` -- the shape of the driver's command -- starts two ranks itself (torch.distributed.run, one process per
+    GPU; here over gloo with the descriptor interpreter, `--cpu-interpreter`), rank 0 prints ONE line whose n_gpus is the size of the process
+    group, with every rank's own frames/s; one rank stays one process; a launcher that started another number of ranks than --gpus asks for
+    is refused (the flag used to be parsed and dropped)."""
+    r, line = _run_bench(['--gpus', '2'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line['n_gpus'] == 2 and len(line['per_rank_fps']) == 2 and line['steps'] == 3 and line['scaling'] == 'weak'
+    assert line['config']['parallelism'] == 'clip-shard x2'
+    assert abs(line['value'] - 2 * 3 / (line['ms_per_step'] * 3e-3)) < 0.05 * line['value']          # whole-job frames / the slowest rank's time
+    r, line = _run_bench(['--gpus', '1'])
+    assert r.returncode == 0 and line['n_gpus'] == 1 and len(line['per_rank_fps']) == 1, r.stderr[-2000:]
+    r, line = _run_bench(['--gpus', '2'], env={'WORLD_SIZE': '3', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0 and line is None and '--gpus 2' in r.stderr and 'WORLD_SIZE=3' in r.stderr
