@@ -73,6 +73,8 @@ def parse():
     ap.add_argument('--multi-mode', choices=('threads', 'interleaved', 'lockstep'), default='lockstep',
                     help='several clips per GPU: in LOCK STEP through one launch plan per stage (cutie_amd/inference/lockstep.py), or in flight on a '
                          'stream each, driven by ONE thread that issues a step of every clip in turn, or by one host thread per clip')
+    ap.add_argument('--lockstep-groups', type=int, default=3, help='(--multi-mode lockstep) also measure this many lock-step groups of --clips-in-flight clips IN FLIGHT next to each '
+                         'other (reported as multi_clip.groups_in_flight; with --multi-only: the leg itself); <= 1: skip')
     ap.add_argument('--multi-only', action='store_true', help='(internal) run the clips-in-flight leg only and print its seconds')
     ap.add_argument('--cpu-interpreter', action='store_true',
                     help='(tests only) no GPU: the launch plans run through the torch interpreter of the descriptors (tests/mock_exec.py) and the ranks '
@@ -303,7 +305,58 @@ def multi_clip_lockstep(net, cfg, args, K, rank, dist, dev, rec=None):
     return secs, roof
 
 
+def multi_clip_lockstep_groups(net, cfg, args, K, rank, dist, dev):
+    """--lockstep-groups G > 1: G lock-step groups of C clips each IN FLIGHT next to each other -- a stream and a CUTIE.fork() per group, this
+    thread issues a lock-step frame of every group in turn (the two schemes of cutie_amd/parallel.py combined).  Returns the seconds for
+    multi_clip_steps(args) frames of every clip (G x C clips)."""
+    from cutie_amd import frame_context
+    from cutie_amd.inference.lockstep import LockstepCores
+    from cutie_amd.utils.synth import SyntheticClip
+    C, G, NF = args.clips_in_flight, args.lockstep_groups, 48
+    steps = multi_clip_steps(args)
+    groups = []
+    lanes = []
+    try:
+      with torch.inference_mode():
+        for g in range(G):
+            view = net if g == 0 else net.fork()
+            lanes.append((view.engine(), view.engine().one_lane))
+            view.engine().one_lane = True                   # a stream per GROUP: its look-ahead lanes in line (cutie_amd/parallel.py)
+            clips = [SyntheticClip(args.height, args.width, K, NF, seed=101 + 16 * rank + g * C + c) for c in range(C)]
+            views = []
+            for cl in clips:
+                fr = torch.stack([cl.frame(t) for t in range(NF)]).to(dev)
+                v = [fr[i] for i in range(NF)]
+                views.append(v + v[:32])
+            st, ctx = torch.cuda.Stream(device=dev), frame_context.new_context()
+            with frame_context.context(ctx), torch.cuda.stream(st):
+                ls = LockstepCores(view, cfg, C)
+                ls.step([v[0] for v in views], [cl.first_mask().to(dev) for cl in clips], [cl.objects for cl in clips])
+            groups.append((ls, views, st, ctx))
+        hint = lambda views, t: {} if args.no_lookahead else {'next_images': [v[(t + 1) % NF:(t + 1) % NF + 16] for v in views]}
+
+        def round_(t):
+            for ls, views, st, ctx in groups:
+                with frame_context.context(ctx), torch.cuda.stream(st):
+                    ls.step([v[t % NF] for v in views], **hint(views, t))
+        for t in range(1, 1 + args.preroll + args.warmup):
+            round_(t)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for t in range(steps):
+            round_(1 + args.preroll + args.warmup + t)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    finally:
+        for eng, was in lanes:
+            eng.one_lane = was
+
+
 def multi_leg(args):
+    if args.multi_mode == 'lockstep' and args.lockstep_groups > 1:
+        return multi_clip_lockstep_groups
     return {'lockstep': multi_clip_lockstep, 'interleaved': multi_clip_interleaved, 'threads': multi_clip_throughput}[args.multi_mode]
 
 
@@ -762,6 +815,16 @@ def main():
                              + '; "value" above stays one clip per GPU, default environment'}
             if multi_roof is not None:
                 multi['roofline'] = multi_roof
+            if args.multi_mode == 'lockstep' and args.lockstep_groups > 1 and world == 1 and not in_child:
+                try:
+                    tg = multi_clip_lockstep_groups(net, cfg, args, K, rank, None, dev)
+                    ncl = args.lockstep_groups * args.clips_in_flight
+                    multi['groups_in_flight'] = {'groups': args.lockstep_groups, 'clips_per_group': args.clips_in_flight, 'clips': ncl,
+                                                 'value': round(ncl * msteps / tg, 2), 'unit': 'frames/s',
+                                                 'note': 'lock-step groups in flight next to each other (a stream + CUTIE.fork() per group, one thread issues a lock-step '
+                                                         'frame of every group in turn: cutie_amd/parallel.py run_batched(in_flight=...))'}
+                except Exception as e:
+                    multi['groups_in_flight'] = {'error': f'{type(e).__name__}: {e}'}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:

@@ -366,9 +366,12 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const bf16_t* __restrict
     }
     if (tid < 2) { gap[tid] = 0.f; gap[C + 2 + tid] = 0.f; }            // zero padding of the conv1d
     __syncthreads();
+    // sc is stored TRANSPOSED -- scale of channel c at [(c & 7) * 32 + (c >> 3)] -- so that the streaming loop below, where lane l reads the
+    // eight scales of channel octet c8 = l & 31, hits 32 consecutive banks per read (PMC r05: channel-major, stride 8 words between the lanes,
+    // every ds_read_b32 was a 4-way conflict: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.43)
     for (int c = tid; c < C; c += 256) {
         float a = wk[0] * gap[c] + wk[1] * gap[c + 1] + wk[2] * gap[c + 2] + wk[3] * gap[c + 3] + wk[4] * gap[c + 4];
-        sc[c] = sigmoidf_(a);
+        sc[(c & 7) * 32 + (c >> 3)] = sigmoidf_(a);
     }
     __syncthreads();
 #pragma unroll
@@ -380,8 +383,8 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const bf16_t* __restrict
         uint32_t o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float lo = __uint_as_float(xu[i] << 16) * sc[c8 * 8 + 2 * i] + __uint_as_float(ru[i] << 16);
-            float hi = __uint_as_float(xu[i] & 0xffff0000u) * sc[c8 * 8 + 2 * i + 1] + __uint_as_float(ru[i] & 0xffff0000u);
+            float lo = __uint_as_float(xu[i] << 16) * sc[(2 * i) * 32 + c8] + __uint_as_float(ru[i] << 16);
+            float hi = __uint_as_float(xu[i] & 0xffff0000u) * sc[(2 * i + 1) * 32 + c8] + __uint_as_float(ru[i] & 0xffff0000u);
             o[i] = pack_bf2(lo, hi);
         }
         *reinterpret_cast<uint4*>(y + offs[it]) = make_uint4(o[0], o[1], o[2], o[3]);
@@ -401,8 +404,8 @@ __global__ __launch_bounds__(256) void eca_apply_kernel(const bf16_t* __restrict
                 const uint32_t* xu = &xv[it].x; const uint32_t* ru = &rv[it].x;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float lo = __uint_as_float(xu[i] << 16) * sc[c8 * 8 + 2 * i] + __uint_as_float(ru[i] << 16);
-                    const float hi = __uint_as_float(xu[i] & 0xffff0000u) * sc[c8 * 8 + 2 * i + 1] + __uint_as_float(ru[i] & 0xffff0000u);
+                    const float lo = __uint_as_float(xu[i] << 16) * sc[(2 * i) * 32 + c8] + __uint_as_float(ru[i] << 16);
+                    const float hi = __uint_as_float(xu[i] & 0xffff0000u) * sc[(2 * i + 1) * 32 + c8] + __uint_as_float(ru[i] & 0xffff0000u);
                     const uint32_t st = pack_bf2(lo, hi);                  // the stored pair
                     part += fmaxf(__uint_as_float(st << 16), 0.f) * __uint_as_float(wu[i] << 16);
                     part += fmaxf(__uint_as_float(st & 0xffff0000u), 0.f) * __uint_as_float(wu[i] & 0xffff0000u);

@@ -65,7 +65,7 @@ class LockstepCores:
 
     # ---- state of the group --------------------------------------------------------------------------------------------------------
     def _batchable(self, images, masks, end) -> bool:
-        if end or masks is not None:
+        if end or masks is not None or len(self.cores) < 2:  # (a group of one clip IS its InferenceCore)
             return False
         c0 = self.cores[0]
         if c0._flip is not None or (c0.chunk_size is not None and c0.chunk_size >= 1) or c0.save_aux:

@@ -7,7 +7,8 @@ gather of per-clip results to rank 0 -- a direct (non-ring) gather, since the pa
 
 Inside one GPU, several clips can be *in flight* at once: ONE HIP stream + ``CUTIE.fork()`` per clip.  A single clip is a chain of
 dependent small launches per frame and leaves compute units idle (kernel-boundary bubbles, layers with < 256 workgroups); independent
-chains interleave on the hardware queues.  A clip in flight keeps the batching of its look-ahead lanes (one encoder plan per 12 frames,
+chains interleave on the hardware queues.  Clips of one geometry and object count can instead advance in LOCK STEP through one launch plan per
+stage (``run_batched``, cutie_amd/inference/lockstep.py): fewer, larger launches -- the better of the two on the MI355X (round 6).  A clip in flight keeps the batching of its look-ahead lanes (one encoder plan per 12 frames,
 one read-out per bank version) but runs them on its own stream (``Engine.one_lane``): next to other clips its extra streams only
 compete for the hardware queues.  Two drivers:
 * ``run_interleaved`` -- ONE host thread issues a step of every clip in turn (generator clips).  ``step`` never waits for the device,
@@ -196,6 +197,64 @@ def run_interleaved(net, clip_ids: Sequence[int], run_clip: Callable, *, streams
     finally:
         for eng, was in lanes:
             eng.one_lane = was
+    return results
+
+
+def run_batched(net, cfg, clips: Sequence[Dict], *, lockstep: int = 4, in_flight: int = 1, lookahead: int = 16, on_frame: Callable = None) -> Dict[int, List]:
+    """Several clips per GPU in LOCK STEP (cutie_amd/inference/lockstep.py): groups of ``lockstep`` clips advance together through ONE launch
+    plan per stage -- batch = clips x objects for the pixel fusion, the object transformer, the decoder and the mask encoder, one joint
+    encoder window, one memory bank and one look-ahead read-out lane per clip.  Per clip the results are bit-identical to its own
+    ``InferenceCore`` run; next to ``run_interleaved`` this divides the launches and the host's issue time per frame by the group size and
+    gives every convolution of the per-object path ``lockstep`` x the rows.  ``in_flight`` > 1 keeps that many GROUPS in flight next to
+    each other (``run_interleaved`` over groups: a stream and a ``CUTIE.fork()`` per group, the calling thread issues a lock-step frame of
+    every group in turn) -- the two schemes multiply.  MI355X, 480p, 3 objects, long-term memory (round 6, one box each): 4 clips ~1710 frames/s
+    in one group against ~1530 interleaved one by one; 12 clips as 3 groups of 4 in flight ~2020.
+
+    clips: [{'frames': sequence of [3, H, W] tensors on the device, 'mask': the first frame's mask, 'objects': its object ids}, ...];
+    the clips of a group should share geometry, object count and length (a group whose clips differ still runs -- clip by clip where the
+    states differ, see LockstepCores).  on_frame(clip_index, t, prob, core) receives every result (default: the uint8 object-id masks are
+    collected).  Returns {clip index: [per-frame results]}."""
+    from . import frame_context
+    from .inference.lockstep import LockstepCores
+    results: Dict[int, List] = {i: [] for i in range(len(clips))}
+    if on_frame is None:
+        def on_frame(i, t, prob, core):
+            results[i].append(core.output_prob_to_mask(prob, dtype=torch.uint8))
+    groups = [list(range(g0, min(len(clips), g0 + max(1, lockstep)))) for g0 in range(0, len(clips), max(1, lockstep))]
+
+    def run_group(view, gi):
+        """Generator: one lock-step frame of group gi per `next`."""
+        group = groups[gi]
+        frames = [clips[i]['frames'] for i in group]
+        T = min(len(f) for f in frames)
+        ls = LockstepCores(view, cfg, len(group))
+        for t in range(T):
+            hint = {}
+            if lookahead > 0 and 0 < t < T - 1:
+                hint = dict(next_images=[[f[j] for j in range(t + 1, min(T, t + 1 + lookahead))] for f in frames])
+            end = all(t == len(f) - 1 for f in frames)
+            if t == 0:
+                probs = ls.step([f[0] for f in frames], [clips[i]['mask'] for i in group], [clips[i]['objects'] for i in group], end=end)
+            else:
+                probs = ls.step([f[t] for f in frames], end=end, **hint)
+            for c, i in enumerate(group):
+                on_frame(i, t, probs[c], ls.cores[c])
+            yield
+        for c, i in enumerate(group):                       # clips longer than the shortest of their group: the rest on their own
+            f = frames[c]
+            with frame_context.context(ls._ctx[c]):
+                for t in range(T, len(f)):
+                    on_frame(i, t, ls.cores[c].step(f[t], end=(t == len(f) - 1)), ls.cores[c])
+                    yield
+        return None
+
+    if in_flight > 1 and len(groups) > 1:
+        run_interleaved(net, list(range(len(groups))), run_group, streams=in_flight)
+    else:
+        with torch.inference_mode():
+            for gi in range(len(groups)):
+                for _ in run_group(net, gi):
+                    pass
     return results
 
 

@@ -1498,7 +1498,7 @@ def test_gru_four_channels_per_thread(monkeypatch):
         h, hb = h0.clone(), torch.zeros((n, C), dtype=BF16, device='cuda')
         ol = O.OpList()
         ol.gru(v0, h, hb, n=n, C=C)
-        assert int(ol.finalize()['flags'][0]) == scalar
+        assert (int(ol.finalize()['flags'][0]) & 1) == scalar      # (bit 8 = CUTIE_F_PRIO, set by the builder)
         ol.run()
         torch.cuda.synchronize()
         outs.append((h, hb.view(torch.int16)))
@@ -1531,3 +1531,137 @@ def test_aff_select_values_per_lane_follow_the_tile_count(G, monkeypatch):
     ref = torch.topk(gm[:HW, :G].float().cpu(), top_k, dim=1).values[:, -1] if G >= top_k else torch.full((HW,), float('-inf'))
     assert torch.equal(taus[0], taus[1])
     assert torch.equal(taus[0], ref)
+
+
+# ---- round 6 (ABI 4): clips in lock step -- every grouped launch against the per-clip launches it replaces, bit for bit ------------------------
+@pytest.mark.parametrize('tile', [None, 2, 66, 68, 100, 103, 105, 110])
+@pytest.mark.parametrize('k', [1, 3])
+def test_conv_residual_groups(tile, k):
+    """CONV with CUTIE_F_RES_BCAST and f0 / f1: the B = G x Kg objects come in G groups, group q adds ITS residual map (f1 rows apart) --
+    equal to G launches of Kg objects with a plain broadcast residual each, on every kernel family (igemm, conv_dma, conv_pc)."""
+    G, Kg, H, W, C, Cout, frames = 3, 2, 13, 17, 64, 72, 4
+    g = _gen(3)
+    w = torch.randn(Cout, C, k, k, generator=g) / math.sqrt(C * k * k)
+    pc = pack_conv(w, torch.randn(Cout, generator=g) * 0.1, 'cuda')
+    x = rnd(g, (G * Kg, H, W, C), dev='cuda')
+    res = rnd(g, (G, frames, H, W, Cout), dev='cuda')             # group q's map = res[q, 1]: maps `frames` x H x W rows apart
+    y, yref = (torch.zeros((G * Kg, H, W, Cout), dtype=BF16, device='cuda') for _ in range(2))
+    ol = O.OpList()
+    kw = dict(H=H, W=W, C1=C, ldx1=C, OH=H, OW=W, ldy=Cout, ldr=Cout, res_bcast=True, act=O.ACT_RELU, tile=tile, pad=(k - 1) // 2)
+    ol.conv(x, pc, y, B=G * Kg, res=res[0, 1], res_group=(Kg, frames * H * W), **kw)
+    for q in range(G):
+        ol.conv(x[q * Kg:], pc, yref[q * Kg:], B=Kg, res=res[q, 1], **kw)
+    ol.run()
+    torch.cuda.synchronize()
+    assert torch.equal(y.view(torch.int16), yref.view(torch.int16))
+    # and the interpreter's reading of the grouped descriptor
+    hip, ref = run_both(lambda dev, gg: _grouped_conv(dev, gg, tile, k), seed=9)
+    check(hip, ref, 'grouped residual')
+
+
+def _grouped_conv(dev, g, tile, k):
+    G, Kg, H, W, C, Cout = 2, 3, 9, 11, 64, 40
+    pc = pack_conv(torch.randn(Cout, C, k, k, generator=g) / math.sqrt(C * k * k), torch.randn(Cout, generator=g) * 0.1, dev)
+    x, res = rnd(g, (G * Kg, H, W, C), dev=dev), rnd(g, (G, 2, H, W, Cout), dev=dev)
+    y = torch.zeros((G * Kg, H, W, Cout), dtype=BF16, device=dev)
+    ol = O.OpList()
+    ol.conv(x, pc, y, B=G * Kg, H=H, W=W, C1=C, ldx1=C, OH=H, OW=W, ldy=Cout, ldr=Cout, res=res, res_bcast=True, res_group=(Kg, 2 * H * W), tile=tile, pad=(k - 1) // 2)
+    return ol, {'y': y}
+
+
+def test_upsample2x_add_skip_groups():
+    """UPSAMPLE2X_ADD i4 / i5: one skip map per group of objects."""
+    G, Kg, h, w, C, frames = 3, 2, 7, 9, 128, 3
+    g = _gen(4)
+    x = rnd(g, (G * Kg, h, w, C), dev='cuda')
+    skip = rnd(g, (G, frames, 2 * h, 2 * w, C), dev='cuda')
+    y, yref = (torch.zeros((G * Kg, 2 * h, 2 * w, C), dtype=BF16, device='cuda') for _ in range(2))
+    ol = O.OpList()
+    ol.upsample2x_add(x, skip[0, 2], y, B=G * Kg, h=h, w=w, C=C, skip_group=(Kg, frames * 4 * h * w))
+    for q in range(G):
+        ol.upsample2x_add(x[q * Kg:], skip[q, 2], yref[q * Kg:], B=Kg, h=h, w=w, C=C)
+    ol.run()
+    torch.cuda.synchronize()
+    assert torch.equal(y.view(torch.int16), yref.view(torch.int16))
+
+    def build(dev, gg):
+        xx, sk = rnd(gg, (4, 5, 6, 64), dev=dev), rnd(gg, (2, 10, 12, 64), dev=dev)
+        yy = torch.zeros((4, 10, 12, 64), dtype=BF16, device=dev)
+        o = O.OpList()
+        o.upsample2x_add(xx, sk, yy, B=4, h=5, w=6, C=64, skip_group=(2, 120))
+        return o, {'y': yy}
+    check(*run_both(build), name='upsample2x_add groups')
+
+
+@pytest.mark.parametrize('K,h,w,md', [(3, 120, 216, True), (2, 8, 12, True), (3, 24, 32, False), (7, 4, 28, True)])
+def test_up4_softmax_clips(K, h, w, md):
+    """UP4_SOFTMAX i4: C clips per launch (grid.y) = C one-clip launches, with and without the MASK_DOWN side results."""
+    C = 3
+    g = _gen(6)
+    lg = (torch.randn((C, K, h, w), generator=g) * 3).cuda()
+    H, W = 4 * h, 4 * w
+    hw16 = (H // 16) * (W // 16)
+    mk = lambda: (torch.zeros((C, K + 1, H, W), device='cuda'), torch.zeros((C * K, hw16, 64), dtype=BF16, device='cuda'), torch.zeros((C * K, hw16), device='cuda'))
+    (pa, ra, ma), (pb, rb, mb) = mk(), mk()
+    ol = O.OpList()
+    ol.up4_softmax(lg, pa, None, P=K + 1, h=h, w=w, from_logits=True, clips=C, mask_down=(ma, ra, 64) if md else None)
+    for c in range(C):
+        ol.up4_softmax(lg[c], pb[c], None, P=K + 1, h=h, w=w, from_logits=True, mask_down=(mb[c * K:], rb[c * K:], 64) if md else None)
+    ol.run()
+    torch.cuda.synchronize()
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(ra.view(torch.int16), rb.view(torch.int16))
+    if md:                                               # the interpreter's reading of the clips form
+        def build(dev, gg):
+            l2 = (torch.randn((2, 2, 8, 8), generator=gg) * 3).to(dev)
+            p2 = torch.zeros((2, 3, 32, 32), device=dev)
+            m2, r2 = torch.zeros((4, 4), device=dev), torch.zeros((4, 4, 8), dtype=BF16, device=dev)
+            o = O.OpList()
+            o.up4_softmax(l2, p2, None, P=3, h=8, w=8, from_logits=True, clips=2, mask_down=(m2, r2, 8))
+            return o, {'prob': p2, 'm16': m2, 'pair': r2}
+        check(*run_both(build), name='up4 clips', rtol=2e-3)
+
+
+@pytest.mark.parametrize('qpre', [0, 1])
+@pytest.mark.parametrize('Kg', [1, 3, 5])
+def test_q2p_chain_clip_objects(Kg, qpre):
+    """ATTN_Q2P i9 (chain form): the foreground masks are decided among the objects of ONE clip -- a launch over G clips of Kg objects adds
+    to the accumulator exactly what G launches of Kg objects add."""
+    G, Q, HW, C, heads = 2, 16, 700, 256, 8
+    K = G * Kg
+    M = K * Q
+    g = _gen(11)
+    lg = torch.cat([_aux_inputs(g, Kg, HW, 'mixed') for _ in range(G)], 0).cuda()
+    x, emb = torch.randn((M, C), generator=g).cuda(), (torch.randn((M, C), generator=g) * 0.5).cuda()
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.1).cuda()
+    Wq = pack_linear(torch.randn((C, C), generator=g) / 16, torch.randn(C, generator=g) * 0.1, 'cuda')
+    Wo = pack_linear(torch.randn((C, C), generator=g) / 16, torch.randn(C, generator=g) * 0.1, 'cuda')
+    kvq = rnd(g, (K, HW, 3 * C), dev='cuda')
+    qs = (torch.randn((M, C), generator=g) * 0.2).cuda()
+    acc_a, acc_b = (torch.zeros((M, C), dtype=torch.int64, device='cuda') for _ in range(2))
+    xn_a, xn_b = (torch.zeros((M, C), dtype=F32, device='cuda') for _ in range(2))
+    ol = O.OpList()
+    ol.keep += [Wq.weight, Wo.weight]
+    common = dict(Q=Q, HW=HW, C=C, heads=heads, ldkv=3 * C, voff=C)
+
+    def launch(k0, k1, acc, xn, clip_objects):
+        if qpre:
+            ol.attn_q2p(None, kvq[k0:], None, None, None, K=k1 - k0, logits=lg[k0:], q_pre=qs[k0 * Q:], out_proj=(Wo, acc[k0 * Q:]), clip_objects=clip_objects, **common)
+        else:
+            ol.attn_q2p(None, kvq[k0:], None, None, None, K=k1 - k0, logits=lg[k0:], proj=dict(x=x[k0 * Q:], W=Wq, emb=emb[k0 * Q:], ln=(gam, bet), ln_out=xn[k0 * Q:]),
+                        out_proj=(Wo, acc[k0 * Q:]), clip_objects=clip_objects, **common)
+    launch(0, K, acc_a, xn_a, Kg)
+    for q in range(G):
+        launch(q * Kg, (q + 1) * Kg, acc_b, xn_b, None)
+    ol.run()
+    torch.cuda.synchronize()
+    assert torch.equal(acc_a, acc_b) and torch.equal(xn_a, xn_b)
+    # ... and NOT what one launch over all K objects as ONE clip adds (the masks differ as soon as a clip has a second object)
+    if Kg > 1:
+        acc_c = torch.zeros_like(acc_a)
+        ol2 = O.OpList()
+        ol2.keep += [Wq.weight, Wo.weight]
+        ol2.attn_q2p(None, kvq, None, None, None, K=K, logits=lg, q_pre=qs, out_proj=(Wo, acc_c), **common) if qpre else \
+            ol2.attn_q2p(None, kvq, None, None, None, K=K, logits=lg, proj=dict(x=x, W=Wq, emb=emb, ln=(gam, bet), ln_out=xn_b), out_proj=(Wo, acc_c), **common)
+        ol2.run()
+        torch.cuda.synchronize()
+        assert not torch.equal(acc_a, acc_c)

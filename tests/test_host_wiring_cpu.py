@@ -242,13 +242,47 @@ def test_lockstep_clips_match_sequential(product_net, hinted):
     ex.per_sample_conv = True          # (torch's CPU conv may sum differently per batch size; the HIP tiles of one K-order class do not)
     try:
         with torch.inference_mode():
-            for cfg_kw, T in ((dict(mem_every=3), 11),
-                              (dict(mem_every=2, use_long_term=True, long_term=dict(S.LT_SMALL)), 24)):
-                seq, got, ls = _lockstep_case(product_net, cfg_kw, T=T, hinted=hinted, window=(4, 1) if hinted else None)
+            for cfg_kw, T, C in ((dict(mem_every=3), 9, 3),
+                                 (dict(mem_every=2, use_long_term=True, long_term=dict(S.LT_SMALL)), 15, 2)):      # (two consolidations)
+                seq, got, ls = _lockstep_case(product_net, cfg_kw, C=C, T=T, hinted=hinted, window=(4, 1) if hinted else None)
                 assert ls.batched_steps == T - 2, ls.batched_steps       # every frame but the first (masks) and the last (end=True)
+                assert not cfg_kw.get('use_long_term') or all(v[0] > 0 for v in seq[0][1].values()), 'the long-term case must consolidate'
                 for c in range(len(seq)):
                     assert seq[c][1] == got[c][1], (cfg_kw, c, seq[c][1], got[c][1])
                     assert torch.equal(seq[c][0], got[c][0]), (cfg_kw, hinted, c, float((seq[c][0] - got[c][0]).abs().max()))
+    finally:
+        ex.per_sample_conv = False
+
+
+def test_run_batched_groups_and_uneven_clips(product_net):
+    """parallel.run_batched: clips in groups of `lockstep`, a last group of one clip, a clip longer than its group's shortest -- every clip
+    gets the object-id masks of its own InferenceCore run."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.parallel import run_batched
+    from cutie_amd.utils.synth import SyntheticClip
+    lens = [7, 9, 6]
+    clips = []
+    for c, T in enumerate(lens):
+        cl = SyntheticClip(48, 80, 2, T, seed=70 + c)
+        clips.append(dict(frames=[cl.frame(t) for t in range(T)], mask=cl.first_mask(), objects=cl.objects))
+    cfg_kw = dict(mem_every=2)
+    ex = _lib.get_executor()
+    ex.per_sample_conv = True
+    try:
+        got = run_batched(product_net, default_config(**cfg_kw), clips, lockstep=2, lookahead=5)
+        got2 = run_batched(product_net, default_config(**cfg_kw), clips, lockstep=2, in_flight=2, lookahead=5)       # the two groups in flight next to each other
+        assert not product_net.engine().one_lane
+        for c in range(len(clips)):
+            assert len(got2[c]) == lens[c] and all(torch.equal(a, b) for a, b in zip(got[c], got2[c])), c
+        with torch.inference_mode():
+            for c, cl in enumerate(clips):
+                proc = InferenceCore(product_net, cfg=default_config(**cfg_kw))
+                want = [proc.output_prob_to_mask(proc.step(cl['frames'][0], cl['mask'], objects=cl['objects']), dtype=torch.uint8)]
+                for t in range(1, lens[c]):
+                    want.append(proc.output_prob_to_mask(proc.step(cl['frames'][t], end=(t == lens[c] - 1)), dtype=torch.uint8))
+                assert len(got[c]) == lens[c]
+                for t in range(lens[c]):
+                    assert torch.equal(got[c][t], want[t]), (c, t)
     finally:
         ex.per_sample_conv = False
 

@@ -15,6 +15,9 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLIC
   i=$((i+1))
   timeout 500 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc$i -- $BENCH --no-lookahead > $OUT/pmc$i.log 2>&1 || tail -3 $OUT/pmc$i.log
 done
+#  counter evidence for the STACKED score launches: the SQ set once more on the HINTED leg (one read-out per bank version:
+# aff_score4_kernel<4, 0> etc. exist only there); summarised per kernel instantiation as `affinity_score_pass_hinted`
+timeout 500 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/hinted -- $BENCH > $OUT/hinted.log 2>&1 || tail -3 $OUT/hinted.log
 python tools/profile_summarize.py $OUT $R
 cp profiles/${R}_* gpurun_out/
 tail -2 $OUT/stats.log
