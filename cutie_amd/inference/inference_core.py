@@ -37,6 +37,9 @@ WAIT_TRACE = None                                          # a list: step() brac
 # including the next memory frame that sit in one encoder batch of the window (MemoryManager.prefetch_affinity_batch; <= 1: frame by frame)
 AFF_BATCH = int(os.environ.get('CUTIE_AMD_AFF_BATCH', '8'))
 AFF_FIRST_ALONE = os.environ.get('CUTIE_AMD_AFF_FIRST_ALONE', '1') not in ('', '0')     # (A/B switch: a memory frame's successor read on its own, see _ahead_affinity)
+# with AFF_FIRST_ALONE: the stacked pass for the rest of the memory cycle is not queued behind the successor's read-out at the memory frame, but by
+# the NEXT step's look-ahead (it then starts behind the memory frame's own tail -- sensory deep update, summarizer -- instead of next to it); A/B switch
+AFF_REST_LATER = os.environ.get('CUTIE_AMD_AFF_REST_LATER', '0') not in ('', '0')
 WINDOW = int(os.environ.get('CUTIE_AMD_WINDOW', '12'))
 WINDOW_LEAD = int(os.environ.get('CUTIE_AMD_WINDOW_LEAD', '3'))
 
@@ -470,7 +473,8 @@ class InferenceCore:
                 need_weights=self.save_aux, _raw=raw, _split=True)
             self.memory.add_memory(key, shrinkage, msk_value, None, ids, selection=selection, as_permanent=as_permanent)
             feats = pre[2]
-            ev = self._ahead_affinity(feats[2], feats[4], pre[3], self._prefetched_rec, next_mem_ti=self.curr_ti + self.mem_every, first_alone=AFF_FIRST_ALONE)
+            ev = self._ahead_affinity(feats[2], feats[4], pre[3], self._prefetched_rec, next_mem_ti=self.curr_ti + self.mem_every, first_alone=AFF_FIRST_ALONE,
+                                      part='first' if (AFF_FIRST_ALONE and AFF_REST_LATER) else None)
             self._prefetched = pre[:3] + (ev,) + pre[4:]
             sensory, obj_value = finish()
             self.memory.add_object_values(obj_value, ids)

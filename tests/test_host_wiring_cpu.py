@@ -846,6 +846,9 @@ def test_announced_frame_overwritten_in_place_is_encoded_again_cpu():
         _lib.set_executor_for_testing(prev)
 
 
+# (the last step raises in the middle of a frame: its features stay in the image feature store, which says so when it is dropped --
+# "Leaking ... in the image feature store", the reference's own warning for the same situation, image_feature_store.py:47-49)
+@pytest.mark.filterwarnings('ignore:Leaking:UserWarning')
 def test_mask_narrower_than_the_frame_is_padded_on_its_own(product_net, oracle_net):
     """examples/masks/judo/00005.png is 480 x 853 while the frames are 480 x 854: the reference pads frame and mask separately
     (inference_core.py:231,263), so the mask lands with ITS pad offsets in the common padded size.  Same at a small size: frame
