@@ -254,6 +254,57 @@ def test_lockstep_clips_match_sequential(product_net, hinted):
         ex.per_sample_conv = False
 
 
+def test_lockstep_leaves_the_batched_path_when_the_clips_stop_being_uniform(product_net):
+    """LockstepCores: a frame that brings masks, and everything behind it once the clips hold a second bucket (objects added mid-clip,
+    kv_memory_store.py:96-117), run clip by clip through the cores' own step -- still every clip's own results; deleting the second
+    bucket's object brings the group back onto the batched path."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.inference.lockstep import LockstepCores
+    from cutie_amd.utils.synth import SyntheticClip
+    C, T = 2, 12
+    clips = [SyntheticClip(48, 80, 3, T, seed=80 + c) for c in range(C)]
+    frames = [[cl.frame(t) for t in range(T)] for cl in clips]
+    first = [(cl.first_mask() * (cl.first_mask() != 3).long()) for cl in clips]          # objects 1, 2 at t = 0
+    late = [(cl.first_mask() * (cl.first_mask() == 3).long()) for cl in clips]           # object 3 at t = 4 (a second bucket)
+    cfg_kw = dict(mem_every=2)
+
+    def script(step, delete):
+        outs = [step(0, first, [[1, 2]] * C)]
+        for t in range(1, T):
+            if t == 4:
+                outs.append(step(t, late, [[3]] * C))
+            else:
+                if t == 8:
+                    delete([3])
+                outs.append(step(t, None, None))
+        return outs
+    ex = _lib.get_executor()
+    ex.per_sample_conv = True
+    try:
+        with torch.inference_mode():
+            seq = []
+            for c in range(C):
+                proc = InferenceCore(product_net, cfg=default_config(**cfg_kw))
+                seq.append(script(lambda t, m, o: proc.step(frames[c][t], *((m[c],) if m is not None else ()), **(dict(objects=o[c]) if o is not None else {})),
+                                  proc.delete_objects))
+            ls = LockstepCores(product_net, default_config(**cfg_kw), C)
+            counts = []
+
+            def ls_step(t, m, o):
+                r = ls.step([f[t] for f in frames], m, o, **({} if (m is not None or t + 1 >= T) else dict(next_images=[f[t + 1:t + 6] for f in frames])))
+                counts.append(ls.batched_steps)
+                return r
+            got = script(ls_step, lambda ids: [core.delete_objects(ids) for core in ls.cores])
+        # batched: t = 1..3; clip by clip: t = 0, 4 (masks), 5..7 (two buckets) and 8 (object 3 deleted, but the last mask still has its plane: the
+        # cores index it by tmp id, memory_manager.py:90-92); batched again from t = 9
+        assert counts == [0, 1, 2, 3, 3, 3, 3, 3, 3, 4, 5, 6], counts
+        for c in range(C):
+            for t in range(T):
+                assert torch.equal(got[t][c], seq[c][t]), (c, t, float((got[t][c] - seq[c][t]).abs().max()))
+    finally:
+        ex.per_sample_conv = False
+
+
 def test_run_batched_groups_and_uneven_clips(product_net):
     """parallel.run_batched: clips in groups of `lockstep`, a last group of one clip, a clip longer than its group's shortest -- every clip
     gets the object-id masks of its own InferenceCore run."""
