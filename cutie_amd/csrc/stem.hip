@@ -34,10 +34,14 @@
 
 typedef __attribute__((ext_vector_type(4))) unsigned int st_u4;
 
+#define ST_MAXIMG 12
 struct StemParams {
     const float* img; const float* masks; const bf16_t* W; const float* bias; bf16_t* y;
     int h0, w0, H, W_, pl, pt, K, Kpad, relu, gx, nb;
     float m0, m1, m2, s0, s1, s2;
+    // ABI 4: several frames per launch (grid.y): frame f > 0 reads imgs[f - 1] (f = 0: img), masks + f * mstride floats and writes
+    // y + f * K * (H/4) * (W/4) * 64 -- the look-ahead window of the image encoder / the clips of a lock-step group in ONE round-filling launch
+    const float* imgs[ST_MAXIMG - 1]; long mstride;
 };
 
 #define ST_NT 512                                        // 8 waves: 4 pixel groups x 2 channel halves (two waves per SIMD hide each other's LDS latency)
@@ -52,6 +56,11 @@ __global__ __launch_bounds__(ST_NT) void stem_kernel(StemParams p) {
     const int wm = wave & 3, wn = wave >> 2;
     const int k = blockIdx.z;
     const int OH = p.H >> 1, OW = p.W_ >> 1, PH = p.H >> 2, PW = p.W_ >> 2;
+    // (block-uniform) frame blockIdx.y of the launch: its image, masks and output (locals: writing to the by-value parameter struct sends it to scratch)
+    const int fr = blockIdx.y;
+    const float* __restrict__ const img_ = fr > 0 ? p.imgs[fr - 1] : p.img;
+    const float* __restrict__ const masks_ = p.masks ? p.masks + (long)fr * p.mstride : nullptr;
+    bf16_t* __restrict__ const y_ = p.y + (long)fr * p.K * PH * PW * 64;
     // XCD-aware order: hardware block b runs on XCD b % 8; every XCD gets one contiguous band of tiles, so the halo pixels that
     // neighbouring tiles share are fetched into ONE L2 (round-robin order: 21.5 MB fetched per launch for a 4.9 MB frame, rocprofv3 PMC)
     const int per = (p.nb + 7) >> 3;
@@ -90,23 +99,23 @@ __global__ __launch_bounds__(ST_NT) void stem_kernel(StemParams p) {
         const int sy = iy - p.pt, sx = ix - p.pl;
         pim_[t] = pin_[t] && (unsigned)sy < (unsigned)p.h0 && (unsigned)sx < (unsigned)p.w0;
         const long o = (long)min(max(sy, 0), p.h0 - 1) * p.w0 + min(max(sx, 0), p.w0 - 1);     // clamped: the loads are unconditional
-        pr_[t] = p.img[o]; pg_[t] = p.img[plane + o]; pb_[t] = p.img[2 * plane + o];
+        pr_[t] = img_[o]; pg_[t] = img_[plane + o]; pb_[t] = img_[2 * plane + o];
         pm_[t] = 0.f; po_[t] = 0.f;
         mpix_[t] = (long)min(max(iy, 0), p.H - 1) * p.W_ + min(max(ix, 0), p.W_ - 1);
     }
-    if (p.masks) {                                       // (block-uniform)
+    if (masks_) {                                       // (block-uniform)
         // four objects per round, the loads of all six pixels in flight together (a `for (j < K) sum += masks[j]` per pixel compiled to
         // one dependent round trip per object and pixel: 6 (K + 1) of them in front of the first MFMA; tools/isa_waits.py).  Same
         // summation order per pixel: objects ascending.
         float msum[NPIX];
 #pragma unroll
-        for (int t = 0; t < NPIX; ++t) { msum[t] = 0.f; pm_[t] = p.masks[(long)k * HWp + mpix_[t]]; }
+        for (int t = 0; t < NPIX; ++t) { msum[t] = 0.f; pm_[t] = masks_[(long)k * HWp + mpix_[t]]; }
         for (int j0 = 0; j0 < p.K; j0 += 4) {
             float mv[NPIX][4];
 #pragma unroll
             for (int t = 0; t < NPIX; ++t)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) mv[t][u] = p.masks[(long)min(j0 + u, p.K - 1) * HWp + mpix_[t]];
+                for (int u = 0; u < 4; ++u) mv[t][u] = masks_[(long)min(j0 + u, p.K - 1) * HWp + mpix_[t]];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (j0 + u < p.K) {
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(ST_NT) void stem_kernel(StemParams p) {
             for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], 0.f);
         }
         if (py < PH && px < PW)
-            *reinterpret_cast<uint4*>(p.y + (((long)k * PH + py) * PW + px) * 64 + q * 8) =
+            *reinterpret_cast<uint4*>(y_ + (((long)k * PH + py) * PW + px) * 64 + q * 8) =
                 make_uint4(pack_bf2(m[0], m[1]), pack_bf2(m[2], m[3]), pack_bf2(m[4], m[5]), pack_bf2(m[6], m[7]));
         }
     }
@@ -234,6 +243,13 @@ int launch_stem(const cutie_op* op, hipStream_t s) {
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(stem_kernel, dim3(((p.nb + 7) / 8) * 8, 1, p.K), dim3(ST_NT), lds, s, p);
+    int nimg = i[8] > 1 ? i[8] : 1;                      // frames per launch: image f > 0 at p[4 + f] (p5 .. p15), masks i9 floats apart
+    if (nimg > ST_MAXIMG) { cutie_set_error("stem: at most %d frames per launch (%d)", ST_MAXIMG, nimg); return -2; }
+    p.mstride = i[9];
+    for (int f = 1; f < ST_MAXIMG; ++f) {
+        p.imgs[f - 1] = f < nimg ? (const float*)q[4 + f] : nullptr;
+        if (f < nimg && !q[4 + f]) { cutie_set_error("stem: frame %d of %d has no image", f, nimg); return -2; }
+    }
+    hipLaunchKernelGGL(stem_kernel, dim3(((p.nb + 7) / 8) * 8, nimg, p.K), dim3(ST_NT), lds, s, p);
     return (int)hipGetLastError();
 }

@@ -537,6 +537,7 @@ class Plan:
 
 # ---------------------------------------------------------------------------------------------------
 STEM = os.environ.get('CUTIE_AMD_STEM', '1') not in ('', '0')
+STEM_BATCH = os.environ.get('CUTIE_AMD_STEM_BATCH', '1') not in ('', '0')     # the frames of an encoder window / the clips of a lock-step group in one STEM launch (A/B switch)
 
 
 def stem_ok(eng, name):
@@ -558,9 +559,10 @@ def build_encode(eng, h0, w0, H, W, pad_left, pad_top, B=1):
     img = (lambda b: Dyn('image')) if B == 1 else (lambda b: Dyn('image%d' % b))
     if stem_ok(eng, 'pixel_encoder.conv1'):                 # IMG_PREP + 7x7 conv + max pool in one launch (csrc/stem.hip)
         pool = P.buf('pool', (B, H // 4, W // 4, 64))
-        for b in range(B):
-            P.ol.stem(img(b), None, eng.w['pixel_encoder.conv1'], pool[b], h0=h0, w0=w0, H=H, W=W, pad_left=pad_left, pad_top=pad_top, K=1,
-                      mean=m['pixel_mean'], std=m['pixel_std'], relu=True)
+        SM = O.OpList.STEM_MAX_IMAGES if STEM_BATCH else 1
+        for b0 in range(0, B, SM):                          # the frames of a window in launches of up to 12 (one frame is a partial round of blocks)
+            P.ol.stem(img(b0), None, eng.w['pixel_encoder.conv1'], pool[b0:], h0=h0, w0=w0, H=H, W=W, pad_left=pad_left, pad_top=pad_top, K=1,
+                      mean=m['pixel_mean'], std=m['pixel_std'], relu=True, more_images=[img(b) for b in range(b0 + 1, min(B, b0 + SM))])
         x = Act(pool, B, H // 4, W // 4, 64)
     else:
         img8 = P.buf('img8', (B, H, W, 8))
@@ -911,9 +913,13 @@ def build_encode_mask(eng, K, h0, w0, H, W, pad_left, pad_top, deep_update=True,
     assert G == 1 or stem_ok(eng, 'mask_encoder.conv1')
     if stem_ok(eng, 'mask_encoder.conv1'):
         pool = P.buf('pool', (K, H // 4, W // 4, 64))
-        for c in range(G):                               # ("others" = the other objects of the same clip, one frame per clip: a launch per clip)
-            ol.stem(Dyn('image' if G == 1 else 'image%d' % c), masks_of(c), eng.w['mask_encoder.conv1'], pool[c * Kc:], h0=h0, w0=w0, H=H, W=W,
-                    pad_left=pad_left, pad_top=pad_top, K=Kc, mean=m['pixel_mean'], std=m['pixel_std'], relu=True)
+        # ("others" = the other objects of the same clip, one frame per clip: the clips are the FRAMES of one launch -- or a launch per clip)
+        iname = lambda c: Dyn('image' if G == 1 else 'image%d' % c)
+        SM = O.OpList.STEM_MAX_IMAGES if STEM_BATCH else 1
+        for c0 in range(0, G, SM):
+            ol.stem(iname(c0), masks_of(c0), eng.w['mask_encoder.conv1'], pool[c0 * Kc:], h0=h0, w0=w0, H=H, W=W, pad_left=pad_left, pad_top=pad_top,
+                    K=Kc, mean=m['pixel_mean'], std=m['pixel_std'], relu=True, more_images=[iname(c) for c in range(c0 + 1, min(G, c0 + SM))],
+                    mask_stride=(Kc + 1) * H * W)
     else:
         x8 = P.buf('x8', (K, H, W, 8))
         ol.img_prep(Dyn('image'), Dyn('masks'), x8, h0=h0, w0=w0, H=H, W=W, pad_left=pad_left, pad_top=pad_top, K=K,

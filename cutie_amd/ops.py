@@ -418,10 +418,17 @@ class OpList:
         OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         return self.add(MAXPOOL, 1 if relu else 0, [B, H, W, C, OH, OW], [], [x, y])
 
-    def stem(self, image, masks, w, y, *, h0, w0, H, W, pad_left, pad_top, K, mean, std, relu=True):
-        """IMG_PREP + 7x7 / stride-2 conv (w: PackedConv, Cin padded to 8, Cout 64) + 3x3 / stride-2 max pool (+ ReLU) in one launch."""
+    STEM_MAX_IMAGES = 12
+
+    def stem(self, image, masks, w, y, *, h0, w0, H, W, pad_left, pad_top, K, mean, std, relu=True, more_images=(), mask_stride=0):
+        """IMG_PREP + 7x7 / stride-2 conv (w: PackedConv, Cin padded to 8, Cout 64) + 3x3 / stride-2 max pool (+ ReLU) in one launch.
+        more_images (ABI 4, <= 11): further frames of the SAME launch -- frame f reads more_images[f - 1], the masks `mask_stride` floats
+        behind frame f - 1's, and writes behind frame f - 1's output (y holds all frames)."""
         assert w.cout == 64 and w.kh == 7 and w.cin_padded == 8 and H % 16 == 0 and W % 16 == 0
-        return self.add(STEM, 1 if relu else 0, [h0, w0, H, W, pad_left, pad_top, K, w.kpad], list(mean) + list(std), [image, masks, w.weight, w.bias, y])
+        more = list(more_images)
+        assert len(more) < self.STEM_MAX_IMAGES
+        ints = [h0, w0, H, W, pad_left, pad_top, K, w.kpad] + ([1 + len(more), int(mask_stride)] if more else [])
+        return self.add(STEM, 1 if relu else 0, ints, list(mean) + list(std), [image, masks, w.weight, w.bias, y] + more)
 
     def img_prep(self, image, masks, y, *, h0, w0, H, W, pad_left, pad_top, K, mean, std):
         return self.add(IMG_PREP, 0, [h0, w0, H, W, pad_left, pad_top, K], list(mean) + list(std), [image, masks, y])

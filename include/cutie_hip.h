@@ -322,7 +322,10 @@ enum {
      * three ops (bf16 after the conv, max of bf16 values).
      * p0=image f32 [3,h0,w0] p1=masks f32 [K,H,W] (0: none, K = 1) p2=packed weights bf16 [64,Kpad] (k = (kh*7+kw)*8 + c)
      * p3=bias f32 [64] p4=y bf16 [K,H/4,W/4,64]   i: 0 h0 1 w0 2 H 3 W (multiples of 16) 4 pad_left 5 pad_top 6 K 7 Kpad
-     * f: 0-2 mean 3-5 std   flags&1: ReLU (before or after the pool: the same) */
+     * f: 0-2 mean 3-5 std   flags&1: ReLU (before or after the pool: the same)
+     * ABI 4: i8 > 1 = frames per launch (<= 12; grid.y): frame f > 0 reads the image at p[4 + f] (p5 .. p15) and the masks at p1 + f * i9 floats and
+     *      writes y + f * K*(H/4)*(W/4)*64 -- the frames of a look-ahead encoder window, or the clips of a lock-step group (one image + K masks each),
+     *      in one launch that fills the chip (a 480p frame is 210 blocks: a partial round of its own); per frame exactly the one-frame launch */
     CUTIE_OP_STEM = 41,
     /* BANK_WRITE: the contiguous copies and fills of one memory insertion (memory_manager.py:210-296, kv_memory_store.py:55-149: the
      * reference torch.cat's every tensor of the bank; here a frame's keys / shrinkage / selection / per-object values go to their slot)

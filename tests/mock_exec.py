@@ -712,6 +712,14 @@ class MockExecutor:
     def _op_41(self, flags, i, f, p):                                   # STEM = IMG_PREP + conv 7x7 s2 p3 (+ bias) + maxpool 3x3 s2 p1 (+ relu)
         h0, w0, H, W, pl, pt, K, Kpad = i[:8]
         K = K if p[1] else 1
+        if i[8] > 1:                                                    # several frames per launch: frame by frame with the pointers advanced
+            for fr in range(i[8]):
+                pf = list(p[:5]) + [0] * 11
+                pf[0] = p[0] if fr == 0 else p[4 + fr]
+                pf[1] = p[1] + 4 * fr * i[9] if p[1] else 0
+                pf[4] = p[4] + 2 * fr * K * (H // 4) * (W // 4) * 64
+                self._op_41(flags, i[:8] + [0] * 16, f, pf)
+            return
         img = view(p[0], F32, (3, h0, w0))
         full = torch.zeros(3, H, W)
         full[:, pt:pt + h0, pl:pl + w0] = img

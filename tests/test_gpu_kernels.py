@@ -1665,3 +1665,43 @@ def test_q2p_chain_clip_objects(Kg, qpre):
         ol2.run()
         torch.cuda.synchronize()
         assert not torch.equal(acc_a, acc_c)
+
+
+@pytest.mark.parametrize('geo', [(480, 854, 480, 864, 5, 0, 0, 12), (100, 120, 112, 128, 4, 6, 2, 3), (30, 43, 32, 48, 2, 1, 3, 5)])
+def test_stem_several_frames_per_launch(geo):
+    """STEM i8 / i9 (ABI 4): the frames of an encoder window (no masks) or the clips of a lock-step group (K masks each, a fixed stride apart)
+    in ONE launch -- bit-identical to one launch per frame; and the interpreter's reading of the descriptor."""
+    h0, w0, H, W, pl, pt, K, NI = geo
+    g = _gen(sum(geo))
+    imgs = [torch.rand((3, h0, w0), generator=g).cuda() for _ in range(NI)]
+    Kk = max(K, 1)
+    masks = None
+    if K:
+        masks = torch.rand((NI, K + 1, H, W), generator=g)
+        masks = (masks * (torch.rand((NI, K + 1, H, W), generator=g) > 0.5)).cuda()      # clip f's object planes at [f, 1:]
+    wt = torch.randn((64, 8, 7, 7), generator=g) / math.sqrt(147)
+    wt[:, 5 if K else 3:] = 0
+    pc = pack_conv(wt, torch.randn(64, generator=g) * 0.1, 'cuda')
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    ya, yb = (torch.zeros((NI * Kk, H // 4, W // 4, 64), dtype=BF16, device='cuda') for _ in range(2))
+    kw = dict(h0=h0, w0=w0, H=H, W=W, pad_left=pl, pad_top=pt, K=Kk, mean=mean, std=std, relu=True)
+    ol = O.OpList()
+    ol.stem(imgs[0], masks[0, 1:] if K else None, pc, ya, more_images=imgs[1:], mask_stride=(K + 1) * H * W, **kw)
+    for f in range(NI):
+        ol.stem(imgs[f], masks[f, 1:] if K else None, pc, yb[f * Kk:], **kw)
+    ol.run()
+    torch.cuda.synchronize()
+    assert torch.equal(ya.view(torch.int16), yb.view(torch.int16))
+
+    def build(dev, gg):
+        im = [torch.rand((3, 20, 30), generator=gg).to(dev) for _ in range(3)]
+        mk = torch.rand((3, 3, 32, 32), generator=gg).to(dev)
+        w2 = torch.randn((64, 8, 7, 7), generator=gg) / math.sqrt(147)
+        w2[:, 5:] = 0
+        p2 = pack_conv(w2, torch.randn(64, generator=gg) * 0.1, dev)
+        yy = torch.zeros((3 * 2, 8, 8, 64), dtype=BF16, device=dev)
+        o = O.OpList()
+        o.keep += [p2.weight]
+        o.stem(im[0], mk[0, 1:], p2, yy, h0=20, w0=30, H=32, W=32, pad_left=1, pad_top=6, K=2, mean=mean, std=std, more_images=im[1:], mask_stride=3 * 32 * 32)
+        return o, {'y': yy}
+    check(*run_both(build, seed=3), name='stem frames')
