@@ -357,6 +357,36 @@ class LockstepCores:
     def output_prob_to_mask(self, probs: Sequence[torch.Tensor], **kw) -> List[torch.Tensor]:
         return [core.output_prob_to_mask(p, **kw) for core, p in zip(self.cores, probs)]
 
+    # ---- the rest of InferenceCore's surface, clip by clip (inference_core.py:52-69, :330-335) ------------------------------------------
+    def __getitem__(self, c: int) -> InferenceCore:
+        return self.cores[c]
+
+    def delete_objects(self, objects: Sequence[Sequence[int]]) -> None:
+        """objects[c]: the ids to delete from clip c (the group leaves the batched path for a step: the last masks still carry their planes)."""
+        for c, (core, ids) in enumerate(zip(self.cores, objects)):
+            if ids:
+                with frame_context.context(self._ctx[c]):
+                    core.delete_objects(list(ids))
+
+    def _each(self, method, *a, **k):
+        self._drop_lookahead()
+        self._md_valid = False
+        for c, core in enumerate(self.cores):
+            with frame_context.context(self._ctx[c]):
+                getattr(core, method)(*a, **k)
+
+    def clear_memory(self):
+        self._each('clear_memory')
+
+    def clear_non_permanent_memory(self):
+        self._each('clear_non_permanent_memory')
+
+    def clear_sensory_memory(self):
+        self._each('clear_sensory_memory')
+
+    def update_config(self, cfg):
+        self._each('update_config', cfg)
+
 
 def _f32c(t):
     if t.dtype != F32:

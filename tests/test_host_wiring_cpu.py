@@ -294,7 +294,7 @@ def test_lockstep_leaves_the_batched_path_when_the_clips_stop_being_uniform(prod
                 r = ls.step([f[t] for f in frames], m, o, **({} if (m is not None or t + 1 >= T) else dict(next_images=[f[t + 1:t + 6] for f in frames])))
                 counts.append(ls.batched_steps)
                 return r
-            got = script(ls_step, lambda ids: [core.delete_objects(ids) for core in ls.cores])
+            got = script(ls_step, lambda ids: ls.delete_objects([ids] * C))
         # batched: t = 1..3; clip by clip: t = 0, 4 (masks), 5..7 (two buckets) and 8 (object 3 deleted, but the last mask still has its plane: the
         # cores index it by tmp id, memory_manager.py:90-92); batched again from t = 9
         assert counts == [0, 1, 2, 3, 3, 3, 3, 3, 3, 4, 5, 6], counts
