@@ -881,6 +881,40 @@ def test_lockstep_clips_match_sequential(gpu_net, size, K, C, T, cfg_kw, hinted)
         assert torch.equal(got, seq[c][0]), (c, [float((got[t] - seq[c][0][t]).abs().max()) for t in range(T)])
 
 
+def test_run_batched_groups_in_flight_and_small_model():
+    """parallel.run_batched on the MI355X: lock-step groups one after the other and IN FLIGHT next to each other (a stream + CUTIE.fork() per
+    group) give every clip the object-id masks of its own InferenceCore run -- on cutie-small (ResNet-18 pixel encoder: other channel counts in
+    every per-clip broadcast), clips of unequal length, a last group of one clip."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.model.cutie import CUTIE
+    from cutie_amd.parallel import run_batched
+    from cutie_amd.utils.synth import SyntheticClip
+    from cutie_amd.utils.synth_weights import make_state_dict as mk, MODEL_CFG_SMALL
+    cfg_kw = dict(model='small', mem_every=3)
+    net = CUTIE(default_config(**cfg_kw)).cuda().eval()
+    net.load_weights(mk(seed=0, m=MODEL_CFG_SMALL))
+    lens = [11, 11, 9, 12, 10]
+    clips = []
+    for c, T in enumerate(lens):
+        cl = SyntheticClip(240, 432, 2, T, seed=90 + c)
+        clips.append(dict(frames=[cl.frame(t).cuda() for t in range(T)], mask=cl.first_mask().cuda(), objects=cl.objects))
+    with torch.inference_mode():
+        want = []
+        for c, cl in enumerate(clips):
+            proc = InferenceCore(net, cfg=default_config(**cfg_kw))
+            w = [proc.output_prob_to_mask(proc.step(cl['frames'][0], cl['mask'], objects=cl['objects']), dtype=torch.uint8)]
+            for t in range(1, lens[c]):
+                w.append(proc.output_prob_to_mask(proc.step(cl['frames'][t], end=(t == lens[c] - 1)), dtype=torch.uint8))
+            want.append(torch.stack(w).cpu())
+    for in_flight in (1, 3):
+        got = run_batched(net, default_config(**cfg_kw), clips, lockstep=2, in_flight=in_flight, lookahead=8)
+        torch.cuda.synchronize()
+        assert not net.engine().one_lane
+        for c in range(len(clips)):
+            g = torch.stack(got[c]).cpu()
+            assert g.shape == want[c].shape and torch.equal(g, want[c]), (in_flight, c, int((g != want[c]).sum()))
+
+
 def test_eval_driver_on_bike_example(gpu_net, tmp_path):
     """Section 8(f) rank 1: the bike frames through VideoReader -> InferenceCore -> fused argmax/remap -> PNG writer; the first
     PNG reproduces the annotation, every PNG equals output_prob_to_mask of a second pass."""
