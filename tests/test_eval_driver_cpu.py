@@ -100,6 +100,47 @@ def test_eval_driver_writes_palette_pngs(tmp_path, product_net):
         assert torch.equal(proc.output_prob_to_mask(prob, dtype=torch.uint8).long(), ids)
 
 
+def test_videos_in_lock_step_write_the_same_pngs(tmp_path, product_net):
+    """eval_vos.process_videos_lockstep (the --lockstep option of the dataset driver): two videos of one frame size and object count, of
+    different lengths, advanced in lock step write byte for byte the PNGs that process_video writes for each of them alone; lockstep_key
+    tells which videos may share a group."""
+    from cutie_amd.eval_vos import lockstep_key, process_video, process_videos_lockstep
+    from cutie_amd.inference.data.vos_test_dataset import VOSTestDataset
+
+    def make(name, n, ids, seed):
+        from cutie_amd.utils.synth import SyntheticClip
+        root = str(tmp_path)
+        clip = SyntheticClip(64, 96, len(ids), n, seed=seed)
+        os.makedirs(os.path.join(root, 'JPEGImages', name)); os.makedirs(os.path.join(root, 'Annotations', name))
+        for t in range(n):
+            arr = (clip.frame(t).permute(1, 2, 0).numpy() * 255).round().astype(np.uint8)
+            Image.fromarray(arr).save(os.path.join(root, 'JPEGImages', name, f'{t:05d}.jpg'), quality=95)
+        lut = np.zeros(256, dtype=np.uint8)
+        for k, oid in enumerate(ids):
+            lut[k + 1] = oid
+        png = Image.fromarray(lut[clip.first_mask().numpy()].astype(np.uint8))
+        png.putpalette(davis_palette)
+        png.save(os.path.join(root, 'Annotations', name, '00000.png'))
+    make('vA', 5, (1, 2), 21)
+    make('vB', 7, (4, 9), 22)
+    make('vC', 4, (1, 2, 3), 23)
+    ds = VOSTestDataset(os.path.join(tmp_path, 'JPEGImages'), os.path.join(tmp_path, 'Annotations'), use_all_masks=False)
+    rds = {rd.vid_name: rd for rd in ds.get_datasets()}
+    assert lockstep_key(rds['vA']) == lockstep_key(rds['vB']) == ((64, 96), 2, False) and lockstep_key(rds['vC']) == ((64, 96), 3, False)
+    cfg = default_config(mem_every=2)
+    with torch.inference_mode():
+        alone = {}
+        for n in ('vA', 'vB'):
+            alone[n] = process_video(product_net, cfg, rds[n], os.path.join(tmp_path, 'alone'))
+        st = process_videos_lockstep(product_net, cfg, [rds['vA'], rds['vB']], os.path.join(tmp_path, 'ls'))
+    assert st[0]['frames'] == 5 and st[1]['frames'] == 7 and st[0]['seconds'] > 0
+    for n, T in (('vA', 5), ('vB', 7)):
+        fa, fl = sorted(os.listdir(os.path.join(tmp_path, 'alone', n))), sorted(os.listdir(os.path.join(tmp_path, 'ls', n)))
+        assert fa == fl and len(fa) == T
+        for f in fa:
+            assert open(os.path.join(tmp_path, 'alone', n, f), 'rb').read() == open(os.path.join(tmp_path, 'ls', n, f), 'rb').read(), (n, f)
+
+
 def test_video_reader_options_and_long_ids(tmp_path):
     """start / end / reverse / enabled_frame_list / to_save / use_all_masks, RGB long-id masks (id = R + 256 G + 65536 B) and the
     long-id writer (random colour per object, as the reference); make_zip layouts."""
