@@ -86,12 +86,18 @@ struct ScoreParams {
     int prio;                                            // 1: s_setprio 1 (a read-out the caller's stream waits for; the stacked look-ahead passes stay at 0)
     int gbase, grem;                                     // 4-tile groups per block row: row by owns gbase (+ 1 if by < grem) groups
     int HWpf;                                            // query rows per frame (HWp = frames x HWpf; row j is a real query iff j % HWpf < HW)
+    // ABI 4, clips in lock step (flags&4): the stacked frames belong to nbanks different memory banks, frame e to bank e % nbanks -- (A_hi, A_lo,
+    // scale) of bank b at tbl[3 b ..]; the token ranges are those of every bank (banks of clips in lock step have one schedule)
+    const unsigned long long* tbl; int nbanks;
 #ifdef AFF_TIMELINE
     unsigned long long* tl;                              // (diagnostic library only: where the cycle stamps go; p10 of the op)
 #endif
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int au32x4;
+typedef const __attribute__((address_space(1))) au32x4* aff_gptr16;
+typedef const __attribute__((address_space(4))) unsigned long long* aff_ctbl;
+typedef const __attribute__((address_space(1))) float* aff_gf32;      // (a pointer loaded from memory has no address space: say global, or hipcc emits flat_load)
 
 // grid (ceil(HWp/128), ceil(G/tiles_per_block)); wave w of the block owns queries j0 + 32w .. +31 (two MFMA column sets).
 // The memory operands of 4 consecutive 16-token tiles (64 rows x [hi|lo] x 256 B = 32 KB) are staged ONCE per block in
@@ -147,7 +153,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int au32x4;
 // of the iteration (both passes: the prefetch never overlapped the barrier).  Registers fed by global loads are waited for by the
 // compiler where AFF_STORE uses them.
 #define AFF_SYNC() { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(15 | (3 << 14) | (7 << 4) | (0 << 8)); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-template <int AFF_NQ, int AFF_MODE>                   // 16-query column sets per wave (1 or 2)
+template <int AFF_NQ, int AFF_MODE, bool JT = false>  // 16-query column sets per wave (1 or 2); JT: one bank per stacked frame (see ScoreParams::tbl)
 __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
     if (p.prio) __builtin_amdgcn_s_setprio(1);
     constexpr int mode = AFF_MODE;
@@ -175,6 +181,13 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
     // (timeline builds: mode 0 parks the stamps in the unused candidate-list area, mode 1 in 3040 B the launch adds behind the regular LDS)
     ATL_DECL(mode == 0 ? aff_smem + 2 * 2 * 64 * 16 * 16 + 4096 : aff_smem + AFF_LDS_BYTES)
     ATL(0)
+    // JT: the bank of this block's queries (a block's 64 * AFF_NQ query rows lie inside ONE frame: the launcher insists on HWpf % (64 * AFF_NQ) == 0)
+    const bf16_t* Ahi_ = p.Ahi; const bf16_t* Alo_ = p.Alo; const float* scale_ = p.scale;
+    if constexpr (JT) {
+        const int b_ = __builtin_amdgcn_readfirstlane(((bx * (64 * AFF_NQ)) / p.HWpf) % p.nbanks);      // (the division runs on the VALU: say that the result is uniform, or the table is read by vector loads)
+        const aff_ctbl tb_ = (aff_ctbl)p.tbl + 3 * b_;        // (constant address space: scalar loads -- a plain global load may not be scalar in a kernel that stores)
+        Ahi_ = reinterpret_cast<const bf16_t*>(tb_[0]); Alo_ = reinterpret_cast<const bf16_t*>(tb_[1]); scale_ = reinterpret_cast<const float*>(tb_[2]);
+    }
     int* wl_j = l_j + wave * AFF_WCAP; int* wl_idx = l_idx + wave * AFF_WCAP; float* wl_val = l_val + wave * AFF_WCAP;
     int wcount = 0;                                                     // wave-uniform fill of the wave's list
     int jq[AFF_NQ];                                                     // query column of this lane, per set
@@ -232,12 +245,12 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
             const int row_ = sr8 + 8 * (e & 1);                                                            \
             const long off_ = (long)(slot0_ + min(row_, nv_ - 1)) * 128 + (c8l + 8 * (e >> 1)) * 8;        \
-            st[e] = *reinterpret_cast<const au32x4*>(p.Ahi + off_);                                        \
-            st[4 + e] = *reinterpret_cast<const au32x4*>(p.Alo + off_);                                    \
+            st[e] = JT ? *(aff_gptr16)(Ahi_ + off_) : *reinterpret_cast<const au32x4*>(p.Ahi + off_);       \
+            st[4 + e] = JT ? *(aff_gptr16)(Alo_ + off_) : *reinterpret_cast<const au32x4*>(p.Alo + off_);   \
         }                                                                                                  \
         /* the per-token scale rides along: a global load inside the MFMA loop would make every tile wait for this whole */ \
         /* prefetch (vmcnt is in-order); unconditional load of a clamped row, selected afterwards */       \
-        st_sc = p.scale[slot0_ + min(l15, nv_ - 1)];           /* (looked at in AFF_STORE: a select here waits for it) */ \
+        st_sc = JT ? ((aff_gf32)scale_)[slot0_ + min(l15, nv_ - 1)] : p.scale[slot0_ + min(l15, nv_ - 1)];   /* (looked at in AFF_STORE: a select here waits for it) */ \
         st_nv = nv_;                                                                                       \
         if (skip) {                                                                                        \
             _Pragma("unroll") for (int u = 0; u < AFF_NQ; ++u)                                             \
@@ -497,9 +510,8 @@ typedef __amdgpu_buffer_rsrc_t aff_rsrc_t;
 #define AF4_PRE 4096
 #define AF4_STAGE (2 * 64 * 256)                      // [hi | lo] x 64 rows x 256 B
 #define AF4_LDS_BYTES (2 * AF4_STAGE + AFF_LCAP * 12 + 16 + 2 * 2 * 64 * 4)
-typedef const __attribute__((address_space(1))) au32x4* aff_gptr16;
 
-template <int NQ, int AFF_MODE>                       // NQ: 16-query column sets per wave (2 or 4)
+template <int NQ, int AFF_MODE, bool JT = false>      // NQ: 16-query column sets per wave (2 or 4); JT: one bank per stacked frame (see ScoreParams::tbl)
 __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
 #if __HIP_DEVICE_COMPILE__
     if (p.prio) __builtin_amdgcn_s_setprio(1);
@@ -536,8 +548,14 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
         slot0 = start + lt * 16;
         nvalid = min(16, n - lt * 16);
     };
-    const aff_rsrc_t rhi = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(const_cast<bf16_t*>(p.Ahi)) - AF4_PRE, 0, 0x7fffffff, 0x00020000);
-    const aff_rsrc_t rlo = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(const_cast<bf16_t*>(p.Alo)) - AF4_PRE, 0, 0x7fffffff, 0x00020000);
+    const bf16_t* Ahi_ = p.Ahi; const bf16_t* Alo_ = p.Alo; const float* scale_ = p.scale;
+    if constexpr (JT) {                                                 // the bank of this block's queries (4 * WQ rows inside ONE frame)
+        const int b_ = __builtin_amdgcn_readfirstlane(((bx * (4 * WQ)) / p.HWpf) % p.nbanks);
+        const aff_ctbl tb_ = (aff_ctbl)p.tbl + 3 * b_;        // (constant address space: scalar loads -- a plain global load may not be scalar in a kernel that stores)
+        Ahi_ = reinterpret_cast<const bf16_t*>(tb_[0]); Alo_ = reinterpret_cast<const bf16_t*>(tb_[1]); scale_ = reinterpret_cast<const float*>(tb_[2]);
+    }
+    const aff_rsrc_t rhi = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(const_cast<bf16_t*>(JT ? Ahi_ : p.Ahi)) - AF4_PRE, 0, 0x7fffffff, 0x00020000);
+    const aff_rsrc_t rlo = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(const_cast<bf16_t*>(JT ? Alo_ : p.Alo)) - AF4_PRE, 0, 0x7fffffff, 0x00020000);
     float st_sc = 0.f;
     int st_nv = 0;
     f32x4 gq[NQ];                                                       // pass-0 maxima of the NEXT group's 4 tiles (mode 1 + skip)
@@ -576,7 +594,7 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
         unsigned char* const dst_ = aff_smem + (STG) * AF4_STAGE + wave * 4096;                            \
         /* the per-token scale: an unconditional (clamped) load whose value is looked at only where it is written to LDS, one */ \
         /* group later (a select right here made hipcc wait -- vmcnt(0) -- in the middle of the DMA pieces) */ \
-        st_sc = p.scale[slot0_ + min(l15, nv_ - 1)];                                                       \
+        st_sc = JT ? ((aff_gf32)scale_)[slot0_ + min(l15, nv_ - 1)] : p.scale[slot0_ + min(l15, nv_ - 1)];   \
         st_nv = nv_;                                                                                       \
         AF4_PIECE(0) AF4_PIECE(1) AF4_PIECE(2) AF4_PIECE(3)                                                \
         if (skip && wave_on) {                                                                             \
@@ -853,7 +871,7 @@ typedef const __attribute__((address_space(1))) ro_u32x4* ro_gptr;
 __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
                                                                  const int* __restrict__ count, const uint64_t* __restrict__ vptrs,
                                                                  float* __restrict__ usage, bf16_t* __restrict__ y, int* __restrict__ overflow,
-                                                                 int HW, int cap, int topk, int K, int CV, int HWpf, int nrows, int ustride, int prio) {
+                                                                 int HW, int cap, int topk, int K, int CV, int HWpf, int nrows, int ustride, int prio, int nbanks) {
     if (prio) __builtin_amdgcn_s_setprio(1);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float* cv = reinterpret_cast<float*>(lds_raw);             // [cap]
@@ -875,6 +893,7 @@ __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __
     if (jl >= HW) return;
     y += (long)fr * K * HW * CV;
     if (usage) usage += (long)fr * ustride;
+    if (nbanks > 1) vptrs += (long)(fr % nbanks) * K;          // (ABI 4) clips in lock step: frame fr reads bank fr % nbanks, whose K value-bank bases follow each other
     // every global round trip that does not depend on another is issued up front: the count, the first RO_THREADS
     // candidates (typical fill is 30-50 of the 1024 slots), the bank base pointer of this thread's object
     const int C8 = CV >> 3;
@@ -1018,22 +1037,31 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             sp.G = i[9]; sp.cap = i[10]; sp.mode = i[11]; sp.Gld = (sp.G + 63) / 64 * 64;
             sp.prio = (op->flags & 64) ? 1 : 0;
             sp.HWpf = i[16] > 0 ? i[16] : sp.HWp;              // i[16]: query rows per frame when one launch serves several frames (HWp = frames x i[16])
+            const bool jt = (op->flags & 4) != 0;               // (ABI 4) the stacked frames read different banks: p11 = (A_hi, A_lo, scale) per bank, i17 = banks
+            sp.tbl = jt ? (const unsigned long long*)p[11] : nullptr; sp.nbanks = jt ? i[17] : 1;
             if (sp.HWp % sp.HWpf || sp.HW > sp.HWpf) { cutie_set_error("aff_score: HWp=%d is not a multiple of the rows per frame %d (HW=%d)", sp.HWp, sp.HWpf, sp.HW); return -2; }
             int G = 0;
             for (int r = 0; r < 3; ++r) G += (sp.rn[r] + 15) / 16;
             if (G != sp.G || (sp.HWp & 63) || sp.nranges < 1 || sp.nranges > 3 || (sp.Gld & 3)) { cutie_set_error("aff_score: bad ranges (G=%d vs %d, HWp=%d)", G, sp.G, sp.HWp); return -2; }
             const bool dma = i[12] == 4 || i[15] == 1;          // aff_score4_kernel (LDS-DMA staging): always for 4 sets per wave, for 2 when i[15] = 1
             const int nq = i[12] == 1 ? 1 : (i[12] == 4 ? 4 : 2);
+            if (jt && (nq != 2 || !sp.tbl || sp.nbanks < 2 || (sp.HWp / sp.HWpf) % sp.nbanks || sp.HWpf % 128)) {
+                cutie_set_error("aff_score (flags&4): needs 2 query sets per wave, the bank table, frames %% banks == 0 and rows per frame %% 128 == 0 (nq=%d banks=%d frames=%d rows=%d)",
+                                nq, sp.nbanks, sp.HWp / sp.HWpf, sp.HWpf);
+                return -2;
+            }
             int qb = (sp.HWp + 64 * nq - 1) / (64 * nq);
             if (sp.mode != 0 && sp.mode != 1) { cutie_set_error("aff_score: mode %d", sp.mode); return -2; }
             const int pass = sp.mode;
             if (pass == 1 && (op->flags & 1)) sp.mode |= 2;     // pass-0 maxima precede tau in memory: tiles without candidates are skipped
             static bool lds_attr_set = false;
             if (!lds_attr_set) {
-                const void* ks[8] = {reinterpret_cast<const void*>(aff_score_kernel<1, 0>), reinterpret_cast<const void*>(aff_score_kernel<1, 1>),
-                                     reinterpret_cast<const void*>(aff_score_kernel<2, 0>), reinterpret_cast<const void*>(aff_score_kernel<2, 1>),
-                                     reinterpret_cast<const void*>(aff_score4_kernel<4, 0>), reinterpret_cast<const void*>(aff_score4_kernel<4, 1>),
-                                     reinterpret_cast<const void*>(aff_score4_kernel<2, 0>), reinterpret_cast<const void*>(aff_score4_kernel<2, 1>)};
+                const void* ks[12] = {reinterpret_cast<const void*>(aff_score_kernel<1, 0>), reinterpret_cast<const void*>(aff_score_kernel<1, 1>),
+                                      reinterpret_cast<const void*>(aff_score_kernel<2, 0>), reinterpret_cast<const void*>(aff_score_kernel<2, 1>),
+                                      reinterpret_cast<const void*>(aff_score4_kernel<4, 0>), reinterpret_cast<const void*>(aff_score4_kernel<4, 1>),
+                                      reinterpret_cast<const void*>(aff_score4_kernel<2, 0>), reinterpret_cast<const void*>(aff_score4_kernel<2, 1>),
+                                      reinterpret_cast<const void*>(aff_score_kernel<2, 0, true>), reinterpret_cast<const void*>(aff_score_kernel<2, 1, true>),
+                                      reinterpret_cast<const void*>(aff_score4_kernel<2, 0, true>), reinterpret_cast<const void*>(aff_score4_kernel<2, 1, true>)};
                 static_assert(AF4_LDS_BYTES == AFF_LDS_BYTES, "one dynamic-LDS size for all score kernels");
                 for (const void* k : ks)
                     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -1064,7 +1092,11 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
 #else
             const int lds2 = AFF_LDS_BYTES;
 #endif
-            if (nq == 4 && pass == 0) hipLaunchKernelGGL((aff_score4_kernel<4, 0>), grid, dim3(256), lds4, s, sp);
+            if (jt && dma && pass == 0) hipLaunchKernelGGL((aff_score4_kernel<2, 0, true>), grid, dim3(256), lds4, s, sp);
+            else if (jt && dma) hipLaunchKernelGGL((aff_score4_kernel<2, 1, true>), grid, dim3(256), lds4, s, sp);
+            else if (jt && pass == 0) hipLaunchKernelGGL((aff_score_kernel<2, 0, true>), grid, dim3(256), lds2, s, sp);
+            else if (jt) hipLaunchKernelGGL((aff_score_kernel<2, 1, true>), grid, dim3(256), lds2, s, sp);
+            else if (nq == 4 && pass == 0) hipLaunchKernelGGL((aff_score4_kernel<4, 0>), grid, dim3(256), lds4, s, sp);
             else if (nq == 4) hipLaunchKernelGGL((aff_score4_kernel<4, 1>), grid, dim3(256), lds4, s, sp);
             else if (dma && nq == 2 && pass == 0) hipLaunchKernelGGL((aff_score4_kernel<2, 0>), grid, dim3(256), lds4, s, sp);
             else if (dma && nq == 2) hipLaunchKernelGGL((aff_score4_kernel<2, 1>), grid, dim3(256), lds4, s, sp);
@@ -1099,9 +1131,10 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             // i[5] > 1: that many frames of i[6] query rows each; i[7] = floats between the frames' usage buffers
             const int frames = i[5] > 1 ? i[5] : 1;
             const int nrows = frames > 1 ? frames * i[6] : i[0];
+            if (i[8] > 1 && frames % i[8]) { cutie_set_error("aff_readout: %d frames over %d banks", frames, i[8]); return -2; }
             hipLaunchKernelGGL(aff_readout_kernel, dim3(((nrows + 7) / 8) * 8), dim3(RO_THREADS), lds, s, (const float*)p[0], (const int*)p[1], (const int*)p[2],
                                (const uint64_t*)p[3], (float*)p[4], (bf16_t*)p[5], (int*)p[6], i[0], i[1], i[2], i[3], i[4],
-                               frames > 1 ? i[6] : nrows, nrows, i[7], (op->flags & 64) ? 1 : 0);
+                               frames > 1 ? i[6] : nrows, nrows, i[7], (op->flags & 64) ? 1 : 0, i[8] > 1 ? i[8] : 1);
             break;
         }
         default:

@@ -44,6 +44,9 @@ class LockstepCores:
     # (defaults set per group size in __init__: clips x WINDOW ~ 12 frames per plan, the batch the conv tile table was swept for)
     WINDOW = int(os.environ.get('CUTIE_AMD_LS_WINDOW', '0'))
     WINDOW_LEAD = int(os.environ.get('CUTIE_AMD_LS_LEAD', '1'))
+    # one look-ahead read-out for the banks of ALL clips (MemoryManager.prefetch_affinity_joint: the encoder window is then laid out frame-major, so
+    # that frame j of every clip -- and with it the read-outs pixel fusion takes -- is one stacked tensor); off: every clip's own look-ahead lane (A/B switch)
+    JOINT = os.environ.get('CUTIE_AMD_LS_JOINT', '1') not in ('', '0')
 
     def __init__(self, network, cfg, clips: int):
         self.network = network
@@ -59,6 +62,8 @@ class LockstepCores:
         self._qtoken = None             # content tokens of the object summaries the transformer's queries were initialised from
         self._win_stream = None
         self.batched_steps = 0          # (diagnostic: how many steps ran as one plan per stage)
+        self.joint_passes = 0           # (... read-out passes over the banks of all clips, _ahead_joint)
+        self.stacked_steps = 0          # (... steps whose pixel fusion took the clips' read-outs as one tensor)
 
     def __len__(self):
         return len(self.cores)
@@ -126,7 +131,8 @@ class LockstepCores:
                 preps.append([core._prepare_image(img) for img in frames[c]])
         h0, w0, H, W, pad = preps[0][0][1]
         geometry = (h0, w0, H, W, pad[0], pad[2])
-        flat = [preps[c][j][0] for c in range(G) for j in range(n)]
+        fm = self.JOINT                                  # frame-major: frame j of clip c is entry j * G + c of the batch
+        flat = [preps[c][j][0] for j in range(n) for c in range(G)] if fm else [preps[c][j][0] for c in range(G) for j in range(n)]
         win = ev = None
         if gpu and ahead:
             main = torch.cuda.current_stream(dev)
@@ -143,8 +149,8 @@ class LockstepCores:
                 ev.record(win)
         for c, core in enumerate(cores):
             for j in range(n):
-                o = recs[c * n + j]
-                o['_wstride'] = n                       # frames between the clips in this batch's outputs
+                o = recs[j * G + c] if fm else recs[c * n + j]
+                o['_wstride'] = 1 if fm else n          # frames between the clips in this batch's outputs
                 if win is not None:
                     for t in o.values():
                         if isinstance(t, torch.Tensor) and t.is_cuda:
@@ -188,12 +194,107 @@ class LockstepCores:
             self._encode_batch([[ni[j] for j in todo] for ni in next_images], [[ks[j] for j in todo] for ks in keys], ahead=True)
         for c, core in enumerate(cores):
             core._prefetched_group = (next_images[c], keys[c])          # (the announcement: _ahead_affinity forms its batches from it)
+        if not affinity or self._ahead_joint(cores[0].last_mem_ti + cores[0].mem_every, first_alone=False):
+            return
+        for c, core in enumerate(cores):
             ent = core._window.get(keys[c][0])
-            if ent is None or not affinity:
+            if ent is None:
                 continue
             with frame_context.context(self._ctx[c]):
                 _, _, key, _, selection = net._adopt_encoded(ent[1])
                 core._ahead_affinity(key, selection, ent[2], ent[1], next_mem_ti=core.last_mem_ti + core.mem_every)
+
+    def _ahead_joint(self, next_mem_ti: int, first_alone: bool) -> bool:
+        """The look-ahead read-outs of all clips in one pass per bank version (what InferenceCore._ahead_affinity does for one clip, with
+        MemoryManager.prefetch_affinity_joint instead of prefetch_affinity_batch): the announced frames up to and including the next
+        memory frame, as far as they lie behind each other in one frame-major encoder batch; first_alone (a memory frame): the next frame
+        of every clip as a pass of its own -- the next step waits for it -- and the rest of the memory cycle behind it.  False: not
+        possible here (the caller lets every clip's own look-ahead lane do it)."""
+        if not self.JOINT:
+            return False
+        cores, net = self.cores, self.network
+        c0 = cores[0]
+        dev = net.device
+        gpu = dev.type == 'cuda'
+        grp = [core._prefetched_group for core in cores]
+        if IC.AFF_BATCH <= 1 or any(g is None for g in grp):
+            return False
+        n = min(IC.AFF_BATCH, next_mem_ti - c0.curr_ti, min(len(g[1]) for g in grp))
+        frames = []
+        for j in range(n):
+            ent = [core._window.get(g[1][j]) for core, g in zip(cores, grp)]
+            if not self._one_batch(ent) or ent[0][1]['_wstride'] != 1:
+                break
+            frames.append(ent)
+        if not frames:
+            return False
+        mms = [core.memory for core in cores]
+        if any(len(mm.buckets) != 1 or not mm.engaged for mm in mms):
+            return False
+
+        def operands(r):
+            q = r.get('_qo')
+            if q is None:
+                q = r['_qo'] = dict(Bhi=r['Bhi'], Blo=r['Blo'], cq=r['cq'], h=r['h'], w=r['w'])
+            return q
+
+        def read(ent):                                          # every clip's frame carries a read-out of its bank as it is now
+            for e, mm in zip(ent, mms):
+                done = e[1].get('_qo', {}).get('_readouts')
+                if not done or set(done) != set(mm.buckets) or any(v[1] != mm._version for v in done.values()):
+                    return False
+            return True
+        if read(frames[0]):
+            return True
+        hwp = frames[0][0][1]['Bhi'].shape[0]
+        G = len(cores)
+
+        def behind(ent, last):                                  # one encoder batch, the frame's rows right behind the last frame's
+            return ent[0][2] is last[0][2] and ent[0][1]['Bhi'].data_ptr() == last[0][1]['Bhi'].data_ptr() + G * hwp * 256
+        runs = [[frames[0]]]
+        for ent in frames[1:]:
+            if len(runs) == 1 and first_alone:
+                runs.append([ent])
+            elif behind(ent, runs[-1][-1]):
+                runs[-1].append(ent)
+            else:
+                break                                           # another encoder batch: read when its turn comes
+        enc = main = None
+        if gpu:
+            main = torch.cuda.current_stream(dev)
+            enc = c0._side_stream(dev)
+            enc.wait_stream(main)
+        pool = net.engine().pool
+        pool.offset = 1
+
+        def record():
+            if not gpu:
+                return None
+            e = torch.cuda.Event()
+            e.record(enc)
+            return e
+        ok = True
+        try:
+            with (torch.cuda.stream(enc) if gpu else contextlib.nullcontext()):
+                for i, run in enumerate(runs):
+                    if gpu and run[0][0][2] is not None:
+                        enc.wait_event(run[0][0][2])
+                    qs = [operands(e[1]) for ent in run for e in ent]
+                    if not IC.MemoryManager.prefetch_affinity_joint(mms, qs, net, event_factory=record, prio=first_alone and i == 0):
+                        ok = i > 0                              # (the banks do not line up: nothing was issued)
+                        break
+                    self.joint_passes += 1
+                    if gpu:
+                        for ent in run:
+                            for e in ent:
+                                for v in e[1]['_qo']['_readouts'].values():
+                                    v[0].record_stream(main)
+                                for t in e[1].values():
+                                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                                        t.record_stream(enc)
+        finally:
+            pool.offset = 0
+        return ok
 
     def _one_batch(self, ent) -> bool:
         """The C window entries are frame j of clips 0 .. C-1 of ONE batched encoder plan: clip c's outputs lie c x (frames per clip of
@@ -271,18 +372,22 @@ class LockstepCores:
         # ---- affinity read-out: per clip (its own bank), taken over from the look-ahead lane where that ran against this bank version
         h, w = recs[0]['h'], recs[0]['w']
         readouts = []
+        stacked = recs[0]['_qo'].pop('_readouts_joint', None)          # (a joint look-ahead pass: the clips' read-outs are slices of this tensor)
         for c, core in enumerate(cores):
             with frame_context.context(self._ctx[c]):
                 vis = core.memory.read_visual(recs[c]['_qo'], h, w, dev, net)
             readouts.append(next(iter(vis.values())))
+        if stacked is not None and any(r.data_ptr() != stacked[c * K].data_ptr() or r.shape[0] != K for c, r in enumerate(readouts)):
+            stacked = None                                              # (a clip read its bank again: its version had moved on)
+        self.stacked_steps += stacked is not None
         # ---- pixel fusion -> object transformer -> decoder: one plan each for the C x K objects
         ws = recs[0]['_wstride']
         m = net.model_cfg
         KT = G * K
         md = self._md_valid
-        P = eng.plan(('ls_fuse', G, K, h, w, md, ws), plans.build_pixel_fusion, K, h, w, True, md, G, ws)
+        P = eng.plan(('ls_fuse', G, K, h, w, md, ws, stacked is not None), plans.build_pixel_fusion, K, h, w, True, md, G, ws, stacked is not None)
         fused = eng.pool.get(('ls_fuse', G, K, h, w, eng.devstr), dict(fused=((KT, h, w, m['embed_dim']), BF16, False)), dev)['fused']
-        dyn = {'pixel%d' % c: readouts[c] for c in range(G)}
+        dyn = {'pixel%d' % c: readouts[c] for c in range(G)} if stacked is None else dict(pixel=stacked)
         if not md:
             dyn.update({'last_mask%d' % c: _f32c(core.last_mask[0]) for c, core in enumerate(cores)})
         P.run(sensory_bf16=sb, fuse_xt=recs[0]['fuse_xt'], fused=fused, **dyn)
@@ -342,7 +447,8 @@ class LockstepCores:
                     with frame_context.context(self._ctx[c]):
                         f = net._adopt_encoded(ent[1])
                     nxt.append((c, core, ent, f))
-            for part in (('first', 'rest') if IC.AFF_FIRST_ALONE else (None,)):
+            joint = len(nxt) == G and self._ahead_joint(cores[0].curr_ti + cores[0].mem_every, first_alone=IC.AFF_FIRST_ALONE)
+            for part in (() if joint else ('first', 'rest') if IC.AFF_FIRST_ALONE else (None,)):
                 for c, core, ent, f in nxt:
                     with frame_context.context(self._ctx[c]):
                         core._ahead_affinity(f[2], f[4], ent[2], ent[1], next_mem_ti=core.curr_ti + core.mem_every,

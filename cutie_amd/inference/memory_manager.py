@@ -28,6 +28,7 @@ _UNFUSED = os.environ.get('CUTIE_AMD_UNFUSED', '0') not in ('', '0')      # diag
 _VALIDATE = os.environ.get('CUTIE_AMD_VALIDATE', '0') not in ('', '0')
 BANK_WRITE = os.environ.get('CUTIE_AMD_BANK_WRITE', '1') not in ('', '0')      # the copies / fills of an insertion in one launch (A/B switch)
 BATCH_FORMS = os.environ.get('CUTIE_AMD_AFF_BATCH_FORMS', '1') not in ('', '0')   # stacked read-outs pick their score kernels by frame count (A/B switch)
+JOINT_DMA = int(os.environ.get('CUTIE_AMD_JOINT_DMA', '0'))      # clips in lock step: the joint read-out stages its memory tiles by LDS-DMA in the score pass (1) / the candidate pass (2) (A/B switch)
 PATCH_PLANS = os.environ.get('CUTIE_AMD_PATCH_PLANS', '1') not in ('', '0')    # sizes that a memory frame changes are patched into the cached affinity / commit plans (off: rebuilt; A/B + test switch)
 COMMIT_ON_SIDE = os.environ.get('CUTIE_AMD_COMMIT_SIDE', '1') not in ('', '0')  # bookkeeping of a consumed look-ahead read-out on the look-ahead stream (A/B switch)
 # bank versions are drawn from one process-wide counter: a look-ahead read-out tagged with the version of one manager can never pass
@@ -435,6 +436,100 @@ class MemoryManager:
             q['_readouts'] = out
             q['_readouts_ev'] = ev
         return per_frame
+
+    @staticmethod
+    def prefetch_affinity_joint(mms: List['MemoryManager'], qs: List[dict], network, event_factory=None, prio: bool = False) -> bool:
+        """Clips in lock step (inference/lockstep.py; no counterpart in the reference): the look-ahead read-outs of F frames of C clips --
+        C banks with ONE schedule, hence one set of token ranges -- as one score / select / score / read-out sequence.  qs: the F x C
+        query-operand dicts FRAME-MAJOR (entry e = frame * C + clip reads bank e % C), rows stacked as `prefetch_affinity_batch` wants
+        them.  Per entry the arithmetic is that of the one-frame plan on the entry's own bank (tests/test_gpu_kernels.py:
+        test_affinity_frames_of_several_banks_in_one_pass).  Every dict receives `_readouts` / `_readouts_ev` as from
+        `prefetch_affinity_batch`; the first dict of every frame also `_readouts_joint` = the [C * K, h, w, CV] read-outs of that frame
+        (the clips' slices of one tensor: pixel fusion takes them without a gather).  False (nothing done): the banks do not line up."""
+        C, E = len(mms), len(qs)
+        m0 = mms[0]
+        if C < 2 or E == 0 or E % C or any(not mm.engaged or mm.CV is None or len(mm.buckets) != 1 for mm in mms):
+            return False
+        bs = [next(iter(mm.buckets.values())) for mm in mms]
+        b0 = bs[0]
+        cfgs = lambda mm: (mm.top_k, mm.use_long_term, mm.count_long_term_usage, mm.CV)
+        sig = lambda b: (len(b.objects), tuple(b.ranges()), int(b.use.shape[0]) if m0.use_long_term else 0)
+        q0 = qs[0]
+        h, w, dev, HWp = q0['h'], q0['w'], q0['Bhi'].device, q0['Bhi'].shape[0]
+        if any(cfgs(mm) != cfgs(m0) for mm in mms) or any(sig(b) != sig(b0) for b in bs) or HWp % 128:
+            return False
+        for a, b in zip(qs, qs[1:]):
+            if not (b['Bhi'].data_ptr() == a['Bhi'].data_ptr() + HWp * 256 and b['Blo'].data_ptr() == a['Blo'].data_ptr() + HWp * 256
+                    and b['cq'].data_ptr() == a['cq'].data_ptr() + HWp * 4):
+                return False
+        HW, K = h * w, len(b0.objects)
+        ranges = [r for r in b0.ranges() if r[1] > 0]
+        G = sum(-(-n // 16) for _, n in ranges)
+        Gld = -(-max(G, 1) // 64) * 64
+        rows = E * HWp
+        pool = network.engine().pool
+        gbuf = m0._buf_rows('gmax_tau#joint', rows * Gld + rows, (), F32, dev)
+        gmax, tau = gbuf[:rows * Gld], gbuf[rows * Gld:]
+        cval = m0._buf_rows('cand_val#joint', rows, (CAND_CAP,), F32, dev)
+        cidx = m0._buf_rows('cand_idx#joint', rows, (CAND_CAP,), torch.int32, dev)
+        count = m0._buf_rows('count#joint', rows, (O.OpList.AFF_CSTRIDE,), torch.int32, dev)
+        ovf = m0._buf('overflow', (1,), torch.int32, dev)
+        spec = dict(r=((E, K, h, w, m0.CV), BF16, False))
+        readout = pool.get_ring(('readout#joint', C, E, K, h, w, str(dev)), spec, dev, ring=3)['r']
+        nslots = sig(b0)[2]
+        clear_long = m0.use_long_term and b0.n_long > 0 and not m0.count_long_term_usage
+        flat = [v for r in ranges for v in r] + [0] * (6 - 2 * len(ranges))
+        key = (len(ranges), K, HW, HWp, m0.top_k, m0.use_long_term, clear_long, nslots, E, C)
+        vals = (tuple(flat), G, b0.n_long)
+        plans_ = m0.__dict__.setdefault('_joint_plans', {})
+        cached = plans_.get((E, prio))
+        if cached is not None and cached[0] == key:
+            if cached[1] != vals:
+                ol, ops_ = cached[2], cached[3]
+                for op in (ops_['score0'], ops_['score1']):
+                    ol.patch_ints(op, 3, flat + [G])
+                ol.patch_ints(ops_['select'], 2, [G])
+                for op in ops_['clear']:
+                    ol.patch_ints(op, 0, [b0.n_long])
+                plans_[(E, prio)] = cached = (key, vals, ol, ops_)
+        else:
+            D = O.Dyn
+            ol = O.OpList()
+            ops_ = dict(clear=[])
+            common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=CAND_CAP, frames=E, nq=2, banks=(D('table'), C), prio=prio)
+            ops_['score0'] = ol.aff_score(None, None, None, D('Bhi'), D('Blo'), D('cq'), D('gmax'), None, None, None, mode=0, dma=bool(JOINT_DMA & 1), **common)
+            ops_['select'] = ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=m0.top_k, clear_count=D('count'), frames=E,
+                                           zero=(D('usage'), E * nslots) if m0.use_long_term else None, prio=prio)
+            ops_['score1'] = ol.aff_score(None, None, None, D('Bhi'), D('Blo'), D('cq'), D('tau'), D('cval'), D('cidx'), D('count'),
+                                          mode=1, gmax_precedes_tau=True, dma=bool(JOINT_DMA & 2), **common)
+            ol.aff_readout(D('cval'), D('cidx'), D('count'), D('vptrs'), D('usage') if m0.use_long_term else None, D('readout'),
+                           D('ovf'), HW=HW, cap=CAND_CAP, top_k=m0.top_k, K=K, CV=m0.CV, frames=E, HWp=HWp, usage_stride=nslots, banks=C, prio=prio)
+            if clear_long:
+                for e in range(E):                                      # (memory_manager.py:145-147, as in the one-frame plan)
+                    ops_['clear'].append(ol.memset32(D('usage', 4 * e * nslots), b0.n_long, 0))
+            plans_[(E, prio)] = cached = (key, vals, ol, ops_)
+        # the banks' operand bases and value pointers, bank-major (rebuilt when an array of a bank moved: it grew)
+        ptrs = tuple((b.Ahi.data_ptr(), b.Alo.data_ptr(), b.scale.data_ptr(), b.vptrs().data_ptr()) for b in bs)
+        tbl = m0.__dict__.get('_joint_table')
+        if tbl is None or tbl[0] != ptrs:
+            table = torch.tensor([list(p[:3]) for p in ptrs], dtype=torch.int64).to(dev)
+            tbl = m0._joint_table = (ptrs, table, torch.cat([b.vptrs() for b in bs]), [b.vptrs() for b in bs])
+        dyn = dict(count=count, table=tbl[1], Bhi=q0['Bhi'], Blo=q0['Blo'], cq=q0['cq'], gmax=gmax, tau=tau, cval=cval, cidx=cidx,
+                   vptrs=tbl[2], readout=readout, ovf=ovf)
+        udelta = None
+        if m0.use_long_term:
+            m0._joint_parity = m0.__dict__.get('_joint_parity', 0) ^ 1      # (two sets of usage side buffers, alternating per pass: see _affinity_batch)
+            udelta = m0._buf_rows(f'udelta#joint{m0._joint_parity}', E, (nslots,), F32, dev)
+            dyn.update(usage=udelta)
+        cached[2].run(**dyn)
+        ev = event_factory() if event_factory is not None else None
+        for e, q in enumerate(qs):
+            mm, b = mms[e % C], bs[e % C]
+            q['_readouts'] = {b.id: (readout[e], mm._version, udelta[e] if udelta is not None else None)}
+            q['_readouts_ev'] = ev
+            if e % C == 0:
+                q['_readouts_joint'] = readout[e:e + C].view(C * K, h, w, m0.CV)
+        return True
 
     def read_visual(self, q: dict, h: int, w: int, dev, network) -> Dict[int, torch.Tensor]:
         """The affinity half of `read` (memory_manager.py:126-167: similarity, top-k softmax, value read-out): bucket id -> read-out

@@ -615,7 +615,7 @@ def build_transform_key(eng, h, w):
     return P
 
 
-def build_pixel_fusion(eng, K, h, w, pre=False, pre_md=False, clips=1, wstride=1):
+def build_pixel_fusion(eng, K, h, w, pre=False, pre_md=False, clips=1, wstride=1, stacked=False):
     """CUTIE.pixel_fusion (cutie.py:142-157; big_modules.py:207-235).
     dyn in: pix_feat, pixel (readout) bf16 [K,h,w,CV], sensory_bf16 [K,h,w,CS], last_mask f32 [K,16h,16w];
     pre: fuse_xt bf16 [1,h,w,CE] = x_transform(pix_feat) from the encoder plan instead of pix_feat.
@@ -623,7 +623,8 @@ def build_pixel_fusion(eng, K, h, w, pre=False, pre_md=False, clips=1, wstride=1
     clips > 1 (clips in lock step, cutie_amd/inference/lockstep.py; no counterpart in the reference, which runs one InferenceCore per
     video): `clips` independent clips of K objects each through ONE plan -- every per-object tensor has clips * K rows (clip-major), the
     per-clip tensors (fuse_xt: needs pre) are the slices of one frame in the encoder window's output, `wstride` frames apart; the read-outs
-    of the clips (dyn in pixel0 .. pixel<clips-1>, one tensor per memory bank) are gathered by the first launch; dyn in last_mask0.. when
+    of the clips (dyn in pixel0 .. pixel<clips-1>, one tensor per memory bank) are gathered by the first launch -- or, stacked, come as
+    one tensor `pixel` [clips * K, h, w, CV] (a read-out pass over all banks, MemoryManager.prefetch_affinity_joint); dyn in last_mask0.. when
     the masks were not down-sampled by the segment in front (pre_md).  Per clip the launches compute what the one-clip plan computes."""
     G, Kc = clips, K
     K = G * Kc
@@ -638,7 +639,7 @@ def build_pixel_fusion(eng, K, h, w, pre=False, pre_md=False, clips=1, wstride=1
         m16 = P.buf('m16', (K, h, w), F32)
         for c in range(G):                               # ("others" = the other objects of the SAME clip: one launch per clip)
             P.ol.mask_down(Dyn('last_mask' if G == 1 else 'last_mask%d' % c), pair[c * Kc:], m16[c * Kc:], K=Kc, H=16 * h, W=16 * w, pair_channels=64)
-    if G > 1:
+    if G > 1 and not stacked:
         px = P.buf('pixel_all', (K, h, w, m['value_dim']))
         nb = Kc * h * w * m['value_dim'] * 2
         P.ol.bank_write([(Dyn('pixel%d' % c), px[c * Kc:], nb) for c in range(G)])

@@ -659,11 +659,13 @@ class OpList:
     AFF_NQ = int(os.environ.get('CUTIE_AMD_AFF_NQ', '2'))      # 16-query column sets per wave of AFF_SCORE (1, 2: aff_score_kernel; 4: aff_score4_kernel)
 
     def aff_score(self, Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count, *, HW, HWp, ranges, cap, mode, gmax_precedes_tau=False, nq=None, dma=None,
-                  frames=1, extra_lds_kb=0, prio=False):
+                  frames=1, extra_lds_kb=0, prio=False, banks=None):
         """gmax_precedes_tau (mode 1): `out` (= tau) sits right behind the [HWp, Gld] maxima of pass 0 in memory; the kernel then
         skips every (tile, 16-query set) that cannot hold a candidate.  nq: query column sets per wave (default AFF_NQ; every
         choice computes the same bits).  frames > 1: the query operands of that many frames, HWp rows each (HW real ones), stacked -- every
-        per-query array (c, maxima, tau, candidate lists, counters) is then indexed by the stacked row."""
+        per-query array (c, maxima, tau, candidate lists, counters) is then indexed by the stacked row.
+        banks = (table, n) (clips in lock step, ABI 4): stacked frame e reads bank e % n -- table: u64 [n, 3] = the (A_hi, A_lo, scale) bases of the
+        banks, which share the token ranges (Ahi / Alo / scale are then ignored); needs nq = 2 and HWp % 128 == 0."""
         ranges = [(s, n) for (s, n) in ranges if n > 0]
         assert 1 <= len(ranges) <= 3
         G = sum(-(-n // 16) for _, n in ranges)
@@ -674,7 +676,14 @@ class OpList:
         if frames > 1:
             ints[1] = frames * HWp
             ints += [HWp]
-        return self.add(AFF_SCORE, (1 if (gmax_precedes_tau and mode == 1) else 0) | (F_AFF_PRIO if (prio and PRIO) else 0), ints, [], [Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count])
+        ptrs = [Ahi, Alo, scale, Bhi, Blo, c, out, cand_val, cand_idx, count]
+        flags = (1 if (gmax_precedes_tau and mode == 1) else 0) | (F_AFF_PRIO if (prio and PRIO) else 0)
+        if banks is not None:
+            assert frames > 1 and frames % banks[1] == 0 and ints[12] == 2 and HWp % 128 == 0
+            ints += [banks[1]]
+            ptrs += [None, banks[0]]
+            flags |= 4
+        return self.add(AFF_SCORE, flags, ints, [], ptrs)
 
     def aff_select(self, gmax, tau, *, HW, HWp, G, top_k, clear_count=None, ticks=(), zero=None, frames=1, prio=False):
         """clear_count: pass 1's candidate counters, zeroed here; ticks: up to two (life, n) ranges advanced by one (USAGE_TICK);
@@ -687,10 +696,11 @@ class OpList:
         assert len(ticks) == 2
         return self.add(AFF_SELECT, SELECT_COARSE | (F_AFF_PRIO if (prio and PRIO) else 0), [HW, HWp, G, top_k, ticks[0][1], ticks[1][1], frames], [], [gmax, tau, clear_count, ticks[0][0], ticks[1][0]])
 
-    def aff_readout(self, cand_val, cand_idx, count, vptrs, usage, y, overflow, *, HW, cap, top_k, K, CV, frames=1, HWp=0, usage_stride=0, prio=False):
+    def aff_readout(self, cand_val, cand_idx, count, vptrs, usage, y, overflow, *, HW, cap, top_k, K, CV, frames=1, HWp=0, usage_stride=0, prio=False, banks=1):
         """frames > 1: stacked queries (HWp rows per frame, see aff_score); frame f's read-out goes to y[f] ([frames, K, HW, CV]) and its
-        usage to usage + f * usage_stride floats."""
-        return self.add(AFF_READOUT, F_AFF_PRIO if (prio and PRIO) else 0, [HW, cap, top_k, K, CV, frames, HWp, usage_stride], [], [cand_val, cand_idx, count, vptrs, usage, y, overflow])
+        usage to usage + f * usage_stride floats.  banks > 1: frame f gathers from bank f % banks -- vptrs: u64 [banks, K]."""
+        assert banks == 1 or frames % banks == 0
+        return self.add(AFF_READOUT, F_AFF_PRIO if (prio and PRIO) else 0, [HW, cap, top_k, K, CV, frames, HWp, usage_stride, banks], [], [cand_val, cand_idx, count, vptrs, usage, y, overflow])
 
     def memset32(self, dst, n, value=0):
         return self.add(MEMSET32, 0, [n, value], [], [dst])

@@ -234,7 +234,12 @@ enum {
      * ABI 3 -- one read-out per bank version (memory_manager.py:112-208 reads once per frame; the bank changes on memory frames only,
      *      inference_core.py:238): i16 > 0 = query rows per frame; i1 (HWp) is then frames x i16 and the query operands of the frames are
      *      stacked (row j is a real query iff j % i16 < i0); c, gmax, tau, the candidate lists and counters are indexed by the stacked row.
-     *      Per query the arithmetic is that of the one-frame launch (same bits). */
+     *      Per query the arithmetic is that of the one-frame launch (same bits).
+     * ABI 4 -- clips in lock step (no counterpart in the reference: one InferenceCore, hence one bank, per video, eval_vos.py:97): flags&4 = the
+     *      stacked frames read DIFFERENT banks, frame e the bank e % i17; p11 = u64 [i17][3] device table of the banks' (A_hi, A_lo, scale) bases
+     *      (p0..p2 are ignored), the token ranges i3..i9 are those of every bank (banks on one schedule).  Needs 2 column sets per wave (i12),
+     *      i16 % 128 == 0 (a block's 128 query rows lie inside one frame) and frames % i17 == 0; per query the bits of the one-frame launch
+     *      on that frame's bank. */
     CUTIE_OP_AFF_SCORE = 24,
     /* AFF_SELECT: tau_j = top_k-th largest of gmax[:,j] (or -inf if G < top_k)
      * p0=gmax f32 [HWp,Gld] p1=tau f32 [HW]   i: 0 HW 1 HWp 2 G 3 top_k
@@ -250,7 +255,8 @@ enum {
      * bf16 [slots,CV]) p4=usage f32 [slots] (may be 0) p5=y bf16 [K,HW,CV] p6=overflow i32[1]
      * i: 0 HW 1 cap 2 top_k 3 K 4 CV
      * ABI 3: i5 > 1 = that many stacked frames of i6 query rows each; frame f's read-out goes to y + f * K*HW*CV and its usage to
-     *      p4 + f * i7 floats (per-frame side buffers: a look-ahead read-out is counted when -- and only when -- its frame is consumed) */
+     *      p4 + f * i7 floats (per-frame side buffers: a look-ahead read-out is counted when -- and only when -- its frame is consumed)
+     * ABI 4: i8 > 1 = that many banks, frame f gathers from bank f % i8: p3 = u64 [i8][K] (see AFF_SCORE flags&4) */
     CUTIE_OP_AFF_READOUT = 26,
     /* MEMSET32: fill n 32-bit words with value i[1]   p0=dst   i: 0 n 1 value */
     CUTIE_OP_MEMSET32 = 27,

@@ -555,6 +555,9 @@ class MockExecutor:
             r0 = fr * HWpf
             pf = list(p)
             pf[3], pf[4], pf[5] = p[3] + 256 * r0, p[4] + 256 * r0, p[5] + 4 * r0
+            if flags & 4:                                               # (ABI 4) frame fr reads bank fr % i[17]: (A_hi, A_lo, scale) from the table p[11]
+                assert i[17] >= 2 and (HWp // HWpf) % i[17] == 0 and HWpf % 128 == 0 and i[12] == 2
+                pf[0], pf[1], pf[2] = [int(v) for v in view(p[11], U64, (i[17], 3))[fr % i[17]]]
             sc = self._scores(i, pf)
             if mode == 0:
                 gmax = view(p[6] + 4 * r0 * Gld, F32, (HWpf, Gld))
@@ -607,8 +610,11 @@ class MockExecutor:
         HW, cap, topk, K, CV = i[:5]
         frames = i[5] if i[5] > 1 else 1
         HWpf, ustride = (i[6], i[7]) if frames > 1 else (HW, 0)
-        vptrs = view(p[3], U64, (K,))
+        nb = i[8] if i[8] > 1 else 1
+        assert frames % nb == 0
+        vptrs_all = view(p[3], U64, (nb, K))
         for fr in range(frames):
+            vptrs = vptrs_all[fr % nb]
             r0 = fr * HWpf
             cv = view(p[0] + 4 * r0 * cap, F32, (HW, cap))
             ci = view(p[1] + 4 * r0 * cap, I32, (HW, cap))

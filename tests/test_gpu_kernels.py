@@ -1190,6 +1190,93 @@ def test_affinity_batched_frames_match_one_frame_plans(case, nq):
         check({'useb': hip['useb']}, {'useb': ref['useb']}, 'aff batched usage', rtol=1e-4)
 
 
+@pytest.mark.parametrize('case', [
+    dict(HW=1620, F=2, NB=4, ranges=[(0, 2000), (2100, 1620), (4000, 8097)], slots=12200, K=3, top_k=30),   # four bench clips, two frames each
+    dict(HW=1620, F=1, NB=2, ranges=[(0, 1620)], slots=1620, K=1, top_k=30),
+    dict(HW=100, F=3, NB=3, ranges=[(0, 1003)], slots=1003, K=2, top_k=5),                                 # ragged tail tile, 128 rows per frame
+    dict(HW=120, F=2, NB=2, ranges=[(0, 48)], slots=48, K=3, top_k=30),                                    # G < top_k: "take everything"
+])
+@pytest.mark.parametrize('dma', [False, True])
+def test_affinity_frames_of_several_banks_in_one_pass(case, dma):
+    """Clips in lock step (ABI 4: AFF_SCORE flags&4 + bank table, AFF_READOUT i8): the stacked frames of NB clips, frame-major (entry
+    e = frame * NB + clip reads bank e % NB), through ONE score / select / score / read-out sequence against the one-frame sequence of
+    every entry on its own bank -- identical thresholds, candidate counts and read-out bits, per-entry usage buffers equal up to the
+    order of the float atomics; the small cases also against the descriptor interpreter."""
+    HW, F, NB, ranges, slots, K, top_k = (case[k] for k in ('HW', 'F', 'NB', 'ranges', 'slots', 'K', 'top_k'))
+    E = F * NB
+
+    def build(dev, g):
+        CV, cap = 256, 1024
+        HWp = -(-HW // 64) * 64
+        assert HWp % 128 == 0
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        nslots = slots + 16
+        G = sum(-(-n // 16) for _, n in ranges if n > 0)
+        Gld = -(-G // 64) * 64
+        ol = O.OpList()
+        banks, vals, vp = [], [], []
+        for b in range(NB):
+            mkey = (torch.randn((slots, 64), generator=g) * 0.8).to(dev)
+            mshr = (torch.rand((slots,), generator=g) * 2 + 1).to(dev)
+            Ahi, Alo, scale = z((nslots, 128), BF16), z((nslots, 128), BF16), z((nslots,), F32)
+            ol.key_prep(mkey, mshr, Ahi, Alo, scale, n=slots, query=False)
+            banks.append((Ahi, Alo, scale))
+            vb = [rnd(g, (nslots, CV), dev=dev) for _ in range(K)]
+            vals += vb
+            vp.append(torch.tensor([v.data_ptr() for v in vb], dtype=torch.int64).to(dev))
+        ol.keep += vals + [t for b in banks for t in b] + vp
+        table = torch.tensor([[t.data_ptr() for t in b] for b in banks], dtype=torch.int64).to(dev)
+        vptrs_all = torch.cat(vp)
+        qkey = (torch.randn((E, HW, 64), generator=g) * 0.8).to(dev)
+        qsel = torch.rand((E, HW, 64), generator=g).to(dev)
+        Bhi, Blo, cq = z((E, HWp, 128), BF16), z((E, HWp, 128), BF16), z((E, HWp), F32)
+        for e in range(E):
+            ol.key_prep(qkey[e], qsel[e], Bhi[e], Blo[e], cq[e], n=HW, query=True)
+        ovf = z((1,), torch.int32)
+        # (a) entry by entry on its own bank
+        y1, use1 = z((E, K, HW, CV), BF16), z((E, nslots), F32) + 3.0
+        tau1, cnt1 = z((E, HW), F32), z((E, HW), torch.int32)
+        keep = []
+        for e in range(E):
+            Ahi, Alo, scale = banks[e % NB]
+            gbuf = z((HWp * Gld + HWp,), F32)
+            gmax, tau = gbuf[:HWp * Gld], gbuf[HWp * Gld:]
+            cval, cidx, count = z((HW, cap), F32), z((HW, cap), torch.int32), z((HW * 32,), torch.int32) + 7
+            keep += [gbuf, cval, cidx, count]
+            common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=cap, nq=2)
+            ol.aff_score(Ahi, Alo, scale, Bhi[e], Blo[e], cq[e], gmax, None, None, None, mode=0, **common)
+            ol.aff_select(gmax, tau, HW=HW, HWp=HWp, G=G, top_k=top_k, clear_count=count, zero=(use1[e], nslots))
+            ol.aff_score(Ahi, Alo, scale, Bhi[e], Blo[e], cq[e], tau, cval, cidx, count, mode=1, gmax_precedes_tau=True, **common)
+            ol.aff_readout(cval, cidx, count, vp[e % NB], use1[e], y1[e], ovf, HW=HW, cap=cap, top_k=top_k, K=K, CV=CV)
+            ol.copy2d(tau, tau1[e], rows=1, rowbytes=4 * HW, src_stride=4 * HW, dst_stride=4 * HW)
+            ol.copy2d(count, cnt1[e], rows=HW, rowbytes=4, src_stride=128, dst_stride=4)
+        # (b) all entries stacked, one bank per entry
+        rows = E * HWp
+        yb, useb = z((E, K, HW, CV), BF16), z((E, nslots), F32) + 3.0
+        gbuf = z((rows * Gld + rows,), F32)
+        gmax, tau = gbuf[:rows * Gld], gbuf[rows * Gld:]
+        cval, cidx, count = z((rows, cap), F32), z((rows, cap), torch.int32), z((rows * 32,), torch.int32) + 7
+        common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=cap, nq=2, dma=dma, frames=E, banks=(table, NB))
+        ol.aff_score(None, None, None, Bhi, Blo, cq, gmax, None, None, None, mode=0, **common)
+        ol.aff_select(gmax, tau, HW=HW, HWp=HWp, G=G, top_k=top_k, clear_count=count, zero=(useb, E * nslots), frames=E)
+        ol.aff_score(None, None, None, Bhi, Blo, cq, tau, cval, cidx, count, mode=1, gmax_precedes_tau=True, **common)
+        ol.aff_readout(cval, cidx, count, vptrs_all, useb, yb, ovf, HW=HW, cap=cap, top_k=top_k, K=K, CV=CV, frames=E, HWp=HWp, usage_stride=nslots, banks=NB)
+        ol.keep += keep + [gbuf, cval, cidx, count, table, vptrs_all]
+        return ol, {'y1': y1, 'yb': yb, 'use1': use1, 'useb': useb, 'tau1': tau1, 'taub': tau.view(E, HWp)[:, :HW],
+                    'cnt1': cnt1, 'cntb': count.view(E, HWp, 32)[:, :HW, 0], 'ovf': ovf}
+
+    hip, ref = run_both(build, seed=11)
+    assert torch.equal(hip['taub'], hip['tau1'])
+    assert torch.equal(hip['cntb'], hip['cnt1'])
+    assert torch.equal(hip['yb'].view(torch.int16), hip['y1'].view(torch.int16))
+    assert int(hip['ovf']) == 0
+    assert torch.allclose(hip['useb'], hip['use1'], rtol=1e-5, atol=1e-6)
+    assert float(hip['useb'].sum()) > 0.99 * E * HW
+    if HW <= 120:
+        check({'yb': hip['yb']}, {'yb': ref['yb']}, 'aff several banks')
+        check({'useb': hip['useb']}, {'useb': ref['useb']}, 'aff several banks usage', rtol=1e-4)
+
+
 @pytest.mark.parametrize('nq', [2, 4])
 def test_affinity_long_candidate_lists(nq):
     """Homogeneous memory (runs of 16 nearly identical tokens): the tile-maximum threshold of pass 1 lets hundreds of candidates

@@ -848,14 +848,15 @@ def test_interleaved_clips_match_sequential(gpu_net):
     ((480, 854), 1, 3, 12, dict(mem_every=5)),
     ((200, 300), 2, 2, 13, dict(mem_every=2, use_long_term=True, long_term=dict(S.LT_SMALL))),
 ])
-@pytest.mark.parametrize('hinted', [True, False])
-def test_lockstep_clips_match_sequential(gpu_net, size, K, C, T, cfg_kw, hinted):
+@pytest.mark.parametrize('hinted', [True, False, 'lanes'])          # 'lanes': hints, every clip's own look-ahead lane instead of the joint read-out
+def test_lockstep_clips_match_sequential(gpu_net, size, K, C, T, cfg_kw, hinted, monkeypatch):
     """inference/lockstep.py: C clips in lock step through ONE plan per stage (batch = C x K objects, conv tiles of the one-clip plans'
     K-order classes, per-clip couplings grouped inside the launches: ABI 4) -- every clip gets the probabilities and the bank of its own
     InferenceCore run, bit for bit.  480p / 3 objects / long-term memory with consolidations and a pruning is the bench's multi_clip leg."""
     from cutie_amd.inference.inference_core import InferenceCore
     from cutie_amd.inference.lockstep import LockstepCores
     from cutie_amd.utils.synth import SyntheticClip
+    monkeypatch.setattr(LockstepCores, 'JOINT', hinted != 'lanes')
     clips = [SyntheticClip(size[0], size[1], K, T, seed=60 + c) for c in range(C)]
     frames = [[cl.frame(t).cuda() for t in range(T)] for cl in clips]
     sizes = lambda mm: {k: (b.n_long, b.n_perm, b.n_work) for k, b in mm.buckets.items()}
@@ -874,6 +875,11 @@ def test_lockstep_clips_match_sequential(gpu_net, size, K, C, T, cfg_kw, hinted)
             outs.append(ls.step([f[t] for f in frames], end=(t == T - 1), **hint))
         torch.cuda.synchronize()
     assert ls.batched_steps == T - 2
+    rows = -(-size[0] // 16) * -(-size[1] // 16)
+    if hinted is True and (-(-rows // 64) * 64) % 128 == 0:             # (whole 128-row blocks per frame: the read-outs of all clips in one pass per bank version)
+        assert ls.joint_passes >= (T - 2) // ls.cores[0].mem_every and ls.stacked_steps >= T - 4, (ls.joint_passes, ls.stacked_steps)
+    else:
+        assert ls.joint_passes == 0 or hinted is True
     for c in range(C):
         got = torch.stack([o[c] for o in outs]).cpu()
         assert torch.isfinite(got).all()

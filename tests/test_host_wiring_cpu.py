@@ -254,6 +254,26 @@ def test_lockstep_clips_match_sequential(product_net, hinted):
         ex.per_sample_conv = False
 
 
+def test_lockstep_joint_readout_over_the_banks_of_all_clips(product_net):
+    """LockstepCores._ahead_joint / MemoryManager.prefetch_affinity_joint (AFF_SCORE flags&4, AFF_READOUT i8): with look-ahead hints and
+    query rows per frame that fill whole 128-row blocks, the read-outs of all clips run as one pass per bank version over a frame-major
+    encoder window, and pixel fusion takes them as one tensor -- still every clip's own bits and bank, with long-term consolidations."""
+    ex = _lib.get_executor()
+    ex.per_sample_conv = True
+    try:
+        with torch.inference_mode():
+            cfg_kw = dict(mem_every=2, use_long_term=True, long_term=dict(S.LT_SMALL))
+            seq, got, ls = _lockstep_case(product_net, cfg_kw, C=2, T=13, hinted=True, size=(96, 176), window=(4, 1))      # 6 x 11 = 66 -> 128 rows
+            assert ls.JOINT and ls.batched_steps == 11
+            assert ls.joint_passes >= 6 and ls.stacked_steps >= 9, (ls.joint_passes, ls.stacked_steps)
+            assert all(v[0] > 0 for v in seq[0][1].values()), 'the case must consolidate'
+            for c in range(len(seq)):
+                assert seq[c][1] == got[c][1], (c, seq[c][1], got[c][1])
+                assert torch.equal(seq[c][0], got[c][0]), (c, float((seq[c][0] - got[c][0]).abs().max()))
+    finally:
+        ex.per_sample_conv = False
+
+
 def test_lockstep_leaves_the_batched_path_when_the_clips_stop_being_uniform(product_net):
     """LockstepCores: a frame that brings masks, and everything behind it once the clips hold a second bucket (objects added mid-clip,
     kv_memory_store.py:96-117), run clip by clip through the cores' own step -- still every clip's own results; deleting the second

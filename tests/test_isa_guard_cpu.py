@@ -30,7 +30,7 @@ def _lone_before_loops(body):
 def test_affinity_kernels_request_their_operands_together():
     ks = dict(_kernels('affinity.o'))
     score = [n for n in ks if n.startswith('_Z16aff_score_kernelILi')]
-    assert len(score) == 4, score                         # <1 | 2 query sets per wave, pass 0 | 1>
+    assert len(score) == 6, score                         # <1 | 2 query sets per wave, pass 0 | 1> + <2, pass 0 | 1, one bank per stacked frame>
     for n in score:
         assert _lone_before_loops(ks[n]) == [], (n, _lone_before_loops(ks[n]))
         pre, _ = W.wait_groups(ks[n])

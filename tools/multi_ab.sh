@@ -16,7 +16,8 @@ for r in $(seq 1 $reps); do
 import json, sys
 args = "$*".split()
 C = int(args[args.index('--clips-in-flight') + 1]) if '--clips-in-flight' in args else 4
-C *= int(args[args.index('--lockstep-groups') + 1]) if '--lockstep-groups' in args else 1
+ls = '--multi-mode' in args and args[args.index('--multi-mode') + 1] == 'lockstep'
+C *= max(1, int(args[args.index('--lockstep-groups') + 1])) if '--lockstep-groups' in args else (3 if ls else 1)     # (bench.py's default: three lock-step groups in flight)
 try:
     d = json.loads(open('$O/v${i}_r$r.json').read().strip().split('\n')[-1])
     print('[${variants[$i]}] run $r: %.1f frames/s (%d clips x %d steps in %.3f s)' % (C * d['steps_per_clip'] / d['seconds'], C, d['steps_per_clip'], d['seconds']))
