@@ -240,7 +240,7 @@ def multi_clip_interleaved(net, cfg, args, K, rank, dist, dev):
 
 def multi_clip_lockstep(net, cfg, args, K, rank, dist, dev, rec=None):
     """Same workload, C clips advanced in LOCK STEP (cutie_amd/inference/lockstep.py): one launch plan per stage for the C x K objects of
-    all clips, one joint encoder window, one memory bank and one look-ahead read-out lane per clip.  Returns (seconds for
+    all clips, one joint encoder window, one memory bank per clip, one look-ahead read-out pass per bank version for the banks of all clips.  Returns (seconds for
     multi_clip_steps(args) frames of every clip, roofline object of the conv launches of the lock-step frames or None)."""
     from cutie_amd import ops as O
     from cutie_amd.inference.lockstep import LockstepCores
@@ -809,8 +809,8 @@ def main():
                      'unit': 'frames/s', 'steps_per_clip': msteps, 'ms_per_step': round(mt / msteps * 1e3, 4),
                      'hw_queues': (args.multi_hw_queues if in_child else os.environ.get('GPU_MAX_HW_QUEUES', 'default (4)')),
                      'mode': args.multi_mode,
-                     'host': {'lockstep': 'ONE launch plan per stage for the C x K objects of all clips (cutie_amd/inference/lockstep.py: joint encoder window, one bank + one '
-                                          'look-ahead read-out lane per clip); per clip bit-identical to its own InferenceCore run',
+                     'host': {'lockstep': 'ONE launch plan per stage for the C x K objects of all clips (cutie_amd/inference/lockstep.py: joint encoder window, one bank per clip, '
+                                          'one look-ahead read-out pass over the banks of all clips); per clip bit-identical to its own InferenceCore run',
                               'interleaved': 'one thread issues a step of every clip in turn (cutie_amd/parallel.py:run_interleaved)',
                               'threads': 'one host thread per clip (cutie_amd/parallel.py:run_concurrent)'}[args.multi_mode],
                      'note': ('same workload, C independent clips per GPU advanced in lock step' if args.multi_mode == 'lockstep' else
@@ -902,8 +902,8 @@ def main():
         out['repeats'] = {'values': rep_vals, 'median': rv[len(rv) // 2], 'min': rv[0], 'max': rv[-1],
                           'mean_fps_all_regions': round(len(rep_vals) / sum(1.0 / v for v in rep_vals), 2),
                           'note': f'{len(rep_vals)} consecutive timed regions on this box, each EXACTLY {args.steps} steps between barrier + synchronize (the first one behind '
-                                  f'the {args.warmup} warm-up steps); "value" = the MEDIAN region, value_first_region = the first.  A region of {args.steps} frames holds 1-2 '
-                                  f'batched encoder plans of {args.window} frames each, so single regions scatter with the phase of the batches; '
+                                  f'the {args.warmup} warm-up steps); "value" = the MEDIAN region, value_first_region = the first.  A region of {args.steps} frames holds '
+                                  f'{args.steps // max(1, args.window)}-{-(-args.steps // max(1, args.window)) + 1} batched encoder plans of {args.window} frames each, so short regions scatter with the phase of the batches; '
                                   'mean_fps_all_regions = all frames / all time'}
         if hinted_protocol is not None:
             out['eval_vos_protocol'] = hinted_protocol

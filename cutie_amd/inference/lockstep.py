@@ -9,9 +9,12 @@ every launch re-streams its weights for them.  Here the C clips 
 batch = C x K objects (clip-major):
 
 * image encoder + key projection: the look-ahead window of ``InferenceCore`` over the frames of ALL clips as one batched plan
-  (``CUTIE._encode_window``; clip-major, so that the frames of one clip stay stacked for its read-outs);
-* affinity read-out: one memory bank per clip, hence per clip -- the look-ahead lane of every clip's ``InferenceCore`` unchanged
-  (one read-out per bank version, ``InferenceCore._ahead_affinity``), all of them on the engine's side stream;
+  (``CUTIE._encode_window``; frame-major: the C clips of a lock-step frame are neighbours in every output);
+* affinity read-out: one memory bank per clip, all of them on ONE schedule -- the look-ahead read-outs of a bank version run as one
+  pass over the stacked frames of all clips (``_ahead_joint`` -> ``MemoryManager.prefetch_affinity_joint``: AFF_SCORE flags&4 /
+  AFF_READOUT i8 pick the bank per stacked frame), on the engine's side stream; their result is the stacked input of pixel fusion.
+  (``JOINT`` off, frames whose query rows do not fill whole 128-row blocks, banks that do not line up: every clip's own look-ahead
+  lane, ``InferenceCore._ahead_affinity``, and a gather in front of pixel fusion);
 * pixel fusion, object transformer, decoder (+ sensory update), mask encoder + summarizer: plans built with ``clips=C``
   (model/plans.py).  What couples the objects of a clip -- the "others" mask, the foreground masks of the transformer, the soft
   aggregation + softmax, the per-clip image features -- is grouped per clip inside the launches (include/cutie_hip.h, ABI 4);

@@ -207,7 +207,7 @@ def run_batched(net, cfg, clips: Sequence[Dict], *, lockstep: int = 4, in_flight
     ``InferenceCore`` run; next to ``run_interleaved`` this divides the launches and the host's issue time per frame by the group size and
     gives every convolution of the per-object path ``lockstep`` x the rows.  ``in_flight`` > 1 keeps that many GROUPS in flight next to
     each other (``run_interleaved`` over groups: a stream and a ``CUTIE.fork()`` per group, the calling thread issues a lock-step frame of
-    every group in turn) -- the two schemes multiply.  MI355X, 480p, 3 objects, long-term memory (round 6, one box each): 4 clips ~1710 frames/s
+    every group in turn) -- the two schemes multiply.  MI355X, 480p, 3 objects, long-term memory (round 6, one box each): 4 clips ~1800 frames/s
     in one group against ~1530 interleaved one by one; 12 clips as 3 groups of 4 in flight ~2020.
 
     clips: [{'frames': sequence of [3, H, W] tensors on the device, 'mask': the first frame's mask, 'objects': its object ids}, ...];
