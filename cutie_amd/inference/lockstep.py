@@ -146,7 +146,7 @@ class LockstepCores:
             side = cores[0]._side_stream(dev)
             win.wait_stream(side)
         with (torch.cuda.stream(win) if win is not None else contextlib.nullcontext()):
-            recs = net._encode_window(flat, *geometry)
+            recs = net._encode_window(flat, *geometry, qrows=128 if fm else 64)       # (whole 128-row blocks per frame: the joint read-out pass)
             if win is not None:
                 ev = torch.cuda.Event()
                 ev.record(win)

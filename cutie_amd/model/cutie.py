@@ -461,19 +461,19 @@ class CUTIE(nn.Module):
         frame_context.remember('fuse_xt', out['pix_feat'], out['fuse_xt'], cap=4)
         return out
 
-    def _encode_window(self, images, h0, w0, H, W, pad_left, pad_top):
+    def _encode_window(self, images, h0, w0, H, W, pad_left, pad_top, qrows=64):
         """B un-padded frames f32 [3,h0,w0] of one geometry through ONE plan (plans.build_encode(B=...)) -> a list of B records shaped
         like `_encode`'s (views of the [B, ...] outputs).  Frame b's record is bit-identical to `_encode(images[b], ...)`.  The
         frame_context entries of a record are NOT made here: `_adopt_encoded` registers them when the frame is about to be consumed
-        (the tables keep the last few frames only)."""
+        (the tables keep the last few frames only).  qrows: see plans.build_encode."""
         eng = self.engine()
         dev = eng.device
         m = self.model_cfg
         B = len(images)
-        P = eng.plan(('encw', B, h0, w0, H, W, pad_left, pad_top), plans.build_encode, h0, w0, H, W, pad_left, pad_top, B)
+        P = eng.plan(('encw', B, h0, w0, H, W, pad_left, pad_top, qrows), plans.build_encode, h0, w0, H, W, pad_left, pad_top, B, qrows)
         h, w = H // 16, W // 16
         hw = h * w
-        HWp = -(-hw // 64) * 64
+        HWp = -(-hw // qrows) * qrows
         ms = self.ms_dims
         W_ = eng.w
         Z = False
@@ -483,7 +483,7 @@ class CUTIE(nn.Module):
                      f8p=((B, 2 * h, 2 * w, W_['mask_decoder.decoder_feat_proc.transforms.0'].cout), BF16, Z),
                      f4p=((B, 4 * h, 4 * w, W_['mask_decoder.decoder_feat_proc.transforms.1'].cout), BF16, Z),
                      fuse_xt=((B, h, w, W_['pixel_fuser.fuser.distributor.x_transform'].cout), BF16, Z))
-        out = eng.pool.get_ring(('encw', B, h, w, eng.devstr), specs, dev, ring=4)
+        out = eng.pool.get_ring(('encw', B, h, w, HWp, eng.devstr), specs, dev, ring=4)
         P.run(**({'image': images[0]} if B == 1 else {'image%d' % b: images[b] for b in range(B)}), **out)
         recs = []
         for b in range(B):

@@ -545,7 +545,7 @@ def stem_ok(eng, name):
     return STEM and not UNFUSED and w is not None and w.cout == 64 and w.kh == 7 and w.kw == 7 and w.cin_padded == 8 and w.bias is not None
 
 
-def build_encode(eng, h0, w0, H, W, pad_left, pad_top, B=1):
+def build_encode(eng, h0, w0, H, W, pad_left, pad_top, B=1, qrows=64):
     """CUTIE.encode_image + transform_key (cutie.py:61-64,92-98; big_modules.py:45-54,81-87) + query-side
     similarity operands.  dyn in: image f32 [3,h0,w0].  dyn out: f16,f8,f4,pix_feat (bf16 NHWC), key,shr,sel
     (f32 [hw,*]), Bhi,Blo (bf16 [HWp,128]), cq (f32 [HWp]).
@@ -553,7 +553,9 @@ def build_encode(eng, h0, w0, H, W, pad_left, pad_top, B=1):
     plan -- every conv sees B x the rows (M = B * OH * OW; at 480p the stride-16 layers of one frame have 1620 rows, a third of a
     round of workgroups), the outputs are [B, ...] with frame b's slice laid out exactly like the B = 1 output.  Rows of different
     frames never meet (batch = outermost dimension of NHWC) and the tiles are taken from the same K-order class as the B = 1 plan's
-    (Plan.korder_ref), so frame b's results are bit-identical to the B = 1 plan's."""
+    (Plan.korder_ref), so frame b's results are bit-identical to the B = 1 plan's.
+    qrows: every frame's query operands (Bhi, Blo, cq) are padded to a multiple of this many rows (zero rows; 64 = a wave's queries; clips in lock
+    step ask for 128 -- one bank per 128-row block of a joint read-out pass, AFF_SCORE flags&4)."""
     P = Plan(eng, touch=weights_go_cold(B * (H // 16) * (W // 16)), prio=False)      # (mostly on a look-ahead stream: yields to the frame's own launches)
     m = eng.m
     img = (lambda b: Dyn('image')) if B == 1 else (lambda b: Dyn('image%d' % b))
@@ -579,7 +581,7 @@ def build_encode(eng, h0, w0, H, W, pad_left, pad_top, B=1):
             'layer3': Act(Dyn('f16'), B, h, w, ms[0])}
     f16, _ = P.resnet('pixel_encoder', x, taps)
     pix = P.conv('pix_feat_proj', f16, out=Act(Dyn('pix_feat'), B, h, w, m['pixel_dim']))
-    build_key_ops(P, f16, h, w)
+    build_key_ops(P, f16, h, w, qrows)
     # Image-only convolutions of the mask decoder and the pixel fuser (DecoderFeatureProcessor, big_modules.py:244-255; the
     # x_transform of MainToGroupDistributor, group_modules.py:112-115): they do not depend on the memory, so they run here -- with the
     # look-ahead encoder on the side stream, off the frame's critical path -- and reach their consumers through frame_context.
@@ -594,7 +596,7 @@ def build_encode(eng, h0, w0, H, W, pad_left, pad_top, B=1):
     return P
 
 
-def build_key_ops(P, f16, h, w):
+def build_key_ops(P, f16, h, w, qrows=64):
     m = P.eng.m
     CK = m['key_dim']
     B = f16.B
@@ -602,7 +604,7 @@ def build_key_ops(P, f16, h, w):
     P.conv('key_proj.key_proj', kx, out=Act(Dyn('key'), B, h, w, CK), out_f32=True)
     P.conv('key_proj.d_proj', kx, out=Act(Dyn('shr'), B, h, w, 1), out_f32=True, act=O.ACT_SQ1)
     P.conv('key_proj.e_proj', kx, out=Act(Dyn('sel'), B, h, w, CK), out_f32=True, act=O.ACT_SIGMOID)
-    hw, HWp = h * w, -(-h * w // 64) * 64
+    hw, HWp = h * w, -(-h * w // qrows) * qrows
     for b in range(B):                                       # (the padding rows [hw, HWp) of every frame's operands stay zero)
         P.ol.key_prep(Dyn('key', b * hw * CK * 4), Dyn('sel', b * hw * CK * 4), Dyn('Bhi', b * HWp * 128 * 2), Dyn('Blo', b * HWp * 128 * 2),
                       Dyn('cq', b * HWp * 4), n=hw, query=True)

@@ -246,6 +246,7 @@ def test_lockstep_clips_match_sequential(product_net, hinted):
                                  (dict(mem_every=2, use_long_term=True, long_term=dict(S.LT_SMALL)), 15, 2)):      # (two consolidations)
                 seq, got, ls = _lockstep_case(product_net, cfg_kw, C=C, T=T, hinted=hinted, window=(4, 1) if hinted else None)
                 assert ls.batched_steps == T - 2, ls.batched_steps       # every frame but the first (masks) and the last (end=True)
+                assert (ls.joint_passes > 0 and ls.stacked_steps >= T - 4) if hinted else ls.joint_passes == 0, (ls.joint_passes, ls.stacked_steps)
                 assert not cfg_kw.get('use_long_term') or all(v[0] > 0 for v in seq[0][1].values()), 'the long-term case must consolidate'
                 for c in range(len(seq)):
                     assert seq[c][1] == got[c][1], (cfg_kw, c, seq[c][1], got[c][1])
