@@ -13,8 +13,8 @@ batch = C x K objects (clip-major):
 * affinity read-out: one memory bank per clip, all of them on ONE schedule -- the look-ahead read-outs of a bank version run as one
   pass over the stacked frames of all clips (``_ahead_joint`` -> ``MemoryManager.prefetch_affinity_joint``: AFF_SCORE flags&4 /
   AFF_READOUT i8 pick the bank per stacked frame), on the engine's side stream; their result is the stacked input of pixel fusion.
-  (``JOINT`` off, frames whose query rows do not fill whole 128-row blocks, banks that do not line up: every clip's own look-ahead
-  lane, ``InferenceCore._ahead_affinity``, and a gather in front of pixel fusion);
+  (``JOINT`` off, or banks that do not line up: every clip's own look-ahead lane, ``InferenceCore._ahead_affinity``, and a gather in
+  front of pixel fusion);
 * pixel fusion, object transformer, decoder (+ sensory update), mask encoder + summarizer: plans built with ``clips=C``
   (model/plans.py).  What couples the objects of a clip -- the "others" mask, the foreground masks of the transformer, the soft
   aggregation + softmax, the per-clip image features -- is grouped per clip inside the launches (include/cutie_hip.h, ABI 4);
