@@ -341,8 +341,9 @@ class LockstepCores:
         dev = net.device
         gpu = dev.type == 'cuda'
         G = len(cores)
-        for core in cores:
+        for c, core in enumerate(cores):
             core.curr_ti += 1
+            core.memory._clip_tag = c                   # (clear_memory gives a core a new MemoryManager)
         eng.pool.tick()
         # this frame's encoder records: found in the look-ahead windows, or encoded now (one plan for the C frames, on this stream)
         keys = [core._frame_key(img) for core, img in zip(cores, images)]

@@ -275,6 +275,39 @@ def test_lockstep_joint_readout_over_the_banks_of_all_clips(product_net):
         ex.per_sample_conv = False
 
 
+def test_lockstep_banks_that_do_not_line_up_keep_their_own_readout_lanes(product_net):
+    """MemoryManager.prefetch_affinity_joint refuses banks that differ in what the joint launches share (here: top_k of one clip changed
+    through update_config): the group stays on the batched plans, every clip's look-ahead read-out runs in its own lane, and every clip
+    still gets the bits of its own InferenceCore run under its own setting."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.inference.lockstep import LockstepCores
+    from cutie_amd.utils.synth import SyntheticClip
+    C, T = 2, 9
+    clips = [SyntheticClip(48, 80, 2, T, seed=90 + c) for c in range(C)]
+    frames = [[cl.frame(t) for t in range(T)] for cl in clips]
+    cfgs = [default_config(mem_every=3), default_config(mem_every=3, top_k=12)]
+    ex = _lib.get_executor()
+    ex.per_sample_conv = True
+    try:
+        with torch.inference_mode():
+            seq = []
+            for c, cl in enumerate(clips):
+                proc = InferenceCore(product_net, cfg=cfgs[c])
+                seq.append(torch.stack([proc.step(frames[c][0], cl.first_mask(), objects=cl.objects)] + [proc.step(frames[c][t]) for t in range(1, T)]))
+            ls = LockstepCores(product_net, cfgs[0], C)
+            ls[1].update_config(cfgs[1])
+            outs = [ls.step([f[0] for f in frames], [cl.first_mask() for cl in clips], [cl.objects for cl in clips])]
+            for t in range(1, T):
+                outs.append(ls.step([f[t] for f in frames], **(dict(next_images=[f[t + 1:t + 8] for f in frames]) if t + 1 < T else {})))
+            assert ls.batched_steps == T - 1 and ls.joint_passes == 0 and ls.stacked_steps == 0, (ls.batched_steps, ls.joint_passes, ls.stacked_steps)
+            for c in range(C):
+                got = torch.stack([o[c] for o in outs])
+                assert torch.equal(got, seq[c]), (c, float((got - seq[c]).abs().max()))
+            assert not torch.equal(seq[1], torch.stack([o[0] for o in outs]))
+    finally:
+        ex.per_sample_conv = False
+
+
 def test_lockstep_leaves_the_batched_path_when_the_clips_stop_being_uniform(product_net):
     """LockstepCores: a frame that brings masks, and everything behind it once the clips hold a second bucket (objects added mid-clip,
     kv_memory_store.py:96-117), run clip by clip through the cores' own step -- still every clip's own results; deleting the second
