@@ -112,10 +112,54 @@ typedef const __attribute__((address_space(1))) float* aff_gf32;      // (a poin
 #define AFF_CSTRIDE 32
 #define AFF_TG 4                                      // tiles per LDS group
 #define AFF_LCAP 1024                                 // LDS candidate list entries per block ...
-#define AFF_WCAP (AFF_LCAP / 4)                       // ... = 4 wave-private lists (overflow -> direct global append)
+#define AFF_WCAP (AFF_LCAP / 4)                       // ... = 4 wave-private lists (a full list is flushed and starts again)
+// The wave's list -> the global per-query lists.  Also the path of a FULL list (round 6): until then what did not fit went to the global lists entry
+// by entry -- a returning atomic and a wait per hit inside the tile loop -- and on the bench clip a third of all candidates did (hits per wave and
+// block: mean 42, 1 % over 976, maximum 1659; tools/top2_probe.py): those few waves were the launch (33 us against a floor of 9).
+// ONE global atomic per query and flush: the entries are ranked inside their query by LDS atomics first (a query of a candidate-dense region
+// collects ~370 candidates; one returning atomic each on its counter's cache line serialised in the L2: the pass ran at that line's pace).
+// The hits of one 16 x 16 fragment (lane: 4 tokens of its query) -> the wave's list.  The wave owns its queries: positions come from a wave-private
+// counter + lane prefixes, no atomics and no waits inside the MFMA loop.  A lane holds 0..4 hits: the prefix over the lanes is built from the THREE bit
+// planes of that count (three ballots, mbcnt on each) instead of one ballot -> branch -> append round per token row (round 6: the four rounds per fragment
+// were most of an executed tile's ~1700 cycles in candidate-dense regions, where every fragment of a wave has hits).
+#define AFF_MBCNT(B) __builtin_amdgcn_mbcnt_hi((unsigned)((B) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)(B), 0u))
+#define AFF_APPEND_HITS(S, JQ, THR, VALID, TOK0, WQ0_, NWQ_)                                                           \
+    {                                                                                                      \
+        bool h_[4];                                                                                        \
+        int nl_ = 0;                                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) { h_[q] = (VALID) && (S)[q] >= (THR) && (S)[q] > -INFINITY; nl_ += h_[q] ? 1 : 0; } \
+        const unsigned long long b0_ = __ballot((nl_ & 1) != 0), b1_ = __ballot((nl_ & 2) != 0), b2_ = __ballot((nl_ & 4) != 0); \
+        const int nh_ = __popcll(b0_) + 2 * __popcll(b1_) + 4 * __popcll(b2_);                             \
+        if (nh_) {                                                      /* wave-uniform */                  \
+            if (wcount + nh_ > AFF_WCAP) { AFF_FLUSH_LIST(wcount, WQ0_, NWQ_); wcount = 0; }   /* a full list is flushed and starts again (nh_ <= AFF_WCAP) */ \
+            int pos_ = wcount + AFF_MBCNT(b0_) + 2 * AFF_MBCNT(b1_) + 4 * AFF_MBCNT(b2_);                  \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                  \
+                if (h_[q]) { wl_j[pos_] = (JQ); wl_idx[pos_] = (TOK0) + q; wl_val[pos_] = (S)[q]; ++pos_; } \
+            wcount += nh_;                                                                                 \
+        }                                                                                                  \
+    }
+#define AFF_FLUSH_LIST(N, WQ0, NWQ)                                                                        \
+    {                                                                                                      \
+        const int n_ = (N);                                                                                \
+        int fj_[AFF_WCAP / 64], fr_[AFF_WCAP / 64];                                                        \
+        _Pragma("unroll") for (int r_ = 0; r_ < AFF_WCAP / 64; ++r_) fj_[r_] = r_ * 64 + lane < n_ ? wl_j[r_ * 64 + lane] - (WQ0) : -1; \
+        /* rank of every entry among the entries of its query: returning LDS atomics on the wave's own counters (zero between two flushes) */ \
+        _Pragma("unroll") for (int r_ = 0; r_ < AFF_WCAP / 64; ++r_) fr_[r_] = fj_[r_] >= 0 ? atomicAdd(&wl_cnt[fj_[r_]], 1) : 0; \
+        if (lane < (NWQ)) {                                             /* ONE returning global atomic per query with entries */ \
+            const int c_ = wl_cnt[lane];                                                                   \
+            wl_cnt[64 + lane] = c_ ? atomicAdd(&p.count[((WQ0) + lane) * AFF_CSTRIDE], c_) : 0;           \
+            wl_cnt[lane] = 0;                                                                              \
+        }                                                                                                  \
+        _Pragma("unroll") for (int r_ = 0; r_ < AFF_WCAP / 64; ++r_)                                       \
+            if (fj_[r_] >= 0) {                                                                            \
+                const int pos_ = wl_cnt[64 + fj_[r_]] + fr_[r_];                                           \
+                const long j_ = (WQ0) + fj_[r_];                                                           \
+                if (pos_ < p.cap) { p.cand_val[j_ * p.cap + pos_] = wl_val[r_ * 64 + lane]; p.cand_idx[j_ * p.cap + pos_] = wl_idx[r_ * 64 + lane]; } \
+            }                                                                                              \
+    }
 #define AFF_LDS_BYTES (2 * 2 * 64 * 16 * 16 + AFF_LCAP * 12 + 16 + 2 * 64 * 4)
 #undef AFF_LDS_BYTES
-#define AFF_LDS_BYTES (2 * 2 * 64 * 16 * 16 + AFF_LCAP * 12 + 16 + 2 * 2 * 64 * 4)
+#define AFF_LDS_BYTES (2 * 2 * 64 * 16 * 16 + AFF_LCAP * 12 + 16 + 2 * 2 * 64 * 4 + 4 * 128 * 4)     // (... + per wave 64 entry counters and 64 list bases of a flush)
 // AFF_MODE (compile-time pass): 0 = per-(tile, query) maxima, 1 = candidate lists.  The max-only pass carries neither the
 // candidate-list code nor its registers (6 instead of 22 non-MFMA instructions per MFMA).
 // Round-2 changes, all from the instruction mix (the loop was SALU / VALU-bound, not MFMA-bound):
@@ -189,6 +233,9 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
         Ahi_ = reinterpret_cast<const bf16_t*>(tb_[0]); Alo_ = reinterpret_cast<const bf16_t*>(tb_[1]); scale_ = reinterpret_cast<const float*>(tb_[2]);
     }
     int* wl_j = l_j + wave * AFF_WCAP; int* wl_idx = l_idx + wave * AFF_WCAP; float* wl_val = l_val + wave * AFF_WCAP;
+    int* const wl_cnt = reinterpret_cast<int*>(lpad + 2) + wave * 128;  // AFF_FLUSH_LIST: [64] entries per query, [64] list bases (wave-private)
+    if (mode == 1) { wl_cnt[lane] = 0; }
+    const int wq0 = bx * (64 * AFF_NQ) + wave * (16 * AFF_NQ);          // first query of this wave
     int wcount = 0;                                                     // wave-uniform fill of the wave's list
     int jq[AFF_NQ];                                                     // query column of this lane, per set
     bool jvalid[AFF_NQ];
@@ -434,25 +481,7 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
                         if (mode == 0) {
                             gm[u][t] = rows_max(mx);
                         } else if (__ballot(jvalid[u] && mx >= thr[u])) {   // wave-uniform: some lane has a candidate in this tile
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const bool hit = jvalid[u] && s[q] >= thr[u] && s[q] > -INFINITY;
-                                const unsigned long long m = __ballot(hit);
-                                if (m) {
-                                    // the wave owns its queries: positions come from a wave-private counter + lane prefix
-                                    // (mbcnt), no atomics and no waits inside the MFMA loop
-                                    const int pos = wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                                    if (hit) {
-                                        const int tok = slot0 + l4 * 4 + q;
-                                        if (pos < AFF_WCAP) { wl_j[pos] = jq[u]; wl_idx[pos] = tok; wl_val[pos] = s[q]; }
-                                        else {                              // wave list full: straight to the global list
-                                            const int gp = atomicAdd(&p.count[jq[u] * AFF_CSTRIDE], 1);
-                                            if (gp < p.cap) { p.cand_val[(long)jq[u] * p.cap + gp] = s[q]; p.cand_idx[(long)jq[u] * p.cap + gp] = tok; }
-                                        }
-                                    }
-                                    wcount += __popcll(m);
-                                }
-                            }
+                            AFF_APPEND_HITS(s, jq[u], thr[u], jvalid[u], slot0 + l4 * 4, wq0, 16 * AFF_NQ)
                         }
                     }
                 }
@@ -479,12 +508,7 @@ __global__ __launch_bounds__(256) void aff_score_kernel(ScoreParams p) {
 #undef AFF_LOAD
 #undef AFF_STORE
     if (mode == 1) {                                                    // flush this wave's candidates: one dense burst of global atomics
-        const int n = min(wcount, AFF_WCAP);
-        for (int e = lane; e < n; e += 64) {
-            const int j = wl_j[e];
-            const int pos = atomicAdd(&p.count[j * AFF_CSTRIDE], 1);
-            if (pos < p.cap) { p.cand_val[(long)j * p.cap + pos] = wl_val[e]; p.cand_idx[(long)j * p.cap + pos] = wl_idx[e]; }
-        }
+        AFF_FLUSH_LIST(wcount, wq0, 16 * AFF_NQ);
 #ifdef AFF_TIMELINE
         __builtin_amdgcn_s_waitcnt(0);                                  // (the stamp behind the flush counts the atomics' round trips)
         ATL(12)
@@ -509,7 +533,7 @@ typedef __amdgpu_buffer_rsrc_t aff_rsrc_t;
 #define AF4_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define AF4_PRE 4096
 #define AF4_STAGE (2 * 64 * 256)                      // [hi | lo] x 64 rows x 256 B
-#define AF4_LDS_BYTES (2 * AF4_STAGE + AFF_LCAP * 12 + 16 + 2 * 2 * 64 * 4)
+#define AF4_LDS_BYTES (2 * AF4_STAGE + AFF_LCAP * 12 + 16 + 2 * 2 * 64 * 4 + 4 * 128 * 4)
 
 template <int NQ, int AFF_MODE, bool JT = false>      // NQ: 16-query column sets per wave (2 or 4); JT: one bank per stacked frame (see ScoreParams::tbl)
 __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
@@ -627,6 +651,8 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
     }
     ATL(2)
     int* wl_j = l_j + wave * AFF_WCAP; int* wl_idx = l_idx + wave * AFF_WCAP; float* wl_val = l_val + wave * AFF_WCAP;
+    int* const wl_cnt = reinterpret_cast<int*>(lpad + 2) + wave * 128;  // (see aff_score_kernel)
+    if (mode == 1) { wl_cnt[lane] = 0; }
     int wcount = 0;                                                     // wave-uniform fill of the wave's list
     f32x4 gcur[NQ];
 #pragma unroll
@@ -698,23 +724,7 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
                                 const float m_ = rows_max(mx);
                                 if (l4 == 0) gmf[(wave * WQ + u * 16 + l15) * 4 + t] = m_;      // parked in LDS until AF4_FLUSH
                             } else if (__ballot(jvalid[u] && mx >= thr[u])) {   // wave-uniform: some lane has a candidate in this tile
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    const bool hit = jvalid[u] && s[q] >= thr[u] && s[q] > -INFINITY;
-                                    const unsigned long long m = __ballot(hit);
-                                    if (m) {
-                                        const int pos = wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                                        if (hit) {
-                                            const int tok = slot0 + l4 * 4 + q;
-                                            if (pos < AFF_WCAP) { wl_j[pos] = jq[u]; wl_idx[pos] = tok; wl_val[pos] = s[q]; }
-                                            else {                          // wave list full: straight to the global list
-                                                const int gp = atomicAdd(&p.count[jq[u] * AFF_CSTRIDE], 1);
-                                                if (gp < p.cap) { p.cand_val[(long)jq[u] * p.cap + gp] = s[q]; p.cand_idx[(long)jq[u] * p.cap + gp] = tok; }
-                                            }
-                                        }
-                                        wcount += __popcll(m);
-                                    }
-                                }
+                                AFF_APPEND_HITS(s, jq[u], thr[u], jvalid[u], slot0 + l4 * 4, wq0, WQ)
                             }
                         }
                     }
@@ -743,14 +753,7 @@ __global__ __launch_bounds__(256) void aff_score4_kernel(ScoreParams p) {
 #undef AF4_LOAD
 #undef AF4_PIECE
 #undef AF4_SYNC
-    if (mode == 1) {                                                    // flush this wave's candidates: one dense burst of global atomics
-        const int n = min(wcount, AFF_WCAP);
-        for (int e = lane; e < n; e += 64) {
-            const int j = wl_j[e];
-            const int pos = atomicAdd(&p.count[j * AFF_CSTRIDE], 1);
-            if (pos < p.cap) { p.cand_val[(long)j * p.cap + pos] = wl_val[e]; p.cand_idx[(long)j * p.cap + pos] = wl_idx[e]; }
-        }
-    }
+    if (mode == 1) AFF_FLUSH_LIST(wcount, wq0, WQ);                     // flush this wave's candidates
 #endif
 }
 

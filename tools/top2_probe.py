@@ -59,3 +59,16 @@ with torch.inference_mode():
         mm = torch.cat([m, torch.zeros((T, q32 * 32 - HW), dtype=torch.bool, device='cuda')], 1).view(T, q32, 32).any(2)
         return mm.float().mean().item()
     print('fraction of (tile, 32-query) pairs executed: today %.3f, with top-2 kept %.3f' % (pairs(top2[:, 0] >= tau), pairs(top2[:, 1] >= tau)))
+    # the candidate pass's wave-private lists: hits per (32-query wave, block row of the launch) -- a list holds 256 entries (AFF_WCAP), what does not
+    # fit goes to the global lists entry by entry
+    thr = tau - tau.abs() * 1e-6 - 1e-30
+    hits = (sim >= thr[None, :]).float()                                # [N, HW]
+    for ny in (39, 20):
+        tiles_per_row = -(-T // ny)
+        rows_tok = tiles_per_row * 16
+        hp = torch.cat([hits, torch.zeros((ny * rows_tok - N, HW), device='cuda')]) if ny * rows_tok > N else hits[:ny * rows_tok]
+        hq = torch.cat([hp, torch.zeros((hp.shape[0], q32 * 32 - HW), device='cuda')], 1)
+        per = hq.view(ny, rows_tok, q32, 32).sum((1, 3))                # [block row, wave]
+        print('block rows %d: hits per (wave, block row): mean %.1f, p99 %.0f, max %.0f; lists over 256 entries: %d of %d (overflowing entries %.0f of %.0f)' % (
+            ny, per.mean().item(), per.flatten().kthvalue(int(0.99 * per.numel()))[0].item(), per.max().item(), int((per > 256).sum()), per.numel(),
+            (per - 256).clamp(min=0).sum().item(), per.sum().item()))
