@@ -920,6 +920,52 @@ def test_run_batched_groups_in_flight_and_small_model():
             assert g.shape == want[c].shape and torch.equal(g, want[c]), (in_flight, c, int((g != want[c]).sum()))
 
 
+def test_eval_driver_videos_in_lock_step_on_gpu(gpu_net, tmp_path):
+    """eval_vos.process_videos_lockstep (the --lockstep option of the dataset driver) on the MI355X: three generated videos of one frame size
+    and object count, of different lengths, advanced in lock step -- the joint encoder window, one read-out pass for the three banks, the
+    lock-step plans, and the clip-by-clip tail once the shortest video has ended -- write byte for byte the PNGs that process_video writes
+    for each of them alone."""
+    import os
+    import numpy as np
+    from PIL import Image
+    from cutie_amd.eval_vos import lockstep_key, process_video, process_videos_lockstep
+    from cutie_amd.inference.data.vos_test_dataset import VOSTestDataset
+    from cutie_amd.inference.utils.results_utils import davis_palette
+    from cutie_amd.utils.synth import SyntheticClip
+    root = str(tmp_path)
+
+    def make(name, n, ids, seed):
+        clip = SyntheticClip(240, 432, len(ids), n, seed=seed)
+        os.makedirs(os.path.join(root, 'JPEGImages', name)); os.makedirs(os.path.join(root, 'Annotations', name))
+        for t in range(n):
+            arr = (clip.frame(t).permute(1, 2, 0).numpy() * 255).round().astype(np.uint8)
+            Image.fromarray(arr).save(os.path.join(root, 'JPEGImages', name, f'{t:05d}.jpg'), quality=95)
+        lut = np.zeros(256, dtype=np.uint8)
+        for k, oid in enumerate(ids):
+            lut[k + 1] = oid
+        png = Image.fromarray(lut[clip.first_mask().numpy()].astype(np.uint8))
+        png.putpalette(davis_palette)
+        png.save(os.path.join(root, 'Annotations', name, '00000.png'))
+    lens = dict(vA=13, vB=17, vC=11)
+    for i, (n, T) in enumerate(lens.items()):
+        make(n, T, (1 + i, 5 + i), 31 + i)
+    ds = VOSTestDataset(os.path.join(root, 'JPEGImages'), os.path.join(root, 'Annotations'), use_all_masks=False)
+    rds = {rd.vid_name: rd for rd in ds.get_datasets()}
+    assert len({lockstep_key(rd) for rd in rds.values()}) == 1
+    cfg = default_config(mem_every=3)
+    with torch.inference_mode():
+        for n in lens:
+            process_video(gpu_net, cfg, rds[n], os.path.join(root, 'alone'))
+        st = process_videos_lockstep(gpu_net, cfg, [rds[n] for n in lens], os.path.join(root, 'ls'))
+    torch.cuda.synchronize()
+    assert [st[i]['frames'] for i in range(len(lens))] == list(lens.values())
+    for n, T in lens.items():
+        fa, fl = sorted(os.listdir(os.path.join(root, 'alone', n))), sorted(os.listdir(os.path.join(root, 'ls', n)))
+        assert fa == fl and len(fa) == T
+        for f in fa:
+            assert open(os.path.join(root, 'alone', n, f), 'rb').read() == open(os.path.join(root, 'ls', n, f), 'rb').read(), (n, f)
+
+
 def test_eval_driver_on_bike_example(gpu_net, tmp_path):
     """Section 8(f) rank 1: the bike frames through VideoReader -> InferenceCore -> fused argmax/remap -> PNG writer; the first
     PNG reproduces the annotation, every PNG equals output_prob_to_mask of a second pass."""
