@@ -874,7 +874,7 @@ typedef const __attribute__((address_space(1))) ro_u32x4* ro_gptr;
 __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
                                                                  const int* __restrict__ count, const uint64_t* __restrict__ vptrs,
                                                                  float* __restrict__ usage, bf16_t* __restrict__ y, int* __restrict__ overflow,
-                                                                 int HW, int cap, int topk, int K, int CV, int HWpf, int nrows, int ustride, int prio, int nbanks) {
+                                                                 int HW, int cap, int topk, int K, int CV, int HWpf, int nrows, int ustride, int prio, int nbanks, int ufx) {
     if (prio) __builtin_amdgcn_s_setprio(1);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float* cv = reinterpret_cast<float*>(lds_raw);             // [cap]
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __
     const int fr = j / HWpf, jl = j - fr * HWpf;
     if (jl >= HW) return;
     y += (long)fr * K * HW * CV;
-    if (usage) usage += (long)fr * ustride;
+    if (usage) usage += (long)fr * ustride * (ufx ? 2 : 1);     // (fixed-point usage: 8-byte counters)
     if (nbanks > 1) vptrs += (long)(fr % nbanks) * K;          // (ABI 4) clips in lock step: frame fr reads bank fr % nbanks, whose K value-bank bases follow each other
     // every global round trip that does not depend on another is issued up front: the count, the first RO_THREADS
     // candidates (typical fill is 30-50 of the 1024 slots), the bank base pointer of this thread's object
@@ -1017,7 +1017,13 @@ __global__ __launch_bounds__(RO_THREADS) void aff_readout_kernel(const float* __
     // usage += softmax weight of every selected token (kv_memory_store.py:151-162).  Last on purpose: on gfx950 an atomic counts in
     // vmcnt like a load, so issued before the gather every wait for a value row also waited for the atomics, which serialise in
     // the L2 on the popular tokens.
-    if (usage && tid < nsel) atomicAdd(&usage[sel_i[tid]], sel_w[tid]);
+    // ufx (what the product uses, round 6): the counters are unsigned 64-bit FIXED POINT (2^-40): integer atomics commute, so the sums do not
+    // depend on the order in which the blocks arrive.  The float form's last bits did -- and with them, a few hundred frames later, a near-tie
+    // of the long-term consolidation's usage ranking: a clip advanced in lock step left its own InferenceCore run (tools/lockstep_soak.py).
+    if (usage && tid < nsel) {
+        if (ufx) atomicAdd(reinterpret_cast<unsigned long long*>(usage) + sel_i[tid], (unsigned long long)(sel_w[tid] * 1099511627776.f));
+        else atomicAdd(&usage[sel_i[tid]], sel_w[tid]);
+    }
 }
 
 int launch_affinity(const cutie_op* op, hipStream_t s) {
@@ -1137,7 +1143,7 @@ int launch_affinity(const cutie_op* op, hipStream_t s) {
             if (i[8] > 1 && frames % i[8]) { cutie_set_error("aff_readout: %d frames over %d banks", frames, i[8]); return -2; }
             hipLaunchKernelGGL(aff_readout_kernel, dim3(((nrows + 7) / 8) * 8), dim3(RO_THREADS), lds, s, (const float*)p[0], (const int*)p[1], (const int*)p[2],
                                (const uint64_t*)p[3], (float*)p[4], (bf16_t*)p[5], (int*)p[6], i[0], i[1], i[2], i[3], i[4],
-                               frames > 1 ? i[6] : nrows, nrows, i[7], (op->flags & 64) ? 1 : 0, i[8] > 1 ? i[8] : 1);
+                               frames > 1 ? i[6] : nrows, nrows, i[7], (op->flags & 64) ? 1 : 0, i[8] > 1 ? i[8] : 1, (op->flags & 1) ? 1 : 0);
             break;
         }
         default:

@@ -416,15 +416,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
         if (n0 + c < p.Cout) {
             const int r0 = part * RPART, r1 = min(r0 + RPART, rows);
             int m = m0 + r0, obj = m / p.OHW, next_b = (obj + 1) * p.OHW;
-            float sum = 0.f;
+            long long sum = 0;                               // (fixed point per VALUE, integer sums: conv_common.h conv_gapfx)
             for (int r = r0; r < r1; ++r, ++m) {
                 if (m == next_b) {
-                    atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)obj * p.Cout + n0 + c), (unsigned long long)__float2ll_rn(sum * GAP_FIXED_SCALE));
-                    sum = 0.f; ++obj; next_b += p.OHW;
+                    atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)obj * p.Cout + n0 + c), (unsigned long long)sum);
+                    sum = 0; ++obj; next_b += p.OHW;
                 }
-                sum += ctile[r * LDC + c];
+                sum += conv_gapfx(ctile[r * LDC + c]);
             }
-            if (r1 > r0) atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)obj * p.Cout + n0 + c), (unsigned long long)__float2ll_rn(sum * GAP_FIXED_SCALE));
+            if (r1 > r0) atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)obj * p.Cout + n0 + c), (unsigned long long)sum);
         }
     }
 #endif

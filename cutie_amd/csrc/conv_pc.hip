@@ -178,11 +178,11 @@ __device__ __forceinline__ int pc_res_row(const ConvParams& p, int m) {
 // per lane and channel (round 3, first version) the same sums were 8 four-lane instructions per fragment whose requests serialise in
 // the L2 on the few lines of the accumulator: +21 us on the 4860 x 256 conv (profiles/r03_conv_ablation.md).
 template <int NCH>
-__device__ __forceinline__ float pc_colsum16(const float (&s)[NCH], int l15, int& c, bool& writer) {
+__device__ __forceinline__ long long pc_colsum16(const long long (&s)[NCH], int l15, int& c, bool& writer) {
     const bool h8 = l15 & 8, h4 = l15 & 4, h2 = l15 & 2;
-    float w;
+    long long w;
     if constexpr (NCH == 8) {
-        float t[4], u[2];
+        long long t[4], u[2];
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[r] = (h8 ? s[4 + r] : s[r]) + __shfl_xor(h8 ? s[r] : s[4 + r], 8, 64);
 #pragma unroll
@@ -192,7 +192,7 @@ __device__ __forceinline__ float pc_colsum16(const float (&s)[NCH], int l15, int
         c = (h8 ? 4 : 0) + (h4 ? 2 : 0) + (h2 ? 1 : 0);
         writer = (l15 & 1) == 0;
     } else {
-        float t[2];
+        long long t[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) t[r] = (h8 ? s[2 + r] : s[r]) + __shfl_xor(h8 ? s[r] : s[2 + r], 8, 64);
         w = (h4 ? t[1] : t[0]) + __shfl_xor(h4 ? t[0] : t[1], 4, 64);
@@ -203,9 +203,9 @@ __device__ __forceinline__ float pc_colsum16(const float (&s)[NCH], int l15, int
     }
     return w;
 }
-__device__ __forceinline__ void pc_gap_add(const ConvParams& p, int obj, int ch, float v) {
-    // fixed point + integer atomics: the total does not depend on the order of arrival (bit-reproducible)
-    if (ch < p.Cout) atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)obj * p.Cout + ch), (unsigned long long)__float2ll_rn(v * GAP_FIXED_SCALE));
+__device__ __forceinline__ long long pc_gapfx(float v) { return conv_gapfx(v); }      // (conv_common.h: fixed point per VALUE, integer sums)
+__device__ __forceinline__ void pc_gap_add(const ConvParams& p, int obj, int ch, long long v) {
+    if (ch < p.Cout) atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)obj * p.Cout + ch), (unsigned long long)v);
 }
 
 // Fast epilogue of the common configurations, chosen ONCE per block by wave-uniform tests: whole tile inside Cout, aligned strides, no
@@ -217,12 +217,12 @@ __device__ __forceinline__ void pc_epilogue_fast(const ConvParams& p, const f32x
                                                  const int (&mrow)[TM], const bool (&mval)[TM], int chbase,
                                                  const unsigned (&rpre)[PRE ? TM : 1][PRE ? TNP : 1][NCH / 2], int gap_obj = 0, int l15 = 0) {
     unsigned rr[TM][TNP][NCH / 2];
-    float gs[GAPJ ? TNP : 1][NCH];                       // GAPJ (the wave's rows lie in ONE object, gap_obj): stored values summed over its fragments
+    long long gs[GAPJ ? TNP : 1][NCH];                   // GAPJ (the wave's rows lie in ONE object, gap_obj): stored values, in fixed point, summed over its fragments
     if (GAPJ) {
 #pragma unroll
         for (int a = 0; a < TNP; ++a)
 #pragma unroll
-            for (int r = 0; r < NCH; ++r) gs[a][r] = 0.f;
+            for (int r = 0; r < NCH; ++r) gs[a][r] = 0;
     }
     if (RES && !PRE) {                                   // all residual loads first: one exposed latency, not one per slice
 #pragma unroll
@@ -276,7 +276,7 @@ __device__ __forceinline__ void pc_epilogue_fast(const ConvParams& p, const f32x
                     else *reinterpret_cast<uint2*>(yp) = make_uint2(o[0], o[1]);
                     if (GAPJ) {                          // the STORED (bf16-rounded) values
 #pragma unroll
-                        for (int r = 0; r < NCH / 2; ++r) { gs[GAPJ ? a : 0][2 * r] += __uint_as_float(o[r] << 16); gs[GAPJ ? a : 0][2 * r + 1] += __uint_as_float(o[r] & 0xffff0000u); }
+                        for (int r = 0; r < NCH / 2; ++r) { gs[GAPJ ? a : 0][2 * r] += pc_gapfx(__uint_as_float(o[r] << 16)); gs[GAPJ ? a : 0][2 * r + 1] += pc_gapfx(__uint_as_float(o[r] & 0xffff0000u)); }
                     }
                 }
             }
@@ -286,7 +286,7 @@ __device__ __forceinline__ void pc_epilogue_fast(const ConvParams& p, const f32x
 #pragma unroll
         for (int a = 0; a < TNP; ++a) {
             int c; bool writer;
-            const float tot = pc_colsum16<NCH>(gs[GAPJ ? a : 0], l15, c, writer);
+            const long long tot = pc_colsum16<NCH>(gs[GAPJ ? a : 0], l15, c, writer);
             if (writer) pc_gap_add(p, gap_obj, chbase + a * (PAIR ? 32 : 16) + c, tot);
         }
     }
@@ -830,11 +830,11 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
         }
     }
 #endif
-    float gsum[TNP][NCH];                                // generic path, GAP with the wave in one object: stored values summed over its fragments
+    long long gsum[TNP][NCH];                            // generic path, GAP with the wave in one object: stored values, in fixed point, summed over its fragments
 #pragma unroll
     for (int a = 0; a < TNP; ++a)
 #pragma unroll
-        for (int r = 0; r < NCH; ++r) gsum[a][r] = 0.f;
+        for (int r = 0; r < NCH; ++r) gsum[a][r] = 0;
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
 #pragma unroll
@@ -855,7 +855,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
             if (p.gap) {
                 if (gap_one) {
 #pragma unroll
-                    for (int r = 0; r < NCH; ++r) gsum[a][r] += st[r];
+                    for (int r = 0; r < NCH; ++r) gsum[a][r] += pc_gapfx(st[r]);
                 } else {
                     // a wave that straddles an object boundary (at most K - 1 row tiles of a launch): per fragment, the lanes of the first
                     // object and the lanes of the second are reduced separately (same-address atomics from 16 lanes of one instruction
@@ -869,18 +869,18 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
                         if (__ballot(mval[b] && ob != o1 && ob != o2)) {
                             if (live) {
 #pragma unroll
-                                for (int r = 0; r < NCH; ++r) pc_gap_add(p, ob, ch0 + r, st[r]);
+                                for (int r = 0; r < NCH; ++r) pc_gap_add(p, ob, ch0 + r, pc_gapfx(st[r]));
                             }
                         } else {
 #pragma unroll
                             for (int pass = 0; pass < 2; ++pass) {
                                 const int oo = pass ? o2 : o1;
                                 if (pass && !rest) break;
-                                float part[NCH];
+                                long long part[NCH];
 #pragma unroll
-                                for (int r = 0; r < NCH; ++r) part[r] = (live && ob == oo) ? st[r] : 0.f;
+                                for (int r = 0; r < NCH; ++r) part[r] = (live && ob == oo) ? pc_gapfx(st[r]) : 0;
                                 int c; bool writer;
-                                const float tot = pc_colsum16<NCH>(part, l15, c, writer);
+                                const long long tot = pc_colsum16<NCH>(part, l15, c, writer);
                                 if (writer) pc_gap_add(p, oo, ch0 + c, tot);
                             }
                         }
@@ -895,7 +895,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
 #pragma unroll
         for (int a = 0; a < TNP; ++a) {
             int c; bool writer;
-            const float tot = pc_colsum16<NCH>(gsum[a], l15, c, writer);
+            const long long tot = pc_colsum16<NCH>(gsum[a], l15, c, writer);
             if (writer) pc_gap_add(p, gap_obj, n0 + cn0 + a * (PAIR ? 32 : 16) + l4 * NCH + c, tot);
         }
     }

@@ -1128,11 +1128,18 @@ __global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, 
 }
 // life counters of up to two token ranges advance by one; optionally use[i] += delta[i] (the usage a look-ahead read-out parked
 // in a side buffer, applied when -- and only when -- that read-out is consumed)
-__global__ void tick_kernel(float* lifeA, long nA, float* lifeB, long nB, float* use, const float* delta, long nU) {
+// dfx & 1: delta holds unsigned 64-bit fixed-point sums (2^-40, AFF_READOUT flags&1): converted with one rounding; dfx & 2: and is cleared behind it
+__global__ void tick_kernel(float* lifeA, long nA, float* lifeB, long nB, float* use, float* delta, long nU, int dfx) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (lifeA && i < nA) lifeA[i] += 1.f;
     if (lifeB && i < nB) lifeB[i] += 1.f;
-    if (use && i < nU) use[i] += delta[i];
+    if (use && i < nU) {
+        if (dfx & 1) {
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(delta);
+            use[i] += (float)((double)d[i] * 9.094947017729282e-13);
+            if (dfx & 2) d[i] = 0ull;
+        } else use[i] += delta[i];
+    }
 }
 __global__ void cast_kernel(const void* s, void* d, long n, int to_f32) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1415,7 +1422,7 @@ int launch_elementwise(const cutie_op* op, hipStream_t s) {
             const long nA = p[0] ? i[0] : 0, nB = p[1] ? i[1] : 0, nU = (p[2] && p[3]) ? i[2] : 0;
             const long n = nA > nB ? (nA > nU ? nA : nU) : (nB > nU ? nB : nU);
             if (n > 0)
-                hipLaunchKernelGGL(tick_kernel, GRID1D(n, BS), dim3(BS), 0, s, (float*)p[0], nA, (float*)p[1], nB, (float*)p[2], (const float*)p[3], nU);
+                hipLaunchKernelGGL(tick_kernel, GRID1D(n, BS), dim3(BS), 0, s, (float*)p[0], nA, (float*)p[1], nB, (float*)p[2], (float*)p[3], nU, op->flags & 3);
         }
             break;
         case CUTIE_OP_CAST:

@@ -222,7 +222,7 @@ class MemoryManager:
                     if ticks_n:
                         ol.patch_ints(ops_['select'], 4, ticks_n)  # AFF_SELECT i4, i5 = the counted ranges (in the order they were given)
                 if ops_['clear'] is not None:
-                    ol.patch_ints(ops_['clear'], 0, [bucket.n_long])
+                    ol.patch_ints(ops_['clear'], 0, [2 * bucket.n_long])
                 plans_[ahead] = cached = (key, vals, ol, ops_)
         else:
             D = O.Dyn
@@ -240,7 +240,7 @@ class MemoryManager:
             if tick_long and not ahead:
                 ticks.append((D('life'), bucket.n_long))
             if ahead and self.use_long_term:
-                ops_['select'] = ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), zero=(D('usage'), nslots), prio=True)
+                ops_['select'] = ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), zero=(D('usage'), 2 * nslots), prio=True)
             elif _UNFUSED:
                 ol.memset32(D('count'), HW * O.OpList.AFF_CSTRIDE, 0)
                 ops_['select'] = ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k)
@@ -250,12 +250,18 @@ class MemoryManager:
                 ops_['select'] = ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), ticks=ticks, prio=True)
             ops_['score1'] = ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('tau'), D('cval'), D('cidx'), D('count'),
                                           mode=1, gmax_precedes_tau=True, **common)
+            # usage (kv_memory_store.py:151-162, the column sums of the affinity): accumulated in unsigned 64-bit FIXED POINT (2^-40) side counters
+            # -- integer atomics commute, a float sum's last bits follow the order in which the read-out's blocks arrive, and a near-tie of
+            # the consolidation's usage ranking follows those bits a few hundred frames later (tools/lockstep_soak.py) -- and added to the
+            # bank's fp32 counters with ONE rounding per read-out: by the last launch of this plan, or when a look-ahead read-out is consumed
             ol.aff_readout(D('cval'), D('cidx'), D('count'), D('vptrs'), D('usage') if self.use_long_term else None, D('readout'),
-                           D('ovf'), HW=HW, cap=CAND_CAP, top_k=self.top_k, K=K, CV=self.CV, prio=True)
+                           D('ovf'), HW=HW, cap=CAND_CAP, top_k=self.top_k, K=K, CV=self.CV, prio=True, usage_fx=True)
             if clear_long:
                 # long_term.count_usage=False: the reference keeps no usage for long-term tokens (memory_manager.py:145-147);
                 # the read-out kernel accumulates usage for every slot, so the long-term part is cleared again
-                ops_['clear'] = ol.memset32(D('usage'), bucket.n_long, 0)
+                ops_['clear'] = ol.memset32(D('usage'), 2 * bucket.n_long, 0)
+            if self.use_long_term and not ahead:
+                ol.usage_tick(None, 0, None, 0, use=D('use'), delta=D('usage'), n_use=nslots, delta_fx=True, clear_delta=True)
             plans_[ahead] = cached = (key, vals, ol, ops_)
         dyn = dict(count=count, Ahi=bucket.Ahi, Alo=bucket.Alo, scale=bucket.scale, Bhi=q['Bhi'], Blo=q['Blo'], cq=q['cq'],
                    gmax=gmax, tau=tau, cval=cval, cidx=cidx, vptrs=bucket.vptrs(), readout=readout, ovf=ovf)
@@ -264,11 +270,11 @@ class MemoryManager:
                 # two side buffers per bucket, alternating PER FRAME (prefetch_affinity flips the parity once per call, not once per
                 # bucket: with an even number of buckets a per-bucket flip handed every bucket the same buffer on every frame): the next
                 # look-ahead (side stream) may start before the caller's stream has applied this one
-                udelta = self._buf(f'udelta{self._ahead_parity}#{bucket.id}', (nslots,), F32, dev)
+                udelta = self._buf(f'udelta{self._ahead_parity}#{bucket.id}', (nslots,), torch.int64, dev)
                 dyn.update(life=bucket.life, usage=udelta)
                 self._last_udelta = udelta
-            else:
-                dyn.update(life=bucket.life, usage=bucket.use)
+            else:                                               # (zero between two read-outs: the plan's last launch clears what it has added)
+                dyn.update(life=bucket.life, usage=self._buf(f'udelta_direct#{bucket.id}', (nslots,), torch.int64, dev), use=bucket.use)
         cached[2].run(**dyn)
         return readout
 
@@ -310,7 +316,7 @@ class MemoryManager:
                     ol.patch_ints(op, 3, flat + [G])
                 ol.patch_ints(ops_['select'], 2, [G])
                 for op in ops_['clear']:
-                    ol.patch_ints(op, 0, [bucket.n_long])
+                    ol.patch_ints(op, 0, [2 * bucket.n_long])
                 plans_[('batch', F)] = cached = (key, vals, ol, ops_)
         else:
             D = O.Dyn
@@ -325,14 +331,14 @@ class MemoryManager:
             nq0, dma1 = (4, True) if big else (None, None)
             ops_['score0'] = ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('gmax'), None, None, None, mode=0, nq=nq0, **common)
             ops_['select'] = ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=self.top_k, clear_count=D('count'), frames=F,
-                                           zero=(D('usage'), F * nslots) if self.use_long_term else None)
+                                           zero=(D('usage'), 2 * F * nslots) if self.use_long_term else None)
             ops_['score1'] = ol.aff_score(D('Ahi'), D('Alo'), D('scale'), D('Bhi'), D('Blo'), D('cq'), D('tau'), D('cval'), D('cidx'), D('count'),
                                           mode=1, gmax_precedes_tau=True, nq=2 if big else None, dma=dma1, **common)
             ol.aff_readout(D('cval'), D('cidx'), D('count'), D('vptrs'), D('usage') if self.use_long_term else None, D('readout'),
-                           D('ovf'), HW=HW, cap=CAND_CAP, top_k=self.top_k, K=K, CV=self.CV, frames=F, HWp=HWp, usage_stride=nslots)
+                           D('ovf'), HW=HW, cap=CAND_CAP, top_k=self.top_k, K=K, CV=self.CV, frames=F, HWp=HWp, usage_stride=nslots, usage_fx=True)
             if clear_long:
                 for f in range(F):                                      # (memory_manager.py:145-147, as in the one-frame plan)
-                    ops_['clear'].append(ol.memset32(D('usage', 4 * f * nslots), bucket.n_long, 0))
+                    ops_['clear'].append(ol.memset32(D('usage', 8 * f * nslots), 2 * bucket.n_long, 0))
             plans_[('batch', F)] = cached = (key, vals, ol, ops_)
         dyn = dict(count=count, Ahi=bucket.Ahi, Alo=bucket.Alo, scale=bucket.scale, Bhi=q['Bhi'], Blo=q['Blo'], cq=q['cq'],
                    gmax=gmax, tau=tau, cval=cval, cidx=cidx, vptrs=bucket.vptrs(), readout=readout, ovf=ovf)
@@ -341,7 +347,7 @@ class MemoryManager:
             # two sets of side buffers per bucket, alternating per BATCH (a counter of the stacked read-outs alone -- ADVICE r05: on the
             # shared counter of the one-frame look-ahead, which flips once more per memory cycle, every batch landed on the same set):
             # the next batch (side stream) may start before the caller's stream has applied the last frame of this one
-            udelta = self._buf_rows(f'udelta#batch{self._batch_parity}#{bucket.id}', F, (nslots,), F32, dev)
+            udelta = self._buf_rows(f'udelta#batch{self._batch_parity}#{bucket.id}', F, (nslots,), torch.int64, dev)
             dyn.update(usage=udelta)
         cached[2].run(**dyn)
         return [(readout[f], udelta[f] if udelta is not None else None) for f in range(F)]
@@ -364,7 +370,7 @@ class MemoryManager:
         if cached is None or cached[0] != sig:
             ol = O.OpList()
             ol.usage_tick(bucket.life[bucket.work_start:] if tick_work else None, counts[0], bucket.life if tick_long else None, counts[1],
-                          use=bucket.use, delta=O.Dyn('delta'), n_use=sig[5])
+                          use=bucket.use, delta=O.Dyn('delta'), n_use=sig[5], delta_fx=True)
             cached = self._commit_plans[bucket.id] = (sig, ol, counts)
         elif cached[2] != counts:
             if PATCH_PLANS:
@@ -490,7 +496,7 @@ class MemoryManager:
                     ol.patch_ints(op, 3, flat + [G])
                 ol.patch_ints(ops_['select'], 2, [G])
                 for op in ops_['clear']:
-                    ol.patch_ints(op, 0, [b0.n_long])
+                    ol.patch_ints(op, 0, [2 * b0.n_long])
                 plans_[(E, prio)] = cached = (key, vals, ol, ops_)
         else:
             D = O.Dyn
@@ -499,14 +505,14 @@ class MemoryManager:
             common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=CAND_CAP, frames=E, nq=2, banks=(D('table'), C), prio=prio)
             ops_['score0'] = ol.aff_score(None, None, None, D('Bhi'), D('Blo'), D('cq'), D('gmax'), None, None, None, mode=0, dma=bool(JOINT_DMA & 1), **common)
             ops_['select'] = ol.aff_select(D('gmax'), D('tau'), HW=HW, HWp=HWp, G=G, top_k=m0.top_k, clear_count=D('count'), frames=E,
-                                           zero=(D('usage'), E * nslots) if m0.use_long_term else None, prio=prio)
+                                           zero=(D('usage'), 2 * E * nslots) if m0.use_long_term else None, prio=prio)
             ops_['score1'] = ol.aff_score(None, None, None, D('Bhi'), D('Blo'), D('cq'), D('tau'), D('cval'), D('cidx'), D('count'),
                                           mode=1, gmax_precedes_tau=True, dma=bool(JOINT_DMA & 2), **common)
             ol.aff_readout(D('cval'), D('cidx'), D('count'), D('vptrs'), D('usage') if m0.use_long_term else None, D('readout'),
-                           D('ovf'), HW=HW, cap=CAND_CAP, top_k=m0.top_k, K=K, CV=m0.CV, frames=E, HWp=HWp, usage_stride=nslots, banks=C, prio=prio)
+                           D('ovf'), HW=HW, cap=CAND_CAP, top_k=m0.top_k, K=K, CV=m0.CV, frames=E, HWp=HWp, usage_stride=nslots, banks=C, prio=prio, usage_fx=True)
             if clear_long:
                 for e in range(E):                                      # (memory_manager.py:145-147, as in the one-frame plan)
-                    ops_['clear'].append(ol.memset32(D('usage', 4 * e * nslots), b0.n_long, 0))
+                    ops_['clear'].append(ol.memset32(D('usage', 8 * e * nslots), 2 * b0.n_long, 0))
             plans_[(E, prio)] = cached = (key, vals, ol, ops_)
         # the banks' operand bases and value pointers, bank-major (rebuilt when an array of a bank moved: it grew)
         ptrs = tuple((b.Ahi.data_ptr(), b.Alo.data_ptr(), b.scale.data_ptr(), b.vptrs().data_ptr()) for b in bs)
@@ -519,7 +525,7 @@ class MemoryManager:
         udelta = None
         if m0.use_long_term:
             m0._joint_parity = m0.__dict__.get('_joint_parity', 0) ^ 1      # (two sets of usage side buffers, alternating per pass: see _affinity_batch)
-            udelta = m0._buf_rows(f'udelta#joint{m0._joint_parity}', E, (nslots,), F32, dev)
+            udelta = m0._buf_rows(f'udelta#joint{m0._joint_parity}', E, (nslots,), torch.int64, dev)
             dyn.update(usage=udelta)
         cached[2].run(**dyn)
         ev = event_factory() if event_factory is not None else None

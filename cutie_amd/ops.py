@@ -696,11 +696,12 @@ class OpList:
         assert len(ticks) == 2
         return self.add(AFF_SELECT, SELECT_COARSE | (F_AFF_PRIO if (prio and PRIO) else 0), [HW, HWp, G, top_k, ticks[0][1], ticks[1][1], frames], [], [gmax, tau, clear_count, ticks[0][0], ticks[1][0]])
 
-    def aff_readout(self, cand_val, cand_idx, count, vptrs, usage, y, overflow, *, HW, cap, top_k, K, CV, frames=1, HWp=0, usage_stride=0, prio=False, banks=1):
+    def aff_readout(self, cand_val, cand_idx, count, vptrs, usage, y, overflow, *, HW, cap, top_k, K, CV, frames=1, HWp=0, usage_stride=0, prio=False, banks=1, usage_fx=False):
         """frames > 1: stacked queries (HWp rows per frame, see aff_score); frame f's read-out goes to y[f] ([frames, K, HW, CV]) and its
-        usage to usage + f * usage_stride floats.  banks > 1: frame f gathers from bank f % banks -- vptrs: u64 [banks, K]."""
+        usage to usage + f * usage_stride counters.  banks > 1: frame f gathers from bank f % banks -- vptrs: u64 [banks, K].
+        usage_fx: the usage counters are unsigned 64-bit fixed point (2^-40) instead of f32 -- integer atomics, sums independent of the order of arrival."""
         assert banks == 1 or frames % banks == 0
-        return self.add(AFF_READOUT, F_AFF_PRIO if (prio and PRIO) else 0, [HW, cap, top_k, K, CV, frames, HWp, usage_stride, banks], [], [cand_val, cand_idx, count, vptrs, usage, y, overflow])
+        return self.add(AFF_READOUT, (F_AFF_PRIO if (prio and PRIO) else 0) | (1 if usage_fx else 0), [HW, cap, top_k, K, CV, frames, HWp, usage_stride, banks], [], [cand_val, cand_idx, count, vptrs, usage, y, overflow])
 
     def memset32(self, dst, n, value=0):
         return self.add(MEMSET32, 0, [n, value], [], [dst])
@@ -729,9 +730,11 @@ class OpList:
     def axpy(self, x, y, *, n, a=1.0):
         return self.add(AXPY, 0, [n], [a], [x, y])
 
-    def usage_tick(self, life, n, life2=None, n2=0, use=None, delta=None, n_use=0):
-        """life[:n] += 1, life2[:n2] += 1, use[:n_use] += delta[:n_use] -- one launch (any part may be absent)."""
-        return self.add(USAGE_TICK, 0, [n, n2, n_use], [], [life, life2, use, delta])
+    def usage_tick(self, life, n, life2=None, n2=0, use=None, delta=None, n_use=0, delta_fx=False, clear_delta=False):
+        """life[:n] += 1, life2[:n2] += 1, use[:n_use] += delta[:n_use] -- one launch (any part may be absent).  delta_fx: delta holds the unsigned
+        64-bit fixed-point sums (2^-40) of AFF_READOUT(usage_fx=True); clear_delta (with delta_fx): and is zero again afterwards."""
+        assert delta_fx or not clear_delta
+        return self.add(USAGE_TICK, (1 if delta_fx else 0) | (2 if clear_delta else 0), [n, n2, n_use], [], [life, life2, use, delta])
 
     RS_SPLIT = 16             # chunks of the all-pairs rank count (csrc/bank.hip)
 

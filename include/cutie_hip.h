@@ -256,7 +256,10 @@ enum {
      * i: 0 HW 1 cap 2 top_k 3 K 4 CV
      * ABI 3: i5 > 1 = that many stacked frames of i6 query rows each; frame f's read-out goes to y + f * K*HW*CV and its usage to
      *      p4 + f * i7 floats (per-frame side buffers: a look-ahead read-out is counted when -- and only when -- its frame is consumed)
-     * ABI 4: i8 > 1 = that many banks, frame f gathers from bank f % i8: p3 = u64 [i8][K] (see AFF_SCORE flags&4) */
+     * ABI 4: i8 > 1 = that many banks, frame f gathers from bank f % i8: p3 = u64 [i8][K] (see AFF_SCORE flags&4)
+     * ABI 4: flags&1 = p4 holds unsigned 64-bit FIXED-POINT counters (2^-40; i7 counts them) instead of f32: integer atomics commute, so the usage
+     *      sums do not depend on the order in which the blocks arrive (the f32 form's last bits do); USAGE_TICK flags&1 adds them to the fp32 bank
+     *      counters with one rounding.  The reference's usage is a dense column sum (memory_utils.py:58-63, kv_memory_store.py:151-162). */
     CUTIE_OP_AFF_READOUT = 26,
     /* MEMSET32: fill n 32-bit words with value i[1]   p0=dst   i: 0 n 1 value */
     CUTIE_OP_MEMSET32 = 27,
@@ -268,7 +271,9 @@ enum {
     CUTIE_OP_AXPY = 29,
     /* USAGE_TICK: life[i] += 1 for i in [0,n)   kv_memory_store.py:161  p0=life  i: 0 n
      * optional (0 = none): p1=life2 f32 [i1]: += 1;  p2=use f32 [i2], p3=delta f32 [i2]: use += delta (the usage of a
-     * look-ahead read-out, accumulated into a side buffer by AFF_READOUT and applied when the read-out is consumed) */
+     * look-ahead read-out, accumulated into a side buffer by AFF_READOUT and applied when the read-out is consumed)
+     * ABI 4: flags&1 = p3 holds unsigned 64-bit fixed-point sums (2^-40, AFF_READOUT flags&1), converted with one rounding; flags&2 = and is
+     *      cleared behind the addition (the side counters of a read-out that is always consumed) */
     CUTIE_OP_USAGE_TICK = 30,
     /* RANK_SELECT: order[r] = index of the r-th largest of use/life (ties -> lower index), r < k
      * torch.topk(usage, k) of memory_manager.py:339 and kv_memory_store.py:222

@@ -619,7 +619,8 @@ class MockExecutor:
             cv = view(p[0] + 4 * r0 * cap, F32, (HW, cap))
             ci = view(p[1] + 4 * r0 * cap, I32, (HW, cap))
             cnt = view(p[2] + 4 * 32 * r0, I32, (HW, 32))[:, 0]
-            usage = p[4] + 4 * fr * ustride if p[4] else 0
+            ufx = bool(flags & 1)                                          # usage counters: unsigned 64-bit fixed point (2^-40)
+            usage = p[4] + (8 if ufx else 4) * fr * ustride if p[4] else 0
             out = view(p[5] + 2 * fr * K * HW * CV, BF16, (K, HW, CV))
             for j in range(HW):
                 n = min(int(cnt[j]), cap)
@@ -632,7 +633,10 @@ class MockExecutor:
                 sv, si = v[order], idx[order]
                 w = torch.exp(sv - sv[0])
                 w = w / w.sum()
-                if usage:
+                if usage and ufx:
+                    u = view(usage, U64, (int(si.max()) + 1,))
+                    u.index_add_(0, si, (w.float() * 1099511627776.0).to(torch.int64))       # (the kernel truncates the f32 product)
+                elif usage:
                     u = view(usage, F32, (int(si.max()) + 1,))
                     u.index_add_(0, si, w)
                 for o in range(K):
@@ -666,7 +670,11 @@ class MockExecutor:
             view(p[0], F32, (i[0],)).add_(1.0)
         if p[1] and i[1] > 0:
             view(p[1], F32, (i[1],)).add_(1.0)
-        if p[2] and p[3] and i[2] > 0:
+        if p[2] and p[3] and i[2] > 0 and (flags & 1):                   # delta: unsigned 64-bit fixed point (2^-40), one rounding
+            view(p[2], F32, (i[2],)).add_((view(p[3], U64, (i[2],)).double() * 2.0 ** -40).float())
+            if flags & 2:
+                view(p[3], U64, (i[2],)).zero_()
+        elif p[2] and p[3] and i[2] > 0:
             view(p[2], F32, (i[2],)).add_(view(p[3], F32, (i[2],)))
 
     def _op_31(self, flags, i, f, p):

@@ -437,7 +437,10 @@ def test_gap_eca():
 def test_conv_gap_accumulation(tile, geo):
     """ECA's average pool riding on the convs of a CAResBlock: conv1 clears the accumulator, conv2 adds the fixed-point channel sums of
     its stored output (tiles straddling 1, 2 or several objects), ECA_APPLY turns them into means.  Against the interpreter, and the
-    sums against the stored tensor exactly (up to the fp32 partial-sum rounding)."""
+    sums against the stored tensor EXACTLY: every stored value goes to fixed point (2^-24) before anything is summed, so the accumulator is the
+    same integer whatever the tile (how it groups rows into fragments and waves) and whatever the order of the atomics -- fp32 partial
+    sums (rounds 3-6) differed between two tiles of one K-order class about once per 35 M outputs, enough for a clip in lock step to leave
+    its own run after a few dozen frames (tools/lockstep_soak.py)."""
     B, H, W = geo
     C = 256
 
@@ -458,9 +461,8 @@ def test_conv_gap_accumulation(tile, geo):
         return ol, {'t2': t2, 'sums': sums, 'gap': gap, 'y': y}
     hip, ref = run_both(build, seed=31)
     check({k: hip[k] for k in ('t2', 'gap', 'y')}, {k: ref[k] for k in ('t2', 'gap', 'y')}, f'conv gap tile{tile}')
-    exact = hip['t2'].float().reshape(B, H * W, C).double().sum(1)
-    got = hip['sums'].double().cpu() / 16777216.0
-    assert float((got - exact.cpu()).abs().max()) < 1e-3 * max(1.0, float(exact.abs().max())), 'sums of the stored tensor'
+    exact = torch.round(hip['t2'].float().reshape(B, H * W, C).double() * 16777216.0).to(torch.int64).sum(1)      # (every bf16 of this test is a multiple of 2^-24)
+    assert torch.equal(hip['sums'].cpu(), exact.cpu()), 'sums of the stored tensor: %d of %d accumulators differ' % (int((hip['sums'].cpu() != exact.cpu()).sum()), exact.numel())
 
 
 @pytest.mark.parametrize('tile', [100, 103, 105, 110, 120, 123, 131, 134])
@@ -1188,6 +1190,86 @@ def test_affinity_batched_frames_match_one_frame_plans(case, nq):
     if case['HW'] <= 100:
         check({'yb': hip['yb']}, {'yb': ref['yb']}, 'aff batched')
         check({'useb': hip['useb']}, {'useb': ref['useb']}, 'aff batched usage', rtol=1e-4)
+
+
+def test_affinity_usage_in_fixed_point_does_not_depend_on_the_launch_shape():
+    """AFF_READOUT flags&1 (what the product runs): usage accumulated in unsigned 64-bit fixed point (2^-40).  Integer atomics commute: the F
+    one-frame read-outs and the stacked one give the SAME counters bit for bit (the f32 form agrees to ~1e-6 only: its last bits follow the
+    arrival order of the blocks -- which, through a near-tie of the consolidation's usage ranking, let a clip in lock step leave its own
+    run after a few hundred frames, tools/lockstep_soak.py); USAGE_TICK flags&1 / &2 adds them to fp32 counters with one rounding and clears them;
+    against the f32 form and the interpreter within float accuracy."""
+    HW, F, ranges, slots, K, top_k = 1620, 4, [(0, 2000), (2100, 1620), (4000, 8097)], 12200, 2, 30
+
+    def build(dev, g):
+        CV, cap = 256, 1024
+        HWp = -(-HW // 64) * 64
+        mkey = (torch.randn((slots, 64), generator=g) * 0.8).to(dev)
+        mkey = (mkey[torch.arange(slots) // 8] + torch.randn((slots, 64), generator=g).to(dev) * 1e-3)      # clustered: popular tokens, long lists
+        mshr = (torch.rand((slots,), generator=g) * 2 + 1).to(dev)
+        qkey = (torch.randn((F, HW, 64), generator=g) * 0.8).to(dev)
+        qsel = torch.rand((F, HW, 64), generator=g).to(dev)
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        nslots = slots + 16
+        Ahi, Alo, scale = z((nslots, 128), BF16), z((nslots, 128), BF16), z((nslots,), F32)
+        Bhi, Blo, cq = z((F, HWp, 128), BF16), z((F, HWp, 128), BF16), z((F, HWp), F32)
+        G = sum(-(-n // 16) for _, n in ranges if n > 0)
+        Gld = -(-G // 64) * 64
+        vals = [rnd(g, (nslots, CV), dev=dev) for _ in range(K)]
+        vptrs = torch.tensor([v.data_ptr() for v in vals], dtype=torch.int64).to(dev)
+        ovf = z((1,), torch.int32)
+        ol = O.OpList()
+        ol.keep += vals
+        ol.key_prep(mkey, mshr, Ahi, Alo, scale, n=slots, query=False)
+        for f in range(F):
+            ol.key_prep(qkey[f], qsel[f], Bhi[f], Blo[f], cq[f], n=HW, query=True)
+        y = z((F, K, HW, CV), BF16)
+        fx1, f32_1 = z((F, nslots), torch.int64) + 7, z((F, nslots), F32) + 3.0
+        keep = []
+        for f in range(F):                                      # one frame at a time: fixed-point and f32 counters
+            for usage, fx in ((fx1[f], True), (f32_1[f], False)):
+                gbuf = z((HWp * Gld + HWp,), F32)
+                gmax, tau = gbuf[:HWp * Gld], gbuf[HWp * Gld:]
+                cval, cidx, count = z((HW, cap), F32), z((HW, cap), torch.int32), z((HW * 32,), torch.int32)
+                keep += [gbuf, cval, cidx, count]
+                common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=cap, nq=2)
+                ol.aff_score(Ahi, Alo, scale, Bhi[f], Blo[f], cq[f], gmax, None, None, None, mode=0, **common)
+                ol.aff_select(gmax, tau, HW=HW, HWp=HWp, G=G, top_k=top_k, clear_count=count, zero=(usage, (2 if fx else 1) * nslots))
+                ol.aff_score(Ahi, Alo, scale, Bhi[f], Blo[f], cq[f], tau, cval, cidx, count, mode=1, gmax_precedes_tau=True, **common)
+                ol.aff_readout(cval, cidx, count, vptrs, usage, y[f], ovf, HW=HW, cap=cap, top_k=top_k, K=K, CV=CV, usage_fx=fx)
+        rows = F * HWp                                          # the F frames stacked, fixed point
+        fxb = z((F, nslots), torch.int64) + 7
+        gbuf = z((rows * Gld + rows,), F32)
+        gmax, tau = gbuf[:rows * Gld], gbuf[rows * Gld:]
+        cval, cidx, count = z((rows, cap), F32), z((rows, cap), torch.int32), z((rows * 32,), torch.int32)
+        common = dict(HW=HW, HWp=HWp, ranges=ranges, cap=cap, nq=4, frames=F)
+        ol.aff_score(Ahi, Alo, scale, Bhi, Blo, cq, gmax, None, None, None, mode=0, **common)
+        ol.aff_select(gmax, tau, HW=HW, HWp=HWp, G=G, top_k=top_k, clear_count=count, zero=(fxb, 2 * F * nslots), frames=F)
+        ol.aff_score(Ahi, Alo, scale, Bhi, Blo, cq, tau, cval, cidx, count, mode=1, gmax_precedes_tau=True, **dict(common, nq=2, dma=True))
+        yb = z((F, K, HW, CV), BF16)
+        ol.aff_readout(cval, cidx, count, vptrs, fxb, yb, ovf, HW=HW, cap=cap, top_k=top_k, K=K, CV=CV, frames=F, HWp=HWp, usage_stride=nslots, usage_fx=True)
+        # the bank's fp32 counters: += every frame's fixed-point sums, one rounding each; the side counters are zero afterwards
+        use = torch.arange(nslots, dtype=F32).to(dev) * 0.25
+        fxc = fxb.clone() if dev == 'cpu' else None
+        fx_copy = z((F, nslots), torch.int64)
+        ol.copy2d(fxb, fx_copy, rows=F, rowbytes=8 * nslots, src_stride=8 * nslots, dst_stride=8 * nslots)
+        for f in range(F):
+            ol.usage_tick(None, 0, None, 0, use=use, delta=fxb[f], n_use=nslots, delta_fx=True, clear_delta=True)
+        ol.keep += keep + [gbuf, cval, cidx, count]
+        return ol, {'fx1': fx1, 'fxb': fx_copy, 'fx_after': fxb, 'f32': f32_1, 'use': use, 'ovf': ovf, 'y': y, 'yb': yb}
+
+    hip, ref = run_both(build, seed=13)
+    assert int(hip['ovf']) == 0
+    assert torch.equal(hip['yb'].view(torch.int16), hip['y'].view(torch.int16))
+    assert torch.equal(hip['fxb'], hip['fx1'])                                        # bit for bit, whatever the launch shape
+    assert int(hip['fx_after'].abs().max()) == 0
+    as_f = hip['fxb'].double() * 2.0 ** -40
+    assert float(as_f.sum()) > 0.99 * F * HW and float(as_f.max()) > 8.0             # (popular tokens: many queries add to one counter)
+    assert torch.allclose(as_f.float(), hip['f32'], rtol=1e-5, atol=1e-5)
+    want = torch.arange(hip['use'].shape[0], dtype=torch.float64) * 0.25
+    for f in range(F):
+        want = (want.float() + as_f[f].float()).double()                              # one rounding per read-out
+    assert torch.equal(hip['use'], want.float())
+    check({'use': hip['use']}, {'use': ref['use']}, 'usage in fixed point', rtol=1e-4)
 
 
 @pytest.mark.parametrize('case', [

@@ -886,6 +886,59 @@ def test_lockstep_clips_match_sequential(gpu_net, size, K, C, T, cfg_kw, hinted,
         assert torch.equal(got, seq[c][0]), (c, [float((got[t] - seq[c][0][t]).abs().max()) for t in range(T)])
 
 
+def test_lockstep_and_lookahead_soak(gpu_net):
+    """160 frames of four 480p clips (3 objects, long-term memory with its default settings): every clip's own un-hinted InferenceCore run
+    against the same clip with look-ahead hints and against the clips in lock step (joint window + joint read-out pass), every frame bit for
+    bit.  The short cases above did not see what this one caught in round 6: the ECA average pool riding on a conv summed a wave's values in
+    fp32 -- two tiles of one K-order class (96 x 64 for one clip, 128 x 64 for four) then differed by one bf16 ulp of a fusion output about
+    once per 35 M elements (frames 28, 106 and 155 of these clips), and the transformer carried that into every pixel; and the float
+    atomics of the usage counters made a clip's long-term consolidation depend on the order in which the read-out's blocks arrive.  Both are
+    integer sums now (conv_pc.hip pc_gapfx, AFF_READOUT flags&1).  tools/lockstep_soak.py is the long form."""
+    from cutie_amd.inference.inference_core import InferenceCore
+    from cutie_amd.inference.lockstep import LockstepCores
+    from cutie_amd.utils.synth import SyntheticClip
+    C, T, NF = 4, 160, 48
+    cfg = default_config(use_long_term=True)
+    clips = [SyntheticClip(480, 854, 3, NF, seed=300 + c) for c in range(C)]
+    frames = [[cl.frame(t).cuda() for t in range(NF)] for cl in clips]
+    fr = lambda c, t: frames[c][t % NF] if (t // NF) % 2 == 0 else frames[c][NF - 1 - t % NF]
+    chk = lambda p: (p.double() * torch.arange(1, p.shape[0] + 1, device=p.device, dtype=torch.float64).view(-1, 1, 1)).sum()
+
+    def bank(mm):
+        b = next(iter(mm.buckets.values()))
+        return (b.n_long, b.n_perm, b.n_work, float(b.use[:b.slots].double().sum()))
+
+    def seq(hinted):
+        res = []
+        for c, cl in enumerate(clips):
+            proc = InferenceCore(gpu_net, cfg=cfg)
+            sums = [chk(proc.step(fr(c, 0), cl.first_mask().cuda(), objects=cl.objects))]
+            for t in range(1, T):
+                hint = dict(next_images=[fr(c, u) for u in range(t + 1, min(T, t + 13))]) if hinted and t + 1 < T else {}
+                sums.append(chk(proc.step(fr(c, t), **hint)))
+            res.append((torch.stack(sums).cpu(), bank(proc.memory)))
+        return res
+    with torch.inference_mode():
+        ref = seq(False)
+        hinted = seq(True)
+        ls = LockstepCores(gpu_net, cfg, C)
+        sums = [[] for _ in clips]
+        for c, p in enumerate(ls.step([fr(c, 0) for c in range(C)], [cl.first_mask().cuda() for cl in clips], [cl.objects for cl in clips])):
+            sums[c].append(chk(p))
+        for t in range(1, T):
+            hint = dict(next_images=[[fr(c, u) for u in range(t + 1, min(T, t + 13))] for c in range(C)]) if t + 1 < T else {}
+            for c, p in enumerate(ls.step([fr(c, t) for c in range(C)], **hint)):
+                sums[c].append(chk(p))
+        torch.cuda.synchronize()
+    assert ref[0][1][0] > 0, 'the clips must consolidate'
+    assert ls.batched_steps == T - 1 and ls.joint_passes > 0
+    for c in range(C):
+        got = torch.stack(sums[c]).cpu()
+        for name, (s_, b_) in (('hinted', hinted[c]), ('lock step', (got, bank(ls[c].memory)))):
+            d = (s_ != ref[c][0]).nonzero().flatten()
+            assert len(d) == 0 and b_ == ref[c][1], (name, c, int(d[0]) if len(d) else None, b_, ref[c][1])
+
+
 def test_run_batched_groups_in_flight_and_small_model():
     """parallel.run_batched on the MI355X: lock-step groups one after the other and IN FLIGHT next to each other (a stream + CUTIE.fork() per
     group) give every clip the object-id masks of its own InferenceCore run -- on cutie-small (ResNet-18 pixel encoder: other channel counts in
