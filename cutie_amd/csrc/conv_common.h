@@ -21,17 +21,14 @@ struct ConvParams {
     int res_grp_rows, res_grp_stride;
 };
 #define GAP_FIXED_SCALE 16777216.f
-// GAP side job of the LDS-DMA / producer-consumer convs: every stored VALUE goes to fixed point (2^-24: exact for a bf16 of magnitude 2^-17 .. 2^15)
-// BEFORE anything is summed -- integer sums depend neither on how a tile groups the rows into fragments and waves nor on the order in which the
-// blocks' atomics arrive.  (Rounds 3-6 summed a wave's values in fp32 and converted the partial sums: exact almost always -- but one bf16 ulp of a
-// fusion output differed between the 128 x 64 tile of clips in lock step and the 96 x 64 tile of one clip about once per 35 M elements, and the
-// transformer carried it into every pixel of the clip: tools/lockstep_soak.py, tools/lockstep_diverge.py.)  Two 32-bit conversions: the value in
-// units of 2^-16 and its remainder in units of 2^-24 (both products and the difference are exact).
-__device__ __forceinline__ long long conv_gapfx(float v) {
-    const float s = v * 65536.f;
-    const float h = rintf(s);
-    return (long long)__float2int_rn(h) * 256 + (long long)__float2int_rn((s - h) * 256.f);
-}
+// GAP side job of the LDS-DMA / producer-consumer convs: every stored VALUE goes to fixed point (2^-20: exact for a bf16 of magnitude 2^-13 .. 2^11,
+// saturating beyond) BEFORE anything is summed -- integer sums depend neither on how a tile groups the rows into fragments and waves nor on the
+// order in which the blocks' atomics arrive.  (Rounds 3-6 summed a wave's values in fp32 and converted the partial sums: exact almost always -- but
+// one bf16 ulp of a fusion output differed between the 128 x 64 tile of clips in lock step and the 96 x 64 tile of one clip about once per 35 M
+// elements, and the transformer carried it into every pixel of the clip: tools/lockstep_soak.py, tools/lockstep_diverge.py.)  One multiply and one
+// conversion per value (the two-part 2^-24 form cost the pooled convs 6.6 us of 33: profiles/r06_lockstep.md); the accumulator keeps its 2^-24 unit.
+#define GAP_ELEM_SHIFT 4                                  // accumulator unit 2^-24 = element unit 2^-20 >> 4
+__device__ __forceinline__ long long conv_gapfx(float v) { return (long long)__float2int_rn(v * 1048576.f); }
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // 16-B load that is a global_load for sure.  Pointers that went through a select, an array of pointers or pointer

@@ -419,12 +419,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_dma_kernel(ConvParams p) {
             long long sum = 0;                               // (fixed point per VALUE, integer sums: conv_common.h conv_gapfx)
             for (int r = r0; r < r1; ++r, ++m) {
                 if (m == next_b) {
-                    atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)obj * p.Cout + n0 + c), (unsigned long long)sum);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)obj * p.Cout + n0 + c), (unsigned long long)(sum << GAP_ELEM_SHIFT));
                     sum = 0; ++obj; next_b += p.OHW;
                 }
                 sum += conv_gapfx(ctile[r * LDC + c]);
             }
-            if (r1 > r0) atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)obj * p.Cout + n0 + c), (unsigned long long)sum);
+            if (r1 > r0) atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)obj * p.Cout + n0 + c), (unsigned long long)(sum << GAP_ELEM_SHIFT));
         }
     }
 #endif

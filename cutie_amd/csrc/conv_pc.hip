@@ -205,7 +205,7 @@ __device__ __forceinline__ long long pc_colsum16(const long long (&s)[NCH], int 
 }
 __device__ __forceinline__ long long pc_gapfx(float v) { return conv_gapfx(v); }      // (conv_common.h: fixed point per VALUE, integer sums)
 __device__ __forceinline__ void pc_gap_add(const ConvParams& p, int obj, int ch, long long v) {
-    if (ch < p.Cout) atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)obj * p.Cout + ch), (unsigned long long)v);
+    if (ch < p.Cout) atomicAdd(reinterpret_cast<unsigned long long*>(p.gap + (long)obj * p.Cout + ch), (unsigned long long)(v << GAP_ELEM_SHIFT));
 }
 
 // Fast epilogue of the common configurations, chosen ONCE per block by wave-uniform tests: whole tile inside Cout, aligned strides, no
@@ -217,13 +217,6 @@ __device__ __forceinline__ void pc_epilogue_fast(const ConvParams& p, const f32x
                                                  const int (&mrow)[TM], const bool (&mval)[TM], int chbase,
                                                  const unsigned (&rpre)[PRE ? TM : 1][PRE ? TNP : 1][NCH / 2], int gap_obj = 0, int l15 = 0) {
     unsigned rr[TM][TNP][NCH / 2];
-    long long gs[GAPJ ? TNP : 1][NCH];                   // GAPJ (the wave's rows lie in ONE object, gap_obj): stored values, in fixed point, summed over its fragments
-    if (GAPJ) {
-#pragma unroll
-        for (int a = 0; a < TNP; ++a)
-#pragma unroll
-            for (int r = 0; r < NCH; ++r) gs[a][r] = 0;
-    }
     if (RES && !PRE) {                                   // all residual loads first: one exposed latency, not one per slice
 #pragma unroll
         for (int b = 0; b < TM; ++b) {
@@ -240,10 +233,15 @@ __device__ __forceinline__ void pc_epilogue_fast(const ConvParams& p, const f32x
             }
         }
     }
+    // (column group outermost: with GAPJ its 64-bit accumulators -- NCH of them, not TNP x NCH: the BN = 128 tiles crossed 128 VGPRs with all of
+    // them alive, four waves per SIMD became three and the 64 x 128 tile 20 % slower -- are reduced and released before the next group)
 #pragma unroll
-    for (int b = 0; b < TM; ++b) {
+    for (int a = 0; a < TNP; ++a) {
+        long long gs[NCH];                               // GAPJ (the wave's rows lie in ONE object, gap_obj): stored values, in fixed point, summed over its fragments
 #pragma unroll
-        for (int a = 0; a < TNP; ++a) {
+        for (int r = 0; r < NCH; ++r) gs[r] = 0;
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
             float v[NCH];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -276,17 +274,14 @@ __device__ __forceinline__ void pc_epilogue_fast(const ConvParams& p, const f32x
                     else *reinterpret_cast<uint2*>(yp) = make_uint2(o[0], o[1]);
                     if (GAPJ) {                          // the STORED (bf16-rounded) values
 #pragma unroll
-                        for (int r = 0; r < NCH / 2; ++r) { gs[GAPJ ? a : 0][2 * r] += pc_gapfx(__uint_as_float(o[r] << 16)); gs[GAPJ ? a : 0][2 * r + 1] += pc_gapfx(__uint_as_float(o[r] & 0xffff0000u)); }
+                        for (int r = 0; r < NCH / 2; ++r) { gs[2 * r] += pc_gapfx(__uint_as_float(o[r] << 16)); gs[2 * r + 1] += pc_gapfx(__uint_as_float(o[r] & 0xffff0000u)); }
                     }
                 }
             }
         }
-    }
-    if (GAPJ) {
-#pragma unroll
-        for (int a = 0; a < TNP; ++a) {
+        if (GAPJ) {
             int c; bool writer;
-            const long long tot = pc_colsum16<NCH>(gs[GAPJ ? a : 0], l15, c, writer);
+            const long long tot = pc_colsum16<NCH>(gs, l15, c, writer);
             if (writer) pc_gap_add(p, gap_obj, chbase + a * (PAIR ? 32 : 16) + c, tot);
         }
     }
@@ -830,15 +825,13 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
         }
     }
 #endif
-    long long gsum[TNP][NCH];                            // generic path, GAP with the wave in one object: stored values, in fixed point, summed over its fragments
 #pragma unroll
-    for (int a = 0; a < TNP; ++a)
+    for (int a = 0; a < TNP; ++a) {                      // (column group outermost: see pc_epilogue_fast)
+        long long gsum[NCH];                             // generic path, GAP with the wave in one object: stored values, in fixed point, summed over its fragments
 #pragma unroll
-        for (int r = 0; r < NCH; ++r) gsum[a][r] = 0;
+        for (int r = 0; r < NCH; ++r) gsum[r] = 0;
 #pragma unroll
-    for (int b = 0; b < TM; ++b) {
-#pragma unroll
-        for (int a = 0; a < TNP; ++a) {
+        for (int b = 0; b < TM; ++b) {
             const int ch0 = n0 + cn0 + a * (PAIR ? 32 : 16) + l4 * NCH;
             const bool live = mval[b] && ch0 < p.Cout;
             float v[NCH], st[NCH];
@@ -855,7 +848,7 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
             if (p.gap) {
                 if (gap_one) {
 #pragma unroll
-                    for (int r = 0; r < NCH; ++r) gsum[a][r] += pc_gapfx(st[r]);
+                    for (int r = 0; r < NCH; ++r) gsum[r] += pc_gapfx(st[r]);
                 } else {
                     // a wave that straddles an object boundary (at most K - 1 row tiles of a launch): per fragment, the lanes of the first
                     // object and the lanes of the second are reduced separately (same-address atomics from 16 lanes of one instruction
@@ -889,17 +882,14 @@ __global__ __launch_bounds__((WM * WN + NPW) * 64) void conv_pc_kernel(ConvParam
             }
 #endif
         }
-    }
 #ifndef PC_ABL_FIXED_EPI
-    if (p.gap && gap_one) {
-#pragma unroll
-        for (int a = 0; a < TNP; ++a) {
+        if (p.gap && gap_one) {
             int c; bool writer;
-            const long long tot = pc_colsum16<NCH>(gsum[a], l15, c, writer);
+            const long long tot = pc_colsum16<NCH>(gsum, l15, c, writer);
             if (writer) pc_gap_add(p, gap_obj, n0 + cn0 + a * (PAIR ? 32 : 16) + l4 * NCH + c, tot);
         }
-    }
 #endif
+    }
     TLE(6)
     TL_DUMP(logical, nb, NC + NPW)
 #undef PC_RELU4

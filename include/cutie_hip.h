@@ -68,7 +68,8 @@ enum {
      *    19 split-K factor (<=1: none; must divide Kpad/BK of the chosen tile).  grid.z slices the K tiles, every slice
      *       parks its fp32 partial tile in p6 and a second launch sums the slices in slice order (deterministic) and
      *       runs the epilogue.  p6 = f32 scratch, capacity i20*1024 floats >= splitk*M*roundup(Cout,8).
-     *    side jobs (LDS-DMA tiles only): p7 = int64 [B,Cout] GAP accumulator the stored output is added to (x 2^24);
+     *    side jobs (LDS-DMA tiles only): p7 = int64 [B,Cout] GAP accumulator the stored output is added to (x 2^24: every stored VALUE is
+     *       converted to fixed point before anything is summed, so the accumulator is the same integer for every tile and arrival order);
      *       p8 = int64 buffer of i21 words cleared by this launch.
      *    p9 / i22, p10 / i23 (producer / consumer tiles 100.., else ignored; 0 = none): device ranges [p, p + bytes) that the
      *       producer waves read and discard once their last DMA piece is out -- the packed weights of the following conv(s)
