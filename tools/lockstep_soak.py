@@ -6,6 +6,8 @@ bench's cadence), every frame's probabilities compared bit for bit (a checksum p
   ls      LockstepCores with hints (joint encoder window, joint read-out pass)
   lsn     LockstepCores without hints
   lsl     LockstepCores with hints, every clip's own read-out lane (JOINT off)
+  il      the clips in flight next to each other (parallel.run_interleaved: a stream + CUTIE.fork() per clip, one issuing thread), hinted
+  grp     parallel.run_batched: lock-step groups of two clips in flight next to each other
 Stream-ordering mistakes between the look-ahead lanes show up rarely, if at all, in the short suite cases.
     python tools/lockstep_soak.py [--clips 4] [--frames 300] [--objects 3] [--modes seq2,seqh,ls,lsn,lsl]"""
 import argparse, os, sys, time
@@ -26,10 +28,15 @@ ap.add_argument('--height', type=int, default=480)
 ap.add_argument('--width', type=int, default=854)
 ap.add_argument('--modes', default='seq2,seqh,ls,lsn,lsl')
 ap.add_argument('--no-long-term', action='store_true')
+ap.add_argument('--model', default='base', choices=['base', 'small'])
 a = ap.parse_args()
-cfg = default_config(use_long_term=not a.no_long_term)
+cfg = default_config(use_long_term=not a.no_long_term, **({'model': 'small'} if a.model == 'small' else {}))
 net = CUTIE(cfg).cuda().eval()
-net.load_weights(make_state_dict(seed=0))
+if a.model == 'small':
+    from cutie_amd.utils.synth_weights import MODEL_CFG_SMALL
+    net.load_weights(make_state_dict(seed=0, m=MODEL_CFG_SMALL))
+else:
+    net.load_weights(make_state_dict(seed=0))
 NF = 48
 clips = [SyntheticClip(a.height, a.width, a.objects, NF, seed=300 + c) for c in range(a.clips)]
 frames = [[cl.frame(t).cuda() for t in range(NF)] for cl in clips]
@@ -69,6 +76,33 @@ def run_ls(hinted, joint):
     return [(torch.stack(sums[c]).cpu(), bank(ls[c].memory)) for c in range(C)]
 
 
+def run_il():
+    from cutie_amd.parallel import run_interleaved
+
+    def gen(view, c):
+        proc = InferenceCore(view, cfg=cfg)
+        sums = [chk(proc.step(fr(c, 0), clips[c].first_mask().cuda(), objects=clips[c].objects))]
+        yield
+        for t in range(1, T):
+            hint = dict(next_images=[fr(c, u) for u in range(t + 1, min(T, t + 13))]) if t + 1 < T else {}
+            sums.append(chk(proc.step(fr(c, t), **hint)))
+            yield
+        return (torch.stack(sums).cpu(), bank(proc.memory))
+    got = run_interleaved(net, list(range(C)), gen, streams=C)
+    return [got[c] for c in range(C)]
+
+
+def run_grp():
+    from cutie_amd.parallel import run_batched
+    sums = [[None] * T for _ in clips]
+
+    def on_frame(c, t, prob, core):
+        sums[c][t] = chk(prob)
+    run_batched(net, cfg, [dict(frames=[fr(c, t) for t in range(T)], mask=clips[c].first_mask().cuda(), objects=clips[c].objects) for c in range(C)],
+                lockstep=2, in_flight=max(1, C // 2), on_frame=on_frame)
+    return [(torch.stack(sums[c]).cpu(), None) for c in range(C)]
+
+
 bad = 0
 with torch.inference_mode():
     t0 = time.time()
@@ -78,12 +112,12 @@ with torch.inference_mode():
     for mode in a.modes.split(','):
         t0 = time.time()
         got = {'seq2': lambda: run_seq(False), 'seqh': lambda: run_seq(True), 'ls': lambda: run_ls(True, True), 'lsn': lambda: run_ls(False, True),
-               'lsl': lambda: run_ls(True, False)}[mode]()
+               'lsl': lambda: run_ls(True, False), 'il': run_il, 'grp': run_grp}[mode]()
         torch.cuda.synchronize()
         n = 0
         for c in range(C):
             same = torch.equal(got[c][0], ref[c][0])
-            if not same or got[c][1][:3] != ref[c][1][:3]:
+            if not same or (got[c][1] is not None and got[c][1][:3] != ref[c][1][:3]):
                 n += 1
                 d = (got[c][0] != ref[c][0]).nonzero().flatten()
                 first = int(d[0]) if len(d) else None
